@@ -1,0 +1,205 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+package (orb_slam3_fast_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liborb_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "orb_oracle_c.cpp", "orb_oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.oro_create.restype = C.c_void_p
+        _lib.oro_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        _lib.oro_destroy.argtypes = [C.c_void_p]
+        _lib.oro_level_ptr.restype = C.c_void_p
+        _lib.oro_blurred_ptr.restype = C.c_void_p
+        _lib.oro_pattern.restype = C.c_void_p
+        _lib.oro_fast_atan2.restype = C.c_float
+        _lib.oro_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.oro_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        _lib.oro_cv_round_f.argtypes = [C.c_float]
+        _lib.oro_ic_angle.restype = C.c_float
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+class OracleExtractor:
+    """Mirror of ORB_SLAM3::ORBextractor on the CPU oracle."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+        self.h = C.c_void_p(lib().oro_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oro_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        L = self.nlevels
+        f = [np.zeros(L, np.float32) for _ in range(4)]
+        nf = np.zeros(L, np.int32)
+        um = np.zeros(16, np.int32)
+        lib().oro_tables(self.h, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(nf), _p(um))
+        return dict(scale=f[0], inv_scale=f[1], sigma2=f[2], inv_sigma2=f[3], nfeat=nf, umax=um)
+
+    def extract(self, img, lap=(0, 0)):
+        img = _u8(img)
+        h, w = img.shape
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        mono = lib().oro_extract(self.h, _p(img), w, h, C.c_long(img.strides[0]), lap[0], lap[1], _p(kps),
+                                 _p(desc), cap, C.byref(n))
+        if mono < 0:
+            return mono, kps[:0], desc[:0]
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def compute_pyramid(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        lib().oro_compute_pyramid(self.h, _p(img), w, h, C.c_long(img.strides[0]))
+
+    def level(self, l, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        lib().oro_level_size(self.h, l, C.byref(w), C.byref(h))
+        ptr = lib().oro_blurred_ptr(self.h, l) if blurred else lib().oro_level_ptr(self.h, l)
+        buf = (C.c_uint8 * (w.value * h.value)).from_address(ptr)
+        return np.frombuffer(buf, np.uint8).reshape(h.value, w.value).copy()
+
+    def detect_candidates(self, l):
+        cap = 1 << 18
+        out = np.zeros(cap, KP_DTYPE)
+        n = lib().oro_detect_candidates(self.h, l, _p(out), cap)
+        assert n >= 0
+        return out[:n].copy()
+
+    def distribute(self, cand, minX, maxX, minY, maxY, N):
+        cand = np.ascontiguousarray(cand)
+        out = np.zeros(N + 64, KP_DTYPE)
+        n = lib().oro_distribute(self.h, _p(cand), len(cand), minX, maxX, minY, maxY, N, _p(out), len(out))
+        assert n >= 0
+        return out[:n].copy()
+
+
+def resize(src, dw, dh):
+    src = _u8(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oro_resize(_p(src), src.shape[1], src.shape[0], _p(dst), dw, dh)
+    return dst
+
+
+def fast(img, threshold, nms=True):
+    img = _u8(img)
+    cap = img.size
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().oro_fast(_p(img), img.strides[0], img.shape[1], img.shape[0], threshold, int(nms), _p(out), cap)
+    return out[:n].copy()
+
+
+def blur(img, variant=451):
+    img = _u8(img)
+    dst = np.zeros_like(img)
+    lib().oro_blur(_p(img), img.shape[1], img.shape[0], _p(dst), variant)
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(lib().oro_fast_atan2(float(y), float(x)))
+
+
+def sincosf(a):
+    s, c = C.c_float(), C.c_float()
+    lib().oro_sincosf(C.c_float(a), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def ic_angle(img, cx, cy):
+    img = _u8(img)
+    return float(lib().oro_ic_angle(_p(img), img.shape[1], img.shape[0], cx, cy))
+
+
+def descriptor(blurred, px, py, angle):
+    blurred = _u8(blurred)
+    out = np.zeros(32, np.uint8)
+    lib().oro_descriptor(_p(blurred), blurred.shape[1], blurred.shape[0], C.c_float(px), C.c_float(py),
+                         C.c_float(angle), _p(out))
+    return out
+
+
+def hamming(a, b):
+    return int(lib().oro_hamming(_p(_u8(a)), _p(_u8(b))))
+
+
+def stereo_match(exL, exR, kL, dL, kR, dR, bf, b):
+    kL, kR = np.ascontiguousarray(kL), np.ascontiguousarray(kR)
+    dL, dR = _u8(dL), _u8(dR)
+    u = np.zeros(len(kL), np.float32)
+    d = np.zeros(len(kL), np.float32)
+    lib().oro_stereo_match(exL.h, exR.h, _p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), C.c_float(bf),
+                           C.c_float(b), _p(u), _p(d))
+    return u, d
+
+
+def bf_knn2(dQ, dT):
+    dQ, dT = _u8(dQ), _u8(dT)
+    nQ, nT = len(dQ), len(dT)
+    idx = np.zeros((nQ, 2), np.int32)
+    dist = np.zeros((nQ, 2), np.int32)
+    ok = np.zeros(nQ, np.uint8)
+    lib().oro_bf_knn2(_p(dQ), nQ, _p(dT), nT, _p(idx), _p(dist), _p(ok))
+    return idx, dist, ok
+
+
+def search_init(k1, d1, k2, d2, bounds, prev, window=100, nnratio=0.9, check_ori=True):
+    k1, k2 = np.ascontiguousarray(k1), np.ascontiguousarray(k2)
+    d1, d2 = _u8(d1), _u8(d2)
+    prev = np.ascontiguousarray(prev, np.float32).copy()
+    m = np.zeros(len(k1), np.int32)
+    n = lib().oro_search_init(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), C.c_float(bounds[0]),
+                              C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(prev),
+                              _p(m), window, C.c_float(nnratio), int(check_ori))
+    return n, m, prev
+
+
+def features_in_area(k, bounds, x, y, r, min_level, max_level):
+    k = np.ascontiguousarray(k)
+    out = np.zeros(len(k) + 1, np.int32)
+    n = lib().oro_features_in_area(_p(k), len(k), C.c_float(bounds[0]), C.c_float(bounds[1]),
+                                   C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(x), C.c_float(y),
+                                   C.c_float(r), min_level, max_level, _p(out), len(out))
+    return out[:n].copy()

@@ -1,0 +1,812 @@
+// orb_oracle.cpp — CPU oracle (see orb_oracle.h header: TEST INFRASTRUCTURE, PARITY UNPINNED).
+// Every function cites the reference file:line (relative to /root/reference) or the SURVEY.md
+// Appendix-B item (OpenCV kernel restated from its published algorithm) it follows.
+// Build: g++ -O2 -std=c++17 -ffp-contract=off (x86-64 baseline: no FMA, like the reference's -O3 build).
+#include "orb_oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+
+namespace orbo {
+
+// ======================================================================================= B1 rounding
+// cvRound = round-half-to-even (SSE cvtss2si under the default MXCSR mode).
+int cv_round(float v) { return (int)std::lrint(v); }
+int cv_round(double v) { return (int)std::lrint(v); }
+static inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+static inline int cv_floor(double v) { int i = (int)v; return i - (i > v); }
+static inline int cv_ceil(float v) { int i = (int)v; return i + (i < v); }
+static inline short sat_short_from_float(float v) {
+  int i = cv_round(v);
+  return (short)(i < SHRT_MIN ? SHRT_MIN : i > SHRT_MAX ? SHRT_MAX : i);
+}
+
+// ======================================================================================= B5 fastAtan2
+// cv::fastAtan2 scalar path (degrees, 7th-order odd polynomial, separate mul/add roundings).
+float fast_atan2(float y, float x) {
+  const float s = (float)(180.0 / 3.1415926535897932384626433832795);
+  static const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s,
+                     p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+  const float eps = (float)2.2204460492503131e-16;  // (float)DBL_EPSILON
+  float ax = std::fabs(x), ay = std::fabs(y), a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// ======================================================================================= B8 sinf/cosf
+// The reference calls libm cosf/sinf (src/ORBextractor.cc:107). glibc's result is within 0.56 ulp and
+// differs between its FMA / non-FMA ifunc variants, i.e. it is machine dependent in the last bit.  The
+// oracle therefore DEFINES sin/cos as: evaluate in IEEE double with the fixed operation sequence below
+// (fdlibm kernel polynomials after a 2-term Cody-Waite reduction by pi/2), then round once to float.
+// That is the correctly-rounded float value except with probability ~1e-8 per call;
+// tests/test_oracle_kernels.py measures the (1-ulp) disagreement with this host's libm.
+void orb_sincosf(float ang, float* s_out, float* c_out) {
+  const double x = (double)ang;
+  const double two_over_pi = 6.36619772367581382433e-01;
+  const double pio2_hi = 1.57079632673412561417e+00;  // 33 bits of pi/2
+  const double pio2_lo = 6.07710050650619224932e-11;  // pi/2 - pio2_hi
+  const double fk = std::floor(x * two_over_pi + 0.5);
+  const int k = (int)fk;
+  const double r = (x - fk * pio2_hi) - fk * pio2_lo;
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double sn = r + (z * r) * (S1 + z * ps);
+  const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double cs = 1.0 - (0.5 * z - z * pc);
+  double sv, cv;
+  switch (k & 3) {
+    case 0: sv = sn; cv = cs; break;
+    case 1: sv = cs; cv = -sn; break;
+    case 2: sv = -sn; cv = -cs; break;
+    default: sv = -cs; cv = sn; break;
+  }
+  *s_out = (float)sv;
+  *c_out = (float)cv;
+}
+
+// ======================================================================================= B2 resize
+// cv::resize(INTER_LINEAR) CV_8UC1, generic fixed-point path (11-bit coefficients).
+void resize_linear_u8(const Image& src, Image& dst, int dw, int dh) {
+  dst = Image(dw, dh);
+  const int sw = src.w, sh = src.h;
+  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+  const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> alpha(2 * dw), beta(2 * dh);
+  std::vector<uint8_t> xplain(dw, 0);  // dx >= xmax: D = S[sx] * 2048
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; xplain[dx] = 1; }
+    xofs[dx] = sx;
+    alpha[2 * dx] = sat_short_from_float((1.f - fx) * 2048.f);
+    alpha[2 * dx + 1] = sat_short_from_float(fx * 2048.f);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = sat_short_from_float((1.f - fy) * 2048.f);
+    beta[2 * dy + 1] = sat_short_from_float(fy * 2048.f);
+  }
+  std::vector<int> r0(dw), r1(dw);
+  auto hrow = [&](int sy, std::vector<int>& out) {
+    sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    const uint8_t* S = src.row(sy);
+    for (int dx = 0; dx < dw; dx++) {
+      int sx = xofs[dx];
+      out[dx] = xplain[dx] ? S[sx] * 2048 : S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+    }
+  };
+  for (int dy = 0; dy < dh; dy++) {
+    hrow(yofs[dy], r0);
+    hrow(yofs[dy] + 1, r1);
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t* D = dst.row(dy);
+    for (int dx = 0; dx < dw; dx++)
+      D[dx] = (uint8_t)((((b0 * (r0[dx] >> 4)) >> 16) + ((b1 * (r1[dx] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+// ======================================================================================= B3 FAST
+static void make_ring16(int stride, int pixel[25]) {
+  static const int off[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                 {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+  for (int k = 0; k < 16; k++) pixel[k] = off[k][0] + off[k][1] * stride;
+  for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+}
+
+// cornerScore<16>: largest threshold for which the pixel is still a corner (= max(t,M) - 1).
+int fast_corner_score16(const uint8_t* ptr, const int pixel[25], int threshold) {
+  int d[25];
+  const int v = ptr[0];
+  for (int k = 0; k < 25; k++) d[k] = v - ptr[pixel[k]];
+  int a0 = threshold;
+  for (int k = 0; k < 16; k += 2) {
+    int a = std::min(d[k + 1], d[k + 2]);
+    a = std::min(a, d[k + 3]);
+    if (a <= a0) continue;
+    for (int q = 4; q <= 8; q++) a = std::min(a, d[k + q]);
+    a0 = std::max(a0, std::min(a, d[k]));
+    a0 = std::max(a0, std::min(a, d[k + 9]));
+  }
+  int b0 = -a0;
+  for (int k = 0; k < 16; k += 2) {
+    int b = std::max(d[k + 1], d[k + 2]);
+    b = std::max(b, d[k + 3]);
+    for (int q = 4; q <= 5; q++) b = std::max(b, d[k + q]);
+    if (b >= b0) continue;
+    for (int q = 6; q <= 8; q++) b = std::max(b, d[k + q]);
+    b0 = std::min(b0, std::max(b, d[k]));
+    b0 = std::min(b0, std::max(b, d[k + 9]));
+  }
+  return -b0 - 1;
+}
+
+// cv::FAST(img, kps, threshold, nms) TYPE_9_16: three rolling u8 score rows (zero-initialised),
+// a pixel is kept iff its score is strictly greater than its 8 neighbours; output in (y, x) order.
+void fast9_16(const uint8_t* img, int stride, int cols, int rows, int threshold, bool nms,
+              std::vector<FastPt>& out) {
+  out.clear();
+  if (cols < 7 || rows < 7) return;
+  int pixel[25];
+  make_ring16(stride, pixel);
+  threshold = std::min(std::max(threshold, 0), 255);
+  std::vector<uint8_t> buf((size_t)cols * 3, 0);
+  std::vector<int> cpbuf((size_t)(cols + 1) * 3, 0);
+  uint8_t* rowbuf[3] = {buf.data(), buf.data() + cols, buf.data() + 2 * cols};
+  int* cprow[3] = {cpbuf.data(), cpbuf.data() + cols + 1, cpbuf.data() + 2 * (cols + 1)};
+  for (int i = 3; i < rows - 2; i++) {
+    const uint8_t* p = img + (size_t)i * stride + 3;
+    uint8_t* curr = rowbuf[(i - 3) % 3];
+    int* cornerpos = cprow[(i - 3) % 3] + 1;
+    std::memset(curr, 0, cols);
+    int ncorners = 0;
+    if (i < rows - 3) {
+      for (int j = 3; j < cols - 3; j++, p++) {
+        const int v = p[0];
+        // 9 contiguous ring pixels all darker than v - t, or all brighter than v + t
+        bool corner = false;
+        for (int pol = 0; pol < 2 && !corner; pol++) {
+          int count = 0;
+          for (int k = 0; k < 25; k++) {
+            const int x = p[pixel[k]];
+            const bool hit = pol == 0 ? (x < v - threshold) : (x > v + threshold);
+            if (hit) {
+              if (++count > 8) { corner = true; break; }
+            } else {
+              count = 0;
+            }
+          }
+        }
+        if (corner) {
+          cornerpos[ncorners++] = j;
+          if (nms) curr[j] = (uint8_t)fast_corner_score16(p, pixel, threshold);
+        }
+      }
+    }
+    cornerpos[-1] = ncorners;
+    if (i == 3) continue;
+    const uint8_t* prev = rowbuf[(i - 4 + 3) % 3];
+    const uint8_t* pprev = rowbuf[(i - 5 + 3) % 3];
+    const int* cp = cprow[(i - 4 + 3) % 3] + 1;
+    const int n = cp[-1];
+    for (int k = 0; k < n; k++) {
+      const int j = cp[k];
+      const int score = prev[j];
+      if (!nms || (score > prev[j + 1] && score > prev[j - 1] && score > pprev[j - 1] &&
+                   score > pprev[j] && score > pprev[j + 1] && score > curr[j - 1] &&
+                   score > curr[j] && score > curr[j + 1]))
+        out.push_back({j, i - 1, score});
+    }
+  }
+}
+
+// ======================================================================================= B4 blur
+const int kBlurTaps451[7] = {18, 34, 48, 56, 48, 34, 18};
+const int kBlurTaps440[7] = {18, 34, 49, 55, 49, 34, 18};
+static inline int reflect101(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+  return p;
+}
+// GaussianBlur 7x7 sigma=2 CV_8U fixed point: u16 horizontal, u32 vertical, one final rounding.
+void gaussian_blur7(const Image& src, Image& dst, const int taps[7]) {
+  const int w = src.w, h = src.h;
+  dst = Image(w, h);
+  std::vector<uint32_t> hp((size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = src.row(y);
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = 0;
+      for (int k = 0; k < 7; k++) acc += (uint32_t)taps[k] * S[reflect101(x + k - 3, w)];
+      hp[(size_t)y * w + x] = acc > 65535u ? 65535u : acc;  // ufixedpoint16 saturates (257-sum taps)
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    uint8_t* D = dst.row(y);
+    for (int x = 0; x < w; x++) {
+      uint64_t acc = 0;
+      for (int k = 0; k < 7; k++) acc += (uint64_t)taps[k] * hp[(size_t)reflect101(y + k - 3, h) * w + x];
+      if (acc > 0xFFFFFFFFull) acc = 0xFFFFFFFFull;  // ufixedpoint32 saturates
+      uint32_t v = (uint32_t)((acc + 32768u) >> 16);
+      D[x] = (uint8_t)(v > 255 ? 255 : v);
+    }
+  }
+}
+
+// ======================================================================================= tables
+const int8_t kPattern[1024] = {
+#include "../orb_slam3_fast_amd/csrc/orb_pattern31.inc"
+};
+
+static const int kPatchSize = 31, kHalfPatch = 15, kEdge = 19;
+
+// ORBextractor::ORBextractor, src/ORBextractor.cc:408-469.
+Extractor::Extractor(int nfeatures_, float scaleFactor_, int nlevels_, int iniTh_, int minTh_)
+    : nfeatures(nfeatures_), nlevels(nlevels_), iniTh(iniTh_), minTh(minTh_), scaleFactor(scaleFactor_) {
+  t.scale.resize(nlevels);
+  t.sigma2.resize(nlevels);
+  t.scale[0] = 1.0f;
+  t.sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    t.scale[i] = (float)(t.scale[i - 1] * scaleFactor);  // float * double -> float (:423)
+    t.sigma2[i] = t.scale[i] * t.scale[i];
+  }
+  t.inv_scale.resize(nlevels);
+  t.inv_sigma2.resize(nlevels);
+  for (int i = 0; i < nlevels; i++) {
+    t.inv_scale[i] = 1.0f / t.scale[i];
+    t.inv_sigma2[i] = 1.0f / t.sigma2[i];
+  }
+  pyramid.resize(nlevels);
+  blurred.resize(nlevels);
+  t.nfeat_level.resize(nlevels);
+  const float factor = (float)(1.0f / scaleFactor);  // :437
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    t.nfeat_level[l] = cv_round(nDesired);
+    sum += t.nfeat_level[l];
+    nDesired *= factor;
+  }
+  t.nfeat_level[nlevels - 1] = std::max(nfeatures - sum, 0);
+  // umax, :456-468
+  t.umax.assign(kHalfPatch + 1, 0);
+  const float s2 = std::sqrt(2.f);
+  const int vmax = cv_floor(kHalfPatch * s2 / 2 + 1);
+  const int vmin = cv_ceil(kHalfPatch * s2 / 2);
+  const double hp2 = kHalfPatch * kHalfPatch;
+  for (int v = 0; v <= vmax; ++v) t.umax[v] = cv_round(std::sqrt(hp2 - v * v));
+  for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (t.umax[v0] == t.umax[v0 + 1]) ++v0;
+    t.umax[v] = v0;
+    ++v0;
+  }
+}
+
+// ORBextractor::ComputePyramid, src/ORBextractor.cc:1108-1145 (borders are written there but never read).
+void Extractor::compute_pyramid(const uint8_t* img, int w, int h, ptrdiff_t stride) {
+  for (int l = 0; l < nlevels; l++) {
+    const float s = t.inv_scale[l];
+    const int lw = cv_round((float)w * s), lh = cv_round((float)h * s);
+    if (l == 0) {
+      pyramid[0] = Image(lw, lh);
+      for (int y = 0; y < h; y++) std::memcpy(pyramid[0].row(y), img + y * stride, w);
+    } else {
+      resize_linear_u8(pyramid[l - 1], pyramid[l], lw, lh);
+    }
+  }
+}
+
+// Cell loop of ComputeKeyPointsOctTree, src/ORBextractor.cc:892-971 (serial variant).
+void Extractor::detect_level_candidates(int level, std::vector<KeyPoint>& cand) const {
+  cand.clear();
+  const Image& im = pyramid[level];
+  const int minBX = kEdge - 3, minBY = minBX;
+  const int maxBX = im.w - kEdge + 3, maxBY = im.h - kEdge + 3;
+  const float W = 35;
+  const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+  const int nCols = (int)(width / W), nRows = (int)(height / W);
+  const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+  std::vector<FastPt> cell;
+  for (int i = 0; i < nRows; i++) {
+    const float iniY = (float)(minBY + i * hCell);
+    float maxY = iniY + hCell + 6;
+    if (iniY >= maxBY - 3) continue;
+    if (maxY > maxBY) maxY = (float)maxBY;
+    for (int j = 0; j < nCols; j++) {
+      const float iniX = (float)(minBX + j * wCell);
+      float maxX = iniX + wCell + 6;
+      if (iniX >= maxBX - 6) continue;
+      if (maxX > maxBX) maxX = (float)maxBX;
+      const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, ch = (int)maxY - y0;
+      fast9_16(im.row(y0) + x0, im.w, cw, ch, iniTh, true, cell);
+      if (cell.empty()) fast9_16(im.row(y0) + x0, im.w, cw, ch, minTh, true, cell);
+      for (const FastPt& p : cell) {
+        KeyPoint kp;
+        kp.x = (float)p.x + j * wCell;
+        kp.y = (float)p.y + i * hCell;
+        kp.size = 7.f;
+        kp.angle = -1.f;
+        kp.response = (float)p.score;
+        kp.octave = 0;
+        kp.class_id = -1;
+        cand.push_back(kp);
+      }
+    }
+  }
+}
+
+// ORBextractor::DistributeOctTree + ExtractorNode::DivideNode + compareNodes,
+// src/ORBextractor.cc:490-757.  Nodes hold indices into `cand` (order preserved = vKeys order).
+namespace {
+struct Node {
+  int ulx, uly, urx, ury, blx, bly, brx, bry;
+  std::vector<int> keys;
+  bool no_more = false;
+  std::list<Node>::iterator self;
+};
+struct SizeNode {
+  int first;
+  Node* second;
+};
+bool compare_nodes(const SizeNode& a, const SizeNode& b) {  // :542-555
+  if (a.first < b.first) return true;
+  if (a.first > b.first) return false;
+  return a.second->ulx < b.second->ulx;
+}
+void divide(const Node& p, const std::vector<KeyPoint>& cand, Node n[4]) {  // :490-540
+  const int halfX = (int)std::ceil((float)(p.urx - p.ulx) / 2);
+  const int halfY = (int)std::ceil((float)(p.bry - p.uly) / 2);
+  n[0].ulx = p.ulx; n[0].uly = p.uly; n[0].urx = p.ulx + halfX; n[0].ury = p.uly;
+  n[0].blx = p.ulx; n[0].bly = p.uly + halfY; n[0].brx = p.ulx + halfX; n[0].bry = p.uly + halfY;
+  n[1].ulx = n[0].urx; n[1].uly = n[0].ury; n[1].urx = p.urx; n[1].ury = p.ury;
+  n[1].blx = n[0].brx; n[1].bly = n[0].bry; n[1].brx = p.urx; n[1].bry = p.uly + halfY;
+  n[2].ulx = n[0].blx; n[2].uly = n[0].bly; n[2].urx = n[0].brx; n[2].ury = n[0].bry;
+  n[2].blx = p.blx; n[2].bly = p.bly; n[2].brx = n[0].brx; n[2].bry = p.bly;
+  n[3].ulx = n[2].urx; n[3].uly = n[2].ury; n[3].urx = n[1].brx; n[3].ury = n[1].bry;
+  n[3].blx = n[2].brx; n[3].bly = n[2].bry; n[3].brx = p.brx; n[3].bry = p.bry;
+  for (int k : p.keys) {
+    const KeyPoint& kp = cand[k];
+    if (kp.x < n[0].urx) {
+      if (kp.y < n[0].bry) n[0].keys.push_back(k); else n[2].keys.push_back(k);
+    } else if (kp.y < n[0].bry) {
+      n[1].keys.push_back(k);
+    } else {
+      n[3].keys.push_back(k);
+    }
+  }
+  for (int q = 0; q < 4; q++) n[q].no_more = n[q].keys.size() == 1;
+}
+}  // namespace
+
+std::vector<KeyPoint> Extractor::distribute_octtree(const std::vector<KeyPoint>& cand, int minX,
+                                                    int maxX, int minY, int maxY, int N) const {
+  const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));  // :566
+  const float hX = (float)(maxX - minX) / nIni;
+  std::list<Node> nodes;
+  std::vector<Node*> ini(nIni);
+  for (int i = 0; i < nIni; i++) {
+    Node ni;
+    ni.ulx = (int)(hX * (float)i); ni.uly = 0;
+    ni.urx = (int)(hX * (float)(i + 1)); ni.ury = 0;
+    ni.blx = ni.ulx; ni.bly = maxY - minY;
+    ni.brx = ni.urx; ni.bry = maxY - minY;
+    nodes.push_back(ni);
+    ini[i] = &nodes.back();
+  }
+  for (int k = 0; k < (int)cand.size(); k++) ini[(size_t)(cand[k].x / hX)]->keys.push_back(k);
+  for (auto it = nodes.begin(); it != nodes.end();) {
+    if (it->keys.size() == 1) { it->no_more = true; ++it; }
+    else if (it->keys.empty()) it = nodes.erase(it);
+    else ++it;
+  }
+  bool finish = false;
+  std::vector<SizeNode> expandable;
+  auto push_children = [&](Node n[4], int* nToExpand) {
+    for (int q = 0; q < 4; q++) {
+      if (n[q].keys.empty()) continue;
+      nodes.push_front(n[q]);
+      if (n[q].keys.size() > 1) {
+        if (nToExpand) ++*nToExpand;
+        expandable.push_back({(int)n[q].keys.size(), &nodes.front()});
+        nodes.front().self = nodes.begin();
+      }
+    }
+  };
+  while (!finish) {
+    int prevSize = (int)nodes.size();
+    int nToExpand = 0;
+    expandable.clear();
+    for (auto it = nodes.begin(); it != nodes.end();) {
+      if (it->no_more) { ++it; continue; }
+      Node n[4];
+      divide(*it, cand, n);
+      push_children(n, &nToExpand);
+      it = nodes.erase(it);
+    }
+    if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) {
+      finish = true;
+    } else if ((int)nodes.size() + nToExpand * 3 > N) {
+      while (!finish) {
+        prevSize = (int)nodes.size();
+        std::vector<SizeNode> prev = expandable;
+        expandable.clear();
+        std::sort(prev.begin(), prev.end(), compare_nodes);  // libstdc++ introsort: tie order matters
+        for (int j = (int)prev.size() - 1; j >= 0; j--) {
+          Node n[4];
+          divide(*prev[j].second, cand, n);
+          push_children(n, nullptr);
+          nodes.erase(prev[j].second->self);
+          if ((int)nodes.size() >= N) break;
+        }
+        if ((int)nodes.size() >= N || (int)nodes.size() == prevSize) finish = true;
+      }
+    }
+  }
+  std::vector<KeyPoint> result;
+  result.reserve(nodes.size());
+  for (const Node& nd : nodes) {  // best response per node, first wins (:741-754)
+    int best = nd.keys[0];
+    float maxResp = cand[best].response;
+    for (size_t k = 1; k < nd.keys.size(); k++)
+      if (cand[nd.keys[k]].response > maxResp) { best = nd.keys[k]; maxResp = cand[best].response; }
+    result.push_back(cand[best]);
+  }
+  return result;
+}
+
+// IC_Angle, src/ORBextractor.cc:75-99.
+float ic_angle(const Image& im, int cx, int cy, const std::vector<int>& umax) {
+  int m01 = 0, m10 = 0;
+  const uint8_t* c = im.row(cy) + cx;
+  const int step = im.w;
+  for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * c[u];
+  for (int v = 1; v <= kHalfPatch; ++v) {
+    int vsum = 0;
+    const int d = umax[v];
+    for (int u = -d; u <= d; ++u) {
+      const int plus = c[u + v * step], minus = c[u - v * step];
+      vsum += plus - minus;
+      m10 += u * (plus + minus);
+    }
+    m01 += v * vsum;
+  }
+  return fast_atan2((float)m01, (float)m10);
+}
+
+// ComputeKeyPointsOctTree, src/ORBextractor.cc:886-999.
+void Extractor::compute_keypoints(std::vector<std::vector<KeyPoint>>& all) const {
+  all.assign(nlevels, {});
+  std::vector<KeyPoint> cand;
+  for (int l = 0; l < nlevels; l++) {
+    const int minBX = kEdge - 3, minBY = minBX;
+    const int maxBX = pyramid[l].w - kEdge + 3, maxBY = pyramid[l].h - kEdge + 3;
+    detect_level_candidates(l, cand);
+    all[l] = distribute_octtree(cand, minBX, maxBX, minBY, maxBY, t.nfeat_level[l]);
+    const int scaledPatch = (int)(kPatchSize * t.scale[l]);
+    for (KeyPoint& kp : all[l]) {
+      kp.x += minBX;
+      kp.y += minBY;
+      kp.octave = l;
+      kp.size = (float)scaledPatch;
+    }
+  }
+  for (int l = 0; l < nlevels; l++)
+    for (KeyPoint& kp : all[l]) kp.angle = ic_angle(pyramid[l], cv_round(kp.x), cv_round(kp.y), t.umax);
+}
+
+// computeOrbDescriptor, src/ORBextractor.cc:101-147.
+void orb_descriptor(const Image& img, float px, float py, float angle_deg, uint8_t out[32]) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float angle = angle_deg * factorPI;
+  float a, b;
+  orb_sincosf(angle, &b, &a);  // a = cos, b = sin
+  const uint8_t* center = img.row(cv_round(py)) + cv_round(px);
+  const int step = img.w;
+  const int8_t* pat = kPattern;
+  for (int i = 0; i < 32; i++, pat += 32) {
+    int val = 0;
+    for (int bit = 0; bit < 8; bit++) {
+      const int8_t* p = pat + 4 * bit;
+      const int t0 = center[cv_round(p[0] * b + p[1] * a) * step + cv_round(p[0] * a - p[1] * b)];
+      const int t1 = center[cv_round(p[2] * b + p[3] * a) * step + cv_round(p[2] * a - p[3] * b)];
+      val |= (t0 < t1) << bit;
+    }
+    out[i] = (uint8_t)val;
+  }
+}
+
+// ORBextractor::operator(), src/ORBextractor.cc:1015-1106, level loop in serial order (:1067).
+int Extractor::extract(const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                       std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc) {
+  if (!img || w <= 0 || h <= 0) return -1;
+  compute_pyramid(img, w, h, stride);
+  std::vector<std::vector<KeyPoint>> all;
+  compute_keypoints(all);
+  int n = 0;
+  for (int l = 0; l < nlevels; l++) n += (int)all[l].size();
+  kps.assign(n, KeyPoint{});
+  desc.assign((size_t)n * 32, 0);
+  int mono = 0, stereo = n - 1;
+  for (int l = 0; l < nlevels; l++) {
+    std::vector<KeyPoint>& lk = all[l];
+    if (lk.empty()) continue;
+    gaussian_blur7(pyramid[l], blurred[l], blur_taps);
+    const float scale = t.scale[l];
+    for (KeyPoint& kp : lk) {
+      uint8_t d[32];
+      orb_descriptor(blurred[l], kp.x, kp.y, kp.angle, d);
+      if (l != 0) { kp.x *= scale; kp.y *= scale; }
+      int slot;
+      if (kp.x >= (float)lap0 && kp.x <= (float)lap1) slot = stereo--; else slot = mono++;
+      kps[slot] = kp;
+      std::memcpy(&desc[(size_t)slot * 32], d, 32);
+    }
+  }
+  return mono;
+}
+
+// ======================================================================================= matcher
+// ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1959-1973.
+int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t x, y;
+    std::memcpy(&x, a + 4 * i, 4);
+    std::memcpy(&y, b + 4 * i, 4);
+    uint32_t v = x ^ y;
+    v = v - ((v >> 1) & 0x55555555u);
+    v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+    dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+  }
+  return dist;
+}
+
+// Frame::ComputeStereoMatches, src/Frame.cc:921-1084.
+void compute_stereo_matches(const std::vector<Image>& pyrL, const std::vector<Image>& pyrR,
+                            const std::vector<KeyPoint>& kL, const uint8_t* dL,
+                            const std::vector<KeyPoint>& kR, const uint8_t* dR,
+                            const std::vector<float>& scale, const std::vector<float>& inv_scale,
+                            float bf, float b, std::vector<float>& uRight, std::vector<float>& depth) {
+  const int N = (int)kL.size();
+  uRight.assign(N, -1.0f);
+  depth.assign(N, -1.0f);
+  const int thOrbDist = (100 + 50) / 2;
+  const int nRows = pyrL[0].h;
+  std::vector<std::vector<size_t>> rowIdx(nRows);
+  for (int iR = 0; iR < (int)kR.size(); iR++) {
+    const KeyPoint& kp = kR[iR];
+    if (kp.y == 0.0 && kp.x == 0.0) continue;
+    const float r = 2.0f * scale[kp.octave];
+    const int maxr = (int)std::ceil(kp.y + r);
+    const int minr = (int)std::floor(kp.y - r);
+    for (int yi = minr; yi <= maxr; yi++) rowIdx[yi].push_back(iR);
+  }
+  const float minZ = b, minD = 0, maxD = bf / minZ;
+  std::vector<std::pair<int, int>> distIdx;
+  for (int iL = 0; iL < N; iL++) {
+    const KeyPoint& kpL = kL[iL];
+    const int levelL = kpL.octave;
+    const float vL = kpL.y, uL = kpL.x;
+    const std::vector<size_t>& cands = rowIdx[(size_t)vL];
+    if (cands.empty()) continue;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = 100;
+    size_t bestIdxR = 0;
+    for (size_t iR : cands) {
+      const KeyPoint& kpR = kR[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = descriptor_distance(dL + (size_t)iL * 32, dR + iR * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = kR[bestIdxR].x;
+      const float sf = inv_scale[kpL.octave];
+      const float scaleduL = std::round(kpL.x * sf);
+      const float scaledvL = std::round(kpL.y * sf);
+      const float scaleduR0 = std::round(uR0 * sf);
+      const int w = 5, L = 5;
+      const Image& imL = pyrL[kpL.octave];
+      const Image& imR = pyrR[kpL.octave];
+      int bestSad = INT_MAX, bestinc = 0;
+      float dists[2 * L + 1];
+      const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= imR.w) continue;
+      const int yl = (int)(scaledvL - w), xl = (int)(scaleduL - w);
+      for (int inc = -L; inc <= L; inc++) {
+        const int xr = (int)(scaleduR0 + inc - w);
+        long sad = 0;
+        for (int yy = 0; yy < 2 * w + 1; yy++) {
+          const uint8_t* pl = imL.row(yl + yy) + xl;
+          const uint8_t* pr = imR.row(yl + yy) + xr;
+          for (int xx = 0; xx < 2 * w + 1; xx++) sad += std::abs((int)pl[xx] - (int)pr[xx]);
+        }
+        const float dist = (float)(double)sad;
+        if (dist < bestSad) { bestSad = (int)dist; bestinc = inc; }
+        dists[L + inc] = dist;
+      }
+      if (bestinc == -L || bestinc == L) continue;
+      const float d1 = dists[L + bestinc - 1], d2 = dists[L + bestinc], d3 = dists[L + bestinc + 1];
+      const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = scale[kpL.octave] * ((float)scaleduR0 + (float)bestinc + deltaR);
+      float disparity = uL - bestuR;
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01;
+          bestuR = uL - 0.01;  // double arithmetic, narrowed on assignment (:1063)
+        }
+        depth[iL] = bf / disparity;
+        uRight[iL] = bestuR;
+        distIdx.push_back({bestSad, iL});
+      }
+    }
+  }
+  if (distIdx.empty()) return;  // the reference reads vDistIdx[0] here (UB): guarded
+  std::sort(distIdx.begin(), distIdx.end());
+  const float median = (float)distIdx[distIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)distIdx.size() - 1; i >= 0; i--) {
+    if (distIdx[i].first < thDist) break;
+    uRight[distIdx[i].second] = -1;
+    depth[distIdx[i].second] = -1;
+  }
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(Q, T, k=2): stable w.r.t. train index (B7) + Lowe test (:1302).
+void bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, std::vector<int>& idx2,
+             std::vector<int>& dist2, std::vector<uint8_t>& ratio_ok) {
+  idx2.assign((size_t)nQ * 2, -1);
+  dist2.assign((size_t)nQ * 2, -1);
+  ratio_ok.assign(nQ, 0);
+  for (int q = 0; q < nQ; q++) {
+    int b0 = INT_MAX, b1 = INT_MAX, i0 = -1, i1 = -1;
+    for (int tI = 0; tI < nT; tI++) {
+      const int d = descriptor_distance(dQ + (size_t)q * 32, dT + (size_t)tI * 32);
+      if (d < b0) { b1 = b0; i1 = i0; b0 = d; i0 = tI; }
+      else if (d < b1) { b1 = d; i1 = tI; }
+    }
+    idx2[2 * q] = i0; idx2[2 * q + 1] = i1;
+    if (i0 >= 0) dist2[2 * q] = b0;
+    if (i1 >= 0) dist2[2 * q + 1] = b1;
+    if (i0 >= 0 && i1 >= 0 && (float)b0 < (float)b1 * 0.7) ratio_ok[q] = 1;
+  }
+}
+
+// Frame::AssignFeaturesToGrid / PosInGrid, src/Frame.cc:520-547,833-844 (64x48 grid, round-to-cell).
+void FrameGrid::build(const std::vector<KeyPoint>& kps, float minX_, float minY_, float maxX_, float maxY_) {
+  minX = minX_; minY = minY_; maxX = maxX_; maxY = maxY_;
+  invW = 64.f / (maxX - minX);  // static_cast<float>(FRAME_GRID_COLS) / (mnMaxX - mnMinX), Frame.cc:243
+  invH = 48.f / (maxY - minY);
+  cells.assign(64 * 48, {});
+  for (int i = 0; i < (int)kps.size(); i++) {
+    const int px = (int)std::round((kps[i].x - minX) * invW);
+    const int py = (int)std::round((kps[i].y - minY) * invH);
+    if (px < 0 || px >= 64 || py < 0 || py >= 48) continue;
+    cells[px * 48 + py].push_back(i);
+  }
+}
+
+// Frame::GetFeaturesInArea, src/Frame.cc:765-831.
+std::vector<int> FrameGrid::features_in_area(const std::vector<KeyPoint>& kps, float x, float y, float r,
+                                             int minLevel, int maxLevel) const {
+  std::vector<int> out;
+  const int cx0 = std::max(0, (int)std::floor((x - minX - r) * invW));
+  if (cx0 >= 64) return out;
+  const int cx1 = std::min(63, (int)std::ceil((x - minX + r) * invW));
+  if (cx1 < 0) return out;
+  const int cy0 = std::max(0, (int)std::floor((y - minY - r) * invH));
+  if (cy0 >= 48) return out;
+  const int cy1 = std::min(47, (int)std::ceil((y - minY + r) * invH));
+  if (cy1 < 0) return out;
+  const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+  for (int ix = cx0; ix <= cx1; ix++)
+    for (int iy = cy0; iy <= cy1; iy++)
+      for (int idx : cells[ix * 48 + iy]) {
+        const KeyPoint& kp = kps[idx];
+        if (checkLevels) {
+          if (kp.octave < minLevel) continue;
+          if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        }
+        const float dx = kp.x - x, dy = kp.y - y;
+        if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(idx);
+      }
+  return out;
+}
+
+// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1920-1955.
+static void three_maxima(const std::vector<int>* histo, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:618-764, executed in serial i1 order.
+int search_for_initialization(const std::vector<KeyPoint>& k1, const uint8_t* d1,
+                              const std::vector<KeyPoint>& k2, const uint8_t* d2, const FrameGrid& g2,
+                              std::vector<float>& prev, std::vector<int>& matches12, int windowSize,
+                              float nnratio, bool checkOri) {
+  const int HISTO = 30, TH_LOW = 50;
+  int nmatches = 0;
+  matches12.assign(k1.size(), -1);
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  std::vector<int> matchedDist(k2.size(), INT_MAX), matches21(k2.size(), -1);
+  for (size_t i1 = 0; i1 < k1.size(); i1++) {
+    const KeyPoint& kp1 = k1[i1];
+    if (kp1.octave > 0) continue;
+    std::vector<int> cand = g2.features_in_area(k2, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize,
+                                                kp1.octave, kp1.octave);
+    if (cand.empty()) continue;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (int i2 : cand) {
+      const int dist = descriptor_distance(d1 + i1 * 32, d2 + (size_t)i2 * 32);
+      if (matchedDist[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+      if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; nmatches--; }
+      matches12[i1] = bestIdx2;
+      matches21[bestIdx2] = (int)i1;
+      matchedDist[bestIdx2] = bestDist;
+      nmatches++;
+      if (checkOri) {
+        float rot = k1[i1].angle - k2[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO) bin = 0;
+        rotHist[bin].push_back((int)i1);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+    }
+  }
+  for (size_t i1 = 0; i1 < matches12.size(); i1++)
+    if (matches12[i1] >= 0) { prev[2 * i1] = k2[matches12[i1]].x; prev[2 * i1 + 1] = k2[matches12[i1]].y; }
+  return nmatches;
+}
+
+}  // namespace orbo

@@ -1,0 +1,117 @@
+// orb_oracle.h — CPU oracle for the ORB front-end hot path.  TEST INFRASTRUCTURE ONLY.
+//
+// This is a from-scratch, single-threaded restatement of the *serial* semantics of the reference
+// (hellovuong/ORB_SLAM3_FAST: src/ORBextractor.cc, src/ORBmatcher.cc, src/Frame.cc) and of the OpenCV 4.x
+// kernels that path calls (resize, FAST, GaussianBlur, fastAtan2, norm, BFMatcher::knnMatch).
+//
+// PARITY UNPINNED: the reference holds no tests or golden vectors for this path, and neither the
+// reference nor OpenCV can be built in this image (no OpenCV/TBB/Eigen/Boost headers, no network).
+// The OpenCV kernels are restated from their published algorithm (generic C++ paths of OpenCV >= 4.5.1);
+// what IS pinned: the rBRIEF pattern (sha256 + scikit-image's independent copy), the umax / quota /
+// pyramid-size tables of SURVEY.md Appendix C, and the hand-derivable KATs of Appendix B.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything in oracle/.
+// The product (orb_slam3_fast_amd/) never links, imports or calls it.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace orbo {
+
+// Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id) = 28 bytes.
+struct KeyPoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+static_assert(sizeof(KeyPoint) == 28, "cv::KeyPoint layout");
+
+struct Image {
+  int w = 0, h = 0;
+  std::vector<uint8_t> px;  // row-major, stride == w
+  Image() {}
+  Image(int w_, int h_) : w(w_), h(h_), px((size_t)w_ * h_) {}
+  uint8_t* row(int y) { return px.data() + (size_t)y * w; }
+  const uint8_t* row(int y) const { return px.data() + (size_t)y * w; }
+};
+
+// ---- OpenCV kernels restated -------------------------------------------------
+int cv_round(float v);
+int cv_round(double v);
+float fast_atan2(float y, float x);                                   // B5
+void orb_sincosf(float ang, float* s, float* c);                      // B8 (see .cpp: defined algorithm)
+void resize_linear_u8(const Image& src, Image& dst, int dw, int dh);  // B2
+// FAST-9-16 with non-max suppression on a standalone image (ROI already cut); out: x,y,score triples.
+struct FastPt { int x, y, score; };
+void fast9_16(const uint8_t* img, int stride, int cols, int rows, int threshold, bool nms,
+              std::vector<FastPt>& out);                              // B3
+int fast_corner_score16(const uint8_t* ptr, const int pixel[25], int threshold);
+void gaussian_blur7(const Image& src, Image& dst, const int taps[7]);  // B4
+extern const int kBlurTaps451[7];  // OpenCV >= 4.5.1 : 18,34,48,56,48,34,18
+extern const int kBlurTaps440[7];  // OpenCV 4.0-4.5.0: 18,34,49,55,49,34,18
+
+// ---- ORBextractor (reference src/ORBextractor.cc) --------------------------------------------------
+struct ExtractorTables {
+  std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+  std::vector<int> nfeat_level;
+  std::vector<int> umax;  // 16 entries
+};
+
+class Extractor {
+ public:
+  Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+  // operator(): returns monoIndex, or -1 on empty image.  lap0/lap1 = vLappingArea.
+  int extract(const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+              std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc);
+
+  // Stages, exposed for stage-level differential tests.
+  void compute_pyramid(const uint8_t* img, int w, int h, ptrdiff_t stride);
+  void detect_level_candidates(int level, std::vector<KeyPoint>& cand) const;  // literal per-cell FAST
+  std::vector<KeyPoint> distribute_octtree(const std::vector<KeyPoint>& cand, int minX, int maxX,
+                                           int minY, int maxY, int N) const;
+  void compute_keypoints(std::vector<std::vector<KeyPoint>>& all) const;
+
+  ExtractorTables t;
+  std::vector<Image> pyramid;  // mvImagePyramid (no 19-px border: it is never read)
+  std::vector<Image> blurred;  // per level, filled by extract() for levels with keypoints
+  int nfeatures, nlevels, iniTh, minTh;
+  double scaleFactor;  // the reference keeps it as double (include/ORBextractor.h:106)
+  const int* blur_taps = kBlurTaps451;
+};
+
+float ic_angle(const Image& im, int cx, int cy, const std::vector<int>& umax);
+void orb_descriptor(const Image& blurred, float px, float py, float angle_deg, uint8_t out[32]);
+extern const int8_t kPattern[1024];
+
+// ---- ORBmatcher / Frame matching (reference src/ORBmatcher.cc, src/Frame.cc) -----------------------
+int descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+// Frame::ComputeStereoMatches (src/Frame.cc:921-1084). maxD = bf / b (intended semantics).
+void compute_stereo_matches(const std::vector<Image>& pyrL, const std::vector<Image>& pyrR,
+                            const std::vector<KeyPoint>& kL, const uint8_t* dL,
+                            const std::vector<KeyPoint>& kR, const uint8_t* dR,
+                            const std::vector<float>& scale, const std::vector<float>& inv_scale,
+                            float bf, float b, std::vector<float>& uRight, std::vector<float>& depth);
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) + Lowe ratio (src/Frame.cc:1293-1302).
+// idx2/dist2: nQ x 2 (-1 when fewer than k train rows). ratio_ok[q] = accepted by d0 < d1*0.7.
+void bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, std::vector<int>& idx2,
+             std::vector<int>& dist2, std::vector<uint8_t>& ratio_ok);
+
+// Frame grid (src/Frame.cc:520-547,765-844).
+struct FrameGrid {
+  float minX, minY, maxX, maxY, invW, invH;
+  std::vector<std::vector<int>> cells;  // [ix*48+iy]
+  void build(const std::vector<KeyPoint>& kps, float minX, float minY, float maxX, float maxY);
+  std::vector<int> features_in_area(const std::vector<KeyPoint>& kps, float x, float y, float r,
+                                    int minLevel, int maxLevel) const;
+};
+
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764), serial i1 order.
+int search_for_initialization(const std::vector<KeyPoint>& k1, const uint8_t* d1,
+                              const std::vector<KeyPoint>& k2, const uint8_t* d2, const FrameGrid& g2,
+                              std::vector<float>& prevMatched /*2*n1 in/out*/,
+                              std::vector<int>& matches12, int windowSize, float nnratio,
+                              bool checkOri);
+
+}  // namespace orbo

@@ -1,0 +1,158 @@
+// C-ABI face of the CPU oracle for ctypes (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+// TEST INFRASTRUCTURE ONLY — see orb_oracle.h.
+#include <cstring>
+
+#include "orb_oracle.h"
+
+using namespace orbo;
+
+extern "C" {
+
+void* oro_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+  return new Extractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+}
+void oro_destroy(void* h) { delete (Extractor*)h; }
+void oro_set_blur_taps(void* h, int variant) {
+  ((Extractor*)h)->blur_taps = variant == 440 ? kBlurTaps440 : kBlurTaps451;
+}
+void oro_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* nfeat,
+                int* umax) {
+  Extractor* e = (Extractor*)h;
+  for (int i = 0; i < e->nlevels; i++) {
+    scale[i] = e->t.scale[i];
+    inv_scale[i] = e->t.inv_scale[i];
+    sigma2[i] = e->t.sigma2[i];
+    inv_sigma2[i] = e->t.inv_sigma2[i];
+    nfeat[i] = e->t.nfeat_level[i];
+  }
+  for (int i = 0; i < 16; i++) umax[i] = e->t.umax[i];
+}
+const int8_t* oro_pattern() { return kPattern; }
+
+int oro_extract(void* h, const uint8_t* img, int w, int h_, long stride, int lap0, int lap1, KeyPoint* kps,
+                uint8_t* desc, int cap, int* n_out) {
+  Extractor* e = (Extractor*)h;
+  std::vector<KeyPoint> k;
+  std::vector<uint8_t> d;
+  int mono = e->extract(img, w, h_, stride, lap0, lap1, k, d);
+  if (mono < 0) { *n_out = 0; return mono; }
+  *n_out = (int)k.size();
+  if ((int)k.size() > cap) return -3;
+  std::memcpy(kps, k.data(), k.size() * sizeof(KeyPoint));
+  std::memcpy(desc, d.data(), d.size());
+  return mono;
+}
+
+void oro_compute_pyramid(void* h, const uint8_t* img, int w, int h_, long stride) {
+  ((Extractor*)h)->compute_pyramid(img, w, h_, stride);
+}
+void oro_level_size(void* h, int level, int* w, int* h_) {
+  Extractor* e = (Extractor*)h;
+  *w = e->pyramid[level].w;
+  *h_ = e->pyramid[level].h;
+}
+const uint8_t* oro_level_ptr(void* h, int level) { return ((Extractor*)h)->pyramid[level].px.data(); }
+const uint8_t* oro_blurred_ptr(void* h, int level) { return ((Extractor*)h)->blurred[level].px.data(); }
+
+// candidates of one level (coordinates relative to the (16,16) window origin, as in the reference).
+int oro_detect_candidates(void* h, int level, KeyPoint* out, int cap) {
+  std::vector<KeyPoint> c;
+  ((Extractor*)h)->detect_level_candidates(level, c);
+  if ((int)c.size() > cap) return -(int)c.size();
+  std::memcpy(out, c.data(), c.size() * sizeof(KeyPoint));
+  return (int)c.size();
+}
+int oro_distribute(void* h, const KeyPoint* cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                   KeyPoint* out, int cap) {
+  std::vector<KeyPoint> c(cand, cand + n);
+  std::vector<KeyPoint> r = ((Extractor*)h)->distribute_octtree(c, minX, maxX, minY, maxY, N);
+  if ((int)r.size() > cap) return -3;
+  std::memcpy(out, r.data(), r.size() * sizeof(KeyPoint));
+  return (int)r.size();
+}
+
+void oro_resize(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+  Image s(sw, sh), d;
+  std::memcpy(s.px.data(), src, (size_t)sw * sh);
+  resize_linear_u8(s, d, dw, dh);
+  std::memcpy(dst, d.px.data(), (size_t)dw * dh);
+}
+int oro_fast(const uint8_t* img, int stride, int cols, int rows, int threshold, int nms, int* xys, int cap) {
+  std::vector<FastPt> out;
+  fast9_16(img, stride, cols, rows, threshold, nms != 0, out);
+  int n = (int)out.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    xys[3 * i] = out[i].x;
+    xys[3 * i + 1] = out[i].y;
+    xys[3 * i + 2] = out[i].score;
+  }
+  return n;
+}
+void oro_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) {
+  Image s(w, h), d;
+  std::memcpy(s.px.data(), src, (size_t)w * h);
+  gaussian_blur7(s, d, variant == 440 ? kBlurTaps440 : kBlurTaps451);
+  std::memcpy(dst, d.px.data(), (size_t)w * h);
+}
+float oro_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void oro_sincosf(float a, float* s, float* c) { orb_sincosf(a, s, c); }
+int oro_cv_round_f(float v) { return cv_round(v); }
+float oro_ic_angle(const uint8_t* img, int w, int h, int cx, int cy) {
+  Image s(w, h);
+  std::memcpy(s.px.data(), img, (size_t)w * h);
+  Extractor e(1000, 1.2f, 8, 20, 7);
+  return ic_angle(s, cx, cy, e.t.umax);
+}
+void oro_descriptor(const uint8_t* blurred, int w, int h, float px, float py, float angle, uint8_t* out) {
+  Image s(w, h);
+  std::memcpy(s.px.data(), blurred, (size_t)w * h);
+  orb_descriptor(s, px, py, angle, out);
+}
+int oro_hamming(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+// Stereo association on the pyramids held by two oracle extractors (after oro_extract on each).
+void oro_stereo_match(void* hl, void* hr, const KeyPoint* kL, const uint8_t* dL, int nL, const KeyPoint* kR,
+                      const uint8_t* dR, int nR, float bf, float b, float* uRight, float* depth) {
+  Extractor* L = (Extractor*)hl;
+  Extractor* R = (Extractor*)hr;
+  std::vector<KeyPoint> kl(kL, kL + nL), kr(kR, kR + nR);
+  std::vector<float> u, d;
+  compute_stereo_matches(L->pyramid, R->pyramid, kl, dL, kr, dR, L->t.scale, L->t.inv_scale, bf, b, u, d);
+  std::memcpy(uRight, u.data(), nL * sizeof(float));
+  std::memcpy(depth, d.data(), nL * sizeof(float));
+}
+
+void oro_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2, uint8_t* ok) {
+  std::vector<int> i2, d2;
+  std::vector<uint8_t> r;
+  bf_knn2(dQ, nQ, dT, nT, i2, d2, r);
+  std::memcpy(idx2, i2.data(), i2.size() * sizeof(int));
+  std::memcpy(dist2, d2.data(), d2.size() * sizeof(int));
+  std::memcpy(ok, r.data(), r.size());
+}
+
+int oro_search_init(const KeyPoint* k1, const uint8_t* d1, int n1, const KeyPoint* k2, const uint8_t* d2,
+                    int n2, float minX, float minY, float maxX, float maxY, float* prevMatched,
+                    int* matches12, int windowSize, float nnratio, int checkOri) {
+  std::vector<KeyPoint> a(k1, k1 + n1), b(k2, k2 + n2);
+  FrameGrid g;
+  g.build(b, minX, minY, maxX, maxY);
+  std::vector<float> prev(prevMatched, prevMatched + 2 * n1);
+  std::vector<int> m;
+  int n = search_for_initialization(a, d1, b, d2, g, prev, m, windowSize, nnratio, checkOri != 0);
+  std::memcpy(prevMatched, prev.data(), prev.size() * sizeof(float));
+  std::memcpy(matches12, m.data(), m.size() * sizeof(int));
+  return n;
+}
+
+int oro_features_in_area(const KeyPoint* k, int n, float minX, float minY, float maxX, float maxY, float x,
+                         float y, float r, int minLevel, int maxLevel, int* out, int cap) {
+  std::vector<KeyPoint> a(k, k + n);
+  FrameGrid g;
+  g.build(a, minX, minY, maxX, maxY);
+  std::vector<int> v = g.features_in_area(a, x, y, r, minLevel, maxLevel);
+  for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
+  return (int)v.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""Known-answer and property tests that pin the oracle's OpenCV-kernel restatements.
+
+The reference holds no tests for this path and OpenCV is not installable here, so these KATs are the
+hand-derivable answers of Appendix B plus independent numpy re-derivations of the same published
+formulas (PARITY UNPINNED against real OpenCV — see oracle/orb_oracle.h).
+"""
+import ctypes
+import ctypes.util
+
+import numpy as np
+import pytest
+
+from orb_slam3_fast_amd import synth
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2),
+        (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+# ------------------------------------------------------------------------------------------- B2 resize
+def np_resize(src, dw, dh):
+    """independent vectorised restatement of the 11-bit fixed-point bilinear resize"""
+    sh, sw = src.shape
+    def coef(dn, sn, clamp_x):
+        scale = 1.0 / (float(dn) / sn)
+        d = np.arange(dn, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if clamp_x:
+            lo = s < 0
+            f[lo], s[lo] = 0, 0
+            hi = s >= sn - 1
+            f[hi], s[hi] = 0, sn - 1
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s, c0, c1
+    sx, a0, a1 = coef(dw, sw, True)
+    sy, b0, b1 = coef(dh, sh, False)
+    S = src.astype(np.int64)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    H = S[:, sx] * a0[None, :] + S[:, sx1] * a1[None, :]
+    r0 = H[np.clip(sy, 0, sh - 1)]
+    r1 = H[np.clip(sy + 1, 0, sh - 1)]
+    out = ((((b0[:, None] * (r0 >> 4)) >> 16) + ((b1[:, None] * (r1 >> 4)) >> 16) + 2) >> 2)
+    return out.astype(np.uint8)
+
+
+def test_resize_constant_and_identity(oracle):
+    c = np.full((100, 120), 77, np.uint8)
+    assert np.all(oracle.resize(c, 100, 83) == 77)
+    rng = np.random.default_rng(1)
+    im = rng.integers(0, 256, (50, 64), dtype=np.uint8)
+    assert np.array_equal(oracle.resize(im, 64, 50), im)
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 533, 400), (357, 201, 298, 168), (64, 48, 53, 40),
+                                         (1280, 720, 1067, 600), (100, 100, 250, 130)])
+def test_resize_vs_numpy_restatement(oracle, sw, sh, dw, dh):
+    rng = np.random.default_rng(sw * 7 + dh)
+    im = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+    assert np.array_equal(oracle.resize(im, dw, dh), np_resize(im, dw, dh))
+
+
+# ------------------------------------------------------------------------------------------- B3 FAST
+def ring_image(center, ring_vals, size=15, bg=None):
+    im = np.full((size, size), center if bg is None else bg, np.uint8)
+    c = size // 2
+    im[c, c] = center
+    for (dx, dy), v in zip(RING, ring_vals):
+        im[c + dy, c + dx] = v
+    return im, c
+
+
+def test_fast_kats(oracle):
+    assert len(oracle.fast(np.full((40, 40), 100, np.uint8), 20)) == 0
+    im, c = ring_image(100, [130] * 9 + [100] * 7)
+    r = oracle.fast(im, 20, nms=False)
+    assert [c, c, 0] in r.tolist() or any((p[0] == c and p[1] == c) for p in r)
+    r = oracle.fast(im, 20, nms=True)
+    hit = [p for p in r if p[0] == c and p[1] == c]
+    assert len(hit) == 1 and hit[0][2] == 29          # score = M - 1 with M = 30
+    im8, c = ring_image(100, [130] * 8 + [100] * 8)
+    assert not any(p[0] == c and p[1] == c for p in oracle.fast(im8, 20, nms=False))
+    # dark arc, wrapping around index 15 -> 0
+    vals = [100] * 16
+    for k in (13, 14, 15, 0, 1, 2, 3, 4, 5):
+        vals[k] = 40
+    imw, c = ring_image(100, vals)
+    hit = [p for p in oracle.fast(imw, 20) if p[0] == c and p[1] == c]
+    assert len(hit) == 1 and hit[0][2] == 59
+
+
+def test_fast_equal_neighbours_both_suppressed(oracle):
+    # strict '>' in the NMS: two adjacent corners with identical scores kill each other.
+    # mirror-symmetric image => mirrored pixels get equal scores
+    rng = np.random.default_rng(5)
+    half = rng.integers(0, 256, (40, 20), dtype=np.uint8)
+    sym = np.hstack([half, half[:, ::-1]])          # columns 19 | 20 are mirror images
+    allc = oracle.fast(sym, 10, nms=False)
+    kept = oracle.fast(sym, 10, nms=True)
+    s_all = {(x, y) for x, y, _ in allc.tolist()}
+    pairs = [y for y in range(3, 37) if (19, y) in s_all and (20, y) in s_all]
+    assert pairs
+    for y in pairs:
+        assert not any((p[0] in (19, 20)) and p[1] == y for p in kept.tolist())
+
+
+def fast_score_map(img, tmin):
+    """level-wide model: S(p) = M-1 if M > tmin else 0, M = max over 9-arcs of min |diff| of one sign"""
+    h, w = img.shape
+    I = img.astype(np.int32)
+    S = np.zeros((h, w), np.int32)
+    d = np.zeros((25, h - 6, w - 6), np.int32)
+    c = I[3:h - 3, 3:w - 3]
+    for k in range(25):
+        dx, dy = RING[k % 16]
+        d[k] = c - I[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx]
+    M = np.full((h - 6, w - 6), -999, np.int32)
+    for k in range(16):
+        arc = d[k:k + 9]
+        M = np.maximum(M, arc.min(0))
+        M = np.maximum(M, (-arc).min(0))
+    S[3:h - 3, 3:w - 3] = np.where(M > tmin, M - 1, 0)
+    return S
+
+
+def levelwide_candidates(img, ini_th, min_th):
+    """The level-wide / cell-masked formulation the HIP path uses, in the reference's order."""
+    h, w = img.shape
+    S = fast_score_map(img, min_th)
+    minB, maxBX, maxBY = 16, w - 16, h - 16
+    width, height = np.float32(maxBX - minB), np.float32(maxBY - minB)
+    nC, nR = int(width / np.float32(35)), int(height / np.float32(35))
+    wC, hC = int(np.ceil(width / np.float32(nC))), int(np.ceil(height / np.float32(nR)))
+    out = []
+    for i in range(nR):
+        iniY = minB + i * hC
+        maxY = iniY + hC + 6
+        if iniY >= maxBY - 3:
+            continue
+        maxY = min(maxY, maxBY)
+        for j in range(nC):
+            iniX = minB + j * wC
+            maxX = iniX + wC + 6
+            if iniX >= maxBX - 6:
+                continue
+            maxX = min(maxX, maxBX)
+            y0, y1, x0, x1 = iniY + 3, maxY - 3, iniX + 3, maxX - 3      # detectable window of the cell
+            if y1 <= y0 or x1 <= x0:
+                continue
+            T = np.zeros((y1 - y0 + 2, x1 - x0 + 2), np.int32)
+            T[1:-1, 1:-1] = S[y0:y1, x0:x1]
+            cen = T[1:-1, 1:-1]
+            keep = cen > 0
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if dx or dy:
+                        keep &= cen > T[1 + dy:T.shape[0] - 1 + dy, 1 + dx:T.shape[1] - 1 + dx]
+            k20 = keep & (cen >= ini_th)
+            sel = k20 if k20.any() else keep
+            ys, xs = np.nonzero(sel)
+            for y, x in zip(ys, xs):
+                out.append((x + x0 - 16, y + y0 - 16, cen[y, x]))
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("w,h,stream", [(320, 240, 3), (389, 277, 4), (241, 250, 5)])
+def test_cellwise_fast_equals_levelwide_formulation(oracle, w, h, stream):
+    img = synth.mono_frame(w, h, stream)
+    img[: h // 3, : w // 2] = (img[: h // 3, : w // 2] // 8) + 100     # low-contrast zone -> min-threshold cells
+    ex = oracle.OracleExtractor(500, 1.2, 1, 20, 7)
+    ex.compute_pyramid(img)
+    c = ex.detect_candidates(0)
+    lit = np.stack([c["x"], c["y"], c["response"]], 1).astype(np.int32)
+    mod = levelwide_candidates(img, 20, 7)
+    assert len(lit) > 50 and (lit[:, 2] < 20).any() and (lit[:, 2] >= 20).any()
+    assert np.array_equal(lit, mod)
+
+
+# ------------------------------------------------------------------------------------------- B4 blur
+def test_blur_kats(oracle):
+    assert np.all(oracle.blur(np.full((30, 40), 93, np.uint8)) == 93)
+    im = np.zeros((21, 21), np.uint8)
+    im[10, 10] = 255
+    out = oracle.blur(im)
+    assert out[10, 10] == 12 and out[10, 9] == (56 * 48 * 255 + 32768) >> 16
+    k = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)
+    rng = np.random.default_rng(2)
+    im = rng.integers(0, 256, (37, 45), dtype=np.uint8)
+    pad = np.pad(im.astype(np.int64), 3, mode="reflect")          # numpy 'reflect' == BORDER_REFLECT_101
+    acc = np.zeros(im.shape, np.int64)
+    for i in range(7):
+        for j in range(7):
+            acc += k[i] * k[j] * pad[i:i + 37, j:j + 45]
+    assert np.array_equal(oracle.blur(im), ((acc + 32768) >> 16).astype(np.uint8))
+    assert oracle.blur(im, 440).shape == im.shape
+
+
+# ------------------------------------------------------------------------------------------- B5 / B8
+def test_fast_atan2_kats(oracle):
+    assert oracle.fast_atan2(0, 0) == 0
+    assert oracle.fast_atan2(0, 1) == 0
+    assert abs(oracle.fast_atan2(1, 0) - 90) < 1e-4
+    assert abs(oracle.fast_atan2(0, -1) - 180) < 1e-4
+    assert abs(oracle.fast_atan2(-1, 0) - 270) < 1e-4
+    assert abs(oracle.fast_atan2(1, 1) - 45) < 0.02
+    rng = np.random.default_rng(3)
+    for y, x in rng.integers(-30000, 30000, (2000, 2)):
+        a = oracle.fast_atan2(y, x)
+        ref = np.degrees(np.arctan2(float(y), float(x))) % 360
+        assert 0 <= a <= 360 and min(abs(a - ref), 360 - abs(a - ref)) < 0.35
+
+
+def test_cv_round_half_even(oracle):
+    f = oracle.lib().oro_cv_round_f
+    assert [f(0.5), f(1.5), f(2.5), f(-0.5), f(-1.5), f(2.4999), f(-2.5)] == [0, 2, 2, 0, -2, 2, -2]
+
+
+def test_sincos_vs_libm(oracle):
+    """Defined sin/cos = double evaluation rounded once; must stay within 1 ulp of this host's libm and
+    agree almost everywhere (the reference's libm result is itself machine dependent, see oracle)."""
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.cosf.restype = ctypes.c_float
+    libm.cosf.argtypes = [ctypes.c_float]
+    libm.sinf.restype = ctypes.c_float
+    libm.sinf.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(4)
+    fpi = np.float32(np.pi / np.float32(180.0))
+    angs = (rng.random(20000).astype(np.float32) * np.float32(360.0)) * fpi
+    angs = np.concatenate([angs, np.array([0, 90, 180, 270, 360], np.float32) * fpi])
+    mism = 0
+    for a in angs:
+        s, c = oracle.sincosf(float(a))
+        ls, lc = libm.sinf(float(a)), libm.cosf(float(a))
+        for v, r in ((s, ls), (c, lc)):
+            if v != r:
+                mism += 1
+                assert abs(v - r) <= np.spacing(np.float32(abs(r))) * 1.01
+        ref_s, ref_c = np.sin(np.float64(a)), np.cos(np.float64(a))
+        assert abs(s - ref_s) < 6e-8 + abs(ref_s) * 6e-8 and abs(c - ref_c) < 6e-8 + abs(ref_c) * 6e-8
+    assert mism < 0.02 * 2 * len(angs)
+
+
+# ------------------------------------------------------------------------------------------- A5 / A7
+def test_ic_angle_symmetry(oracle):
+    im = np.zeros((41, 41), np.uint8)
+    im[:, 21:] = 200                                # brighter to the right -> angle 0
+    assert oracle.ic_angle(im, 20, 20) == 0.0
+    assert abs(oracle.ic_angle(im.T.copy(), 20, 20) - 90) < 1e-3
+    assert abs(oracle.ic_angle(im[:, ::-1].copy(), 20, 20) - 180) < 1e-3
+
+
+def test_descriptor_bit_order(oracle):
+    # angle 0: a=1,b=0 -> sample (y, x) offsets straight from the pattern; bit i of byte k = test 8k+i
+    rng = np.random.default_rng(6)
+    im = rng.integers(0, 256, (61, 61), dtype=np.uint8)
+    d = oracle.descriptor(im, 30.0, 30.0, 0.0)
+    ptr = oracle.lib().oro_pattern()
+    pat = np.frombuffer((ctypes.c_int8 * 1024).from_address(ptr), np.int8).reshape(256, 4).astype(int)
+    exp = np.zeros(32, np.uint8)
+    for t, (x0, y0, x1, y1) in enumerate(pat):
+        if im[30 + y0, 30 + x0] < im[30 + y1, 30 + x1]:
+            exp[t // 8] |= 1 << (t % 8)
+    assert np.array_equal(d, exp)
+
+
+def test_hamming(oracle):
+    rng = np.random.default_rng(7)
+    a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+    assert oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+    assert oracle.hamming(a, a) == 0 and oracle.hamming(a, ~a) == 256
