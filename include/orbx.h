@@ -1,0 +1,152 @@
+/* orbx.h — C ABI of the MI355X-native ORB front-end (liborbx.so).
+ *
+ * Drop-in boundary for the reference's ORB hot path (hellovuong/ORB_SLAM3_FAST).  Every entry point names
+ * the reference interface it replaces (file:line relative to the reference root).  Plain pointers and
+ * sizes only: no OpenCV, no torch types.  The C++ mirror classes ORB_SLAM3::ORBextractor / ORBmatcher in
+ * orb_slam3_fast_amd/csrc/ORBextractor.h / ORBmatcher.h sit on top of exactly these calls; INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is no CPU fallback: without a HIP device
+ * every compute call returns ORBX_E_NODEVICE / ORBX_E_HIP.
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBX_MAX_LEVELS 12
+
+/* Error codes.  ORBX_E_EMPTY keeps ORBextractor::operator()'s "-1 on empty image"
+ * (src/ORBextractor.cc:1021). */
+#define ORBX_OK 0
+#define ORBX_E_EMPTY (-1)
+#define ORBX_E_BADARG (-2)
+#define ORBX_E_CAPACITY (-3)
+#define ORBX_E_HIP (-4)
+#define ORBX_E_NODEVICE (-5)
+#define ORBX_E_UNSUPPORTED (-6) /* image too small for the pyramid or aspect (Q11) */
+
+/* Layout-identical to cv::KeyPoint (28 bytes): pt.x pt.y size angle response octave class_id
+ * (SURVEY 8a row a13). */
+typedef struct orbx_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orbx_keypoint;
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:53-57, src/ORBextractor.cc:408-417). */
+typedef struct orbx_params {
+  int32_t nfeatures;
+  float scale_factor;
+  int32_t nlevels;
+  int32_t ini_th_fast;
+  int32_t min_th_fast;
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+const char* orbx_last_error(void);
+int orbx_device_count(void);
+int orbx_abi_version(void);
+
+/* ---- ORBextractor ---------------------------------------------------------------------------------- */
+
+/* Replaces ORBextractor::ORBextractor (src/ORBextractor.cc:408-469).  One handle = one extractor instance
+ * bound to `device` with its own HIP stream; it owns pyramids and result buffers for up to max_batch images
+ * of up to max_width x max_height per call.  Handles are not re-entrant (like the reference instance, which
+ * mutates mvImagePyramid); distinct handles may be used concurrently from different threads
+ * (src/Frame.cc:200-203). */
+int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, int max_batch, int device,
+                          orbx_extractor** out);
+void orbx_extractor_destroy(orbx_extractor* ex);
+
+/* Replaces GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:65-83) plus the private mnFeaturesPerLevel / umax tables.  Any pointer may be
+ * NULL.  Arrays hold nlevels entries, umax16 holds 16. */
+int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int32_t* nfeatures_per_level, int32_t* umax16);
+
+/* Replaces ORBextractor::operator() (src/ORBextractor.cc:1015-1106) for ONE host image (CV_8UC1, `stride`
+ * bytes per row).  lap0/lap1 = vLappingArea.  Writes *n_out keypoints (serial-order slots: mono from the
+ * front, lapping from the back) and n_out x 32 descriptor bytes.  Returns monoIndex (>= 0), ORBX_E_EMPTY for
+ * an empty image, or another negative error.  cap = capacity of kps / desc rows (nfeatures + 3*nlevels
+ * always suffices). */
+int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched many-camera mode: n_images device-resident images (image i at d_images + i*image_pitch, rows
+ * row_pitch bytes apart; base and pitches 4-byte aligned), all w x h.  d_lap = n_images x 2 int32 lapping
+ * areas on the HOST (NULL = all {0,0} as the rectified stereo callers pass, src/Frame.cc:200-201).
+ * Enqueues the whole extraction on the handle's stream and returns without synchronising; the images must
+ * stay valid until orbx_sync (level 0 of the pyramid aliases them). */
+int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_images, int w, int h,
+                              ptrdiff_t row_pitch, ptrdiff_t image_pitch, const int32_t* lap);
+int orbx_sync(orbx_extractor* ex);
+
+/* Device-resident results of the last (batch) extraction: keypoints [n_images][cap] and descriptors
+ * [n_images][cap][32], counts[n_images] (n) and mono[n_images] (monoIndex), all on the device. */
+int orbx_batch_results_device(const orbx_extractor* ex, const orbx_keypoint** d_kps, const uint8_t** d_desc,
+                              const int32_t** d_counts, const int32_t** d_mono, int* cap);
+/* Copy one image's results to the host (synchronises the handle's stream). Returns monoIndex or error. */
+int orbx_batch_download(orbx_extractor* ex, int image, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Replaces reads of the public member ORBextractor::mvImagePyramid (include/ORBextractor.h:86;
+ * used by src/Frame.cc:927,1011,1024,1029): copies level `level` of image `image` of the last extraction
+ * to dst (dst_stride bytes per row; dst may be NULL to query the size only). blurred != 0 returns the
+ * 7x7 Gaussian-blurred working copy (src/ORBextractor.cc:1074-1076) instead. */
+int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, uint8_t* dst,
+                       ptrdiff_t dst_stride, int* w, int* h);
+
+/* Stage taps for differential tests: FAST candidates handed to DistributeOctTree for (image, level), in
+ * unspecified order (x, y relative to the (16,16) window origin as in src/ORBextractor.cc:965-967;
+ * response = FAST score).  Returns the count or a negative error; copies at most cap entries. */
+int orbx_debug_candidates(orbx_extractor* ex, int image, int level, int32_t* xys, int cap);
+
+/* ---- ORBmatcher / Frame matching -------------------------------------------------------------------- */
+
+/* Replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1959-1973) — host-side convenience, the
+ * device matchers use v_bcnt on the same 8 little-endian words. */
+int orbx_hamming256(const void* a, const void* b);
+
+/* Replaces Frame::ComputeStereoMatches (src/Frame.cc:921-1084) for n_pairs rectified pairs whose left
+ * images are images [first_left, first_left+n_pairs) of `left`'s last extraction and whose right images are
+ * [first_right, ...) of `right`'s (left == right is allowed: one handle holding both eyes).  bf = mbf,
+ * b = mb (maxD = bf / b).  Results stay on the device of `left`:
+ * uRight / depth [n_pairs][cap_left] floats (-1 = no match).  Enqueued on left's stream after right's work. */
+int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                            int n_pairs, float bf, float b);
+int orbx_stereo_results_device(const orbx_extractor* left, const float** d_uright, const float** d_depth);
+/* Host copy of pair `pair` (synchronises): n = keypoint count of the left image. */
+int orbx_stereo_download(orbx_extractor* left, int pair, float* uright, float* depth, int cap);
+
+/* Replaces cv::BFMatcher(NORM_HAMMING).knnMatch(Q, T, k=2) + Lowe ratio of
+ * Frame::ComputeStereoFishEyeMatches (src/Frame.cc:46,1293-1302).  Host descriptor rows in, host results
+ * out: idx2 / dist2 [nQ][2] (-1 when the train set has fewer rows), ratio_ok[nQ] = d0 < d1*0.7. */
+int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx2,
+                 int32_t* dist2, uint8_t* ratio_ok);
+
+/* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) incl. Frame::GetFeaturesInArea /
+ * AssignFeaturesToGrid / PosInGrid on F2 (src/Frame.cc:520-547,765-844) and ComputeThreeMaxima
+ * (src/ORBmatcher.cc:1920-1955).  kps are the undistorted keypoints (mvKeysUn); bounds = mnMinX, mnMinY,
+ * mnMaxX, mnMaxY of F2; prev_matched = vbPrevMatched (2*n1 floats, in/out); matches12 = vnMatches12 (n1).
+ * Returns nmatches or a negative error. */
+int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                   const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
+                                   float min_y, float max_x, float max_y, float* prev_matched,
+                                   int32_t* matches12, int window_size, float nnratio, int check_orientation);
+
+/* ---- test hooks -------------------------------------------------------------------------------------- */
+
+/* Runs the quadtree's host/device introsort replica (csrc/orbx_introsort.h) on the host: sorts n 64-bit
+ * elements by their key bits 16..63, payload bits 0..15 ride along.  tests/ compare it with std::sort
+ * (the tie order DistributeOctTree depends on, src/ORBextractor.cc:686). */
+void orbx_debug_introsort(uint64_t* v, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H_ */

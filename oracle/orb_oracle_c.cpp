@@ -1,5 +1,6 @@
 // C-ABI face of the CPU oracle for ctypes (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
 // TEST INFRASTRUCTURE ONLY — see orb_oracle.h.
+#include <algorithm>
 #include <cstring>
 
 #include "orb_oracle.h"
@@ -153,6 +154,12 @@ int oro_features_in_area(const KeyPoint* k, int n, float minX, float minY, float
   std::vector<int> v = g.features_in_area(a, x, y, r, minLevel, maxLevel);
   for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = v[i];
   return (int)v.size();
+}
+
+// libstdc++ std::sort with the (count, UL.x) comparator of compareNodes (src/ORBextractor.cc:542-555) on
+// packed 64-bit elements (key = bits 16..63): the tie order the device quadtree's replica must reproduce.
+void oro_std_sort_keys(uint64_t* v, int n) {
+  std::sort(v, v + n, [](uint64_t a, uint64_t b) { return (a >> 16) < (b >> 16); });
 }
 
 }  // extern "C"

@@ -1,0 +1,258 @@
+"""orb_slam3_fast_amd — MI355X-native ORB front-end (extract + match) behind the reference's API surface.
+
+Host-side mirror (Python, over the C ABI of include/orbx.h) of the reference's
+`ORB_SLAM3::ORBextractor` (include/ORBextractor.h:49-118, src/ORBextractor.cc) and the matching routines
+of `ORB_SLAM3::ORBmatcher` / `Frame` that are on the hot path (src/ORBmatcher.cc:618-764,1920-1973,
+src/Frame.cc:921-1084,1273-1304).  Same names, argument meaning and error behaviour; all compute runs in
+the hand-written HIP kernels of liborbx.so.  There is NO CPU fallback: importing works anywhere, but every
+compute call raises if the library or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28  # cv::KeyPoint
+
+OK, E_EMPTY, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # src/ORBmatcher.cc:35-37
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("orbx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load liborbx.so (built by __graft_entry__.build() / csrc/Makefile).  Fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("liborbx.so not built (%s): run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` — there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.orbx_last_error.restype = C.c_char_p
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.orbx_extractor_create.argtypes = [C.POINTER(_Params), i, i, i, i, C.POINTER(vp)]
+        L.orbx_extractor_destroy.argtypes = [vp]
+        L.orbx_get_tables.argtypes = [vp] + [vp] * 6
+        L.orbx_extract.argtypes = [vp, vp, i, i, C.c_ssize_t, i, i, vp, vp, i, C.POINTER(i)]
+        L.orbx_extract_batch_device.argtypes = [vp, vp, i, i, i, C.c_ssize_t, C.c_ssize_t, vp]
+        L.orbx_sync.argtypes = [vp]
+        L.orbx_batch_results_device.argtypes = [vp] + [C.POINTER(vp)] * 4 + [C.POINTER(i)]
+        L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
+        L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, C.c_ssize_t, C.POINTER(i), C.POINTER(i)]
+        L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
+        L.orbx_hamming256.argtypes = [vp, vp]
+        L.orbx_stereo_match_batch.argtypes = [vp, i, vp, i, i, f, f]
+        L.orbx_stereo_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+        L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
+        L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
+        L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
+        L.orbx_debug_introsort.argtypes = [vp, i]
+        L.orbx_debug_introsort.restype = None
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise OrbxError(rc, lib().orbx_last_error().decode())
+    return rc
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().orbx_device_count()
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:49-118).
+
+    `ex(image, lap)` is operator() (src/ORBextractor.cc:1015-1106): returns (monoIndex, keypoints,
+    descriptors) with keypoints as a structured array laid out like cv::KeyPoint.  An empty image returns
+    (-1, [], []) like the reference.  The batched entry points (`extract_batch_device`) are the
+    many-camera mode: independent images of one size through every kernel in one launch each.
+    """
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_width=1280, max_height=720,
+                 max_batch=1, device=0):
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self.max_batch = max_batch
+        p = _Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+        h = C.c_void_p()
+        _check(lib().orbx_extractor_create(C.byref(p), max_width, max_height, max_batch, device, C.byref(h)))
+        self._h = h
+        L = self.nlevels
+        t = [np.zeros(L, np.float32) for _ in range(4)]
+        self._nfeat = np.zeros(L, np.int32)
+        self._umax = np.zeros(16, np.int32)
+        _check(lib().orbx_get_tables(h, _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(self._nfeat), _p(self._umax)))
+        self._scale, self._inv_scale, self._sigma2, self._inv_sigma2 = t
+        cap = C.c_int()
+        _check(lib().orbx_batch_results_device(h, None, None, None, None, C.byref(cap)))
+        self.capacity = cap.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().orbx_extractor_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- getters, include/ORBextractor.h:65-83
+    def GetLevels(self):
+        return self.nlevels
+
+    def GetScaleFactor(self):
+        return float(self._scale[1]) if self.nlevels > 1 else 1.0
+
+    def GetScaleFactors(self):
+        return self._scale.copy()
+
+    def GetInverseScaleFactors(self):
+        return self._inv_scale.copy()
+
+    def GetScaleSigmaSquares(self):
+        return self._sigma2.copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._inv_sigma2.copy()
+
+    def features_per_level(self):
+        return self._nfeat.copy()
+
+    def umax(self):
+        return self._umax.copy()
+
+    # ---- operator()
+    def __call__(self, image, vLappingArea=(0, 0)):
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 image expected"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int()
+        mono = _check(lib().orbx_extract(self._h, _p(image), w, h, image.strides[0], int(vLappingArea[0]),
+                                         int(vLappingArea[1]), _p(kps), _p(desc), self.capacity, C.byref(n)))
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    # ---- batched many-camera mode
+    def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
+        """Enqueue extraction of device-resident images (raw device pointer).  Asynchronous."""
+        lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(n_images, 2)
+        _check(lib().orbx_extract_batch_device(self._h, C.c_void_p(d_images_ptr), n_images, w, h, row_pitch,
+                                               image_pitch, None if lap_arr is None else _p(lap_arr)))
+
+    def sync(self):
+        _check(lib().orbx_sync(self._h))
+
+    def download(self, image):
+        kps = np.zeros(self.capacity, KP_DTYPE)
+        desc = np.zeros((self.capacity, 32), np.uint8)
+        n = C.c_int()
+        mono = _check(lib().orbx_batch_download(self._h, image, _p(kps), _p(desc), self.capacity, C.byref(n)))
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def results_device(self):
+        """(d_kps, d_desc, d_counts, d_mono, cap) raw device pointers of the last extraction."""
+        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        cap = C.c_int()
+        _check(lib().orbx_batch_results_device(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d),
+                                               C.byref(cap)))
+        return a.value, b.value, c.value, d.value, cap.value
+
+    # ---- mvImagePyramid (include/ORBextractor.h:86)
+    def image_pyramid(self, level, image=0, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().orbx_pyramid_level(self._h, image, level, int(blurred), None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().orbx_pyramid_level(self._h, image, level, int(blurred), _p(out), out.strides[0],
+                                        C.byref(w), C.byref(h)))
+        return out
+
+    def debug_candidates(self, level, image=0):
+        cap = 1 << 20
+        out = np.zeros((cap, 3), np.int32)
+        n = _check(lib().orbx_debug_candidates(self._h, image, level, _p(out), cap))
+        return out[:n].copy()
+
+
+def ComputeStereoMatches(left, right, bf, b, first_left=0, first_right=0, n_pairs=1):
+    """Frame::ComputeStereoMatches (src/Frame.cc:921-1084) on the last extractions of two extractors
+    (or one extractor holding both eyes).  Returns (mvuRight, mvDepth) arrays [n_pairs][capacity]."""
+    _check(lib().orbx_stereo_match_batch(left._h, first_left, right._h, first_right, n_pairs, bf, b))
+    out_u = np.zeros((n_pairs, left.capacity), np.float32)
+    out_d = np.zeros((n_pairs, left.capacity), np.float32)
+    for p in range(n_pairs):
+        _check(lib().orbx_stereo_download(left._h, p, _p(out_u[p]), _p(out_d[p]), left.capacity))
+    return out_u, out_d
+
+
+def stereo_match_async(left, right, bf, b, first_left=0, first_right=0, n_pairs=1):
+    _check(lib().orbx_stereo_match_batch(left._h, first_left, right._h, first_right, n_pairs, bf, b))
+
+
+def bf_knn2(descQ, descT, device=0):
+    """cv::BFMatcher(NORM_HAMMING).knnMatch(Q, T, 2) + Lowe ratio 0.7 of ComputeStereoFishEyeMatches
+    (src/Frame.cc:1293-1302). Returns (idx[nQ,2], dist[nQ,2], ratio_ok[nQ])."""
+    q = np.ascontiguousarray(descQ, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(descT, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    ok = np.zeros(len(q), np.uint8)
+    _check(lib().orbx_bf_knn2(device, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist), _p(ok)))
+    return idx, dist, ok
+
+
+class ORBmatcher:
+    """Mirror of the hot-path part of ORB_SLAM3::ORBmatcher (include/ORBmatcher.h:36-101)."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = TH_HIGH, TH_LOW, HISTO_LENGTH
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.mfNNratio, self.mbCheckOrientation, self.device = float(nnratio), bool(checkOri), device
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(32)
+        return lib().orbx_hamming256(_p(a), _p(b))
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):
+        """src/ORBmatcher.cc:618-764.  kps = mvKeysUn of F1 / F2, bounds2 = (mnMinX, mnMinY, mnMaxX, mnMaxY)
+        of F2.  Returns (nmatches, vnMatches12, updated vbPrevMatched)."""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).reshape(-1, 2).copy()
+        assert len(prev) == len(k1)
+        m12 = np.full(len(k1), -1, np.int32)
+        n = _check(lib().orbx_search_for_initialization(
+            self.device, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), bounds2[0], bounds2[1], bounds2[2],
+            bounds2[3], _p(prev), _p(m12), int(windowSize), self.mfNNratio, int(self.mbCheckOrientation)))
+        return n, m12, prev

@@ -1,0 +1,665 @@
+// orbx_api.hip — C ABI of liborbx (include/orbx.h): handles, buffers, geometry, launch sequencing.
+// Host-side restatement of the ORBextractor constructor tables (src/ORBextractor.cc:408-469) and of the
+// OpenCV resize coefficient tables; all pixel/bit work is in orbx_kernels.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "orbx_internal.h"
+
+using namespace orbx;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPC(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(ORBX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(float v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(float v) {
+  int i = cv_round(v);
+  return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+inline int align_up(long long v, int a) { return (int)((v + a - 1) / a * a); }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    free();
+    n = count;
+    if (!count) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct orbx_extractor {
+  orbx_params prm{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int maxW = 0, maxH = 0, maxB = 0;
+  std::vector<float> scale, inv, sig2, invsig2;
+  std::vector<int> nfeat;
+  int umax[16];
+  Geom g{};
+  Geom gmax{};
+  int curW = 0, curH = 0;
+  Pyr pyr{};
+  int lastN = 0;
+  DevBuf<uint8_t> d_pyr, d_blur, d_stage, d_desc;
+  DevBuf<uint32_t> d_cand, d_sel;
+  DevBuf<uint16_t> d_knode;
+  DevBuf<int> d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
+  DevBuf<short> d_xab, d_yab;
+  DevBuf<orbx_keypoint> d_kps;
+  DevBuf<float> d_uR, d_depth;
+  int stagePitch = 0;
+  int stereoPairs = 0;
+};
+
+namespace {
+
+// ---- tables: ORBextractor::ORBextractor, src/ORBextractor.cc:408-469 --------------------------------
+void build_tables(orbx_extractor* ex) {
+  const int L = ex->prm.nlevels;
+  const double sf = (double)ex->prm.scale_factor;  // member is double, argument float (:106 of the header)
+  ex->scale.assign(L, 1.f);
+  ex->sig2.assign(L, 1.f);
+  for (int i = 1; i < L; i++) {
+    ex->scale[i] = (float)(ex->scale[i - 1] * sf);
+    ex->sig2[i] = ex->scale[i] * ex->scale[i];
+  }
+  ex->inv.resize(L);
+  ex->invsig2.resize(L);
+  for (int i = 0; i < L; i++) {
+    ex->inv[i] = 1.0f / ex->scale[i];
+    ex->invsig2[i] = 1.0f / ex->sig2[i];
+  }
+  ex->nfeat.assign(L, 0);
+  const float factor = (float)(1.0f / sf);
+  float nDesired = ex->prm.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+  int sum = 0;
+  for (int l = 0; l < L - 1; l++) {
+    ex->nfeat[l] = cv_round(nDesired);
+    sum += ex->nfeat[l];
+    nDesired *= factor;
+  }
+  ex->nfeat[L - 1] = std::max(ex->prm.nfeatures - sum, 0);
+  int um[16] = {0};
+  const float s2 = std::sqrt(2.f);
+  const int vmax = cv_floor(kHalfPatch * s2 / 2 + 1), vmin = cv_ceil(kHalfPatch * s2 / 2);
+  const double hp2 = kHalfPatch * kHalfPatch;
+  for (int v = 0; v <= vmax; ++v) um[v] = cv_round(std::sqrt(hp2 - v * v));
+  for (int v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+    while (um[v0] == um[v0 + 1]) ++v0;
+    um[v] = v0;
+    ++v0;
+  }
+  std::memcpy(ex->umax, um, sizeof(um));
+}
+
+// ---- geometry for one image size (pyramid sizes :1111-1113, cell grid :901-907) ----------------------
+int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why) {
+  std::memset(&g, 0, sizeof(g));
+  const int L = ex->prm.nlevels;
+  g.nlevels = L;
+  g.iniTh = ex->prm.ini_th_fast;
+  g.minTh = ex->prm.min_th_fast;
+  long long off = 0, candOff = 0;
+  int cells = 0, sel = 0, xc = 0, yc = 0;
+  int maxCW = 0, maxCH = 0;
+  for (int l = 0; l < L; l++) {
+    LevelDev& v = g.lv[l];
+    v.w = cv_round((float)w * ex->inv[l]);
+    v.h = cv_round((float)h * ex->inv[l]);
+    v.pitch = align_up(v.w, 64);
+    v.off = off;
+    off += (long long)v.pitch * v.h;
+    off = (off + 255) / 256 * 256;
+    const int maxBX = v.w - kBorder, maxBY = v.h - kBorder;
+    const float width = (float)(maxBX - kBorder), height = (float)(maxBY - kBorder);
+    if (width < 35.f || height < 35.f) {
+      why = "level " + std::to_string(l) + " is smaller than one 35 px FAST cell (+32 px border)";
+      return ORBX_E_UNSUPPORTED;
+    }
+    v.nCols = (int)(width / 35.f);
+    v.nRows = (int)(height / 35.f);
+    v.wCell = (int)std::ceil(width / v.nCols);
+    v.hCell = (int)std::ceil(height / v.nRows);
+    v.cellStart = cells;
+    cells += v.nCols * v.nRows;
+    v.quota = ex->nfeat[l];
+    const int nIni = (int)std::round(width / height);
+    if (nIni < 1 || nIni > kMaxIni) {
+      why = "unsupported aspect ratio at level " + std::to_string(l);
+      return ORBX_E_UNSUPPORTED;
+    }
+    v.candCap = (((int)width + v.nCols + 1) / 2 + 1) * (((int)height + v.nRows + 1) / 2 + 1);
+    v.candOff = candOff;
+    candOff += v.candCap;
+    v.selOff = sel;
+    v.selCap = v.quota + 4 * nIni + 4;
+    sel += v.selCap;
+    v.xcoef = xc;
+    v.ycoef = yc;
+    xc += v.w;
+    yc += v.h;
+    v.scale = ex->scale[l];
+    v.patch = (float)(int)(31 * ex->scale[l]);
+    maxCW = std::max(maxCW, v.wCell);
+    maxCH = std::max(maxCH, v.hCell);
+    if (v.w - 2 * kBorder > 4095 || v.h - 2 * kBorder > 4095) {
+      why = "image larger than 4127 px is not supported by the 12-bit key packing";
+      return ORBX_E_UNSUPPORTED;
+    }
+  }
+  if (maxCW > 250 || maxCH > 120) {
+    why = "FAST cell too large for the packed corner list";
+    return ORBX_E_UNSUPPORTED;
+  }
+  g.totalCells = cells;
+  g.tileP = align_up(maxCW + 6 + 3, 4);
+  g.tileH = maxCH + 6;
+  g.scoreP = align_up(maxCW + 2, 4);
+  g.scoreH = maxCH + 2;
+  g.listCap = align_up((long long)maxCW * maxCH, 8);
+  g.selImg = sel;
+  g.outCap = sel;
+  g.pyrImg = off;
+  g.candImg = candOff;
+  if (octree_lds_bytes(g) > 160 * 1024 - 2048) {
+    why = "nfeatures too large for the LDS-resident quadtree";
+    return ORBX_E_UNSUPPORTED;
+  }
+  return ORBX_OK;
+}
+
+// ---- resize coefficient tables, cv::resize INTER_LINEAR 8U -------------------------------
+void build_coefs(const Geom& g, std::vector<int>& xofs, std::vector<short>& xab, std::vector<int>& yofs,
+                 std::vector<short>& yab) {
+  int nx = 0, ny = 0;
+  for (int l = 0; l < g.nlevels; l++) {
+    nx += g.lv[l].w;
+    ny += g.lv[l].h;
+  }
+  xofs.assign(nx, 0);
+  xab.assign(2 * nx, 0);
+  yofs.assign(ny, 0);
+  yab.assign(2 * ny, 0);
+  for (int l = 1; l < g.nlevels; l++) {
+    const LevelDev &D = g.lv[l], &S = g.lv[l - 1];
+    const double scale_x = 1.0 / ((double)D.w / S.w), scale_y = 1.0 / ((double)D.h / S.h);
+    for (int dx = 0; dx < D.w; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = cv_floor(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
+      xofs[D.xcoef + dx] = sx;
+      xab[2 * (D.xcoef + dx)] = sat_short((1.f - fx) * 2048.f);
+      xab[2 * (D.xcoef + dx) + 1] = sat_short(fx * 2048.f);
+    }
+    for (int dy = 0; dy < D.h; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = cv_floor(fy);
+      fy -= sy;
+      yofs[D.ycoef + dy] = sy;
+      yab[2 * (D.ycoef + dy)] = sat_short((1.f - fy) * 2048.f);
+      yab[2 * (D.ycoef + dy) + 1] = sat_short(fy * 2048.f);
+    }
+  }
+}
+
+int configure(orbx_extractor* ex, int w, int h) {
+  if (w == ex->curW && h == ex->curH) return ORBX_OK;
+  Geom g;
+  std::string why;
+  int rc = build_geom(ex, w, h, g, why);
+  if (rc != ORBX_OK) return fail(rc, why);
+  const Geom& m = ex->gmax;
+  if (g.pyrImg > m.pyrImg || g.candImg > m.candImg || g.selImg > m.selImg)
+    return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
+  g.outCap = m.outCap;  // keep result strides fixed for the life of the handle
+  g.selImg = m.selImg;
+  g.pyrImg = m.pyrImg;
+  g.candImg = m.candImg;
+  std::vector<int> xofs, yofs;
+  std::vector<short> xab, yab;
+  build_coefs(g, xofs, xab, yofs, yab);
+  HIPC(hipStreamSynchronize(ex->stream));
+  HIPC(hipMemcpy(ex->d_xofs.p, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ex->d_xab.p, xab.data(), xab.size() * sizeof(short), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ex->d_yofs.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ex->d_yab.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
+  HIPC(prepare_kernels(g));
+  ex->g = g;
+  ex->curW = w;
+  ex->curH = h;
+  return ORBX_OK;
+}
+
+int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
+                    ptrdiff_t image_pitch, const int32_t* lap) {
+  int rc = configure(ex, w, h);
+  if (rc != ORBX_OK) return rc;
+  const Geom& g = ex->g;
+  ex->pyr.l0 = d_images;
+  ex->pyr.l0Row = row_pitch;
+  ex->pyr.l0Img = image_pitch;
+  ex->pyr.pyr = ex->d_pyr.p;
+  ex->pyr.blur = ex->d_blur.p;
+  ex->lastN = n;
+  hipStream_t s = ex->stream;
+  HIPC(hipMemsetAsync(ex->d_candCount.p, 0, (size_t)n * g.nlevels * sizeof(int), s));
+  if (lap)
+    HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+  else
+    HIPC(hipMemsetAsync(ex->d_lap.p, 0, (size_t)n * 2 * sizeof(int), s));
+  for (int l = 1; l < g.nlevels; l++)
+    HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, s));
+  HIPC(launch_detect(g, ex->pyr, n, ex->d_cand.p, ex->d_candCount.p, s));
+  HIPC(launch_octree(g, n, ex->d_cand.p, ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
+  HIPC(launch_blur(g, ex->pyr, n, s));
+  HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
+  HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, ex->d_slot.p, ex->d_kps.p, ex->d_desc.p, s));
+  return ORBX_OK;
+}
+
+int set_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ORBX_E_NODEVICE, "no HIP device available");
+  if (device < 0 || device >= n) return fail(ORBX_E_BADARG, "device index out of range");
+  HIPC(hipSetDevice(device));
+  return ORBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* orbx_last_error(void) { return g_err.c_str(); }
+int orbx_abi_version(void) { return 1; }
+int orbx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, int max_batch, int device,
+                          orbx_extractor** out) {
+  if (!p || !out) return fail(ORBX_E_BADARG, "null argument");
+  *out = nullptr;
+  if (p->nlevels < 1 || p->nlevels > ORBX_MAX_LEVELS || p->nfeatures < 1 || !(p->scale_factor > 1.0f) ||
+      p->ini_th_fast < p->min_th_fast || p->min_th_fast < 1 || p->ini_th_fast > 254 || max_batch < 1 ||
+      max_width < 1 || max_height < 1)
+    return fail(ORBX_E_BADARG, "invalid extractor parameters");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  orbx_extractor* ex = new orbx_extractor();
+  ex->prm = *p;
+  ex->device = device;
+  ex->maxW = max_width;
+  ex->maxH = max_height;
+  ex->maxB = max_batch;
+  build_tables(ex);
+  std::string why;
+  rc = build_geom(ex, max_width, max_height, ex->gmax, why);
+  if (rc != ORBX_OK) {
+    delete ex;
+    return fail(rc, why);
+  }
+  const Geom& m = ex->gmax;
+  const size_t B = (size_t)max_batch;
+  ex->stagePitch = align_up(max_width, 64);
+  int nx = 0, ny = 0;
+  for (int l = 0; l < m.nlevels; l++) {
+    nx += m.lv[l].w;
+    ny += m.lv[l].h;
+  }
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) {
+    if (e == hipSuccess) e = r;
+  };
+  ok(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
+  ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
+  ok(ex->d_pyr.alloc(B * m.pyrImg + 256));
+  ok(ex->d_blur.alloc(B * m.pyrImg + 256));
+  ok(ex->d_stage.alloc(B * (size_t)ex->stagePitch * max_height + 256));
+  ok(ex->d_cand.alloc(B * m.candImg));
+  ok(ex->d_knode.alloc(B * m.candImg));
+  ok(ex->d_candCount.alloc(B * m.nlevels));
+  ok(ex->d_sel.alloc(B * m.selImg));
+  ok(ex->d_selCount.alloc(B * m.nlevels));
+  ok(ex->d_slot.alloc(B * m.selImg));
+  ok(ex->d_kps.alloc(B * m.outCap));
+  ok(ex->d_desc.alloc(B * m.outCap * 32));
+  ok(ex->d_nOut.alloc(B));
+  ok(ex->d_mono.alloc(B));
+  ok(ex->d_lap.alloc(B * 2));
+  ok(ex->d_xofs.alloc(nx + 64));
+  ok(ex->d_xab.alloc(2 * nx + 64));
+  ok(ex->d_yofs.alloc(ny + 64));
+  ok(ex->d_yab.alloc(2 * ny + 64));
+  if (e != hipSuccess) {
+    std::string msg = std::string("allocation failed: ") + hipGetErrorString(e);
+    orbx_extractor_destroy(ex);
+    return fail(ORBX_E_HIP, msg);
+  }
+  *out = ex;
+  return ORBX_OK;
+}
+
+void orbx_extractor_destroy(orbx_extractor* ex) {
+  if (!ex) return;
+  (void)hipSetDevice(ex->device);
+  if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+  ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free();
+  ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
+  ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_xofs.free(); ex->d_yofs.free();
+  ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free();
+  if (ex->done) (void)hipEventDestroy(ex->done);
+  if (ex->stream) (void)hipStreamDestroy(ex->stream);
+  delete ex;
+}
+
+int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* nfeatures_per_level, int32_t* umax16) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  const int L = ex->prm.nlevels;
+  if (scale) std::memcpy(scale, ex->scale.data(), L * sizeof(float));
+  if (inv_scale) std::memcpy(inv_scale, ex->inv.data(), L * sizeof(float));
+  if (sigma2) std::memcpy(sigma2, ex->sig2.data(), L * sizeof(float));
+  if (inv_sigma2) std::memcpy(inv_sigma2, ex->invsig2.data(), L * sizeof(float));
+  if (nfeatures_per_level) std::memcpy(nfeatures_per_level, ex->nfeat.data(), L * sizeof(int));
+  if (umax16) std::memcpy(umax16, ex->umax, sizeof(ex->umax));
+  return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_images, int w, int h,
+                              ptrdiff_t row_pitch, ptrdiff_t image_pitch, const int32_t* lap) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (!d_images || n_images <= 0 || w <= 0 || h <= 0) return fail(ORBX_E_EMPTY, "empty image");
+  if (n_images > ex->maxB) return fail(ORBX_E_CAPACITY, "batch larger than max_batch");
+  if (row_pitch < w || ((uintptr_t)d_images & 3) || (row_pitch & 3) || (image_pitch & 3))
+    return fail(ORBX_E_BADARG, "images must be 4-byte aligned with 4-byte aligned pitches >= width");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  return enqueue_extract(ex, d_images, n_images, w, h, row_pitch, image_pitch, lap);
+}
+
+int orbx_sync(orbx_extractor* ex) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  return ORBX_OK;
+}
+
+int orbx_batch_results_device(const orbx_extractor* ex, const orbx_keypoint** d_kps, const uint8_t** d_desc,
+                              const int32_t** d_counts, const int32_t** d_mono, int* cap) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (d_kps) *d_kps = ex->d_kps.p;
+  if (d_desc) *d_desc = ex->d_desc.p;
+  if (d_counts) *d_counts = ex->d_nOut.p;
+  if (d_mono) *d_mono = ex->d_mono.p;
+  if (cap) *cap = ex->gmax.outCap;
+  return ORBX_OK;
+}
+
+int orbx_batch_download(orbx_extractor* ex, int image, orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+  if (!ex || !n_out) return fail(ORBX_E_BADARG, "null argument");
+  if (image < 0 || image >= ex->lastN) return fail(ORBX_E_BADARG, "image index out of range");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  int n = 0, mono = 0;
+  HIPC(hipMemcpy(&n, ex->d_nOut.p + image, sizeof(int), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(&mono, ex->d_mono.p + image, sizeof(int), hipMemcpyDeviceToHost));
+  *n_out = n;
+  if (n > cap) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
+  const size_t oc = (size_t)ex->gmax.outCap;
+  if (n > 0 && kps) HIPC(hipMemcpy(kps, ex->d_kps.p + image * oc, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+  if (n > 0 && desc) HIPC(hipMemcpy(desc, ex->d_desc.p + image * oc * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+  return mono;
+}
+
+int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                 orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (n_out) *n_out = 0;
+  if (!img || w <= 0 || h <= 0) return fail(ORBX_E_EMPTY, "empty image");  // :1021
+  if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's maximum");
+  if (stride < w) return fail(ORBX_E_BADARG, "stride < width");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int pitch = align_up(w, 64);
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img, stride, w, h, hipMemcpyHostToDevice, ex->stream));
+  const int32_t lap[2] = {lap0, lap1};
+  rc = enqueue_extract(ex, ex->d_stage.p, 1, w, h, pitch, (ptrdiff_t)pitch * h, lap);
+  if (rc != ORBX_OK) return rc;
+  return orbx_batch_download(ex, 0, kps, desc, cap, n_out);
+}
+
+int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, uint8_t* dst, ptrdiff_t dst_stride,
+                       int* w, int* h) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (ex->curW == 0 || image < 0 || image >= ex->lastN || level < 0 || level >= ex->g.nlevels)
+    return fail(ORBX_E_BADARG, "no such pyramid level");
+  const LevelDev& L = ex->g.lv[level];
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  if (!dst) return ORBX_OK;
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  const uint8_t* src;
+  size_t pitch;
+  if (blurred) {
+    src = ex->pyr.blur + (long long)image * ex->g.pyrImg + L.off;
+    pitch = L.pitch;
+  } else {
+    int p;
+    src = level_ptr(ex->g, ex->pyr, image, level, p);
+    pitch = p;
+  }
+  HIPC(hipMemcpy2D(dst, dst_stride, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_debug_candidates(orbx_extractor* ex, int image, int level, int32_t* xys, int cap) {
+  if (!ex || image < 0 || image >= ex->lastN || level < 0 || level >= ex->g.nlevels)
+    return fail(ORBX_E_BADARG, "bad argument");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  int n = 0;
+  HIPC(hipMemcpy(&n, ex->d_candCount.p + image * ex->g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+  const LevelDev& L = ex->g.lv[level];
+  if (n > L.candCap) n = L.candCap;
+  std::vector<uint32_t> v(n);
+  if (n)
+    HIPC(hipMemcpy(v.data(), ex->d_cand.p + (long long)image * ex->g.candImg + L.candOff, (size_t)n * 4,
+                   hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap; i++) {
+    xys[3 * i] = key_x(v[i]);
+    xys[3 * i + 1] = key_y(v[i]);
+    xys[3 * i + 2] = key_r(v[i]);
+  }
+  return n;
+}
+
+int orbx_hamming256(const void* a, const void* b) {
+  const uint32_t* x = (const uint32_t*)a;
+  const uint32_t* y = (const uint32_t*)b;
+  int d = 0;
+  for (int i = 0; i < 8; i++) d += __builtin_popcount(x[i] ^ y[i]);
+  return d;
+}
+
+int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                            int n_pairs, float bf, float b) {
+  if (!left || !right) return fail(ORBX_E_BADARG, "null handle");
+  if (n_pairs <= 0 || first_left < 0 || first_right < 0 || first_left + n_pairs > left->lastN ||
+      first_right + n_pairs > right->lastN)
+    return fail(ORBX_E_BADARG, "pair range outside the last extraction");
+  if (left->device != right->device || left->curW != right->curW || left->curH != right->curH ||
+      std::memcmp(&left->prm, &right->prm, sizeof(orbx_params)) != 0)
+    return fail(ORBX_E_BADARG, "left and right extractors must share device, image size and parameters");
+  if (!(b > 0.f)) return fail(ORBX_E_BADARG, "baseline must be positive");
+  HIPC(hipSetDevice(left->device));
+  const size_t capL = (size_t)left->gmax.outCap;
+  if (left->stereoPairs < n_pairs) {
+    HIPC(hipStreamSynchronize(left->stream));
+    HIPC(left->d_uR.alloc((size_t)n_pairs * capL));
+    HIPC(left->d_depth.alloc((size_t)n_pairs * capL));
+    HIPC(left->d_sad.alloc((size_t)n_pairs * capL));
+    left->stereoPairs = n_pairs;
+  }
+  if (right != left) {  // order left's stream after right's extraction
+    HIPC(hipEventRecord(right->done, right->stream));
+    HIPC(hipStreamWaitEvent(left->stream, right->done, 0));
+  }
+  StereoArgs a;
+  a.kL = left->d_kps.p;
+  a.kR = right->d_kps.p;
+  a.dL = left->d_desc.p;
+  a.dR = right->d_desc.p;
+  a.nL = left->d_nOut.p;
+  a.nR = right->d_nOut.p;
+  a.capL = (int)capL;
+  a.capR = right->gmax.outCap;
+  a.firstL = first_left;
+  a.firstR = first_right;
+  a.bf = bf;
+  a.b = b;
+  a.uRight = left->d_uR.p;
+  a.depth = left->d_depth.p;
+  a.sad = left->d_sad.p;
+  HIPC(launch_stereo(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));
+  return ORBX_OK;
+}
+
+int orbx_stereo_results_device(const orbx_extractor* left, const float** d_uright, const float** d_depth) {
+  if (!left) return fail(ORBX_E_BADARG, "null handle");
+  if (d_uright) *d_uright = left->d_uR.p;
+  if (d_depth) *d_depth = left->d_depth.p;
+  return ORBX_OK;
+}
+
+int orbx_stereo_download(orbx_extractor* left, int pair, float* uright, float* depth, int cap) {
+  if (!left || pair < 0 || pair >= left->stereoPairs) return fail(ORBX_E_BADARG, "bad pair index");
+  HIPC(hipSetDevice(left->device));
+  HIPC(hipStreamSynchronize(left->stream));
+  const size_t capL = (size_t)left->gmax.outCap;
+  const size_t n = std::min((size_t)cap, capL);
+  if (uright) HIPC(hipMemcpy(uright, left->d_uR.p + pair * capL, n * sizeof(float), hipMemcpyDeviceToHost));
+  if (depth) HIPC(hipMemcpy(depth, left->d_depth.p + pair * capL, n * sizeof(float), hipMemcpyDeviceToHost));
+  return ORBX_OK;
+}
+
+int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx2,
+                 int32_t* dist2, uint8_t* ratio_ok) {
+  if (nQ < 0 || nT < 0 || (nQ && (!descQ || !idx2 || !dist2 || !ratio_ok)) || (nT && !descT))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (nQ == 0) return ORBX_OK;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  DevBuf<uint8_t> q, t, ok;
+  DevBuf<int> i2, d2;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  chk(q.alloc((size_t)nQ * 32));
+  chk(t.alloc((size_t)std::max(nT, 1) * 32));
+  chk(ok.alloc(nQ));
+  chk(i2.alloc((size_t)nQ * 2));
+  chk(d2.alloc((size_t)nQ * 2));
+  if (e == hipSuccess) chk(hipMemcpy(q.p, descQ, (size_t)nQ * 32, hipMemcpyHostToDevice));
+  if (e == hipSuccess && nT) chk(hipMemcpy(t.p, descT, (size_t)nT * 32, hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(launch_bf_knn2(q.p, nQ, t.p, nT, i2.p, d2.p, ok.p, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy(idx2, i2.p, (size_t)nQ * 2 * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(dist2, d2.p, (size_t)nQ * 2 * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(ratio_ok, ok.p, nQ, hipMemcpyDeviceToHost));
+  q.free(); t.free(); ok.free(); i2.free(); d2.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
+int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                   const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
+                                   float min_y, float max_x, float max_y, float* prev_matched,
+                                   int32_t* matches12, int window_size, float nnratio, int check_orientation) {
+  if (n1 < 0 || n2 < 0 || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kps2 || !desc2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n1 == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  DevBuf<orbx_keypoint> k1, k2;
+  DevBuf<uint8_t> d1, d2;
+  DevBuf<float> prev;
+  DevBuf<int> m12, cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, result;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  chk(k1.alloc(n1)); chk(k2.alloc(std::max(n2, 1))); chk(d1.alloc((size_t)n1 * 32));
+  chk(d2.alloc((size_t)std::max(n2, 1) * 32)); chk(prev.alloc((size_t)n1 * 2)); chk(m12.alloc(n1));
+  chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(std::max(n2, 1))); chk(candOff.alloc(n1 + 1));
+  chk(mdist.alloc(std::max(n2, 1))); chk(m21.alloc(std::max(n2, 1))); chk(result.alloc(2));
+  if (e == hipSuccess) chk(hipMemcpy(k1.p, kps1, (size_t)n1 * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+  if (e == hipSuccess && n2) chk(hipMemcpy(k2.p, kps2, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
+  if (e == hipSuccess && n2) chk(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(prev.p, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+  InitArgs a{};
+  a.k1 = k1.p; a.k2 = k2.p; a.d1 = d1.p; a.d2 = d2.p; a.n1 = n1; a.n2 = n2;
+  a.minX = min_x; a.minY = min_y;
+  a.invW = 64.f / (max_x - min_x);  // mfGridElementWidthInv, src/Frame.cc:243
+  a.invH = 48.f / (max_y - min_y);
+  a.prev = prev.p; a.matches12 = m12.p; a.window = window_size; a.nnratio = nnratio;
+  a.checkOri = check_orientation;
+  a.cellStart = cellStart.p; a.cellItems = cellItems.p; a.candOff = candOff.p;
+  a.matchedDist = mdist.p; a.matches21 = m21.p; a.result = result.p;
+  a.candCap = 1 << 30;
+  int total = 0, res[2] = {0, 0};
+  if (e == hipSuccess) chk(launch_search_init(a, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy(&total, candOff.p + n1, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) {
+    chk(candIdx.alloc((size_t)std::max(total, 1)));
+    chk(candDist.alloc((size_t)std::max(total, 1)));
+    a.candIdx = candIdx.p;
+    a.candDist = candDist.p;
+    a.candCap = std::max(total, 1);
+  }
+  if (e == hipSuccess) chk(launch_search_init_fill(a, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(matches12, m12.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(prev_matched, prev.p, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
+  k1.free(); k2.free(); d1.free(); d2.free(); prev.free(); m12.free(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); result.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return res[0];
+}
+
+// Test hook: the device quadtree's introsort replica, run on the host (compared with std::sort in tests).
+void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
+
+}  // extern "C"

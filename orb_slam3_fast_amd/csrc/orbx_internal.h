@@ -1,0 +1,123 @@
+// orbx_internal.h — shared host/device structures of liborbx (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+
+namespace orbx {
+
+constexpr int kEdge = 19;        // EDGE_THRESHOLD, src/ORBextractor.cc:73
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE, :72
+constexpr int kBorder = 16;      // EDGE_THRESHOLD - 3: origin of the FAST window, :893
+constexpr int kMaxIni = 8;       // max initial quadtree roots supported (aspect <= 8.49)
+
+// Per pyramid level geometry (derived on the host for the current (w, h), passed to kernels by value).
+struct LevelDev {
+  int w, h, pitch;               // pitch of the internal buffers (level 0 input uses Pyr::l0RowPitch)
+  int nCols, nRows, wCell, hCell;  // FAST cell grid, src/ORBextractor.cc:904-907
+  int cellStart;                 // number of cells in coarser-indexed levels before this one
+  int quota;                     // mnFeaturesPerLevel[l]
+  int candCap;                   // capacity of the candidate list of this level (per image)
+  int selOff, selCap;            // slot range of this level in the per-image selected-keypoint block
+  int xcoef, ycoef;              // offsets into the resize coefficient tables (level l from l-1)
+  long long off;                 // byte offset of the level inside one image's pyramid block
+  long long candOff;             // entry offset of the candidate list inside one image's block
+  float scale;                   // mvScaleFactor[l]
+  float patch;                   // (float)(int)(31 * scale), :984
+};
+
+struct Geom {
+  int nlevels, totalCells, iniTh, minTh;
+  int tileP, tileH;              // LDS image-tile pitch / rows of the detect kernel
+  int scoreP, scoreH;            // LDS score-tile pitch / rows
+  int listCap;                   // max pixels in one cell's detectable window
+  int selImg;                    // selected-keypoint slots per image (sum of selCap)
+  int outCap;                    // output keypoint capacity per image
+  int pad_;
+  long long pyrImg;              // bytes per image of the internal pyramid block
+  long long candImg;             // candidate entries per image
+  LevelDev lv[ORBX_MAX_LEVELS];
+};
+
+// Where the pyramid of the current batch lives.  Level 0 aliases the caller's images.
+struct Pyr {
+  const uint8_t* l0;
+  long long l0Row, l0Img;
+  uint8_t* pyr;                  // levels >= 1 (and an unused level-0 slot) : [B][pyrImg]
+  uint8_t* blur;                 // blurred copies of all levels: [B][pyrImg]
+};
+
+__host__ __device__ inline const uint8_t* level_ptr(const Geom& g, const Pyr& p, int img, int l, int& pitch) {
+  if (l == 0) {
+    pitch = (int)p.l0Row;
+    return p.l0 + (long long)img * p.l0Img;
+  }
+  pitch = g.lv[l].pitch;
+  return p.pyr + (long long)img * g.pyrImg + g.lv[l].off;
+}
+
+// Candidate / selected keypoint packing: x (12 bits) | y (12 bits) << 12 | response << 24.
+// Candidates: x, y relative to the (16,16) FAST window origin.  Selected: level coordinates.
+__host__ __device__ inline uint32_t pack_key(int x, int y, int r) {
+  return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)r << 24);
+}
+__host__ __device__ inline int key_x(uint32_t k) { return k & 0xFFF; }
+__host__ __device__ inline int key_y(uint32_t k) { return (k >> 12) & 0xFFF; }
+__host__ __device__ inline int key_r(uint32_t k) { return k >> 24; }
+
+// Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
+                         const int* yofs, const short* yab, hipStream_t s);
+hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cand, int* candCount, hipStream_t s);
+hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cand, const int* candCount, uint16_t* knode,
+                         uint32_t* sel, int* selCount, hipStream_t s);
+hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, hipStream_t s);
+hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int* selCount, const int* lap,
+                        int* slot, int* nOut, int* mono, hipStream_t s);
+hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
+                           const int* slot, orbx_keypoint* kps, uint8_t* desc, hipStream_t s);
+size_t octree_lds_bytes(const Geom& g);
+
+struct StereoArgs {
+  const orbx_keypoint *kL, *kR;
+  const uint8_t *dL, *dR;
+  const int *nL, *nR;            // per image counts
+  int capL, capR;                // per-image strides (entries)
+  int firstL, firstR;
+  float bf, b;
+  float* uRight;                 // [pairs][capL]
+  float* depth;
+  int* sad;                      // [pairs][capL] best SAD or -1
+};
+hipError_t launch_stereo(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
+                         hipStream_t s);
+hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
+                          uint8_t* ok, hipStream_t s);
+struct InitArgs {
+  const orbx_keypoint *k1, *k2;
+  const uint8_t *d1, *d2;
+  int n1, n2;
+  float minX, minY, invW, invH;
+  float* prev;                   // 2*n1
+  int* matches12;                // n1
+  int window;
+  float nnratio;
+  int checkOri;
+  // scratch
+  int* cellStart;                // 64*48+1
+  int* cellItems;                // n2
+  int* candOff;                  // n1+1
+  int* candIdx;                  // candidate i2 lists
+  int* candDist;
+  int candCap;
+  int* matchedDist;              // n2
+  int* matches21;                // n2
+  int* result;                   // [0]=nmatches, [1]=overflow flag
+};
+hipError_t launch_search_init(const InitArgs& a, hipStream_t s);       // grid + candidate counts + scan
+hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s);  // candidate fill + serial resolve
+hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
+void debug_introsort_host(uint64_t* v, int n);
+
+}  // namespace orbx

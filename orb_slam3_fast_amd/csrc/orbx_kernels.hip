@@ -1,0 +1,1417 @@
+// orbx_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the ORB front-end.
+//
+// One kernel per stage of ORBextractor::operator() (src/ORBextractor.cc:1015-1106 of the reference); every
+// kernel covers all images of the batch (and all pyramid levels where the stage allows) in one launch:
+//   k_resize    ComputePyramid               :1108-1145  (cv::resize INTER_LINEAR 8U)
+//   k_detect    per-cell cv::FAST + NMS + ini/min threshold fallback :892-971, one wave per cell
+//   k_octree    DistributeOctTree            :557-757    one workgroup per (image, level), node tables in LDS
+//   k_blur      GaussianBlur 7x7 sigma 2     :1074-1076  
+//   k_slots     mono/lapping slot assignment :1062-1099  (serial-order semantics)
+//   k_describe  IC_Angle + computeOrbDescriptor + output :75-147, one wave per keypoint, ballot-packed bits
+// and of the matchers:
+//   k_stereo*   Frame::ComputeStereoMatches  src/Frame.cc:921-1084
+//   k_bf_knn2   BFMatcher::knnMatch(k=2)     src/Frame.cc:1293-1302
+//   k_init_*    ORBmatcher::SearchForInitialization src/ORBmatcher.cc:618-764
+//
+// Integer/bitwise work: no MFMA.  Float steps that decide bits (fastAtan2, the rotated sampling
+// coordinates, sub-pixel disparity) use IEEE ops without contraction (-ffp-contract=off for this TU) and
+// round-half-even conversions, mirroring the x86-64 baseline (no FMA) build of the reference.
+#include "orbx_internal.h"
+#include "orbx_introsort.h"
+
+namespace orbx {
+
+__constant__ int8_t c_pattern[1024] = {
+#include "orb_pattern31.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ int rne_f(float v) { return __float2int_rn(v); }  // cvRound
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// ================================================================================================ resize
+// 4 destination pixels per thread, one u32 store.  Coefficient tables (sx, a0/a1 ; sy, b0/b1) are built on
+// the host exactly as OpenCV builds them and uploaded once per image size.
+__global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int* __restrict__ xofs,
+                                                const short* __restrict__ xab, const int* __restrict__ yofs,
+                                                const short* __restrict__ yab) {
+  const LevelDev D = g.lv[l];
+  const LevelDev S = g.lv[l - 1];
+  const int img = blockIdx.z;
+  const int gx = blockIdx.x * 64 + threadIdx.x;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  if (dy >= D.h || gx * 4 >= D.w) return;
+  int sp;
+  const uint8_t* src = level_ptr(g, p, img, l - 1, sp);
+  uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
+  const int sy = yofs[D.ycoef + dy];
+  const int b0 = yab[2 * (D.ycoef + dy)], b1 = yab[2 * (D.ycoef + dy) + 1];
+  const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+  const uint8_t* r0 = src + (long long)sy0 * sp;
+  const uint8_t* r1 = src + (long long)sy1 * sp;
+  uint32_t outw = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int dx = min(gx * 4 + j, D.w - 1);
+    const int sx = xofs[D.xcoef + dx];
+    const int a0 = xab[2 * (D.xcoef + dx)], a1 = xab[2 * (D.xcoef + dx) + 1];
+    const int sx1 = min(sx + 1, S.w - 1);
+    const int t0 = r0[sx] * a0 + r0[sx1] * a1;
+    const int t1 = r1[sx] * a0 + r1[sx1] * a1;
+    const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+    outw |= (uint32_t)(v & 255) << (8 * j);
+  }
+  *reinterpret_cast<uint32_t*>(dst + gx * 4) = outw;
+}
+
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
+                         const int* yofs, const short* yab, hipStream_t s) {
+  const LevelDev& D = g.lv[level];
+  dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 3) / 4, nimg);
+  hipLaunchKernelGGL(k_resize, grid, block, 0, s, g, p, level, xofs, xab, yofs, yab);
+  return hipGetLastError();
+}
+
+// ================================================================================================ detect
+// FAST-9-16 helpers on an LDS tile with row pitch TP.  Ring order = OpenCV's.
+#define ORBX_RING(F)                                                                                       \
+  F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)   \
+  F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+
+__device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
+  uint32_t d = m | (m << 16);
+  uint32_t x = d & (d >> 1);
+  x &= x >> 2;
+  x &= x >> 4;
+  x &= d >> 8;
+  return (x & 0xFFFFu) != 0;
+}
+
+__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int TP, int t) {
+  const int v = c[0];
+  const int hi = v + t, lo = v - t;
+  uint32_t br = 0, dk = 0;
+#define F(k, dx, dy)                 \
+  {                                  \
+    const int r = c[(dy)*TP + (dx)]; \
+    br |= (uint32_t)(r > hi) << k;   \
+    dk |= (uint32_t)(r < lo) << k;   \
+  }
+  ORBX_RING(F)
+#undef F
+  return has_arc9(br) || has_arc9(dk);
+}
+
+// M = max over the 16 nine-pixel arcs of the arc's minimum one-signed contrast; cornerScore = M - 1.
+__device__ __forceinline__ int fast_contrast(const uint8_t* c, int TP) {
+  const int v = c[0];
+  int d[16];
+#define F(k, dx, dy) d[k] = v - (int)c[(dy)*TP + (dx)];
+  ORBX_RING(F)
+#undef F
+  int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn2[i] = min(d[i], d[(i + 1) & 15]);
+    mx2[i] = max(d[i], d[(i + 1) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
+    mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    mn8[i] = min(mn4[i], mn4[(i + 4) & 15]);
+    mx8[i] = max(mx4[i], mx4[(i + 4) & 15]);
+  }
+  int best_dark = -256, best_bright = 256;  // max of arc-min(d), min of arc-max(d)
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    best_dark = max(best_dark, min(mn8[i], d[(i + 8) & 15]));
+    best_bright = min(best_bright, max(mx8[i], d[(i + 8) & 15]));
+  }
+  return max(best_dark, -best_bright);
+}
+
+// One wave per FAST cell (workgroup = 64 threads, so __syncthreads() is a wave barrier).
+// LDS: image tile (cell + 6 px halo), u8 score tile with a zero ring, list of corner positions + scores.
+__global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cand,
+                                               int* __restrict__ candCount) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x;
+  const int img = blockIdx.y;
+  int cell = blockIdx.x;
+  int l = 0;
+  while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellStart) l++;
+  const LevelDev L = g.lv[l];
+  cell -= L.cellStart;
+  const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+  const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
+  const int iniY = kBorder + ci * L.hCell, iniX = kBorder + cj * L.wCell;
+  if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return;  // src/ORBextractor.cc:913,919
+  const int maxY = min(iniY + L.hCell + 6, maxBY), maxX = min(iniX + L.wCell + 6, maxBX);
+  const int rw = maxX - iniX, rh = maxY - iniY;
+  const int dw = rw - 6, dh = rh - 6;  // detectable window of the cell (FAST needs a 3 px ring)
+  if (dw <= 0 || dh <= 0) return;
+
+  const int TP = g.tileP, SP = g.scoreP;
+  uint8_t* tile = smem;
+  uint8_t* score = tile + TP * g.tileH;
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + SP * g.scoreH);
+  uint8_t* lscore = reinterpret_cast<uint8_t*>(list + g.listCap);
+
+  int pitch;
+  const uint8_t* im = level_ptr(g, p, img, l, pitch);
+  const int mis = iniX & 3, xa = iniX - mis;
+  const int dpr = (rw + mis + 3) >> 2;
+  {  // tile load: aligned dwords, rows iniY..maxY-1
+    const float inv = 1.0f / (float)dpr;
+    const int n = rh * dpr;
+    for (int idx = lane; idx < n; idx += 64) {
+      const int r = (int)(((float)idx + 0.5f) * inv);
+      const int cc = idx - r * dpr;
+      const int gx = xa + 4 * cc;
+      const uint8_t* src = im + (long long)(iniY + r) * pitch + gx;
+      uint32_t v;
+      if (gx + 4 <= L.w) {
+        v = *reinterpret_cast<const uint32_t*>(src);
+      } else {
+        v = 0;
+        for (int k = 0; k < 4; k++)
+          if (gx + k < L.w) v |= (uint32_t)src[k] << (8 * k);
+      }
+      *reinterpret_cast<uint32_t*>(tile + r * TP + 4 * cc) = v;
+    }
+    const int nz = ((dh + 2) * SP) >> 2;
+    for (int idx = lane; idx < nz; idx += 64) reinterpret_cast<uint32_t*>(score)[idx] = 0;
+  }
+  __syncthreads();
+
+  // dense corner test at the min threshold; corners are appended to the list in raster order
+  int nList = 0;
+  {
+    const float inv = 1.0f / (float)dw;
+    const int n = dw * dh;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      bool corner = false;
+      int y = 0, x = 0;
+      if (i < n) {
+        y = (int)(((float)i + 0.5f) * inv);
+        x = i - y * dw;
+        corner = fast_is_corner(tile + (y + 3) * TP + (x + 3 + mis), TP, g.minTh);
+      }
+      const uint64_t m = __ballot(corner);
+      if (corner) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)((y << 8) | x);
+      nList += __popcll(m);
+    }
+  }
+  __syncthreads();
+
+  // score of every min-threshold corner -> score tile (offset by the 1 px zero ring)
+  for (int e = lane; e < nList; e += 64) {
+    const int yx = list[e], y = yx >> 8, x = yx & 255;
+    const int s = fast_contrast(tile + (y + 3) * TP + (x + 3 + mis), TP) - 1;
+    lscore[e] = (uint8_t)s;
+    score[(y + 1) * SP + (x + 1)] = (uint8_t)s;
+  }
+  __syncthreads();
+
+  // 3x3 non-max suppression inside the cell; decide ini vs min threshold on the post-NMS set
+  bool any_ini = false;
+  for (int base = 0; base < nList; base += 64) {
+    const int e = base + lane;
+    bool keep = false;
+    int s = 0;
+    if (e < nList) {
+      const int yx = list[e], y = yx >> 8, x = yx & 255;
+      s = lscore[e];
+      const uint8_t* q = score + (y + 1) * SP + (x + 1);
+      keep = s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
+             s > q[SP] && s > q[SP + 1];
+      if (keep) list[e] = (uint16_t)(yx | 0x8000);
+    }
+    any_ini |= __ballot(keep && s >= g.iniTh) != 0;
+  }
+  __syncthreads();
+
+  uint32_t* out = cand + (long long)img * g.candImg + L.candOff;
+  int* counter = candCount + img * g.nlevels + l;
+  for (int base = 0; base < nList; base += 64) {
+    const int e = base + lane;
+    bool emit = false;
+    int yx = 0, s = 0;
+    if (e < nList) {
+      yx = list[e];
+      s = lscore[e];
+      emit = (yx & 0x8000) && (s >= g.iniTh || !any_ini);
+    }
+    const uint64_t m = __ballot(emit);
+    if (m) {
+      int pos = 0;
+      if (lane == 0) pos = atomicAdd(counter, __popcll(m));
+      pos = __shfl(pos, 0);
+      if (emit) {
+        const int y = (yx >> 8) & 0x7F, x = yx & 255;
+        const int o = pos + __popcll(m & lanemask_lt());
+        if (o < L.candCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, s);
+      }
+    }
+  }
+}
+
+hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cand, int* candCount, hipStream_t s) {
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + (size_t)g.listCap * 3 + 16;
+  dim3 grid(g.totalCells, nimg);
+  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cand, candCount);
+  return hipGetLastError();
+}
+
+// ================================================================================================ octree
+// DistributeOctTree without moving keys: every candidate keeps a node id (knode), a pass counts the keys of
+// each child quadrant with LDS atomics, and the node list of the next pass is laid out by prefix sums in
+// exactly the order the reference's std::list ends up in (children push_front'ed as n1..n4 => a visited
+// node's children appear as n4,n3,n2,n1, later-visited nodes first; untouched nodes keep their order).
+// The final largest-first expansion sorts with the libstdc++ introsort replica (orbx_introsort.h).
+
+struct OctLds {  // byte offsets into dynamic LDS, all 8-byte aligned
+  int nx0[2], nx1[2], ny0[2], ny1[2], ncnt[2];
+  int cnt4, cpos, scan, e[2], mark, bestk, tsum;
+  int total;
+};
+__host__ __device__ inline OctLds oct_layout(int maxn) {
+  OctLds o;
+  int off = 0;
+  auto take = [&](int bytes) {
+    int r = off;
+    off += (bytes + 7) & ~7;
+    return r;
+  };
+  for (int b = 0; b < 2; b++) {
+    o.nx0[b] = take(maxn * 2);
+    o.nx1[b] = take(maxn * 2);
+    o.ny0[b] = take(maxn * 2);
+    o.ny1[b] = take(maxn * 2);
+    o.ncnt[b] = take(maxn * 4);
+  }
+  o.cnt4 = take(maxn * 16);
+  o.cpos = take(maxn * 8);
+  o.scan = take(maxn * 8);  // u64 scan values; reused as best[] at the end
+  o.e[0] = take(maxn * 8);
+  o.e[1] = take(maxn * 8);
+  o.mark = take(maxn * 2);
+  o.bestk = take(maxn * 4);
+  o.tsum = take(256 * 8 + 64);
+  o.total = off;
+  return o;
+}
+__host__ __device__ inline int oct_maxn(const Geom& g) {
+  int q = 0;
+  for (int l = 0; l < g.nlevels; l++) q = g.lv[l].quota > q ? g.lv[l].quota : q;
+  return q + 4 * kMaxIni + 8;
+}
+size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g)).total; }
+
+// Exclusive scan of n u64 values in LDS (in place) by a 256-thread block; returns the total.
+// Packed fields must not overflow into each other (callers keep each field < 2^21).
+__device__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
+  const int tid = threadIdx.x;
+  const int per = (n + 255) >> 8;
+  const int b = tid * per, e = min(b + per, n);
+  uint64_t s = 0;
+  for (int i = b; i < e; i++) s += v[i];
+  tsum[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint64_t t = tid >= d ? tsum[tid - d] : 0;
+    __syncthreads();
+    tsum[tid] += t;
+    __syncthreads();
+  }
+  const uint64_t total = tsum[255];
+  uint64_t run = tid ? tsum[tid - 1] : 0;
+  for (int i = b; i < e; i++) {
+    const uint64_t t = v[i];
+    v[i] = run;
+    run += t;
+  }
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ int quadrant(int x, int y, int x0, int x1, int y0, int y1) {
+  const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;  // ceil(float(len) / 2), :494-495
+  return (x < x0 + hx ? 0 : 1) | (y < y0 + hy ? 0 : 2);
+}
+
+__global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restrict__ cand,
+                                                const int* __restrict__ candCount, uint16_t* __restrict__ knode,
+                                                uint32_t* __restrict__ sel, int* __restrict__ selCount) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_i[8];
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x, img = blockIdx.y;
+  const LevelDev L = g.lv[l];
+  const int maxn = oct_maxn(g);
+  const OctLds o = oct_layout(maxn);
+  int16_t* nx0[2] = {(int16_t*)(smem + o.nx0[0]), (int16_t*)(smem + o.nx0[1])};
+  int16_t* nx1[2] = {(int16_t*)(smem + o.nx1[0]), (int16_t*)(smem + o.nx1[1])};
+  int16_t* ny0[2] = {(int16_t*)(smem + o.ny0[0]), (int16_t*)(smem + o.ny0[1])};
+  int16_t* ny1[2] = {(int16_t*)(smem + o.ny1[0]), (int16_t*)(smem + o.ny1[1])};
+  uint32_t* ncnt[2] = {(uint32_t*)(smem + o.ncnt[0]), (uint32_t*)(smem + o.ncnt[1])};
+  uint32_t* cnt4 = (uint32_t*)(smem + o.cnt4);
+  uint16_t* cpos = (uint16_t*)(smem + o.cpos);
+  uint64_t* scan = (uint64_t*)(smem + o.scan);
+  uint64_t* ebuf[2] = {(uint64_t*)(smem + o.e[0]), (uint64_t*)(smem + o.e[1])};
+  uint16_t* mark = (uint16_t*)(smem + o.mark);
+  uint32_t* bestk = (uint32_t*)(smem + o.bestk);
+  uint64_t* tsum = (uint64_t*)(smem + o.tsum);
+
+  const int n = min(candCount[img * g.nlevels + l], L.candCap);
+  const int N = L.quota;
+  const uint32_t* keys = cand + (long long)img * g.candImg + L.candOff;
+  uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
+  int* outCount = selCount + img * g.nlevels + l;
+  uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
+
+  const int W = L.w - 2 * kBorder, H = L.h - 2 * kBorder;
+  const int nIni = (int)roundf((float)W / (float)H);  // :566
+  const float hX = (float)W / (float)nIni;             // :568
+
+  // ---- roots (:575-601)
+  if (tid < kMaxIni) cnt4[tid] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const int r = (int)((float)key_x(keys[k]) / hX);
+    kn[k] = (uint16_t)r;
+    atomicAdd(&cnt4[r], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int na = 0;
+    for (int i = 0; i < nIni; i++) {
+      if (cnt4[i] == 0) {
+        cpos[i] = 0xFFFF;
+        continue;
+      }
+      nx0[0][na] = (int16_t)(int)(hX * (float)i);
+      nx1[0][na] = (int16_t)(int)(hX * (float)(i + 1));
+      ny0[0][na] = 0;
+      ny1[0][na] = (int16_t)H;
+      ncnt[0][na] = cnt4[i];
+      cpos[i] = (uint16_t)na;
+      na++;
+    }
+    s_i[0] = na;
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) kn[k] = cpos[kn[k]];
+  int nA = s_i[0];
+  int cur = 0;
+  __syncthreads();
+
+  bool finish = false;
+  int nE = 0, ecur = 0;
+  // ---- phase 1: split every expandable node per pass (:610-677)
+  while (!finish) {
+    const int prevSize = nA;
+    for (int i = tid; i < nA * 4; i += 256) cnt4[i] = 0;
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int nd = kn[k];
+      if (ncnt[cur][nd] > 1) {
+        const uint32_t key = keys[k];
+        const int q = quadrant(key_x(key), key_y(key), nx0[cur][nd], nx1[cur][nd], ny0[cur][nd], ny1[cur][nd]);
+        atomicAdd(&cnt4[nd * 4 + q], 1u);
+        kn[k] = (uint16_t)(nd | (q << 14));
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nA; i += 256) {
+      uint64_t c = 0, nm = 1, ce = 0;
+      if (ncnt[cur][i] > 1) {
+        nm = 0;
+        for (int q = 0; q < 4; q++) {
+          c += cnt4[i * 4 + q] > 0;
+          ce += cnt4[i * 4 + q] > 1;
+        }
+      }
+      scan[i] = c | (nm << 21) | (ce << 42);
+    }
+    __syncthreads();
+    const uint64_t tot = block_scan_u64(scan, nA, tsum);
+    const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
+    const int nxt = cur ^ 1;
+    for (int i = tid; i < nA; i += 256) {
+      const uint64_t pre = scan[i];
+      const int pc = (int)(pre & 0x1FFFFF), pnm = (int)((pre >> 21) & 0x1FFFFF), pce = (int)(pre >> 42);
+      if (ncnt[cur][i] > 1) {
+        const int x0 = nx0[cur][i], x1 = nx1[cur][i], y0 = ny0[cur][i], y1 = ny1[cur][i];
+        const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+        int c = 0;
+        for (int q = 0; q < 4; q++) c += cnt4[i * 4 + q] > 0;
+        const int base = tc - (pc + c);
+        int after = 0, eb = pce;
+        for (int q = 0; q < 4; q++) {  // E entries in creation order n1..n4
+          const uint32_t cq = cnt4[i * 4 + q];
+          if (cq > 1) {
+            int rank_after = 0;
+            for (int q2 = q + 1; q2 < 4; q2++) rank_after += cnt4[i * 4 + q2] > 0;
+            const int cx0 = (q & 1) ? x0 + hx : x0;
+            ebuf[ecur][eb++] = ((uint64_t)cq << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+          }
+        }
+        for (int q = 3; q >= 0; q--) {  // list order n4,n3,n2,n1
+          const uint32_t cq = cnt4[i * 4 + q];
+          if (cq == 0) continue;
+          const int pos = base + after++;
+          nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
+          nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
+          ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
+          ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
+          ncnt[nxt][pos] = cq;
+          cpos[i * 4 + q] = (uint16_t)pos;
+        }
+      } else {
+        const int pos = tc + pnm;
+        nx0[nxt][pos] = nx0[cur][i];
+        nx1[nxt][pos] = nx1[cur][i];
+        ny0[nxt][pos] = ny0[cur][i];
+        ny1[nxt][pos] = ny1[cur][i];
+        ncnt[nxt][pos] = ncnt[cur][i];
+        cpos[i * 4] = (uint16_t)pos;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int v = kn[k], nd = v & 0x3FFF;
+      kn[k] = ncnt[cur][nd] > 1 ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
+    }
+    __syncthreads();
+    cur = nxt;
+    nA = tc + tnm;
+    nE = tce;
+    if (nA >= N || nA == prevSize) {
+      finish = true;
+    } else if (nA + 3 * nE > N) {
+      break;  // -> phase 2
+    }
+  }
+
+  // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
+  while (!finish) {
+    const int prevSize = nA;
+    uint64_t* E = ebuf[ecur];
+    uint64_t* E2 = ebuf[ecur ^ 1];
+    if (tid == 0) {
+      introsort<uint64_t, KeyLess>(E, nE, KeyLess());
+      s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
+      s_i[2] = 0;   // broke
+    }
+    for (int i = tid; i < nA * 4; i += 256) cnt4[i] = 0;
+    for (int i = tid; i < nA; i += 256) mark[i] = 0;
+    __syncthreads();
+    for (int m = tid; m < nE; m += 256) mark[(int)(E[nE - 1 - m] & 0xFFFF)] = (uint16_t)(m + 1);
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int nd = kn[k];
+      if (mark[nd]) {
+        const uint32_t key = keys[k];
+        const int q = quadrant(key_x(key), key_y(key), nx0[cur][nd], nx1[cur][nd], ny0[cur][nd], ny1[cur][nd]);
+        atomicAdd(&cnt4[nd * 4 + q], 1u);
+        kn[k] = (uint16_t)(nd | (q << 14));
+      }
+    }
+    __syncthreads();
+    // scan over the processing order m: c (children), ce (expandable children)
+    for (int m = tid; m < nE; m += 256) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      uint64_t c = 0, ce = 0;
+      for (int q = 0; q < 4; q++) {
+        c += cnt4[nd * 4 + q] > 0;
+        ce += cnt4[nd * 4 + q] > 1;
+      }
+      scan[m] = c | (ce << 21);
+    }
+    __syncthreads();
+    block_scan_u64(scan, nE, tsum);
+    // first m at which the list reaches N nodes: size after m+1 expansions = nA + C_incl(m) - (m+1)
+    for (int m = tid; m < nE; m += 256) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      int c = 0;
+      for (int q = 0; q < 4; q++) c += cnt4[nd * 4 + q] > 0;
+      const int cincl = (int)(scan[m] & 0x1FFFFF) + c;
+      if (nA + cincl - (m + 1) >= N) {
+        atomicMin(&s_i[1], m + 1);
+        s_i[2] = 1;
+      }
+    }
+    __syncthreads();
+    const int nP = s_i[1];  // nodes m < nP are expanded
+    const bool broke = s_i[2] != 0;
+    int tc, tce;
+    if (nP < nE) {
+      tc = (int)(scan[nP] & 0x1FFFFF);
+      tce = (int)(scan[nP] >> 21);
+    } else {
+      const int nd = (int)(E[0] & 0xFFFF);  // m = nE-1
+      int c = 0, ce = 0;
+      for (int q = 0; q < 4; q++) {
+        c += cnt4[nd * 4 + q] > 0;
+        ce += cnt4[nd * 4 + q] > 1;
+      }
+      tc = nE ? (int)(scan[nE - 1] & 0x1FFFFF) + c : 0;
+      tce = nE ? (int)(scan[nE - 1] >> 21) + ce : 0;
+    }
+    const int nxt = cur ^ 1;
+    // children of processed nodes: later processed first, each group n4..n1
+    for (int m = tid; m < nP; m += 256) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      const int x0 = nx0[cur][nd], x1 = nx1[cur][nd], y0 = ny0[cur][nd], y1 = ny1[cur][nd];
+      const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+      int c = 0;
+      for (int q = 0; q < 4; q++) c += cnt4[nd * 4 + q] > 0;
+      const int pc = (int)(scan[m] & 0x1FFFFF);
+      int eb = (int)(scan[m] >> 21);
+      const int base = tc - (pc + c);
+      for (int q = 0; q < 4; q++) {
+        const uint32_t cq = cnt4[nd * 4 + q];
+        if (cq > 1) {
+          int rank_after = 0;
+          for (int q2 = q + 1; q2 < 4; q2++) rank_after += cnt4[nd * 4 + q2] > 0;
+          const int cx0 = (q & 1) ? x0 + hx : x0;
+          E2[eb++] = ((uint64_t)cq << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+        }
+      }
+      int after = 0;
+      for (int q = 3; q >= 0; q--) {
+        const uint32_t cq = cnt4[nd * 4 + q];
+        if (cq == 0) continue;
+        const int pos = base + after++;
+        nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
+        nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
+        ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
+        ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
+        ncnt[nxt][pos] = cq;
+        cpos[nd * 4 + q] = (uint16_t)pos;
+      }
+    }
+    __syncthreads();
+    // untouched nodes keep their relative order behind the new children
+    for (int i = tid; i < nA; i += 256) scan[i] = (mark[i] == 0 || mark[i] > nP) ? 1 : 0;
+    __syncthreads();
+    const int nKeep = (int)block_scan_u64(scan, nA, tsum);
+    for (int i = tid; i < nA; i += 256) {
+      if (mark[i] == 0 || mark[i] > nP) {
+        const int pos = tc + (int)scan[i];
+        nx0[nxt][pos] = nx0[cur][i];
+        nx1[nxt][pos] = nx1[cur][i];
+        ny0[nxt][pos] = ny0[cur][i];
+        ny1[nxt][pos] = ny1[cur][i];
+        ncnt[nxt][pos] = ncnt[cur][i];
+        cpos[i * 4] = (uint16_t)pos;
+      }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+      const int v = kn[k], nd = v & 0x3FFF;
+      const int mk = mark[nd];
+      kn[k] = (mk != 0 && mk <= nP) ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
+    }
+    __syncthreads();
+    cur = nxt;
+    nA = tc + nKeep;
+    nE = tce;
+    ecur ^= 1;
+    if (broke || nA == prevSize) finish = true;
+  }
+
+  // ---- best response per node, first candidate (reference order) wins ties (:741-754)
+  uint64_t* best = scan;
+  for (int i = tid; i < nA; i += 256) best[i] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const uint32_t key = keys[k];
+    const int xr = key_x(key) - 3, yr = key_y(key) - 3;  // relative to the first detectable pixel (19,19)
+    const int cy = yr / L.hCell, cx = xr / L.wCell;
+    const uint32_t rank = (uint32_t)(((cy * L.nCols + cx) * L.hCell + (yr - cy * L.hCell)) * L.wCell + (xr - cx * L.wCell));
+    atomicMax((unsigned long long*)&best[kn[k]], ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank));
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += 256) {
+    const uint32_t key = keys[k];
+    const int xr = key_x(key) - 3, yr = key_y(key) - 3;
+    const int cy = yr / L.hCell, cx = xr / L.wCell;
+    const uint32_t rank = (uint32_t)(((cy * L.nCols + cx) * L.hCell + (yr - cy * L.hCell)) * L.wCell + (xr - cx * L.wCell));
+    const int nd = kn[k];
+    if (best[nd] == (((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank))) bestk[nd] = (uint32_t)k;
+  }
+  __syncthreads();
+  const int nOut = min(nA, L.selCap);
+  for (int i = tid; i < nOut; i += 256) {
+    const uint32_t key = keys[bestk[i]];
+    out[i] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
+  }
+  if (tid == 0) *outCount = nOut;
+}
+
+hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cand, const int* candCount, uint16_t* knode,
+                         uint32_t* sel, int* selCount, hipStream_t s) {
+  dim3 grid(g.nlevels, nimg);
+  hipLaunchKernelGGL(k_octree, grid, dim3(256), octree_lds_bytes(g), s, g, cand, candCount, knode, sel, selCount);
+  return hipGetLastError();
+}
+
+// ================================================================================================ blur
+// 7x7 Gaussian, fixed point 8.8 taps {18,34,48,56,48,34,18} (OpenCV >= 4.5.1), BORDER_REFLECT_101 at the
+// level's own edges, exact integer accumulation with one rounding.  64x32 output tile / block.
+__device__ __forceinline__ int reflect101(int p, int n) {
+  if (p < 0) p = -p;
+  if (p >= n) p = 2 * n - 2 - p;
+  return p;
+}
+
+#define BL_TW 64
+#define BL_TH 32
+__global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
+  __shared__ uint8_t in[(BL_TH + 6)][BL_TW + 8];
+  __shared__ uint16_t hp[(BL_TH + 6)][BL_TW];
+  const int tid = threadIdx.x;
+  const int img = blockIdx.z;
+  int tile = blockIdx.x;
+  // tiles of all levels are enumerated in one grid dimension
+  int l = 0;
+  for (;; l++) {
+    const int tx = (g.lv[l].w + BL_TW - 1) / BL_TW, ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
+    if (tile < tx * ty || l + 1 == g.nlevels) break;
+    tile -= tx * ty;
+  }
+  const LevelDev L = g.lv[l];
+  const int tx = (L.w + BL_TW - 1) / BL_TW;
+  if (tile >= tx * ((L.h + BL_TH - 1) / BL_TH)) return;
+  const int x0 = (tile % tx) * BL_TW, y0 = (tile / tx) * BL_TH;
+  int pitch;
+  const uint8_t* im = level_ptr(g, p, img, l, pitch);
+  for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
+    const int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
+    const int yy = reflect101(min(y0 + r - 3, L.h + 2), L.h), xx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
+    in[r][c] = im[(long long)yy * pitch + xx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
+    const int r = i / BL_TW, c = i - r * BL_TW;
+    const uint8_t* q = &in[r][c];
+    hp[r][c] = (uint16_t)(18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 48 * (q[2] + q[4]) + 56 * q[3]);
+  }
+  __syncthreads();
+  uint8_t* dst = p.blur + (long long)img * g.pyrImg + L.off;
+  for (int i = tid; i < BL_TH * (BL_TW / 4); i += 256) {
+    const int r = i / (BL_TW / 4), c4 = (i - r * (BL_TW / 4)) * 4;
+    if (y0 + r >= L.h || x0 + c4 >= L.w) continue;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = c4 + j;
+      const uint32_t acc = 18u * (hp[r][c] + hp[r + 6][c]) + 34u * (hp[r + 1][c] + hp[r + 5][c]) +
+                           48u * (hp[r + 2][c] + hp[r + 4][c]) + 56u * hp[r + 3][c];
+      w |= ((acc + 32768u) >> 16) << (8 * j);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * L.pitch + x0 + c4) = w;
+  }
+}
+
+hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, hipStream_t s) {
+  int tiles = 0;
+  for (int l = 0; l < g.nlevels; l++)
+    tiles += ((g.lv[l].w + BL_TW - 1) / BL_TW) * ((g.lv[l].h + BL_TH - 1) / BL_TH);
+  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p);
+  return hipGetLastError();
+}
+
+// ================================================================================================ slots
+// Output slot of every selected keypoint under the serial semantics of :1062-1099: walk levels then list
+// order; keypoints inside the lapping area fill from the back, the others from the front.
+__global__ __launch_bounds__(256) void k_slots(Geom g, const uint32_t* __restrict__ sel,
+                                               const int* __restrict__ selCount, const int* __restrict__ lap,
+                                               int* __restrict__ slot, int* __restrict__ nOut,
+                                               int* __restrict__ mono) {
+  __shared__ int cum[ORBX_MAX_LEVELS + 1];
+  __shared__ int tsum[256];
+  const int tid = threadIdx.x, img = blockIdx.x;
+  if (tid == 0) {
+    int c = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+      cum[l] = c;
+      c += selCount[img * g.nlevels + l];
+    }
+    cum[g.nlevels] = c;
+  }
+  __syncthreads();
+  const int n = cum[g.nlevels];
+  const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
+  const int per = (n + 255) >> 8;
+  const int b = min(tid * per, n), e = min(b + per, n);
+  auto in_lap = [&](int gidx, int& lvl, int& idx) {
+    lvl = 0;
+    while (gidx >= cum[lvl + 1]) lvl++;
+    idx = gidx - cum[lvl];
+    const uint32_t key = sel[(long long)img * g.selImg + g.lv[lvl].selOff + idx];
+    float x = (float)key_x(key);
+    if (lvl != 0) x = x * g.lv[lvl].scale;
+    return x >= lap0 && x <= lap1;
+  };
+  int cnt = 0;
+  for (int i = b; i < e; i++) {
+    int lv, ix;
+    cnt += in_lap(i, lv, ix) ? 1 : 0;
+  }
+  tsum[tid] = cnt;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? tsum[tid - d] : 0;
+    __syncthreads();
+    tsum[tid] += t;
+    __syncthreads();
+  }
+  int lapBefore = tid ? tsum[tid - 1] : 0;
+  for (int i = b; i < e; i++) {
+    int lv, ix;
+    const bool il = in_lap(i, lv, ix);
+    const int s = il ? (n - 1 - lapBefore) : (i - lapBefore);
+    slot[(long long)img * g.selImg + g.lv[lv].selOff + ix] = s;
+    lapBefore += il ? 1 : 0;
+  }
+  if (tid == 0) {
+    nOut[img] = n;
+    mono[img] = n - tsum[255];
+  }
+}
+
+hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int* selCount, const int* lap,
+                        int* slot, int* nOut, int* mono, hipStream_t s) {
+  hipLaunchKernelGGL(k_slots, dim3(nimg), dim3(256), 0, s, g, sel, selCount, lap, slot, nOut, mono);
+  return hipGetLastError();
+}
+
+// ================================================================================================ describe
+// cv::fastAtan2: every product / sum rounded separately.
+__device__ __forceinline__ float fast_atan2_dev(float y, float x) {
+  const float s = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s,
+              p7 = -0.04432655554792128f * s;
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  } else {
+    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+    c2 = __fmul_rn(c, c);
+    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+  }
+  if (x < 0) a = __fsub_rn(180.f, a);
+  if (y < 0) a = __fsub_rn(360.f, a);
+  return a;
+}
+
+// sin/cos of the descriptor rotation: IEEE double, fixed operation sequence (identical to the oracle's
+// definition, oracle/orb_oracle.cpp orb_sincosf), rounded once to float.
+__device__ __forceinline__ void orb_sincos_dev(float ang, float& s_out, float& c_out) {
+  const double x = (double)ang;
+  const double fk = floor(__dadd_rn(__dmul_rn(x, 6.36619772367581382433e-01), 0.5));
+  const int k = (int)fk;
+  const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(fk, 1.57079632673412561417e+00)),
+                             __dmul_rn(fk, 6.07710050650619224932e-11));
+  const double z = __dmul_rn(r, r);
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+#define DM(a, b) __dmul_rn(a, b)
+#define DA(a, b) __dadd_rn(a, b)
+  const double ps = DA(S2, DM(z, DA(S3, DM(z, DA(S4, DM(z, DA(S5, DM(z, S6))))))));
+  const double sn = DA(r, DM(DM(z, r), DA(S1, DM(z, ps))));
+  const double pc = DM(z, DA(C1, DM(z, DA(C2, DM(z, DA(C3, DM(z, DA(C4, DM(z, DA(C5, DM(z, C6)))))))))));
+  const double cs = __dsub_rn(1.0, __dsub_rn(DM(0.5, z), DM(z, pc)));
+#undef DM
+#undef DA
+  double sv, cv;
+  switch (k & 3) {
+    case 0: sv = sn; cv = cs; break;
+    case 1: sv = cs; cv = -sn; break;
+    case 2: sv = -sn; cv = -cs; break;
+    default: sv = -cs; cv = sn; break;
+  }
+  s_out = (float)sv;
+  c_out = (float)cv;
+}
+
+// One wave per selected keypoint: intensity-centroid angle on the unblurred level, 256 rotated tests on the
+// blurred level (lane t evaluates tests t, t+64, t+128, t+192; each __ballot is 8 descriptor bytes already
+// in the reference's byte/bit order), then the keypoint + descriptor are written to their output slot.
+__global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
+                                                  const int* __restrict__ selCount, const int* __restrict__ slot,
+                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+  const int lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int img = blockIdx.y;
+  if (s >= g.selImg) return;
+  int l = 0;
+  while (l + 1 < g.nlevels && s >= g.lv[l + 1].selOff) l++;
+  const LevelDev L = g.lv[l];
+  const int idx = s - L.selOff;
+  if (idx >= selCount[img * g.nlevels + l]) return;
+  const uint32_t key = sel[(long long)img * g.selImg + s];
+  const int X = key_x(key), Y = key_y(key);
+  int pitch;
+  const uint8_t* im = level_ptr(g, p, img, l, pitch);
+  // IC_Angle: lanes 0..30 take one row v = lane - 15 of the circular patch
+  int m10 = 0, m01 = 0;
+  if (lane < 31) {
+    const int v = lane - 15;
+    const int d = c_umax[v < 0 ? -v : v];
+    const uint8_t* row = im + (long long)(Y + v) * pitch + X;
+    int rs = 0;
+    for (int u = -d; u <= d; u++) {
+      const int val = row[u];
+      rs += val;
+      m10 += u * val;
+    }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m10 += __shfl_xor(m10, o);
+    m01 += __shfl_xor(m01, o);
+  }
+  const float angle = fast_atan2_dev((float)m01, (float)m10);
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, b;
+  orb_sincos_dev(__fmul_rn(angle, factorPI), b, a);  // a = cos, b = sin
+  const uint8_t* bl = p.blur + (long long)img * g.pyrImg + L.off + (long long)Y * L.pitch + X;
+  const int n_out_slot = slot[(long long)img * g.selImg + s];
+  uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
+#pragma unroll
+  for (int gI = 0; gI < 4; gI++) {
+    const int8_t* pt = c_pattern + 4 * (64 * gI + lane);
+    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    const int iy0 = rne_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+    const int ix0 = rne_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+    const int iy1 = rne_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+    const int ix1 = rne_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+    const int t0 = bl[iy0 * L.pitch + ix0], t1 = bl[iy1 * L.pitch + ix1];
+    const uint64_t bits = __ballot(t0 < t1);
+    if (lane == 0) *reinterpret_cast<uint64_t*>(dout + 8 * gI) = bits;
+  }
+  if (lane == 0) {
+    orbx_keypoint kp;
+    kp.x = l ? __fmul_rn((float)X, L.scale) : (float)X;
+    kp.y = l ? __fmul_rn((float)Y, L.scale) : (float)Y;
+    kp.size = L.patch;
+    kp.angle = angle;
+    kp.response = (float)key_r(key);
+    kp.octave = l;
+    kp.class_id = -1;
+    kps[(long long)img * g.outCap + n_out_slot] = kp;
+  }
+}
+
+hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
+                           const int* slot, orbx_keypoint* kps, uint8_t* desc, hipStream_t s) {
+  hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
+                     kps, desc);
+  return hipGetLastError();
+}
+
+// ================================================================================================ stereo
+__device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* b) {
+  int d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d += __popc(a[i] ^ b[i]);
+  return d;
+}
+
+// One wave per left keypoint.  The reference scans vRowIndices[vL] (right keypoints whose +-2*scale row band
+// covers row vL, ascending iR) and keeps the first strict minimum; that is the minimum of (dist, iR) over
+// all right keypoints passing the same band/octave/disparity filters, which is what the lanes compute.
+__global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pair = blockIdx.y;
+  const int imgL = a.firstL + pair, imgR = a.firstR + pair;
+  const int nL = a.nL[imgL], nR = a.nR[imgR];
+  if (iL >= nL) return;
+  const long long oL = (long long)pair * a.capL + iL;
+  const orbx_keypoint kpL = a.kL[(long long)imgL * a.capL + iL];
+  const orbx_keypoint* kR = a.kR + (long long)imgR * a.capR;
+  const uint32_t* dR = reinterpret_cast<const uint32_t*>(a.dR + (long long)imgR * a.capR * 32);
+  uint32_t dl[8];
+  {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a.dL + ((long long)imgL * a.capL + iL) * 32);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dl[i] = q[i];
+  }
+  float uR_out = -1.f, depth_out = -1.f;
+  int sad_out = -1;
+  const float uL = kpL.x, vL = kpL.y;
+  const int levelL = kpL.octave;
+  const float maxD = __fdiv_rn(a.bf, a.b);
+  const float minU = __fsub_rn(uL, maxD), maxU = uL;
+  const int row = (int)vL;
+  uint32_t best = (100u << 16);  // TH_HIGH, strict '<'
+  if (!(maxU < 0)) {
+    for (int base = 0; base < nR; base += 64) {
+      const int iR = base + lane;
+      if (iR < nR) {
+        const orbx_keypoint k = kR[iR];
+        const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
+        const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
+        const bool ok = !(k.y == 0.0f && k.x == 0.0f) && row >= minr && row <= maxr &&
+                        k.octave >= levelL - 1 && k.octave <= levelL + 1 && k.x >= minU && k.x <= maxU;
+        if (ok) {
+          const uint32_t cand = ((uint32_t)hamming256(dl, dR + (long long)iR * 8) << 16) | (uint32_t)iR;
+          best = min(best, cand);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+  const int bestDist = (int)(best >> 16);
+  if (bestDist < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
+    const int bestIdxR = (int)(best & 0xFFFF);
+    const float uR0 = kR[bestIdxR].x;
+    const float sf = 1.0f / g.lv[levelL].scale;  // mvInvScaleFactors
+    const float su = roundf(__fmul_rn(kpL.x, sf)), sv = roundf(__fmul_rn(kpL.y, sf)), sr = roundf(__fmul_rn(uR0, sf));
+    const LevelDev L = g.lv[levelL];
+    const float endu = sr + 11.0f;
+    if (!(sr < 0 || endu >= (float)L.w)) {
+      int pitchL, pitchR;
+      const uint8_t* imL = level_ptr(g, pl, imgL, levelL, pitchL);
+      const uint8_t* imR = level_ptr(g, pr, imgR, levelL, pitchR);
+      const int yl = (int)sv - 5, xl = (int)su - 5, xr0 = (int)sr - 5;
+      // 11x11 SAD for the 11 shifts; lanes cover the 121 pixels
+      int sadv[11];
+      int l0 = 0, l1 = 0;
+      const int p0 = lane, p1 = lane + 64;
+      const int y0 = p0 / 11, x0 = p0 - y0 * 11, y1 = p1 / 11, x1 = p1 - y1 * 11;
+      l0 = imL[(long long)(yl + y0) * pitchL + xl + x0];
+      if (p1 < 121) l1 = imL[(long long)(yl + y1) * pitchL + xl + x1];
+#pragma unroll
+      for (int inc = 0; inc < 11; inc++) {
+        int s = abs(l0 - (int)imR[(long long)(yl + y0) * pitchR + xr0 + (inc - 5) + x0]);
+        if (p1 < 121) s += abs(l1 - (int)imR[(long long)(yl + y1) * pitchR + xr0 + (inc - 5) + x1]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        sadv[inc] = s;
+      }
+      int bestSad = 0x7FFFFFFF, bestinc = 0;
+#pragma unroll
+      for (int inc = 0; inc < 11; inc++)
+        if (sadv[inc] < bestSad) {
+          bestSad = sadv[inc];
+          bestinc = inc - 5;
+        }
+      if (bestinc != -5 && bestinc != 5) {
+        float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+        for (int inc = 1; inc < 10; inc++)
+          if (inc - 5 == bestinc) {
+            d1 = (float)sadv[inc - 1];
+            d2 = (float)sadv[inc];
+            d3 = (float)sadv[inc + 1];
+          }
+        const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+        const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR = __fmul_rn(g.lv[levelL].scale, __fadd_rn(__fadd_rn(sr, (float)bestinc), deltaR));
+          float disparity = __fsub_rn(uL, bestuR);
+          if (disparity >= 0 && disparity < maxD) {
+            if (disparity <= 0) {
+              disparity = 0.01f;
+              bestuR = (float)__dsub_rn((double)uL, 0.01);
+            }
+            depth_out = __fdiv_rn(a.bf, disparity);
+            uR_out = bestuR;
+            sad_out = bestSad;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    a.uRight[oL] = uR_out;
+    a.depth[oL] = depth_out;
+    a.sad[oL] = sad_out;
+  }
+}
+
+// Median-of-SAD outlier cut (:1072-1083): median = element size/2 of the ascending (SAD, iL) list;
+// matches with SAD >= 1.5*1.4*median are dropped.  One block per pair, bitonic sort in LDS.
+__global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a, int npow2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint32_t* v = reinterpret_cast<uint32_t*>(smem);
+  __shared__ int s_m;
+  const int tid = threadIdx.x, pair = blockIdx.x;
+  const int nL = a.nL[a.firstL + pair];
+  const int* sad = a.sad + (long long)pair * a.capL;
+  if (tid == 0) s_m = 0;
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < npow2; i += 256) {
+    const int s = i < nL ? sad[i] : -1;
+    v[i] = s >= 0 ? (uint32_t)s : 0xFFFFFFFFu;
+    cnt += s >= 0;
+  }
+  atomicAdd(&s_m, cnt);
+  __syncthreads();
+  const int m = s_m;
+  if (m == 0) return;  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
+  for (int k = 2; k <= npow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow2; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t x = v[i], y = v[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            v[i] = y;
+            v[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  const float median = (float)(int)v[m / 2];
+  const float th = __fmul_rn(1.5f * 1.4f, median);
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0 && !((float)s < th)) {
+      a.uRight[(long long)pair * a.capL + i] = -1.f;
+      a.depth[(long long)pair * a.capL + i] = -1.f;
+    }
+  }
+}
+
+hipError_t launch_stereo(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_match, dim3((a.capL + 3) / 4, npairs), dim3(256), 0, s, g, pl, pr, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  int np2 = 1;
+  while (np2 < a.capL) np2 <<= 1;
+  hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), (size_t)np2 * 4, s, a, np2);
+  return hipGetLastError();
+}
+
+// ================================================================================================ bf knn2
+// Brute-force Hamming 2-NN, stable w.r.t. the train index.  Thread per query, 256 train rows
+// staged per LDS tile.
+__global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ dQ, int nQ,
+                                                 const uint8_t* __restrict__ dT, int nT, int* __restrict__ idx2,
+                                                 int* __restrict__ dist2, uint8_t* __restrict__ ok) {
+  __shared__ uint32_t tile[256 * 9];  // 8 words + 1 pad per row: conflict-free broadcast reads
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  uint32_t dq[8];
+  if (q < nQ) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) dq[i] = reinterpret_cast<const uint32_t*>(dQ)[(long long)q * 8 + i];
+  }
+  int b0 = 0x7FFFFFFF, b1 = 0x7FFFFFFF, i0 = -1, i1 = -1;
+  for (int t0 = 0; t0 < nT; t0 += 256) {
+    const int nt = min(256, nT - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * 8; i += 256)
+      tile[(i >> 3) * 9 + (i & 7)] = reinterpret_cast<const uint32_t*>(dT)[(long long)t0 * 8 + i];
+    __syncthreads();
+    if (q < nQ) {
+      for (int t = 0; t < nt; t++) {
+        const int d = hamming256(dq, tile + t * 9);
+        if (d < b0) {
+          b1 = b0;
+          i1 = i0;
+          b0 = d;
+          i0 = t0 + t;
+        } else if (d < b1) {
+          b1 = d;
+          i1 = t0 + t;
+        }
+      }
+    }
+  }
+  if (q < nQ) {
+    idx2[2 * q] = i0;
+    idx2[2 * q + 1] = i1;
+    dist2[2 * q] = i0 >= 0 ? b0 : -1;
+    dist2[2 * q + 1] = i1 >= 0 ? b1 : -1;
+    ok[q] = (i0 >= 0 && i1 >= 0 && (double)(float)b0 < __dmul_rn((double)(float)b1, 0.7)) ? 1 : 0;
+  }
+}
+
+hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
+                          uint8_t* ok, hipStream_t s) {
+  if (nQ <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bf_knn2, dim3((nQ + 255) / 256), dim3(256), 0, s, dQ, nQ, dT, nT, idx2, dist2, ok);
+  return hipGetLastError();
+}
+
+// ================================================================================================ search init
+// Frame grid (64 x 48, PosInGrid rounds to the nearest cell, src/Frame.cc:833-844) as CSR lists with
+// ascending keypoint indices.
+__device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs& a) {
+  const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, a.minX), a.invW));
+  const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, a.minY), a.invH));
+  if (px < 0 || px >= 64 || py < 0 || py >= 48) return -1;
+  return px * 48 + py;
+}
+
+__global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single block
+  __shared__ int cnt[64 * 48];
+  const int tid = threadIdx.x;
+  for (int c = tid; c < 64 * 48; c += 256) cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < a.n2; i += 256) {
+    const int c = grid_cell(a.k2[i], a);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 0; c < 64 * 48; c++) {
+      a.cellStart[c] = run;
+      run += cnt[c];
+    }
+    a.cellStart[64 * 48] = run;
+  }
+  __syncthreads();
+  // ascending fill: thread per cell walks all keypoints (n2 x 3072 cheap tests)
+  for (int c = tid; c < 64 * 48; c += 256) {
+    if (cnt[c] == 0) continue;
+    int w = a.cellStart[c];
+    for (int i = 0; i < a.n2; i++)
+      if (grid_cell(a.k2[i], a) == c) a.cellItems[w++] = i;
+  }
+  for (int i = tid; i < a.n2; i += 256) {
+    a.matchedDist[i] = 0x7FFFFFFF;
+    a.matches21[i] = -1;
+  }
+  for (int i = tid; i < a.n1; i += 256) a.matches12[i] = -1;
+  if (tid == 0) {
+    a.result[0] = 0;
+    a.result[1] = 0;
+  }
+}
+
+// GetFeaturesInArea(x, y, r, 0, 0) (src/Frame.cc:765-831) for one level-0 keypoint of F1 per wave, in the
+// reference's candidate order (ix outer, iy inner, in-cell order).  pass 0 counts, pass 1 writes (i2, dist).
+__global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  const orbx_keypoint k1 = a.k1[i1];
+  int total = 0;
+  if (k1.octave <= 0) {
+    const float x = a.prev[2 * i1], y = a.prev[2 * i1 + 1], r = (float)a.window;
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
+    const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.minX), r), a.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.minY), r), a.invH)));
+    const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
+    if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+      uint32_t d1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(a.d1)[(long long)i1 * 8 + i];
+      const int wbase = pass ? a.candOff[i1] : 0;
+      for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+          const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
+          for (int base = b; base < e; base += 64) {
+            const int j = base + lane;
+            bool ok = false;
+            int i2 = 0;
+            if (j < e) {
+              i2 = a.cellItems[j];
+              const orbx_keypoint k2 = a.k2[i2];
+              ok = k2.octave == 0 && fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+            }
+            const uint64_t m = __ballot(ok);
+            if (pass && ok) {
+              const int o = wbase + total + __popcll(m & lanemask_lt());
+              if (o < a.candCap) {
+                a.candIdx[o] = i2;
+                a.candDist[o] = hamming256(d1, reinterpret_cast<const uint32_t*>(a.d2) + (long long)i2 * 8);
+              }
+            }
+            total += __popcll(m);
+          }
+        }
+    }
+  }
+  if (!pass && lane == 0) a.candOff[i1] = total;
+}
+
+__global__ __launch_bounds__(256) void k_init_scan(InitArgs a) {  // single block: exclusive scan of candOff
+  __shared__ int tsum[256];
+  const int tid = threadIdx.x, n = a.n1;
+  const int per = (n + 255) >> 8, b = min(tid * per, n), e = min(b + per, n);
+  int s = 0;
+  for (int i = b; i < e; i++) s += a.candOff[i];
+  tsum[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? tsum[tid - d] : 0;
+    __syncthreads();
+    tsum[tid] += t;
+    __syncthreads();
+  }
+  int run = tid ? tsum[tid - 1] : 0;
+  for (int i = b; i < e; i++) {
+    const int t = a.candOff[i];
+    a.candOff[i] = run;
+    run += t;
+  }
+  if (tid == 255) {
+    a.candOff[n] = tsum[255];
+    if (tsum[255] > a.candCap) a.result[1] = tsum[255];
+  }
+}
+
+// The greedy bookkeeping (vMatchedDistance gate, match stealing, rotation histogram) is order dependent:
+// one wave walks i1 in serial order, the lanes reduce each keypoint's candidate list.
+__global__ __launch_bounds__(64) void k_init_resolve(InitArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int8_t* bins = reinterpret_cast<int8_t*>(smem);  // n1 entries: histogram bin of i1 or -1
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
+  for (int i = lane; i < a.n1; i += 64) bins[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int i1 = 0; i1 < a.n1; i1++) {
+    const int b = a.candOff[i1], e = a.candOff[i1 + 1];
+    if (e <= b) continue;
+    // best = first strict minimum in list order; second = second order statistic (strict updates)
+    uint64_t best = ~0ull;  // (dist << 32 | position)
+    for (int j = b + lane; j < e; j += 64) {
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (a.matchedDist[i2] <= d) continue;
+      const uint64_t v = ((uint64_t)(uint32_t)d << 32) | (uint32_t)(j - b);
+      best = v < best ? v : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t t = __shfl_xor((unsigned long long)best, o);
+      best = t < best ? t : best;
+    }
+    if (best == ~0ull) continue;
+    const int bestDist = (int)(best >> 32), bestPos = (int)(best & 0xFFFFFFFFu);
+    int second = 0x7FFFFFFF;
+    for (int j = b + lane; j < e; j += 64) {
+      if (j - b == bestPos) continue;
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (a.matchedDist[i2] <= d) continue;
+      second = min(second, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+    if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)second, a.nnratio)) {
+      if (lane == 0) {
+        const int bestIdx2 = a.candIdx[b + bestPos];
+        const int owner = a.matches21[bestIdx2];
+        if (owner >= 0) {
+          a.matches12[owner] = -1;
+          nmatches--;
+        }
+        a.matches12[i1] = bestIdx2;
+        a.matches21[bestIdx2] = i1;
+        a.matchedDist[bestIdx2] = bestDist;
+        nmatches++;
+        if (a.checkOri) {
+          float rot = __fsub_rn(a.k1[i1].angle, a.k2[bestIdx2].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          bins[i1] = (int8_t)bin;
+          hist[bin]++;
+        }
+      }
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  nmatches = __shfl(nmatches, 0);
+  if (a.checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {  // ComputeThreeMaxima, src/ORBmatcher.cc:1920-1955
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < a.n1; i += 64) {
+      const int bn = bins[i];
+      if (bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && a.matches12[i] >= 0) {
+        a.matches12[i] = -1;
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  __syncthreads();
+  for (int i = lane; i < a.n1; i += 64) {
+    const int m = a.matches12[i];
+    if (m >= 0) {
+      a.prev[2 * i] = a.k2[m].x;
+      a.prev[2 * i + 1] = a.k2[m].y;
+    }
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  if (a.n1 > 0) {
+    hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);
+  return hipGetLastError();
+}
+
+hipError_t prepare_kernels(const Geom& g) {
+  const size_t lds_oct = octree_lds_bytes(g);
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + (size_t)g.listCap * 3 + 16;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds_det);
+}
+
+// Host-callable check of the introsort replica (tests compare with std::sort).
+void debug_introsort_host(uint64_t* v, int n) { introsort<uint64_t, KeyLess>(v, n, KeyLess()); }
+
+}  // namespace orbx

@@ -1,0 +1,81 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/orbx.h declares, the host
+tables match the oracle, and compute entry points fail loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orb_slam3_fast_amd as orbx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = orbx.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), "liborbx.so does not export " + s
+    assert lib.orbx_abi_version() == 1
+
+
+def test_keypoint_layout_is_cv_keypoint():
+    assert orbx.KP_DTYPE.itemsize == 28
+    assert [orbx.KP_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == \
+        [0, 4, 8, 12, 16, 20, 24]
+
+
+def test_hamming_host_helper(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
+        assert orbx.ORBmatcher.DescriptorDistance(a, b) == oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+
+
+def test_no_cpu_fallback_without_device():
+    if orbx.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(orbx.OrbxError) as e:
+        orbx.ORBextractor(1000, 1.2, 8, 20, 7)
+    assert e.value.code in (orbx.E_NODEVICE, orbx.E_HIP)
+    with pytest.raises(orbx.OrbxError):
+        orbx.bf_knn2(np.zeros((4, 32), np.uint8), np.zeros((4, 32), np.uint8))
+    with pytest.raises(orbx.OrbxError):
+        k = np.zeros(4, orbx.KP_DTYPE)
+        orbx.ORBmatcher(0.9).SearchForInitialization(k, np.zeros((4, 32), np.uint8), k, np.zeros((4, 32), np.uint8),
+                                                      (0, 0, 640, 480), np.zeros((4, 2), np.float32), 100)
+
+
+def test_bad_parameters_rejected():
+    lib = orbx.lib()
+    p = orbx._Params(0, 1.2, 8, 20, 7)
+    h = C.c_void_p()
+    assert lib.orbx_extractor_create(C.byref(p), 640, 480, 1, 0, C.byref(h)) == orbx.E_BADARG
+    p = orbx._Params(1000, 1.0, 8, 20, 7)
+    assert lib.orbx_extractor_create(C.byref(p), 640, 480, 1, 0, C.byref(h)) == orbx.E_BADARG
+    p = orbx._Params(1000, 1.2, 99, 20, 7)
+    assert lib.orbx_extractor_create(C.byref(p), 640, 480, 1, 0, C.byref(h)) == orbx.E_BADARG
+    assert b"invalid" in lib.orbx_last_error()
+
+
+def test_introsort_replica_matches_libstdcxx(oracle):
+    """The quadtree's tie order is std::sort's (src/ORBextractor.cc:686): replica vs the oracle's std::sort."""
+    rng = np.random.default_rng(1)
+    osort = oracle.lib().oro_std_sort_keys
+    for trial in range(300):
+        n = int(rng.integers(1, 700))
+        cnt = rng.integers(2, 2 + int(rng.integers(1, 6)), n).astype(np.uint64)
+        ulx = rng.integers(0, int(rng.integers(1, 9)), n).astype(np.uint64)
+        v = (cnt << np.uint64(28)) | (ulx << np.uint64(16)) | np.arange(n, dtype=np.uint64)
+        a, b = v.copy(), v.copy()
+        orbx.lib().orbx_debug_introsort(a.ctypes.data_as(C.c_void_p), n)
+        osort(b.ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(a, b)

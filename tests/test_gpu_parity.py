@@ -1,0 +1,183 @@
+"""GPU parity: every stage of the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Stage taps (pyramid levels, blurred levels, FAST candidates) localise a mismatch; the end-to-end checks
+compare the full keypoint structs (28 bytes each, including angle and response floats) and the 32-byte
+descriptors byte for byte, in the reference's serial output order.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orb_slam3_fast_amd as orbx
+from orb_slam3_fast_amd import synth
+
+CASES = [
+    # w, h, nfeatures, nlevels, stream
+    (384, 288, 500, 8, 11),
+    (640, 480, 1000, 8, 12),
+    (752, 480, 1000, 8, 13),
+    (1280, 720, 1500, 8, 14),
+    (512, 512, 1500, 8, 15),
+    (160, 120, 300, 3, 16),
+]
+
+
+def _kp_bytes(k):
+    return np.ascontiguousarray(k).view(np.uint8).reshape(len(k), 28)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if orbx.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on the MI355X box")
+    return True
+
+
+@pytest.mark.parametrize("w,h,nf,nl,stream", CASES)
+def test_stages_and_end_to_end(gpu, oracle, w, h, nf, nl, stream):
+    img = synth.mono_frame(w, h, stream)
+    img[: h // 4, : w // 3] = (img[: h // 4, : w // 3] // 8) + 90      # low-contrast zone: min-threshold cells
+    ex = orbx.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(nf, 1.2, nl, 20, 7)
+    mono, k, d = ex(img, (0, 0))
+    omono, ok_, od = oe.extract(img, (0, 0))
+    # tables
+    t = oe.tables()
+    assert np.array_equal(ex.GetScaleFactors(), t["scale"])
+    assert np.array_equal(ex.GetInverseScaleFactors(), t["inv_scale"])
+    assert np.array_equal(ex.GetScaleSigmaSquares(), t["sigma2"])
+    assert np.array_equal(ex.GetInverseScaleSigmaSquares(), t["inv_sigma2"])
+    assert np.array_equal(ex.features_per_level(), t["nfeat"])
+    assert np.array_equal(ex.umax(), t["umax"])
+    # stage: pyramid + blur
+    for l in range(nl):
+        assert np.array_equal(ex.image_pyramid(l), oe.level(l)), "pyramid level %d" % l
+        assert np.array_equal(ex.image_pyramid(l, blurred=True), oracle.blur(oe.level(l))), "blur level %d" % l
+    # stage: FAST candidates (order-free)
+    for l in range(nl):
+        c = oe.detect_candidates(l)
+        want = np.stack([c["x"], c["y"], c["response"]], 1).astype(np.int32)
+        got = ex.debug_candidates(l)
+        want = want[np.lexsort(want.T[::-1])]
+        got = got[np.lexsort(got.T[::-1])]
+        assert np.array_equal(got, want), "candidates level %d" % l
+    # end to end
+    assert mono == omono and len(k) == len(ok_)
+    assert (ok_["response"] < 20).any() or w < 200
+    assert np.array_equal(_kp_bytes(k), _kp_bytes(ok_))
+    assert np.array_equal(d, od)
+
+
+def test_lapping_area_partition(gpu, oracle):
+    w, h = 640, 480
+    img = synth.mono_frame(w, h, 21)
+    ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    for lap in [(0, 1000), (200, 420), (0, 0), (639, 700)]:
+        mono, k, d = ex(img, lap)
+        omono, ok_, od = oe.extract(img, lap)
+        assert mono == omono
+        assert np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+
+
+def test_empty_and_unsupported(gpu):
+    ex = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    mono, k, d = ex(np.zeros((0, 0), np.uint8))
+    assert mono == -1 and len(k) == 0                      # src/ORBextractor.cc:1021
+    with pytest.raises(orbx.OrbxError) as e:
+        ex(np.zeros((100, 100), np.uint8))                 # too small for 8 levels
+    assert e.value.code == orbx.E_UNSUPPORTED
+    mono, k, d = ex(np.full((300, 400), 128, np.uint8))    # flat image: no corners at all
+    assert mono == 0 and len(k) == 0
+
+
+def test_strided_input_and_reuse(gpu, oracle):
+    w, h = 400, 300
+    big = synth.mono_frame(w + 40, h + 10, 22)
+    view = big[5:5 + h, 17:17 + w]                         # non-contiguous rows, odd alignment
+    ex = orbx.ORBextractor(600, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    oe = oracle.OracleExtractor(600, 1.2, 8, 20, 7)
+    for im in (view, synth.mono_frame(640, 480, 23), view):  # size changes between calls on one handle
+        mono, k, d = ex(im, (0, 0))
+        omono, ok_, od = oe.extract(np.ascontiguousarray(im), (0, 0))
+        assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+
+
+@pytest.mark.parametrize("w,h,nf,stream", [(640, 480, 1000, 31), (1280, 720, 1500, 32)])
+def test_stereo_matches(gpu, oracle, w, h, nf, stream):
+    L, R = synth.stereo_pair(w, h, stream)
+    exL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+    _, kL, dL = exL(L)
+    _, kR, dR = exR(R)
+    _, okL, odL = oL.extract(L)
+    _, okR, odR = oR.extract(R)
+    assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(_kp_bytes(kR), _kp_bytes(okR))
+    bf, b = 0.12 * 532.03, 0.12
+    u, dep = orbx.ComputeStereoMatches(exL, exR, bf, b)
+    ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    n = len(kL)
+    assert (ou >= 0).sum() > n // 5
+    assert np.array_equal(u[0, :n].view(np.uint32), ou.view(np.uint32))
+    assert np.array_equal(dep[0, :n].view(np.uint32), od.view(np.uint32))
+
+
+def test_batched_pairs_one_handle(gpu, oracle):
+    """Many-camera mode: 3 stereo pairs in one batch on one handle (images L0 L1 L2 R0 R1 R2)."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h, nf, npairs = 640, 480, 800, 3
+    pairs = [synth.stereo_pair(w, h, 40 + i) for i in range(npairs)]
+    imgs = np.stack([p[0] for p in pairs] + [p[1] for p in pairs])
+    dbuf = DeviceBuffer.from_numpy(imgs)
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * npairs)
+    ex.extract_batch_device(dbuf.ptr.value, 2 * npairs, w, h, w, w * h)
+    bf, b = 0.12 * 532.03, 0.12
+    u, dep = orbx.ComputeStereoMatches(ex, ex, bf, b, first_left=0, first_right=npairs, n_pairs=npairs)
+    for i in range(npairs):
+        oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+        _, okL, odL = oL.extract(pairs[i][0])
+        _, okR, odR = oR.extract(pairs[i][1])
+        _, kL, dL = ex.download(i)
+        _, kR, dR = ex.download(npairs + i)
+        assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dL, odL)
+        assert np.array_equal(_kp_bytes(kR), _kp_bytes(okR)) and np.array_equal(dR, odR)
+        ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+        n = len(kL)
+        assert np.array_equal(u[i, :n].view(np.uint32), ou.view(np.uint32))
+        assert np.array_equal(dep[i, :n].view(np.uint32), od.view(np.uint32))
+    ex.sync()
+    dbuf.free()
+
+
+def test_bf_knn2(gpu, oracle):
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    q = base[:500].copy()
+    flip = rng.integers(0, 256, q.shape, dtype=np.uint8) & rng.integers(0, 256, q.shape, dtype=np.uint8) & \
+        rng.integers(0, 256, q.shape, dtype=np.uint8)
+    q ^= flip
+    t = np.concatenate([base[100:], base[100:130]])            # duplicates -> distance ties
+    for qq, tt in ((q, t), (q[:3], t[:1]), (q[:5], t[:0]), (q[:0], t)):
+        i, d, okk = orbx.bf_knn2(qq, tt)
+        oi, od, ook = oracle.bf_knn2(qq, tt) if len(qq) else (i, d, okk)
+        assert np.array_equal(i, oi) and np.array_equal(d, od) and np.array_equal(okk, ook)
+
+
+def test_search_for_initialization(gpu, oracle):
+    w, h = 752, 480
+    f1, f2 = synth.mono_frame(w, h, 50, 0), synth.mono_frame(w, h, 50, 1)
+    ex = orbx.ORBextractor(5000, 1.2, 8, 20, 7, max_width=w, max_height=h)    # mpIniORBextractor = 5 x nFeatures
+    _, k1, d1 = ex(f1, (0, 1000))
+    _, k2, d2 = ex(f2, (0, 1000))
+    bounds = (0.0, 0.0, float(w), float(h))
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    m = orbx.ORBmatcher(0.9, True)
+    for check in (True, False):
+        m.mbCheckOrientation = check
+        n, m12, newprev = m.SearchForInitialization(k1, d1, k2, d2, bounds, prev, 100)
+        on, om12, oprev = oracle.search_init(k1, d1, k2, d2, bounds, prev, 100, 0.9, check)
+        assert on > 50
+        assert n == on and np.array_equal(m12, om12)
+        assert np.array_equal(newprev.reshape(-1).view(np.uint32), oprev.reshape(-1).view(np.uint32))
