@@ -160,7 +160,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     v.candOff = candOff;
     candOff += v.candCap;
     v.selOff = sel;
-    v.selCap = v.quota + 4 * nIni + 4;
+    v.selCap = v.quota + 4 * kMaxIni + 4;  // independent of the image size: fixed result strides
     sel += v.selCap;
     v.xcoef = xc;
     v.ycoef = yc;
