@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — ORB extract + stereo-match throughput on MI355X (BASELINE.json metric, config C3).
+
+A step = one pass of the hot path over one batch of B synthetic 1280x720 rectified stereo pairs per GPU:
+both-eye ORBextractor::operator() (pyramid, per-cell FAST, quadtree, orientation, blur, rBRIEF) followed by
+Frame::ComputeStereoMatches, all in the hand-written HIP kernels of liborbx.so, inputs resident in HBM.
+One process per GPU; frames are independent, so ranks share nothing on the data path ("scaling": "weak");
+torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
+  "cpu_baseline": the CPU oracle (single-thread port of the reference's serial semantics) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step per GPU")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--nfeatures", type=int, default=1500)
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per GPU")
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--allgather", action="store_true",
+                    help="config C5 extra: RCCL all-gather of every rank's descriptor blocks after each step")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(stage, NI, P, plevels, ncand, nsel, nmatch_in, npairs):
+    """Algorithmic HBM bytes of one batch for each kernel (SURVEY.md 8d per-unit figures x units/launch).
+    NI images, P = sum of level pixels, plevels = pixels per level, ncand / nsel = mean candidates /
+    selected keypoints per image, npairs stereo pairs."""
+    if stage == "k_resize":      # level l reads level l-1 and writes level l
+        return NI * sum(plevels[l - 1] + plevels[l] for l in range(1, len(plevels)))
+    if stage == "k_detect":      # one compulsory read of every level + 4 B per emitted candidate
+        return NI * (P + 4 * ncand)
+    if stage == "k_octree":      # candidates in (4 B), selected keypoints out (4 B)
+        return NI * (4 * ncand + 4 * nsel)
+    if stage == "k_blur":        # read P, write P
+        return NI * 2 * P
+    if stage == "k_slots":
+        return NI * 8 * nsel
+    if stage == "k_describe":    # 749 B patch (angle) + 37x37 blurred footprint + 28 B keypoint + 32 B descriptor
+        return NI * nsel * (749 + 1369 + 28 + 32)
+    if stage == "k_stereo_match":  # (28+32) B per keypoint of both eyes + 352 B SAD windows per matched keypoint
+        return npairs * (60 * 2 * nsel + 352 * nmatch_in)
+    if stage == "k_stereo_filter":
+        return npairs * 12 * nsel
+    return 0
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    import numpy as np
+    import torch  # first: liborbx.so then binds to the same HIP runtime as torch (SONAME libamdhip64.so.7)
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd import synth
+
+    W, H, B, NF = a.width, a.height, a.pairs, a.nfeatures
+    # ---- synthetic streams (deterministic): D distinct pairs tiled to B per GPU
+    D = max(1, min(a.distinct, B))
+    pairs = [synth.stereo_pair(W, H, stream=1000 * rank + i, frame=0) for i in range(D)]
+    lefts = np.stack([pairs[i % D][0] for i in range(B)])
+    rights = np.stack([pairs[i % D][1] for i in range(B)])
+    images = torch.from_numpy(np.concatenate([lefts, rights])).cuda(local_rank)  # [2B, H, W]: L0..LB-1 R0..RB-1
+    torch.cuda.synchronize()
+
+    ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local_rank)
+    bf, b = 0.12 * 532.03, 0.12  # ZED2-like rig: fx = 532.03 px, baseline 0.12 m
+    ptr = images.data_ptr()
+
+    gather_out = None
+
+    def step():
+        ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H)
+        orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
+        if a.allgather and dist is not None:
+            ex.sync()
+            d_kps, d_desc, d_cnt, d_mono, cap = ex.results_device()
+
+            class _Raw:
+                __cuda_array_interface__ = {"shape": (2 * B * cap * 32,), "typestr": "|u1", "data": (d_desc, False),
+                                            "version": 2}
+            local = torch.as_tensor(_Raw(), device="cuda")
+            nonlocal gather_out
+            if gather_out is None:
+                gather_out = torch.empty(world * local.numel(), dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(gather_out, local)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    if not a.no_profile:
+        ex.profile_enable(True)
+        ex.profile_collect()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ex.profile_collect() if not a.no_profile else {}
+    ex.profile_enable(False)
+
+    # ---- workload statistics for the algorithmic byte counts
+    lw, lh, nc, ns = ex.level_stats(0)
+    plevels = [int(x) * int(y) for x, y in zip(lw, lh)]
+    P = sum(plevels)
+    ncand_mean = float(np.mean([ex.level_stats(i)[2].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
+    nsel_mean = float(np.mean([ex.level_stats(i)[3].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
+    u, dep = None, None
+    d_u = np.zeros((1, ex.capacity), np.float32)
+    orbx._check(orbx.lib().orbx_stereo_download(ex._h, 0, orbx._p(d_u[0]), None, ex.capacity))
+    nmatch = int((d_u >= 0).sum())
+
+    value = a.gpus * B * a.steps / elapsed
+    out = {
+        "metric": "ORB extract+match stereo frames/sec @1280x720 (both-eye ORBextractor + ComputeStereoMatches)",
+        "value": round(value, 2),
+        "unit": "stereo frames/s",
+        "n_gpus": a.gpus,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(1000.0 * elapsed / a.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
+                        "ComputeStereoMatches (bf=0.12*532.03, b=0.12)" % (W, H, NF),
+            "pairs_per_step_per_gpu": B,
+            "distinct_streams_per_gpu": D,
+            "keypoints_per_image": round(nsel_mean, 1),
+            "fast_candidates_per_image": round(ncand_mean, 1),
+            "stereo_matches_pair0": nmatch,
+            "parallelism": "independent stereo pairs sharded across GPUs, no data-path collective"
+                           + (" + RCCL all-gather of descriptor blocks" if a.allgather and dist else ""),
+        },
+    }
+
+    if prof:
+        tot = sum(v[0] for v in prof.values())
+        stages = {}
+        for name, (ms, cnt) in prof.items():
+            if cnt == 0:
+                continue
+            nb = algorithmic_bytes(name, 2 * B, P, plevels, ncand_mean, nsel_mean, nmatch, B) * a.steps
+            stages[name] = {"ms_total": round(ms, 3), "launches": cnt, "avg_us": round(1000.0 * ms / cnt, 2),
+                            "share": round(ms / tot, 4), "algorithmic_GBps": round(nb / (ms * 1e-3) / 1e9, 1)}
+        dom = max(stages, key=lambda k: stages[k]["ms_total"])
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+            try:
+                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        ach = stages[dom]["algorithmic_GBps"]
+        out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "avg_launch_us": stages[dom]["avg_us"],
+                           "algorithmic_bytes_per_launch": int(algorithmic_bytes(dom, 2 * B, P, plevels, ncand_mean,
+                                                                                 nsel_mean, nmatch, B)
+                                                               / max(1, stages[dom]["launches"] // a.steps))}
+        out["stages"] = stages
+        a_pair = 2 * (2 * P + 60 * nsel_mean) + 120 * nsel_mean + 352 * nmatch
+        out["end_to_end_algorithmic_GBps"] = round(a_pair * value / a.gpus / 1e9, 2)
+
+    # ---- CPU baseline: the oracle (port of the reference's serial semantics), rank 0, N=1 only
+    if rank == 0 and a.gpus == 1 and a.cpu_pairs > 0:
+        from oracle import oracle_py as oracle
+        oL, oR = oracle.OracleExtractor(NF), oracle.OracleExtractor(NF)
+        n = 0
+        tc0 = time.perf_counter()
+        while n < a.cpu_pairs and (n < 2 or time.perf_counter() - tc0 < 25.0):
+            L, R = pairs[n % D]
+            _, kL, dL = oL.extract(L)
+            _, kR, dR = oR.extract(R)
+            oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b)
+            n += 1
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": round(n / tc, 3), "unit": "stereo frames/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same synthetic %dx%d pairs, oracle/liborb_oracle.so (single thread, "
+                                         "g++ -O2), %.1f s; host has %d cores" % (n, W, H, tc, os.cpu_count())}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -139,6 +139,29 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
                                    float min_y, float max_x, float max_y, float* prev_matched,
                                    int32_t* matches12, int window_size, float nnratio, int check_orientation);
 
+/* ---- measurement ------------------------------------------------------------------------------------ */
+
+/* Per-kernel timing with HIP events recorded on the handle's own stream around every kernel launch (the
+ * numbers bench.py's roofline object is built from).  Stages: */
+#define ORBX_STAGE_RESIZE 0        /* 7 launches per extraction (one per pyramid level >= 1) */
+#define ORBX_STAGE_DETECT 1
+#define ORBX_STAGE_OCTREE 2
+#define ORBX_STAGE_BLUR 3
+#define ORBX_STAGE_SLOTS 4
+#define ORBX_STAGE_DESCRIBE 5
+#define ORBX_STAGE_STEREO_MATCH 6
+#define ORBX_STAGE_STEREO_FILTER 7
+#define ORBX_NUM_STAGES 8
+int orbx_profile_enable(orbx_extractor* ex, int on);
+/* Synchronises the stream, adds up the elapsed milliseconds / launch counts per stage since the last
+ * collect and resets the log.  ms and launches hold ORBX_NUM_STAGES entries. */
+int orbx_profile_collect(orbx_extractor* ex, double* ms, int32_t* launches);
+const char* orbx_stage_name(int stage);
+/* Pyramid geometry of the last configured image size: w/h per level (nlevels entries each) and the number
+ * of FAST candidates / selected keypoints of image `image` per level (device counters, synchronises). */
+int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int32_t* n_candidates,
+                     int32_t* n_selected);
+
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 
 /* Runs the quadtree's host/device introsort replica (csrc/orbx_introsort.h) on the host: sorts n 64-bit

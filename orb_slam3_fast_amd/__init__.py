@@ -21,6 +21,7 @@ assert KP_DTYPE.itemsize == 28  # cv::KeyPoint
 
 OK, E_EMPTY, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # src/ORBmatcher.cc:35-37
+NUM_STAGES = 8
 
 
 class OrbxError(RuntimeError):
@@ -63,6 +64,11 @@ def lib():
         L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
+        L.orbx_profile_enable.argtypes = [vp, i]
+        L.orbx_profile_collect.argtypes = [vp, vp, vp]
+        L.orbx_stage_name.restype = C.c_char_p
+        L.orbx_stage_name.argtypes = [i]
+        L.orbx_level_stats.argtypes = [vp, i, vp, vp, vp, vp]
         L.orbx_debug_introsort.argtypes = [vp, i]
         L.orbx_debug_introsort.restype = None
         _lib = L
@@ -185,6 +191,23 @@ class ORBextractor:
         _check(lib().orbx_batch_results_device(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d),
                                                C.byref(cap)))
         return a.value, b.value, c.value, d.value, cap.value
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        _check(lib().orbx_profile_enable(self._h, int(on)))
+
+    def profile_collect(self):
+        """{stage name: (total ms, launches)} since the last collect (HIP events on the launch stream)."""
+        ms = np.zeros(NUM_STAGES, np.float64)
+        cnt = np.zeros(NUM_STAGES, np.int32)
+        _check(lib().orbx_profile_collect(self._h, _p(ms), _p(cnt)))
+        return {lib().orbx_stage_name(s).decode(): (float(ms[s]), int(cnt[s])) for s in range(NUM_STAGES)}
+
+    def level_stats(self, image=0):
+        L = self.nlevels
+        w, h, nc, ns = (np.zeros(L, np.int32) for _ in range(4))
+        _check(lib().orbx_level_stats(self._h, image, _p(w), _p(h), _p(nc), _p(ns)))
+        return w, h, nc, ns
 
     # ---- mvImagePyramid (include/ORBextractor.h:86)
     def image_pyramid(self, level, image=0, blurred=False):

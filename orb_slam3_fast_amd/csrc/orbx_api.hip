@@ -77,7 +77,46 @@ struct orbx_extractor {
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
   int stereoPairs = 0;
+  // per-launch HIP event log (orbx_profile_*)
+  bool profiling = false;
+  std::vector<hipEvent_t> evPool;
+  size_t evCursor = 0;
+  struct EvRec { int stage; size_t e0, e1; };
+  std::vector<EvRec> evLog;
+  hipEvent_t next_event() {
+    if (evCursor == evPool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      evPool.push_back(e);
+    }
+    return evPool[evCursor++];
+  }
 };
+
+namespace {
+// Brackets one kernel launch with events on the launch stream when profiling is on.
+struct StageTimer {
+  orbx_extractor* ex;
+  hipStream_t s;
+  int stage;
+  size_t i0 = 0;
+  bool on;
+  StageTimer(orbx_extractor* ex_, hipStream_t s_, int stage_) : ex(ex_), s(s_), stage(stage_), on(ex_->profiling) {
+    if (on) {
+      hipEvent_t e = ex->next_event();
+      i0 = ex->evCursor - 1;
+      if (e) (void)hipEventRecord(e, s);
+    }
+  }
+  ~StageTimer() {
+    if (on) {
+      hipEvent_t e = ex->next_event();
+      if (e) (void)hipEventRecord(e, s);
+      ex->evLog.push_back({stage, i0, ex->evCursor - 1});
+    }
+  }
+};
+}  // namespace
 
 namespace {
 
@@ -277,13 +316,30 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
   else
     HIPC(hipMemsetAsync(ex->d_lap.p, 0, (size_t)n * 2 * sizeof(int), s));
-  for (int l = 1; l < g.nlevels; l++)
+  for (int l = 1; l < g.nlevels; l++) {
+    StageTimer t(ex, s, ORBX_STAGE_RESIZE);
     HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, s));
-  HIPC(launch_detect(g, ex->pyr, n, ex->d_cand.p, ex->d_candCount.p, s));
-  HIPC(launch_octree(g, n, ex->d_cand.p, ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
-  HIPC(launch_blur(g, ex->pyr, n, s));
-  HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
-  HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, ex->d_slot.p, ex->d_kps.p, ex->d_desc.p, s));
+  }
+  {
+    StageTimer t(ex, s, ORBX_STAGE_DETECT);
+    HIPC(launch_detect(g, ex->pyr, n, ex->d_cand.p, ex->d_candCount.p, s));
+  }
+  {
+    StageTimer t(ex, s, ORBX_STAGE_OCTREE);
+    HIPC(launch_octree(g, n, ex->d_cand.p, ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
+  }
+  {
+    StageTimer t(ex, s, ORBX_STAGE_BLUR);
+    HIPC(launch_blur(g, ex->pyr, n, s));
+  }
+  {
+    StageTimer t(ex, s, ORBX_STAGE_SLOTS);
+    HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
+  }
+  {
+    StageTimer t(ex, s, ORBX_STAGE_DESCRIBE);
+    HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, ex->d_slot.p, ex->d_kps.p, ex->d_desc.p, s));
+  }
   return ORBX_OK;
 }
 
@@ -379,6 +435,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_xofs.free(); ex->d_yofs.free();
   ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free();
+  for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
@@ -553,7 +610,14 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
   a.uRight = left->d_uR.p;
   a.depth = left->d_depth.p;
   a.sad = left->d_sad.p;
-  HIPC(launch_stereo(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));
+  {
+    StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
+    HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));
+  }
+  {
+    StageTimer t(left, left->stream, ORBX_STAGE_STEREO_FILTER);
+    HIPC(launch_stereo_filter(a, n_pairs, left->stream));
+  }
   return ORBX_OK;
 }
 
@@ -657,6 +721,54 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); result.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
+}
+
+int orbx_profile_enable(orbx_extractor* ex, int on) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  ex->profiling = on != 0;
+  return ORBX_OK;
+}
+
+int orbx_profile_collect(orbx_extractor* ex, double* ms, int32_t* launches) {
+  if (!ex || !ms || !launches) return fail(ORBX_E_BADARG, "null argument");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  for (int i = 0; i < ORBX_NUM_STAGES; i++) {
+    ms[i] = 0;
+    launches[i] = 0;
+  }
+  for (const auto& r : ex->evLog) {
+    float t = 0;
+    HIPC(hipEventElapsedTime(&t, ex->evPool[r.e0], ex->evPool[r.e1]));
+    ms[r.stage] += t;
+    launches[r.stage]++;
+  }
+  ex->evLog.clear();
+  ex->evCursor = 0;
+  return ORBX_OK;
+}
+
+const char* orbx_stage_name(int stage) {
+  static const char* names[ORBX_NUM_STAGES] = {"k_resize", "k_detect", "k_octree", "k_blur",
+                                                "k_slots",  "k_describe", "k_stereo_match", "k_stereo_filter"};
+  return stage >= 0 && stage < ORBX_NUM_STAGES ? names[stage] : "?";
+}
+
+int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int32_t* n_candidates,
+                     int32_t* n_selected) {
+  if (!ex || ex->curW == 0 || image < 0 || image >= ex->lastN) return fail(ORBX_E_BADARG, "bad argument");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  const int L = ex->g.nlevels;
+  for (int l = 0; l < L; l++) {
+    if (w) w[l] = ex->g.lv[l].w;
+    if (h) h[l] = ex->g.lv[l].h;
+  }
+  if (n_candidates)
+    HIPC(hipMemcpy(n_candidates, ex->d_candCount.p + image * L, L * sizeof(int), hipMemcpyDeviceToHost));
+  if (n_selected)
+    HIPC(hipMemcpy(n_selected, ex->d_selCount.p + image * L, L * sizeof(int), hipMemcpyDeviceToHost));
+  return ORBX_OK;
 }
 
 // Test hook: the device quadtree's introsort replica, run on the host (compared with std::sort in tests).

@@ -90,8 +90,9 @@ struct StereoArgs {
   float* depth;
   int* sad;                      // [pairs][capL] best SAD or -1
 };
-hipError_t launch_stereo(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                         hipStream_t s);
+hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
+                               hipStream_t s);
+hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
                           uint8_t* ok, hipStream_t s);
 struct InitArgs {

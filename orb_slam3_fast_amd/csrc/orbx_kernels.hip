@@ -1099,11 +1099,12 @@ __global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a, int npow2) 
   }
 }
 
-hipError_t launch_stereo(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                         hipStream_t s) {
+hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
+                               hipStream_t s) {
   hipLaunchKernelGGL(k_stereo_match, dim3((a.capL + 3) / 4, npairs), dim3(256), 0, s, g, pl, pr, a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
+  return hipGetLastError();
+}
+hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) {
   int np2 = 1;
   while (np2 < a.capL) np2 <<= 1;
   hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), (size_t)np2 * 4, s, a, np2);
