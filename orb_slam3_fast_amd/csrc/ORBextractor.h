@@ -1,0 +1,217 @@
+// ORBextractor.h — C++ host mirror of ORB_SLAM3::ORBextractor over the C ABI of include/orbx.h.
+//
+// Same class name, constructor arguments, operator() signature, getters and public mvImagePyramid member as
+// the reference (include/ORBextractor.h:49-118 of hellovuong/ORB_SLAM3_FAST), so Frame / Tracking call sites
+// (src/Frame.cc:549-560, src/Tracking.cc:628-637) compile unchanged against it.  Header-only; it contains no
+// pixel arithmetic — every stage runs in the HIP kernels of liborbx.so, and construction throws when no
+// MI355X is visible (no CPU fallback).
+//
+// With OpenCV headers on the include path the cv:: types are used directly; without them (this repo's own
+// tests) a minimal layout-compatible stand-in (orbx::cvlite) keeps the signatures.
+#ifndef ORBX_SHIM_ORBEXTRACTOR_H
+#define ORBX_SHIM_ORBEXTRACTOR_H
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+
+#if defined(__has_include)
+#if __has_include(<opencv2/core.hpp>) && !defined(ORBX_NO_OPENCV)
+#include <opencv2/core.hpp>
+#define ORBX_HAVE_OPENCV 1
+#endif
+#endif
+
+namespace orbx {
+namespace cvlite {
+// Minimal stand-ins with cv::KeyPoint's memory layout and the handful of cv::Mat members the shim needs.
+struct Point2f {
+  float x = 0, y = 0;
+  Point2f() {}
+  Point2f(float x_, float y_) : x(x_), y(y_) {}
+};
+struct KeyPoint {
+  Point2f pt;
+  float size = 0, angle = -1, response = 0;
+  int octave = 0, class_id = -1;
+};
+static_assert(sizeof(KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint layout");
+class Mat {
+ public:
+  int rows = 0, cols = 0;
+  size_t step = 0;
+  uint8_t* data = nullptr;
+  Mat() {}
+  Mat(int r, int c, uint8_t* ext, size_t step_) : rows(r), cols(c), step(step_), data(ext) {}
+  void create(int r, int c) {
+    buf_ = std::shared_ptr<uint8_t>(new uint8_t[(size_t)r * c], std::default_delete<uint8_t[]>());
+    rows = r;
+    cols = c;
+    step = (size_t)c;
+    data = buf_.get();
+  }
+  void release() {
+    buf_.reset();
+    rows = cols = 0;
+    step = 0;
+    data = nullptr;
+  }
+  bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+  uint8_t* ptr(int r = 0) { return data + (size_t)r * step; }
+  const uint8_t* ptr(int r = 0) const { return data + (size_t)r * step; }
+
+ private:
+  std::shared_ptr<uint8_t> buf_;
+};
+}  // namespace cvlite
+}  // namespace orbx
+
+namespace ORB_SLAM3 {
+
+#ifdef ORBX_HAVE_OPENCV
+namespace ocv {
+using Mat = cv::Mat;
+using KeyPoint = cv::KeyPoint;
+using Point2f = cv::Point2f;
+using InputArray = cv::InputArray;
+using OutputArray = cv::OutputArray;
+}  // namespace ocv
+#else
+namespace ocv {
+using Mat = orbx::cvlite::Mat;
+using KeyPoint = orbx::cvlite::KeyPoint;
+using Point2f = orbx::cvlite::Point2f;
+using InputArray = const orbx::cvlite::Mat&;
+using OutputArray = orbx::cvlite::Mat&;
+}  // namespace ocv
+#endif
+static_assert(sizeof(ocv::KeyPoint) == sizeof(orbx_keypoint), "KeyPoint must be 28 bytes like cv::KeyPoint");
+
+class ORBextractor {
+ public:
+  enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+  // src/ORBextractor.cc:408-469.  max_width/max_height bound the images this instance will see (device
+  // buffers are sized once); the reference has no such limit because it reallocates per call.
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int max_width = 1920,
+               int max_height = 1200, int device = 0)
+      : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST),
+        minThFAST(minThFAST) {
+    orbx_params p{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
+    int rc = orbx_extractor_create(&p, max_width, max_height, 1, device, &h_);
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error());
+    mvScaleFactor.resize(nlevels);
+    mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    umax.resize(16);
+    orbx_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                    mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data());
+    mvImagePyramid.resize(nlevels);
+  }
+  ~ORBextractor() { orbx_extractor_destroy(h_); }
+  ORBextractor(const ORBextractor&) = delete;
+  ORBextractor& operator=(const ORBextractor&) = delete;
+
+  // src/ORBextractor.cc:1015-1106.  Returns monoIndex, -1 for an empty image; throws on device errors
+  // (the reference can throw cv::Exception from the same call).  The mask is ignored, as in the reference.
+  int operator()(ocv::InputArray _image, ocv::InputArray _mask, std::vector<ocv::KeyPoint>& _keypoints,
+                 ocv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+    (void)_mask;
+#ifdef ORBX_HAVE_OPENCV
+    if (_image.empty()) return -1;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    const uint8_t* data = image.data;
+    const int w = image.cols, h = image.rows;
+    const ptrdiff_t step = (ptrdiff_t)image.step;
+#else
+    if (_image.empty()) return -1;
+    const uint8_t* data = _image.data;
+    const int w = _image.cols, h = _image.rows;
+    const ptrdiff_t step = (ptrdiff_t)_image.step;
+#endif
+    const int cap = nfeatures + 40 * nlevels;
+    kp_.resize(cap);
+    desc_.resize((size_t)cap * 32);
+    int n = 0;
+    const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0;
+    const int lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+    const int mono = orbx_extract(h_, data, w, h, step, lap0, lap1, kp_.data(), desc_.data(), cap, &n);
+    if (mono == ORBX_E_EMPTY) return -1;
+    if (mono < 0) throw std::runtime_error(std::string("ORBextractor::operator(): ") + orbx_last_error());
+    _keypoints.resize(n);
+    if (n) std::memcpy(static_cast<void*>(_keypoints.data()), kp_.data(), (size_t)n * sizeof(orbx_keypoint));
+    if (n == 0) {
+      _descriptors.release();
+    } else {
+#ifdef ORBX_HAVE_OPENCV
+      _descriptors.create(n, 32, CV_8U);
+      cv::Mat d = _descriptors.getMat();
+      for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc_[(size_t)i * 32], 32);
+#else
+      _descriptors.create(n, 32);
+      std::memcpy(_descriptors.data, desc_.data(), (size_t)n * 32);
+#endif
+    }
+    if (mbKeepHostPyramid) SyncImagePyramid();
+    return mono;
+  }
+
+  int inline GetLevels() { return nlevels; }
+  float inline GetScaleFactor() { return (float)scaleFactor; }
+  std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+  std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+  std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+  // Public in the reference (include/ORBextractor.h:86) and read by Frame::ComputeStereoMatches.  The
+  // pyramid lives in HBM; host copies are made only on request (SyncImagePyramid / mbKeepHostPyramid),
+  // because the stereo matcher of this repo reads the device copy (ComputeStereoMatches in ORBmatcher.h).
+  std::vector<ocv::Mat> mvImagePyramid;
+  bool mbKeepHostPyramid = false;
+  void SyncImagePyramid() {
+    for (int l = 0; l < nlevels; l++) {
+      int w = 0, h = 0;
+      if (orbx_pyramid_level(h_, 0, l, 0, nullptr, 0, &w, &h) != ORBX_OK)
+        throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+#ifdef ORBX_HAVE_OPENCV
+      mvImagePyramid[l].create(h, w, CV_8UC1);
+#else
+      mvImagePyramid[l].create(h, w);
+#endif
+      if (orbx_pyramid_level(h_, 0, l, 0, mvImagePyramid[l].ptr(0), (ptrdiff_t)mvImagePyramid[l].step, &w, &h) != ORBX_OK)
+        throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+    }
+  }
+
+  orbx_extractor* handle() { return h_; }
+
+ protected:
+  int nfeatures;
+  double scaleFactor;
+  int nlevels;
+  int iniThFAST;
+  int minThFAST;
+  std::vector<int> mnFeaturesPerLevel;
+  std::vector<int> umax;
+  std::vector<float> mvScaleFactor;
+  std::vector<float> mvInvScaleFactor;
+  std::vector<float> mvLevelSigma2;
+  std::vector<float> mvInvLevelSigma2;
+
+ private:
+  orbx_extractor* h_ = nullptr;
+  std::vector<orbx_keypoint> kp_;
+  std::vector<uint8_t> desc_;
+};
+
+}  // namespace ORB_SLAM3
+
+#endif  // ORBX_SHIM_ORBEXTRACTOR_H

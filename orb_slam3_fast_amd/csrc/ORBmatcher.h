@@ -1,0 +1,90 @@
+// ORBmatcher.h — C++ host mirror of the hot-path part of ORB_SLAM3::ORBmatcher and of the two Frame
+// stereo-association members, over the C ABI of include/orbx.h.
+//
+// Reference: include/ORBmatcher.h:36-101, src/ORBmatcher.cc:618-764,1920-1973 (SearchForInitialization,
+// ComputeThreeMaxima, DescriptorDistance); src/Frame.cc:921-1084 (ComputeStereoMatches),
+// src/Frame.cc:1273-1304 (brute-force kNN part of ComputeStereoFishEyeMatches).
+//
+// The reference's methods take Frame&; Frame itself (poses, map points, IMU) is out of scope, so the
+// mirror takes the few Frame members those methods read (FrameView).  INTEGRATION.md shows the three-line
+// forwarding overloads a maintainer adds to keep `matcher.SearchForInitialization(F1, F2, ...)` call sites.
+#ifndef ORBX_SHIM_ORBMATCHER_H
+#define ORBX_SHIM_ORBMATCHER_H
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ORBextractor.h"
+
+namespace ORB_SLAM3 {
+
+// The members of Frame that SearchForInitialization reads: mvKeysUn, mDescriptors and the image bounds
+// mnMinX/mnMinY/mnMaxX/mnMaxY used by the 64x48 feature grid (include/Frame.h:249-272,314-319).
+struct FrameView {
+  const ocv::KeyPoint* mvKeysUn = nullptr;
+  const uint8_t* mDescriptors = nullptr;  // N x 32, continuous
+  int N = 0;
+  float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+};
+
+class ORBmatcher {
+ public:
+  static const int TH_LOW = 50;    // src/ORBmatcher.cc:35-37
+  static const int TH_HIGH = 100;
+  static const int HISTO_LENGTH = 30;
+
+  ORBmatcher(float nnratio = 0.6, bool checkOri = true, int device = 0)
+      : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
+
+  // src/ORBmatcher.cc:1959-1973 (two 32-byte descriptor rows).
+  static int DescriptorDistance(const ocv::Mat& a, const ocv::Mat& b) { return orbx_hamming256(a.ptr(0), b.ptr(0)); }
+  static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return orbx_hamming256(a, b); }
+
+  // src/ORBmatcher.cc:618-764, serial-order semantics.
+  int SearchForInitialization(const FrameView& F1, const FrameView& F2, std::vector<ocv::Point2f>& vbPrevMatched,
+                              std::vector<int>& vnMatches12, int windowSize = 10) {
+    if ((int)vbPrevMatched.size() != F1.N) throw std::invalid_argument("vbPrevMatched.size() != F1.N");
+    vnMatches12.assign(F1.N, -1);
+    static_assert(sizeof(ocv::Point2f) == 8, "Point2f is two floats");
+    const int n = orbx_search_for_initialization(
+        device_, reinterpret_cast<const orbx_keypoint*>(F1.mvKeysUn), F1.mDescriptors, F1.N,
+        reinterpret_cast<const orbx_keypoint*>(F2.mvKeysUn), F2.mDescriptors, F2.N, F2.mnMinX, F2.mnMinY, F2.mnMaxX,
+        F2.mnMaxY, reinterpret_cast<float*>(vbPrevMatched.data()), vnMatches12.data(), windowSize, mfNNratio,
+        mbCheckOrientation ? 1 : 0);
+    if (n < 0) throw std::runtime_error(std::string("SearchForInitialization: ") + orbx_last_error());
+    return n;
+  }
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+  int device_;
+};
+
+// Frame::ComputeStereoMatches (src/Frame.cc:921-1084) on the device-resident results of the two
+// extractors' last operator() calls.  mbf / mb as in Frame; fills mvuRight / mvDepth (size N = left count).
+inline void ComputeStereoMatches(ORBextractor& left, ORBextractor& right, int N, float mbf, float mb,
+                                 std::vector<float>& mvuRight, std::vector<float>& mvDepth) {
+  if (orbx_stereo_match_batch(left.handle(), 0, right.handle(), 0, 1, mbf, mb) != ORBX_OK)
+    throw std::runtime_error(std::string("ComputeStereoMatches: ") + orbx_last_error());
+  mvuRight.assign(N, -1.0f);
+  mvDepth.assign(N, -1.0f);
+  if (N && orbx_stereo_download(left.handle(), 0, mvuRight.data(), mvDepth.data(), N) != ORBX_OK)
+    throw std::runtime_error(std::string("ComputeStereoMatches: ") + orbx_last_error());
+}
+
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) + Lowe ratio of Frame::ComputeStereoFishEyeMatches
+// (src/Frame.cc:46,1293-1302).  idx2/dist2: nQ x 2; ratio_ok[q] = 1 when (*it)[0].distance < (*it)[1].distance*0.7.
+inline void BFKnnMatch2(const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, std::vector<int>& idx2,
+                        std::vector<int>& dist2, std::vector<uint8_t>& ratio_ok, int device = 0) {
+  idx2.assign((size_t)nQ * 2, -1);
+  dist2.assign((size_t)nQ * 2, -1);
+  ratio_ok.assign(nQ, 0);
+  if (orbx_bf_knn2(device, descQ, nQ, descT, nT, idx2.data(), dist2.data(), ratio_ok.data()) != ORBX_OK)
+    throw std::runtime_error(std::string("BFKnnMatch2: ") + orbx_last_error());
+}
+
+}  // namespace ORB_SLAM3
+
+#endif  // ORBX_SHIM_ORBMATCHER_H

@@ -69,9 +69,9 @@ struct orbx_extractor {
   Pyr pyr{};
   int lastN = 0;
   DevBuf<uint8_t> d_pyr, d_blur, d_stage, d_desc;
-  DevBuf<uint32_t> d_cand, d_sel;
+  DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
   DevBuf<uint16_t> d_knode;
-  DevBuf<int> d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
+  DevBuf<int> d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
   DevBuf<short> d_xab, d_yab;
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
@@ -166,7 +166,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
   g.nlevels = L;
   g.iniTh = ex->prm.ini_th_fast;
   g.minTh = ex->prm.min_th_fast;
-  long long off = 0, candOff = 0;
+  long long off = 0, candOff = 0, cellOff = 0;
   int cells = 0, sel = 0, xc = 0, yc = 0;
   int maxCW = 0, maxCH = 0;
   for (int l = 0; l < L; l++) {
@@ -198,6 +198,9 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     v.candCap = (((int)width + v.nCols + 1) / 2 + 1) * (((int)height + v.nRows + 1) / 2 + 1);
     v.candOff = candOff;
     candOff += v.candCap;
+    v.cellCap = ((v.wCell + 1) / 2) * ((v.hCell + 1) / 2);  // NMS keeps at most one pixel per 2x2 block
+    v.cellOff = cellOff;
+    cellOff += (long long)v.nCols * v.nRows * v.cellCap;
     v.selOff = sel;
     v.selCap = v.quota + 4 * kMaxIni + 4;  // independent of the image size: fixed result strides
     sel += v.selCap;
@@ -219,15 +222,16 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     return ORBX_E_UNSUPPORTED;
   }
   g.totalCells = cells;
-  g.tileP = align_up(maxCW + 6 + 3, 4);
+  g.tileP = 4 * ((maxCW + 3) / 4 + 3);   // quads per row + 2 dwords of read-ahead + 1
   g.tileH = maxCH + 6;
-  g.scoreP = align_up(maxCW + 2, 4);
+  g.scoreP = 4 * ((maxCW + 3) / 4 + 2);  // 1 dword zero pad left + quads + 1 dword zero pad right
   g.scoreH = maxCH + 2;
   g.listCap = align_up((long long)maxCW * maxCH, 8);
   g.selImg = sel;
   g.outCap = sel;
   g.pyrImg = off;
   g.candImg = candOff;
+  g.cellImg = cellOff;
   if (octree_lds_bytes(g) > 160 * 1024 - 2048) {
     why = "nfeatures too large for the LDS-resident quadtree";
     return ORBX_E_UNSUPPORTED;
@@ -278,12 +282,14 @@ int configure(orbx_extractor* ex, int w, int h) {
   int rc = build_geom(ex, w, h, g, why);
   if (rc != ORBX_OK) return fail(rc, why);
   const Geom& m = ex->gmax;
-  if (g.pyrImg > m.pyrImg || g.candImg > m.candImg || g.selImg > m.selImg)
+  if (g.pyrImg > m.pyrImg || g.candImg > m.candImg || g.selImg > m.selImg || g.cellImg > m.cellImg ||
+      g.totalCells > m.totalCells)
     return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
   g.outCap = m.outCap;  // keep result strides fixed for the life of the handle
   g.selImg = m.selImg;
   g.pyrImg = m.pyrImg;
   g.candImg = m.candImg;
+  g.cellImg = m.cellImg;
   std::vector<int> xofs, yofs;
   std::vector<short> xab, yab;
   build_coefs(g, xofs, xab, yofs, yab);
@@ -311,7 +317,6 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->pyr.blur = ex->d_blur.p;
   ex->lastN = n;
   hipStream_t s = ex->stream;
-  HIPC(hipMemsetAsync(ex->d_candCount.p, 0, (size_t)n * g.nlevels * sizeof(int), s));
   if (lap)
     HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
   else
@@ -322,11 +327,12 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   }
   {
     StageTimer t(ex, s, ORBX_STAGE_DETECT);
-    HIPC(launch_detect(g, ex->pyr, n, ex->d_cand.p, ex->d_candCount.p, s));
+    HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, s));
   }
   {
     StageTimer t(ex, s, ORBX_STAGE_OCTREE);
-    HIPC(launch_octree(g, n, ex->d_cand.p, ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
+    HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,
+                       ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
   }
   {
     StageTimer t(ex, s, ORBX_STAGE_BLUR);
@@ -404,6 +410,9 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_blur.alloc(B * m.pyrImg + 256));
   ok(ex->d_stage.alloc(B * (size_t)ex->stagePitch * max_height + 256));
   ok(ex->d_cand.alloc(B * m.candImg));
+  ok(ex->d_cellCand.alloc(B * m.cellImg));
+  ok(ex->d_cellCount.alloc(B * m.totalCells));
+  ok(ex->d_cellPrefix.alloc(B * m.totalCells));
   ok(ex->d_knode.alloc(B * m.candImg));
   ok(ex->d_candCount.alloc(B * m.nlevels));
   ok(ex->d_sel.alloc(B * m.selImg));
@@ -431,7 +440,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   if (!ex) return;
   (void)hipSetDevice(ex->device);
   if (ex->stream) (void)hipStreamSynchronize(ex->stream);
-  ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free();
+  ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_xofs.free(); ex->d_yofs.free();
   ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free();

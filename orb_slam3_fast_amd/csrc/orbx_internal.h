@@ -18,11 +18,13 @@ struct LevelDev {
   int nCols, nRows, wCell, hCell;  // FAST cell grid, src/ORBextractor.cc:904-907
   int cellStart;                 // number of cells in coarser-indexed levels before this one
   int quota;                     // mnFeaturesPerLevel[l]
-  int candCap;                   // capacity of the candidate list of this level (per image)
+  int candCap;                   // capacity of the dense candidate list of this level (per image)
+  int cellCap;                   // slots per FAST cell in the sparse per-cell candidate store
   int selOff, selCap;            // slot range of this level in the per-image selected-keypoint block
   int xcoef, ycoef;              // offsets into the resize coefficient tables (level l from l-1)
   long long off;                 // byte offset of the level inside one image's pyramid block
-  long long candOff;             // entry offset of the candidate list inside one image's block
+  long long candOff;             // entry offset of the dense candidate list inside one image's block
+  long long cellOff;             // entry offset of this level's per-cell slots inside one image's block
   float scale;                   // mvScaleFactor[l]
   float patch;                   // (float)(int)(31 * scale), :984
 };
@@ -36,7 +38,8 @@ struct Geom {
   int outCap;                    // output keypoint capacity per image
   int pad_;
   long long pyrImg;              // bytes per image of the internal pyramid block
-  long long candImg;             // candidate entries per image
+  long long candImg;             // dense candidate entries per image
+  long long cellImg;             // per-cell slot entries per image
   LevelDev lv[ORBX_MAX_LEVELS];
 };
 
@@ -69,9 +72,10 @@ __host__ __device__ inline int key_r(uint32_t k) { return k >> 24; }
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
                          const int* yofs, const short* yab, hipStream_t s);
-hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cand, int* candCount, hipStream_t s);
-hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cand, const int* candCount, uint16_t* knode,
-                         uint32_t* sel, int* selCount, hipStream_t s);
+hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, hipStream_t s);
+hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
+                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
+                         hipStream_t s);
 hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, hipStream_t s);
 hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int* selCount, const int* lap,
                         int* slot, int* nOut, int* mono, hipStream_t s);

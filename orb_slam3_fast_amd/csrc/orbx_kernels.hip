@@ -74,10 +74,17 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 }
 
 // ================================================================================================ detect
-// FAST-9-16 helpers on an LDS tile with row pitch TP.  Ring order = OpenCV's.
-#define ORBX_RING(F)                                                                                       \
-  F(0, 0, 3) F(1, 1, 3) F(2, 2, 2) F(3, 3, 1) F(4, 3, 0) F(5, 3, -1) F(6, 2, -2) F(7, 1, -3) F(8, 0, -3)   \
-  F(9, -1, -3) F(10, -2, -2) F(11, -3, -1) F(12, -3, 0) F(13, -3, 1) F(14, -2, 2) F(15, -1, 3)
+// FAST-9-16 on an LDS tile, four horizontally adjacent pixels per lane.
+//
+// Layout: the cell ROI (cell + 3 px FAST halo each side) sits in LDS with ROI column 0 on a dword boundary
+// (the loader funnel-shifts the unaligned global row).  A lane owns a "quad" of 4 detectable pixels; the 7x10
+// byte neighbourhood it needs is 7 rows x 3 dwords, read with 21 ds_read_b32 and kept in registers, so every
+// ring byte is a compile-time (register, byte) pair.  Per ring pixel and polarity: one subtract and one
+// v_alignbit funnel shift that appends the sign bit to a 16-bit arc mask; a 9-arc exists iff the doubled
+// mask has 9 contiguous ones (shift-and ladder).
+constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+constexpr int kListCap = 1024;  // LDS corner list of k_detect (flushed when it could overflow)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
   uint32_t d = m | (m << 16);
@@ -88,29 +95,31 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits
   return (x & 0xFFFFu) != 0;
 }
 
-__device__ __forceinline__ bool fast_is_corner(const uint8_t* c, int TP, int t) {
-  const int v = c[0];
-  const int hi = v + t, lo = v - t;
-  uint32_t br = 0, dk = 0;
-#define F(k, dx, dy)                 \
-  {                                  \
-    const int r = c[(dy)*TP + (dx)]; \
-    br |= (uint32_t)(r > hi) << k;   \
-    dk |= (uint32_t)(r < lo) << k;   \
+// Pixel slot P (0..3) of a quad: is the pixel a corner at threshold t?  r[row][dword] holds ROI bytes
+// [4j, 4j+12) of rows yd .. yd+6; the pixel is at row 3, byte 3 + P.
+template <int P>
+__device__ __forceinline__ bool fast_px(const uint32_t (&r)[7][3], int t) {
+  const int c = (r[3][(3 + P) >> 2] >> (8 * ((3 + P) & 3))) & 0xFF;
+  const int hi = c + t, lo = c - t;
+  uint32_t ab = 0, ad = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int col = 3 + P + kRingDX[k];
+    const int v = (r[3 + kRingDY[k]][col >> 2] >> (8 * (col & 3))) & 0xFF;
+    ab = __builtin_amdgcn_alignbit(ab, (uint32_t)(hi - v), 31);  // (ab << 1) | (v > hi)
+    ad = __builtin_amdgcn_alignbit(ad, (uint32_t)(v - lo), 31);  // (ad << 1) | (v < lo)
   }
-  ORBX_RING(F)
-#undef F
-  return has_arc9(br) || has_arc9(dk);
+  return has_arc9(ab & 0xFFFFu) || has_arc9(ad & 0xFFFFu);
 }
 
-// M = max over the 16 nine-pixel arcs of the arc's minimum one-signed contrast; cornerScore = M - 1.
-__device__ __forceinline__ int fast_contrast(const uint8_t* c, int TP) {
-  const int v = c[0];
+// cornerScore of a known corner: M - 1, M = max over the 16 nine-pixel arcs of the arc's minimum
+// one-signed contrast, by sliding min / max with doubling.  c8 points at the pixel in the LDS tile (pitch TP).
+__device__ __forceinline__ int fast_score(const uint8_t* c8, int TP) {
+  const int c = c8[0];
   int d[16];
-#define F(k, dx, dy) d[k] = v - (int)c[(dy)*TP + (dx)];
-  ORBX_RING(F)
-#undef F
-  int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) d[k] = c - (int)c8[kRingDY[k] * TP + kRingDX[k]];
+  int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     mn2[i] = min(d[i], d[(i + 1) & 15]);
@@ -121,24 +130,24 @@ __device__ __forceinline__ int fast_contrast(const uint8_t* c, int TP) {
     mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
     mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
   }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    mn8[i] = min(mn4[i], mn4[(i + 4) & 15]);
-    mx8[i] = max(mx4[i], mx4[(i + 4) & 15]);
-  }
   int best_dark = -256, best_bright = 256;  // max of arc-min(d), min of arc-max(d)
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    best_dark = max(best_dark, min(mn8[i], d[(i + 8) & 15]));
-    best_bright = min(best_bright, max(mx8[i], d[(i + 8) & 15]));
+    const int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+    const int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+    best_dark = max(best_dark, mn9);
+    best_bright = min(best_bright, mx9);
   }
-  return max(best_dark, -best_bright);
+  return max(best_dark, -best_bright) - 1;
 }
 
 // One wave per FAST cell (workgroup = 64 threads, so __syncthreads() is a wave barrier).
-// LDS: image tile (cell + 6 px halo), u8 score tile with a zero ring, list of corner positions + scores.
-__global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cand,
-                                               int* __restrict__ candCount) {
+// Pass 1 runs at iniThFAST; only a cell whose post-NMS set is empty is redone at minThFAST (:942-959).
+// The NMS needs no threshold masking: a neighbour that is not a corner at t has score < t <= the centre's.
+// Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
+// ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
+__global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
+                                               int* __restrict__ cellCount, int ablate) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
@@ -146,27 +155,35 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   int l = 0;
   while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellStart) l++;
   const LevelDev L = g.lv[l];
+  int* myCount = cellCount + (long long)img * g.totalCells + cell;
   cell -= L.cellStart;
   const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
   const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
   const int iniY = kBorder + ci * L.hCell, iniX = kBorder + cj * L.wCell;
-  if (iniY >= maxBY - 3 || iniX >= maxBX - 6) return;  // src/ORBextractor.cc:913,919
   const int maxY = min(iniY + L.hCell + 6, maxBY), maxX = min(iniX + L.wCell + 6, maxBX);
   const int rw = maxX - iniX, rh = maxY - iniY;
   const int dw = rw - 6, dh = rh - 6;  // detectable window of the cell (FAST needs a 3 px ring)
-  if (dw <= 0 || dh <= 0) return;
+  if (iniY >= maxBY - 3 || iniX >= maxBX - 6 || dw <= 0 || dh <= 0) {  // src/ORBextractor.cc:913,919
+    if (lane == 0) *myCount = 0;
+    return;
+  }
 
-  const int TP = g.tileP, SP = g.scoreP;
-  uint8_t* tile = smem;
-  uint8_t* score = tile + TP * g.tileH;
-  uint16_t* list = reinterpret_cast<uint16_t*>(score + SP * g.scoreH);
-  uint8_t* lscore = reinterpret_cast<uint8_t*>(list + g.listCap);
+  const int TPd = g.tileP >> 2, SPd = g.scoreP >> 2;  // pitches in dwords
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* score = tile + TPd * g.tileH;
+  uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kListCap corner positions (y << 8 | x)
+  const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile);
+  const int qpr = (dw + 3) >> 2;  // quads per detect row
+  const int nq = qpr * dh;
+  const float inv_qpr = 1.0f / (float)qpr;
 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  const int mis = iniX & 3, xa = iniX - mis;
-  const int dpr = (rw + mis + 3) >> 2;
-  {  // tile load: aligned dwords, rows iniY..maxY-1
+  if (ablate & 16) return;
+  if (!(ablate & 1)) {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
+    const int mis = iniX & 3, xa = iniX - mis;
+    const int dpr = (rw + 3) >> 2;
     const float inv = 1.0f / (float)dpr;
     const int n = rh * dpr;
     for (int idx = lane; idx < n; idx += 64) {
@@ -174,98 +191,143 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       const int cc = idx - r * dpr;
       const int gx = xa + 4 * cc;
       const uint8_t* src = im + (long long)(iniY + r) * pitch + gx;
-      uint32_t v;
-      if (gx + 4 <= L.w) {
-        v = *reinterpret_cast<const uint32_t*>(src);
+      uint32_t lo, hi = 0;
+      if (gx + 8 <= L.w) {
+        lo = reinterpret_cast<const uint32_t*>(src)[0];
+        hi = reinterpret_cast<const uint32_t*>(src)[1];
       } else {
-        v = 0;
-        for (int k = 0; k < 4; k++)
-          if (gx + k < L.w) v |= (uint32_t)src[k] << (8 * k);
+        uint64_t v = 0;
+        for (int k = 0; k < 8; k++)
+          if (gx + k < L.w) v |= (uint64_t)src[k] << (8 * k);
+        lo = (uint32_t)v;
+        hi = (uint32_t)(v >> 32);
       }
-      *reinterpret_cast<uint32_t*>(tile + r * TP + 4 * cc) = v;
+      tile[r * TPd + cc] = __builtin_amdgcn_alignbyte(hi, lo, mis);
     }
-    const int nz = ((dh + 2) * SP) >> 2;
-    for (int idx = lane; idx < nz; idx += 64) reinterpret_cast<uint32_t*>(score)[idx] = 0;
+    // zero ring of the score tile: rows 0 and dh+1, dword columns 0 and qpr+1
+    for (int idx = lane; idx < SPd; idx += 64) {
+      score[idx] = 0;
+      score[(dh + 1) * SPd + idx] = 0;
+    }
+    for (int idx = lane; idx < dh; idx += 64) {
+      score[(idx + 1) * SPd] = 0;
+      score[(idx + 1) * SPd + qpr + 1] = 0;
+    }
   }
   __syncthreads();
 
-  // dense corner test at the min threshold; corners are appended to the list in raster order
-  int nList = 0;
-  {
-    const float inv = 1.0f / (float)dw;
-    const int n = dw * dh;
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      bool corner = false;
-      int y = 0, x = 0;
-      if (i < n) {
-        y = (int)(((float)i + 0.5f) * inv);
-        x = i - y * dw;
-        corner = fast_is_corner(tile + (y + 3) * TP + (x + 3 + mis), TP, g.minTh);
+  uint32_t* out = cellCand + (long long)img * g.cellImg + L.cellOff + (long long)cell * L.cellCap;
+  int kept = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int t = pass == 0 ? g.iniTh : g.minTh;
+    // dense corner test, 4 pixels per lane; corners are compacted into an LDS list and scored with dense
+    // lanes (the score needs ~110 min/max ops: running it under per-lane divergence would dominate).
+    int nList = 0;
+    auto flush = [&]() {
+      __syncthreads();
+      for (int e = lane; e < nList; e += 64) {
+        const int yx = list[e], y = yx >> 8, x = yx & 255;
+        score8[(y + 1) * g.scoreP + x + 4] = (uint8_t)fast_score(tile8 + (y + 3) * g.tileP + x + 3, g.tileP);
       }
-      const uint64_t m = __ballot(corner);
-      if (corner) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)((y << 8) | x);
-      nList += __popcll(m);
-    }
-  }
-  __syncthreads();
-
-  // score of every min-threshold corner -> score tile (offset by the 1 px zero ring)
-  for (int e = lane; e < nList; e += 64) {
-    const int yx = list[e], y = yx >> 8, x = yx & 255;
-    const int s = fast_contrast(tile + (y + 3) * TP + (x + 3 + mis), TP) - 1;
-    lscore[e] = (uint8_t)s;
-    score[(y + 1) * SP + (x + 1)] = (uint8_t)s;
-  }
-  __syncthreads();
-
-  // 3x3 non-max suppression inside the cell; decide ini vs min threshold on the post-NMS set
-  bool any_ini = false;
-  for (int base = 0; base < nList; base += 64) {
-    const int e = base + lane;
-    bool keep = false;
-    int s = 0;
-    if (e < nList) {
-      const int yx = list[e], y = yx >> 8, x = yx & 255;
-      s = lscore[e];
-      const uint8_t* q = score + (y + 1) * SP + (x + 1);
-      keep = s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
-             s > q[SP] && s > q[SP + 1];
-      if (keep) list[e] = (uint16_t)(yx | 0x8000);
-    }
-    any_ini |= __ballot(keep && s >= g.iniTh) != 0;
-  }
-  __syncthreads();
-
-  uint32_t* out = cand + (long long)img * g.candImg + L.candOff;
-  int* counter = candCount + img * g.nlevels + l;
-  for (int base = 0; base < nList; base += 64) {
-    const int e = base + lane;
-    bool emit = false;
-    int yx = 0, s = 0;
-    if (e < nList) {
-      yx = list[e];
-      s = lscore[e];
-      emit = (yx & 0x8000) && (s >= g.iniTh || !any_ini);
-    }
-    const uint64_t m = __ballot(emit);
-    if (m) {
-      int pos = 0;
-      if (lane == 0) pos = atomicAdd(counter, __popcll(m));
-      pos = __shfl(pos, 0);
-      if (emit) {
-        const int y = (yx >> 8) & 0x7F, x = yx & 255;
-        const int o = pos + __popcll(m & lanemask_lt());
-        if (o < L.candCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, s);
+      __syncthreads();
+      nList = 0;
+    };
+    const int nq_round = (nq + 63) & ~63;
+    for (int q = lane; q < nq_round; q += 64) {
+      uint32_t cm = 0;  // corner flags of the 4 pixels
+      int yd = 0, j = 0;
+      if (q < nq && !(ablate & 2)) {
+        yd = (int)(((float)q + 0.5f) * inv_qpr);
+        j = q - yd * qpr;
+        uint32_t r[7][3];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+          const uint32_t* row = tile + (yd + i) * TPd + j;
+          r[i][0] = row[0];
+          r[i][1] = row[1];
+          r[i][2] = row[2];
+        }
+        cm = (uint32_t)fast_px<0>(r, t) | ((uint32_t)fast_px<1>(r, t) << 1) | ((uint32_t)fast_px<2>(r, t) << 2) |
+             ((uint32_t)fast_px<3>(r, t) << 3);
+        const int valid = dw - 4 * j;  // pixels of this quad inside the detectable window
+        if (valid < 4) cm &= (1u << valid) - 1u;
+        score[(yd + 1) * SPd + j + 1] = 0;
+      }
+      if (__ballot(cm != 0)) {
+#pragma unroll
+        for (int pI = 0; pI < 4; pI++) {
+          const bool c = (cm >> pI) & 1u;
+          const uint64_t m = __ballot(c);
+          if (c) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)((yd << 8) | (4 * j + pI));
+          nList += __popcll(m);
+        }
+        if (nList > kListCap - 256) flush();
       }
     }
+    flush();
+    // 3x3 non-max suppression (strict '>') inside the cell + emission
+    if (ablate & 4) kept = 1;
+    if (!(ablate & 4))
+    for (int q = lane; q < nq_round; q += 64) {
+      uint32_t sw = 0;
+      int yd = 0, j = 0;
+      if (q < nq) {
+        yd = (int)(((float)q + 0.5f) * inv_qpr);
+        j = q - yd * qpr;
+        sw = score[(yd + 1) * SPd + j + 1];
+      }
+      uint32_t keepmask = 0;
+      if (sw) {
+        const int SP = g.scoreP;
+        const uint8_t* q8 = score8 + (yd + 1) * SP + 4 * (j + 1);
+#pragma unroll
+        for (int pI = 0; pI < 4; pI++) {
+          const int sc = (sw >> (8 * pI)) & 0xFF;
+          if (sc) {
+            const uint8_t* c8 = q8 + pI;
+            const bool keep = sc > c8[-1] && sc > c8[1] && sc > c8[-SP - 1] && sc > c8[-SP] && sc > c8[-SP + 1] &&
+                              sc > c8[SP - 1] && sc > c8[SP] && sc > c8[SP + 1];
+            keepmask |= (uint32_t)keep << pI;
+          }
+        }
+      }
+      const uint64_t any = __ballot(keepmask != 0);
+      if (any) {
+        // per-lane counts -> wave exclusive prefix via 4 ballots
+        int before = 0, total = 0;
+#pragma unroll
+        for (int pI = 0; pI < 4; pI++) {
+          const uint64_t m = __ballot((keepmask >> pI) & 1u);
+          before += __popcll(m & lanemask_lt());
+          total += __popcll(m);
+        }
+        const int pos = kept + before;
+        // lane-local order: slots in ascending pI after the lanes before it
+        int lanebefore = 0;
+#pragma unroll
+        for (int pI = 0; pI < 4; pI++) {
+          if ((keepmask >> pI) & 1u) {
+            // entries of lower lanes for ALL slots come first, so add this lane's earlier slots only
+            const int o = pos + lanebefore;
+            lanebefore++;
+            if (o < L.cellCap)
+              out[o] = pack_key(iniX + 3 + 4 * j + pI - kBorder, iniY + 3 + yd - kBorder, (sw >> (8 * pI)) & 0xFF);
+          }
+        }
+        kept += total;
+      }
+    }
+    if (kept > 0) break;
+    __syncthreads();
   }
+  if (lane == 0) *myCount = min(kept, L.cellCap);
 }
 
-hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cand, int* candCount, hipStream_t s) {
-  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + (size_t)g.listCap * 3 + 16;
+hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, hipStream_t s) {
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListCap + 16;
   dim3 grid(g.totalCells, nimg);
-  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cand, candCount);
+  static const int ablate = getenv("ORBX_DETECT_ABLATE") ? atoi(getenv("ORBX_DETECT_ABLATE")) : 0;
+  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate);
   return hipGetLastError();
 }
 
@@ -346,9 +408,11 @@ __device__ __forceinline__ int quadrant(int x, int y, int x0, int x1, int y0, in
   return (x < x0 + hx ? 0 : 1) | (y < y0 + hy ? 0 : 2);
 }
 
-__global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restrict__ cand,
-                                                const int* __restrict__ candCount, uint16_t* __restrict__ knode,
-                                                uint32_t* __restrict__ sel, int* __restrict__ selCount) {
+__global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
+                                                const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
+                                                uint32_t* __restrict__ cand, int* __restrict__ candCount,
+                                                uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
+                                                int* __restrict__ selCount) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_i[8];
   const int tid = threadIdx.x;
@@ -369,9 +433,46 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   uint32_t* bestk = (uint32_t*)(smem + o.bestk);
   uint64_t* tsum = (uint64_t*)(smem + o.tsum);
 
-  const int n = min(candCount[img * g.nlevels + l], L.candCap);
+  // ---- gather: exclusive scan of the level's per-cell counts, then compact the sparse per-cell slots into
+  // the dense candidate list (order is irrelevant: ties are broken by the canonical rank below)
+  uint32_t* keys = cand + (long long)img * g.candImg + L.candOff;
+  int n;
+  {
+    const int cells = L.nCols * L.nRows;
+    const int* cc = cellCount + (long long)img * g.totalCells + L.cellStart;
+    int* cp = cellPrefix + (long long)img * g.totalCells + L.cellStart;
+    const int per = (cells + 255) >> 8;
+    const int cb = min(tid * per, cells), ce = min(cb + per, cells);
+    uint64_t sum = 0;
+    for (int c = cb; c < ce; c++) sum += (uint64_t)cc[c];
+    tsum[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const uint64_t t = tid >= d ? tsum[tid - d] : 0;
+      __syncthreads();
+      tsum[tid] += t;
+      __syncthreads();
+    }
+    n = min((int)tsum[255], L.candCap);
+    int run = tid ? (int)tsum[tid - 1] : 0;
+    for (int c = cb; c < ce; c++) {
+      cp[c] = run;
+      run += cc[c];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t* sparse = cellCand + (long long)img * g.cellImg + L.cellOff;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int c = wave; c < cells; c += 4) {
+      const int cnt = cc[c], base = cp[c];
+      for (int i = lane; i < cnt; i += 64)
+        if (base + i < L.candCap) keys[base + i] = sparse[(long long)c * L.cellCap + i];
+    }
+    if (tid == 0) candCount[img * g.nlevels + l] = n;
+    __threadfence_block();
+    __syncthreads();
+  }
   const int N = L.quota;
-  const uint32_t* keys = cand + (long long)img * g.candImg + L.candOff;
   uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
   int* outCount = selCount + img * g.nlevels + l;
   uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
@@ -657,10 +758,12 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   if (tid == 0) *outCount = nOut;
 }
 
-hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cand, const int* candCount, uint16_t* knode,
-                         uint32_t* sel, int* selCount, hipStream_t s) {
+hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
+                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
+                         hipStream_t s) {
   dim3 grid(g.nlevels, nimg);
-  hipLaunchKernelGGL(k_octree, grid, dim3(256), octree_lds_bytes(g), s, g, cand, candCount, knode, sel, selCount);
+  hipLaunchKernelGGL(k_octree, grid, dim3(256), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
+                     candCount, knode, sel, selCount);
   return hipGetLastError();
 }
 
@@ -673,17 +776,20 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
-#define BL_TW 64
+#define BL_TW 128
 #define BL_TH 32
+// Tile of 128x32 outputs per 256-thread block.  In-tile: rows y0-3 .. y0+34, columns x0-4 .. x0+131 as aligned
+// dwords.  Horizontal pass: a thread turns 3 dwords into 4 outputs with 6 v_alignbyte + 8 v_dot4_u32_u8 (taps
+// 18,34,48,56 | 48,34,18,0), stored as u16 (max 255*256).  Vertical pass: a thread owns a 4x4 output block and
+// reads 10 rows x 4 u16.  All integer, exact; one rounding (+32768 >> 16) at the end.
 __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
-  __shared__ uint8_t in[(BL_TH + 6)][BL_TW + 8];
-  __shared__ uint16_t hp[(BL_TH + 6)][BL_TW];
+  __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];   // +1: pad against bank conflicts
+  __shared__ uint32_t hp[BL_TH + 6][BL_TW / 2 + 1];       // two u16 per dword
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   int tile = blockIdx.x;
-  // tiles of all levels are enumerated in one grid dimension
   int l = 0;
-  for (;; l++) {
+  for (;; l++) {  // tiles of all levels are enumerated in one grid dimension
     const int tx = (g.lv[l].w + BL_TW - 1) / BL_TW, ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
     if (tile < tx * ty || l + 1 == g.nlevels) break;
     tile -= tx * ty;
@@ -694,31 +800,64 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
   const int x0 = (tile % tx) * BL_TW, y0 = (tile / tx) * BL_TH;
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  for (int i = tid; i < (BL_TH + 6) * (BL_TW + 6); i += 256) {
-    const int r = i / (BL_TW + 6), c = i - r * (BL_TW + 6);
-    const int yy = reflect101(min(y0 + r - 3, L.h + 2), L.h), xx = reflect101(min(x0 + c - 3, L.w + 2), L.w);
-    in[r][c] = im[(long long)yy * pitch + xx];
-  }
-  __syncthreads();
-  for (int i = tid; i < (BL_TH + 6) * BL_TW; i += 256) {
-    const int r = i / BL_TW, c = i - r * BL_TW;
-    const uint8_t* q = &in[r][c];
-    hp[r][c] = (uint16_t)(18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 48 * (q[2] + q[4]) + 56 * q[3]);
-  }
-  __syncthreads();
-  uint8_t* dst = p.blur + (long long)img * g.pyrImg + L.off;
-  for (int i = tid; i < BL_TH * (BL_TW / 4); i += 256) {
-    const int r = i / (BL_TW / 4), c4 = (i - r * (BL_TW / 4)) * 4;
-    if (y0 + r >= L.h || x0 + c4 >= L.w) continue;
-    uint32_t w = 0;
+  constexpr int IW = BL_TW / 4 + 2;  // in-tile dwords per row
+  for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
+    const int r = i / IW, c = i - r * IW;
+    const int y = y0 + r - 3, x = x0 - 4 + 4 * c;
+    uint32_t v;
+    if (y >= 0 && y < L.h && x >= 0 && x + 4 <= L.w) {
+      v = *reinterpret_cast<const uint32_t*>(im + (long long)y * pitch + x);
+    } else {  // image border: BORDER_REFLECT_101 (coordinates further out only feed discarded outputs)
+      const int yy = reflect101(min(max(y, -3), L.h + 2), L.h);
+      v = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int c = c4 + j;
-      const uint32_t acc = 18u * (hp[r][c] + hp[r + 6][c]) + 34u * (hp[r + 1][c] + hp[r + 5][c]) +
-                           48u * (hp[r + 2][c] + hp[r + 4][c]) + 56u * hp[r + 3][c];
-      w |= ((acc + 32768u) >> 16) << (8 * j);
+      for (int k = 0; k < 4; k++) {
+        const int xx = reflect101(min(max(x + k, -3), L.w + 2), L.w);
+        v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * k);
+      }
     }
-    *reinterpret_cast<uint32_t*>(dst + (long long)(y0 + r) * L.pitch + x0 + c4) = w;
+    in[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
+    const int r = i / (BL_TW / 4), c = i - r * (BL_TW / 4);
+    const uint32_t Lw = in[r][c], C = in[r][c + 1], R = in[r][c + 2];
+    const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps -3..0 and +1..+3 (LSB = lowest x)
+    const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 1), wA,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), wB, 0, false), false);
+    const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 2), wA,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), wB, 0, false), false);
+    const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 3), wA,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), wB, 0, false), false);
+    const uint32_t h3 = __builtin_amdgcn_udot4(C, wA, __builtin_amdgcn_udot4(R, wB, 0, false), false);
+    hp[r][2 * c] = h0 | (h1 << 16);
+    hp[r][2 * c + 1] = h2 | (h3 << 16);
+  }
+  __syncthreads();
+  {
+    const int bc = tid & 31, br = tid >> 5;  // 32 x 8 blocks of 4x4 outputs
+    uint32_t lo[10], hi[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      lo[k] = hp[4 * br + k][2 * bc];
+      hi[k] = hp[4 * br + k][2 * bc + 1];
+    }
+    uint8_t* dst = p.blur + (long long)img * g.pyrImg + L.off;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        auto H = [&](int k) -> uint32_t {
+          const uint32_t v = (j < 2) ? lo[rr + k] : hi[rr + k];
+          return (j & 1) ? (v >> 16) : (v & 0xFFFFu);
+        };
+        const uint32_t acc = 18u * (H(0) + H(6)) + 34u * (H(1) + H(5)) + 48u * (H(2) + H(4)) + 56u * H(3);
+        w |= ((acc + 32768u) >> 16) << (8 * j);
+      }
+      const int y = y0 + 4 * br + rr, x = x0 + 4 * bc;
+      if (y < L.h && x < L.w) *reinterpret_cast<uint32_t*>(dst + (long long)y * L.pitch + x) = w;
+    }
   }
 }
 
@@ -1404,7 +1543,7 @@ hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
 
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
-  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + (size_t)g.listCap * 3 + 16;
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListCap + 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;

@@ -1,0 +1,74 @@
+// Drives the C++ mirror classes the way the reference's Frame does (src/Frame.cc:149-232): two extractor
+// instances called from two threads, then ComputeStereoMatches; optional SearchForInitialization between
+// two mono frames.  Reads raw u8 images, writes results as flat binary files for the pytest to diff
+// against the oracle.   usage: frame_like <w> <h> <nfeat> <left.raw> <right.raw> <outprefix>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <thread>
+#include <vector>
+
+#include "../../orb_slam3_fast_amd/csrc/ORBextractor.h"
+#include "../../orb_slam3_fast_amd/csrc/ORBmatcher.h"
+
+using namespace ORB_SLAM3;
+
+static std::vector<uint8_t> slurp(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+template <class T>
+static void dump(const std::string& path, const T* p, size_t n) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    // no arguments: construction must fail loudly without a GPU, succeed with one
+    try {
+      ORBextractor ex(1000, 1.2f, 8, 20, 7, 640, 480);
+      std::printf("constructed on a GPU\n");
+      return 0;
+    } catch (const std::exception& e) {
+      std::printf("no-device error: %s\n", e.what());
+      return 3;
+    }
+  }
+  const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), nf = std::atoi(argv[3]);
+  std::vector<uint8_t> L = slurp(argv[4]), R = slurp(argv[5]);
+  const std::string out = argv[6];
+  ORBextractor exL(nf, 1.2f, 8, 20, 7, w, h), exR(nf, 1.2f, 8, 20, 7, w, h);
+  ocv::Mat imL(h, w, L.data(), (size_t)w), imR(h, w, R.data(), (size_t)w), mask;
+  std::vector<ocv::KeyPoint> kL, kR;
+  ocv::Mat dL, dR;
+  std::vector<int> lap = {0, 0};
+  int monoL = 0, monoR = 0;
+  std::thread tl([&] { monoL = exL(imL, mask, kL, dL, lap); });  // src/Frame.cc:200-203
+  std::thread tr([&] { monoR = exR(imR, mask, kR, dR, lap); });
+  tl.join();
+  tr.join();
+  std::vector<float> uR, depth;
+  ComputeStereoMatches(exL, exR, (int)kL.size(), 0.12f * 532.03f, 0.12f, uR, depth);
+  exL.SyncImagePyramid();
+  dump(out + ".kL", kL.data(), kL.size());
+  dump(out + ".dL", dL.data, (size_t)dL.rows * 32);
+  dump(out + ".kR", kR.data(), kR.size());
+  dump(out + ".dR", dR.data, (size_t)dR.rows * 32);
+  dump(out + ".uR", uR.data(), uR.size());
+  dump(out + ".depth", depth.data(), depth.size());
+  dump(out + ".pyr3", exL.mvImagePyramid[3].data, (size_t)exL.mvImagePyramid[3].rows * exL.mvImagePyramid[3].cols);
+  // monocular initialisation match between the two views (stand-in for two consecutive frames)
+  FrameView F1, F2;
+  F1.mvKeysUn = kL.data(); F1.mDescriptors = dL.data; F1.N = (int)kL.size();
+  F2.mvKeysUn = kR.data(); F2.mDescriptors = dR.data; F2.N = (int)kR.size();
+  F1.mnMaxX = F2.mnMaxX = (float)w; F1.mnMaxY = F2.mnMaxY = (float)h;
+  std::vector<ocv::Point2f> prev(kL.size());
+  for (size_t i = 0; i < kL.size(); i++) prev[i] = kL[i].pt;
+  std::vector<int> m12;
+  ORBmatcher matcher(0.9f, true);
+  const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
+  dump(out + ".m12", m12.data(), m12.size());
+  std::printf("%d %d %d %d %d\n", monoL, monoR, (int)kL.size(), (int)kR.size(), nm);
+  return 0;
+}
