@@ -31,45 +31,98 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // ================================================================================================ resize
-// 4 destination pixels per thread, one u32 store.  Coefficient tables (sx, a0/a1 ; sy, b0/b1) are built on
-// the host exactly as OpenCV builds them and uploaded once per image size.
+// cv::resize INTER_LINEAR 8U, level l from level l-1.  Coefficient tables (sx, a0/a1 ; sy, b0/b1)
+// are built on the host exactly as OpenCV builds them and uploaded once per image size.
+// Block = 256 dst columns x RS_DR dst rows.  The source footprint is staged in LDS with coalesced dword loads;
+// the horizontal pass (one thread per dst column, walking the footprint rows) leaves (S0*a0 + S1*a1) >> 4 as u16
+// in LDS; the vertical pass emits 4 pixels per thread with one u32 store.
+#define RS_DW 256
+#define RS_DR 8
 __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int* __restrict__ xofs,
                                                 const short* __restrict__ xab, const int* __restrict__ yofs,
-                                                const short* __restrict__ yab) {
+                                                const short* __restrict__ yab, int srcRowsMax, int srcDwMax) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const LevelDev D = g.lv[l];
   const LevelDev S = g.lv[l - 1];
+  const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  const int gx = blockIdx.x * 64 + threadIdx.x;
-  const int dy = blockIdx.y * 4 + threadIdx.y;
-  if (dy >= D.h || gx * 4 >= D.w) return;
+  const int x0 = blockIdx.x * RS_DW, y0 = blockIdx.y * RS_DR;
+  const int x1 = min(x0 + RS_DW, D.w) - 1, y1 = min(y0 + RS_DR, D.h) - 1;  // last dst column / row of the block
   int sp;
   const uint8_t* src = level_ptr(g, p, img, l - 1, sp);
-  uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
-  const int sy = yofs[D.ycoef + dy];
-  const int b0 = yab[2 * (D.ycoef + dy)], b1 = yab[2 * (D.ycoef + dy) + 1];
-  const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
-  const uint8_t* r0 = src + (long long)sy0 * sp;
-  const uint8_t* r1 = src + (long long)sy1 * sp;
-  uint32_t outw = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int dx = min(gx * 4 + j, D.w - 1);
+  uint32_t* st = reinterpret_cast<uint32_t*>(smem);                            // [srcRowsMax][srcDwMax] dwords
+  uint16_t* ht = reinterpret_cast<uint16_t*>(st + srcRowsMax * srcDwMax);      // [srcRowsMax][RS_DW] u16
+  const uint8_t* st8 = reinterpret_cast<const uint8_t*>(st);
+  const int rb = min(max(yofs[D.ycoef + y0], 0), S.h - 1);                      // first source row needed
+  const int re = min(max(yofs[D.ycoef + y1] + 1, 0), S.h - 1);                  // last source row needed
+  const int nrows = re - rb + 1;
+  const int cb = xofs[D.xcoef + x0] & ~3;                                       // first source byte (dword aligned)
+  const int ce = min(xofs[D.xcoef + x1] + 1, S.w - 1);
+  const int ndw = ((ce - cb) >> 2) + 1;
+  {
+    const float inv = 1.0f / (float)ndw;
+    const int n = nrows * ndw;
+    for (int i = tid; i < n; i += 256) {
+      const int r = (int)(((float)i + 0.5f) * inv), c = i - r * ndw;
+      const int gx = cb + 4 * c;
+      const uint8_t* q = src + (long long)(rb + r) * sp + gx;
+      uint32_t v;
+      if (gx + 4 <= S.w) {
+        v = *reinterpret_cast<const uint32_t*>(q);
+      } else {
+        v = 0;
+        for (int k = 0; k < 4; k++)
+          if (gx + k < S.w) v |= (uint32_t)q[k] << (8 * k);
+      }
+      st[r * srcDwMax + c] = v;
+    }
+  }
+  __syncthreads();
+  {  // horizontal pass: thread = dst column
+    const int dx = min(x0 + tid, D.w - 1);
     const int sx = xofs[D.xcoef + dx];
     const int a0 = xab[2 * (D.xcoef + dx)], a1 = xab[2 * (D.xcoef + dx) + 1];
-    const int sx1 = min(sx + 1, S.w - 1);
-    const int t0 = r0[sx] * a0 + r0[sx1] * a1;
-    const int t1 = r1[sx] * a0 + r1[sx1] * a1;
-    const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-    outw |= (uint32_t)(v & 255) << (8 * j);
+    const int o0 = sx - cb, o1 = min(sx + 1, S.w - 1) - cb;
+    const int pitchB = srcDwMax * 4;
+    for (int r = 0; r < nrows; r++) {
+      const int t = st8[r * pitchB + o0] * a0 + st8[r * pitchB + o1] * a1;
+      ht[r * RS_DW + tid] = (uint16_t)(t >> 4);
+    }
   }
-  *reinterpret_cast<uint32_t*>(dst + gx * 4) = outw;
+  __syncthreads();
+  // vertical pass: 64 quads x RS_DR rows = 512 items, 2 per thread
+  for (int i = tid; i < 64 * RS_DR; i += 256) {
+    const int dyl = i >> 6, qx = i & 63;
+    const int dy = y0 + dyl, dx = x0 + 4 * qx;
+    if (dy >= D.h || dx >= D.w) continue;
+    const int sy = yofs[D.ycoef + dy];
+    const int b0 = yab[2 * (D.ycoef + dy)], b1 = yab[2 * (D.ycoef + dy) + 1];
+    const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
+    const uint2 t0 = *reinterpret_cast<const uint2*>(ht + r0 * RS_DW + 4 * qx);
+    const uint2 t1 = *reinterpret_cast<const uint2*>(ht + r1 * RS_DW + 4 * qx);
+    const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
+    const int u1[4] = {(int)(t1.x & 0xFFFF), (int)(t1.x >> 16), (int)(t1.y & 0xFFFF), (int)(t1.y >> 16)};
+    uint32_t outw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
+      outw |= (uint32_t)(v & 255) << (8 * j);
+    }
+    uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
+    *reinterpret_cast<uint32_t*>(dst + dx) = outw;
+  }
 }
 
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
                          const int* yofs, const short* yab, hipStream_t s) {
   const LevelDev& D = g.lv[level];
-  dim3 block(64, 4), grid((D.w + 255) / 256, (D.h + 3) / 4, nimg);
-  hipLaunchKernelGGL(k_resize, grid, block, 0, s, g, p, level, xofs, xab, yofs, yab);
+  const LevelDev& S = g.lv[level - 1];
+  // footprint bounds of a 256 x 8 dst block for this level's scale (+ slack for the floor/ceil of the taps)
+  const int srcRowsMax = (int)((double)RS_DR * S.h / D.h) + 4;
+  const int srcDwMax = ((int)((double)RS_DW * S.w / D.w) + 12) / 4 + 1;
+  const size_t lds = (size_t)srcRowsMax * srcDwMax * 4 + (size_t)srcRowsMax * RS_DW * 2;
+  dim3 grid((D.w + RS_DW - 1) / RS_DW, (D.h + RS_DR - 1) / RS_DR, nimg);
+  hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, s, g, p, level, xofs, xab, yofs, yab, srcRowsMax, srcDwMax);
   return hipGetLastError();
 }
 
