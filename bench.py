@@ -85,7 +85,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import orb_slam3_fast_amd as orbx
-    from orb_slam3_fast_amd import synth
+    from orb_slam3_fast_amd import sharding, synth
 
     W, H, B, NF = a.width, a.height, a.pairs, a.nfeatures
     # ---- synthetic streams (deterministic): D distinct pairs tiled to B per GPU
@@ -102,21 +102,21 @@ def main():
 
     gather_out = None
 
+    class _Raw:  # zero-copy view of a liborbx device buffer as a torch tensor
+        def __init__(self, ptr, shape, typestr):
+            self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
     def step():
         ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H)
         orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
         if a.allgather and dist is not None:
+            # config C5 extra: every GPU ends up with all cameras' descriptor blocks (RCCL all-gather over xGMI)
             ex.sync()
             d_kps, d_desc, d_cnt, d_mono, cap = ex.results_device()
-
-            class _Raw:
-                __cuda_array_interface__ = {"shape": (2 * B * cap * 32,), "typestr": "|u1", "data": (d_desc, False),
-                                            "version": 2}
-            local = torch.as_tensor(_Raw(), device="cuda")
+            desc = torch.as_tensor(_Raw(d_desc, (2 * B, cap, 32), "|u1"), device="cuda")
+            cnt = torch.as_tensor(_Raw(d_cnt, (2 * B,), "<i4"), device="cuda")
             nonlocal gather_out
-            if gather_out is None:
-                gather_out = torch.empty(world * local.numel(), dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(gather_out, local)
+            gather_out = sharding.allgather_descriptor_blocks(cnt, desc, cap)
 
     def barrier():
         if dist is not None:

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing for the batched many-camera mode.
+
+The path shards naturally: a stereo pair of one camera stream depends on nothing from other streams, so stream
+s goes to rank s mod G, whole pairs stay on one GPU (stereo matching needs both pyramids) and NO collective is
+needed on the data path.  The only optional exchange is the cross-camera descriptor all-gather of config C5:
+every rank contributes fixed-capacity blocks {int32 n; uint8 desc[cap][32]} per image so that every GPU ends
+up with all cameras' descriptors.  torch.distributed is used as plumbing only (backend "nccl" = RCCL over xGMI
+on the GPUs, "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def assign_streams(n_streams, world, rank):
+    """Camera streams handled by `rank`: stream s -> rank s mod world (round robin)."""
+    return [s for s in range(n_streams) if s % world == rank]
+
+
+def pack_descriptor_blocks(counts, desc, cap):
+    """counts [I] int32, desc [I, cap, 32] uint8 -> one uint8 tensor [I, 4 + cap*32] (count header + rows)."""
+    I = counts.shape[0]
+    out = torch.zeros((I, 4 + cap * 32), dtype=torch.uint8, device=desc.device)
+    out[:, :4] = counts.to(torch.int32).contiguous().view(torch.uint8).reshape(I, 4)
+    out[:, 4:] = desc.reshape(I, cap * 32)
+    return out
+
+
+def unpack_descriptor_blocks(blocks, cap):
+    """inverse of pack_descriptor_blocks -> (counts [I] int32, desc [I, cap, 32] uint8)"""
+    I = blocks.shape[0]
+    counts = blocks[:, :4].contiguous().view(torch.int32).reshape(I)
+    return counts, blocks[:, 4:].reshape(I, cap, 32)
+
+
+def allgather_descriptor_blocks(counts, desc, cap, group=None):
+    """All-gather every rank's descriptor blocks.  Returns (counts [G*I], desc [G*I, cap, 32]) ordered by rank,
+    then by local image index (rank r, image i is camera stream i*G + r under assign_streams)."""
+    world = dist.get_world_size(group)
+    local = pack_descriptor_blocks(counts, desc, cap)
+    out = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)  # flat: backend agnostic
+    dist.all_gather_into_tensor(out, local.reshape(-1), group=group)
+    return unpack_descriptor_blocks(out.reshape(world * local.shape[0], local.shape[1]), cap)
+
+
+def max_over_ranks(seconds, device="cpu", group=None):
+    """bench.py contract: the step time is the MAX over ranks."""
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def whole_job_rate(units_per_rank, steps, seconds, group=None):
+    """units all ranks processed / max-over-ranks time"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    return world * units_per_rank * steps / seconds
