@@ -393,10 +393,10 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
 
 struct OctLds {  // byte offsets into dynamic LDS, all 8-byte aligned
   int nx0[2], nx1[2], ny0[2], ny1[2], ncnt[2];
-  int cnt4, cpos, scan, e[2], mark, bestk, tsum;
+  int cnt4, cpos, scan, e[2], mark, bestk, tsum, cellpre;
   int total;
 };
-__host__ __device__ inline OctLds oct_layout(int maxn) {
+__host__ __device__ inline OctLds oct_layout(int maxn, int maxcells) {
   OctLds o;
   int off = 0;
   auto take = [&](int bytes) {
@@ -419,6 +419,7 @@ __host__ __device__ inline OctLds oct_layout(int maxn) {
   o.mark = take(maxn * 2);
   o.bestk = take(maxn * 4);
   o.tsum = take(256 * 8 + 64);
+  o.cellpre = take((maxcells + 1) * 4);
   o.total = off;
   return o;
 }
@@ -427,7 +428,12 @@ __host__ __device__ inline int oct_maxn(const Geom& g) {
   for (int l = 0; l < g.nlevels; l++) q = g.lv[l].quota > q ? g.lv[l].quota : q;
   return q + 4 * kMaxIni + 8;
 }
-size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g)).total; }
+__host__ __device__ inline int oct_maxcells(const Geom& g) {
+  int c = 0;
+  for (int l = 0; l < g.nlevels; l++) c = g.lv[l].nCols * g.lv[l].nRows > c ? g.lv[l].nCols * g.lv[l].nRows : c;
+  return c;
+}
+size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g), oct_maxcells(g)).total; }
 
 // Exclusive scan of n u64 values in LDS (in place) by a 256-thread block; returns the total.
 // Packed fields must not overflow into each other (callers keep each field < 2^21).
@@ -465,14 +471,16 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
                                                 const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
                                                 uint32_t* __restrict__ cand, int* __restrict__ candCount,
                                                 uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
-                                                int* __restrict__ selCount) {
+                                                int* __restrict__ selCount, int ablate) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_i[8];
+#define OCT_EXIT(stage) if (ablate == stage) { if (threadIdx.x == 0) selCount[blockIdx.y * g.nlevels + blockIdx.x] = 0; return; }
   const int tid = threadIdx.x;
   const int l = blockIdx.x, img = blockIdx.y;
   const LevelDev L = g.lv[l];
   const int maxn = oct_maxn(g);
-  const OctLds o = oct_layout(maxn);
+  const OctLds o = oct_layout(maxn, oct_maxcells(g));
+  int* cellpre = (int*)(smem + o.cellpre);
   int16_t* nx0[2] = {(int16_t*)(smem + o.nx0[0]), (int16_t*)(smem + o.nx0[1])};
   int16_t* nx1[2] = {(int16_t*)(smem + o.nx1[0]), (int16_t*)(smem + o.nx1[1])};
   int16_t* ny0[2] = {(int16_t*)(smem + o.ny0[0]), (int16_t*)(smem + o.ny0[1])};
@@ -493,7 +501,6 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   {
     const int cells = L.nCols * L.nRows;
     const int* cc = cellCount + (long long)img * g.totalCells + L.cellStart;
-    int* cp = cellPrefix + (long long)img * g.totalCells + L.cellStart;
     const int per = (cells + 255) >> 8;
     const int cb = min(tid * per, cells), ce = min(cb + per, cells);
     uint64_t sum = 0;
@@ -506,25 +513,30 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
       tsum[tid] += t;
       __syncthreads();
     }
-    n = min((int)tsum[255], L.candCap);
+    const int total = (int)tsum[255];
+    n = min(total, L.candCap);
     int run = tid ? (int)tsum[tid - 1] : 0;
     for (int c = cb; c < ce; c++) {
-      cp[c] = run;
+      cellpre[c] = run;
       run += cc[c];
     }
-    __threadfence_block();
+    if (tid == 0) cellpre[cells] = total;
     __syncthreads();
+    // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
     const uint32_t* sparse = cellCand + (long long)img * g.cellImg + L.cellOff;
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int c = wave; c < cells; c += 4) {
-      const int cnt = cc[c], base = cp[c];
-      for (int i = lane; i < cnt; i += 64)
-        if (base + i < L.candCap) keys[base + i] = sparse[(long long)c * L.cellCap + i];
+    for (int k = tid; k < n; k += 256) {
+      int lo = 0, hi = cells;  // largest c with cellpre[c] <= k
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cellpre[mid] <= k) lo = mid; else hi = mid;
+      }
+      keys[k] = sparse[(long long)lo * L.cellCap + (k - cellpre[lo])];
     }
     if (tid == 0) candCount[img * g.nlevels + l] = n;
     __threadfence_block();
     __syncthreads();
   }
+  OCT_EXIT(1)
   const int N = L.quota;
   uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
   int* outCount = selCount + img * g.nlevels + l;
@@ -566,6 +578,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   int cur = 0;
   __syncthreads();
 
+  OCT_EXIT(2)
   bool finish = false;
   int nE = 0, ecur = 0;
   // ---- phase 1: split every expandable node per pass (:610-677)
@@ -654,13 +667,14 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     }
   }
 
+  OCT_EXIT(3)
   // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
   while (!finish) {
     const int prevSize = nA;
     uint64_t* E = ebuf[ecur];
     uint64_t* E2 = ebuf[ecur ^ 1];
     if (tid == 0) {
-      introsort<uint64_t, KeyLess>(E, nE, KeyLess());
+      if (ablate != 5) introsort<uint64_t, KeyLess>(E, nE, KeyLess());
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
     }
@@ -782,6 +796,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     if (broke || nA == prevSize) finish = true;
   }
 
+  OCT_EXIT(4)
   // ---- best response per node, first candidate (reference order) wins ties (:741-754)
   uint64_t* best = scan;
   for (int i = tid; i < nA; i += 256) best[i] = 0;
@@ -815,8 +830,9 @@ hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, cons
                          uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
                          hipStream_t s) {
   dim3 grid(g.nlevels, nimg);
+  static const int ablate = getenv("ORBX_OCTREE_ABLATE") ? atoi(getenv("ORBX_OCTREE_ABLATE")) : 0;
   hipLaunchKernelGGL(k_octree, grid, dim3(256), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
-                     candCount, knode, sel, selCount);
+                     candCount, knode, sel, selCount, ablate);
   return hipGetLastError();
 }
 
@@ -1044,14 +1060,23 @@ __device__ __forceinline__ void orb_sincos_dev(float ang, float& s_out, float& c
   c_out = (float)cv;
 }
 
-// One wave per selected keypoint: intensity-centroid angle on the unblurred level, 256 rotated tests on the
-// blurred level (lane t evaluates tests t, t+64, t+128, t+192; each __ballot is 8 descriptor bytes already
-// in the reference's byte/bit order), then the keypoint + descriptor are written to their output slot.
+// One wave per selected keypoint.
+//  * IC_Angle (:75-99): lanes run along patch COLUMNS so that every load instruction reads one 31-byte row
+//    segment (1-2 cache lines) — two half-waves take the upper / lower 15 rows; integer moments are reduced
+//    with DPP shuffles.
+//  * rBRIEF (:102-147): the 37x37 footprint of the blurred level is staged in LDS with aligned dword loads,
+//    then lane t evaluates tests t, t+64, t+128, t+192; each __ballot is 8 descriptor bytes already in the
+//    reference's byte/bit order.
+//  * the keypoint + descriptor are written to their serial-order output slot.
+#define DS_PITCH 48
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
-                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
-  const int lane = threadIdx.x & 63;
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                  int ablate) {
+  __shared__ uint32_t patch_all[4][37 * DS_PITCH / 4];
+  if (ablate == 1) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wv;
   const int img = blockIdx.y;
   if (s >= g.selImg) return;
   int l = 0;
@@ -1061,34 +1086,56 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   if (idx >= selCount[img * g.nlevels + l]) return;
   const uint32_t key = sel[(long long)img * g.selImg + s];
   const int X = key_x(key), Y = key_y(key);
+  if (ablate == 2) return;
+  uint32_t* patch = patch_all[wv];
+  const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch);
+  // stage the blurred 37x37 footprint: rows Y-18..Y+18, aligned dwords covering columns X-18..X+18
+  const uint8_t* bl = p.blur + (long long)img * g.pyrImg + L.off;
+  const int xs = (X - 18) & ~3, mis = (X - 18) - xs;  // level pitch is a multiple of 64 -> rows are dword aligned
+  for (int i = lane; i < 37 * 11; i += 64) {
+    const int r = i / 11, c = i - r * 11;
+    patch[r * (DS_PITCH / 4) + c] =
+        *reinterpret_cast<const uint32_t*>(bl + (long long)(Y - 18 + r) * L.pitch + xs + 4 * c);
+  }
+  if (ablate == 3) return;
+  // IC_Angle on the unblurred level
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  // IC_Angle: lanes 0..30 take one row v = lane - 15 of the circular patch
-  int m10 = 0, m01 = 0;
-  if (lane < 31) {
-    const int v = lane - 15;
-    const int d = c_umax[v < 0 ? -v : v];
-    const uint8_t* row = im + (long long)(Y + v) * pitch + X;
-    int rs = 0;
-    for (int u = -d; u <= d; u++) {
-      const int val = row[u];
-      rs += val;
-      m10 += u * val;
+  int colsum = 0, m01 = 0;
+  {
+    const int c = lane & 31, h = lane >> 5;  // column u = c - 15, half h: rows 0,-1..-15 / 1..15
+    const int u = min(c, 30) - 15, au = u < 0 ? -u : u;
+    const uint8_t* col = im + (long long)Y * pitch + X + u;
+    constexpr int kUmax[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
+    int vals[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)  // all 16 loads are issued back to back (addresses are always inside the image)
+      vals[k] = col[(long long)(h ? min(k + 1, 15) : -k) * pitch];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const int v = h ? k + 1 : -k;
+      const int lim = h ? kUmax[k + 1] : kUmax[k];  // umax[|v|]; -1 masks the non-existent row 16
+      const int val = (c < 31 && au <= lim) ? vals[k] : 0;
+      colsum += val;
+      m01 += v * val;
     }
-    m01 = v * rs;
   }
+  int m10 = (((lane & 31) - 15)) * colsum;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     m10 += __shfl_xor(m10, o);
     m01 += __shfl_xor(m01, o);
   }
+  if (ablate == 4) { if (m10 == 12345 && lane == 0) kps[0].x = 1; return; }
   const float angle = fast_atan2_dev((float)m01, (float)m10);
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, b;
   orb_sincos_dev(__fmul_rn(angle, factorPI), b, a);  // a = cos, b = sin
-  const uint8_t* bl = p.blur + (long long)img * g.pyrImg + L.off + (long long)Y * L.pitch + X;
   const int n_out_slot = slot[(long long)img * g.selImg + s];
   uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // patch writes of this wave before its own reads
+  __builtin_amdgcn_wave_barrier();
+  const uint8_t* centre = patch8 + 18 * DS_PITCH + 18 + mis;
 #pragma unroll
   for (int gI = 0; gI < 4; gI++) {
     const int8_t* pt = c_pattern + 4 * (64 * gI + lane);
@@ -1097,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     const int ix0 = rne_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int iy1 = rne_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int ix1 = rne_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = bl[iy0 * L.pitch + ix0], t1 = bl[iy1 * L.pitch + ix1];
+    const int t0 = centre[iy0 * DS_PITCH + ix0], t1 = centre[iy1 * DS_PITCH + ix1];
     const uint64_t bits = __ballot(t0 < t1);
     if (lane == 0) *reinterpret_cast<uint64_t*>(dout + 8 * gI) = bits;
   }
@@ -1116,8 +1163,9 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
 
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, hipStream_t s) {
+  static const int ablate = getenv("ORBX_DESC_ABLATE") ? atoi(getenv("ORBX_DESC_ABLATE")) : 0;
   hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc);
+                     kps, desc, ablate);
   return hipGetLastError();
 }
 

@@ -25,24 +25,31 @@ else:
     np.save(cache, base)
 imgs = np.concatenate([np.stack([base[i % 2] for i in range(B)]), np.stack([base[2 + i % 2] for i in range(B)])])
 d = DeviceBuffer.from_numpy(imgs)
-ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B)
+NH = int(os.environ.get("KB_HANDLES", "1"))
+exs = [orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B) for _ in range(NH)]
+ex = exs[0]
 bf, b = 0.12 * 532.03, 0.12
+_it = [0]
 
 
 def step():
-    ex.extract_batch_device(d.ptr.value, 2 * B, W, H, W, W * H)
-    orbx.stereo_match_async(ex, ex, bf, b, 0, B, B)
+    e = exs[_it[0] % NH]
+    _it[0] += 1
+    e.extract_batch_device(d.ptr.value, 2 * B, W, H, W, W * H)
+    orbx.stereo_match_async(e, e, bf, b, 0, B, B)
 
 
-for _ in range(2):
+for _ in range(2 * NH):
     step()
-ex.sync()
-ex.profile_enable(True)
-ex.profile_collect()
+for e in exs:
+    e.sync()
+    e.profile_enable(os.environ.get("KB_NOPROF") is None)
+    e.profile_collect()
 t0 = time.perf_counter()
 for _ in range(K):
     step()
-ex.sync()
+for e in exs:
+    e.sync()
 dt = time.perf_counter() - t0
 prof = ex.profile_collect()
 tag = os.environ.get("KB_TAG", "")
