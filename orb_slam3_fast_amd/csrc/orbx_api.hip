@@ -71,7 +71,7 @@ struct orbx_extractor {
   DevBuf<uint8_t> d_pyr, d_blur, d_stage, d_desc;
   DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
   DevBuf<uint16_t> d_knode;
-  DevBuf<int> d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
+  DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
   DevBuf<short> d_xab, d_yab;
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
@@ -443,7 +443,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_xofs.free(); ex->d_yofs.free();
-  ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free();
+  ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
@@ -597,6 +597,8 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
     HIPC(left->d_uR.alloc((size_t)n_pairs * capL));
     HIPC(left->d_depth.alloc((size_t)n_pairs * capL));
     HIPC(left->d_sad.alloc((size_t)n_pairs * capL));
+    HIPC(left->d_rowStart.alloc((size_t)n_pairs * (left->maxH + 2)));
+    HIPC(left->d_rowItems.alloc((size_t)n_pairs * right->gmax.outCap));
     left->stereoPairs = n_pairs;
   }
   if (right != left) {  // order left's stream after right's extraction
@@ -619,6 +621,14 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
   a.uRight = left->d_uR.p;
   a.depth = left->d_depth.p;
   a.sad = left->d_sad.p;
+  a.rowStart = left->d_rowStart.p;
+  a.rowItems = left->d_rowItems.p;
+  a.imgH = left->curH;
+  a.band = (int)std::ceil(2.0f * left->scale.back()) + 2;
+  {
+    StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
+    HIPC(launch_stereo_rows(a, n_pairs, left->stream));
+  }
   {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
     HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));

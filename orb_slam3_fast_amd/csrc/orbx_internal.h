@@ -93,7 +93,12 @@ struct StereoArgs {
   float* uRight;                 // [pairs][capL]
   float* depth;
   int* sad;                      // [pairs][capL] best SAD or -1
+  int* rowStart;                 // [pairs][imgH + 1] CSR of right keypoints by integer row
+  int* rowItems;                 // [pairs][capR] right keypoint indices, grouped by row
+  int imgH;                      // level-0 height
+  int band;                      // max rows a right keypoint's +-2*scale band can be away from its own row
 };
+hipError_t launch_stereo_rows(const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
                                hipStream_t s);
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);

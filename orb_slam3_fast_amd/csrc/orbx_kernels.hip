@@ -1177,6 +1177,51 @@ __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* b) 
   return d;
 }
 
+// Right keypoints bucketed by integer row (counting sort, one block per pair): the analogue of the
+// reference's vRowIndices table (src/Frame.cc:930-949), but one entry per keypoint; the +-2*scale band is
+// applied by the matcher, which only has to visit rows [vL - band, vL + band].
+__global__ __launch_bounds__(256) void k_stereo_rows(StereoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* hist = reinterpret_cast<int*>(smem);  // imgH + 1 counters, then running offsets
+  __shared__ int tsum[256];
+  const int tid = threadIdx.x, pair = blockIdx.x;
+  const int imgR = a.firstR + pair;
+  const int nR = a.nR[imgR];
+  const orbx_keypoint* kR = a.kR + (long long)imgR * a.capR;
+  int* rowStart = a.rowStart + (long long)pair * (a.imgH + 1);
+  int* items = a.rowItems + (long long)pair * a.capR;
+  for (int r = tid; r <= a.imgH; r += 256) hist[r] = 0;
+  __syncthreads();
+  for (int i = tid; i < nR; i += 256) atomicAdd(&hist[min(max((int)kR[i].y, 0), a.imgH - 1)], 1);
+  __syncthreads();
+  const int per = (a.imgH + 256) >> 8;
+  const int b = min(tid * per, a.imgH + 1), e = min(b + per, a.imgH + 1);
+  int sum = 0;
+  for (int r = b; r < e; r++) sum += hist[r];
+  tsum[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? tsum[tid - d] : 0;
+    __syncthreads();
+    tsum[tid] += t;
+    __syncthreads();
+  }
+  int run = tid ? tsum[tid - 1] : 0;
+  for (int r = b; r < e; r++) {
+    const int c = hist[r];
+    hist[r] = run;
+    rowStart[r] = run;
+    run += c;
+  }
+  __syncthreads();
+  for (int i = tid; i < nR; i += 256) items[atomicAdd(&hist[min(max((int)kR[i].y, 0), a.imgH - 1)], 1)] = i;
+}
+
+hipError_t launch_stereo_rows(const StereoArgs& a, int npairs, hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(256), (size_t)(a.imgH + 2) * 4, s, a);
+  return hipGetLastError();
+}
+
 // One wave per left keypoint.  The reference scans vRowIndices[vL] (right keypoints whose +-2*scale row band
 // covers row vL, ascending iR) and keeps the first strict minimum; that is the minimum of (dist, iR) over
 // all right keypoints passing the same band/octave/disparity filters, which is what the lanes compute.
@@ -1185,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
   const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int pair = blockIdx.y;
   const int imgL = a.firstL + pair, imgR = a.firstR + pair;
-  const int nL = a.nL[imgL], nR = a.nR[imgR];
+  const int nL = a.nL[imgL];
   if (iL >= nL) return;
   const long long oL = (long long)pair * a.capL + iL;
   const orbx_keypoint kpL = a.kL[(long long)imgL * a.capL + iL];
@@ -1206,9 +1251,13 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
   const int row = (int)vL;
   uint32_t best = (100u << 16);  // TH_HIGH, strict '<'
   if (!(maxU < 0)) {
-    for (int base = 0; base < nR; base += 64) {
-      const int iR = base + lane;
-      if (iR < nR) {
+    const int* rowStart = a.rowStart + (long long)pair * (a.imgH + 1);
+    const int* items = a.rowItems + (long long)pair * a.capR;
+    const int jb = rowStart[min(max(row - a.band, 0), a.imgH)], je = rowStart[min(max(row + a.band + 1, 0), a.imgH)];
+    for (int base = jb; base < je; base += 64) {
+      const int j = base + lane;
+      if (j < je) {
+        const int iR = items[j];
         const orbx_keypoint k = kR[iR];
         const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
         const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
@@ -1292,43 +1341,52 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
   }
 }
 
-// Median-of-SAD outlier cut (:1072-1083): median = element size/2 of the ascending (SAD, iL) list;
-// matches with SAD >= 1.5*1.4*median are dropped.  One block per pair, bitonic sort in LDS.
-__global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a, int npow2) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint32_t* v = reinterpret_cast<uint32_t*>(smem);
-  __shared__ int s_m;
+// Median-of-SAD outlier cut (:1072-1083): median = element size/2 of the ascending (SAD, iL) list, i.e. the
+// (size/2)-th smallest SAD; matches with SAD >= 1.5*1.4*median are dropped.  One block per pair; the order
+// statistic is found exactly with a two-level LDS histogram (SAD <= 121*255 < 2^15: high 8 bits, low 7 bits).
+__global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a) {
+  __shared__ int hist[256];
+  __shared__ int s_v[4];
   const int tid = threadIdx.x, pair = blockIdx.x;
   const int nL = a.nL[a.firstL + pair];
   const int* sad = a.sad + (long long)pair * a.capL;
-  if (tid == 0) s_m = 0;
+  hist[tid] = 0;
   __syncthreads();
-  int cnt = 0;
-  for (int i = tid; i < npow2; i += 256) {
-    const int s = i < nL ? sad[i] : -1;
-    v[i] = s >= 0 ? (uint32_t)s : 0xFFFFFFFFu;
-    cnt += s >= 0;
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0) atomicAdd(&hist[min(s >> 7, 255)], 1);
   }
-  atomicAdd(&s_m, cnt);
   __syncthreads();
-  const int m = s_m;
-  if (m == 0) return;  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
-  for (int k = 2; k <= npow2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < npow2; i += 256) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const uint32_t x = v[i], y = v[ixj];
-          const bool up = (i & k) == 0;
-          if ((x > y) == up) {
-            v[i] = y;
-            v[ixj] = x;
-          }
-        }
-      }
-      __syncthreads();
+  if (tid == 0) {
+    int m = 0;
+    for (int k = 0; k < 256; k++) m += hist[k];
+    int target = m / 2, k = 0, cum = 0;  // 0-based rank of the median
+    if (m > 0) {
+      while (cum + hist[k] <= target) cum += hist[k++];
     }
-  const float median = (float)(int)v[m / 2];
+    s_v[0] = m;
+    s_v[1] = k;
+    s_v[2] = target - cum;  // rank inside the bucket
+  }
+  __syncthreads();
+  const int m = s_v[0];
+  if (m == 0) return;  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
+  const int bucket = s_v[1];
+  __syncthreads();
+  hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < nL; i += 256) {
+    const int s = sad[i];
+    if (s >= 0 && min(s >> 7, 255) == bucket) atomicAdd(&hist[s & 127], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0, cum = 0;
+    while (cum + hist[k] <= s_v[2]) cum += hist[k++];
+    s_v[3] = (bucket << 7) | k;
+  }
+  __syncthreads();
+  const float median = (float)s_v[3];
   const float th = __fmul_rn(1.5f * 1.4f, median);
   for (int i = tid; i < nL; i += 256) {
     const int s = sad[i];
@@ -1345,9 +1403,7 @@ hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, cons
   return hipGetLastError();
 }
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) {
-  int np2 = 1;
-  while (np2 < a.capL) np2 <<= 1;
-  hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), (size_t)np2 * 4, s, a, np2);
+  hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
