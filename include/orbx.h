@@ -169,6 +169,10 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
  * (the tie order DistributeOctTree depends on, src/ORBextractor.cc:686). */
 void orbx_debug_introsort(uint64_t* v, int n);
 
+/* Shrinks (>= 320) or restores (1024) the capacity of k_detect's LDS survivor / corner lists so that tests can
+ * force the list-overflow paths (mid-cell flushes, tile-scan NMS) that natural images never reach. */
+void orbx_debug_set_detect_list_cap(int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -792,5 +792,6 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 
 // Test hook: the device quadtree's introsort replica, run on the host (compared with std::sort in tests).
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
+void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
 
 }  // extern "C"

@@ -129,5 +129,6 @@ hipError_t launch_search_init(const InitArgs& a, hipStream_t s);       // grid +
 hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s);  // candidate fill + serial resolve
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
+void debug_set_detect_list_cap(int cap);
 
 }  // namespace orbx

@@ -165,6 +165,40 @@ __device__ __forceinline__ bool fast_px(const uint32_t (&r)[7][3], int t) {
   return has_arc9(ab & 0xFFFFu) || has_arc9(ad & 0xFFFFu);
 }
 
+// Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
+// polarity.  v_cmp leaves each comparison as a 64-lane mask in SGPRs, so the combination is scalar-ALU work:
+// per pixel slot 8 VALU compares + 14 scalar ops.  Returns the wave mask of lanes whose pixel survives.
+template <int P>
+__device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int t) {
+  const int c = (r[3][(3 + P) >> 2] >> (8 * ((3 + P) & 3))) & 0xFF;
+  const int hi = c + t, lo = c - t;
+  uint64_t B[4], D[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int k = 4 * q;
+    const int col = 3 + P + kRingDX[k];
+    const int v = (r[3 + kRingDY[k]][col >> 2] >> (8 * (col & 3))) & 0xFF;
+    B[q] = __ballot(v > hi);
+    D[q] = __ballot(v < lo);
+  }
+  return (B[0] & B[1]) | (B[1] & B[2]) | (B[2] & B[3]) | (B[3] & B[0]) | (D[0] & D[1]) | (D[1] & D[2]) |
+         (D[2] & D[3]) | (D[3] & D[0]);
+}
+
+// Full FAST-9-16 test of one pixel addressed in the LDS tile (pitch TP bytes).
+__device__ __forceinline__ bool fast_test_lds(const uint8_t* c8, int TP, int t) {
+  const int c = c8[0];
+  const int hi = c + t, lo = c - t;
+  uint32_t ab = 0, ad = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int v = c8[kRingDY[k] * TP + kRingDX[k]];
+    ab = __builtin_amdgcn_alignbit(ab, (uint32_t)(hi - v), 31);  // (ab << 1) | (v > hi)
+    ad = __builtin_amdgcn_alignbit(ad, (uint32_t)(v - lo), 31);  // (ad << 1) | (v < lo)
+  }
+  return has_arc9(ab & 0xFFFFu) || has_arc9(ad & 0xFFFFu);
+}
+
 // cornerScore of a known corner: M - 1, M = max over the 16 nine-pixel arcs of the arc's minimum
 // one-signed contrast, by sliding min / max with doubling.  c8 points at the pixel in the LDS tile (pitch TP).
 __device__ __forceinline__ int fast_score(const uint8_t* c8, int TP) {
@@ -200,7 +234,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* c8, int TP) {
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
-                                               int* __restrict__ cellCount, int ablate) {
+                                               int* __restrict__ cellCount, int ablate, int listCap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
@@ -226,6 +260,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   uint32_t* score = tile + TPd * g.tileH;
   uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
   uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kListCap corner positions (y << 8 | x)
+  uint16_t* slist = list + kListCap;                                     // kListCap compass-test survivors
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile);
   const int qpr = (dw + 3) >> 2;  // quads per detect row
   const int nq = qpr * dh;
@@ -275,52 +310,89 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     const int t = pass == 0 ? g.iniTh : g.minTh;
     // dense corner test, 4 pixels per lane; corners are compacted into an LDS list and scored with dense
     // lanes (the score needs ~110 min/max ops: running it under per-lane divergence would dominate).
-    int nList = 0;
-    auto flush = [&]() {
+    // Stage 1 (4 pixels per lane, registers): compass pre-test -> survivor list.
+    // Stage 2 (dense lanes over survivors): full 16-pixel arc test -> corner list.
+    // Stage 3 (dense lanes over corners): cornerScore -> u8 score tile.
+    int nList = 0, nSurv = 0;
+    bool overflowed = false;  // the corner list was flushed before the end: fall back to the tile-scan NMS
+    auto flush_corners = [&]() {
       __syncthreads();
       for (int e = lane; e < nList; e += 64) {
         const int yx = list[e], y = yx >> 8, x = yx & 255;
         score8[(y + 1) * g.scoreP + x + 4] = (uint8_t)fast_score(tile8 + (y + 3) * g.tileP + x + 3, g.tileP);
       }
       __syncthreads();
-      nList = 0;
+    };
+    auto flush_survivors = [&]() {
+      __syncthreads();
+      for (int base = 0; base < nSurv; base += 64) {
+        const int e = base + lane;
+        const int yx = slist[min(e, nSurv - 1)], y = yx >> 8, x = yx & 255;
+        const bool corner = e < nSurv && fast_test_lds(tile8 + (y + 3) * g.tileP + x + 3, g.tileP, t);
+        const uint64_t m = __ballot(corner);
+        if (corner) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)yx;
+        nList += __popcll(m);
+        if (nList > listCap - 64) {
+          flush_corners();
+          nList = 0;
+          overflowed = true;
+        }
+      }
+      __syncthreads();
+      nSurv = 0;
     };
     const int nq_round = (nq + 63) & ~63;
     for (int q = lane; q < nq_round; q += 64) {
-      uint32_t cm = 0;  // corner flags of the 4 pixels
-      int yd = 0, j = 0;
-      if (q < nq && !(ablate & 2)) {
-        yd = (int)(((float)q + 0.5f) * inv_qpr);
-        j = q - yd * qpr;
-        uint32_t r[7][3];
+      const bool act = q < nq && !(ablate & 2);
+      const int qq = min(q, nq - 1);  // idle lanes of the last round redo the last quad (masked out below)
+      const int yd = (int)(((float)qq + 0.5f) * inv_qpr);
+      const int j = qq - yd * qpr;
+      uint32_t r[7][3];
 #pragma unroll
-        for (int i = 0; i < 7; i++) {
-          const uint32_t* row = tile + (yd + i) * TPd + j;
-          r[i][0] = row[0];
-          r[i][1] = row[1];
-          r[i][2] = row[2];
-        }
-        cm = (uint32_t)fast_px<0>(r, t) | ((uint32_t)fast_px<1>(r, t) << 1) | ((uint32_t)fast_px<2>(r, t) << 2) |
-             ((uint32_t)fast_px<3>(r, t) << 3);
-        const int valid = dw - 4 * j;  // pixels of this quad inside the detectable window
-        if (valid < 4) cm &= (1u << valid) - 1u;
-        score[(yd + 1) * SPd + j + 1] = 0;
+      for (int i = 0; i < 7; i++) {
+        const uint32_t* row = tile + (yd + i) * TPd + j;
+        r[i][0] = row[0];
+        r[i][1] = row[1];
+        r[i][2] = row[2];
       }
-      if (__ballot(cm != 0)) {
+      const int valid = dw - 4 * j;  // pixels of this quad inside the detectable window
+      uint64_t sm[4];
+      sm[0] = compass_wave<0>(r, t) & __ballot(act);
+      sm[1] = compass_wave<1>(r, t) & __ballot(act && valid > 1);
+      sm[2] = compass_wave<2>(r, t) & __ballot(act && valid > 2);
+      sm[3] = compass_wave<3>(r, t) & __ballot(act && valid > 3);
+      if (act) score[(yd + 1) * SPd + j + 1] = 0;
 #pragma unroll
-        for (int pI = 0; pI < 4; pI++) {
-          const bool c = (cm >> pI) & 1u;
-          const uint64_t m = __ballot(c);
-          if (c) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)((yd << 8) | (4 * j + pI));
-          nList += __popcll(m);
-        }
-        if (nList > kListCap - 256) flush();
+      for (int pI = 0; pI < 4; pI++) {
+        const uint64_t m = sm[pI];
+        if ((m >> lane) & 1ull) slist[nSurv + __popcll(m & lanemask_lt())] = (uint16_t)((yd << 8) | (4 * j + pI));
+        nSurv += __popcll(m);
       }
+      if (nSurv > listCap - 256) flush_survivors();
     }
-    flush();
+    flush_survivors();
+    const int nCorners = nList;  // flush_corners() scores them but leaves the list intact
+    flush_corners();
     // 3x3 non-max suppression (strict '>') inside the cell + emission
     if (ablate & 4) kept = 1;
-    if (!(ablate & 4))
+    if (!(ablate & 4) && !overflowed) {
+      // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each
+      const int SP = g.scoreP;
+      for (int base = 0; base < nCorners; base += 64) {
+        const int e = base + lane;
+        const int yx = list[min(e, nCorners - 1)], y = yx >> 8, x = yx & 255;
+        const uint8_t* c8 = score8 + (y + 1) * SP + x + 4;
+        const int sc = c8[0];
+        const bool keep = e < nCorners && sc > c8[-1] && sc > c8[1] && sc > c8[-SP - 1] && sc > c8[-SP] &&
+                          sc > c8[-SP + 1] && sc > c8[SP - 1] && sc > c8[SP] && sc > c8[SP + 1];
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+          const int o = kept + __popcll(m & lanemask_lt());
+          if (o < L.cellCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, sc);
+        }
+        kept += __popcll(m);
+      }
+    } else if (!(ablate & 4))
     for (int q = lane; q < nq_round; q += 64) {
       uint32_t sw = 0;
       int yd = 0, j = 0;
@@ -346,7 +418,6 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       }
       const uint64_t any = __ballot(keepmask != 0);
       if (any) {
-        // per-lane counts -> wave exclusive prefix via 4 ballots
         int before = 0, total = 0;
 #pragma unroll
         for (int pI = 0; pI < 4; pI++) {
@@ -355,12 +426,10 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
           total += __popcll(m);
         }
         const int pos = kept + before;
-        // lane-local order: slots in ascending pI after the lanes before it
         int lanebefore = 0;
 #pragma unroll
         for (int pI = 0; pI < 4; pI++) {
           if ((keepmask >> pI) & 1u) {
-            // entries of lower lanes for ALL slots come first, so add this lane's earlier slots only
             const int o = pos + lanebefore;
             lanebefore++;
             if (o < L.cellCap)
@@ -373,14 +442,17 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     if (kept > 0) break;
     __syncthreads();
   }
-  if (lane == 0) *myCount = min(kept, L.cellCap);
+  if (lane == 0) *myCount = (ablate & 4) ? 0 : min(kept, L.cellCap);
 }
 
+static int g_detect_list_cap = kListCap;
+void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : (cap > kListCap ? kListCap : cap); }
+
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, hipStream_t s) {
-  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListCap + 16;
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;
   dim3 grid(g.totalCells, nimg);
   static const int ablate = getenv("ORBX_DETECT_ABLATE") ? atoi(getenv("ORBX_DETECT_ABLATE")) : 0;
-  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate);
+  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate, g_detect_list_cap);
   return hipGetLastError();
 }
 
@@ -1700,7 +1772,7 @@ hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
 
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
-  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListCap + 16;
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;

@@ -69,6 +69,28 @@ def test_stages_and_end_to_end(gpu, oracle, w, h, nf, nl, stream):
     assert np.array_equal(d, od)
 
 
+def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
+    """White noise puts ~340 corners in a 36x37 cell; with the LDS lists shrunk to 320 entries that forces the
+    survivor-list and corner-list flushes and the tile-scan NMS fallback of k_detect."""
+    rng = np.random.default_rng(9)
+    w, h = 400, 300
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    mixed = synth.mono_frame(w, h, 77)
+    mixed[:, w // 2:] = noise[:, w // 2:]
+    ex = orbx.ORBextractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(800, 1.2, 8, 20, 7)
+    try:
+        for cap in (320, 1024):
+            orbx.lib().orbx_debug_set_detect_list_cap(cap)
+            for img in (noise, mixed):
+                mono, k, d = ex(img)
+                omono, ok_, od = oe.extract(img)
+                assert len(ok_) > 700
+                assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+    finally:
+        orbx.lib().orbx_debug_set_detect_list_cap(1024)
+
+
 def test_lapping_area_partition(gpu, oracle):
     w, h = 640, 480
     img = synth.mono_frame(w, h, 21)
