@@ -168,6 +168,8 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
  * elements by their key bits 16..63, payload bits 0..15 ride along.  tests/ compare it with std::sort
  * (the tie order DistributeOctTree depends on, src/ORBextractor.cc:686). */
 void orbx_debug_introsort(uint64_t* v, int n);
+/* The wave-cooperative device version the quadtree kernel actually runs (n <= 4000). */
+int orbx_debug_introsort_device(int device, uint64_t* v, int n);
 
 /* Shrinks (>= 320) or restores (1024) the capacity of k_detect's LDS survivor / corner lists so that tests can
  * force the list-overflow paths (mid-cell flushes, tile-scan NMS) that natural images never reach. */

@@ -71,6 +71,7 @@ def lib():
         L.orbx_level_stats.argtypes = [vp, i, vp, vp, vp, vp]
         L.orbx_debug_introsort.argtypes = [vp, i]
         L.orbx_debug_introsort.restype = None
+        L.orbx_debug_introsort_device.argtypes = [i, vp, i]
         L.orbx_debug_set_detect_list_cap.argtypes = [i]
         L.orbx_debug_set_detect_list_cap.restype = None
         _lib = L

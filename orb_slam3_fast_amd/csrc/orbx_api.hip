@@ -83,6 +83,10 @@ struct orbx_extractor {
   size_t evCursor = 0;
   struct EvRec { int stage; size_t e0, e1; };
   std::vector<EvRec> evLog;
+  size_t lastEv = 0;
+  bool lastEvValid = false;
+  hipStream_t stream2 = nullptr;   // side stream: k_blur overlaps detect / quadtree
+  hipEvent_t evPyr = nullptr, evBlur = nullptr;
   hipEvent_t next_event() {
     if (evCursor == evPool.size()) {
       hipEvent_t e;
@@ -94,7 +98,9 @@ struct orbx_extractor {
 };
 
 namespace {
-// Brackets one kernel launch with events on the launch stream when profiling is on.
+// Brackets one kernel launch with events on the launch stream when profiling is on.  Consecutive launches on
+// the main stream share their boundary event (the end of one is the start of the next), which halves the
+// number of event records in the timed region.
 struct StageTimer {
   orbx_extractor* ex;
   hipStream_t s;
@@ -102,17 +108,23 @@ struct StageTimer {
   size_t i0 = 0;
   bool on;
   StageTimer(orbx_extractor* ex_, hipStream_t s_, int stage_) : ex(ex_), s(s_), stage(stage_), on(ex_->profiling) {
-    if (on) {
+    if (!on) return;
+    if (s == ex->stream && ex->lastEvValid) {
+      i0 = ex->lastEv;
+    } else {
       hipEvent_t e = ex->next_event();
       i0 = ex->evCursor - 1;
       if (e) (void)hipEventRecord(e, s);
     }
   }
   ~StageTimer() {
-    if (on) {
-      hipEvent_t e = ex->next_event();
-      if (e) (void)hipEventRecord(e, s);
-      ex->evLog.push_back({stage, i0, ex->evCursor - 1});
+    if (!on) return;
+    hipEvent_t e = ex->next_event();
+    if (e) (void)hipEventRecord(e, s);
+    ex->evLog.push_back({stage, i0, ex->evCursor - 1});
+    if (s == ex->stream) {
+      ex->lastEv = ex->evCursor - 1;
+      ex->lastEvValid = true;
     }
   }
 };
@@ -316,6 +328,7 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->pyr.pyr = ex->d_pyr.p;
   ex->pyr.blur = ex->d_blur.p;
   ex->lastN = n;
+  ex->lastEvValid = false;
   hipStream_t s = ex->stream;
   if (lap)
     HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
@@ -329,19 +342,26 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     StageTimer t(ex, s, ORBX_STAGE_DETECT);
     HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, s));
   }
+  // The blurred copies only depend on the pyramid.  They run on the side stream, released once k_detect (which
+  // fills the chip by itself) is done, so that the streaming blur shares the GPU with the latency-bound quadtree.
+  HIPC(hipEventRecord(ex->evPyr, s));
+  HIPC(hipStreamWaitEvent(ex->stream2, ex->evPyr, 0));
+  {
+    StageTimer t(ex, ex->stream2, ORBX_STAGE_BLUR);
+    HIPC(launch_blur(g, ex->pyr, n, ex->stream2));
+  }
+  HIPC(hipEventRecord(ex->evBlur, ex->stream2));
   {
     StageTimer t(ex, s, ORBX_STAGE_OCTREE);
     HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,
                        ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
   }
   {
-    StageTimer t(ex, s, ORBX_STAGE_BLUR);
-    HIPC(launch_blur(g, ex->pyr, n, s));
-  }
-  {
     StageTimer t(ex, s, ORBX_STAGE_SLOTS);
     HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
   }
+  HIPC(hipStreamWaitEvent(s, ex->evBlur, 0));
+  ex->lastEvValid = false;  // fresh start event: do not bill the wait for the side stream to k_describe
   {
     StageTimer t(ex, s, ORBX_STAGE_DESCRIBE);
     HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, ex->d_slot.p, ex->d_kps.p, ex->d_desc.p, s));
@@ -406,6 +426,9 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   };
   ok(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
   ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
+  ok(hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking));
+  ok(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
+  ok(hipEventCreateWithFlags(&ex->evBlur, hipEventDisableTiming));
   ok(ex->d_pyr.alloc(B * m.pyrImg + 256));
   ok(ex->d_blur.alloc(B * m.pyrImg + 256));
   ok(ex->d_stage.alloc(B * (size_t)ex->stagePitch * max_height + 256));
@@ -446,6 +469,9 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
+  if (ex->evPyr) (void)hipEventDestroy(ex->evPyr);
+  if (ex->evBlur) (void)hipEventDestroy(ex->evBlur);
+  if (ex->stream2) (void)hipStreamDestroy(ex->stream2);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
 }
@@ -764,6 +790,7 @@ int orbx_profile_collect(orbx_extractor* ex, double* ms, int32_t* launches) {
   }
   ex->evLog.clear();
   ex->evCursor = 0;
+  ex->lastEvValid = false;
   return ORBX_OK;
 }
 
@@ -793,5 +820,20 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 // Test hook: the device quadtree's introsort replica, run on the host (compared with std::sort in tests).
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
 void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
+int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
+  if (!v || n < 0 || n > 4000) return fail(ORBX_E_BADARG, "bad argument");
+  if (n == 0) return ORBX_OK;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  DevBuf<uint64_t> d;
+  HIPC(d.alloc(n));
+  hipError_t e = hipMemcpy(d.p, v, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_debug_sort(d.p, n, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(v, d.p, (size_t)n * 8, hipMemcpyDeviceToHost);
+  d.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
 
 }  // extern "C"

@@ -130,5 +130,6 @@ hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s);  // candid
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);
+hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s);
 
 }  // namespace orbx

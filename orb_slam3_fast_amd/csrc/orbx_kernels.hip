@@ -463,6 +463,147 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
 // node's children appear as n4,n3,n2,n1, later-visited nodes first; untouched nodes keep their order).
 // The final largest-first expansion sorts with the libstdc++ introsort replica (orbx_introsort.h).
 
+// ---- wave-cooperative exact replica of std::sort -----------------------------------------------------------
+// Same result as introsort() (orbx_introsort.h) — verified against std::sort on the CPU model of this
+// formulation and on the device (orbx_debug_introsort_device) — but the partition and the final insertion sort
+// are data parallel:
+//  * Hoare partition with an unguarded pivot == "pair the k-th element >= pivot from the left with the k-th
+//    element <= pivot from the right and swap them while they have not crossed"; the cut is
+//    min(L[K], R[K-1]).  Both stopper lists come from ballot-compaction over the range.
+//  * __final_insertion_sort is a stable sort of an array whose elements are at most 16 positions away from
+//    home, i.e. a stable rank inside a +-16 window.
+// All 64 lanes of ONE wave call it with uniform arguments; `a`, the scratch arrays and the stack are in LDS.
+__device__ __forceinline__ void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ int partition_wave(uint64_t* a, int first, int last, uint16_t* Li, uint16_t* Ri, int lane) {
+  const KeyLess less;
+  const int mid = first + (last - first) / 2;
+  {
+    const uint64_t va = a[first + 1], vb = a[mid], vc = a[last - 1];
+    int sel;
+    if (less(va, vb)) sel = less(vb, vc) ? mid : (less(va, vc) ? last - 1 : first + 1);
+    else if (less(va, vc)) sel = first + 1;
+    else sel = less(vb, vc) ? last - 1 : mid;
+    if (lane == 0) {
+      const uint64_t t = a[first];
+      a[first] = a[sel];
+      a[sel] = t;
+    }
+  }
+  wsync();
+  const uint64_t pivot = a[first];
+  int nL = 0, nR = 0;
+  for (int base = first + 1; base < last; base += 64) {
+    const int i = base + lane;
+    const bool st = i < last && !less(a[min(i, last - 1)], pivot);
+    const uint64_t m = __ballot(st);
+    if (st) Li[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
+    nL += __popcll(m);
+  }
+  for (int top = last - 1; top >= first + 1; top -= 64) {
+    const int i = top - lane;
+    const bool st = i >= first + 1 && !less(pivot, a[max(i, first + 1)]);
+    const uint64_t m = __ballot(st);
+    if (st) Ri[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
+    nR += __popcll(m);
+  }
+  wsync();
+  const int nmin = min(nL, nR);
+  int K = 0;
+  for (int base = 0; base < nmin; base += 64) {
+    const int k = base + lane;
+    K += __popcll(__ballot(k < nmin && Li[min(k, nmin - 1)] < Ri[min(k, nmin - 1)]));
+  }
+  const int INF = 1 << 30;
+  const int lk = K < nL ? (int)Li[K] : INF, rk = K > 0 ? (int)Ri[K - 1] : INF;
+  for (int k = lane; k < K; k += 64) {
+    const int i = Li[k], j = Ri[k];
+    const uint64_t t = a[i];
+    a[i] = a[j];
+    a[j] = t;
+  }
+  wsync();
+  return min(lk, rk);
+}
+
+__device__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp, uint16_t* Li, uint16_t* Ri, int* stk, int lane) {
+  if (n <= 1) return;
+  const KeyLess less;
+  int lg = 0;
+  for (int t = n; t > 1; t >>= 1) lg++;
+  int sp = 0;
+  if (lane == 0) {
+    stk[0] = 0;
+    stk[1] = n;
+    stk[2] = 2 * lg;
+  }
+  sp = 1;
+  wsync();
+  while (sp > 0) {
+    --sp;
+    int first = stk[3 * sp], last = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+    wsync();
+    while (last - first > 16) {
+      if (depth == 0) {
+        if (lane == 0) is_heapsort<uint64_t, KeyLess>(a, first, last, less);
+        wsync();
+        break;
+      }
+      --depth;
+      const int cut = partition_wave(a, first, last, Li, Ri, lane);
+      if (lane == 0) {
+        stk[3 * sp] = cut;
+        stk[3 * sp + 1] = last;
+        stk[3 * sp + 2] = depth;
+      }
+      ++sp;
+      wsync();
+      last = cut;
+    }
+  }
+  // __final_insertion_sort == stable rank inside a +-16 window
+  for (int i = lane; i < n; i += 64) {
+    const uint64_t vi = a[i];
+    const int w0 = max(0, i - 16), w1 = min(n, i + 17);
+    int c = 0;
+    for (int j = w0; j < w1; j++) {
+      const uint64_t vj = a[j];
+      c += (less(vj, vi) || (!less(vi, vj) && j < i)) ? 1 : 0;
+    }
+    tmp[w0 + c] = vi;
+  }
+  wsync();
+  for (int i = lane; i < n; i += 64) a[i] = tmp[i];
+  wsync();
+}
+
+// Test entry: sort n elements with the wave version (one block, dynamic LDS).
+__global__ __launch_bounds__(64) void k_debug_sort(uint64_t* v, int n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint64_t* a = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* tmp = a + n;
+  uint16_t* Li = reinterpret_cast<uint16_t*>(tmp + n);
+  uint16_t* Ri = Li + n + 4;
+  int* stk = reinterpret_cast<int*>(Ri + n + 4 + ((n & 1) ? 1 : 0) + 2);
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n; i += 64) a[i] = v[i];
+  __syncthreads();
+  introsort_wave(a, n, tmp, Li, Ri, stk, lane);
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) v[i] = a[i];
+}
+hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s) {
+  const size_t lds = (size_t)n * 16 + (size_t)(2 * n + 16) * 2 + 3 * 64 * 4 + 64;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sort),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), lds, s, d_v, n);
+  return hipGetLastError();
+}
+
 struct OctLds {  // byte offsets into dynamic LDS, all 8-byte aligned
   int nx0[2], nx1[2], ny0[2], ny1[2], ncnt[2];
   int cnt4, cpos, scan, e[2], mark, bestk, tsum, cellpre;
@@ -745,8 +886,10 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     const int prevSize = nA;
     uint64_t* E = ebuf[ecur];
     uint64_t* E2 = ebuf[ecur ^ 1];
+    if (tid < 64 && ablate != 5)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
+      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + maxn + 4,
+                     reinterpret_cast<int*>(tsum), tid);
     if (tid == 0) {
-      if (ablate != 5) introsort<uint64_t, KeyLess>(E, nE, KeyLess());
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
     }

@@ -91,6 +91,25 @@ def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
         orbx.lib().orbx_debug_set_detect_list_cap(1024)
 
 
+def test_device_introsort_matches_libstdcxx(gpu, oracle):
+    """The quadtree's wave-cooperative sort must reproduce std::sort's permutation, ties included."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    osort = oracle.lib().oro_std_sort_keys
+    sizes = [1, 2, 15, 16, 17, 31, 33, 64, 65, 100, 250, 333, 1000, 2500, 4000] + [int(v) for v in rng.integers(18, 900, 60)]
+    for trial, n in enumerate(sizes):
+        mode = trial % 4
+        cnt = rng.integers(2, 2 + [3, 1, 100, 8][mode], n).astype(np.uint64)
+        ulx = rng.integers(0, [4, 2, 1200, 1][mode], n).astype(np.uint64)
+        if trial % 7 == 0:
+            cnt = np.sort(cnt)[::-1].copy()                    # descending input
+        v = (cnt << np.uint64(28)) | (ulx << np.uint64(16)) | np.arange(n, dtype=np.uint64)
+        a, b = v.copy(), v.copy()
+        assert orbx.lib().orbx_debug_introsort_device(0, a.ctypes.data_as(C.c_void_p), n) == 0
+        osort(b.ctypes.data_as(C.c_void_p), n)
+        assert np.array_equal(a, b), "n=%d mode=%d" % (n, mode)
+
+
 def test_lapping_area_partition(gpu, oracle):
     w, h = 640, 480
     img = synth.mono_frame(w, h, 21)
