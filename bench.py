@@ -34,8 +34,10 @@ def parse():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=1500)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per GPU")
-    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--handles", type=int, default=1,
+                    help="extractor handles used round-robin (each owns streams + buffers; >1 overlaps batches)")
     ap.add_argument("--allgather", action="store_true",
                     help="config C5 extra: RCCL all-gather of every rank's descriptor blocks after each step")
     return ap.parse_args()
@@ -96,7 +98,10 @@ def main():
     images = torch.from_numpy(np.concatenate([lefts, rights])).cuda(local_rank)  # [2B, H, W]: L0..LB-1 R0..RB-1
     torch.cuda.synchronize()
 
-    ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local_rank)
+    exs = [orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local_rank)
+           for _ in range(max(1, a.handles))]
+    ex = exs[0]
+    step_no = [0]
     bf, b = 0.12 * 532.03, 0.12  # ZED2-like rig: fx = 532.03 px, baseline 0.12 m
     ptr = images.data_ptr()
 
@@ -107,6 +112,8 @@ def main():
             self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
     def step():
+        ex = exs[step_no[0] % len(exs)]
+        step_no[0] += 1
         ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H)
         orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
         if a.allgather and dist is not None:
@@ -123,12 +130,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, len(exs))):
         step()
     barrier()
     if not a.no_profile:
-        ex.profile_enable(True)
-        ex.profile_collect()
+        for e in exs:
+            e.profile_enable(True)
+            e.profile_collect()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -140,8 +148,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = ex.profile_collect() if not a.no_profile else {}
-    ex.profile_enable(False)
+    prof = {}
+    if not a.no_profile:
+        for e in exs:
+            for k, v in e.profile_collect().items():
+                prof[k] = (prof.get(k, (0.0, 0))[0] + v[0], prof.get(k, (0.0, 0))[1] + v[1])
+            e.profile_enable(False)
 
     # ---- workload statistics for the algorithmic byte counts
     lw, lh, nc, ns = ex.level_stats(0)
@@ -172,6 +184,7 @@ def main():
             "workload": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
                         "ComputeStereoMatches (bf=0.12*532.03, b=0.12)" % (W, H, NF),
             "pairs_per_step_per_gpu": B,
+            "handles": len(exs),
             "distinct_streams_per_gpu": D,
             "keypoints_per_image": round(nsel_mean, 1),
             "fast_candidates_per_image": round(ncand_mean, 1),
