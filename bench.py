@@ -81,7 +81,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ORBX_FORCE_DIST") == "1":  # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -234,13 +234,14 @@ __device__ __forceinline__ int fast_score(const uint8_t* c8, int TP) {
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
-                                               int* __restrict__ cellCount, int ablate, int listCap) {
+                                               int* __restrict__ cellCount, int ablate, int listCap,
+                                               int cellBegin) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
   // Plain cell order: an XCD-aware remap (consecutive cells per XCD, to share halo lines in one L2) was
   // measured slower here (526-583 vs 494 us): the kernel is VALU-bound and the remap unbalances the XCDs.
-  int cell = blockIdx.x;
+  int cell = cellBegin + blockIdx.x;
   int l = 0;
   while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellStart) l++;
   const LevelDev L = g.lv[l];
@@ -450,11 +451,17 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 static int g_detect_list_cap = kListCap;
 void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : (cap > kListCap ? kListCap : cap); }
 
-hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, hipStream_t s) {
+// Cells of levels [level0, level1) only: level 0 needs no resize and is launched beside the pyramid chain.
+hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
+                         int level1, hipStream_t s) {
   const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;
-  dim3 grid(g.totalCells, nimg);
+  const int cellBegin = g.lv[level0].cellStart;
+  const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
+  if (cellEnd <= cellBegin) return hipSuccess;
+  dim3 grid(cellEnd - cellBegin, nimg);
   static const int ablate = getenv("ORBX_DETECT_ABLATE") ? atoi(getenv("ORBX_DETECT_ABLATE")) : 0;
-  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate, g_detect_list_cap);
+  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate, g_detect_list_cap,
+                     cellBegin);
   return hipGetLastError();
 }
 
