@@ -35,12 +35,32 @@ def parse():
     ap.add_argument("--nfeatures", type=int, default=1500)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per GPU")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--handles", type=int, default=1,
                     help="extractor handles used round-robin (each owns streams + buffers; >1 overlaps batches)")
     ap.add_argument("--allgather", action="store_true",
                     help="config C5 extra: RCCL all-gather of every rank's descriptor blocks after each step")
     return ap.parse_args()
+
+
+def usable_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota (a container on a
+    256-core host is often limited to a handful of CPUs, and os.cpu_count() does not know)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def algorithmic_bytes(stage, NI, P, plevels, ncand, nsel, nmatch_in, npairs):
@@ -222,22 +242,32 @@ def main():
         a_pair = 2 * (2 * P + 60 * nsel_mean) + 120 * nsel_mean + 352 * nmatch
         out["end_to_end_algorithmic_GBps"] = round(a_pair * value / a.gpus / 1e9, 2)
 
-    # ---- CPU baseline: the oracle (port of the reference's serial semantics), rank 0, N=1 only
+    # ---- CPU baseline: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
+    # Frame-parallel over the host cores in a separate process tree (`cpu_mt` of BASELINE.md), plus 1 core.
     if rank == 0 and a.gpus == 1 and a.cpu_pairs > 0:
-        from oracle import oracle_py as oracle
-        oL, oR = oracle.OracleExtractor(NF), oracle.OracleExtractor(NF)
-        n = 0
-        tc0 = time.perf_counter()
-        while n < a.cpu_pairs and (n < 2 or time.perf_counter() - tc0 < 25.0):
-            L, R = pairs[n % D]
-            _, kL, dL = oL.extract(L)
-            _, kR, dR = oR.extract(R)
-            oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b)
-            n += 1
-        tc = time.perf_counter() - tc0
-        out["cpu_baseline"] = {"value": round(n / tc, 3), "unit": "stereo frames/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same synthetic %dx%d pairs, oracle/liborb_oracle.so (single thread, "
-                                         "g++ -O2), %.1f s; host has %d cores" % (n, W, H, tc, os.cpu_count())}
+        import subprocess
+        import tempfile
+        tmp = os.path.join(tempfile.gettempdir(), "orbx_cpu_pairs_%d.npy" % os.getpid())
+        np.save(tmp, np.stack([np.stack(p) for p in pairs]))
+        cores = usable_cores() if a.cpu_cores <= 0 else a.cpu_cores
+        per = max(2, a.cpu_pairs // 8)  # ~ per * 0.3 s per worker
+        try:
+            r1 = json.loads(subprocess.run([sys.executable, "-m", "oracle.cpu_bench", tmp, str(NF), str(bf), str(b), "1",
+                                            str(max(4, a.cpu_pairs // 4))], cwd=ROOT, capture_output=True, text=True,
+                                           timeout=300).stdout.strip().splitlines()[-1])
+            rN = json.loads(subprocess.run([sys.executable, "-m", "oracle.cpu_bench", tmp, str(NF), str(bf), str(b),
+                                            str(cores), str(per)], cwd=ROOT, capture_output=True, text=True,
+                                           timeout=600).stdout.strip().splitlines()[-1])
+            out["cpu_baseline"] = {
+                "value": round(rN["pairs_per_s"], 2), "unit": "stereo frames/s", "cores": cores, "kind": "port",
+                "single_core_value": round(r1["pairs_per_s"], 3),
+                "sample": "oracle/liborb_oracle.so (g++ -O2 port of the reference's serial semantics), frame-parallel: "
+                          "%d worker processes x %d of the same synthetic %dx%d pairs, wall %.1f s; single worker: %d pairs "
+                          "in %.1f s; host reports %d cores, %d usable (affinity / cgroup quota)" % (
+                              cores, per, W, H, rN["wall_s"], r1["pairs"], r1["wall_s"], os.cpu_count(), usable_cores())}
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
     if rank == 0:
         print(json.dumps(out))

@@ -84,7 +84,18 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
     const int a0 = xab[2 * (D.xcoef + dx)], a1 = xab[2 * (D.xcoef + dx) + 1];
     const int o0 = sx - cb, o1 = min(sx + 1, S.w - 1) - cb;
     const int pitchB = srcDwMax * 4;
-    for (int r = 0; r < nrows; r++) {
+    int r = 0;
+    for (; r + 4 <= nrows; r += 4) {  // 4 rows per trip: 8 independent LDS reads in flight
+      int v0[4], v1[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v0[k] = st8[(r + k) * pitchB + o0];
+        v1[k] = st8[(r + k) * pitchB + o1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ht[(r + k) * RS_DW + tid] = (uint16_t)((v0[k] * a0 + v1[k] * a1) >> 4);
+    }
+    for (; r < nrows; r++) {
       const int t = st8[r * pitchB + o0] * a0 + st8[r * pitchB + o1] * a1;
       ht[r * RS_DW + tid] = (uint16_t)(t >> 4);
     }
