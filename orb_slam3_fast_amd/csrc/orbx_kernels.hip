@@ -1324,6 +1324,22 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   if (ablate == 2) return;
   uint32_t* patch = patch_all[wv];
   const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch);
+  // IC_Angle on the unblurred level (:75-99): the 31 rows x 9 aligned dwords covering the circular patch are
+  // loaded as 279 coalesced dword items (5 per lane, all issued up front); every lane folds its bytes into the
+  // integer moments (u * I, v * I) under the circle mask |u| <= umax[|v|].
+  int pitch;
+  const uint8_t* im = level_ptr(g, p, img, l, pitch);
+  int m10 = 0, m01 = 0;
+    const int xr = (X - 15) & ~3, misr = (X - 15) - xr;
+    uint32_t w[5];  // (loads issued before the footprint staging below, so 12 loads are in flight together)
+    int um[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int i = min(lane + 64 * t, 278);
+      const int r = i / 9, c = i - r * 9;
+      w[t] = *reinterpret_cast<const uint32_t*>(im + (long long)(Y - 15 + r) * pitch + xr + 4 * c);
+      um[t] = c_umax[r < 15 ? 15 - r : r - 15];
+    }
   // stage the blurred 37x37 footprint: rows Y-18..Y+18, aligned dwords covering columns X-18..X+18
   const uint8_t* bl = p.blur + (long long)img * g.pyrImg + L.off;
   const int xs = (X - 18) & ~3, mis = (X - 18) - xs;  // level pitch is a multiple of 64 -> rows are dword aligned
@@ -1333,29 +1349,24 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
         *reinterpret_cast<const uint32_t*>(bl + (long long)(Y - 18 + r) * L.pitch + xs + 4 * c);
   }
   if (ablate == 3) return;
-  // IC_Angle on the unblurred level
-  int pitch;
-  const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  int colsum = 0, m01 = 0;
-  {
-    const int c = lane & 31, h = lane >> 5;  // column u = c - 15, half h: rows 0,-1..-15 / 1..15
-    const int u = min(c, 30) - 15, au = u < 0 ? -u : u;
-    const uint8_t* col = im + (long long)Y * pitch + X + u;
-    constexpr int kUmax[17] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3, -1};
-    int vals[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++)  // all 16 loads are issued back to back (addresses are always inside the image)
-      vals[k] = col[(long long)(h ? min(k + 1, 15) : -k) * pitch];
+    for (int t = 0; t < 5; t++) {
+      const int i = lane + 64 * t;
+      const int ii = min(i, 278);
+      const int r = ii / 9, c = ii - r * 9;
+      const int v = r - 15;
+      const int lim = i < 279 ? um[t] : -1;
+      int rs = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const int v = h ? k + 1 : -k;
-      const int lim = h ? kUmax[k + 1] : kUmax[k];  // umax[|v|]; -1 masks the non-existent row 16
-      const int val = (c < 31 && au <= lim) ? vals[k] : 0;
-      colsum += val;
-      m01 += v * val;
+      for (int bI = 0; bI < 4; bI++) {
+        const int u = 4 * c + bI - misr - 15;
+        const int au = u < 0 ? -u : u;
+        const int val = au <= lim ? (int)((w[t] >> (8 * bI)) & 0xFF) : 0;
+        rs += val;
+        m10 += u * val;
+      }
+      m01 += v * rs;
     }
-  }
-  int m10 = (((lane & 31) - 15)) * colsum;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     m10 += __shfl_xor(m10, o);
