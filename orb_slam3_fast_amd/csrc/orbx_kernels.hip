@@ -148,7 +148,7 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 // mask has 9 contiguous ones (shift-and ladder).
 constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-constexpr int kListCap = 1024;  // LDS corner list of k_detect (flushed when it could overflow)
+constexpr int kListCap = 640;  // LDS corner list of k_detect (flushed when it could overflow)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
   uint32_t d = m | (m << 16);
