@@ -86,6 +86,8 @@ void orb_sincosf(float ang, float* s_out, float* c_out) {
 
 // ======================================================================================= B2 resize
 // cv::resize(INTER_LINEAR) CV_8UC1, generic fixed-point path (11-bit coefficients).
+// (For an exact 2x reduction OpenCV takes the INTER_AREA fast path instead; with fx = fy = 0.5 the formula below
+// reduces to the same (s00 + s01 + s10 + s11 + 2) >> 2, see tests/test_oracle_kernels.py.)
 void resize_linear_u8(const Image& src, Image& dst, int dw, int dh) {
   dst = Image(dw, dh);
   const int sw = src.w, sh = src.h;

@@ -110,6 +110,47 @@ def test_device_introsort_matches_libstdcxx(gpu, oracle):
         assert np.array_equal(a, b), "n=%d mode=%d" % (n, mode)
 
 
+@pytest.mark.parametrize("nf,sf,nl,ini,mn,w,h", [
+    (2000, 1.5, 5, 12, 5, 640, 480),      # other scale factor / thresholds / level count
+    (700, 2.0, 3, 30, 10, 512, 384),      # exact 2x steps: OpenCV switches INTER_LINEAR to the 2x2 INTER_AREA fast
+                                           # path there, which equals the fixed-point bilinear ((a+b+c+d+2)>>2)
+    (1200, 1.2, 8, 20, 7, 1280, 720),     # the reference's ZED2 yaml (Examples/Stereo-Inertial/Zed2.yaml:111)
+    (1000, 1.1, 12, 20, 7, 800, 600),     # 12 levels
+    (300, 1.2, 1, 20, 7, 320, 240),       # single level
+])
+def test_extractor_parameter_sweep(gpu, oracle, nf, sf, nl, ini, mn, w, h):
+    img = synth.mono_frame(w, h, 90 + nl)
+    ex = orbx.ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(nf, sf, nl, ini, mn)
+    mono, k, d = ex(img, (0, 0))
+    omono, ok_, od = oe.extract(img, (0, 0))
+    assert len(ok_) > nf // 2
+    assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+    for l in range(nl):
+        assert np.array_equal(ex.image_pyramid(l), oe.level(l))
+
+
+def test_fisheye_stereo_flow(gpu, oracle):
+    """TUM-VI-like config C4: 512x512, 1500 features, lapping areas, then the brute-force kNN of
+    ComputeStereoFishEyeMatches on the lapping descriptors [mono, N) of both eyes (src/Frame.cc:1275-1302)."""
+    w = h = 512
+    L, R = synth.stereo_pair(w, h, 95)
+    exL = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oL, oR = oracle.OracleExtractor(1500), oracle.OracleExtractor(1500)
+    lapL, lapR = (100, 511), (0, 400)
+    mL, kL, dL = exL(L, lapL)
+    mR, kR, dR = exR(R, lapR)
+    omL, okL, odL = oL.extract(L, lapL)
+    omR, okR, odR = oR.extract(R, lapR)
+    assert (mL, mR) == (omL, omR) and 0 < mL < len(kL) and 0 < mR < len(kR)
+    assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dL, odL)
+    assert np.array_equal(_kp_bytes(kR), _kp_bytes(okR)) and np.array_equal(dR, odR)
+    idx, dist, ok = orbx.bf_knn2(dL[mL:], dR[mR:])
+    oidx, odist, ook = oracle.bf_knn2(odL[omL:], odR[omR:])
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist) and np.array_equal(ok, ook) and ok.sum() > 20
+
+
 def test_lapping_area_partition(gpu, oracle):
     w, h = 640, 480
     img = synth.mono_frame(w, h, 21)

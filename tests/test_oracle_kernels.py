@@ -53,6 +53,14 @@ def test_resize_constant_and_identity(oracle):
     assert np.array_equal(oracle.resize(im, 64, 50), im)
 
 
+def test_resize_exact_half_equals_area_average(oracle):
+    rng = np.random.default_rng(8)
+    im = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    a = im.astype(np.int32)
+    box = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(oracle.resize(im, 64, 48), box)
+
+
 @pytest.mark.parametrize("sw,sh,dw,dh", [(640, 480, 533, 400), (357, 201, 298, 168), (64, 48, 53, 40),
                                          (1280, 720, 1067, 600), (100, 100, 250, 130)])
 def test_resize_vs_numpy_restatement(oracle, sw, sh, dw, dh):
