@@ -284,27 +284,29 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   if (ablate & 16) return;
   if (!(ablate & 1)) {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
+    // lane = (row phase, dword column): 16 columns x 4 rows per pass, no index divisions in the loop
     const int mis = iniX & 3, xa = iniX - mis;
     const int dpr = (rw + 3) >> 2;
-    const float inv = 1.0f / (float)dpr;
-    const int n = rh * dpr;
-    for (int idx = lane; idx < n; idx += 64) {
-      const int r = (int)(((float)idx + 0.5f) * inv);
-      const int cc = idx - r * dpr;
+    const int r0 = lane >> 4;
+    for (int cc = lane & 15; cc < dpr; cc += 16) {  // one trip unless the cell is wider than 58 px (tiny levels)
       const int gx = xa + 4 * cc;
-      const uint8_t* src = im + (long long)(iniY + r) * pitch + gx;
-      uint32_t lo, hi = 0;
-      if (gx + 8 <= L.w) {
-        lo = reinterpret_cast<const uint32_t*>(src)[0];
-        hi = reinterpret_cast<const uint32_t*>(src)[1];
-      } else {
-        uint64_t v = 0;
-        for (int k = 0; k < 8; k++)
-          if (gx + k < L.w) v |= (uint64_t)src[k] << (8 * k);
-        lo = (uint32_t)v;
-        hi = (uint32_t)(v >> 32);
+      const bool wide = gx + 8 <= L.w;
+      const uint8_t* src = im + (long long)(iniY + r0) * pitch + gx;
+      uint32_t* dstw = tile + r0 * TPd + cc;
+      for (int r = r0; r < rh; r += 4, src += 4 * (long long)pitch, dstw += 4 * TPd) {
+        uint32_t lo, hi = 0;
+        if (wide) {
+          lo = reinterpret_cast<const uint32_t*>(src)[0];
+          hi = reinterpret_cast<const uint32_t*>(src)[1];
+        } else {
+          uint64_t v = 0;
+          for (int k = 0; k < 8; k++)
+            if (gx + k < L.w) v |= (uint64_t)src[k] << (8 * k);
+          lo = (uint32_t)v;
+          hi = (uint32_t)(v >> 32);
+        }
+        *dstw = __builtin_amdgcn_alignbyte(hi, lo, mis);
       }
-      tile[r * TPd + cc] = __builtin_amdgcn_alignbyte(hi, lo, mis);
     }
     // zero ring of the score tile: rows 0 and dh+1, dword columns 0 and qpr+1
     for (int idx = lane; idx < SPd; idx += 64) {

@@ -117,6 +117,7 @@ def test_device_introsort_matches_libstdcxx(gpu, oracle):
     (1200, 1.2, 8, 20, 7, 1280, 720),     # the reference's ZED2 yaml (Examples/Stereo-Inertial/Zed2.yaml:111)
     (1000, 1.1, 12, 20, 7, 800, 600),     # 12 levels
     (300, 1.2, 1, 20, 7, 320, 240),       # single level
+    (200, 1.2, 2, 20, 7, 101, 99),        # one 69 x 67 cell per level (cells wider than 64 px)
 ])
 def test_extractor_parameter_sweep(gpu, oracle, nf, sf, nl, ini, mn, w, h):
     img = synth.mono_frame(w, h, 90 + nl)
