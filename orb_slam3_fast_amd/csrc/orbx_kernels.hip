@@ -159,23 +159,6 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits
   return (x & 0xFFFFu) != 0;
 }
 
-// Pixel slot P (0..3) of a quad: is the pixel a corner at threshold t?  r[row][dword] holds ROI bytes
-// [4j, 4j+12) of rows yd .. yd+6; the pixel is at row 3, byte 3 + P.
-template <int P>
-__device__ __forceinline__ bool fast_px(const uint32_t (&r)[7][3], int t) {
-  const int c = (r[3][(3 + P) >> 2] >> (8 * ((3 + P) & 3))) & 0xFF;
-  const int hi = c + t, lo = c - t;
-  uint32_t ab = 0, ad = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int col = 3 + P + kRingDX[k];
-    const int v = (r[3 + kRingDY[k]][col >> 2] >> (8 * (col & 3))) & 0xFF;
-    ab = __builtin_amdgcn_alignbit(ab, (uint32_t)(hi - v), 31);  // (ab << 1) | (v > hi)
-    ad = __builtin_amdgcn_alignbit(ad, (uint32_t)(v - lo), 31);  // (ad << 1) | (v < lo)
-  }
-  return has_arc9(ab & 0xFFFFu) || has_arc9(ad & 0xFFFFu);
-}
-
 // Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
 // polarity.  v_cmp leaves each comparison as a 64-lane mask in SGPRs, so the combination is scalar-ALU work:
 // per pixel slot 8 VALU compares + 14 scalar ops.  Returns the wave mask of lanes whose pixel survives.
@@ -196,47 +179,34 @@ __device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int 
          (D[2] & D[3]) | (D[3] & D[0]);
 }
 
-// Full FAST-9-16 test of one pixel addressed in the LDS tile (pitch TP bytes).
-__device__ __forceinline__ bool fast_test_lds(const uint8_t* c8, int TP, int t) {
+// FAST contrast of one pixel from the LDS tile: M = max over the 16 nine-pixel arcs of the arc's minimum
+// one-signed contrast = max( max_s min(arc_s) - c , c - min_s max(arc_s) ).  Sliding 9-windows are built from
+// 3-windows (v_min3 / v_max3): 16 + 16 + 8 three-input ops per polarity.  The pixel is a corner at threshold t
+// iff M > t, and its cornerScore is M - 1 — one pass gives both the decision and the score.
+__device__ __forceinline__ int fast_contrast_lds(const uint8_t* c8, int TP) {
+  int r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = c8[kRingDY[k] * TP + kRingDX[k]];
+  int lo3[16], hi3[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo3[i] = min(min(r[i], r[(i + 1) & 15]), r[(i + 2) & 15]);
+    hi3[i] = max(max(r[i], r[(i + 1) & 15]), r[(i + 2) & 15]);
+  }
+  int lo9[16], hi9[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo9[i] = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);
+    hi9[i] = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
+  }
+  int maxmin = lo9[0], minmax = hi9[0];
+#pragma unroll
+  for (int i = 1; i < 16; i++) {
+    maxmin = max(maxmin, lo9[i]);
+    minmax = min(minmax, hi9[i]);
+  }
   const int c = c8[0];
-  const int hi = c + t, lo = c - t;
-  uint32_t ab = 0, ad = 0;
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int v = c8[kRingDY[k] * TP + kRingDX[k]];
-    ab = __builtin_amdgcn_alignbit(ab, (uint32_t)(hi - v), 31);  // (ab << 1) | (v > hi)
-    ad = __builtin_amdgcn_alignbit(ad, (uint32_t)(v - lo), 31);  // (ad << 1) | (v < lo)
-  }
-  return has_arc9(ab & 0xFFFFu) || has_arc9(ad & 0xFFFFu);
-}
-
-// cornerScore of a known corner: M - 1, M = max over the 16 nine-pixel arcs of the arc's minimum
-// one-signed contrast, by sliding min / max with doubling.  c8 points at the pixel in the LDS tile (pitch TP).
-__device__ __forceinline__ int fast_score(const uint8_t* c8, int TP) {
-  const int c = c8[0];
-  int d[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) d[k] = c - (int)c8[kRingDY[k] * TP + kRingDX[k]];
-  int mn2[16], mx2[16], mn4[16], mx4[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    mn2[i] = min(d[i], d[(i + 1) & 15]);
-    mx2[i] = max(d[i], d[(i + 1) & 15]);
-  }
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
-    mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
-  }
-  int best_dark = -256, best_bright = 256;  // max of arc-min(d), min of arc-max(d)
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
-    const int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
-    best_dark = max(best_dark, mn9);
-    best_bright = min(best_bright, mx9);
-  }
-  return max(best_dark, -best_bright) - 1;
+  return max(maxmin - c, c - minmax);
 }
 
 // One wave per FAST cell (workgroup = 64 threads, so __syncthreads() is a wave barrier).
@@ -327,32 +297,26 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     // dense corner test, 4 pixels per lane; corners are compacted into an LDS list and scored with dense
     // lanes (the score needs ~110 min/max ops: running it under per-lane divergence would dominate).
     // Stage 1 (4 pixels per lane, registers): compass pre-test -> survivor list.
-    // Stage 2 (dense lanes over survivors): full 16-pixel arc test -> corner list.
-    // Stage 3 (dense lanes over corners): cornerScore -> u8 score tile.
+    // Stage 2 (dense lanes over survivors): contrast M from the 16 ring pixels; corner iff M > t, score M - 1
+    //          goes to the u8 score tile and the corner to the corner list (for the list-based NMS).
     int nList = 0, nSurv = 0;
-    bool overflowed = false;  // the corner list was flushed before the end: fall back to the tile-scan NMS
-    auto flush_corners = [&]() {
-      __syncthreads();
-      for (int e = lane; e < nList; e += 64) {
-        const int yx = list[e], y = yx >> 8, x = yx & 255;
-        score8[(y + 1) * g.scoreP + x + 4] = (uint8_t)fast_score(tile8 + (y + 3) * g.tileP + x + 3, g.tileP);
-      }
-      __syncthreads();
-    };
+    bool overflowed = false;  // more corners than the list holds: the NMS falls back to scanning the score tile
     auto flush_survivors = [&]() {
       __syncthreads();
       for (int base = 0; base < nSurv; base += 64) {
         const int e = base + lane;
         const int yx = slist[min(e, nSurv - 1)], y = yx >> 8, x = yx & 255;
-        const bool corner = e < nSurv && fast_test_lds(tile8 + (y + 3) * g.tileP + x + 3, g.tileP, t);
+        const int M = fast_contrast_lds(tile8 + (y + 3) * g.tileP + x + 3, g.tileP);
+        const bool corner = e < nSurv && M > t;
+        if (corner) score8[(y + 1) * g.scoreP + x + 4] = (uint8_t)(M - 1);
         const uint64_t m = __ballot(corner);
-        if (corner) list[nList + __popcll(m & lanemask_lt())] = (uint16_t)yx;
+        const int o = nList + __popcll(m & lanemask_lt());
+        if (corner && o < listCap) list[o] = (uint16_t)yx;
         nList += __popcll(m);
-        if (nList > listCap - 64) {
-          flush_corners();
-          nList = 0;
-          overflowed = true;
-        }
+      }
+      if (nList > listCap) {
+        overflowed = true;
+        nList = listCap;
       }
       __syncthreads();
       nSurv = 0;
@@ -387,8 +351,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       if (nSurv > listCap - 256) flush_survivors();
     }
     flush_survivors();
-    const int nCorners = nList;  // flush_corners() scores them but leaves the list intact
-    flush_corners();
+    const int nCorners = nList;
     // 3x3 non-max suppression (strict '>') inside the cell + emission
     if (ablate & 4) kept = 1;
     if (!(ablate & 4) && !overflowed) {
@@ -1082,15 +1045,21 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
+typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {  // a.lo*b.lo + a.hi*b.hi + c
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_us2, a), __builtin_bit_cast(orbx_us2, b), c, false);
+}
 #define BL_TW 128
 #define BL_TH 32
 // Tile of 128x32 outputs per 256-thread block.  In-tile: rows y0-3 .. y0+34, columns x0-4 .. x0+131 as aligned
 // dwords.  Horizontal pass: a thread turns 3 dwords into 4 outputs with 6 v_alignbyte + 8 v_dot4_u32_u8 (taps
-// 18,34,48,56 | 48,34,18,0), stored as u16 (max 255*256).  Vertical pass: a thread owns a 4x4 output block and
-// reads 10 rows x 4 u16.  All integer, exact; one rounding (+32768 >> 16) at the end.
+// 18,34,48,56 | 48,34,18,0) for TWO vertically adjacent rows and stores them as u16 pairs (row r | row r+1 << 16;
+// max 255*256 fits).  Vertical pass: a thread owns a 4x4 output block; with rows packed in pairs the 7-tap
+// column filter is 3 v_dot2_u32_u16 + 1 mad per output.  All integer, exact; one rounding (+32768 >> 16).
 __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
-  __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];   // +1: pad against bank conflicts
-  __shared__ uint32_t hp[BL_TH + 6][BL_TW / 2 + 1];       // two u16 per dword
+  __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];    // +1: pad against bank conflicts
+  __shared__ uint32_t hp[(BL_TH + 6) / 2][BL_TW + 1];      // [row pair][32*(x%4) + x/4] = H(2j, x) | H(2j+1, x) << 16
+                                                           // (quad-transposed columns: both passes bank-conflict free)
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   int tile = blockIdx.x;
@@ -1107,62 +1076,86 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   constexpr int IW = BL_TW / 4 + 2;  // in-tile dwords per row
-  for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
-    const int r = i / IW, c = i - r * IW;
-    const int y = y0 + r - 3, x = x0 - 4 + 4 * c;
-    uint32_t v;
-    if (y >= 0 && y < L.h && x >= 0 && x + 4 <= L.w) {
-      v = *reinterpret_cast<const uint32_t*>(im + (long long)y * pitch + x);
-    } else {  // image border: BORDER_REFLECT_101 (coordinates further out only feed discarded outputs)
-      const int yy = reflect101(min(max(y, -3), L.h + 2), L.h);
-      v = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int xx = reflect101(min(max(x + k, -3), L.w + 2), L.w);
-        v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * k);
-      }
+  if (x0 >= 4 && y0 >= 3 && x0 + BL_TW + 4 <= L.w && y0 + BL_TH + 3 <= L.h) {
+    // interior tile: every dword is inside the image
+    const uint8_t* base = im + (long long)(y0 - 3) * pitch + (x0 - 4);
+    for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
+      const int r = i / IW, c = i - r * IW;
+      in[r][c] = *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch + 4 * c);
     }
-    in[r][c] = v;
+  } else {
+    for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
+      const int r = i / IW, c = i - r * IW;
+      const int y = y0 + r - 3, x = x0 - 4 + 4 * c;
+      uint32_t v;
+      if (y >= 0 && y < L.h && x >= 0 && x + 4 <= L.w) {
+        v = *reinterpret_cast<const uint32_t*>(im + (long long)y * pitch + x);
+      } else {  // image border: BORDER_REFLECT_101 (coordinates further out only feed discarded outputs)
+        const int yy = reflect101(min(max(y, -3), L.h + 2), L.h);
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int xx = reflect101(min(max(x + k, -3), L.w + 2), L.w);
+          v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * k);
+        }
+      }
+      in[r][c] = v;
+    }
   }
   __syncthreads();
-  for (int i = tid; i < (BL_TH + 6) * (BL_TW / 4); i += 256) {
-    const int r = i / (BL_TW / 4), c = i - r * (BL_TW / 4);
-    const uint32_t Lw = in[r][c], C = in[r][c + 1], R = in[r][c + 2];
-    const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps -3..0 and +1..+3 (LSB = lowest x)
-    const uint32_t h0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 1), wA,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), wB, 0, false), false);
-    const uint32_t h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 2), wA,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), wB, 0, false), false);
-    const uint32_t h2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 3), wA,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), wB, 0, false), false);
-    const uint32_t h3 = __builtin_amdgcn_udot4(C, wA, __builtin_amdgcn_udot4(R, wB, 0, false), false);
-    hp[r][2 * c] = h0 | (h1 << 16);
-    hp[r][2 * c + 1] = h2 | (h3 << 16);
+  // horizontal pass: item = (row pair j, dword column c): 19 x 32 items
+  for (int i = tid; i < ((BL_TH + 6) / 2) * (BL_TW / 4); i += 256) {
+    const int j = i / (BL_TW / 4), c = i - j * (BL_TW / 4);
+    uint32_t h[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      const uint32_t Lw = in[2 * j + rr][c], C = in[2 * j + rr][c + 1], R = in[2 * j + rr][c + 2];
+      const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps -3..0 and +1..+3 (LSB = lowest x)
+      h[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 1), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), wB, 0, false), false);
+      h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 2), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 2), wB, 0, false), false);
+      h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 3), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 3), wB, 0, false), false);
+      h[rr][3] = __builtin_amdgcn_udot4(C, wA, __builtin_amdgcn_udot4(R, wB, 0, false), false);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) hp[j][32 * k + c] = h[0][k] | (h[1][k] << 16);  // column 4c+k -> slot 32k+c
   }
   __syncthreads();
   {
-    const int bc = tid & 31, br = tid >> 5;  // 32 x 8 blocks of 4x4 outputs
-    uint32_t lo[10], hi[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-      lo[k] = hp[4 * br + k][2 * bc];
-      hi[k] = hp[4 * br + k][2 * bc + 1];
-    }
+    const int bc = tid & 31, br = tid >> 5;  // 32 x 8 blocks of 4x4 outputs; block rows 4*br .. 4*br+3 (even start)
     uint8_t* dst = p.blur + (long long)img * g.pyrImg + L.off;
+    uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int cI = 0; cI < 4; cI++) {
+      uint32_t pr[5];  // row pairs (4br .. 4br+9) of column 4*bc + cI
+#pragma unroll
+      for (int k = 0; k < 5; k++) pr[k] = hp[2 * br + k][32 * cI + bc];  // lanes read consecutive dwords
+      // taps {18,34,48,56,48,34,18} on rows r..r+6
+      const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16);   // even start
+      const uint32_t v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);   // odd start
+#pragma unroll
+      for (int rr = 0; rr < 4; rr++) {
+        uint32_t acc;
+        if ((rr & 1) == 0) {  // rows r = 4br + rr (even): pairs k0 = rr/2 .. k0+2, then the low half of pair k0+3
+          const int k0 = rr >> 1;
+          acc = udot2_u16(pr[k0], w01, 18u * (pr[k0 + 3] & 0xFFFFu));
+          acc = udot2_u16(pr[k0 + 1], w23, acc);
+          acc = udot2_u16(pr[k0 + 2], w45, acc);
+        } else {              // odd r: high half of pair k0, then pairs k0+1 .. k0+3
+          const int k0 = rr >> 1;
+          acc = udot2_u16(pr[k0 + 1], v12, 18u * (pr[k0] >> 16));
+          acc = udot2_u16(pr[k0 + 2], v34, acc);
+          acc = udot2_u16(pr[k0 + 3], v56, acc);
+        }
+        outw[rr] |= ((acc + 32768u) >> 16) << (8 * cI);
+      }
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
-      uint32_t w = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        auto H = [&](int k) -> uint32_t {
-          const uint32_t v = (j < 2) ? lo[rr + k] : hi[rr + k];
-          return (j & 1) ? (v >> 16) : (v & 0xFFFFu);
-        };
-        const uint32_t acc = 18u * (H(0) + H(6)) + 34u * (H(1) + H(5)) + 48u * (H(2) + H(4)) + 56u * H(3);
-        w |= ((acc + 32768u) >> 16) << (8 * j);
-      }
       const int y = y0 + 4 * br + rr, x = x0 + 4 * bc;
-      if (y < L.h && x < L.w) *reinterpret_cast<uint32_t*>(dst + (long long)y * L.pitch + x) = w;
+      if (y < L.h && x < L.w) *reinterpret_cast<uint32_t*>(dst + (long long)y * L.pitch + x) = outw[rr];
     }
   }
 }
