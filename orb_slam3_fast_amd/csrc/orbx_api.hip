@@ -345,13 +345,15 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   // The blurred copies only depend on the pyramid.  They run on the side stream, released once k_detect (which
   // fills the chip by itself) is done, so that the streaming blur shares the GPU with the latency-bound quadtree.
   // (Also tried: FAST on level 0 beside the resize chain -- slower, 1.48 vs 1.33 ms/step: both just time-slice.)
+  static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
+  hipStream_t sb = serial ? s : ex->stream2;
   HIPC(hipEventRecord(ex->evPyr, s));
-  HIPC(hipStreamWaitEvent(ex->stream2, ex->evPyr, 0));
+  HIPC(hipStreamWaitEvent(sb, ex->evPyr, 0));
   {
-    StageTimer t(ex, ex->stream2, ORBX_STAGE_BLUR);
-    HIPC(launch_blur(g, ex->pyr, n, ex->stream2));
+    StageTimer t(ex, sb, ORBX_STAGE_BLUR);
+    HIPC(launch_blur(g, ex->pyr, n, sb));
   }
-  HIPC(hipEventRecord(ex->evBlur, ex->stream2));
+  HIPC(hipEventRecord(ex->evBlur, sb));
   {
     StageTimer t(ex, s, ORBX_STAGE_OCTREE);
     HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,

@@ -633,24 +633,33 @@ __host__ __device__ inline int oct_maxcells(const Geom& g) {
 }
 size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g), oct_maxcells(g)).total; }
 
-// Exclusive scan of n u64 values in LDS (in place) by a 256-thread block; returns the total.
+constexpr int OCT_NT = 512;  // threads per quadtree block: halves the key-loop trip counts vs 256, 2 blocks/CU stay resident
+// Exclusive scan of n u64 values in LDS (in place) by an OCT_NT-thread block; returns the total.
 // Packed fields must not overflow into each other (callers keep each field < 2^21).
+// Per-thread chunk sums are scanned inside each wave with DPP/bpermute shuffles (no barriers); only the four
+// wave totals go through LDS: 2 barriers per call instead of the 18 of a Hillis-Steele scan over 256 threads.
 __device__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
-  const int tid = threadIdx.x;
-  const int per = (n + 255) >> 8;
-  const int b = tid * per, e = min(b + per, n);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (n + OCT_NT - 1) / OCT_NT;
+  const int b = min(tid * per, n), e = min(b + per, n);
   uint64_t s = 0;
   for (int i = b; i < e; i++) s += v[i];
-  tsum[tid] = s;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    uint64_t t = tid >= d ? tsum[tid - d] : 0;
-    __syncthreads();
-    tsum[tid] += t;
-    __syncthreads();
+  uint64_t incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t t = __shfl_up((unsigned long long)incl, d);
+    if (lane >= d) incl += t;
   }
-  const uint64_t total = tsum[255];
-  uint64_t run = tid ? tsum[tid - 1] : 0;
+  if (lane == 63) tsum[wv] = incl;
+  __syncthreads();
+  uint64_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < OCT_NT / 64; w++) {
+    const uint64_t t = tsum[w];
+    if (w < wv) wbase += t;
+    total += t;
+  }
+  uint64_t run = wbase + incl - s;
   for (int i = b; i < e; i++) {
     const uint64_t t = v[i];
     v[i] = run;
@@ -665,7 +674,7 @@ __device__ __forceinline__ int quadrant(int x, int y, int x0, int x1, int y0, in
   return (x < x0 + hx ? 0 : 1) | (y < y0 + hy ? 0 : 2);
 }
 
-__global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
+__global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
                                                 uint32_t* __restrict__ cand, int* __restrict__ candCount,
                                                 uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
@@ -699,21 +708,30 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   {
     const int cells = L.nCols * L.nRows;
     const int* cc = cellCount + (long long)img * g.totalCells + L.cellStart;
-    const int per = (cells + 255) >> 8;
+    const int per = (cells + OCT_NT - 1) / OCT_NT;
     const int cb = min(tid * per, cells), ce = min(cb + per, cells);
-    uint64_t sum = 0;
-    for (int c = cb; c < ce; c++) sum += (uint64_t)cc[c];
-    tsum[tid] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const uint64_t t = tid >= d ? tsum[tid - d] : 0;
-      __syncthreads();
-      tsum[tid] += t;
-      __syncthreads();
+    int sum = 0;
+    for (int c = cb; c < ce; c++) sum += cc[c];
+    int incl = sum;
+    {
+      const int lane = tid & 63;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) tsum[tid >> 6] = (uint64_t)incl;
     }
-    const int total = (int)tsum[255];
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_NT / 64; w++) {
+      const int t = (int)tsum[w];
+      if (w < (tid >> 6)) wbase += t;
+      total += t;
+    }
     n = min(total, L.candCap);
-    int run = tid ? (int)tsum[tid - 1] : 0;
+    int run = wbase + incl - sum;
     for (int c = cb; c < ce; c++) {
       cellpre[c] = run;
       run += cc[c];
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     __syncthreads();
     // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
     const uint32_t* sparse = cellCand + (long long)img * g.cellImg + L.cellOff;
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += OCT_NT) {
       int lo = 0, hi = cells;  // largest c with cellpre[c] <= k
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -747,7 +765,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   // ---- roots (:575-601)
   if (tid < kMaxIni) cnt4[tid] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += OCT_NT) {
     const int r = (int)((float)key_x(keys[k]) / hX);
     kn[k] = (uint16_t)r;
     atomicAdd(&cnt4[r], 1u);
@@ -771,7 +789,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     s_i[0] = na;
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) kn[k] = cpos[kn[k]];
+  for (int k = tid; k < n; k += OCT_NT) kn[k] = cpos[kn[k]];
   int nA = s_i[0];
   int cur = 0;
   __syncthreads();
@@ -782,9 +800,9 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   // ---- phase 1: split every expandable node per pass (:610-677)
   while (!finish) {
     const int prevSize = nA;
-    for (int i = tid; i < nA * 4; i += 256) cnt4[i] = 0;
+    for (int i = tid; i < nA * 4; i += OCT_NT) cnt4[i] = 0;
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += OCT_NT) {
       const int nd = kn[k];
       if (ncnt[cur][nd] > 1) {
         const uint32_t key = keys[k];
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
       }
     }
     __syncthreads();
-    for (int i = tid; i < nA; i += 256) {
+    for (int i = tid; i < nA; i += OCT_NT) {
       uint64_t c = 0, nm = 1, ce = 0;
       if (ncnt[cur][i] > 1) {
         nm = 0;
@@ -809,7 +827,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     const uint64_t tot = block_scan_u64(scan, nA, tsum);
     const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
     const int nxt = cur ^ 1;
-    for (int i = tid; i < nA; i += 256) {
+    for (int i = tid; i < nA; i += OCT_NT) {
       const uint64_t pre = scan[i];
       const int pc = (int)(pre & 0x1FFFFF), pnm = (int)((pre >> 21) & 0x1FFFFF), pce = (int)(pre >> 42);
       if (ncnt[cur][i] > 1) {
@@ -850,7 +868,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
       }
     }
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += OCT_NT) {
       const int v = kn[k], nd = v & 0x3FFF;
       kn[k] = ncnt[cur][nd] > 1 ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
     }
@@ -878,12 +896,12 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
     }
-    for (int i = tid; i < nA * 4; i += 256) cnt4[i] = 0;
-    for (int i = tid; i < nA; i += 256) mark[i] = 0;
+    for (int i = tid; i < nA * 4; i += OCT_NT) cnt4[i] = 0;
+    for (int i = tid; i < nA; i += OCT_NT) mark[i] = 0;
     __syncthreads();
-    for (int m = tid; m < nE; m += 256) mark[(int)(E[nE - 1 - m] & 0xFFFF)] = (uint16_t)(m + 1);
+    for (int m = tid; m < nE; m += OCT_NT) mark[(int)(E[nE - 1 - m] & 0xFFFF)] = (uint16_t)(m + 1);
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += OCT_NT) {
       const int nd = kn[k];
       if (mark[nd]) {
         const uint32_t key = keys[k];
@@ -894,7 +912,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     }
     __syncthreads();
     // scan over the processing order m: c (children), ce (expandable children)
-    for (int m = tid; m < nE; m += 256) {
+    for (int m = tid; m < nE; m += OCT_NT) {
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
       uint64_t c = 0, ce = 0;
       for (int q = 0; q < 4; q++) {
@@ -906,7 +924,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     __syncthreads();
     block_scan_u64(scan, nE, tsum);
     // first m at which the list reaches N nodes: size after m+1 expansions = nA + C_incl(m) - (m+1)
-    for (int m = tid; m < nE; m += 256) {
+    for (int m = tid; m < nE; m += OCT_NT) {
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
       int c = 0;
       for (int q = 0; q < 4; q++) c += cnt4[nd * 4 + q] > 0;
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     }
     const int nxt = cur ^ 1;
     // children of processed nodes: later processed first, each group n4..n1
-    for (int m = tid; m < nP; m += 256) {
+    for (int m = tid; m < nP; m += OCT_NT) {
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
       const int x0 = nx0[cur][nd], x1 = nx1[cur][nd], y0 = ny0[cur][nd], y1 = ny1[cur][nd];
       const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
@@ -968,10 +986,10 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     }
     __syncthreads();
     // untouched nodes keep their relative order behind the new children
-    for (int i = tid; i < nA; i += 256) scan[i] = (mark[i] == 0 || mark[i] > nP) ? 1 : 0;
+    for (int i = tid; i < nA; i += OCT_NT) scan[i] = (mark[i] == 0 || mark[i] > nP) ? 1 : 0;
     __syncthreads();
     const int nKeep = (int)block_scan_u64(scan, nA, tsum);
-    for (int i = tid; i < nA; i += 256) {
+    for (int i = tid; i < nA; i += OCT_NT) {
       if (mark[i] == 0 || mark[i] > nP) {
         const int pos = tc + (int)scan[i];
         nx0[nxt][pos] = nx0[cur][i];
@@ -983,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
       }
     }
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
+    for (int k = tid; k < n; k += OCT_NT) {
       const int v = kn[k], nd = v & 0x3FFF;
       const int mk = mark[nd];
       kn[k] = (mk != 0 && mk <= nP) ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
@@ -999,9 +1017,9 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   OCT_EXIT(4)
   // ---- best response per node, first candidate (reference order) wins ties (:741-754)
   uint64_t* best = scan;
-  for (int i = tid; i < nA; i += 256) best[i] = 0;
+  for (int i = tid; i < nA; i += OCT_NT) best[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += OCT_NT) {
     const uint32_t key = keys[k];
     const int xr = key_x(key) - 3, yr = key_y(key) - 3;  // relative to the first detectable pixel (19,19)
     const int cy = yr / L.hCell, cx = xr / L.wCell;
@@ -1009,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
     atomicMax((unsigned long long*)&best[kn[k]], ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank));
   }
   __syncthreads();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += OCT_NT) {
     const uint32_t key = keys[k];
     const int xr = key_x(key) - 3, yr = key_y(key) - 3;
     const int cy = yr / L.hCell, cx = xr / L.wCell;
@@ -1019,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_octree(Geom g, const uint32_t* __restri
   }
   __syncthreads();
   const int nOut = min(nA, L.selCap);
-  for (int i = tid; i < nOut; i += 256) {
+  for (int i = tid; i < nOut; i += OCT_NT) {
     const uint32_t key = keys[bestk[i]];
     out[i] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
   }
@@ -1031,7 +1049,7 @@ hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, cons
                          hipStream_t s) {
   dim3 grid(g.nlevels, nimg);
   static const int ablate = getenv("ORBX_OCTREE_ABLATE") ? atoi(getenv("ORBX_OCTREE_ABLATE")) : 0;
-  hipLaunchKernelGGL(k_octree, grid, dim3(256), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
+  hipLaunchKernelGGL(k_octree, grid, dim3(OCT_NT), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
                      candCount, knode, sel, selCount, ablate);
   return hipGetLastError();
 }
