@@ -152,6 +152,7 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
 #define ORBX_STAGE_STEREO_MATCH 6
 #define ORBX_STAGE_STEREO_FILTER 7
 #define ORBX_NUM_STAGES 8
+/* on: 0 = off, 1 = bracket every kernel launch, 2 + s = bracket only the launches of stage s. */
 int orbx_profile_enable(orbx_extractor* ex, int on);
 /* Synchronises the stream, adds up the elapsed milliseconds / launch counts per stage since the last
  * collect and resets the log.  ms and launches hold ORBX_NUM_STAGES entries. */

@@ -196,8 +196,13 @@ class ORBextractor:
         return a.value, b.value, c.value, d.value, cap.value
 
     # ---- measurement
-    def profile_enable(self, on=True):
-        _check(lib().orbx_profile_enable(self._h, int(on)))
+    def profile_enable(self, on=True, stage=None):
+        """on=True: bracket every kernel launch with HIP events; stage="k_detect" etc.: only that kernel."""
+        mode = int(bool(on))
+        if on and stage is not None:
+            names = [lib().orbx_stage_name(s).decode() for s in range(NUM_STAGES)]
+            mode = 2 + names.index(stage)
+        _check(lib().orbx_profile_enable(self._h, mode))
 
     def profile_collect(self):
         """{stage name: (total ms, launches)} since the last collect (HIP events on the launch stream)."""

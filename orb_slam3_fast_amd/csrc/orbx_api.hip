@@ -79,6 +79,7 @@ struct orbx_extractor {
   int stereoPairs = 0;
   // per-launch HIP event log (orbx_profile_*)
   bool profiling = false;
+  int profStage = -1;              // >= 0: only launches of this stage are bracketed
   std::vector<hipEvent_t> evPool;
   size_t evCursor = 0;
   struct EvRec { int stage; size_t e0, e1; };
@@ -107,8 +108,12 @@ struct StageTimer {
   int stage;
   size_t i0 = 0;
   bool on;
-  StageTimer(orbx_extractor* ex_, hipStream_t s_, int stage_) : ex(ex_), s(s_), stage(stage_), on(ex_->profiling) {
-    if (!on) return;
+  StageTimer(orbx_extractor* ex_, hipStream_t s_, int stage_)
+      : ex(ex_), s(s_), stage(stage_), on(ex_->profiling && (ex_->profStage < 0 || ex_->profStage == stage_)) {
+    if (!on) {
+      if (s == ex->stream) ex->lastEvValid = false;  // the chain of shared boundary events is broken here
+      return;
+    }
     if (s == ex->stream && ex->lastEvValid) {
       i0 = ex->lastEv;
     } else {
@@ -777,7 +782,10 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
 
 int orbx_profile_enable(orbx_extractor* ex, int on) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  // on: 0 = off, 1 = every kernel launch, 2 + s = only launches of stage s (ORBX_STAGE_*)
   ex->profiling = on != 0;
+  ex->profStage = on >= 2 ? on - 2 : -1;
+  ex->lastEvValid = false;
   return ORBX_OK;
 }
 
