@@ -139,6 +139,17 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
                                    float min_y, float max_x, float max_y, float* prev_matched,
                                    int32_t* matches12, int window_size, float nnratio, int check_orientation);
 
+/* Replaces Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:520-547,833-844: 64 x 48 grid, round-to-cell) and
+ * Frame::GetFeaturesInArea (src/Frame.cc:765-831) for a batch of queries.  kps = mvKeysUn (n), bounds = mnMinX/Y,
+ * mnMaxX/Y; queries = n_queries x {x, y, r, minLevel, maxLevel} floats.  Output is CSR: offsets[n_queries + 1] and
+ * indices (keypoint indices in the reference's order: ix outer, iy inner, in-cell ascending).  Optionally returns
+ * the grid itself: grid_cell_start[64*48 + 1] (cell ix*48 + iy) and grid_items[n] (= mGrid[ix][iy] concatenated).
+ * Returns the total number of indices or a negative error (ORBX_E_CAPACITY if indices_cap is too small; offsets are
+ * still valid then). */
+int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x,
+                          float max_y, const float* queries, int n_queries, int32_t* offsets, int32_t* indices,
+                          int indices_cap, int32_t* grid_cell_start, int32_t* grid_items);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events recorded on the handle's own stream around every kernel launch (the

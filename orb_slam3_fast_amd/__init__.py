@@ -64,6 +64,7 @@ def lib():
         L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
+        L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
         L.orbx_stage_name.restype = C.c_char_p
@@ -258,6 +259,24 @@ def bf_knn2(descQ, descT, device=0):
     ok = np.zeros(len(q), np.uint8)
     _check(lib().orbx_bf_knn2(device, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist), _p(ok)))
     return idx, dist, ok
+
+
+def GetFeaturesInArea(kpsUn, bounds, queries, device=0, return_grid=False):
+    """Frame::AssignFeaturesToGrid + GetFeaturesInArea (src/Frame.cc:520-547,765-844) for a batch of queries
+    (rows of x, y, r, minLevel, maxLevel).  Returns a list of index arrays (reference order), optionally the
+    grid as (cell_start[3073], items[n])."""
+    k = np.ascontiguousarray(kpsUn, KP_DTYPE)
+    q = np.ascontiguousarray(queries, np.float32).reshape(-1, 5)
+    offs = np.zeros(len(q) + 1, np.int32)
+    cs = np.zeros(64 * 48 + 1, np.int32)
+    items = np.zeros(max(len(k), 1), np.int32)
+    cap = max(1, len(k)) * max(1, len(q))
+    idx = np.zeros(min(cap, 1 << 26), np.int32)
+    tot = _check(lib().orbx_features_in_area(device, _p(k), len(k), bounds[0], bounds[1], bounds[2], bounds[3], _p(q),
+                                             len(q), _p(offs), _p(idx), len(idx), _p(cs), _p(items)))
+    res = [idx[offs[i]:offs[i + 1]].copy() for i in range(len(q))]
+    assert tot == offs[-1]
+    return (res, cs, items[:len(k)]) if return_grid else res
 
 
 class ORBmatcher:

@@ -780,6 +780,57 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   return res[0];
 }
 
+int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x,
+                          float max_y, const float* queries, int n_queries, int32_t* offsets, int32_t* indices,
+                          int indices_cap, int32_t* grid_cell_start, int32_t* grid_items) {
+  if (n < 0 || n_queries < 0 || (n && !kps) || (n_queries && (!queries || !offsets)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  DevBuf<orbx_keypoint> k;
+  DevBuf<float> q;
+  DevBuf<int> cellStart, cellItems, qOff, out, mdist, m21, m12, result;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  const int nn = std::max(n, 1), nq = std::max(n_queries, 1);
+  chk(k.alloc(nn)); chk(q.alloc((size_t)nq * 5)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(nn));
+  chk(qOff.alloc(nq + 1)); chk(mdist.alloc(nn)); chk(m21.alloc(nn)); chk(m12.alloc(1)); chk(result.alloc(2));
+  if (e == hipSuccess && n) chk(hipMemcpy(k.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+  if (e == hipSuccess && n_queries) chk(hipMemcpy(q.p, queries, (size_t)n_queries * 5 * sizeof(float), hipMemcpyHostToDevice));
+  InitArgs a{};
+  a.k2 = k.p; a.n2 = n; a.n1 = 0;
+  a.minX = min_x; a.minY = min_y;
+  a.invW = 64.f / (max_x - min_x);
+  a.invH = 48.f / (max_y - min_y);
+  a.cellStart = cellStart.p; a.cellItems = cellItems.p; a.matchedDist = mdist.p; a.matches21 = m21.p;
+  a.matches12 = m12.p; a.result = result.p; a.candOff = qOff.p; a.candCap = 1 << 30;
+  int total = 0;
+  if (e == hipSuccess) chk(launch_grid_build(a, nullptr));
+  if (e == hipSuccess && n_queries) {
+    chk(launch_area_query(a, q.p, n_queries, qOff.p, nullptr, 0, nullptr));
+    a.n1 = n_queries;  // k_init_scan scans candOff[0..n1)
+    if (e == hipSuccess) chk(launch_scan_offsets(a, nullptr));
+    if (e == hipSuccess) chk(hipDeviceSynchronize());
+    if (e == hipSuccess) chk(hipMemcpy(&total, qOff.p + n_queries, sizeof(int), hipMemcpyDeviceToHost));
+    if (e == hipSuccess) chk(hipMemcpy(offsets, qOff.p, (size_t)(n_queries + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (e == hipSuccess && total > 0 && indices && total <= indices_cap) {
+      chk(out.alloc(total));
+      if (e == hipSuccess) chk(launch_area_query(a, q.p, n_queries, qOff.p, out.p, 1, nullptr));
+      if (e == hipSuccess) chk(hipDeviceSynchronize());
+      if (e == hipSuccess) chk(hipMemcpy(indices, out.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    }
+  }
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess && grid_cell_start)
+    chk(hipMemcpy(grid_cell_start, cellStart.p, (64 * 48 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess && grid_items && n) chk(hipMemcpy(grid_items, cellItems.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  k.free(); q.free(); cellStart.free(); cellItems.free(); qOff.free(); out.free(); mdist.free(); m21.free(); m12.free();
+  result.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (indices && total > indices_cap) return fail(ORBX_E_CAPACITY, "indices buffer too small");
+  return total;
+}
+
 int orbx_profile_enable(orbx_extractor* ex, int on) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
   // on: 0 = off, 1 = every kernel launch, 2 + s = only launches of stage s (ORBX_STAGE_*)

@@ -126,6 +126,9 @@ struct InitArgs {
   int* matches21;                // n2
   int* result;                   // [0]=nmatches, [1]=overflow flag
 };
+hipError_t launch_grid_build(const InitArgs& a, hipStream_t s);        // AssignFeaturesToGrid of (k2, n2) as CSR
+hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s);
+hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s);
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s);       // grid + candidate counts + scan
 hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s);  // candidate fill + serial resolve
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits

@@ -1943,6 +1943,59 @@ __global__ __launch_bounds__(64) void k_init_resolve(InitArgs a) {
   if (lane == 0) a.result[0] = nmatches;
 }
 
+// Frame::GetFeaturesInArea (src/Frame.cc:765-831) for a batch of queries (x, y, r, minLevel, maxLevel): one wave
+// per query walks the cells in the reference's order (ix outer, iy inner, in-cell order).  pass 0 counts,
+// pass 1 writes the indices at qOff[q].
+__global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __restrict__ q, int nq,
+                                                    int* __restrict__ qOff, int* __restrict__ out, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const float x = q[5 * qi], y = q[5 * qi + 1], r = q[5 * qi + 2];
+  const int minLevel = (int)q[5 * qi + 3], maxLevel = (int)q[5 * qi + 4];
+  const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+  int total = 0;
+  const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+    const int wbase = pass ? qOff[qi] : 0;
+    for (int ix = cx0; ix <= cx1; ix++)
+      for (int iy = cy0; iy <= cy1; iy++) {
+        const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
+        for (int base = b; base < e; base += 64) {
+          const int j = base + lane;
+          bool ok = false;
+          int i2 = 0;
+          if (j < e) {
+            i2 = a.cellItems[j];
+            const orbx_keypoint k2 = a.k2[i2];
+            ok = !(checkLevels && (k2.octave < minLevel || (maxLevel >= 0 && k2.octave > maxLevel))) &&
+                 fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+          }
+          const uint64_t m = __ballot(ok);
+          if (pass && ok) out[wbase + total + __popcll(m & lanemask_lt())] = i2;
+          total += __popcll(m);
+        }
+      }
+  }
+  if (!pass && lane == 0) qOff[qi] = total;
+}
+
+hipError_t launch_grid_build(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s) {
+  if (nq > 0) hipLaunchKernelGGL(k_area_query, dim3((nq + 3) / 4), dim3(256), 0, s, a, q, nq, qOff, out, pass);
+  return hipGetLastError();
+}
+hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s) {  // exclusive scan of a.candOff[0..n1] (n1 = #queries)
+  hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
   if (a.n1 > 0) {

@@ -248,6 +248,33 @@ def test_bf_knn2(gpu, oracle):
         assert np.array_equal(i, oi) and np.array_equal(d, od) and np.array_equal(okk, ook)
 
 
+def test_features_in_area_and_grid(gpu, oracle):
+    """AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea as a standalone batched call."""
+    w, h = 752, 480
+    ex = orbx.ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    _, k, _ = ex(synth.mono_frame(w, h, 55))
+    bounds = (0.0, 0.0, float(w), float(h))
+    rng = np.random.default_rng(11)
+    q = np.stack([rng.uniform(-50, w + 50, 200), rng.uniform(-50, h + 50, 200), rng.choice([5.0, 15.0, 40.0, 100.0], 200),
+                  rng.choice([-1.0, 0.0, 1.0, 2.0], 200), rng.choice([-1.0, 0.0, 2.0, 7.0], 200)], 1).astype(np.float32)
+    q[0] = (k["x"][3], k["y"][3], 10.0, 0, 0)
+    res, cs, items = orbx.GetFeaturesInArea(k, bounds, q, return_grid=True)
+    nonempty = 0
+    for i in range(len(q)):
+        want = oracle.features_in_area(k, bounds, q[i, 0], q[i, 1], q[i, 2], int(q[i, 3]), int(q[i, 4]))
+        assert np.array_equal(res[i], want), i
+        nonempty += len(want) > 0
+    assert nonempty > 50
+    # the grid itself: PosInGrid rounds to the nearest cell; lists hold ascending indices
+    invw, invh = np.float32(64.0) / np.float32(w), np.float32(48.0) / np.float32(h)
+    px = np.floor((k["x"] * invw).astype(np.float32) + np.float32(0.5)).astype(int)   # round() of non-negative values
+    py = np.floor((k["y"] * invh).astype(np.float32) + np.float32(0.5)).astype(int)
+    for c in rng.integers(0, 64 * 48, 300):
+        got = items[cs[c]:cs[c + 1]]
+        want = np.nonzero((px == c // 48) & (py == c % 48) & (px < 64) & (py < 48))[0]
+        assert np.array_equal(got, want)
+
+
 def test_search_for_initialization(gpu, oracle):
     w, h = 752, 480
     f1, f2 = synth.mono_frame(w, h, 50, 0), synth.mono_frame(w, h, 50, 1)
