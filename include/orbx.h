@@ -150,6 +150,29 @@ int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min
                           float max_y, const float* queries, int n_queries, int32_t* offsets, int32_t* indices,
                           int indices_cap, int32_t* grid_cell_start, int32_t* grid_items);
 
+/* ---- widening row f1: projection-guided matching ------------------------------------------ */
+
+/* The MapPoint members ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, ...) reads
+ * (src/ORBmatcher.cc:41-221): mTrackProjX/Y/XR, mTrackViewCos, mTrackDepth, mnTrackScaleLevel, mbTrackInView,
+ * isBad(), Observations() > 0, GetDescriptor().  60 bytes. */
+typedef struct orbx_map_point_view {
+  float proj_x, proj_y, proj_xr, view_cos, track_depth;
+  int32_t predicted_level;
+  uint8_t in_view, bad, has_observations, pad_;
+  uint8_t desc[32];
+} orbx_map_point_view;
+
+/* Replaces ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, th, bFarPoints,
+ * thFarPoints) (src/ORBmatcher.cc:41-221) for the pinhole case (F.Nleft == -1), serial iMP semantics.
+ * F is given by mvKeysUn (n), mDescriptors, mvuRight (may be NULL), the grid bounds mnMinX/Y, mnMaxX/Y and
+ * mvScaleFactors (nlevels).  occupied[i] != 0 <=> F.mvpMapPoints[i] already holds a point with Observations() > 0
+ * (in/out).  match[i] receives the index of the map point newly assigned to keypoint i, or -1.
+ * Returns nmatches or a negative error. */
+int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                              int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                              int nlevels, const orbx_map_point_view* map_points, int n_map_points, float th,
+                              int far_points, float th_far_points, float nnratio, uint8_t* occupied, int32_t* match);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events recorded on the handle's own stream around every kernel launch (the

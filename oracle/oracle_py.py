@@ -196,6 +196,27 @@ def search_init(k1, d1, k2, d2, bounds, prev, window=100, nnratio=0.9, check_ori
     return n, m, prev
 
 
+MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
+                     ("predicted_level", "<i4"), ("in_view", "u1"), ("bad", "u1"), ("has_observations", "u1"),
+                     ("pad_", "u1"), ("desc", "u1", (32,))])
+assert MP_DTYPE.itemsize == 60
+
+
+def search_by_projection(k, desc, uright, bounds, scale_factors, mps, th, far, th_far, nnratio, occupied):
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    mps = np.ascontiguousarray(mps, MP_DTYPE)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.zeros(len(k), np.int32)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    n = lib().oro_search_by_projection(_p(k), _p(desc), None if ur is None else _p(ur), len(k), C.c_float(bounds[0]),
+                                       C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(sf), len(sf),
+                                       _p(mps), len(mps), C.c_float(th), int(far), C.c_float(th_far), C.c_float(nnratio),
+                                       _p(occ), _p(match))
+    return n, match, occ
+
+
 def features_in_area(k, bounds, x, y, r, min_level, max_level):
     k = np.ascontiguousarray(k)
     out = np.zeros(len(k) + 1, np.int32)

@@ -811,4 +811,56 @@ int search_for_initialization(const std::vector<KeyPoint>& k1, const uint8_t* d1
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection (local map points), src/ORBmatcher.cc:41-221, F.Nleft == -1 branch, executed in
+// serial iMP order (the fork's tbb::parallel_for around this body is a data race on F.mvpMapPoints / nmatches).
+int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
+                             const FrameGrid& grid, const std::vector<float>& scaleFactors,
+                             const std::vector<MapPointView>& mps, float th, bool bFarPoints, float thFarPoints,
+                             float nnratio, std::vector<uint8_t>& occupied, std::vector<int>& match) {
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  match.assign(kpsUn.size(), -1);
+  const bool bFactor = th != 1.0;
+  for (size_t iMP = 0; iMP < mps.size(); iMP++) {
+    const MapPointView& mp = mps[iMP];
+    if (!mp.in_view) continue;
+    if (bFarPoints && mp.track_depth > thFarPoints) continue;
+    if (mp.bad) continue;
+    const int level = mp.predicted_level;
+    float r = mp.view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, :223-228
+    if (bFactor) r *= th;
+    const std::vector<int> cand =
+        grid.features_in_area(kpsUn, mp.proj_x, mp.proj_y, r * scaleFactors[level], level - 1, level);
+    if (cand.empty()) continue;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int idx : cand) {
+      if (occupied[idx]) continue;
+      if (uRight && uRight[idx] > 0) {
+        const float er = std::fabs(mp.proj_xr - uRight[idx]);
+        if (er > r * scaleFactors[level]) continue;
+      }
+      const int dist = descriptor_distance(mp.desc, desc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestLevel2 = bestLevel;
+        bestLevel = kpsUn[idx].octave;
+        bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = kpsUn[idx].octave;
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+        match[bestIdx] = (int)iMP;            // F.mvpMapPoints[bestIdx] = pMP
+        occupied[bestIdx] = mp.has_observations;  // later points skip it only if pMP->Observations() > 0
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace orbo

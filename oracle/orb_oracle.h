@@ -114,4 +114,22 @@ int search_for_initialization(const std::vector<KeyPoint>& k1, const uint8_t* d1
                               std::vector<int>& matches12, int windowSize, float nnratio,
                               bool checkOri);
 
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+// (src/ORBmatcher.cc:41-221), pinhole case (F.Nleft == -1), serial iMP order.  MapPointView carries the MapPoint
+// members that routine reads (mbTrackInView, mTrackDepth, isBad(), mnTrackScaleLevel, mTrackViewCos,
+// mTrackProjX/Y/XR, GetDescriptor(), Observations() > 0).
+struct MapPointView {
+  float proj_x, proj_y, proj_xr, view_cos, track_depth;
+  int32_t predicted_level;
+  uint8_t in_view, bad, has_observations, pad_;
+  uint8_t desc[32];
+};
+static_assert(sizeof(MapPointView) == 60, "POD layout shared with orbx_map_point_view");
+// occupied[i] != 0  <=>  F.mvpMapPoints[i] != NULL && ->Observations() > 0 (in/out: assignments update it).
+// match[i] = index of the map point assigned to keypoint i by this call, or -1.  Returns nmatches.
+int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
+                             const FrameGrid& grid, const std::vector<float>& scaleFactors,
+                             const std::vector<MapPointView>& mps, float th, bool bFarPoints, float thFarPoints,
+                             float nnratio, std::vector<uint8_t>& occupied, std::vector<int>& match);
+
 }  // namespace orbo

@@ -22,6 +22,10 @@ assert KP_DTYPE.itemsize == 28  # cv::KeyPoint
 OK, E_EMPTY, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # src/ORBmatcher.cc:35-37
 NUM_STAGES = 8
+MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
+                     ("predicted_level", "<i4"), ("in_view", "u1"), ("bad", "u1"), ("has_observations", "u1"),
+                     ("pad_", "u1"), ("desc", "u1", (32,))])   # orbx_map_point_view
+assert MP_DTYPE.itemsize == 60
 
 
 class OrbxError(RuntimeError):
@@ -64,6 +68,7 @@ def lib():
         L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
+        L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
@@ -291,6 +296,23 @@ class ORBmatcher:
         a = np.ascontiguousarray(a, np.uint8).reshape(32)
         b = np.ascontiguousarray(b, np.uint8).reshape(32)
         return lib().orbx_hamming256(_p(a), _p(b))
+
+    def SearchByProjection(self, kpsUn, desc, uRight, bounds, scaleFactors, mapPoints, occupied, th=1.0,
+                           bFarPoints=False, thFarPoints=50.0):
+        """src/ORBmatcher.cc:41-221 (local map points -> frame, pinhole case).  mapPoints: MP_DTYPE records.
+        Returns (nmatches, match[n] = map point index or -1, updated occupied[n])."""
+        k = np.ascontiguousarray(kpsUn, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        mp = np.ascontiguousarray(mapPoints, MP_DTYPE)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        occ = np.ascontiguousarray(occupied, np.uint8).copy()
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        match = np.full(len(k), -1, np.int32)
+        n = _check(lib().orbx_search_by_projection(
+            self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
+            bounds[3], _p(sf), len(sf), _p(mp), len(mp), float(th), int(bFarPoints), float(thFarPoints),
+            self.mfNNratio, _p(occ), _p(match)))
+        return n, match, occ
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):
         """src/ORBmatcher.cc:618-764.  kps = mvKeysUn of F1 / F2, bounds2 = (mnMinX, mnMinY, mnMaxX, mnMaxY)

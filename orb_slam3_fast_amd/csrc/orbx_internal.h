@@ -131,6 +131,26 @@ hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOf
 hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s);
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s);       // grid + candidate counts + scan
 hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s);  // candidate fill + serial resolve
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, ...) — pinhole case.
+struct ProjArgs {
+  InitArgs grid;                  // k2/n2/minX/minY/invW/invH/cellStart/cellItems describe the frame F
+  const uint8_t* desc;            // F.mDescriptors
+  const float* uRight;            // F.mvuRight or nullptr
+  const float* scale;             // F.mvScaleFactors
+  const orbx_map_point_view* mps;
+  int nmp;
+  float th, thFar, nnratio;
+  int far;
+  uint8_t* occupied;              // n2, in/out
+  int* match;                     // n2
+  int* candOff;                   // nmp + 1
+  int* candIdx;                   // candidate keypoint index
+  int* candDist;                  // (dist << 8) | octave
+  int candCap;
+  int* result;                    // [0] = nmatches
+};
+hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s);   // grid + candidate counts + scan
+hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s);    // candidate fill + serial resolve
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);

@@ -2010,6 +2010,148 @@ hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ================================================================================================ projection
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:41-221), pinhole case.
+// Per map point the candidate list (GetFeaturesInArea order, level filter, stereo-consistency filter) and the
+// Hamming distances do not depend on the evolving F.mvpMapPoints, so they are produced in parallel (one wave per
+// map point); only the occupancy gate + best / second-best + assignment is walked serially in iMP order.
+__device__ __forceinline__ bool proj_active(const orbx_map_point_view& mp, const ProjArgs& a, float& radius) {
+  if (!mp.in_view) return false;
+  if (a.far && mp.track_depth > a.thFar) return false;
+  if (mp.bad) return false;
+  float r = ((double)mp.view_cos > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, :223-228
+  if ((double)a.th != 1.0) r = __fmul_rn(r, a.th);
+  radius = __fmul_rn(r, a.scale[mp.predicted_level]);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  const orbx_map_point_view mp = a.mps[im];
+  const InitArgs& g = a.grid;
+  float r;
+  int total = 0;
+  if (proj_active(mp, a, r)) {
+    const float x = mp.proj_x, y = mp.proj_y;
+    const int minLevel = mp.predicted_level - 1, maxLevel = mp.predicted_level;
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+      uint32_t d1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(mp.desc)[i];
+      const int wbase = pass ? a.candOff[im] : 0;
+      for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+          const int b = g.cellStart[ix * 48 + iy], e = g.cellStart[ix * 48 + iy + 1];
+          for (int base = b; base < e; base += 64) {
+            const int j = base + lane;
+            bool ok = false;
+            int i2 = 0, oct = 0;
+            if (j < e) {
+              i2 = g.cellItems[j];
+              const orbx_keypoint k2 = g.k2[i2];
+              oct = k2.octave;
+              ok = !(checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) &&
+                   fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+              if (ok && a.uRight) {  // stereo consistency, :97-100
+                const float ur = a.uRight[i2];
+                if (ur > 0 && fabsf(__fsub_rn(mp.proj_xr, ur)) > r) ok = false;
+              }
+            }
+            const uint64_t m = __ballot(ok);
+            if (pass && ok) {
+              const int o = wbase + total + __popcll(m & lanemask_lt());
+              if (o < a.candCap) {
+                a.candIdx[o] = i2;
+                a.candDist[o] = (hamming256(d1, reinterpret_cast<const uint32_t*>(a.desc) + (long long)i2 * 8) << 8) | oct;
+              }
+            }
+            total += __popcll(m);
+          }
+        }
+    }
+  }
+  if (!pass && lane == 0) a.candOff[im] = total;
+}
+
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+  const int lane = threadIdx.x;
+  for (int i = lane; i < a.grid.n2; i += 64) a.match[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int im = 0; im < a.nmp; im++) {
+    const int b = a.candOff[im], e = a.candOff[im + 1];
+    if (e <= b) continue;
+    // two smallest (dist, position) among the candidates whose keypoint is still free == the reference's
+    // best / second-best tracking with strict '<' updates
+    uint64_t best = ~0ull, second = ~0ull;  // (dist << 40) | (position << 8) | octave
+    for (int j = b + lane; j < e; j += 64) {
+      if (a.occupied[a.candIdx[j]]) continue;
+      const int dv = a.candDist[j];
+      const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+      if (v < best) {
+        second = best;
+        best = v;
+      } else if (v < second) {
+        second = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+      // merge two sorted pairs (best <= second, ob <= os): new best = min, new second = second smallest of the four
+      const uint64_t nb = best < ob ? best : ob;
+      const uint64_t mx = best < ob ? ob : best;
+      const uint64_t ms = second < os ? second : os;
+      second = mx < ms ? mx : ms;
+      best = nb;
+    }
+    if (best == ~0ull) continue;
+    const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
+    const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+    const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+    if (bestDist <= 100) {  // TH_HIGH
+      const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+      const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
+      if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= lim)) {
+        if (lane == 0) {
+          const int bestIdx = a.candIdx[b + bestPos];
+          a.match[bestIdx] = im;
+          a.occupied[bestIdx] = a.mps[im].has_observations;
+        }
+        nmatches++;
+        __threadfence_block();
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a.grid);
+  if (a.nmp > 0) {
+    hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 0);
+    InitArgs sc = a.grid;  // k_init_scan scans candOff[0 .. n1]
+    sc.candOff = a.candOff;
+    sc.n1 = a.nmp;
+    sc.candCap = 1 << 30;
+    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, sc);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
   const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;

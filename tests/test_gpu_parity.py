@@ -275,6 +275,47 @@ def test_features_in_area_and_grid(gpu, oracle):
         assert np.array_equal(got, want)
 
 
+def test_search_by_projection_local_map(gpu, oracle):
+    """Widening row f1: SearchByProjection(Frame&, vector<MapPoint*>&) (pinhole), serial iMP semantics."""
+    w, h, nf = 752, 480, 1500
+    L0, R0 = synth.stereo_pair(w, h, 70, 0)
+    L1, R1 = synth.stereo_pair(w, h, 70, 1)
+    exL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    _, kp, dp = exL(L0)                               # "last frame": its keypoints play the map points
+    _, kc, dc = exL(L1)
+    exR(R1)
+    u, _ = orbx.ComputeStereoMatches(exL, exR, 0.12 * 532.03, 0.12)
+    uR = u[0, :len(kc)].copy()
+    rng = np.random.default_rng(17)
+    n = len(kp)
+    mps = np.zeros(n, orbx.MP_DTYPE)
+    dx, dy = rng.normal(0, 3.0, n), rng.normal(0, 3.0, n)
+    mps["proj_x"] = kp["x"] - 4 + dx                  # the camera panned by a few px between the frames
+    mps["proj_y"] = kp["y"] - 2 + dy
+    mps["proj_xr"] = mps["proj_x"] - rng.uniform(2, 60, n).astype(np.float32)
+    mps["view_cos"] = rng.choice([0.9, 0.9985, 0.998, 0.99801], n).astype(np.float32)
+    mps["track_depth"] = rng.uniform(1, 80, n).astype(np.float32)
+    mps["predicted_level"] = np.clip(kp["octave"] + rng.integers(-1, 2, n), 0, 7)
+    mps["in_view"] = rng.random(n) < 0.9
+    mps["bad"] = rng.random(n) < 0.05
+    mps["has_observations"] = rng.random(n) < 0.85
+    flips = (rng.random((n, 32, 8)) < 0.04)
+    mps["desc"] = dp ^ np.packbits(flips, axis=2).reshape(n, 32)
+    occupied = (rng.random(len(kc)) < 0.05).astype(np.uint8)
+    sf = exL.GetScaleFactors()
+    bounds = (0.0, 0.0, float(w), float(h))
+    for th, far, thfar, ratio, ur in [(1.0, False, 50.0, 0.8, uR), (3.0, True, 40.0, 0.8, uR), (1.0, False, 50.0, 0.6, None),
+                                      (5.0, True, 20.0, 0.9, uR)]:
+        nm, match, occ = orbx.ORBmatcher(ratio, True).SearchByProjection(kc, dc, ur, bounds, sf, mps, occupied, th, far, thfar)
+        onm, omatch, oocc = oracle.search_by_projection(kc, dc, ur, bounds, sf, mps, th, far, thfar, ratio, occupied)
+        assert onm > 100
+        assert nm == onm and np.array_equal(match, omatch) and np.array_equal(occ, oocc)
+    # degenerate inputs
+    nm, match, occ = orbx.ORBmatcher(0.8).SearchByProjection(kc, dc, None, bounds, sf, mps[:0], occupied)
+    assert nm == 0 and (match == -1).all() and np.array_equal(occ, occupied)
+
+
 def test_search_for_initialization(gpu, oracle):
     w, h = 752, 480
     f1, f2 = synth.mono_frame(w, h, 50, 0), synth.mono_frame(w, h, 50, 1)
