@@ -173,6 +173,27 @@ int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uin
                               int nlevels, const orbx_map_point_view* map_points, int n_map_points, float th,
                               int far_points, float th_far_points, float nnratio, uint8_t* occupied, int32_t* match);
 
+/* One LastFrame point after the reference's pose / camera projection (src/ORBmatcher.cc:1606-1648): uv, the
+ * right-image coordinate ur = u - mbf * invz, radius = th * mvScaleFactors[nLastOctave], the level window picked by
+ * bForward / bBackward ((nLastOctave, -1), (0, nLastOctave) or (nLastOctave-1, nLastOctave+1)), the last-frame
+ * keypoint angle, the MapPoint's descriptor and Observations() > 0.  valid = 0 for points the reference skips
+ * (no MapPoint, outlier, invz < 0, projection outside the image).  64 bytes. */
+typedef struct orbx_projected_point {
+  float u, v, ur, radius, angle;
+  int32_t min_level, max_level;
+  uint8_t valid, has_observations, pad_[2];
+  uint8_t desc[32];
+} orbx_projected_point;
+
+/* Replaces the matching part of ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th,
+ * bMono) (src/ORBmatcher.cc:1594-1806, pinhole case): window search on CurrentFrame's grid, occupancy gate,
+ * stereo-consistency gate, best Hamming <= TH_HIGH, assignment in serial order, rotation-histogram cull
+ * (check_orientation).  match[i2] = LastFrame point index assigned to keypoint i2 or -1.  Returns nmatches. */
+int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                                    int n, float min_x, float min_y, float max_x, float max_y,
+                                    const orbx_projected_point* points, int n_points, int check_orientation,
+                                    uint8_t* occupied, int32_t* match);
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events recorded on the handle's own stream around every kernel launch (the

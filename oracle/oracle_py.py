@@ -217,6 +217,25 @@ def search_by_projection(k, desc, uright, bounds, scale_factors, mps, th, far, t
     return n, match, occ
 
 
+PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("angle", "<f4"), ("min_level", "<i4"),
+                     ("max_level", "<i4"), ("valid", "u1"), ("has_observations", "u1"), ("pad_", "u1", (2,)),
+                     ("desc", "u1", (32,))])
+assert PP_DTYPE.itemsize == 64
+
+
+def search_by_projection_frame(k, desc, uright, bounds, pts, check_ori, occupied):
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    pts = np.ascontiguousarray(pts, PP_DTYPE)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.zeros(len(k), np.int32)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    n = lib().oro_search_by_projection_frame(_p(k), _p(desc), None if ur is None else _p(ur), len(k),
+                                             C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]),
+                                             C.c_float(bounds[3]), _p(pts), len(pts), int(check_ori), _p(occ), _p(match))
+    return n, match, occ
+
+
 def features_in_area(k, bounds, x, y, r, min_level, max_level):
     k = np.ascontiguousarray(k)
     out = np.zeros(len(k) + 1, np.int32)

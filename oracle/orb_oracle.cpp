@@ -863,4 +863,56 @@ int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* 
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection (CurrentFrame <- LastFrame), src/ORBmatcher.cc:1614-1700 (Nleft == -1) and the
+// rotation-consistency cull :1780-1800.
+int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
+                               const FrameGrid& grid, const std::vector<ProjectedPoint>& pts, bool checkOri,
+                               std::vector<uint8_t>& occupied, std::vector<int>& match) {
+  const int HISTO = 30, TH_HIGH = 100;
+  int nmatches = 0;
+  match.assign(kpsUn.size(), -1);
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  for (size_t i = 0; i < pts.size(); i++) {
+    const ProjectedPoint& p = pts[i];
+    if (!p.valid) continue;  // no MapPoint, outlier, behind the camera or outside the image (:1615-1636)
+    const std::vector<int> cand = grid.features_in_area(kpsUn, p.u, p.v, p.radius, p.min_level, p.max_level);
+    if (cand.empty()) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : cand) {
+      if (occupied[i2]) continue;
+      if (uRight && uRight[i2] > 0) {
+        const float er = std::fabs(p.ur - uRight[i2]);
+        if (er > p.radius) continue;
+      }
+      const int dist = descriptor_distance(p.desc, desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      match[bestIdx2] = (int)i;
+      occupied[bestIdx2] = p.has_observations;
+      nmatches++;
+      if (checkOri) {
+        float rot = p.angle - kpsUn[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        match[idx] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace orbo

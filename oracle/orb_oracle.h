@@ -132,4 +132,21 @@ int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* 
                              const std::vector<MapPointView>& mps, float th, bool bFarPoints, float thFarPoints,
                              float nnratio, std::vector<uint8_t>& occupied, std::vector<int>& match);
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+// (src/ORBmatcher.cc:1594-1806), pinhole case.  The pose / camera projection of the reference (Eigen float code,
+// :1606-1636) stays on the caller's side; ProjectedPoint carries its results per LastFrame point: uv, the
+// right-image coordinate ur = u - mbf*invz, radius = th * mvScaleFactors[nLastOctave], the level window chosen by
+// bForward / bBackward, the last-frame keypoint angle, the MapPoint descriptor and Observations() > 0.
+struct ProjectedPoint {
+  float u, v, ur, radius, angle;
+  int32_t min_level, max_level;
+  uint8_t valid, has_observations, pad_[2];
+  uint8_t desc[32];
+};
+static_assert(sizeof(ProjectedPoint) == 64, "POD layout shared with orbx_projected_point");
+// match[i2] = index of the LastFrame point assigned to CurrentFrame keypoint i2, or -1.  Returns nmatches.
+int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
+                               const FrameGrid& grid, const std::vector<ProjectedPoint>& pts, bool checkOri,
+                               std::vector<uint8_t>& occupied, std::vector<int>& match);
+
 }  // namespace orbo

@@ -173,6 +173,21 @@ int oro_search_by_projection(const KeyPoint* k, const uint8_t* desc, const float
   return nm;
 }
 
+int oro_search_by_projection_frame(const KeyPoint* k, const uint8_t* desc, const float* uRight, int n, float minX,
+                                   float minY, float maxX, float maxY, const ProjectedPoint* pts, int npts, int checkOri,
+                                   uint8_t* occupied, int* match) {
+  std::vector<KeyPoint> a(k, k + n);
+  FrameGrid g;
+  g.build(a, minX, minY, maxX, maxY);
+  std::vector<ProjectedPoint> p(pts, pts + npts);
+  std::vector<uint8_t> occ(occupied, occupied + n);
+  std::vector<int> mt;
+  const int nm = search_by_projection_frame(a, desc, uRight, g, p, checkOri != 0, occ, mt);
+  std::memcpy(occupied, occ.data(), n);
+  std::memcpy(match, mt.data(), n * sizeof(int));
+  return nm;
+}
+
 // libstdc++ std::sort with the (count, UL.x) comparator of compareNodes (src/ORBextractor.cc:542-555) on
 // packed 64-bit elements (key = bits 16..63): the tie order the device quadtree's replica must reproduce.
 void oro_std_sort_keys(uint64_t* v, int n) {

@@ -26,6 +26,10 @@ MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), (
                      ("predicted_level", "<i4"), ("in_view", "u1"), ("bad", "u1"), ("has_observations", "u1"),
                      ("pad_", "u1"), ("desc", "u1", (32,))])   # orbx_map_point_view
 assert MP_DTYPE.itemsize == 60
+PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("angle", "<f4"), ("min_level", "<i4"),
+                     ("max_level", "<i4"), ("valid", "u1"), ("has_observations", "u1"), ("pad_", "u1", (2,)),
+                     ("desc", "u1", (32,))])   # orbx_projected_point
+assert PP_DTYPE.itemsize == 64
 
 
 class OrbxError(RuntimeError):
@@ -69,6 +73,7 @@ def lib():
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
+        L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
@@ -312,6 +317,21 @@ class ORBmatcher:
             self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
             bounds[3], _p(sf), len(sf), _p(mp), len(mp), float(th), int(bFarPoints), float(thFarPoints),
             self.mfNNratio, _p(occ), _p(match)))
+        return n, match, occ
+
+    def SearchByProjectionFrame(self, kpsUn, desc, uRight, bounds, projectedPoints, occupied):
+        """Matching part of SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1594-1806,
+        pinhole case); projectedPoints: PP_DTYPE records computed by the caller's pose / camera projection.
+        Returns (nmatches, match[n] = LastFrame point index or -1, updated occupied[n])."""
+        k = np.ascontiguousarray(kpsUn, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        pp = np.ascontiguousarray(projectedPoints, PP_DTYPE)
+        occ = np.ascontiguousarray(occupied, np.uint8).copy()
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        match = np.full(len(k), -1, np.int32)
+        n = _check(lib().orbx_search_by_projection_frame(
+            self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
+            bounds[3], _p(pp), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):

@@ -26,6 +26,9 @@ struct FrameView {
   const uint8_t* mDescriptors = nullptr;  // N x 32, continuous
   int N = 0;
   float mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0;
+  const float* mvuRight = nullptr;        // optional (SearchByProjection stereo-consistency gate)
+  const float* mvScaleFactors = nullptr;  // nLevels entries (SearchByProjection)
+  int nLevels = 0;
 };
 
 class ORBmatcher {
@@ -53,6 +56,37 @@ class ORBmatcher {
         F2.mnMaxY, reinterpret_cast<float*>(vbPrevMatched.data()), vnMatches12.data(), windowSize, mfNNratio,
         mbCheckOrientation ? 1 : 0);
     if (n < 0) throw std::runtime_error(std::string("SearchForInitialization: ") + orbx_last_error());
+    return n;
+  }
+
+  // SearchByProjection(Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:41-221,
+  // pinhole case.  vpMapPoints[i] is given as the POD view of the members the routine reads; occupied[i] != 0 <=>
+  // F.mvpMapPoints[i] holds a point with Observations() > 0 (updated); match[i] = map point index newly assigned to
+  // keypoint i, or -1 (the caller stores F.mvpMapPoints[i] = vpMapPoints[match[i]]).
+  int SearchByProjection(const FrameView& F, const std::vector<orbx_map_point_view>& vpMapPoints,
+                         std::vector<uint8_t>& occupied, std::vector<int>& match, const float th = 3,
+                         const bool bFarPoints = false, const float thFarPoints = 50.0f) {
+    match.assign(F.N, -1);
+    const int n = orbx_search_by_projection(
+        device_, reinterpret_cast<const orbx_keypoint*>(F.mvKeysUn), F.mDescriptors, F.mvuRight, F.N, F.mnMinX, F.mnMinY,
+        F.mnMaxX, F.mnMaxY, F.mvScaleFactors, F.nLevels, vpMapPoints.data(), (int)vpMapPoints.size(), th,
+        bFarPoints ? 1 : 0, thFarPoints, mfNNratio, occupied.data(), match.data());
+    if (n < 0) throw std::runtime_error(std::string("SearchByProjection: ") + orbx_last_error());
+    return n;
+  }
+
+  // Matching part of SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono),
+  // src/ORBmatcher.cc:1594-1806, pinhole case: the caller keeps the pose / camera projection (:1606-1648) and passes
+  // one orbx_projected_point per LastFrame point.
+  int SearchByProjection(const FrameView& CurrentFrame, const std::vector<orbx_projected_point>& lastFramePoints,
+                         std::vector<uint8_t>& occupied, std::vector<int>& match) {
+    match.assign(CurrentFrame.N, -1);
+    const int n = orbx_search_by_projection_frame(
+        device_, reinterpret_cast<const orbx_keypoint*>(CurrentFrame.mvKeysUn), CurrentFrame.mDescriptors,
+        CurrentFrame.mvuRight, CurrentFrame.N, CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mnMaxX,
+        CurrentFrame.mnMaxY, lastFramePoints.data(), (int)lastFramePoints.size(), mbCheckOrientation ? 1 : 0,
+        occupied.data(), match.data());
+    if (n < 0) throw std::runtime_error(std::string("SearchByProjection: ") + orbx_last_error());
     return n;
   }
 

@@ -831,16 +831,13 @@ int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min
   return total;
 }
 
-int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
-                              int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
-                              int nlevels, const orbx_map_point_view* map_points, int n_map_points, float th,
-                              int far_points, float th_far_points, float nnratio, uint8_t* occupied, int32_t* match) {
-  if (n < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors || (n && (!kps_un || !desc || !occupied || !match)) ||
-      (n_map_points && !map_points))
-    return fail(ORBX_E_BADARG, "bad argument");
-  for (int i = 0; i < n_map_points; i++)
-    if (map_points[i].predicted_level < 0 || map_points[i].predicted_level >= nlevels)
-      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+namespace {
+int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
+                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                              uint8_t* occupied, int32_t* match) {
+  const int mode = points ? 1 : 0;
   if (n == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
@@ -848,20 +845,24 @@ int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uin
   DevBuf<uint8_t> d, occ;
   DevBuf<float> ur, sf;
   DevBuf<orbx_map_point_view> mp;
+  DevBuf<orbx_projected_point> pp;
   DevBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  const int nm = std::max(n_map_points, 1);
-  chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(ur.alloc(n)); chk(sf.alloc(nlevels));
-  chk(mp.alloc(nm)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n)); chk(candOff.alloc(nm + 1));
-  chk(mt.alloc(n)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1)); chk(result.alloc(2));
+  const int nm = std::max(n_points, 1);
+  chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(ur.alloc(n)); chk(sf.alloc(std::max(nlevels, 1)));
+  chk(mp.alloc(nm)); chk(pp.alloc(nm)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
+  chk(candOff.alloc(nm + 1)); chk(mt.alloc(n)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
+  chk(result.alloc(2));
   if (e == hipSuccess) chk(hipMemcpy(k.p, kps_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
   if (e == hipSuccess) chk(hipMemcpy(d.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
   if (e == hipSuccess) chk(hipMemcpy(occ.p, occupied, n, hipMemcpyHostToDevice));
   if (e == hipSuccess && u_right) chk(hipMemcpy(ur.p, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(sf.p, scale_factors, nlevels * sizeof(float), hipMemcpyHostToDevice));
-  if (e == hipSuccess && n_map_points)
-    chk(hipMemcpy(mp.p, map_points, (size_t)n_map_points * sizeof(orbx_map_point_view), hipMemcpyHostToDevice));
+  if (e == hipSuccess && scale_factors) chk(hipMemcpy(sf.p, scale_factors, nlevels * sizeof(float), hipMemcpyHostToDevice));
+  if (e == hipSuccess && n_points && mode == 0)
+    chk(hipMemcpy(mp.p, map_points, (size_t)n_points * sizeof(orbx_map_point_view), hipMemcpyHostToDevice));
+  if (e == hipSuccess && n_points && mode == 1)
+    chk(hipMemcpy(pp.p, points, (size_t)n_points * sizeof(orbx_projected_point), hipMemcpyHostToDevice));
   ProjArgs a{};
   a.grid.k2 = k.p; a.grid.n2 = n; a.grid.n1 = 0;
   a.grid.minX = min_x; a.grid.minY = min_y;
@@ -869,13 +870,14 @@ int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uin
   a.grid.invH = 48.f / (max_y - min_y);
   a.grid.cellStart = cellStart.p; a.grid.cellItems = cellItems.p; a.grid.matchedDist = mdist.p; a.grid.matches21 = m21.p;
   a.grid.matches12 = m12.p; a.grid.result = result.p; a.grid.candOff = candOff.p; a.grid.candCap = 1 << 30;
-  a.desc = d.p; a.uRight = u_right ? ur.p : nullptr; a.scale = sf.p; a.mps = mp.p; a.nmp = n_map_points;
+  a.desc = d.p; a.uRight = u_right ? ur.p : nullptr; a.scale = sf.p; a.mps = mp.p; a.pts = pp.p; a.nmp = n_points;
+  a.mode = mode; a.checkOri = check_ori;
   a.th = th; a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
   a.occupied = occ.p; a.match = mt.p; a.candOff = candOff.p; a.result = result.p; a.candCap = 1 << 30;
   int total = 0, res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_proj_count(a, nullptr));
   if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess && n_map_points) chk(hipMemcpy(&total, candOff.p + n_map_points, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess && n_points) chk(hipMemcpy(&total, candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
   if (e == hipSuccess) {
     chk(candIdx.alloc((size_t)std::max(total, 1)));
     chk(candDist.alloc((size_t)std::max(total, 1)));
@@ -886,10 +888,39 @@ int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uin
   if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
-  k.free(); d.free(); occ.free(); ur.free(); sf.free(); mp.free(); cellStart.free(); cellItems.free(); candOff.free();
-  candIdx.free(); candDist.free(); mt.free(); mdist.free(); m21.free(); m12.free(); result.free();
+  k.free(); d.free(); occ.free(); ur.free(); sf.free(); mp.free(); pp.free(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mt.free(); mdist.free(); m21.free(); m12.free(); result.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
+}
+}  // namespace
+
+int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                              int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                              int nlevels, const orbx_map_point_view* map_points, int n_map_points, float th,
+                              int far_points, float th_far_points, float nnratio, uint8_t* occupied, int32_t* match) {
+  if (n < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors || (n && (!kps_un || !desc || !occupied || !match)) ||
+      (n_map_points && !map_points))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_map_points; i++)
+    if (map_points[i].predicted_level < 0 || map_points[i].predicted_level >= nlevels)
+      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+  static const orbx_map_point_view dummy{};
+  return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels,
+                                   map_points ? map_points : &dummy, nullptr, n_map_points, th, far_points,
+                                   th_far_points, nnratio, 0, occupied, match);
+}
+
+int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                                    int n, float min_x, float min_y, float max_x, float max_y,
+                                    const orbx_projected_point* points, int n_points, int check_orientation,
+                                    uint8_t* occupied, int32_t* match) {
+  if (n < 0 || n_points < 0 || (n && (!kps_un || !desc || !occupied || !match)) || (n_points && !points))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_points > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 projected points");
+  static const orbx_projected_point dummy{};
+  return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
+                                   points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
 int orbx_profile_enable(orbx_extractor* ex, int on) {

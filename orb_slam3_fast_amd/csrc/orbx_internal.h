@@ -137,7 +137,9 @@ struct ProjArgs {
   const uint8_t* desc;            // F.mDescriptors
   const float* uRight;            // F.mvuRight or nullptr
   const float* scale;             // F.mvScaleFactors
-  const orbx_map_point_view* mps;
+  const orbx_map_point_view* mps;        // mode 0: local map points
+  const orbx_projected_point* pts;       // mode 1: projected LastFrame points
+  int mode, checkOri;
   int nmp;
   float th, thFar, nnratio;
   int far;

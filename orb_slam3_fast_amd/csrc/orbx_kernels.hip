@@ -2025,17 +2025,46 @@ __device__ __forceinline__ bool proj_active(const orbx_map_point_view& mp, const
   return true;
 }
 
+// One query per point, common to both SearchByProjection flavours.
+struct ProjQuery {
+  float x, y, ur, r;
+  int minLevel, maxLevel;
+  const uint8_t* desc;
+};
+__device__ __forceinline__ bool proj_query(const ProjArgs& a, int im, ProjQuery& q) {
+  if (a.mode == 0) {
+    const orbx_map_point_view& mp = a.mps[im];
+    if (!proj_active(mp, a, q.r)) return false;
+    q.x = mp.proj_x;
+    q.y = mp.proj_y;
+    q.ur = mp.proj_xr;
+    q.minLevel = mp.predicted_level - 1;
+    q.maxLevel = mp.predicted_level;
+    q.desc = mp.desc;
+    return true;
+  }
+  const orbx_projected_point& p = a.pts[im];
+  if (!p.valid) return false;
+  q.x = p.u;
+  q.y = p.v;
+  q.ur = p.ur;
+  q.r = p.radius;
+  q.minLevel = p.min_level;
+  q.maxLevel = p.max_level;
+  q.desc = p.desc;
+  return true;
+}
+
 __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (im >= a.nmp) return;
-  const orbx_map_point_view mp = a.mps[im];
   const InitArgs& g = a.grid;
-  float r;
+  ProjQuery q;
   int total = 0;
-  if (proj_active(mp, a, r)) {
-    const float x = mp.proj_x, y = mp.proj_y;
-    const int minLevel = mp.predicted_level - 1, maxLevel = mp.predicted_level;
+  if (proj_query(a, im, q)) {
+    const float x = q.x, y = q.y, r = q.r;
+    const int minLevel = q.minLevel, maxLevel = q.maxLevel;
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
     const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
     const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
@@ -2044,7 +2073,7 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
     if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
       uint32_t d1[8];
 #pragma unroll
-      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(mp.desc)[i];
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(q.desc)[i];
       const int wbase = pass ? a.candOff[im] : 0;
       for (int ix = cx0; ix <= cx1; ix++)
         for (int iy = cy0; iy <= cy1; iy++) {
@@ -2059,9 +2088,9 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
               oct = k2.octave;
               ok = !(checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) &&
                    fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
-              if (ok && a.uRight) {  // stereo consistency, :97-100
+              if (ok && a.uRight) {  // stereo consistency, :97-100 / :1666-1670
                 const float ur = a.uRight[i2];
-                if (ur > 0 && fabsf(__fsub_rn(mp.proj_xr, ur)) > r) ok = false;
+                if (ur > 0 && fabsf(__fsub_rn(q.ur, ur)) > r) ok = false;
               }
             }
             const uint64_t m = __ballot(ok);
@@ -2081,10 +2110,14 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
 }
 
 __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* binIdx = reinterpret_cast<int*>(smem);  // mode 1: (bin << 24 | keypoint index) per accepted match, in order
   const int lane = threadIdx.x;
   for (int i = lane; i < a.grid.n2; i += 64) a.match[i] = -1;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
   __syncthreads();
-  int nmatches = 0;
+  int nmatches = 0, nBin = 0;
   for (int im = 0; im < a.nmp; im++) {
     const int b = a.candOff[im], e = a.candOff[im + 1];
     if (e <= b) continue;
@@ -2114,22 +2147,68 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
     }
     if (best == ~0ull) continue;
     const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
-    const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
-    const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+    bool accept = false;
     if (bestDist <= 100) {  // TH_HIGH
-      const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
-      const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
-      if (!reject && (bestLevel != bestLevel2 || (float)bestDist <= lim)) {
-        if (lane == 0) {
-          const int bestIdx = a.candIdx[b + bestPos];
-          a.match[bestIdx] = im;
-          a.occupied[bestIdx] = a.mps[im].has_observations;
-        }
-        nmatches++;
-        __threadfence_block();
+      if (a.mode == 0) {
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
+        accept = !reject && (bestLevel != bestLevel2 || (float)bestDist <= lim);
+      } else {
+        accept = true;
       }
     }
+    if (accept) {
+      if (lane == 0) {
+        const int bestIdx = a.candIdx[b + bestPos];
+        a.match[bestIdx] = im;
+        a.occupied[bestIdx] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+        if (a.mode == 1 && a.checkOri) {
+          float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[bestIdx].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          binIdx[nBin] = (bin << 24) | bestIdx;
+          hist[bin]++;
+        }
+      }
+      nBin++;
+      nmatches++;
+      __threadfence_block();
+    }
     __syncthreads();
+  }
+  if (a.mode == 1 && a.checkOri) {  // rotation-consistency cull, :1780-1800 (+ ComputeThreeMaxima :1920-1955)
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < nBin; i += 64) {
+      const int bn = binIdx[i] >> 24, idx = binIdx[i] & 0xFFFFFF;
+      if (bn != ind1 && bn != ind2 && bn != ind3) {
+        a.match[idx] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL (even if a later point re-took the slot)
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
   }
   if (lane == 0) a.result[0] = nmatches;
 }
@@ -2148,7 +2227,8 @@ hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
 }
 hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
   if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
-  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), 0, s, a);
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;  // one int per accepted match
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
   return hipGetLastError();
 }
 

@@ -316,6 +316,51 @@ def test_search_by_projection_local_map(gpu, oracle):
     assert nm == 0 and (match == -1).all() and np.array_equal(occ, occupied)
 
 
+def test_search_by_projection_frame_to_frame(gpu, oracle):
+    """Widening row f1: matching part of SearchByProjection(CurrentFrame, LastFrame, th, bMono) (pinhole)."""
+    w, h, nf = 752, 480, 1500
+    L0, _ = synth.stereo_pair(w, h, 71, 0)
+    L1, R1 = synth.stereo_pair(w, h, 71, 1)
+    exL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    _, kp, dp = exL(L0)
+    _, kc, dc = exL(L1)
+    exR(R1)
+    u, _ = orbx.ComputeStereoMatches(exL, exR, 0.12 * 532.03, 0.12)
+    uR = u[0, :len(kc)].copy()
+    rng = np.random.default_rng(19)
+    n = len(kp)
+    sf = exL.GetScaleFactors()
+    pts = np.zeros(n, orbx.PP_DTYPE)
+    pts["u"] = kp["x"] - 4 + rng.normal(0, 2.0, n)
+    pts["v"] = kp["y"] - 2 + rng.normal(0, 2.0, n)
+    pts["ur"] = pts["u"] - rng.uniform(2, 60, n).astype(np.float32)
+    octv = kp["octave"]
+    pts["angle"] = kp["angle"]
+    pts["valid"] = rng.random(n) < 0.85
+    pts["has_observations"] = rng.random(n) < 0.8
+    flips = (rng.random((n, 32, 8)) < 0.04)
+    pts["desc"] = dp ^ np.packbits(flips, axis=2).reshape(n, 32)
+    occupied = (rng.random(len(kc)) < 0.05).astype(np.uint8)
+    bounds = (0.0, 0.0, float(w), float(h))
+    for th, mode, ur, ori in [(15.0, "plain", uR, True), (7.0, "forward", uR, True), (7.0, "backward", None, True),
+                              (15.0, "plain", uR, False)]:
+        pts["radius"] = (np.float32(th) * sf[octv]).astype(np.float32)
+        if mode == "forward":
+            pts["min_level"], pts["max_level"] = octv, -1
+        elif mode == "backward":
+            pts["min_level"], pts["max_level"] = 0, octv
+        else:
+            pts["min_level"], pts["max_level"] = octv - 1, octv + 1
+        m = orbx.ORBmatcher(0.9, ori)
+        nm, match, occ = m.SearchByProjectionFrame(kc, dc, ur, bounds, pts, occupied)
+        onm, omatch, oocc = oracle.search_by_projection_frame(kc, dc, ur, bounds, pts, ori, occupied)
+        assert onm > 150
+        assert nm == onm and np.array_equal(match, omatch) and np.array_equal(occ, oocc)
+    nm, match, occ = orbx.ORBmatcher(0.9, True).SearchByProjectionFrame(kc, dc, None, bounds, pts[:0], occupied)
+    assert nm == 0 and (match == -1).all()
+
+
 def test_search_for_initialization(gpu, oracle):
     w, h = 752, 480
     f1, f2 = synth.mono_frame(w, h, 50, 0), synth.mono_frame(w, h, 50, 1)
