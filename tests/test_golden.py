@@ -43,6 +43,39 @@ def test_oracle_reproduces_stereo_golden(oracle, path):
     assert n == int(g["init_n"]) and np.array_equal(m12, g["init_m12"]) and prev.tobytes() == g["init_prev"].tobytes()
 
 
+PROJ = sorted(glob.glob(os.path.join(HERE, "golden", "projection_*.npz")))
+
+
+def _proj_inputs(g, mod):
+    kc = np.ascontiguousarray(g["kc"]).view(mod.KP_DTYPE).reshape(-1)
+    mps = np.ascontiguousarray(g["mps"]).view(mod.MP_DTYPE).reshape(-1)
+    pts = np.ascontiguousarray(g["pts"]).view(mod.PP_DTYPE).reshape(-1)
+    return kc, mps, pts, (0.0, 0.0, float(g["w"]), float(g["h"]))
+
+
+@pytest.mark.parametrize("path", PROJ, ids=os.path.basename)
+def test_oracle_reproduces_projection_golden(oracle, path):
+    g = np.load(path)
+    kc, mps, pts, bounds = _proj_inputs(g, oracle)
+    n1, m1, o1 = oracle.search_by_projection(kc, g["dc"], g["uR"], bounds, g["scale"], mps, 3.0, True, 60.0, 0.8, g["occupied"])
+    assert n1 == int(g["map_n"]) and np.array_equal(m1, g["map_match"]) and np.array_equal(o1, g["map_occ"])
+    n2, m2, o2 = oracle.search_by_projection_frame(kc, g["dc"], g["uR"], bounds, pts, True, g["occupied"])
+    assert n2 == int(g["frame_n"]) and np.array_equal(m2, g["frame_match"]) and np.array_equal(o2, g["frame_occ"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PROJ, ids=os.path.basename)
+def test_hip_reproduces_projection_golden(path):
+    import orb_slam3_fast_amd as orbx
+    g = np.load(path)
+    kc, mps, pts, bounds = _proj_inputs(g, orbx)
+    n1, m1, o1 = orbx.ORBmatcher(0.8, True).SearchByProjection(kc, g["dc"], g["uR"], bounds, g["scale"], mps, g["occupied"],
+                                                              3.0, True, 60.0)
+    assert n1 == int(g["map_n"]) and np.array_equal(m1, g["map_match"]) and np.array_equal(o1, g["map_occ"])
+    n2, m2, o2 = orbx.ORBmatcher(0.8, True).SearchByProjectionFrame(kc, g["dc"], g["uR"], bounds, pts, g["occupied"])
+    assert n2 == int(g["frame_n"]) and np.array_equal(m2, g["frame_match"]) and np.array_equal(o2, g["frame_occ"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", EXTRACT, ids=os.path.basename)
 def test_hip_reproduces_extract_golden(path):

@@ -48,9 +48,53 @@ def stereo_case(name, w, h, nf, stream):
     print(name, len(kL), len(kR), int((u >= 0).sum()), int(ok.sum()), n)
 
 
+def projection_case(name, w, h, nf, stream):
+    """SearchByProjection (local map + frame-to-frame, pinhole): seeded map-point / projected-point views."""
+    L0, _ = synth.stereo_pair(w, h, stream, 0)
+    L1, R1 = synth.stereo_pair(w, h, stream, 1)
+    eP, eL, eR = O.OracleExtractor(nf), O.OracleExtractor(nf), O.OracleExtractor(nf)
+    _, kp, dp = eP.extract(L0)
+    _, kc, dc = eL.extract(L1)
+    _, kr, dr = eR.extract(R1)
+    uR, _ = O.stereo_match(eL, eR, kc, dc, kr, dr, np.float32(0.12) * np.float32(532.03), np.float32(0.12))
+    rng = np.random.default_rng(2024)
+    n = len(kp)
+    sf = eL.tables()["scale"]
+    flips = rng.random((n, 32, 8)) < 0.04
+    desc = dp ^ np.packbits(flips, axis=2).reshape(n, 32)
+    mps = np.zeros(n, O.MP_DTYPE)
+    mps["proj_x"] = kp["x"] - 4 + rng.normal(0, 3.0, n)
+    mps["proj_y"] = kp["y"] - 2 + rng.normal(0, 3.0, n)
+    mps["proj_xr"] = mps["proj_x"] - rng.uniform(2, 60, n).astype(np.float32)
+    mps["view_cos"] = rng.choice([0.9, 0.9985], n).astype(np.float32)
+    mps["track_depth"] = rng.uniform(1, 80, n).astype(np.float32)
+    mps["predicted_level"] = np.clip(kp["octave"] + rng.integers(-1, 2, n), 0, 7)
+    mps["in_view"] = rng.random(n) < 0.9
+    mps["bad"] = rng.random(n) < 0.05
+    mps["has_observations"] = rng.random(n) < 0.85
+    mps["desc"] = desc
+    pts = np.zeros(n, O.PP_DTYPE)
+    pts["u"], pts["v"], pts["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+    pts["radius"] = (np.float32(15.0) * sf[kp["octave"]]).astype(np.float32)
+    pts["angle"] = kp["angle"]
+    pts["min_level"], pts["max_level"] = kp["octave"] - 1, kp["octave"] + 1
+    pts["valid"] = mps["in_view"]
+    pts["has_observations"] = mps["has_observations"]
+    pts["desc"] = desc
+    occupied = (rng.random(len(kc)) < 0.05).astype(np.uint8)
+    bounds = (0.0, 0.0, float(w), float(h))
+    n1, m1, o1 = O.search_by_projection(kc, dc, uR, bounds, sf, mps, 3.0, True, 60.0, 0.8, occupied)
+    n2, m2, o2 = O.search_by_projection_frame(kc, dc, uR, bounds, pts, True, occupied)
+    np.savez_compressed(os.path.join(OUT, name), w=w, h=h, kc=kc.view(np.uint8).reshape(len(kc), 28), dc=dc, uR=uR,
+                        scale=sf, mps=mps.view(np.uint8).reshape(n, 60), pts=pts.view(np.uint8).reshape(n, 64),
+                        occupied=occupied, map_n=n1, map_match=m1, map_occ=o1, frame_n=n2, frame_match=m2, frame_occ=o2)
+    print(name, len(kc), n, n1, n2)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_160x120_L3.npz", 160, 120, 300, 3, 101, (0, 0))
     extract_case("extract_384x288_L8.npz", 384, 288, 500, 8, 102, (0, 0))
     extract_case("extract_384x288_L8_lap.npz", 384, 288, 500, 8, 102, (100, 250))
     stereo_case("stereo_400x300.npz", 400, 300, 600, 103)
+    projection_case("projection_480x360.npz", 480, 360, 800, 104)
