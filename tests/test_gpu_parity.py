@@ -234,6 +234,37 @@ def test_batched_pairs_one_handle(gpu, oracle):
     dbuf.free()
 
 
+def test_concurrent_handles_and_repeatability(gpu, oracle):
+    """Distinct handles are used concurrently from different threads (src/Frame.cc:200-203); results must not depend
+    on interleaving, and repeated calls on one handle must be bit-identical (no stale state between frames)."""
+    import threading
+    w, h, nf = 640, 480, 1000
+    imgs = [synth.mono_frame(w, h, 80 + i) for i in range(4)]
+    want = []
+    for im in imgs:
+        oe = oracle.OracleExtractor(nf)
+        want.append(oe.extract(im))
+    exs = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h) for _ in range(4)]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                im = imgs[(t + rep) % 4]
+                mono, k, d = exs[t](im)
+                omono, ok_, od = want[(t + rep) % 4]
+                assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+
+
 def test_bf_knn2(gpu, oracle):
     rng = np.random.default_rng(5)
     base = rng.integers(0, 256, (700, 32), dtype=np.uint8)
