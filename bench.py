@@ -88,6 +88,12 @@ def algorithmic_bytes(stage, NI, P, plevels, ncand, nsel, nmatch_in, npairs):
 
 def main():
     a = parse()
+    # Exactly ONE line on stdout: libraries (RCCL prints a version banner when NCCL_DEBUG=VERSION is set, HIP /
+    # libdrm print warnings) must not interleave with it, so fd 1 is pointed at stderr for the run and the JSON
+    # line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,7 +296,8 @@ def main():
                 os.remove(tmp)
 
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
