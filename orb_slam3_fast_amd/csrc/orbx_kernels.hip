@@ -1095,11 +1095,15 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   constexpr int IW = BL_TW / 4 + 2;  // in-tile dwords per row
   if (x0 >= 4 && y0 >= 3 && x0 + BL_TW + 4 <= L.w && y0 + BL_TH + 3 <= L.h) {
-    // interior tile: every dword is inside the image
-    const uint8_t* base = im + (long long)(y0 - 3) * pitch + (x0 - 4);
-    for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
-      const int r = i / IW, c = i - r * IW;
-      in[r][c] = *reinterpret_cast<const uint32_t*>(base + (long long)r * pitch + 4 * c);
+    // interior tile: every dword is inside the image; thread = (row phase, dword column), 7 rows per pass
+    const int c = tid % IW, r0 = tid / IW;  // IW = 34: 238 of the 256 threads take part
+    if (r0 < 7) {
+      const uint8_t* src = im + (long long)(y0 - 3 + r0) * pitch + (x0 - 4) + 4 * c;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int r = r0 + 7 * k;
+        if (r < BL_TH + 6) in[r][c] = *reinterpret_cast<const uint32_t*>(src + (long long)(7 * k) * pitch);
+      }
     }
   } else {
     for (int i = tid; i < (BL_TH + 6) * IW; i += 256) {
@@ -1144,31 +1148,40 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
   {
     const int bc = tid & 31, br = tid >> 5;  // 32 x 8 blocks of 4x4 outputs; block rows 4*br .. 4*br+3 (even start)
     uint8_t* dst = p.blur + (long long)img * g.pyrImg + L.off;
-    uint32_t outw[4] = {0, 0, 0, 0};
+    uint32_t outw[4];
+    uint32_t accs[4][4];
 #pragma unroll
     for (int cI = 0; cI < 4; cI++) {
       uint32_t pr[5];  // row pairs (4br .. 4br+9) of column 4*bc + cI
 #pragma unroll
       for (int k = 0; k < 5; k++) pr[k] = hp[2 * br + k][32 * cI + bc];  // lanes read consecutive dwords
-      // taps {18,34,48,56,48,34,18} on rows r..r+6
-      const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16);   // even start
-      const uint32_t v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);   // odd start
+      // taps {18,34,48,56,48,34,18} on rows r..r+6; the lone 7th tap is a dot2 with a zero partner and the rounding
+      // constant rides in as the first accumulator, so an output is 4 v_dot2_u32_u16
+      const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16), w6 = 18u;  // even r
+      const uint32_t v0 = 18u << 16, v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);  // odd r
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
+        const int k0 = rr >> 1;
         uint32_t acc;
-        if ((rr & 1) == 0) {  // rows r = 4br + rr (even): pairs k0 = rr/2 .. k0+2, then the low half of pair k0+3
-          const int k0 = rr >> 1;
-          acc = udot2_u16(pr[k0], w01, 18u * (pr[k0 + 3] & 0xFFFFu));
+        if ((rr & 1) == 0) {  // rows r = 4br + rr (even): pairs k0 .. k0+2, then the low half of pair k0+3
+          acc = udot2_u16(pr[k0], w01, 32768u);
           acc = udot2_u16(pr[k0 + 1], w23, acc);
           acc = udot2_u16(pr[k0 + 2], w45, acc);
+          acc = udot2_u16(pr[k0 + 3], w6, acc);
         } else {              // odd r: high half of pair k0, then pairs k0+1 .. k0+3
-          const int k0 = rr >> 1;
-          acc = udot2_u16(pr[k0 + 1], v12, 18u * (pr[k0] >> 16));
+          acc = udot2_u16(pr[k0], v0, 32768u);
+          acc = udot2_u16(pr[k0 + 1], v12, acc);
           acc = udot2_u16(pr[k0 + 2], v34, acc);
           acc = udot2_u16(pr[k0 + 3], v56, acc);
         }
-        outw[rr] |= ((acc + 32768u) >> 16) << (8 * cI);
+        accs[rr][cI] = acc;  // result byte = bits 16..23
       }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; rr++) {  // gather byte 2 of the four accumulators with v_perm_b32
+      const uint32_t lo = __builtin_amdgcn_perm(accs[rr][1], accs[rr][0], 0x0c0c0602u);  // [acc0.b2, acc1.b2, 0, 0]
+      const uint32_t hi = __builtin_amdgcn_perm(accs[rr][3], accs[rr][2], 0x06020c0cu);  // [0, 0, acc2.b2, acc3.b2]
+      outw[rr] = lo | hi;
     }
 #pragma unroll
     for (int rr = 0; rr < 4; rr++) {
