@@ -339,13 +339,32 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
   else
     HIPC(hipMemsetAsync(ex->d_lap.p, 0, (size_t)n * 2 * sizeof(int), s));
-  for (int l = 1; l < g.nlevels; l++) {
+  static const int splitEnv = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 0;
+  const int split = (splitEnv > 0 && splitEnv < g.nlevels) ? splitEnv : g.nlevels;  // levels [split, L) on the side stream
+  for (int l = 1; l < split; l++) {
     StageTimer t(ex, s, ORBX_STAGE_RESIZE);
     HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, s));
   }
+  if (split < g.nlevels) {
+    HIPC(hipEventRecord(ex->evStart, s));
+    HIPC(hipStreamWaitEvent(ex->stream2, ex->evStart, 0));
+    for (int l = split; l < g.nlevels; l++) {
+      StageTimer t(ex, ex->stream2, ORBX_STAGE_RESIZE);
+      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, ex->stream2));
+    }
+    {
+      StageTimer t(ex, ex->stream2, ORBX_STAGE_DETECT);
+      HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, split, g.nlevels, ex->stream2));
+    }
+    HIPC(hipEventRecord(ex->evDet0, ex->stream2));
+  }
   {
     StageTimer t(ex, s, ORBX_STAGE_DETECT);
-    HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, g.nlevels, s));
+    HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, split, s));
+  }
+  if (split < g.nlevels) {
+    HIPC(hipStreamWaitEvent(s, ex->evDet0, 0));
+    ex->lastEvValid = false;
   }
   // The blurred copies only depend on the pyramid.  They run on the side stream, released once k_detect (which
   // fills the chip by itself) is done, so that the streaming blur shares the GPU with the latency-bound quadtree.
@@ -434,7 +453,11 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   };
   ok(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
   ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
-  ok(hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;  // side stream at the highest priority: its small kernels must not queue behind big ones
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    ok(hipStreamCreateWithPriority(&ex->stream2, hipStreamNonBlocking, hi));
+  }
   ok(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
   ok(hipEventCreateWithFlags(&ex->evBlur, hipEventDisableTiming));
   ok(hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming));

@@ -209,6 +209,48 @@ __device__ __forceinline__ int fast_contrast_lds(const uint8_t* c8, int TP) {
   return max(maxmin - c, c - minmax);
 }
 
+// Two pixels per lane: the same contrast computation in packed half precision.  A pixel value v (0..255) is
+// represented as the f16 bit pattern 0x6400 | v == 1024 + v, which is exact and order preserving; differences of two
+// such values (|d| <= 255) are exact too, so v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_add_f16 give bit-exact
+// integer results for two pixels at the cost of one.  Returns M for pixel A in .x and pixel B in .y.
+typedef _Float16 orbx_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ orbx_h2 pk_min3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
+  return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c);
+}
+__device__ __forceinline__ orbx_h2 pk_max3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
+  return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
+}
+__device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
+  orbx_h2 r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int off = kRingDY[k] * TP + kRingDX[k];
+    r[k] = __builtin_bit_cast(orbx_h2, (uint32_t)a8[off] | ((uint32_t)b8[off] << 16) | 0x64006400u);
+  }
+  orbx_h2 lo3[16], hi3[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo3[i] = pk_min3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+    hi3[i] = pk_max3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+  }
+  orbx_h2 lo9[16], hi9[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    lo9[i] = pk_min3(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
+    hi9[i] = pk_max3(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
+  }
+  orbx_h2 maxmin = pk_max3(lo9[0], lo9[1], lo9[2]), minmax = pk_min3(hi9[0], hi9[1], hi9[2]);
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) {
+    maxmin = pk_max3(maxmin, lo9[i], lo9[i + 1]);
+    minmax = pk_min3(minmax, hi9[i], hi9[i + 1]);
+  }
+  maxmin = __builtin_elementwise_maximum(maxmin, lo9[15]);
+  minmax = __builtin_elementwise_minimum(minmax, hi9[15]);
+  const orbx_h2 c = __builtin_bit_cast(orbx_h2, (uint32_t)a8[0] | ((uint32_t)b8[0] << 16) | 0x64006400u);
+  return __builtin_elementwise_maximum(maxmin - c, c - minmax);
+}
+
 // One wave per FAST cell (workgroup = 64 threads, so __syncthreads() is a wave barrier).
 // Pass 1 runs at iniThFAST; only a cell whose post-NMS set is empty is redone at minThFAST (:942-959).
 // The NMS needs no threshold masking: a neighbour that is not a corner at t has score < t <= the centre's.
@@ -303,16 +345,22 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     bool overflowed = false;  // more corners than the list holds: the NMS falls back to scanning the score tile
     auto flush_survivors = [&]() {
       __syncthreads();
-      for (int base = 0; base < nSurv; base += 64) {
-        const int e = base + lane;
-        const int yx = slist[min(e, nSurv - 1)], y = yx >> 8, x = yx & 255;
-        const int M = fast_contrast_lds(tile8 + (y + 3) * g.tileP + x + 3, g.tileP);
-        const bool corner = e < nSurv && M > t;
-        if (corner) score8[(y + 1) * g.scoreP + x + 4] = (uint8_t)(M - 1);
-        const uint64_t m = __ballot(corner);
-        const int o = nList + __popcll(m & lanemask_lt());
-        if (corner && o < listCap) list[o] = (uint16_t)yx;
-        nList += __popcll(m);
+      const orbx_h2 th2 = {(_Float16)t, (_Float16)t};
+      for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
+        const int eA = base + lane, eB = base + 64 + lane;
+        const int yxA = slist[min(eA, nSurv - 1)], yxB = slist[min(eB, nSurv - 1)];
+        const int yA = yxA >> 8, xA = yxA & 255, yB = yxB >> 8, xB = yxB & 255;
+        const orbx_h2 M = fast_contrast2_lds(tile8 + (yA + 3) * g.tileP + xA + 3, tile8 + (yB + 3) * g.tileP + xB + 3,
+                                            g.tileP);
+        const bool cornerA = eA < nSurv && M.x > th2.x, cornerB = eB < nSurv && M.y > th2.y;
+        if (cornerA) score8[(yA + 1) * g.scoreP + xA + 4] = (uint8_t)((int)M.x - 1);
+        if (cornerB) score8[(yB + 1) * g.scoreP + xB + 4] = (uint8_t)((int)M.y - 1);
+        const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
+        const int oA = nList + __popcll(mA & lanemask_lt());
+        const int oB = nList + __popcll(mA) + __popcll(mB & lanemask_lt());
+        if (cornerA && oA < listCap) list[oA] = (uint16_t)yxA;
+        if (cornerB && oB < listCap) list[oB] = (uint16_t)yxB;
+        nList += __popcll(mA) + __popcll(mB);
       }
       if (nList > listCap) {
         overflowed = true;
