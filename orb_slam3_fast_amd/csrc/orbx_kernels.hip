@@ -29,6 +29,10 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 __device__ __forceinline__ int rne_f(float v) { return __float2int_rn(v); }  // cvRound
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+// number of set bits of a wave mask below this lane: v_mbcnt_lo + v_mbcnt_hi (no 64-bit vector shifts)
+__device__ __forceinline__ int prefix_count(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // ================================================================================================ resize
 // cv::resize INTER_LINEAR 8U, level l from level l-1.  Coefficient tables (sx, a0/a1 ; sy, b0/b1)
@@ -356,8 +360,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         if (cornerA) score8[(yA + 1) * g.scoreP + xA + 4] = (uint8_t)((int)M.x - 1);
         if (cornerB) score8[(yB + 1) * g.scoreP + xB + 4] = (uint8_t)((int)M.y - 1);
         const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
-        const int oA = nList + __popcll(mA & lanemask_lt());
-        const int oB = nList + __popcll(mA) + __popcll(mB & lanemask_lt());
+        const int oA = nList + prefix_count(mA);
+        const int oB = nList + __popcll(mA) + prefix_count(mB);
         if (cornerA && oA < listCap) list[oA] = (uint16_t)yxA;
         if (cornerB && oB < listCap) list[oB] = (uint16_t)yxB;
         nList += __popcll(mA) + __popcll(mB);
@@ -393,7 +397,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
-        if ((m >> lane) & 1ull) slist[nSurv + __popcll(m & lanemask_lt())] = (uint16_t)((yd << 8) | (4 * j + pI));
+        if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
+          slist[nSurv + prefix_count(m)] = (uint16_t)((yd << 8) | (4 * j + pI));
         nSurv += __popcll(m);
       }
       if (nSurv > listCap - 256) flush_survivors();
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
                           sc > c8[-SP + 1] && sc > c8[SP - 1] && sc > c8[SP] && sc > c8[SP + 1];
         const uint64_t m = __ballot(keep);
         if (keep) {
-          const int o = kept + __popcll(m & lanemask_lt());
+          const int o = kept + prefix_count(m);
           if (o < L.cellCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, sc);
         }
         kept += __popcll(m);
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 #pragma unroll
         for (int pI = 0; pI < 4; pI++) {
           const uint64_t m = __ballot((keepmask >> pI) & 1u);
-          before += __popcll(m & lanemask_lt());
+          before += prefix_count(m);
           total += __popcll(m);
         }
         const int pos = kept + before;
@@ -533,14 +538,14 @@ __device__ int partition_wave(uint64_t* a, int first, int last, uint16_t* Li, ui
     const int i = base + lane;
     const bool st = i < last && !less(a[min(i, last - 1)], pivot);
     const uint64_t m = __ballot(st);
-    if (st) Li[nL + __popcll(m & lanemask_lt())] = (uint16_t)i;
+    if (st) Li[nL + prefix_count(m)] = (uint16_t)i;
     nL += __popcll(m);
   }
   for (int top = last - 1; top >= first + 1; top -= 64) {
     const int i = top - lane;
     const bool st = i >= first + 1 && !less(pivot, a[max(i, first + 1)]);
     const uint64_t m = __ballot(st);
-    if (st) Ri[nR + __popcll(m & lanemask_lt())] = (uint16_t)i;
+    if (st) Ri[nR + prefix_count(m)] = (uint16_t)i;
     nR += __popcll(m);
   }
   wsync();
@@ -1858,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
             }
             const uint64_t m = __ballot(ok);
             if (pass && ok) {
-              const int o = wbase + total + __popcll(m & lanemask_lt());
+              const int o = wbase + total + prefix_count(m);
               if (o < a.candCap) {
                 a.candIdx[o] = i2;
                 a.candDist[o] = hamming256(d1, reinterpret_cast<const uint32_t*>(a.d2) + (long long)i2 * 8);
@@ -2036,7 +2041,7 @@ __global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __r
                  fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
           }
           const uint64_t m = __ballot(ok);
-          if (pass && ok) out[wbase + total + __popcll(m & lanemask_lt())] = i2;
+          if (pass && ok) out[wbase + total + prefix_count(m)] = i2;
           total += __popcll(m);
         }
       }
@@ -2156,7 +2161,7 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
             }
             const uint64_t m = __ballot(ok);
             if (pass && ok) {
-              const int o = wbase + total + __popcll(m & lanemask_lt());
+              const int o = wbase + total + prefix_count(m);
               if (o < a.candCap) {
                 a.candIdx[o] = i2;
                 a.candDist[o] = (hamming256(d1, reinterpret_cast<const uint32_t*>(a.desc) + (long long)i2 * 8) << 8) | oct;
