@@ -41,7 +41,7 @@ __device__ __forceinline__ int prefix_count(uint64_t m) {
 // the horizontal pass (one thread per dst column, walking the footprint rows) leaves (S0*a0 + S1*a1) >> 4 as u16
 // in LDS; the vertical pass emits 4 pixels per thread with one u32 store.
 #define RS_DW 256
-#define RS_DR 8
+#define RS_DR 16
 __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int* __restrict__ xofs,
                                                 const short* __restrict__ xab, const int* __restrict__ yofs,
                                                 const short* __restrict__ yab, int srcRowsMax, int srcDwMax) {
