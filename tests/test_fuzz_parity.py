@@ -85,3 +85,77 @@ def test_fuzz_extract_and_stereo(oracle):
         exL.close()
         exR.close()
     assert not fails, "mismatching cases (seed, w, h, nfeatures, scale, levels, ini, min, lap): %r" % fails
+
+
+def test_fuzz_matchers(oracle):
+    """SearchForInitialization, both SearchByProjection flavours, GetFeaturesInArea and kNN on random frame pairs."""
+    ncases = int(os.environ.get("ORBX_FUZZ_CASES", "60")) // 3 + 1
+    seed0 = int(os.environ.get("ORBX_FUZZ_SEED", "12345")) + 5000
+    fails = []
+    for case in range(ncases):
+        rng = np.random.default_rng(seed0 + case)
+        w, h = int(rng.integers(320, 900)), int(rng.integers(300, 700))
+        nf = int(rng.integers(300, 4000))
+        try:
+            ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+        except orbx.OrbxError as e:
+            if e.code == orbx.E_UNSUPPORTED:   # portrait aspect < 0.5: the reference divides by zero there (SURVEY Q11)
+                continue
+            raise
+        f0, f1 = synth.mono_frame(w, h, 900 + case, 0), synth.mono_frame(w, h, 900 + case, int(rng.integers(1, 4)))
+        lap = (0, 1000) if rng.random() < 0.5 else (0, 0)
+        try:
+            _, k1, d1 = ex(f0, lap)
+            _, k2, d2 = ex(f1, lap)
+        except orbx.OrbxError as e:
+            if e.code == orbx.E_UNSUPPORTED:   # portrait aspect < 0.5: the reference divides by zero there (SURVEY Q11)
+                continue
+            raise
+        if len(k1) < 20 or len(k2) < 20:
+            continue
+        bounds = (0.0, 0.0, float(w), float(h))
+        prev = np.stack([k1["x"], k1["y"]], 1) + rng.normal(0, 2.0, (len(k1), 2)).astype(np.float32)
+        win = int(rng.choice([10, 30, 100]))
+        ratio = float(rng.choice([0.6, 0.8, 0.9]))
+        ori = bool(rng.integers(0, 2))
+        n, m12, np_ = orbx.ORBmatcher(ratio, ori).SearchForInitialization(k1, d1, k2, d2, bounds, prev, win)
+        on, om12, onp = oracle.search_init(k1, d1, k2, d2, bounds, prev, win, ratio, ori)
+        ok = n == on and np.array_equal(m12, om12) and np_.tobytes() == onp.tobytes()
+        # projection matchers with k1 as the "map points"
+        nmp = len(k1)
+        sf = ex.GetScaleFactors()
+        mps = np.zeros(nmp, orbx.MP_DTYPE)
+        mps["proj_x"] = k1["x"] + rng.normal(0, 4.0, nmp)
+        mps["proj_y"] = k1["y"] + rng.normal(0, 4.0, nmp)
+        mps["proj_xr"] = mps["proj_x"] - rng.uniform(0, 50, nmp).astype(np.float32)
+        mps["view_cos"] = rng.uniform(0.99, 1.0, nmp).astype(np.float32)
+        mps["track_depth"] = rng.uniform(1, 80, nmp).astype(np.float32)
+        mps["predicted_level"] = np.clip(k1["octave"] + rng.integers(-1, 2, nmp), 0, 7)
+        mps["in_view"] = rng.random(nmp) < 0.9
+        mps["bad"] = rng.random(nmp) < 0.05
+        mps["has_observations"] = rng.random(nmp) < 0.8
+        mps["desc"] = d1 ^ np.packbits(rng.random((nmp, 32, 8)) < 0.05, axis=2).reshape(nmp, 32)
+        uR = np.where(rng.random(len(k2)) < 0.6, k2["x"] - rng.uniform(0, 40, len(k2)), -1).astype(np.float32)
+        occ = (rng.random(len(k2)) < 0.1).astype(np.uint8)
+        th = float(rng.choice([1.0, 2.0, 5.0]))
+        pts = np.zeros(nmp, orbx.PP_DTYPE)
+        pts["u"], pts["v"], pts["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+        pts["radius"] = (np.float32(rng.choice([7.0, 15.0])) * sf[k1["octave"]]).astype(np.float32)
+        pts["angle"] = k1["angle"]
+        pts["min_level"], pts["max_level"] = k1["octave"] - 1, k1["octave"] + 1
+        pts["valid"] = mps["in_view"]
+        pts["has_observations"] = mps["has_observations"]
+        pts["desc"] = mps["desc"]
+        n2, m2, o2 = orbx.ORBmatcher(ratio, ori).SearchByProjectionFrame(k2, d2, uR, bounds, pts, occ)
+        on2, om2, oo2 = oracle.search_by_projection_frame(k2, d2, uR, bounds, pts, ori, occ)
+        ok = ok and n2 == on2 and np.array_equal(m2, om2) and np.array_equal(o2, oo2)
+        n1, m1, o1 = orbx.ORBmatcher(ratio, ori).SearchByProjection(k2, d2, uR, bounds, sf, mps, occ, th, True, 40.0)
+        on1, om1, oo1 = oracle.search_by_projection(k2, d2, uR, bounds, sf, mps, th, True, 40.0, ratio, occ)
+        ok = ok and n1 == on1 and np.array_equal(m1, om1) and np.array_equal(o1, oo1)
+        idx, dist, okk = orbx.bf_knn2(d1[: min(400, len(d1))], d2)
+        oidx, odist, ookk = oracle.bf_knn2(d1[: min(400, len(d1))], d2)
+        ok = ok and np.array_equal(idx, oidx) and np.array_equal(dist, odist) and np.array_equal(okk, ookk)
+        if not ok:
+            fails.append((seed0 + case, w, h, nf, win, ratio, ori))
+        ex.close()
+    assert not fails, "mismatching matcher cases: %r" % fails
