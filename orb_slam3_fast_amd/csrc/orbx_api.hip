@@ -339,6 +339,18 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
   else
     HIPC(hipMemsetAsync(ex->d_lap.p, 0, (size_t)n * 2 * sizeof(int), s));
+  static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
+  hipStream_t sb = serial ? s : ex->stream2;
+  // Experiment knob (default off): blur level 0 beside the resize chain.  Measured 1.063 vs 1.039 ms/step — the chain
+  // slows down more than the quadtree-side blur gains.
+  static const int blur0 = getenv("ORBX_BLUR0") ? atoi(getenv("ORBX_BLUR0")) : 0;
+  const int nb0 = serial ? 0 : std::min(blur0, 1);  // only level 0 exists before the chain
+  if (nb0 > 0) {  // level 0 is the caller's image: its blur runs beside the (latency-bound) resize chain
+    HIPC(hipEventRecord(ex->evStart, s));
+    HIPC(hipStreamWaitEvent(sb, ex->evStart, 0));
+    StageTimer t(ex, sb, ORBX_STAGE_BLUR);
+    HIPC(launch_blur(g, ex->pyr, n, 0, nb0, sb));
+  }
   static const int splitEnv = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 0;
   const int split = (splitEnv > 0 && splitEnv < g.nlevels) ? splitEnv : g.nlevels;  // levels [split, L) on the side stream
   for (int l = 1; l < split; l++) {
@@ -369,13 +381,11 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   // The blurred copies only depend on the pyramid.  They run on the side stream, released once k_detect (which
   // fills the chip by itself) is done, so that the streaming blur shares the GPU with the latency-bound quadtree.
   // (Also tried: FAST on level 0 beside the resize chain -- slower, 1.48 vs 1.33 ms/step: both just time-slice.)
-  static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
-  hipStream_t sb = serial ? s : ex->stream2;
   HIPC(hipEventRecord(ex->evPyr, s));
   HIPC(hipStreamWaitEvent(sb, ex->evPyr, 0));
   {
     StageTimer t(ex, sb, ORBX_STAGE_BLUR);
-    HIPC(launch_blur(g, ex->pyr, n, sb));
+    HIPC(launch_blur(g, ex->pyr, n, nb0, g.nlevels, sb));
   }
   HIPC(hipEventRecord(ex->evBlur, sb));
   {

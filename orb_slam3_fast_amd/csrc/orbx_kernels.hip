@@ -1127,17 +1127,17 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
 // 18,34,48,56 | 48,34,18,0) for TWO vertically adjacent rows and stores them as u16 pairs (row r | row r+1 << 16;
 // max 255*256 fits).  Vertical pass: a thread owns a 4x4 output block; with rows packed in pairs the 7-tap
 // column filter is 3 v_dot2_u32_u16 + 1 mad per output.  All integer, exact; one rounding (+32768 >> 16).
-__global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
+__global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int level1) {
   __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];    // +1: pad against bank conflicts
   __shared__ uint32_t hp[(BL_TH + 6) / 2][BL_TW + 1];      // [row pair][32*(x%4) + x/4] = H(2j, x) | H(2j+1, x) << 16
                                                            // (quad-transposed columns: both passes bank-conflict free)
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   int tile = blockIdx.x;
-  int l = 0;
-  for (;; l++) {  // tiles of all levels are enumerated in one grid dimension
+  int l = level0;
+  for (;; l++) {  // tiles of levels [level0, level1) are enumerated in one grid dimension
     const int tx = (g.lv[l].w + BL_TW - 1) / BL_TW, ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
-    if (tile < tx * ty || l + 1 == g.nlevels) break;
+    if (tile < tx * ty || l + 1 == level1) break;
     tile -= tx * ty;
   }
   const LevelDev L = g.lv[l];
@@ -1244,11 +1244,12 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p) {
   }
 }
 
-hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, hipStream_t s) {
+hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int level1, hipStream_t s) {
   int tiles = 0;
-  for (int l = 0; l < g.nlevels; l++)
+  for (int l = level0; l < level1; l++)
     tiles += ((g.lv[l].w + BL_TW - 1) / BL_TW) * ((g.lv[l].h + BL_TH - 1) / BL_TH);
-  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p);
+  if (tiles == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1);
   return hipGetLastError();
 }
 
