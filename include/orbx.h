@@ -129,6 +129,34 @@ int orbx_stereo_download(orbx_extractor* left, int pair, float* uright, float* d
 int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx2,
                  int32_t* dist2, uint8_t* ratio_ok);
 
+/* The fisheye stereo rig Frame::ComputeStereoFishEyeMatches works on: the two KannalaBrandt8 cameras
+ * (GeometricCamera::mvParameters = fx fy cx cy k0 k1 k2 k3, include/CameraModels/KannalaBrandt8.h:42-57), the Newton
+ * stop of KannalaBrandt8::unproject (`precision`, :102) and the left-from-right transform mRlr / mtlr
+ * (include/Frame.h:208-209, src/Frame.cc:1240-1243), R12 row-major. */
+typedef struct orbx_kb8_rig {
+  float cam1[8];
+  float cam2[8];
+  float precision;
+  float R12[9];
+  float t12[3];
+} orbx_kb8_rig;
+
+/* Replaces the whole of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1273-1331): brute-force 2-NN of the
+ * lapping-area rows [mono_left, n_left) x [mono_right, n_right) (as orbx_bf_knn2), Lowe ratio 0.7, and for every
+ * surviving pair KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:341-432: unproject by Newton
+ * iteration, parallax gate 0.9998, linear triangulation = smallest right singular vector of the 4x4 system, cheirality
+ * and the two chi-square reprojection gates 5.991 * mvLevelSigma2[octave]).  Outputs (host, caller-allocated):
+ * left_to_right[n_left] = mvLeftToRightMatch, right_to_left[n_right] = mvRightToLeftMatch (serial semantics: a right
+ * keypoint claimed by several left ones keeps the LAST), depth[n_left] = mvDepth (-1 = none), points3d[n_left][3] =
+ * mvStereo3Dpoints (zeros where unmatched), *n_desc_matches = pairs that passed the ratio test (may be NULL).
+ * Returns nMatches >= 0 or an ORBX_E_* code.  This is the one floating-point routine of the path: results agree with
+ * the reference to float rounding (device libm, no Eigen), not bit for bit -- see DESIGN.md. */
+int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                              int mono_left, const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                              int mono_right, const orbx_kb8_rig* rig, const float* level_sigma2, int n_levels,
+                              int32_t* left_to_right, int32_t* right_to_left, float* depth, float* points3d,
+                              int32_t* n_desc_matches);
+
 /* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) incl. Frame::GetFeaturesInArea /
  * AssignFeaturesToGrid / PosInGrid on F2 (src/Frame.cc:520-547,765-844) and ComputeThreeMaxima
  * (src/ORBmatcher.cc:1920-1955).  kps are the undistorted keypoints (mvKeysUn); bounds = mnMinX, mnMinY,

@@ -44,6 +44,9 @@ def lib():
         _lib.oro_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.oro_cv_round_f.argtypes = [C.c_float]
         _lib.oro_ic_angle.restype = C.c_float
+        _lib.oro_kb8_triangulate.restype = C.c_float
+        _lib.oro_kb8_triangulate.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p]
+        _lib.oro_kb8_unproject.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
     return _lib
 
 
@@ -243,3 +246,56 @@ def features_in_area(k, bounds, x, y, r, min_level, max_level):
                                    C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(x), C.c_float(y),
                                    C.c_float(r), min_level, max_level, _p(out), len(out))
     return out[:n].copy()
+
+
+# ---- KannalaBrandt8 / ComputeStereoFishEyeMatches (float part of the path: tolerance parity) -------------------------
+def kb8_rig(cam1, cam2, R12, t12, precision=1e-6):
+    """The 29 floats of orbx_kb8_rig: cam1[8] cam2[8] precision R12[9] (row-major) t12[3]."""
+    return np.concatenate([np.asarray(cam1, np.float32).ravel(), np.asarray(cam2, np.float32).ravel(),
+                           np.array([precision], np.float32), np.asarray(R12, np.float32).ravel(),
+                           np.asarray(t12, np.float32).ravel()]).astype(np.float32)
+
+
+def kb8_project(cam, X):
+    cam, X = np.ascontiguousarray(cam, np.float32), np.ascontiguousarray(X, np.float32)
+    uv = np.zeros(2, np.float32)
+    lib().oro_kb8_project(_p(cam), _p(X), _p(uv))
+    return uv
+
+
+def kb8_unproject(cam, u, v, precision=1e-6):
+    cam = np.ascontiguousarray(cam, np.float32)
+    ray = np.zeros(3, np.float32)
+    lib().oro_kb8_unproject(_p(cam), precision, float(u), float(v), _p(ray))
+    return ray
+
+
+def null_vector4(A):
+    A = np.ascontiguousarray(A, np.float32)
+    v = np.zeros(4, np.float32)
+    lib().oro_null_vector4(_p(A), _p(v))
+    return v
+
+
+def kb8_triangulate(rig, uv1, uv2, sigma1=1.0, sigma2=1.0):
+    rig = np.ascontiguousarray(rig, np.float32)
+    p = np.zeros(3, np.float32)
+    gate = np.zeros(5, np.float32)
+    d = lib().oro_kb8_triangulate(_p(rig), float(uv1[0]), float(uv1[1]), float(uv2[0]), float(uv2[1]), sigma1, sigma2,
+                                  _p(p), _p(gate))
+    return float(d), p, gate
+
+
+def fisheye_stereo_match(kL, dL, monoL, kR, dR, monoR, rig, level_sigma2):
+    """-> nMatches, descMatches, leftToRight, rightToLeft, depth, p3D [nL,3], gates [nL,6]."""
+    kL, kR = np.ascontiguousarray(kL), np.ascontiguousarray(kR)
+    dL, dR = _u8(dL), _u8(dR)
+    rig = np.ascontiguousarray(rig, np.float32)
+    s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    nL, nR = len(kL), len(kR)
+    l2r, r2l = np.zeros(nL, np.int32), np.zeros(nR, np.int32)
+    dep, pts, gates = np.zeros(nL, np.float32), np.zeros((nL, 3), np.float32), np.zeros((nL, 6), np.float32)
+    nd = C.c_int(0)
+    nm = lib().oro_fisheye_stereo_match(_p(kL), _p(dL), nL, monoL, _p(kR), _p(dR), nR, monoR, _p(rig), _p(s2), len(s2),
+                                        _p(l2r), _p(r2l), _p(dep), _p(pts), C.byref(nd), _p(gates))
+    return nm, nd.value, l2r, r2l, dep, pts, gates

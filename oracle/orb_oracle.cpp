@@ -704,6 +704,187 @@ void bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, std::vector<i
   }
 }
 
+// ---- KannalaBrandt8 (src/CameraModels/KannalaBrandt8.cpp) -----------------------------------------------------
+// Float arithmetic in the reference's expression order.  atan2f / tanf / cosf / sinf come from the host libm and the
+// reference build may contract to FMA (-march=native): this part of the path is tolerance parity by construction.
+void kb8_project(const KB8& c, const float X[3], float uv[2]) {  // :67-86 (Eigen::Vector3f overload)
+  const float x2_plus_y2 = X[0] * X[0] + X[1] * X[1];
+  const float theta = atan2f(sqrtf(x2_plus_y2), X[2]);
+  const float psi = atan2f(X[1], X[0]);
+  const float theta2 = theta * theta;
+  const float theta3 = theta * theta2;
+  const float theta5 = theta3 * theta2;
+  const float theta7 = theta5 * theta2;
+  const float theta9 = theta7 * theta2;
+  const float r = theta + c.p[4] * theta3 + c.p[5] * theta5 + c.p[6] * theta7 + c.p[7] * theta9;
+  uv[0] = c.p[0] * r * std::cos(psi) + c.p[2];
+  uv[1] = c.p[1] * r * std::sin(psi) + c.p[3];
+}
+
+void kb8_unproject(const KB8& c, float u, float v, float ray[3]) {  // :116-147
+  const float pwx = (u - c.p[2]) / c.p[0], pwy = (v - c.p[3]) / c.p[1];
+  float scale = 1.f;
+  float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+  const double kPi = 3.1415926535897932384626433832795;  // CV_PI
+  theta_d = fminf(fmaxf((float)(-kPi / 2.f), theta_d), (float)(kPi / 2.f));
+  if (theta_d > 1e-8) {
+    float theta = theta_d;
+    for (int j = 0; j < 10; j++) {
+      const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      const float k0_theta2 = c.p[4] * theta2, k1_theta4 = c.p[5] * theta4;
+      const float k2_theta6 = c.p[6] * theta6, k3_theta8 = c.p[7] * theta8;
+      const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                              (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+      theta = theta - theta_fix;
+      if (fabsf(theta_fix) < c.precision) break;
+    }
+    scale = std::tan(theta) / theta_d;
+  }
+  ray[0] = pwx * scale;
+  ray[1] = pwy * scale;
+  ray[2] = 1.f;
+}
+
+void smallest_right_singular_vector(const float A[16], float v[4]) {
+  double U[4][4], V[4][4];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      U[i][j] = A[4 * i + j];
+      V[i][j] = i == j ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; sweep++) {  // one-sided (Hestenes) Jacobi: orthogonalise the columns of U = A V
+    bool rotated = false;
+    for (int p = 0; p < 3; p++)
+      for (int q = p + 1; q < 4; q++) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 4; i++) {
+          al += U[i][p] * U[i][p];
+          be += U[i][q] * U[i][q];
+          ga += U[i][p] * U[i][q];
+        }
+        if (ga == 0.0 || std::fabs(ga) <= 1e-15 * std::sqrt(al * be)) continue;
+        rotated = true;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+        for (int i = 0; i < 4; i++) {
+          const double up = U[i][p], uq = U[i][q];
+          U[i][p] = cs * up - sn * uq;
+          U[i][q] = sn * up + cs * uq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = cs * vp - sn * vq;
+          V[i][q] = sn * vp + cs * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  int best = 0;
+  double bestn = 0;
+  for (int j = 0; j < 4; j++) {
+    double n = 0;
+    for (int i = 0; i < 4; i++) n += U[i][j] * U[i][j];
+    if (j == 0 || n < bestn) {
+      bestn = n;
+      best = j;
+    }
+  }
+  for (int i = 0; i < 4; i++) v[i] = (float)V[i][best];
+}
+
+float kb8_triangulate_matches(const KB8& c1, const KB8& c2, float u1, float v1, float u2, float v2, const float R12[9],
+                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate) {
+  if (gate)
+    for (int i = 0; i < 5; i++) gate[i] = NAN;
+  float r1[3], r2[3], r21[3];
+  kb8_unproject(c1, u1, v1, r1);
+  kb8_unproject(c2, u2, v2, r2);
+  for (int i = 0; i < 3; i++) r21[i] = R12[3 * i] * r2[0] + R12[3 * i + 1] * r2[1] + R12[3 * i + 2] * r2[2];  // :352
+  const float dot = r1[0] * r21[0] + r1[1] * r21[1] + r1[2] * r21[2];
+  const float n1 = sqrtf(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+  const float n2 = sqrtf(r21[0] * r21[0] + r21[1] * r21[1] + r21[2] * r21[2]);
+  const float cosParallaxRays = dot / (n1 * n2);
+  if (gate) gate[0] = cosParallaxRays;
+  if (cosParallaxRays > 0.9998) return -1;  // :356
+  // Tcw1 = [I | 0], Tcw2 = [R21 | -R21 t12]  (:369-376)
+  float T1[3][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}}, T2[3][4];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) T2[i][j] = R12[3 * j + i];
+    T2[i][3] = (-T2[i][0]) * t12[0] + (-T2[i][1]) * t12[1] + (-T2[i][2]) * t12[2];
+  }
+  float A[16];  // Triangulate, :420-427
+  for (int j = 0; j < 4; j++) {
+    A[j] = r1[0] * T1[2][j] - T1[0][j];
+    A[4 + j] = r1[1] * T1[2][j] - T1[1][j];
+    A[8 + j] = r2[0] * T2[2][j] - T2[0][j];
+    A[12 + j] = r2[1] * T2[2][j] - T2[1][j];
+  }
+  float xh[4];
+  smallest_right_singular_vector(A, xh);
+  const float x3D[3] = {xh[0] / xh[3], xh[1] / xh[3], xh[2] / xh[3]};
+  const float z1 = x3D[2];
+  if (gate) gate[1] = z1;
+  if (!(z1 > 0)) return -2;  // `z1 <= 0`; NaN (xh[3] == 0) rejected as well
+  const float z2 = T2[2][0] * x3D[0] + T2[2][1] * x3D[1] + T2[2][2] * x3D[2] + T2[2][3];
+  if (gate) gate[2] = z2;
+  if (!(z2 > 0)) return -3;
+  float uv1[2];
+  kb8_project(c1, x3D, uv1);
+  const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
+  if (gate) gate[3] = (float)((errX1 * errX1 + errY1 * errY1) / (5.991 * sigmaLevel));
+  if ((errX1 * errX1 + errY1 * errY1) > 5.991 * sigmaLevel) return -4;
+  float x3D2[3];
+  for (int i = 0; i < 3; i++) x3D2[i] = T2[i][0] * x3D[0] + T2[i][1] * x3D[1] + T2[i][2] * x3D[2] + T2[i][3];
+  float uv2[2];
+  kb8_project(c2, x3D2, uv2);
+  const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;
+  if (gate) gate[4] = (float)((errX2 * errX2 + errY2 * errY2) / (5.991 * unc));
+  if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -5;
+  p3D[0] = x3D[0];
+  p3D[1] = x3D[1];
+  p3D[2] = x3D[2];
+  return z1;
+}
+
+int compute_stereo_fisheye_matches(const std::vector<KeyPoint>& kL, const uint8_t* dL, int monoL,
+                                   const std::vector<KeyPoint>& kR, const uint8_t* dR, int monoR, const KB8& c1,
+                                   const KB8& c2, const float R12[9], const float t12[3],
+                                   const std::vector<float>& levelSigma2, std::vector<int>& leftToRight,
+                                   std::vector<int>& rightToLeft, std::vector<float>& depth,
+                                   std::vector<float>& p3D, int* descMatches, std::vector<float>* gates) {
+  const int nL = (int)kL.size(), nR = (int)kR.size();
+  leftToRight.assign(nL, -1);
+  rightToLeft.assign(nR, -1);
+  depth.assign(nL, -1.0f);
+  p3D.assign((size_t)nL * 3, 0.0f);
+  if (gates) gates->assign((size_t)nL * 6, NAN);
+  const int nQ = nL - monoL, nT = nR - monoR;
+  std::vector<int> idx2, dist2;
+  std::vector<uint8_t> ok;
+  bf_knn2(dL + (size_t)monoL * 32, nQ, dR + (size_t)monoR * 32, nT, idx2, dist2, ok);
+  int nMatches = 0, nDesc = 0;
+  for (int q = 0; q < nQ; q++) {
+    if (!ok[q]) continue;
+    nDesc++;
+    const int iL = q + monoL, iR = idx2[2 * q] + monoR;
+    const float sigma1 = levelSigma2[kL[iL].octave], sigma2 = levelSigma2[kR[iR].octave];
+    float P[3] = {0, 0, 0};
+    float* gt = gates ? gates->data() + (size_t)iL * 6 : nullptr;
+    const float d = kb8_triangulate_matches(c1, c2, kL[iL].x, kL[iL].y, kR[iR].x, kR[iR].y, R12, t12, sigma1, sigma2, P, gt);
+    if (gt) gt[5] = d;
+    if (d > 0.0001f) {
+      leftToRight[iL] = iR;
+      rightToLeft[iR] = iL;
+      p3D[3 * iL] = P[0];
+      p3D[3 * iL + 1] = P[1];
+      p3D[3 * iL + 2] = P[2];
+      depth[iL] = d;
+      nMatches++;
+    }
+  }
+  if (descMatches) *descMatches = nDesc;
+  return nMatches;
+}
+
 // Frame::AssignFeaturesToGrid / PosInGrid, src/Frame.cc:520-547,833-844 (64x48 grid, round-to-cell).
 void FrameGrid::build(const std::vector<KeyPoint>& kps, float minX_, float minY_, float maxX_, float maxY_) {
   minX = minX_; minY = minY_; maxX = maxX_; maxY = maxY_;

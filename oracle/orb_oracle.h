@@ -98,6 +98,34 @@ void compute_stereo_matches(const std::vector<Image>& pyrL, const std::vector<Im
 void bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, std::vector<int>& idx2,
              std::vector<int>& dist2, std::vector<uint8_t>& ratio_ok);
 
+// ---- KannalaBrandt8 + Frame::ComputeStereoFishEyeMatches tail (FLOAT: tolerance parity, see tests) ------------
+// KannalaBrandt8 camera: mvParameters = fx fy cx cy k0 k1 k2 k3 and the Newton stop `precision`
+// (include/CameraModels/KannalaBrandt8.h:42-57,102).
+struct KB8 {
+  float p[8];
+  float precision = 1e-6f;
+};
+void kb8_project(const KB8& c, const float X[3], float uv[2]);   // src/CameraModels/KannalaBrandt8.cpp:67-86
+void kb8_unproject(const KB8& c, float u, float v, float ray[3]);  // :116-147
+// Right singular vector of the smallest singular value of a row-major 4x4 (what Eigen::JacobiSVD(...).matrixV().col(3)
+// returns, :420-432), by one-sided Jacobi in double.  Eigen is not in this image: the reference's float JacobiSVD is
+// matched to its own rounding noise only.
+void smallest_right_singular_vector(const float A[16], float v[4]);
+// KannalaBrandt8::TriangulateMatches (:341-417).  Returns z1 (> 0), or -1..-5 for the rejecting gate.  gate[5] (may
+// be null) receives the gated quantities {cosParallax, z1, z2, err1/(5.991 sigma1), err2/(5.991 sigma2)} so that a
+// tolerance test can tell borderline decisions from wrong ones.
+float kb8_triangulate_matches(const KB8& c1, const KB8& c2, float u1, float v1, float u2, float v2, const float R12[9],
+                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate);
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1273-1331): BF 2-NN on the lapping-area rows [mono, n) of both
+// eyes, Lowe 0.7, triangulation gates; serial order (a right keypoint claimed twice keeps the later left index).
+// Outputs sized nL / nR / nL / 3 nL; returns nMatches, *descMatches = pairs that passed the ratio test.
+int compute_stereo_fisheye_matches(const std::vector<KeyPoint>& kL, const uint8_t* dL, int monoL,
+                                   const std::vector<KeyPoint>& kR, const uint8_t* dR, int monoR, const KB8& c1,
+                                   const KB8& c2, const float R12[9], const float t12[3],
+                                   const std::vector<float>& levelSigma2, std::vector<int>& leftToRight,
+                                   std::vector<int>& rightToLeft, std::vector<float>& depth,
+                                   std::vector<float>& p3D, int* descMatches, std::vector<float>* gates);
+
 // Frame grid (src/Frame.cc:520-547,765-844).
 struct FrameGrid {
   float minX, minY, maxX, maxY, invW, invH;

@@ -188,6 +188,39 @@ int oro_search_by_projection_frame(const KeyPoint* k, const uint8_t* desc, const
   return nm;
 }
 
+// cam = fx fy cx cy k0 k1 k2 k3 ; rig = cam1[8] cam2[8] precision R12[9] t12[3] (29 floats, = orbx_kb8_rig)
+static KB8 kb8_from(const float* cam, float precision) {
+  KB8 c;
+  std::memcpy(c.p, cam, sizeof(c.p));
+  c.precision = precision;
+  return c;
+}
+void oro_kb8_project(const float* cam, const float* X, float* uv) { kb8_project(kb8_from(cam, 1e-6f), X, uv); }
+void oro_kb8_unproject(const float* cam, float precision, float u, float v, float* ray) {
+  kb8_unproject(kb8_from(cam, precision), u, v, ray);
+}
+void oro_null_vector4(const float* A, float* v) { smallest_right_singular_vector(A, v); }
+float oro_kb8_triangulate(const float* rig, float u1, float v1, float u2, float v2, float sigma1, float sigma2, float* p3D,
+                          float* gate) {
+  return kb8_triangulate_matches(kb8_from(rig, rig[16]), kb8_from(rig + 8, rig[16]), u1, v1, u2, v2, rig + 17, rig + 26,
+                                 sigma1, sigma2, p3D, gate);
+}
+int oro_fisheye_stereo_match(const KeyPoint* kL, const uint8_t* dL, int nL, int monoL, const KeyPoint* kR, const uint8_t* dR,
+                             int nR, int monoR, const float* rig, const float* levelSigma2, int nLevels, int* leftToRight,
+                             int* rightToLeft, float* depth, float* p3D, int* descMatches, float* gates /* nL x 6 or null */) {
+  std::vector<KeyPoint> a(kL, kL + nL), b(kR, kR + nR);
+  std::vector<float> s2(levelSigma2, levelSigma2 + nLevels), dep, pts, gt;
+  std::vector<int> l2r, r2l;
+  const int nm = compute_stereo_fisheye_matches(a, dL, monoL, b, dR, monoR, kb8_from(rig, rig[16]), kb8_from(rig + 8, rig[16]),
+                                                rig + 17, rig + 26, s2, l2r, r2l, dep, pts, descMatches, gates ? &gt : nullptr);
+  std::memcpy(leftToRight, l2r.data(), nL * sizeof(int));
+  std::memcpy(rightToLeft, r2l.data(), nR * sizeof(int));
+  std::memcpy(depth, dep.data(), nL * sizeof(float));
+  std::memcpy(p3D, pts.data(), (size_t)nL * 3 * sizeof(float));
+  if (gates) std::memcpy(gates, gt.data(), (size_t)nL * 6 * sizeof(float));
+  return nm;
+}
+
 // libstdc++ std::sort with the (count, UL.x) comparator of compareNodes (src/ORBextractor.cc:542-555) on
 // packed 64-bit elements (key = bits 16..63): the tie order the device quadtree's replica must reproduce.
 void oro_std_sort_keys(uint64_t* v, int n) {

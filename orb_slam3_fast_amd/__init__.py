@@ -71,6 +71,7 @@ def lib():
         L.orbx_stereo_results_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
         L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
+        L.orbx_fisheye_stereo_match.argtypes = [i, vp, vp, i, i, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
@@ -269,6 +270,38 @@ def bf_knn2(descQ, descT, device=0):
     ok = np.zeros(len(q), np.uint8)
     _check(lib().orbx_bf_knn2(device, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist), _p(ok)))
     return idx, dist, ok
+
+
+def kb8_rig(cam1, cam2, R12, t12, precision=1e-6):
+    """orbx_kb8_rig as 29 float32: the two KannalaBrandt8 parameter vectors (fx fy cx cy k0 k1 k2 k3), the Newton stop
+    of unproject, and mRlr (row-major) / mtlr (include/Frame.h:208-209)."""
+    rig = np.concatenate([np.asarray(cam1, np.float32).ravel(), np.asarray(cam2, np.float32).ravel(),
+                          np.array([precision], np.float32), np.asarray(R12, np.float32).ravel(),
+                          np.asarray(t12, np.float32).ravel()]).astype(np.float32)
+    if rig.size != 29:
+        raise ValueError("kb8_rig: need 8 + 8 camera parameters, a 3x3 rotation and a 3-vector")
+    return rig
+
+
+def ComputeStereoFishEyeMatches(kpsL, descL, monoL, kpsR, descR, monoR, rig, level_sigma2, device=0):
+    """Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1273-1331) incl. KannalaBrandt8::TriangulateMatches.
+    Returns (nMatches, descMatches, mvLeftToRightMatch, mvRightToLeftMatch, mvDepth, mvStereo3Dpoints[nL, 3])."""
+    kl, kr = np.ascontiguousarray(kpsL, KP_DTYPE), np.ascontiguousarray(kpsR, KP_DTYPE)
+    dl = np.ascontiguousarray(descL, np.uint8).reshape(-1, 32)
+    dr = np.ascontiguousarray(descR, np.uint8).reshape(-1, 32)
+    if len(dl) != len(kl) or len(dr) != len(kr):
+        raise ValueError("one descriptor row per keypoint")
+    rig = np.ascontiguousarray(rig, np.float32)
+    if rig.size != 29:
+        raise ValueError("rig: use kb8_rig()")
+    s2 = np.ascontiguousarray(level_sigma2, np.float32)
+    l2r, r2l = np.zeros(len(kl), np.int32), np.zeros(len(kr), np.int32)
+    depth, pts = np.zeros(len(kl), np.float32), np.zeros((len(kl), 3), np.float32)
+    nd = C.c_int(0)
+    n = _check(lib().orbx_fisheye_stereo_match(device, _p(kl), _p(dl), len(kl), int(monoL), _p(kr), _p(dr), len(kr),
+                                               int(monoR), _p(rig), _p(s2), len(s2), _p(l2r), _p(r2l), _p(depth),
+                                               _p(pts), C.byref(nd)))
+    return n, nd.value, l2r, r2l, depth, pts
 
 
 def GetFeaturesInArea(kpsUn, bounds, queries, device=0, return_grid=False):

@@ -3,7 +3,7 @@
 //
 // Reference: include/ORBmatcher.h:36-101, src/ORBmatcher.cc:618-764,1920-1973 (SearchForInitialization,
 // ComputeThreeMaxima, DescriptorDistance); src/Frame.cc:921-1084 (ComputeStereoMatches),
-// src/Frame.cc:1273-1304 (brute-force kNN part of ComputeStereoFishEyeMatches).
+// src/Frame.cc:1273-1331 (ComputeStereoFishEyeMatches: brute-force kNN + KannalaBrandt8 triangulation).
 //
 // The reference's methods take Frame&; Frame itself (poses, map points, IMU) is out of scope, so the
 // mirror takes the few Frame members those methods read (FrameView).  INTEGRATION.md shows the three-line
@@ -117,6 +117,32 @@ inline void BFKnnMatch2(const uint8_t* descQ, int nQ, const uint8_t* descT, int 
   ratio_ok.assign(nQ, 0);
   if (orbx_bf_knn2(device, descQ, nQ, descT, nT, idx2.data(), dist2.data(), ratio_ok.data()) != ORBX_OK)
     throw std::runtime_error(std::string("BFKnnMatch2: ") + orbx_last_error());
+}
+
+// Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1273-1331) incl. KannalaBrandt8::TriangulateMatches
+// (src/CameraModels/KannalaBrandt8.cpp:341-432).  Arguments are the Frame members the routine reads (mvKeys,
+// mDescriptors, monoLeft, mvKeysRight, mDescriptorsRight, monoRight, mvLevelSigma2) and the rig (both cameras'
+// mvParameters, mRlr, mtlr); outputs are the members it fills.  mvStereo3Dpoints holds x, y, z per left keypoint
+// (Eigen::Vector3f in the reference; zeros where the reference leaves the entry uninitialised).  Returns nMatches.
+inline int ComputeStereoFishEyeMatches(const std::vector<ocv::KeyPoint>& mvKeys, const uint8_t* mDescriptors, int monoLeft,
+                                       const std::vector<ocv::KeyPoint>& mvKeysRight, const uint8_t* mDescriptorsRight,
+                                       int monoRight, const orbx_kb8_rig& rig, const std::vector<float>& mvLevelSigma2,
+                                       std::vector<int>& mvLeftToRightMatch, std::vector<int>& mvRightToLeftMatch,
+                                       std::vector<float>& mvDepth, std::vector<float>& mvuRight,
+                                       std::vector<float>& mvStereo3Dpoints, int device = 0) {
+  const int Nleft = (int)mvKeys.size(), Nright = (int)mvKeysRight.size();
+  mvLeftToRightMatch.assign(Nleft, -1);
+  mvRightToLeftMatch.assign(Nright, -1);
+  mvDepth.assign(Nleft, -1.0f);
+  mvuRight.assign(Nleft, -1.0f);  // :1288, never written afterwards
+  mvStereo3Dpoints.assign((size_t)Nleft * 3, 0.0f);
+  const int n = orbx_fisheye_stereo_match(
+      device, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), mDescriptors, Nleft, monoLeft,
+      reinterpret_cast<const orbx_keypoint*>(mvKeysRight.data()), mDescriptorsRight, Nright, monoRight, &rig,
+      mvLevelSigma2.data(), (int)mvLevelSigma2.size(), mvLeftToRightMatch.data(), mvRightToLeftMatch.data(), mvDepth.data(),
+      mvStereo3Dpoints.data(), nullptr);
+  if (n < 0) throw std::runtime_error(std::string("ComputeStereoFishEyeMatches: ") + orbx_last_error());
+  return n;
 }
 
 }  // namespace ORB_SLAM3

@@ -335,10 +335,13 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->lastN = n;
   ex->lastEvValid = false;
   hipStream_t s = ex->stream;
+  // Keypoint x is >= 19 at every level (16-px border + the 3-px FAST ring, scaled by >= 1), so a lapping area that
+  // ends below 19 -- the rectified-stereo {0, 0} in particular -- can hold no keypoint: the output order is then
+  // just level-major list order, k_slots is skipped and k_describe derives its slot from the level counts.
+  bool lapTrivial = true;
   if (lap)
-    HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
-  else
-    HIPC(hipMemsetAsync(ex->d_lap.p, 0, (size_t)n * 2 * sizeof(int), s));
+    for (int i = 0; i < n; i++) lapTrivial = lapTrivial && lap[2 * i + 1] < 19;
+  if (!lapTrivial) HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
   static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
   hipStream_t sb = serial ? s : ex->stream2;
   // Experiment knob (default off): blur level 0 beside the resize chain.  Measured 1.063 vs 1.039 ms/step — the chain
@@ -393,7 +396,7 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,
                        ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
   }
-  {
+  if (!lapTrivial) {
     StageTimer t(ex, s, ORBX_STAGE_SLOTS);
     HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
   }
@@ -401,7 +404,8 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->lastEvValid = false;  // fresh start event: do not bill the wait for the side stream to k_describe
   {
     StageTimer t(ex, s, ORBX_STAGE_DESCRIBE);
-    HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, ex->d_slot.p, ex->d_kps.p, ex->d_desc.p, s));
+    HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, lapTrivial ? nullptr : ex->d_slot.p, ex->d_kps.p,
+                         ex->d_desc.p, ex->d_nOut.p, ex->d_mono.p, s));
   }
   return ORBX_OK;
 }
@@ -755,6 +759,77 @@ int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT,
   q.free(); t.free(); ok.free(); i2.free(); d2.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return ORBX_OK;
+}
+
+int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                              int mono_left, const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                              int mono_right, const orbx_kb8_rig* rig, const float* level_sigma2, int n_levels,
+                              int32_t* left_to_right, int32_t* right_to_left, float* depth, float* points3d,
+                              int32_t* n_desc_matches) {
+  if (n_left < 0 || n_right < 0 || mono_left < 0 || mono_left > n_left || mono_right < 0 || mono_right > n_right ||
+      !rig || !level_sigma2 || n_levels <= 0 || n_levels > ORBX_MAX_LEVELS ||
+      (n_left && (!kps_left || !desc_left || !left_to_right || !depth || !points3d)) ||
+      (n_right && (!kps_right || !desc_right || !right_to_left)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_left; i++) {
+    left_to_right[i] = -1;
+    depth[i] = -1.0f;
+    points3d[3 * i] = points3d[3 * i + 1] = points3d[3 * i + 2] = 0.0f;
+  }
+  for (int i = 0; i < n_right; i++) right_to_left[i] = -1;
+  if (n_desc_matches) *n_desc_matches = 0;
+  const int nQ = n_left - mono_left, nT = n_right - mono_right;
+  // knnMatch(k = 2) yields pairs only when the train set has two rows (`(*it).size() >= 2`, src/Frame.cc:1302)
+  if (nQ == 0 || nT < 2) {
+    int rc0 = set_device(device);  // still a device routine: no GPU is an error, never a silent host path
+    return rc0 != ORBX_OK ? rc0 : 0;
+  }
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  DevBuf<orbx_keypoint> kl, kr;
+  DevBuf<uint8_t> dq, dt, ok;
+  DevBuf<int> i2, d2, l2r, r2l, cnt;
+  DevBuf<float> dep, pts, sg;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  chk(kl.alloc(n_left)); chk(kr.alloc(n_right)); chk(dq.alloc((size_t)nQ * 32)); chk(dt.alloc((size_t)nT * 32));
+  chk(ok.alloc(nQ)); chk(i2.alloc((size_t)nQ * 2)); chk(d2.alloc((size_t)nQ * 2)); chk(l2r.alloc(n_left));
+  chk(r2l.alloc(n_right)); chk(cnt.alloc(2)); chk(dep.alloc(n_left)); chk(pts.alloc((size_t)n_left * 3));
+  chk(sg.alloc(n_levels));
+  if (e == hipSuccess) {
+    chk(hipMemcpy(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+    chk(hipMemcpy(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+    chk(hipMemcpy(dq.p, desc_left + (size_t)mono_left * 32, (size_t)nQ * 32, hipMemcpyHostToDevice));
+    chk(hipMemcpy(dt.p, desc_right + (size_t)mono_right * 32, (size_t)nT * 32, hipMemcpyHostToDevice));
+    chk(hipMemcpy(sg.p, level_sigma2, (size_t)n_levels * sizeof(float), hipMemcpyHostToDevice));
+    chk(hipMemcpy(l2r.p, left_to_right, (size_t)n_left * sizeof(int), hipMemcpyHostToDevice));   // the -1 / 0 fills
+    chk(hipMemcpy(r2l.p, right_to_left, (size_t)n_right * sizeof(int), hipMemcpyHostToDevice));
+    chk(hipMemcpy(dep.p, depth, (size_t)n_left * sizeof(float), hipMemcpyHostToDevice));
+    chk(hipMemset(pts.p, 0, (size_t)n_left * 3 * sizeof(float)));
+    chk(hipMemset(cnt.p, 0, 2 * sizeof(int)));
+  }
+  if (e == hipSuccess) chk(launch_bf_knn2(dq.p, nQ, dt.p, nT, i2.p, d2.p, ok.p, nullptr));
+  if (e == hipSuccess) {
+    FisheyeArgs a;
+    a.kL = kl.p; a.kR = kr.p; a.nL = n_left; a.nR = n_right; a.monoL = mono_left; a.monoR = mono_right;
+    a.idx2 = i2.p; a.ratioOk = ok.p; a.rig = *rig; a.sigma2 = sg.p; a.nLevels = n_levels;
+    a.leftToRight = l2r.p; a.rightToLeft = r2l.p; a.depth = dep.p; a.p3D = pts.p; a.counters = cnt.p;
+    chk(launch_fisheye_triangulate(a, nullptr));
+  }
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  int counts[2] = {0, 0};
+  if (e == hipSuccess) {
+    chk(hipMemcpy(left_to_right, l2r.p, (size_t)n_left * sizeof(int), hipMemcpyDeviceToHost));
+    chk(hipMemcpy(right_to_left, r2l.p, (size_t)n_right * sizeof(int), hipMemcpyDeviceToHost));
+    chk(hipMemcpy(depth, dep.p, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
+    chk(hipMemcpy(points3d, pts.p, (size_t)n_left * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    chk(hipMemcpy(counts, cnt.p, sizeof(counts), hipMemcpyDeviceToHost));
+  }
+  kl.free(); kr.free(); dq.free(); dt.free(); ok.free(); i2.free(); d2.free(); l2r.free(); r2l.free(); cnt.free();
+  dep.free(); pts.free(); sg.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (n_desc_matches) *n_desc_matches = counts[1];
+  return counts[0];
 }
 
 int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,

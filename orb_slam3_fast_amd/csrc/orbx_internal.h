@@ -81,7 +81,7 @@ hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int le
 hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int* selCount, const int* lap,
                         int* slot, int* nOut, int* mono, hipStream_t s);
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
-                           const int* slot, orbx_keypoint* kps, uint8_t* desc, hipStream_t s);
+                           const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s);
 size_t octree_lds_bytes(const Geom& g);
 
 struct StereoArgs {
@@ -105,6 +105,24 @@ hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, cons
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
                           uint8_t* ok, hipStream_t s);
+
+// Frame::ComputeStereoFishEyeMatches tail (src/Frame.cc:1298-1330) on the k_bf_knn2 results of the lapping rows.
+struct FisheyeArgs {
+  const orbx_keypoint* kL;  // all left keypoints (nL), lapping rows start at monoL
+  const orbx_keypoint* kR;
+  int nL, nR, monoL, monoR;
+  const int* idx2;          // [nL - monoL][2] from k_bf_knn2
+  const uint8_t* ratioOk;   // [nL - monoL]
+  orbx_kb8_rig rig;
+  const float* sigma2;
+  int nLevels;
+  int* leftToRight;         // [nL]  (pre-set to -1)
+  int* rightToLeft;         // [nR]  (pre-set to -1; atomicMax = "last left index wins")
+  float* depth;             // [nL]  (pre-set to -1)
+  float* p3D;               // [nL][3] (pre-set to 0)
+  int* counters;            // [0] = nMatches, [1] = descMatches (pre-set to 0)
+};
+hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s);
 struct InitArgs {
   const orbx_keypoint *k1, *k2;
   const uint8_t *d1, *d2;

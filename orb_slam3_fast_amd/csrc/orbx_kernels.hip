@@ -1387,7 +1387,7 @@ __device__ __forceinline__ void orb_sincos_dev(float ang, float& s_out, float& c
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                  int ablate) {
+                                                  int* __restrict__ nOut, int* __restrict__ mono, int ablate) {
   __shared__ uint32_t patch_all[4][37 * DS_PITCH / 4];
   if (ablate == 1) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1398,6 +1398,12 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   while (l + 1 < g.nlevels && s >= g.lv[l + 1].selOff) l++;
   const LevelDev L = g.lv[l];
   const int idx = s - L.selOff;
+  if (!slot && s == 0 && lane == 0) {  // k_slots skipped: this wave publishes the image's counts
+    int total = 0;
+    for (int q = 0; q < g.nlevels; q++) total += selCount[img * g.nlevels + q];
+    nOut[img] = total;
+    mono[img] = total;
+  }
   if (idx >= selCount[img * g.nlevels + l]) return;
   const uint32_t key = sel[(long long)img * g.selImg + s];
   const int X = key_x(key), Y = key_y(key);
@@ -1457,7 +1463,16 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, b;
   orb_sincos_dev(__fmul_rn(angle, factorPI), b, a);  // a = cos, b = sin
-  const int n_out_slot = slot[(long long)img * g.selImg + s];
+  // slot == nullptr: no keypoint can lie in the lapping area (lap1 < 19 <= every x), so the serial-order slot is
+  // simply (keypoints of the earlier levels) + idx and k_slots is not launched at all
+  int n_out_slot;
+  if (slot) {
+    n_out_slot = slot[(long long)img * g.selImg + s];
+  } else {
+    int before = 0;
+    for (int q = 0; q < l; q++) before += selCount[img * g.nlevels + q];
+    n_out_slot = before + idx;
+  }
   uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // patch writes of this wave before its own reads
   __builtin_amdgcn_wave_barrier();
@@ -1488,10 +1503,10 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
 }
 
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
-                           const int* slot, orbx_keypoint* kps, uint8_t* desc, hipStream_t s) {
+                           const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s) {
   static const int ablate = getenv("ORBX_DESC_ABLATE") ? atoi(getenv("ORBX_DESC_ABLATE")) : 0;
   hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc, ablate);
+                     kps, desc, nOut, mono, ablate);
   return hipGetLastError();
 }
 
@@ -1781,6 +1796,206 @@ hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, 
                           uint8_t* ok, hipStream_t s) {
   if (nQ <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_bf_knn2, dim3((nQ + 255) / 256), dim3(256), 0, s, dQ, nQ, dT, nT, idx2, dist2, ok);
+  return hipGetLastError();
+}
+
+// ================================================================================================ fisheye stereo
+// Tail of Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1298-1330): one thread per lapping-area left keypoint whose
+// 2-NN passed the Lowe test runs KannalaBrandt8::TriangulateMatches (src/CameraModels/KannalaBrandt8.cpp:341-432).
+// This is the floating-point corner of the path: float expressions in the reference's order (this TU is compiled
+// with -ffp-contract=off), device libm for atan2f / tanf / cosf / sinf, and the null vector of the 4x4 system from a
+// one-sided Jacobi SVD in double instead of Eigen::JacobiSVD<Matrix4f> -- parity is to float rounding, not bit-exact.
+struct KB8Cam {
+  float p[8];
+  float precision;
+};
+
+__device__ __forceinline__ void kb8_project(const KB8Cam& c, const float X[3], float uv[2]) {  // :67-86
+  const float x2_plus_y2 = X[0] * X[0] + X[1] * X[1];
+  const float theta = atan2f(sqrtf(x2_plus_y2), X[2]);
+  const float psi = atan2f(X[1], X[0]);
+  const float theta2 = theta * theta;
+  const float theta3 = theta * theta2;
+  const float theta5 = theta3 * theta2;
+  const float theta7 = theta5 * theta2;
+  const float theta9 = theta7 * theta2;
+  const float r = theta + c.p[4] * theta3 + c.p[5] * theta5 + c.p[6] * theta7 + c.p[7] * theta9;
+  uv[0] = c.p[0] * r * cosf(psi) + c.p[2];
+  uv[1] = c.p[1] * r * sinf(psi) + c.p[3];
+}
+
+__device__ __forceinline__ void kb8_unproject(const KB8Cam& c, float u, float v, float ray[3]) {  // :116-147
+  const float pwx = (u - c.p[2]) / c.p[0], pwy = (v - c.p[3]) / c.p[1];
+  float scale = 1.f;
+  float theta_d = sqrtf(pwx * pwx + pwy * pwy);
+  const float halfPi = (float)(3.1415926535897932384626433832795 / 2.0);
+  theta_d = fminf(fmaxf(-halfPi, theta_d), halfPi);
+  if ((double)theta_d > 1e-8) {
+    float theta = theta_d;
+    for (int j = 0; j < 10; j++) {  // Newton on theta (1 + k0 theta^2 + ...) = theta_d
+      const float theta2 = theta * theta, theta4 = theta2 * theta2, theta6 = theta4 * theta2, theta8 = theta4 * theta4;
+      const float k0_theta2 = c.p[4] * theta2, k1_theta4 = c.p[5] * theta4;
+      const float k2_theta6 = c.p[6] * theta6, k3_theta8 = c.p[7] * theta8;
+      const float theta_fix = (theta * (1 + k0_theta2 + k1_theta4 + k2_theta6 + k3_theta8) - theta_d) /
+                              (1 + 3 * k0_theta2 + 5 * k1_theta4 + 7 * k2_theta6 + 9 * k3_theta8);
+      theta = theta - theta_fix;
+      if (fabsf(theta_fix) < c.precision) break;
+    }
+    scale = tanf(theta) / theta_d;
+  }
+  ray[0] = pwx * scale;
+  ray[1] = pwy * scale;
+  ray[2] = 1.f;
+}
+
+// Right singular vector of the smallest singular value (= JacobiSVD::matrixV().col(3), :429-431) of a row-major 4x4.
+__device__ void null_vector4(const float A[16], float v[4]) {
+  double U[4][4], V[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      U[i][j] = (double)A[4 * i + j];
+      V[i][j] = i == j ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; sweep++) {
+    bool rotated = false;
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+      for (int q = p + 1; q < 4; q++) {
+        double al = 0, be = 0, ga = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          al += U[i][p] * U[i][p];
+          be += U[i][q] * U[i][q];
+          ga += U[i][p] * U[i][q];
+        }
+        if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+        rotated = true;
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const double up = U[i][p], uq = U[i][q];
+          U[i][p] = cs * up - sn * uq;
+          U[i][q] = sn * up + cs * uq;
+          const double vp = V[i][p], vq = V[i][q];
+          V[i][p] = cs * vp - sn * vq;
+          V[i][q] = sn * vp + cs * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  double n[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) n[j] = U[0][j] * U[0][j] + U[1][j] * U[1][j] + U[2][j] * U[2][j] + U[3][j] * U[3][j];
+  int best = 0;
+#pragma unroll
+  for (int j = 1; j < 4; j++)
+    if (n[j] < n[best]) best = j;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double x = V[i][0];
+    x = best == 1 ? V[i][1] : x;
+    x = best == 2 ? V[i][2] : x;
+    x = best == 3 ? V[i][3] : x;
+    v[i] = (float)x;
+  }
+}
+
+__device__ float kb8_triangulate_matches(const KB8Cam& c1, const KB8Cam& c2, float u1, float v1, float u2, float v2,
+                                         const float* R12, const float* t12, float sigmaLevel, float unc, float p3D[3]) {
+  float r1[3], r2[3], r21[3];
+  kb8_unproject(c1, u1, v1, r1);
+  kb8_unproject(c2, u2, v2, r2);
+#pragma unroll
+  for (int i = 0; i < 3; i++) r21[i] = R12[3 * i] * r2[0] + R12[3 * i + 1] * r2[1] + R12[3 * i + 2] * r2[2];
+  const float dot = r1[0] * r21[0] + r1[1] * r21[1] + r1[2] * r21[2];
+  const float n1 = sqrtf(r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2]);
+  const float n2 = sqrtf(r21[0] * r21[0] + r21[1] * r21[1] + r21[2] * r21[2]);
+  const float cosParallaxRays = dot / (n1 * n2);
+  if ((double)cosParallaxRays > 0.9998) return -1;  // :356
+  float T2[3][4];  // Tcw2 = [R21 | -R21 t12]; Tcw1 = [I | 0] is folded into the rows of A below (:369-376)
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) T2[i][j] = R12[3 * j + i];
+    T2[i][3] = (-T2[i][0]) * t12[0] + (-T2[i][1]) * t12[1] + (-T2[i][2]) * t12[2];
+  }
+  float A[16];  // Triangulate, :420-427
+  A[0] = -1.f; A[1] = 0.f; A[2] = r1[0]; A[3] = 0.f;
+  A[4] = 0.f; A[5] = -1.f; A[6] = r1[1]; A[7] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    A[8 + j] = r2[0] * T2[2][j] - T2[0][j];
+    A[12 + j] = r2[1] * T2[2][j] - T2[1][j];
+  }
+  float xh[4];
+  null_vector4(A, xh);
+  const float x3D[3] = {xh[0] / xh[3], xh[1] / xh[3], xh[2] / xh[3]};
+  const float z1 = x3D[2];
+  if (!(z1 > 0)) return -2;
+  const float z2 = T2[2][0] * x3D[0] + T2[2][1] * x3D[1] + T2[2][2] * x3D[2] + T2[2][3];
+  if (!(z2 > 0)) return -3;
+  float uv1[2];
+  kb8_project(c1, x3D, uv1);
+  const float errX1 = uv1[0] - u1, errY1 = uv1[1] - v1;
+  if ((double)(errX1 * errX1 + errY1 * errY1) > 5.991 * (double)sigmaLevel) return -4;
+  float x3D2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) x3D2[i] = T2[i][0] * x3D[0] + T2[i][1] * x3D[1] + T2[i][2] * x3D[2] + T2[i][3];
+  float uv2[2];
+  kb8_project(c2, x3D2, uv2);
+  const float errX2 = uv2[0] - u2, errY2 = uv2[1] - v2;
+  if ((double)(errX2 * errX2 + errY2 * errY2) > 5.991 * (double)unc) return -5;
+  p3D[0] = x3D[0];
+  p3D[1] = x3D[1];
+  p3D[2] = x3D[2];
+  return z1;
+}
+
+__global__ __launch_bounds__(64) void k_fisheye_triangulate(FisheyeArgs a) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  const int nQ = a.nL - a.monoL;
+  bool desc = false, matched = false;
+  if (q < nQ && a.ratioOk[q]) {
+    desc = true;
+    const int iL = q + a.monoL, iR = a.idx2[2 * q] + a.monoR;
+    const orbx_keypoint k1 = a.kL[iL], k2 = a.kR[iR];
+    KB8Cam c1, c2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      c1.p[i] = a.rig.cam1[i];
+      c2.p[i] = a.rig.cam2[i];
+    }
+    c1.precision = c2.precision = a.rig.precision;
+    const float sigma1 = a.sigma2[min(max(k1.octave, 0), a.nLevels - 1)];
+    const float sigma2 = a.sigma2[min(max(k2.octave, 0), a.nLevels - 1)];
+    float P[3] = {0.f, 0.f, 0.f};
+    const float d = kb8_triangulate_matches(c1, c2, k1.x, k1.y, k2.x, k2.y, a.rig.R12, a.rig.t12, sigma1, sigma2, P);
+    if (d > 0.0001f) {  // src/Frame.cc:1319
+      matched = true;
+      a.leftToRight[iL] = iR;
+      atomicMax(a.rightToLeft + iR, iL);  // serial loop: the later left keypoint overwrites (:1322-1323)
+      a.p3D[3 * iL] = P[0];
+      a.p3D[3 * iL + 1] = P[1];
+      a.p3D[3 * iL + 2] = P[2];
+      a.depth[iL] = d;
+    }
+  }
+  const uint64_t mm = __ballot(matched), md = __ballot(desc);
+  if (threadIdx.x == 0) {
+    if (mm) atomicAdd(a.counters, __popcll(mm));
+    if (md) atomicAdd(a.counters + 1, __popcll(md));
+  }
+}
+
+hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s) {
+  const int nQ = a.nL - a.monoL;
+  if (nQ <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_fisheye_triangulate, dim3((nQ + 63) / 64), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

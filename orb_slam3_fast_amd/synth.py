@@ -152,3 +152,74 @@ def stereo_pair(w, h, stream=0, frame=0):
 
 def mono_frame(w, h, stream=0, frame=0):
     return stereo_pair(w, h, stream, frame)[0]
+
+
+# ---- fisheye stereo rig (config C4: TUM-VI-like KannalaBrandt8 pair) ---------------------------------------------------
+TUMVI_CAM1 = (190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504,
+              0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182)
+TUMVI_CAM2 = (190.44236969414825, 190.4344384721956, 252.59949716835982, 254.91723064636983,
+              0.0034003170790442797, 0.001766278153469831, -0.00266312569781606, 0.0003299517423931039)
+
+
+def kb8_project_np(cam, X):
+    """KannalaBrandt8::project in float64 numpy (scene construction only; the checked arithmetic is the oracle's)."""
+    X = np.asarray(X, np.float64)
+    th = np.arctan2(np.hypot(X[..., 0], X[..., 1]), X[..., 2])
+    psi = np.arctan2(X[..., 1], X[..., 0])
+    r = th + cam[4] * th ** 3 + cam[5] * th ** 5 + cam[6] * th ** 7 + cam[7] * th ** 9
+    return np.stack([cam[0] * r * np.cos(psi) + cam[2], cam[1] * r * np.sin(psi) + cam[3]], -1)
+
+
+def fisheye_stereo_scene(seed=0, n_left=900, n_right=850, mono_left=300, mono_right=280, n_levels=8):
+    """Keypoints + descriptors of a synthetic fisheye stereo frame for ComputeStereoFishEyeMatches: 3-D points seen by
+    both KB8 cameras (0.3-40 m, so the parallax gate fires on the far ones), pixel noise that grows with the octave
+    (chi-square gates), wrong descriptor pairings (cheirality / reprojection gates), duplicated left keypoints
+    (right keypoint claimed twice) and unmatched clutter.  Returns a dict of arrays; kps use KP_DTYPE records."""
+    rng = np.random.default_rng(0xF15E + seed)
+    kp_dtype = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                         ("octave", "<i4"), ("class_id", "<i4")])
+    nQ, nT = n_left - mono_left, n_right - mono_right
+    ang = np.deg2rad(rng.normal(0, 0.6, 3))
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    R12 = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @
+           np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+    t12 = np.array([0.1011, 0.0019, 0.0012]) + rng.normal(0, 2e-4, 3)
+    sigma2 = (1.2 ** np.arange(n_levels)) ** 2
+    kL, kR = np.zeros(n_left, kp_dtype), np.zeros(n_right, kp_dtype)
+    dL = rng.integers(0, 256, (n_left, 32), dtype=np.uint8)
+    dR = rng.integers(0, 256, (n_right, 32), dtype=np.uint8)
+    for k in (kL, kR):
+        k["x"], k["y"] = rng.uniform(20, 490, len(k)), rng.uniform(20, 490, len(k))
+        k["octave"] = rng.integers(0, n_levels, len(k))
+        k["size"], k["angle"], k["response"], k["class_id"] = 31.0, rng.uniform(0, 360, len(k)), 30.0, -1
+    n_true = min(nQ, nT) * 3 // 4
+    depth = np.exp(rng.uniform(np.log(0.3), np.log(40.0), n_true))
+    th, ph = rng.uniform(0, 1.0, n_true), rng.uniform(0, 2 * np.pi, n_true)
+    X1 = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], 1) * depth[:, None]
+    X2 = (X1 - t12) @ R12            # x2 = R12^T (x1 - t12)
+    ql = mono_left + rng.permutation(nQ)[:n_true]
+    qr = mono_right + rng.permutation(nT)[:n_true]
+    octv = rng.integers(0, n_levels, n_true)
+    noise = rng.normal(0, 0.45, (n_true, 2, 2)) * (1.2 ** octv)[:, None, None] * rng.choice([1.0, 3.0], n_true, p=[0.8, 0.2])[:, None, None]
+    uv1, uv2 = kb8_project_np(TUMVI_CAM1, X1) + noise[:, 0], kb8_project_np(TUMVI_CAM2, X2) + noise[:, 1]
+    kL["x"][ql], kL["y"][ql], kL["octave"][ql] = uv1[:, 0], uv1[:, 1], octv
+    kR["x"][qr], kR["y"][qr], kR["octave"][qr] = uv2[:, 0], uv2[:, 1], octv
+    flips = rng.random((n_true, 32, 8)) < 0.03
+    dR[qr] = dL[ql] ^ np.packbits(flips, axis=2).reshape(n_true, 32)
+    # wrong pairings: descriptor says match, geometry says no
+    wrong = rng.permutation(n_true)[: n_true // 5]
+    kR["x"][qr[wrong]] += rng.normal(0, 60, len(wrong)).astype(np.float32)
+    kR["y"][qr[wrong]] += rng.normal(0, 60, len(wrong)).astype(np.float32)
+    # loose left gate (octave 7), tight right gate (octave 0) with a displaced right point: the -5 exit
+    tight = rng.permutation(n_true)[: n_true // 10]
+    kL["octave"][ql[tight]], kR["octave"][qr[tight]] = n_levels - 1, 0
+    kR["x"][qr[tight]] += rng.normal(0, 2.5, len(tight)).astype(np.float32)
+    kR["y"][qr[tight]] += rng.normal(0, 2.5, len(tight)).astype(np.float32)
+    # duplicated left keypoints: two lapping rows, same pixel + descriptor -> the same right keypoint claimed twice
+    free = np.setdiff1d(np.arange(mono_left, n_left), ql)
+    dup = rng.permutation(n_true)[: min(len(free), 24)]
+    kL[free[: len(dup)]] = kL[ql[dup]]
+    dL[free[: len(dup)]] = dL[ql[dup]]
+    return dict(kL=kL, dL=dL, kR=kR, dR=dR, mono_left=mono_left, mono_right=mono_right, cam1=np.array(TUMVI_CAM1, np.float32),
+                cam2=np.array(TUMVI_CAM2, np.float32), R12=R12.astype(np.float32), t12=t12.astype(np.float32),
+                level_sigma2=sigma2.astype(np.float32), true_left=ql, true_right=qr, true_depth=depth.astype(np.float32))

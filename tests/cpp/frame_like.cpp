@@ -4,7 +4,9 @@
 // against the oracle.   usage: frame_like <w> <h> <nfeat> <left.raw> <right.raw> <outprefix>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -34,6 +36,31 @@ int main(int argc, char** argv) {
       std::printf("no-device error: %s\n", e.what());
       return 3;
     }
+  }
+  if (std::string(argv[1]) == "fisheye") {
+    // frame_like fisheye <kL.raw> <dL.raw> <monoL> <kR.raw> <dR.raw> <monoR> <rig.raw (29 floats)> <sigma2.raw> <outprefix>
+    std::vector<uint8_t> kLb = slurp(argv[2]), dLb = slurp(argv[3]), kRb = slurp(argv[5]), dRb = slurp(argv[6]);
+    std::vector<uint8_t> rigb = slurp(argv[8]), sgb = slurp(argv[9]);
+    const std::string out = argv[10];
+    std::vector<ocv::KeyPoint> kL(kLb.size() / 28), kR(kRb.size() / 28);
+    std::memcpy(static_cast<void*>(kL.data()), kLb.data(), kLb.size());
+    std::memcpy(static_cast<void*>(kR.data()), kRb.data(), kRb.size());
+    orbx_kb8_rig rig;
+    static_assert(sizeof(orbx_kb8_rig) == 29 * sizeof(float), "rig is 29 packed floats");
+    std::memcpy(&rig, rigb.data(), sizeof(rig));
+    std::vector<float> sigma2(sgb.size() / 4);
+    std::memcpy(sigma2.data(), sgb.data(), sgb.size());
+    std::vector<int> l2r, r2l;
+    std::vector<float> depth, uR, p3d;
+    const int n = ComputeStereoFishEyeMatches(kL, dLb.data(), std::atoi(argv[4]), kR, dRb.data(), std::atoi(argv[7]), rig, sigma2,
+                                              l2r, r2l, depth, uR, p3d);
+    dump(out + ".l2r", l2r.data(), l2r.size());
+    dump(out + ".r2l", r2l.data(), r2l.size());
+    dump(out + ".depth", depth.data(), depth.size());
+    dump(out + ".p3d", p3d.data(), p3d.size());
+    dump(out + ".uR", uR.data(), uR.size());
+    std::printf("%d\n", n);
+    return 0;
   }
   const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), nf = std::atoi(argv[3]);
   std::vector<uint8_t> L = slurp(argv[4]), R = slurp(argv[5]);

@@ -57,3 +57,29 @@ def test_cpp_mirror_matches_oracle(oracle, tmp_path):
     prev = np.stack([okL["x"], okL["y"]], 1)
     on, om12, _ = oracle.search_init(okL, odL, okR, odR, (0, 0, w, h), prev, 100, 0.9, True)
     assert nm == on and np.fromfile(out + ".m12", np.int32).tolist() == om12.tolist()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_fisheye_matches_python_binding(tmp_path):
+    """ORB_SLAM3::ComputeStereoFishEyeMatches (csrc/ORBmatcher.h) is the same C-ABI call as the ctypes mirror."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd import synth
+    exe = build_exe()
+    sc = synth.fisheye_stereo_scene(4)
+    rig = orbx.kb8_rig(sc["cam1"], sc["cam2"], sc["R12"], sc["t12"])
+    names = {}
+    for key, arr in (("kL", sc["kL"]), ("dL", sc["dL"]), ("kR", sc["kR"]), ("dR", sc["dR"]), ("rig", rig),
+                     ("s2", sc["level_sigma2"])):
+        names[key] = str(tmp_path / (key + ".raw"))
+        np.ascontiguousarray(arr).tofile(names[key])
+    out = str(tmp_path / "f")
+    r = subprocess.run([exe, "fisheye", names["kL"], names["dL"], str(sc["mono_left"]), names["kR"], names["dR"],
+                        str(sc["mono_right"]), names["rig"], names["s2"], out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    n, nd, l2r, r2l, dep, pts = orbx.ComputeStereoFishEyeMatches(sc["kL"], sc["dL"], sc["mono_left"], sc["kR"], sc["dR"],
+                                                                 sc["mono_right"], rig, sc["level_sigma2"])
+    assert int(r.stdout.split()[0]) == n > 100
+    assert np.array_equal(np.fromfile(out + ".l2r", np.int32), l2r) and np.array_equal(np.fromfile(out + ".r2l", np.int32), r2l)
+    assert np.fromfile(out + ".depth", np.float32).tobytes() == dep.tobytes()
+    assert np.fromfile(out + ".p3d", np.float32).tobytes() == pts.tobytes()
+    assert (np.fromfile(out + ".uR", np.float32) == -1).all()

@@ -91,6 +91,20 @@ def projection_case(name, w, h, nf, stream):
     print(name, len(kc), n, n1, n2)
 
 
+def fisheye_case(name, seed):
+    """ComputeStereoFishEyeMatches incl. KB8 triangulation (float: consumers compare with the tolerances stated in
+    tests/test_fisheye.py); `gates` keeps the gated quantities so borderline decisions can be told apart."""
+    sc = synth.fisheye_stereo_scene(seed)
+    rig = O.kb8_rig(sc["cam1"], sc["cam2"], sc["R12"], sc["t12"])
+    n, nd, l2r, r2l, dep, pts, gates = O.fisheye_stereo_match(sc["kL"], sc["dL"], sc["mono_left"], sc["kR"], sc["dR"],
+                                                              sc["mono_right"], rig, sc["level_sigma2"])
+    np.savez_compressed(os.path.join(OUT, name), kL=sc["kL"].view(np.uint8).reshape(-1, 28), dL=sc["dL"],
+                        kR=sc["kR"].view(np.uint8).reshape(-1, 28), dR=sc["dR"], mono_left=sc["mono_left"],
+                        mono_right=sc["mono_right"], rig=rig, level_sigma2=sc["level_sigma2"], n=n, nd=nd, l2r=l2r, r2l=r2l,
+                        depth=dep, p3d=pts, gates=gates)
+    print(name, n, nd)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_160x120_L3.npz", 160, 120, 300, 3, 101, (0, 0))
@@ -98,3 +112,4 @@ if __name__ == "__main__":
     extract_case("extract_384x288_L8_lap.npz", 384, 288, 500, 8, 102, (100, 250))
     stereo_case("stereo_400x300.npz", 400, 300, 600, 103)
     projection_case("projection_480x360.npz", 480, 360, 800, 104)
+    fisheye_case("fisheye_stereo.npz", 105)
