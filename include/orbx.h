@@ -258,6 +258,9 @@ int orbx_debug_introsort_device(int device, uint64_t* v, int n);
 /* Shrinks (>= 320) or restores (1024) the capacity of k_detect's LDS survivor / corner lists so that tests can
  * force the list-overflow paths (mid-cell flushes, tile-scan NMS) that natural images never reach. */
 void orbx_debug_set_detect_list_cap(int cap);
+/* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
+ * than 16384 FAST candidates); 0 restores the register-resident path. */
+void orbx_debug_set_octree_global(int on);
 
 #ifdef __cplusplus
 }

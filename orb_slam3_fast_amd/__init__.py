@@ -86,6 +86,8 @@ def lib():
         L.orbx_debug_introsort_device.argtypes = [i, vp, i]
         L.orbx_debug_set_detect_list_cap.argtypes = [i]
         L.orbx_debug_set_detect_list_cap.restype = None
+        L.orbx_debug_set_octree_global.argtypes = [i]
+        L.orbx_debug_set_octree_global.restype = None
         _lib = L
     return _lib
 

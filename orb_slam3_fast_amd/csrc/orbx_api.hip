@@ -465,13 +465,15 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   auto ok = [&](hipError_t r) {
     if (e == hipSuccess) e = r;
   };
-  ok(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
-  ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
   {
-    int lo = 0, hi = 0;  // side stream at the highest priority: its small kernels must not queue behind big ones
+    // ORBX_PRIO (experiment knob): 0 = both default, 1 = side stream (blur) high, 2 = main stream (quadtree) high
+    static const int prio = getenv("ORBX_PRIO") ? atoi(getenv("ORBX_PRIO")) : 1;
+    int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    ok(hipStreamCreateWithPriority(&ex->stream2, hipStreamNonBlocking, hi));
+    ok(hipStreamCreateWithPriority(&ex->stream, hipStreamNonBlocking, prio == 2 ? hi : 0));
+    ok(hipStreamCreateWithPriority(&ex->stream2, hipStreamNonBlocking, prio == 1 ? hi : (prio == 2 ? lo : 0)));
   }
+  ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
   ok(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
   ok(hipEventCreateWithFlags(&ex->evBlur, hipEventDisableTiming));
   ok(hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming));
@@ -1086,6 +1088,7 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 // Test hook: the device quadtree's introsort replica, run on the host (compared with std::sort in tests).
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
 void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
+void orbx_debug_set_octree_global(int on) { debug_set_octree_global(on); }
 int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
   if (!v || n < 0 || n > 4000) return fail(ORBX_E_BADARG, "bad argument");
   if (n == 0) return ORBX_OK;

@@ -174,6 +174,7 @@ hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s);    // candidate f
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);
+void debug_set_octree_global(int on);
 hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s);
 
 }  // namespace orbx

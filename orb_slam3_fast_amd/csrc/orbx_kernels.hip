@@ -567,7 +567,7 @@ __device__ int partition_wave(uint64_t* a, int first, int last, uint16_t* Li, ui
   return min(lk, rk);
 }
 
-__device__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp, uint16_t* Li, uint16_t* Ri, int* stk, int lane) {
+__device__ __forceinline__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp, uint16_t* Li, uint16_t* Ri, int* stk, int lane) {
   if (n <= 1) return;
   const KeyLess less;
   int lg = 0;
@@ -644,10 +644,10 @@ hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s) {
 
 struct OctLds {  // byte offsets into dynamic LDS, all 8-byte aligned
   int nx0[2], nx1[2], ny0[2], ny1[2], ncnt[2];
-  int cnt4, cpos, scan, e[2], mark, bestk, tsum, cellpre;
+  int cnt4, cntr, cpos, scan, e[2], mark, bestk, tsum, cellpre;
   int total;
 };
-__host__ __device__ inline OctLds oct_layout(int maxn, int maxcells) {
+__host__ __device__ inline OctLds oct_layout(int maxn, int maxcells, int rep) {
   OctLds o;
   int off = 0;
   auto take = [&](int bytes) {
@@ -663,6 +663,7 @@ __host__ __device__ inline OctLds oct_layout(int maxn, int maxcells) {
     o.ncnt[b] = take(maxn * 4);
   }
   o.cnt4 = take(maxn * 16);
+  o.cntr = take(maxn * 16 * rep);  // quadrant counters, `rep` replicas each (see OctCtx::cntr)
   o.cpos = take(maxn * 8);
   o.scan = take(maxn * 8);  // u64 scan values; reused as best[] at the end
   o.e[0] = take(maxn * 8);
@@ -684,14 +685,21 @@ __host__ __device__ inline int oct_maxcells(const Geom& g) {
   for (int l = 0; l < g.nlevels; l++) c = g.lv[l].nCols * g.lv[l].nRows > c ? g.lv[l].nCols * g.lv[l].nRows : c;
   return c;
 }
-size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g), oct_maxcells(g)).total; }
+// Counter replicas: 4 when two blocks still fit one CU's 160 KB of LDS, fewer for very large per-level quotas.
+__host__ __device__ inline int oct_rep(const Geom& g) {
+  const int maxn = oct_maxn(g), maxcells = oct_maxcells(g);
+  if (oct_layout(maxn, maxcells, 4).total <= 78 * 1024) return 4;
+  if (oct_layout(maxn, maxcells, 2).total <= 78 * 1024) return 2;
+  return 1;
+}
+size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g), oct_maxcells(g), oct_rep(g)).total; }
 
 constexpr int OCT_NT = 512;  // threads per quadtree block: halves the key-loop trip counts vs 256, 2 blocks/CU stay resident
 // Exclusive scan of n u64 values in LDS (in place) by an OCT_NT-thread block; returns the total.
 // Packed fields must not overflow into each other (callers keep each field < 2^21).
 // Per-thread chunk sums are scanned inside each wave with DPP/bpermute shuffles (no barriers); only the four
 // wave totals go through LDS: 2 barriers per call instead of the 18 of a Hillis-Steele scan over 256 threads.
-__device__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
+__device__ __forceinline__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int per = (n + OCT_NT - 1) / OCT_NT;
   const int b = min(tid * per, n), e = min(b + per, n);
@@ -727,102 +735,177 @@ __device__ __forceinline__ int quadrant(int x, int y, int x0, int x1, int y0, in
   return (x < x0 + hx ? 0 : 1) | (y < y0 + hy ? 0 : 2);
 }
 
-__global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
-                                                const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
-                                                uint32_t* __restrict__ cand, int* __restrict__ candCount,
-                                                uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
-                                                int* __restrict__ selCount, int ablate) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  __shared__ int s_i[8];
-#define OCT_EXIT(stage) if (ablate == stage) { if (threadIdx.x == 0) selCount[blockIdx.y * g.nlevels + blockIdx.x] = 0; return; }
-  const int tid = threadIdx.x;
-  const int l = blockIdx.x, img = blockIdx.y;
-  const LevelDev L = g.lv[l];
-  const int maxn = oct_maxn(g);
-  const OctLds o = oct_layout(maxn, oct_maxcells(g));
-  int* cellpre = (int*)(smem + o.cellpre);
-  int16_t* nx0[2] = {(int16_t*)(smem + o.nx0[0]), (int16_t*)(smem + o.nx0[1])};
-  int16_t* nx1[2] = {(int16_t*)(smem + o.nx1[0]), (int16_t*)(smem + o.nx1[1])};
-  int16_t* ny0[2] = {(int16_t*)(smem + o.ny0[0]), (int16_t*)(smem + o.ny0[1])};
-  int16_t* ny1[2] = {(int16_t*)(smem + o.ny1[0]), (int16_t*)(smem + o.ny1[1])};
-  uint32_t* ncnt[2] = {(uint32_t*)(smem + o.ncnt[0]), (uint32_t*)(smem + o.ncnt[1])};
-  uint32_t* cnt4 = (uint32_t*)(smem + o.cnt4);
-  uint16_t* cpos = (uint16_t*)(smem + o.cpos);
-  uint64_t* scan = (uint64_t*)(smem + o.scan);
-  uint64_t* ebuf[2] = {(uint64_t*)(smem + o.e[0]), (uint64_t*)(smem + o.e[1])};
-  uint16_t* mark = (uint16_t*)(smem + o.mark);
-  uint32_t* bestk = (uint32_t*)(smem + o.bestk);
-  uint64_t* tsum = (uint64_t*)(smem + o.tsum);
-
-  // ---- gather: exclusive scan of the level's per-cell counts, then compact the sparse per-cell slots into
-  // the dense candidate list (order is irrelevant: ties are broken by the canonical rank below)
-  uint32_t* keys = cand + (long long)img * g.candImg + L.candOff;
+// Candidates of one (image, level) as seen by the quadtree passes.  REG: every thread keeps its candidates
+// k = tid + j * OCT_NT (key and current node id) in registers for the whole kernel, so the ~12 passes over the
+// candidate set touch only registers and LDS (the passes were latency-bound on L2 round trips: 163 -> see DESIGN).
+// !REG (more than OCT_KMAX * OCT_NT candidates): keys / node ids live in global memory, same thread <-> k mapping.
+constexpr int OCT_KMAX = 32;
+constexpr int OCT_GROUP = 4;  // candidates per thread processed together in a sweep
+template <bool REG>
+struct OctCands {
+  uint32_t rk[REG ? OCT_KMAX : 1];
+  uint32_t rn2[REG ? OCT_KMAX / 2 : 1];  // node ids, two 16-bit ids per register (node | quadrant << 14, or kNoCand)
+  uint32_t* keys;
+  uint16_t* kn;
   int n;
-  {
-    const int cells = L.nCols * L.nRows;
-    const int* cc = cellCount + (long long)img * g.totalCells + L.cellStart;
-    const int per = (cells + OCT_NT - 1) / OCT_NT;
-    const int cb = min(tid * per, cells), ce = min(cb + per, cells);
-    int sum = 0;
-    for (int c = cb; c < ce; c++) sum += cc[c];
-    int incl = sum;
-    {
-      const int lane = tid & 63;
+  static constexpr uint32_t kNoCand = 0xFFFFu;
+  template <class F>
+  __device__ __forceinline__ void sweep(F f) {  // f(k, key, node&)
+    if constexpr (REG) {
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-      }
-      if (lane == 63) tsum[tid >> 6] = (uint64_t)incl;
-    }
-    __syncthreads();
-    int wbase = 0, total = 0;
+      for (int j0 = 0; j0 < OCT_KMAX; j0 += OCT_GROUP) {  // (no early exit: its phi copies double the live arrays)
 #pragma unroll
-    for (int w = 0; w < OCT_NT / 64; w++) {
-      const int t = (int)tsum[w];
-      if (w < (tid >> 6)) wbase += t;
-      total += t;
-    }
-    n = min(total, L.candCap);
-    int run = wbase + incl - sum;
-    for (int c = cb; c < ce; c++) {
-      cellpre[c] = run;
-      run += cc[c];
-    }
-    if (tid == 0) cellpre[cells] = total;
-    __syncthreads();
-    // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
-    const uint32_t* sparse = cellCand + (long long)img * g.cellImg + L.cellOff;
-    for (int k = tid; k < n; k += OCT_NT) {
-      int lo = 0, hi = cells;  // largest c with cellpre[c] <= k
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cellpre[mid] <= k) lo = mid; else hi = mid;
+        for (int j = j0; j < j0 + OCT_GROUP; j++)  // padding entries carry the sentinel node id (a per-j `k < n`
+        {                                          // test would be hoisted out of every pass: 64 live SGPRs)
+          uint32_t key = rk[j], nd = (rn2[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+          asm volatile("" : "+v"(key), "+v"(nd));  // opaque: keeps LICM from hoisting per-key values (key_x, key_y,
+          if (nd != kNoCand) {                     // validity) of all 32 slots out of the passes
+            f(0, key, nd);
+            rn2[j >> 1] = (j & 1) ? (rn2[j >> 1] & 0xFFFFu) | (nd << 16) : (rn2[j >> 1] & 0xFFFF0000u) | nd;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: interleaving all 32 costs > 200 VGPRs
       }
-      keys[k] = sparse[(long long)lo * L.cellCap + (k - cellpre[lo])];
+    } else {
+      for (int k = threadIdx.x; k < n; k += OCT_NT) {
+        uint32_t nd = kn[k];
+        const uint32_t nd0 = nd;
+        f(k, keys[k], nd);
+        if (nd != nd0) kn[k] = (uint16_t)nd;
+      }
     }
-    if (tid == 0) candCount[img * g.nlevels + l] = n;
-    __threadfence_block();
-    __syncthreads();
   }
+  template <class F>
+  __device__ __forceinline__ void fill(F f) {  // key = f(k), node = 0
+    if constexpr (REG) {
+#pragma unroll
+      for (int j = 0; j < OCT_KMAX; j++) {  // all gather loads are issued before the first use (one latency, not 8)
+        const int k = (int)threadIdx.x + j * OCT_NT;
+        rk[j] = 0;
+        if (k < n) rk[j] = f(k);
+      }
+#pragma unroll
+      for (int j = 0; j < OCT_KMAX; j++) {
+        const int k = (int)threadIdx.x + j * OCT_NT;
+        const uint32_t nd = k < n ? 0u : kNoCand;
+        if (k < n) keys[k] = rk[j];  // kept for orbx_debug_candidates
+        rn2[j >> 1] = (j & 1) ? rn2[j >> 1] | (nd << 16) : nd;
+      }
+    } else {
+      for (int k = threadIdx.x; k < n; k += OCT_NT) {
+        keys[k] = f(k);
+        kn[k] = 0;
+      }
+    }
+  }
+};
+
+struct OctCtx {  // node tables are double buffered: buffer b of table T sits at T + b * nodeStride bytes
+  int16_t *nx0, *nx1, *ny0, *ny1;
+  uint32_t* ncnt;
+  int nodeStride;
+  uint32_t* cnt4;
+  int nrep;        // counter replicas (1, 2 or 4)
+  uint32_t* cntr;  // [node * 4 + q][nrep]: a lane adds to replica (lane % nrep) -- a wave's candidates fall into 1-4 nodes,
+                   // so unreplicated ds_add_u32 serialise 64 deep on one address; the replicas sit in different banks
+  uint16_t* cpos;
+  uint64_t* scan;
+  uint64_t* ebuf;  // two buffers of maxn entries
+  uint16_t* mark;
+  uint32_t* nmid;  // per node of the current list: split point x | y << 12, bit 31 = "this pass splits the node"
+  uint64_t* tsum;
+  int* cellpre;
+  int* s_i;
+  int maxn;
+};
+
+template <bool REG>
+__device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, const OctCtx& c, int n, int cells,
+                                            const uint32_t* __restrict__ sparse, uint32_t* __restrict__ keys,
+                                            uint16_t* __restrict__ kn, uint32_t* __restrict__ out,
+                                            int* __restrict__ outCount, int ablate) {
+#define OCT_EXIT(stage) if (ablate == stage) { if (threadIdx.x == 0) *outCount = 0; return; }
+  const int tid = threadIdx.x;
+#ifdef OCT_PROF  // section timing of one block (tools/octree_prof.py; build with -DOCT_PROF, select the level with
+                 // ORBX_OCTREE_ABLATE=100+level): thread 0 prints the 10 ns ticks between the MK() markers
+  long long tmk[96]; int nmk = 0;
+#define MK() do { if (nmk < 96) tmk[nmk++] = wall_clock64(); } while (0)
+#else
+#define MK() do {} while (0)
+#endif
+  MK();
+  OctCands<REG> cd;
+  cd.keys = keys;
+  cd.kn = kn;
+  cd.n = n;
+  // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
+  cd.fill([&](int k) {
+    int lo = 0, hi = cells;  // largest cell with cellpre[cell] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (c.cellpre[mid] <= k) lo = mid; else hi = mid;
+    }
+    return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
+  });
+  MK();
   OCT_EXIT(1)
   const int N = L.quota;
-  uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
-  int* outCount = selCount + img * g.nlevels + l;
-  uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
+  struct Buf {  // nx0[b][i] etc. as before, by address arithmetic (no pointer arrays -> no scratch)
+    char* base;
+    int stride;
+    __device__ __forceinline__ int16_t* operator[](int b) const { return reinterpret_cast<int16_t*>(base + b * stride); }
+  };
+  struct BufU {
+    char* base;
+    int stride;
+    __device__ __forceinline__ uint32_t* operator[](int b) const { return reinterpret_cast<uint32_t*>(base + b * stride); }
+  };
+  const Buf nx0{(char*)c.nx0, c.nodeStride}, nx1{(char*)c.nx1, c.nodeStride}, ny0{(char*)c.ny0, c.nodeStride},
+      ny1{(char*)c.ny1, c.nodeStride};
+  const BufU ncnt{(char*)c.ncnt, c.nodeStride};
+  uint32_t* cnt4 = c.cnt4;
+  uint32_t* cntr = c.cntr;
+  const int nrep = c.nrep, rep = tid & (nrep - 1);
+  auto zero_counters = [&](int nslots) {  // the caller syncs
+    for (int i = tid; i < nslots * nrep; i += OCT_NT) cntr[i] = 0;
+  };
+  auto reduce_counters = [&](int nslots) {  // cnt4[i] = sum of the replicas; the caller syncs before and after
+    for (int i = tid; i < nslots; i += OCT_NT) {
+      uint32_t v = 0;
+      for (int r = 0; r < nrep; r++) v += cntr[i * nrep + r];
+      cnt4[i] = v;
+    }
+  };
+  uint16_t* cpos = c.cpos;
+  uint64_t* scan = c.scan;
+  uint16_t* mark = c.mark;
+  uint32_t* nmid = c.nmid;
+  uint64_t* tsum = c.tsum;
+  // split point of node i of buffer b (DivideNode :494-495: halfX = ceil(width / 2)) + the phase-1 split flag
+  auto pack_mid = [&](int b, int i) {
+    const int x0 = nx0[b][i], x1 = nx1[b][i], y0 = ny0[b][i], y1 = ny1[b][i];
+    return (uint32_t)(x0 + ((x1 - x0 + 1) >> 1)) | ((uint32_t)(y0 + ((y1 - y0 + 1) >> 1)) << 12) |
+           (ncnt[b][i] > 1 ? 0x80000000u : 0u);
+  };
+  auto classify = [&](uint32_t key, uint32_t mid) {  // quadrant(), from the packed split point
+    return (key_x(key) >= (int)(mid & 0xFFF) ? 1 : 0) | (key_y(key) >= (int)((mid >> 12) & 0xFFF) ? 2 : 0);
+  };
+  int* s_i = c.s_i;
 
   const int W = L.w - 2 * kBorder, H = L.h - 2 * kBorder;
   const int nIni = (int)roundf((float)W / (float)H);  // :566
   const float hX = (float)W / (float)nIni;             // :568
 
   // ---- roots (:575-601)
-  if (tid < kMaxIni) cnt4[tid] = 0;
+  zero_counters(kMaxIni);
   __syncthreads();
-  for (int k = tid; k < n; k += OCT_NT) {
-    const int r = (int)((float)key_x(keys[k]) / hX);
-    kn[k] = (uint16_t)r;
-    atomicAdd(&cnt4[r], 1u);
-  }
+  cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+    const int r = (int)((float)key_x(key) / hX);
+    nd = (uint32_t)r;
+    atomicAdd(&cntr[r * nrep + rep], 1u);
+  });
+  __syncthreads();
+  reduce_counters(kMaxIni);
   __syncthreads();
   if (tid == 0) {
     int na = 0;
@@ -840,44 +923,50 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
       na++;
     }
     s_i[0] = na;
+    for (int i = 0; i < na; i++) nmid[i] = pack_mid(0, i);
   }
   __syncthreads();
-  for (int k = tid; k < n; k += OCT_NT) kn[k] = cpos[kn[k]];
+  cd.sweep([&](int, uint32_t, uint32_t& nd) { nd = cpos[nd]; });
   int nA = s_i[0];
   int cur = 0;
   __syncthreads();
 
+  MK();
   OCT_EXIT(2)
   bool finish = false;
   int nE = 0, ecur = 0;
   // ---- phase 1: split every expandable node per pass (:610-677)
   while (!finish) {
     const int prevSize = nA;
-    for (int i = tid; i < nA * 4; i += OCT_NT) cnt4[i] = 0;
+    zero_counters(nA * 4);
     __syncthreads();
-    for (int k = tid; k < n; k += OCT_NT) {
-      const int nd = kn[k];
-      if (ncnt[cur][nd] > 1) {
-        const uint32_t key = keys[k];
-        const int q = quadrant(key_x(key), key_y(key), nx0[cur][nd], nx1[cur][nd], ny0[cur][nd], ny1[cur][nd]);
-        atomicAdd(&cnt4[nd * 4 + q], 1u);
-        kn[k] = (uint16_t)(nd | (q << 14));
+    MK();
+    cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+      const uint32_t mid = nmid[nd];
+      if (mid >> 31) {
+        const int q = classify(key, mid);
+        atomicAdd(&cntr[(nd * 4 + q) * nrep + rep], 1u);
+        nd |= (uint32_t)q << 14;
       }
-    }
+    });
     __syncthreads();
+    reduce_counters(nA * 4);
+    __syncthreads();
+    MK();
     for (int i = tid; i < nA; i += OCT_NT) {
-      uint64_t c = 0, nm = 1, ce = 0;
+      uint64_t cc = 0, nm = 1, ce = 0;
       if (ncnt[cur][i] > 1) {
         nm = 0;
         for (int q = 0; q < 4; q++) {
-          c += cnt4[i * 4 + q] > 0;
+          cc += cnt4[i * 4 + q] > 0;
           ce += cnt4[i * 4 + q] > 1;
         }
       }
-      scan[i] = c | (nm << 21) | (ce << 42);
+      scan[i] = cc | (nm << 21) | (ce << 42);
     }
     __syncthreads();
     const uint64_t tot = block_scan_u64(scan, nA, tsum);
+    MK();
     const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
     const int nxt = cur ^ 1;
     for (int i = tid; i < nA; i += OCT_NT) {
@@ -886,9 +975,9 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
       if (ncnt[cur][i] > 1) {
         const int x0 = nx0[cur][i], x1 = nx1[cur][i], y0 = ny0[cur][i], y1 = ny1[cur][i];
         const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
-        int c = 0;
-        for (int q = 0; q < 4; q++) c += cnt4[i * 4 + q] > 0;
-        const int base = tc - (pc + c);
+        int cc = 0;
+        for (int q = 0; q < 4; q++) cc += cnt4[i * 4 + q] > 0;
+        const int base = tc - (pc + cc);
         int after = 0, eb = pce;
         for (int q = 0; q < 4; q++) {  // E entries in creation order n1..n4
           const uint32_t cq = cnt4[i * 4 + q];
@@ -896,7 +985,7 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
             int rank_after = 0;
             for (int q2 = q + 1; q2 < 4; q2++) rank_after += cnt4[i * 4 + q2] > 0;
             const int cx0 = (q & 1) ? x0 + hx : x0;
-            ebuf[ecur][eb++] = ((uint64_t)cq << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+            (c.ebuf + ecur * c.maxn)[eb++] = ((uint64_t)cq << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
           }
         }
         for (int q = 3; q >= 0; q--) {  // list order n4,n3,n2,n1
@@ -921,11 +1010,12 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
       }
     }
     __syncthreads();
-    for (int k = tid; k < n; k += OCT_NT) {
-      const int v = kn[k], nd = v & 0x3FFF;
-      kn[k] = ncnt[cur][nd] > 1 ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
-    }
+    MK();
+    // (a node that is not split never had its quadrant tagged: tag 0 -> cpos[nd * 4])
+    cd.sweep([&](int, uint32_t, uint32_t& v) { v = cpos[(v & 0x3FFF) * 4 + (v >> 14)]; });
+    for (int i = tid; i < tc + tnm; i += OCT_NT) nmid[i] = pack_mid(nxt, i);
     __syncthreads();
+    MK();
     cur = nxt;
     nA = tc + tnm;
     nE = tce;
@@ -936,52 +1026,62 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
     }
   }
 
+  MK();
   OCT_EXIT(3)
   // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
   while (!finish) {
     const int prevSize = nA;
-    uint64_t* E = ebuf[ecur];
-    uint64_t* E2 = ebuf[ecur ^ 1];
+    uint64_t* E = c.ebuf + ecur * c.maxn;
+    uint64_t* E2 = c.ebuf + (ecur ^ 1) * c.maxn;
     if (tid < 64 && ablate != 5)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
-      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + maxn + 4,
+      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
                      reinterpret_cast<int*>(tsum), tid);
+    MK();
     if (tid == 0) {
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
     }
-    for (int i = tid; i < nA * 4; i += OCT_NT) cnt4[i] = 0;
-    for (int i = tid; i < nA; i += OCT_NT) mark[i] = 0;
-    __syncthreads();
-    for (int m = tid; m < nE; m += OCT_NT) mark[(int)(E[nE - 1 - m] & 0xFFFF)] = (uint16_t)(m + 1);
-    __syncthreads();
-    for (int k = tid; k < n; k += OCT_NT) {
-      const int nd = kn[k];
-      if (mark[nd]) {
-        const uint32_t key = keys[k];
-        const int q = quadrant(key_x(key), key_y(key), nx0[cur][nd], nx1[cur][nd], ny0[cur][nd], ny1[cur][nd]);
-        atomicAdd(&cnt4[nd * 4 + q], 1u);
-        kn[k] = (uint16_t)(nd | (q << 14));
-      }
+    zero_counters(nA * 4);
+    for (int i = tid; i < nA; i += OCT_NT) {
+      mark[i] = 0;
+      nmid[i] &= 0x7FFFFFFFu;  // this pass splits exactly the nodes of the E list
     }
+    __syncthreads();
+    for (int m = tid; m < nE; m += OCT_NT) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      mark[nd] = (uint16_t)(m + 1);
+      nmid[nd] |= 0x80000000u;
+    }
+    __syncthreads();
+    cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+      const uint32_t mid = nmid[nd];
+      if (mid >> 31) {
+        const int q = classify(key, mid);
+        atomicAdd(&cntr[(nd * 4 + q) * nrep + rep], 1u);
+        nd |= (uint32_t)q << 14;
+      }
+    });
+    __syncthreads();
+    reduce_counters(nA * 4);
     __syncthreads();
     // scan over the processing order m: c (children), ce (expandable children)
     for (int m = tid; m < nE; m += OCT_NT) {
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
-      uint64_t c = 0, ce = 0;
+      uint64_t cc = 0, ce = 0;
       for (int q = 0; q < 4; q++) {
-        c += cnt4[nd * 4 + q] > 0;
+        cc += cnt4[nd * 4 + q] > 0;
         ce += cnt4[nd * 4 + q] > 1;
       }
-      scan[m] = c | (ce << 21);
+      scan[m] = cc | (ce << 21);
     }
     __syncthreads();
     block_scan_u64(scan, nE, tsum);
     // first m at which the list reaches N nodes: size after m+1 expansions = nA + C_incl(m) - (m+1)
     for (int m = tid; m < nE; m += OCT_NT) {
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
-      int c = 0;
-      for (int q = 0; q < 4; q++) c += cnt4[nd * 4 + q] > 0;
-      const int cincl = (int)(scan[m] & 0x1FFFFF) + c;
+      int cc = 0;
+      for (int q = 0; q < 4; q++) cc += cnt4[nd * 4 + q] > 0;
+      const int cincl = (int)(scan[m] & 0x1FFFFF) + cc;
       if (nA + cincl - (m + 1) >= N) {
         atomicMin(&s_i[1], m + 1);
         s_i[2] = 1;
@@ -996,12 +1096,12 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
       tce = (int)(scan[nP] >> 21);
     } else {
       const int nd = (int)(E[0] & 0xFFFF);  // m = nE-1
-      int c = 0, ce = 0;
+      int cc = 0, ce = 0;
       for (int q = 0; q < 4; q++) {
-        c += cnt4[nd * 4 + q] > 0;
+        cc += cnt4[nd * 4 + q] > 0;
         ce += cnt4[nd * 4 + q] > 1;
       }
-      tc = nE ? (int)(scan[nE - 1] & 0x1FFFFF) + c : 0;
+      tc = nE ? (int)(scan[nE - 1] & 0x1FFFFF) + cc : 0;
       tce = nE ? (int)(scan[nE - 1] >> 21) + ce : 0;
     }
     const int nxt = cur ^ 1;
@@ -1010,11 +1110,11 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
       const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
       const int x0 = nx0[cur][nd], x1 = nx1[cur][nd], y0 = ny0[cur][nd], y1 = ny1[cur][nd];
       const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
-      int c = 0;
-      for (int q = 0; q < 4; q++) c += cnt4[nd * 4 + q] > 0;
+      int cc = 0;
+      for (int q = 0; q < 4; q++) cc += cnt4[nd * 4 + q] > 0;
       const int pc = (int)(scan[m] & 0x1FFFFF);
       int eb = (int)(scan[m] >> 21);
-      const int base = tc - (pc + c);
+      const int base = tc - (pc + cc);
       for (int q = 0; q < 4; q++) {
         const uint32_t cq = cnt4[nd * 4 + q];
         if (cq > 1) {
@@ -1050,52 +1150,161 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(Geom g, const uint32_t* __res
         ny0[nxt][pos] = ny0[cur][i];
         ny1[nxt][pos] = ny1[cur][i];
         ncnt[nxt][pos] = ncnt[cur][i];
-        cpos[i * 4] = (uint16_t)pos;
+        // counted (tagged) but not expanded nodes map every quadrant tag back to the node itself
+        cpos[i * 4] = cpos[i * 4 + 1] = cpos[i * 4 + 2] = cpos[i * 4 + 3] = (uint16_t)pos;
       }
     }
     __syncthreads();
-    for (int k = tid; k < n; k += OCT_NT) {
-      const int v = kn[k], nd = v & 0x3FFF;
-      const int mk = mark[nd];
-      kn[k] = (mk != 0 && mk <= nP) ? cpos[nd * 4 + (v >> 14)] : cpos[nd * 4];
-    }
+    cd.sweep([&](int, uint32_t, uint32_t& v) { v = cpos[(v & 0x3FFF) * 4 + (v >> 14)]; });
+    for (int i = tid; i < tc + nKeep; i += OCT_NT) nmid[i] = pack_mid(nxt, i);
     __syncthreads();
     cur = nxt;
     nA = tc + nKeep;
     nE = tce;
     ecur ^= 1;
+    MK();
     if (broke || nA == prevSize) finish = true;
   }
 
+  MK();
   OCT_EXIT(4)
-  // ---- best response per node, first candidate (reference order) wins ties (:741-754)
+  // ---- best response per node, first candidate (reference order) wins ties (:741-754): the canonical rank
+  // (cell row, cell column, y, x) is unique per candidate, so exactly one candidate equals its node's maximum
+  // and writes the node's output slot itself.
+  // (replicated like the counters: all candidates of a node hammer one 64-bit LDS word otherwise)
   uint64_t* best = scan;
-  for (int i = tid; i < nA; i += OCT_NT) best[i] = 0;
+  uint64_t* bestr = reinterpret_cast<uint64_t*>(cntr);  // [node][nrepB]; cntr holds maxn * 4 * nrep words
+  const int nrepB = nrep >= 2 ? nrep * 2 : 1, repB = tid & (nrepB - 1);
+  if (nrepB > 1)
+    for (int i = tid; i < nA * nrepB; i += OCT_NT) bestr[i] = 0;
+  else
+    for (int i = tid; i < nA; i += OCT_NT) best[i] = 0;
   __syncthreads();
-  for (int k = tid; k < n; k += OCT_NT) {
-    const uint32_t key = keys[k];
+  const float invH = 1.0f / (float)L.hCell, invW = 1.0f / (float)L.wCell;
+  auto rank_key = [&](uint32_t key) {
     const int xr = key_x(key) - 3, yr = key_y(key) - 3;  // relative to the first detectable pixel (19,19)
-    const int cy = yr / L.hCell, cx = xr / L.wCell;
+    // floor(v / cell) for 0 <= v < 4096: (v + 0.5) / cell is >= 0.5 / cell away from every integer, far above float error
+    const int cy = (int)(((float)yr + 0.5f) * invH), cx = (int)(((float)xr + 0.5f) * invW);
     const uint32_t rank = (uint32_t)(((cy * L.nCols + cx) * L.hCell + (yr - cy * L.hCell)) * L.wCell + (xr - cx * L.wCell));
-    atomicMax((unsigned long long*)&best[kn[k]], ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank));
-  }
-  __syncthreads();
-  for (int k = tid; k < n; k += OCT_NT) {
-    const uint32_t key = keys[k];
-    const int xr = key_x(key) - 3, yr = key_y(key) - 3;
-    const int cy = yr / L.hCell, cx = xr / L.wCell;
-    const uint32_t rank = (uint32_t)(((cy * L.nCols + cx) * L.hCell + (yr - cy * L.hCell)) * L.wCell + (xr - cx * L.wCell));
-    const int nd = kn[k];
-    if (best[nd] == (((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank))) bestk[nd] = (uint32_t)k;
+    return ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank);
+  };
+  if (nrepB > 1) {
+    cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+      atomicMax((unsigned long long*)&bestr[nd * nrepB + repB], rank_key(key));
+    });
+    __syncthreads();
+    for (int i = tid; i < nA; i += OCT_NT) {
+      uint64_t v = 0;
+      for (int r = 0; r < nrepB; r++) v = bestr[i * nrepB + r] > v ? bestr[i * nrepB + r] : v;
+      best[i] = v;
+    }
+  } else {
+    cd.sweep([&](int, uint32_t key, uint32_t& nd) { atomicMax((unsigned long long*)&best[nd], rank_key(key)); });
   }
   __syncthreads();
   const int nOut = min(nA, L.selCap);
-  for (int i = tid; i < nOut; i += OCT_NT) {
-    const uint32_t key = keys[bestk[i]];
-    out[i] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
-  }
+  cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+    if ((int)nd < nOut && best[nd] == rank_key(key)) out[nd] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
+  });
   if (tid == 0) *outCount = nOut;
+  MK();
+#ifdef OCT_PROF
+  if (tid == 0 && blockIdx.y == 0 && (int)blockIdx.x == ablate - 100) {
+    printf("L%d n=%d nA=%d :", (int)blockIdx.x, n, nA);
+    for (int i = 1; i < nmk; i++) printf(" %d", (int)(tmk[i] - tmk[i - 1]));
+    printf("\n");
+  }
+#endif
+#undef MK
+#undef OCT_EXIT
 }
+
+__global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
+                                                const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
+                                                uint32_t* __restrict__ cand, int* __restrict__ candCount,
+                                                uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
+                                                int* __restrict__ selCount, int ablate, int forceGlobal) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_i[8];
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x, img = blockIdx.y;
+  const LevelDev L = g.lv[l];
+  const int maxn = oct_maxn(g);
+  const int nrep = oct_rep(g);
+  const OctLds o = oct_layout(maxn, oct_maxcells(g), nrep);
+  OctCtx c;
+  c.nx0 = (int16_t*)(smem + o.nx0[0]);
+  c.nx1 = (int16_t*)(smem + o.nx1[0]);
+  c.ny0 = (int16_t*)(smem + o.ny0[0]);
+  c.ny1 = (int16_t*)(smem + o.ny1[0]);
+  c.ncnt = (uint32_t*)(smem + o.ncnt[0]);
+  c.nodeStride = o.nx0[1] - o.nx0[0];  // the five tables of one buffer are laid out back to back
+  c.ebuf = (uint64_t*)(smem + o.e[0]);  // e[1] follows e[0] (maxn entries each)
+  c.cnt4 = (uint32_t*)(smem + o.cnt4);
+  c.cntr = (uint32_t*)(smem + o.cntr);
+  c.nrep = nrep;
+  c.cpos = (uint16_t*)(smem + o.cpos);
+  c.scan = (uint64_t*)(smem + o.scan);
+  c.mark = (uint16_t*)(smem + o.mark);
+  c.nmid = (uint32_t*)(smem + o.bestk);
+  c.tsum = (uint64_t*)(smem + o.tsum);
+  c.cellpre = (int*)(smem + o.cellpre);
+  c.s_i = s_i;
+  c.maxn = maxn;
+
+  // ---- exclusive scan of the level's per-cell counts (the sparse per-cell slots are compacted by octree_body;
+  // candidate order is irrelevant: ties are broken by the canonical rank)
+  const int cells = L.nCols * L.nRows;
+  int n;
+  {
+    const int* cc = cellCount + (long long)img * g.totalCells + L.cellStart;
+    const int per = (cells + OCT_NT - 1) / OCT_NT;
+    const int cb = min(tid * per, cells), ce = min(cb + per, cells);
+    int sum = 0;
+    for (int ci = cb; ci < ce; ci++) sum += cc[ci];
+    int incl = sum;
+    {
+      const int lane = tid & 63;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+      }
+      if (lane == 63) c.tsum[tid >> 6] = (uint64_t)incl;
+    }
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < OCT_NT / 64; w++) {
+      const int t = (int)c.tsum[w];
+      if (w < (tid >> 6)) wbase += t;
+      total += t;
+    }
+    n = min(total, L.candCap);
+    int run = wbase + incl - sum;
+    for (int ci = cb; ci < ce; ci++) {
+      c.cellpre[ci] = run;
+      run += cc[ci];
+    }
+    if (tid == 0) {
+      c.cellpre[cells] = total;
+      candCount[img * g.nlevels + l] = n;
+    }
+    __syncthreads();
+  }
+  const uint32_t* sparse = cellCand + (long long)img * g.cellImg + L.cellOff;
+  uint32_t* keys = cand + (long long)img * g.candImg + L.candOff;
+  uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
+  uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
+  int* outCount = selCount + img * g.nlevels + l;
+  if (n <= OCT_KMAX * OCT_NT && !forceGlobal)
+    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, ablate);
+  else
+    octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, ablate);
+}
+
+static int g_octree_force_global_host = 0;
+void debug_set_octree_global(int on) { g_octree_force_global_host = on ? 1 : 0; }
 
 hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
                          uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
@@ -1103,7 +1312,7 @@ hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, cons
   dim3 grid(g.nlevels, nimg);
   static const int ablate = getenv("ORBX_OCTREE_ABLATE") ? atoi(getenv("ORBX_OCTREE_ABLATE")) : 0;
   hipLaunchKernelGGL(k_octree, grid, dim3(OCT_NT), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
-                     candCount, knode, sel, selCount, ablate);
+                     candCount, knode, sel, selCount, ablate, g_octree_force_global_host);
   return hipGetLastError();
 }
 

@@ -91,6 +91,30 @@ def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
         orbx.lib().orbx_debug_set_detect_list_cap(1024)
 
 
+def test_octree_global_candidate_path(gpu, oracle):
+    """k_octree keeps up to 16384 candidates per (image, level) in registers; beyond that (dense noise at 1280x720)
+    and under the test hook it walks them in global memory.  Both must reproduce the oracle."""
+    rng = np.random.default_rng(19)
+    w, h = 1280, 720
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
+    mono, k, d = ex(noise)
+    assert ex.level_stats()[2][0] > 16384  # level-0 candidates: the global path was taken naturally
+    omono, ok_, od = oe.extract(noise)
+    assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+    img = synth.mono_frame(w, h, 78)
+    omono, ok_, od = oe.extract(img)
+    try:
+        for forced in (1, 0):
+            orbx.lib().orbx_debug_set_octree_global(forced)
+            mono, k, d = ex(img)
+            assert ex.level_stats()[2][0] <= 16384
+            assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+    finally:
+        orbx.lib().orbx_debug_set_octree_global(0)
+
+
 def test_device_introsort_matches_libstdcxx(gpu, oracle):
     """The quadtree's wave-cooperative sort must reproduce std::sort's permutation, ties included."""
     import ctypes as C
