@@ -34,6 +34,11 @@ __device__ __forceinline__ int prefix_count(uint64_t m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {  // a.lo*b.lo + a.hi*b.hi + c
+  return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_us2, a), __builtin_bit_cast(orbx_us2, b), c, false);
+}
+
 // ================================================================================================ resize
 // cv::resize INTER_LINEAR 8U, level l from level l-1.  Coefficient tables (sx, a0/a1 ; sy, b0/b1)
 // are built on the host exactly as OpenCV builds them and uploaded once per image size.
@@ -56,7 +61,9 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   const uint8_t* src = level_ptr(g, p, img, l - 1, sp);
   uint32_t* st = reinterpret_cast<uint32_t*>(smem);                            // [srcRowsMax][srcDwMax] dwords
   uint16_t* ht = reinterpret_cast<uint16_t*>(st + srcRowsMax * srcDwMax);      // [srcRowsMax][RS_DW] u16
-  const uint8_t* st8 = reinterpret_cast<const uint8_t*>(st);
+#ifdef RS_PROF
+  long long tq0 = wall_clock64();
+#endif
   const int rb = min(max(yofs[D.ycoef + y0], 0), S.h - 1);                      // first source row needed
   const int re = min(max(yofs[D.ycoef + y1] + 1, 0), S.h - 1);                  // last source row needed
   const int nrows = re - rb + 1;
@@ -64,68 +71,111 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   const int ce = min(xofs[D.xcoef + x1] + 1, S.w - 1);
   const int ndw = ((ce - cb) >> 2) + 1;
   {
+    // Footprint -> LDS.  All of a thread's global loads are issued before the first LDS store: with a plain loop
+    // every trip waited for its own load (7 serialized HBM latencies per block, the bulk of the kernel's time).
     const float inv = 1.0f / (float)ndw;
     const int n = nrows * ndw;
-    for (int i = tid; i < n; i += 256) {
-      const int r = (int)(((float)i + 0.5f) * inv), c = i - r * ndw;
-      const int gx = cb + 4 * c;
-      const uint8_t* q = src + (long long)(rb + r) * sp + gx;
-      uint32_t v;
-      if (gx + 4 <= S.w) {
-        v = *reinterpret_cast<const uint32_t*>(q);
-      } else {
-        v = 0;
-        for (int k = 0; k < 4; k++)
-          if (gx + k < S.w) v |= (uint32_t)q[k] << (8 * k);
+    constexpr int kTrips = 8;  // one batch covers the footprint at scale 1.2 (21 x 78 dwords); larger scales loop
+    for (int base = 0; base < n; base += 256 * kTrips) {
+    uint32_t v[kTrips];
+    int slot[kTrips];
+#pragma unroll
+    for (int k = 0; k < kTrips; k++) {
+      const int i = base + tid + 256 * k;
+      slot[k] = -1;
+      v[k] = 0;
+      if (i < n) {
+        const int r = (int)(((float)i + 0.5f) * inv), c = i - r * ndw;
+        const int gx = cb + 4 * c;
+        const uint8_t* q = src + (long long)(rb + r) * sp + gx;
+        slot[k] = r * srcDwMax + c;
+        if (gx + 4 <= S.w) {
+          v[k] = *reinterpret_cast<const uint32_t*>(q);
+        } else {
+          for (int b = 0; b < 4; b++)
+            if (gx + b < S.w) v[k] |= (uint32_t)q[b] << (8 * b);
+        }
       }
-      st[r * srcDwMax + c] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < kTrips; k++)
+      if (slot[k] >= 0) st[slot[k]] = v[k];
     }
   }
+#ifdef RS_PROF
+  long long tq1 = wall_clock64();
+#endif
   __syncthreads();
-  {  // horizontal pass: thread = dst column
-    const int dx = min(x0 + tid, D.w - 1);
-    const int sx = xofs[D.xcoef + dx];
-    const int a0 = xab[2 * (D.xcoef + dx)], a1 = xab[2 * (D.xcoef + dx) + 1];
-    const int o0 = sx - cb, o1 = min(sx + 1, S.w - 1) - cb;
-    const int pitchB = srcDwMax * 4;
-    int r = 0;
-    for (; r + 4 <= nrows; r += 4) {  // 4 rows per trip: 8 independent LDS reads in flight
-      int v0[4], v1[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        v0[k] = st8[(r + k) * pitchB + o0];
-        v1[k] = st8[(r + k) * pitchB + o1];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) ht[(r + k) * RS_DW + tid] = (uint16_t)((v0[k] * a0 + v1[k] * a1) >> 4);
-    }
-    for (; r < nrows; r++) {
-      const int t = st8[r * pitchB + o0] * a0 + st8[r * pitchB + o1] * a1;
-      ht[r * RS_DW + tid] = (uint16_t)(t >> 4);
-    }
-  }
-  __syncthreads();
-  // vertical pass: 64 quads x RS_DR rows = 512 items, 2 per thread
-  for (int i = tid; i < 64 * RS_DR; i += 256) {
-    const int dyl = i >> 6, qx = i & 63;
-    const int dy = y0 + dyl, dx = x0 + 4 * qx;
-    if (dy >= D.h || dx >= D.w) continue;
-    const int sy = yofs[D.ycoef + dy];
-    const int b0 = yab[2 * (D.ycoef + dy)], b1 = yab[2 * (D.ycoef + dy) + 1];
-    const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
-    const uint2 t0 = *reinterpret_cast<const uint2*>(ht + r0 * RS_DW + 4 * qx);
-    const uint2 t1 = *reinterpret_cast<const uint2*>(ht + r1 * RS_DW + 4 * qx);
-    const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
-    const int u1[4] = {(int)(t1.x & 0xFFFF), (int)(t1.x >> 16), (int)(t1.y & 0xFFFF), (int)(t1.y >> 16)};
-    uint32_t outw = 0;
+#ifdef RS_PROF
+  long long tq2 = wall_clock64();
+#endif
+  {  // horizontal pass: lane = quad of 4 dst columns, wave = source-row phase (rows w, w + 4, ...).  Per output one
+     // ds_read2_b32 (the aligned dword pair holding S[sx], S[sx+1]), one v_perm with a per-lane selector that spreads
+     // the two bytes into u16 halves, one v_dot2_u32_u16 against (a0, a1), one shift; four results leave as one b64.
+    const int qc = tid & 63, w = tid >> 6;
+    uint32_t sel[4], coef[4];
+    int dwi[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
-      outw |= (uint32_t)(v & 255) << (8 * j);
+      const int dx = min(x0 + 4 * qc + j, D.w - 1);
+      const int o = xofs[D.xcoef + dx] - cb;  // S[sx + 1] is only weighted by a1 != 0 when it exists (build_coefs)
+      const int sh = o & 3;
+      dwi[j] = o >> 2;
+      sel[j] = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16);
+      coef[j] = reinterpret_cast<const uint32_t*>(xab)[D.xcoef + dx];  // a0 | a1 << 16
     }
-    uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
-    *reinterpret_cast<uint32_t*>(dst + dx) = outw;
+    for (int r = w; r < nrows; r += 4) {
+      const uint32_t* row = st + r * srcDwMax;
+      uint32_t t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t lo = row[dwi[j]], hi = row[dwi[j] + 1];
+        t[j] = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), coef[j], 0u) >> 4;
+      }
+      uint2 pk;
+      pk.x = t[0] | (t[1] << 16);
+      pk.y = t[2] | (t[3] << 16);
+      *reinterpret_cast<uint2*>(ht + r * RS_DW + 4 * qc) = pk;
+    }
   }
+#ifdef RS_PROF
+  long long tq3 = wall_clock64();
+#endif
+  __syncthreads();
+#ifdef RS_PROF
+  long long tq4 = wall_clock64();
+#endif
+  // vertical pass: lane = quad, wave w owns dst rows w, w + 4, ... of the block: the row constants are wave-uniform
+  {
+    const int qx = tid & 63;
+    const int dx = x0 + 4 * qx;
+    for (int dyl = __builtin_amdgcn_readfirstlane(tid >> 6); dyl < RS_DR; dyl += 4) {
+      const int dy = y0 + dyl;
+      if (dy >= D.h) break;
+      const int sy = yofs[D.ycoef + dy];
+      const uint32_t bb = reinterpret_cast<const uint32_t*>(yab)[D.ycoef + dy];
+      const int b0 = (int)(bb & 0xFFFF), b1 = (int)(bb >> 16);
+      const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
+      if (dx >= D.w) continue;
+      const uint2 t0 = *reinterpret_cast<const uint2*>(ht + r0 * RS_DW + 4 * qx);
+      const uint2 t1 = *reinterpret_cast<const uint2*>(ht + r1 * RS_DW + 4 * qx);
+      const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
+      const int u1[4] = {(int)(t1.x & 0xFFFF), (int)(t1.x >> 16), (int)(t1.y & 0xFFFF), (int)(t1.y >> 16)};
+      uint32_t outw = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
+        outw |= (uint32_t)(v & 255) << (8 * j);
+      }
+      uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
+      *reinterpret_cast<uint32_t*>(dst + dx) = outw;
+    }
+  }
+#ifdef RS_PROF
+  if (tid == 0 && blockIdx.z == 7 && blockIdx.x == 1 && (blockIdx.y % 9) == 3)
+    printf("L%d by %d: load %d wait %d horiz %d wait %d vert %d (x10ns)\n", l, (int)blockIdx.y, (int)(tq1 - tq0), (int)(tq2 - tq1),
+           (int)(tq3 - tq2), (int)(tq4 - tq3), (int)(wall_clock64() - tq4));
+#endif
 }
 
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
@@ -213,10 +263,12 @@ __device__ __forceinline__ int fast_contrast_lds(const uint8_t* c8, int TP) {
   return max(maxmin - c, c - minmax);
 }
 
-// Two pixels per lane: the same contrast computation in packed half precision.  A pixel value v (0..255) is
-// represented as the f16 bit pattern 0x6400 | v == 1024 + v, which is exact and order preserving; differences of two
-// such values (|d| <= 255) are exact too, so v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_add_f16 give bit-exact
-// integer results for two pixels at the cost of one.  Returns M for pixel A in .x and pixel B in .y.
+// Two pixels per lane: the same contrast computation in packed half precision.  A pixel value v (0..255) is used
+// as the f16 BIT PATTERN v, i.e. the subnormal v * 2^-24 (kernels run with f16 denormals preserved,
+// .amdhsa_float_denorm_mode_16_64 3): order preserving, and sums / differences of such values (|d| <= 255) are exact
+// multiples of 2^-24, so v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_add_f16 give bit-exact integer results for two
+// pixels at the cost of one, and the two bytes are packed by a single v_perm (no bias to OR in).  Returns M for
+// pixel A in .x and pixel B in .y, each as the bit pattern of |M| with the f16 sign bit for M < 0.
 typedef _Float16 orbx_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ orbx_h2 pk_min3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
   return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c);
@@ -229,7 +281,7 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int off = kRingDY[k] * TP + kRingDX[k];
-    r[k] = __builtin_bit_cast(orbx_h2, (uint32_t)a8[off] | ((uint32_t)b8[off] << 16) | 0x64006400u);
+    r[k] = __builtin_bit_cast(orbx_h2, (uint32_t)a8[off] | ((uint32_t)b8[off] << 16));  // one v_perm
   }
   orbx_h2 lo3[16], hi3[16];
 #pragma unroll
@@ -251,7 +303,7 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
   }
   maxmin = __builtin_elementwise_maximum(maxmin, lo9[15]);
   minmax = __builtin_elementwise_minimum(minmax, hi9[15]);
-  const orbx_h2 c = __builtin_bit_cast(orbx_h2, (uint32_t)a8[0] | ((uint32_t)b8[0] << 16) | 0x64006400u);
+  const orbx_h2 c = __builtin_bit_cast(orbx_h2, (uint32_t)a8[0] | ((uint32_t)b8[0] << 16));
   return __builtin_elementwise_maximum(maxmin - c, c - minmax);
 }
 
@@ -349,7 +401,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     bool overflowed = false;  // more corners than the list holds: the NMS falls back to scanning the score tile
     auto flush_survivors = [&]() {
       __syncthreads();
-      const orbx_h2 th2 = {(_Float16)t, (_Float16)t};
+      const orbx_h2 th2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);  // t in the same subnormal encoding
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
         const int eA = base + lane, eB = base + 64 + lane;
         const int yxA = slist[min(eA, nSurv - 1)], yxB = slist[min(eB, nSurv - 1)];
@@ -357,8 +409,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         const orbx_h2 M = fast_contrast2_lds(tile8 + (yA + 3) * g.tileP + xA + 3, tile8 + (yB + 3) * g.tileP + xB + 3,
                                             g.tileP);
         const bool cornerA = eA < nSurv && M.x > th2.x, cornerB = eB < nSurv && M.y > th2.y;
-        if (cornerA) score8[(yA + 1) * g.scoreP + xA + 4] = (uint8_t)((int)M.x - 1);
-        if (cornerB) score8[(yB + 1) * g.scoreP + xB + 4] = (uint8_t)((int)M.y - 1);
+        const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
+        if (cornerA) score8[(yA + 1) * g.scoreP + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
+        if (cornerB) score8[(yB + 1) * g.scoreP + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
         const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
         const int oA = nList + prefix_count(mA);
         const int oB = nList + __popcll(mA) + prefix_count(mB);
@@ -1325,10 +1378,6 @@ __device__ __forceinline__ int reflect101(int p, int n) {
   return p;
 }
 
-typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c) {  // a.lo*b.lo + a.hi*b.hi + c
-  return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_us2, a), __builtin_bit_cast(orbx_us2, b), c, false);
-}
 #define BL_TW 128
 #define BL_TH 32
 // Tile of 128x32 outputs per 256-thread block.  In-tile: rows y0-3 .. y0+34, columns x0-4 .. x0+131 as aligned
