@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--handles", type=int, default=2,
                     help="extractor handles used round-robin (each owns streams + buffers); 2 = double buffering: the "
                          "next batch's pyramid / FAST overlaps the tail of the previous one (+12%% over 1)")
+    ap.add_argument("--mode", choices=("stereo", "mono", "fisheye"), default="stereo",
+                    help="stereo = BASELINE config C3 (the headline metric); mono = extraction only (C2: --width 640 "
+                         "--height 480 --nfeatures 1000), value counts single frames; fisheye = C4 (--width 512 --height 512):"
+                         " lapping areas + ComputeStereoFishEyeMatches (2-NN + KB8 triangulation) on the device")
     ap.add_argument("--allgather", action="store_true",
                     help="config C5 extra: RCCL all-gather of every rank's descriptor blocks after each step")
     return ap.parse_args()
@@ -138,11 +142,19 @@ def main():
         def __init__(self, ptr, shape, typestr):
             self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
+    lap = None
+    if a.mode == "fisheye":  # TUM-VI-like lapping areas (Examples/Stereo-Inertial/TUM-VI.yaml:45-49 scaled to W)
+        lap = np.array([[W // 5, W - 1]] * B + [[0, (4 * W) // 5]] * B, np.int32)
+        rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM2, np.eye(3), [0.101, 0.002, 0.001])
+
     def step():
         ex = exs[step_no[0] % len(exs)]
         step_no[0] += 1
-        ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H)
-        orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
+        ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H, lap=lap)
+        if a.mode == "stereo":
+            orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
+        elif a.mode == "fisheye":
+            orbx.fisheye_match_async(ex, ex, rig, first_left=0, first_right=B, n_pairs=B)
         if a.allgather and dist is not None:
             # config C5 extra: every GPU ends up with all cameras' descriptor blocks (RCCL all-gather over xGMI)
             ex.sync()
@@ -209,16 +221,24 @@ def main():
     P = sum(plevels)
     ncand_mean = float(np.mean([ex.level_stats(i)[2].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
     nsel_mean = float(np.mean([ex.level_stats(i)[3].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
-    u, dep = None, None
-    d_u = np.zeros((1, ex.capacity), np.float32)
-    orbx._check(orbx.lib().orbx_stereo_download(ex._h, 0, orbx._p(d_u[0]), None, ex.capacity))
-    nmatch = int((d_u >= 0).sum())
+    if a.mode == "stereo":
+        d_u = np.zeros((1, ex.capacity), np.float32)
+        orbx._check(orbx.lib().orbx_stereo_download(ex._h, 0, orbx._p(d_u[0]), None, ex.capacity))
+        nmatch = int((d_u >= 0).sum())
+    elif a.mode == "fisheye":
+        nmatch = orbx.fisheye_download(ex, ex, 0)[0]
+    else:
+        nmatch = 0
 
-    value = a.gpus * B * a.steps / elapsed
+    units_per_step = 2 * B if a.mode == "mono" else B  # mono: every image is a frame
+    value = a.gpus * units_per_step * a.steps / elapsed
     out = {
-        "metric": "ORB extract+match stereo frames/sec @1280x720 (both-eye ORBextractor + ComputeStereoMatches)",
+        "metric": {"stereo": "ORB extract+match stereo frames/sec @%dx%d (both-eye ORBextractor + ComputeStereoMatches)",
+                   "mono": "ORB extract mono frames/sec @%dx%d (ORBextractor::operator())",
+                   "fisheye": "ORB extract+match fisheye stereo frames/sec @%dx%d (both-eye ORBextractor with lapping areas "
+                              "+ ComputeStereoFishEyeMatches)"}[a.mode] % (W, H),
         "value": round(value, 2),
-        "unit": "stereo frames/s",
+        "unit": "frames/s" if a.mode == "mono" else "stereo frames/s",
         "n_gpus": a.gpus,
         "steps": a.steps,
         "warmup": a.warmup,
@@ -229,8 +249,11 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
-                        "ComputeStereoMatches (bf=0.12*532.03, b=0.12)" % (W, H, NF),
+            "workload": {"stereo": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
+                                   "ComputeStereoMatches (bf=0.12*532.03, b=0.12)",
+                         "mono": "C2: synthetic %dx%d mono frames, %d features, 8 levels, scale 1.2, FAST 20/7",
+                         "fisheye": "C4: synthetic %dx%d fisheye stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
+                                    "lapping areas, BF 2-NN + KannalaBrandt8 triangulation"}[a.mode] % (W, H, NF),
             "pairs_per_step_per_gpu": B,
             "handles": len(exs),
             "distinct_streams_per_gpu": D,
@@ -283,7 +306,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
     # Frame-parallel over the host cores in a separate process tree (`cpu_mt` of BASELINE.md), plus 1 core.
-    if rank == 0 and a.gpus == 1 and a.cpu_pairs > 0:
+    if rank == 0 and a.gpus == 1 and a.cpu_pairs > 0 and a.mode == "stereo":
         import subprocess
         import tempfile
         tmp = os.path.join(tempfile.gettempdir(), "orbx_cpu_pairs_%d.npy" % os.getpid())

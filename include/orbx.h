@@ -157,6 +157,20 @@ int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const u
                               int32_t* left_to_right, int32_t* right_to_left, float* depth, float* points3d,
                               int32_t* n_desc_matches);
 
+/* The same routine on device-resident extraction results (config C4, batched many-camera mode): pair p associates
+ * image first_left + p of `left`'s last extraction with image first_right + p of `right`'s (left == right allowed);
+ * the lapping rows [monoIndex, n) and mvLevelSigma2 come from the handles.  Enqueued on left's stream after right's
+ * work; results stay on the device of `left`: left_to_right / depth [n_pairs][cap_left], points3d [n_pairs][cap_left][3],
+ * right_to_left [n_pairs][cap_right], counts [n_pairs][2] = {nMatches, descMatches}. */
+int orbx_fisheye_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                                    int n_pairs, const orbx_kb8_rig* rig);
+int orbx_fisheye_results_device(const orbx_extractor* left, const int32_t** d_left_to_right,
+                                const int32_t** d_right_to_left, const float** d_depth, const float** d_points3d,
+                                const int32_t** d_counts);
+/* Host copy of pair `pair` (synchronises; any pointer may be NULL).  Returns nMatches or a negative error. */
+int orbx_fisheye_download(orbx_extractor* left, int pair, int32_t* left_to_right, int32_t* right_to_left, float* depth,
+                          float* points3d, int cap_left, int cap_right, int32_t* n_desc_matches);
+
 /* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) incl. Frame::GetFeaturesInArea /
  * AssignFeaturesToGrid / PosInGrid on F2 (src/Frame.cc:520-547,765-844) and ComputeThreeMaxima
  * (src/ORBmatcher.cc:1920-1955).  kps are the undistorted keypoints (mvKeysUn); bounds = mnMinX, mnMinY,

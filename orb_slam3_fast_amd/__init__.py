@@ -72,6 +72,9 @@ def lib():
         L.orbx_stereo_download.argtypes = [vp, i, vp, vp, i]
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_fisheye_stereo_match.argtypes = [i, vp, vp, i, i, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, vp]
+        L.orbx_fisheye_stereo_match_batch.argtypes = [vp, i, vp, i, i, vp]
+        L.orbx_fisheye_results_device.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.orbx_fisheye_download.argtypes = [vp, i, vp, vp, vp, vp, i, i, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
@@ -303,6 +306,26 @@ def ComputeStereoFishEyeMatches(kpsL, descL, monoL, kpsR, descR, monoR, rig, lev
     n = _check(lib().orbx_fisheye_stereo_match(device, _p(kl), _p(dl), len(kl), int(monoL), _p(kr), _p(dr), len(kr),
                                                int(monoR), _p(rig), _p(s2), len(s2), _p(l2r), _p(r2l), _p(depth),
                                                _p(pts), C.byref(nd)))
+    return n, nd.value, l2r, r2l, depth, pts
+
+
+def fisheye_match_async(left, right, rig, first_left=0, first_right=0, n_pairs=1):
+    """Enqueue Frame::ComputeStereoFishEyeMatches for n_pairs image pairs of the extractors' last (batch) extraction;
+    everything stays on the device (config C4 in batched mode)."""
+    rig = np.ascontiguousarray(rig, np.float32)
+    if rig.size != 29:
+        raise ValueError("rig: use kb8_rig()")
+    _check(lib().orbx_fisheye_stereo_match_batch(left._h, first_left, right._h, first_right, n_pairs, _p(rig)))
+
+
+def fisheye_download(left, right, pair=0):
+    """Host copy of one pair of the last fisheye_match_async: (nMatches, descMatches, l2r, r2l, depth, p3d), arrays
+    sized by the handles' capacities (entries beyond the keypoint counts are -1 / 0)."""
+    l2r, r2l = np.zeros(left.capacity, np.int32), np.zeros(right.capacity, np.int32)
+    depth, pts = np.zeros(left.capacity, np.float32), np.zeros((left.capacity, 3), np.float32)
+    nd = C.c_int(0)
+    n = _check(lib().orbx_fisheye_download(left._h, pair, _p(l2r), _p(r2l), _p(depth), _p(pts), left.capacity,
+                                           right.capacity, C.byref(nd)))
     return n, nd.value, l2r, r2l, depth, pts
 
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "orbx_internal.h"
@@ -77,6 +78,9 @@ struct orbx_extractor {
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
   int stereoPairs = 0;
+  DevBuf<int> d_fl2r, d_fr2l, d_fcnt;  // batched fisheye association (orbx_fisheye_stereo_match_batch)
+  DevBuf<float> d_fdepth, d_fp3d;
+  int fisheyePairs = 0, fisheyeCapR = 0;
   // per-launch HIP event log (orbx_profile_*)
   bool profiling = false;
   int profStage = -1;              // >= 0: only launches of this stage are bracketed
@@ -322,6 +326,28 @@ int configure(orbx_extractor* ex, int w, int h) {
   return ORBX_OK;
 }
 
+struct DetectToken {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  bool valid = false;
+  const orbx_extractor* last = nullptr;
+};
+static DetectToken* detect_token(int device) {  // one per device, created on first use (never destroyed: process lifetime)
+  static std::mutex mu;
+  static DetectToken* toks[64] = {nullptr};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!toks[device]) {
+    DetectToken* t = new DetectToken();
+    if (hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) != hipSuccess) {
+      delete t;
+      return nullptr;
+    }
+    toks[device] = t;
+  }
+  return toks[device];
+}
+
 int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
                     ptrdiff_t image_pitch, const int32_t* lap) {
   int rc = configure(ex, w, h);
@@ -373,7 +399,23 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
     }
     HIPC(hipEventRecord(ex->evDet0, ex->stream2));
   }
-  {
+  // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
+  // each other.  A per-device token orders the k_detect launches of all handles one after the other, while each still
+  // overlaps the other handles' quadtree / describe / stereo / resize work.  (ORBX_DETECT_TOKEN=0 disables it.)
+  static const bool useToken = !(getenv("ORBX_DETECT_TOKEN") && atoi(getenv("ORBX_DETECT_TOKEN")) == 0);
+  DetectToken* tok = useToken ? detect_token(ex->device) : nullptr;
+  if (tok) {
+    std::lock_guard<std::mutex> lk(tok->mu);
+    if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
+    ex->lastEvValid = false;
+    {
+      StageTimer t(ex, s, ORBX_STAGE_DETECT);
+      HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, split, s));
+    }
+    HIPC(hipEventRecord(tok->ev, s));
+    tok->valid = true;
+    tok->last = ex;
+  } else {
     StageTimer t(ex, s, ORBX_STAGE_DETECT);
     HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, split, s));
   }
@@ -514,7 +556,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   if (ex->stream) (void)hipStreamSynchronize(ex->stream);
   ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
-  ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_xofs.free(); ex->d_yofs.free();
+  ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xofs.free(); ex->d_yofs.free();
   ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
@@ -761,6 +803,75 @@ int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT,
   q.free(); t.free(); ok.free(); i2.free(); d2.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return ORBX_OK;
+}
+
+int orbx_fisheye_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                                    int n_pairs, const orbx_kb8_rig* rig) {
+  if (!left || !right || !rig) return fail(ORBX_E_BADARG, "null argument");
+  if (n_pairs <= 0 || first_left < 0 || first_right < 0 || first_left + n_pairs > left->lastN ||
+      first_right + n_pairs > right->lastN)
+    return fail(ORBX_E_BADARG, "pair range outside the last extraction");
+  if (left->device != right->device || std::memcmp(&left->prm, &right->prm, sizeof(orbx_params)) != 0)
+    return fail(ORBX_E_BADARG, "left and right extractors must share device and parameters");
+  HIPC(hipSetDevice(left->device));
+  const size_t capL = (size_t)left->gmax.outCap, capR = (size_t)right->gmax.outCap;
+  if (left->fisheyePairs < n_pairs || left->fisheyeCapR < (int)capR) {
+    HIPC(hipStreamSynchronize(left->stream));
+    HIPC(left->d_fl2r.alloc((size_t)n_pairs * capL));
+    HIPC(left->d_fr2l.alloc((size_t)n_pairs * capR));
+    HIPC(left->d_fdepth.alloc((size_t)n_pairs * capL));
+    HIPC(left->d_fp3d.alloc((size_t)n_pairs * capL * 3));
+    HIPC(left->d_fcnt.alloc((size_t)n_pairs * 2));
+    left->fisheyePairs = n_pairs;
+    left->fisheyeCapR = (int)capR;
+  }
+  hipStream_t s = left->stream;
+  if (right != left) {  // order left's stream after right's extraction
+    HIPC(hipEventRecord(right->done, right->stream));
+    HIPC(hipStreamWaitEvent(s, right->done, 0));
+  }
+  FisheyeBatchArgs a;
+  a.kL = left->d_kps.p; a.kR = right->d_kps.p; a.dL = left->d_desc.p; a.dR = right->d_desc.p;
+  a.nL = left->d_nOut.p; a.nR = right->d_nOut.p; a.monoL = left->d_mono.p; a.monoR = right->d_mono.p;
+  a.capL = (int)capL; a.capR = (int)capR; a.firstL = first_left; a.firstR = first_right;
+  a.rig = *rig;
+  a.nLevels = left->prm.nlevels;
+  for (int l = 0; l < ORBX_MAX_LEVELS; l++) a.sigma2[l] = l < a.nLevels ? left->sig2[l] : 0.f;  // Frame::mvLevelSigma2
+  a.leftToRight = left->d_fl2r.p; a.rightToLeft = left->d_fr2l.p; a.depth = left->d_fdepth.p; a.p3D = left->d_fp3d.p;
+  a.counters = left->d_fcnt.p;
+  {
+    StageTimer t(left, s, ORBX_STAGE_STEREO_MATCH);
+    HIPC(launch_fisheye_batch(a, n_pairs, s));
+  }
+  return ORBX_OK;
+}
+
+int orbx_fisheye_results_device(const orbx_extractor* left, const int32_t** d_left_to_right, const int32_t** d_right_to_left,
+                                const float** d_depth, const float** d_points3d, const int32_t** d_counts) {
+  if (!left || left->fisheyePairs == 0) return fail(ORBX_E_BADARG, "no fisheye association has been run on this handle");
+  if (d_left_to_right) *d_left_to_right = left->d_fl2r.p;
+  if (d_right_to_left) *d_right_to_left = left->d_fr2l.p;
+  if (d_depth) *d_depth = left->d_fdepth.p;
+  if (d_points3d) *d_points3d = left->d_fp3d.p;
+  if (d_counts) *d_counts = left->d_fcnt.p;
+  return ORBX_OK;
+}
+
+int orbx_fisheye_download(orbx_extractor* left, int pair, int32_t* left_to_right, int32_t* right_to_left, float* depth,
+                          float* points3d, int cap_left, int cap_right, int32_t* n_desc_matches) {
+  if (!left || pair < 0 || pair >= left->fisheyePairs) return fail(ORBX_E_BADARG, "bad pair index");
+  HIPC(hipSetDevice(left->device));
+  HIPC(hipStreamSynchronize(left->stream));
+  const size_t capL = (size_t)left->gmax.outCap, capR = (size_t)left->fisheyeCapR;
+  const size_t nl = std::min(capL, (size_t)std::max(cap_left, 0)), nr = std::min(capR, (size_t)std::max(cap_right, 0));
+  if (left_to_right) HIPC(hipMemcpy(left_to_right, left->d_fl2r.p + pair * capL, nl * sizeof(int), hipMemcpyDeviceToHost));
+  if (right_to_left) HIPC(hipMemcpy(right_to_left, left->d_fr2l.p + pair * capR, nr * sizeof(int), hipMemcpyDeviceToHost));
+  if (depth) HIPC(hipMemcpy(depth, left->d_fdepth.p + pair * capL, nl * sizeof(float), hipMemcpyDeviceToHost));
+  if (points3d) HIPC(hipMemcpy(points3d, left->d_fp3d.p + pair * capL * 3, nl * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  int cnt[2] = {0, 0};
+  HIPC(hipMemcpy(cnt, left->d_fcnt.p + 2 * pair, sizeof(cnt), hipMemcpyDeviceToHost));
+  if (n_desc_matches) *n_desc_matches = cnt[1];
+  return cnt[0];
 }
 
 int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,

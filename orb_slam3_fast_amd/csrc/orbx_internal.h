@@ -123,6 +123,29 @@ struct FisheyeArgs {
   int* counters;            // [0] = nMatches, [1] = descMatches (pre-set to 0)
 };
 hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s);
+
+// Batched, device-resident Frame::ComputeStereoFishEyeMatches: pair p = image firstL + p of the left extraction against
+// image firstR + p of the right one; lapping rows [mono, n) come from the extractors' device-side counts.
+struct FisheyeBatchArgs {
+  const orbx_keypoint* kL;  // [images][capL]
+  const orbx_keypoint* kR;
+  const uint8_t* dL;        // [images][capL][32]
+  const uint8_t* dR;
+  const int* nL;            // per image: keypoint count / monoIndex
+  const int* nR;
+  const int* monoL;
+  const int* monoR;
+  int capL, capR, firstL, firstR;
+  orbx_kb8_rig rig;
+  float sigma2[ORBX_MAX_LEVELS];
+  int nLevels;
+  int* leftToRight;         // [pairs][capL]  (pre-set to -1)
+  int* rightToLeft;         // [pairs][capR]  (pre-set to -1)
+  float* depth;             // [pairs][capL]  (pre-set to -1)
+  float* p3D;               // [pairs][capL][3] (pre-set to 0)
+  int* counters;            // [pairs][2] = nMatches, descMatches (pre-set to 0)
+};
+hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream_t s);
 struct InitArgs {
   const orbx_keypoint *k1, *k2;
   const uint8_t *d1, *d2;

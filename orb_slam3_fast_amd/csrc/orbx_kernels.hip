@@ -2250,6 +2250,120 @@ __global__ __launch_bounds__(64) void k_fisheye_triangulate(FisheyeArgs a) {
   }
 }
 
+// Batched variant on the extractors' device-resident results: thread per lapping-area left keypoint of pair
+// blockIdx.y does the 2-NN over the pair's right lapping rows (256-row LDS tiles, as k_bf_knn2), the Lowe test and the
+// triangulation in one go.
+__global__ __launch_bounds__(256) void k_fisheye_batch(FisheyeBatchArgs a) {
+  // 64 queries per block; wave w scans the train rows t = w (mod 4) of every 256-row LDS tile (all lanes read the same
+  // row: broadcast, 2 x ds_read_b128), the four partial (distance, index) top-2 lists are merged lexicographically --
+  // exactly the stable first-minimum order of the serial scan -- and wave 0 triangulates.
+  __shared__ uint4 tile[256 * 2];
+  __shared__ uint32_t part[3][64][2];  // waves 1..3: packed (distance << 16 | index) best / second
+  const int pr = blockIdx.y;
+  const int imL = a.firstL + pr, imR = a.firstR + pr;
+  const int nL = min(a.nL[imL], a.capL), nR = min(a.nR[imR], a.capR);
+  const int monoL = min(max(a.monoL[imL], 0), nL), monoR = min(max(a.monoR[imR], 0), nR);
+  const int nQ = nL - monoL, nT = nR - monoR;
+  if ((int)blockIdx.x * 64 >= nQ) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + lane;
+  const uint4* dQ = reinterpret_cast<const uint4*>(a.dL + ((long long)imL * a.capL + monoL) * 32);
+  const uint4* dT = reinterpret_cast<const uint4*>(a.dR + ((long long)imR * a.capR + monoR) * 32);
+  uint4 qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
+  if (q < nQ) {
+    qa = dQ[(long long)q * 2];
+    qb = dQ[(long long)q * 2 + 1];
+  }
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // (distance << 16 | train index): lexicographic order, nT < 65536
+  for (int t0 = 0; t0 < nT; t0 += 256) {
+    const int nt = min(256, nT - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * 2; i += 256) tile[i] = dT[(long long)t0 * 2 + i];
+    __syncthreads();
+    for (int t = w; t < nt; t += 4) {
+      const uint4 ta = tile[2 * t], tb = tile[2 * t + 1];
+      const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                    __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+      const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + t);
+      const uint32_t lo = min(k0, key);
+      k1 = min(k1, max(k0, key));
+      k0 = lo;
+    }
+  }
+  if (w > 0) {
+    part[w - 1][lane][0] = k0;
+    part[w - 1][lane][1] = k1;
+  }
+  __syncthreads();
+  bool desc = false, matched = false;
+  if (w == 0) {
+#pragma unroll
+    for (int o = 0; o < 3; o++) {
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const uint32_t key = part[o][lane][e];
+        const uint32_t lo = min(k0, key);
+        k1 = min(k1, max(k0, key));
+        k0 = lo;
+      }
+    }
+    const int b0 = (int)(k0 >> 16), b1 = (int)(k1 >> 16), i0 = (int)(k0 & 0xFFFF);
+    if (q < nQ && k1 != 0xFFFFFFFFu && (double)(float)b0 < __dmul_rn((double)(float)b1, 0.7)) {  // src/Frame.cc:1302
+      desc = true;
+      const int iL = q + monoL, iR = i0 + monoR;
+      const orbx_keypoint kp1 = a.kL[(long long)imL * a.capL + iL], kp2 = a.kR[(long long)imR * a.capR + iR];
+      KB8Cam c1, c2;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        c1.p[i] = a.rig.cam1[i];
+        c2.p[i] = a.rig.cam2[i];
+      }
+      c1.precision = c2.precision = a.rig.precision;
+      const float sigma1 = a.sigma2[min(max(kp1.octave, 0), a.nLevels - 1)];
+      const float sigma2 = a.sigma2[min(max(kp2.octave, 0), a.nLevels - 1)];
+      float P[3] = {0.f, 0.f, 0.f};
+      const float d = kb8_triangulate_matches(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, a.rig.R12, a.rig.t12, sigma1, sigma2, P);
+      if (d > 0.0001f) {
+        matched = true;
+        const long long o = (long long)pr * a.capL + iL;
+        a.leftToRight[o] = iR;
+        atomicMax(a.rightToLeft + (long long)pr * a.capR + iR, iL);
+        a.p3D[3 * o] = P[0];
+        a.p3D[3 * o + 1] = P[1];
+        a.p3D[3 * o + 2] = P[2];
+        a.depth[o] = d;
+      }
+    }
+    const uint64_t mm = __ballot(matched), md = __ballot(desc);
+    if (lane == 0) {
+      if (mm) atomicAdd(a.counters + 2 * pr, __popcll(mm));
+      if (md) atomicAdd(a.counters + 2 * pr + 1, __popcll(md));
+    }
+  }
+}
+
+// One launch presets every output of the batch: -1 matches / depths, zero points and counters.
+__global__ __launch_bounds__(256) void k_fisheye_init(FisheyeBatchArgs a, int npairs) {
+  const long long nl = (long long)npairs * a.capL, nr = (long long)npairs * a.capR;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nl * 3; i += (long long)gridDim.x * 256) {
+    a.p3D[i] = 0.f;
+    if (i < nl) {
+      a.leftToRight[i] = -1;
+      a.depth[i] = -1.0f;
+    }
+    if (i < nr) a.rightToLeft[i] = -1;
+    if (i < 2 * npairs) a.counters[i] = 0;
+  }
+}
+
+hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream_t s) {
+  const long long work = (long long)npairs * (a.capL > a.capR ? a.capL : a.capR) * 3;
+  hipLaunchKernelGGL(k_fisheye_init, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, s, a,
+                     npairs);
+  hipLaunchKernelGGL(k_fisheye_batch, dim3((a.capL + 63) / 64, npairs), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s) {
   const int nQ = a.nL - a.monoL;
   if (nQ <= 0) return hipSuccess;

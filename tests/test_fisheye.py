@@ -214,3 +214,36 @@ def test_hip_fisheye_flow_from_extraction(oracle):
                                       sigma2)
     assert compare_float_results(hip, ora[:6], ora[6], mL) <= 2
     assert hip[1] > 20
+
+
+@pytest.mark.gpu
+def test_hip_fisheye_batch_on_device_results(oracle):
+    """Batched, device-resident variant (orbx_fisheye_stereo_match_batch): three fisheye stereo pairs extracted in one
+    batch on one handle (left eyes = images 0..2, right eyes = 3..5, per-image lapping areas), associated without
+    leaving the device, against the oracle run on the downloaded keypoints."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w = h = 512
+    pairs = [synth.stereo_pair(w, h, 96 + i) for i in range(3)]
+    imgs = np.stack([p[0] for p in pairs] + [p[1] for p in pairs])
+    lap = np.array([[100, 511]] * 3 + [[0, 400]] * 3, np.int32)
+    ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=6)
+    d = DeviceBuffer.from_numpy(imgs)
+    ex.extract_batch_device(d.ptr.value, 6, w, h, w, w * h, lap=lap)
+    rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM1, np.eye(3), [0.1, 0.0, 0.0])
+    orbx.fisheye_match_async(ex, ex, rig, first_left=0, first_right=3, n_pairs=3)
+    ex.sync()
+    sigma2 = ex.GetScaleSigmaSquares()
+    for p in range(3):
+        mL, kL, dL = ex.download(p)
+        mR, kR, dR = ex.download(3 + p)
+        assert 0 < mL < len(kL) and 0 < mR < len(kR)
+        n, nd, l2r, r2l, dep, pts = orbx.fisheye_download(ex, ex, p)
+        assert (l2r[len(kL):] == -1).all() and (r2l[len(kR):] == -1).all() and (dep[len(kL):] == -1).all()
+        hip = (n, nd, l2r[: len(kL)], r2l[: len(kR)], dep[: len(kL)], pts[: len(kL)])
+        ora = oracle.fisheye_stereo_match(kL, dL, mL, kR, dR, mR, oracle.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM1, np.eye(3), [0.1, 0, 0]),
+                                          sigma2)
+        assert compare_float_results(hip, ora[:6], ora[6], mL) <= 2 and nd > 20
+        # and it is the same routine as the host-array entry point
+        host = orbx.ComputeStereoFishEyeMatches(kL, dL, mL, kR, dR, mR, rig, sigma2)
+        assert host[0] == n and np.array_equal(host[2], hip[2]) and host[4].tobytes() == hip[4].tobytes()
