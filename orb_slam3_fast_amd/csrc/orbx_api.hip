@@ -53,6 +53,72 @@ struct DevBuf {
   }
 };
 
+// Scratch memory of the one-shot matcher entry points (orbx_bf_knn2, orbx_search_*, orbx_fisheye_stereo_match ...):
+// they need a dozen small device buffers per call, and hipMalloc / hipFree cost more than their kernels.  Blocks are
+// cached per device (size classes: powers of two) and reused; at most kScratchCap bytes stay cached per device.
+class ScratchPool {
+ public:
+  static void* take(size_t bytes, size_t* granted) {
+    size_t cls = 4096;
+    while (cls < bytes) cls <<= 1;
+    *granted = cls;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu());
+      auto& fl = lists()[dev];
+      for (size_t i = 0; i < fl.size(); i++)
+        if (fl[i].first == cls) {
+          void* p = fl[i].second;
+          fl[i] = fl.back();
+          fl.pop_back();
+          cached()[dev] -= cls;
+          return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) return nullptr;
+    return p;
+  }
+  static void give(void* p, size_t cls) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) {
+      std::lock_guard<std::mutex> lk(mu());
+      if (cached()[dev] + cls <= kScratchCap) {
+        lists()[dev].push_back({cls, p});
+        cached()[dev] += cls;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+
+ private:
+  static constexpr int kMaxDev = 64;
+  static constexpr size_t kScratchCap = 256u << 20;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::vector<std::pair<size_t, void*>>* lists() { static std::vector<std::pair<size_t, void*>> l[kMaxDev]; return l; }
+  static size_t* cached() { static size_t c[kMaxDev] = {0}; return c; }
+};
+
+template <class T>
+struct ScratchBuf {  // same face as DevBuf; the caller has made its device current (set_device)
+  T* p = nullptr;
+  size_t n = 0, cls = 0;
+  hipError_t alloc(size_t count) {
+    free();
+    n = count;
+    if (!count) return hipSuccess;
+    p = static_cast<T*>(ScratchPool::take(count * sizeof(T), &cls));
+    return p ? hipSuccess : hipErrorOutOfMemory;
+  }
+  void free() {
+    if (p) ScratchPool::give(p, cls);
+    p = nullptr;
+    n = 0;
+  }
+};
+
 }  // namespace
 
 struct orbx_extractor {
@@ -784,8 +850,8 @@ int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT,
   if (nQ == 0) return ORBX_OK;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<uint8_t> q, t, ok;
-  DevBuf<int> i2, d2;
+  ScratchBuf<uint8_t> q, t, ok;
+  ScratchBuf<int> i2, d2;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   chk(q.alloc((size_t)nQ * 32));
@@ -899,10 +965,10 @@ int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const u
   }
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<orbx_keypoint> kl, kr;
-  DevBuf<uint8_t> dq, dt, ok;
-  DevBuf<int> i2, d2, l2r, r2l, cnt;
-  DevBuf<float> dep, pts, sg;
+  ScratchBuf<orbx_keypoint> kl, kr;
+  ScratchBuf<uint8_t> dq, dt, ok;
+  ScratchBuf<int> i2, d2, l2r, r2l, cnt;
+  ScratchBuf<float> dep, pts, sg;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   chk(kl.alloc(n_left)); chk(kr.alloc(n_right)); chk(dq.alloc((size_t)nQ * 32)); chk(dt.alloc((size_t)nT * 32));
@@ -954,10 +1020,10 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   if (n1 == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<orbx_keypoint> k1, k2;
-  DevBuf<uint8_t> d1, d2;
-  DevBuf<float> prev;
-  DevBuf<int> m12, cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, result;
+  ScratchBuf<orbx_keypoint> k1, k2;
+  ScratchBuf<uint8_t> d1, d2;
+  ScratchBuf<float> prev;
+  ScratchBuf<int> m12, cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, result;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   chk(k1.alloc(n1)); chk(k2.alloc(std::max(n2, 1))); chk(d1.alloc((size_t)n1 * 32));
@@ -1008,9 +1074,9 @@ int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min
     return fail(ORBX_E_BADARG, "bad argument");
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<orbx_keypoint> k;
-  DevBuf<float> q;
-  DevBuf<int> cellStart, cellItems, qOff, out, mdist, m21, m12, result;
+  ScratchBuf<orbx_keypoint> k;
+  ScratchBuf<float> q;
+  ScratchBuf<int> cellStart, cellItems, qOff, out, mdist, m21, m12, result;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nn = std::max(n, 1), nq = std::max(n_queries, 1);
@@ -1062,12 +1128,12 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   if (n == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<orbx_keypoint> k;
-  DevBuf<uint8_t> d, occ;
-  DevBuf<float> ur, sf;
-  DevBuf<orbx_map_point_view> mp;
-  DevBuf<orbx_projected_point> pp;
-  DevBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result;
+  ScratchBuf<orbx_keypoint> k;
+  ScratchBuf<uint8_t> d, occ;
+  ScratchBuf<float> ur, sf;
+  ScratchBuf<orbx_map_point_view> mp;
+  ScratchBuf<orbx_projected_point> pp;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
@@ -1205,7 +1271,7 @@ int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
   if (n == 0) return ORBX_OK;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  DevBuf<uint64_t> d;
+  ScratchBuf<uint64_t> d;
   HIPC(d.alloc(n));
   hipError_t e = hipMemcpy(d.p, v, (size_t)n * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = launch_debug_sort(d.p, n, nullptr);

@@ -2382,30 +2382,62 @@ __device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs&
 }
 
 __global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single block
+  // Counting sort of the keypoints by grid cell, ascending keypoint index inside a cell (mGrid[i][j].push_back order,
+  // src/Frame.cc:536-546): count -> block scan -> unordered atomic fill -> per-cell insertion sort of the short lists.
   __shared__ int cnt[64 * 48];
-  const int tid = threadIdx.x;
-  for (int c = tid; c < 64 * 48; c += 256) cnt[c] = 0;
+  __shared__ int wsum[4];
+  constexpr int kCells = 64 * 48, kPer = kCells / 256;  // 12 consecutive cells per thread
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = tid; c < kCells; c += 256) cnt[c] = 0;
   __syncthreads();
   for (int i = tid; i < a.n2; i += 256) {
     const int c = grid_cell(a.k2[i], a);
     if (c >= 0) atomicAdd(&cnt[c], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int c = 0; c < 64 * 48; c++) {
-      a.cellStart[c] = run;
-      run += cnt[c];
-    }
-    a.cellStart[64 * 48] = run;
+  int local[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    local[k] = cnt[tid * kPer + k];
+    sum += local[k];
   }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[tid >> 6] = incl;
   __syncthreads();
-  // ascending fill: thread per cell walks all keypoints (n2 x 3072 cheap tests)
-  for (int c = tid; c < 64 * 48; c += 256) {
-    if (cnt[c] == 0) continue;
-    int w = a.cellStart[c];
-    for (int i = 0; i < a.n2; i++)
-      if (grid_cell(a.k2[i], a) == c) a.cellItems[w++] = i;
+  int run = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    a.cellStart[tid * kPer + k] = run;
+    cnt[tid * kPer + k] = run;  // becomes the fill cursor of the cell
+    run += local[k];
+  }
+  if (tid == 255) a.cellStart[kCells] = run;
+  __syncthreads();
+  for (int i = tid; i < a.n2; i += 256) {
+    const int c = grid_cell(a.k2[i], a);
+    if (c >= 0) a.cellItems[atomicAdd(&cnt[c], 1)] = i;
+  }
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {  // cells hold a handful of keypoints: insertion sort, thread per cell
+    const int c = tid * kPer + k;
+    const int b = cnt[c] - local[k];
+    for (int i = 1; i < local[k]; i++) {
+      const int v = a.cellItems[b + i];
+      int j = i - 1;
+      while (j >= 0 && a.cellItems[b + j] > v) {
+        a.cellItems[b + j + 1] = a.cellItems[b + j];
+        j--;
+      }
+      a.cellItems[b + j + 1] = v;
+    }
   }
   for (int i = tid; i < a.n2; i += 256) {
     a.matchedDist[i] = 0x7FFFFFFF;

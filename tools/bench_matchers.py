@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Wall-clock of the matcher entry points of the C ABI (host arrays in, host results out, one call at a time -- the way
+Tracking calls them once per frame) next to the CPU oracle on the same inputs.  Inputs: keypoints / descriptors of a
+synthetic 1280x720 stereo stream extracted with 1500 features, seeded map-point / projected-point views as in
+tools/gen_golden.py.  usage: python tools/bench_matchers.py [reps]   (GPU box; the oracle is only the comparison)"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import orb_slam3_fast_amd as orbx
+from orb_slam3_fast_amd import synth
+from oracle import oracle_py as O
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+w, h, nf = 1280, 720, 1500
+L0, _ = synth.stereo_pair(w, h, 300, 0)
+L1, R1 = synth.stereo_pair(w, h, 300, 1)
+eP, eL, eR = (orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h) for _ in range(3))
+_, kp, dp = eP(L0)
+_, kc, dc = eL(L1)
+_, kr, dr = eR(R1)
+uR = orbx.ComputeStereoMatches(eL, eR, 0.12 * 532.03, 0.12)[0][0, : len(kc)]
+sf = eL.GetScaleFactors()
+rng = np.random.default_rng(2024)
+n = len(kp)
+flips = rng.random((n, 32, 8)) < 0.04
+desc = dp ^ np.packbits(flips, axis=2).reshape(n, 32)
+mps = np.zeros(n, orbx.MP_DTYPE)
+mps["proj_x"], mps["proj_y"] = kp["x"] - 4 + rng.normal(0, 3.0, n), kp["y"] - 2 + rng.normal(0, 3.0, n)
+mps["proj_xr"] = mps["proj_x"] - rng.uniform(2, 60, n).astype(np.float32)
+mps["view_cos"], mps["track_depth"] = rng.choice([0.9, 0.9985], n), rng.uniform(1, 80, n)
+mps["predicted_level"] = np.clip(kp["octave"] + rng.integers(-1, 2, n), 0, 7)
+mps["in_view"], mps["bad"], mps["has_observations"] = rng.random(n) < 0.9, rng.random(n) < 0.05, rng.random(n) < 0.85
+mps["desc"] = desc
+pts = np.zeros(n, orbx.PP_DTYPE)
+pts["u"], pts["v"], pts["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+pts["radius"], pts["angle"] = (np.float32(15.0) * sf[kp["octave"]]), kp["angle"]
+pts["min_level"], pts["max_level"] = kp["octave"] - 1, kp["octave"] + 1
+pts["valid"], pts["has_observations"], pts["desc"] = mps["in_view"], mps["has_observations"], desc
+occ = (rng.random(len(kc)) < 0.05).astype(np.uint8)
+bounds = (0.0, 0.0, float(w), float(h))
+prev = np.stack([kp["x"], kp["y"]], 1)
+sc = synth.fisheye_stereo_scene(0, 1500, 1500, 500, 500)
+rig = orbx.kb8_rig(sc["cam1"], sc["cam2"], sc["R12"], sc["t12"])
+omps, opts = mps.view(O.MP_DTYPE), pts.view(O.PP_DTYPE)
+m = orbx.ORBmatcher(0.8, True)
+mi = orbx.ORBmatcher(0.9, True)
+cases = [
+    ("SearchByProjection(F, MapPoints)  %d pts x %d kps" % (n, len(kc)),
+     lambda: m.SearchByProjection(kc, dc, uR, bounds, sf, mps, occ, 3.0, True, 60.0),
+     lambda: O.search_by_projection(kc, dc, uR, bounds, sf, omps, 3.0, True, 60.0, 0.8, occ)),
+    ("SearchByProjection(Cur, Last)     %d pts x %d kps" % (n, len(kc)),
+     lambda: m.SearchByProjectionFrame(kc, dc, uR, bounds, pts, occ),
+     lambda: O.search_by_projection_frame(kc, dc, uR, bounds, opts, True, occ)),
+    ("SearchForInitialization           %d x %d kps, window 100" % (n, len(kc)),
+     lambda: mi.SearchForInitialization(kp, dp, kc, dc, bounds, prev, 100),
+     lambda: O.search_init(kp, dp, kc, dc, bounds, prev, 100, 0.9, True)),
+    ("BFMatcher kNN-2 + ratio           %d x %d" % (len(kc), len(kr)),
+     lambda: orbx.bf_knn2(dc, dr), lambda: O.bf_knn2(dc, dr)),
+    ("ComputeStereoFishEyeMatches       1000 x 1000 lapping rows",
+     lambda: orbx.ComputeStereoFishEyeMatches(sc["kL"], sc["dL"], 500, sc["kR"], sc["dR"], 500, rig, sc["level_sigma2"]),
+     lambda: O.fisheye_stereo_match(sc["kL"], sc["dL"], 500, sc["kR"], sc["dR"], 500, rig, sc["level_sigma2"])),
+]
+print("%-62s %12s %12s %8s" % ("entry point (host API, one call)", "MI355X ms", "oracle ms", "ratio"))
+for name, fg, fo in cases:
+    for _ in range(3):
+        fg()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fg()
+    tg = (time.perf_counter() - t0) / reps * 1e3
+    ro = max(3, reps // 6)
+    t0 = time.perf_counter()
+    for _ in range(ro):
+        fo()
+    to = (time.perf_counter() - t0) / ro * 1e3
+    print("%-62s %12.3f %12.3f %8.1f" % (name, tg, to, to / tg))
