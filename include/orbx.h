@@ -171,6 +171,18 @@ int orbx_fisheye_results_device(const orbx_extractor* left, const int32_t** d_le
 int orbx_fisheye_download(orbx_extractor* left, int pair, int32_t* left_to_right, int32_t* right_to_left, float* depth,
                           float* points3d, int cap_left, int cap_right, int32_t* n_desc_matches);
 
+/* Replaces Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys through
+ * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) -- five fixed-point iterations of the inverse distortion
+ * in double, then x' = fx x + cx.  K = fx fy cx cy (Pinhole::toK()); dist = the n_dist (4, 5, 8, 12 or 14) OpenCV
+ * coefficients of mDistCoef, tilt terms unsupported (must be 0).  dist[0] == 0 copies the keypoints, as the reference
+ * does.  Host arrays in and out; out may alias kps. */
+int orbx_undistort_keypoints(int device, const orbx_keypoint* kps, int n, const float K[4], const float* dist, int n_dist,
+                             orbx_keypoint* out);
+/* Replaces Frame::ComputeImageBounds (src/Frame.cc:887-919): bounds = mnMinX, mnMinY, mnMaxX, mnMaxY of a cols x rows
+ * image (the undistorted corners, or 0, 0, cols, rows when dist[0] == 0). */
+int orbx_compute_image_bounds(int device, int cols, int rows, const float K[4], const float* dist, int n_dist,
+                              float bounds[4]);
+
 /* Replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) incl. Frame::GetFeaturesInArea /
  * AssignFeaturesToGrid / PosInGrid on F2 (src/Frame.cc:520-547,765-844) and ComputeThreeMaxima
  * (src/ORBmatcher.cc:1920-1955).  kps are the undistorted keypoints (mvKeysUn); bounds = mnMinX, mnMinY,

@@ -299,3 +299,21 @@ def fisheye_stereo_match(kL, dL, monoL, kR, dR, monoR, rig, level_sigma2):
     nm = lib().oro_fisheye_stereo_match(_p(kL), _p(dL), nL, monoL, _p(kR), _p(dR), nR, monoR, _p(rig), _p(s2), len(s2),
                                         _p(l2r), _p(r2l), _p(dep), _p(pts), C.byref(nd), _p(gates))
     return nm, nd.value, l2r, r2l, dep, pts, gates
+
+
+# ---- Frame::UndistortKeyPoints / ComputeImageBounds ---------------------------------------------------------------------
+def undistort_keypoints(kps, K, dist):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(len(kps), KP_DTYPE)
+    lib().oro_undistort_keypoints(_p(kps), len(kps), _p(K), _p(dist), len(dist), _p(out))
+    return out
+
+
+def image_bounds(cols, rows, K, dist):
+    K = np.ascontiguousarray(K, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    b = np.zeros(4, np.float32)
+    lib().oro_image_bounds(int(cols), int(rows), _p(K), _p(dist), len(dist), _p(b))
+    return b

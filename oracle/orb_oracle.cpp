@@ -885,6 +885,71 @@ int compute_stereo_fisheye_matches(const std::vector<KeyPoint>& kL, const uint8_
   return nMatches;
 }
 
+// ---- cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it -------------------------------------
+void undistort_points(const float* xy_in, int n, const float K[4], const float* dist, int n_dist, float* xy_out) {
+  double k[14] = {0};
+  for (int i = 0; i < n_dist && i < 14; i++) k[i] = (double)dist[i];
+  const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; i++) {
+    const double u = xy_in[2 * i], v = xy_in[2 * i + 1];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    if (n_dist > 0) {
+      for (int j = 0; j < 5; j++) {  // TermCriteria(MAX_ITER, 5, 0.01): the count is the only active criterion
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) {  // "test: undistortPoints.regression_14583"
+          x = (u - cx) * ifx;
+          y = (v - cy) * ify;
+          break;
+        }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+      }
+    }
+    // P = K, R = I: xx = fx x + 0 y + cx, ww = 1 / (0 x + 0 y + 1)
+    const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+    xy_out[2 * i] = (float)(xx * ww);
+    xy_out[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+void undistort_keypoints(const std::vector<KeyPoint>& kps, const float K[4], const float* dist, int n_dist,
+                         std::vector<KeyPoint>& out) {
+  out = kps;
+  if (n_dist <= 0 || dist[0] == 0.0f) return;  // src/Frame.cc:854-857
+  std::vector<float> xy(2 * kps.size()), uo(2 * kps.size());
+  for (size_t i = 0; i < kps.size(); i++) {
+    xy[2 * i] = kps[i].x;
+    xy[2 * i + 1] = kps[i].y;
+  }
+  undistort_points(xy.data(), (int)kps.size(), K, dist, n_dist, uo.data());
+  for (size_t i = 0; i < kps.size(); i++) {
+    out[i].x = uo[2 * i];
+    out[i].y = uo[2 * i + 1];
+  }
+}
+
+void compute_image_bounds(int cols, int rows, const float K[4], const float* dist, int n_dist, float bounds[4]) {
+  if (n_dist > 0 && dist[0] != 0.0f) {
+    const float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+    float o[8];
+    undistort_points(c, 4, K, dist, n_dist, o);
+    bounds[0] = std::min(o[0], o[4]);  // mnMinX
+    bounds[2] = std::max(o[2], o[6]);  // mnMaxX
+    bounds[1] = std::min(o[1], o[3]);  // mnMinY
+    bounds[3] = std::max(o[5], o[7]);  // mnMaxY
+  } else {
+    bounds[0] = 0.f;
+    bounds[1] = 0.f;
+    bounds[2] = (float)cols;
+    bounds[3] = (float)rows;
+  }
+}
+
 // Frame::AssignFeaturesToGrid / PosInGrid, src/Frame.cc:520-547,833-844 (64x48 grid, round-to-cell).
 void FrameGrid::build(const std::vector<KeyPoint>& kps, float minX_, float minY_, float maxX_, float maxY_) {
   minX = minX_; minY = minY_; maxX = maxX_; maxY = maxY_;

@@ -126,6 +126,19 @@ int compute_stereo_fisheye_matches(const std::vector<KeyPoint>& kL, const uint8_
                                    std::vector<int>& rightToLeft, std::vector<float>& depth,
                                    std::vector<float>& p3D, int* descMatches, std::vector<float>* gates);
 
+// ---- Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:853-919) --------------------------------------------
+// cv::undistortPoints(src, dst, K, distCoeffs, noArray(), P = K) with its default TermCriteria(MAX_ITER, 5, 0.01): five
+// fixed-point iterations of the inverse distortion in double, then x' = fx x + cx (OpenCV calib3d undistort.dispatch.cpp,
+// restated from the published algorithm -- not pinnable here, see the header note).  K = fx fy cx cy (float, as
+// Pinhole::toK()); dist = up to 14 OpenCV coefficients k1 k2 p1 p2 k3 k4 k5 k6 s1..s4 tx ty (ORB-SLAM3 passes 4 or 5;
+// tx / ty must be 0).  xy_in / xy_out: n interleaved float pairs.
+void undistort_points(const float* xy_in, int n, const float K[4], const float* dist, int n_dist, float* xy_out);
+// mvKeysUn from mvKeys (identity when dist[0] == 0, :854-857).
+void undistort_keypoints(const std::vector<KeyPoint>& kps, const float K[4], const float* dist, int n_dist,
+                         std::vector<KeyPoint>& out);
+// mnMinX, mnMinY, mnMaxX, mnMaxY (:887-919).
+void compute_image_bounds(int cols, int rows, const float K[4], const float* dist, int n_dist, float bounds[4]);
+
 // Frame grid (src/Frame.cc:520-547,765-844).
 struct FrameGrid {
   float minX, minY, maxX, maxY, invW, invH;

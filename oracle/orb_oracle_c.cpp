@@ -221,6 +221,15 @@ int oro_fisheye_stereo_match(const KeyPoint* kL, const uint8_t* dL, int nL, int 
   return nm;
 }
 
+void oro_undistort_keypoints(const KeyPoint* k, int n, const float* K, const float* dist, int n_dist, KeyPoint* out) {
+  std::vector<KeyPoint> a(k, k + n), o;
+  undistort_keypoints(a, K, dist, n_dist, o);
+  std::memcpy(out, o.data(), (size_t)n * sizeof(KeyPoint));
+}
+void oro_image_bounds(int cols, int rows, const float* K, const float* dist, int n_dist, float* bounds) {
+  compute_image_bounds(cols, rows, K, dist, n_dist, bounds);
+}
+
 // libstdc++ std::sort with the (count, UL.x) comparator of compareNodes (src/ORBextractor.cc:542-555) on
 // packed 64-bit elements (key = bits 16..63): the tie order the device quadtree's replica must reproduce.
 void oro_std_sort_keys(uint64_t* v, int n) {

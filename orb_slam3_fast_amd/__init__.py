@@ -73,6 +73,8 @@ def lib():
         L.orbx_bf_knn2.argtypes = [i, vp, i, vp, i, vp, vp, vp]
         L.orbx_fisheye_stereo_match.argtypes = [i, vp, vp, i, i, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, vp]
         L.orbx_fisheye_stereo_match_batch.argtypes = [vp, i, vp, i, i, vp]
+        L.orbx_undistort_keypoints.argtypes = [i, vp, i, vp, vp, i, vp]
+        L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
         L.orbx_fisheye_results_device.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orbx_fisheye_download.argtypes = [vp, i, vp, vp, vp, vp, i, i, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
@@ -327,6 +329,25 @@ def fisheye_download(left, right, pair=0):
     n = _check(lib().orbx_fisheye_download(left._h, pair, _p(l2r), _p(r2l), _p(depth), _p(pts), left.capacity,
                                            right.capacity, C.byref(nd)))
     return n, nd.value, l2r, r2l, depth, pts
+
+
+def UndistortKeyPoints(kps, K, dist, device=0):
+    """Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys; K = (fx, fy, cx, cy), dist = mDistCoef."""
+    k = np.ascontiguousarray(kps, KP_DTYPE)
+    K = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist, np.float32).ravel()
+    out = np.zeros(len(k), KP_DTYPE)
+    _check(lib().orbx_undistort_keypoints(device, _p(k), len(k), _p(K), _p(d) if len(d) else None, len(d), _p(out)))
+    return out
+
+
+def ComputeImageBounds(cols, rows, K, dist, device=0):
+    """Frame::ComputeImageBounds (src/Frame.cc:887-919) -> (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+    K = np.ascontiguousarray(K, np.float32)
+    d = np.ascontiguousarray(dist, np.float32).ravel()
+    b = np.zeros(4, np.float32)
+    _check(lib().orbx_compute_image_bounds(device, int(cols), int(rows), _p(K), _p(d) if len(d) else None, len(d), _p(b)))
+    return b
 
 
 def GetFeaturesInArea(kpsUn, bounds, queries, device=0, return_grid=False):

@@ -145,6 +145,26 @@ inline int ComputeStereoFishEyeMatches(const std::vector<ocv::KeyPoint>& mvKeys,
   return n;
 }
 
+// Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys.  K = fx fy cx cy of Pinhole::toK(),
+// mDistCoef = the 4 or 5 OpenCV coefficients (float).
+inline void UndistortKeyPoints(const std::vector<ocv::KeyPoint>& mvKeys, const float K[4], const std::vector<float>& mDistCoef,
+                               std::vector<ocv::KeyPoint>& mvKeysUn, int device = 0) {
+  mvKeysUn.resize(mvKeys.size());
+  if (orbx_undistort_keypoints(device, reinterpret_cast<const orbx_keypoint*>(mvKeys.data()), (int)mvKeys.size(), K,
+                               mDistCoef.data(), (int)mDistCoef.size(), reinterpret_cast<orbx_keypoint*>(mvKeysUn.data())) !=
+      ORBX_OK)
+    throw std::runtime_error(std::string("UndistortKeyPoints: ") + orbx_last_error());
+}
+
+// Frame::ComputeImageBounds (src/Frame.cc:887-919): fills mnMinX, mnMinY, mnMaxX, mnMaxY.
+inline void ComputeImageBounds(int cols, int rows, const float K[4], const std::vector<float>& mDistCoef, float& mnMinX,
+                               float& mnMinY, float& mnMaxX, float& mnMaxY, int device = 0) {
+  float b[4];
+  if (orbx_compute_image_bounds(device, cols, rows, K, mDistCoef.data(), (int)mDistCoef.size(), b) != ORBX_OK)
+    throw std::runtime_error(std::string("ComputeImageBounds: ") + orbx_last_error());
+  mnMinX = b[0]; mnMinY = b[1]; mnMaxX = b[2]; mnMaxY = b[3];
+}
+
 }  // namespace ORB_SLAM3
 
 #endif  // ORBX_SHIM_ORBMATCHER_H

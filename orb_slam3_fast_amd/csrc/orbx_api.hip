@@ -1011,6 +1011,71 @@ int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const u
   return counts[0];
 }
 
+static int fill_undistort_args(UndistortArgs& a, const float K[4], const float* dist, int n_dist) {
+  if (!K || n_dist < 0 || n_dist > 14 || (n_dist && !dist)) return fail(ORBX_E_BADARG, "bad camera arguments");
+  if (!(K[0] != 0.f) || !(K[1] != 0.f)) return fail(ORBX_E_BADARG, "fx / fy must be non-zero");
+  for (int i = 12; i < n_dist; i++)
+    if (dist[i] != 0.f) return fail(ORBX_E_UNSUPPORTED, "tilted-sensor distortion terms are not supported");
+  for (int i = 0; i < 4; i++) a.K[i] = K[i];
+  for (int i = 0; i < 12; i++) a.k[i] = i < n_dist ? dist[i] : 0.f;
+  a.hasDist = n_dist > 0;
+  return ORBX_OK;
+}
+
+int orbx_undistort_keypoints(int device, const orbx_keypoint* kps, int n, const float K[4], const float* dist, int n_dist,
+                             orbx_keypoint* out) {
+  if (n < 0 || (n && (!kps || !out))) return fail(ORBX_E_BADARG, "bad argument");
+  UndistortArgs a{};
+  int rc = fill_undistort_args(a, K, dist, n_dist);
+  if (rc != ORBX_OK) return rc;
+  rc = set_device(device);  // a device routine even for the identity case: no GPU is an error, never a host path
+  if (rc != ORBX_OK) return rc;
+  if (out != kps && n) std::memmove(static_cast<void*>(out), kps, (size_t)n * sizeof(orbx_keypoint));
+  if (n == 0 || n_dist == 0 || dist[0] == 0.0f) return ORBX_OK;  // src/Frame.cc:854-857
+  ScratchBuf<orbx_keypoint> d;
+  hipError_t e = d.alloc(n);
+  if (e == hipSuccess) e = hipMemcpy(d.p, out, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice);
+  a.in = reinterpret_cast<const float*>(d.p);
+  a.out = reinterpret_cast<float*>(d.p);
+  a.n = n;
+  a.stride = sizeof(orbx_keypoint) / sizeof(float);
+  if (e == hipSuccess) e = launch_undistort(a, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(out, d.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost);
+  d.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
+int orbx_compute_image_bounds(int device, int cols, int rows, const float K[4], const float* dist, int n_dist,
+                              float bounds[4]) {
+  if (!bounds || cols <= 0 || rows <= 0) return fail(ORBX_E_BADARG, "bad argument");
+  UndistortArgs a{};
+  int rc = fill_undistort_args(a, K, dist, n_dist);
+  if (rc != ORBX_OK) return rc;
+  rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  if (n_dist == 0 || dist[0] == 0.0f) {  // src/Frame.cc:913-918
+    bounds[0] = 0.f; bounds[1] = 0.f; bounds[2] = (float)cols; bounds[3] = (float)rows;
+    return ORBX_OK;
+  }
+  float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+  ScratchBuf<float> d;
+  hipError_t e = d.alloc(8);
+  if (e == hipSuccess) e = hipMemcpy(d.p, c, sizeof(c), hipMemcpyHostToDevice);
+  a.in = d.p; a.out = d.p; a.n = 4; a.stride = 2;
+  if (e == hipSuccess) e = launch_undistort(a, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(c, d.p, sizeof(c), hipMemcpyDeviceToHost);
+  d.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  bounds[0] = std::min(c[0], c[4]);  // mnMinX (:907)
+  bounds[2] = std::max(c[2], c[6]);  // mnMaxX
+  bounds[1] = std::min(c[1], c[3]);  // mnMinY
+  bounds[3] = std::max(c[5], c[7]);  // mnMaxY
+  return ORBX_OK;
+}
+
 int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
                                    const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
                                    float min_y, float max_x, float max_y, float* prev_matched,

@@ -146,6 +146,17 @@ struct FisheyeBatchArgs {
   int* counters;            // [pairs][2] = nMatches, descMatches (pre-set to 0)
 };
 hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream_t s);
+
+// cv::undistortPoints (5 iterations, P = K) on n interleaved float pairs; k = 12 coefficients as doubles' source floats.
+struct UndistortArgs {
+  const float* in;
+  float* out;
+  int n, stride;  // stride in floats between consecutive points (2 = packed pairs, 7 = orbx_keypoint records)
+  float K[4];
+  float k[12];
+  int hasDist;
+};
+hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s);
 struct InitArgs {
   const orbx_keypoint *k1, *k2;
   const uint8_t *d1, *d2;

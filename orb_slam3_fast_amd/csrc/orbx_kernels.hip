@@ -2371,6 +2371,46 @@ hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ================================================================================================ undistort
+// cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it (src/Frame.cc:853-919): double
+// arithmetic in OpenCV's expression order, no contraction (TU flag) -- identical to the oracle's.
+__global__ __launch_bounds__(256) void k_undistort(UndistortArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  double k[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) k[j] = (double)a.k[j];
+  const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const double u = a.in[(long long)i * a.stride], v = a.in[(long long)i * a.stride + 1];
+  double x = (u - cx) * ifx, y = (v - cy) * ify;
+  const double x0 = x, y0 = y;
+  if (a.hasDist) {
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) {
+        x = (u - cx) * ifx;
+        y = (v - cy) * ify;
+        break;
+      }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+  }
+  const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+  a.out[(long long)i * a.stride] = (float)(xx * ww);
+  a.out[(long long)i * a.stride + 1] = (float)(yy * ww);
+}
+
+hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_undistort, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ================================================================================================ search init
 // Frame grid (64 x 48, PosInGrid rounds to the nearest cell, src/Frame.cc:833-844) as CSR lists with
 // ascending keypoint indices.
