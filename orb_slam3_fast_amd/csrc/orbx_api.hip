@@ -1198,11 +1198,12 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   ScratchBuf<float> ur, sf;
   ScratchBuf<orbx_map_point_view> mp;
   ScratchBuf<orbx_projected_point> pp;
-  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result, taker0, taker1, choice, flags;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
   chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(ur.alloc(n)); chk(sf.alloc(std::max(nlevels, 1)));
+  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40));
   chk(mp.alloc(nm)); chk(pp.alloc(nm)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
   chk(candOff.alloc(nm + 1)); chk(mt.alloc(n)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
   chk(result.alloc(2));
@@ -1235,13 +1236,28 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
     chk(candDist.alloc((size_t)std::max(total, 1)));
     a.candIdx = candIdx.p; a.candDist = candDist.p; a.candCap = std::max(total, 1);
   }
-  if (e == hipSuccess) chk(launch_proj_fill(a, nullptr));
+  a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.choice = choice.p; a.flags = flags.p;
+  // Resolve: rounds of the parallel fixed-point iteration (k_proj_round) until a round changes nothing; the one-wave
+  // serial walk stays as the fallback for a pathological claim chain (ORBX_PROJ_SERIAL=1 forces it, for the tests).
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  if (e == hipSuccess) chk(launch_proj_cands_fill(a, nullptr));
+  bool done = false;
+  if (!forceSerial && n_points > 0) {
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_proj_rounds(a, r, 4, nullptr));
+      int changed = 1;
+      if (e == hipSuccess) chk(hipMemcpy(&changed, flags.p, sizeof(int), hipMemcpyDeviceToHost));  // synchronises
+      done = changed == 0;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_proj_finish(a, 0, nullptr) : launch_proj_resolve_serial(a, nullptr));
   if (e == hipSuccess) chk(hipDeviceSynchronize());
   if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
   k.free(); d.free(); occ.free(); ur.free(); sf.free(); mp.free(); pp.free(); cellStart.free(); cellItems.free();
   candOff.free(); candIdx.free(); candDist.free(); mt.free(); mdist.free(); m21.free(); m12.free(); result.free();
+  taker0.free(); taker1.free(); choice.free(); flags.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
 }

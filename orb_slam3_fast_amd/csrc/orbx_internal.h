@@ -202,9 +202,17 @@ struct ProjArgs {
   int* candDist;                  // (dist << 8) | octave
   int candCap;
   int* result;                    // [0] = nmatches
+  // parallel fixed-point resolve (launch_proj_resolve_parallel): scratch
+  int* taker[2];                  // n2 each: smallest point index that (with observations) claims the keypoint
+  int* choice;                    // nmp: chosen keypoint (-1 none)
+  int* flags;                     // [0] changed in the last round, [1] accepted, [2] removed, [3..32] orientation histogram
 };
 hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s);   // grid + candidate counts + scan
 hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s);    // candidate fill + serial resolve
+hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s);                 // candidate fill only
+hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s);  // fixed-point rounds
+hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s);     // match / occupied / cull / count
+hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s);             // the one-wave walk (fallback)
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);

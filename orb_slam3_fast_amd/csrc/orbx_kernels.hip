@@ -2939,6 +2939,179 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
   if (lane == 0) a.result[0] = nmatches;
 }
 
+// ---- parallel resolve ------------------------------------------------------------------------------------------------
+// The serial walk (point im sees the keypoints claimed by points < im) is the unique fixed point of
+//   choice[im] = best candidate among keypoints k with !occupied0[k] and no accepted, observed point im' < im with
+//                choice[im'] == k.
+// Round r evaluates every point in parallel against the claims of round r - 1 (taker[k] = smallest claiming point
+// index).  By induction point t is final after round t + 1, and a round that changes nothing has reached the fixed
+// point, which is the serial result; on real inputs a handful of rounds suffice (a claim only matters when two points
+// compete for one keypoint).  Wave per point.
+__global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  const int* takerPrev = a.taker[prev];
+  int* takerNew = a.taker[prev ^ 1];
+  const int b = a.candOff[im], e = a.candOff[im + 1];
+  uint64_t best = ~0ull, second = ~0ull;  // (dist << 40) | (position << 8) | octave
+  for (int j = b + lane; j < e; j += 64) {
+    const int idx = a.candIdx[j];
+    if (a.occupied[idx] || (round_no > 0 && takerPrev[idx] < im)) continue;
+    const int dv = a.candDist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+  int chosen = -1;
+  if (best != ~0ull) {
+    const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
+    bool accept = false;
+    if (bestDist <= 100) {  // TH_HIGH
+      if (a.mode == 0) {
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
+        accept = !reject && (bestLevel != bestLevel2 || (float)bestDist <= lim);
+      } else {
+        accept = true;
+      }
+    }
+    if (accept) chosen = a.candIdx[b + bestPos];
+  }
+  if (lane == 0) {
+    if (round_no == 0 || a.choice[im] != chosen) a.flags[0] = 1;
+    a.choice[im] = chosen;
+    if (chosen >= 0 && (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations))
+      atomicMin(&takerNew[chosen], im);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a, int which, int first) {  // taker[which] = +inf
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.grid.n2; i += gridDim.x * 256) {
+    a.taker[which][i] = 0x7FFFFFFF;
+    if (first) a.match[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 33) {
+    if (threadIdx.x == 0) a.flags[0] = 0;                 // "changed in this round"
+    else if (first) a.flags[threadIdx.x] = 0;             // accepted, removed, histogram
+  }
+}
+
+// After convergence: match[k] = the LAST point that chose k (later assignments overwrite), occupied[k] = that point's
+// observation flag, orientation histogram of the accepted pairs (mode 1).
+__global__ __launch_bounds__(256) void k_proj_assign(ProjArgs a) {
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  bool acc = false;
+  if (im < a.nmp) {
+    const int k = a.choice[im];
+    if (k >= 0) {
+      acc = true;
+      atomicMax(&a.match[k], im);
+      if (a.mode == 1 && a.checkOri) {
+        float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[k].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+        if (bin == 30) bin = 0;
+        atomicAdd(&a.flags[3 + bin], 1);
+      }
+    }
+  }
+  const uint64_t m = __ballot(acc);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[1], __popcll(m));
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull(ProjArgs a) {
+  // occupied: set by the last chooser (a keypoint whose first chooser has observations has no later chooser)
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.grid.n2; k += gridDim.x * 256) {
+    const int im = a.match[k];
+    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-consistency cull (:1780-1800, :1920-1955)
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < 30; i++) {
+    const int s = a.flags[3 + i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+    ind3 = -1;
+  }
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  bool rem = false;
+  if (im < a.nmp) {
+    const int k = a.choice[im];
+    if (k >= 0) {
+      float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[k].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      if (bin != ind1 && bin != ind2 && bin != ind3) {
+        a.match[k] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL, even if a later point re-took the slot
+        rem = true;
+      }
+    }
+  }
+  const uint64_t m = __ballot(rem);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[2], __popcll(m));
+}
+
+__global__ void k_proj_result(ProjArgs a) { a.result[0] = a.flags[1] - a.flags[2]; }
+
+hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s) {
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  return hipGetLastError();
+}
+hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s) {
+  if (a.nmp <= 0) return hipSuccess;
+  const int gb = (a.grid.n2 + 255) / 256;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;  // round r reads taker[r & 1] (claims of round r - 1) and writes taker[(r & 1) ^ 1]
+    hipLaunchKernelGGL(k_proj_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_proj_round, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s) {
+  (void)last_round;
+  if (a.nmp > 0) {
+    hipLaunchKernelGGL(k_proj_assign, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_proj_cull, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, a);
+    if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull2, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(k_proj_result, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s) {
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a.grid);
   if (a.nmp > 0) {
