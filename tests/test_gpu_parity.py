@@ -432,3 +432,17 @@ def test_search_for_initialization(gpu, oracle):
         assert on > 50
         assert n == on and np.array_equal(m12, om12)
         assert np.array_equal(newprev.reshape(-1).view(np.uint32), oprev.reshape(-1).view(np.uint32))
+
+
+def test_projection_serial_fallback_in_fresh_process(gpu):
+    """The projection matchers resolve by parallel fixed-point rounds; the one-wave serial walk they fall back to must
+    give the same (golden) results.  ORBX_PROJ_SERIAL is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBX_PROJ_SERIAL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "projection and not fallback",
+                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
+                       cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
