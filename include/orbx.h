@@ -248,6 +248,38 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                     const orbx_projected_point* points, int n_points, int check_orientation,
                                     uint8_t* occupied, int32_t* match);
 
+/* Stereo-fisheye frames (F.Nleft != -1): the frame holds N = n_left + n_right keypoints (mvKeys then mvKeysRight), one
+ * descriptor row each in the same order, mGrid over the left and mGridRight over the right keypoints, and the stereo
+ * association mvLeftToRightMatch / mvRightToLeftMatch (orbx_fisheye_stereo_match).  orbx_map_point_right carries the
+ * right-camera members of MapPoint next to orbx_map_point_view (whose proj_xr is mTrackProjXR): mTrackProjYR,
+ * mTrackViewCosR, mnTrackScaleLevelR (-1 = none), mbTrackInViewR. */
+typedef struct orbx_map_point_right {
+  float proj_yr, view_cos_r;
+  int32_t predicted_level_r;
+  uint8_t in_view_r, pad_[3];
+} orbx_map_point_right;
+
+/* Replaces ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
+ * (src/ORBmatcher.cc:41-221) for F.Nleft != -1: left-camera search, right-camera search (radius not scaled by th, :144),
+ * and the assignments to the stereo partner slots (:126-132, :199-204).  occupied / match have N entries, the right
+ * keypoint i at n_left + i; semantics as orbx_search_by_projection.  Returns nmatches or an error. */
+int orbx_search_by_projection_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* map_points,
+                                      const orbx_map_point_right* map_points_right, int n_map_points, float th,
+                                      int far_points, float th_far_points, float nnratio, const int32_t* left_to_right,
+                                      const int32_t* right_to_left, uint8_t* occupied, int32_t* match);
+
+/* Replaces the matching part of ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono)
+ * (src/ORBmatcher.cc:1594-1806) for CurrentFrame.Nleft != -1: uv_right = the caller's projection of every point into the
+ * right camera (2 floats per point, :1705-1706); the right search runs only when the left one found candidates
+ * (:1651).  Returns nmatches after the rotation-consistency cull. */
+int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left,
+                                            int n_right, float min_x, float min_y, float max_x, float max_y,
+                                            const orbx_projected_point* points, const float* uv_right, int n_points,
+                                            int check_orientation, uint8_t* occupied, int32_t* match);
+
+
 /* ---- measurement ------------------------------------------------------------------------------------ */
 
 /* Per-kernel timing with HIP events recorded on the handle's own stream around every kernel launch (the

@@ -317,3 +317,37 @@ def image_bounds(cols, rows, K, dist):
     b = np.zeros(4, np.float32)
     lib().oro_image_bounds(int(cols), int(rows), _p(K), _p(dist), len(dist), _p(b))
     return b
+
+
+# ---- stereo-fisheye branches of the SearchByProjection matchers -----------------------------------------------------------
+MPR_DTYPE = np.dtype([("proj_yr", "<f4"), ("view_cos_r", "<f4"), ("predicted_level_r", "<i4"), ("in_view_r", "u1"),
+                      ("pad_", "u1", (3,))])
+assert MPR_DTYPE.itemsize == 16
+
+
+def search_by_projection_fisheye(k, desc, n_left, bounds, scale_factors, mps, mps_r, th, far, th_far, nnratio, l2r, r2l, occupied):
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    mps, mps_r = np.ascontiguousarray(mps, MP_DTYPE), np.ascontiguousarray(mps_r, MPR_DTYPE)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    l2r, r2l = np.ascontiguousarray(l2r, np.int32), np.ascontiguousarray(r2l, np.int32)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.zeros(len(k), np.int32)
+    n = lib().oro_search_by_projection_fisheye(_p(k), _p(desc), n_left, len(k) - n_left, C.c_float(bounds[0]), C.c_float(bounds[1]),
+                                               C.c_float(bounds[2]), C.c_float(bounds[3]), _p(sf), len(sf), _p(mps), _p(mps_r),
+                                               len(mps), C.c_float(th), int(far), C.c_float(th_far), C.c_float(nnratio), _p(l2r),
+                                               _p(r2l), _p(occ), _p(match))
+    return n, match, occ
+
+
+def search_by_projection_frame_fisheye(k, desc, n_left, bounds, pts, uv_right, check_ori, occupied):
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    pts = np.ascontiguousarray(pts, PP_DTYPE)
+    uv = np.ascontiguousarray(uv_right, np.float32).reshape(-1, 2)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.zeros(len(k), np.int32)
+    n = lib().oro_search_by_projection_frame_fisheye(_p(k), _p(desc), n_left, len(k) - n_left, C.c_float(bounds[0]),
+                                                     C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(pts),
+                                                     _p(uv), len(pts), int(check_ori), _p(occ), _p(match))
+    return n, match, occ

@@ -1161,4 +1161,161 @@ int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t
   return nmatches;
 }
 
+// ---- stereo-fisheye branches ------------------------------------------------------------------------------------------------
+int search_by_projection_map_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
+                                     const FrameGrid& gridR, const std::vector<float>& scaleFactors,
+                                     const std::vector<MapPointView>& mps, const std::vector<MapPointRight>& mpsR, float th,
+                                     bool bFarPoints, float thFarPoints, float nnratio, const std::vector<int>& leftToRight,
+                                     const std::vector<int>& rightToLeft, std::vector<uint8_t>& occupied,
+                                     std::vector<int>& match) {
+  const int TH_HIGH = 100;
+  int nmatches = 0;
+  match.assign(kps.size(), -1);
+  const std::vector<KeyPoint> kL(kps.begin(), kps.begin() + nLeft), kR(kps.begin() + nLeft, kps.end());
+  const bool bFactor = th != 1.0;
+  auto assign = [&](int slot, size_t iMP) {  // F.mvpMapPoints[slot] = pMP
+    match[slot] = (int)iMP;
+    occupied[slot] = mps[iMP].has_observations;
+  };
+  for (size_t iMP = 0; iMP < mps.size(); iMP++) {
+    const MapPointView& mp = mps[iMP];
+    const MapPointRight& mr = mpsR[iMP];
+    if (!mp.in_view && !mr.in_view_r) continue;               // :54
+    if (bFarPoints && mp.track_depth > thFarPoints) continue;  // :56
+    if (mp.bad) continue;                                      // :58
+    if (mp.in_view) {                                          // :60-138
+      const int level = mp.predicted_level;
+      float r = mp.view_cos > 0.998 ? 2.5f : 4.0f;
+      if (bFactor) r *= th;
+      const std::vector<int> cand = gridL.features_in_area(kL, mp.proj_x, mp.proj_y, r * scaleFactors[level], level - 1, level);
+      if (!cand.empty()) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+          if (occupied[idx]) continue;  // (no mvuRight gate: F.Nleft != -1, :90)
+          const int dist = descriptor_distance(mp.desc, desc + (size_t)idx * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist;
+            bestDist = dist;
+            bestLevel2 = bestLevel;
+            bestLevel = kL[idx].octave;
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = kL[idx].octave;
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;  // skips the right camera too, :120
+          if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+            assign(bestIdx, iMP);
+            if (leftToRight[bestIdx] != -1) {  // also the stereo observation in the right camera, :126-132
+              assign(leftToRight[bestIdx] + nLeft, iMP);
+              nmatches++;
+            }
+            nmatches++;
+          }
+        }
+      }
+    }
+    if (mr.in_view_r) {  // :141-213
+      const int level = mr.predicted_level_r;
+      if (level != -1) {
+        const float r = mr.view_cos_r > 0.998 ? 2.5f : 4.0f;  // not scaled by th, :144
+        const std::vector<int> cand = gridR.features_in_area(kR, mp.proj_xr, mr.proj_yr, r * scaleFactors[level], level - 1, level);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+          if (occupied[idx + nLeft]) continue;
+          const int dist = descriptor_distance(mp.desc, desc + (size_t)(idx + nLeft) * 32);
+          if (dist < bestDist) {
+            bestDist2 = bestDist;
+            bestDist = dist;
+            bestLevel2 = bestLevel;
+            bestLevel = kR[idx].octave;
+            bestIdx = idx;
+          } else if (dist < bestDist2) {
+            bestLevel2 = kR[idx].octave;
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist <= TH_HIGH) {
+          if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+          if (rightToLeft[bestIdx] != -1) {  // :199-204
+            assign(rightToLeft[bestIdx], iMP);
+            nmatches++;
+          }
+          assign(bestIdx + nLeft, iMP);
+          nmatches++;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+int search_by_projection_frame_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
+                                       const FrameGrid& gridR, const std::vector<ProjectedPoint>& pts, const float* uvRight,
+                                       bool checkOri, std::vector<uint8_t>& occupied, std::vector<int>& match) {
+  const int HISTO = 30, TH_HIGH = 100;
+  int nmatches = 0;
+  match.assign(kps.size(), -1);
+  const std::vector<KeyPoint> kL(kps.begin(), kps.begin() + nLeft), kR(kps.begin() + nLeft, kps.end());
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  auto vote = [&](float angleLF, float angleCF, int slot) {
+    float rot = angleLF - angleCF;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO) bin = 0;
+    rotHist[bin].push_back(slot);
+  };
+  for (size_t i = 0; i < pts.size(); i++) {
+    const ProjectedPoint& p = pts[i];
+    if (!p.valid) continue;
+    {
+      const std::vector<int> cand = gridL.features_in_area(kL, p.u, p.v, p.radius, p.min_level, p.max_level);
+      if (cand.empty()) continue;  // skips the right camera as well, :1651
+      int bestDist = 256, bestIdx2 = -1;
+      for (int i2 : cand) {
+        if (occupied[i2]) continue;  // (no mvuRight gate: CurrentFrame.Nleft != -1, :1667)
+        const int dist = descriptor_distance(p.desc, desc + (size_t)i2 * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+      if (bestDist <= TH_HIGH) {
+        match[bestIdx2] = (int)i;
+        occupied[bestIdx2] = p.has_observations;
+        nmatches++;
+        if (checkOri) vote(p.angle, kL[bestIdx2].angle, bestIdx2);
+      }
+    }
+    {  // :1703-1775
+      const std::vector<int> cand = gridR.features_in_area(kR, uvRight[2 * i], uvRight[2 * i + 1], p.radius, p.min_level, p.max_level);
+      int bestDist = 256, bestIdx2 = -1;
+      for (int i2 : cand) {
+        if (occupied[i2 + nLeft]) continue;
+        const int dist = descriptor_distance(p.desc, desc + (size_t)(i2 + nLeft) * 32);
+        if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+      }
+      if (bestDist <= TH_HIGH) {
+        match[bestIdx2 + nLeft] = (int)i;
+        occupied[bestIdx2 + nLeft] = p.has_observations;
+        nmatches++;
+        if (checkOri) vote(p.angle, kR[bestIdx2].angle, bestIdx2 + nLeft);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        match[idx] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 }  // namespace orbo

@@ -190,4 +190,28 @@ int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t
                                const FrameGrid& grid, const std::vector<ProjectedPoint>& pts, bool checkOri,
                                std::vector<uint8_t>& occupied, std::vector<int>& match);
 
+// ---- stereo-fisheye (F.Nleft != -1) branches of the two SearchByProjection matchers ---------------------------------------
+// The frame holds N = nLeft + nRight keypoints (mvKeys then mvKeysRight), descriptors in the same order, two grids
+// (mGrid over the left keypoints, mGridRight over the right ones with indices relative to mvKeysRight), and the stereo
+// association mvLeftToRightMatch / mvRightToLeftMatch.  MapPointRight carries the right-camera members
+// (mTrackProjXR = MapPointView::proj_xr, mTrackProjYR, mTrackViewCosR, mnTrackScaleLevelR, mbTrackInViewR).
+struct MapPointRight {
+  float proj_yr, view_cos_r;
+  int32_t predicted_level_r;
+  uint8_t in_view_r, pad_[3];
+};
+static_assert(sizeof(MapPointRight) == 16, "POD layout shared with orbx_map_point_right");
+// src/ORBmatcher.cc:41-221 with F.Nleft != -1.  occupied / match have N entries (right slots at nLeft + i).
+int search_by_projection_map_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
+                                     const FrameGrid& gridR, const std::vector<float>& scaleFactors,
+                                     const std::vector<MapPointView>& mps, const std::vector<MapPointRight>& mpsR, float th,
+                                     bool bFarPoints, float thFarPoints, float nnratio, const std::vector<int>& leftToRight,
+                                     const std::vector<int>& rightToLeft, std::vector<uint8_t>& occupied,
+                                     std::vector<int>& match);
+// src/ORBmatcher.cc:1594-1806 with CurrentFrame.Nleft != -1: uvRight = the projection of each point into the right camera
+// (2 floats per point, :1705-1706).
+int search_by_projection_frame_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
+                                       const FrameGrid& gridR, const std::vector<ProjectedPoint>& pts, const float* uvRight,
+                                       bool checkOri, std::vector<uint8_t>& occupied, std::vector<int>& match);
+
 }  // namespace orbo

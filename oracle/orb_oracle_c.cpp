@@ -221,6 +221,44 @@ int oro_fisheye_stereo_match(const KeyPoint* kL, const uint8_t* dL, int nL, int 
   return nm;
 }
 
+int oro_search_by_projection_fisheye(const KeyPoint* k, const uint8_t* desc, int nLeft, int nRight, float minX, float minY,
+                                      float maxX, float maxY, const float* scaleFactors, int nlevels, const MapPointView* mps,
+                                      const MapPointRight* mpsR, int nmp, float th, int bFarPoints, float thFarPoints,
+                                      float nnratio, const int* l2r, const int* r2l, uint8_t* occupied, int* match) {
+  const int n = nLeft + nRight;
+  std::vector<KeyPoint> a(k, k + n), kl(k, k + nLeft), kr(k + nLeft, k + n);
+  FrameGrid gl, gr;
+  gl.build(kl, minX, minY, maxX, maxY);
+  gr.build(kr, minX, minY, maxX, maxY);
+  std::vector<float> sf(scaleFactors, scaleFactors + nlevels);
+  std::vector<MapPointView> m(mps, mps + nmp);
+  std::vector<MapPointRight> mr(mpsR, mpsR + nmp);
+  std::vector<int> a12(l2r, l2r + nLeft), a21(r2l, r2l + nRight), mt;
+  std::vector<uint8_t> occ(occupied, occupied + n);
+  const int nm = search_by_projection_map_fisheye(a, desc, nLeft, gl, gr, sf, m, mr, th, bFarPoints != 0, thFarPoints, nnratio, a12,
+                                                  a21, occ, mt);
+  std::memcpy(occupied, occ.data(), n);
+  std::memcpy(match, mt.data(), n * sizeof(int));
+  return nm;
+}
+
+int oro_search_by_projection_frame_fisheye(const KeyPoint* k, const uint8_t* desc, int nLeft, int nRight, float minX, float minY,
+                                            float maxX, float maxY, const ProjectedPoint* pts, const float* uvRight, int npts,
+                                            int checkOri, uint8_t* occupied, int* match) {
+  const int n = nLeft + nRight;
+  std::vector<KeyPoint> a(k, k + n), kl(k, k + nLeft), kr(k + nLeft, k + n);
+  FrameGrid gl, gr;
+  gl.build(kl, minX, minY, maxX, maxY);
+  gr.build(kr, minX, minY, maxX, maxY);
+  std::vector<ProjectedPoint> p(pts, pts + npts);
+  std::vector<uint8_t> occ(occupied, occupied + n);
+  std::vector<int> mt;
+  const int nm = search_by_projection_frame_fisheye(a, desc, nLeft, gl, gr, p, uvRight, checkOri != 0, occ, mt);
+  std::memcpy(occupied, occ.data(), n);
+  std::memcpy(match, mt.data(), n * sizeof(int));
+  return nm;
+}
+
 void oro_undistort_keypoints(const KeyPoint* k, int n, const float* K, const float* dist, int n_dist, KeyPoint* out) {
   std::vector<KeyPoint> a(k, k + n), o;
   undistort_keypoints(a, K, dist, n_dist, o);

@@ -30,6 +30,9 @@ PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"
                      ("max_level", "<i4"), ("valid", "u1"), ("has_observations", "u1"), ("pad_", "u1", (2,)),
                      ("desc", "u1", (32,))])   # orbx_projected_point
 assert PP_DTYPE.itemsize == 64
+MPR_DTYPE = np.dtype([("proj_yr", "<f4"), ("view_cos_r", "<f4"), ("predicted_level_r", "<i4"), ("in_view_r", "u1"),
+                      ("pad_", "u1", (3,))])   # orbx_map_point_right
+assert MPR_DTYPE.itemsize == 16
 
 
 class OrbxError(RuntimeError):
@@ -74,6 +77,8 @@ def lib():
         L.orbx_fisheye_stereo_match.argtypes = [i, vp, vp, i, i, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, vp]
         L.orbx_fisheye_stereo_match_batch.argtypes = [vp, i, vp, i, i, vp]
         L.orbx_undistort_keypoints.argtypes = [i, vp, i, vp, vp, i, vp]
+        L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
+        L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
         L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
         L.orbx_fisheye_results_device.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orbx_fisheye_download.argtypes = [vp, i, vp, vp, vp, vp, i, i, vp]
@@ -411,6 +416,37 @@ class ORBmatcher:
         n = _check(lib().orbx_search_by_projection_frame(
             self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
             bounds[3], _p(pp), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
+        return n, match, occ
+
+    def SearchByProjectionFisheye(self, kps, desc, n_left, bounds, scaleFactors, mapPoints, mapPointsRight, leftToRight,
+                                  rightToLeft, occupied, th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """src/ORBmatcher.cc:41-221 with F.Nleft != -1: kps / desc = mvKeys then mvKeysRight (N = n_left + n_right rows),
+        mapPointsRight = MPR_DTYPE records.  Returns (nmatches, match[N], updated occupied[N])."""
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        mp, mr = np.ascontiguousarray(mapPoints, MP_DTYPE), np.ascontiguousarray(mapPointsRight, MPR_DTYPE)
+        sf = np.ascontiguousarray(scaleFactors, np.float32)
+        l2r, r2l = np.ascontiguousarray(leftToRight, np.int32), np.ascontiguousarray(rightToLeft, np.int32)
+        occ = np.ascontiguousarray(occupied, np.uint8).copy()
+        match = np.full(len(k), -1, np.int32)
+        n = _check(lib().orbx_search_by_projection_fisheye(
+            self.device, _p(k), _p(d), int(n_left), len(k) - int(n_left), bounds[0], bounds[1], bounds[2], bounds[3], _p(sf),
+            len(sf), _p(mp), _p(mr), len(mp), float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, _p(l2r), _p(r2l),
+            _p(occ), _p(match)))
+        return n, match, occ
+
+    def SearchByProjectionFrameFisheye(self, kps, desc, n_left, bounds, projectedPoints, uvRight, occupied):
+        """src/ORBmatcher.cc:1594-1806 with CurrentFrame.Nleft != -1; uvRight[i] = projection of point i into the right
+        camera.  Returns (nmatches, match[N], updated occupied[N])."""
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        pp = np.ascontiguousarray(projectedPoints, PP_DTYPE)
+        uv = np.ascontiguousarray(uvRight, np.float32).reshape(-1, 2)
+        occ = np.ascontiguousarray(occupied, np.uint8).copy()
+        match = np.full(len(k), -1, np.int32)
+        n = _check(lib().orbx_search_by_projection_frame_fisheye(
+            self.device, _p(k), _p(d), int(n_left), len(k) - int(n_left), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp),
+            _p(uv), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):

@@ -90,6 +90,36 @@ class ORBmatcher {
     return n;
   }
 
+  // The same two searches for stereo-fisheye frames (F.Nleft != -1, src/ORBmatcher.cc:41-221 / :1594-1806): F holds
+  // N = Nleft + Nright keypoints (mvKeys then mvKeysRight; FrameView::mvKeysUn points at that array, N at the total),
+  // vpMapPointsRight the right-camera members of every MapPoint, and the stereo association of the frame.
+  int SearchByProjection(const FrameView& F, int Nleft, const std::vector<orbx_map_point_view>& vpMapPoints,
+                         const std::vector<orbx_map_point_right>& vpMapPointsRight, const std::vector<int>& mvLeftToRightMatch,
+                         const std::vector<int>& mvRightToLeftMatch, std::vector<uint8_t>& occupied, std::vector<int>& match,
+                         const float th = 3, const bool bFarPoints = false, const float thFarPoints = 50.0f) {
+    if (vpMapPoints.size() != vpMapPointsRight.size()) throw std::invalid_argument("one right-camera record per map point");
+    match.assign(F.N, -1);
+    const int n = orbx_search_by_projection_fisheye(
+        device_, reinterpret_cast<const orbx_keypoint*>(F.mvKeysUn), F.mDescriptors, Nleft, F.N - Nleft, F.mnMinX, F.mnMinY,
+        F.mnMaxX, F.mnMaxY, F.mvScaleFactors, F.nLevels, vpMapPoints.data(), vpMapPointsRight.data(), (int)vpMapPoints.size(), th,
+        bFarPoints ? 1 : 0, thFarPoints, mfNNratio, mvLeftToRightMatch.data(), mvRightToLeftMatch.data(), occupied.data(),
+        match.data());
+    if (n < 0) throw std::runtime_error(std::string("SearchByProjection: ") + orbx_last_error());
+    return n;
+  }
+  int SearchByProjection(const FrameView& CurrentFrame, int Nleft, const std::vector<orbx_projected_point>& lastFramePoints,
+                         const std::vector<float>& uvRight, std::vector<uint8_t>& occupied, std::vector<int>& match) {
+    if (uvRight.size() != 2 * lastFramePoints.size()) throw std::invalid_argument("two right-camera coordinates per point");
+    match.assign(CurrentFrame.N, -1);
+    const int n = orbx_search_by_projection_frame_fisheye(
+        device_, reinterpret_cast<const orbx_keypoint*>(CurrentFrame.mvKeysUn), CurrentFrame.mDescriptors, Nleft,
+        CurrentFrame.N - Nleft, CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mnMaxX, CurrentFrame.mnMaxY,
+        lastFramePoints.data(), uvRight.data(), (int)lastFramePoints.size(), mbCheckOrientation ? 1 : 0, occupied.data(),
+        match.data());
+    if (n < 0) throw std::runtime_error(std::string("SearchByProjection: ") + orbx_last_error());
+    return n;
+  }
+
  protected:
   float mfNNratio;
   bool mbCheckOrientation;

@@ -1291,6 +1291,157 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
+namespace {
+// One side (left or right camera) of a stereo-fisheye projection search: grid + candidate lists on the device.
+struct ProjSide {
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, result;
+  ScratchBuf<orbx_map_point_view> mp;
+  ScratchBuf<orbx_projected_point> pp;
+  ProjArgs a{};
+  void release() {
+    cellStart.free(); cellItems.free(); candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
+    m12.free(); result.free(); mp.free(); pp.free();
+  }
+};
+
+int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
+                                      const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, int n_points,
+                                      float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                                      const int32_t* l2r, const int32_t* r2l, uint8_t* occupied, int32_t* match) {
+  const int mode = ptsL ? 1 : 0, n = n_left + n_right;
+  if (n == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<orbx_keypoint> k;
+  ScratchBuf<uint8_t> d, occ;
+  ScratchBuf<float> sf;
+  ScratchBuf<int> a12, a21, mt, res;
+  ProjSide S[2];
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  const int nm = std::max(n_points, 1);
+  chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(sf.alloc(std::max(nlevels, 1)));
+  chk(a12.alloc(std::max(n_left, 1))); chk(a21.alloc(std::max(n_right, 1))); chk(mt.alloc(n)); chk(res.alloc(2));
+  if (e == hipSuccess) chk(hipMemcpy(k.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(d.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(occ.p, occupied, n, hipMemcpyHostToDevice));
+  if (e == hipSuccess && scale_factors) chk(hipMemcpy(sf.p, scale_factors, nlevels * sizeof(float), hipMemcpyHostToDevice));
+  if (e == hipSuccess && l2r && n_left) chk(hipMemcpy(a12.p, l2r, (size_t)n_left * sizeof(int), hipMemcpyHostToDevice));
+  if (e == hipSuccess && r2l && n_right) chk(hipMemcpy(a21.p, r2l, (size_t)n_right * sizeof(int), hipMemcpyHostToDevice));
+  for (int side = 0; side < 2 && e == hipSuccess; side++) {
+    ProjSide& P = S[side];
+    const int ns = side ? n_right : n_left, first = side ? n_left : 0;
+    chk(P.cellStart.alloc(64 * 48 + 1)); chk(P.cellItems.alloc(std::max(ns, 1))); chk(P.candOff.alloc(nm + 1));
+    chk(P.mdist.alloc(std::max(ns, 1))); chk(P.m21.alloc(std::max(ns, 1))); chk(P.m12.alloc(1)); chk(P.result.alloc(2));
+    chk(P.mp.alloc(nm)); chk(P.pp.alloc(nm));
+    if (e == hipSuccess && n_points && mode == 0)
+      chk(hipMemcpy(P.mp.p, side ? viewsR : viewsL, (size_t)n_points * sizeof(orbx_map_point_view), hipMemcpyHostToDevice));
+    if (e == hipSuccess && n_points && mode == 1)
+      chk(hipMemcpy(P.pp.p, side ? ptsR : ptsL, (size_t)n_points * sizeof(orbx_projected_point), hipMemcpyHostToDevice));
+    ProjArgs& a = P.a;
+    a.grid.k2 = k.p + first; a.grid.n2 = ns; a.grid.n1 = 0;
+    a.grid.minX = min_x; a.grid.minY = min_y;
+    a.grid.invW = 64.f / (max_x - min_x);
+    a.grid.invH = 48.f / (max_y - min_y);
+    a.grid.cellStart = P.cellStart.p; a.grid.cellItems = P.cellItems.p; a.grid.matchedDist = P.mdist.p;
+    a.grid.matches21 = P.m21.p; a.grid.matches12 = P.m12.p; a.grid.result = P.result.p; a.grid.candOff = P.candOff.p;
+    a.grid.candCap = 1 << 30;
+    a.desc = d.p + (size_t)first * 32; a.uRight = nullptr;  // no mvuRight gate when F.Nleft != -1 (:90, :1667)
+    a.scale = sf.p; a.mps = P.mp.p; a.pts = P.pp.p; a.nmp = n_points; a.mode = mode; a.checkOri = check_ori;
+    a.th = side ? 1.0f : th;  // the right-camera radius is not scaled by th (:144)
+    a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
+    a.occupied = occ.p + first; a.match = mt.p + first; a.candOff = P.candOff.p; a.result = P.result.p; a.candCap = 1 << 30;
+    if (ns > 0) chk(launch_proj_count(a, nullptr));
+    else chk(hipMemset(P.candOff.p, 0, (size_t)(nm + 1) * sizeof(int)));
+  }
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  for (int side = 0; side < 2 && e == hipSuccess; side++) {
+    ProjSide& P = S[side];
+    int total = 0;
+    if (n_points) chk(hipMemcpy(&total, P.candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
+    chk(P.candIdx.alloc((size_t)std::max(total, 1)));
+    chk(P.candDist.alloc((size_t)std::max(total, 1)));
+    P.a.candIdx = P.candIdx.p; P.a.candDist = P.candDist.p; P.a.candCap = std::max(total, 1);
+    if (e == hipSuccess && (side ? n_right : n_left) > 0) chk(launch_proj_cands_fill(P.a, nullptr));
+  }
+  ProjFeArgs f{};
+  f.offL = S[0].candOff.p; f.idxL = S[0].candIdx.p; f.distL = S[0].candDist.p;
+  f.offR = S[1].candOff.p; f.idxR = S[1].candIdx.p; f.distR = S[1].candDist.p;
+  f.nLeft = n_left; f.n = n; f.nmp = n_points; f.mode = mode; f.checkOri = check_ori; f.nnratio = nnratio;
+  f.mps = S[0].mp.p; f.pts = S[0].pp.p; f.kps = k.p; f.l2r = a12.p; f.r2l = a21.p;
+  f.occupied = occ.p; f.match = mt.p; f.result = res.p;
+  int result[2] = {0, 0};
+  if (e == hipSuccess) chk(launch_proj_resolve_fisheye(f, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy(result, res.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
+  k.free(); d.free(); occ.free(); sf.free(); a12.free(); a21.free(); mt.free(); res.free();
+  S[0].release(); S[1].release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return result[0];
+}
+}  // namespace
+
+int orbx_search_by_projection_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* map_points,
+                                      const orbx_map_point_right* map_points_right, int n_map_points, float th,
+                                      int far_points, float th_far_points, float nnratio, const int32_t* left_to_right,
+                                      const int32_t* right_to_left, uint8_t* occupied, int32_t* match) {
+  const int n = n_left + n_right;
+  if (n_left < 0 || n_right < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors ||
+      (n && (!kps || !desc || !occupied || !match)) || (n_map_points && (!map_points || !map_points_right)) ||
+      (n_left && !left_to_right) || (n_right && !right_to_left))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_left; i++)
+    if (left_to_right[i] < -1 || left_to_right[i] >= n_right) return fail(ORBX_E_BADARG, "left_to_right entry out of range");
+  for (int i = 0; i < n_right; i++)
+    if (right_to_left[i] < -1 || right_to_left[i] >= n_left) return fail(ORBX_E_BADARG, "right_to_left entry out of range");
+  // the right camera as a second list of views: (mTrackProjXR, mTrackProjYR), mTrackViewCosR, mnTrackScaleLevelR
+  std::vector<orbx_map_point_view> left(map_points, map_points + n_map_points), right(map_points, map_points + n_map_points);
+  for (int i = 0; i < n_map_points; i++) {
+    const orbx_map_point_right& r = map_points_right[i];
+    if ((left[i].in_view && (left[i].predicted_level < 0 || left[i].predicted_level >= nlevels)) ||
+        (r.in_view_r && (r.predicted_level_r < -1 || r.predicted_level_r >= nlevels)))
+      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+    if (!left[i].in_view) left[i].predicted_level = 0;
+    right[i].proj_x = map_points[i].proj_xr;
+    right[i].proj_y = r.proj_yr;
+    right[i].view_cos = r.view_cos_r;
+    right[i].predicted_level = r.predicted_level_r < 0 ? 0 : r.predicted_level_r;
+    right[i].in_view = (r.in_view_r && r.predicted_level_r != -1) ? 1 : 0;  // :141-143
+    // `if (!mbTrackInView && !mbTrackInViewR) continue` (:54) is implied: both lists stay empty
+  }
+  static const orbx_map_point_view dummy{};
+  return search_by_projection_fisheye_impl(device, kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, scale_factors, nlevels,
+                                           n_map_points ? left.data() : &dummy, n_map_points ? right.data() : &dummy, nullptr,
+                                           nullptr, n_map_points, th, far_points, th_far_points, nnratio, 0, left_to_right,
+                                           right_to_left, occupied, match);
+}
+
+int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left,
+                                            int n_right, float min_x, float min_y, float max_x, float max_y,
+                                            const orbx_projected_point* points, const float* uv_right, int n_points,
+                                            int check_orientation, uint8_t* occupied, int32_t* match) {
+  const int n = n_left + n_right;
+  if (n_left < 0 || n_right < 0 || n_points < 0 || (n && (!kps || !desc || !occupied || !match)) ||
+      (n_points && (!points || !uv_right)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_points > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 projected points");
+  std::vector<orbx_projected_point> right(points, points + n_points);
+  for (int i = 0; i < n_points; i++) {
+    right[i].u = uv_right[2 * i];
+    right[i].v = uv_right[2 * i + 1];
+  }
+  static const orbx_projected_point dummy{};
+  return search_by_projection_fisheye_impl(device, kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
+                                           nullptr, n_points ? points : &dummy, n_points ? right.data() : &dummy, n_points, 1.0f,
+                                           0, 0.f, 0.f, check_orientation, nullptr, nullptr, occupied, match);
+}
+
 int orbx_profile_enable(orbx_extractor* ex, int on) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
   // on: 0 = off, 1 = every kernel launch, 2 + s = only launches of stage s (ORBX_STAGE_*)

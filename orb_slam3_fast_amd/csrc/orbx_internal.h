@@ -213,6 +213,22 @@ hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s);            
 hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s);  // fixed-point rounds
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s);     // match / occupied / cull / count
 hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s);             // the one-wave walk (fallback)
+
+// Stereo-fisheye resolve: one wave walks the points, left then right camera, with the partner-slot assignments.
+struct ProjFeArgs {
+  const int *offL, *idxL, *distL;   // candidate lists against the left / right grid (k_proj_cands)
+  const int *offR, *idxR, *distR;
+  int nLeft, n, nmp, mode, checkOri;
+  float nnratio;
+  const orbx_map_point_view* mps;   // mode 0
+  const orbx_projected_point* pts;  // mode 1
+  const orbx_keypoint* kps;         // n = nLeft + nRight
+  const int *l2r, *r2l;             // mode 0
+  uint8_t* occupied;                // n
+  int* match;                       // n
+  int* result;
+};
+hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);

@@ -3112,6 +3112,174 @@ hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- stereo-fisheye resolve (F.Nleft != -1) ------------------------------------------------------------------------------
+// best / second-best (dist << 40 | position << 8 | octave) over the still-free candidates of one point, all lanes.
+__device__ __forceinline__ void proj_best2(const int* off, const int* idx, const int* dist, const uint8_t* occ, int im, int lane,
+                                           uint64_t& best, uint64_t& second, int& b) {
+  b = off[im];
+  const int e = off[im + 1];
+  best = ~0ull;
+  second = ~0ull;
+  for (int j = b + lane; j < e; j += 64) {
+    if (occ[idx[j]]) continue;
+    const int dv = dist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_proj_resolve_fe(ProjFeArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* binIdx = reinterpret_cast<int*>(smem);  // mode 1: (bin << 24 | slot) per accepted match
+  const int lane = threadIdx.x;
+  for (int i = lane; i < a.n; i += 64) a.match[i] = -1;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
+  __syncthreads();
+  int nmatches = 0, nBin = 0;
+  const uint8_t* occL = a.occupied;
+  const uint8_t* occR = a.occupied + a.nLeft;
+  for (int im = 0; im < a.nmp; im++) {
+    const uint8_t obs = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+    auto assign = [&](int slot) {  // F.mvpMapPoints[slot] = pMP (lane 0 writes; the barrier below publishes it)
+      if (lane == 0) {
+        a.match[slot] = im;
+        a.occupied[slot] = obs;
+      }
+    };
+    auto vote = [&](int slot) {
+      if (a.mode == 1 && a.checkOri) {
+        if (lane == 0) {
+          float rot = __fsub_rn(a.pts[im].angle, a.kps[slot].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          binIdx[nBin] = (bin << 24) | slot;
+          hist[bin]++;
+        }
+        nBin++;
+      }
+    };
+    bool skipRight = false;
+    // ---- left camera (:60-138 / :1639-1701)
+    if (a.offL[im + 1] > a.offL[im]) {
+      uint64_t best, second;
+      int b;
+      proj_best2(a.offL, a.idxL, a.distL, occL, im, lane, best, second, b);
+      if (best != ~0ull && (int)(best >> 40) <= 100) {
+        const int bestDist = (int)(best >> 40), bestIdx = a.idxL[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+        if (a.mode == 0) {
+          const int bestLevel = (int)(best & 0xFF);
+          const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+          const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+          const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+          if (bestLevel == bestLevel2 && (float)bestDist > lim) {
+            skipRight = true;  // `continue`, :120
+          } else if (bestLevel != bestLevel2 || (float)bestDist <= lim) {
+            assign(bestIdx);
+            nmatches++;
+            const int partner = a.l2r[bestIdx];
+            if (partner != -1) {
+              assign(partner + a.nLeft);
+              nmatches++;
+            }
+          }
+        } else {
+          assign(bestIdx);
+          nmatches++;
+          vote(bestIdx);
+        }
+      }
+    } else if (a.mode == 1) {
+      skipRight = true;  // `if (vIndices2.empty()) continue;`, :1651
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- right camera (:141-213 / :1703-1775)
+    if (!skipRight && a.offR[im + 1] > a.offR[im]) {
+      uint64_t best, second;
+      int b;
+      proj_best2(a.offR, a.idxR, a.distR, occR, im, lane, best, second, b);
+      if (best != ~0ull && (int)(best >> 40) <= 100) {
+        const int bestDist = (int)(best >> 40), bestIdx = a.idxR[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+        bool accept = true;
+        if (a.mode == 0) {
+          const int bestLevel = (int)(best & 0xFF);
+          const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+          const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+          accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2));
+        }
+        if (accept) {
+          if (a.mode == 0) {
+            const int partner = a.r2l[bestIdx];
+            if (partner != -1) {
+              assign(partner);
+              nmatches++;
+            }
+          }
+          assign(bestIdx + a.nLeft);
+          nmatches++;
+          if (a.mode == 1) vote(bestIdx + a.nLeft);
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (a.mode == 1 && a.checkOri) {
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < nBin; i += 64) {
+      const int bn = binIdx[i] >> 24, slot = binIdx[i] & 0xFFFFFF;
+      if (bn != ind1 && bn != ind2 && bn != ind3) {
+        a.match[slot] = -1;
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s) {
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(2 * a.nmp + 4) * 4 : 16;  // up to two votes per point
+  hipLaunchKernelGGL(k_proj_resolve_fe, dim3(1), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a.grid);
   if (a.nmp > 0) {

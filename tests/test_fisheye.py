@@ -247,3 +247,103 @@ def test_hip_fisheye_batch_on_device_results(oracle):
         # and it is the same routine as the host-array entry point
         host = orbx.ComputeStereoFishEyeMatches(kL, dL, mL, kR, dR, mR, rig, sigma2)
         assert host[0] == n and np.array_equal(host[2], hip[2]) and host[4].tobytes() == hip[4].tobytes()
+
+
+# ---------------------------------------------------------------------------------------------- SearchByProjection, Nleft != -1
+def _fisheye_frame(mod, seed, w=512, h=512):
+    """A stereo-fisheye frame as the tracker sees it: N = nL + nR keypoints (mvKeys then mvKeysRight) from the synthetic
+    stereo pair, partner arrays from a brute-force association, and seeded map-point / projected-point views that
+    project near left keypoints (left camera) and near their partners or random right keypoints (right camera)."""
+    rng = np.random.default_rng(1000 + seed)
+    L, R = synth.stereo_pair(w, h, 140 + seed)
+    from oracle import oracle_py as O
+    eL, eR = O.OracleExtractor(800), O.OracleExtractor(800)
+    _, kL, dL = eL.extract(L)
+    _, kR, dR = eR.extract(R)
+    nL, nR = len(kL), len(kR)
+    idx, dist, ok = O.bf_knn2(dL, dR)
+    l2r = np.where(ok.astype(bool) & (rng.random(nL) < 0.8), idx[:, 0], -1).astype(np.int32)
+    r2l = np.full(nR, -1, np.int32)
+    for i in np.nonzero(l2r >= 0)[0]:
+        r2l[l2r[i]] = i
+    kps = np.concatenate([kL, kR])
+    desc = np.concatenate([dL, dR])
+    sf = eL.tables()["scale"]
+    n = 900
+    src = rng.integers(0, nL, n)                 # the left keypoint each view is derived from
+    flips = rng.random((n, 32, 8)) < 0.05
+    vdesc = dL[src] ^ np.packbits(flips, axis=2).reshape(n, 32)
+    part = np.where(l2r[src] >= 0, l2r[src], rng.integers(0, nR, n))
+    mps = np.zeros(n, mod.MP_DTYPE)
+    mps["proj_x"], mps["proj_y"] = kL["x"][src] + rng.normal(0, 2.5, n), kL["y"][src] + rng.normal(0, 2.5, n)
+    mps["proj_xr"] = kR["x"][part] + rng.normal(0, 2.5, n)
+    mps["view_cos"], mps["track_depth"] = rng.choice([0.9, 0.9985], n), rng.uniform(1, 80, n)
+    mps["predicted_level"] = np.clip(kL["octave"][src] + rng.integers(-1, 2, n), 0, 7)
+    mps["in_view"], mps["bad"], mps["has_observations"] = rng.random(n) < 0.8, rng.random(n) < 0.05, rng.random(n) < 0.7
+    mps["desc"] = vdesc
+    mpr = np.zeros(n, mod.MPR_DTYPE)
+    mpr["proj_yr"], mpr["view_cos_r"] = kR["y"][part] + rng.normal(0, 2.5, n), rng.choice([0.9, 0.9985], n)
+    mpr["predicted_level_r"] = np.where(rng.random(n) < 0.1, -1, np.clip(kR["octave"][part] + rng.integers(-1, 2, n), 0, 7))
+    mpr["in_view_r"] = rng.random(n) < 0.7
+    pts = np.zeros(n, mod.PP_DTYPE)
+    pts["u"], pts["v"] = mps["proj_x"], mps["proj_y"]
+    pts["radius"], pts["angle"] = (np.float32(7.0) * sf[kL["octave"][src]]), kL["angle"][src] + rng.normal(0, 4, n)
+    pts["min_level"], pts["max_level"] = kL["octave"][src] - 1, kL["octave"][src] + 1
+    pts["valid"], pts["has_observations"], pts["desc"] = rng.random(n) < 0.85, mps["has_observations"], vdesc
+    uvr = np.stack([mps["proj_xr"], mpr["proj_yr"]], 1).astype(np.float32)
+    occ = (rng.random(nL + nR) < 0.05).astype(np.uint8)
+    return dict(kps=kps, desc=desc, nL=nL, sf=sf, mps=mps, mpr=mpr, pts=pts, uvr=uvr, l2r=l2r, r2l=r2l, occ=occ,
+                bounds=(0.0, 0.0, float(w), float(h)))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_oracle_fisheye_projection_semantics(oracle, seed):
+    f = _fisheye_frame(oracle, seed)
+    nL = f["nL"]
+    n, m, occ = oracle.search_by_projection_fisheye(f["kps"], f["desc"], nL, f["bounds"], f["sf"], f["mps"], f["mpr"], 3.0, True, 60.0,
+                                                    0.8, f["l2r"], f["r2l"], f["occ"])
+    assert n > 150 and (m[:nL] >= 0).sum() > 50 and (m[nL:] >= 0).sum() > 50
+    # a left keypoint taken by a point takes its stereo partner along (unless a later point re-took the partner slot)
+    both = [i for i in np.nonzero(m[:nL] >= 0)[0] if f["l2r"][i] >= 0 and m[nL + f["l2r"][i]] == m[i]]
+    assert len(both) > 20
+    # without partners and with the right camera switched off the left half equals the pinhole routine without mvuRight
+    off = f["mpr"].copy()
+    off["in_view_r"] = 0
+    none_l, none_r = np.full(nL, -1, np.int32), np.full(len(f["kps"]) - nL, -1, np.int32)
+    n1, m1, o1 = oracle.search_by_projection_fisheye(f["kps"], f["desc"], nL, f["bounds"], f["sf"], f["mps"], off, 3.0, True, 60.0, 0.8,
+                                                     none_l, none_r, f["occ"])
+    n2, m2, o2 = oracle.search_by_projection(f["kps"][:nL], f["desc"][:nL], None, f["bounds"], f["sf"], f["mps"], 3.0, True, 60.0, 0.8,
+                                             f["occ"][:nL])
+    assert n1 == n2 and np.array_equal(m1[:nL], m2) and (m1[nL:] == -1).all() and np.array_equal(o1[:nL], o2)
+    nf, mf, of = oracle.search_by_projection_frame_fisheye(f["kps"], f["desc"], nL, f["bounds"], f["pts"], f["uvr"], True, f["occ"])
+    assert nf > 100 and (mf[nL:] >= 0).sum() > 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_hip_fisheye_projection_matchers_parity(oracle, seed):
+    import orb_slam3_fast_amd as orbx
+    f = _fisheye_frame(orbx, seed)
+    m = orbx.ORBmatcher(0.8, True)
+    for th, far in ((3.0, True), (1.0, False)):
+        got = m.SearchByProjectionFisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["sf"], f["mps"], f["mpr"], f["l2r"], f["r2l"],
+                                          f["occ"], th, far, 60.0)
+        exp = oracle.search_by_projection_fisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["sf"], f["mps"].view(oracle.MP_DTYPE),
+                                                  f["mpr"].view(oracle.MPR_DTYPE), th, far, 60.0, 0.8, f["l2r"], f["r2l"], f["occ"])
+        assert got[0] == exp[0] and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]) and got[0] > 100
+    for ori in (True, False):
+        mm = orbx.ORBmatcher(0.8, ori)
+        got = mm.SearchByProjectionFrameFisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["pts"], f["uvr"], f["occ"])
+        exp = oracle.search_by_projection_frame_fisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["pts"].view(oracle.PP_DTYPE),
+                                                        f["uvr"], ori, f["occ"])
+        assert got[0] == exp[0] and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]) and got[0] > 80
+    # degenerate frames: no right keypoints / no points
+    nL = f["nL"]
+    got = m.SearchByProjectionFisheye(f["kps"][:nL], f["desc"][:nL], nL, f["bounds"], f["sf"], f["mps"], f["mpr"],
+                                      np.full(nL, -1, np.int32), np.zeros(0, np.int32), f["occ"][:nL], 3.0, True, 60.0)
+    exp = oracle.search_by_projection_fisheye(f["kps"][:nL], f["desc"][:nL], nL, f["bounds"], f["sf"], f["mps"].view(oracle.MP_DTYPE),
+                                              f["mpr"].view(oracle.MPR_DTYPE), 3.0, True, 60.0, 0.8, np.full(nL, -1, np.int32),
+                                              np.zeros(0, np.int32), f["occ"][:nL])
+    assert got[0] == exp[0] and np.array_equal(got[1], exp[1])
+    got = m.SearchByProjectionFrameFisheye(f["kps"], f["desc"], nL, f["bounds"], f["pts"][:0], f["uvr"][:0], f["occ"])
+    assert got[0] == 0 and (got[1] == -1).all()

@@ -152,6 +152,27 @@ def test_fuzz_matchers(oracle):
         n1, m1, o1 = orbx.ORBmatcher(ratio, ori).SearchByProjection(k2, d2, uR, bounds, sf, mps, occ, th, True, 40.0)
         on1, om1, oo1 = oracle.search_by_projection(k2, d2, uR, bounds, sf, mps, th, True, 40.0, ratio, occ)
         ok = ok and n1 == on1 and np.array_equal(m1, om1) and np.array_equal(o1, oo1)
+        # stereo-fisheye flavours: frame = (k2 | k1) as left | right keypoints, random partner arrays
+        nL, nR = len(k2), len(k1)
+        kk, dd = np.concatenate([k2, k1]), np.concatenate([d2, d1])
+        l2r = np.where(rng.random(nL) < 0.4, rng.integers(0, nR, nL), -1).astype(np.int32)
+        r2l = np.where(rng.random(nR) < 0.4, rng.integers(0, nL, nR), -1).astype(np.int32)
+        mpr = np.zeros(nmp, orbx.MPR_DTYPE)
+        mpr["proj_yr"] = k1["y"] + rng.normal(0, 3.0, nmp)
+        mpr["view_cos_r"] = rng.uniform(0.99, 1.0, nmp)
+        mpr["predicted_level_r"] = np.where(rng.random(nmp) < 0.1, -1, np.clip(k1["octave"] + rng.integers(-1, 2, nmp), 0, 7))
+        mpr["in_view_r"] = rng.random(nmp) < 0.8
+        mpsf = mps.copy()
+        mpsf["proj_xr"] = k1["x"] + rng.normal(0, 3.0, nmp)   # mTrackProjXR is a right-camera x here
+        occf = (rng.random(nL + nR) < 0.1).astype(np.uint8)
+        uvr = np.stack([mpsf["proj_xr"], mpr["proj_yr"]], 1).astype(np.float32)
+        n3, m3, o3 = orbx.ORBmatcher(ratio, ori).SearchByProjectionFisheye(kk, dd, nL, bounds, sf, mpsf, mpr, l2r, r2l, occf, th, True, 40.0)
+        on3, om3, oo3 = oracle.search_by_projection_fisheye(kk, dd, nL, bounds, sf, mpsf.view(oracle.MP_DTYPE), mpr.view(oracle.MPR_DTYPE),
+                                                            th, True, 40.0, ratio, l2r, r2l, occf)
+        ok = ok and n3 == on3 and np.array_equal(m3, om3) and np.array_equal(o3, oo3)
+        n4, m4, o4 = orbx.ORBmatcher(ratio, ori).SearchByProjectionFrameFisheye(kk, dd, nL, bounds, pts, uvr, occf)
+        on4, om4, oo4 = oracle.search_by_projection_frame_fisheye(kk, dd, nL, bounds, pts.view(oracle.PP_DTYPE), uvr, ori, occf)
+        ok = ok and n4 == on4 and np.array_equal(m4, om4) and np.array_equal(o4, oo4)
         idx, dist, okk = orbx.bf_knn2(d1[: min(400, len(d1))], d2)
         oidx, odist, ookk = oracle.bf_knn2(d1[: min(400, len(d1))], d2)
         ok = ok and np.array_equal(idx, oidx) and np.array_equal(dist, odist) and np.array_equal(okk, ookk)
