@@ -299,8 +299,8 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     v.patch = (float)(int)(31 * ex->scale[l]);
     maxCW = std::max(maxCW, v.wCell);
     maxCH = std::max(maxCH, v.hCell);
-    if (v.w - 2 * kBorder > 4095 || v.h - 2 * kBorder > 4095) {
-      why = "image larger than 4127 px is not supported by the 12-bit key packing";
+    if (v.w > 4096 || v.h > 4096) {  // selected keys carry level coordinates (<= w - 1) in 12 bits
+      why = "images larger than 4096 px are not supported by the 12-bit key packing";
       return ORBX_E_UNSUPPORTED;
     }
   }

@@ -446,3 +446,15 @@ def test_projection_serial_fallback_in_fresh_process(gpu):
                         os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
                        cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
+def test_size_limit_of_the_key_packing(gpu, oracle):
+    """Keys carry 12-bit coordinates: 4096 px wide works (bit-exact), 4100 px is rejected with E_UNSUPPORTED."""
+    ex = orbx.ORBextractor(600, 1.2, 8, 20, 7, max_width=4096, max_height=600)
+    img = synth.mono_frame(4096, 600, 88)
+    mono, k, d = ex(img)
+    om, ok_, od = oracle.OracleExtractor(600).extract(img)
+    assert mono == om and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od) and k["x"].max() > 4000
+    with pytest.raises(orbx.OrbxError) as e:
+        orbx.ORBextractor(600, 1.2, 8, 20, 7, max_width=4100, max_height=600)
+    assert e.value.code == orbx.E_UNSUPPORTED
