@@ -1373,9 +1373,31 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
   f.mps = S[0].mp.p; f.pts = S[0].pp.p; f.kps = k.p; f.l2r = a12.p; f.r2l = a21.p;
   f.occupied = occ.p; f.match = mt.p; f.result = res.p;
   int result[2] = {0, 0};
-  if (e == hipSuccess) chk(launch_proj_resolve_fisheye(f, nullptr));
+  // parallel fixed-point rounds (k_proj_round_fe); the serial walk is the fallback (writer-list overflow, no convergence
+  // within 48 rounds) and the ORBX_PROJ_SERIAL=1 cross-check
+  ScratchBuf<int4> wr0, wr1;
+  ScratchBuf<int> wl0, wl1, wc0, wc1, fl;
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  bool done = false;
+  int lastRound = 0;
+  if (!forceSerial && n_points > 0) {
+    chk(wr0.alloc(nm)); chk(wr1.alloc(nm)); chk(wl0.alloc((size_t)n * kFeWriters)); chk(wl1.alloc((size_t)n * kFeWriters));
+    chk(wc0.alloc(n)); chk(wc1.alloc(n)); chk(fl.alloc(40));
+    f.writes[0] = wr0.p; f.writes[1] = wr1.p; f.writers[0] = wl0.p; f.writers[1] = wl1.p;
+    f.nwriters[0] = wc0.p; f.nwriters[1] = wc1.p; f.flags = fl.p;
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_proj_rounds_fisheye(f, r, 4, nullptr));
+      int st[2] = {1, 0};
+      if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
+      if (st[1]) break;  // a slot collected more than kFeWriters writers in one round
+      done = st[0] == 0;
+      lastRound = r + 3;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_proj_finish_fisheye(f, lastRound, nullptr) : launch_proj_resolve_fisheye(f, nullptr));
   if (e == hipSuccess) chk(hipDeviceSynchronize());
   if (e == hipSuccess) chk(hipMemcpy(result, res.p, sizeof(int), hipMemcpyDeviceToHost));
+  wr0.free(); wr1.free(); wl0.free(); wl1.free(); wc0.free(); wc1.free(); fl.free();
   if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
   k.free(); d.free(); occ.free(); sf.free(); a12.free(); a21.free(); mt.free(); res.free();

@@ -227,8 +227,16 @@ struct ProjFeArgs {
   uint8_t* occupied;                // n
   int* match;                       // n
   int* result;
+  // parallel fixed-point rounds (k_proj_round_fe): tentative writes of every point and per-slot writer lists
+  int4* writes[2];                  // nmp each: slots written by the point {left best, its partner, right best, its partner} or -1
+  int* writers[2];                  // n * kFeWriters each: points that wrote the slot in that round
+  int* nwriters[2];                 // n each
+  int* flags;                       // [0] changed, [1] writer-list overflow, [2] writes, [3] removed, [4..33] histogram
 };
+constexpr int kFeWriters = 4;
 hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
+hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s);
+hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s);
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);

@@ -3274,6 +3274,259 @@ __global__ __launch_bounds__(64) void k_proj_resolve_fe(ProjFeArgs a) {
   if (lane == 0) a.result[0] = nmatches;
 }
 
+// ---- stereo-fisheye resolve as a parallel fixed-point iteration ---------------------------------------------------------
+// Slot occupancy is a last-writer relation here (the stereo-partner assignments overwrite unconditionally):
+//   occupied(s, im) = has_observations[last point < im that wrote s], or the initial flag if there is none.
+// Round r evaluates every point in parallel against the writes of round r - 1 (every slot keeps the list of points that
+// wrote it, at most kFeWriters; an overflow sends the call to the serial walk).  Point t is final after round t + 1 and a
+// round that reproduces the previous writes is the serial result, exactly as in k_proj_round.
+__device__ __forceinline__ bool fe_occupied(const ProjFeArgs& a, int prev, int round_no, int s, int im) {
+  int lw = -1;
+  if (round_no > 0) {
+    const int c = min(a.nwriters[prev][s], kFeWriters);
+    for (int e = 0; e < c; e++) {
+      const int w = a.writers[prev][s * kFeWriters + e];
+      if (w < im && w > lw) lw = w;
+    }
+  }
+  if (lw < 0) return a.occupied[s] != 0;
+  return (a.mode == 0 ? a.mps[lw].has_observations : a.pts[lw].has_observations) != 0;
+}
+
+__device__ __forceinline__ void fe_best2(const ProjFeArgs& a, int prev, int round_no, const int* off, const int* idx,
+                                         const int* dist, int slot0, int im, int lane, uint64_t& best, uint64_t& second,
+                                         int& b) {
+  b = off[im];
+  const int e = off[im + 1];
+  best = ~0ull;
+  second = ~0ull;
+  for (int j = b + lane; j < e; j += 64) {
+    if (fe_occupied(a, prev, round_no, slot0 + idx[j], im)) continue;
+    const int dv = dist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  int4 w = {-1, -1, -1, -1};
+  bool skipRight = false;
+  if (a.offL[im + 1] > a.offL[im]) {
+    uint64_t best, second;
+    int b;
+    fe_best2(a, prev, round_no, a.offL, a.idxL, a.distL, 0, im, lane, best, second, b);
+    if (best != ~0ull && (int)(best >> 40) <= 100) {
+      const int bestDist = (int)(best >> 40), bestIdx = a.idxL[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+      if (a.mode == 0) {
+        const int bestLevel = (int)(best & 0xFF);
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        if (bestLevel == bestLevel2 && (float)bestDist > lim) {
+          skipRight = true;
+        } else if (bestLevel != bestLevel2 || (float)bestDist <= lim) {
+          w.x = bestIdx;
+          const int partner = a.l2r[bestIdx];
+          if (partner != -1) w.y = partner + a.nLeft;
+        }
+      } else {
+        w.x = bestIdx;
+      }
+    }
+  } else if (a.mode == 1) {
+    skipRight = true;
+  }
+  if (!skipRight && a.offR[im + 1] > a.offR[im]) {
+    // the right search of point im sees im's own left-camera writes only through slots it cannot select (a left slot,
+    // or the partner of the left best: that right slot now holds im itself, i.e. occupied iff im has observations)
+    uint64_t best, second;
+    int b;
+    const int bb = a.offR[im], ee = a.offR[im + 1];
+    best = ~0ull;
+    second = ~0ull;
+    const bool selfObs = (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations) != 0;
+    b = bb;
+    for (int j = bb + lane; j < ee; j += 64) {
+      const int s = a.nLeft + a.idxR[j];
+      const bool occ = (s == w.y) ? selfObs : fe_occupied(a, prev, round_no, s, im);
+      if (occ) continue;
+      const int dv = a.distR[j];
+      const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - bb) << 8) | (uint32_t)(dv & 0xFF);
+      if (v < best) {
+        second = best;
+        best = v;
+      } else if (v < second) {
+        second = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+      const uint64_t nb = best < ob ? best : ob;
+      const uint64_t mx = best < ob ? ob : best;
+      const uint64_t ms = second < os ? second : os;
+      second = mx < ms ? mx : ms;
+      best = nb;
+    }
+    if (best != ~0ull && (int)(best >> 40) <= 100) {
+      const int bestDist = (int)(best >> 40), bestIdx = a.idxR[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+      bool accept = true;
+      if (a.mode == 0) {
+        const int bestLevel = (int)(best & 0xFF);
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2));
+      }
+      if (accept) {
+        w.z = bestIdx + a.nLeft;
+        if (a.mode == 0) {
+          const int partner = a.r2l[bestIdx];
+          if (partner != -1) w.w = partner;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    const int4 o = a.writes[prev][im];
+    if (round_no == 0 || o.x != w.x || o.y != w.y || o.z != w.z || o.w != w.w) a.flags[0] = 1;
+    a.writes[prev ^ 1][im] = w;
+    const int ws[4] = {w.x, w.y, w.z, w.w};
+    for (int t = 0; t < 4; t++) {
+      if (ws[t] < 0) continue;
+      bool dup = false;
+      for (int u = 0; u < t; u++) dup = dup || ws[u] == ws[t];
+      if (dup) continue;
+      const int pos = atomicAdd(&a.nwriters[prev ^ 1][ws[t]], 1);
+      if (pos < kFeWriters) a.writers[prev ^ 1][ws[t] * kFeWriters + pos] = im;
+      else a.flags[1] = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_reset_fe(ProjFeArgs a, int which, int first) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    a.nwriters[which][i] = 0;
+    if (first) a.match[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 34) {
+    if (threadIdx.x == 0) a.flags[0] = 0;
+    else if (first) a.flags[threadIdx.x] = 0;
+  }
+}
+
+__device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
+  float rot = __fsub_rn(a.pts[im].angle, a.kps[slot].angle);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+__global__ __launch_bounds__(256) void k_proj_assign_fe(ProjFeArgs a, int last) {  // last writer wins every slot
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  int nw = 0;
+  if (im < a.nmp) {
+    const int4 w = a.writes[last][im];
+    // order of the serial writes of one point: left best, its partner, [right partner], right best -- a later write of
+    // the same point to the same slot changes nothing (same point index), so only the count matters
+    const int ws[4] = {w.x, w.y, w.w, w.z};
+    for (int t = 0; t < 4; t++)
+      if (ws[t] >= 0) {
+        atomicMax(&a.match[ws[t]], im);
+        nw++;
+      }
+    if (a.mode == 1 && a.checkOri) {
+      if (w.x >= 0) atomicAdd(&a.flags[4 + fe_bin(a, im, w.x)], 1);
+      if (w.z >= 0) atomicAdd(&a.flags[4 + fe_bin(a, im, w.z)], 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nw += __shfl_xor(nw, o);
+  if ((threadIdx.x & 63) == 0 && nw) atomicAdd(&a.flags[2], nw);
+}
+
+__global__ __launch_bounds__(256) void k_proj_occ_fe(ProjFeArgs a) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.n; k += gridDim.x * 256) {
+    const int im = a.match[k];
+    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull_fe(ProjFeArgs a, int last) {
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < 30; i++) {
+    const int s = a.flags[4 + i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+    ind3 = -1;
+  }
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  int rem = 0;
+  if (im < a.nmp) {
+    const int4 w = a.writes[last][im];
+    const int ws[2] = {w.x, w.z};
+    for (int t = 0; t < 2; t++)
+      if (ws[t] >= 0) {
+        const int bin = fe_bin(a, im, ws[t]);
+        if (bin != ind1 && bin != ind2 && bin != ind3) {
+          a.match[ws[t]] = -1;
+          rem++;
+        }
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rem += __shfl_xor(rem, o);
+  if ((threadIdx.x & 63) == 0 && rem) atomicAdd(&a.flags[3], rem);
+}
+
+__global__ void k_proj_result_fe(ProjFeArgs a) { a.result[0] = a.flags[2] - a.flags[3]; }
+
+hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s) {
+  if (a.nmp <= 0) return hipSuccess;
+  const int gb = (a.n + 255) / 256;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;
+    hipLaunchKernelGGL(k_proj_reset_fe, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_proj_round_fe, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s) {
+  const int last = (last_round & 1) ^ 1;  // round r wrote writes[(r & 1) ^ 1]
+  hipLaunchKernelGGL(k_proj_assign_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_proj_occ_fe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_proj_result_fe, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s) {
   const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(2 * a.nmp + 4) * 4 : 16;  // up to two votes per point
   hipLaunchKernelGGL(k_proj_resolve_fe, dim3(1), dim3(64), lds, s, a);

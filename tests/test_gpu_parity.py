@@ -443,7 +443,8 @@ def test_projection_serial_fallback_in_fresh_process(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ORBX_PROJ_SERIAL="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "projection and not fallback",
-                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
+                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_fisheye.py")],
                        cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
 

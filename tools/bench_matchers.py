@@ -64,6 +64,26 @@ cases = [
      lambda: orbx.ComputeStereoFishEyeMatches(sc["kL"], sc["dL"], 500, sc["kR"], sc["dR"], 500, rig, sc["level_sigma2"]),
      lambda: O.fisheye_stereo_match(sc["kL"], sc["dL"], 500, sc["kR"], sc["dR"], 500, rig, sc["level_sigma2"])),
 ]
+# stereo-fisheye flavours: frame = current-left | current-right keypoints, partners from the brute-force association
+kk, dd = np.concatenate([kc, kr]), np.concatenate([dc, dr])
+nLk, nRk = len(kc), len(kr)
+bi, bd, bok = orbx.bf_knn2(dc, dr)
+l2r = np.where(bok.astype(bool), bi[:, 0], -1).astype(np.int32)
+r2l = np.full(nRk, -1, np.int32)
+r2l[l2r[l2r >= 0]] = np.nonzero(l2r >= 0)[0]
+mpr = np.zeros(n, orbx.MPR_DTYPE)
+mpr["proj_yr"], mpr["view_cos_r"] = mps["proj_y"], mps["view_cos"]
+mpr["predicted_level_r"], mpr["in_view_r"] = mps["predicted_level"], mps["in_view"]
+occf = (rng.random(nLk + nRk) < 0.05).astype(np.uint8)
+uvr = np.stack([mps["proj_xr"], mps["proj_y"]], 1).astype(np.float32)
+cases += [
+    ("SearchByProjection(F, MapPoints), Nleft != -1  %d pts x %d+%d kps" % (n, nLk, nRk),
+     lambda: m.SearchByProjectionFisheye(kk, dd, nLk, bounds, sf, mps, mpr, l2r, r2l, occf, 3.0, True, 60.0),
+     lambda: O.search_by_projection_fisheye(kk, dd, nLk, bounds, sf, omps, mpr.view(O.MPR_DTYPE), 3.0, True, 60.0, 0.8, l2r, r2l, occf)),
+    ("SearchByProjection(Cur, Last), Nleft != -1     %d pts x %d+%d kps" % (n, nLk, nRk),
+     lambda: m.SearchByProjectionFrameFisheye(kk, dd, nLk, bounds, pts, uvr, occf),
+     lambda: O.search_by_projection_frame_fisheye(kk, dd, nLk, bounds, opts, uvr, True, occf)),
+]
 print("%-62s %12s %12s %8s" % ("entry point (host API, one call)", "MI355X ms", "oracle ms", "ratio"))
 for name, fg, fo in cases:
     for _ in range(3):
