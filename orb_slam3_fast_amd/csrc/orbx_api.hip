@@ -1121,9 +1121,31 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
     a.candDist = candDist.p;
     a.candCap = std::max(total, 1);
   }
-  if (e == hipSuccess) chk(launch_search_init_fill(a, nullptr));
+  // resolve: parallel fixed-point rounds (k_init_round), serial walk as fallback / ORBX_PROJ_SERIAL=1 cross-check
+  ScratchBuf<int2> cl0, cl1, cr0, cr1;
+  ScratchBuf<int> nc0, nc1, fl;
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  bool done = false;
+  int lastRound = 0;
+  if (e == hipSuccess) chk(launch_search_init_cands_fill(a, nullptr));
+  if (!forceSerial && n2 > 0) {
+    chk(cl0.alloc(n1)); chk(cl1.alloc(n1)); chk(cr0.alloc((size_t)n2 * kFeWriters)); chk(cr1.alloc((size_t)n2 * kFeWriters));
+    chk(nc0.alloc(n2)); chk(nc1.alloc(n2)); chk(fl.alloc(40));
+    a.claim[0] = cl0.p; a.claim[1] = cl1.p; a.claimers[0] = cr0.p; a.claimers[1] = cr1.p;
+    a.nclaimers[0] = nc0.p; a.nclaimers[1] = nc1.p; a.flags = fl.p;
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_search_init_rounds(a, r, 4, nullptr));
+      int st[2] = {1, 0};
+      if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
+      if (st[1]) break;
+      done = st[0] == 0;
+      lastRound = r + 3;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_search_init_finish(a, lastRound, nullptr) : launch_search_init_resolve_serial(a, nullptr));
   if (e == hipSuccess) chk(hipDeviceSynchronize());
   if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
+  cl0.free(); cl1.free(); cr0.free(); cr1.free(); nc0.free(); nc1.free(); fl.free();
   if (e == hipSuccess) chk(hipMemcpy(matches12, m12.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
   if (e == hipSuccess) chk(hipMemcpy(prev_matched, prev.p, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
   k1.free(); k2.free(); d1.free(); d2.free(); prev.free(); m12.free(); cellStart.free(); cellItems.free();

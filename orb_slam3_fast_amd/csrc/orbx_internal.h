@@ -157,6 +157,7 @@ struct UndistortArgs {
   int hasDist;
 };
 hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s);
+constexpr int kFeWriters = 4;  // writers / claimers remembered per slot and round by the fixed-point resolves
 struct InitArgs {
   const orbx_keypoint *k1, *k2;
   const uint8_t *d1, *d2;
@@ -177,7 +178,16 @@ struct InitArgs {
   int* matchedDist;              // n2
   int* matches21;                // n2
   int* result;                   // [0]=nmatches, [1]=overflow flag
+  // parallel fixed-point rounds (k_init_round): claims of every F1 keypoint and per-F2-keypoint claimer lists
+  int2* claim[2];                // n1 each: (i2, dist) or (-1, 0)
+  int2* claimers[2];             // n2 * kFeWriters each: (i1, dist) of the points that claimed i2 in that round
+  int* nclaimers[2];             // n2 each
+  int* flags;                    // [0] changed, [1] claimer-list overflow, [2] claimed slots, [3] removed, [4..33] histogram
 };
+hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s);
+hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s);
+hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s);
+hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s);
 hipError_t launch_grid_build(const InitArgs& a, hipStream_t s);        // AssignFeaturesToGrid of (k2, n2) as CSR
 hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s);
 hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s);
@@ -233,7 +243,6 @@ struct ProjFeArgs {
   int* nwriters[2];                 // n each
   int* flags;                       // [0] changed, [1] writer-list overflow, [2] writes, [3] removed, [4..33] histogram
 };
-constexpr int kFeWriters = 4;
 hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
 hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s);
 hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s);

@@ -2730,6 +2730,173 @@ hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
   }
   return hipGetLastError();
 }
+// ---- SearchForInitialization: the greedy walk as a parallel fixed-point iteration ------------------------------------------
+// vMatchedDistance[i2] seen by keypoint i1 = the distance of the LAST claim on i2 by a keypoint < i1 (claims on one i2
+// strictly decrease, :665), so the walk is the unique fixed point of "claim[i1] = best candidate under the gates given
+// the claims of all i1' < i1".  Rounds re-evaluate every i1 against the previous round's claims (per i2 the list of
+// claimers, at most kFeWriters) until a round changes nothing; overflow or no convergence -> k_init_resolve.
+__device__ __forceinline__ int init_matched_dist(const InitArgs& a, int prev, int round_no, int i2, int i1) {
+  int lw = -1, ld = 0x7FFFFFFF;
+  if (round_no > 0) {
+    const int c = min(a.nclaimers[prev][i2], kFeWriters);
+    for (int e = 0; e < c; e++) {
+      const int2 w = a.claimers[prev][i2 * kFeWriters + e];
+      if (w.x < i1 && w.x > lw) {
+        lw = w.x;
+        ld = w.y;
+      }
+    }
+  }
+  return ld;
+}
+
+__global__ __launch_bounds__(256) void k_init_round(InitArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  const int b = a.candOff[i1], e = a.candOff[i1 + 1];
+  int2 cl = {-1, 0};
+  if (e > b) {
+    uint64_t best = ~0ull;  // (dist << 32 | position)
+    for (int j = b + lane; j < e; j += 64) {
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (init_matched_dist(a, prev, round_no, i2, i1) <= d) continue;
+      const uint64_t v = ((uint64_t)(uint32_t)d << 32) | (uint32_t)(j - b);
+      best = v < best ? v : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t t = __shfl_xor((unsigned long long)best, o);
+      best = t < best ? t : best;
+    }
+    if (best != ~0ull) {
+      const int bestDist = (int)(best >> 32), bestPos = (int)(best & 0xFFFFFFFFu);
+      int second = 0x7FFFFFFF;
+      for (int j = b + lane; j < e; j += 64) {
+        if (j - b == bestPos) continue;
+        const int i2 = a.candIdx[j], d = a.candDist[j];
+        if (init_matched_dist(a, prev, round_no, i2, i1) <= d) continue;
+        second = min(second, d);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+      if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)second, a.nnratio)) {
+        cl.x = a.candIdx[b + bestPos];
+        cl.y = bestDist;
+      }
+    }
+  }
+  if (lane == 0) {
+    const int2 o = a.claim[prev][i1];
+    if (round_no == 0 || o.x != cl.x || o.y != cl.y) a.flags[0] = 1;
+    a.claim[prev ^ 1][i1] = cl;
+    if (cl.x >= 0) {
+      const int pos = atomicAdd(&a.nclaimers[prev ^ 1][cl.x], 1);
+      if (pos < kFeWriters) a.claimers[prev ^ 1][cl.x * kFeWriters + pos] = make_int2(i1, cl.y);
+      else a.flags[1] = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_init_reset(InitArgs a, int which, int first) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) {
+    a.nclaimers[which][i] = 0;
+    if (first) a.matches21[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 34) {
+    if (threadIdx.x == 0) a.flags[0] = 0;
+    else if (first) a.flags[threadIdx.x] = 0;
+  }
+}
+
+__device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
+  float rot = __fsub_rn(a.k1[i1].angle, a.k2[i2].angle);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+__global__ __launch_bounds__(256) void k_init_owner(InitArgs a, int last) {  // vnMatches21 = the last claimer; votes
+  const int i1 = blockIdx.x * 256 + threadIdx.x;
+  if (i1 >= a.n1) return;
+  const int2 cl = a.claim[last][i1];
+  if (cl.x < 0) return;
+  atomicMax(&a.matches21[cl.x], i1);
+  if (a.checkOri) atomicAdd(&a.flags[4 + init_bin(a, i1, cl.x)], 1);  // stolen matches stay in rotHist (:712-719)
+}
+
+__global__ __launch_bounds__(256) void k_init_finish(InitArgs a, int last) {
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  if (a.checkOri) {
+    for (int i = 0; i < 30; i++) {
+      const int s = a.flags[4 + i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+  }
+  const int i1 = blockIdx.x * 256 + threadIdx.x;
+  int kept = 0;
+  if (i1 < a.n1) {
+    const int2 cl = a.claim[last][i1];
+    int m = -1;
+    if (cl.x >= 0 && a.matches21[cl.x] == i1) {  // not stolen by a later keypoint
+      m = cl.x;
+      if (a.checkOri) {
+        const int bin = init_bin(a, i1, cl.x);
+        if (bin != ind1 && bin != ind2 && bin != ind3) m = -1;
+      }
+    }
+    a.matches12[i1] = m;
+    if (m >= 0) {
+      kept = 1;
+      a.prev[2 * i1] = a.k2[m].x;
+      a.prev[2 * i1 + 1] = a.k2[m].y;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&a.flags[2], kept);
+}
+
+__global__ void k_init_result(InitArgs a) { a.result[0] = a.flags[2]; }
+
+hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s) {
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  return hipGetLastError();
+}
+hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s) {
+  const int gb = (a.n2 + 255) / 256 > 0 ? (a.n2 + 255) / 256 : 1;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;
+    hipLaunchKernelGGL(k_init_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_init_round, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s) {
+  const int last = (last_round & 1) ^ 1;
+  hipLaunchKernelGGL(k_init_owner, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_init_finish, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
   if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
   hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);

@@ -435,14 +435,15 @@ def test_search_for_initialization(gpu, oracle):
 
 
 def test_projection_serial_fallback_in_fresh_process(gpu):
-    """The projection matchers resolve by parallel fixed-point rounds; the one-wave serial walk they fall back to must
-    give the same (golden) results.  ORBX_PROJ_SERIAL is read once per process, hence the subprocess."""
+    """The guided matchers (SearchByProjection pinhole / fisheye, SearchForInitialization) resolve by parallel fixed-point
+    rounds; the one-wave serial walks they fall back to must give the same results.  ORBX_PROJ_SERIAL is read once per
+    process, hence the subprocess."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ORBX_PROJ_SERIAL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "projection and not fallback",
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "(projection or initialization or stereo_golden) and not fallback",
                         os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
                         os.path.join(root, "tests", "test_fisheye.py")],
                        cwd=root, env=env, capture_output=True, text=True)
