@@ -347,3 +347,36 @@ def test_hip_fisheye_projection_matchers_parity(oracle, seed):
     assert got[0] == exp[0] and np.array_equal(got[1], exp[1])
     got = m.SearchByProjectionFrameFisheye(f["kps"], f["desc"], nL, f["bounds"], f["pts"][:0], f["uvr"][:0], f["occ"])
     assert got[0] == 0 and (got[1] == -1).all()
+
+
+GOLDEN_PROJ = os.path.join(os.path.dirname(__file__), "golden", "fisheye_projection.npz")
+
+
+def _golden_proj(mod):
+    g = np.load(GOLDEN_PROJ)
+    kps = np.ascontiguousarray(g["kps"]).view(mod.KP_DTYPE).reshape(-1)
+    mps = np.ascontiguousarray(g["mps"]).view(mod.MP_DTYPE).reshape(-1)
+    mpr = np.ascontiguousarray(g["mpr"]).view(mod.MPR_DTYPE).reshape(-1)
+    pts = np.ascontiguousarray(g["pts"]).view(mod.PP_DTYPE).reshape(-1)
+    return g, kps, mps, mpr, pts, tuple(float(v) for v in g["bounds"])
+
+
+def test_oracle_reproduces_fisheye_projection_golden(oracle):
+    g, kps, mps, mpr, pts, bounds = _golden_proj(oracle)
+    n1, m1, o1 = oracle.search_by_projection_fisheye(kps, g["desc"], int(g["n_left"]), bounds, g["scale"], mps, mpr, 3.0, True, 60.0, 0.8,
+                                                     g["l2r"], g["r2l"], g["occ"])
+    assert n1 == int(g["map_n"]) and np.array_equal(m1, g["map_match"]) and np.array_equal(o1, g["map_occ"])
+    n2, m2, o2 = oracle.search_by_projection_frame_fisheye(kps, g["desc"], int(g["n_left"]), bounds, pts, g["uvr"], True, g["occ"])
+    assert n2 == int(g["frame_n"]) and np.array_equal(m2, g["frame_match"]) and np.array_equal(o2, g["frame_occ"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_fisheye_projection_golden():
+    import orb_slam3_fast_amd as orbx
+    g, kps, mps, mpr, pts, bounds = _golden_proj(orbx)
+    m = orbx.ORBmatcher(0.8, True)
+    n1, m1, o1 = m.SearchByProjectionFisheye(kps, g["desc"], int(g["n_left"]), bounds, g["scale"], mps, mpr, g["l2r"], g["r2l"], g["occ"],
+                                             3.0, True, 60.0)
+    assert n1 == int(g["map_n"]) and np.array_equal(m1, g["map_match"]) and np.array_equal(o1, g["map_occ"])
+    n2, m2, o2 = m.SearchByProjectionFrameFisheye(kps, g["desc"], int(g["n_left"]), bounds, pts, g["uvr"], g["occ"])
+    assert n2 == int(g["frame_n"]) and np.array_equal(m2, g["frame_match"]) and np.array_equal(o2, g["frame_occ"])

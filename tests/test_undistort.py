@@ -83,3 +83,27 @@ def test_hip_undistort_edge_cases():
         orbx.UndistortKeyPoints(k, (0.0, 1.0, 0.0, 0.0), TUM_D)
     with pytest.raises(orbx.OrbxError):   # tilted sensor model
         orbx.UndistortKeyPoints(k, TUM_K, (0.1,) * 12 + (0.01, 0.0))
+
+
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "undistort.npz")
+
+
+def _golden_cases(mod):
+    g = np.load(GOLDEN)
+    for tag in ("euroc", "tum1"):
+        k = np.ascontiguousarray(g[tag + "_kps"]).view(mod.KP_DTYPE).reshape(-1)
+        yield g[tag + "_K"], g[tag + "_D"], [int(v) for v in g[tag + "_size"]], k, g[tag + "_un"], g[tag + "_bounds"]
+
+
+def test_oracle_reproduces_undistort_golden(oracle):
+    for K, D, (w, h), k, un, bounds in _golden_cases(oracle):
+        assert np.array_equal(oracle.undistort_keypoints(k, K, D).view(np.uint8).reshape(-1, 28), un)
+        assert oracle.image_bounds(w, h, K, D).tobytes() == bounds.tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_undistort_golden():
+    import orb_slam3_fast_amd as orbx
+    for K, D, (w, h), k, un, bounds in _golden_cases(orbx):
+        assert np.array_equal(orbx.UndistortKeyPoints(k, K, D).view(np.uint8).reshape(-1, 28), un)
+        assert orbx.ComputeImageBounds(w, h, K, D).tobytes() == bounds.tobytes()

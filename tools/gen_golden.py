@@ -105,6 +105,40 @@ def fisheye_case(name, seed):
     print(name, n, nd)
 
 
+def projection_fisheye_case(name, seed):
+    """Both SearchByProjection matchers on a stereo-fisheye frame (Nleft != -1); the frame comes from the helper the
+    parity tests use (tests/test_fisheye.py:_fisheye_frame)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_fisheye import _fisheye_frame
+    f = _fisheye_frame(O, seed)
+    n1, m1, o1 = O.search_by_projection_fisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["sf"], f["mps"], f["mpr"], 3.0, True, 60.0,
+                                                0.8, f["l2r"], f["r2l"], f["occ"])
+    n2, m2, o2 = O.search_by_projection_frame_fisheye(f["kps"], f["desc"], f["nL"], f["bounds"], f["pts"], f["uvr"], True, f["occ"])
+    np.savez_compressed(os.path.join(OUT, name), kps=f["kps"].view(np.uint8).reshape(-1, 28), desc=f["desc"], n_left=f["nL"],
+                        scale=f["sf"], mps=f["mps"].view(np.uint8).reshape(-1, 60), mpr=f["mpr"].view(np.uint8).reshape(-1, 16),
+                        pts=f["pts"].view(np.uint8).reshape(-1, 64), uvr=f["uvr"], l2r=f["l2r"], r2l=f["r2l"], occ=f["occ"],
+                        bounds=np.array(f["bounds"], np.float32), map_n=n1, map_match=m1, map_occ=o1, frame_n=n2,
+                        frame_match=m2, frame_occ=o2)
+    print(name, len(f["kps"]), n1, n2)
+
+
+def undistort_case(name):
+    """UndistortKeyPoints / ComputeImageBounds for the EuRoC (4 coefficients) and TUM1 (5 coefficients) cameras."""
+    rng = np.random.default_rng(106)
+    out = {}
+    for tag, K, D, w, h in (("euroc", (458.654, 457.296, 367.215, 248.375), (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05), 752, 480),
+                            ("tum1", (517.306408, 516.469215, 318.643040, 255.313989), (0.262383, -0.953104, -0.005358, 0.002628, 1.163314), 640, 480)):
+        k = np.zeros(400, O.KP_DTYPE)
+        k["x"], k["y"] = rng.uniform(0, w, 400), rng.uniform(0, h, 400)
+        k["size"], k["angle"], k["response"], k["octave"], k["class_id"] = 31, rng.uniform(0, 360, 400), 30, rng.integers(0, 8, 400), -1
+        out[tag + "_K"], out[tag + "_D"], out[tag + "_size"] = np.array(K, np.float32), np.array(D, np.float32), np.array([w, h])
+        out[tag + "_kps"] = k.view(np.uint8).reshape(-1, 28)
+        out[tag + "_un"] = O.undistort_keypoints(k, K, D).view(np.uint8).reshape(-1, 28)
+        out[tag + "_bounds"] = O.image_bounds(w, h, K, D)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, out["euroc_bounds"], out["tum1_bounds"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_160x120_L3.npz", 160, 120, 300, 3, 101, (0, 0))
@@ -113,3 +147,5 @@ if __name__ == "__main__":
     stereo_case("stereo_400x300.npz", 400, 300, 600, 103)
     projection_case("projection_480x360.npz", 480, 360, 800, 104)
     fisheye_case("fisheye_stereo.npz", 105)
+    undistort_case("undistort.npz")
+    projection_fisheye_case("fisheye_projection.npz", 7)
