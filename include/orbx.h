@@ -171,6 +171,20 @@ int orbx_fisheye_results_device(const orbx_extractor* left, const int32_t** d_le
 int orbx_fisheye_download(orbx_extractor* left, int pair, int32_t* left_to_right, int32_t* right_to_left, float* depth,
                           float* points3d, int cap_left, int cap_right, int32_t* n_desc_matches);
 
+/* ---- image pre-processing in front of the extractor ------------------------------------------ */
+
+/* Replaces cv::cvtColor(im, im, cv::COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) of Tracking::GrabImageStereo / RGBD / Monocular
+ * (src/Tracking.cc:1394-1412, 1441-1459, 1481-1499): OpenCV's 8-bit fixed-point formula, coefficients 9798 / 19235 /
+ * 3735 with (sum + 16384) >> 15.  channels = 3 or 4 (interleaved), rgb_order != 0 when the first channel is red (mbRGB).
+ * Host images in and out. */
+int orbx_cvt_gray(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, int rgb_order,
+                  uint8_t* dst, ptrdiff_t dst_stride);
+/* Replaces cv::resize(im, out, newImSize) (INTER_LINEAR) of System::TrackStereo / TrackRGBD / TrackMonocular
+ * (src/System.cc:297-298, 369-370, 437-438) for 8UC1 / 8UC3 / 8UC4 images: the fixed-point bilinear arithmetic of
+ * ComputePyramid's cv::resize on every interleaved channel. */
+int orbx_resize_linear(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, uint8_t* dst,
+                       int dst_w, int dst_h, ptrdiff_t dst_stride);
+
 /* Replaces Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys through
  * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) -- five fixed-point iterations of the inverse distortion
  * in double, then x' = fx x + cx.  K = fx fy cx cy (Pinhole::toK()); dist = the n_dist (4, 5, 8, 12 or 14) OpenCV

@@ -351,3 +351,21 @@ def search_by_projection_frame_fisheye(k, desc, n_left, bounds, pts, uv_right, c
                                                      C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(pts),
                                                      _p(uv), len(pts), int(check_ori), _p(occ), _p(match))
     return n, match, occ
+
+
+# ---- image pre-processing (gray conversion, input resize) -----------------------------------------------------------------
+def cvt_gray(img, rgb=True, variant=15):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, cn = img.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().oro_cvt_gray(_p(img), w, h, C.c_long(img.strides[0]), cn, int(rgb), _p(dst), C.c_long(dst.strides[0]), variant)
+    return dst
+
+
+def resize_c(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    dst = np.zeros((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    lib().oro_resize_c(_p(img), w, h, C.c_long(img.strides[0]), cn, _p(dst), dw, dh, C.c_long(dst.strides[0]))
+    return dst

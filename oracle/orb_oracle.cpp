@@ -133,6 +133,59 @@ void resize_linear_u8(const Image& src, Image& dst, int dw, int dh) {
   }
 }
 
+void cvt_gray_u8(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int cn, bool rgb, uint8_t* dst, ptrdiff_t dst_stride,
+                 int variant) {
+  const int shift = variant == 14 ? 14 : 15;
+  const int cr = variant == 14 ? 4899 : 9798, cg = variant == 14 ? 9617 : 19235, cb = variant == 14 ? 1868 : 3735;
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = src + y * src_stride;
+    uint8_t* D = dst + y * dst_stride;
+    for (int x = 0; x < w; x++, S += cn) {
+      const int r = rgb ? S[0] : S[2], g = S[1], b = rgb ? S[2] : S[0];
+      D[x] = (uint8_t)((b * cb + g * cg + r * cr + (1 << (shift - 1))) >> shift);  // CV_DESCALE
+    }
+  }
+}
+
+void resize_linear_u8c(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride, int cn, uint8_t* dst, int dw, int dh,
+                       ptrdiff_t dst_stride) {
+  const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> alpha(2 * dw), beta(2 * dh);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    alpha[2 * dx] = sat_short_from_float((1.f - fx) * 2048.f);
+    alpha[2 * dx + 1] = sat_short_from_float(fx * 2048.f);
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = sat_short_from_float((1.f - fy) * 2048.f);
+    beta[2 * dy + 1] = sat_short_from_float(fy * 2048.f);
+  }
+  auto tap = [&](int sy, int dx, int c) {
+    sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
+    const uint8_t* S = src + sy * src_stride;
+    const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sw - 1;  // alpha[1] == 0 whenever sx is the last column
+    return S[sx * cn + c] * alpha[2 * dx] + S[sx1 * cn + c] * alpha[2 * dx + 1];
+  };
+  for (int dy = 0; dy < dh; dy++) {
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t* D = dst + dy * dst_stride;
+    for (int dx = 0; dx < dw; dx++)
+      for (int c = 0; c < cn; c++)
+        D[dx * cn + c] =
+            (uint8_t)((((b0 * (tap(yofs[dy], dx, c) >> 4)) >> 16) + ((b1 * (tap(yofs[dy] + 1, dx, c) >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
 // ======================================================================================= B3 FAST
 static void make_ring16(int stride, int pixel[25]) {
   static const int off[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},

@@ -126,6 +126,17 @@ int compute_stereo_fisheye_matches(const std::vector<KeyPoint>& kL, const uint8_
                                    std::vector<int>& rightToLeft, std::vector<float>& depth,
                                    std::vector<float>& p3D, int* descMatches, std::vector<float>* gates);
 
+// ---- image pre-processing in front of the extractor (the gray conversion and the input resize) ------------
+// cv::cvtColor(src, dst, COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for 8U (src/Tracking.cc:1394-1412,1441-1459,1481-1499):
+// fixed point with 15-bit coefficients RY15 = 9798, GY15 = 19235, BY15 = 3735, (sum + 16384) >> 15 (OpenCV >= 3.4.2 /
+// 4.x; variant 14 = the older 14-bit set 4899 / 9617 / 1868).  cn = 3 or 4 interleaved channels, rgb != 0: R first.
+void cvt_gray_u8(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int cn, bool rgb, uint8_t* dst, ptrdiff_t dst_stride,
+                 int variant = 15);
+// cv::resize(src, dst, Size(dw, dh)) with INTER_LINEAR on 8UC1 / 8UC3 / 8UC4 (src/System.cc:297-298,369-370,437-438;
+// src/Settings.cc:330-343): the B2 arithmetic of resize_linear_u8 on every interleaved channel.
+void resize_linear_u8c(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride, int cn, uint8_t* dst, int dw, int dh,
+                       ptrdiff_t dst_stride);
+
 // ---- Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:853-919) --------------------------------------------
 // cv::undistortPoints(src, dst, K, distCoeffs, noArray(), P = K) with its default TermCriteria(MAX_ITER, 5, 0.01): five
 // fixed-point iterations of the inverse distortion in double, then x' = fx x + cx (OpenCV calib3d undistort.dispatch.cpp,

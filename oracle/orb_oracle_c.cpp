@@ -259,6 +259,13 @@ int oro_search_by_projection_frame_fisheye(const KeyPoint* k, const uint8_t* des
   return nm;
 }
 
+void oro_cvt_gray(const uint8_t* src, int w, int h, long src_stride, int cn, int rgb, uint8_t* dst, long dst_stride, int variant) {
+  cvt_gray_u8(src, w, h, src_stride, cn, rgb != 0, dst, dst_stride, variant);
+}
+void oro_resize_c(const uint8_t* src, int sw, int sh, long src_stride, int cn, uint8_t* dst, int dw, int dh, long dst_stride) {
+  resize_linear_u8c(src, sw, sh, src_stride, cn, dst, dw, dh, dst_stride);
+}
+
 void oro_undistort_keypoints(const KeyPoint* k, int n, const float* K, const float* dist, int n_dist, KeyPoint* out) {
   std::vector<KeyPoint> a(k, k + n), o;
   undistort_keypoints(a, K, dist, n_dist, o);

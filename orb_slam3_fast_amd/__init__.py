@@ -77,6 +77,8 @@ def lib():
         L.orbx_fisheye_stereo_match.argtypes = [i, vp, vp, i, i, vp, vp, i, i, vp, vp, i, vp, vp, vp, vp, vp]
         L.orbx_fisheye_stereo_match_batch.argtypes = [vp, i, vp, i, i, vp]
         L.orbx_undistort_keypoints.argtypes = [i, vp, i, vp, vp, i, vp]
+        L.orbx_cvt_gray.argtypes = [i, vp, i, i, C.c_ssize_t, i, i, vp, C.c_ssize_t]
+        L.orbx_resize_linear.argtypes = [i, vp, i, i, C.c_ssize_t, i, vp, i, i, C.c_ssize_t]
         L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
         L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
         L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
@@ -334,6 +336,26 @@ def fisheye_download(left, right, pair=0):
     n = _check(lib().orbx_fisheye_download(left._h, pair, _p(l2r), _p(r2l), _p(depth), _p(pts), left.capacity,
                                            right.capacity, C.byref(nd)))
     return n, nd.value, l2r, r2l, depth, pts
+
+
+def cvtColorGray(img, rgb=True, device=0):
+    """cv::cvtColor(img, COLOR_RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY) as Tracking::GrabImage* calls it
+    (src/Tracking.cc:1394-1412): img is H x W x 3|4 uint8, rgb = the reference's mbRGB."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w, cn = img.shape
+    dst = np.zeros((h, w), np.uint8)
+    _check(lib().orbx_cvt_gray(device, _p(img), w, h, img.strides[0], cn, int(bool(rgb)), _p(dst), dst.strides[0]))
+    return dst
+
+
+def resize(img, dst_w, dst_h, device=0):
+    """cv::resize(img, out, Size(dst_w, dst_h)) with INTER_LINEAR (src/System.cc:297-298) for H x W [x 3|4] uint8 images."""
+    img = np.ascontiguousarray(img, np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    dst = np.zeros((dst_h, dst_w) if img.ndim == 2 else (dst_h, dst_w, cn), np.uint8)
+    _check(lib().orbx_resize_linear(device, _p(img), w, h, img.strides[0], cn, _p(dst), dst_w, dst_h, dst.strides[0]))
+    return dst
 
 
 def UndistortKeyPoints(kps, K, dist, device=0):

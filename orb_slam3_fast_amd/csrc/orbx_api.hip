@@ -1011,6 +1011,77 @@ int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const u
   return counts[0];
 }
 
+int orbx_cvt_gray(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, int rgb_order,
+                  uint8_t* dst, ptrdiff_t dst_stride) {
+  if (!src || !dst || w <= 0 || h <= 0 || (channels != 3 && channels != 4) || src_stride < (ptrdiff_t)w * channels ||
+      dst_stride < w)
+    return fail(ORBX_E_BADARG, "bad argument");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<uint8_t> ds, dd;
+  const size_t sp = (size_t)w * channels, dp = (size_t)w;
+  hipError_t e = ds.alloc(sp * h);
+  if (e == hipSuccess) e = dd.alloc(dp * h);
+  if (e == hipSuccess) e = hipMemcpy2D(ds.p, sp, src, (size_t)src_stride, sp, h, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_cvt_gray(ds.p, w, h, (long long)sp, channels, rgb_order ? 1 : 0, dd.p, (long long)dp, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy2D(dst, (size_t)dst_stride, dd.p, dp, dp, h, hipMemcpyDeviceToHost);
+  ds.free(); dd.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
+int orbx_resize_linear(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, uint8_t* dst,
+                       int dst_w, int dst_h, ptrdiff_t dst_stride) {
+  if (!src || !dst || w <= 0 || h <= 0 || dst_w <= 0 || dst_h <= 0 || (channels != 1 && channels != 3 && channels != 4) ||
+      src_stride < (ptrdiff_t)w * channels || dst_stride < (ptrdiff_t)dst_w * channels)
+    return fail(ORBX_E_BADARG, "bad argument");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  // coefficient tables exactly as cv::resize builds them (the same code path as the pyramid's build_coefs)
+  std::vector<int> xofs(dst_w), yofs(dst_h);
+  std::vector<short> xab(2 * (size_t)dst_w), yab(2 * (size_t)dst_h);
+  const double scale_x = 1.0 / ((double)dst_w / w), scale_y = 1.0 / ((double)dst_h / h);
+  for (int dx = 0; dx < dst_w; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= w - 1) { fx = 0; sx = w - 1; }
+    xofs[dx] = sx;
+    xab[2 * dx] = sat_short((1.f - fx) * 2048.f);
+    xab[2 * dx + 1] = sat_short(fx * 2048.f);
+  }
+  for (int dy = 0; dy < dst_h; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    yab[2 * dy] = sat_short((1.f - fy) * 2048.f);
+    yab[2 * dy + 1] = sat_short(fy * 2048.f);
+  }
+  ScratchBuf<uint8_t> ds, dd;
+  ScratchBuf<int> dxo, dyo;
+  ScratchBuf<short> dxa, dya;
+  const size_t sp = (size_t)w * channels, dp = (size_t)dst_w * channels;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  chk(ds.alloc(sp * h)); chk(dd.alloc(dp * dst_h)); chk(dxo.alloc(dst_w)); chk(dyo.alloc(dst_h)); chk(dxa.alloc(2 * (size_t)dst_w));
+  chk(dya.alloc(2 * (size_t)dst_h));
+  if (e == hipSuccess) chk(hipMemcpy2D(ds.p, sp, src, (size_t)src_stride, sp, h, hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(dxo.p, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(dyo.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(dxa.p, xab.data(), xab.size() * sizeof(short), hipMemcpyHostToDevice));
+  if (e == hipSuccess) chk(hipMemcpy(dya.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
+  if (e == hipSuccess)
+    chk(launch_resize_generic(ds.p, w, h, (long long)sp, channels, dd.p, dst_w, dst_h, (long long)dp, dxo.p, dxa.p, dyo.p, dya.p, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy2D(dst, (size_t)dst_stride, dd.p, dp, dp, dst_h, hipMemcpyDeviceToHost));
+  ds.free(); dd.free(); dxo.free(); dyo.free(); dxa.free(); dya.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
 static int fill_undistort_args(UndistortArgs& a, const float K[4], const float* dist, int n_dist) {
   if (!K || n_dist < 0 || n_dist > 14 || (n_dist && !dist)) return fail(ORBX_E_BADARG, "bad camera arguments");
   if (!(K[0] != 0.f) || !(K[1] != 0.f)) return fail(ORBX_E_BADARG, "fx / fy must be non-zero");

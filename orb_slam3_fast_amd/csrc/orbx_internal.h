@@ -157,6 +157,11 @@ struct UndistortArgs {
   int hasDist;
 };
 hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s);
+
+// Pre-processing: gray conversion and a generic (any size, 1/3/4 channels) bilinear resize; pitches in bytes.
+hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, int cn, int rgb, uint8_t* dst, long long dp, hipStream_t s);
+hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, int cn, uint8_t* dst, int dw, int dh,
+                                 long long dp, const int* xofs, const short* xab, const int* yofs, const short* yab, hipStream_t s);
 constexpr int kFeWriters = 4;  // writers / claimers remembered per slot and round by the fixed-point resolves
 struct InitArgs {
   const orbx_keypoint *k1, *k2;

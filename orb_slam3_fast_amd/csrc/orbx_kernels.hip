@@ -2371,6 +2371,48 @@ hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ================================================================================================ pre-processing
+// cvtColor(..., COLOR_*2GRAY) for 8U (OpenCV >= 3.4.2 / 4.x: 15-bit coefficients, one rounding).  Thread per pixel.
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, int w, int h, long long sp, int cn, int rgb,
+                                                  uint8_t* __restrict__ dst, long long dp) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const uint8_t* S = src + y * sp + (long long)x * cn;
+  const int c0 = S[0], g = S[1], c2 = S[2];
+  const int r = rgb ? c0 : c2, b = rgb ? c2 : c0;
+  dst[y * dp + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
+}
+
+// cv::resize INTER_LINEAR 8U on interleaved channels with host-built coefficient tables (the B2 arithmetic of k_resize):
+// thread per destination pixel, all channels.  A once-per-frame convenience kernel, not tiled.
+__global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restrict__ src, int sw, int sh, long long sp, int cn,
+                                                        uint8_t* __restrict__ dst, int dw, int dh, long long dp,
+                                                        const int* __restrict__ xofs, const short* __restrict__ xab,
+                                                        const int* __restrict__ yofs, const short* __restrict__ yab) {
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1), a0 = xab[2 * dx], a1 = xab[2 * dx + 1];
+  const int sy = yofs[dy], b0 = yab[2 * dy], b1 = yab[2 * dy + 1];
+  const uint8_t* R0 = src + (long long)min(max(sy, 0), sh - 1) * sp;
+  const uint8_t* R1 = src + (long long)min(max(sy + 1, 0), sh - 1) * sp;
+  for (int c = 0; c < cn; c++) {
+    const int t0 = R0[sx * cn + c] * a0 + R0[sx1 * cn + c] * a1;
+    const int t1 = R1[sx * cn + c] * a0 + R1[sx1 * cn + c] * a1;
+    dst[dy * dp + (long long)dx * cn + c] = (uint8_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, int cn, int rgb, uint8_t* dst, long long dp, hipStream_t s) {
+  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 255) / 256, h), dim3(256), 0, s, src, w, h, sp, cn, rgb, dst, dp);
+  return hipGetLastError();
+}
+hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, int cn, uint8_t* dst, int dw, int dh,
+                                 long long dp, const int* xofs, const short* xab, const int* yofs, const short* yab, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_generic, dim3((dw + 255) / 256, dh), dim3(256), 0, s, src, sw, sh, sp, cn, dst, dw, dh, dp, xofs, xab,
+                     yofs, yab);
+  return hipGetLastError();
+}
+
 // ================================================================================================ undistort
 // cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it (src/Frame.cc:853-919): double
 // arithmetic in OpenCV's expression order, no contraction (TU flag) -- identical to the oracle's.
