@@ -144,6 +144,10 @@ struct orbx_extractor {
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
   int stereoPairs = 0;
+  // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)
+  hipGraphExec_t graphExec[2] = {nullptr, nullptr};
+  int graphW = 0, graphH = 0;
+  bool graphOff = false;
   DevBuf<int> d_fl2r, d_fr2l, d_fcnt;  // batched fisheye association (orbx_fisheye_stereo_match_batch)
   DevBuf<float> d_fdepth, d_fp3d;
   int fisheyePairs = 0, fisheyeCapR = 0;
@@ -414,11 +418,18 @@ static DetectToken* detect_token(int device) {  // one per device, created on fi
   return toks[device];
 }
 
+int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing);
+static void drop_graphs(orbx_extractor* ex) {
+  for (auto& e : ex->graphExec) {
+    if (e) (void)hipGraphExecDestroy(e);
+    e = nullptr;
+  }
+}
+
 int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
                     ptrdiff_t image_pitch, const int32_t* lap) {
   int rc = configure(ex, w, h);
   if (rc != ORBX_OK) return rc;
-  const Geom& g = ex->g;
   ex->pyr.l0 = d_images;
   ex->pyr.l0Row = row_pitch;
   ex->pyr.l0Img = image_pitch;
@@ -434,6 +445,47 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   if (lap)
     for (int i = 0; i < n; i++) lapTrivial = lapTrivial && lap[2 * i + 1] < 19;
   if (!lapTrivial) HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+  // Single images through the host API are launch-bound (12 small kernels on two streams), so the pipeline can be
+  // captured once per image size into a hipGraph and replayed (ORBX_GRAPH=1).  Measured on ROCm 7.2 / MI355X it is
+  // SLOWER than the plain launches -- one 1280x720 eye 0.487 vs 0.310 ms, a stereo frame 0.823 vs 0.711 ms (640x480:
+  // 0.263 vs 0.247 ms per eye) -- so it stays off by default.  Never used while profiling (the stage events are not
+  // captured) nor for device batches (their image pointer is the caller's and changes from call to call).
+  static const bool useGraph = getenv("ORBX_GRAPH") && atoi(getenv("ORBX_GRAPH")) != 0;
+  if (useGraph && n == 1 && d_images == ex->d_stage.p && !ex->profiling && !ex->graphOff) {
+    if (ex->graphW != w || ex->graphH != h) {
+      drop_graphs(ex);
+      ex->graphW = w;
+      ex->graphH = h;
+    }
+    hipGraphExec_t& exec = ex->graphExec[lapTrivial ? 1 : 0];
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rcCap = record_pipeline(ex, n, lapTrivial, true);
+        const hipError_t ee = hipStreamEndCapture(s, &graph);
+        ok = rcCap == ORBX_OK && ee == hipSuccess && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (!ok) {  // never fatal: fall back to plain launches for the life of the handle
+        (void)hipGetLastError();
+        exec = nullptr;
+        ex->graphOff = true;
+      }
+    }
+    if (exec) {
+      HIPC(hipGraphLaunch(exec, s));
+      return ORBX_OK;
+    }
+  }
+  return record_pipeline(ex, n, lapTrivial, false);
+}
+
+// The kernel launches of one extraction on the handle's two streams (also the body captured into the hipGraph).
+int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) {
+  const Geom& g = ex->g;
+  hipStream_t s = ex->stream;
   static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
   hipStream_t sb = serial ? s : ex->stream2;
   // Experiment knob (default off): blur level 0 beside the resize chain.  Measured 1.063 vs 1.039 ms/step — the chain
@@ -469,7 +521,7 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   // each other.  A per-device token orders the k_detect launches of all handles one after the other, while each still
   // overlaps the other handles' quadtree / describe / stereo / resize work.  (ORBX_DETECT_TOKEN=0 disables it.)
   static const bool useToken = !(getenv("ORBX_DETECT_TOKEN") && atoi(getenv("ORBX_DETECT_TOKEN")) == 0);
-  DetectToken* tok = useToken ? detect_token(ex->device) : nullptr;
+  DetectToken* tok = (useToken && !capturing) ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
   if (tok) {
     std::lock_guard<std::mutex> lk(tok->mu);
     if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
@@ -620,6 +672,10 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   if (!ex) return;
   (void)hipSetDevice(ex->device);
   if (ex->stream) (void)hipStreamSynchronize(ex->stream);
+  for (auto& e : ex->graphExec) {
+    if (e) (void)hipGraphExecDestroy(e);
+    e = nullptr;
+  }
   ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xofs.free(); ex->d_yofs.free();

@@ -460,3 +460,18 @@ def test_size_limit_of_the_key_packing(gpu, oracle):
     with pytest.raises(orbx.OrbxError) as e:
         orbx.ORBextractor(600, 1.2, 8, 20, 7, max_width=4100, max_height=600)
     assert e.value.code == orbx.E_UNSUPPORTED
+
+
+def test_hipgraph_replay_of_the_single_image_pipeline(gpu):
+    """ORBX_GRAPH=1 captures the single-image pipeline into a hipGraph and replays it (off by default: measured slower);
+    results must not change.  The switch is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBX_GRAPH="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k",
+                        "stages_and_end_to_end or lapping_area_partition or extract_golden or size_changes",
+                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
+                       cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
