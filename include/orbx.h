@@ -78,6 +78,19 @@ int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, fl
 int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
 
+/* Both eyes of ONE stereo frame through one batched pipeline and one synchronisation: replaces the two threaded
+ * ExtractORB calls of the stereo Frame constructor (src/Frame.cc:200-203, 549-560) and, when bf > 0, the
+ * ComputeStereoMatches that follows them (:921-1084; b = baseline, maxD = bf / b).  The handle needs max_batch >= 2; the
+ * left eye becomes image 0 and the right eye image 1 of the extraction (orbx_pyramid_level, orbx_stereo_match_batch with
+ * left == right handle, first_left 0, first_right 1).  Outputs as orbx_extract for each eye (n_* keypoints, mono_* =
+ * monoIndex); uright / depth (cap_left floats each, -1 = no match) may be NULL and are ignored when bf <= 0.
+ * Returns ORBX_OK, ORBX_E_EMPTY for an empty image, or another negative error. */
+int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
+                        ptrdiff_t stride_left, ptrdiff_t stride_right, const int32_t lap_left[2],
+                        const int32_t lap_right[2], orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left,
+                        int* n_left, int* mono_left, orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right,
+                        int* n_right, int* mono_right, float bf, float b, float* uright, float* depth);
+
 /* Batched many-camera mode: n_images device-resident images (image i at d_images + i*image_pitch, rows
  * row_pitch bytes apart; base and pitches 4-byte aligned), all w x h.  d_lap = n_images x 2 int32 lapping
  * areas on the HOST (NULL = all {0,0} as the rectified stereo callers pass, src/Frame.cc:200-201).

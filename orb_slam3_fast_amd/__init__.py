@@ -65,6 +65,7 @@ def lib():
         L.orbx_extract.argtypes = [vp, vp, i, i, C.c_ssize_t, i, i, vp, vp, i, C.POINTER(i)]
         L.orbx_extract_batch_device.argtypes = [vp, vp, i, i, i, C.c_ssize_t, C.c_ssize_t, vp]
         L.orbx_sync.argtypes = [vp]
+        L.orbx_extract_stereo.argtypes = [vp, vp, vp, i, i, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, f, f, vp, vp]
         L.orbx_batch_results_device.argtypes = [vp] + [C.POINTER(vp)] * 4 + [C.POINTER(i)]
         L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
         L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, C.c_ssize_t, C.POINTER(i), C.POINTER(i)]
@@ -197,6 +198,25 @@ class ORBextractor:
         return mono, kps[:n.value].copy(), desc[:n.value].copy()
 
     # ---- batched many-camera mode
+    def extract_stereo(self, left, right, lap_left=(0, 0), lap_right=(0, 0), bf=0.0, b=0.0):
+        """Both eyes of one stereo frame in one batched pipeline (orbx_extract_stereo; the handle needs max_batch >= 2).
+        Returns ((monoL, kpsL, descL), (monoR, kpsR, descR)) and, when bf > 0, also (mvuRight, mvDepth) of the left eye."""
+        L, R = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        if L.shape != R.shape or L.ndim != 2:
+            raise ValueError("two gray images of the same size")
+        h, w = L.shape
+        cap = self.capacity
+        kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+        dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        nl, nr, ml, mr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        ll, lr = np.array(lap_left, np.int32), np.array(lap_right, np.int32)
+        _check(lib().orbx_extract_stereo(self._h, _p(L), _p(R), w, h, L.strides[0], R.strides[0], _p(ll), _p(lr), _p(kl), _p(dl),
+                                         cap, C.byref(nl), C.byref(ml), _p(kr), _p(dr), cap, C.byref(nr), C.byref(mr), float(bf),
+                                         float(b), _p(ur), _p(dp)))
+        out = ((ml.value, kl[:nl.value].copy(), dl[:nl.value].copy()), (mr.value, kr[:nr.value].copy(), dr[:nr.value].copy()))
+        return out + ((ur[:nl.value].copy(), dp[:nl.value].copy()),) if bf > 0 else out
+
     def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
         """Enqueue extraction of device-resident images (raw device pointer).  Asynchronous."""
         lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(n_images, 2)

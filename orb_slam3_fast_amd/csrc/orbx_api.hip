@@ -767,6 +767,52 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   return orbx_batch_download(ex, 0, kps, desc, cap, n_out);
 }
 
+int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
+                        ptrdiff_t stride_left, ptrdiff_t stride_right, const int32_t lap_left[2],
+                        const int32_t lap_right[2], orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left,
+                        int* n_left, int* mono_left, orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right,
+                        int* n_right, int* mono_right, float bf, float b, float* uright, float* depth) {
+  if (!ex || !n_left || !n_right || !mono_left || !mono_right) return fail(ORBX_E_BADARG, "null argument");
+  *n_left = *n_right = 0;
+  *mono_left = *mono_right = 0;
+  if (!img_left || !img_right || w <= 0 || h <= 0) return fail(ORBX_E_EMPTY, "empty image");
+  if (ex->maxB < 2) return fail(ORBX_E_CAPACITY, "orbx_extract_stereo needs a handle created with max_batch >= 2");
+  if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's maximum");
+  if (stride_left < w || stride_right < w) return fail(ORBX_E_BADARG, "stride < width");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int pitch = align_up(w, 64);
+  const size_t imgBytes = (size_t)pitch * h;
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, ex->stream));
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, ex->stream));
+  const int32_t lap[4] = {lap_left ? lap_left[0] : 0, lap_left ? lap_left[1] : 0, lap_right ? lap_right[0] : 0,
+                          lap_right ? lap_right[1] : 0};
+  rc = enqueue_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap);
+  if (rc != ORBX_OK) return rc;
+  const bool stereo = bf > 0.f && uright && depth;
+  if (stereo) {
+    rc = orbx_stereo_match_batch(ex, 0, ex, 1, 1, bf, b);
+    if (rc != ORBX_OK) return rc;
+  }
+  HIPC(hipStreamSynchronize(ex->stream));
+  int cnt[2] = {0, 0}, mono[2] = {0, 0};
+  HIPC(hipMemcpy(cnt, ex->d_nOut.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(mono, ex->d_mono.p, sizeof(mono), hipMemcpyDeviceToHost));
+  *n_left = cnt[0]; *n_right = cnt[1];
+  *mono_left = mono[0]; *mono_right = mono[1];
+  if (cnt[0] > cap_left || cnt[1] > cap_right) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
+  const size_t oc = (size_t)ex->gmax.outCap;
+  if (cnt[0] > 0 && kps_left) HIPC(hipMemcpy(kps_left, ex->d_kps.p, (size_t)cnt[0] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+  if (cnt[0] > 0 && desc_left) HIPC(hipMemcpy(desc_left, ex->d_desc.p, (size_t)cnt[0] * 32, hipMemcpyDeviceToHost));
+  if (cnt[1] > 0 && kps_right) HIPC(hipMemcpy(kps_right, ex->d_kps.p + oc, (size_t)cnt[1] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+  if (cnt[1] > 0 && desc_right) HIPC(hipMemcpy(desc_right, ex->d_desc.p + oc * 32, (size_t)cnt[1] * 32, hipMemcpyDeviceToHost));
+  if (stereo && cnt[0] > 0) {
+    HIPC(hipMemcpy(uright, ex->d_uR.p, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(depth, ex->d_depth.p, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return ORBX_OK;
+}
+
 int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, uint8_t* dst, ptrdiff_t dst_stride,
                        int* w, int* h) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");

@@ -96,6 +96,18 @@ int main(int argc, char** argv) {
   ORBmatcher matcher(0.9f, true);
   const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
   dump(out + ".m12", m12.data(), m12.size());
+  {  // the single-call stereo path must give the same keypoints, descriptors and depths
+    ORBextractor exP(nf, 1.2f, 8, 20, 7, w, h);
+    std::vector<ocv::KeyPoint> pL, pR;
+    ocv::Mat pdL, pdR;
+    std::vector<float> puR, pdepth;
+    int pmL = 0, pmR = 0;
+    exP.ExtractStereo(imL, imR, pL, pdL, pR, pdR, lap, lap, pmL, pmR, 0.12f * 532.03f, 0.12f, &puR, &pdepth);
+    dump(out + ".pkL", pL.data(), pL.size());
+    dump(out + ".pdR", pdR.data, (size_t)pdR.rows * 32);
+    dump(out + ".puR", puR.data(), puR.size());
+    dump(out + ".pdepth", pdepth.data(), pdepth.size());
+  }
   std::printf("%d %d %d %d %d\n", monoL, monoR, (int)kL.size(), (int)kR.size(), nm);
   return 0;
 }

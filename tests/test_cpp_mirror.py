@@ -57,6 +57,9 @@ def test_cpp_mirror_matches_oracle(oracle, tmp_path):
     prev = np.stack([okL["x"], okL["y"]], 1)
     on, om12, _ = oracle.search_init(okL, odL, okR, odR, (0, 0, w, h), prev, 100, 0.9, True)
     assert nm == on and np.fromfile(out + ".m12", np.int32).tolist() == om12.tolist()
+    # ORBextractor::ExtractStereo (one batched pipeline for both eyes + ComputeStereoMatches)
+    assert open(out + ".pkL", "rb").read() == okL.tobytes() and open(out + ".pdR", "rb").read() == odR.tobytes()
+    assert open(out + ".puR", "rb").read() == ou.tobytes() and open(out + ".pdepth", "rb").read() == od.tobytes()
 
 
 @pytest.mark.gpu

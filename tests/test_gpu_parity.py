@@ -475,3 +475,27 @@ def test_hipgraph_replay_of_the_single_image_pipeline(gpu):
                         os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
                        cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
+def test_extract_stereo_single_call(gpu, oracle):
+    """orbx_extract_stereo: both eyes + ComputeStereoMatches in one batched pipeline == the two-handle flow == oracle."""
+    w, h, nf = 752, 480, 1000
+    L, R = synth.stereo_pair(w, h, 66)
+    bf, b = np.float32(0.12) * np.float32(532.03), np.float32(0.12)
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    (mL, kL, dL), (mR, kR, dR), (u, dep) = ex.extract_stereo(L, R, bf=float(bf), b=float(b))
+    oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+    omL, okL, odL = oL.extract(L)
+    omR, okR, odR = oR.extract(R)
+    assert (mL, mR) == (omL, omR)
+    assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dL, odL)
+    assert np.array_equal(_kp_bytes(kR), _kp_bytes(okR)) and np.array_equal(dR, odR)
+    ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    assert u.tobytes() == ou.tobytes() and dep.tobytes() == od.tobytes() and (u >= 0).sum() > 100
+    # fisheye-style lapping areas, no stereo association
+    (mL, kL, dL), (mR, kR, dR) = ex.extract_stereo(L, R, (150, 751), (0, 600))
+    omL, okL, odL = oL.extract(L, (150, 751))
+    omR, okR, odR = oR.extract(R, (0, 600))
+    assert (mL, mR) == (omL, omR) and np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dR, odR)
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h).extract_stereo(L, R)

@@ -49,6 +49,15 @@ t0 = time.perf_counter()
 for _ in range(reps):
     exL(L)
 seq = (time.perf_counter() - t0) / reps * 1e3
+exP = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+for _ in range(5):
+    exP.extract_stereo(L, R, bf=bf, b=b)
+t0 = time.perf_counter()
+for _ in range(reps):
+    exP.extract_stereo(L, R, bf=bf, b=b)
+pair = (time.perf_counter() - t0) / reps * 1e3
+print("%dx%d N=%d  orbx_extract_stereo (both eyes + ComputeStereoMatches, one batched pipeline, one thread): %.3f ms (%.0f fps)"
+      % (w, h, nf, pair, 1e3 / pair))
 print("%dx%d N=%d  both-eye extraction (2 threads) %.3f +- %.3f ms   stereo match %.3f +- %.3f ms   total %.3f ms (%.0f fps); "
       "one eye alone %.3f ms" % (w, h, nf, ext.mean(), ext.std(), st.mean(), st.std(), (ext + st).mean(),
                                  1e3 / (ext + st).mean(), seq))
