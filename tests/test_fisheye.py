@@ -380,3 +380,21 @@ def test_hip_reproduces_fisheye_projection_golden():
     assert n1 == int(g["map_n"]) and np.array_equal(m1, g["map_match"]) and np.array_equal(o1, g["map_occ"])
     n2, m2, o2 = m.SearchByProjectionFrameFisheye(kps, g["desc"], int(g["n_left"]), bounds, pts, g["uvr"], g["occ"])
     assert n2 == int(g["frame_n"]) and np.array_equal(m2, g["frame_match"]) and np.array_equal(o2, g["frame_occ"])
+
+
+@pytest.mark.gpu
+def test_hip_single_call_fisheye_frame(oracle):
+    """One fisheye stereo frame through the latency path: orbx_extract_stereo (lapping areas, both eyes in one batch) and
+    the device-resident association on the same handle (left = image 0, right = image 1)."""
+    import orb_slam3_fast_amd as orbx
+    w = h = 512
+    L, R = synth.stereo_pair(w, h, 97)
+    ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    (mL, kL, dL), (mR, kR, dR) = ex.extract_stereo(L, R, (100, 511), (0, 400))
+    rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM1, np.eye(3), [0.1, 0.0, 0.0])
+    orbx.fisheye_match_async(ex, ex, rig, first_left=0, first_right=1, n_pairs=1)
+    n, nd, l2r, r2l, dep, pts = orbx.fisheye_download(ex, ex, 0)
+    ora = oracle.fisheye_stereo_match(kL, dL, mL, kR, dR, mR, oracle.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM1, np.eye(3), [0.1, 0, 0]),
+                                      ex.GetScaleSigmaSquares())
+    hip = (n, nd, l2r[: len(kL)], r2l[: len(kR)], dep[: len(kL)], pts[: len(kL)])
+    assert compare_float_results(hip, ora[:6], ora[6], mL) <= 2 and nd > 20
