@@ -121,6 +121,14 @@ struct ScratchBuf {  // same face as DevBuf; the caller has made its device curr
 
 }  // namespace
 
+// Layout of orbx_extractor::hostResults for the host entry points (one or two images):
+//   [0,16)  counts[2], mono[2]   | keypoints 2 x cap | descriptors 2 x cap x 32 | uRight cap | depth cap
+static inline size_t hr_kps(size_t) { return 64; }
+static inline size_t hr_desc(size_t cap) { return hr_kps(cap) + 2 * cap * sizeof(orbx_keypoint); }
+static inline size_t hr_ur(size_t cap) { return hr_desc(cap) + 2 * cap * 32; }
+static inline size_t hr_depth(size_t cap) { return hr_ur(cap) + cap * sizeof(float); }
+static inline size_t host_results_bytes(size_t cap) { return hr_depth(cap) + cap * sizeof(float) + 64; }
+
 struct orbx_extractor {
   orbx_params prm{};
   int device = 0;
@@ -144,6 +152,7 @@ struct orbx_extractor {
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
   int stereoPairs = 0;
+  uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)
   hipGraphExec_t graphExec[2] = {nullptr, nullptr};
   int graphW = 0, graphH = 0;
@@ -659,6 +668,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_xab.alloc(2 * nx + 64));
   ok(ex->d_yofs.alloc(ny + 64));
   ok(ex->d_yab.alloc(2 * ny + 64));
+  ok(hipHostMalloc(reinterpret_cast<void**>(&ex->hostResults), host_results_bytes(m.outCap), hipHostMallocDefault));
   if (e != hipSuccess) {
     std::string msg = std::string("allocation failed: ") + hipGetErrorString(e);
     orbx_extractor_destroy(ex);
@@ -676,6 +686,8 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
     if (e) (void)hipGraphExecDestroy(e);
     e = nullptr;
   }
+  if (ex->hostResults) (void)hipHostFree(ex->hostResults);
+  ex->hostResults = nullptr;
   ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xofs.free(); ex->d_yofs.free();
@@ -764,7 +776,21 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   const int32_t lap[2] = {lap0, lap1};
   rc = enqueue_extract(ex, ex->d_stage.p, 1, w, h, pitch, (ptrdiff_t)pitch * h, lap);
   if (rc != ORBX_OK) return rc;
-  return orbx_batch_download(ex, 0, kps, desc, cap, n_out);
+  if (!n_out) return fail(ORBX_E_BADARG, "null argument");
+  const size_t oc = (size_t)ex->gmax.outCap;  // results through pinned memory: async copies, one synchronisation
+  uint8_t* H = ex->hostResults;
+  hipStream_t st = ex->stream;
+  HIPC(hipMemcpyAsync(H, ex->d_nOut.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + 8, ex->d_mono.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + hr_kps(oc), ex->d_kps.p, oc * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + hr_desc(oc), ex->d_desc.p, oc * 32, hipMemcpyDeviceToHost, st));
+  HIPC(hipStreamSynchronize(st));
+  const int n = *reinterpret_cast<const int*>(H), mono = *reinterpret_cast<const int*>(H + 8);
+  *n_out = n;
+  if (n > cap) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
+  if (n > 0 && kps) std::memcpy(kps, H + hr_kps(oc), (size_t)n * sizeof(orbx_keypoint));
+  if (n > 0 && desc) std::memcpy(desc, H + hr_desc(oc), (size_t)n * 32);
+  return mono;
 }
 
 int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
@@ -794,21 +820,31 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
     rc = orbx_stereo_match_batch(ex, 0, ex, 1, 1, bf, b);
     if (rc != ORBX_OK) return rc;
   }
-  HIPC(hipStreamSynchronize(ex->stream));
-  int cnt[2] = {0, 0}, mono[2] = {0, 0};
-  HIPC(hipMemcpy(cnt, ex->d_nOut.p, sizeof(cnt), hipMemcpyDeviceToHost));
-  HIPC(hipMemcpy(mono, ex->d_mono.p, sizeof(mono), hipMemcpyDeviceToHost));
+  // all results travel with asynchronous copies into pinned memory behind the kernels: one synchronisation in total
+  const size_t oc = (size_t)ex->gmax.outCap;
+  uint8_t* H = ex->hostResults;
+  hipStream_t st = ex->stream;
+  HIPC(hipMemcpyAsync(H, ex->d_nOut.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + 8, ex->d_mono.p, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + hr_kps(oc), ex->d_kps.p, 2 * oc * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+  HIPC(hipMemcpyAsync(H + hr_desc(oc), ex->d_desc.p, 2 * oc * 32, hipMemcpyDeviceToHost, st));
+  if (stereo) {
+    HIPC(hipMemcpyAsync(H + hr_ur(oc), ex->d_uR.p, oc * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPC(hipMemcpyAsync(H + hr_depth(oc), ex->d_depth.p, oc * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
+  HIPC(hipStreamSynchronize(st));
+  const int* cnt = reinterpret_cast<const int*>(H);
+  const int* mono = reinterpret_cast<const int*>(H + 8);
   *n_left = cnt[0]; *n_right = cnt[1];
   *mono_left = mono[0]; *mono_right = mono[1];
   if (cnt[0] > cap_left || cnt[1] > cap_right) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
-  const size_t oc = (size_t)ex->gmax.outCap;
-  if (cnt[0] > 0 && kps_left) HIPC(hipMemcpy(kps_left, ex->d_kps.p, (size_t)cnt[0] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-  if (cnt[0] > 0 && desc_left) HIPC(hipMemcpy(desc_left, ex->d_desc.p, (size_t)cnt[0] * 32, hipMemcpyDeviceToHost));
-  if (cnt[1] > 0 && kps_right) HIPC(hipMemcpy(kps_right, ex->d_kps.p + oc, (size_t)cnt[1] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-  if (cnt[1] > 0 && desc_right) HIPC(hipMemcpy(desc_right, ex->d_desc.p + oc * 32, (size_t)cnt[1] * 32, hipMemcpyDeviceToHost));
+  if (cnt[0] > 0 && kps_left) std::memcpy(kps_left, H + hr_kps(oc), (size_t)cnt[0] * sizeof(orbx_keypoint));
+  if (cnt[0] > 0 && desc_left) std::memcpy(desc_left, H + hr_desc(oc), (size_t)cnt[0] * 32);
+  if (cnt[1] > 0 && kps_right) std::memcpy(kps_right, H + hr_kps(oc) + oc * sizeof(orbx_keypoint), (size_t)cnt[1] * sizeof(orbx_keypoint));
+  if (cnt[1] > 0 && desc_right) std::memcpy(desc_right, H + hr_desc(oc) + oc * 32, (size_t)cnt[1] * 32);
   if (stereo && cnt[0] > 0) {
-    HIPC(hipMemcpy(uright, ex->d_uR.p, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToHost));
-    HIPC(hipMemcpy(depth, ex->d_depth.p, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToHost));
+    std::memcpy(uright, H + hr_ur(oc), (size_t)cnt[0] * sizeof(float));
+    std::memcpy(depth, H + hr_depth(oc), (size_t)cnt[0] * sizeof(float));
   }
   return ORBX_OK;
 }
