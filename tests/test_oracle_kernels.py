@@ -277,3 +277,55 @@ def test_hamming(oracle):
     a, b = rng.integers(0, 256, (2, 32), dtype=np.uint8)
     assert oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
     assert oracle.hamming(a, a) == 0 and oracle.hamming(a, ~a) == 256
+
+
+def test_ic_angle_vs_numpy_restatement(oracle):
+    """IC_Angle (src/ORBextractor.cc:75-99) transcribed with numpy: integer moments over the circular patch, then
+    cv::fastAtan2 of (m01, m10)."""
+    rng = np.random.default_rng(21)
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    for _ in range(40):
+        im = rng.integers(0, 256, (50, 60), dtype=np.uint8)
+        cx, cy = int(rng.integers(16, 44)), int(rng.integers(16, 34))
+        c = im.astype(np.int64)
+        m10 = sum(u * c[cy, cx + u] for u in range(-15, 16))
+        m01 = 0
+        for v in range(1, 16):
+            v_sum = 0
+            for u in range(-umax[v], umax[v] + 1):
+                plus, minus = c[cy + v, cx + u], c[cy - v, cx + u]
+                v_sum += plus - minus
+                m10 += u * (plus + minus)
+            m01 += v * v_sum
+        assert oracle.ic_angle(im, cx, cy) == oracle.fast_atan2(float(np.float32(m01)), float(np.float32(m10)))
+
+
+def test_rotated_descriptor_vs_numpy_restatement(oracle):
+    """computeOrbDescriptor (src/ORBextractor.cc:102-147) transcribed with numpy float32: a = cos, b = sin of
+    angle * (float)(CV_PI / 180.f) (through the oracle's defined sin/cos), sample rows
+    cvRound(x b + y a), columns cvRound(x a - y b) with separately rounded float products, bit i of byte k = test 8k + i."""
+    f32 = np.float32
+    rng = np.random.default_rng(22)
+    ptr = oracle.lib().oro_pattern()
+    pat = np.frombuffer((ctypes.c_int8 * 1024).from_address(ptr), np.int8).reshape(512, 2).astype(np.int64)
+    factor_pi = f32(np.pi / f32(180.0))
+
+    def cv_round(v):  # cvRound(float): round half to even
+        return int(np.rint(np.float64(v)))
+
+    for _ in range(25):
+        im = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+        px, py = float(rng.integers(20, 44)), float(rng.integers(20, 44))
+        angle = f32(rng.uniform(0, 360))
+        s, c = oracle.sincosf(float(angle * factor_pi))
+        a, b = f32(c), f32(s)
+        exp = np.zeros(32, np.uint8)
+        for i in range(256):
+            vals = []
+            for x, y in (pat[2 * i], pat[2 * i + 1]):
+                row = cv_round(f32(f32(x) * b) + f32(f32(y) * a))
+                col = cv_round(f32(f32(x) * a) - f32(f32(y) * b))
+                vals.append(int(im[int(py) + row, int(px) + col]))
+            if vals[0] < vals[1]:
+                exp[i // 8] |= 1 << (i % 8)
+        assert np.array_equal(oracle.descriptor(im, px, py, float(angle)), exp)
