@@ -329,3 +329,34 @@ def test_rotated_descriptor_vs_numpy_restatement(oracle):
             if vals[0] < vals[1]:
                 exp[i // 8] |= 1 << (i % 8)
         assert np.array_equal(oracle.descriptor(im, px, py, float(angle)), exp)
+
+
+def test_resize_geometry_vs_torch_float_bilinear(oracle):
+    """cv::resize(INTER_LINEAR) samples at half-pixel centres, like torch's bilinear interpolate with
+    align_corners=False (no antialiasing); the 11-bit fixed-point arithmetic may differ from the float result by one
+    gray level.  An independent check of the coefficient geometry (sx, fx) of B2."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(31)
+    for (sh, sw, dh, dw) in ((720, 1280, 600, 1067), (480, 752, 400, 627), (240, 320, 201, 267), (100, 90, 84, 75)):
+        img = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float64))[None, None], size=(dh, dw), mode="bilinear",
+                                              align_corners=False)[0, 0].numpy()
+        got = oracle.resize(img, dw, dh).astype(np.float64)
+        assert np.abs(got - ref).max() <= 1.0 + 1e-9
+        assert np.abs(got - np.rint(ref)).mean() < 0.2  # equal to the rounded float value in ~87 % of the pixels (the
+        # intermediate >> 4 and >> 16 truncations bias the fixed-point result down by a fraction of a level)
+
+
+def test_blur_vs_float_gaussian(oracle):
+    """The fixed-point 7x7 blur against scipy's float convolution with the normalised sigma = 2 Gaussian (mirror border =
+    BORDER_REFLECT_101): the integer taps {18, 34, 48, 56, ...} / 256 are that kernel to 8 bits, so results agree within
+    two gray levels."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(32)
+    img = rng.integers(0, 256, (90, 120), dtype=np.uint8)
+    x = np.arange(-3, 4)
+    g = np.exp(-x * x / (2 * 2.0 * 2.0))
+    g /= g.sum()
+    assert np.abs(g * 256 - np.array([18, 34, 48, 56, 48, 34, 18])).max() < 0.9
+    ref = ndi.convolve1d(ndi.convolve1d(img.astype(np.float64), g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
+    assert np.abs(oracle.blur(img).astype(np.float64) - ref).max() < 2.0
