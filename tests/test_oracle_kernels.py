@@ -360,3 +360,43 @@ def test_blur_vs_float_gaussian(oracle):
     assert np.abs(g * 256 - np.array([18, 34, 48, 56, 48, 34, 18])).max() < 0.9
     ref = ndi.convolve1d(ndi.convolve1d(img.astype(np.float64), g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
     assert np.abs(oracle.blur(img).astype(np.float64) - ref).max() < 2.0
+
+
+def test_fast_against_the_definition(oracle):
+    """FAST-9-16 from its definition, by brute force: p is a corner at threshold t iff 9 contiguous ring pixels are all
+    > I(p) + t or all < I(p) - t; cornerScore = the largest t at which p is still a corner (OpenCV's documented
+    meaning); non-maximum suppression keeps p iff its score is strictly greater than the 8 neighbours' scores."""
+    rng = np.random.default_rng(41)
+    base = rng.integers(0, 256, (6, 7), dtype=np.uint8)
+    img = np.kron(base, np.ones((6, 6), np.uint8))
+    img = (img.astype(np.int16) + rng.integers(-25, 26, img.shape)).clip(0, 255).astype(np.uint8)
+    h, w = img.shape
+    I = img.astype(np.int32)
+
+    def is_corner(x, y, t):
+        ring = [int(I[y + dy, x + dx]) for dx, dy in RING]
+        c = int(I[y, x])
+        for s in range(16):
+            arc = [ring[(s + k) % 16] for k in range(9)]
+            if all(v > c + t for v in arc) or all(v < c - t for v in arc):
+                return True
+        return False
+
+    th = 20
+    score = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if is_corner(x, y, th):
+                t = th
+                while t + 1 <= 255 and is_corner(x, y, t + 1):
+                    t += 1
+                score[y, x] = t
+    exp_all = {(x, y, int(score[y, x])) for y in range(h) for x in range(w) if score[y, x] > 0}
+    got_all = {tuple(p) for p in oracle.fast(img, th, nms=False).tolist()}
+    assert {(x, y) for x, y, _ in got_all} == {(x, y) for x, y, _ in exp_all} and len(exp_all) > 20
+    exp_nms = set()
+    for (x, y, s) in exp_all:
+        nb = [score[y + j, x + i] for j in (-1, 0, 1) for i in (-1, 0, 1) if (i, j) != (0, 0)]
+        if all(s > v for v in nb):
+            exp_nms.add((x, y, s))
+    assert {tuple(p) for p in oracle.fast(img, th, nms=True).tolist()} == exp_nms and len(exp_nms) > 5
