@@ -202,7 +202,9 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 // mask has 9 contiguous ones (shift-and ladder).
 constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-constexpr int kListCap = 640;  // LDS corner list of k_detect (flushed when it could overflow)
+constexpr int kListCap = 640;    // upper bound of the test hook orbx_debug_set_detect_list_cap
+constexpr int kSurvCap = 448;    // LDS list of compass-test survivors of k_detect (flushed before it would overflow)
+constexpr int kCornerCap = 256;  // LDS corner list (a cell with more corners takes the tile-scan NMS)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
   uint32_t d = m | (m << 16);
@@ -215,7 +217,7 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits
 
 // Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
 // polarity.  v_cmp leaves each comparison as a 64-lane mask in SGPRs, so the combination is scalar-ALU work:
-// per pixel slot 8 VALU compares + 14 scalar ops.  Returns the wave mask of lanes whose pixel survives.
+// per pixel slot 8 VALU compares + 7 scalar ops.  Returns the wave mask of lanes whose pixel survives.
 template <int P>
 __device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int t) {
   const int c = (r[3][(3 + P) >> 2] >> (8 * ((3 + P) & 3))) & 0xFF;
@@ -229,8 +231,9 @@ __device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int 
     B[q] = __ballot(v > hi);
     D[q] = __ballot(v < lo);
   }
-  return (B[0] & B[1]) | (B[1] & B[2]) | (B[2] & B[3]) | (B[3] & B[0]) | (D[0] & D[1]) | (D[1] & D[2]) |
-         (D[2] & D[3]) | (D[3] & D[0]);
+  // two cyclically adjacent compass points set  <=>  one of {0, 2} and one of {1, 3} set (in a 4-cycle every even
+  // position is adjacent to every odd one): 7 scalar ops instead of 15
+  return ((B[0] | B[2]) & (B[1] | B[3])) | ((D[0] | D[2]) & (D[1] | D[3]));
 }
 
 // FAST contrast of one pixel from the LDS tile: M = max over the 16 nine-pixel arcs of the arc's minimum
@@ -341,8 +344,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
   uint32_t* score = tile + TPd * g.tileH;
   uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
-  uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kListCap corner positions (y << 8 | x)
-  uint16_t* slist = list + kListCap;                                     // kListCap compass-test survivors
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kCornerCap corner positions (y << 8 | x)
+  uint16_t* slist = list + kCornerCap;                                   // kSurvCap compass-test survivors
+  const int survCap = min(listCap, kSurvCap), cornerCap = min(listCap, kCornerCap);
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile);
   const int qpr = (dw + 3) >> 2;  // quads per detect row
   const int nq = qpr * dh;
@@ -415,13 +419,13 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
         const int oA = nList + prefix_count(mA);
         const int oB = nList + __popcll(mA) + prefix_count(mB);
-        if (cornerA && oA < listCap) list[oA] = (uint16_t)yxA;
-        if (cornerB && oB < listCap) list[oB] = (uint16_t)yxB;
+        if (cornerA && oA < cornerCap) list[oA] = (uint16_t)yxA;
+        if (cornerB && oB < cornerCap) list[oB] = (uint16_t)yxB;
         nList += __popcll(mA) + __popcll(mB);
       }
-      if (nList > listCap) {
+      if (nList > cornerCap) {
         overflowed = true;
-        nList = listCap;
+        nList = cornerCap;
       }
       __syncthreads();
       nSurv = 0;
@@ -447,6 +451,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       sm[2] = compass_wave<2>(r, t) & __ballot(act && valid > 2);
       sm[3] = compass_wave<3>(r, t) & __ballot(act && valid > 3);
       if (act) score[(yd + 1) * SPd + j + 1] = 0;
+      // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
+      if (nSurv + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > survCap) flush_survivors();
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
@@ -454,7 +460,6 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
           slist[nSurv + prefix_count(m)] = (uint16_t)((yd << 8) | (4 * j + pI));
         nSurv += __popcll(m);
       }
-      if (nSurv > listCap - 256) flush_survivors();
     }
     flush_survivors();
     const int nCorners = nList;
@@ -536,7 +541,7 @@ void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : 
 // Cells of levels [level0, level1) only: level 0 needs no resize and is launched beside the pyramid chain.
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, hipStream_t s) {
-  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 16;
   const int cellBegin = g.lv[level0].cellStart;
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
@@ -3763,7 +3768,7 @@ hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
 
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
-  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 4 * kListCap + 16;
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;
