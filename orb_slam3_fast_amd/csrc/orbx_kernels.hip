@@ -321,6 +321,19 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
+#ifdef DET_CLK  // shader-clock measurement aid: cycles per 10 ns tick over the life of a few waves
+  const long long clk0 = clock64(), wall0 = wall_clock64();
+  struct ClkPrint {
+    long long c0, w0;
+    int on;
+    __device__ ~ClkPrint() {
+      if (on) {
+        const long long dc = clock64() - c0, dw = wall_clock64() - w0;
+        printf("det wave: %lld shader cycles in %lld x 10 ns -> %.3f GHz\n", dc, dw, dw ? (double)dc / (double)dw / 10.0 : 0.0);
+      }
+    }
+  } clkPrint{clk0, wall0, (int)(lane == 0 && blockIdx.y == 31 && (blockIdx.x % 400) == 7)};
+#endif
   // Plain cell order: an XCD-aware remap (consecutive cells per XCD, to share halo lines in one L2) was
   // measured slower here (526-583 vs 494 us): the kernel is VALU-bound and the remap unbalances the XCDs.
   int cell = cellBegin + blockIdx.x;
