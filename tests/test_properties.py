@@ -1,0 +1,92 @@
+"""Property tests (hypothesis) of the oracle's kernels: invariants that hold for any input, complementing the KATs."""
+import numpy as np
+import pytest
+
+hyp = pytest.importorskip("hypothesis")
+from hypothesis import given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+from hypothesis.extra import numpy as hnp  # noqa: E402
+
+SET = settings(max_examples=40, deadline=None)
+desc32 = hnp.arrays(np.uint8, (32,))
+
+
+@SET
+@given(desc32, desc32, desc32)
+def test_hamming_is_a_metric(oracle, a, b, c):
+    h = oracle.hamming
+    assert h(a, a) == 0 and h(a, b) == h(b, a) == int(np.unpackbits(a ^ b).sum())
+    assert h(a, c) <= h(a, b) + h(b, c) and 0 <= h(a, b) <= 256
+
+
+@SET
+@given(st.integers(0, 255), st.integers(8, 60), st.integers(8, 60), st.integers(5, 70), st.integers(5, 70))
+def test_resize_and_blur_keep_constants(oracle, v, w, h, dw, dh):
+    img = np.full((h, w), v, np.uint8)
+    assert (oracle.resize(img, dw, dh) == v).all() and (oracle.blur(img) == v).all()
+
+
+@SET
+@given(hnp.arrays(np.uint8, st.tuples(st.integers(9, 30), st.integers(9, 30))))
+def test_blur_stays_within_the_local_range(oracle, img):
+    out = oracle.blur(img).astype(int)
+    pad = np.pad(img.astype(int), 3, mode="reflect")
+    h, w = img.shape
+    win = np.lib.stride_tricks.sliding_window_view(pad, (7, 7))
+    assert (out >= win.min((2, 3))).all() and (out <= win.max((2, 3))).all()
+
+
+@SET
+@given(hnp.arrays(np.uint8, st.tuples(st.integers(12, 28), st.integers(12, 28))), st.integers(5, 60), st.integers(1, 40))
+def test_fast_threshold_monotonicity_and_scores(oracle, img, t, dt):
+    lo = oracle.fast(img, t, nms=False)
+    hi = oracle.fast(img, t + dt, nms=False)
+    s_lo = {(x, y) for x, y, _ in lo.tolist()}
+    s_hi = {(x, y) for x, y, _ in hi.tolist()}
+    assert s_hi <= s_lo                                   # raising the threshold never creates a corner
+    nms = oracle.fast(img, t, nms=True)
+    assert {(x, y) for x, y, _ in nms.tolist()} <= s_lo   # suppression only removes
+    assert all(s >= t for _, _, s in nms.tolist())         # cornerScore = M - 1 >= t  <=>  M > t
+    sc = {(x, y): s for x, y, s in nms.tolist()}
+    assert all(((x, y) in s_hi) == (s >= t + dt) for (x, y), s in sc.items())  # score >= t'  <=>  corner at t'
+    h, w = img.shape
+    assert all(3 <= x < w - 3 and 3 <= y < h - 3 for x, y in s_lo)
+
+
+@SET
+@given(hnp.arrays(np.uint8, st.tuples(st.integers(1, 12), st.just(32))), hnp.arrays(np.uint8, st.tuples(st.integers(0, 12), st.just(32))))
+def test_bf_knn2_properties(oracle, q, t):
+    idx, dist, ok = oracle.bf_knn2(q, t)
+    for i in range(len(q)):
+        d = [oracle.hamming(q[i], t[j]) for j in range(len(t))]
+        if len(t) >= 1:
+            assert dist[i, 0] == min(d) and idx[i, 0] == d.index(min(d))   # first minimum
+        else:
+            assert idx[i, 0] == -1
+        if len(t) >= 2:
+            rest = d[: idx[i, 0]] + d[idx[i, 0] + 1:]
+            assert dist[i, 1] == min(rest) and dist[i, 0] <= dist[i, 1]
+            assert bool(ok[i]) == (np.float32(dist[i, 0]) < np.float32(dist[i, 1]) * 0.7)
+        else:
+            assert idx[i, 1] == -1 and not ok[i]
+
+
+@SET
+@given(st.integers(0, 2 ** 31 - 1), st.floats(-30, 700), st.floats(-30, 500), st.sampled_from([3.0, 11.0, 40.0, 150.0]),
+       st.integers(-1, 3), st.integers(-1, 7))
+def test_features_in_area_equals_brute_force_over_the_cells_it_visits(oracle, seed, x, y, r, lo, hi):
+    rng = np.random.default_rng(seed)
+    n = 300
+    k = np.zeros(n, oracle.KP_DTYPE)
+    k["x"], k["y"], k["octave"] = rng.uniform(0, 640, n), rng.uniform(0, 480, n), rng.integers(0, 8, n)
+    got = oracle.features_in_area(k, (0.0, 0.0, 640.0, 480.0), x, y, r, lo, hi).tolist()
+    x32, y32, r32 = np.float32(x), np.float32(y), np.float32(r)
+    inside = (np.abs(k["x"] - x32) < r32) & (np.abs(k["y"] - y32) < r32)
+    if lo > 0 or hi >= 0:
+        inside &= k["octave"] >= lo
+        if hi >= 0:
+            inside &= k["octave"] <= hi
+    # every reported keypoint satisfies the window + level test; keypoints inside the window are reported unless the
+    # grid rounding (PosInGrid rounds to the NEAREST cell) puts them in a cell outside the scanned block
+    assert all(inside[i] for i in got) and len(set(got)) == len(got)
+    assert len(got) >= 0.7 * int(inside.sum()) - 2
