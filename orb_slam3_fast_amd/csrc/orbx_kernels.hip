@@ -310,6 +310,20 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
   return __builtin_elementwise_maximum(maxmin - c, c - minmax);
 }
 
+// XCD-aware block -> tile mapping.  Workgroups go to the 8 XCDs round-robin by flat workgroup id, so neighbouring
+// tiles land in 8 different L2s and every shared halo line is fetched from HBM once per XCD.  This permutation keeps
+// the dispatch order balanced (every aligned chunk of 8*K flat ids still covers the same 8*K tiles) but hands each
+// XCD a run of K consecutive tiles.  `by` is the slower grid index (image); chunks cut by an image boundary keep
+// the identity order.
+__device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
+  if (K <= 1) return bx;
+  const int o = (int)(((unsigned)by * (unsigned)nbx) & 7u), xs = bx + o, ch = 8 * K;
+  const int c0 = (xs / ch) * ch;
+  if (c0 < o || c0 + ch > nbx + o) return bx;
+  const int r = xs - c0;
+  return c0 + (r & 7) * K + (r >> 3) - o;
+}
+
 // One wave per FAST cell (workgroup = 64 threads, so __syncthreads() is a wave barrier).
 // Pass 1 runs at iniThFAST; only a cell whose post-NMS set is empty is redone at minThFAST (:942-959).
 // The NMS needs no threshold masking: a neighbour that is not a corner at t has score < t <= the centre's.
@@ -317,7 +331,7 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
                                                int* __restrict__ cellCount, int ablate, int listCap,
-                                               int cellBegin) {
+                                               int cellBegin, int xcdRun) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
@@ -334,9 +348,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     }
   } clkPrint{clk0, wall0, (int)(lane == 0 && blockIdx.y == 31 && (blockIdx.x % 400) == 7)};
 #endif
-  // Plain cell order: an XCD-aware remap (consecutive cells per XCD, to share halo lines in one L2) was
-  // measured slower here (526-583 vs 494 us): the kernel is VALU-bound and the remap unbalances the XCDs.
-  int cell = cellBegin + blockIdx.x;
+  // Runs of xcdRun horizontally consecutive cells share an XCD and therefore the L2 lines of their common halo
+  // columns (HBM-side fetch 410 -> 151 MB per 64-image launch; same duration, the kernel is VALU-bound).
+  int cell = cellBegin + xcd_run_remap(blockIdx.x, gridDim.x, blockIdx.y, xcdRun);
   int l = 0;
   while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellStart) l++;
   const LevelDev L = g.lv[l];
@@ -560,8 +574,9 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
   if (cellEnd <= cellBegin) return hipSuccess;
   dim3 grid(cellEnd - cellBegin, nimg);
   static const int ablate = getenv("ORBX_DETECT_ABLATE") ? atoi(getenv("ORBX_DETECT_ABLATE")) : 0;
+  static const int xcdRun = getenv("ORBX_DETECT_XCD_RUN") ? atoi(getenv("ORBX_DETECT_XCD_RUN")) : 8;
   hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate, g_detect_list_cap,
-                     cellBegin);
+                     cellBegin, xcdRun);
   return hipGetLastError();
 }
 
@@ -1403,13 +1418,13 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // 18,34,48,56 | 48,34,18,0) for TWO vertically adjacent rows and stores them as u16 pairs (row r | row r+1 << 16;
 // max 255*256 fits).  Vertical pass: a thread owns a 4x4 output block; with rows packed in pairs the 7-tap
 // column filter is 3 v_dot2_u32_u16 + 1 mad per output.  All integer, exact; one rounding (+32768 >> 16).
-__global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int level1) {
+__global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int level1, int xcdRun) {
   __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];    // +1: pad against bank conflicts
   __shared__ uint32_t hp[(BL_TH + 6) / 2][BL_TW + 1];      // [row pair][32*(x%4) + x/4] = H(2j, x) | H(2j+1, x) << 16
                                                            // (quad-transposed columns: both passes bank-conflict free)
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  int tile = blockIdx.x;
+  int tile = xcd_run_remap(blockIdx.x, gridDim.x, blockIdx.z, xcdRun);
   int l = level0;
   for (;; l++) {  // tiles of levels [level0, level1) are enumerated in one grid dimension
     const int tx = (g.lv[l].w + BL_TW - 1) / BL_TW, ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
@@ -1525,7 +1540,8 @@ hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int le
   for (int l = level0; l < level1; l++)
     tiles += ((g.lv[l].w + BL_TW - 1) / BL_TW) * ((g.lv[l].h + BL_TH - 1) / BL_TH);
   if (tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1);
+  static const int xcdRun = getenv("ORBX_BLUR_XCD_RUN") ? atoi(getenv("ORBX_BLUR_XCD_RUN")) : 1;
+  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, xcdRun);
   return hipGetLastError();
 }
 
