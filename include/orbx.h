@@ -198,6 +198,52 @@ int orbx_cvt_gray(int device, const uint8_t* src, int w, int h, ptrdiff_t src_st
 int orbx_resize_linear(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, uint8_t* dst,
                        int dst_w, int dst_h, ptrdiff_t dst_stride);
 
+/* Replaces cv::remap(im, imToFeed, M1, M2, cv::INTER_LINEAR) of System::TrackStereo (src/System.cc:294-295) with the
+ * CV_32F maps Settings::precomputeRectificationMaps builds (src/Settings.cc:557-572): OpenCV's fixed-point bilinear remap
+ * (positions rounded to 1/32 px, 15-bit weights, BORDER_CONSTANT 0) on 8UC1 / 8UC3 / 8UC4.  map_x / map_y hold dst_h rows of
+ * dst_w floats, map_stride floats apart.  Host images in and out. */
+int orbx_remap_linear(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, int channels, const float* map_x,
+                      const float* map_y, ptrdiff_t map_stride, uint8_t* dst, int dst_w, int dst_h, ptrdiff_t dst_stride);
+/* Replaces cv::createCLAHE(clip_limit, cv::Size(tiles_x, tiles_y))->apply(im, im) of the TUM-VI front ends
+ * (Examples/Stereo/stereo_tum_vi.cc:100,142-143; Examples/Stereo-Inertial/stereo_inertial_tum_vi.cc:151,190-191; the
+ * examples pass 3.0 and 8 x 8) on 8UC1.  Host images in and out (src == dst is allowed). */
+int orbx_clahe(int device, const uint8_t* src, int w, int h, ptrdiff_t src_stride, double clip_limit, int tiles_x, int tiles_y,
+               uint8_t* dst, ptrdiff_t dst_stride);
+
+/* Device-resident pre-processing chain in front of the extractor, so that raw camera frames never return to the host:
+ * [CLAHE] -> [remap | resize] -> [gray], the order in which the reference applies them (example main: clahe->apply;
+ * System::TrackStereo: remap or resize, src/System.cc:288-302; Tracking::GrabImageStereo: cvtColor, src/Tracking.cc:1394-1412).
+ * A stage is enabled by its fields: clahe_tiles_x/y > 0 (single-channel frames only); map_x/map_y != NULL (n_maps maps of
+ * out_h x out_w floats each, map m directly after map m-1, rows map_stride floats apart, 0 = out_w; frame i of a batch uses
+ * map i % n_maps, i.e. 2 maps = left / right eye interleaved); otherwise out_w x out_h != src size enables cv::resize;
+ * channels 3 / 4 enables the gray conversion.  The maps are copied to the device at creation. */
+typedef struct orbx_preproc_params {
+  int32_t src_w, src_h, channels, rgb_order;
+  int32_t out_w, out_h;
+  const float* map_x;
+  const float* map_y;
+  ptrdiff_t map_stride;
+  int32_t n_maps;
+  double clahe_clip_limit;
+  int32_t clahe_tiles_x, clahe_tiles_y;
+} orbx_preproc_params;
+typedef struct orbx_preproc orbx_preproc;
+int orbx_preproc_create(const orbx_preproc_params* p, int max_batch, int device, orbx_preproc** out);
+void orbx_preproc_destroy(orbx_preproc* pp);
+int orbx_preproc_output_size(const orbx_preproc* pp, int* out_w, int* out_h);
+/* One host frame through the chain (map `map_index`), host result out_w x out_h gray. */
+int orbx_preproc_run(orbx_preproc* pp, const uint8_t* frame, ptrdiff_t stride, int map_index, uint8_t* dst, ptrdiff_t dst_stride);
+/* n_frames device-resident raw frames (frame i at d_frames + i*image_pitch) through the chain; synchronises and returns the
+ * device-resident result (owned by the handle, valid until its next run). */
+int orbx_preproc_run_device(orbx_preproc* pp, const uint8_t* d_frames, int n_frames, ptrdiff_t row_pitch,
+                            ptrdiff_t image_pitch, const uint8_t** d_out, int* out_w, int* out_h, ptrdiff_t* out_row_pitch,
+                            ptrdiff_t* out_image_pitch);
+/* orbx_extract_batch_device on raw frames: the chain and the extraction are enqueued on the extractor's stream, nothing
+ * synchronises.  The pre-processor's buffers back level 0 of the pyramid until orbx_sync: use one orbx_preproc per extractor
+ * handle in flight. */
+int orbx_extract_batch_raw_device(orbx_extractor* ex, orbx_preproc* pp, const uint8_t* d_frames, int n_frames,
+                                  ptrdiff_t row_pitch, ptrdiff_t image_pitch, const int32_t* lap);
+
 /* Replaces Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys through
  * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) -- five fixed-point iterations of the inverse distortion
  * in double, then x' = fx x + cx.  K = fx fy cx cy (Pinhole::toK()); dist = the n_dist (4, 5, 8, 12 or 14) OpenCV

@@ -369,3 +369,24 @@ def resize_c(img, dw, dh):
     dst = np.zeros((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
     lib().oro_resize_c(_p(img), w, h, C.c_long(img.strides[0]), cn, _p(dst), dw, dh, C.c_long(dst.strides[0]))
     return dst
+
+
+def remap(img, mapx, mapy):
+    img = np.ascontiguousarray(img, np.uint8)
+    mapx = np.ascontiguousarray(mapx, np.float32)
+    mapy = np.ascontiguousarray(mapy, np.float32)
+    h, w = img.shape
+    dh, dw = mapx.shape
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oro_remap(_p(img), w, h, C.c_long(img.strides[0]), _p(mapx), _p(mapy), C.c_long(dw), _p(dst), dw, dh,
+                    C.c_long(dst.strides[0]))
+    return dst
+
+
+def clahe(img, clip=3.0, tiles=(8, 8)):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().oro_clahe(_p(img), w, h, C.c_long(img.strides[0]), C.c_double(clip), tiles[0], tiles[1], _p(dst),
+                    C.c_long(dst.strides[0]))
+    return dst

@@ -186,6 +186,135 @@ void resize_linear_u8c(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride,
   }
 }
 
+// cv::remap(src, dst, map1 (CV_32FC1 x), map2 (CV_32FC1 y), INTER_LINEAR, BORDER_CONSTANT, 0) on 8UC1
+// (src/System.cc:294-295 with the maps of src/Settings.cc:557-572).  OpenCV imgwarp.cpp, restated from memory:
+//  * RemapInvoker turns the float maps into fixed point per pixel: sx = cvRound(mapx * INTER_TAB_SIZE) (INTER_BITS = 5),
+//    integer part saturate_cast<short>(sx >> 5), fraction index (sy & 31) * 32 + (sx & 31);
+//  * remapBilinear reads the 2x2 weights from BilinearTab_i: float weights (1-fy)(1-fx) ... times 2^15
+//    (INTER_REMAP_COEF_BITS), saturate_cast<short>; the only table entry whose sum is not 2^15 is fraction (0,0)
+//    (32768 saturates to 32767) and initInterTab2D repairs it by adding the difference to the LAST tap: {32767,0,0,1};
+//  * result = saturate_cast<uchar>((sum of tap * weight + 2^14) >> 15); taps outside the source count as borderValue 0.
+static inline int sat_short_int(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+void remap_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride, const float* mapx, const float* mapy,
+                     ptrdiff_t map_stride, uint8_t* dst, int dw, int dh, ptrdiff_t dst_stride) {
+  static short wtab[1024][4];
+  static bool init = false;
+  if (!init) {
+    for (int fy = 0; fy < 32; fy++)
+      for (int fx = 0; fx < 32; fx++) {
+        const float vx[2] = {1.f - fx * (1.f / 32), fx * (1.f / 32)}, vy[2] = {1.f - fy * (1.f / 32), fy * (1.f / 32)};
+        short* w = wtab[fy * 32 + fx];
+        int isum = 0;
+        for (int k1 = 0; k1 < 2; k1++)
+          for (int k2 = 0; k2 < 2; k2++) {
+            w[k1 * 2 + k2] = (short)sat_short_int(cv_round(vy[k1] * vx[k2] * 32768.f));
+            isum += w[k1 * 2 + k2];
+          }
+        if (isum != 32768) w[3] = (short)(w[3] - (isum - 32768));  // ksize 2: the repaired tap is [1][1]
+      }
+    init = true;
+  }
+  for (int y = 0; y < dh; y++) {
+    const float* MX = mapx + y * map_stride;
+    const float* MY = mapy + y * map_stride;
+    uint8_t* D = dst + y * dst_stride;
+    for (int x = 0; x < dw; x++) {
+      // cvRound(float) is cvtss2si: NaN and values outside int give INT_MIN (lrint would give a 64-bit indefinite)
+      auto rnd = [](float t) { return std::fabs(t) < 2147483648.f ? (int)std::lrint(t) : INT_MIN; };
+      const int fsx = rnd(MX[x] * 32.f), fsy = rnd(MY[x] * 32.f);
+      const int sx = sat_short_int(fsx >> 5), sy = sat_short_int(fsy >> 5);
+      const short* w = wtab[(fsy & 31) * 32 + (fsx & 31)];
+      auto px = [&](int xx, int yy) -> int {
+        return (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[yy * src_stride + xx] : 0;
+      };
+      const int v = px(sx, sy) * w[0] + px(sx + 1, sy) * w[1] + px(sx, sy + 1) * w[2] + px(sx + 1, sy + 1) * w[3];
+      const int r = (v + (1 << 14)) >> 15;
+      D[x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+  }
+}
+
+// cv::createCLAHE(clipLimit, Size(tilesX, tilesY))->apply(src, dst) on 8UC1 (Examples/Stereo-Inertial/
+// stereo_inertial_tum_vi.cc:151,190-191; Examples/Stereo/stereo_tum_vi.cc:100,142-143: clip 3.0, 8x8 tiles).  OpenCV
+// clahe.cpp (>= 4.0), restated from memory:
+//  * an image that does not divide into the tiles is extended at the right / bottom with BORDER_REFLECT_101 by
+//    tiles - (size % tiles) pixels for the histograms only;
+//  * per tile: 256-bin histogram, bins clipped at max(int(clipLimit * tileArea / 256), 1), the clipped mass handed
+//    back as clipped / 256 to every bin plus one count to every (256 / residual)-th bin from bin 0;
+//    lut[i] = saturate_cast<uchar>(cumsum * (255.f / tileArea)) (float product, round half even);
+//  * per pixel: bilinear blend of the four neighbouring tiles' lut values in float, tile coordinate x / tileW - 0.5,
+//    indices clamped AFTER the weights are taken; saturate_cast<uchar> of the float result.
+void clahe_u8(const uint8_t* src, int w, int h, ptrdiff_t src_stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t* dst, ptrdiff_t dst_stride) {
+  int ew = w, eh = h;
+  if (w % tiles_x != 0 || h % tiles_y != 0) {
+    ew = w + (tiles_x - w % tiles_x);
+    eh = h + (tiles_y - h % tiles_y);
+  }
+  auto r101 = [](int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * n - 2 - p;
+    return p;
+  };
+  const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+  const float lut_scale = (float)255 / area;
+  int clip = 0;
+  if (clip_limit > 0.0) {
+    clip = (int)(clip_limit * area / 256);
+    if (clip < 1) clip = 1;
+  }
+  std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+  for (int ty = 0; ty < tiles_y; ty++)
+    for (int tx = 0; tx < tiles_x; tx++) {
+      int hist[256] = {0};
+      for (int y = ty * th; y < (ty + 1) * th; y++)
+        for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[src[r101(y, h) * src_stride + r101(x, w)]]++;
+      if (clip > 0) {
+        int clipped = 0;
+        for (int i = 0; i < 256; i++)
+          if (hist[i] > clip) {
+            clipped += hist[i] - clip;
+            hist[i] = clip;
+          }
+        const int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        for (int i = 0; i < 256; i++) hist[i] += batch;
+        if (residual != 0) {
+          const int step = std::max(256 / residual, 1);
+          for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+        }
+      }
+      uint8_t* L = &lut[(size_t)(ty * tiles_x + tx) * 256];
+      int sum = 0;
+      for (int i = 0; i < 256; i++) {
+        sum += hist[i];
+        const int v = cv_round((float)sum * lut_scale);
+        L[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    }
+  const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+  for (int y = 0; y < h; y++) {
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = cv_floor(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = std::max(ty1, 0);
+    ty2 = std::min(ty2, tiles_y - 1);
+    for (int x = 0; x < w; x++) {
+      const float txf = x * inv_tw - 0.5f;
+      int tx1 = cv_floor(txf), tx2 = tx1 + 1;
+      const float xa = txf - tx1, xa1 = 1.0f - xa;
+      tx1 = std::max(tx1, 0);
+      tx2 = std::min(tx2, tiles_x - 1);
+      const int v = src[y * src_stride + x];
+      const float l11 = lut[(size_t)(ty1 * tiles_x + tx1) * 256 + v], l12 = lut[(size_t)(ty1 * tiles_x + tx2) * 256 + v];
+      const float l21 = lut[(size_t)(ty2 * tiles_x + tx1) * 256 + v], l22 = lut[(size_t)(ty2 * tiles_x + tx2) * 256 + v];
+      const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;  // built with -ffp-contract=off
+      const int r = cv_round(res);
+      dst[y * dst_stride + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+  }
+}
+
 // ======================================================================================= B3 FAST
 static void make_ring16(int stride, int pixel[25]) {
   static const int off[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},

@@ -137,6 +137,14 @@ void cvt_gray_u8(const uint8_t* src, int w, int h, ptrdiff_t src_stride, int cn,
 void resize_linear_u8c(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride, int cn, uint8_t* dst, int dw, int dh,
                        ptrdiff_t dst_stride);
 
+// cv::remap(src, dst, mapx, mapy, INTER_LINEAR) with CV_32FC1 maps, BORDER_CONSTANT 0, 8UC1 (src/System.cc:294-295): the
+// stereo rectification of every raw frame.  map_stride in floats.
+void remap_linear_u8(const uint8_t* src, int sw, int sh, ptrdiff_t src_stride, const float* mapx, const float* mapy,
+                     ptrdiff_t map_stride, uint8_t* dst, int dw, int dh, ptrdiff_t dst_stride);
+// cv::createCLAHE(clip_limit, Size(tiles_x, tiles_y))->apply(src, dst), 8UC1 (Examples/Stereo/stereo_tum_vi.cc:100,142-143).
+void clahe_u8(const uint8_t* src, int w, int h, ptrdiff_t src_stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t* dst, ptrdiff_t dst_stride);
+
 // ---- Frame::UndistortKeyPoints / ComputeImageBounds (src/Frame.cc:853-919) --------------------------------------------
 // cv::undistortPoints(src, dst, K, distCoeffs, noArray(), P = K) with its default TermCriteria(MAX_ITER, 5, 0.01): five
 // fixed-point iterations of the inverse distortion in double, then x' = fx x + cx (OpenCV calib3d undistort.dispatch.cpp,

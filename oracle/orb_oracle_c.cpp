@@ -266,6 +266,14 @@ void oro_resize_c(const uint8_t* src, int sw, int sh, long src_stride, int cn, u
   resize_linear_u8c(src, sw, sh, src_stride, cn, dst, dw, dh, dst_stride);
 }
 
+void oro_remap(const uint8_t* src, int sw, int sh, long src_stride, const float* mapx, const float* mapy, long map_stride,
+               uint8_t* dst, int dw, int dh, long dst_stride) {
+  remap_linear_u8(src, sw, sh, src_stride, mapx, mapy, map_stride, dst, dw, dh, dst_stride);
+}
+void oro_clahe(const uint8_t* src, int w, int h, long src_stride, double clip, int tx, int ty, uint8_t* dst, long dst_stride) {
+  clahe_u8(src, w, h, src_stride, clip, tx, ty, dst, dst_stride);
+}
+
 void oro_undistort_keypoints(const KeyPoint* k, int n, const float* K, const float* dist, int n_dist, KeyPoint* out) {
   std::vector<KeyPoint> a(k, k + n), o;
   undistort_keypoints(a, K, dist, n_dist, o);

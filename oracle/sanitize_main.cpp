@@ -2,6 +2,7 @@
 // per-cell FAST, quadtree, orientation, blur, descriptors, stereo association, brute-force kNN, the guided matchers,
 // KB8 triangulation, undistortion and the pre-processing helpers on a deterministic synthetic pair.
 // TEST INFRASTRUCTURE ONLY.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -128,7 +129,19 @@ int main() {
   for (size_t i = 0; i < rgb.size(); i++) rgb[i] = L[i / 3];
   cvt_gray_u8(rgb.data(), w, h, (ptrdiff_t)w * 3, 3, true, gray.data(), w);
   resize_linear_u8c(rgb.data(), w, h, (ptrdiff_t)w * 3, 3, small.data(), 300, 225, 300 * 3);
+  // rectification maps that also point outside the source / hold NaN, and CLAHE on a size that does not divide into 8 x 8 tiles
+  const int rw = w - 13, rh = h - 7;
+  std::vector<float> mapx((size_t)rw * rh), mapy((size_t)rw * rh);
+  for (int y = 0; y < rh; y++)
+    for (int x = 0; x < rw; x++) {
+      mapx[(size_t)y * rw + x] = 1.04f * x - 9.3f + 0.01f * y;
+      mapy[(size_t)y * rw + x] = 1.03f * y - 6.7f - 0.02f * x;
+    }
+  mapx[0] = std::nanf(""); mapx[1] = 3e9f; mapy[2] = -3e9f; mapx[3] = -1.f; mapy[3] = (float)h;
+  std::vector<uint8_t> rect((size_t)rw * rh), eq((size_t)rw * rh);
+  remap_linear_u8(L.data(), w, h, w, mapx.data(), mapy.data(), rw, rect.data(), rw, rh, rw);
+  clahe_u8(rect.data(), rw, rh, rw, 3.0, 8, 8, eq.data(), rw);
   std::printf("ok %d %d %zu %zu stereo %d knn %d init %d proj %d %d fe %d %d fisheye %d/%d un %.2f b %.1f g %d\n", mL, mR, kL.size(),
-              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5]);
+              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7]);
   return 0;
 }

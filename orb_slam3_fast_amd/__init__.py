@@ -46,6 +46,13 @@ class _Params(C.Structure):
                 ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32)]
 
 
+class _PreprocParams(C.Structure):
+    _fields_ = [("src_w", C.c_int32), ("src_h", C.c_int32), ("channels", C.c_int32), ("rgb_order", C.c_int32),
+                ("out_w", C.c_int32), ("out_h", C.c_int32), ("map_x", C.c_void_p), ("map_y", C.c_void_p),
+                ("map_stride", C.c_ssize_t), ("n_maps", C.c_int32), ("clahe_clip_limit", C.c_double),
+                ("clahe_tiles_x", C.c_int32), ("clahe_tiles_y", C.c_int32)]
+
+
 _lib = None
 
 
@@ -80,6 +87,16 @@ def lib():
         L.orbx_undistort_keypoints.argtypes = [i, vp, i, vp, vp, i, vp]
         L.orbx_cvt_gray.argtypes = [i, vp, i, i, C.c_ssize_t, i, i, vp, C.c_ssize_t]
         L.orbx_resize_linear.argtypes = [i, vp, i, i, C.c_ssize_t, i, vp, i, i, C.c_ssize_t]
+        L.orbx_remap_linear.argtypes = [i, vp, i, i, C.c_ssize_t, i, vp, vp, C.c_ssize_t, vp, i, i, C.c_ssize_t]
+        L.orbx_clahe.argtypes = [i, vp, i, i, C.c_ssize_t, C.c_double, i, i, vp, C.c_ssize_t]
+        L.orbx_preproc_create.argtypes = [C.POINTER(_PreprocParams), i, i, C.POINTER(vp)]
+        L.orbx_preproc_destroy.argtypes = [vp]
+        L.orbx_preproc_destroy.restype = None
+        L.orbx_preproc_output_size.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+        L.orbx_preproc_run.argtypes = [vp, vp, C.c_ssize_t, i, vp, C.c_ssize_t]
+        L.orbx_preproc_run_device.argtypes = [vp, vp, i, C.c_ssize_t, C.c_ssize_t, C.POINTER(vp), C.POINTER(i), C.POINTER(i),
+                                              C.POINTER(C.c_ssize_t), C.POINTER(C.c_ssize_t)]
+        L.orbx_extract_batch_raw_device.argtypes = [vp, vp, vp, i, C.c_ssize_t, C.c_ssize_t, vp]
         L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
         L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
         L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
@@ -222,6 +239,12 @@ class ORBextractor:
         lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(n_images, 2)
         _check(lib().orbx_extract_batch_device(self._h, C.c_void_p(d_images_ptr), n_images, w, h, row_pitch,
                                                image_pitch, None if lap_arr is None else _p(lap_arr)))
+
+    def extract_batch_raw_device(self, preproc, d_frames_ptr, n_frames, row_pitch, image_pitch, lap=None):
+        """Pre-processing chain + extraction of device-resident RAW frames on this handle's stream.  Asynchronous."""
+        lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(n_frames, 2)
+        _check(lib().orbx_extract_batch_raw_device(self._h, preproc._h, C.c_void_p(d_frames_ptr), n_frames, row_pitch,
+                                                   image_pitch, None if lap_arr is None else _p(lap_arr)))
 
     def sync(self):
         _check(lib().orbx_sync(self._h))
@@ -376,6 +399,86 @@ def resize(img, dst_w, dst_h, device=0):
     dst = np.zeros((dst_h, dst_w) if img.ndim == 2 else (dst_h, dst_w, cn), np.uint8)
     _check(lib().orbx_resize_linear(device, _p(img), w, h, img.strides[0], cn, _p(dst), dst_w, dst_h, dst.strides[0]))
     return dst
+
+
+def remap(img, map_x, map_y, device=0):
+    """cv::remap(img, out, map_x, map_y, cv::INTER_LINEAR) with CV_32FC1 maps (src/System.cc:294-295) for H x W [x 3|4] uint8."""
+    img = np.ascontiguousarray(img, np.uint8)
+    mx = np.ascontiguousarray(map_x, np.float32)
+    my = np.ascontiguousarray(map_y, np.float32)
+    if mx.shape != my.shape or mx.ndim != 2:
+        raise ValueError("map_x and map_y must be two float images of the same size")
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    dh, dw = mx.shape
+    dst = np.zeros((dh, dw) if img.ndim == 2 else (dh, dw, cn), np.uint8)
+    _check(lib().orbx_remap_linear(device, _p(img), w, h, img.strides[0], cn, _p(mx), _p(my), dw, _p(dst), dw, dh, dst.strides[0]))
+    return dst
+
+
+class CLAHE:
+    """cv::createCLAHE(clipLimit, tileGridSize) as the TUM-VI examples use it (Examples/Stereo/stereo_tum_vi.cc:100,142-143)."""
+
+    def __init__(self, clipLimit=3.0, tileGridSize=(8, 8), device=0):
+        self.clip, self.tiles, self.device = float(clipLimit), (int(tileGridSize[0]), int(tileGridSize[1])), device
+
+    def apply(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        if img.ndim != 2:
+            raise ValueError("CLAHE needs a single-channel image")
+        h, w = img.shape
+        dst = np.zeros((h, w), np.uint8)
+        _check(lib().orbx_clahe(self.device, _p(img), w, h, img.strides[0], self.clip, self.tiles[0], self.tiles[1], _p(dst),
+                                dst.strides[0]))
+        return dst
+
+
+class Preproc:
+    """Device-resident pre-processing chain [CLAHE] -> [remap | resize] -> [gray] in front of the extractor
+    (include/orbx.h orbx_preproc_*).  maps = (map_x, map_y) float arrays of shape (n_maps, out_h, out_w) or (out_h, out_w)."""
+
+    def __init__(self, src_w, src_h, channels=1, rgb=True, maps=None, out_size=None, clahe=None, max_batch=2, device=0):
+        prm = _PreprocParams()
+        prm.src_w, prm.src_h, prm.channels, prm.rgb_order = src_w, src_h, channels, int(bool(rgb))
+        keep = []
+        if maps is not None:
+            mx = np.ascontiguousarray(maps[0], np.float32)
+            my = np.ascontiguousarray(maps[1], np.float32)
+            if mx.ndim == 2:
+                mx, my = mx[None], my[None]
+            prm.n_maps, prm.out_h, prm.out_w = mx.shape
+            prm.map_x, prm.map_y, prm.map_stride = mx.ctypes.data, my.ctypes.data, mx.shape[2]
+            keep = [mx, my]
+        elif out_size is not None:
+            prm.out_w, prm.out_h = out_size
+        if clahe is not None:
+            prm.clahe_clip_limit, (prm.clahe_tiles_x, prm.clahe_tiles_y) = float(clahe[0]), clahe[1]
+        h = C.c_void_p()
+        _check(lib().orbx_preproc_create(C.byref(prm), max_batch, device, C.byref(h)))
+        del keep
+        self._h = h
+        ow, oh = C.c_int(), C.c_int()
+        _check(lib().orbx_preproc_output_size(self._h, C.byref(ow), C.byref(oh)))
+        self.out_w, self.out_h, self.channels, self.src_w, self.src_h = ow.value, oh.value, channels, src_w, src_h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbx_preproc_destroy(self._h)
+            self._h = None
+
+    def run(self, frame, map_index=0):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        dst = np.zeros((self.out_h, self.out_w), np.uint8)
+        _check(lib().orbx_preproc_run(self._h, _p(frame), frame.strides[0], map_index, _p(dst), dst.strides[0]))
+        return dst
+
+    def run_device(self, d_frames_ptr, n_frames, row_pitch, image_pitch):
+        """-> (device pointer, w, h, row_pitch, image_pitch) of the pre-processed gray frames (owned by the handle)."""
+        out, w, h = C.c_void_p(), C.c_int(), C.c_int()
+        rp, ip = C.c_ssize_t(), C.c_ssize_t()
+        _check(lib().orbx_preproc_run_device(self._h, C.c_void_p(d_frames_ptr), n_frames, row_pitch, image_pitch, C.byref(out),
+                                             C.byref(w), C.byref(h), C.byref(rp), C.byref(ip)))
+        return out.value, w.value, h.value, rp.value, ip.value
 
 
 def UndistortKeyPoints(kps, K, dist, device=0):

@@ -159,9 +159,28 @@ struct UndistortArgs {
 hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s);
 
 // Pre-processing: gray conversion and a generic (any size, 1/3/4 channels) bilinear resize; pitches in bytes.
-hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, int cn, int rgb, uint8_t* dst, long long dp, hipStream_t s);
-hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, int cn, uint8_t* dst, int dw, int dh,
-                                 long long dp, const int* xofs, const short* xab, const int* yofs, const short* yab, hipStream_t s);
+// cv::remap INTER_LINEAR with float maps (k_remap): batch of nimg images, image i uses map i % nMaps.
+struct RemapArgs {
+  const uint8_t* src; int sw, sh, cn; long long srcPitch, srcImgPitch;
+  const float* mapx; const float* mapy; long long mapPitch, mapImgPitch; int nMaps;  // pitches in floats
+  uint8_t* dst; int dw, dh; long long dstPitch, dstImgPitch;
+  int mapVec4, dstVec4;  // 16-byte aligned map rows / 4-byte aligned destination rows
+};
+hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s);
+// cv::CLAHE::apply (k_clahe_lut + k_clahe_apply)
+struct ClaheArgs {
+  const uint8_t* src; int w, h; long long srcPitch, srcImgPitch;
+  uint8_t* dst; long long dstPitch, dstImgPitch;
+  uint8_t* lut;  // [nimg][tilesY * tilesX][256]
+  int tilesX, tilesY, tw, th, clip; float lutScale, invTw, invTh;
+  int srcVec4, dstVec4;
+};
+hipError_t launch_clahe(const ClaheArgs& a, int nimg, hipStream_t s);
+hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, long long sip, int cn, int rgb, uint8_t* dst,
+                           long long dp, long long dip, int nimg, hipStream_t s);
+hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, long long sip, int cn, uint8_t* dst, int dw,
+                                 int dh, long long dp, long long dip, const int* xofs, const short* xab, const int* yofs,
+                                 const short* yab, int nimg, hipStream_t s);
 constexpr int kFeWriters = 4;  // writers / claimers remembered per slot and round by the fixed-point resolves
 struct InitArgs {
   const orbx_keypoint *k1, *k2;

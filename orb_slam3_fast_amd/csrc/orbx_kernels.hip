@@ -2407,24 +2407,27 @@ hipError_t launch_fisheye_triangulate(const FisheyeArgs& a, hipStream_t s) {
 
 // ================================================================================================ pre-processing
 // cvtColor(..., COLOR_*2GRAY) for 8U (OpenCV >= 3.4.2 / 4.x: 15-bit coefficients, one rounding).  Thread per pixel.
-__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, int w, int h, long long sp, int cn, int rgb,
-                                                  uint8_t* __restrict__ dst, long long dp) {
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, int w, int h, long long sp, long long sip,
+                                                  int cn, int rgb, uint8_t* __restrict__ dst, long long dp, long long dip) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= w || y >= h) return;
-  const uint8_t* S = src + y * sp + (long long)x * cn;
+  const uint8_t* S = src + blockIdx.z * sip + y * sp + (long long)x * cn;
   const int c0 = S[0], g = S[1], c2 = S[2];
   const int r = rgb ? c0 : c2, b = rgb ? c2 : c0;
-  dst[y * dp + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
+  dst[blockIdx.z * dip + y * dp + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
 }
 
 // cv::resize INTER_LINEAR 8U on interleaved channels with host-built coefficient tables (the B2 arithmetic of k_resize):
 // thread per destination pixel, all channels.  A once-per-frame convenience kernel, not tiled.
-__global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restrict__ src, int sw, int sh, long long sp, int cn,
-                                                        uint8_t* __restrict__ dst, int dw, int dh, long long dp,
-                                                        const int* __restrict__ xofs, const short* __restrict__ xab,
-                                                        const int* __restrict__ yofs, const short* __restrict__ yab) {
+__global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restrict__ src, int sw, int sh, long long sp,
+                                                        long long sip, int cn, uint8_t* __restrict__ dst, int dw, int dh,
+                                                        long long dp, long long dip, const int* __restrict__ xofs,
+                                                        const short* __restrict__ xab, const int* __restrict__ yofs,
+                                                        const short* __restrict__ yab) {
   const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
   if (dx >= dw || dy >= dh) return;
+  src += blockIdx.z * sip;
+  dst += blockIdx.z * dip;
   const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1), a0 = xab[2 * dx], a1 = xab[2 * dx + 1];
   const int sy = yofs[dy], b0 = yab[2 * dy], b1 = yab[2 * dy + 1];
   const uint8_t* R0 = src + (long long)min(max(sy, 0), sh - 1) * sp;
@@ -2436,14 +2439,188 @@ __global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restric
   }
 }
 
-hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, int cn, int rgb, uint8_t* dst, long long dp, hipStream_t s) {
-  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 255) / 256, h), dim3(256), 0, s, src, w, h, sp, cn, rgb, dst, dp);
+hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, long long sip, int cn, int rgb, uint8_t* dst,
+                           long long dp, long long dip, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 255) / 256, h, nimg), dim3(256), 0, s, src, w, h, sp, sip, cn, rgb, dst, dp, dip);
   return hipGetLastError();
 }
-hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, int cn, uint8_t* dst, int dw, int dh,
-                                 long long dp, const int* xofs, const short* xab, const int* yofs, const short* yab, hipStream_t s) {
-  hipLaunchKernelGGL(k_resize_generic, dim3((dw + 255) / 256, dh), dim3(256), 0, s, src, sw, sh, sp, cn, dst, dw, dh, dp, xofs, xab,
-                     yofs, yab);
+hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, long long sip, int cn, uint8_t* dst, int dw,
+                                 int dh, long long dp, long long dip, const int* xofs, const short* xab, const int* yofs,
+                                 const short* yab, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_generic, dim3((dw + 255) / 256, dh, nimg), dim3(256), 0, s, src, sw, sh, sp, sip, cn, dst, dw, dh,
+                     dp, dip, xofs, xab, yofs, yab);
+  return hipGetLastError();
+}
+
+// cv::remap(src, dst, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT 0) with CV_32FC1 maps on 8UC1/3/4 (src/System.cc:294-295).
+// Fixed point exactly as OpenCV's RemapInvoker / remapBilinear: position = cvRound(map * 32), 5 fraction bits per axis,
+// weights (32-fx)(32-fy)*32 ... (= BilinearTab_i, exact products) except fraction (0,0) whose 32768 saturates to 32767
+// and is repaired on the last tap: {32767, 0, 0, 1}; out = (sum + 2^14) >> 15; taps outside the source are 0.
+// A thread produces 4 consecutive destination pixels: two 16-byte map loads, 4 x 4 byte gathers (the maps are smooth, so a
+// wave's gathers fall into a few cache lines), one dword store for single-channel images.  HBM-bound: 8 B of map per
+// pixel against 1 B read + 1 B written.  Image i of a batch uses map i % nMaps (left / right eye).
+__device__ __forceinline__ int cv_round_sse(float t) {  // cvtss2si: out-of-range and NaN give INT_MIN
+  return fabsf(t) < 2147483648.f ? __float2int_rn(t) : (int)0x80000000;
+}
+__global__ __launch_bounds__(256) void k_remap(RemapArgs a) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
+  if (x0 >= a.dw || y >= a.dh) return;
+  const int m = img % a.nMaps;
+  const float* MX = a.mapx + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  const float* MY = a.mapy + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
+  uint8_t* D = a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + (long long)x0 * a.cn;
+  float mx[4], my[4];
+  const bool full = x0 + 3 < a.dw;
+  if (full && a.mapVec4) {
+    const float4 vx = *reinterpret_cast<const float4*>(MX), vy = *reinterpret_cast<const float4*>(MY);
+    mx[0] = vx.x; mx[1] = vx.y; mx[2] = vx.z; mx[3] = vx.w;
+    my[0] = vy.x; my[1] = vy.y; my[2] = vy.z; my[3] = vy.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = x0 + k < a.dw;
+      mx[k] = in ? MX[k] : 0.f;
+      my[k] = in ? MY[k] : 0.f;
+    }
+  }
+  const int cn = a.cn;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int fsx = cv_round_sse(mx[k] * 32.f), fsy = cv_round_sse(my[k] * 32.f);
+    const int sx = min(max(fsx >> 5, -32768), 32767), sy = min(max(fsy >> 5, -32768), 32767);
+    const int fx = fsx & 31, fy = fsy & 31;
+    int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+    if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+    const bool x0in = (unsigned)sx < (unsigned)a.sw, x1in = (unsigned)(sx + 1) < (unsigned)a.sw;
+    const bool y0in = (unsigned)sy < (unsigned)a.sh, y1in = (unsigned)(sy + 1) < (unsigned)a.sh;
+    const uint8_t* R0 = S + (long long)sy * a.srcPitch + (long long)sx * cn;
+    const uint8_t* R1 = R0 + a.srcPitch;
+    if (cn == 1) {
+      const int p00 = (x0in && y0in) ? R0[0] : 0, p01 = (x1in && y0in) ? R0[1] : 0;
+      const int p10 = (x0in && y1in) ? R1[0] : 0, p11 = (x1in && y1in) ? R1[1] : 0;
+      const uint32_t r = (uint32_t)(p00 * w0 + p01 * w1 + p10 * w2 + p11 * w3 + 16384) >> 15;
+      packed |= r << (8 * k);
+    } else if (x0 + k < a.dw) {
+      for (int c = 0; c < cn; c++) {
+        const int p00 = (x0in && y0in) ? R0[c] : 0, p01 = (x1in && y0in) ? R0[cn + c] : 0;
+        const int p10 = (x0in && y1in) ? R1[c] : 0, p11 = (x1in && y1in) ? R1[cn + c] : 0;
+        D[k * cn + c] = (uint8_t)((uint32_t)(p00 * w0 + p01 * w1 + p10 * w2 + p11 * w3 + 16384) >> 15);
+      }
+    }
+  }
+  if (cn == 1) {
+    if (full && a.dstVec4) {
+      *reinterpret_cast<uint32_t*>(D) = packed;
+    } else {
+      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+  }
+}
+hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_remap, dim3((a.dw + 255) / 256, (a.dh + 3) / 4, nimg), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// cv::CLAHE::apply on 8UC1 (Examples/Stereo/stereo_tum_vi.cc:100,142-143; OpenCV clahe.cpp).  Two kernels:
+//  k_clahe_lut   block per (tile, image): per-wave LDS histograms of the tile (BORDER_REFLECT_101 extension at the right /
+//                bottom when the image does not divide into tiles), clip + redistribution (clipped / 256 to every bin,
+//                one extra count to every (256 / residual)-th bin), block prefix sum, lut = rne(cumsum * 255.f / area);
+//  k_clahe_apply thread per 4 pixels: the float bilinear blend of the four neighbouring tiles' lut entries in
+//                OpenCV's expression order (the TU is built with -ffp-contract=off), rne + saturate.
+// The lut of an image (tilesX * tilesY * 256 B = 16 KB for 8x8) stays in L1 / L2 for the apply pass.
+__global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
+  __shared__ int hist[4][256];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x, img = blockIdx.y;
+  const int ty = tile / a.tilesX, tx = tile - ty * a.tilesX;
+  for (int k = 0; k < 4; k++) hist[k][tid] = 0;
+  __syncthreads();
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
+  const int area = a.tw * a.th;
+  for (int i = tid; i < area; i += 256) {
+    const int yy = i / a.tw, xx = i - yy * a.tw;
+    int y = ty * a.th + yy, x = tx * a.tw + xx;
+    while (y >= a.h || y < 0) y = y < 0 ? -y : 2 * a.h - 2 - y;  // reflect 101 (the extension is shorter than the image)
+    while (x >= a.w || x < 0) x = x < 0 ? -x : 2 * a.w - 2 - x;
+    atomicAdd(&hist[wave][S[(long long)y * a.srcPitch + x]], 1);
+  }
+  __syncthreads();
+  int v = hist[0][tid] + hist[1][tid] + hist[2][tid] + hist[3][tid];
+  if (a.clip > 0) {
+    int ex = max(v - a.clip, 0);
+    v -= ex;
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
+    if (lane == 0) wsum[wave] = ex;
+    __syncthreads();
+    const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int batch = clipped >> 8, residual = clipped & 255;
+    v += batch;
+    if (residual) {
+      const int step = max(256 / residual, 1);
+      if (tid % step == 0 && tid / step < residual) v++;
+    }
+  }
+  int sum = v;  // inclusive prefix sum over the 256 bins
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(sum, o);
+    if (lane >= o) sum += t;
+  }
+  if (lane == 63) wsum[wave] = sum;
+  __syncthreads();
+  for (int k = 0; k < wave; k++) sum += wsum[k];
+  const int r = __float2int_rn((float)sum * a.lutScale);
+  a.lut[((long long)img * a.tilesX * a.tilesY + tile) * 256 + tid] = (uint8_t)min(max(r, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(ClaheArgs a) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
+  if (x0 >= a.w || y >= a.h) return;
+  const float tyf = (float)y * a.invTh - 0.5f;
+  int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+  const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+  ty1 = max(ty1, 0);
+  ty2 = min(ty2, a.tilesY - 1);
+  const uint8_t* L = a.lut + (long long)img * a.tilesX * a.tilesY * 256;
+  const uint8_t* L1 = L + (long long)ty1 * a.tilesX * 256;
+  const uint8_t* L2 = L + (long long)ty2 * a.tilesX * 256;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch + (long long)y * a.srcPitch + x0;
+  uint8_t* D = a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+  const bool full = x0 + 3 < a.w;
+  uint32_t in4;
+  if (full && a.srcVec4) {
+    in4 = *reinterpret_cast<const uint32_t*>(S);
+  } else {
+    in4 = 0;
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) in4 |= (uint32_t)S[k] << (8 * k);
+  }
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, a.tilesX - 1);
+    const int v = (in4 >> (8 * k)) & 255;
+    const float l11 = (float)L1[tx1 * 256 + v], l12 = (float)L1[tx2 * 256 + v];
+    const float l21 = (float)L2[tx1 * 256 + v], l22 = (float)L2[tx2 * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    const int r = __float2int_rn(res);
+    packed |= (uint32_t)min(max(r, 0), 255) << (8 * k);
+  }
+  if (full && a.dstVec4) {
+    *reinterpret_cast<uint32_t*>(D) = packed;
+  } else {
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) D[k] = (uint8_t)(packed >> (8 * k));
+  }
+}
+hipError_t launch_clahe(const ClaheArgs& a, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_clahe_lut, dim3(a.tilesX * a.tilesY, nimg), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_clahe_apply, dim3((a.w + 255) / 256, (a.h + 3) / 4, nimg), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -223,3 +223,34 @@ def fisheye_stereo_scene(seed=0, n_left=900, n_right=850, mono_left=300, mono_ri
     return dict(kL=kL, dL=dL, kR=kR, dR=dR, mono_left=mono_left, mono_right=mono_right, cam1=np.array(TUMVI_CAM1, np.float32),
                 cam2=np.array(TUMVI_CAM2, np.float32), R12=R12.astype(np.float32), t12=t12.astype(np.float32),
                 level_sigma2=sigma2.astype(np.float32), true_left=ql, true_right=qr, true_depth=depth.astype(np.float32))
+
+
+def rectify_maps(w, h, src_w=None, src_h=None, k1=-0.28, k2=0.07, p1=3e-4, p2=-2e-4, rot_deg=(0.4, -0.6, 0.25), seed=0):
+    """Float rectification maps (map_x, map_y) of the kind cv::initUndistortRectifyMap(K, D, R, P, size, CV_32F) hands
+    to System::TrackStereo (src/Settings.cc:557-572, src/System.cc:294-295): for every rectified pixel the raw-image
+    position, radial-tangential distortion + a small rectifying rotation.  Test / bench input only; the product takes
+    the maps as given."""
+    src_w = src_w or w
+    src_h = src_h or h
+    rng = np.random.RandomState(seed)
+    fx = 0.61 * src_w * (1 + 0.01 * rng.randn())
+    fy = fx * (1 + 0.002 * rng.randn())
+    cx, cy = 0.5 * src_w + 3.1 * rng.randn(), 0.5 * src_h + 2.3 * rng.randn()
+    nfx, nfy, ncx, ncy = 0.56 * src_w * w / src_w, 0.56 * src_w * w / src_w, 0.5 * w + 1.7, 0.5 * h - 0.9
+    ax, ay, az = np.deg2rad(rot_deg)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    P = np.array([[nfx, 0, ncx], [0, nfy, ncy], [0, 0, 1.0]])
+    iR = np.linalg.inv(P @ R)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    X = iR[0, 0] * u + iR[0, 1] * v + iR[0, 2]
+    Y = iR[1, 0] * u + iR[1, 1] * v + iR[1, 2]
+    W = iR[2, 0] * u + iR[2, 1] * v + iR[2, 2]
+    x, y = X / W, Y / W
+    r2 = x * x + y * y
+    kr = 1 + k1 * r2 + k2 * r2 * r2
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return (fx * xd + cx).astype(np.float32), (fy * yd + cy).astype(np.float32)

@@ -12,6 +12,7 @@
 
 #include "../../orb_slam3_fast_amd/csrc/ORBextractor.h"
 #include "../../orb_slam3_fast_amd/csrc/ORBmatcher.h"
+#include "../../orb_slam3_fast_amd/csrc/Preprocess.h"
 
 using namespace ORB_SLAM3;
 
@@ -36,6 +37,28 @@ int main(int argc, char** argv) {
       std::printf("no-device error: %s\n", e.what());
       return 3;
     }
+  }
+  if (std::string(argv[1]) == "rectify") {
+    // frame_like rectify <sw> <sh> <dw> <dh> <L.raw> <R.raw> <maps.raw (M1l M2l M1r M2r, dw*dh floats each)> <outprefix>
+    const int sw = std::atoi(argv[2]), sh = std::atoi(argv[3]), dw = std::atoi(argv[4]), dh = std::atoi(argv[5]);
+    std::vector<uint8_t> Lb = slurp(argv[6]), Rb = slurp(argv[7]), mb = slurp(argv[8]);
+    const std::string out = argv[9];
+    const float* m = reinterpret_cast<const float*>(mb.data());
+    const size_t per = (size_t)dw * dh;
+    ocv::Mat L(sh, sw, Lb.data(), (size_t)sw), R(sh, sw, Rb.data(), (size_t)sw), eqL, eqR, a, b, c, d;
+    auto clahe = createCLAHE(3.0, 8, 8);  // Examples/Stereo/stereo_tum_vi.cc:100,142-143
+    clahe->apply(L, eqL);
+    clahe->apply(R, eqR);
+    remap(eqL, a, m, m + per, dw, dh);  // src/System.cc:294
+    remap(eqR, b, m + 2 * per, m + 3 * per, dw, dh);
+    StereoRectifier rect(sw, sh, dw, dh, m, m + per, m + 2 * per, m + 3 * per, 3.0, 8);
+    rect(L, R, c, d);
+    dump(out + ".eqL", eqL.data, (size_t)sw * sh);
+    dump(out + ".a", a.data, per);
+    dump(out + ".b", b.data, per);
+    dump(out + ".c", c.data, per);
+    dump(out + ".d", d.data, per);
+    return 0;
   }
   if (std::string(argv[1]) == "fisheye") {
     // frame_like fisheye <kL.raw> <dL.raw> <monoL> <kR.raw> <dR.raw> <monoR> <rig.raw (29 floats)> <sigma2.raw> <outprefix>

@@ -13,7 +13,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "frame_like")
 def build_exe():
     src = os.path.join(ROOT, "tests", "cpp", "frame_like.cpp")
     libdir = os.path.join(ROOT, "orb_slam3_fast_amd")
-    hdrs = [os.path.join(libdir, "csrc", h) for h in ("ORBextractor.h", "ORBmatcher.h")]
+    hdrs = [os.path.join(libdir, "csrc", h) for h in ("ORBextractor.h", "ORBmatcher.h", "Preprocess.h")]
     if (not os.path.exists(EXE)) or any(os.path.getmtime(p) > os.path.getmtime(EXE) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-DORBX_NO_OPENCV", src, "-o", EXE, "-L" + libdir,
                                "-lorbx", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
@@ -86,3 +86,26 @@ def test_cpp_mirror_fisheye_matches_python_binding(tmp_path):
     assert np.fromfile(out + ".depth", np.float32).tobytes() == dep.tobytes()
     assert np.fromfile(out + ".p3d", np.float32).tobytes() == pts.tobytes()
     assert (np.fromfile(out + ".uR", np.float32) == -1).all()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_rectify_clahe_matches_oracle(oracle, tmp_path):
+    """ORB_SLAM3::remap / CLAHE / StereoRectifier (csrc/Preprocess.h) against the oracle's cv::remap / CLAHE restatement."""
+    from orb_slam3_fast_amd import synth
+    exe = build_exe()
+    sw, sh, dw, dh = 512, 512, 480, 470
+    L, R = synth.stereo_pair(sw, sh, 71)
+    ml = synth.rectify_maps(dw, dh, sw, sh, seed=3)
+    mr = synth.rectify_maps(dw, dh, sw, sh, seed=4, rot_deg=(-0.2, 0.3, 0.1))
+    L.tofile(tmp_path / "L.raw")
+    R.tofile(tmp_path / "R.raw")
+    np.stack([ml[0], ml[1], mr[0], mr[1]]).astype(np.float32).tofile(tmp_path / "maps.raw")
+    out = str(tmp_path / "r")
+    r = subprocess.run([exe, "rectify", str(sw), str(sh), str(dw), str(dh), str(tmp_path / "L.raw"), str(tmp_path / "R.raw"),
+                        str(tmp_path / "maps.raw"), out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    eqL, eqR = oracle.clahe(L, 3.0, (8, 8)), oracle.clahe(R, 3.0, (8, 8))
+    wl, wr = oracle.remap(eqL, *ml), oracle.remap(eqR, *mr)
+    assert np.array_equal(np.fromfile(out + ".eqL", np.uint8).reshape(sh, sw), eqL)
+    for name, want in (("a", wl), ("b", wr), ("c", wl), ("d", wr)):
+        assert np.array_equal(np.fromfile(out + "." + name, np.uint8).reshape(dh, dw), want), name

@@ -139,6 +139,20 @@ def undistort_case(name):
     print(name, out["euroc_bounds"], out["tum1_bounds"])
 
 
+def rectify_clahe_case(name):
+    """cv::remap rectification (float maps, INTER_LINEAR) and CLAHE(3.0, 8x8) on a small frame, incl. a size that does not
+    divide into the tiles and map entries outside the source."""
+    from orb_slam3_fast_amd import synth
+    img = synth.mono_frame(136, 100, 107)
+    mx, my = synth.rectify_maps(120, 90, 136, 100, seed=5, k1=-0.35, rot_deg=(0.8, -1.1, 0.6))
+    mx[0, :3], my[0, :3] = (np.nan, -40.0, 1e9), (5.0, 5.0, 5.0)
+    eq = O.clahe(img, 3.0, (8, 8))
+    out = {"img": img, "map_x": mx, "map_y": my, "clahe": eq, "remap": O.remap(img, mx, my), "chain": O.remap(eq, mx, my),
+           "clahe_4x3_clip2": O.clahe(img, 2.0, (4, 3))}
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_160x120_L3.npz", 160, 120, 300, 3, 101, (0, 0))
@@ -149,3 +163,4 @@ if __name__ == "__main__":
     fisheye_case("fisheye_stereo.npz", 105)
     undistort_case("undistort.npz")
     projection_fisheye_case("fisheye_projection.npz", 7)
+    rectify_clahe_case("rectify_clahe.npz")
