@@ -1295,18 +1295,20 @@ int orbx_clahe(int device, const uint8_t* src, int w, int h, ptrdiff_t src_strid
   rc = set_device(device);
   if (rc != ORBX_OK) return rc;
   ScratchBuf<uint8_t> ds, dd, lut;
+  ScratchBuf<uint32_t> cells;
   const size_t p = ((size_t)w + 3) & ~(size_t)3;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   chk(ds.alloc(p * h)); chk(dd.alloc(p * h)); chk(lut.alloc((size_t)tiles_x * tiles_y * 256));
+  chk(cells.alloc(clahe_cells_bytes(a, 1) / sizeof(uint32_t)));
   if (e == hipSuccess) chk(hipMemcpy2D(ds.p, p, src, (size_t)src_stride, (size_t)w, h, hipMemcpyHostToDevice));
   a.src = ds.p; a.srcPitch = (long long)p; a.srcImgPitch = 0;
   a.dst = dd.p; a.dstPitch = (long long)p; a.dstImgPitch = 0;
   a.lut = lut.p; a.srcVec4 = 1; a.dstVec4 = 1;
-  if (e == hipSuccess) chk(launch_clahe(a, 1, nullptr));
+  if (e == hipSuccess) chk(launch_clahe(a, 1, cells.p, nullptr));
   if (e == hipSuccess) chk(hipDeviceSynchronize());
   if (e == hipSuccess) chk(hipMemcpy2D(dst, (size_t)dst_stride, dd.p, p, (size_t)w, h, hipMemcpyDeviceToHost));
-  ds.free(); dd.free(); lut.free();
+  ds.free(); dd.free(); lut.free(); cells.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return ORBX_OK;
 }
@@ -1321,13 +1323,14 @@ struct orbx_preproc {
   DevBuf<int> d_xofs, d_yofs;
   DevBuf<short> d_xab, d_yab;
   DevBuf<uint8_t> d_clahe, d_lut, d_geo, d_gray;
+  DevBuf<uint32_t> d_cells;
   long long clahePitch = 0, geoPitch = 0, grayPitch = 0;
   int outW = 0, outH = 0;
   const uint8_t* out = nullptr;  // result of the last run (a stage buffer, or the caller's frames when nothing is enabled)
   long long outPitch = 0, outImgPitch = 0;
   ~orbx_preproc() {
     d_mapx.free(); d_mapy.free(); d_xofs.free(); d_yofs.free(); d_xab.free(); d_yab.free();
-    d_clahe.free(); d_lut.free(); d_geo.free(); d_gray.free();
+    d_clahe.free(); d_lut.free(); d_geo.free(); d_gray.free(); d_cells.free();
   }
 };
 
@@ -1365,6 +1368,7 @@ int orbx_preproc_create(const orbx_preproc_params* p, int max_batch, int device,
     pp->clahePitch = ((long long)p->src_w + 3) & ~3ll;
     chk(pp->d_clahe.alloc((size_t)pp->clahePitch * p->src_h * max_batch));
     chk(pp->d_lut.alloc((size_t)p->clahe_tiles_x * p->clahe_tiles_y * 256 * max_batch));
+    chk(pp->d_cells.alloc(clahe_cells_bytes(pp->clahe, max_batch) / sizeof(uint32_t)));
   }
   if (remap) {
     pp->mapPitch = ((long long)p->out_w + 3) & ~3ll;
@@ -1428,7 +1432,7 @@ static int preproc_enqueue(orbx_preproc* pp, const uint8_t* d_frames, int n, ptr
     a.lut = pp->d_lut.p;
     a.srcVec4 = !(((uintptr_t)cur | (uintptr_t)cp | (uintptr_t)cip) & 3);
     a.dstVec4 = 1;
-    e = launch_clahe(a, n, s);
+    e = launch_clahe(a, n, pp->d_cells.p, s);
     cur = a.dst; cp = a.dstPitch; cip = a.dstImgPitch;
   }
   if (e == hipSuccess && pp->doRemap) {

@@ -175,7 +175,9 @@ struct ClaheArgs {
   int tilesX, tilesY, tw, th, clip; float lutScale, invTw, invTh;
   int srcVec4, dstVec4;
 };
-hipError_t launch_clahe(const ClaheArgs& a, int nimg, hipStream_t s);
+// cells: clahe_cells_bytes() of scratch for the packed cell tables (nullptr: per-pixel lut gathers)
+size_t clahe_cells_bytes(const ClaheArgs& a, int nimg);
+hipError_t launch_clahe(const ClaheArgs& a, int nimg, uint32_t* cells, hipStream_t s);
 hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, long long sip, int cn, int rgb, uint8_t* dst,
                            long long dp, long long dip, int nimg, hipStream_t s);
 hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, long long sip, int cn, uint8_t* dst, int dw,

@@ -1,7 +1,7 @@
 """Image pre-processing in front of the extractor (the part that is pinned by published constants):
 cv::cvtColor(..., *2GRAY) (src/Tracking.cc:1394-1412) and cv::resize(..., INTER_LINEAR) of the input image
-(src/System.cc:297-298).  Integer arithmetic: device == oracle exactly.  (cv::remap rectification and CLAHE are not
-restated: their fixed-point tables are not reproducible from memory.)"""
+(src/System.cc:297-298).  Integer arithmetic: device == oracle exactly.  (cv::remap rectification and CLAHE:
+tests/test_rectify_clahe.py.)"""
 import numpy as np
 import pytest
 

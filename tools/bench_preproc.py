@@ -27,6 +27,7 @@ def timed(fn, iters=20, warm=3):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # 'rectify' | 'clahe': just that stage (for kernel traces)
     out = {}
     B = 64
     w, h = 1280, 720
@@ -34,13 +35,15 @@ def main():
     frames = DeviceBuffer.from_numpy(np.stack([L, R] * (B // 2)))
     ml, mr = synth.rectify_maps(w, h, seed=1), synth.rectify_maps(w, h, seed=2, rot_deg=(-0.3, 0.5, -0.2))
     pp = orbx.Preproc(w, h, maps=(np.stack([ml[0], mr[0]]), np.stack([ml[1], mr[1]])), max_batch=B)
-    t = timed(lambda: pp.run_device(frames.ptr.value, B, w, w * h))
+    t = timed(lambda: pp.run_device(frames.ptr.value, B, w, w * h)) if only in (None, 'rectify') else 1.0
     out["rectify_1280x720"] = {"frames_per_s": B / t, "us_per_batch": t * 1e6, "batch": B,
                                "algorithmic_GBps": B * (2 * w * h) / t / 1e9, "with_maps_GBps": (B * 2 * w * h + 2 * 8 * w * h) / t / 1e9}
     w2 = h2 = 512
     f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
     pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)
-    t = timed(lambda: pc.run_device(f2.ptr.value, B, w2, w2 * h2))
+    t = timed(lambda: pc.run_device(f2.ptr.value, B, w2, w2 * h2)) if only in (None, 'clahe') else 1.0
+    if only:
+        return
     out["clahe_512x512"] = {"frames_per_s": B / t, "us_per_batch": t * 1e6, "batch": B, "algorithmic_GBps": B * (3 * w2 * h2) / t / 1e9}
     w3, h3 = 752, 480
     L3, R3 = synth.stereo_pair(w3, h3, 6)
