@@ -244,6 +244,52 @@ int orbx_preproc_run_device(orbx_preproc* pp, const uint8_t* d_frames, int n_fra
 int orbx_extract_batch_raw_device(orbx_extractor* ex, orbx_preproc* pp, const uint8_t* d_frames, int n_frames,
                                   ptrdiff_t row_pitch, ptrdiff_t image_pitch, const int32_t* lap);
 
+/* ---- bag of words --------------------------------------------------------------------------------- */
+
+/* Replaces ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/ORBVocabulary.h;
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h) as far as Frame::ComputeBoW uses it: the tree on the device.
+ * orbx_vocabulary_load_text replaces loadFromTextFile(strVocFile) of System::System (src/System.cc:131,
+ * TemplatedVocabulary.h:1338-1421; "k L scoring weighting", then one node per line: parent isLeaf 32 bytes weight).
+ * orbx_vocabulary_create takes the same columns: node 0 = root (its columns are ignored), parent[i] < i, the children of a
+ * node in file order, words numbered in the file order of the leaves.  info = k, L, n_nodes, n_words, scoring, weighting. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+int orbx_vocabulary_create(int device, int k, int L, int scoring, int weighting, int n_nodes, const int32_t* parent,
+                           const uint8_t* is_leaf, const uint8_t* descriptors, const double* weights, orbx_vocabulary** out);
+int orbx_vocabulary_load_text(int device, const char* path, orbx_vocabulary** out);
+void orbx_vocabulary_destroy(orbx_vocabulary* voc);
+int orbx_vocabulary_info(const orbx_vocabulary* voc, int32_t info[6]);
+
+/* Replaces Frame::ComputeBoW / KeyFrame::ComputeBoW (src/Frame.cc:846-851, src/KeyFrame.cc:100-107):
+ * mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, 4) (TemplatedVocabulary.h:1125-1250) for n descriptors (n x 32
+ * bytes, n <= 8192).  mBowVec: n_words ascending (word id, value) pairs, values bit-identical to the reference's sequential
+ * double additions and normalisation; mFeatVec as CSR: n_nodes ascending node ids, features of node j =
+ * feature_idx[node_start[j] .. node_start[j + 1]) in ascending order.  Output arrays hold n entries (node_start n + 1).
+ * Returns the number of features in the feature vector (stopped words are left out) or a negative error. */
+int orbx_bow_transform(const orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, uint32_t* word_ids,
+                       double* word_values, int* n_words, uint32_t* node_ids, int32_t* node_start, uint32_t* feature_idx,
+                       int* n_nodes);
+/* The same for every image of the handle's last extraction, enqueued on its stream; results stay on the device: arrays of
+ * [n_images][cap] (node_start [n_images][cap + 1]), counts [n_images][3] = n_words, n_nodes, n_features. */
+int orbx_bow_transform_batch(orbx_extractor* ex, const orbx_vocabulary* voc, int levelsup);
+int orbx_bow_results_device(const orbx_extractor* ex, const uint32_t** d_word_ids, const double** d_word_values,
+                            const uint32_t** d_node_ids, const int32_t** d_node_start, const uint32_t** d_feature_idx,
+                            const int32_t** d_counts, int* cap);
+/* Host copy of image `image` (synchronises); cap = capacity of the arrays.  Returns n_features or a negative error. */
+int orbx_bow_download(orbx_extractor* ex, int image, uint32_t* word_ids, double* word_values, int* n_words, uint32_t* node_ids,
+                      int32_t* node_start, uint32_t* feature_idx, int* n_nodes, int cap);
+
+/* Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * (src/ORBmatcher.cc:230-404).  kf_* = pKF->mFeatVec (CSR as above), its keypoints (angle is read; left | right
+ * concatenated for two-camera rigs), mDescriptors and kf_valid[i] = (vpMapPointsKF[i] && !isBad()); f_* = F.mFeatVec,
+ * F's keypoints and descriptors, n_left_f = F.Nleft (-1 for monocular / rectified frames).  matches[i] = index of the
+ * keyframe feature whose map point F's feature i received, or -1 (vpMapPointMatches).  nnratio = mfNNratio,
+ * check_orientation = mbCheckOrientation.  Returns nmatches or a negative error. */
+int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* kf_node_start, const uint32_t* kf_feature_idx,
+                       int n_kf_nodes, const orbx_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid, int n_kf,
+                       const uint32_t* f_node_ids, const int32_t* f_node_start, const uint32_t* f_feature_idx, int n_f_nodes,
+                       const orbx_keypoint* f_kps, const uint8_t* f_desc, int n_f, int n_left_f, float nnratio,
+                       int check_orientation, int32_t* matches);
+
 /* Replaces Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys through
  * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) -- five fixed-point iterations of the inverse distortion
  * in double, then x' = fx x + cx.  K = fx fy cx cy (Pinhole::toK()); dist = the n_dist (4, 5, 8, 12 or 14) OpenCV

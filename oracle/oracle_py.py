@@ -390,3 +390,70 @@ def clahe(img, clip=3.0, tiles=(8, 8)):
     lib().oro_clahe(_p(img), w, h, C.c_long(img.strides[0]), C.c_double(clip), tiles[0], tiles[1], _p(dst),
                     C.c_long(dst.strides[0]))
     return dst
+
+
+# ---- f4: bag of words (DBoW2 vocabulary tree, transform, SearchByBoW) -------------------------------------------------------------
+class Vocabulary:
+    """Oracle twin of DBoW2::TemplatedVocabulary<FORB> (transform only).  Columns per node as in the ORBvoc.txt file."""
+
+    def __init__(self, k=None, L=None, parent=None, is_leaf=None, desc=None, weight=None, scoring=0, weighting=0, path=None):
+        L_ = lib()
+        L_.oro_voc_create.restype = C.c_void_p
+        L_.oro_voc_load.restype = C.c_void_p
+        if path is not None:
+            self._h = L_.oro_voc_load(path.encode())
+            if not self._h:
+                raise IOError("cannot load vocabulary " + path)
+        else:
+            parent = np.ascontiguousarray(parent, np.int32)
+            is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            desc = _u8(desc)
+            weight = np.ascontiguousarray(weight, np.float64)
+            self._h = L_.oro_voc_create(k, L, scoring, weighting, len(parent), _p(parent), _p(is_leaf), _p(desc), _p(weight))
+        info = np.zeros(6, np.int32)
+        L_.oro_voc_info(C.c_void_p(self._h), _p(info))
+        self.k, self.L, self.n_nodes, self.n_words, self.scoring, self.weighting = (int(x) for x in info)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().oro_voc_destroy(C.c_void_p(self._h))
+            self._h = None
+
+    def save(self, path):
+        assert lib().oro_voc_save(C.c_void_p(self._h), path.encode()) == 0
+
+    def export(self):
+        n = self.n_nodes
+        parent, leaf, desc, weight = np.zeros(n, np.int32), np.zeros(n, np.uint8), np.zeros((n, 32), np.uint8), np.zeros(n, np.float64)
+        lib().oro_voc_export(C.c_void_p(self._h), _p(parent), _p(leaf), _p(desc), _p(weight))
+        return parent, leaf, desc, weight
+
+    def transform_one(self, desc, levelsup=4):
+        desc = _u8(desc)
+        n = len(desc)
+        w, wt, nd = np.zeros(n, np.int32), np.zeros(n, np.float64), np.zeros(n, np.int32)
+        lib().oro_bow_transform_one(C.c_void_p(self._h), _p(desc), n, levelsup, _p(w), _p(wt), _p(nd))
+        return w, wt, nd
+
+    def transform(self, desc, levelsup=4):
+        """-> (word_ids, values), (node_ids, node_start, feature_idx): BowVector and FeatureVector (CSR)."""
+        desc = _u8(desc)
+        n = len(desc)
+        words, values = np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        nodes, start, feats = np.zeros(n, np.uint32), np.zeros(n + 1, np.int32), np.zeros(n, np.uint32)
+        cnt = np.zeros(3, np.int32)
+        lib().oro_bow_transform(C.c_void_p(self._h), _p(desc), n, levelsup, _p(words), _p(values), _p(nodes), _p(start), _p(feats),
+                                _p(cnt))
+        return (words[:cnt[0]].copy(), values[:cnt[0]].copy()), (nodes[:cnt[1]].copy(), start[:cnt[1] + 1].copy(), feats[:cnt[2]].copy())
+
+
+def search_by_bow(kf_fv, kf_desc, kf_angle, kf_valid, f_fv, f_desc, f_angle, n_left_f=-1, nnratio=0.7, check_ori=True):
+    kn, ks, kf = (np.ascontiguousarray(kf_fv[0], np.uint32), np.ascontiguousarray(kf_fv[1], np.int32), np.ascontiguousarray(kf_fv[2], np.uint32))
+    fn, fs, ff = (np.ascontiguousarray(f_fv[0], np.uint32), np.ascontiguousarray(f_fv[1], np.int32), np.ascontiguousarray(f_fv[2], np.uint32))
+    kd, fd = _u8(kf_desc), _u8(f_desc)
+    ka, fa = np.ascontiguousarray(kf_angle, np.float32), np.ascontiguousarray(f_angle, np.float32)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    match = np.zeros(len(fd), np.int32)
+    n = lib().oro_search_by_bow(_p(kn), len(kn), _p(ks), _p(kf), _p(kd), _p(ka), _p(kv), _p(fn), len(fn), _p(fs), _p(ff), _p(fd), _p(fa),
+                                len(fd), int(n_left_f), C.c_float(nnratio), int(check_ori), _p(match))
+    return n, match

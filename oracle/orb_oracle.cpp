@@ -7,9 +7,11 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <map>
 
 namespace orbo {
 
@@ -1495,6 +1497,213 @@ int search_by_projection_frame_fisheye(const std::vector<KeyPoint>& kps, const u
         match[idx] = -1;
         nmatches--;
       }
+    }
+  }
+  return nmatches;
+}
+
+// ======================================================================================= f4: bag of words (DBoW2)
+void Vocabulary::build(int k_, int L_, int scoring_, int weighting_, int n, const int* parent_, const uint8_t* isLeaf,
+                       const uint8_t* desc_, const double* weight_) {
+  k = k_; L = L_; scoring = scoring_; weighting = weighting_;
+  parent.assign(parent_, parent_ + n);
+  desc.assign(desc_, desc_ + (size_t)n * 32);
+  weight.assign(weight_, weight_ + n);
+  wordId.assign(n, -1);
+  std::vector<int> cnt(n + 1, 0);
+  for (int i = 1; i < n; i++) cnt[parent[i] + 1]++;
+  childStart.assign(n + 1, 0);
+  for (int i = 0; i < n; i++) childStart[i + 1] = childStart[i] + cnt[i + 1];
+  children.assign(n > 0 ? n - 1 : 0, 0);
+  std::vector<int> fill(childStart.begin(), childStart.end() - 1);
+  nWords = 0;
+  for (int i = 1; i < n; i++) {  // file order: children.push_back(nid), words numbered as their leaves appear (:1389-1414)
+    children[fill[parent[i]]++] = i;
+    if (isLeaf[i]) wordId[i] = nWords++;
+  }
+}
+
+bool Vocabulary::load_text(const char* path) {
+  FILE* f = std::fopen(path, "r");
+  if (!f) return false;
+  int k_, L_, n1, n2;
+  if (std::fscanf(f, "%d %d %d %d", &k_, &L_, &n1, &n2) != 4 || k_ < 0 || k_ > 20 || L_ < 1 || L_ > 10 || n1 < 0 || n1 > 5 ||
+      n2 < 0 || n2 > 3) {
+    std::fclose(f);
+    return false;
+  }
+  std::vector<int> par(1, 0);
+  std::vector<uint8_t> leaf(1, 0), d(32, 0);
+  std::vector<double> w(1, 0.0);
+  for (;;) {
+    int pid, isLeaf;
+    if (std::fscanf(f, "%d %d", &pid, &isLeaf) != 2) break;
+    uint8_t row[32];
+    bool ok = true;
+    for (int i = 0; i < 32 && ok; i++) {
+      int b;
+      ok = std::fscanf(f, "%d", &b) == 1;
+      row[i] = (uint8_t)b;
+    }
+    double wt;
+    if (!ok || std::fscanf(f, "%lf", &wt) != 1) break;
+    par.push_back(pid);
+    leaf.push_back(isLeaf > 0);
+    d.insert(d.end(), row, row + 32);
+    w.push_back(wt);
+  }
+  std::fclose(f);
+  build(k_, L_, n1, n2, (int)par.size(), par.data(), leaf.data(), d.data(), w.data());
+  return true;
+}
+
+bool Vocabulary::save_text(const char* path) const {
+  FILE* f = std::fopen(path, "w");
+  if (!f) return false;
+  std::fprintf(f, "%d %d  %d %d\n", k, L, scoring, weighting);
+  for (size_t i = 1; i < parent.size(); i++) {
+    std::fprintf(f, "%d %d ", parent[i], is_leaf((int)i) ? 1 : 0);
+    for (int b = 0; b < 32; b++) std::fprintf(f, "%d ", desc[i * 32 + b]);
+    std::fprintf(f, "%.17g\n", weight[i]);
+  }
+  std::fclose(f);
+  return true;
+}
+
+void bow_transform_one(const Vocabulary& v, const uint8_t* d, int levelsup, int& wordId, double& weight, int& nodeId) {
+  const int nidLevel = v.L - levelsup;
+  nodeId = 0;
+  bool nidSet = nidLevel <= 0;
+  int cur = 0, level = 0;
+  do {
+    ++level;
+    const int c0 = v.childStart[cur], c1 = v.childStart[cur + 1];
+    int best = v.children[c0];
+    int bestD = descriptor_distance(d, &v.desc[(size_t)best * 32]);
+    for (int c = c0 + 1; c < c1; c++) {
+      const int id = v.children[c];
+      const int dist = descriptor_distance(d, &v.desc[(size_t)id * 32]);
+      if (dist < bestD) { bestD = dist; best = id; }
+    }
+    cur = best;
+    if (level == nidLevel) { nodeId = cur; nidSet = true; }
+  } while (!v.is_leaf(cur));
+  if (!nidSet) nodeId = cur;
+  wordId = v.wordId[cur];
+  weight = v.weight[cur];
+}
+
+void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup, std::vector<uint32_t>& words,
+                   std::vector<double>& values, std::vector<uint32_t>& nodes, std::vector<int>& nodeStart,
+                   std::vector<uint32_t>& features) {
+  words.clear(); values.clear(); nodes.clear(); nodeStart.assign(1, 0); features.clear();
+  if (v.parent.size() <= 1) return;  // empty()
+  // mustNormalize: every scoring but DOT_PRODUCT; L2 norm only for L2_NORM (ScoringObject.h:73-90)
+  const bool must = v.scoring != 5;
+  const bool l2 = v.scoring == 1;
+  std::map<uint32_t, double> bow;
+  std::map<uint32_t, std::vector<uint32_t>> fv;
+  const bool additive = v.weighting == 0 || v.weighting == 1;  // TF_IDF, TF
+  for (int i = 0; i < n; i++) {
+    int wid, nid;
+    double w;
+    bow_transform_one(v, desc + (size_t)i * 32, levelsup, wid, w, nid);
+    if (w > 0) {
+      auto it = bow.lower_bound((uint32_t)wid);
+      if (it != bow.end() && it->first == (uint32_t)wid) {
+        if (additive) it->second += w;  // addWeight; addIfNotExist keeps the first
+      } else {
+        bow.insert(it, std::make_pair((uint32_t)wid, w));
+      }
+      fv[(uint32_t)nid].push_back((uint32_t)i);
+    }
+  }
+  if (additive && !bow.empty() && !must) {
+    const double nd = (double)bow.size();
+    for (auto& e : bow) e.second /= nd;
+  }
+  if (must) {
+    double norm = 0.0;
+    if (!l2) {
+      for (auto& e : bow) norm += std::fabs(e.second);
+    } else {
+      for (auto& e : bow) norm += e.second * e.second;
+      norm = std::sqrt(norm);
+    }
+    if (norm > 0.0)
+      for (auto& e : bow) e.second /= norm;
+  }
+  for (auto& e : bow) { words.push_back(e.first); values.push_back(e.second); }
+  for (auto& e : fv) {
+    nodes.push_back(e.first);
+    features.insert(features.end(), e.second.begin(), e.second.end());
+    nodeStart.push_back((int)features.size());
+  }
+}
+
+int search_by_bow(const std::vector<uint32_t>& kfNodes, const std::vector<int>& kfStart, const std::vector<uint32_t>& kfFeat,
+                  const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfValid, const std::vector<uint32_t>& fNodes,
+                  const std::vector<int>& fStart, const std::vector<uint32_t>& fFeat, const uint8_t* fDesc, const float* fAngle,
+                  int nF, int nLeftF, float nnratio, bool checkOri, std::vector<int>& match) {
+  const int HISTO = 30, TH_LOW = 50;
+  match.assign(nF, -1);
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  auto vote = [&](int iKF, int iF) {
+    float rot = kfAngle[iKF] - fAngle[iF];
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO) bin = 0;
+    rotHist[bin].push_back(iF);
+  };
+  size_t a = 0, b = 0;
+  while (a < kfNodes.size() && b < fNodes.size()) {
+    if (kfNodes[a] == fNodes[b]) {
+      for (int p = kfStart[a]; p < kfStart[a + 1]; p++) {
+        const int iKF = (int)kfFeat[p];
+        if (!kfValid[iKF]) continue;  // !pMP || pMP->isBad()
+        const uint8_t* dKF = kfDesc + (size_t)iKF * 32;
+        int best1 = 256, bestIdx = -1, best2 = 256, best1R = 256, bestIdxR = -1, best2R = 256;
+        for (int q = fStart[b]; q < fStart[b + 1]; q++) {
+          const int iF = (int)fFeat[q];
+          if (match[iF] >= 0) continue;
+          const int dist = descriptor_distance(dKF, fDesc + (size_t)iF * 32);
+          if (nLeftF == -1 || iF < nLeftF) {
+            if (dist < best1) { best2 = best1; best1 = dist; bestIdx = iF; }
+            else if (dist < best2) { best2 = dist; }
+          } else {
+            if (dist < best1R) { best2R = best1R; best1R = dist; bestIdxR = iF; }
+            else if (dist < best2R) { best2R = dist; }
+          }
+        }
+        if (best1 <= TH_LOW) {
+          if ((float)best1 < nnratio * (float)best2) {
+            match[bestIdx] = iKF;
+            if (checkOri) vote(iKF, bestIdx);
+            nmatches++;
+          }
+          if (best1R <= TH_LOW) {  // ":363-365": the ratio test of the right eye is short-circuited by "|| true"
+            match[bestIdxR] = iKF;
+            if (checkOri) vote(iKF, bestIdxR);
+            nmatches++;
+          }
+        }
+      }
+      a++;
+      b++;
+    } else if (kfNodes[a] < fNodes[b]) {
+      a = std::lower_bound(kfNodes.begin(), kfNodes.end(), fNodes[b]) - kfNodes.begin();
+    } else {
+      b = std::lower_bound(fNodes.begin(), fNodes.end(), kfNodes[a]) - fNodes.begin();
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx : rotHist[i]) { match[idx] = -1; nmatches--; }
     }
   }
   return nmatches;

@@ -233,4 +233,40 @@ int search_by_projection_frame_fisheye(const std::vector<KeyPoint>& kps, const u
                                        const FrameGrid& gridR, const std::vector<ProjectedPoint>& pts, const float* uvRight,
                                        bool checkOri, std::vector<uint8_t>& occupied, std::vector<int>& match);
 
+// ---- bag of words (Thirdparty/DBoW2) --------------------------------------------------------------------
+// The vocabulary tree as TemplatedVocabulary::loadFromTextFile leaves it (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+// 1338-1421): node 0 is the root, nodes 1.. in file order with parent[i] < i, a node's children in file order, words
+// numbered in the file order of the leaves.  The ORB vocabulary file itself (ORBvoc.txt, 10^6 words) is not in the reference
+// tree; every test runs on synthetic trees.
+struct Vocabulary {
+  int k = 0, L = 0, scoring = 0, weighting = 0;  // ScoringType / WeightingType of BowVector.h:39-56
+  std::vector<int> parent, childStart, children, wordId;  // childStart has n + 1 entries; wordId -1 for inner nodes
+  std::vector<uint8_t> desc;                              // n x 32
+  std::vector<double> weight;
+  int nWords = 0;
+  bool is_leaf(int n) const { return childStart[n + 1] == childStart[n]; }
+  // build from the per-node file columns (parent, isLeaf, descriptor, weight); entry 0 = root (ignored columns)
+  void build(int k_, int L_, int scoring_, int weighting_, int n, const int* parent_, const uint8_t* isLeaf,
+             const uint8_t* desc_, const double* weight_);
+  bool load_text(const char* path);   // the ORBvoc.txt format of loadFromTextFile
+  bool save_text(const char* path) const;
+};
+// TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (:1202-1250): descend by first-minimum Hamming
+// distance among the children; *nid = the node of the path at level L - levelsup (root if that is <= 0).  A leaf above
+// that level leaves *nid uninitialised in the reference; here it is the leaf itself.
+void bow_transform_one(const Vocabulary& v, const uint8_t* d, int levelsup, int& wordId, double& weight, int& nodeId);
+// TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) (:1125-1188) as Frame::ComputeBoW calls it
+// (src/Frame.cc:846-851, levelsup 4): BowVector = ascending (word, value) with the map's sequential += in feature order and
+// the scoring's normalisation (BowVector.cpp:58-80); FeatureVector = ascending node id -> feature indices in order.
+void bow_transform(const Vocabulary& v, const uint8_t* desc, int n, int levelsup, std::vector<uint32_t>& words,
+                   std::vector<double>& values, std::vector<uint32_t>& nodes, std::vector<int>& nodeStart,
+                   std::vector<uint32_t>& features);
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:230-404).  Feature vectors as CSR
+// (ascending node ids); kfValid[i] = the keyframe feature holds a good map point; angles = kp.angle of the concatenated
+// (left | right) keypoints; nLeftF = F.Nleft (-1: monocular / rectified).  match[iF] = keyframe feature index or -1.
+int search_by_bow(const std::vector<uint32_t>& kfNodes, const std::vector<int>& kfStart, const std::vector<uint32_t>& kfFeat,
+                  const uint8_t* kfDesc, const float* kfAngle, const uint8_t* kfValid, const std::vector<uint32_t>& fNodes,
+                  const std::vector<int>& fStart, const std::vector<uint32_t>& fFeat, const uint8_t* fDesc, const float* fAngle,
+                  int nF, int nLeftF, float nnratio, bool checkOri, std::vector<int>& match);
+
 }  // namespace orbo

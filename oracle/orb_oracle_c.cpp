@@ -289,4 +289,61 @@ void oro_std_sort_keys(uint64_t* v, int n) {
   std::sort(v, v + n, [](uint64_t a, uint64_t b) { return (a >> 16) < (b >> 16); });
 }
 
+// ---- f4: bag of words ------------------------------------------------------------------------------------------------
+void* oro_voc_create(int k, int L, int scoring, int weighting, int n, const int* parent, const uint8_t* isLeaf,
+                     const uint8_t* desc, const double* weight) {
+  Vocabulary* v = new Vocabulary();
+  v->build(k, L, scoring, weighting, n, parent, isLeaf, desc, weight);
+  return v;
+}
+void* oro_voc_load(const char* path) {
+  Vocabulary* v = new Vocabulary();
+  if (!v->load_text(path)) { delete v; return nullptr; }
+  return v;
+}
+int oro_voc_save(void* h, const char* path) { return static_cast<Vocabulary*>(h)->save_text(path) ? 0 : -1; }
+void oro_voc_destroy(void* h) { delete static_cast<Vocabulary*>(h); }
+void oro_voc_info(void* h, int* out) {
+  const Vocabulary* v = static_cast<Vocabulary*>(h);
+  out[0] = v->k; out[1] = v->L; out[2] = (int)v->parent.size(); out[3] = v->nWords; out[4] = v->scoring; out[5] = v->weighting;
+}
+void oro_voc_export(void* h, int* parent, uint8_t* isLeaf, uint8_t* desc, double* weight) {
+  const Vocabulary* v = static_cast<Vocabulary*>(h);
+  const int n = (int)v->parent.size();
+  for (int i = 0; i < n; i++) {
+    parent[i] = v->parent[i];
+    isLeaf[i] = i > 0 && v->wordId[i] >= 0;
+    weight[i] = v->weight[i];
+  }
+  std::memcpy(desc, v->desc.data(), (size_t)n * 32);
+}
+void oro_bow_transform_one(void* h, const uint8_t* desc, int n, int levelsup, int* word, double* weight, int* node) {
+  for (int i = 0; i < n; i++) bow_transform_one(*static_cast<Vocabulary*>(h), desc + (size_t)i * 32, levelsup, word[i], weight[i], node[i]);
+}
+// outputs sized n (words, values, nodes, feats) and n + 1 (nodeStart); counts[0] = words, counts[1] = nodes, counts[2] = features
+void oro_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* words, double* values, uint32_t* nodes,
+                       int* nodeStart, uint32_t* feats, int* counts) {
+  std::vector<uint32_t> w, nd, ft;
+  std::vector<double> val;
+  std::vector<int> st;
+  bow_transform(*static_cast<Vocabulary*>(h), desc, n, levelsup, w, val, nd, st, ft);
+  std::copy(w.begin(), w.end(), words);
+  std::copy(val.begin(), val.end(), values);
+  std::copy(nd.begin(), nd.end(), nodes);
+  std::copy(st.begin(), st.end(), nodeStart);
+  std::copy(ft.begin(), ft.end(), feats);
+  counts[0] = (int)w.size(); counts[1] = (int)nd.size(); counts[2] = (int)ft.size();
+}
+int oro_search_by_bow(const uint32_t* kfNodes, int nKfNodes, const int* kfStart, const uint32_t* kfFeat, const uint8_t* kfDesc,
+                      const float* kfAngle, const uint8_t* kfValid, const uint32_t* fNodes, int nFNodes, const int* fStart,
+                      const uint32_t* fFeat, const uint8_t* fDesc, const float* fAngle, int nF, int nLeftF, float nnratio,
+                      int checkOri, int* match) {
+  std::vector<uint32_t> a(kfNodes, kfNodes + nKfNodes), af(kfFeat, kfFeat + kfStart[nKfNodes]);
+  std::vector<uint32_t> b(fNodes, fNodes + nFNodes), bf(fFeat, fFeat + fStart[nFNodes]);
+  std::vector<int> as(kfStart, kfStart + nKfNodes + 1), bs(fStart, fStart + nFNodes + 1), m;
+  const int n = search_by_bow(a, as, af, kfDesc, kfAngle, kfValid, b, bs, bf, fDesc, fAngle, nF, nLeftF, nnratio, checkOri != 0, m);
+  std::copy(m.begin(), m.end(), match);
+  return n;
+}
+
 }  // extern "C"

@@ -119,6 +119,7 @@ int main() {
   int nd = 0;
   const int nfm = compute_stereo_fisheye_matches(kL, dL.data(), mL, kR, dR.data(), mR, c1, c2, R12, t12, eL.t.sigma2, a12, a21, fdep,
                                                  p3d, &nd, nullptr);
+  int nfm_bow = 0;
   // undistortion + pre-processing
   const float K[4] = {458.654f, 457.296f, 200.f, 150.f}, D[4] = {-0.2834f, 0.0740f, 0.00019f, 1.76e-05f};
   std::vector<KeyPoint> un;
@@ -141,7 +142,38 @@ int main() {
   std::vector<uint8_t> rect((size_t)rw * rh), eq((size_t)rw * rh);
   remap_linear_u8(L.data(), w, h, w, mapx.data(), mapy.data(), rw, rect.data(), rw, rh, rw);
   clahe_u8(rect.data(), rw, rh, rw, 3.0, 8, 8, eq.data(), rw);
+  // bag of words: a small irregular tree (leaves at two depths, one stopped word), transform + SearchByBoW on the frame's own
+  // descriptors (keyframe = left eye, frame = left | right eyes)
+  {
+    std::vector<int> par(1, 0);
+    std::vector<uint8_t> leaf(1, 0), nd(32, 0);
+    std::vector<double> wts(1, 0.0);
+    auto add = [&](int p, bool lf, const uint8_t* d, double wgt) {
+      par.push_back(p); leaf.push_back(lf); nd.insert(nd.end(), d, d + 32); wts.push_back(wgt);
+      return (int)par.size() - 1;
+    };
+    for (int c = 0; c < 5; c++) {
+      const int id = add(0, c == 4, dL.data() + (size_t)(c * 37 % std::max(1, (int)kL.size())) * 32, c == 4 ? 2.5 : 0.0);
+      if (c < 4)
+        for (int e = 0; e < 3; e++) add(id, true, dR.data() + (size_t)((c * 3 + e) * 11 % std::max(1, (int)kR.size())) * 32, e == 2 && c == 1 ? 0.0 : 1.0 + e);
+    }
+    Vocabulary voc;
+    voc.build(5, 2, 0, 0, (int)par.size(), par.data(), leaf.data(), nd.data(), wts.data());
+    std::vector<uint32_t> w1, n1, f1, w2, n2, f2;
+    std::vector<double> v1, v2;
+    std::vector<int> s1, s2, bm;
+    std::vector<uint8_t> both(dL);
+    both.insert(both.end(), dR.begin(), dR.end());
+    std::vector<float> angK, angF;
+    for (auto& k : kL) { angK.push_back(k.angle); angF.push_back(k.angle); }
+    for (auto& k : kR) angF.push_back(k.angle);
+    bow_transform(voc, dL.data(), (int)kL.size(), 1, w1, v1, n1, s1, f1);
+    bow_transform(voc, both.data(), (int)(kL.size() + kR.size()), 1, w2, v2, n2, s2, f2);
+    std::vector<uint8_t> valid(kL.size(), 1);
+    nfm_bow = search_by_bow(n1, s1, f1, dL.data(), angK.data(), valid.data(), n2, s2, f2, both.data(), angF.data(),
+                            (int)(kL.size() + kR.size()), (int)kL.size(), 0.7f, true, bm);
+  }
   std::printf("ok %d %d %zu %zu stereo %d knn %d init %d proj %d %d fe %d %d fisheye %d/%d un %.2f b %.1f g %d\n", mL, mR, kL.size(),
-              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7]);
+              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow);
   return 0;
 }

@@ -97,6 +97,16 @@ def lib():
         L.orbx_preproc_run_device.argtypes = [vp, vp, i, C.c_ssize_t, C.c_ssize_t, C.POINTER(vp), C.POINTER(i), C.POINTER(i),
                                               C.POINTER(C.c_ssize_t), C.POINTER(C.c_ssize_t)]
         L.orbx_extract_batch_raw_device.argtypes = [vp, vp, vp, i, C.c_ssize_t, C.c_ssize_t, vp]
+        L.orbx_vocabulary_create.argtypes = [i, i, i, i, i, i, vp, vp, vp, vp, C.POINTER(vp)]
+        L.orbx_vocabulary_load_text.argtypes = [i, C.c_char_p, C.POINTER(vp)]
+        L.orbx_vocabulary_destroy.argtypes = [vp]
+        L.orbx_vocabulary_destroy.restype = None
+        L.orbx_vocabulary_info.argtypes = [vp, vp]
+        L.orbx_bow_transform.argtypes = [vp, vp, i, i, vp, vp, C.POINTER(i), vp, vp, vp, C.POINTER(i)]
+        L.orbx_bow_transform_batch.argtypes = [vp, vp, i]
+        L.orbx_bow_results_device.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i)]
+        L.orbx_bow_download.argtypes = [vp, i, vp, vp, C.POINTER(i), vp, vp, vp, C.POINTER(i), i]
+        L.orbx_search_by_bow.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, f, i, vp]
         L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
         L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
         L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
@@ -479,6 +489,73 @@ class Preproc:
         _check(lib().orbx_preproc_run_device(self._h, C.c_void_p(d_frames_ptr), n_frames, row_pitch, image_pitch, C.byref(out),
                                              C.byref(w), C.byref(h), C.byref(rp), C.byref(ip)))
         return out.value, w.value, h.value, rp.value, ip.value
+
+
+class ORBVocabulary:
+    """ORBVocabulary (DBoW2::TemplatedVocabulary<FORB>) on the device: loadFromTextFile (src/System.cc:131) or the file's
+    columns (parent, is_leaf, descriptor, weight per node); transform() = Frame::ComputeBoW (src/Frame.cc:846-851)."""
+
+    def __init__(self, k=None, L=None, parent=None, is_leaf=None, desc=None, weight=None, scoring=0, weighting=0, path=None,
+                 device=0):
+        h = C.c_void_p()
+        if path is not None:
+            _check(lib().orbx_vocabulary_load_text(device, path.encode(), C.byref(h)))
+        else:
+            parent = np.ascontiguousarray(parent, np.int32)
+            leaf = np.ascontiguousarray(is_leaf, np.uint8)
+            d = np.ascontiguousarray(desc, np.uint8)
+            w = np.ascontiguousarray(weight, np.float64)
+            _check(lib().orbx_vocabulary_create(device, k, L, scoring, weighting, len(parent), _p(parent), _p(leaf), _p(d), _p(w),
+                                                C.byref(h)))
+        self._h = h
+        info = np.zeros(6, np.int32)
+        _check(lib().orbx_vocabulary_info(self._h, _p(info)))
+        self.k, self.L, self.n_nodes, self.n_words, self.scoring, self.weighting = (int(x) for x in info)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orbx_vocabulary_destroy(self._h)
+            self._h = None
+
+    def transform(self, desc, levelsup=4):
+        """-> (word_ids, values), (node_ids, node_start, feature_idx): mBowVec and mFeatVec (CSR)."""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        words, values = np.zeros(n, np.uint32), np.zeros(n, np.float64)
+        nodes, start, feats = np.zeros(n, np.uint32), np.zeros(n + 1, np.int32), np.zeros(n, np.uint32)
+        nw, nn = C.c_int(), C.c_int()
+        nf = _check(lib().orbx_bow_transform(self._h, _p(d), n, levelsup, _p(words), _p(values), C.byref(nw), _p(nodes), _p(start),
+                                             _p(feats), C.byref(nn)))
+        return (words[:nw.value].copy(), values[:nw.value].copy()), (nodes[:nn.value].copy(), start[:nn.value + 1].copy(), feats[:nf].copy())
+
+    def transform_batch(self, extractor, levelsup=4):
+        """ComputeBoW for every image of the extractor's last extraction, on its stream (results stay on the device)."""
+        _check(lib().orbx_bow_transform_batch(extractor._h, self._h, levelsup))
+
+    @staticmethod
+    def download(extractor, image):
+        cap = extractor.capacity
+        words, values = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        nodes, start, feats = np.zeros(cap, np.uint32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.uint32)
+        nw, nn = C.c_int(), C.c_int()
+        nf = _check(lib().orbx_bow_download(extractor._h, image, _p(words), _p(values), C.byref(nw), _p(nodes), _p(start), _p(feats),
+                                            C.byref(nn), cap))
+        return (words[:nw.value].copy(), values[:nw.value].copy()), (nodes[:nn.value].copy(), start[:nn.value + 1].copy(), feats[:nf].copy())
+
+
+def SearchByBoW(kf_fv, kf_kps, kf_desc, kf_valid, f_fv, f_kps, f_desc, n_left_f=-1, nnratio=0.7, check_ori=True, device=0):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:230-404): feature vectors as the CSR triples
+    ORBVocabulary.transform returns; -> (nmatches, match[n_f] = keyframe feature index or -1)."""
+    kn, ks, kfi = (np.ascontiguousarray(kf_fv[0], np.uint32), np.ascontiguousarray(kf_fv[1], np.int32), np.ascontiguousarray(kf_fv[2], np.uint32))
+    fn, fs, ffi = (np.ascontiguousarray(f_fv[0], np.uint32), np.ascontiguousarray(f_fv[1], np.int32), np.ascontiguousarray(f_fv[2], np.uint32))
+    kk, fk = np.ascontiguousarray(kf_kps, KP_DTYPE), np.ascontiguousarray(f_kps, KP_DTYPE)
+    kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    match = np.zeros(len(fk), np.int32)
+    n = _check(lib().orbx_search_by_bow(device, _p(kn), _p(ks), _p(kfi), len(kn), _p(kk), _p(kd), _p(kv), len(kk), _p(fn), _p(fs),
+                                        _p(ffi), len(fn), _p(fk), _p(fd), len(fk), int(n_left_f), float(nnratio), int(bool(check_ori)),
+                                        _p(match)))
+    return n, match
 
 
 def UndistortKeyPoints(kps, K, dist, device=0):

@@ -159,6 +159,35 @@ struct UndistortArgs {
 hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s);
 
 // Pre-processing: gray conversion and a generic (any size, 1/3/4 channels) bilinear resize; pitches in bytes.
+// ---- bag of words ---------------------------------------------------------------------------------------
+// DBoW2 vocabulary tree on the device: children of node i = children[childStart[i] .. childStart[i + 1]) in file order.
+struct BowVoc {
+  const int* childStart; const int* children; const uint32_t* desc; const double* weight; const int* wordId;
+  int L, nNodes, scoring, weighting;
+};
+constexpr int kBowMaxFeatures = 8192;  // per image: the assembly sorts (word, index) pairs in LDS
+// Per image i of a batch: descriptors at desc + i * descImgPitch, count = counts ? counts[i] : n.  Per-feature results
+// (word / weight / node, `cap` entries per image) and the assembled vectors (cap entries per image, nodeStart cap + 1,
+// outCounts 3 per image = words, nodes, features).
+struct BowArgs {
+  BowVoc voc;
+  const uint8_t* desc; long long descImgPitch; const int* counts; int n, cap, levelsup;
+  int* word; double* weight; int* node;
+  uint32_t* words; double* values; uint32_t* nodes; int* nodeStart; uint32_t* feats; int* outCounts;
+};
+hipError_t launch_bow_transform(const BowArgs& a, int nimg, hipStream_t s);
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&): feature vectors as CSR, match[nF] = keyframe feature or -1,
+// flags: [0] matches made, [1] matches culled, [2..32) rotation histogram; result[0] = nmatches.
+struct BowMatchArgs {
+  const uint32_t* kfNodes; const int* kfStart; const uint32_t* kfFeat; int nKfNodes;
+  const uint32_t* kfDesc; const orbx_keypoint* kfKps; const uint8_t* kfValid;
+  const uint32_t* fNodes; const int* fStart; const uint32_t* fFeat; int nFNodes;
+  const uint32_t* fDesc; const orbx_keypoint* fKps; int nF, nLeftF;
+  float nnratio; int checkOri;
+  int* match; int* bin; int* flags; int* result;
+};
+hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s);
+
 // cv::remap INTER_LINEAR with float maps (k_remap): batch of nimg images, image i uses map i % nMaps.
 struct RemapArgs {
   const uint8_t* src; int sw, sh, cn; long long srcPitch, srcImgPitch;

@@ -254,3 +254,73 @@ def rectify_maps(w, h, src_w=None, src_h=None, k1=-0.28, k2=0.07, p1=3e-4, p2=-2
     xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
     yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
     return (fx * xd + cx).astype(np.float32), (fy * yd + cy).astype(np.float32)
+
+
+def make_vocabulary(k=10, L=4, seed=0, early_leaf_prob=0.03, stop_prob=0.02):
+    """Synthetic DBoW2-style vocabulary tree in the node order of TemplatedVocabulary::HKmeansStep / the ORBvoc.txt file
+    (the k children of a node are created together, then each child is expanded): per-node columns parent, is_leaf,
+    descriptor (32 B), weight.  Children are their parent's descriptor with random bit flips (fewer at deeper levels), so a
+    descriptor close to a leaf descends to it; a few inner positions become early leaves and a few words are stopped
+    (weight 0).  The real ORBvoc.txt (k = 10, L = 6) is not part of the reference tree."""
+    rng = np.random.RandomState(seed)
+    parent, leaf, desc, weight = [0], [0], [np.zeros(32, np.uint8)], [0.0]
+
+    def flip(d, nbits):
+        bits = np.unpackbits(d)
+        idx = rng.choice(256, nbits, replace=False)
+        bits[idx] ^= 1
+        return np.packbits(bits)
+
+    def expand(pid, level):
+        first = len(parent)
+        base = desc[pid] if pid else rng.randint(0, 256, 32).astype(np.uint8)
+        for _ in range(k):
+            parent.append(pid)
+            is_leaf = level == L or (level >= 2 and rng.rand() < early_leaf_prob)
+            leaf.append(int(is_leaf))
+            desc.append(flip(base, max(96 >> (level - 1), 6)))
+            weight.append(0.0 if (is_leaf and rng.rand() < stop_prob) else (float(rng.uniform(0.5, 9.0)) if is_leaf else 0.0))
+        for c in range(first, first + k):
+            if not leaf[c]:
+                expand(c, level + 1)
+
+    expand(0, 1)
+    return (np.array(parent, np.int32), np.array(leaf, np.uint8), np.stack(desc).astype(np.uint8), np.array(weight, np.float64))
+
+
+def vocabulary_features(voc_cols, n, seed=0, noise_bits=10):
+    """n descriptors near random leaves of a make_vocabulary() tree (plus a few purely random ones)."""
+    rng = np.random.RandomState(seed)
+    parent, leaf, desc, weight = voc_cols
+    leaves = np.flatnonzero(leaf)
+    pick = desc[rng.choice(leaves, n)].copy()
+    bits = np.unpackbits(pick, axis=1)
+    for i in range(n):
+        bits[i, rng.choice(256, rng.randint(0, noise_bits + 1), replace=False)] ^= 1
+    out = np.packbits(bits, axis=1)
+    rnd = rng.rand(n) < 0.05
+    out[rnd] = rng.randint(0, 256, (int(rnd.sum()), 32))
+    return out
+
+
+def make_vocabulary_bfs(k=10, L=6, seed=0):
+    """A full k^L-word tree (ORBvoc.txt has k = 10, L = 6: 1 111 111 nodes) generated level by level with numpy: node order
+    is breadth first (parent[i] < i still holds, which is all the loaders need).  Same column layout as make_vocabulary."""
+    rng = np.random.RandomState(seed)
+    parent, leaf, desc, weight = [np.zeros(1, np.int32)], [np.zeros(1, np.uint8)], [np.zeros((1, 32), np.uint8)], [np.zeros(1)]
+    prev_ids, prev_desc, nxt = np.zeros(1, np.int64), rng.randint(0, 256, (1, 32)).astype(np.uint8), 1
+    for level in range(1, L + 1):
+        n = len(prev_ids) * k
+        par = np.repeat(prev_ids, k)
+        base = np.repeat(prev_desc, k, axis=0)
+        nb = max(96 >> (level - 1), 6)
+        flips = np.zeros((n, 256), np.uint8)
+        cols = rng.randint(0, 256, (n, nb))
+        flips[np.arange(n)[:, None], cols] = 1
+        d = base ^ np.packbits(flips, axis=1)
+        parent.append(par.astype(np.int32))
+        leaf.append(np.full(n, int(level == L), np.uint8))
+        desc.append(d)
+        weight.append(rng.uniform(0.5, 9.0, n) if level == L else np.zeros(n))
+        prev_ids, prev_desc, nxt = np.arange(nxt, nxt + n), d, nxt + n
+    return np.concatenate(parent), np.concatenate(leaf), np.concatenate(desc), np.concatenate(weight)

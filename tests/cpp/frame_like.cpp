@@ -12,6 +12,7 @@
 
 #include "../../orb_slam3_fast_amd/csrc/ORBextractor.h"
 #include "../../orb_slam3_fast_amd/csrc/ORBmatcher.h"
+#include "../../orb_slam3_fast_amd/csrc/ORBVocabulary.h"
 #include "../../orb_slam3_fast_amd/csrc/Preprocess.h"
 
 using namespace ORB_SLAM3;
@@ -37,6 +38,35 @@ int main(int argc, char** argv) {
       std::printf("no-device error: %s\n", e.what());
       return 3;
     }
+  }
+  if (std::string(argv[1]) == "bow") {
+    // frame_like bow <voc.txt> <kfDesc.raw> <kfAngle.raw> <kfValid.raw> <fDesc.raw> <fAngle.raw> <levelsup> <nLeftF> <outprefix>
+    ORBVocabulary voc;
+    if (!voc.loadFromTextFile(argv[2])) {
+      std::printf("cannot load %s: %s\n", argv[2], orbx_last_error());
+      return 4;
+    }
+    std::vector<uint8_t> kd = slurp(argv[3]), kab = slurp(argv[4]), kv = slurp(argv[5]), fd = slurp(argv[6]), fab = slurp(argv[7]);
+    const int levelsup = std::atoi(argv[8]), nLeftF = std::atoi(argv[9]);
+    const std::string out = argv[10];
+    const int nk = (int)kd.size() / 32, nf = (int)fd.size() / 32;
+    std::vector<ocv::KeyPoint> kk(nk), fk(nf);
+    for (int i = 0; i < nk; i++) std::memcpy(&kk[i].angle, kab.data() + 4 * i, 4);
+    for (int i = 0; i < nf; i++) std::memcpy(&fk[i].angle, fab.data() + 4 * i, 4);
+    DBoW2::BowVector bk, bf;
+    DBoW2::FeatureVector vk, vf;
+    voc.transform(kd.data(), nk, bk, vk, levelsup);  // KeyFrame::ComputeBoW
+    voc.transform(fd.data(), nf, bf, vf, levelsup);  // Frame::ComputeBoW
+    std::vector<int> matches;
+    const int n = SearchByBoW(vk, kk, kd.data(), kv, vf, fk, fd.data(), nLeftF, 0.7f, true, matches);
+    std::vector<uint32_t> w;
+    std::vector<double> val;
+    for (const auto& e : bf) { w.push_back(e.first); val.push_back(e.second); }
+    dump(out + ".words", w.data(), w.size());
+    dump(out + ".values", val.data(), val.size());
+    dump(out + ".match", matches.data(), matches.size());
+    std::printf("bow %u words, %zu / %zu nodes, %d matches\n", voc.size(), vk.size(), vf.size(), n);
+    return 0;
   }
   if (std::string(argv[1]) == "rectify") {
     // frame_like rectify <sw> <sh> <dw> <dh> <L.raw> <R.raw> <maps.raw (M1l M2l M1r M2r, dw*dh floats each)> <outprefix>

@@ -1,0 +1,367 @@
+"""Bag of words: Frame::ComputeBoW = DBoW2 TemplatedVocabulary::transform(features, BowVector,
+FeatureVector, 4) (src/Frame.cc:846-851; Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1125-1250) and
+ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:230-404).
+
+The ORB vocabulary file is not in the reference tree, so every case runs on synthetic trees (synth.make_vocabulary, same node
+order and text format as ORBvoc.txt).  The C++ oracle is checked against a literal Python transcription of the reference's
+map-based code; the HIP path against the oracle: words, nodes, feature lists and matches exactly, BowVector values bit for
+bit (the same sequential double additions)."""
+import os
+
+import numpy as np
+import pytest
+
+from orb_slam3_fast_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "bow.npz")
+
+
+# ---- literal transcription of the reference (dicts for the std::maps) -------------------------------------------------------
+def _ham(a, b):
+    return int(np.unpackbits(np.bitwise_xor(a, b)).sum())
+
+
+class PyVoc:
+    def __init__(self, k, L, cols, scoring=0, weighting=0):
+        self.k, self.L, self.scoring, self.weighting = k, L, scoring, weighting
+        parent, leaf, desc, weight = cols
+        n = len(parent)
+        self.children = [[] for _ in range(n)]
+        self.desc, self.weight = desc, weight
+        self.word_id = [0] * n
+        nw = 0
+        for i in range(1, n):  # loadFromTextFile :1378-1419
+            self.children[parent[i]].append(i)
+            if leaf[i]:
+                self.word_id[i] = nw
+                nw += 1
+
+    def transform_one(self, f, levelsup):  # :1202-1250
+        nid_level = self.L - levelsup
+        nid = 0 if nid_level <= 0 else None
+        final, level = 0, 0
+        while True:
+            level += 1
+            nodes = self.children[final]
+            final = nodes[0]
+            best = _ham(f, self.desc[final])
+            for c in nodes[1:]:
+                d = _ham(f, self.desc[c])
+                if d < best:
+                    best, final = d, c
+            if level == nid_level:
+                nid = final
+            if not self.children[final]:
+                break
+        if nid is None:  # uninitialised in the reference; the oracle defines it as the leaf
+            nid = final
+        return self.word_id[final], float(self.weight[final]), nid
+
+    def transform(self, feats, levelsup):  # :1125-1188 with BowVector.cpp:36-80, FeatureVector.cpp:31-45
+        bow, fv = {}, {}
+        must, l2 = self.scoring != 5, self.scoring == 1
+        additive = self.weighting in (0, 1)
+        for i, f in enumerate(feats):
+            wid, w, nid = self.transform_one(f, levelsup)
+            if w > 0:
+                if wid in bow:
+                    if additive:
+                        bow[wid] = bow[wid] + w
+                else:
+                    bow[wid] = w
+                fv.setdefault(nid, []).append(i)
+        keys = sorted(bow)
+        if additive and bow and not must:
+            for kk in keys:
+                bow[kk] /= float(len(bow))
+        if must:
+            norm = 0.0
+            for kk in keys:
+                norm += abs(bow[kk]) if not l2 else bow[kk] * bow[kk]
+            if l2:
+                norm = float(np.sqrt(norm))
+            if norm > 0.0:
+                for kk in keys:
+                    bow[kk] /= norm
+        return [(kk, bow[kk]) for kk in keys], [(kk, fv[kk]) for kk in sorted(fv)]
+
+
+def py_search_by_bow(kf_fv, kf_desc, kf_angle, kf_valid, f_fv, f_desc, f_angle, n_left_f, nnratio, check_ori):
+    """src/ORBmatcher.cc:230-404, feature vectors as lists of (node, [indices])."""
+    match = [-1] * len(f_desc)
+    rot = [[] for _ in range(30)]
+    nm = 0
+    kfd, fd = dict(kf_fv), dict(f_fv)
+
+    def vote(ikf, i_f):
+        r = np.float32(kf_angle[ikf]) - np.float32(f_angle[i_f])
+        if r < 0.0:
+            r = np.float32(r + np.float32(360.0))
+        v = float(np.float32(r * np.float32(1.0 / 30)))
+        b = int(np.floor(v + 0.5)) if v >= 0 else -int(np.floor(-v + 0.5))
+        rot[0 if b == 30 else b].append(i_f)
+
+    for node in sorted(set(kfd) & set(fd)):  # the two-pointer walk with lower_bound visits exactly the common nodes, ascending
+        for ikf in kfd[node]:
+            if not kf_valid[ikf]:
+                continue
+            b1, bi, b2, b1r, bir, b2r = 256, -1, 256, 256, -1, 256
+            for i_f in fd[node]:
+                if match[i_f] >= 0:
+                    continue
+                d = _ham(kf_desc[ikf], f_desc[i_f])
+                if n_left_f == -1 or i_f < n_left_f:
+                    if d < b1:
+                        b2, b1, bi = b1, d, i_f
+                    elif d < b2:
+                        b2 = d
+                else:
+                    if d < b1r:
+                        b2r, b1r, bir = b1r, d, i_f
+                    elif d < b2r:
+                        b2r = d
+            if b1 <= 50:
+                if np.float32(b1) < np.float32(nnratio) * np.float32(b2):
+                    match[bi] = ikf
+                    if check_ori:
+                        vote(ikf, bi)
+                    nm += 1
+                if b1r <= 50:
+                    match[bir] = ikf
+                    if check_ori:
+                        vote(ikf, bir)
+                    nm += 1
+    if check_ori:
+        sizes = [len(r) for r in rot]
+        m1 = m2 = m3 = 0
+        i1 = i2 = i3 = -1
+        for i, s in enumerate(sizes):  # ComputeThreeMaxima :1920-1955
+            if s > m1:
+                m3, m2, m1, i3, i2, i1 = m2, m1, s, i2, i1, i
+            elif s > m2:
+                m3, m2, i3, i2 = m2, s, i2, i
+            elif s > m3:
+                m3, i3 = s, i
+        if m2 < np.float32(0.1) * np.float32(m1):
+            i2 = i3 = -1
+        elif m3 < np.float32(0.1) * np.float32(m1):
+            i3 = -1
+        for i in range(30):
+            if i in (i1, i2, i3):
+                continue
+            for idx in rot[i]:
+                match[idx] = -1
+                nm -= 1
+    return nm, np.array(match, np.int32)
+
+
+def _fv_lists(fv):
+    nodes, start, feats = fv
+    return [(int(nodes[i]), [int(x) for x in feats[start[i]:start[i + 1]]]) for i in range(len(nodes))]
+
+
+def _scene(voc_cols, n_kf, n_f, seed, n_left_f=-1):
+    """A keyframe and a frame observing overlapping words: the frame's descriptors are noisy copies of the keyframe's."""
+    rng = np.random.RandomState(seed)
+    kf_desc = synth.vocabulary_features(voc_cols, n_kf, seed)
+    src = rng.randint(0, n_kf, n_f)
+    bits = np.unpackbits(kf_desc[src], axis=1)
+    for i in range(n_f):
+        bits[i, rng.choice(256, rng.randint(0, 25), replace=False)] ^= 1
+    f_desc = np.packbits(bits, axis=1)
+    fresh = rng.rand(n_f) < 0.25
+    f_desc[fresh] = synth.vocabulary_features(voc_cols, int(fresh.sum()), seed + 1)
+    kf_angle = rng.uniform(0, 360, n_kf).astype(np.float32)
+    f_angle = ((kf_angle[src] + rng.normal(12.0, 4.0, n_f)) % 360).astype(np.float32)
+    wrong = rng.rand(n_f) < 0.15
+    f_angle[wrong] = rng.uniform(0, 360, int(wrong.sum()))
+    kf_valid = (rng.rand(n_kf) < 0.8).astype(np.uint8)
+    return kf_desc, kf_angle, kf_valid, f_desc, f_angle
+
+
+# ---- oracle vs transcription --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,L,levelsup,scoring,weighting", [(5, 3, 1, 0, 0), (4, 4, 4, 0, 0), (6, 3, 2, 1, 1), (5, 3, 1, 5, 0),
+                                                            (5, 3, 1, 0, 2), (3, 5, 4, 2, 3)])
+def test_oracle_transform_matches_python_transcription(oracle, k, L, levelsup, scoring, weighting):
+    cols = synth.make_vocabulary(k, L, seed=k * 10 + L, early_leaf_prob=0.1, stop_prob=0.05)
+    voc = oracle.Vocabulary(k, L, *cols, scoring=scoring, weighting=weighting)
+    py = PyVoc(k, L, cols, scoring, weighting)
+    assert voc.n_words == int(cols[1].sum())
+    feats = synth.vocabulary_features(cols, 160, seed=3)
+    (words, values), fv = voc.transform(feats, levelsup)
+    want_bow, want_fv = py.transform(feats, levelsup)
+    assert [int(w) for w in words] == [w for w, _ in want_bow]
+    assert np.array_equal(values.view(np.uint64), np.array([v for _, v in want_bow], np.float64).view(np.uint64))
+    assert _fv_lists(fv) == want_fv
+    w1, wt1, nd1 = voc.transform_one(feats[:20], levelsup)
+    for i in range(20):
+        assert (int(w1[i]), float(wt1[i]), int(nd1[i])) == py.transform_one(feats[i], levelsup)
+
+
+def test_oracle_vocabulary_text_round_trip(oracle, tmp_path):
+    cols = synth.make_vocabulary(4, 3, seed=9)
+    voc = oracle.Vocabulary(4, 3, *cols)
+    path = str(tmp_path / "voc.txt")
+    voc.save(path)
+    with open(path) as f:
+        assert f.readline().split() == ["4", "3", "0", "0"]  # "k L scoring weighting", as saveToTextFile writes it
+        first = f.readline().split()
+        assert len(first) == 2 + 32 + 1 and first[0] == "0"  # parent, isLeaf, 32 bytes, weight
+    back = oracle.Vocabulary(path=path)
+    assert (back.k, back.L, back.n_nodes, back.n_words) == (voc.k, voc.L, voc.n_nodes, voc.n_words)
+    for a, b in zip(back.export(), cols):
+        assert np.array_equal(a, b)
+    feats = synth.vocabulary_features(cols, 50, seed=1)
+    assert all(np.array_equal(x, y) for x, y in zip(back.transform(feats, 1)[0], voc.transform(feats, 1)[0]))
+
+
+def test_oracle_transform_properties(oracle):
+    cols = synth.make_vocabulary(6, 3, seed=2, early_leaf_prob=0.0, stop_prob=0.0)
+    voc = oracle.Vocabulary(6, 3, *cols)
+    parent, leaf, desc, weight = cols
+    leaves = np.flatnonzero(leaf)
+    # a leaf's own descriptor descends to ... some word at distance 0 from a child at the last level (ties: first child wins)
+    w, wt, nd = voc.transform_one(desc[leaves[:40]], 1)
+    assert (wt > 0).all()
+    # L1 scoring: the values sum to 1; every feature appears once in the feature vector
+    feats = synth.vocabulary_features(cols, 300, seed=5)
+    (words, values), (nodes, start, fidx) = voc.transform(feats, 1)
+    assert abs(values.sum() - 1.0) < 1e-12 and (np.diff(words.astype(np.int64)) > 0).all()
+    assert sorted(fidx.tolist()) == list(range(300)) and (np.diff(nodes.astype(np.int64)) > 0).all()
+    for i in range(len(nodes)):
+        assert (np.diff(fidx[start[i]:start[i + 1]].astype(np.int64)) > 0).all()
+    # levelsup >= L: every feature hangs off the root
+    assert voc.transform(feats, 3)[1][0].tolist() == [0]
+
+
+@pytest.mark.parametrize("seed,n_left", [(1, -1), (2, -1), (3, 140), (4, 90)])
+def test_oracle_search_by_bow_matches_python_transcription(oracle, seed, n_left):
+    cols = synth.make_vocabulary(5, 4, seed=seed)
+    voc = oracle.Vocabulary(5, 4, *cols)
+    kd, ka, kv, fd, fa = _scene(cols, 220, 200, seed, n_left)
+    kf_fv, f_fv = voc.transform(kd, 2)[1], voc.transform(fd, 2)[1]
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        n, m = oracle.search_by_bow(kf_fv, kd, ka, kv, f_fv, fd, fa, n_left, ratio, ori)
+        pn, pm = py_search_by_bow(_fv_lists(kf_fv), kd, ka, kv, _fv_lists(f_fv), fd, fa, n_left, ratio, ori)
+        assert n == pn and np.array_equal(m, pm)
+        assert n == int((m >= 0).sum()) and n > 20
+        assert all(kv[i] for i in m[m >= 0])
+
+
+def _golden_check(g, voc, search, kps=lambda a: a):
+    (fw, fval), ffv = voc.transform(g["f_desc"], 1)
+    kfv = voc.transform(g["kf_desc"], 1)[1]
+    assert np.array_equal(fw, g["f_words"]) and np.array_equal(fval.view(np.uint64), g["f_values"].view(np.uint64))
+    assert np.array_equal(ffv[0], g["f_nodes"]) and np.array_equal(ffv[1], g["f_start"]) and np.array_equal(ffv[2], g["f_feats"])
+    assert np.array_equal(kfv[0], g["kf_nodes"]) and np.array_equal(kfv[1], g["kf_start"]) and np.array_equal(kfv[2], g["kf_feats"])
+    for n_left, tag in ((-1, "mono"), (100, "fisheye")):
+        n, m = search(kfv, g, ffv, n_left)
+        assert n == int(g["n_" + tag]) and np.array_equal(m, g["match_" + tag])
+
+
+def test_oracle_reproduces_bow_golden(oracle):
+    g = np.load(GOLDEN)
+    voc = oracle.Vocabulary(4, 3, g["parent"], g["is_leaf"], g["node_desc"], g["weight"])
+    _golden_check(g, voc, lambda kfv, g, ffv, nl: oracle.search_by_bow(kfv, g["kf_desc"], g["kf_angle"], g["kf_valid"], ffv,
+                                                                        g["f_desc"], g["f_angle"], nl, 0.7, True))
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_bow_golden():
+    import orb_slam3_fast_amd as orbx
+    g = np.load(GOLDEN)
+    voc = orbx.ORBVocabulary(4, 3, g["parent"], g["is_leaf"], g["node_desc"], g["weight"])
+    _golden_check(g, voc, lambda kfv, g, ffv, nl: orbx.SearchByBoW(kfv, _kps(g["kf_angle"]), g["kf_desc"], g["kf_valid"], ffv,
+                                                                    _kps(g["f_angle"]), g["f_desc"], nl, 0.7, True))
+
+
+# ---- HIP vs oracle ---------------------------------------------------------------------------------------------------------------
+def _same_transform(got, want):
+    (gw, gv), (gn, gs, gf) = got
+    (ww, wv), (wn, ws, wf) = want
+    assert np.array_equal(gw, ww) and np.array_equal(gv.view(np.uint64), wv.view(np.uint64))  # doubles bit for bit
+    assert np.array_equal(gn, wn) and np.array_equal(gs, ws) and np.array_equal(gf, wf)
+
+
+def _kps(angle):
+    import orb_slam3_fast_amd as orbx
+    k = np.zeros(len(angle), orbx.KP_DTYPE)
+    k["angle"] = angle
+    return k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L,levelsup,scoring,weighting,n", [(10, 4, 2, 0, 0, 1500), (5, 3, 1, 0, 0, 300), (4, 4, 4, 0, 0, 257),
+                                                              (6, 3, 2, 1, 1, 1000), (5, 3, 1, 5, 0, 64), (5, 3, 1, 0, 2, 500),
+                                                              (3, 5, 4, 2, 3, 33), (10, 3, 1, 0, 0, 5000), (17, 2, 0, 0, 0, 700)])
+def test_hip_bow_transform_matches_oracle(oracle, k, L, levelsup, scoring, weighting, n):
+    import orb_slam3_fast_amd as orbx
+    cols = synth.make_vocabulary(k, L, seed=k + L, early_leaf_prob=0.08, stop_prob=0.04)
+    ovoc = oracle.Vocabulary(k, L, *cols, scoring=scoring, weighting=weighting)
+    voc = orbx.ORBVocabulary(k, L, *cols, scoring=scoring, weighting=weighting)
+    assert (voc.k, voc.L, voc.n_nodes, voc.n_words) == (k, L, len(cols[0]), ovoc.n_words)
+    feats = synth.vocabulary_features(cols, n, seed=n)
+    _same_transform(voc.transform(feats, levelsup), ovoc.transform(feats, levelsup))
+    assert voc.transform(np.zeros((0, 32), np.uint8))[1][1].tolist() == [0]  # no features: empty vectors
+
+
+@pytest.mark.gpu
+def test_hip_vocabulary_text_file_and_errors(oracle, tmp_path):
+    import orb_slam3_fast_amd as orbx
+    cols = synth.make_vocabulary(6, 3, seed=4)
+    ovoc = oracle.Vocabulary(6, 3, *cols)
+    path = str(tmp_path / "ORBvoc_synth.txt")
+    ovoc.save(path)
+    voc = orbx.ORBVocabulary(path=path)
+    assert (voc.k, voc.L, voc.n_nodes, voc.n_words) == (6, 3, ovoc.n_nodes, ovoc.n_words)
+    feats = synth.vocabulary_features(cols, 400, seed=8)
+    _same_transform(voc.transform(feats, 1), ovoc.transform(feats, 1))
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBVocabulary(path=str(tmp_path / "missing.txt"))
+    bad = cols[0].copy()
+    bad[5] = 9  # a parent that does not precede its child
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBVocabulary(6, 3, bad, cols[1], cols[2], cols[3])
+    with pytest.raises(orbx.OrbxError):
+        voc.transform(np.zeros((8193, 32), np.uint8))
+
+
+@pytest.mark.gpu
+def test_hip_bow_batch_on_extracted_frames(oracle):
+    """ComputeBoW for a batch: descriptors straight from the extraction on the device."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    cols = synth.make_vocabulary(10, 3, seed=12)
+    ovoc, voc = oracle.Vocabulary(10, 3, *cols), orbx.ORBVocabulary(10, 3, *cols)
+    w, h = 512, 384
+    imgs = np.stack([synth.mono_frame(w, h, 90 + i) for i in range(3)])
+    buf = DeviceBuffer.from_numpy(imgs)
+    ex = orbx.ORBextractor(700, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=3)
+    ex.extract_batch_device(buf.ptr.value, 3, w, h, w, w * h)
+    voc.transform_batch(ex, 1)
+    for i in range(3):
+        _, k, d = ex.download(i)
+        _same_transform(orbx.ORBVocabulary.download(ex, i), ovoc.transform(d, 1))
+        assert len(d) > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_left", [(1, -1), (2, -1), (3, 140), (4, 90), (5, -1), (6, 700)])
+def test_hip_search_by_bow_matches_oracle(oracle, seed, n_left):
+    import orb_slam3_fast_amd as orbx
+    big = seed >= 5
+    k, L, lu = (10, 4, 2) if big else (5, 4, 2)
+    cols = synth.make_vocabulary(k, L, seed=seed)
+    ovoc, voc = oracle.Vocabulary(k, L, *cols), orbx.ORBVocabulary(k, L, *cols)
+    kd, ka, kv, fd, fa = _scene(cols, 1500 if big else 220, 1400 if big else 200, seed, n_left)
+    kf_fv, f_fv = voc.transform(kd, lu)[1], voc.transform(fd, lu)[1]
+    _same_transform(voc.transform(kd, lu), ovoc.transform(kd, lu))
+    for ratio, ori in ((0.7, True), (0.9, False), (0.6, True)):
+        n, m = orbx.SearchByBoW(kf_fv, _kps(ka), kd, kv, f_fv, _kps(fa), fd, n_left, ratio, ori)
+        on, om = oracle.search_by_bow(kf_fv, kd, ka, kv, f_fv, fd, fa, n_left, ratio, ori)
+        assert n == on and np.array_equal(m, om), (seed, ratio, ori)
+    # a coarse feature vector (levelsup = L: everything under the root) is one node with every feature: long lists
+    kf0, f0 = voc.transform(kd, L)[1], voc.transform(fd, L)[1]
+    n, m = orbx.SearchByBoW(kf0, _kps(ka), kd, kv, f0, _kps(fa), fd, n_left, 0.7, True)
+    on, om = oracle.search_by_bow(kf0, kd, ka, kv, f0, fd, fa, n_left, 0.7, True)
+    assert n == on and np.array_equal(m, om)

@@ -13,7 +13,7 @@ EXE = os.path.join(ROOT, "tests", "cpp", "frame_like")
 def build_exe():
     src = os.path.join(ROOT, "tests", "cpp", "frame_like.cpp")
     libdir = os.path.join(ROOT, "orb_slam3_fast_amd")
-    hdrs = [os.path.join(libdir, "csrc", h) for h in ("ORBextractor.h", "ORBmatcher.h", "Preprocess.h")]
+    hdrs = [os.path.join(libdir, "csrc", h) for h in ("ORBextractor.h", "ORBmatcher.h", "Preprocess.h", "ORBVocabulary.h")]
     if (not os.path.exists(EXE)) or any(os.path.getmtime(p) > os.path.getmtime(EXE) for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-DORBX_NO_OPENCV", src, "-o", EXE, "-L" + libdir,
                                "-lorbx", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
@@ -109,3 +109,29 @@ def test_cpp_mirror_rectify_clahe_matches_oracle(oracle, tmp_path):
     assert np.array_equal(np.fromfile(out + ".eqL", np.uint8).reshape(sh, sw), eqL)
     for name, want in (("a", wl), ("b", wr), ("c", wl), ("d", wr)):
         assert np.array_equal(np.fromfile(out + "." + name, np.uint8).reshape(dh, dw), want), name
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_bow_matches_oracle(oracle, tmp_path):
+    """ORB_SLAM3::ORBVocabulary (loadFromTextFile, transform) and SearchByBoW (csrc/ORBVocabulary.h) against the oracle."""
+    from orb_slam3_fast_amd import synth
+    from test_bow import _scene
+    exe = build_exe()
+    cols = synth.make_vocabulary(8, 3, seed=21)
+    ovoc = oracle.Vocabulary(8, 3, *cols)
+    path = str(tmp_path / "voc.txt")
+    ovoc.save(path)
+    kd, ka, kv, fd, fa = _scene(cols, 600, 550, 21)
+    for name, arr in (("kd", kd), ("ka", ka), ("kv", kv), ("fd", fd), ("fa", fa)):
+        np.ascontiguousarray(arr).tofile(tmp_path / (name + ".raw"))
+    out = str(tmp_path / "b")
+    r = subprocess.run([exe, "bow", path] + [str(tmp_path / (n + ".raw")) for n in ("kd", "ka", "kv", "fd", "fa")] + ["1", "-1", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    (words, values), f_fv = ovoc.transform(fd, 1)
+    kf_fv = ovoc.transform(kd, 1)[1]
+    n, m = oracle.search_by_bow(kf_fv, kd, ka, kv, f_fv, fd, fa, -1, 0.7, True)
+    assert np.array_equal(np.fromfile(out + ".words", np.uint32), words)
+    assert np.array_equal(np.fromfile(out + ".values", np.float64).view(np.uint64), values.view(np.uint64))
+    assert np.array_equal(np.fromfile(out + ".match", np.int32), m)
+    assert ("%d matches" % n) in r.stdout and n > 50

@@ -84,6 +84,19 @@ cases += [
      lambda: m.SearchByProjectionFrameFisheye(kk, dd, nLk, bounds, pts, uvr, occf),
      lambda: O.search_by_projection_frame_fisheye(kk, dd, nLk, bounds, opts, uvr, True, occf)),
 ]
+# bag of words: a full 10^6-word tree (the size of ORBvoc.txt), ComputeBoW of the current frame, SearchByBoW keyframe -> frame
+vcols = synth.make_vocabulary_bfs(10, 6, seed=1)
+voc, ovoc = orbx.ORBVocabulary(10, 6, *vcols), O.Vocabulary(10, 6, *vcols)
+kf_fv, f_fv = voc.transform(dp, 4)[1], voc.transform(dc, 4)[1]
+kvalid = (rng.random(n) < 0.8).astype(np.uint8)
+mb = orbx.ORBmatcher(0.7, True)
+cases += [
+    ("Frame::ComputeBoW (transform, 10^6 words, levelsup 4)  %d descriptors" % len(dc),
+     lambda: voc.transform(dc, 4), lambda: ovoc.transform(dc, 4)),
+    ("SearchByBoW(KeyFrame, Frame)      %d x %d kps, %d / %d nodes" % (n, len(kc), len(kf_fv[0]), len(f_fv[0])),
+     lambda: orbx.SearchByBoW(kf_fv, kp, dp, kvalid, f_fv, kc, dc, -1, 0.7, True),
+     lambda: O.search_by_bow(kf_fv, dp, kp["angle"], kvalid, f_fv, dc, kc["angle"], -1, 0.7, True)),
+]
 print("%-62s %12s %12s %8s" % ("entry point (host API, one call)", "MI355X ms", "oracle ms", "ratio"))
 for name, fg, fo in cases:
     for _ in range(3):
@@ -98,3 +111,20 @@ for name, fg, fo in cases:
         fo()
     to = (time.perf_counter() - t0) / ro * 1e3
     print("%-62s %12.3f %12.3f %8.1f" % (name, tg, to, to / tg))
+
+# batched ComputeBoW on device-resident extraction results (64 images, one launch pair)
+from orb_slam3_fast_amd.hipmem import DeviceBuffer
+B = 64
+imgs = DeviceBuffer.from_numpy(np.stack([L1, R1] * (B // 2)))
+exb = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=B)
+exb.extract_batch_device(imgs.ptr.value, B, w, h, w, w * h)
+exb.sync()
+for _ in range(3):
+    voc.transform_batch(exb, 4)
+    exb.sync()
+t0 = time.perf_counter()
+for _ in range(reps):
+    voc.transform_batch(exb, 4)
+    exb.sync()
+tb = (time.perf_counter() - t0) / reps * 1e3
+print("%-62s %12.3f   (%.1f us per image, results stay in HBM)" % ("ComputeBoW, batch of %d extracted images" % B, tb, tb * 1e3 / B))

@@ -153,6 +153,28 @@ def rectify_clahe_case(name):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def bow_case(name):
+    """A small vocabulary tree (k = 4, L = 3, with early leaves and stopped words), ComputeBoW of a keyframe and a frame,
+    SearchByBoW between them (mono and Nleft != -1)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_bow import _scene
+    from orb_slam3_fast_amd import synth
+    cols = synth.make_vocabulary(4, 3, seed=31, early_leaf_prob=0.1, stop_prob=0.05)
+    voc = O.Vocabulary(4, 3, *cols)
+    kd, ka, kv, fd, fa = _scene(cols, 180, 160, 31)
+    (kw, kval), kfv = voc.transform(kd, 1)
+    (fw, fval), ffv = voc.transform(fd, 1)
+    n0, m0 = O.search_by_bow(kfv, kd, ka, kv, ffv, fd, fa, -1, 0.7, True)
+    n1, m1 = O.search_by_bow(kfv, kd, ka, kv, ffv, fd, fa, 100, 0.7, True)
+    out = {"parent": cols[0], "is_leaf": cols[1], "node_desc": cols[2], "weight": cols[3], "kf_desc": kd, "kf_angle": ka,
+           "kf_valid": kv, "f_desc": fd, "f_angle": fa, "f_words": fw, "f_values": fval, "f_nodes": ffv[0], "f_start": ffv[1],
+           "f_feats": ffv[2], "kf_nodes": kfv[0], "kf_start": kfv[1], "kf_feats": kfv[2], "n_mono": np.array(n0), "match_mono": m0,
+           "n_fisheye": np.array(n1), "match_fisheye": m1}
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, len(fw), len(ffv[0]), n0, n1)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_case("extract_160x120_L3.npz", 160, 120, 300, 3, 101, (0, 0))
@@ -164,3 +186,4 @@ if __name__ == "__main__":
     undistort_case("undistort.npz")
     projection_fisheye_case("fisheye_projection.npz", 7)
     rectify_clahe_case("rectify_clahe.npz")
+    bow_case("bow.npz")
