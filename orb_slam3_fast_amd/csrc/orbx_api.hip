@@ -121,6 +121,67 @@ struct ScratchBuf {  // same face as DevBuf; the caller has made its device curr
   }
 };
 
+// One-shot entry points move a dozen small arrays per call; a synchronous hipMemcpy from pageable memory costs ~10 us
+// each, more than the kernels.  Pack lays the inputs (and the scratch / output areas) of a call out in ONE device block,
+// stages the inputs through a per-thread pinned buffer and uploads them with one asynchronous copy on the null stream,
+// in front of the kernels; outputs come back the same way (one copy of a contiguous output area, then memcpy out).
+class Pack {
+ public:
+  // reserves `bytes` (256-byte aligned); src != nullptr: filled from the host.  All inputs must be added before any
+  // scratch / output area so that one prefix copy covers them.
+  size_t add(const void* src, size_t bytes) {
+    const size_t off = (total_ + 255) & ~(size_t)255;
+    items_.push_back({src, bytes, off});
+    total_ = off + bytes;
+    if (src && bytes) inputEnd_ = total_;
+    return off;
+  }
+  hipError_t commit() {
+    hipError_t e = dev_.alloc(std::max<size_t>(total_, 256));
+    if (e != hipSuccess) return e;
+    if (inputEnd_) {
+      uint8_t* h = pinned(inputEnd_);
+      if (!h) return hipErrorOutOfMemory;
+      for (const Item& it : items_)
+        if (it.src && it.bytes) std::memcpy(h + it.off, it.src, it.bytes);
+      e = hipMemcpyAsync(dev_.p, h, inputEnd_, hipMemcpyHostToDevice, nullptr);
+    }
+    return e;
+  }
+  template <class T>
+  T* ptr(size_t off) const { return reinterpret_cast<T*>(dev_.p + off); }
+  // device [off, off + bytes) -> pinned staging; synchronises the null stream.  The returned pointer is valid until the
+  // thread's next Pack operation.
+  const uint8_t* fetch(size_t off, size_t bytes, hipError_t* e) {
+    uint8_t* h = pinned(std::max<size_t>(bytes, 1));
+    if (!h) { *e = hipErrorOutOfMemory; return nullptr; }
+    *e = hipMemcpyAsync(h, dev_.p + off, bytes, hipMemcpyDeviceToHost, nullptr);
+    if (*e == hipSuccess) *e = hipStreamSynchronize(nullptr);
+    return h;
+  }
+  void release() { dev_.free(); }
+
+ private:
+  struct Item { const void* src; size_t bytes, off; };
+  static uint8_t* pinned(size_t bytes) {
+    thread_local uint8_t* buf = nullptr;
+    thread_local size_t cap = 0;
+    if (bytes > cap) {
+      if (buf) (void)hipHostFree(buf);
+      buf = nullptr;
+      cap = 0;
+      size_t want = 1 << 20;
+      while (want < bytes) want <<= 1;
+      if (hipHostMalloc(reinterpret_cast<void**>(&buf), want, hipHostMallocDefault) != hipSuccess) return nullptr;
+      cap = want;
+    }
+    return buf;
+  }
+  std::vector<Item> items_;
+  size_t total_ = 0, inputEnd_ = 0;
+  ScratchBuf<uint8_t> dev_;
+};
+
 }  // namespace
 
 // Layout of orbx_extractor::hostResults for the host entry points (one or two images):
@@ -996,23 +1057,24 @@ int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT,
   if (nQ == 0) return ORBX_OK;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  ScratchBuf<uint8_t> q, t, ok;
-  ScratchBuf<int> i2, d2;
-  hipError_t e = hipSuccess;
-  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  chk(q.alloc((size_t)nQ * 32));
-  chk(t.alloc((size_t)std::max(nT, 1) * 32));
-  chk(ok.alloc(nQ));
-  chk(i2.alloc((size_t)nQ * 2));
-  chk(d2.alloc((size_t)nQ * 2));
-  if (e == hipSuccess) chk(hipMemcpy(q.p, descQ, (size_t)nQ * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess && nT) chk(hipMemcpy(t.p, descT, (size_t)nT * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(launch_bf_knn2(q.p, nQ, t.p, nT, i2.p, d2.p, ok.p, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess) chk(hipMemcpy(idx2, i2.p, (size_t)nQ * 2 * sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(dist2, d2.p, (size_t)nQ * 2 * sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(ratio_ok, ok.p, nQ, hipMemcpyDeviceToHost));
-  q.free(); t.free(); ok.free(); i2.free(); d2.free();
+  Pack pk;
+  const size_t Q = (size_t)nQ;
+  const size_t oQ = pk.add(descQ, Q * 32), oT = pk.add(descT, (size_t)std::max(nT, 1) * 32);
+  const size_t oOut = pk.add(nullptr, Q * 2 * 4 * 2 + Q);  // idx2 | dist2 | ratio_ok: one copy back
+  hipError_t e = pk.commit();
+  int* i2 = pk.ptr<int>(oOut);
+  int* d2 = i2 + Q * 2;
+  uint8_t* ok = reinterpret_cast<uint8_t*>(d2 + Q * 2);
+  if (e == hipSuccess) e = launch_bf_knn2(pk.ptr<uint8_t>(oQ), nQ, pk.ptr<uint8_t>(oT), nT, i2, d2, ok, nullptr);
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, Q * 17, &e);
+    if (e == hipSuccess) {
+      std::memcpy(idx2, h, Q * 8);
+      std::memcpy(dist2, h + Q * 8, Q * 8);
+      std::memcpy(ratio_ok, h + Q * 16, Q);
+    }
+  }
+  pk.release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return ORBX_OK;
 }
@@ -1111,47 +1173,43 @@ int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const u
   }
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  ScratchBuf<orbx_keypoint> kl, kr;
-  ScratchBuf<uint8_t> dq, dt, ok;
-  ScratchBuf<int> i2, d2, l2r, r2l, cnt;
-  ScratchBuf<float> dep, pts, sg;
-  hipError_t e = hipSuccess;
+  // one packed upload (the -1 / 0 fills of the outputs travel with it); the outputs are contiguous: one copy back
+  std::vector<float> zeros((size_t)n_left * 3 + 2, 0.0f);  // points3d fill + the two counters
+  Pack pk;
+  const size_t NL = (size_t)n_left, NR = (size_t)n_right;
+  const size_t oKl = pk.add(kps_left, NL * sizeof(orbx_keypoint)), oKr = pk.add(kps_right, NR * sizeof(orbx_keypoint));
+  const size_t oDq = pk.add(desc_left + (size_t)mono_left * 32, (size_t)nQ * 32);
+  const size_t oDt = pk.add(desc_right + (size_t)mono_right * 32, (size_t)nT * 32);
+  const size_t oSg = pk.add(level_sigma2, (size_t)n_levels * sizeof(float));
+  const size_t oL2r = pk.add(left_to_right, NL * 4), oR2l = pk.add(right_to_left, NR * 4), oDep = pk.add(depth, NL * 4);
+  const size_t oPts = pk.add(zeros.data(), NL * 12), oCnt = pk.add(zeros.data(), 8);
+  const size_t outBytes = oCnt + 8 - oL2r;
+  const size_t oOk = pk.add(nullptr, nQ), oI2 = pk.add(nullptr, (size_t)nQ * 8), oD2 = pk.add(nullptr, (size_t)nQ * 8);
+  hipError_t e = pk.commit();
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  chk(kl.alloc(n_left)); chk(kr.alloc(n_right)); chk(dq.alloc((size_t)nQ * 32)); chk(dt.alloc((size_t)nT * 32));
-  chk(ok.alloc(nQ)); chk(i2.alloc((size_t)nQ * 2)); chk(d2.alloc((size_t)nQ * 2)); chk(l2r.alloc(n_left));
-  chk(r2l.alloc(n_right)); chk(cnt.alloc(2)); chk(dep.alloc(n_left)); chk(pts.alloc((size_t)n_left * 3));
-  chk(sg.alloc(n_levels));
-  if (e == hipSuccess) {
-    chk(hipMemcpy(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-    chk(hipMemcpy(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-    chk(hipMemcpy(dq.p, desc_left + (size_t)mono_left * 32, (size_t)nQ * 32, hipMemcpyHostToDevice));
-    chk(hipMemcpy(dt.p, desc_right + (size_t)mono_right * 32, (size_t)nT * 32, hipMemcpyHostToDevice));
-    chk(hipMemcpy(sg.p, level_sigma2, (size_t)n_levels * sizeof(float), hipMemcpyHostToDevice));
-    chk(hipMemcpy(l2r.p, left_to_right, (size_t)n_left * sizeof(int), hipMemcpyHostToDevice));   // the -1 / 0 fills
-    chk(hipMemcpy(r2l.p, right_to_left, (size_t)n_right * sizeof(int), hipMemcpyHostToDevice));
-    chk(hipMemcpy(dep.p, depth, (size_t)n_left * sizeof(float), hipMemcpyHostToDevice));
-    chk(hipMemset(pts.p, 0, (size_t)n_left * 3 * sizeof(float)));
-    chk(hipMemset(cnt.p, 0, 2 * sizeof(int)));
-  }
-  if (e == hipSuccess) chk(launch_bf_knn2(dq.p, nQ, dt.p, nT, i2.p, d2.p, ok.p, nullptr));
+  if (e == hipSuccess)
+    chk(launch_bf_knn2(pk.ptr<uint8_t>(oDq), nQ, pk.ptr<uint8_t>(oDt), nT, pk.ptr<int>(oI2), pk.ptr<int>(oD2), pk.ptr<uint8_t>(oOk), nullptr));
   if (e == hipSuccess) {
     FisheyeArgs a;
-    a.kL = kl.p; a.kR = kr.p; a.nL = n_left; a.nR = n_right; a.monoL = mono_left; a.monoR = mono_right;
-    a.idx2 = i2.p; a.ratioOk = ok.p; a.rig = *rig; a.sigma2 = sg.p; a.nLevels = n_levels;
-    a.leftToRight = l2r.p; a.rightToLeft = r2l.p; a.depth = dep.p; a.p3D = pts.p; a.counters = cnt.p;
+    a.kL = pk.ptr<orbx_keypoint>(oKl); a.kR = pk.ptr<orbx_keypoint>(oKr); a.nL = n_left; a.nR = n_right; a.monoL = mono_left;
+    a.monoR = mono_right;
+    a.idx2 = pk.ptr<int>(oI2); a.ratioOk = pk.ptr<uint8_t>(oOk); a.rig = *rig; a.sigma2 = pk.ptr<float>(oSg); a.nLevels = n_levels;
+    a.leftToRight = pk.ptr<int>(oL2r); a.rightToLeft = pk.ptr<int>(oR2l); a.depth = pk.ptr<float>(oDep);
+    a.p3D = pk.ptr<float>(oPts); a.counters = pk.ptr<int>(oCnt);
     chk(launch_fisheye_triangulate(a, nullptr));
   }
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
   int counts[2] = {0, 0};
   if (e == hipSuccess) {
-    chk(hipMemcpy(left_to_right, l2r.p, (size_t)n_left * sizeof(int), hipMemcpyDeviceToHost));
-    chk(hipMemcpy(right_to_left, r2l.p, (size_t)n_right * sizeof(int), hipMemcpyDeviceToHost));
-    chk(hipMemcpy(depth, dep.p, (size_t)n_left * sizeof(float), hipMemcpyDeviceToHost));
-    chk(hipMemcpy(points3d, pts.p, (size_t)n_left * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    chk(hipMemcpy(counts, cnt.p, sizeof(counts), hipMemcpyDeviceToHost));
+    const uint8_t* h = pk.fetch(oL2r, outBytes, &e);
+    if (e == hipSuccess) {
+      std::memcpy(left_to_right, h, NL * 4);
+      std::memcpy(right_to_left, h + (oR2l - oL2r), NR * 4);
+      std::memcpy(depth, h + (oDep - oL2r), NL * 4);
+      std::memcpy(points3d, h + (oPts - oL2r), NL * 12);
+      std::memcpy(counts, h + (oCnt - oL2r), sizeof(counts));
+    }
   }
-  kl.free(); kr.free(); dq.free(); dt.free(); ok.free(); i2.free(); d2.free(); l2r.free(); r2l.free(); cnt.free();
-  dep.free(); pts.free(); sg.free();
+  pk.release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   if (n_desc_matches) *n_desc_matches = counts[1];
   return counts[0];
@@ -1648,29 +1706,37 @@ int orbx_bow_transform(const orbx_vocabulary* voc, const uint8_t* desc, int n, i
   *n_words = *n_nodes = 0;
   node_start[0] = 0;
   if (n == 0) return 0;
-  ScratchBuf<uint8_t> d;
-  ScratchBuf<int> word, node, start, counts;
-  ScratchBuf<double> wt, values;
-  ScratchBuf<uint32_t> words, nodes, feats;
-  hipError_t e = hipSuccess;
-  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  chk(d.alloc((size_t)n * 32)); chk(word.alloc(n)); chk(node.alloc(n)); chk(start.alloc((size_t)n + 1)); chk(counts.alloc(3));
-  chk(wt.alloc(n)); chk(values.alloc(n)); chk(words.alloc(n)); chk(nodes.alloc(n)); chk(feats.alloc(n));
-  if (e == hipSuccess) chk(hipMemcpy(d.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  Pack pk;
+  const size_t N = (size_t)n;
+  const size_t oD = pk.add(desc, N * 32);
+  const size_t oWord = pk.add(nullptr, N * 4), oNode = pk.add(nullptr, N * 4), oWt = pk.add(nullptr, N * 8);
+  // outputs in one area: values | words | nodes | feats | nodeStart | counts  -> one copy back
+  const size_t oOut = pk.add(nullptr, N * 8 + 3 * N * 4 + (N + 1) * 4 + 3 * 4);
+  const size_t rValues = 0, rWords = N * 8, rNodes = rWords + N * 4, rFeats = rNodes + N * 4, rStart = rFeats + N * 4,
+               rCounts = rStart + (N + 1) * 4, outBytes = rCounts + 12;
+  hipError_t e = pk.commit();
   BowArgs a{};
   a.voc = voc->view();
-  a.desc = d.p; a.descImgPitch = 0; a.counts = nullptr; a.n = n; a.cap = n; a.levelsup = levelsup;
-  a.word = word.p; a.weight = wt.p; a.node = node.p;
-  a.words = words.p; a.values = values.p; a.nodes = nodes.p; a.nodeStart = start.p; a.feats = feats.p; a.outCounts = counts.p;
-  if (e == hipSuccess) chk(launch_bow_transform(a, 1, nullptr));
+  a.desc = pk.ptr<uint8_t>(oD); a.descImgPitch = 0; a.counts = nullptr; a.n = n; a.cap = n; a.levelsup = levelsup;
+  a.word = pk.ptr<int>(oWord); a.weight = pk.ptr<double>(oWt); a.node = pk.ptr<int>(oNode);
+  uint8_t* out = pk.ptr<uint8_t>(oOut);
+  a.values = reinterpret_cast<double*>(out + rValues); a.words = reinterpret_cast<uint32_t*>(out + rWords);
+  a.nodes = reinterpret_cast<uint32_t*>(out + rNodes); a.feats = reinterpret_cast<uint32_t*>(out + rFeats);
+  a.nodeStart = reinterpret_cast<int*>(out + rStart); a.outCounts = reinterpret_cast<int*>(out + rCounts);
+  if (e == hipSuccess) e = launch_bow_transform(a, 1, nullptr);
   int cnt[3] = {0, 0, 0};
-  if (e == hipSuccess) chk(hipMemcpy(cnt, counts.p, sizeof(cnt), hipMemcpyDeviceToHost));
-  if (e == hipSuccess && cnt[0] && word_ids) chk(hipMemcpy(word_ids, words.p, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
-  if (e == hipSuccess && cnt[0] && word_values) chk(hipMemcpy(word_values, values.p, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
-  if (e == hipSuccess && cnt[1] && node_ids) chk(hipMemcpy(node_ids, nodes.p, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(node_start, start.p, (size_t)(cnt[1] + 1) * 4, hipMemcpyDeviceToHost));
-  if (e == hipSuccess && cnt[2] && feature_idx) chk(hipMemcpy(feature_idx, feats.p, (size_t)cnt[2] * 4, hipMemcpyDeviceToHost));
-  d.free(); word.free(); node.free(); start.free(); counts.free(); wt.free(); values.free(); words.free(); nodes.free(); feats.free();
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, outBytes, &e);
+    if (e == hipSuccess) {
+      std::memcpy(cnt, h + rCounts, sizeof(cnt));
+      if (cnt[0] && word_ids) std::memcpy(word_ids, h + rWords, (size_t)cnt[0] * 4);
+      if (cnt[0] && word_values) std::memcpy(word_values, h + rValues, (size_t)cnt[0] * 8);
+      if (cnt[1] && node_ids) std::memcpy(node_ids, h + rNodes, (size_t)cnt[1] * 4);
+      std::memcpy(node_start, h + rStart, (size_t)(cnt[1] + 1) * 4);
+      if (cnt[2] && feature_idx) std::memcpy(feature_idx, h + rFeats, (size_t)cnt[2] * 4);
+    }
+  }
+  pk.release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   *n_words = cnt[0];
   *n_nodes = cnt[1];
@@ -1760,34 +1826,33 @@ int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* k
   if (rc != ORBX_OK) return rc;
   for (int i = 0; i < n_f; i++) matches[i] = -1;
   if (n_kf_nodes == 0 || n_f_nodes == 0 || n_f == 0) return 0;
-  ScratchBuf<uint32_t> kn, kfi, fn, ffi;
-  ScratchBuf<int> ks, fs, mt, bin, flags, res;
-  ScratchBuf<uint8_t> kd, fd, kv;
-  ScratchBuf<orbx_keypoint> kk, fk;
-  hipError_t e = hipSuccess;
-  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  chk(kn.alloc(n_kf_nodes)); chk(ks.alloc((size_t)n_kf_nodes + 1)); chk(kfi.alloc(std::max(nkl, 1))); chk(kd.alloc((size_t)n_kf * 32));
-  chk(kv.alloc(n_kf)); chk(kk.alloc(n_kf)); chk(fn.alloc(n_f_nodes)); chk(fs.alloc((size_t)n_f_nodes + 1));
-  chk(ffi.alloc(std::max(nfl, 1))); chk(fd.alloc((size_t)n_f * 32)); chk(fk.alloc(n_f)); chk(mt.alloc(n_f)); chk(bin.alloc(n_f));
-  chk(flags.alloc(33)); chk(res.alloc(1));
-  auto up = [&](void* dst, const void* src, size_t bytes) { if (e == hipSuccess && bytes) chk(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); };
-  up(kn.p, kf_node_ids, (size_t)n_kf_nodes * 4); up(ks.p, kf_node_start, ((size_t)n_kf_nodes + 1) * 4); up(kfi.p, kf_feature_idx, (size_t)nkl * 4);
-  up(kd.p, kf_desc, (size_t)n_kf * 32); up(kv.p, kf_valid, n_kf); up(kk.p, kf_kps, (size_t)n_kf * sizeof(orbx_keypoint));
-  up(fn.p, f_node_ids, (size_t)n_f_nodes * 4); up(fs.p, f_node_start, ((size_t)n_f_nodes + 1) * 4); up(ffi.p, f_feature_idx, (size_t)nfl * 4);
-  up(fd.p, f_desc, (size_t)n_f * 32); up(fk.p, f_kps, (size_t)n_f * sizeof(orbx_keypoint));
+  Pack pk;
+  const size_t oKn = pk.add(kf_node_ids, (size_t)n_kf_nodes * 4), oKs = pk.add(kf_node_start, ((size_t)n_kf_nodes + 1) * 4);
+  const size_t oKf = pk.add(kf_feature_idx, (size_t)nkl * 4), oKd = pk.add(kf_desc, (size_t)n_kf * 32);
+  const size_t oKv = pk.add(kf_valid, n_kf), oKk = pk.add(kf_kps, (size_t)n_kf * sizeof(orbx_keypoint));
+  const size_t oFn = pk.add(f_node_ids, (size_t)n_f_nodes * 4), oFs = pk.add(f_node_start, ((size_t)n_f_nodes + 1) * 4);
+  const size_t oFf = pk.add(f_feature_idx, (size_t)nfl * 4), oFd = pk.add(f_desc, (size_t)n_f * 32);
+  const size_t oFk = pk.add(f_kps, (size_t)n_f * sizeof(orbx_keypoint));
+  const size_t oBin = pk.add(nullptr, (size_t)n_f * 4), oFlags = pk.add(nullptr, 33 * 4);
+  const size_t oOut = pk.add(nullptr, ((size_t)n_f + 1) * 4);  // result, then the matches: one copy back
+  hipError_t e = pk.commit();
   BowMatchArgs a{};
-  a.kfNodes = kn.p; a.kfStart = ks.p; a.kfFeat = kfi.p; a.nKfNodes = n_kf_nodes;
-  a.kfDesc = reinterpret_cast<const uint32_t*>(kd.p); a.kfKps = kk.p; a.kfValid = kv.p;
-  a.fNodes = fn.p; a.fStart = fs.p; a.fFeat = ffi.p; a.nFNodes = n_f_nodes;
-  a.fDesc = reinterpret_cast<const uint32_t*>(fd.p); a.fKps = fk.p; a.nF = n_f; a.nLeftF = n_left_f;
+  a.kfNodes = pk.ptr<uint32_t>(oKn); a.kfStart = pk.ptr<int>(oKs); a.kfFeat = pk.ptr<uint32_t>(oKf); a.nKfNodes = n_kf_nodes;
+  a.kfDesc = pk.ptr<uint32_t>(oKd); a.kfKps = pk.ptr<orbx_keypoint>(oKk); a.kfValid = pk.ptr<uint8_t>(oKv);
+  a.fNodes = pk.ptr<uint32_t>(oFn); a.fStart = pk.ptr<int>(oFs); a.fFeat = pk.ptr<uint32_t>(oFf); a.nFNodes = n_f_nodes;
+  a.fDesc = pk.ptr<uint32_t>(oFd); a.fKps = pk.ptr<orbx_keypoint>(oFk); a.nF = n_f; a.nLeftF = n_left_f;
   a.nnratio = nnratio; a.checkOri = check_orientation ? 1 : 0;
-  a.match = mt.p; a.bin = bin.p; a.flags = flags.p; a.result = res.p;
-  if (e == hipSuccess) chk(launch_bow_match(a, nullptr));
+  a.result = pk.ptr<int>(oOut); a.match = pk.ptr<int>(oOut) + 1; a.bin = pk.ptr<int>(oBin); a.flags = pk.ptr<int>(oFlags);
+  if (e == hipSuccess) e = launch_bow_match(a, nullptr);
   int n = 0;
-  if (e == hipSuccess) chk(hipMemcpy(&n, res.p, sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(matches, mt.p, (size_t)n_f * sizeof(int), hipMemcpyDeviceToHost));
-  kn.free(); kfi.free(); fn.free(); ffi.free(); ks.free(); fs.free(); mt.free(); bin.free(); flags.free(); res.free(); kd.free();
-  fd.free(); kv.free(); kk.free(); fk.free();
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, ((size_t)n_f + 1) * 4, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&n, h, 4);
+      std::memcpy(matches, h + 4, (size_t)n_f * 4);
+    }
+  }
+  pk.release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   if (n < 0) return fail(ORBX_E_UNSUPPORTED, "a vocabulary node holds more than 4096 frame features");
   return n;
@@ -1874,21 +1939,23 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   if (n1 == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  ScratchBuf<orbx_keypoint> k1, k2;
-  ScratchBuf<uint8_t> d1, d2;
-  ScratchBuf<float> prev;
-  ScratchBuf<int> m12, cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, result;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  chk(k1.alloc(n1)); chk(k2.alloc(std::max(n2, 1))); chk(d1.alloc((size_t)n1 * 32));
-  chk(d2.alloc((size_t)std::max(n2, 1) * 32)); chk(prev.alloc((size_t)n1 * 2)); chk(m12.alloc(n1));
+  // one packed upload; vbPrevMatched | result | vnMatches12 are contiguous and come back in one copy
+  Pack pk;
+  const size_t oK1 = pk.add(kps1, (size_t)n1 * sizeof(orbx_keypoint)), oK2 = pk.add(kps2, (size_t)std::max(n2, 1) * sizeof(orbx_keypoint));
+  const size_t oD1 = pk.add(desc1, (size_t)n1 * 32), oD2 = pk.add(desc2, (size_t)std::max(n2, 1) * 32);
+  const size_t oPrev = pk.add(prev_matched, (size_t)n1 * 2 * sizeof(float)), oRes = pk.add(nullptr, 2 * sizeof(int));
+  const size_t oM12 = pk.add(nullptr, (size_t)n1 * sizeof(int));
+  const size_t outBytes = oM12 + (size_t)n1 * sizeof(int) - oPrev;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k1{pk.ptr<orbx_keypoint>(oK1)}, k2{pk.ptr<orbx_keypoint>(oK2)};
+  struct { uint8_t* p; } d1{pk.ptr<uint8_t>(oD1)}, d2{pk.ptr<uint8_t>(oD2)};
+  struct { float* p; } prev{pk.ptr<float>(oPrev)};
+  struct { int* p; } m12{pk.ptr<int>(oM12)}, result{pk.ptr<int>(oRes)};
   chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(std::max(n2, 1))); chk(candOff.alloc(n1 + 1));
-  chk(mdist.alloc(std::max(n2, 1))); chk(m21.alloc(std::max(n2, 1))); chk(result.alloc(2));
-  if (e == hipSuccess) chk(hipMemcpy(k1.p, kps1, (size_t)n1 * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-  if (e == hipSuccess && n2) chk(hipMemcpy(k2.p, kps2, (size_t)n2 * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(d1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess && n2) chk(hipMemcpy(d2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(prev.p, prev_matched, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice));
+  chk(mdist.alloc(std::max(n2, 1))); chk(m21.alloc(std::max(n2, 1)));
   InitArgs a{};
   a.k1 = k1.p; a.k2 = k2.p; a.d1 = d1.p; a.d2 = d2.p; a.n1 = n1; a.n2 = n2;
   a.minX = min_x; a.minY = min_y;
@@ -1932,13 +1999,17 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
     }
   }
   if (e == hipSuccess) chk(done ? launch_search_init_finish(a, lastRound, nullptr) : launch_search_init_resolve_serial(a, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oPrev, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(prev_matched, h, (size_t)n1 * 2 * sizeof(float));
+      std::memcpy(res, h + (oRes - oPrev), sizeof(res));
+      std::memcpy(matches12, h + (oM12 - oPrev), (size_t)n1 * sizeof(int));
+    }
+  }
   cl0.free(); cl1.free(); cr0.free(); cr1.free(); nc0.free(); nc1.free(); fl.free();
-  if (e == hipSuccess) chk(hipMemcpy(matches12, m12.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(prev_matched, prev.p, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost));
-  k1.free(); k2.free(); d1.free(); d2.free(); prev.free(); m12.free(); cellStart.free(); cellItems.free();
-  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); result.free();
+  pk.release(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
 }
@@ -2004,29 +2075,29 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   if (n == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  ScratchBuf<orbx_keypoint> k;
-  ScratchBuf<uint8_t> d, occ;
-  ScratchBuf<float> ur, sf;
-  ScratchBuf<orbx_map_point_view> mp;
-  ScratchBuf<orbx_projected_point> pp;
-  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mt, mdist, m21, m12, result, taker0, taker1, choice, flags;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, choice, flags;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
-  chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(ur.alloc(n)); chk(sf.alloc(std::max(nlevels, 1)));
+  // inputs in one packed upload; occupied | result | match are contiguous so that they come back in one copy
+  Pack pk;
+  const size_t oK = pk.add(kps_un, (size_t)n * sizeof(orbx_keypoint)), oD = pk.add(desc, (size_t)n * 32);
+  const size_t oUr = pk.add(u_right, (size_t)n * sizeof(float));
+  const size_t oSf = pk.add(scale_factors, (size_t)std::max(nlevels, 1) * sizeof(float));
+  const size_t oMp = pk.add(mode == 0 && n_points ? map_points : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
+  const size_t oPp = pk.add(mode == 1 && n_points ? points : nullptr, (size_t)nm * sizeof(orbx_projected_point));
+  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
+  struct { uint8_t* p; } d{pk.ptr<uint8_t>(oD)}, occ{pk.ptr<uint8_t>(oOcc)};
+  struct { float* p; } ur{pk.ptr<float>(oUr)}, sf{pk.ptr<float>(oSf)};
+  struct { orbx_map_point_view* p; } mp{pk.ptr<orbx_map_point_view>(oMp)};
+  struct { orbx_projected_point* p; } pp{pk.ptr<orbx_projected_point>(oPp)};
+  struct { int* p; } mt{pk.ptr<int>(oMt)}, result{pk.ptr<int>(oRes)};
   chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40));
-  chk(mp.alloc(nm)); chk(pp.alloc(nm)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
-  chk(candOff.alloc(nm + 1)); chk(mt.alloc(n)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
-  chk(result.alloc(2));
-  if (e == hipSuccess) chk(hipMemcpy(k.p, kps_un, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(d.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(occ.p, occupied, n, hipMemcpyHostToDevice));
-  if (e == hipSuccess && u_right) chk(hipMemcpy(ur.p, u_right, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-  if (e == hipSuccess && scale_factors) chk(hipMemcpy(sf.p, scale_factors, nlevels * sizeof(float), hipMemcpyHostToDevice));
-  if (e == hipSuccess && n_points && mode == 0)
-    chk(hipMemcpy(mp.p, map_points, (size_t)n_points * sizeof(orbx_map_point_view), hipMemcpyHostToDevice));
-  if (e == hipSuccess && n_points && mode == 1)
-    chk(hipMemcpy(pp.p, points, (size_t)n_points * sizeof(orbx_projected_point), hipMemcpyHostToDevice));
+  chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
+  chk(candOff.alloc(nm + 1)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
   ProjArgs a{};
   a.grid.k2 = k.p; a.grid.n2 = n; a.grid.n1 = 0;
   a.grid.minX = min_x; a.grid.minY = min_y;
@@ -2062,12 +2133,16 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
     }
   }
   if (e == hipSuccess) chk(done ? launch_proj_finish(a, 0, nullptr) : launch_proj_resolve_serial(a, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess) chk(hipMemcpy(res, result.p, sizeof(res), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
-  k.free(); d.free(); occ.free(); ur.free(); sf.free(); mp.free(); pp.free(); cellStart.free(); cellItems.free();
-  candOff.free(); candIdx.free(); candDist.free(); mt.free(); mdist.free(); m21.free(); m12.free(); result.free();
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(occupied, h, n);
+      std::memcpy(res, h + (oRes - oOcc), sizeof(res));
+      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+    }
+  }
+  pk.release(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); m12.free();
   taker0.free(); taker1.free(); choice.free(); flags.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
@@ -2106,12 +2181,12 @@ namespace {
 // One side (left or right camera) of a stereo-fisheye projection search: grid + candidate lists on the device.
 struct ProjSide {
   ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, result;
-  ScratchBuf<orbx_map_point_view> mp;
-  ScratchBuf<orbx_projected_point> pp;
+  orbx_map_point_view* mpp = nullptr;  // views of this camera inside the call's packed upload
+  orbx_projected_point* ppp = nullptr;
   ProjArgs a{};
   void release() {
     cellStart.free(); cellItems.free(); candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
-    m12.free(); result.free(); mp.free(); pp.free();
+    m12.free(); result.free();
   }
 };
 
@@ -2125,32 +2200,35 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
   if (n == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
-  ScratchBuf<orbx_keypoint> k;
-  ScratchBuf<uint8_t> d, occ;
-  ScratchBuf<float> sf;
-  ScratchBuf<int> a12, a21, mt, res;
   ProjSide S[2];
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
-  chk(k.alloc(n)); chk(d.alloc((size_t)n * 32)); chk(occ.alloc(n)); chk(sf.alloc(std::max(nlevels, 1)));
-  chk(a12.alloc(std::max(n_left, 1))); chk(a21.alloc(std::max(n_right, 1))); chk(mt.alloc(n)); chk(res.alloc(2));
-  if (e == hipSuccess) chk(hipMemcpy(k.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(d.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-  if (e == hipSuccess) chk(hipMemcpy(occ.p, occupied, n, hipMemcpyHostToDevice));
-  if (e == hipSuccess && scale_factors) chk(hipMemcpy(sf.p, scale_factors, nlevels * sizeof(float), hipMemcpyHostToDevice));
-  if (e == hipSuccess && l2r && n_left) chk(hipMemcpy(a12.p, l2r, (size_t)n_left * sizeof(int), hipMemcpyHostToDevice));
-  if (e == hipSuccess && r2l && n_right) chk(hipMemcpy(a21.p, r2l, (size_t)n_right * sizeof(int), hipMemcpyHostToDevice));
+  // one packed upload of every input (both cameras' views included); occupied | result | match come back in one copy
+  Pack pk;
+  const size_t oK = pk.add(kps, (size_t)n * sizeof(orbx_keypoint)), oD = pk.add(desc, (size_t)n * 32);
+  const size_t oSf = pk.add(scale_factors, (size_t)std::max(nlevels, 1) * sizeof(float));
+  const size_t oA12 = pk.add(n_left ? l2r : nullptr, (size_t)std::max(n_left, 1) * 4);
+  const size_t oA21 = pk.add(n_right ? r2l : nullptr, (size_t)std::max(n_right, 1) * 4);
+  size_t oMp[2], oPp[2];
+  for (int side = 0; side < 2; side++) {
+    oMp[side] = pk.add(n_points && mode == 0 ? (side ? viewsR : viewsL) : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
+    oPp[side] = pk.add(n_points && mode == 1 ? (side ? ptsR : ptsL) : nullptr, (size_t)nm * sizeof(orbx_projected_point));
+  }
+  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
+  struct { uint8_t* p; } d{pk.ptr<uint8_t>(oD)}, occ{pk.ptr<uint8_t>(oOcc)};
+  struct { float* p; } sf{pk.ptr<float>(oSf)};
+  struct { int* p; } a12{pk.ptr<int>(oA12)}, a21{pk.ptr<int>(oA21)}, mt{pk.ptr<int>(oMt)}, res{pk.ptr<int>(oRes)};
   for (int side = 0; side < 2 && e == hipSuccess; side++) {
     ProjSide& P = S[side];
     const int ns = side ? n_right : n_left, first = side ? n_left : 0;
     chk(P.cellStart.alloc(64 * 48 + 1)); chk(P.cellItems.alloc(std::max(ns, 1))); chk(P.candOff.alloc(nm + 1));
     chk(P.mdist.alloc(std::max(ns, 1))); chk(P.m21.alloc(std::max(ns, 1))); chk(P.m12.alloc(1)); chk(P.result.alloc(2));
-    chk(P.mp.alloc(nm)); chk(P.pp.alloc(nm));
-    if (e == hipSuccess && n_points && mode == 0)
-      chk(hipMemcpy(P.mp.p, side ? viewsR : viewsL, (size_t)n_points * sizeof(orbx_map_point_view), hipMemcpyHostToDevice));
-    if (e == hipSuccess && n_points && mode == 1)
-      chk(hipMemcpy(P.pp.p, side ? ptsR : ptsL, (size_t)n_points * sizeof(orbx_projected_point), hipMemcpyHostToDevice));
+    P.mpp = pk.ptr<orbx_map_point_view>(oMp[side]);
+    P.ppp = pk.ptr<orbx_projected_point>(oPp[side]);
     ProjArgs& a = P.a;
     a.grid.k2 = k.p + first; a.grid.n2 = ns; a.grid.n1 = 0;
     a.grid.minX = min_x; a.grid.minY = min_y;
@@ -2160,7 +2238,7 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
     a.grid.matches21 = P.m21.p; a.grid.matches12 = P.m12.p; a.grid.result = P.result.p; a.grid.candOff = P.candOff.p;
     a.grid.candCap = 1 << 30;
     a.desc = d.p + (size_t)first * 32; a.uRight = nullptr;  // no mvuRight gate when F.Nleft != -1 (:90, :1667)
-    a.scale = sf.p; a.mps = P.mp.p; a.pts = P.pp.p; a.nmp = n_points; a.mode = mode; a.checkOri = check_ori;
+    a.scale = sf.p; a.mps = P.mpp; a.pts = P.ppp; a.nmp = n_points; a.mode = mode; a.checkOri = check_ori;
     a.th = side ? 1.0f : th;  // the right-camera radius is not scaled by th (:144)
     a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
     a.occupied = occ.p + first; a.match = mt.p + first; a.candOff = P.candOff.p; a.result = P.result.p; a.candCap = 1 << 30;
@@ -2181,7 +2259,7 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
   f.offL = S[0].candOff.p; f.idxL = S[0].candIdx.p; f.distL = S[0].candDist.p;
   f.offR = S[1].candOff.p; f.idxR = S[1].candIdx.p; f.distR = S[1].candDist.p;
   f.nLeft = n_left; f.n = n; f.nmp = n_points; f.mode = mode; f.checkOri = check_ori; f.nnratio = nnratio;
-  f.mps = S[0].mp.p; f.pts = S[0].pp.p; f.kps = k.p; f.l2r = a12.p; f.r2l = a21.p;
+  f.mps = S[0].mpp; f.pts = S[0].ppp; f.kps = k.p; f.l2r = a12.p; f.r2l = a21.p;
   f.occupied = occ.p; f.match = mt.p; f.result = res.p;
   int result[2] = {0, 0};
   // parallel fixed-point rounds (k_proj_round_fe); the serial walk is the fallback (writer-list overflow, no convergence
@@ -2206,12 +2284,16 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
     }
   }
   if (e == hipSuccess) chk(done ? launch_proj_finish_fisheye(f, lastRound, nullptr) : launch_proj_resolve_fisheye(f, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess) chk(hipMemcpy(result, res.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(occupied, h, n);
+      std::memcpy(result, h + (oRes - oOcc), sizeof(int));
+      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+    }
+  }
   wr0.free(); wr1.free(); wl0.free(); wl1.free(); wc0.free(); wc1.free(); fl.free();
-  if (e == hipSuccess) chk(hipMemcpy(match, mt.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) chk(hipMemcpy(occupied, occ.p, n, hipMemcpyDeviceToHost));
-  k.free(); d.free(); occ.free(); sf.free(); a12.free(); a21.free(); mt.free(); res.free();
+  pk.release();
   S[0].release(); S[1].release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return result[0];
