@@ -2874,27 +2874,32 @@ __global__ __launch_bounds__(256) void k_bow_descend(BowArgs a) {
   }
 }
 
-// (key, index) pairs sorted ascending by key then index: bitonic network over P = 2^k slots in LDS, 256 threads.
-__device__ __forceinline__ void bow_sort_pairs(uint32_t* key, uint16_t* idx, int P) {
+// Sort of the (key << 16 | index) words: bitonic network over P = 2^k slots in LDS, kBowThreads threads.  A compare-exchange
+// at distance j < 64 stays inside an aligned group of 64 slots, and thread t always owns the pairs of the same groups, so
+// those stages need no workgroup barrier (the wave's own LDS operations are ordered); only the 15 of 66 stages (P = 2048)
+// with j >= 64 do -- the kernel is one workgroup per image and pure latency.
+constexpr int kBowThreads = 1024;
+__device__ __forceinline__ void bow_sort(uint64_t* key, int P) {
+  const int tid = threadIdx.x;
   for (int k = 2; k <= P; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < P; t += 256) {
-        const int u = t ^ j;
-        if (u > t) {
-          const uint32_t ka = key[t], kb = key[u];
-          const uint16_t ia = idx[t], ib = idx[u];
-          const bool gt = ka > kb || (ka == kb && ia > ib);
-          if (gt == ((t & k) == 0)) { key[t] = kb; key[u] = ka; idx[t] = ib; idx[u] = ia; }
-        }
+      for (int q = tid; q < (P >> 1); q += kBowThreads) {
+        // pair q of this stage: t = q with a zero bit inserted at position log2(j).  For j < 64 pair q and slot t share their
+        // aligned group of 32 pairs / 64 slots, i.e. the wave that owned the group in the previous stage owns it again.
+        const int t = ((q & ~(j - 1)) << 1) | (q & (j - 1)), u = t | j;
+        const uint64_t ka = key[t], kb = key[u];
+        if ((ka > kb) == ((t & k) == 0)) { key[t] = kb; key[u] = ka; }
       }
-      __syncthreads();
+      if (j >= 64 || j == 1) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); }
     }
 }
 // rank[t] = number of set flags before slot t (exclusive), returns the total; flag / rank share one LDS int array.
 __device__ __forceinline__ int bow_rank_heads(int* fr, int P, int* wsum) {
-  const int per = P >> 8, b = threadIdx.x * per;  // P >= 256
+  const int per = max(P / kBowThreads, 1), b = threadIdx.x * per;
   int s = 0;
-  for (int i = 0; i < per; i++) s += fr[b + i];
+  if (b < P)
+    for (int i = 0; i < per; i++) s += fr[b + i];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int incl = s;
   for (int o = 1; o < 64; o <<= 1) {
@@ -2904,16 +2909,17 @@ __device__ __forceinline__ int bow_rank_heads(int* fr, int P, int* wsum) {
   if (lane == 63) wsum[wv] = incl;
   __syncthreads();
   int base = 0, total = 0;
-  for (int w = 0; w < 4; w++) {
+  for (int w = 0; w < kBowThreads / 64; w++) {
     if (w < wv) base += wsum[w];
     total += wsum[w];
   }
   int run = base + incl - s;
-  for (int i = 0; i < per; i++) {
-    const int t = fr[b + i];
-    fr[b + i] = run;
-    run += t;
-  }
+  if (b < P)
+    for (int i = 0; i < per; i++) {
+      const int t = fr[b + i];
+      fr[b + i] = run;
+      run += t;
+    }
   __syncthreads();
   return total;
 }
@@ -2922,18 +2928,19 @@ __device__ __forceinline__ int bow_rank_heads(int* fr, int P, int* wsum) {
 // per image.  The std::map semantics become a sort: (word, feature index) pairs ascending give the BowVector's key order and,
 // per word, the reference's additions in feature order (value = w + w + ... sequentially -- every addend of a word is
 // the same idf weight); the L1 / L2 norm is accumulated sequentially in ascending word order like BowVector::normalize,
-// by one thread, so the doubles come out bit-identical.  (node, feature index) pairs give the FeatureVector as CSR.
-__global__ __launch_bounds__(256) void k_bow_assemble(BowArgs a) {
+// by one thread (values staged in LDS), so the doubles come out bit-identical.  (node, feature index) pairs give the
+// FeatureVector as CSR.
+__global__ __launch_bounds__(kBowThreads) void k_bow_assemble(BowArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t bow_smem[];
-  __shared__ int wsum[4];
+  __shared__ int wsum[kBowThreads / 64];
   __shared__ double normShared;
   const int img = blockIdx.x, tid = threadIdx.x;
   const int nf = a.counts ? a.counts[img] : a.n;
-  int P = 256;
+  int P = 128;
   while (P < nf) P <<= 1;
-  uint32_t* key = reinterpret_cast<uint32_t*>(bow_smem);
+  uint64_t* key = reinterpret_cast<uint64_t*>(bow_smem);
+  double* lval = reinterpret_cast<double*>(bow_smem);  // the values of the unique words, once the keys are consumed
   int* fr = reinterpret_cast<int*>(key + P);
-  uint16_t* idx = reinterpret_cast<uint16_t*>(fr + P);
   const long long o = (long long)img * a.cap;
   const int* word = a.word + o;
   const double* wt = a.weight + o;
@@ -2945,71 +2952,72 @@ __global__ __launch_bounds__(256) void k_bow_assemble(BowArgs a) {
   uint32_t* feats = a.feats + o;
   const bool additive = a.voc.weighting == 0 || a.voc.weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
   const bool must = a.voc.scoring != 5, l2 = a.voc.scoring == 1;       // mustNormalize (ScoringObject.h:73-90)
+  constexpr uint64_t kNone = ~0ull;
 
   // ---- BowVector
-  for (int t = tid; t < P; t += 256) {
-    const bool ok = t < nf && wt[t] > 0;  // "w > 0: not stopped"
-    key[t] = ok ? (uint32_t)word[t] : 0xffffffffu;
-    idx[t] = ok ? (uint16_t)t : (uint16_t)0xffff;
-  }
+  for (int t = tid; t < P; t += kBowThreads)
+    key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)word[t] << 16) | (uint64_t)t : kNone;  // "w > 0: not stopped"
   __syncthreads();
-  bow_sort_pairs(key, idx, P);
-  for (int t = tid; t < P; t += 256) fr[t] = idx[t] != 0xffff && (t == 0 || key[t] != key[t - 1]);
+  bow_sort(key, P);
+  for (int t = tid; t < P; t += kBowThreads) fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
   __syncthreads();
   const int U = bow_rank_heads(fr, P, wsum);
-  for (int t = tid; t < P; t += 256) {
-    if (idx[t] == 0xffff || (t > 0 && key[t] == key[t - 1])) continue;
-    const double w = wt[idx[t]];  // the first feature of the word in feature order
+  double myV[8];  // values of the heads this thread owns (P / kBowThreads <= 8 slots per thread)
+  int myU[8], nMine = 0;
+  for (int t = tid; t < P; t += kBowThreads) {
+    if (key[t] == kNone || (t > 0 && (key[t] >> 16) == (key[t - 1] >> 16))) continue;
+    const double w = wt[key[t] & 0xffff];  // the first feature of the word in feature order
     double v = w;
     if (additive)
-      for (int r = t + 1; r < P && idx[r] != 0xffff && key[r] == key[t]; r++) v += w;
-    words[fr[t]] = key[t];
-    values[fr[t]] = v;
+      for (int r = t + 1; r < P && (key[r] >> 16) == (key[t] >> 16); r++) v += w;
+    words[fr[t]] = (uint32_t)(key[t] >> 16);
+    myU[nMine] = fr[t];
+    myV[nMine++] = v;
   }
+  __syncthreads();  // every key has been read: the array now holds the values
+  for (int i = 0; i < nMine; i++) lval[myU[i]] = myV[i];
   __syncthreads();
+  double scale = 1.0;
+  bool divide = false;
   if (additive && U > 0 && !must) {
-    const double nd = (double)U;
-    for (int u = tid; u < U; u += 256) values[u] /= nd;
-    __syncthreads();
+    scale = (double)U;
+    divide = true;
   }
   if (must) {
     if (tid == 0) {
       double norm = 0.0;
       if (!l2) {
-        for (int u = 0; u < U; u++) norm += fabs(values[u]);
+        for (int u = 0; u < U; u++) norm += fabs(lval[u]);
       } else {
-        for (int u = 0; u < U; u++) norm += values[u] * values[u];
+        for (int u = 0; u < U; u++) norm += lval[u] * lval[u];
         norm = sqrt(norm);
       }
       normShared = norm;
     }
     __syncthreads();
-    const double norm = normShared;
-    if (norm > 0.0)
-      for (int u = tid; u < U; u += 256) values[u] /= norm;
+    scale = normShared;
+    divide = scale > 0.0;
   }
+  for (int u = tid; u < U; u += kBowThreads) values[u] = divide ? lval[u] / scale : lval[u];
   __syncthreads();
 
   // ---- FeatureVector
-  int nUsed = 0;
-  for (int t = tid; t < P; t += 256) {
-    const bool ok = t < nf && wt[t] > 0;
-    key[t] = ok ? (uint32_t)node[t] : 0xffffffffu;
-    idx[t] = ok ? (uint16_t)t : (uint16_t)0xffff;
-  }
+  for (int t = tid; t < P; t += kBowThreads)
+    key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)node[t] << 16) | (uint64_t)t : kNone;
   __syncthreads();
-  bow_sort_pairs(key, idx, P);
-  for (int t = tid; t < P; t += 256) {
-    fr[t] = idx[t] != 0xffff && (t == 0 || key[t] != key[t - 1]);
-    nUsed += idx[t] != 0xffff;
+  bow_sort(key, P);
+  int nUsed = 0;
+  for (int t = tid; t < P; t += kBowThreads) {
+    fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
+    nUsed += key[t] != kNone;
   }
   __syncthreads();
   const int V = bow_rank_heads(fr, P, wsum);
-  for (int t = tid; t < P; t += 256) {
-    if (idx[t] == 0xffff) continue;
-    feats[t] = idx[t];
-    if (t == 0 || key[t] != key[t - 1]) {
-      nodes[fr[t]] = key[t];
+  for (int t = tid; t < P; t += kBowThreads) {
+    if (key[t] == kNone) continue;
+    feats[t] = (uint32_t)(key[t] & 0xffff);
+    if (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16)) {
+      nodes[fr[t]] = (uint32_t)(key[t] >> 16);
       nodeStart[fr[t]] = t;
     }
   }
@@ -3018,7 +3026,8 @@ __global__ __launch_bounds__(256) void k_bow_assemble(BowArgs a) {
   if ((tid & 63) == 0) wsum[tid >> 6] = nUsed;
   __syncthreads();
   if (tid == 0) {
-    const int used = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int used = 0;
+    for (int w = 0; w < kBowThreads / 64; w++) used += wsum[w];
     nodeStart[V] = used;
     a.outCounts[img * 3 + 0] = U;
     a.outCounts[img * 3 + 1] = V;
@@ -3029,15 +3038,15 @@ __global__ __launch_bounds__(256) void k_bow_assemble(BowArgs a) {
 hipError_t launch_bow_transform(const BowArgs& a, int nimg, hipStream_t s) {
   if (a.n <= 0 || nimg <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_bow_descend, dim3((a.n + 15) / 16, nimg), dim3(256), 0, s, a);
-  int P = 256;
+  int P = 128;
   while (P < a.n) P <<= 1;
-  const size_t lds = (size_t)P * 10;
-  if (lds > 48 * 1024) {  // up to 80 KB for 8192 features: above the default dynamic-LDS limit
+  const size_t lds = (size_t)P * 12;
+  if (lds > 48 * 1024) {  // up to 96 KB for 8192 features: above the default dynamic-LDS limit
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_assemble), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_bow_assemble, dim3(nimg), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(k_bow_assemble, dim3(nimg), dim3(kBowThreads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -3066,79 +3075,92 @@ __global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
   }
   for (int i = lane; i < nfl; i += 64) taken[i] = 0;
   __syncthreads();
+  // the node's first 64 frame features stay in registers for the whole walk (a node of a real vocabulary holds ~15)
+  int iF0 = -1;
+  uint32_t fD0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane < nfl) {
+    iF0 = (int)a.fFeat[f0 + lane];
+    const uint32_t* dF = a.fDesc + (long long)iF0 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) fD0[i] = dF[i];
+  }
+  const bool twoEyes = a.nLeftF != -1;
   int made = 0;
-  for (int p = k0; p < k1; p++) {
-    const int iKF = (int)a.kfFeat[p];
-    if (!a.kfValid[iKF]) continue;
-    const uint32_t* dK = a.kfDesc + (long long)iKF * 8;
-    uint32_t d[8];
+  for (int kc = k0; kc < k1; kc += 64) {  // keyframe features of the node: 64 at a time into registers, then walked in order
+    int myKF = -1, myValid = 0;
+    uint32_t myD[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kc + lane < k1) {
+      myKF = (int)a.kfFeat[kc + lane];
+      myValid = a.kfValid[myKF];
+      if (myValid) {
+        const uint32_t* dK = a.kfDesc + (long long)myKF * 8;
 #pragma unroll
-    for (int i = 0; i < 8; i++) d[i] = dK[i];
-    // running best / second of the left and the right eye, merged chunk by chunk in list order
-    int b1 = 256, bi = -1, b2 = 256, b1r = 256, bir = -1, b2r = 256;
-    for (int q0 = 0; q0 < nfl; q0 += 64) {
-      const int q = q0 + lane;
-      int dist = 0x7fff, iF = -1;
-      bool right = false;
-      if (q < nfl && !taken[q]) {
-        iF = (int)a.fFeat[f0 + q];
-        dist = hamming256(d, a.fDesc + (long long)iF * 8);
-        right = a.nLeftF != -1 && iF >= a.nLeftF;
-      }
-#pragma unroll
-      for (int side = 0; side < 2; side++) {
-        const bool mine = iF >= 0 && right == (side == 1);
-        uint32_t k1st = mine ? ((uint32_t)dist << 8) | (uint32_t)lane : 0xffffffffu;  // first minimum: lower lane = earlier
-        for (int o = 32; o > 0; o >>= 1) k1st = min(k1st, (uint32_t)__shfl_xor((int)k1st, o));
-        uint32_t k2nd = (mine && (k1st & 255u) != (uint32_t)lane) ? (uint32_t)dist : 0xffffffffu;
-        for (int o = 32; o > 0; o >>= 1) k2nd = min(k2nd, (uint32_t)__shfl_xor((int)k2nd, o));
-        if (k1st != 0xffffffffu) {
-          const int c1 = (int)(k1st >> 8), cl = (int)(k1st & 255u), c2 = k2nd == 0xffffffffu ? 256 : (int)k2nd;
-          const int ci = (int)a.fFeat[f0 + q0 + cl];
-          int& B1 = side ? b1r : b1; int& BI = side ? bir : bi; int& B2 = side ? b2r : b2;
-          if (c1 < B1) { B2 = min(B1, c2); B1 = c1; BI = ci; }
-          else { B2 = min(B2, c1); }
-        }
+        for (int i = 0; i < 8; i++) myD[i] = dK[i];
       }
     }
-    if (b1 <= 50) {  // TH_LOW
-      bool any = false;
-      if ((float)b1 < __fmul_rn(a.nnratio, (float)b2)) {
-        if (lane == 0) {
-          a.match[bi] = iKF;
-          if (a.checkOri) {
-            float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[bi].angle);
-            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
-            if (bin == 30) bin = 0;
-            a.bin[bi] = bin;
-            atomicAdd(&a.flags[2 + bin], 1);
+    const int cnt = min(64, k1 - kc);
+    for (int c = 0; c < cnt; c++) {
+      if (!__builtin_amdgcn_readlane(myValid, c)) continue;
+      const int iKF = __builtin_amdgcn_readlane(myKF, c);
+      uint32_t d[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d[i] = (uint32_t)__builtin_amdgcn_readlane((int)myD[i], c);
+      // running best / second of the left and the right eye, merged chunk by chunk in list order
+      int b1 = 256, bi = -1, b2 = 256, b1r = 256, bir = -1, b2r = 256;
+      for (int q0 = 0; q0 < nfl; q0 += 64) {
+        const int q = q0 + lane;
+        int dist = 0x7fff, iF = -1;
+        bool right = false;
+        if (q < nfl && !taken[q]) {
+          if (q0 == 0) {
+            iF = iF0;
+            dist = hamming256(d, fD0);
+          } else {
+            iF = (int)a.fFeat[f0 + q];
+            dist = hamming256(d, a.fDesc + (long long)iF * 8);
+          }
+          right = twoEyes && iF >= a.nLeftF;
+        }
+        for (int side = 0; side < (twoEyes ? 2 : 1); side++) {
+          const bool mine = iF >= 0 && right == (side == 1);
+          uint32_t k1st = mine ? ((uint32_t)dist << 8) | (uint32_t)lane : 0xffffffffu;  // first minimum: lower lane = earlier
+          for (int o = 32; o > 0; o >>= 1) k1st = min(k1st, (uint32_t)__shfl_xor((int)k1st, o));
+          uint32_t k2nd = (mine && (k1st & 255u) != (uint32_t)lane) ? (uint32_t)dist : 0xffffffffu;
+          for (int o = 32; o > 0; o >>= 1) k2nd = min(k2nd, (uint32_t)__shfl_xor((int)k2nd, o));
+          if (k1st != 0xffffffffu) {
+            const int c1 = (int)(k1st >> 8), cl = (int)(k1st & 255u), c2 = k2nd == 0xffffffffu ? 256 : (int)k2nd;
+            const int ci = q0 == 0 ? __builtin_amdgcn_readlane(iF0, cl) : (int)a.fFeat[f0 + q0 + cl];
+            int& B1 = side ? b1r : b1; int& BI = side ? bir : bi; int& B2 = side ? b2r : b2;
+            if (c1 < B1) { B2 = min(B1, c2); B1 = c1; BI = ci; }
+            else { B2 = min(B2, c1); }
           }
         }
-        made++;
-        any = true;
       }
-      if (b1r <= 50) {
+      if (b1 <= 50) {  // TH_LOW
+        const bool leftOk = (float)b1 < __fmul_rn(a.nnratio, (float)b2), rightOk = b1r <= 50;
         if (lane == 0) {
-          a.match[bir] = iKF;
-          if (a.checkOri) {
-            float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[bir].angle);
-            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
-            if (bin == 30) bin = 0;
-            a.bin[bir] = bin;
-            atomicAdd(&a.flags[2 + bin], 1);
+          for (int side = 0; side < 2; side++) {
+            if (!(side ? rightOk : leftOk)) continue;
+            const int iF = side ? bir : bi;
+            a.match[iF] = iKF;
+            if (a.checkOri) {
+              float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[iF].angle);
+              if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+              int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+              if (bin == 30) bin = 0;
+              a.bin[iF] = bin;
+              atomicAdd(&a.flags[2 + bin], 1);
+            }
           }
         }
-        made++;
-        any = true;
-      }
-      if (any) {  // mark the taken frame features of this node (positions in the node's list)
-        for (int q = lane; q < nfl; q += 64) {
-          const int iF = (int)a.fFeat[f0 + q];
-          if (((float)b1 < __fmul_rn(a.nnratio, (float)b2) && iF == bi) || (b1r <= 50 && iF == bir)) taken[q] = 1;
+        made += (leftOk ? 1 : 0) + (rightOk ? 1 : 0);
+        if (leftOk || rightOk) {  // mark the taken frame features of this node (positions in the node's list)
+          for (int q = lane; q < nfl; q += 64) {
+            const int iF = q < 64 ? iF0 : (int)a.fFeat[f0 + q];
+            if ((leftOk && iF == bi) || (rightOk && iF == bir)) taken[q] = 1;
+          }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
   }
