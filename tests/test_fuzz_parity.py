@@ -180,3 +180,81 @@ def test_fuzz_matchers(oracle):
             fails.append((seed0 + case, w, h, nf, win, ratio, ori))
         ex.close()
     assert not fails, "mismatching matcher cases: %r" % fails
+
+
+def test_fuzz_preprocess(oracle):
+    """cv::remap and CLAHE over random sizes, tile grids, clip limits and maps (smooth, seams, magnification, out of range)."""
+    ncases = int(os.environ.get("ORBX_FUZZ_CASES", "60"))
+    seed0 = int(os.environ.get("ORBX_FUZZ_SEED", "12345")) + 9000
+    fails = []
+    for case in range(ncases):
+        rng = np.random.default_rng(seed0 + case)
+        sw, sh = int(rng.integers(9, 700)), int(rng.integers(9, 500))
+        img = make_image(rng, max(sw, 160), max(sh, 120), case)[0][:sh, :sw] if rng.random() < 0.6 else \
+            rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        img = np.ascontiguousarray(img)
+        dw, dh = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+        u, v = np.meshgrid(np.arange(dw, dtype=np.float32), np.arange(dh, dtype=np.float32))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            mx, my = synth.rectify_maps(dw, dh, sw, sh, seed=case, k1=float(rng.uniform(-0.4, 0.2)),
+                                        rot_deg=tuple(rng.uniform(-2, 2, 3)))
+        elif kind == 1:  # magnification / minification with a shear: windows of a thread's taps do not always fit
+            sc = float(rng.choice([0.3, 0.7, 1.0, 1.6, 2.5, 5.0]))
+            mx, my = (u * sc + v * 0.13 - 3).astype(np.float32), (v * sc - u * 0.21 + 2).astype(np.float32)
+        elif kind == 2:
+            mx = rng.uniform(-4, sw + 4, (dh, dw)).astype(np.float32)
+            my = rng.uniform(-4, sh + 4, (dh, dw)).astype(np.float32)
+        elif kind == 3:  # a seam: the right half of the map jumps elsewhere
+            mx, my = (u + 0.37).astype(np.float32), (v - 0.62).astype(np.float32)
+            mx[:, dw // 2:] = (sw - 1 - u[:, dw // 2:] * 0.5).astype(np.float32)
+        else:  # exact 1/32 fractions and integer positions
+            mx = (u + rng.integers(0, 33, (dh, dw)) / 32).astype(np.float32)
+            my = (v + rng.integers(0, 33, (dh, dw)) / 32).astype(np.float32)
+        if rng.random() < 0.3:
+            mx[rng.integers(0, dh), rng.integers(0, dw)] = rng.choice([np.nan, np.inf, -np.inf, 1e10, -1e10])
+        if not np.array_equal(orbx.remap(img, mx, my), oracle.remap(img, mx, my)):
+            fails.append(("remap", case, sw, sh, dw, dh, kind))
+        tiles = (int(rng.integers(1, 12)), int(rng.integers(1, 12)))
+        clip = float(rng.choice([0.0, 0.5, 1.0, 2.0, 3.0, 4.0, 40.0]))
+        if sw > tiles[0] and sh > tiles[1]:
+            if not np.array_equal(orbx.CLAHE(clip, tiles).apply(img), oracle.clahe(img, clip, tiles)):
+                fails.append(("clahe", case, sw, sh, tiles, clip))
+    assert not fails, fails[:10]
+
+
+def test_fuzz_bow(oracle):
+    """ComputeBoW + SearchByBoW over random tree shapes, scoring / weighting types, feature counts and eye splits."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_bow import _scene, _kps
+    ncases = int(os.environ.get("ORBX_FUZZ_CASES", "60")) // 2 + 1
+    seed0 = int(os.environ.get("ORBX_FUZZ_SEED", "12345")) + 13000
+    fails = []
+    for case in range(ncases):
+        rng = np.random.default_rng(seed0 + case)
+        k, L = int(rng.integers(2, 13)), int(rng.integers(1, 5))
+        while k ** L > 20000:
+            L -= 1
+        lu = int(rng.integers(0, L + 2))
+        scoring, weighting = int(rng.integers(0, 6)), int(rng.integers(0, 4))
+        cols = synth.make_vocabulary(k, L, seed=case, early_leaf_prob=float(rng.choice([0.0, 0.05, 0.3])),
+                                     stop_prob=float(rng.choice([0.0, 0.05, 0.5])))
+        ovoc = oracle.Vocabulary(k, L, *cols, scoring=scoring, weighting=weighting)
+        voc = orbx.ORBVocabulary(k, L, *cols, scoring=scoring, weighting=weighting)
+        n_kf, n_f = int(rng.integers(1, 2500)), int(rng.integers(1, 2500))
+        n_left = -1 if rng.random() < 0.5 else int(rng.integers(0, n_f + 1))
+        kd, ka, kv, fd, fa = _scene(cols, n_kf, n_f, case, n_left)
+        got_k, got_f = voc.transform(kd, lu), voc.transform(fd, lu)
+        want_k, want_f = ovoc.transform(kd, lu), ovoc.transform(fd, lu)
+        same = all(np.array_equal(x, y) for g, wnt in ((got_k, want_k), (got_f, want_f)) for x, y in zip(g[0] + g[1], wnt[0] + wnt[1]))
+        same = same and np.array_equal(got_f[0][1].view(np.uint64), want_f[0][1].view(np.uint64))
+        if not same:
+            fails.append(("transform", case, k, L, lu, scoring, weighting, n_kf, n_f))
+            continue
+        ratio, ori = float(rng.choice([0.6, 0.7, 0.9])), bool(rng.integers(0, 2))
+        n, m = orbx.SearchByBoW(want_k[1], _kps(ka), kd, kv, want_f[1], _kps(fa), fd, n_left, ratio, ori)
+        on, om = oracle.search_by_bow(want_k[1], kd, ka, kv, want_f[1], fd, fa, n_left, ratio, ori)
+        if n != on or not np.array_equal(m, om):
+            fails.append(("search", case, k, L, lu, n_kf, n_f, n_left, ratio, ori))
+    assert not fails, fails[:10]
