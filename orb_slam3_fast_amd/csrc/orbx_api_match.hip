@@ -1,0 +1,581 @@
+// orbx_api_match.hip — C ABI of the matchers (include/orbx.h): brute-force 2-NN, fisheye stereo association, SearchForInitialization,
+// the SearchByProjection family, SearchByBoW.  One-shot calls: host arrays in, host results out, inputs through one packed upload.
+#include "orbx_host.h"
+
+extern "C" {
+
+int orbx_bf_knn2(int device, const uint8_t* descQ, int nQ, const uint8_t* descT, int nT, int32_t* idx2,
+                 int32_t* dist2, uint8_t* ratio_ok) {
+  if (nQ < 0 || nT < 0 || (nQ && (!descQ || !idx2 || !dist2 || !ratio_ok)) || (nT && !descT))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (nQ == 0) return ORBX_OK;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  Pack pk;
+  const size_t Q = (size_t)nQ;
+  const size_t oQ = pk.add(descQ, Q * 32), oT = pk.add(descT, (size_t)std::max(nT, 1) * 32);
+  const size_t oOut = pk.add(nullptr, Q * 2 * 4 * 2 + Q);  // idx2 | dist2 | ratio_ok: one copy back
+  hipError_t e = pk.commit();
+  int* i2 = pk.ptr<int>(oOut);
+  int* d2 = i2 + Q * 2;
+  uint8_t* ok = reinterpret_cast<uint8_t*>(d2 + Q * 2);
+  if (e == hipSuccess) e = launch_bf_knn2(pk.ptr<uint8_t>(oQ), nQ, pk.ptr<uint8_t>(oT), nT, i2, d2, ok, nullptr);
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, Q * 17, &e);
+    if (e == hipSuccess) {
+      std::memcpy(idx2, h, Q * 8);
+      std::memcpy(dist2, h + Q * 8, Q * 8);
+      std::memcpy(ratio_ok, h + Q * 16, Q);
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
+int orbx_fisheye_stereo_match(int device, const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                              int mono_left, const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                              int mono_right, const orbx_kb8_rig* rig, const float* level_sigma2, int n_levels,
+                              int32_t* left_to_right, int32_t* right_to_left, float* depth, float* points3d,
+                              int32_t* n_desc_matches) {
+  if (n_left < 0 || n_right < 0 || mono_left < 0 || mono_left > n_left || mono_right < 0 || mono_right > n_right ||
+      !rig || !level_sigma2 || n_levels <= 0 || n_levels > ORBX_MAX_LEVELS ||
+      (n_left && (!kps_left || !desc_left || !left_to_right || !depth || !points3d)) ||
+      (n_right && (!kps_right || !desc_right || !right_to_left)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_left; i++) {
+    left_to_right[i] = -1;
+    depth[i] = -1.0f;
+    points3d[3 * i] = points3d[3 * i + 1] = points3d[3 * i + 2] = 0.0f;
+  }
+  for (int i = 0; i < n_right; i++) right_to_left[i] = -1;
+  if (n_desc_matches) *n_desc_matches = 0;
+  const int nQ = n_left - mono_left, nT = n_right - mono_right;
+  // knnMatch(k = 2) yields pairs only when the train set has two rows (`(*it).size() >= 2`, src/Frame.cc:1302)
+  if (nQ == 0 || nT < 2) {
+    int rc0 = set_device(device);  // still a device routine: no GPU is an error, never a silent host path
+    return rc0 != ORBX_OK ? rc0 : 0;
+  }
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  // one packed upload (the -1 / 0 fills of the outputs travel with it); the outputs are contiguous: one copy back
+  std::vector<float> zeros((size_t)n_left * 3 + 2, 0.0f);  // points3d fill + the two counters
+  Pack pk;
+  const size_t NL = (size_t)n_left, NR = (size_t)n_right;
+  const size_t oKl = pk.add(kps_left, NL * sizeof(orbx_keypoint)), oKr = pk.add(kps_right, NR * sizeof(orbx_keypoint));
+  const size_t oDq = pk.add(desc_left + (size_t)mono_left * 32, (size_t)nQ * 32);
+  const size_t oDt = pk.add(desc_right + (size_t)mono_right * 32, (size_t)nT * 32);
+  const size_t oSg = pk.add(level_sigma2, (size_t)n_levels * sizeof(float));
+  const size_t oL2r = pk.add(left_to_right, NL * 4), oR2l = pk.add(right_to_left, NR * 4), oDep = pk.add(depth, NL * 4);
+  const size_t oPts = pk.add(zeros.data(), NL * 12), oCnt = pk.add(zeros.data(), 8);
+  const size_t outBytes = oCnt + 8 - oL2r;
+  const size_t oOk = pk.add(nullptr, nQ), oI2 = pk.add(nullptr, (size_t)nQ * 8), oD2 = pk.add(nullptr, (size_t)nQ * 8);
+  hipError_t e = pk.commit();
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  if (e == hipSuccess)
+    chk(launch_bf_knn2(pk.ptr<uint8_t>(oDq), nQ, pk.ptr<uint8_t>(oDt), nT, pk.ptr<int>(oI2), pk.ptr<int>(oD2), pk.ptr<uint8_t>(oOk), nullptr));
+  if (e == hipSuccess) {
+    FisheyeArgs a;
+    a.kL = pk.ptr<orbx_keypoint>(oKl); a.kR = pk.ptr<orbx_keypoint>(oKr); a.nL = n_left; a.nR = n_right; a.monoL = mono_left;
+    a.monoR = mono_right;
+    a.idx2 = pk.ptr<int>(oI2); a.ratioOk = pk.ptr<uint8_t>(oOk); a.rig = *rig; a.sigma2 = pk.ptr<float>(oSg); a.nLevels = n_levels;
+    a.leftToRight = pk.ptr<int>(oL2r); a.rightToLeft = pk.ptr<int>(oR2l); a.depth = pk.ptr<float>(oDep);
+    a.p3D = pk.ptr<float>(oPts); a.counters = pk.ptr<int>(oCnt);
+    chk(launch_fisheye_triangulate(a, nullptr));
+  }
+  int counts[2] = {0, 0};
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oL2r, outBytes, &e);
+    if (e == hipSuccess) {
+      std::memcpy(left_to_right, h, NL * 4);
+      std::memcpy(right_to_left, h + (oR2l - oL2r), NR * 4);
+      std::memcpy(depth, h + (oDep - oL2r), NL * 4);
+      std::memcpy(points3d, h + (oPts - oL2r), NL * 12);
+      std::memcpy(counts, h + (oCnt - oL2r), sizeof(counts));
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (n_desc_matches) *n_desc_matches = counts[1];
+  return counts[0];
+}
+
+int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* kf_node_start, const uint32_t* kf_feature_idx,
+                       int n_kf_nodes, const orbx_keypoint* kf_kps, const uint8_t* kf_desc, const uint8_t* kf_valid, int n_kf,
+                       const uint32_t* f_node_ids, const int32_t* f_node_start, const uint32_t* f_feature_idx, int n_f_nodes,
+                       const orbx_keypoint* f_kps, const uint8_t* f_desc, int n_f, int n_left_f, float nnratio,
+                       int check_orientation, int32_t* matches) {
+  if (n_kf < 0 || n_f < 0 || n_kf_nodes < 0 || n_f_nodes < 0 || (n_f && !matches) ||
+      (n_kf_nodes && (!kf_node_ids || !kf_node_start || !kf_feature_idx || !kf_kps || !kf_desc || !kf_valid)) ||
+      (n_f_nodes && (!f_node_ids || !f_node_start || !f_feature_idx || !f_kps || !f_desc)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  const int nkl = n_kf_nodes ? kf_node_start[n_kf_nodes] : 0, nfl = n_f_nodes ? f_node_start[n_f_nodes] : 0;
+  if (nkl < 0 || nkl > n_kf || nfl < 0 || nfl > n_f) return fail(ORBX_E_BADARG, "feature vector larger than the frame");
+  for (int i = 0; i < nkl; i++)
+    if (kf_feature_idx[i] >= (uint32_t)n_kf) return fail(ORBX_E_BADARG, "keyframe feature index out of range");
+  for (int i = 0; i < nfl; i++)
+    if (f_feature_idx[i] >= (uint32_t)n_f) return fail(ORBX_E_BADARG, "frame feature index out of range");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  for (int i = 0; i < n_f; i++) matches[i] = -1;
+  if (n_kf_nodes == 0 || n_f_nodes == 0 || n_f == 0) return 0;
+  Pack pk;
+  const size_t oKn = pk.add(kf_node_ids, (size_t)n_kf_nodes * 4), oKs = pk.add(kf_node_start, ((size_t)n_kf_nodes + 1) * 4);
+  const size_t oKf = pk.add(kf_feature_idx, (size_t)nkl * 4), oKd = pk.add(kf_desc, (size_t)n_kf * 32);
+  const size_t oKv = pk.add(kf_valid, n_kf), oKk = pk.add(kf_kps, (size_t)n_kf * sizeof(orbx_keypoint));
+  const size_t oFn = pk.add(f_node_ids, (size_t)n_f_nodes * 4), oFs = pk.add(f_node_start, ((size_t)n_f_nodes + 1) * 4);
+  const size_t oFf = pk.add(f_feature_idx, (size_t)nfl * 4), oFd = pk.add(f_desc, (size_t)n_f * 32);
+  const size_t oFk = pk.add(f_kps, (size_t)n_f * sizeof(orbx_keypoint));
+  const size_t oBin = pk.add(nullptr, (size_t)n_f * 4), oFlags = pk.add(nullptr, 33 * 4);
+  const size_t oOut = pk.add(nullptr, ((size_t)n_f + 1) * 4);  // result, then the matches: one copy back
+  hipError_t e = pk.commit();
+  BowMatchArgs a{};
+  a.kfNodes = pk.ptr<uint32_t>(oKn); a.kfStart = pk.ptr<int>(oKs); a.kfFeat = pk.ptr<uint32_t>(oKf); a.nKfNodes = n_kf_nodes;
+  a.kfDesc = pk.ptr<uint32_t>(oKd); a.kfKps = pk.ptr<orbx_keypoint>(oKk); a.kfValid = pk.ptr<uint8_t>(oKv);
+  a.fNodes = pk.ptr<uint32_t>(oFn); a.fStart = pk.ptr<int>(oFs); a.fFeat = pk.ptr<uint32_t>(oFf); a.nFNodes = n_f_nodes;
+  a.fDesc = pk.ptr<uint32_t>(oFd); a.fKps = pk.ptr<orbx_keypoint>(oFk); a.nF = n_f; a.nLeftF = n_left_f;
+  a.nnratio = nnratio; a.checkOri = check_orientation ? 1 : 0;
+  a.result = pk.ptr<int>(oOut); a.match = pk.ptr<int>(oOut) + 1; a.bin = pk.ptr<int>(oBin); a.flags = pk.ptr<int>(oFlags);
+  if (e == hipSuccess) e = launch_bow_match(a, nullptr);
+  int n = 0;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, ((size_t)n_f + 1) * 4, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&n, h, 4);
+      std::memcpy(matches, h + 4, (size_t)n_f * 4);
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (n < 0) return fail(ORBX_E_UNSUPPORTED, "a vocabulary node holds more than 4096 frame features");
+  return n;
+}
+
+int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                   const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
+                                   float min_y, float max_x, float max_y, float* prev_matched,
+                                   int32_t* matches12, int window_size, float nnratio, int check_orientation) {
+  if (n1 < 0 || n2 < 0 || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kps2 || !desc2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n1 == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  // one packed upload; vbPrevMatched | result | vnMatches12 are contiguous and come back in one copy
+  Pack pk;
+  const size_t oK1 = pk.add(kps1, (size_t)n1 * sizeof(orbx_keypoint)), oK2 = pk.add(kps2, (size_t)std::max(n2, 1) * sizeof(orbx_keypoint));
+  const size_t oD1 = pk.add(desc1, (size_t)n1 * 32), oD2 = pk.add(desc2, (size_t)std::max(n2, 1) * 32);
+  const size_t oPrev = pk.add(prev_matched, (size_t)n1 * 2 * sizeof(float)), oRes = pk.add(nullptr, 2 * sizeof(int));
+  const size_t oM12 = pk.add(nullptr, (size_t)n1 * sizeof(int));
+  const size_t outBytes = oM12 + (size_t)n1 * sizeof(int) - oPrev;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k1{pk.ptr<orbx_keypoint>(oK1)}, k2{pk.ptr<orbx_keypoint>(oK2)};
+  struct { uint8_t* p; } d1{pk.ptr<uint8_t>(oD1)}, d2{pk.ptr<uint8_t>(oD2)};
+  struct { float* p; } prev{pk.ptr<float>(oPrev)};
+  struct { int* p; } m12{pk.ptr<int>(oM12)}, result{pk.ptr<int>(oRes)};
+  chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(std::max(n2, 1))); chk(candOff.alloc(n1 + 1));
+  chk(mdist.alloc(std::max(n2, 1))); chk(m21.alloc(std::max(n2, 1)));
+  InitArgs a{};
+  a.k1 = k1.p; a.k2 = k2.p; a.d1 = d1.p; a.d2 = d2.p; a.n1 = n1; a.n2 = n2;
+  a.minX = min_x; a.minY = min_y;
+  a.invW = 64.f / (max_x - min_x);  // mfGridElementWidthInv, src/Frame.cc:243
+  a.invH = 48.f / (max_y - min_y);
+  a.prev = prev.p; a.matches12 = m12.p; a.window = window_size; a.nnratio = nnratio;
+  a.checkOri = check_orientation;
+  a.cellStart = cellStart.p; a.cellItems = cellItems.p; a.candOff = candOff.p;
+  a.matchedDist = mdist.p; a.matches21 = m21.p; a.result = result.p;
+  a.candCap = 1 << 30;
+  int total = 0, res[2] = {0, 0};
+  if (e == hipSuccess) chk(launch_search_init(a, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess) chk(hipMemcpy(&total, candOff.p + n1, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) {
+    chk(candIdx.alloc((size_t)std::max(total, 1)));
+    chk(candDist.alloc((size_t)std::max(total, 1)));
+    a.candIdx = candIdx.p;
+    a.candDist = candDist.p;
+    a.candCap = std::max(total, 1);
+  }
+  // resolve: parallel fixed-point rounds (k_init_round), serial walk as fallback / ORBX_PROJ_SERIAL=1 cross-check
+  ScratchBuf<int2> cl0, cl1, cr0, cr1;
+  ScratchBuf<int> nc0, nc1, fl;
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  bool done = false;
+  int lastRound = 0;
+  if (e == hipSuccess) chk(launch_search_init_cands_fill(a, nullptr));
+  if (!forceSerial && n2 > 0) {
+    chk(cl0.alloc(n1)); chk(cl1.alloc(n1)); chk(cr0.alloc((size_t)n2 * kFeWriters)); chk(cr1.alloc((size_t)n2 * kFeWriters));
+    chk(nc0.alloc(n2)); chk(nc1.alloc(n2)); chk(fl.alloc(40));
+    a.claim[0] = cl0.p; a.claim[1] = cl1.p; a.claimers[0] = cr0.p; a.claimers[1] = cr1.p;
+    a.nclaimers[0] = nc0.p; a.nclaimers[1] = nc1.p; a.flags = fl.p;
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_search_init_rounds(a, r, 4, nullptr));
+      int st[2] = {1, 0};
+      if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
+      if (st[1]) break;
+      done = st[0] == 0;
+      lastRound = r + 3;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_search_init_finish(a, lastRound, nullptr) : launch_search_init_resolve_serial(a, nullptr));
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oPrev, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(prev_matched, h, (size_t)n1 * 2 * sizeof(float));
+      std::memcpy(res, h + (oRes - oPrev), sizeof(res));
+      std::memcpy(matches12, h + (oM12 - oPrev), (size_t)n1 * sizeof(int));
+    }
+  }
+  cl0.free(); cl1.free(); cr0.free(); cr1.free(); nc0.free(); nc1.free(); fl.free();
+  pk.release(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return res[0];
+}
+
+int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x,
+                          float max_y, const float* queries, int n_queries, int32_t* offsets, int32_t* indices,
+                          int indices_cap, int32_t* grid_cell_start, int32_t* grid_items) {
+  if (n < 0 || n_queries < 0 || (n && !kps) || (n_queries && (!queries || !offsets)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<orbx_keypoint> k;
+  ScratchBuf<float> q;
+  ScratchBuf<int> cellStart, cellItems, qOff, out, mdist, m21, m12, result;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  const int nn = std::max(n, 1), nq = std::max(n_queries, 1);
+  chk(k.alloc(nn)); chk(q.alloc((size_t)nq * 5)); chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(nn));
+  chk(qOff.alloc(nq + 1)); chk(mdist.alloc(nn)); chk(m21.alloc(nn)); chk(m12.alloc(1)); chk(result.alloc(2));
+  if (e == hipSuccess && n) chk(hipMemcpy(k.p, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+  if (e == hipSuccess && n_queries) chk(hipMemcpy(q.p, queries, (size_t)n_queries * 5 * sizeof(float), hipMemcpyHostToDevice));
+  InitArgs a{};
+  a.k2 = k.p; a.n2 = n; a.n1 = 0;
+  a.minX = min_x; a.minY = min_y;
+  a.invW = 64.f / (max_x - min_x);
+  a.invH = 48.f / (max_y - min_y);
+  a.cellStart = cellStart.p; a.cellItems = cellItems.p; a.matchedDist = mdist.p; a.matches21 = m21.p;
+  a.matches12 = m12.p; a.result = result.p; a.candOff = qOff.p; a.candCap = 1 << 30;
+  int total = 0;
+  if (e == hipSuccess) chk(launch_grid_build(a, nullptr));
+  if (e == hipSuccess && n_queries) {
+    chk(launch_area_query(a, q.p, n_queries, qOff.p, nullptr, 0, nullptr));
+    a.n1 = n_queries;  // k_init_scan scans candOff[0..n1)
+    if (e == hipSuccess) chk(launch_scan_offsets(a, nullptr));
+    if (e == hipSuccess) chk(hipDeviceSynchronize());
+    if (e == hipSuccess) chk(hipMemcpy(&total, qOff.p + n_queries, sizeof(int), hipMemcpyDeviceToHost));
+    if (e == hipSuccess) chk(hipMemcpy(offsets, qOff.p, (size_t)(n_queries + 1) * sizeof(int), hipMemcpyDeviceToHost));
+    if (e == hipSuccess && total > 0 && indices && total <= indices_cap) {
+      chk(out.alloc(total));
+      if (e == hipSuccess) chk(launch_area_query(a, q.p, n_queries, qOff.p, out.p, 1, nullptr));
+      if (e == hipSuccess) chk(hipDeviceSynchronize());
+      if (e == hipSuccess) chk(hipMemcpy(indices, out.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost));
+    }
+  }
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess && grid_cell_start)
+    chk(hipMemcpy(grid_cell_start, cellStart.p, (64 * 48 + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess && grid_items && n) chk(hipMemcpy(grid_items, cellItems.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  k.free(); q.free(); cellStart.free(); cellItems.free(); qOff.free(); out.free(); mdist.free(); m21.free(); m12.free();
+  result.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (indices && total > indices_cap) return fail(ORBX_E_CAPACITY, "indices buffer too small");
+  return total;
+}
+
+namespace {
+int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
+                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                              uint8_t* occupied, int32_t* match) {
+  const int mode = points ? 1 : 0;
+  if (n == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, choice, flags;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  const int nm = std::max(n_points, 1);
+  // inputs in one packed upload; occupied | result | match are contiguous so that they come back in one copy
+  Pack pk;
+  const size_t oK = pk.add(kps_un, (size_t)n * sizeof(orbx_keypoint)), oD = pk.add(desc, (size_t)n * 32);
+  const size_t oUr = pk.add(u_right, (size_t)n * sizeof(float));
+  const size_t oSf = pk.add(scale_factors, (size_t)std::max(nlevels, 1) * sizeof(float));
+  const size_t oMp = pk.add(mode == 0 && n_points ? map_points : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
+  const size_t oPp = pk.add(mode == 1 && n_points ? points : nullptr, (size_t)nm * sizeof(orbx_projected_point));
+  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
+  struct { uint8_t* p; } d{pk.ptr<uint8_t>(oD)}, occ{pk.ptr<uint8_t>(oOcc)};
+  struct { float* p; } ur{pk.ptr<float>(oUr)}, sf{pk.ptr<float>(oSf)};
+  struct { orbx_map_point_view* p; } mp{pk.ptr<orbx_map_point_view>(oMp)};
+  struct { orbx_projected_point* p; } pp{pk.ptr<orbx_projected_point>(oPp)};
+  struct { int* p; } mt{pk.ptr<int>(oMt)}, result{pk.ptr<int>(oRes)};
+  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40));
+  chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
+  chk(candOff.alloc(nm + 1)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
+  ProjArgs a{};
+  a.grid.k2 = k.p; a.grid.n2 = n; a.grid.n1 = 0;
+  a.grid.minX = min_x; a.grid.minY = min_y;
+  a.grid.invW = 64.f / (max_x - min_x);
+  a.grid.invH = 48.f / (max_y - min_y);
+  a.grid.cellStart = cellStart.p; a.grid.cellItems = cellItems.p; a.grid.matchedDist = mdist.p; a.grid.matches21 = m21.p;
+  a.grid.matches12 = m12.p; a.grid.result = result.p; a.grid.candOff = candOff.p; a.grid.candCap = 1 << 30;
+  a.desc = d.p; a.uRight = u_right ? ur.p : nullptr; a.scale = sf.p; a.mps = mp.p; a.pts = pp.p; a.nmp = n_points;
+  a.mode = mode; a.checkOri = check_ori;
+  a.th = th; a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
+  a.occupied = occ.p; a.match = mt.p; a.candOff = candOff.p; a.result = result.p; a.candCap = 1 << 30;
+  int total = 0, res[2] = {0, 0};
+  if (e == hipSuccess) chk(launch_proj_count(a, nullptr));
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  if (e == hipSuccess && n_points) chk(hipMemcpy(&total, candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
+  if (e == hipSuccess) {
+    chk(candIdx.alloc((size_t)std::max(total, 1)));
+    chk(candDist.alloc((size_t)std::max(total, 1)));
+    a.candIdx = candIdx.p; a.candDist = candDist.p; a.candCap = std::max(total, 1);
+  }
+  a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.choice = choice.p; a.flags = flags.p;
+  // Resolve: rounds of the parallel fixed-point iteration (k_proj_round) until a round changes nothing; the one-wave
+  // serial walk stays as the fallback for a pathological claim chain (ORBX_PROJ_SERIAL=1 forces it, for the tests).
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  if (e == hipSuccess) chk(launch_proj_cands_fill(a, nullptr));
+  bool done = false;
+  if (!forceSerial && n_points > 0) {
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_proj_rounds(a, r, 4, nullptr));
+      int changed = 1;
+      if (e == hipSuccess) chk(hipMemcpy(&changed, flags.p, sizeof(int), hipMemcpyDeviceToHost));  // synchronises
+      done = changed == 0;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_proj_finish(a, 0, nullptr) : launch_proj_resolve_serial(a, nullptr));
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(occupied, h, n);
+      std::memcpy(res, h + (oRes - oOcc), sizeof(res));
+      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+    }
+  }
+  pk.release(); cellStart.free(); cellItems.free();
+  candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); m12.free();
+  taker0.free(); taker1.free(); choice.free(); flags.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return res[0];
+}
+}  // namespace
+
+int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                              int n, float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                              int nlevels, const orbx_map_point_view* map_points, int n_map_points, float th,
+                              int far_points, float th_far_points, float nnratio, uint8_t* occupied, int32_t* match) {
+  if (n < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors || (n && (!kps_un || !desc || !occupied || !match)) ||
+      (n_map_points && !map_points))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_map_points; i++)
+    if (map_points[i].predicted_level < 0 || map_points[i].predicted_level >= nlevels)
+      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+  static const orbx_map_point_view dummy{};
+  return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels,
+                                   map_points ? map_points : &dummy, nullptr, n_map_points, th, far_points,
+                                   th_far_points, nnratio, 0, occupied, match);
+}
+
+int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right,
+                                    int n, float min_x, float min_y, float max_x, float max_y,
+                                    const orbx_projected_point* points, int n_points, int check_orientation,
+                                    uint8_t* occupied, int32_t* match) {
+  if (n < 0 || n_points < 0 || (n && (!kps_un || !desc || !occupied || !match)) || (n_points && !points))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_points > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 projected points");
+  static const orbx_projected_point dummy{};
+  return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
+                                   points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
+}
+
+namespace {
+// One side (left or right camera) of a stereo-fisheye projection search: grid + candidate lists on the device.
+struct ProjSide {
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, result;
+  orbx_map_point_view* mpp = nullptr;  // views of this camera inside the call's packed upload
+  orbx_projected_point* ppp = nullptr;
+  ProjArgs a{};
+  void release() {
+    cellStart.free(); cellItems.free(); candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
+    m12.free(); result.free();
+  }
+};
+
+int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
+                                      const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, int n_points,
+                                      float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                                      const int32_t* l2r, const int32_t* r2l, uint8_t* occupied, int32_t* match) {
+  const int mode = ptsL ? 1 : 0, n = n_left + n_right;
+  if (n == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ProjSide S[2];
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  const int nm = std::max(n_points, 1);
+  // one packed upload of every input (both cameras' views included); occupied | result | match come back in one copy
+  Pack pk;
+  const size_t oK = pk.add(kps, (size_t)n * sizeof(orbx_keypoint)), oD = pk.add(desc, (size_t)n * 32);
+  const size_t oSf = pk.add(scale_factors, (size_t)std::max(nlevels, 1) * sizeof(float));
+  const size_t oA12 = pk.add(n_left ? l2r : nullptr, (size_t)std::max(n_left, 1) * 4);
+  const size_t oA21 = pk.add(n_right ? r2l : nullptr, (size_t)std::max(n_right, 1) * 4);
+  size_t oMp[2], oPp[2];
+  for (int side = 0; side < 2; side++) {
+    oMp[side] = pk.add(n_points && mode == 0 ? (side ? viewsR : viewsL) : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
+    oPp[side] = pk.add(n_points && mode == 1 ? (side ? ptsR : ptsL) : nullptr, (size_t)nm * sizeof(orbx_projected_point));
+  }
+  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
+  chk(pk.commit());
+  struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
+  struct { uint8_t* p; } d{pk.ptr<uint8_t>(oD)}, occ{pk.ptr<uint8_t>(oOcc)};
+  struct { float* p; } sf{pk.ptr<float>(oSf)};
+  struct { int* p; } a12{pk.ptr<int>(oA12)}, a21{pk.ptr<int>(oA21)}, mt{pk.ptr<int>(oMt)}, res{pk.ptr<int>(oRes)};
+  for (int side = 0; side < 2 && e == hipSuccess; side++) {
+    ProjSide& P = S[side];
+    const int ns = side ? n_right : n_left, first = side ? n_left : 0;
+    chk(P.cellStart.alloc(64 * 48 + 1)); chk(P.cellItems.alloc(std::max(ns, 1))); chk(P.candOff.alloc(nm + 1));
+    chk(P.mdist.alloc(std::max(ns, 1))); chk(P.m21.alloc(std::max(ns, 1))); chk(P.m12.alloc(1)); chk(P.result.alloc(2));
+    P.mpp = pk.ptr<orbx_map_point_view>(oMp[side]);
+    P.ppp = pk.ptr<orbx_projected_point>(oPp[side]);
+    ProjArgs& a = P.a;
+    a.grid.k2 = k.p + first; a.grid.n2 = ns; a.grid.n1 = 0;
+    a.grid.minX = min_x; a.grid.minY = min_y;
+    a.grid.invW = 64.f / (max_x - min_x);
+    a.grid.invH = 48.f / (max_y - min_y);
+    a.grid.cellStart = P.cellStart.p; a.grid.cellItems = P.cellItems.p; a.grid.matchedDist = P.mdist.p;
+    a.grid.matches21 = P.m21.p; a.grid.matches12 = P.m12.p; a.grid.result = P.result.p; a.grid.candOff = P.candOff.p;
+    a.grid.candCap = 1 << 30;
+    a.desc = d.p + (size_t)first * 32; a.uRight = nullptr;  // no mvuRight gate when F.Nleft != -1 (:90, :1667)
+    a.scale = sf.p; a.mps = P.mpp; a.pts = P.ppp; a.nmp = n_points; a.mode = mode; a.checkOri = check_ori;
+    a.th = side ? 1.0f : th;  // the right-camera radius is not scaled by th (:144)
+    a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
+    a.occupied = occ.p + first; a.match = mt.p + first; a.candOff = P.candOff.p; a.result = P.result.p; a.candCap = 1 << 30;
+    if (ns > 0) chk(launch_proj_count(a, nullptr));
+    else chk(hipMemset(P.candOff.p, 0, (size_t)(nm + 1) * sizeof(int)));
+  }
+  if (e == hipSuccess) chk(hipDeviceSynchronize());
+  for (int side = 0; side < 2 && e == hipSuccess; side++) {
+    ProjSide& P = S[side];
+    int total = 0;
+    if (n_points) chk(hipMemcpy(&total, P.candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
+    chk(P.candIdx.alloc((size_t)std::max(total, 1)));
+    chk(P.candDist.alloc((size_t)std::max(total, 1)));
+    P.a.candIdx = P.candIdx.p; P.a.candDist = P.candDist.p; P.a.candCap = std::max(total, 1);
+    if (e == hipSuccess && (side ? n_right : n_left) > 0) chk(launch_proj_cands_fill(P.a, nullptr));
+  }
+  ProjFeArgs f{};
+  f.offL = S[0].candOff.p; f.idxL = S[0].candIdx.p; f.distL = S[0].candDist.p;
+  f.offR = S[1].candOff.p; f.idxR = S[1].candIdx.p; f.distR = S[1].candDist.p;
+  f.nLeft = n_left; f.n = n; f.nmp = n_points; f.mode = mode; f.checkOri = check_ori; f.nnratio = nnratio;
+  f.mps = S[0].mpp; f.pts = S[0].ppp; f.kps = k.p; f.l2r = a12.p; f.r2l = a21.p;
+  f.occupied = occ.p; f.match = mt.p; f.result = res.p;
+  int result[2] = {0, 0};
+  // parallel fixed-point rounds (k_proj_round_fe); the serial walk is the fallback (writer-list overflow, no convergence
+  // within 48 rounds) and the ORBX_PROJ_SERIAL=1 cross-check
+  ScratchBuf<int4> wr0, wr1;
+  ScratchBuf<int> wl0, wl1, wc0, wc1, fl;
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  bool done = false;
+  int lastRound = 0;
+  if (!forceSerial && n_points > 0) {
+    chk(wr0.alloc(nm)); chk(wr1.alloc(nm)); chk(wl0.alloc((size_t)n * kFeWriters)); chk(wl1.alloc((size_t)n * kFeWriters));
+    chk(wc0.alloc(n)); chk(wc1.alloc(n)); chk(fl.alloc(40));
+    f.writes[0] = wr0.p; f.writes[1] = wr1.p; f.writers[0] = wl0.p; f.writers[1] = wl1.p;
+    f.nwriters[0] = wc0.p; f.nwriters[1] = wc1.p; f.flags = fl.p;
+    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
+      chk(launch_proj_rounds_fisheye(f, r, 4, nullptr));
+      int st[2] = {1, 0};
+      if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
+      if (st[1]) break;  // a slot collected more than kFeWriters writers in one round
+      done = st[0] == 0;
+      lastRound = r + 3;
+    }
+  }
+  if (e == hipSuccess) chk(done ? launch_proj_finish_fisheye(f, lastRound, nullptr) : launch_proj_resolve_fisheye(f, nullptr));
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      std::memcpy(occupied, h, n);
+      std::memcpy(result, h + (oRes - oOcc), sizeof(int));
+      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+    }
+  }
+  wr0.free(); wr1.free(); wl0.free(); wl1.free(); wc0.free(); wc1.free(); fl.free();
+  pk.release();
+  S[0].release(); S[1].release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return result[0];
+}
+}  // namespace
+
+int orbx_search_by_projection_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* map_points,
+                                      const orbx_map_point_right* map_points_right, int n_map_points, float th,
+                                      int far_points, float th_far_points, float nnratio, const int32_t* left_to_right,
+                                      const int32_t* right_to_left, uint8_t* occupied, int32_t* match) {
+  const int n = n_left + n_right;
+  if (n_left < 0 || n_right < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors ||
+      (n && (!kps || !desc || !occupied || !match)) || (n_map_points && (!map_points || !map_points_right)) ||
+      (n_left && !left_to_right) || (n_right && !right_to_left))
+    return fail(ORBX_E_BADARG, "bad argument");
+  for (int i = 0; i < n_left; i++)
+    if (left_to_right[i] < -1 || left_to_right[i] >= n_right) return fail(ORBX_E_BADARG, "left_to_right entry out of range");
+  for (int i = 0; i < n_right; i++)
+    if (right_to_left[i] < -1 || right_to_left[i] >= n_left) return fail(ORBX_E_BADARG, "right_to_left entry out of range");
+  // the right camera as a second list of views: (mTrackProjXR, mTrackProjYR), mTrackViewCosR, mnTrackScaleLevelR
+  std::vector<orbx_map_point_view> left(map_points, map_points + n_map_points), right(map_points, map_points + n_map_points);
+  for (int i = 0; i < n_map_points; i++) {
+    const orbx_map_point_right& r = map_points_right[i];
+    if ((left[i].in_view && (left[i].predicted_level < 0 || left[i].predicted_level >= nlevels)) ||
+        (r.in_view_r && (r.predicted_level_r < -1 || r.predicted_level_r >= nlevels)))
+      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+    if (!left[i].in_view) left[i].predicted_level = 0;
+    right[i].proj_x = map_points[i].proj_xr;
+    right[i].proj_y = r.proj_yr;
+    right[i].view_cos = r.view_cos_r;
+    right[i].predicted_level = r.predicted_level_r < 0 ? 0 : r.predicted_level_r;
+    right[i].in_view = (r.in_view_r && r.predicted_level_r != -1) ? 1 : 0;  // :141-143
+    // `if (!mbTrackInView && !mbTrackInViewR) continue` (:54) is implied: both lists stay empty
+  }
+  static const orbx_map_point_view dummy{};
+  return search_by_projection_fisheye_impl(device, kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, scale_factors, nlevels,
+                                           n_map_points ? left.data() : &dummy, n_map_points ? right.data() : &dummy, nullptr,
+                                           nullptr, n_map_points, th, far_points, th_far_points, nnratio, 0, left_to_right,
+                                           right_to_left, occupied, match);
+}
+
+int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left,
+                                            int n_right, float min_x, float min_y, float max_x, float max_y,
+                                            const orbx_projected_point* points, const float* uv_right, int n_points,
+                                            int check_orientation, uint8_t* occupied, int32_t* match) {
+  const int n = n_left + n_right;
+  if (n_left < 0 || n_right < 0 || n_points < 0 || (n && (!kps || !desc || !occupied || !match)) ||
+      (n_points && (!points || !uv_right)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_points > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 projected points");
+  std::vector<orbx_projected_point> right(points, points + n_points);
+  for (int i = 0; i < n_points; i++) {
+    right[i].u = uv_right[2 * i];
+    right[i].v = uv_right[2 * i + 1];
+  }
+  static const orbx_projected_point dummy{};
+  return search_by_projection_fisheye_impl(device, kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
+                                           nullptr, n_points ? points : &dummy, n_points ? right.data() : &dummy, n_points, 1.0f,
+                                           0, 0.f, 0.f, check_orientation, nullptr, nullptr, occupied, match);
+}
+
+}  // extern "C"

@@ -1,0 +1,383 @@
+// orbx_bow.hip — bag of words: DBoW2 transform and ORBmatcher::SearchByBoW.
+#include "orbx_device.h"
+
+namespace orbx {
+
+// ================================================================================================ bag of words
+// TemplatedVocabulary::transform(feature, word, weight, nid, levelsup) (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1202-1250):
+// 16 lanes per feature, lane c scores child c of the current node (ORB vocabularies have k = 10), the first minimum by
+// child order is a min-reduction over (distance << 16 | child position).  L dependent gathers of k x 32 B per feature.
+__global__ __launch_bounds__(256) void k_bow_descend(BowArgs a) {
+  const int img = blockIdx.y, sub = threadIdx.x & 15;
+  const int f = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int nf = a.counts ? a.counts[img] : a.n;
+  if (f >= nf) return;  // whole 16-lane groups leave together
+  const uint32_t* D = reinterpret_cast<const uint32_t*>(a.desc + (long long)img * a.descImgPitch) + (long long)f * 8;
+  uint32_t d[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = D[i];
+  const BowVoc& v = a.voc;
+  const int nidLevel = v.L - a.levelsup;
+  int cur = 0, level = 0, nid = 0;
+  bool nidSet = nidLevel <= 0;
+  for (;;) {
+    const int c0 = v.childStart[cur], c1 = v.childStart[cur + 1];
+    if (c0 == c1) break;  // leaf (the root of a non-empty vocabulary has children)
+    uint32_t best = 0xffffffffu;
+    for (int c = c0 + sub; c < c1; c += 16) {
+      const uint32_t* nd = v.desc + (long long)v.children[c] * 8;
+      best = min(best, ((uint32_t)hamming256(d, nd) << 16) | (uint32_t)(c - c0));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 16));
+    cur = v.children[c0 + (int)(best & 0xffffu)];
+    if (++level == nidLevel) { nid = cur; nidSet = true; }
+  }
+  if (!nidSet) nid = cur;  // a leaf above level L - levelsup: the reference leaves *nid unset
+  if (sub == 0) {
+    const long long o = (long long)img * a.cap + f;
+    a.word[o] = v.wordId[cur];
+    a.weight[o] = v.weight[cur];
+    a.node[o] = nid;
+  }
+}
+
+// Sort of the (key << 16 | index) words: bitonic network over P = 2^k slots in LDS, kBowThreads threads.  A compare-exchange
+// at distance j < 64 stays inside an aligned group of 64 slots, and thread t always owns the pairs of the same groups, so
+// those stages need no workgroup barrier (the wave's own LDS operations are ordered); only the 15 of 66 stages (P = 2048)
+// with j >= 64 do -- the kernel is one workgroup per image and pure latency.
+constexpr int kBowThreads = 1024;
+__device__ __forceinline__ void bow_sort(uint64_t* key, int P) {
+  const int tid = threadIdx.x;
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int q = tid; q < (P >> 1); q += kBowThreads) {
+        // pair q of this stage: t = q with a zero bit inserted at position log2(j).  For j < 64 pair q and slot t share their
+        // aligned group of 32 pairs / 64 slots, i.e. the wave that owned the group in the previous stage owns it again.
+        const int t = ((q & ~(j - 1)) << 1) | (q & (j - 1)), u = t | j;
+        const uint64_t ka = key[t], kb = key[u];
+        if ((ka > kb) == ((t & k) == 0)) { key[t] = kb; key[u] = ka; }
+      }
+      if (j >= 64 || j == 1) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    }
+}
+// rank[t] = number of set flags before slot t (exclusive), returns the total; flag / rank share one LDS int array.
+__device__ __forceinline__ int bow_rank_heads(int* fr, int P, int* wsum) {
+  const int per = max(P / kBowThreads, 1), b = threadIdx.x * per;
+  int s = 0;
+  if (b < P)
+    for (int i = 0; i < per; i++) s += fr[b + i];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < kBowThreads / 64; w++) {
+    if (w < wv) base += wsum[w];
+    total += wsum[w];
+  }
+  int run = base + incl - s;
+  if (b < P)
+    for (int i = 0; i < per; i++) {
+      const int t = fr[b + i];
+      fr[b + i] = run;
+      run += t;
+    }
+  __syncthreads();
+  return total;
+}
+
+// TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) (:1125-1188) after the descents: one block
+// per image.  The std::map semantics become a sort: (word, feature index) pairs ascending give the BowVector's key order and,
+// per word, the reference's additions in feature order (value = w + w + ... sequentially -- every addend of a word is
+// the same idf weight); the L1 / L2 norm is accumulated sequentially in ascending word order like BowVector::normalize,
+// by one thread (values staged in LDS), so the doubles come out bit-identical.  (node, feature index) pairs give the
+// FeatureVector as CSR.
+__global__ __launch_bounds__(kBowThreads) void k_bow_assemble(BowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t bow_smem[];
+  __shared__ int wsum[kBowThreads / 64];
+  __shared__ double normShared;
+  const int img = blockIdx.x, tid = threadIdx.x;
+  const int nf = a.counts ? a.counts[img] : a.n;
+  int P = 128;
+  while (P < nf) P <<= 1;
+  uint64_t* key = reinterpret_cast<uint64_t*>(bow_smem);
+  double* lval = reinterpret_cast<double*>(bow_smem);  // the values of the unique words, once the keys are consumed
+  int* fr = reinterpret_cast<int*>(key + P);
+  const long long o = (long long)img * a.cap;
+  const int* word = a.word + o;
+  const double* wt = a.weight + o;
+  const int* node = a.node + o;
+  uint32_t* words = a.words + o;
+  double* values = a.values + o;
+  uint32_t* nodes = a.nodes + o;
+  int* nodeStart = a.nodeStart + (long long)img * (a.cap + 1);
+  uint32_t* feats = a.feats + o;
+  const bool additive = a.voc.weighting == 0 || a.voc.weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+  const bool must = a.voc.scoring != 5, l2 = a.voc.scoring == 1;       // mustNormalize (ScoringObject.h:73-90)
+  constexpr uint64_t kNone = ~0ull;
+
+  // ---- BowVector
+  for (int t = tid; t < P; t += kBowThreads)
+    key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)word[t] << 16) | (uint64_t)t : kNone;  // "w > 0: not stopped"
+  __syncthreads();
+  bow_sort(key, P);
+  for (int t = tid; t < P; t += kBowThreads) fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
+  __syncthreads();
+  const int U = bow_rank_heads(fr, P, wsum);
+  double myV[8];  // values of the heads this thread owns (P / kBowThreads <= 8 slots per thread)
+  int myU[8], nMine = 0;
+  for (int t = tid; t < P; t += kBowThreads) {
+    if (key[t] == kNone || (t > 0 && (key[t] >> 16) == (key[t - 1] >> 16))) continue;
+    const double w = wt[key[t] & 0xffff];  // the first feature of the word in feature order
+    double v = w;
+    if (additive)
+      for (int r = t + 1; r < P && (key[r] >> 16) == (key[t] >> 16); r++) v += w;
+    words[fr[t]] = (uint32_t)(key[t] >> 16);
+    myU[nMine] = fr[t];
+    myV[nMine++] = v;
+  }
+  __syncthreads();  // every key has been read: the array now holds the values
+  for (int i = 0; i < nMine; i++) lval[myU[i]] = myV[i];
+  __syncthreads();
+  double scale = 1.0;
+  bool divide = false;
+  if (additive && U > 0 && !must) {
+    scale = (double)U;
+    divide = true;
+  }
+  if (must) {
+    if (tid == 0) {
+      double norm = 0.0;
+      if (!l2) {
+        for (int u = 0; u < U; u++) norm += fabs(lval[u]);
+      } else {
+        for (int u = 0; u < U; u++) norm += lval[u] * lval[u];
+        norm = sqrt(norm);
+      }
+      normShared = norm;
+    }
+    __syncthreads();
+    scale = normShared;
+    divide = scale > 0.0;
+  }
+  for (int u = tid; u < U; u += kBowThreads) values[u] = divide ? lval[u] / scale : lval[u];
+  __syncthreads();
+
+  // ---- FeatureVector
+  for (int t = tid; t < P; t += kBowThreads)
+    key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)node[t] << 16) | (uint64_t)t : kNone;
+  __syncthreads();
+  bow_sort(key, P);
+  int nUsed = 0;
+  for (int t = tid; t < P; t += kBowThreads) {
+    fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
+    nUsed += key[t] != kNone;
+  }
+  __syncthreads();
+  const int V = bow_rank_heads(fr, P, wsum);
+  for (int t = tid; t < P; t += kBowThreads) {
+    if (key[t] == kNone) continue;
+    feats[t] = (uint32_t)(key[t] & 0xffff);
+    if (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16)) {
+      nodes[fr[t]] = (uint32_t)(key[t] >> 16);
+      nodeStart[fr[t]] = t;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) nUsed += __shfl_xor(nUsed, off);
+  __syncthreads();
+  if ((tid & 63) == 0) wsum[tid >> 6] = nUsed;
+  __syncthreads();
+  if (tid == 0) {
+    int used = 0;
+    for (int w = 0; w < kBowThreads / 64; w++) used += wsum[w];
+    nodeStart[V] = used;
+    a.outCounts[img * 3 + 0] = U;
+    a.outCounts[img * 3 + 1] = V;
+    a.outCounts[img * 3 + 2] = used;
+  }
+}
+
+hipError_t launch_bow_transform(const BowArgs& a, int nimg, hipStream_t s) {
+  if (a.n <= 0 || nimg <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_bow_descend, dim3((a.n + 15) / 16, nimg), dim3(256), 0, s, a);
+  int P = 128;
+  while (P < a.n) P <<= 1;
+  const size_t lds = (size_t)P * 12;
+  if (lds > 48 * 1024) {  // up to 96 KB for 8192 features: above the default dynamic-LDS limit
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_assemble), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_bow_assemble, dim3(nimg), dim3(kBowThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:230-404).  Features are only compared inside a shared
+// vocabulary node and a frame feature belongs to one node, so the nodes are independent: one wave per keyframe node finds
+// its partner in the frame's node list (binary search) and walks the node's keyframe features in order, like the reference
+// (the "already matched" gate makes that walk order dependent); its lanes score the node's frame features, best / second
+// by the serial rule (first minimum; an equal later distance becomes the second).  The right-eye branch keeps the
+// reference's "|| true" (:363-365): no ratio test, and only inside "bestDist1 <= TH_LOW".
+constexpr int kBowNodeCap = 4096;  // frame features of one node tracked in LDS (a node above this: serial fallback on lane 0)
+__global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
+  __shared__ uint8_t taken[kBowNodeCap];
+  const int lane = threadIdx.x, ia = blockIdx.x;
+  const uint32_t node = a.kfNodes[ia];
+  int lo = 0, hi = a.nFNodes;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.fNodes[mid] < node) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= a.nFNodes || a.fNodes[lo] != node) return;
+  const int f0 = a.fStart[lo], nfl = a.fStart[lo + 1] - f0;
+  const int k0 = a.kfStart[ia], k1 = a.kfStart[ia + 1];
+  if (nfl > kBowNodeCap) {  // never with a real vocabulary (levelsup 4 of 6: 100 nodes); keep the exact semantics anyway
+    if (lane == 0) a.flags[32] = 1;
+    return;
+  }
+  for (int i = lane; i < nfl; i += 64) taken[i] = 0;
+  __syncthreads();
+  // the node's first 64 frame features stay in registers for the whole walk (a node of a real vocabulary holds ~15)
+  int iF0 = -1;
+  uint32_t fD0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane < nfl) {
+    iF0 = (int)a.fFeat[f0 + lane];
+    const uint32_t* dF = a.fDesc + (long long)iF0 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) fD0[i] = dF[i];
+  }
+  const bool twoEyes = a.nLeftF != -1;
+  int made = 0;
+  for (int kc = k0; kc < k1; kc += 64) {  // keyframe features of the node: 64 at a time into registers, then walked in order
+    int myKF = -1, myValid = 0;
+    uint32_t myD[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kc + lane < k1) {
+      myKF = (int)a.kfFeat[kc + lane];
+      myValid = a.kfValid[myKF];
+      if (myValid) {
+        const uint32_t* dK = a.kfDesc + (long long)myKF * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) myD[i] = dK[i];
+      }
+    }
+    const int cnt = min(64, k1 - kc);
+    for (int c = 0; c < cnt; c++) {
+      if (!__builtin_amdgcn_readlane(myValid, c)) continue;
+      const int iKF = __builtin_amdgcn_readlane(myKF, c);
+      uint32_t d[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d[i] = (uint32_t)__builtin_amdgcn_readlane((int)myD[i], c);
+      // running best / second of the left and the right eye, merged chunk by chunk in list order
+      int b1 = 256, bi = -1, b2 = 256, b1r = 256, bir = -1, b2r = 256;
+      for (int q0 = 0; q0 < nfl; q0 += 64) {
+        const int q = q0 + lane;
+        int dist = 0x7fff, iF = -1;
+        bool right = false;
+        if (q < nfl && !taken[q]) {
+          if (q0 == 0) {
+            iF = iF0;
+            dist = hamming256(d, fD0);
+          } else {
+            iF = (int)a.fFeat[f0 + q];
+            dist = hamming256(d, a.fDesc + (long long)iF * 8);
+          }
+          right = twoEyes && iF >= a.nLeftF;
+        }
+        for (int side = 0; side < (twoEyes ? 2 : 1); side++) {
+          const bool mine = iF >= 0 && right == (side == 1);
+          uint32_t k1st = mine ? ((uint32_t)dist << 8) | (uint32_t)lane : 0xffffffffu;  // first minimum: lower lane = earlier
+          for (int o = 32; o > 0; o >>= 1) k1st = min(k1st, (uint32_t)__shfl_xor((int)k1st, o));
+          uint32_t k2nd = (mine && (k1st & 255u) != (uint32_t)lane) ? (uint32_t)dist : 0xffffffffu;
+          for (int o = 32; o > 0; o >>= 1) k2nd = min(k2nd, (uint32_t)__shfl_xor((int)k2nd, o));
+          if (k1st != 0xffffffffu) {
+            const int c1 = (int)(k1st >> 8), cl = (int)(k1st & 255u), c2 = k2nd == 0xffffffffu ? 256 : (int)k2nd;
+            const int ci = q0 == 0 ? __builtin_amdgcn_readlane(iF0, cl) : (int)a.fFeat[f0 + q0 + cl];
+            int& B1 = side ? b1r : b1; int& BI = side ? bir : bi; int& B2 = side ? b2r : b2;
+            if (c1 < B1) { B2 = min(B1, c2); B1 = c1; BI = ci; }
+            else { B2 = min(B2, c1); }
+          }
+        }
+      }
+      if (b1 <= 50) {  // TH_LOW
+        const bool leftOk = (float)b1 < __fmul_rn(a.nnratio, (float)b2), rightOk = b1r <= 50;
+        if (lane == 0) {
+          for (int side = 0; side < 2; side++) {
+            if (!(side ? rightOk : leftOk)) continue;
+            const int iF = side ? bir : bi;
+            a.match[iF] = iKF;
+            if (a.checkOri) {
+              float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[iF].angle);
+              if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+              int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+              if (bin == 30) bin = 0;
+              a.bin[iF] = bin;
+              atomicAdd(&a.flags[2 + bin], 1);
+            }
+          }
+        }
+        made += (leftOk ? 1 : 0) + (rightOk ? 1 : 0);
+        if (leftOk || rightOk) {  // mark the taken frame features of this node (positions in the node's list)
+          for (int q = lane; q < nfl; q += 64) {
+            const int iF = q < 64 ? iF0 : (int)a.fFeat[f0 + q];
+            if ((leftOk && iF == bi) || (rightOk && iF == bir)) taken[q] = 1;
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+  if (lane == 0 && made) atomicAdd(&a.flags[0], made);
+}
+
+__global__ __launch_bounds__(256) void k_bow_cull(BowMatchArgs a) {  // :384-401 with ComputeThreeMaxima :1920-1955
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < 30; i++) {
+    const int s = a.flags[2 + i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+    ind3 = -1;
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool rem = false;
+  if (i < a.nF && a.match[i] >= 0) {
+    const int bin = a.bin[i];
+    if (bin != ind1 && bin != ind2 && bin != ind3) {
+      a.match[i] = -1;
+      rem = true;
+    }
+  }
+  const uint64_t m = __ballot(rem);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[1], __popcll(m));
+}
+__global__ void k_bow_result(BowMatchArgs a) { a.result[0] = a.flags[32] ? -1 : a.flags[0] - a.flags[1]; }
+__global__ __launch_bounds__(256) void k_bow_match_reset(BowMatchArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.nF) a.match[i] = -1;
+  if (i < 33) a.flags[i] = 0;
+}
+
+hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_bow_match_reset, dim3((max(a.nF, 33) + 255) / 256), dim3(256), 0, s, a);
+  if (a.nKfNodes > 0 && a.nFNodes > 0) hipLaunchKernelGGL(k_bow_match, dim3(a.nKfNodes), dim3(64), 0, s, a);
+  if (a.checkOri && a.nF > 0) hipLaunchKernelGGL(k_bow_cull, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_bow_result, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace orbx

@@ -1,0 +1,1315 @@
+// orbx_guided.hip — grid-guided matchers: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) and the two
+// SearchByProjection flavours (:41-221, :1594-1806), pinhole and stereo-fisheye.
+#include "orbx_device.h"
+
+namespace orbx {
+
+// ================================================================================================ search init
+// Frame grid (64 x 48, PosInGrid rounds to the nearest cell, src/Frame.cc:833-844) as CSR lists with
+// ascending keypoint indices.
+__device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs& a) {
+  const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, a.minX), a.invW));
+  const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, a.minY), a.invH));
+  if (px < 0 || px >= 64 || py < 0 || py >= 48) return -1;
+  return px * 48 + py;
+}
+
+__global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single block
+  // Counting sort of the keypoints by grid cell, ascending keypoint index inside a cell (mGrid[i][j].push_back order,
+  // src/Frame.cc:536-546): count -> block scan -> unordered atomic fill -> per-cell insertion sort of the short lists.
+  __shared__ int cnt[64 * 48];
+  __shared__ int wsum[4];
+  constexpr int kCells = 64 * 48, kPer = kCells / 256;  // 12 consecutive cells per thread
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int c = tid; c < kCells; c += 256) cnt[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < a.n2; i += 256) {
+    const int c = grid_cell(a.k2[i], a);
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  __syncthreads();
+  int local[kPer], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    local[k] = cnt[tid * kPer + k];
+    sum += local[k];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int run = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    a.cellStart[tid * kPer + k] = run;
+    cnt[tid * kPer + k] = run;  // becomes the fill cursor of the cell
+    run += local[k];
+  }
+  if (tid == 255) a.cellStart[kCells] = run;
+  __syncthreads();
+  for (int i = tid; i < a.n2; i += 256) {
+    const int c = grid_cell(a.k2[i], a);
+    if (c >= 0) a.cellItems[atomicAdd(&cnt[c], 1)] = i;
+  }
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {  // cells hold a handful of keypoints: insertion sort, thread per cell
+    const int c = tid * kPer + k;
+    const int b = cnt[c] - local[k];
+    for (int i = 1; i < local[k]; i++) {
+      const int v = a.cellItems[b + i];
+      int j = i - 1;
+      while (j >= 0 && a.cellItems[b + j] > v) {
+        a.cellItems[b + j + 1] = a.cellItems[b + j];
+        j--;
+      }
+      a.cellItems[b + j + 1] = v;
+    }
+  }
+  for (int i = tid; i < a.n2; i += 256) {
+    a.matchedDist[i] = 0x7FFFFFFF;
+    a.matches21[i] = -1;
+  }
+  for (int i = tid; i < a.n1; i += 256) a.matches12[i] = -1;
+  if (tid == 0) {
+    a.result[0] = 0;
+    a.result[1] = 0;
+  }
+}
+
+// GetFeaturesInArea(x, y, r, 0, 0) (src/Frame.cc:765-831) for one level-0 keypoint of F1 per wave, in the
+// reference's candidate order (ix outer, iy inner, in-cell order).  pass 0 counts, pass 1 writes (i2, dist).
+__global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  const orbx_keypoint k1 = a.k1[i1];
+  int total = 0;
+  if (k1.octave <= 0) {
+    const float x = a.prev[2 * i1], y = a.prev[2 * i1 + 1], r = (float)a.window;
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
+    const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.minX), r), a.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.minY), r), a.invH)));
+    const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
+    if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+      uint32_t d1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(a.d1)[(long long)i1 * 8 + i];
+      const int wbase = pass ? a.candOff[i1] : 0;
+      for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+          const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
+          for (int base = b; base < e; base += 64) {
+            const int j = base + lane;
+            bool ok = false;
+            int i2 = 0;
+            if (j < e) {
+              i2 = a.cellItems[j];
+              const orbx_keypoint k2 = a.k2[i2];
+              ok = k2.octave == 0 && fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+            }
+            const uint64_t m = __ballot(ok);
+            if (pass && ok) {
+              const int o = wbase + total + prefix_count(m);
+              if (o < a.candCap) {
+                a.candIdx[o] = i2;
+                a.candDist[o] = hamming256(d1, reinterpret_cast<const uint32_t*>(a.d2) + (long long)i2 * 8);
+              }
+            }
+            total += __popcll(m);
+          }
+        }
+    }
+  }
+  if (!pass && lane == 0) a.candOff[i1] = total;
+}
+
+__global__ __launch_bounds__(256) void k_init_scan(InitArgs a) {  // single block: exclusive scan of candOff
+  __shared__ int tsum[256];
+  const int tid = threadIdx.x, n = a.n1;
+  const int per = (n + 255) >> 8, b = min(tid * per, n), e = min(b + per, n);
+  int s = 0;
+  for (int i = b; i < e; i++) s += a.candOff[i];
+  tsum[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int t = tid >= d ? tsum[tid - d] : 0;
+    __syncthreads();
+    tsum[tid] += t;
+    __syncthreads();
+  }
+  int run = tid ? tsum[tid - 1] : 0;
+  for (int i = b; i < e; i++) {
+    const int t = a.candOff[i];
+    a.candOff[i] = run;
+    run += t;
+  }
+  if (tid == 255) {
+    a.candOff[n] = tsum[255];
+    if (tsum[255] > a.candCap) a.result[1] = tsum[255];
+  }
+}
+
+// The greedy bookkeeping (vMatchedDistance gate, match stealing, rotation histogram) is order dependent:
+// one wave walks i1 in serial order, the lanes reduce each keypoint's candidate list.
+__global__ __launch_bounds__(64) void k_init_resolve(InitArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int8_t* bins = reinterpret_cast<int8_t*>(smem);  // n1 entries: histogram bin of i1 or -1
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
+  for (int i = lane; i < a.n1; i += 64) bins[i] = -1;
+  __syncthreads();
+  int nmatches = 0;
+  for (int i1 = 0; i1 < a.n1; i1++) {
+    const int b = a.candOff[i1], e = a.candOff[i1 + 1];
+    if (e <= b) continue;
+    // best = first strict minimum in list order; second = second order statistic (strict updates)
+    uint64_t best = ~0ull;  // (dist << 32 | position)
+    for (int j = b + lane; j < e; j += 64) {
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (a.matchedDist[i2] <= d) continue;
+      const uint64_t v = ((uint64_t)(uint32_t)d << 32) | (uint32_t)(j - b);
+      best = v < best ? v : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t t = __shfl_xor((unsigned long long)best, o);
+      best = t < best ? t : best;
+    }
+    if (best == ~0ull) continue;
+    const int bestDist = (int)(best >> 32), bestPos = (int)(best & 0xFFFFFFFFu);
+    int second = 0x7FFFFFFF;
+    for (int j = b + lane; j < e; j += 64) {
+      if (j - b == bestPos) continue;
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (a.matchedDist[i2] <= d) continue;
+      second = min(second, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+    if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)second, a.nnratio)) {
+      if (lane == 0) {
+        const int bestIdx2 = a.candIdx[b + bestPos];
+        const int owner = a.matches21[bestIdx2];
+        if (owner >= 0) {
+          a.matches12[owner] = -1;
+          nmatches--;
+        }
+        a.matches12[i1] = bestIdx2;
+        a.matches21[bestIdx2] = i1;
+        a.matchedDist[bestIdx2] = bestDist;
+        nmatches++;
+        if (a.checkOri) {
+          float rot = __fsub_rn(a.k1[i1].angle, a.k2[bestIdx2].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          bins[i1] = (int8_t)bin;
+          hist[bin]++;
+        }
+      }
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  nmatches = __shfl(nmatches, 0);
+  if (a.checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {  // ComputeThreeMaxima, src/ORBmatcher.cc:1920-1955
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < a.n1; i += 64) {
+      const int bn = bins[i];
+      if (bn >= 0 && bn != ind1 && bn != ind2 && bn != ind3 && a.matches12[i] >= 0) {
+        a.matches12[i] = -1;
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  __syncthreads();
+  for (int i = lane; i < a.n1; i += 64) {
+    const int m = a.matches12[i];
+    if (m >= 0) {
+      a.prev[2 * i] = a.k2[m].x;
+      a.prev[2 * i + 1] = a.k2[m].y;
+    }
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+// Frame::GetFeaturesInArea (src/Frame.cc:765-831) for a batch of queries (x, y, r, minLevel, maxLevel): one wave
+// per query walks the cells in the reference's order (ix outer, iy inner, in-cell order).  pass 0 counts,
+// pass 1 writes the indices at qOff[q].
+__global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __restrict__ q, int nq,
+                                                    int* __restrict__ qOff, int* __restrict__ out, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= nq) return;
+  const float x = q[5 * qi], y = q[5 * qi + 1], r = q[5 * qi + 2];
+  const int minLevel = (int)q[5 * qi + 3], maxLevel = (int)q[5 * qi + 4];
+  const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+  int total = 0;
+  const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, a.minX), r), a.invW)));
+  const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
+  if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+    const int wbase = pass ? qOff[qi] : 0;
+    for (int ix = cx0; ix <= cx1; ix++)
+      for (int iy = cy0; iy <= cy1; iy++) {
+        const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
+        for (int base = b; base < e; base += 64) {
+          const int j = base + lane;
+          bool ok = false;
+          int i2 = 0;
+          if (j < e) {
+            i2 = a.cellItems[j];
+            const orbx_keypoint k2 = a.k2[i2];
+            ok = !(checkLevels && (k2.octave < minLevel || (maxLevel >= 0 && k2.octave > maxLevel))) &&
+                 fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+          }
+          const uint64_t m = __ballot(ok);
+          if (pass && ok) out[wbase + total + prefix_count(m)] = i2;
+          total += __popcll(m);
+        }
+      }
+  }
+  if (!pass && lane == 0) qOff[qi] = total;
+}
+
+hipError_t launch_grid_build(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s) {
+  if (nq > 0) hipLaunchKernelGGL(k_area_query, dim3((nq + 3) / 4), dim3(256), 0, s, a, q, nq, qOff, out, pass);
+  return hipGetLastError();
+}
+hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s) {  // exclusive scan of a.candOff[0..n1] (n1 = #queries)
+  hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  if (a.n1 > 0) {
+    hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+// ---- SearchForInitialization: the greedy walk as a parallel fixed-point iteration ------------------------------------------
+// vMatchedDistance[i2] seen by keypoint i1 = the distance of the LAST claim on i2 by a keypoint < i1 (claims on one i2
+// strictly decrease, :665), so the walk is the unique fixed point of "claim[i1] = best candidate under the gates given
+// the claims of all i1' < i1".  Rounds re-evaluate every i1 against the previous round's claims (per i2 the list of
+// claimers, at most kFeWriters) until a round changes nothing; overflow or no convergence -> k_init_resolve.
+__device__ __forceinline__ int init_matched_dist(const InitArgs& a, int prev, int round_no, int i2, int i1) {
+  int lw = -1, ld = 0x7FFFFFFF;
+  if (round_no > 0) {
+    const int c = min(a.nclaimers[prev][i2], kFeWriters);
+    for (int e = 0; e < c; e++) {
+      const int2 w = a.claimers[prev][i2 * kFeWriters + e];
+      if (w.x < i1 && w.x > lw) {
+        lw = w.x;
+        ld = w.y;
+      }
+    }
+  }
+  return ld;
+}
+
+__global__ __launch_bounds__(256) void k_init_round(InitArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i1 >= a.n1) return;
+  const int b = a.candOff[i1], e = a.candOff[i1 + 1];
+  int2 cl = {-1, 0};
+  if (e > b) {
+    uint64_t best = ~0ull;  // (dist << 32 | position)
+    for (int j = b + lane; j < e; j += 64) {
+      const int i2 = a.candIdx[j], d = a.candDist[j];
+      if (init_matched_dist(a, prev, round_no, i2, i1) <= d) continue;
+      const uint64_t v = ((uint64_t)(uint32_t)d << 32) | (uint32_t)(j - b);
+      best = v < best ? v : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t t = __shfl_xor((unsigned long long)best, o);
+      best = t < best ? t : best;
+    }
+    if (best != ~0ull) {
+      const int bestDist = (int)(best >> 32), bestPos = (int)(best & 0xFFFFFFFFu);
+      int second = 0x7FFFFFFF;
+      for (int j = b + lane; j < e; j += 64) {
+        if (j - b == bestPos) continue;
+        const int i2 = a.candIdx[j], d = a.candDist[j];
+        if (init_matched_dist(a, prev, round_no, i2, i1) <= d) continue;
+        second = min(second, d);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+      if (bestDist <= 50 && (float)bestDist < __fmul_rn((float)second, a.nnratio)) {
+        cl.x = a.candIdx[b + bestPos];
+        cl.y = bestDist;
+      }
+    }
+  }
+  if (lane == 0) {
+    const int2 o = a.claim[prev][i1];
+    if (round_no == 0 || o.x != cl.x || o.y != cl.y) a.flags[0] = 1;
+    a.claim[prev ^ 1][i1] = cl;
+    if (cl.x >= 0) {
+      const int pos = atomicAdd(&a.nclaimers[prev ^ 1][cl.x], 1);
+      if (pos < kFeWriters) a.claimers[prev ^ 1][cl.x * kFeWriters + pos] = make_int2(i1, cl.y);
+      else a.flags[1] = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_init_reset(InitArgs a, int which, int first) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) {
+    a.nclaimers[which][i] = 0;
+    if (first) a.matches21[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 34) {
+    if (threadIdx.x == 0) a.flags[0] = 0;
+    else if (first) a.flags[threadIdx.x] = 0;
+  }
+}
+
+__device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
+  float rot = __fsub_rn(a.k1[i1].angle, a.k2[i2].angle);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+__global__ __launch_bounds__(256) void k_init_owner(InitArgs a, int last) {  // vnMatches21 = the last claimer; votes
+  const int i1 = blockIdx.x * 256 + threadIdx.x;
+  if (i1 >= a.n1) return;
+  const int2 cl = a.claim[last][i1];
+  if (cl.x < 0) return;
+  atomicMax(&a.matches21[cl.x], i1);
+  if (a.checkOri) atomicAdd(&a.flags[4 + init_bin(a, i1, cl.x)], 1);  // stolen matches stay in rotHist (:712-719)
+}
+
+__global__ __launch_bounds__(256) void k_init_finish(InitArgs a, int last) {
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  if (a.checkOri) {
+    for (int i = 0; i < 30; i++) {
+      const int s = a.flags[4 + i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+  }
+  const int i1 = blockIdx.x * 256 + threadIdx.x;
+  int kept = 0;
+  if (i1 < a.n1) {
+    const int2 cl = a.claim[last][i1];
+    int m = -1;
+    if (cl.x >= 0 && a.matches21[cl.x] == i1) {  // not stolen by a later keypoint
+      m = cl.x;
+      if (a.checkOri) {
+        const int bin = init_bin(a, i1, cl.x);
+        if (bin != ind1 && bin != ind2 && bin != ind3) m = -1;
+      }
+    }
+    a.matches12[i1] = m;
+    if (m >= 0) {
+      kept = 1;
+      a.prev[2 * i1] = a.k2[m].x;
+      a.prev[2 * i1 + 1] = a.k2[m].y;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+  if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&a.flags[2], kept);
+}
+
+__global__ void k_init_result(InitArgs a) { a.result[0] = a.flags[2]; }
+
+hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s) {
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  return hipGetLastError();
+}
+hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s) {
+  const int gb = (a.n2 + 255) / 256 > 0 ? (a.n2 + 255) / 256 : 1;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;
+    hipLaunchKernelGGL(k_init_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_init_round, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s) {
+  const int last = (last_round & 1) ^ 1;
+  hipLaunchKernelGGL(k_init_owner, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_init_finish, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);
+  return hipGetLastError();
+}
+
+// ================================================================================================ projection
+// ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:41-221), pinhole case.
+// Per map point the candidate list (GetFeaturesInArea order, level filter, stereo-consistency filter) and the
+// Hamming distances do not depend on the evolving F.mvpMapPoints, so they are produced in parallel (one wave per
+// map point); only the occupancy gate + best / second-best + assignment is walked serially in iMP order.
+__device__ __forceinline__ bool proj_active(const orbx_map_point_view& mp, const ProjArgs& a, float& radius) {
+  if (!mp.in_view) return false;
+  if (a.far && mp.track_depth > a.thFar) return false;
+  if (mp.bad) return false;
+  float r = ((double)mp.view_cos > 0.998) ? 2.5f : 4.0f;  // RadiusByViewingCos, :223-228
+  if ((double)a.th != 1.0) r = __fmul_rn(r, a.th);
+  radius = __fmul_rn(r, a.scale[mp.predicted_level]);
+  return true;
+}
+
+// One query per point, common to both SearchByProjection flavours.
+struct ProjQuery {
+  float x, y, ur, r;
+  int minLevel, maxLevel;
+  const uint8_t* desc;
+};
+__device__ __forceinline__ bool proj_query(const ProjArgs& a, int im, ProjQuery& q) {
+  if (a.mode == 0) {
+    const orbx_map_point_view& mp = a.mps[im];
+    if (!proj_active(mp, a, q.r)) return false;
+    q.x = mp.proj_x;
+    q.y = mp.proj_y;
+    q.ur = mp.proj_xr;
+    q.minLevel = mp.predicted_level - 1;
+    q.maxLevel = mp.predicted_level;
+    q.desc = mp.desc;
+    return true;
+  }
+  const orbx_projected_point& p = a.pts[im];
+  if (!p.valid) return false;
+  q.x = p.u;
+  q.y = p.v;
+  q.ur = p.ur;
+  q.r = p.radius;
+  q.minLevel = p.min_level;
+  q.maxLevel = p.max_level;
+  q.desc = p.desc;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  const InitArgs& g = a.grid;
+  ProjQuery q;
+  int total = 0;
+  if (proj_query(a, im, q)) {
+    const float x = q.x, y = q.y, r = q.r;
+    const int minLevel = q.minLevel, maxLevel = q.maxLevel;
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+      uint32_t d1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(q.desc)[i];
+      const int wbase = pass ? a.candOff[im] : 0;
+      for (int ix = cx0; ix <= cx1; ix++)
+        for (int iy = cy0; iy <= cy1; iy++) {
+          const int b = g.cellStart[ix * 48 + iy], e = g.cellStart[ix * 48 + iy + 1];
+          for (int base = b; base < e; base += 64) {
+            const int j = base + lane;
+            bool ok = false;
+            int i2 = 0, oct = 0;
+            if (j < e) {
+              i2 = g.cellItems[j];
+              const orbx_keypoint k2 = g.k2[i2];
+              oct = k2.octave;
+              ok = !(checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) &&
+                   fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+              if (ok && a.uRight) {  // stereo consistency, :97-100 / :1666-1670
+                const float ur = a.uRight[i2];
+                if (ur > 0 && fabsf(__fsub_rn(q.ur, ur)) > r) ok = false;
+              }
+            }
+            const uint64_t m = __ballot(ok);
+            if (pass && ok) {
+              const int o = wbase + total + prefix_count(m);
+              if (o < a.candCap) {
+                a.candIdx[o] = i2;
+                a.candDist[o] = (hamming256(d1, reinterpret_cast<const uint32_t*>(a.desc) + (long long)i2 * 8) << 8) | oct;
+              }
+            }
+            total += __popcll(m);
+          }
+        }
+    }
+  }
+  if (!pass && lane == 0) a.candOff[im] = total;
+}
+
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* binIdx = reinterpret_cast<int*>(smem);  // mode 1: (bin << 24 | keypoint index) per accepted match, in order
+  const int lane = threadIdx.x;
+  for (int i = lane; i < a.grid.n2; i += 64) a.match[i] = -1;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
+  __syncthreads();
+  int nmatches = 0, nBin = 0;
+  for (int im = 0; im < a.nmp; im++) {
+    const int b = a.candOff[im], e = a.candOff[im + 1];
+    if (e <= b) continue;
+    // two smallest (dist, position) among the candidates whose keypoint is still free == the reference's
+    // best / second-best tracking with strict '<' updates
+    uint64_t best = ~0ull, second = ~0ull;  // (dist << 40) | (position << 8) | octave
+    for (int j = b + lane; j < e; j += 64) {
+      if (a.occupied[a.candIdx[j]]) continue;
+      const int dv = a.candDist[j];
+      const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+      if (v < best) {
+        second = best;
+        best = v;
+      } else if (v < second) {
+        second = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+      // merge two sorted pairs (best <= second, ob <= os): new best = min, new second = second smallest of the four
+      const uint64_t nb = best < ob ? best : ob;
+      const uint64_t mx = best < ob ? ob : best;
+      const uint64_t ms = second < os ? second : os;
+      second = mx < ms ? mx : ms;
+      best = nb;
+    }
+    if (best == ~0ull) continue;
+    const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
+    bool accept = false;
+    if (bestDist <= 100) {  // TH_HIGH
+      if (a.mode == 0) {
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
+        accept = !reject && (bestLevel != bestLevel2 || (float)bestDist <= lim);
+      } else {
+        accept = true;
+      }
+    }
+    if (accept) {
+      if (lane == 0) {
+        const int bestIdx = a.candIdx[b + bestPos];
+        a.match[bestIdx] = im;
+        a.occupied[bestIdx] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+        if (a.mode == 1 && a.checkOri) {
+          float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[bestIdx].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          binIdx[nBin] = (bin << 24) | bestIdx;
+          hist[bin]++;
+        }
+      }
+      nBin++;
+      nmatches++;
+      __threadfence_block();
+    }
+    __syncthreads();
+  }
+  if (a.mode == 1 && a.checkOri) {  // rotation-consistency cull, :1780-1800 (+ ComputeThreeMaxima :1920-1955)
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < nBin; i += 64) {
+      const int bn = binIdx[i] >> 24, idx = binIdx[i] & 0xFFFFFF;
+      if (bn != ind1 && bn != ind2 && bn != ind3) {
+        a.match[idx] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL (even if a later point re-took the slot)
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+// ---- parallel resolve ------------------------------------------------------------------------------------------------
+// The serial walk (point im sees the keypoints claimed by points < im) is the unique fixed point of
+//   choice[im] = best candidate among keypoints k with !occupied0[k] and no accepted, observed point im' < im with
+//                choice[im'] == k.
+// Round r evaluates every point in parallel against the claims of round r - 1 (taker[k] = smallest claiming point
+// index).  By induction point t is final after round t + 1, and a round that changes nothing has reached the fixed
+// point, which is the serial result; on real inputs a handful of rounds suffice (a claim only matters when two points
+// compete for one keypoint).  Wave per point.
+__global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  const int* takerPrev = a.taker[prev];
+  int* takerNew = a.taker[prev ^ 1];
+  const int b = a.candOff[im], e = a.candOff[im + 1];
+  uint64_t best = ~0ull, second = ~0ull;  // (dist << 40) | (position << 8) | octave
+  for (int j = b + lane; j < e; j += 64) {
+    const int idx = a.candIdx[j];
+    if (a.occupied[idx] || (round_no > 0 && takerPrev[idx] < im)) continue;
+    const int dv = a.candDist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+  int chosen = -1;
+  if (best != ~0ull) {
+    const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
+    bool accept = false;
+    if (bestDist <= 100) {  // TH_HIGH
+      if (a.mode == 0) {
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        const bool reject = bestLevel == bestLevel2 && (float)bestDist > lim;
+        accept = !reject && (bestLevel != bestLevel2 || (float)bestDist <= lim);
+      } else {
+        accept = true;
+      }
+    }
+    if (accept) chosen = a.candIdx[b + bestPos];
+  }
+  if (lane == 0) {
+    if (round_no == 0 || a.choice[im] != chosen) a.flags[0] = 1;
+    a.choice[im] = chosen;
+    if (chosen >= 0 && (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations))
+      atomicMin(&takerNew[chosen], im);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a, int which, int first) {  // taker[which] = +inf
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.grid.n2; i += gridDim.x * 256) {
+    a.taker[which][i] = 0x7FFFFFFF;
+    if (first) a.match[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 33) {
+    if (threadIdx.x == 0) a.flags[0] = 0;                 // "changed in this round"
+    else if (first) a.flags[threadIdx.x] = 0;             // accepted, removed, histogram
+  }
+}
+
+// After convergence: match[k] = the LAST point that chose k (later assignments overwrite), occupied[k] = that point's
+// observation flag, orientation histogram of the accepted pairs (mode 1).
+__global__ __launch_bounds__(256) void k_proj_assign(ProjArgs a) {
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  bool acc = false;
+  if (im < a.nmp) {
+    const int k = a.choice[im];
+    if (k >= 0) {
+      acc = true;
+      atomicMax(&a.match[k], im);
+      if (a.mode == 1 && a.checkOri) {
+        float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[k].angle);
+        if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+        int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+        if (bin == 30) bin = 0;
+        atomicAdd(&a.flags[3 + bin], 1);
+      }
+    }
+  }
+  const uint64_t m = __ballot(acc);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[1], __popcll(m));
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull(ProjArgs a) {
+  // occupied: set by the last chooser (a keypoint whose first chooser has observations has no later chooser)
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.grid.n2; k += gridDim.x * 256) {
+    const int im = a.match[k];
+    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-consistency cull (:1780-1800, :1920-1955)
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < 30; i++) {
+    const int s = a.flags[3 + i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+    ind3 = -1;
+  }
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  bool rem = false;
+  if (im < a.nmp) {
+    const int k = a.choice[im];
+    if (k >= 0) {
+      float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[k].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      if (bin != ind1 && bin != ind2 && bin != ind3) {
+        a.match[k] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL, even if a later point re-took the slot
+        rem = true;
+      }
+    }
+  }
+  const uint64_t m = __ballot(rem);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[2], __popcll(m));
+}
+
+__global__ void k_proj_result(ProjArgs a) { a.result[0] = a.flags[1] - a.flags[2]; }
+
+hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s) {
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  return hipGetLastError();
+}
+hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s) {
+  if (a.nmp <= 0) return hipSuccess;
+  const int gb = (a.grid.n2 + 255) / 256;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;  // round r reads taker[r & 1] (claims of round r - 1) and writes taker[(r & 1) ^ 1]
+    hipLaunchKernelGGL(k_proj_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_proj_round, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s) {
+  (void)last_round;
+  if (a.nmp > 0) {
+    hipLaunchKernelGGL(k_proj_assign, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_proj_cull, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, a);
+    if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull2, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(k_proj_result, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s) {
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---- stereo-fisheye resolve (F.Nleft != -1) ------------------------------------------------------------------------------
+// best / second-best (dist << 40 | position << 8 | octave) over the still-free candidates of one point, all lanes.
+__device__ __forceinline__ void proj_best2(const int* off, const int* idx, const int* dist, const uint8_t* occ, int im, int lane,
+                                           uint64_t& best, uint64_t& second, int& b) {
+  b = off[im];
+  const int e = off[im + 1];
+  best = ~0ull;
+  second = ~0ull;
+  for (int j = b + lane; j < e; j += 64) {
+    if (occ[idx[j]]) continue;
+    const int dv = dist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_proj_resolve_fe(ProjFeArgs a) {
+  __shared__ int hist[30];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* binIdx = reinterpret_cast<int*>(smem);  // mode 1: (bin << 24 | slot) per accepted match
+  const int lane = threadIdx.x;
+  for (int i = lane; i < a.n; i += 64) a.match[i] = -1;
+  for (int i = lane; i < 30; i += 64) hist[i] = 0;
+  __syncthreads();
+  int nmatches = 0, nBin = 0;
+  const uint8_t* occL = a.occupied;
+  const uint8_t* occR = a.occupied + a.nLeft;
+  for (int im = 0; im < a.nmp; im++) {
+    const uint8_t obs = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+    auto assign = [&](int slot) {  // F.mvpMapPoints[slot] = pMP (lane 0 writes; the barrier below publishes it)
+      if (lane == 0) {
+        a.match[slot] = im;
+        a.occupied[slot] = obs;
+      }
+    };
+    auto vote = [&](int slot) {
+      if (a.mode == 1 && a.checkOri) {
+        if (lane == 0) {
+          float rot = __fsub_rn(a.pts[im].angle, a.kps[slot].angle);
+          if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+          int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+          if (bin == 30) bin = 0;
+          binIdx[nBin] = (bin << 24) | slot;
+          hist[bin]++;
+        }
+        nBin++;
+      }
+    };
+    bool skipRight = false;
+    // ---- left camera (:60-138 / :1639-1701)
+    if (a.offL[im + 1] > a.offL[im]) {
+      uint64_t best, second;
+      int b;
+      proj_best2(a.offL, a.idxL, a.distL, occL, im, lane, best, second, b);
+      if (best != ~0ull && (int)(best >> 40) <= 100) {
+        const int bestDist = (int)(best >> 40), bestIdx = a.idxL[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+        if (a.mode == 0) {
+          const int bestLevel = (int)(best & 0xFF);
+          const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+          const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+          const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+          if (bestLevel == bestLevel2 && (float)bestDist > lim) {
+            skipRight = true;  // `continue`, :120
+          } else if (bestLevel != bestLevel2 || (float)bestDist <= lim) {
+            assign(bestIdx);
+            nmatches++;
+            const int partner = a.l2r[bestIdx];
+            if (partner != -1) {
+              assign(partner + a.nLeft);
+              nmatches++;
+            }
+          }
+        } else {
+          assign(bestIdx);
+          nmatches++;
+          vote(bestIdx);
+        }
+      }
+    } else if (a.mode == 1) {
+      skipRight = true;  // `if (vIndices2.empty()) continue;`, :1651
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- right camera (:141-213 / :1703-1775)
+    if (!skipRight && a.offR[im + 1] > a.offR[im]) {
+      uint64_t best, second;
+      int b;
+      proj_best2(a.offR, a.idxR, a.distR, occR, im, lane, best, second, b);
+      if (best != ~0ull && (int)(best >> 40) <= 100) {
+        const int bestDist = (int)(best >> 40), bestIdx = a.idxR[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+        bool accept = true;
+        if (a.mode == 0) {
+          const int bestLevel = (int)(best & 0xFF);
+          const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+          const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+          accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2));
+        }
+        if (accept) {
+          if (a.mode == 0) {
+            const int partner = a.r2l[bestIdx];
+            if (partner != -1) {
+              assign(partner);
+              nmatches++;
+            }
+          }
+          assign(bestIdx + a.nLeft);
+          nmatches++;
+          if (a.mode == 1) vote(bestIdx + a.nLeft);
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (a.mode == 1 && a.checkOri) {
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {
+      const int s = hist[i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = lane; i < nBin; i += 64) {
+      const int bn = binIdx[i] >> 24, slot = binIdx[i] & 0xFFFFFF;
+      if (bn != ind1 && bn != ind2 && bn != ind3) {
+        a.match[slot] = -1;
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    nmatches -= removed;
+  }
+  if (lane == 0) a.result[0] = nmatches;
+}
+
+// ---- stereo-fisheye resolve as a parallel fixed-point iteration ---------------------------------------------------------
+// Slot occupancy is a last-writer relation here (the stereo-partner assignments overwrite unconditionally):
+//   occupied(s, im) = has_observations[last point < im that wrote s], or the initial flag if there is none.
+// Round r evaluates every point in parallel against the writes of round r - 1 (every slot keeps the list of points that
+// wrote it, at most kFeWriters; an overflow sends the call to the serial walk).  Point t is final after round t + 1 and a
+// round that reproduces the previous writes is the serial result, exactly as in k_proj_round.
+__device__ __forceinline__ bool fe_occupied(const ProjFeArgs& a, int prev, int round_no, int s, int im) {
+  int lw = -1;
+  if (round_no > 0) {
+    const int c = min(a.nwriters[prev][s], kFeWriters);
+    for (int e = 0; e < c; e++) {
+      const int w = a.writers[prev][s * kFeWriters + e];
+      if (w < im && w > lw) lw = w;
+    }
+  }
+  if (lw < 0) return a.occupied[s] != 0;
+  return (a.mode == 0 ? a.mps[lw].has_observations : a.pts[lw].has_observations) != 0;
+}
+
+__device__ __forceinline__ void fe_best2(const ProjFeArgs& a, int prev, int round_no, const int* off, const int* idx,
+                                         const int* dist, int slot0, int im, int lane, uint64_t& best, uint64_t& second,
+                                         int& b) {
+  b = off[im];
+  const int e = off[im + 1];
+  best = ~0ull;
+  second = ~0ull;
+  for (int j = b + lane; j < e; j += 64) {
+    if (fe_occupied(a, prev, round_no, slot0 + idx[j], im)) continue;
+    const int dv = dist[j];
+    const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - b) << 8) | (uint32_t)(dv & 0xFF);
+    if (v < best) {
+      second = best;
+      best = v;
+    } else if (v < second) {
+      second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+    const uint64_t nb = best < ob ? best : ob;
+    const uint64_t mx = best < ob ? ob : best;
+    const uint64_t ms = second < os ? second : os;
+    second = mx < ms ? mx : ms;
+    best = nb;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int prev, int round_no) {
+  const int lane = threadIdx.x & 63;
+  const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (im >= a.nmp) return;
+  int4 w = {-1, -1, -1, -1};
+  bool skipRight = false;
+  if (a.offL[im + 1] > a.offL[im]) {
+    uint64_t best, second;
+    int b;
+    fe_best2(a, prev, round_no, a.offL, a.idxL, a.distL, 0, im, lane, best, second, b);
+    if (best != ~0ull && (int)(best >> 40) <= 100) {
+      const int bestDist = (int)(best >> 40), bestIdx = a.idxL[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+      if (a.mode == 0) {
+        const int bestLevel = (int)(best & 0xFF);
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        const float lim = __fmul_rn(a.nnratio, (float)bestDist2);
+        if (bestLevel == bestLevel2 && (float)bestDist > lim) {
+          skipRight = true;
+        } else if (bestLevel != bestLevel2 || (float)bestDist <= lim) {
+          w.x = bestIdx;
+          const int partner = a.l2r[bestIdx];
+          if (partner != -1) w.y = partner + a.nLeft;
+        }
+      } else {
+        w.x = bestIdx;
+      }
+    }
+  } else if (a.mode == 1) {
+    skipRight = true;
+  }
+  if (!skipRight && a.offR[im + 1] > a.offR[im]) {
+    // the right search of point im sees im's own left-camera writes only through slots it cannot select (a left slot,
+    // or the partner of the left best: that right slot now holds im itself, i.e. occupied iff im has observations)
+    uint64_t best, second;
+    int b;
+    const int bb = a.offR[im], ee = a.offR[im + 1];
+    best = ~0ull;
+    second = ~0ull;
+    const bool selfObs = (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations) != 0;
+    b = bb;
+    for (int j = bb + lane; j < ee; j += 64) {
+      const int s = a.nLeft + a.idxR[j];
+      const bool occ = (s == w.y) ? selfObs : fe_occupied(a, prev, round_no, s, im);
+      if (occ) continue;
+      const int dv = a.distR[j];
+      const uint64_t v = ((uint64_t)(uint32_t)(dv >> 8) << 40) | ((uint64_t)(uint32_t)(j - bb) << 8) | (uint32_t)(dv & 0xFF);
+      if (v < best) {
+        second = best;
+        best = v;
+      } else if (v < second) {
+        second = v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = __shfl_xor((unsigned long long)best, o), os = __shfl_xor((unsigned long long)second, o);
+      const uint64_t nb = best < ob ? best : ob;
+      const uint64_t mx = best < ob ? ob : best;
+      const uint64_t ms = second < os ? second : os;
+      second = mx < ms ? mx : ms;
+      best = nb;
+    }
+    if (best != ~0ull && (int)(best >> 40) <= 100) {
+      const int bestDist = (int)(best >> 40), bestIdx = a.idxR[b + (int)((best >> 8) & 0xFFFFFFFFu)];
+      bool accept = true;
+      if (a.mode == 0) {
+        const int bestLevel = (int)(best & 0xFF);
+        const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
+        const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
+        accept = !(bestLevel == bestLevel2 && (float)bestDist > __fmul_rn(a.nnratio, (float)bestDist2));
+      }
+      if (accept) {
+        w.z = bestIdx + a.nLeft;
+        if (a.mode == 0) {
+          const int partner = a.r2l[bestIdx];
+          if (partner != -1) w.w = partner;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    const int4 o = a.writes[prev][im];
+    if (round_no == 0 || o.x != w.x || o.y != w.y || o.z != w.z || o.w != w.w) a.flags[0] = 1;
+    a.writes[prev ^ 1][im] = w;
+    const int ws[4] = {w.x, w.y, w.z, w.w};
+    for (int t = 0; t < 4; t++) {
+      if (ws[t] < 0) continue;
+      bool dup = false;
+      for (int u = 0; u < t; u++) dup = dup || ws[u] == ws[t];
+      if (dup) continue;
+      const int pos = atomicAdd(&a.nwriters[prev ^ 1][ws[t]], 1);
+      if (pos < kFeWriters) a.writers[prev ^ 1][ws[t] * kFeWriters + pos] = im;
+      else a.flags[1] = 1;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_reset_fe(ProjFeArgs a, int which, int first) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    a.nwriters[which][i] = 0;
+    if (first) a.match[i] = -1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 34) {
+    if (threadIdx.x == 0) a.flags[0] = 0;
+    else if (first) a.flags[threadIdx.x] = 0;
+  }
+}
+
+__device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
+  float rot = __fsub_rn(a.pts[im].angle, a.kps[slot].angle);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  return bin;
+}
+
+__global__ __launch_bounds__(256) void k_proj_assign_fe(ProjFeArgs a, int last) {  // last writer wins every slot
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  int nw = 0;
+  if (im < a.nmp) {
+    const int4 w = a.writes[last][im];
+    // order of the serial writes of one point: left best, its partner, [right partner], right best -- a later write of
+    // the same point to the same slot changes nothing (same point index), so only the count matters
+    const int ws[4] = {w.x, w.y, w.w, w.z};
+    for (int t = 0; t < 4; t++)
+      if (ws[t] >= 0) {
+        atomicMax(&a.match[ws[t]], im);
+        nw++;
+      }
+    if (a.mode == 1 && a.checkOri) {
+      if (w.x >= 0) atomicAdd(&a.flags[4 + fe_bin(a, im, w.x)], 1);
+      if (w.z >= 0) atomicAdd(&a.flags[4 + fe_bin(a, im, w.z)], 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nw += __shfl_xor(nw, o);
+  if ((threadIdx.x & 63) == 0 && nw) atomicAdd(&a.flags[2], nw);
+}
+
+__global__ __launch_bounds__(256) void k_proj_occ_fe(ProjFeArgs a) {
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < a.n; k += gridDim.x * 256) {
+    const int im = a.match[k];
+    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_proj_cull_fe(ProjFeArgs a, int last) {
+  int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < 30; i++) {
+    const int s = a.flags[4 + i];
+    if (s > max1) {
+      max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+    } else if (s > max2) {
+      max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+    } else if (s > max3) {
+      max3 = s; ind3 = i;
+    }
+  }
+  if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+    ind3 = -1;
+  }
+  const int im = blockIdx.x * 256 + threadIdx.x;
+  int rem = 0;
+  if (im < a.nmp) {
+    const int4 w = a.writes[last][im];
+    const int ws[2] = {w.x, w.z};
+    for (int t = 0; t < 2; t++)
+      if (ws[t] >= 0) {
+        const int bin = fe_bin(a, im, ws[t]);
+        if (bin != ind1 && bin != ind2 && bin != ind3) {
+          a.match[ws[t]] = -1;
+          rem++;
+        }
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rem += __shfl_xor(rem, o);
+  if ((threadIdx.x & 63) == 0 && rem) atomicAdd(&a.flags[3], rem);
+}
+
+__global__ void k_proj_result_fe(ProjFeArgs a) { a.result[0] = a.flags[2] - a.flags[3]; }
+
+hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s) {
+  if (a.nmp <= 0) return hipSuccess;
+  const int gb = (a.n + 255) / 256;
+  for (int r = first_round; r < first_round + rounds; r++) {
+    const int prev = r & 1;
+    hipLaunchKernelGGL(k_proj_reset_fe, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_proj_round_fe, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s) {
+  const int last = (last_round & 1) ^ 1;  // round r wrote writes[(r & 1) ^ 1]
+  hipLaunchKernelGGL(k_proj_assign_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_proj_occ_fe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
+  hipLaunchKernelGGL(k_proj_result_fe, dim3(1), dim3(1), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s) {
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(2 * a.nmp + 4) * 4 : 16;  // up to two votes per point
+  hipLaunchKernelGGL(k_proj_resolve_fe, dim3(1), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a.grid);
+  if (a.nmp > 0) {
+    hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 0);
+    InitArgs sc = a.grid;  // k_init_scan scans candOff[0 .. n1]
+    sc.candOff = a.candOff;
+    sc.n1 = a.nmp;
+    sc.candCap = 1 << 30;
+    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, sc);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;  // one int per accepted match
+  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace orbx

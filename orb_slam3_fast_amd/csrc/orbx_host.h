@@ -1,0 +1,264 @@
+// orbx_host.h — host-side internals shared by the C-ABI translation units of liborbx (orbx_api*.hip): error state, device
+// buffers, the per-call scratch pool and packed staging, and the extractor handle.
+#ifndef ORBX_HOST_H
+#define ORBX_HOST_H
+#include <memory>
+#include <new>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <mutex>
+#include <vector>
+
+#include "orbx_internal.h"
+
+using namespace orbx;
+
+namespace orbx_host {
+
+
+extern thread_local std::string g_err;  // defined in orbx_api.hip
+inline int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPC(expr)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess)                                                                              \
+      return fail(ORBX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+  } while (0)
+
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(float v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(float v) {
+  int i = cv_round(v);
+  return (short)(i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+inline int align_up(long long v, int a) { return (int)((v + a - 1) / a * a); }
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    free();
+    n = count;
+    if (!count) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// Scratch memory of the one-shot matcher entry points (orbx_bf_knn2, orbx_search_*, orbx_fisheye_stereo_match ...):
+// they need a dozen small device buffers per call, and hipMalloc / hipFree cost more than their kernels.  Blocks are
+// cached per device (size classes: powers of two) and reused; at most kScratchCap bytes stay cached per device.
+class ScratchPool {
+ public:
+  static void* take(size_t bytes, size_t* granted) {
+    size_t cls = 4096;
+    while (cls < bytes) cls <<= 1;
+    *granted = cls;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu());
+      auto& fl = lists()[dev];
+      for (size_t i = 0; i < fl.size(); i++)
+        if (fl[i].first == cls) {
+          void* p = fl[i].second;
+          fl[i] = fl.back();
+          fl.pop_back();
+          cached()[dev] -= cls;
+          return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) return nullptr;
+    return p;
+  }
+  static void give(void* p, size_t cls) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) {
+      std::lock_guard<std::mutex> lk(mu());
+      if (cached()[dev] + cls <= kScratchCap) {
+        lists()[dev].push_back({cls, p});
+        cached()[dev] += cls;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+
+ private:
+  static constexpr int kMaxDev = 64;
+  static constexpr size_t kScratchCap = 256u << 20;
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static std::vector<std::pair<size_t, void*>>* lists() { static std::vector<std::pair<size_t, void*>> l[kMaxDev]; return l; }
+  static size_t* cached() { static size_t c[kMaxDev] = {0}; return c; }
+};
+
+template <class T>
+struct ScratchBuf {  // same face as DevBuf; the caller has made its device current (set_device)
+  T* p = nullptr;
+  size_t n = 0, cls = 0;
+  hipError_t alloc(size_t count) {
+    free();
+    n = count;
+    if (!count) return hipSuccess;
+    p = static_cast<T*>(ScratchPool::take(count * sizeof(T), &cls));
+    return p ? hipSuccess : hipErrorOutOfMemory;
+  }
+  void free() {
+    if (p) ScratchPool::give(p, cls);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// One-shot entry points move a dozen small arrays per call; a synchronous hipMemcpy from pageable memory costs ~10 us
+// each, more than the kernels.  Pack lays the inputs (and the scratch / output areas) of a call out in ONE device block,
+// stages the inputs through a per-thread pinned buffer and uploads them with one asynchronous copy on the null stream,
+// in front of the kernels; outputs come back the same way (one copy of a contiguous output area, then memcpy out).
+class Pack {
+ public:
+  // reserves `bytes` (256-byte aligned); src != nullptr: filled from the host.  All inputs must be added before any
+  // scratch / output area so that one prefix copy covers them.
+  size_t add(const void* src, size_t bytes) {
+    const size_t off = (total_ + 255) & ~(size_t)255;
+    items_.push_back({src, bytes, off});
+    total_ = off + bytes;
+    if (src && bytes) inputEnd_ = total_;
+    return off;
+  }
+  hipError_t commit() {
+    hipError_t e = dev_.alloc(std::max<size_t>(total_, 256));
+    if (e != hipSuccess) return e;
+    if (inputEnd_) {
+      uint8_t* h = pinned(inputEnd_);
+      if (!h) return hipErrorOutOfMemory;
+      for (const Item& it : items_)
+        if (it.src && it.bytes) std::memcpy(h + it.off, it.src, it.bytes);
+      e = hipMemcpyAsync(dev_.p, h, inputEnd_, hipMemcpyHostToDevice, nullptr);
+    }
+    return e;
+  }
+  template <class T>
+  T* ptr(size_t off) const { return reinterpret_cast<T*>(dev_.p + off); }
+  // device [off, off + bytes) -> pinned staging; synchronises the null stream.  The returned pointer is valid until the
+  // thread's next Pack operation.
+  const uint8_t* fetch(size_t off, size_t bytes, hipError_t* e) {
+    uint8_t* h = pinned(std::max<size_t>(bytes, 1));
+    if (!h) { *e = hipErrorOutOfMemory; return nullptr; }
+    *e = hipMemcpyAsync(h, dev_.p + off, bytes, hipMemcpyDeviceToHost, nullptr);
+    if (*e == hipSuccess) *e = hipStreamSynchronize(nullptr);
+    return h;
+  }
+  void release() { dev_.free(); }
+
+ private:
+  struct Item { const void* src; size_t bytes, off; };
+  static uint8_t* pinned(size_t bytes) {
+    thread_local uint8_t* buf = nullptr;
+    thread_local size_t cap = 0;
+    if (bytes > cap) {
+      if (buf) (void)hipHostFree(buf);
+      buf = nullptr;
+      cap = 0;
+      size_t want = 1 << 20;
+      while (want < bytes) want <<= 1;
+      if (hipHostMalloc(reinterpret_cast<void**>(&buf), want, hipHostMallocDefault) != hipSuccess) return nullptr;
+      cap = want;
+    }
+    return buf;
+  }
+  std::vector<Item> items_;
+  size_t total_ = 0, inputEnd_ = 0;
+  ScratchBuf<uint8_t> dev_;
+};
+
+
+int set_device(int device);  // makes `device` current; ORBX_E_NODEVICE without a GPU (there is no host path)
+
+}  // namespace orbx_host
+using namespace orbx_host;
+
+
+// Layout of orbx_extractor::hostResults for the host entry points (one or two images):
+//   [0,16)  counts[2], mono[2]   | keypoints 2 x cap | descriptors 2 x cap x 32 | uRight cap | depth cap
+static inline size_t hr_kps(size_t) { return 64; }
+static inline size_t hr_desc(size_t cap) { return hr_kps(cap) + 2 * cap * sizeof(orbx_keypoint); }
+static inline size_t hr_ur(size_t cap) { return hr_desc(cap) + 2 * cap * 32; }
+static inline size_t hr_depth(size_t cap) { return hr_ur(cap) + cap * sizeof(float); }
+static inline size_t host_results_bytes(size_t cap) { return hr_depth(cap) + cap * sizeof(float) + 64; }
+
+struct orbx_extractor {
+  orbx_params prm{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  int maxW = 0, maxH = 0, maxB = 0;
+  std::vector<float> scale, inv, sig2, invsig2;
+  std::vector<int> nfeat;
+  int umax[16];
+  Geom g{};
+  Geom gmax{};
+  int curW = 0, curH = 0;
+  Pyr pyr{};
+  int lastN = 0;
+  DevBuf<uint8_t> d_pyr, d_blur, d_stage, d_desc;
+  DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
+  DevBuf<uint16_t> d_knode;
+  DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
+  DevBuf<short> d_xab, d_yab;
+  DevBuf<orbx_keypoint> d_kps;
+  DevBuf<float> d_uR, d_depth;
+  int stagePitch = 0;
+  int stereoPairs = 0;
+  uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
+  // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)
+  hipGraphExec_t graphExec[2] = {nullptr, nullptr};
+  int graphW = 0, graphH = 0;
+  bool graphOff = false;
+  // bag of words of the last extraction (orbx_bow_transform_batch): per-feature word / weight / node, assembled vectors
+  DevBuf<int> d_bowWord, d_bowNode, d_bowStart, d_bowCounts;
+  DevBuf<double> d_bowWeight, d_bowValues;
+  DevBuf<uint32_t> d_bowWords, d_bowNodes, d_bowFeats;
+  int bowImages = 0;
+  DevBuf<int> d_fl2r, d_fr2l, d_fcnt;  // batched fisheye association (orbx_fisheye_stereo_match_batch)
+  DevBuf<float> d_fdepth, d_fp3d;
+  int fisheyePairs = 0, fisheyeCapR = 0;
+  // per-launch HIP event log (orbx_profile_*)
+  bool profiling = false;
+  int profStage = -1;              // >= 0: only launches of this stage are bracketed
+  std::vector<hipEvent_t> evPool;
+  size_t evCursor = 0;
+  struct EvRec { int stage; size_t e0, e1; };
+  std::vector<EvRec> evLog;
+  size_t lastEv = 0;
+  bool lastEvValid = false;
+  hipStream_t stream2 = nullptr;   // side stream: k_blur overlaps detect / quadtree
+  hipEvent_t evPyr = nullptr, evBlur = nullptr, evStart = nullptr, evDet0 = nullptr;
+  hipEvent_t next_event() {
+    if (evCursor == evPool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      evPool.push_back(e);
+    }
+    return evPool[evCursor++];
+  }
+};
+
+namespace orbx_host {
+// the whole extraction pipeline of n device-resident images on ex->stream (orbx_api.hip)
+int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
+                    ptrdiff_t image_pitch, const int32_t* lap);
+}  // namespace orbx_host
+#endif

@@ -1,0 +1,477 @@
+// orbx_preproc.hip — image pre-processing in front of the extractor (gray, resize, cv::remap, CLAHE) and
+// Frame::UndistortKeyPoints (src/Frame.cc:853-919).
+#include "orbx_device.h"
+
+namespace orbx {
+
+// ================================================================================================ pre-processing
+// cvtColor(..., COLOR_*2GRAY) for 8U (OpenCV >= 3.4.2 / 4.x: 15-bit coefficients, one rounding).  Thread per pixel.
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t* __restrict__ src, int w, int h, long long sp, long long sip,
+                                                  int cn, int rgb, uint8_t* __restrict__ dst, long long dp, long long dip) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= w || y >= h) return;
+  const uint8_t* S = src + blockIdx.z * sip + y * sp + (long long)x * cn;
+  const int c0 = S[0], g = S[1], c2 = S[2];
+  const int r = rgb ? c0 : c2, b = rgb ? c2 : c0;
+  dst[blockIdx.z * dip + y * dp + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
+}
+
+// cv::resize INTER_LINEAR 8U on interleaved channels with host-built coefficient tables (the B2 arithmetic of k_resize):
+// thread per destination pixel, all channels.  A once-per-frame convenience kernel, not tiled.
+__global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restrict__ src, int sw, int sh, long long sp,
+                                                        long long sip, int cn, uint8_t* __restrict__ dst, int dw, int dh,
+                                                        long long dp, long long dip, const int* __restrict__ xofs,
+                                                        const short* __restrict__ xab, const int* __restrict__ yofs,
+                                                        const short* __restrict__ yab) {
+  const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+  if (dx >= dw || dy >= dh) return;
+  src += blockIdx.z * sip;
+  dst += blockIdx.z * dip;
+  const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1), a0 = xab[2 * dx], a1 = xab[2 * dx + 1];
+  const int sy = yofs[dy], b0 = yab[2 * dy], b1 = yab[2 * dy + 1];
+  const uint8_t* R0 = src + (long long)min(max(sy, 0), sh - 1) * sp;
+  const uint8_t* R1 = src + (long long)min(max(sy + 1, 0), sh - 1) * sp;
+  for (int c = 0; c < cn; c++) {
+    const int t0 = R0[sx * cn + c] * a0 + R0[sx1 * cn + c] * a1;
+    const int t1 = R1[sx * cn + c] * a0 + R1[sx1 * cn + c] * a1;
+    dst[dy * dp + (long long)dx * cn + c] = (uint8_t)((((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, long long sip, int cn, int rgb, uint8_t* dst,
+                           long long dp, long long dip, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 255) / 256, h, nimg), dim3(256), 0, s, src, w, h, sp, sip, cn, rgb, dst, dp, dip);
+  return hipGetLastError();
+}
+hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, long long sip, int cn, uint8_t* dst, int dw,
+                                 int dh, long long dp, long long dip, const int* xofs, const short* xab, const int* yofs,
+                                 const short* yab, int nimg, hipStream_t s) {
+  hipLaunchKernelGGL(k_resize_generic, dim3((dw + 255) / 256, dh, nimg), dim3(256), 0, s, src, sw, sh, sp, sip, cn, dst, dw, dh,
+                     dp, dip, xofs, xab, yofs, yab);
+  return hipGetLastError();
+}
+
+// cv::remap(src, dst, mapx, mapy, INTER_LINEAR, BORDER_CONSTANT 0) with CV_32FC1 maps on 8UC1/3/4 (src/System.cc:294-295).
+// Fixed point exactly as OpenCV's RemapInvoker / remapBilinear: position = cvRound(map * 32), 5 fraction bits per axis,
+// weights (32-fx)(32-fy)*32 ... (= BilinearTab_i, exact products) except fraction (0,0) whose 32768 saturates to 32767
+// and is repaired on the last tap: {32767, 0, 0, 1}; out = (sum + 2^14) >> 15; taps outside the source are 0.
+// A thread produces 4 consecutive destination pixels: two 16-byte map loads, 4 x 4 byte gathers (the maps are smooth, so a
+// wave's gathers fall into a few cache lines), one dword store for single-channel images.  HBM-bound: 8 B of map per
+// pixel against 1 B read + 1 B written.  Image i of a batch uses map i % nMaps (left / right eye).
+__device__ __forceinline__ int cv_round_sse(float t) {  // cvtss2si: out-of-range and NaN give INT_MIN
+  return fabsf(t) < 2147483648.f ? __float2int_rn(t) : (int)0x80000000;
+}
+__global__ __launch_bounds__(256) void k_remap(RemapArgs a) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
+  if (x0 >= a.dw || y >= a.dh) return;
+  const int m = img % a.nMaps;
+  const float* MX = a.mapx + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  const float* MY = a.mapy + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
+  uint8_t* D = a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + (long long)x0 * a.cn;
+  float mx[4], my[4];
+  const bool full = x0 + 3 < a.dw;
+  if (full && a.mapVec4) {
+    const float4 vx = *reinterpret_cast<const float4*>(MX), vy = *reinterpret_cast<const float4*>(MY);
+    mx[0] = vx.x; mx[1] = vx.y; mx[2] = vx.z; mx[3] = vx.w;
+    my[0] = vy.x; my[1] = vy.y; my[2] = vy.z; my[3] = vy.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = x0 + k < a.dw;
+      mx[k] = in ? MX[k] : 0.f;
+      my[k] = in ? MY[k] : 0.f;
+    }
+  }
+  const int cn = a.cn;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int fsx = cv_round_sse(mx[k] * 32.f), fsy = cv_round_sse(my[k] * 32.f);
+    const int sx = min(max(fsx >> 5, -32768), 32767), sy = min(max(fsy >> 5, -32768), 32767);
+    const int fx = fsx & 31, fy = fsy & 31;
+    int w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+    if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+    const bool x0in = (unsigned)sx < (unsigned)a.sw, x1in = (unsigned)(sx + 1) < (unsigned)a.sw;
+    const bool y0in = (unsigned)sy < (unsigned)a.sh, y1in = (unsigned)(sy + 1) < (unsigned)a.sh;
+    const uint8_t* R0 = S + (long long)sy * a.srcPitch + (long long)sx * cn;
+    const uint8_t* R1 = R0 + a.srcPitch;
+    if (cn == 1) {
+      const int p00 = (x0in && y0in) ? R0[0] : 0, p01 = (x1in && y0in) ? R0[1] : 0;
+      const int p10 = (x0in && y1in) ? R1[0] : 0, p11 = (x1in && y1in) ? R1[1] : 0;
+      const uint32_t r = (uint32_t)(p00 * w0 + p01 * w1 + p10 * w2 + p11 * w3 + 16384) >> 15;
+      packed |= r << (8 * k);
+    } else if (x0 + k < a.dw) {
+      for (int c = 0; c < cn; c++) {
+        const int p00 = (x0in && y0in) ? R0[c] : 0, p01 = (x1in && y0in) ? R0[cn + c] : 0;
+        const int p10 = (x0in && y1in) ? R1[c] : 0, p11 = (x1in && y1in) ? R1[cn + c] : 0;
+        D[k * cn + c] = (uint8_t)((uint32_t)(p00 * w0 + p01 * w1 + p10 * w2 + p11 * w3 + 16384) >> 15);
+      }
+    }
+  }
+  if (cn == 1) {
+    if (full && a.dstVec4) {
+      *reinterpret_cast<uint32_t*>(D) = packed;
+    } else {
+      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+  }
+}
+// Single-channel batches: the images that share a map (image % nMaps) are processed in groups of kRemapGroup by the same
+// thread, so the 8 B / pixel of map data and the fixed-point weights are fetched / built once per group instead of once per
+// image -- the maps, not the pixels, are the kernel's HBM traffic.
+constexpr int kRemapGroup = 8;
+__global__ __launch_bounds__(256) void k_remap1(RemapArgs a, int nimg) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x0 >= a.dw || y >= a.dh) return;
+  const int m = blockIdx.z % a.nMaps, grp = blockIdx.z / a.nMaps;
+  const float* MX = a.mapx + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  const float* MY = a.mapy + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
+  float mx[4], my[4];
+  const bool full = x0 + 3 < a.dw;
+  if (full && a.mapVec4) {
+    const float4 vx = *reinterpret_cast<const float4*>(MX), vy = *reinterpret_cast<const float4*>(MY);
+    mx[0] = vx.x; mx[1] = vx.y; mx[2] = vx.z; mx[3] = vx.w;
+    my[0] = vy.x; my[1] = vy.y; my[2] = vy.z; my[3] = vy.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = x0 + k < a.dw;
+      mx[k] = in ? MX[k] : -8.f;  // outside the source: no loads for the padding lanes
+      my[k] = in ? MY[k] : -8.f;
+    }
+  }
+  // Taps.  Per pixel: the horizontal pair (sx, sx + 1) of source rows sy and sy + 1, addresses clamped into the image;
+  // taps outside the source get weight 0 (BORDER_CONSTANT 0), and when the clamp moved the pair by one column (sx == -1
+  // or sx == sw - 1) the surviving weight moves to the other half of the pair.
+  // The gathers are the cost of this kernel (scattered sub-dword loads run at a few lanes per clock), so the four pixels of
+  // a thread share them: rectification maps are smooth, their 4 x 2 x 2 taps fall into an 8-byte window of three
+  // consecutive source rows, which is fetched with three (unaligned) 8-byte loads; the pairs come out of the window with one
+  // v_perm_b32 each (selector precomputed per pixel).  A thread whose taps do not fit (strong magnification, a seam of the
+  // map) takes the per-pixel path: eight 16-bit loads.  Needs sw >= 8.
+  int off0[4], off1[4];  // byte offsets of the pairs in source rows sy and sy + 1
+  uint32_t wlo[4];       // w0 | w1 << 16
+  uint32_t whi[4];       // w2 | w3 << 16
+  int sxc[4], syc0[4], syc1[4];
+  const int pitch = (int)a.srcPitch;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int fsx = cv_round_sse(mx[k] * 32.f), fsy = cv_round_sse(my[k] * 32.f);
+    const int sx = min(max(fsx >> 5, -32768), 32767), sy = min(max(fsy >> 5, -32768), 32767);
+    const int fx = fsx & 31, fy = fsy & 31;
+    uint32_t w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+    if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+    const bool xin0 = (unsigned)sx < (unsigned)a.sw, xin1 = (unsigned)(sx + 1) < (unsigned)a.sw;
+    const bool yin0 = (unsigned)sy < (unsigned)a.sh, yin1 = (unsigned)(sy + 1) < (unsigned)a.sh;
+    if (!xin0) w0 = w2 = 0;
+    if (!xin1) w1 = w3 = 0;
+    if (!yin0) w0 = w1 = 0;
+    if (!yin1) w2 = w3 = 0;
+    sxc[k] = min(max(sx, 0), a.sw - 2);
+    if (sxc[k] > sx) { w0 = w1; w2 = w3; w1 = w3 = 0; }       // sx == -1 (or further left, all weights already 0)
+    else if (sxc[k] < sx) { w1 = w0; w3 = w2; w0 = w2 = 0; }  // sx == sw - 1 (or further right)
+    wlo[k] = w0 | (w1 << 16);
+    whi[k] = w2 | (w3 << 16);
+    syc0[k] = min(max(sy, 0), a.sh - 1);
+    syc1[k] = min(max(sy + 1, 0), a.sh - 1);
+    off0[k] = syc0[k] * pitch + sxc[k];
+    off1[k] = syc1[k] * pitch + sxc[k];
+  }
+  const int bx = min(min(min(sxc[0], sxc[1]), min(sxc[2], sxc[3])), a.sw - 8);
+  const int by = min(min(syc0[0], syc0[1]), min(syc0[2], syc0[3]));
+  bool fast = true;
+  uint32_t selTop[4], selBot[4];  // v_perm selectors: byte d -> bits 0..7, byte d + 1 -> bits 16..23 of the 8-byte window
+  int e0[4], e1[4];               // window row of the top / bottom pair
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int d = sxc[k] - bx;
+    e0[k] = syc0[k] - by;
+    e1[k] = syc1[k] - by;
+    fast = fast && d <= 6 && e0[k] <= 1 && e1[k] <= 2;
+    selTop[k] = selBot[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
+  }
+  const int wo0 = by * pitch + bx, wo1 = min(by + 1, a.sh - 1) * pitch + bx, wo2 = min(by + 2, a.sh - 1) * pitch + bx;
+  const uint8_t* __restrict__ src = a.src;
+  uint8_t* __restrict__ dst = a.dst;
+  const int first = grp * kRemapGroup, perMap = (nimg - m + a.nMaps - 1) / a.nMaps;
+  const int count = min(kRemapGroup, perMap - first);
+  for (int g = 0; g < count; g++) {
+    const int img = m + a.nMaps * (first + g);
+    const uint8_t* S = src + (long long)img * a.srcImgPitch;
+    uint2 r0, r1, r2;
+    __builtin_memcpy(&r0, S + wo0, 8);
+    __builtin_memcpy(&r1, S + wo1, 8);
+    __builtin_memcpy(&r2, S + wo2, 8);
+    uint32_t packed = 0;
+    if (fast) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t tlo = e0[k] ? r1.x : r0.x, thi = e0[k] ? r1.y : r0.y;
+        const uint32_t blo = e1[k] == 0 ? r0.x : (e1[k] == 1 ? r1.x : r2.x), bhi = e1[k] == 0 ? r0.y : (e1[k] == 1 ? r1.y : r2.y);
+        // two v_dot2_u32_u16: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3); every weight is below 2^15
+        uint32_t acc = udot2_u16(__builtin_amdgcn_perm(thi, tlo, selTop[k]), wlo[k], 16384u);
+        acc = udot2_u16(__builtin_amdgcn_perm(bhi, blo, selBot[k]), whi[k], acc);
+        packed |= (acc >> 15) << (8 * k);
+      }
+    } else {
+      uint16_t t[4], b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        __builtin_memcpy(&t[k], S + off0[k], 2);
+        __builtin_memcpy(&b[k], S + off1[k], 2);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t acc = udot2_u16(__builtin_amdgcn_perm(0u, (uint32_t)t[k], 0x0c010c00u), wlo[k], 16384u);
+        acc = udot2_u16(__builtin_amdgcn_perm(0u, (uint32_t)b[k], 0x0c010c00u), whi[k], acc);
+        packed |= (acc >> 15) << (8 * k);
+      }
+    }
+    uint8_t* D = dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+    if (full && a.dstVec4) {
+      *reinterpret_cast<uint32_t*>(D) = packed;
+    } else {
+      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+  }
+}
+hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s) {
+  if (a.cn == 1 && a.sw >= 8) {
+    const int perMap = (nimg + a.nMaps - 1) / a.nMaps, groups = (perMap + kRemapGroup - 1) / kRemapGroup;
+    hipLaunchKernelGGL(k_remap1, dim3((a.dw + 255) / 256, (a.dh + 3) / 4, a.nMaps * groups), dim3(256), 0, s, a, nimg);
+  } else {
+    hipLaunchKernelGGL(k_remap, dim3((a.dw + 255) / 256, (a.dh + 3) / 4, nimg), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+// cv::CLAHE::apply on 8UC1 (Examples/Stereo/stereo_tum_vi.cc:100,142-143; OpenCV clahe.cpp).  Two kernels:
+//  k_clahe_lut   block per (tile, image): per-wave LDS histograms of the tile (BORDER_REFLECT_101 extension at the right /
+//                bottom when the image does not divide into tiles), clip + redistribution (clipped / 256 to every bin,
+//                one extra count to every (256 / residual)-th bin), block prefix sum, lut = rne(cumsum * 255.f / area);
+//  k_clahe_apply thread per 4 pixels: the float bilinear blend of the four neighbouring tiles' lut entries in
+//                OpenCV's expression order (the TU is built with -ffp-contract=off), rne + saturate.
+// The lut of an image (tilesX * tilesY * 256 B = 16 KB for 8x8) stays in L1 / L2 for the apply pass.
+__global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
+  // 16 histogram copies, copy = lane & 15, stride 257 words: neighbouring pixels carry (nearly) the same grey value, and LDS
+  // atomics on one address retire one lane per clock -- a single copy per wave made flat image regions run 16x slower.
+  __shared__ int hist[16 * 257];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x, img = blockIdx.y;
+  const int ty = tile / a.tilesX, tx = tile - ty * a.tilesX;
+  for (int k = tid; k < 16 * 257; k += 256) hist[k] = 0;
+  __syncthreads();
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
+  // thread per 4 pixels of a tile row (sub-dword loads run at a fraction of the dword rate); quads that touch the tile's right
+  // edge or the reflected extension go pixel by pixel
+  const int qpr = (a.tw + 3) >> 2, nquads = qpr * a.th;
+  const float inv_qpr = 1.0f / (float)qpr;
+  const int hcopy = (lane & 15) * 257;
+  for (int i = tid; i < nquads; i += 256) {
+    int yy = (int)((float)i * inv_qpr);
+    int xq = i - yy * qpr;
+    if (xq < 0) { yy--; xq += qpr; }
+    if (xq >= qpr) { yy++; xq -= qpr; }
+    const int y = ty * a.th + yy, xx = 4 * xq, x = tx * a.tw + xx;
+    if (y < a.h && xx + 3 < a.tw && x + 3 < a.w) {
+      uint32_t q;
+      __builtin_memcpy(&q, S + (long long)y * a.srcPitch + x, 4);
+      atomicAdd(&hist[hcopy + (q & 255)], 1);
+      atomicAdd(&hist[hcopy + ((q >> 8) & 255)], 1);
+      atomicAdd(&hist[hcopy + ((q >> 16) & 255)], 1);
+      atomicAdd(&hist[hcopy + (q >> 24)], 1);
+    } else {
+      int yr = y;
+      while (yr >= a.h || yr < 0) yr = yr < 0 ? -yr : 2 * a.h - 2 - yr;  // reflect 101 (the extension is shorter than the image)
+      for (int k = 0; k < 4 && xx + k < a.tw; k++) {
+        int xr = x + k;
+        while (xr >= a.w || xr < 0) xr = xr < 0 ? -xr : 2 * a.w - 2 - xr;
+        atomicAdd(&hist[hcopy + S[(long long)yr * a.srcPitch + xr]], 1);
+      }
+    }
+  }
+  __syncthreads();
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) v += hist[k * 257 + tid];
+  if (a.clip > 0) {
+    int ex = max(v - a.clip, 0);
+    v -= ex;
+    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
+    if (lane == 0) wsum[wave] = ex;
+    __syncthreads();
+    const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int batch = clipped >> 8, residual = clipped & 255;
+    v += batch;
+    if (residual) {
+      const int step = max(256 / residual, 1);
+      if (tid % step == 0 && tid / step < residual) v++;
+    }
+  }
+  int sum = v;  // inclusive prefix sum over the 256 bins
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(sum, o);
+    if (lane >= o) sum += t;
+  }
+  if (lane == 63) wsum[wave] = sum;
+  __syncthreads();
+  for (int k = 0; k < wave; k++) sum += wsum[k];
+  const int r = __float2int_rn((float)sum * a.lutScale);
+  a.lut[((long long)img * a.tilesX * a.tilesY + tile) * 256 + tid] = (uint8_t)min(max(r, 0), 255);
+}
+
+__global__ __launch_bounds__(256) void k_clahe_apply(ClaheArgs a) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
+  if (x0 >= a.w || y >= a.h) return;
+  const float tyf = (float)y * a.invTh - 0.5f;
+  int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+  const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+  ty1 = max(ty1, 0);
+  ty2 = min(ty2, a.tilesY - 1);
+  const uint8_t* L = a.lut + (long long)img * a.tilesX * a.tilesY * 256;
+  const uint8_t* L1 = L + (long long)ty1 * a.tilesX * 256;
+  const uint8_t* L2 = L + (long long)ty2 * a.tilesX * 256;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch + (long long)y * a.srcPitch + x0;
+  uint8_t* D = a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+  const bool full = x0 + 3 < a.w;
+  uint32_t in4;
+  if (full && a.srcVec4) {
+    in4 = *reinterpret_cast<const uint32_t*>(S);
+  } else {
+    in4 = 0;
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) in4 |= (uint32_t)S[k] << (8 * k);
+  }
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0);
+    tx2 = min(tx2, a.tilesX - 1);
+    const int v = (in4 >> (8 * k)) & 255;
+    const float l11 = (float)L1[tx1 * 256 + v], l12 = (float)L1[tx2 * 256 + v];
+    const float l21 = (float)L2[tx1 * 256 + v], l22 = (float)L2[tx2 * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    const int r = __float2int_rn(res);
+    packed |= (uint32_t)min(max(r, 0), 255) << (8 * k);
+  }
+  if (full && a.dstVec4) {
+    *reinterpret_cast<uint32_t*>(D) = packed;
+  } else {
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) D[k] = (uint8_t)(packed >> (8 * k));
+  }
+}
+// Fast apply pass.  Between the centres of four neighbouring tiles (an "interpolation cell": fixed tx1, tx2, ty1, ty2) the
+// four lut bytes of a grey value can be packed into one dword, so a pixel costs ONE gather instead of four:
+//  k_clahe_pack    cell tables [img][tilesY + 1][tilesX + 1][256] = l11 | l12 << 8 | l21 << 16 | l22 << 24 (81 KB per image
+//                  for 8 x 8 tiles, L2-resident);
+//  k_clahe_apply4  thread per 4 pixels: dword load, 4 x (dword gather, 4 v_cvt_f32_ubyte, blend), dword store.
+// (A variant that staged the cell tables of a row band in LDS was slower: the tables are as large as the slab they serve.)
+__global__ __launch_bounds__(256) void k_clahe_pack(ClaheArgs a, uint32_t* __restrict__ cells) {
+  const int cx = blockIdx.x % (a.tilesX + 1), cy = blockIdx.x / (a.tilesX + 1), img = blockIdx.y, v = threadIdx.x;
+  const int tx1 = max(cx - 1, 0), tx2 = min(cx, a.tilesX - 1), ty1 = max(cy - 1, 0), ty2 = min(cy, a.tilesY - 1);
+  const uint8_t* L = a.lut + (long long)img * a.tilesX * a.tilesY * 256;
+  const uint32_t l11 = L[(ty1 * a.tilesX + tx1) * 256 + v], l12 = L[(ty1 * a.tilesX + tx2) * 256 + v];
+  const uint32_t l21 = L[(ty2 * a.tilesX + tx1) * 256 + v], l22 = L[(ty2 * a.tilesX + tx2) * 256 + v];
+  cells[((long long)img * (a.tilesY + 1) * (a.tilesX + 1) + blockIdx.x) * 256 + v] = l11 | (l12 << 8) | (l21 << 16) | (l22 << 24);
+}
+__global__ __launch_bounds__(256) void k_clahe_apply4(ClaheArgs a, const uint32_t* __restrict__ cells) {
+  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6), img = blockIdx.z;
+  if (x0 >= a.w || y >= a.h) return;
+  const float tyf = (float)y * a.invTh - 0.5f;
+  const int ty1 = (int)floorf(tyf);
+  const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+  const int ncx = a.tilesX + 1;
+  const uint32_t* C = cells + ((long long)img * (a.tilesY + 1) + min(max(ty1 + 1, 0), a.tilesY)) * ncx * 256;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch + (long long)y * a.srcPitch + x0;
+  uint8_t* D = a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+  const bool full = x0 + 3 < a.w;
+  uint32_t in4;
+  if (full && a.srcVec4) {
+    in4 = *reinterpret_cast<const uint32_t*>(S);
+  } else {
+    in4 = 0;
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) in4 |= (uint32_t)S[k] << (8 * k);
+  }
+  uint32_t e[4];
+  float xa[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    const int tx1 = (int)floorf(txf);
+    xa[k] = txf - (float)tx1;
+    e[k] = C[min(max(tx1 + 1, 0), a.tilesX) * 256 + ((in4 >> (8 * k)) & 255)];
+  }
+  uint32_t packed = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float xa1 = 1.0f - xa[k];
+    const float l11 = (float)(e[k] & 255), l12 = (float)((e[k] >> 8) & 255), l21 = (float)((e[k] >> 16) & 255), l22 = (float)(e[k] >> 24);
+    const float res = (l11 * xa1 + l12 * xa[k]) * ya1 + (l21 * xa1 + l22 * xa[k]) * ya;
+    packed |= (uint32_t)min(max(__float2int_rn(res), 0), 255) << (8 * k);
+  }
+  if (full && a.dstVec4) {
+    *reinterpret_cast<uint32_t*>(D) = packed;
+  } else {
+    for (int k = 0; k < 4 && x0 + k < a.w; k++) D[k] = (uint8_t)(packed >> (8 * k));
+  }
+}
+size_t clahe_cells_bytes(const ClaheArgs& a, int nimg) {
+  return (size_t)nimg * (a.tilesY + 1) * (a.tilesX + 1) * 256 * sizeof(uint32_t);
+}
+hipError_t launch_clahe(const ClaheArgs& a, int nimg, uint32_t* cells, hipStream_t s) {
+  hipLaunchKernelGGL(k_clahe_lut, dim3(a.tilesX * a.tilesY, nimg), dim3(256), 0, s, a);
+  const dim3 grid((a.w + 255) / 256, (a.h + 3) / 4, nimg);
+  if (cells) {
+    hipLaunchKernelGGL(k_clahe_pack, dim3((a.tilesX + 1) * (a.tilesY + 1), nimg), dim3(256), 0, s, a, cells);
+    hipLaunchKernelGGL(k_clahe_apply4, grid, dim3(256), 0, s, a, cells);
+  } else {
+    hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+// ================================================================================================ undistort
+// cv::undistortPoints as Frame::UndistortKeyPoints / ComputeImageBounds call it (src/Frame.cc:853-919): double
+// arithmetic in OpenCV's expression order, no contraction (TU flag) -- identical to the oracle's.
+__global__ __launch_bounds__(256) void k_undistort(UndistortArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  double k[12];
+#pragma unroll
+  for (int j = 0; j < 12; j++) k[j] = (double)a.k[j];
+  const double fx = a.K[0], fy = a.K[1], cx = a.K[2], cy = a.K[3];
+  const double ifx = 1. / fx, ify = 1. / fy;
+  const double u = a.in[(long long)i * a.stride], v = a.in[(long long)i * a.stride + 1];
+  double x = (u - cx) * ifx, y = (v - cy) * ify;
+  const double x0 = x, y0 = y;
+  if (a.hasDist) {
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) {
+        x = (u - cx) * ifx;
+        y = (v - cy) * ify;
+        break;
+      }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+  }
+  const double xx = fx * x + 0. * y + cx, yy = 0. * x + fy * y + cy, ww = 1. / (0. * x + 0. * y + 1.);
+  a.out[(long long)i * a.stride] = (float)(xx * ww);
+  a.out[(long long)i * a.stride + 1] = (float)(yy * ww);
+}
+
+hipError_t launch_undistort(const UndistortArgs& a, hipStream_t s) {
+  if (a.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_undistort, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace orbx

@@ -3,7 +3,8 @@
 
 Build the instrumented library first:
   cd orb_slam3_fast_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DOCT_PROF \
-      -shared -o ../liborbx_prof.so orbx_kernels.hip orbx_api.hip -Wl,-rpath,/opt/rocm/lib
+      -shared -o ../liborbx_prof.so orbx_kernels.hip orbx_stereo.hip orbx_guided.hip orbx_preproc.hip orbx_bow.hip orbx_api.hip \
+      -Wl,-rpath,/opt/rocm/lib
 then   ORBX_OCTREE_ABLATE=100 ORBX_SERIAL=1 python tools/octree_prof.py      (100 + pyramid level)
 prints, for image 0, the 10 ns ticks between the MK() markers: gather, roots, then per phase-1 pass
 {count sweep, node loop, scan, node loop, relabel sweep}, per phase-2 round {sort, rest}, final selection.
