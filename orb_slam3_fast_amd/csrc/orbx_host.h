@@ -147,6 +147,7 @@ class Pack {
       for (const Item& it : items_)
         if (it.src && it.bytes) std::memcpy(h + it.off, it.src, it.bytes);
       e = hipMemcpyAsync(dev_.p, h, inputEnd_, hipMemcpyHostToDevice, nullptr);
+      pending_ = true;
     }
     return e;
   }
@@ -159,9 +160,14 @@ class Pack {
     if (!h) { *e = hipErrorOutOfMemory; return nullptr; }
     *e = hipMemcpyAsync(h, dev_.p + off, bytes, hipMemcpyDeviceToHost, nullptr);
     if (*e == hipSuccess) *e = hipStreamSynchronize(nullptr);
+    if (*e == hipSuccess) pending_ = false;
     return h;
   }
-  void release() { dev_.free(); }
+  void release() {  // an error path may leave the upload in flight: the staging buffer is reused by the thread's next call
+    if (pending_) (void)hipStreamSynchronize(nullptr);
+    pending_ = false;
+    dev_.free();
+  }
 
  private:
   struct Item { const void* src; size_t bytes, off; };
@@ -181,6 +187,7 @@ class Pack {
   }
   std::vector<Item> items_;
   size_t total_ = 0, inputEnd_ = 0;
+  bool pending_ = false;
   ScratchBuf<uint8_t> dev_;
 };
 
