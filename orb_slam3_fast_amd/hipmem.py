@@ -24,6 +24,8 @@ def hip():
         _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         _hip.hipFree.argtypes = [C.c_void_p]
         _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+        _hip.hipHostFree.argtypes = [C.c_void_p]
         _hip.hipGetErrorString.restype = C.c_char_p
         _hip.hipGetErrorString.argtypes = [C.c_int]
     return _hip
@@ -62,3 +64,20 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def pinned_like(a):
+    """A page-locked host copy of `a` (hipHostMalloc): uploads from it are plain DMA, not staged through the driver's
+    bounce buffer -- what a capture pipeline gets by registering its frame buffers once.  Tools / tests only: the block
+    stays allocated for the life of the process."""
+    a = np.ascontiguousarray(a)
+    ptr = C.c_void_p()
+    _ck(hip().hipHostMalloc(C.byref(ptr), max(a.nbytes, 1), 0))
+    buf = (C.c_uint8 * max(a.nbytes, 1)).from_address(ptr.value)
+    out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+    out[...] = a
+    _PINNED_BLOCKS.append(ptr)
+    return out
+
+
+_PINNED_BLOCKS = []

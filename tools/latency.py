@@ -58,6 +58,16 @@ for _ in range(reps):
 pair = (time.perf_counter() - t0) / reps * 1e3
 print("%dx%d N=%d  orbx_extract_stereo (both eyes + ComputeStereoMatches, one batched pipeline, one thread): %.3f ms (%.0f fps)"
       % (w, h, nf, pair, 1e3 / pair))
+from orb_slam3_fast_amd.hipmem import pinned_like
+Lp, Rp = pinned_like(L), pinned_like(R)
+for _ in range(5):
+    exP.extract_stereo(Lp, Rp, bf=bf, b=b)
+t0 = time.perf_counter()
+for _ in range(reps):
+    exP.extract_stereo(Lp, Rp, bf=bf, b=b)
+pairp = (time.perf_counter() - t0) / reps * 1e3
+print("%dx%d N=%d  the same with the frames in page-locked host memory (hipHostMalloc / registered capture buffers): %.3f ms (%.0f fps)"
+      % (w, h, nf, pairp, 1e3 / pairp))
 print("%dx%d N=%d  both-eye extraction (2 threads) %.3f +- %.3f ms   stereo match %.3f +- %.3f ms   total %.3f ms (%.0f fps); "
       "one eye alone %.3f ms" % (w, h, nf, ext.mean(), ext.std(), st.mean(), st.std(), (ext + st).mean(),
                                  1e3 / (ext + st).mean(), seq))
