@@ -90,3 +90,70 @@ def test_features_in_area_equals_brute_force_over_the_cells_it_visits(oracle, se
     # grid rounding (PosInGrid rounds to the NEAREST cell) puts them in a cell outside the scanned block
     assert all(inside[i] for i in got) and len(set(got)) == len(got)
     assert len(got) >= 0.7 * int(inside.sum()) - 2
+
+
+# ---- pre-processing and bag of words ----------------------------------------------------------------
+@SET
+@given(st.integers(0, 255), st.integers(9, 40), st.integers(9, 40), st.integers(0, 2 ** 31 - 1))
+def test_remap_keeps_constants_inside_and_zero_outside(oracle, v, w, h, seed):
+    """The four weights of every table entry sum to 2^15, so a constant image stays constant wherever all four taps are
+    inside the source; a map that points beyond the border by more than a pixel gives the border value 0."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), v, np.uint8)
+    mx = rng.uniform(0, w - 1.0001, (11, 13)).astype(np.float32)
+    my = rng.uniform(0, h - 1.0001, (11, 13)).astype(np.float32)
+    sx, sy = np.rint(mx * np.float32(32)).astype(int) >> 5, np.rint(my * np.float32(32)).astype(int) >> 5
+    inside = (sx + 1 < w) & (sy + 1 < h)  # all four taps of the pixel lie in the source
+    out = oracle.remap(img, mx, my)
+    assert (out[inside] == v).all()
+    far = oracle.remap(img, mx + np.float32(w + 2), my)
+    assert not far.any()
+
+
+@SET
+@given(hnp.arrays(np.uint8, st.tuples(st.integers(10, 40), st.integers(10, 40))), st.integers(-6, 6), st.integers(-6, 6))
+def test_remap_integer_translation_is_a_shift(oracle, img, dx, dy):
+    h, w = img.shape
+    u, v = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    out = oracle.remap(img, u + np.float32(dx), v + np.float32(dy))
+    want = np.zeros_like(img)
+    ys, xs = np.arange(h) + dy, np.arange(w) + dx
+    oky, okx = (ys >= 0) & (ys < h), (xs >= 0) & (xs < w)
+    want[np.ix_(oky, okx)] = img[np.ix_(ys[oky], xs[okx])]
+    assert np.array_equal(out, want)
+
+
+@SET
+@given(hnp.arrays(np.uint8, st.tuples(st.integers(16, 48), st.integers(16, 48))), st.sampled_from([0.0, 1.0, 3.0, 40.0]),
+       st.integers(1, 4), st.integers(1, 4))
+def test_clahe_flat_images_stay_flat_and_global_equalisation_preserves_rank(oracle, img, clip, tx, ty):
+    """A flat image has one occupied bin in every tile, so all luts agree on it; with one tile and no clipping CLAHE is
+    plain histogram equalisation, a non-decreasing function of the grey value."""
+    out = oracle.clahe(img, clip, (tx, ty))
+    assert out.shape == img.shape and out.dtype == np.uint8
+    flat = np.full_like(img, int(img[0, 0]))
+    of = oracle.clahe(flat, clip, (tx, ty))
+    assert (of == of[0, 0]).all()
+    if clip == 0.0 and tx == 1 and ty == 1:  # plain global equalisation: rank preserving
+        order = np.argsort(img.ravel(), kind="stable")
+        assert (np.diff(out.ravel()[order].astype(int)) >= 0).all()
+
+
+@SET
+@given(st.integers(0, 2 ** 31 - 1), st.integers(2, 6), st.integers(1, 3), st.integers(0, 4))
+def test_bow_vector_is_invariant_under_feature_permutation(oracle, seed, k, L, levelsup):
+    """A word's value is n sequential additions of the same weight and the norm runs over ascending word ids, so the
+    BowVector does not depend on the order of the features -- bit for bit; the FeatureVector permutes with them."""
+    from orb_slam3_fast_amd import synth
+    cols = synth.make_vocabulary(k, L, seed=seed % 1000, early_leaf_prob=0.1, stop_prob=0.1)
+    voc = oracle.Vocabulary(k, L, *cols)
+    feats = synth.vocabulary_features(cols, 60, seed=seed % 997)
+    perm = np.random.default_rng(seed).permutation(len(feats))
+    (w0, v0), (n0, s0, f0) = voc.transform(feats, levelsup)
+    (w1, v1), (n1, s1, f1) = voc.transform(feats[perm], levelsup)
+    assert np.array_equal(w0, w1) and np.array_equal(v0.view(np.uint64), v1.view(np.uint64))
+    assert np.array_equal(n0, n1) and np.array_equal(s0, s1)
+    for j in range(len(n0)):
+        assert sorted(perm[f1[s1[j]:s1[j + 1]]].tolist()) == f0[s0[j]:s0[j + 1]].tolist()
+    if len(v0):
+        assert abs(v0.sum() - 1.0) < 1e-12 and (v0 > 0).all()
