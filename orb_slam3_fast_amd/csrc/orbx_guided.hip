@@ -14,16 +14,29 @@ __device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs&
   return px * 48 + py;
 }
 
-__global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single block
+constexpr int kGridThreads = 1024;
+__global__ __launch_bounds__(kGridThreads) void k_init_grid(InitArgs a) {  // single block
   // Counting sort of the keypoints by grid cell, ascending keypoint index inside a cell (mGrid[i][j].push_back order,
   // src/Frame.cc:536-546): count -> block scan -> unordered atomic fill -> per-cell insertion sort of the short lists.
+  // One workgroup, pure latency: 1024 threads so that the keypoints are read in one or two trips, and the cell of a
+  // keypoint is kept in a register between the counting and the filling pass.
   __shared__ int cnt[64 * 48];
-  __shared__ int wsum[4];
-  constexpr int kCells = 64 * 48, kPer = kCells / 256;  // 12 consecutive cells per thread
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int c = tid; c < kCells; c += 256) cnt[c] = 0;
+  __shared__ int wsum[kGridThreads / 64];
+  constexpr int kCells = 64 * 48, kPer = kCells / kGridThreads;  // 3 consecutive cells per thread
+  constexpr int kKeep = 4;                                       // cached cells per thread (n2 <= 4096)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int c = tid; c < kCells; c += kGridThreads) cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < a.n2; i += 256) {
+  int mycell[kKeep];
+#pragma unroll
+  for (int j = 0; j < kKeep; j++) {
+    const int i = tid + j * kGridThreads;
+    mycell[j] = i < a.n2 ? grid_cell(a.k2[i], a) : -1;
+  }
+#pragma unroll
+  for (int j = 0; j < kKeep; j++)
+    if (mycell[j] >= 0) atomicAdd(&cnt[mycell[j]], 1);
+  for (int i = tid + kKeep * kGridThreads; i < a.n2; i += kGridThreads) {
     const int c = grid_cell(a.k2[i], a);
     if (c >= 0) atomicAdd(&cnt[c], 1);
   }
@@ -40,19 +53,22 @@ __global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single bloc
     const int t = __shfl_up(incl, d);
     if (lane >= d) incl += t;
   }
-  if (lane == 63) wsum[tid >> 6] = incl;
+  if (lane == 63) wsum[wv] = incl;
   __syncthreads();
   int run = incl - sum;
-  for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+  for (int w = 0; w < wv; w++) run += wsum[w];
 #pragma unroll
   for (int k = 0; k < kPer; k++) {
     a.cellStart[tid * kPer + k] = run;
     cnt[tid * kPer + k] = run;  // becomes the fill cursor of the cell
     run += local[k];
   }
-  if (tid == 255) a.cellStart[kCells] = run;
+  if (tid == kGridThreads - 1) a.cellStart[kCells] = run;
   __syncthreads();
-  for (int i = tid; i < a.n2; i += 256) {
+#pragma unroll
+  for (int j = 0; j < kKeep; j++)
+    if (mycell[j] >= 0) a.cellItems[atomicAdd(&cnt[mycell[j]], 1)] = tid + j * kGridThreads;
+  for (int i = tid + kKeep * kGridThreads; i < a.n2; i += kGridThreads) {
     const int c = grid_cell(a.k2[i], a);
     if (c >= 0) a.cellItems[atomicAdd(&cnt[c], 1)] = i;
   }
@@ -72,11 +88,11 @@ __global__ __launch_bounds__(256) void k_init_grid(InitArgs a) {  // single bloc
       a.cellItems[b + j + 1] = v;
     }
   }
-  for (int i = tid; i < a.n2; i += 256) {
+  for (int i = tid; i < a.n2; i += kGridThreads) {
     a.matchedDist[i] = 0x7FFFFFFF;
     a.matches21[i] = -1;
   }
-  for (int i = tid; i < a.n1; i += 256) a.matches12[i] = -1;
+  for (int i = tid; i < a.n1; i += kGridThreads) a.matches12[i] = -1;
   if (tid == 0) {
     a.result[0] = 0;
     a.result[1] = 0;
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __r
 }
 
 hipError_t launch_grid_build(const InitArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s) {
@@ -316,7 +332,7 @@ hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s) {  // exclusive
 }
 
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a);
   if (a.n1 > 0) {
     hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 0);
     hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
@@ -1294,7 +1310,7 @@ hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(256), 0, s, a.grid);
+  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a.grid);
   if (a.nmp > 0) {
     hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 0);
     InitArgs sc = a.grid;  // k_init_scan scans candOff[0 .. n1]

@@ -330,6 +330,29 @@ def test_features_in_area_and_grid(gpu, oracle):
         assert np.array_equal(got, want)
 
 
+def test_grid_of_a_large_and_a_clustered_keypoint_set(gpu, oracle):
+    """The frame grid beyond the 4096 keypoints k_init_grid keeps in registers, and with everything in a few cells."""
+    w, h = 1000, 700
+    bounds = (0.0, 0.0, float(w), float(h))
+    rng = np.random.default_rng(12)
+    for n, spread in ((7000, None), (5000, 8.0), (4097, None), (1, None)):
+        k = np.zeros(n, orbx.KP_DTYPE)
+        if spread is None:
+            k["x"], k["y"] = rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)
+        else:  # three tight clusters: cells with hundreds of entries (long insertion sorts)
+            c = rng.integers(0, 3, n)
+            k["x"] = np.array([200.0, 640.0, 900.0])[c] + rng.normal(0, spread, n)
+            k["y"] = np.array([150.0, 400.0, 600.0])[c] + rng.normal(0, spread, n)
+        k["octave"] = rng.integers(0, 8, n)
+        q = np.stack([rng.uniform(0, w, 40), rng.uniform(0, h, 40), rng.choice([10.0, 60.0], 40), np.full(40, -1.0),
+                      np.full(40, -1.0)], 1).astype(np.float32)
+        q[0] = (640.0, 400.0, 30.0, -1, -1)
+        res = orbx.GetFeaturesInArea(k, bounds, q)
+        for i in range(len(q)):
+            want = oracle.features_in_area(k, bounds, q[i, 0], q[i, 1], q[i, 2], -1, -1)
+            assert np.array_equal(res[i], want), (n, i)
+
+
 def test_search_by_projection_local_map(gpu, oracle):
     """Widening row f1: SearchByProjection(Frame&, vector<MapPoint*>&) (pinhole), serial iMP semantics."""
     w, h, nf = 752, 480, 1500
