@@ -151,15 +151,13 @@ int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* k
   return n;
 }
 
-int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
-                                   const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
-                                   float min_y, float max_x, float max_y, float* prev_matched,
-                                   int32_t* matches12, int window_size, float nnratio, int check_orientation) {
-  if (n1 < 0 || n2 < 0 || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kps2 || !desc2)))
-    return fail(ORBX_E_BADARG, "bad argument");
-  if (n1 == 0) return 0;
-  int rc = set_device(device);
-  if (rc != ORBX_OK) return rc;
+namespace {
+// One attempt with candidate arrays of cand_cap entries; see search_by_projection_try.
+int search_for_initialization_try(const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const orbx_keypoint* kps2,
+                                  const uint8_t* desc2, int n2, float min_x, float min_y, float max_x, float max_y,
+                                  float* prev_matched, int32_t* matches12, int window_size, float nnratio,
+                                  int check_orientation, int cand_cap, int* needed) {
+  *needed = 0;
   ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -186,18 +184,13 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   a.checkOri = check_orientation;
   a.cellStart = cellStart.p; a.cellItems = cellItems.p; a.candOff = candOff.p;
   a.matchedDist = mdist.p; a.matches21 = m21.p; a.result = result.p;
-  a.candCap = 1 << 30;
-  int total = 0, res[2] = {0, 0};
+  chk(candIdx.alloc((size_t)cand_cap));
+  chk(candDist.alloc((size_t)cand_cap));
+  a.candIdx = candIdx.p;
+  a.candDist = candDist.p;
+  a.candCap = cand_cap;
+  int res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_search_init(a, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess) chk(hipMemcpy(&total, candOff.p + n1, sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) {
-    chk(candIdx.alloc((size_t)std::max(total, 1)));
-    chk(candDist.alloc((size_t)std::max(total, 1)));
-    a.candIdx = candIdx.p;
-    a.candDist = candDist.p;
-    a.candCap = std::max(total, 1);
-  }
   // resolve: parallel fixed-point rounds (k_init_round), serial walk as fallback / ORBX_PROJ_SERIAL=1 cross-check
   ScratchBuf<int2> cl0, cl1, cr0, cr1;
   ScratchBuf<int> nc0, nc1, fl;
@@ -223,9 +216,13 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   if (e == hipSuccess) {
     const uint8_t* h = pk.fetch(oPrev, outBytes, &e);  // synchronises
     if (e == hipSuccess) {
-      std::memcpy(prev_matched, h, (size_t)n1 * 2 * sizeof(float));
       std::memcpy(res, h + (oRes - oPrev), sizeof(res));
-      std::memcpy(matches12, h + (oM12 - oPrev), (size_t)n1 * sizeof(int));
+      if (res[1] > cand_cap) {
+        *needed = res[1];
+      } else {
+        std::memcpy(prev_matched, h, (size_t)n1 * 2 * sizeof(float));
+        std::memcpy(matches12, h + (oM12 - oPrev), (size_t)n1 * sizeof(int));
+      }
     }
   }
   cl0.free(); cl1.free(); cr0.free(); cr1.free(); nc0.free(); nc1.free(); fl.free();
@@ -233,6 +230,28 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
+}
+}  // namespace
+
+int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                   const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
+                                   float min_y, float max_x, float max_y, float* prev_matched,
+                                   int32_t* matches12, int window_size, float nnratio, int check_orientation) {
+  if (n1 < 0 || n2 < 0 || (n1 && (!kps1 || !desc1 || !prev_matched || !matches12)) || (n2 && (!kps2 || !desc2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n1 == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  // first guess: 128 candidates per keypoint (a 100 px window over 1500 level-0 keypoints holds ~60); a denser frame repeats
+  // the call once with the exact size (ORBX_PROJ_CAND_CAP forces that path in the tests)
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  int cap = capEnv > 0 ? capEnv : n1 * 128, needed = 0;
+  rc = search_for_initialization_try(kps1, desc1, n1, kps2, desc2, n2, min_x, min_y, max_x, max_y, prev_matched, matches12,
+                                     window_size, nnratio, check_orientation, cap, &needed);
+  if (rc >= 0 && needed > cap)
+    rc = search_for_initialization_try(kps1, desc1, n1, kps2, desc2, n2, min_x, min_y, max_x, max_y, prev_matched, matches12,
+                                       window_size, nnratio, check_orientation, needed, &needed);
+  return rc;
 }
 
 int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x,
@@ -287,15 +306,16 @@ int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min
 }
 
 namespace {
-int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
-                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
-                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
-                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
-                              uint8_t* occupied, int32_t* match) {
+// One attempt with candidate arrays of cand_cap entries (all candidate lists together).  Nothing synchronises between the
+// upload and the convergence check of the rounds: the lists are counted, scanned and filled back to back; when they did not
+// fit, the kernels worked on truncated lists, *needed reports the size and the outputs are left untouched.
+int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                             float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                             const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
+                             float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                             uint8_t* occupied, int32_t* match, int cand_cap, int* needed) {
   const int mode = points ? 1 : 0;
-  if (n == 0) return 0;
-  int rc = set_device(device);
-  if (rc != ORBX_OK) return rc;
+  *needed = 0;
   ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, choice, flags;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -329,16 +349,12 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   a.desc = d.p; a.uRight = u_right ? ur.p : nullptr; a.scale = sf.p; a.mps = mp.p; a.pts = pp.p; a.nmp = n_points;
   a.mode = mode; a.checkOri = check_ori;
   a.th = th; a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
-  a.occupied = occ.p; a.match = mt.p; a.candOff = candOff.p; a.result = result.p; a.candCap = 1 << 30;
-  int total = 0, res[2] = {0, 0};
+  a.occupied = occ.p; a.match = mt.p; a.candOff = candOff.p; a.result = result.p;
+  chk(candIdx.alloc((size_t)cand_cap));
+  chk(candDist.alloc((size_t)cand_cap));
+  a.candIdx = candIdx.p; a.candDist = candDist.p; a.candCap = cand_cap;
+  int res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_proj_count(a, nullptr));
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  if (e == hipSuccess && n_points) chk(hipMemcpy(&total, candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
-  if (e == hipSuccess) {
-    chk(candIdx.alloc((size_t)std::max(total, 1)));
-    chk(candDist.alloc((size_t)std::max(total, 1)));
-    a.candIdx = candIdx.p; a.candDist = candDist.p; a.candCap = std::max(total, 1);
-  }
   a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.choice = choice.p; a.flags = flags.p;
   // Resolve: rounds of the parallel fixed-point iteration (k_proj_round) until a round changes nothing; the one-wave
   // serial walk stays as the fallback for a pathological claim chain (ORBX_PROJ_SERIAL=1 forces it, for the tests).
@@ -357,9 +373,13 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   if (e == hipSuccess) {
     const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
     if (e == hipSuccess) {
-      std::memcpy(occupied, h, n);
       std::memcpy(res, h + (oRes - oOcc), sizeof(res));
-      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+      if (res[1] > cand_cap) {
+        *needed = res[1];
+      } else {
+        std::memcpy(occupied, h, n);
+        std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+      }
     }
   }
   pk.release(); cellStart.free(); cellItems.free();
@@ -367,6 +387,26 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   taker0.free(); taker1.free(); choice.free(); flags.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
+}
+
+int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uint8_t* desc, const float* u_right, int n,
+                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
+                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
+                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                              uint8_t* occupied, int32_t* match) {
+  if (n == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  // room for 96 candidates per point on average (a search window holds 10-40); denser inputs repeat the call once with the
+  // exact size.  ORBX_PROJ_CAND_CAP overrides the first guess (tests force the second attempt with it).
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  int cap = capEnv > 0 ? capEnv : std::max(n_points, 1) * 96, needed = 0;
+  rc = search_by_projection_try(kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels, map_points, points,
+                                n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, cap, &needed);
+  if (rc >= 0 && needed > cap)
+    rc = search_by_projection_try(kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels, map_points, points,
+                                  n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, needed, &needed);
+  return rc;
 }
 }  // namespace
 

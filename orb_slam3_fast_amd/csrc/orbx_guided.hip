@@ -160,14 +160,16 @@ __global__ __launch_bounds__(256) void k_init_scan(InitArgs a) {  // single bloc
     tsum[tid] += t;
     __syncthreads();
   }
+  // offsets are clamped to the capacity of the candidate arrays: when the lists do not fit, every later kernel sees
+  // truncated (never out-of-range) lists, result[1] reports the size that was needed and the host repeats the call
   int run = tid ? tsum[tid - 1] : 0;
   for (int i = b; i < e; i++) {
     const int t = a.candOff[i];
-    a.candOff[i] = run;
+    a.candOff[i] = min(run, a.candCap);
     run += t;
   }
   if (tid == 255) {
-    a.candOff[n] = tsum[255];
+    a.candOff[n] = min(tsum[255], a.candCap);
     if (tsum[255] > a.candCap) a.result[1] = tsum[255];
   }
 }
@@ -1316,7 +1318,7 @@ hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
     InitArgs sc = a.grid;  // k_init_scan scans candOff[0 .. n1]
     sc.candOff = a.candOff;
     sc.n1 = a.nmp;
-    sc.candCap = 1 << 30;
+    sc.candCap = a.candCap;
     hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, sc);
   }
   return hipGetLastError();

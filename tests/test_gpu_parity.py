@@ -473,6 +473,21 @@ def test_projection_serial_fallback_in_fresh_process(gpu):
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
 
 
+def test_projection_candidate_overflow_retry_in_fresh_process(gpu):
+    """SearchByProjection / SearchForInitialization size their candidate arrays by a guess and repeat the call with the exact
+    size when the lists do not fit; ORBX_PROJ_CAND_CAP=64 makes every call take that second attempt (read once per process,
+    hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ORBX_PROJ_CAND_CAP="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "(projection or initialization) and not fallback and not retry",
+                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
+                       cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
+
+
 def test_size_limit_of_the_key_packing(gpu, oracle):
     """Keys carry 12-bit coordinates: 4096 px wide works (bit-exact), 4100 px is rejected with E_UNSUPPORTED."""
     ex = orbx.ORBextractor(600, 1.2, 8, 20, 7, max_width=4096, max_height=600)
