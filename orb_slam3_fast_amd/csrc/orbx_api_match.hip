@@ -441,26 +441,26 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
 namespace {
 // One side (left or right camera) of a stereo-fisheye projection search: grid + candidate lists on the device.
 struct ProjSide {
-  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, result;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12;
   orbx_map_point_view* mpp = nullptr;  // views of this camera inside the call's packed upload
   orbx_projected_point* ppp = nullptr;
   ProjArgs a{};
   void release() {
     cellStart.free(); cellItems.free(); candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
-    m12.free(); result.free();
+    m12.free();
   }
 };
 
-int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
-                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
-                                      int nlevels, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
-                                      const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, int n_points,
-                                      float th, int far_points, float th_far_points, float nnratio, int check_ori,
-                                      const int32_t* l2r, const int32_t* r2l, uint8_t* occupied, int32_t* match) {
+// One attempt with candidate arrays of cand_cap entries per camera; see search_by_projection_try.
+int search_by_projection_fisheye_try(const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                     float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                     int nlevels, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
+                                     const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, int n_points,
+                                     float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                                     const int32_t* l2r, const int32_t* r2l, uint8_t* occupied, int32_t* match, int cand_cap,
+                                     int* needed) {
   const int mode = ptsL ? 1 : 0, n = n_left + n_right;
-  if (n == 0) return 0;
-  int rc = set_device(device);
-  if (rc != ORBX_OK) return rc;
+  *needed = 0;
   ProjSide S[2];
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -476,7 +476,9 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
     oMp[side] = pk.add(n_points && mode == 0 ? (side ? viewsR : viewsL) : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
     oPp[side] = pk.add(n_points && mode == 1 ? (side ? ptsR : ptsL) : nullptr, (size_t)nm * sizeof(orbx_projected_point));
   }
-  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  static const int zero4[4] = {0, 0, 0, 0};
+  const size_t oOcc = pk.add(occupied, n), oSideRes = pk.add(zero4, 4 * sizeof(int));  // per camera: {count, lists needed}
+  const size_t oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
   const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
   chk(pk.commit());
   struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
@@ -487,7 +489,9 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
     ProjSide& P = S[side];
     const int ns = side ? n_right : n_left, first = side ? n_left : 0;
     chk(P.cellStart.alloc(64 * 48 + 1)); chk(P.cellItems.alloc(std::max(ns, 1))); chk(P.candOff.alloc(nm + 1));
-    chk(P.mdist.alloc(std::max(ns, 1))); chk(P.m21.alloc(std::max(ns, 1))); chk(P.m12.alloc(1)); chk(P.result.alloc(2));
+    chk(P.mdist.alloc(std::max(ns, 1))); chk(P.m21.alloc(std::max(ns, 1))); chk(P.m12.alloc(1));
+    chk(P.candIdx.alloc((size_t)cand_cap)); chk(P.candDist.alloc((size_t)cand_cap));
+    int* sideRes = pk.ptr<int>(oSideRes) + 2 * side;
     P.mpp = pk.ptr<orbx_map_point_view>(oMp[side]);
     P.ppp = pk.ptr<orbx_projected_point>(oPp[side]);
     ProjArgs& a = P.a;
@@ -496,25 +500,21 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
     a.grid.invW = 64.f / (max_x - min_x);
     a.grid.invH = 48.f / (max_y - min_y);
     a.grid.cellStart = P.cellStart.p; a.grid.cellItems = P.cellItems.p; a.grid.matchedDist = P.mdist.p;
-    a.grid.matches21 = P.m21.p; a.grid.matches12 = P.m12.p; a.grid.result = P.result.p; a.grid.candOff = P.candOff.p;
-    a.grid.candCap = 1 << 30;
+    a.grid.matches21 = P.m21.p; a.grid.matches12 = P.m12.p; a.grid.result = sideRes; a.grid.candOff = P.candOff.p;
+    a.grid.candCap = cand_cap;
     a.desc = d.p + (size_t)first * 32; a.uRight = nullptr;  // no mvuRight gate when F.Nleft != -1 (:90, :1667)
     a.scale = sf.p; a.mps = P.mpp; a.pts = P.ppp; a.nmp = n_points; a.mode = mode; a.checkOri = check_ori;
     a.th = side ? 1.0f : th;  // the right-camera radius is not scaled by th (:144)
     a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
-    a.occupied = occ.p + first; a.match = mt.p + first; a.candOff = P.candOff.p; a.result = P.result.p; a.candCap = 1 << 30;
-    if (ns > 0) chk(launch_proj_count(a, nullptr));
-    else chk(hipMemset(P.candOff.p, 0, (size_t)(nm + 1) * sizeof(int)));
-  }
-  if (e == hipSuccess) chk(hipDeviceSynchronize());
-  for (int side = 0; side < 2 && e == hipSuccess; side++) {
-    ProjSide& P = S[side];
-    int total = 0;
-    if (n_points) chk(hipMemcpy(&total, P.candOff.p + n_points, sizeof(int), hipMemcpyDeviceToHost));
-    chk(P.candIdx.alloc((size_t)std::max(total, 1)));
-    chk(P.candDist.alloc((size_t)std::max(total, 1)));
-    P.a.candIdx = P.candIdx.p; P.a.candDist = P.candDist.p; P.a.candCap = std::max(total, 1);
-    if (e == hipSuccess && (side ? n_right : n_left) > 0) chk(launch_proj_cands_fill(P.a, nullptr));
+    a.occupied = occ.p + first; a.match = mt.p + first; a.candOff = P.candOff.p; a.result = sideRes; a.candCap = cand_cap;
+    a.candIdx = P.candIdx.p; a.candDist = P.candDist.p;
+    if (e != hipSuccess) break;
+    if (ns > 0) {
+      chk(launch_proj_count(a, nullptr));
+      chk(launch_proj_cands_fill(a, nullptr));
+    } else {
+      chk(hipMemsetAsync(P.candOff.p, 0, (size_t)(nm + 1) * sizeof(int), nullptr));
+    }
   }
   ProjFeArgs f{};
   f.offL = S[0].candOff.p; f.idxL = S[0].candIdx.p; f.distL = S[0].candDist.p;
@@ -548,9 +548,15 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
   if (e == hipSuccess) {
     const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
     if (e == hipSuccess) {
-      std::memcpy(occupied, h, n);
+      int side_res[4];
+      std::memcpy(side_res, h + (oSideRes - oOcc), sizeof(side_res));
       std::memcpy(result, h + (oRes - oOcc), sizeof(int));
-      std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+      if (std::max(side_res[1], side_res[3]) > cand_cap) {
+        *needed = std::max(side_res[1], side_res[3]);
+      } else {
+        std::memcpy(occupied, h, n);
+        std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
+      }
     }
   }
   wr0.free(); wr1.free(); wl0.free(); wl1.free(); wc0.free(); wc1.free(); fl.free();
@@ -558,6 +564,27 @@ int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, cons
   S[0].release(); S[1].release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return result[0];
+}
+
+int search_by_projection_fisheye_impl(int device, const orbx_keypoint* kps, const uint8_t* desc, int n_left, int n_right,
+                                      float min_x, float min_y, float max_x, float max_y, const float* scale_factors,
+                                      int nlevels, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
+                                      const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, int n_points,
+                                      float th, int far_points, float th_far_points, float nnratio, int check_ori,
+                                      const int32_t* l2r, const int32_t* r2l, uint8_t* occupied, int32_t* match) {
+  if (n_left + n_right == 0) return 0;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  int cap = capEnv > 0 ? capEnv : std::max(n_points, 1) * 96, needed = 0;
+  rc = search_by_projection_fisheye_try(kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, scale_factors, nlevels, viewsL,
+                                        viewsR, ptsL, ptsR, n_points, th, far_points, th_far_points, nnratio, check_ori, l2r, r2l,
+                                        occupied, match, cap, &needed);
+  if (rc >= 0 && needed > cap)
+    rc = search_by_projection_fisheye_try(kps, desc, n_left, n_right, min_x, min_y, max_x, max_y, scale_factors, nlevels, viewsL,
+                                          viewsR, ptsL, ptsR, n_points, th, far_points, th_far_points, nnratio, check_ori, l2r,
+                                          r2l, occupied, match, needed, &needed);
+  return rc;
 }
 }  // namespace
 

@@ -483,7 +483,8 @@ def test_projection_candidate_overflow_retry_in_fresh_process(gpu):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ORBX_PROJ_CAND_CAP="64")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "(projection or initialization) and not fallback and not retry",
-                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py")],
+                        os.path.join(root, "tests", "test_golden.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_fisheye.py")],
                        cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:] + r.stderr[-400:]
 
