@@ -316,7 +316,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
                              uint8_t* occupied, int32_t* match, int cand_cap, int* needed) {
   const int mode = points ? 1 : 0;
   *needed = 0;
-  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, choice, flags;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, taker2, choice, flags;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
@@ -336,7 +336,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   struct { orbx_map_point_view* p; } mp{pk.ptr<orbx_map_point_view>(oMp)};
   struct { orbx_projected_point* p; } pp{pk.ptr<orbx_projected_point>(oPp)};
   struct { int* p; } mt{pk.ptr<int>(oMt)}, result{pk.ptr<int>(oRes)};
-  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40));
+  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(taker2.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40 + 48));
   chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
   chk(candOff.alloc(nm + 1)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
   ProjArgs a{};
@@ -355,7 +355,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   a.candIdx = candIdx.p; a.candDist = candDist.p; a.candCap = cand_cap;
   int res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_proj_count(a, nullptr));
-  a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.choice = choice.p; a.flags = flags.p;
+  a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.taker[2] = taker2.p; a.choice = choice.p; a.flags = flags.p;
   // Resolve: rounds of the parallel fixed-point iteration (k_proj_round) until a round changes nothing; the one-wave
   // serial walk stays as the fallback for a pathological claim chain (ORBX_PROJ_SERIAL=1 forces it, for the tests).
   static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
@@ -364,8 +364,8 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   if (!forceSerial && n_points > 0) {
     for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
       chk(launch_proj_rounds(a, r, 4, nullptr));
-      int changed = 1;
-      if (e == hipSuccess) chk(hipMemcpy(&changed, flags.p, sizeof(int), hipMemcpyDeviceToHost));  // synchronises
+      int changed = 1;  // did the last round of this group still change a choice?
+      if (e == hipSuccess) chk(hipMemcpy(&changed, flags.p + 40 + r + 3, sizeof(int), hipMemcpyDeviceToHost));  // synchronises
       done = changed == 0;
     }
   }
@@ -384,7 +384,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   }
   pk.release(); cellStart.free(); cellItems.free();
   candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); m12.free();
-  taker0.free(); taker1.free(); choice.free(); flags.free();
+  taker0.free(); taker1.free(); taker2.free(); choice.free(); flags.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
 }

@@ -725,12 +725,17 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
 // index).  By induction point t is final after round t + 1, and a round that changes nothing has reached the fixed
 // point, which is the serial result; on real inputs a handful of rounds suffice (a claim only matters when two points
 // compete for one keypoint).  Wave per point.
-__global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int prev, int round_no) {
+constexpr int kProjChanged = 40;  // flags[kProjChanged + r] = round r changed a choice (flags has 40 + 48 entries)
+__global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int* takerPrev = a.taker[round_no % 3];
+  int* takerNew = a.taker[(round_no + 1) % 3];
+  {  // the buffer the NEXT round writes is cleared here (nobody touches it in this round): one launch per round
+    int* takerClr = a.taker[(round_no + 2) % 3];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.grid.n2; i += gridDim.x * 256) takerClr[i] = 0x7FFFFFFF;
+  }
   if (im >= a.nmp) return;
-  const int* takerPrev = a.taker[prev];
-  int* takerNew = a.taker[prev ^ 1];
   const int b = a.candOff[im], e = a.candOff[im + 1];
   uint64_t best = ~0ull, second = ~0ull;  // (dist << 40) | (position << 8) | octave
   for (int j = b + lane; j < e; j += 64) {
@@ -772,22 +777,19 @@ __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int prev, int ro
     if (accept) chosen = a.candIdx[b + bestPos];
   }
   if (lane == 0) {
-    if (round_no == 0 || a.choice[im] != chosen) a.flags[0] = 1;
+    if (round_no == 0 || a.choice[im] != chosen) a.flags[kProjChanged + round_no] = 1;
     a.choice[im] = chosen;
     if (chosen >= 0 && (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations))
       atomicMin(&takerNew[chosen], im);
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a, int which, int first) {  // taker[which] = +inf
+__global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a) {  // before round 0: taker[1] = +inf, no matches, flags 0
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.grid.n2; i += gridDim.x * 256) {
-    a.taker[which][i] = 0x7FFFFFFF;
-    if (first) a.match[i] = -1;
+    a.taker[1][i] = 0x7FFFFFFF;
+    a.match[i] = -1;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 33) {
-    if (threadIdx.x == 0) a.flags[0] = 0;                 // "changed in this round"
-    else if (first) a.flags[threadIdx.x] = 0;             // accepted, removed, histogram
-  }
+  if (blockIdx.x == 0 && threadIdx.x < kProjChanged + 48) a.flags[threadIdx.x] = 0;  // accepted, removed, histogram, changed[]
 }
 
 // After convergence: match[k] = the LAST point that chose k (later assignments overwrite), occupied[k] = that point's
@@ -866,12 +868,9 @@ hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s) {
 }
 hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s) {
   if (a.nmp <= 0) return hipSuccess;
-  const int gb = (a.grid.n2 + 255) / 256;
-  for (int r = first_round; r < first_round + rounds; r++) {
-    const int prev = r & 1;  // round r reads taker[r & 1] (claims of round r - 1) and writes taker[(r & 1) ^ 1]
-    hipLaunchKernelGGL(k_proj_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_proj_round, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
-  }
+  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, a);
+  for (int r = first_round; r < first_round + rounds; r++)
+    hipLaunchKernelGGL(k_proj_round, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, r);
   return hipGetLastError();
 }
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s) {

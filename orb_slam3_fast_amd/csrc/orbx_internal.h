@@ -268,7 +268,8 @@ struct ProjArgs {
   int candCap;
   int* result;                    // [0] = nmatches
   // parallel fixed-point resolve (launch_proj_resolve_parallel): scratch
-  int* taker[2];                  // n2 each: smallest point index that (with observations) claims the keypoint
+  int* taker[3];                  // n2 each: smallest point index that (with observations) claims the keypoint; round r
+                                  // reads taker[r % 3], writes taker[(r + 1) % 3] and clears taker[(r + 2) % 3]
   int* choice;                    // nmp: chosen keypoint (-1 none)
   int* flags;                     // [0] changed in the last round, [1] accepted, [2] removed, [3..32] orientation histogram
 };
