@@ -189,11 +189,18 @@ def main():
         for e in exs:
             e.profile_enable(True, stage=dom)   # timed region: only the dominant kernel is bracketed
     barrier()
+    # The host side of a step is ~60 us of Python; a generation-2 garbage collection (tens of ms with torch's object graph
+    # loaded) that happens to fall into the 20 timed steps would be billed to the GPU path -- it made C4 read 13 k instead
+    # of 63 k pairs/s in every process but the first one on a box.  Collect now, then keep the collector out of the region.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     t1 = time.perf_counter()
+    gc.enable()
     elapsed = t1 - t0
     if dist is not None:
         elapsed = sharding.max_over_ranks(elapsed, device="cuda")

@@ -279,7 +279,17 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   bool lapTrivial = true;
   if (lap)
     for (int i = 0; i < n; i++) lapTrivial = lapTrivial && lap[2 * i + 1] < 19;
-  if (!lapTrivial) HIPC(hipMemcpyAsync(ex->d_lap.p, lap, (size_t)n * 2 * sizeof(int), hipMemcpyHostToDevice, s));
+  if (!lapTrivial) {
+    // The lapping areas of a rig do not change from frame to frame: they are uploaded only when they differ from what the
+    // device holds, and then from page-locked memory (no per-step copy from the caller's pageable array).
+    const size_t nb = (size_t)n * 2 * sizeof(int);
+    if (ex->lapN != n || std::memcmp(ex->h_lap, lap, nb) != 0) {
+      HIPC(hipStreamSynchronize(s));  // an earlier upload from h_lap may still be queued
+      std::memcpy(ex->h_lap, lap, nb);
+      ex->lapN = n;
+      HIPC(hipMemcpyAsync(ex->d_lap.p, ex->h_lap, nb, hipMemcpyHostToDevice, s));
+    }
+  }
   // Single images through the host API are launch-bound (12 small kernels on two streams), so the pipeline can be
   // captured once per image size into a hipGraph and replayed (ORBX_GRAPH=1).  Measured on ROCm 7.2 / MI355X it is
   // SLOWER than the plain launches -- one 1280x720 eye 0.487 vs 0.310 ms, a stereo frame 0.823 vs 0.711 ms (640x480:
@@ -490,6 +500,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_nOut.alloc(B));
   ok(ex->d_mono.alloc(B));
   ok(ex->d_lap.alloc(B * 2));
+  ok(hipHostMalloc(reinterpret_cast<void**>(&ex->h_lap), (size_t)B * 2 * sizeof(int), hipHostMallocDefault));
   ok(ex->d_xofs.alloc(nx + 64));
   ok(ex->d_xab.alloc(2 * nx + 64));
   ok(ex->d_yofs.alloc(ny + 64));
@@ -514,6 +525,8 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   }
   if (ex->hostResults) (void)hipHostFree(ex->hostResults);
   ex->hostResults = nullptr;
+  if (ex->h_lap) (void)hipHostFree(ex->h_lap);
+  ex->h_lap = nullptr;
   ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();

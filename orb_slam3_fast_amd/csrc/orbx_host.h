@@ -4,8 +4,10 @@
 #define ORBX_HOST_H
 #include <memory>
 #include <new>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <mutex>
@@ -23,9 +25,21 @@ inline int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+// ORBX_TRACE_SLOW=<ms>: report every wrapped HIP call / launch sequence that blocks the host longer than that (debug aid
+// for enqueue stalls; one getenv at first use, two clock reads per call only when it is set).
+inline double trace_slow_ms() {
+  static const double v = getenv("ORBX_TRACE_SLOW") ? atof(getenv("ORBX_TRACE_SLOW")) : 0.0;
+  return v;
+}
 #define HIPC(expr)                                                                                     \
   do {                                                                                                 \
+    const double lim_ = trace_slow_ms();                                                               \
+    const auto t0_ = lim_ > 0 ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); \
     hipError_t e_ = (expr);                                                                            \
+    if (lim_ > 0) {                                                                                    \
+      const double ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); \
+      if (ms_ > lim_) std::fprintf(stderr, "ORBX_TRACE_SLOW %.2f ms: %s (%s:%d)\n", ms_, #expr, __FILE__, __LINE__); \
+    }                                                                                                  \
     if (e_ != hipSuccess)                                                                              \
       return fail(ORBX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                      \
   } while (0)
@@ -230,6 +244,8 @@ struct orbx_extractor {
   int stagePitch = 0;
   int stereoPairs = 0;
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
+  int32_t* h_lap = nullptr;        // pinned copy of the lapping areas the device currently holds (lapN images)
+  int lapN = 0;
   // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)
   hipGraphExec_t graphExec[2] = {nullptr, nullptr};
   int graphW = 0, graphH = 0;
