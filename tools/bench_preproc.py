@@ -27,6 +27,9 @@ def timed(fn, iters=20, warm=3):
 
 
 def main():
+    import gc
+    gc.collect()
+    gc.disable()  # a generation-2 collection inside a 2 ms timing window would dominate it
     only = sys.argv[1] if len(sys.argv) > 1 else None  # 'rectify' | 'clahe': just that stage (for kernel traces)
     out = {}
     B = 64

@@ -41,6 +41,9 @@ def frame():
     return t1 - t0, t2 - t1
 
 
+import gc
+gc.collect()
+gc.disable()  # a generation-2 collection inside a millisecond timing window would dominate it
 for _ in range(5):
     frame()
 ext, st = zip(*[frame() for _ in range(reps)])
