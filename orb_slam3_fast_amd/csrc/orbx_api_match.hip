@@ -111,6 +111,13 @@ int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* k
     return fail(ORBX_E_BADARG, "bad argument");
   const int nkl = n_kf_nodes ? kf_node_start[n_kf_nodes] : 0, nfl = n_f_nodes ? f_node_start[n_f_nodes] : 0;
   if (nkl < 0 || nkl > n_kf || nfl < 0 || nfl > n_f) return fail(ORBX_E_BADARG, "feature vector larger than the frame");
+  // a FeatureVector is a std::map: ascending node ids, and the CSR offsets must be monotone (the kernels trust them)
+  for (int j = 0; j < n_kf_nodes; j++)
+    if (kf_node_start[j] < 0 || kf_node_start[j] > kf_node_start[j + 1] || (j && kf_node_ids[j] <= kf_node_ids[j - 1]))
+      return fail(ORBX_E_BADARG, "keyframe feature vector: node ids must ascend and offsets must be monotone");
+  for (int j = 0; j < n_f_nodes; j++)
+    if (f_node_start[j] < 0 || f_node_start[j] > f_node_start[j + 1] || (j && f_node_ids[j] <= f_node_ids[j - 1]))
+      return fail(ORBX_E_BADARG, "frame feature vector: node ids must ascend and offsets must be monotone");
   for (int i = 0; i < nkl; i++)
     if (kf_feature_idx[i] >= (uint32_t)n_kf) return fail(ORBX_E_BADARG, "keyframe feature index out of range");
   for (int i = 0; i < nfl; i++)

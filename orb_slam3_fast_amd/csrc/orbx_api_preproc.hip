@@ -275,6 +275,7 @@ static int preproc_enqueue(orbx_preproc* pp, const uint8_t* d_frames, int n, ptr
   if (!d_frames || n <= 0) return fail(ORBX_E_EMPTY, "empty image");
   if (n > pp->maxB) return fail(ORBX_E_CAPACITY, "batch larger than max_batch");
   if (row_pitch < (ptrdiff_t)p.src_w * cn) return fail(ORBX_E_BADARG, "row pitch smaller than a row");
+  if ((long long)row_pitch * p.src_h > 0x7fffffffll) return fail(ORBX_E_UNSUPPORTED, "frames larger than 2 GiB (32-bit tap offsets)");
   const uint8_t* cur = d_frames;
   long long cp = row_pitch, cip = image_pitch;
   hipError_t e = hipSuccess;

@@ -360,6 +360,14 @@ def test_hip_search_by_bow_matches_oracle(oracle, seed, n_left):
         n, m = orbx.SearchByBoW(kf_fv, _kps(ka), kd, kv, f_fv, _kps(fa), fd, n_left, ratio, ori)
         on, om = oracle.search_by_bow(kf_fv, kd, ka, kv, f_fv, fd, fa, n_left, ratio, ori)
         assert n == on and np.array_equal(m, om), (seed, ratio, ori)
+    if seed == 1:  # malformed feature vectors are rejected, not trusted
+        bad = (kf_fv[0][::-1].copy(), kf_fv[1], kf_fv[2])
+        with pytest.raises(orbx.OrbxError):
+            orbx.SearchByBoW(bad, _kps(ka), kd, kv, f_fv, _kps(fa), fd, n_left, 0.7, True)
+        st = f_fv[1].copy()
+        st[1] = st[-1] + 5
+        with pytest.raises(orbx.OrbxError):
+            orbx.SearchByBoW(kf_fv, _kps(ka), kd, kv, (f_fv[0], st, f_fv[2]), _kps(fa), fd, n_left, 0.7, True)
     # a coarse feature vector (levelsup = L: everything under the root) is one node with every feature: long lists
     kf0, f0 = voc.transform(kd, L)[1], voc.transform(fd, L)[1]
     n, m = orbx.SearchByBoW(kf0, _kps(ka), kd, kv, f0, _kps(fa), fd, n_left, 0.7, True)
