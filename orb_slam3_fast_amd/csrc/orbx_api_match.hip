@@ -199,23 +199,25 @@ int search_for_initialization_try(const orbx_keypoint* kps1, const uint8_t* desc
   int res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_search_init(a, nullptr));
   // resolve: parallel fixed-point rounds (k_init_round), serial walk as fallback / ORBX_PROJ_SERIAL=1 cross-check
-  ScratchBuf<int2> cl0, cl1, cr0, cr1;
-  ScratchBuf<int> nc0, nc1, fl;
+  ScratchBuf<int2> cl0, cl1, cr0, cr1, cr2;
+  ScratchBuf<int> nc0, nc1, nc2, fl;
   static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
   bool done = false;
   int lastRound = 0;
   if (e == hipSuccess) chk(launch_search_init_cands_fill(a, nullptr));
   if (!forceSerial && n2 > 0) {
     chk(cl0.alloc(n1)); chk(cl1.alloc(n1)); chk(cr0.alloc((size_t)n2 * kFeWriters)); chk(cr1.alloc((size_t)n2 * kFeWriters));
-    chk(nc0.alloc(n2)); chk(nc1.alloc(n2)); chk(fl.alloc(40));
-    a.claim[0] = cl0.p; a.claim[1] = cl1.p; a.claimers[0] = cr0.p; a.claimers[1] = cr1.p;
-    a.nclaimers[0] = nc0.p; a.nclaimers[1] = nc1.p; a.flags = fl.p;
+    chk(cr2.alloc((size_t)n2 * kFeWriters)); chk(nc0.alloc(n2)); chk(nc1.alloc(n2)); chk(nc2.alloc(n2)); chk(fl.alloc(40 + 48));
+    a.claim[0] = cl0.p; a.claim[1] = cl1.p; a.claimers[0] = cr0.p; a.claimers[1] = cr1.p; a.claimers[2] = cr2.p;
+    a.nclaimers[0] = nc0.p; a.nclaimers[1] = nc1.p; a.nclaimers[2] = nc2.p; a.flags = fl.p;
     for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
       chk(launch_search_init_rounds(a, r, 4, nullptr));
-      int st[2] = {1, 0};
+      int st[40 + 48];
+      st[1] = 0;
+      st[40 + r + 3] = 1;
       if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
-      if (st[1]) break;
-      done = st[0] == 0;
+      if (st[1]) break;  // an i2 collected more than kFeWriters claimers in one round
+      done = st[40 + r + 3] == 0;  // the last round of the group changed nothing
       lastRound = r + 3;
     }
   }
@@ -232,7 +234,7 @@ int search_for_initialization_try(const orbx_keypoint* kps1, const uint8_t* desc
       }
     }
   }
-  cl0.free(); cl1.free(); cr0.free(); cr1.free(); nc0.free(); nc1.free(); fl.free();
+  cl0.free(); cl1.free(); cr0.free(); cr1.free(); cr2.free(); nc0.free(); nc1.free(); nc2.free(); fl.free();
   pk.release(); cellStart.free(); cellItems.free();
   candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
@@ -533,21 +535,23 @@ int search_by_projection_fisheye_try(const orbx_keypoint* kps, const uint8_t* de
   // parallel fixed-point rounds (k_proj_round_fe); the serial walk is the fallback (writer-list overflow, no convergence
   // within 48 rounds) and the ORBX_PROJ_SERIAL=1 cross-check
   ScratchBuf<int4> wr0, wr1;
-  ScratchBuf<int> wl0, wl1, wc0, wc1, fl;
+  ScratchBuf<int> wl0, wl1, wl2, wc0, wc1, wc2, fl;
   static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
   bool done = false;
   int lastRound = 0;
   if (!forceSerial && n_points > 0) {
     chk(wr0.alloc(nm)); chk(wr1.alloc(nm)); chk(wl0.alloc((size_t)n * kFeWriters)); chk(wl1.alloc((size_t)n * kFeWriters));
-    chk(wc0.alloc(n)); chk(wc1.alloc(n)); chk(fl.alloc(40));
-    f.writes[0] = wr0.p; f.writes[1] = wr1.p; f.writers[0] = wl0.p; f.writers[1] = wl1.p;
-    f.nwriters[0] = wc0.p; f.nwriters[1] = wc1.p; f.flags = fl.p;
+    chk(wl2.alloc((size_t)n * kFeWriters)); chk(wc0.alloc(n)); chk(wc1.alloc(n)); chk(wc2.alloc(n)); chk(fl.alloc(40 + 48));
+    f.writes[0] = wr0.p; f.writes[1] = wr1.p; f.writers[0] = wl0.p; f.writers[1] = wl1.p; f.writers[2] = wl2.p;
+    f.nwriters[0] = wc0.p; f.nwriters[1] = wc1.p; f.nwriters[2] = wc2.p; f.flags = fl.p;
     for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
       chk(launch_proj_rounds_fisheye(f, r, 4, nullptr));
-      int st[2] = {1, 0};
+      int st[40 + 48];
+      st[1] = 0;
+      st[40 + r + 3] = 1;
       if (e == hipSuccess) chk(hipMemcpy(st, fl.p, sizeof(st), hipMemcpyDeviceToHost));  // synchronises
       if (st[1]) break;  // a slot collected more than kFeWriters writers in one round
-      done = st[0] == 0;
+      done = st[40 + r + 3] == 0;  // the last round of the group changed nothing
       lastRound = r + 3;
     }
   }
@@ -566,7 +570,7 @@ int search_by_projection_fisheye_try(const orbx_keypoint* kps, const uint8_t* de
       }
     }
   }
-  wr0.free(); wr1.free(); wl0.free(); wl1.free(); wc0.free(); wc1.free(); fl.free();
+  wr0.free(); wr1.free(); wl0.free(); wl1.free(); wl2.free(); wc0.free(); wc1.free(); wc2.free(); fl.free();
   pk.release();
   S[0].release(); S[1].release();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));

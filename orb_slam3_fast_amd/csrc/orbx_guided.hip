@@ -14,6 +14,8 @@ __device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs&
   return px * 48 + py;
 }
 
+// flags[kProjChanged + r] = round r of a fixed-point resolve changed a choice (the flag arrays hold 40 + 48 entries)
+constexpr int kProjChanged = 40;
 constexpr int kGridThreads = 1024;
 __global__ __launch_bounds__(kGridThreads) void k_init_grid(InitArgs a) {  // single block
   // Counting sort of the keypoints by grid cell, ascending keypoint index inside a cell (mGrid[i][j].push_back order,
@@ -361,9 +363,16 @@ __device__ __forceinline__ int init_matched_dist(const InitArgs& a, int prev, in
   return ld;
 }
 
-__global__ __launch_bounds__(256) void k_init_round(InitArgs a, int prev, int round_no) {
+__global__ __launch_bounds__(256) void k_init_round(InitArgs a, int round_no) {
   const int lane = threadIdx.x & 63;
   const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // claimer lists rotate through three buffers (read [r % 3], append to [(r + 1) % 3], clear [(r + 2) % 3] for the next
+  // round): one launch per round; claim[] is rewritten completely every round and alternates between two
+  const int prev = round_no % 3, next = (round_no + 1) % 3, c2 = round_no & 1;
+  {
+    int* clr = a.nclaimers[(round_no + 2) % 3];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) clr[i] = 0;
+  }
   if (i1 >= a.n1) return;
   const int b = a.candOff[i1], e = a.candOff[i1 + 1];
   int2 cl = {-1, 0};
@@ -398,26 +407,23 @@ __global__ __launch_bounds__(256) void k_init_round(InitArgs a, int prev, int ro
     }
   }
   if (lane == 0) {
-    const int2 o = a.claim[prev][i1];
-    if (round_no == 0 || o.x != cl.x || o.y != cl.y) a.flags[0] = 1;
-    a.claim[prev ^ 1][i1] = cl;
+    const int2 o = a.claim[c2][i1];
+    if (round_no == 0 || o.x != cl.x || o.y != cl.y) a.flags[kProjChanged + round_no] = 1;
+    a.claim[c2 ^ 1][i1] = cl;
     if (cl.x >= 0) {
-      const int pos = atomicAdd(&a.nclaimers[prev ^ 1][cl.x], 1);
-      if (pos < kFeWriters) a.claimers[prev ^ 1][cl.x * kFeWriters + pos] = make_int2(i1, cl.y);
+      const int pos = atomicAdd(&a.nclaimers[next][cl.x], 1);
+      if (pos < kFeWriters) a.claimers[next][cl.x * kFeWriters + pos] = make_int2(i1, cl.y);
       else a.flags[1] = 1;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_init_reset(InitArgs a, int which, int first) {
+__global__ __launch_bounds__(256) void k_init_reset(InitArgs a) {  // before round 0: empty claimer lists, no owners
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) {
-    a.nclaimers[which][i] = 0;
-    if (first) a.matches21[i] = -1;
+    a.nclaimers[1][i] = 0;
+    a.matches21[i] = -1;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 34) {
-    if (threadIdx.x == 0) a.flags[0] = 0;
-    else if (first) a.flags[threadIdx.x] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x < kProjChanged + 48) a.flags[threadIdx.x] = 0;
 }
 
 __device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
@@ -489,11 +495,9 @@ hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s) {
 }
 hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s) {
   const int gb = (a.n2 + 255) / 256 > 0 ? (a.n2 + 255) / 256 : 1;
-  for (int r = first_round; r < first_round + rounds; r++) {
-    const int prev = r & 1;
-    hipLaunchKernelGGL(k_init_reset, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_init_round, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, prev, r);
-  }
+  if (first_round == 0) hipLaunchKernelGGL(k_init_reset, dim3(gb), dim3(256), 0, s, a);
+  for (int r = first_round; r < first_round + rounds; r++)
+    hipLaunchKernelGGL(k_init_round, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, r);
   return hipGetLastError();
 }
 hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s) {
@@ -725,7 +729,6 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
 // index).  By induction point t is final after round t + 1, and a round that changes nothing has reached the fixed
 // point, which is the serial result; on real inputs a handful of rounds suffice (a claim only matters when two points
 // compete for one keypoint).  Wave per point.
-constexpr int kProjChanged = 40;  // flags[kProjChanged + r] = round r changed a choice (flags has 40 + 48 entries)
 __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1099,9 +1102,17 @@ __device__ __forceinline__ void fe_best2(const ProjFeArgs& a, int prev, int roun
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int prev, int round_no) {
+__global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int round_no) {
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // writer lists rotate through three buffers: round r reads [r % 3], appends to [(r + 1) % 3] and clears the counts of
+  // [(r + 2) % 3] for the next round (nobody touches that one now) -- one launch per round; writes[] (fully rewritten every
+  // round) alternates between two
+  const int prev = round_no % 3, next = (round_no + 1) % 3, w2 = round_no & 1;
+  {
+    int* clr = a.nwriters[(round_no + 2) % 3];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) clr[i] = 0;
+  }
   if (im >= a.nmp) return;
   int4 w = {-1, -1, -1, -1};
   bool skipRight = false;
@@ -1181,31 +1192,28 @@ __global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int prev, i
     }
   }
   if (lane == 0) {
-    const int4 o = a.writes[prev][im];
-    if (round_no == 0 || o.x != w.x || o.y != w.y || o.z != w.z || o.w != w.w) a.flags[0] = 1;
-    a.writes[prev ^ 1][im] = w;
+    const int4 o = a.writes[w2][im];
+    if (round_no == 0 || o.x != w.x || o.y != w.y || o.z != w.z || o.w != w.w) a.flags[kProjChanged + round_no] = 1;
+    a.writes[w2 ^ 1][im] = w;
     const int ws[4] = {w.x, w.y, w.z, w.w};
     for (int t = 0; t < 4; t++) {
       if (ws[t] < 0) continue;
       bool dup = false;
       for (int u = 0; u < t; u++) dup = dup || ws[u] == ws[t];
       if (dup) continue;
-      const int pos = atomicAdd(&a.nwriters[prev ^ 1][ws[t]], 1);
-      if (pos < kFeWriters) a.writers[prev ^ 1][ws[t] * kFeWriters + pos] = im;
+      const int pos = atomicAdd(&a.nwriters[next][ws[t]], 1);
+      if (pos < kFeWriters) a.writers[next][ws[t] * kFeWriters + pos] = im;
       else a.flags[1] = 1;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_reset_fe(ProjFeArgs a, int which, int first) {
+__global__ __launch_bounds__(256) void k_proj_reset_fe(ProjFeArgs a) {  // before round 0: empty writer lists, no matches
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
-    a.nwriters[which][i] = 0;
-    if (first) a.match[i] = -1;
+    a.nwriters[1][i] = 0;
+    a.match[i] = -1;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 34) {
-    if (threadIdx.x == 0) a.flags[0] = 0;
-    else if (first) a.flags[threadIdx.x] = 0;
-  }
+  if (blockIdx.x == 0 && threadIdx.x < kProjChanged + 48) a.flags[threadIdx.x] = 0;  // overflow, counts, histogram, changed[]
 }
 
 __device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
@@ -1287,12 +1295,9 @@ __global__ void k_proj_result_fe(ProjFeArgs a) { a.result[0] = a.flags[2] - a.fl
 
 hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s) {
   if (a.nmp <= 0) return hipSuccess;
-  const int gb = (a.n + 255) / 256;
-  for (int r = first_round; r < first_round + rounds; r++) {
-    const int prev = r & 1;
-    hipLaunchKernelGGL(k_proj_reset_fe, dim3(gb), dim3(256), 0, s, a, prev ^ 1, r == 0 ? 1 : 0);
-    hipLaunchKernelGGL(k_proj_round_fe, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, prev, r);
-  }
+  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset_fe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  for (int r = first_round; r < first_round + rounds; r++)
+    hipLaunchKernelGGL(k_proj_round_fe, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, r);
   return hipGetLastError();
 }
 hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s) {

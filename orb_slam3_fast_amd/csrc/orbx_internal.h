@@ -235,8 +235,8 @@ struct InitArgs {
   int* result;                   // [0]=nmatches, [1]=overflow flag
   // parallel fixed-point rounds (k_init_round): claims of every F1 keypoint and per-F2-keypoint claimer lists
   int2* claim[2];                // n1 each: (i2, dist) or (-1, 0)
-  int2* claimers[2];             // n2 * kFeWriters each: (i1, dist) of the points that claimed i2 in that round
-  int* nclaimers[2];             // n2 each
+  int2* claimers[3];             // n2 * kFeWriters each: (i1, dist) of the points that claimed i2 in that round
+  int* nclaimers[3];             // (rotating, see k_init_round); n2 each
   int* flags;                    // [0] changed, [1] claimer-list overflow, [2] claimed slots, [3] removed, [4..33] histogram
 };
 hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s);
@@ -295,8 +295,8 @@ struct ProjFeArgs {
   int* result;
   // parallel fixed-point rounds (k_proj_round_fe): tentative writes of every point and per-slot writer lists
   int4* writes[2];                  // nmp each: slots written by the point {left best, its partner, right best, its partner} or -1
-  int* writers[2];                  // n * kFeWriters each: points that wrote the slot in that round
-  int* nwriters[2];                 // n each
+  int* writers[3];                  // n * kFeWriters each: points that wrote the slot in that round (rotating, see
+  int* nwriters[3];                 // k_proj_round_fe); n each
   int* flags;                       // [0] changed, [1] writer-list overflow, [2] writes, [3] removed, [4..33] histogram
 };
 hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
