@@ -280,10 +280,48 @@ __global__ __launch_bounds__(256) void k_bf_knn2(const uint8_t* __restrict__ dQ,
   }
 }
 
+// The same 2-NN with 16 lanes per query (train rows t = lane, lane + 16, ...): a one-shot call has ~1500 queries, and a
+// thread per query left all but six CUs idle behind a 1500-step serial loop.  (distance << 16 | train index) keys are all
+// different, so "best = first minimum, second = the next smallest, an equal later distance included" is simply the two
+// smallest keys, and partial results merge with min / max.  nT < 65536.
+__global__ __launch_bounds__(256) void k_bf_knn2_split(const uint8_t* __restrict__ dQ, int nQ, const uint8_t* __restrict__ dT,
+                                                       int nT, int* __restrict__ idx2, int* __restrict__ dist2,
+                                                       uint8_t* __restrict__ ok) {
+  const int q = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (q >= nQ) return;  // whole 16-lane groups leave together
+  uint32_t dq[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) dq[i] = reinterpret_cast<const uint32_t*>(dQ)[(long long)q * 8 + i];
+  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+  for (int t = sub; t < nT; t += 16) {
+    const uint32_t k = ((uint32_t)hamming256(dq, reinterpret_cast<const uint32_t*>(dT) + (long long)t * 8) << 16) | (uint32_t)t;
+    k1 = min(k1, max(k0, k));
+    k0 = min(k0, k);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const uint32_t o0 = (uint32_t)__shfl_xor((int)k0, o, 16), o1 = (uint32_t)__shfl_xor((int)k1, o, 16);
+    k1 = min(min(k1, o1), max(k0, o0));
+    k0 = min(k0, o0);
+  }
+  if (sub == 0) {
+    const bool h0 = k0 != 0xFFFFFFFFu, h1 = k1 != 0xFFFFFFFFu;
+    const int b0 = (int)(k0 >> 16), b1 = (int)(k1 >> 16);
+    idx2[2 * q] = h0 ? (int)(k0 & 0xFFFFu) : -1;
+    idx2[2 * q + 1] = h1 ? (int)(k1 & 0xFFFFu) : -1;
+    dist2[2 * q] = h0 ? b0 : -1;
+    dist2[2 * q + 1] = h1 ? b1 : -1;
+    ok[q] = (h0 && h1 && (double)(float)b0 < __dmul_rn((double)(float)b1, 0.7)) ? 1 : 0;
+  }
+}
+
 hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
                           uint8_t* ok, hipStream_t s) {
   if (nQ <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_bf_knn2, dim3((nQ + 255) / 256), dim3(256), 0, s, dQ, nQ, dT, nT, idx2, dist2, ok);
+  if (nT < 65536)
+    hipLaunchKernelGGL(k_bf_knn2_split, dim3((nQ + 15) / 16), dim3(256), 0, s, dQ, nQ, dT, nT, idx2, dist2, ok);
+  else
+    hipLaunchKernelGGL(k_bf_knn2, dim3((nQ + 255) / 256), dim3(256), 0, s, dQ, nQ, dT, nT, idx2, dist2, ok);
   return hipGetLastError();
 }
 
