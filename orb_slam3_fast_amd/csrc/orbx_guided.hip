@@ -120,29 +120,31 @@ __global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
 #pragma unroll
       for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(a.d1)[(long long)i1 * 8 + i];
       const int wbase = pass ? a.candOff[i1] : 0;
-      for (int ix = cx0; ix <= cx1; ix++)
-        for (int iy = cy0; iy <= cy1; iy++) {
-          const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
-          for (int base = b; base < e; base += 64) {
-            const int j = base + lane;
-            bool ok = false;
-            int i2 = 0;
-            if (j < e) {
-              i2 = a.cellItems[j];
-              const orbx_keypoint k2 = a.k2[i2];
-              ok = k2.octave == 0 && fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
-            }
-            const uint64_t m = __ballot(ok);
-            if (pass && ok) {
-              const int o = wbase + total + prefix_count(m);
-              if (o < a.candCap) {
-                a.candIdx[o] = i2;
-                a.candDist[o] = hamming256(d1, reinterpret_cast<const uint32_t*>(a.d2) + (long long)i2 * 8);
-              }
-            }
-            total += __popcll(m);
+      // the cells (ix, cy0..cy1) of a grid column are neighbours in the CSR (cell = ix * 48 + iy), so a column is ONE
+      // contiguous item range, already in the reference's order (iy inner, in-cell order): a trip per 64 items of a
+      // column instead of a trip per cell (cells hold ~0.5 keypoints; a 100 px window spans ~120 of them)
+      for (int ix = cx0; ix <= cx1; ix++) {
+        const int b = a.cellStart[ix * 48 + cy0], e = a.cellStart[ix * 48 + cy1 + 1];
+        for (int base = b; base < e; base += 64) {
+          const int j = base + lane;
+          bool ok = false;
+          int i2 = 0;
+          if (j < e) {
+            i2 = a.cellItems[j];
+            const orbx_keypoint k2 = a.k2[i2];
+            ok = k2.octave == 0 && fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
           }
+          const uint64_t m = __ballot(ok);
+          if (pass && ok) {
+            const int o = wbase + total + prefix_count(m);
+            if (o < a.candCap) {
+              a.candIdx[o] = i2;
+              a.candDist[o] = hamming256(d1, reinterpret_cast<const uint32_t*>(a.d2) + (long long)i2 * 8);
+            }
+          }
+          total += __popcll(m);
         }
+      }
     }
   }
   if (!pass && lane == 0) a.candOff[i1] = total;
@@ -300,24 +302,23 @@ __global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __r
   const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, a.minY), r), a.invH)));
   if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
     const int wbase = pass ? qOff[qi] : 0;
-    for (int ix = cx0; ix <= cx1; ix++)
-      for (int iy = cy0; iy <= cy1; iy++) {
-        const int b = a.cellStart[ix * 48 + iy], e = a.cellStart[ix * 48 + iy + 1];
-        for (int base = b; base < e; base += 64) {
-          const int j = base + lane;
-          bool ok = false;
-          int i2 = 0;
-          if (j < e) {
-            i2 = a.cellItems[j];
-            const orbx_keypoint k2 = a.k2[i2];
-            ok = !(checkLevels && (k2.octave < minLevel || (maxLevel >= 0 && k2.octave > maxLevel))) &&
-                 fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
-          }
-          const uint64_t m = __ballot(ok);
-          if (pass && ok) out[wbase + total + prefix_count(m)] = i2;
-          total += __popcll(m);
+    for (int ix = cx0; ix <= cx1; ix++) {  // a grid column is one contiguous CSR range (see k_init_cands)
+      const int b = a.cellStart[ix * 48 + cy0], e = a.cellStart[ix * 48 + cy1 + 1];
+      for (int base = b; base < e; base += 64) {
+        const int j = base + lane;
+        bool ok = false;
+        int i2 = 0;
+        if (j < e) {
+          i2 = a.cellItems[j];
+          const orbx_keypoint k2 = a.k2[i2];
+          ok = !(checkLevels && (k2.octave < minLevel || (maxLevel >= 0 && k2.octave > maxLevel))) &&
+               fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
         }
+        const uint64_t m = __ballot(ok);
+        if (pass && ok) out[wbase + total + prefix_count(m)] = i2;
+        total += __popcll(m);
       }
+    }
   }
   if (!pass && lane == 0) qOff[qi] = total;
 }
@@ -583,35 +584,34 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
 #pragma unroll
       for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(q.desc)[i];
       const int wbase = pass ? a.candOff[im] : 0;
-      for (int ix = cx0; ix <= cx1; ix++)
-        for (int iy = cy0; iy <= cy1; iy++) {
-          const int b = g.cellStart[ix * 48 + iy], e = g.cellStart[ix * 48 + iy + 1];
-          for (int base = b; base < e; base += 64) {
-            const int j = base + lane;
-            bool ok = false;
-            int i2 = 0, oct = 0;
-            if (j < e) {
-              i2 = g.cellItems[j];
-              const orbx_keypoint k2 = g.k2[i2];
-              oct = k2.octave;
-              ok = !(checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) &&
-                   fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
-              if (ok && a.uRight) {  // stereo consistency, :97-100 / :1666-1670
-                const float ur = a.uRight[i2];
-                if (ur > 0 && fabsf(__fsub_rn(q.ur, ur)) > r) ok = false;
-              }
+      for (int ix = cx0; ix <= cx1; ix++) {  // a grid column is one contiguous CSR range (see k_init_cands)
+        const int b = g.cellStart[ix * 48 + cy0], e = g.cellStart[ix * 48 + cy1 + 1];
+        for (int base = b; base < e; base += 64) {
+          const int j = base + lane;
+          bool ok = false;
+          int i2 = 0, oct = 0;
+          if (j < e) {
+            i2 = g.cellItems[j];
+            const orbx_keypoint k2 = g.k2[i2];
+            oct = k2.octave;
+            ok = !(checkLevels && (oct < minLevel || (maxLevel >= 0 && oct > maxLevel))) &&
+                 fabsf(__fsub_rn(k2.x, x)) < r && fabsf(__fsub_rn(k2.y, y)) < r;
+            if (ok && a.uRight) {  // stereo consistency, :97-100 / :1666-1670
+              const float ur = a.uRight[i2];
+              if (ur > 0 && fabsf(__fsub_rn(q.ur, ur)) > r) ok = false;
             }
-            const uint64_t m = __ballot(ok);
-            if (pass && ok) {
-              const int o = wbase + total + prefix_count(m);
-              if (o < a.candCap) {
-                a.candIdx[o] = i2;
-                a.candDist[o] = (hamming256(d1, reinterpret_cast<const uint32_t*>(a.desc) + (long long)i2 * 8) << 8) | oct;
-              }
-            }
-            total += __popcll(m);
           }
+          const uint64_t m = __ballot(ok);
+          if (pass && ok) {
+            const int o = wbase + total + prefix_count(m);
+            if (o < a.candCap) {
+              a.candIdx[o] = i2;
+              a.candDist[o] = (hamming256(d1, reinterpret_cast<const uint32_t*>(a.desc) + (long long)i2 * 8) << 8) | oct;
+            }
+          }
+          total += __popcll(m);
         }
+      }
     }
   }
   if (!pass && lane == 0) a.candOff[im] = total;
