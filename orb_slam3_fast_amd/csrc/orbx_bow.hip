@@ -20,17 +20,21 @@ __global__ __launch_bounds__(256) void k_bow_descend(BowArgs a) {
   const int nidLevel = v.L - a.levelsup;
   int cur = 0, level = 0, nid = 0;
   bool nidSet = nidLevel <= 0;
-  for (;;) {
-    const int c0 = v.childStart[cur], c1 = v.childStart[cur + 1];
+  for (;;) {  // three dependent loads per level: child range, child ids, child descriptors
+    int2 cr;
+    __builtin_memcpy(&cr, v.childStart + cur, 8);  // childStart[cur], childStart[cur + 1]
+    const int c0 = cr.x, c1 = cr.y;
     if (c0 == c1) break;  // leaf (the root of a non-empty vocabulary has children)
     uint32_t best = 0xffffffffu;
+    int bestChild = 0;
     for (int c = c0 + sub; c < c1; c += 16) {
-      const uint32_t* nd = v.desc + (long long)v.children[c] * 8;
-      best = min(best, ((uint32_t)hamming256(d, nd) << 16) | (uint32_t)(c - c0));
+      const int child = v.children[c];
+      const uint32_t k = ((uint32_t)hamming256(d, v.desc + (long long)child * 8) << 16) | (uint32_t)(c - c0);
+      if (k < best) { best = k; bestChild = child; }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 16));
-    cur = v.children[c0 + (int)(best & 0xffffu)];
+    cur = __shfl(bestChild, (int)(best & 15u), 16);  // position p was scored by lane p mod 16, whose own best it is
     if (++level == nidLevel) { nid = cur; nidSet = true; }
   }
   if (!nidSet) nid = cur;  // a leaf above level L - levelsup: the reference leaves *nid unset
