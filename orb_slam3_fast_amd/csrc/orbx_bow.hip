@@ -126,52 +126,56 @@ __global__ __launch_bounds__(kBowThreads) void k_bow_assemble(BowArgs a) {
   const bool must = a.voc.scoring != 5, l2 = a.voc.scoring == 1;       // mustNormalize (ScoringObject.h:73-90)
   constexpr uint64_t kNone = ~0ull;
 
-  // ---- BowVector
-  for (int t = tid; t < P; t += kBowThreads)
-    key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)word[t] << 16) | (uint64_t)t : kNone;  // "w > 0: not stopped"
-  __syncthreads();
-  bow_sort(key, P);
-  for (int t = tid; t < P; t += kBowThreads) fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
-  __syncthreads();
-  const int U = bow_rank_heads(fr, P, wsum);
-  double myV[8];  // values of the heads this thread owns (P / kBowThreads <= 8 slots per thread)
-  int myU[8], nMine = 0;
-  for (int t = tid; t < P; t += kBowThreads) {
-    if (key[t] == kNone || (t > 0 && (key[t] >> 16) == (key[t - 1] >> 16))) continue;
-    const double w = wt[key[t] & 0xffff];  // the first feature of the word in feature order
-    double v = w;
-    if (additive)
-      for (int r = t + 1; r < P && (key[r] >> 16) == (key[t] >> 16); r++) v += w;
-    words[fr[t]] = (uint32_t)(key[t] >> 16);
-    myU[nMine] = fr[t];
-    myV[nMine++] = v;
-  }
-  __syncthreads();  // every key has been read: the array now holds the values
-  for (int i = 0; i < nMine; i++) lval[myU[i]] = myV[i];
-  __syncthreads();
-  double scale = 1.0;
-  bool divide = false;
-  if (additive && U > 0 && !must) {
-    scale = (double)U;
-    divide = true;
-  }
-  if (must) {
-    if (tid == 0) {
-      double norm = 0.0;
-      if (!l2) {
-        for (int u = 0; u < U; u++) norm += fabs(lval[u]);
-      } else {
-        for (int u = 0; u < U; u++) norm += lval[u] * lval[u];
-        norm = sqrt(norm);
-      }
-      normShared = norm;
-    }
+  // the two vectors are independent: blockIdx.y = 0 assembles the BowVector, 1 the FeatureVector (half the latency)
+  if (blockIdx.y == 0) {
+    // ---- BowVector
+    for (int t = tid; t < P; t += kBowThreads)
+      key[t] = (t < nf && wt[t] > 0) ? ((uint64_t)(uint32_t)word[t] << 16) | (uint64_t)t : kNone;  // "w > 0: not stopped"
     __syncthreads();
-    scale = normShared;
-    divide = scale > 0.0;
+    bow_sort(key, P);
+    for (int t = tid; t < P; t += kBowThreads) fr[t] = key[t] != kNone && (t == 0 || (key[t] >> 16) != (key[t - 1] >> 16));
+    __syncthreads();
+    const int U = bow_rank_heads(fr, P, wsum);
+    double myV[8];  // values of the heads this thread owns (P / kBowThreads <= 8 slots per thread)
+    int myU[8], nMine = 0;
+    for (int t = tid; t < P; t += kBowThreads) {
+      if (key[t] == kNone || (t > 0 && (key[t] >> 16) == (key[t - 1] >> 16))) continue;
+      const double w = wt[key[t] & 0xffff];  // the first feature of the word in feature order
+      double v = w;
+      if (additive)
+        for (int r = t + 1; r < P && (key[r] >> 16) == (key[t] >> 16); r++) v += w;
+      words[fr[t]] = (uint32_t)(key[t] >> 16);
+      myU[nMine] = fr[t];
+      myV[nMine++] = v;
+    }
+    __syncthreads();  // every key has been read: the array now holds the values
+    for (int i = 0; i < nMine; i++) lval[myU[i]] = myV[i];
+    __syncthreads();
+    double scale = 1.0;
+    bool divide = false;
+    if (additive && U > 0 && !must) {
+      scale = (double)U;
+      divide = true;
+    }
+    if (must) {
+      if (tid == 0) {
+        double norm = 0.0;
+        if (!l2) {
+          for (int u = 0; u < U; u++) norm += fabs(lval[u]);
+        } else {
+          for (int u = 0; u < U; u++) norm += lval[u] * lval[u];
+          norm = sqrt(norm);
+        }
+        normShared = norm;
+      }
+      __syncthreads();
+      scale = normShared;
+      divide = scale > 0.0;
+    }
+    for (int u = tid; u < U; u += kBowThreads) values[u] = divide ? lval[u] / scale : lval[u];
+    if (tid == 0) a.outCounts[img * 3 + 0] = U;
+    return;
   }
-  for (int u = tid; u < U; u += kBowThreads) values[u] = divide ? lval[u] / scale : lval[u];
-  __syncthreads();
 
   // ---- FeatureVector
   for (int t = tid; t < P; t += kBowThreads)
@@ -201,7 +205,6 @@ __global__ __launch_bounds__(kBowThreads) void k_bow_assemble(BowArgs a) {
     int used = 0;
     for (int w = 0; w < kBowThreads / 64; w++) used += wsum[w];
     nodeStart[V] = used;
-    a.outCounts[img * 3 + 0] = U;
     a.outCounts[img * 3 + 1] = V;
     a.outCounts[img * 3 + 2] = used;
   }
@@ -218,7 +221,7 @@ hipError_t launch_bow_transform(const BowArgs& a, int nimg, hipStream_t s) {
                                        (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_bow_assemble, dim3(nimg), dim3(kBowThreads), lds, s, a);
+  hipLaunchKernelGGL(k_bow_assemble, dim3(nimg, 2), dim3(kBowThreads), lds, s, a);
   return hipGetLastError();
 }
 
