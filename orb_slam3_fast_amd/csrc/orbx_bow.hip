@@ -313,20 +313,9 @@ __global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
       }
       if (b1 <= 50) {  // TH_LOW
         const bool leftOk = (float)b1 < __fmul_rn(a.nnratio, (float)b2), rightOk = b1r <= 50;
-        if (lane == 0) {
-          for (int side = 0; side < 2; side++) {
-            if (!(side ? rightOk : leftOk)) continue;
-            const int iF = side ? bir : bi;
-            a.match[iF] = iKF;
-            if (a.checkOri) {
-              float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[iF].angle);
-              if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
-              int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
-              if (bin == 30) bin = 0;
-              a.bin[iF] = bin;
-              atomicAdd(&a.flags[2 + bin], 1);
-            }
-          }
+        if (lane == 0) {  // (the rotation votes are cast afterwards by k_bow_vote: a frame feature is matched at most once,
+          if (leftOk) a.match[bi] = iKF;    // so the final matches ARE the votes, and the serial walk stays free of
+          if (rightOk) a.match[bir] = iKF;  // dependent keypoint loads)
         }
         made += (leftOk ? 1 : 0) + (rightOk ? 1 : 0);
         if (leftOk || rightOk) {  // mark the taken frame features of this node (positions in the node's list)
@@ -340,6 +329,19 @@ __global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
     }
   }
   if (lane == 0 && made) atomicAdd(&a.flags[0], made);
+}
+
+__global__ __launch_bounds__(256) void k_bow_vote(BowMatchArgs a) {  // rotHist[bin].push_back(bestIdxF), :336-346 / :367-377
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.nF) return;
+  const int iKF = a.match[i];
+  if (iKF < 0) return;
+  float rot = __fsub_rn(a.kfKps[iKF].angle, a.fKps[i].angle);
+  if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+  int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+  if (bin == 30) bin = 0;
+  a.bin[i] = bin;
+  atomicAdd(&a.flags[2 + bin], 1);
 }
 
 __global__ __launch_bounds__(256) void k_bow_cull(BowMatchArgs a) {  // :384-401 with ComputeThreeMaxima :1920-1955
@@ -382,7 +384,10 @@ __global__ __launch_bounds__(256) void k_bow_match_reset(BowMatchArgs a) {
 hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_bow_match_reset, dim3((max(a.nF, 33) + 255) / 256), dim3(256), 0, s, a);
   if (a.nKfNodes > 0 && a.nFNodes > 0) hipLaunchKernelGGL(k_bow_match, dim3(a.nKfNodes), dim3(64), 0, s, a);
-  if (a.checkOri && a.nF > 0) hipLaunchKernelGGL(k_bow_cull, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
+  if (a.checkOri && a.nF > 0) {
+    hipLaunchKernelGGL(k_bow_vote, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bow_cull, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
+  }
   hipLaunchKernelGGL(k_bow_result, dim3(1), dim3(1), 0, s, a);
   return hipGetLastError();
 }
