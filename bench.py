@@ -242,7 +242,7 @@ def main():
     units_per_step = 2 * B if a.mode == "mono" else B  # mono: every image is a frame
     value = a.gpus * units_per_step * a.steps / elapsed
     out = {
-        "metric": {"stereo": "ORB extract+match stereo frames/sec @%dx%d (both-eye ORBextractor + ComputeStereoMatches)",
+        "metric": {"stereo": "ORB extract+match frames/sec @%d\u00d7%d stereo (both-eye ORBextractor + ComputeStereoMatches)",
                    "mono": "ORB extract mono frames/sec @%dx%d (ORBextractor::operator())",
                    "fisheye": "ORB extract+match fisheye stereo frames/sec @%dx%d (both-eye ORBextractor with lapping areas "
                               "+ ComputeStereoFishEyeMatches)"}[a.mode] % (W, H),
