@@ -247,6 +247,11 @@ def test_hip_preproc_chain_and_raw_extraction(oracle):
     col = np.stack([L, np.roll(L, 2, 1), (L // 2 + 50).astype(np.uint8)], 2)
     pc = orbx.Preproc(sw, sh, channels=3, rgb=False, out_size=(600, 384), max_batch=1)
     assert np.array_equal(pc.run(col), oracle.cvt_gray(oracle.resize_c(col, 600, 384), rgb=False))
+    # colour frames through the rectification: cv::remap works per interleaved channel, GrabImageStereo converts afterwards
+    pr = orbx.Preproc(sw, sh, channels=3, rgb=True, maps=maps, max_batch=2)
+    for eye, (mx, my) in enumerate((ml, mr)):
+        planes = np.stack([oracle.remap(np.ascontiguousarray(col[..., c]), mx, my) for c in range(3)], 2)
+        assert np.array_equal(pr.run(col, eye), oracle.cvt_gray(planes, rgb=True)), eye
     # nothing enabled: pass-through
     p0 = orbx.Preproc(sw, sh, max_batch=1)
     assert np.array_equal(p0.run(L), L)
