@@ -303,6 +303,50 @@ def test_bf_knn2(gpu, oracle):
         assert np.array_equal(i, oi) and np.array_equal(d, od) and np.array_equal(okk, ook)
 
 
+def test_concurrent_one_shot_matchers(gpu, oracle):
+    """The one-shot entry points share the null stream, the per-device scratch pool and per-thread pinned staging: four
+    threads hammering different matchers at once must each get the oracle's answer every time."""
+    import threading
+    w, h = 640, 480
+    exA, exB = (orbx.ORBextractor(900, 1.2, 8, 20, 7, max_width=w, max_height=h) for _ in range(2))
+    L, R = synth.stereo_pair(w, h, 81)
+    _, k1, d1 = exA(L)
+    _, k2, d2 = exB(R)
+    bounds = (0.0, 0.0, float(w), float(h))
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    want_knn = oracle.bf_knn2(d1, d2)
+    want_init = oracle.search_init(k1, d1, k2, d2, bounds, prev, 60, 0.9, True)
+    q = np.stack([k1["x"][:64], k1["y"][:64], np.full(64, 25.0), np.full(64, -1.0), np.full(64, -1.0)], 1).astype(np.float32)
+    want_area = [oracle.features_in_area(k2, bounds, q[i, 0], q[i, 1], q[i, 2], -1, -1) for i in range(len(q))]
+    errors = []
+
+    def knn():
+        for _ in range(25):
+            got = orbx.bf_knn2(d1, d2)
+            if not all(np.array_equal(a, b) for a, b in zip(got, want_knn)):
+                errors.append("knn")
+
+    def init():
+        m = orbx.ORBmatcher(0.9, True)
+        for _ in range(25):
+            n, m12, newprev = m.SearchForInitialization(k1, d1, k2, d2, bounds, prev, 60)
+            if n != want_init[0] or not np.array_equal(m12, want_init[1]):
+                errors.append("init")
+
+    def area():
+        for _ in range(25):
+            res = orbx.GetFeaturesInArea(k2, bounds, q)
+            if not all(np.array_equal(a, b) for a, b in zip(res, want_area)):
+                errors.append("area")
+
+    ths = [threading.Thread(target=f) for f in (knn, init, area, knn)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, sorted(set(errors))
+
+
 def test_features_in_area_and_grid(gpu, oracle):
     """AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea as a standalone batched call."""
     w, h = 752, 480
