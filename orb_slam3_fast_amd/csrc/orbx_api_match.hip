@@ -322,10 +322,11 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
-                             uint8_t* occupied, int32_t* match, int cand_cap, int* needed) {
+                             uint8_t* occupied, int32_t* match, int cand_cap, int* needed, bool serial, bool* converged) {
   const int mode = points ? 1 : 0;
   *needed = 0;
-  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, taker2, choice, flags;
+  *converged = true;
+  ScratchBuf<int> cellStart, cellItems, candOff, candIdx, candDist, mdist, m21, m12, taker0, taker1, taker2, choice;
   hipError_t e = hipSuccess;
   auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
   const int nm = std::max(n_points, 1);
@@ -336,7 +337,8 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   const size_t oSf = pk.add(scale_factors, (size_t)std::max(nlevels, 1) * sizeof(float));
   const size_t oMp = pk.add(mode == 0 && n_points ? map_points : nullptr, (size_t)nm * sizeof(orbx_map_point_view));
   const size_t oPp = pk.add(mode == 1 && n_points ? points : nullptr, (size_t)nm * sizeof(orbx_projected_point));
-  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
+  const size_t oOcc = pk.add(occupied, n), oRes = pk.add(nullptr, 2 * sizeof(int));
+  const size_t oFlags = pk.add(nullptr, (40 + 48) * sizeof(int)), oMt = pk.add(nullptr, (size_t)n * sizeof(int));
   const size_t outBytes = oMt + (size_t)n * sizeof(int) - oOcc;
   chk(pk.commit());
   struct { orbx_keypoint* p; } k{pk.ptr<orbx_keypoint>(oK)};
@@ -344,8 +346,8 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   struct { float* p; } ur{pk.ptr<float>(oUr)}, sf{pk.ptr<float>(oSf)};
   struct { orbx_map_point_view* p; } mp{pk.ptr<orbx_map_point_view>(oMp)};
   struct { orbx_projected_point* p; } pp{pk.ptr<orbx_projected_point>(oPp)};
-  struct { int* p; } mt{pk.ptr<int>(oMt)}, result{pk.ptr<int>(oRes)};
-  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(taker2.alloc(n)); chk(choice.alloc(nm)); chk(flags.alloc(40 + 48));
+  struct { int* p; } mt{pk.ptr<int>(oMt)}, result{pk.ptr<int>(oRes)}, flags{pk.ptr<int>(oFlags)};
+  chk(taker0.alloc(n)); chk(taker1.alloc(n)); chk(taker2.alloc(n)); chk(choice.alloc(nm));
   chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n));
   chk(candOff.alloc(nm + 1)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
   ProjArgs a{};
@@ -365,26 +367,25 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   int res[2] = {0, 0};
   if (e == hipSuccess) chk(launch_proj_count(a, nullptr));
   a.taker[0] = taker0.p; a.taker[1] = taker1.p; a.taker[2] = taker2.p; a.choice = choice.p; a.flags = flags.p;
-  // Resolve: rounds of the parallel fixed-point iteration (k_proj_round) until a round changes nothing; the one-wave
-  // serial walk stays as the fallback for a pathological claim chain (ORBX_PROJ_SERIAL=1 forces it, for the tests).
-  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
+  // Resolve: kProjBlindRounds (16; ORBX_PROJ_BLIND) rounds of the parallel fixed-point iteration (k_proj_round) are enqueued without looking --
+  // rounds after the fixed point return at once -- followed by the finish kernels; whether the last round still changed
+  // something comes back with the results.  Then (pathological claim chains) the caller repeats the attempt with the
+  // one-wave serial walk, which ORBX_PROJ_SERIAL=1 also forces (tests).
+  static const int kProjBlindRounds = getenv("ORBX_PROJ_BLIND") ? std::min(48, std::max(1, atoi(getenv("ORBX_PROJ_BLIND")))) : 16;
   if (e == hipSuccess) chk(launch_proj_cands_fill(a, nullptr));
-  bool done = false;
-  if (!forceSerial && n_points > 0) {
-    for (int r = 0; r < 48 && e == hipSuccess && !done; r += 4) {
-      chk(launch_proj_rounds(a, r, 4, nullptr));
-      int changed = 1;  // did the last round of this group still change a choice?
-      if (e == hipSuccess) chk(hipMemcpy(&changed, flags.p + 40 + r + 3, sizeof(int), hipMemcpyDeviceToHost));  // synchronises
-      done = changed == 0;
-    }
-  }
-  if (e == hipSuccess) chk(done ? launch_proj_finish(a, 0, nullptr) : launch_proj_resolve_serial(a, nullptr));
+  const bool rounds = !serial && n_points > 0;
+  if (e == hipSuccess && rounds) chk(launch_proj_rounds(a, 0, kProjBlindRounds, nullptr));
+  if (e == hipSuccess) chk(rounds ? launch_proj_finish(a, 0, nullptr) : launch_proj_resolve_serial(a, nullptr));
   if (e == hipSuccess) {
     const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
     if (e == hipSuccess) {
       std::memcpy(res, h + (oRes - oOcc), sizeof(res));
+      int lastChanged = 0;
+      if (rounds) std::memcpy(&lastChanged, h + (oFlags - oOcc) + (40 + kProjBlindRounds - 1) * sizeof(int), sizeof(int));
       if (res[1] > cand_cap) {
         *needed = res[1];
+      } else if (lastChanged) {
+        *converged = false;
       } else {
         std::memcpy(occupied, h, n);
         std::memcpy(match, h + (oMt - oOcc), (size_t)n * sizeof(int));
@@ -393,7 +394,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   }
   pk.release(); cellStart.free(); cellItems.free();
   candOff.free(); candIdx.free(); candDist.free(); mdist.free(); m21.free(); m12.free();
-  taker0.free(); taker1.free(); taker2.free(); choice.free(); flags.free();
+  taker0.free(); taker1.free(); taker2.free(); choice.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   return res[0];
 }
@@ -409,12 +410,22 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   // room for 96 candidates per point on average (a search window holds 10-40); denser inputs repeat the call once with the
   // exact size.  ORBX_PROJ_CAND_CAP overrides the first guess (tests force the second attempt with it).
   static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  static const bool forceSerial = getenv("ORBX_PROJ_SERIAL") && atoi(getenv("ORBX_PROJ_SERIAL")) != 0;
   int cap = capEnv > 0 ? capEnv : std::max(n_points, 1) * 96, needed = 0;
-  rc = search_by_projection_try(kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels, map_points, points,
-                                n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, cap, &needed);
-  if (rc >= 0 && needed > cap)
+  bool serial = forceSerial, converged = true;
+  for (int attempt = 0; attempt < 3; attempt++) {  // at most: capacity retry, then serial retry
     rc = search_by_projection_try(kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels, map_points, points,
-                                  n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, needed, &needed);
+                                  n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, cap, &needed,
+                                  serial, &converged);
+    if (rc < 0) break;
+    if (needed > cap) { cap = needed; continue; }
+    if (!converged) {
+      if (trace_slow_ms() > 0) std::fprintf(stderr, "ORBX_TRACE_SLOW SearchByProjection: no fixed point within the blind rounds, serial walk\n");
+      serial = true;
+      continue;
+    }
+    break;
+  }
   return rc;
 }
 }  // namespace

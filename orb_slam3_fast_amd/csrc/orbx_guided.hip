@@ -732,6 +732,9 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
 __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the host enqueues a fixed number of rounds without looking: once a round has changed nothing the fixed point is reached
+  // and every later round returns at once (its changed[] entry stays 0)
+  if (round_no > 0 && a.flags[kProjChanged + round_no - 1] == 0) return;
   const int* takerPrev = a.taker[round_no % 3];
   int* takerNew = a.taker[(round_no + 1) % 3];
   {  // the buffer the NEXT round writes is cleared here (nobody touches it in this round): one launch per round
