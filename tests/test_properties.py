@@ -157,3 +157,27 @@ def test_bow_vector_is_invariant_under_feature_permutation(oracle, seed, k, L, l
         assert sorted(perm[f1[s1[j]:s1[j + 1]]].tolist()) == f0[s0[j]:s0[j + 1]].tolist()
     if len(v0):
         assert abs(v0.sum() - 1.0) < 1e-12 and (v0 > 0).all()
+
+
+@SET
+@given(st.integers(0, 2 ** 31 - 1), st.sampled_from([-1, 0, 30, 80]), st.booleans())
+def test_search_by_bow_invariants(oracle, seed, n_left, check_ori):
+    """Whatever the inputs: a matched pair shares its vocabulary node, the keyframe feature holds a good map point and passed
+    TH_LOW, and the returned count is the number of matched frame features."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_bow import _scene
+    from orb_slam3_fast_amd import synth
+    cols = synth.make_vocabulary(4, 3, seed=seed % 50)
+    voc = oracle.Vocabulary(4, 3, *cols)
+    kd, ka, kv, fd, fa = _scene(cols, 90, 80, seed % 1000, n_left)
+    kf_fv, f_fv = voc.transform(kd, 1)[1], voc.transform(fd, 1)[1]
+    n, m = oracle.search_by_bow(kf_fv, kd, ka, kv, f_fv, fd, fa, n_left, 0.7, check_ori)
+    assert n == int((m >= 0).sum())
+    node_of_kf = {int(i): int(kf_fv[0][j]) for j in range(len(kf_fv[0])) for i in kf_fv[2][kf_fv[1][j]:kf_fv[1][j + 1]]}
+    node_of_f = {int(i): int(f_fv[0][j]) for j in range(len(f_fv[0])) for i in f_fv[2][f_fv[1][j]:f_fv[1][j + 1]]}
+    for i_f in np.flatnonzero(m >= 0):
+        ikf = int(m[i_f])
+        assert kv[ikf] and node_of_kf[ikf] == node_of_f[int(i_f)]
+        d = int(np.unpackbits(kd[ikf] ^ fd[i_f]).sum())
+        assert d <= 50  # TH_LOW gates both eyes (the right eye additionally needs the LEFT best below it, :349-363)
