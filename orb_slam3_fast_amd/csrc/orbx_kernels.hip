@@ -1664,12 +1664,25 @@ __device__ __forceinline__ void orb_sincos_dev(float ang, float& s_out, float& c
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                  int* __restrict__ nOut, int* __restrict__ mono, int ablate) {
+                                                  int* __restrict__ nOut, int* __restrict__ mono, int ablate,
+                                                  int xcdImages) {
   __shared__ uint32_t patch_all[4][37 * DS_PITCH / 4];
   if (ablate == 1) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = blockIdx.x * 4 + wv;
-  const int img = blockIdx.y;
+  // The load phase of this kernel runs at HBM speed, and the keypoints of an image arrive in quadtree order (spatially
+  // scattered): with workgroups dealt round-robin to the 8 XCDs every L2 ends up fetching most of every image.  With
+  // xcdImages set, all workgroups of an image go to ONE XCD (image i -> XCD i mod 8), so its pyramid lines are fetched into
+  // one L2 only.  Only for the first 8 * floor(nimg / 8) images; the rest keep the plain order.
+  int bx = blockIdx.x, img = blockIdx.y;
+  if (xcdImages) {
+    const unsigned nbx = gridDim.x, flat = blockIdx.y * nbx + blockIdx.x, full = (gridDim.y / 8u) * 8u;
+    if (flat < full * nbx) {
+      const unsigned c = flat & 7u, j = flat >> 3;  // j-th workgroup of XCD c
+      img = (int)(c + 8u * (j / nbx));
+      bx = (int)(j % nbx);
+    }
+  }
+  const int s = bx * 4 + wv;
   if (s >= g.selImg) return;
   int l = 0;
   while (l + 1 < g.nlevels && s >= g.lv[l + 1].selOff) l++;
@@ -1782,8 +1795,9 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s) {
   static const int ablate = getenv("ORBX_DESC_ABLATE") ? atoi(getenv("ORBX_DESC_ABLATE")) : 0;
+  static const int xcdImages = getenv("ORBX_DESC_XCD") ? atoi(getenv("ORBX_DESC_XCD")) : 1;
   hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc, nOut, mono, ablate);
+                     kps, desc, nOut, mono, ablate, nimg >= 8 ? xcdImages : 0);
   return hipGetLastError();
 }
 
