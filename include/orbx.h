@@ -438,6 +438,10 @@ void orbx_debug_set_detect_list_cap(int cap);
 /* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
  * than 16384 FAST candidates); 0 restores the register-resident path. */
 void orbx_debug_set_octree_global(int on);
+/* The device's sinf / cosf of the descriptor steering (computeOrbDescriptor, src/ORBextractor.cc:106-107: libm cosf / sinf;
+ * csrc/orbx_sincos.h restates glibc's two x86-64 ifunc variants): evaluates n angles (radians, host arrays) with the FMA
+ * (fused != 0) or the SSE2 variant.  tests/ compare both with the host's libm bit for bit. */
+int orbx_debug_sincos(int device, const float* angles, int n, int fused, float* sin_out, float* cos_out);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,11 @@ def lib():
         _lib.oro_fast_atan2.restype = C.c_float
         _lib.oro_fast_atan2.argtypes = [C.c_float, C.c_float]
         _lib.oro_sincosf.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        _lib.oro_sincos_model.argtypes = [C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.oro_sincos_check.restype = C.c_longlong
+        _lib.oro_sincos_check.argtypes = [C.c_uint64, C.c_longlong, C.c_int, C.c_void_p]
+        _lib.oro_libm_sincos_array.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
+        _lib.oro_reachable_angles.argtypes = [C.c_uint64, C.c_longlong, C.c_void_p]
         _lib.oro_cv_round_f.argtypes = [C.c_float]
         _lib.oro_ic_angle.restype = C.c_float
         _lib.oro_kb8_triangulate.restype = C.c_float
@@ -149,6 +154,41 @@ def sincosf(a):
     s, c = C.c_float(), C.c_float()
     lib().oro_sincosf(C.c_float(a), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def set_sincos_mode(mode):
+    """0 = host libm sinf/cosf (default: the reference's own dependency), 1 / 2 = model of glibc's FMA / SSE2 variant."""
+    lib().oro_set_sincos_mode(int(mode))
+
+
+def host_libm_variant():
+    return int(lib().oro_host_libm_variant())
+
+
+def sincos_model(a, fused):
+    s, c = C.c_float(), C.c_float()
+    lib().oro_sincos_model(C.c_float(a), int(fused), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sincos_check(seed, n, fused):
+    """Mismatches of the glibc model against the host libm over n fastAtan2-reachable angles (+ the first bad angle)."""
+    fb = C.c_float(0)
+    bad = lib().oro_sincos_check(int(seed), int(n), int(fused), C.byref(fb))
+    return int(bad), fb.value
+
+
+def reachable_angles(seed, n):
+    out = np.zeros(n, np.float32)
+    lib().oro_reachable_angles(int(seed), int(n), _p(out))
+    return out
+
+
+def libm_sincos(angles):
+    a = np.ascontiguousarray(angles, np.float32)
+    s, c = np.zeros_like(a), np.zeros_like(a)
+    lib().oro_libm_sincos_array(_p(a), a.size, _p(s), _p(c))
+    return s, c
 
 
 def ic_angle(img, cx, cy):

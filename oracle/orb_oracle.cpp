@@ -50,40 +50,139 @@ float fast_atan2(float y, float x) {
 }
 
 // ======================================================================================= B8 sinf/cosf
-// The reference calls libm cosf/sinf (src/ORBextractor.cc:107). glibc's result is within 0.56 ulp and
-// differs between its FMA / non-FMA ifunc variants, i.e. it is machine dependent in the last bit.  The
-// oracle therefore DEFINES sin/cos as: evaluate in IEEE double with the fixed operation sequence below
-// (fdlibm kernel polynomials after a 2-term Cody-Waite reduction by pi/2), then round once to float.
-// That is the correctly-rounded float value except with probability ~1e-8 per call;
-// tests/test_oracle_kernels.py measures the (1-ulp) disagreement with this host's libm.
-void orb_sincosf(float ang, float* s_out, float* c_out) {
-  const double x = (double)ang;
-  const double two_over_pi = 6.36619772367581382433e-01;
-  const double pio2_hi = 1.57079632673412561417e+00;  // 33 bits of pi/2
-  const double pio2_lo = 6.07710050650619224932e-11;  // pi/2 - pio2_hi
-  const double fk = std::floor(x * two_over_pi + 0.5);
-  const int k = (int)fk;
-  const double r = (x - fk * pio2_hi) - fk * pio2_lo;
-  const double z = r * r;
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  const double ps = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  const double sn = r + (z * r) * (S1 + z * ps);
-  const double pc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
-  const double cs = 1.0 - (0.5 * z - z * pc);
-  double sv, cv;
-  switch (k & 3) {
-    case 0: sv = sn; cv = cs; break;
-    case 1: sv = cs; cv = -sn; break;
-    case 2: sv = -sn; cv = -cs; break;
-    default: sv = -cs; cv = sn; break;
+// The reference calls libm: `(float)cos(angle), (float)sin(angle)` with a float argument under `using namespace std`
+// (src/ORBextractor.cc:66-67,106-107) resolves to std::cos(float) / std::sin(float) = cosf / sinf (GCC may merge the
+// pair into one sincosf call; glibc's three entry points run the same arithmetic per result).  The oracle therefore
+// CALLS THE HOST'S libm (mode 0, the default): on a glibc >= 2.28 x86-64 host that is the reference's own dependency.
+//
+// glibc's sinf/cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c; ARM optimized-routines
+// algorithm) evaluate in double: |y| < pi/4 directly, otherwise n = round(y * 2/pi) by a scaled int conversion,
+// r = y - n * pi/2, then a degree-7 sine or degree-8 cosine polynomial picked by the quadrant.  x86-64 builds select
+// one of two ifunc variants of the SAME C code at load time: __sinf_fma (every a + b*c fused, CPUs with FMA + AVX2)
+// and __sinf_sse2 (separate multiply and add).  Their results differ in the last bit for ~0.1 % of the arguments, so
+// "what sinf returns" is a property of the machine.  glibc_sinf_model / glibc_cosf_model below restate both variants
+// (operation order read off the glibc 2.35 objects of this image: libm-2.35.a, s_sinf-fma.o / s_sinf-sse2.o /
+// s_cosf-*.o / s_sincosf-fma.o; coefficients from s_sincosf_data.o); modes 1 / 2 select them so that fixtures can
+// be generated for a stated variant, and tests check model == host libm over >= 10^7 fastAtan2-reachable angles and
+// (tools/sincos_sweep) over every float in [0, 2 pi].  The device runs the same two variants (csrc/orbx_sincos.h).
+namespace {
+struct SinCosTab {
+  double sign[4], hpi_inv, hpi, c0, c1, s1, c2, s2, c3, s3, c4;
+};
+const SinCosTab kSinCosTab[2] = {
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2,
+     -0x1.555545995a603p-3, 0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, -0x1.6c087e89a359dp-10,
+     -0x1.994eb3774cf24p-13, 0x1.99343027bf8c3p-16},
+    {{1.0, -1.0, -1.0, 1.0}, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2,
+     -0x1.555545995a603p-3, -0x1.55553e1068f19p-5, 0x1.1107605230bc4p-7, 0x1.6c087e89a359dp-10,
+     -0x1.994eb3774cf24p-13, -0x1.99343027bf8c3p-16}};
+inline double mul_add(double a, double b, double c, bool fused) { return fused ? std::fma(a, b, c) : a * b + c; }
+// sinf_poly of sincosf.h: n even -> sine of x (x2 = x*x up to the sign folded into x), n odd -> cosine
+inline float sinf_poly_model(double x, double x2, const SinCosTab& p, int n, bool fused) {
+  if ((n & 1) == 0) {
+    const double x3 = x * x2;
+    const double s1 = mul_add(x2, p.s3, p.s2, fused);
+    const double x7 = x3 * x2;
+    const double s = mul_add(x3, p.s1, x, fused);
+    return (float)mul_add(x7, s1, s, fused);
   }
-  *s_out = (float)sv;
-  *c_out = (float)cv;
+  const double x4 = x2 * x2;
+  const double c2 = mul_add(x2, p.c4, p.c3, fused);
+  const double c1 = mul_add(x2, p.c1, p.c0, fused);
+  const double x6 = x4 * x2;
+  const double c = mul_add(x4, p.c2, c1, fused);
+  return (float)mul_add(x6, c2, c, fused);
+}
+inline uint32_t abstop12(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  return (u >> 20) & 0x7ff;
+}
+inline double reduce_fast_model(double x, const SinCosTab& p, int* np, bool fused) {
+  const double r = x * p.hpi_inv;
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return fused ? std::fma(-(double)n, p.hpi, x) : x - (double)n * p.hpi;
+}
+int g_sincos_mode = 0;
+}  // namespace
+
+// Valid for |y| < 120 (the path only produces y in [0, 2 pi]); larger arguments take glibc's reduce_large, not restated.
+float glibc_sinf_model(float y, bool fused) {
+  double x = y;
+  const SinCosTab* p = &kSinCosTab[0];
+  if (abstop12(y) < 0x3f4) {  // |y| < pi/4
+    if (abstop12(y) < 0x398) return y;  // |y| < 2^-12
+    return sinf_poly_model(x, x * x, *p, 0, fused);
+  }
+  int n;
+  x = reduce_fast_model(x, *p, &n, fused);
+  const double s = p->sign[n & 3];
+  if (n & 2) p = &kSinCosTab[1];
+  return sinf_poly_model(x * s, x * x, *p, n, fused);
+}
+float glibc_cosf_model(float y, bool fused) {
+  double x = y;
+  const SinCosTab* p = &kSinCosTab[0];
+  if (abstop12(y) < 0x3f4) {
+    if (abstop12(y) < 0x398) return 1.0f;
+    return sinf_poly_model(x, x * x, *p, 1, fused);
+  }
+  int n;
+  x = reduce_fast_model(x, *p, &n, fused);
+  const double s = p->sign[n & 3];
+  if (n & 2) p = &kSinCosTab[1];
+  return sinf_poly_model(x * s, x * x, *p, n ^ 1, fused);
+}
+
+void orb_set_sincos_mode(int mode) { g_sincos_mode = mode; }
+int orb_get_sincos_mode() { return g_sincos_mode; }
+void orb_sincosf(float ang, float* s_out, float* c_out) {
+  if (g_sincos_mode == 0) {  // the reference's own dependency on this machine
+    *s_out = sinf(ang);
+    *c_out = cosf(ang);
+  } else {
+    *s_out = glibc_sinf_model(ang, g_sincos_mode == 1);
+    *c_out = glibc_cosf_model(ang, g_sincos_mode == 1);
+  }
+}
+
+// Which glibc variant this host's libm runs: 1 = FMA, 2 = SSE2, 0 = neither model matches (not glibc >= 2.28 / x86-64).
+// Sweeps every 2^11-th float of [0, 2 pi] (>= 5e5 arguments; the two variants differ on ~1e-3 of them).
+int orb_host_libm_variant() {
+  bool okF = true, okS = true;
+  for (uint32_t u = 0; u <= 0x40C91000u; u += 2039u) {
+    float y;
+    std::memcpy(&y, &u, 4);
+    const float hs = sinf(y), hc = cosf(y);
+    okF = okF && hs == glibc_sinf_model(y, true) && hc == glibc_cosf_model(y, true);
+    okS = okS && hs == glibc_sinf_model(y, false) && hc == glibc_cosf_model(y, false);
+    if (!okF && !okS) return 0;
+  }
+  return okF ? 1 : (okS ? 2 : 0);
+}
+
+// Mismatch count of one model against the host libm over n angles the path can produce: fastAtan2 of random
+// integer moment pairs (|m| < 2^21, the range of IC_Angle's sums) times factorPI, as computeOrbDescriptor forms it.
+long long orb_sincos_check(uint64_t seed, long long n, int fused, float* first_bad) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  long long bad = 0;
+  uint64_t st = seed;
+  for (long long i = 0; i < n; i++) {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const int sh = (int)((z >> 60) & 15);  // mixed magnitudes: small moments give "round" angles
+    const int m01 = (int)((int64_t)(z & 0x3FFFFF) - 0x200000) >> sh, m10 = (int)((int64_t)((z >> 24) & 0x3FFFFF) - 0x200000) >> sh;
+    const float ang = fast_atan2((float)m01, (float)m10) * factorPI;
+    if (sinf(ang) != glibc_sinf_model(ang, fused != 0) || cosf(ang) != glibc_cosf_model(ang, fused != 0)) {
+      if (bad == 0 && first_bad) *first_bad = ang;
+      bad++;
+    }
+  }
+  return bad;
 }
 
 // ======================================================================================= B2 resize

@@ -39,7 +39,13 @@ struct Image {
 int cv_round(float v);
 int cv_round(double v);
 float fast_atan2(float y, float x);                                   // B5
-void orb_sincosf(float ang, float* s, float* c);                      // B8 (see .cpp: defined algorithm)
+void orb_sincosf(float ang, float* s, float* c);                      // B8: host libm sinf/cosf (mode 0) or a glibc model
+void orb_set_sincos_mode(int mode);  // 0 = host libm (default), 1 = glibc FMA-variant model, 2 = glibc SSE2-variant model
+int orb_get_sincos_mode();
+float glibc_sinf_model(float y, bool fused);
+float glibc_cosf_model(float y, bool fused);
+int orb_host_libm_variant();         // 1 = FMA, 2 = SSE2, 0 = no model matches the host libm
+long long orb_sincos_check(uint64_t seed, long long n, int fused, float* first_bad);
 void resize_linear_u8(const Image& src, Image& dst, int dw, int dh);  // B2
 // FAST-9-16 with non-max suppression on a standalone image (ROI already cut); out: x,y,score triples.
 struct FastPt { int x, y, score; };

@@ -5,6 +5,8 @@
 
 #include "orb_oracle.h"
 
+#include <math.h>
+
 using namespace orbo;
 
 extern "C" {
@@ -97,6 +99,38 @@ void oro_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) {
 }
 float oro_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 void oro_sincosf(float a, float* s, float* c) { orb_sincosf(a, s, c); }
+void oro_set_sincos_mode(int mode) { orb_set_sincos_mode(mode); }
+int oro_get_sincos_mode() { return orb_get_sincos_mode(); }
+int oro_host_libm_variant() { return orb_host_libm_variant(); }
+void oro_sincos_model(float a, int fused, float* s, float* c) {
+  *s = glibc_sinf_model(a, fused != 0);
+  *c = glibc_cosf_model(a, fused != 0);
+}
+// host libm over an array (the reference's dependency itself; used to check the device's restatement)
+void oro_libm_sincos_array(const float* a, long long n, float* s, float* c) {
+  for (long long i = 0; i < n; i++) {
+    s[i] = sinf(a[i]);
+    c[i] = cosf(a[i]);
+  }
+}
+// the angles orb_sincos_check draws: fastAtan2 of random integer moments times factorPI
+void oro_reachable_angles(uint64_t seed, long long n, float* out) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  uint64_t st = seed;
+  for (long long i = 0; i < n; i++) {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const int sh = (int)((z >> 60) & 15);
+    const int m01 = (int)((int64_t)(z & 0x3FFFFF) - 0x200000) >> sh, m10 = (int)((int64_t)((z >> 24) & 0x3FFFFF) - 0x200000) >> sh;
+    out[i] = fast_atan2((float)m01, (float)m10) * factorPI;
+  }
+}
+long long oro_sincos_check(uint64_t seed, long long n, int fused, float* first_bad) {
+  return orb_sincos_check(seed, n, fused, first_bad);
+}
 int oro_cv_round_f(float v) { return cv_round(v); }
 float oro_ic_angle(const uint8_t* img, int w, int h, int cx, int cy) {
   Image s(w, h);

@@ -128,6 +128,7 @@ def lib():
         L.orbx_debug_set_detect_list_cap.restype = None
         L.orbx_debug_set_octree_global.argtypes = [i]
         L.orbx_debug_set_octree_global.restype = None
+        L.orbx_debug_sincos.argtypes = [i, vp, i, i, vp, vp]
         _lib = L
     return _lib
 
@@ -325,6 +326,14 @@ def ComputeStereoMatches(left, right, bf, b, first_left=0, first_right=0, n_pair
 
 def stereo_match_async(left, right, bf, b, first_left=0, first_right=0, n_pairs=1):
     _check(lib().orbx_stereo_match_batch(left._h, first_left, right._h, first_right, n_pairs, bf, b))
+
+
+def debug_sincos(angles, fused=True, device=0):
+    """Test hook: the device's sinf / cosf (csrc/orbx_sincos.h: glibc's FMA or SSE2 variant) of angles in radians."""
+    a = np.ascontiguousarray(angles, np.float32)
+    sn, cs = np.zeros_like(a), np.zeros_like(a)
+    _check(lib().orbx_debug_sincos(device, _p(a), a.size, 1 if fused else 0, _p(sn), _p(cs)))
+    return sn, cs
 
 
 def bf_knn2(descQ, descT, device=0):

@@ -962,4 +962,21 @@ int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
   return ORBX_OK;
 }
 
+int orbx_debug_sincos(int device, const float* angles, int n, int fused, float* sin_out, float* cos_out) {
+  if (!angles || !sin_out || !cos_out || n < 0) return fail(ORBX_E_BADARG, "bad argument");
+  if (n == 0) return ORBX_OK;
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  ScratchBuf<float> d;
+  HIPC(d.alloc((size_t)3 * n));
+  hipError_t e = hipMemcpy(d.p, angles, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = launch_debug_sincos(d.p, n, fused, d.p + n, d.p + 2 * (size_t)n, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(sin_out, d.p + n, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(cos_out, d.p + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost);
+  d.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
 }  // extern "C"

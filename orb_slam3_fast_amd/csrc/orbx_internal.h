@@ -307,5 +307,6 @@ void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);
 void debug_set_octree_global(int on);
 hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s);
+hipError_t launch_debug_sincos(const float* ang, int n, int fused, float* s, float* c, hipStream_t st);
 
 }  // namespace orbx

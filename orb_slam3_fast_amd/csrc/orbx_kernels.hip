@@ -16,6 +16,7 @@
 // round-half-even conversions, mirroring the x86-64 baseline (no FMA) build of the reference.
 #include "orbx_device.h"
 #include "orbx_introsort.h"
+#include "orbx_sincos.h"
 
 namespace orbx {
 
@@ -1618,40 +1619,6 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
   return a;
 }
 
-// sin/cos of the descriptor rotation: IEEE double, fixed operation sequence (identical to the oracle's
-// definition, oracle/orb_oracle.cpp orb_sincosf), rounded once to float.
-__device__ __forceinline__ void orb_sincos_dev(float ang, float& s_out, float& c_out) {
-  const double x = (double)ang;
-  const double fk = floor(__dadd_rn(__dmul_rn(x, 6.36619772367581382433e-01), 0.5));
-  const int k = (int)fk;
-  const double r = __dsub_rn(__dsub_rn(x, __dmul_rn(fk, 1.57079632673412561417e+00)),
-                             __dmul_rn(fk, 6.07710050650619224932e-11));
-  const double z = __dmul_rn(r, r);
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-#define DM(a, b) __dmul_rn(a, b)
-#define DA(a, b) __dadd_rn(a, b)
-  const double ps = DA(S2, DM(z, DA(S3, DM(z, DA(S4, DM(z, DA(S5, DM(z, S6))))))));
-  const double sn = DA(r, DM(DM(z, r), DA(S1, DM(z, ps))));
-  const double pc = DM(z, DA(C1, DM(z, DA(C2, DM(z, DA(C3, DM(z, DA(C4, DM(z, DA(C5, DM(z, C6)))))))))));
-  const double cs = __dsub_rn(1.0, __dsub_rn(DM(0.5, z), DM(z, pc)));
-#undef DM
-#undef DA
-  double sv, cv;
-  switch (k & 3) {
-    case 0: sv = sn; cv = cs; break;
-    case 1: sv = cs; cv = -sn; break;
-    case 2: sv = -sn; cv = -cs; break;
-    default: sv = -cs; cv = sn; break;
-  }
-  s_out = (float)sv;
-  c_out = (float)cv;
-}
-
 // One wave per selected keypoint.
 //  * IC_Angle (:75-99): lanes run along patch COLUMNS so that every load instruction reads one 31-byte row
 //    segment (1-2 cache lines) — two half-waves take the upper / lower 15 rows; integer moments are reduced
@@ -1752,7 +1719,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   const float angle = fast_atan2_dev((float)m01, (float)m10);
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, b;
-  orb_sincos_dev(__fmul_rn(angle, factorPI), b, a);  // a = cos, b = sin
+  glibc_sincosf<true>(__fmul_rn(angle, factorPI), b, a);  // a = cosf, b = sinf (orbx_sincos.h)
   // slot == nullptr: no keypoint can lie in the lapping area (lap1 < 19 <= every x), so the serial-order slot is
   // simply (keypoints of the earlier levels) + idx and k_slots is not launched at all
   int n_out_slot;
@@ -1809,6 +1776,21 @@ hipError_t prepare_kernels(const Geom& g) {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_det);
+}
+
+// Test entry: both glibc sinf/cosf variants on the device (compared with the host libm in tests).
+__global__ void k_debug_sincos(const float* __restrict__ ang, int n, int fused, float* __restrict__ s, float* __restrict__ c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sv, cv;
+  if (fused) glibc_sincosf<true>(ang[i], sv, cv);
+  else glibc_sincosf<false>(ang[i], sv, cv);
+  s[i] = sv;
+  c[i] = cv;
+}
+hipError_t launch_debug_sincos(const float* ang, int n, int fused, float* s, float* c, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_sincos, dim3((n + 255) / 256), dim3(256), 0, st, ang, n, fused, s, c);
+  return hipGetLastError();
 }
 
 // Host-callable check of the introsort replica (tests compare with std::sort).

@@ -134,6 +134,26 @@ def test_device_introsort_matches_libstdcxx(gpu, oracle):
         assert np.array_equal(a, b), "n=%d mode=%d" % (n, mode)
 
 
+def test_device_sincos_equals_host_libm(gpu, oracle):
+    """computeOrbDescriptor steers the pattern with libm cosf / sinf (src/ORBextractor.cc:106-107).  The device's
+    restatement of glibc's sinf / cosf — both x86-64 ifunc variants — must return the host libm's floats bit for bit:
+    1.2e7 angles formed the way the path forms them (fastAtan2 of integer moments x factorPI) + a strided sweep of
+    every float in [0, 2 pi] + the float neighbourhoods of the quadrant boundaries."""
+    around = []
+    for q in (np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, 5 * np.pi / 4, 3 * np.pi / 2, 7 * np.pi / 4, 2 * np.pi, 2.0 ** -12):
+        b = np.float32(q).view(np.uint32).astype(np.int64)
+        around.append((b + np.arange(-4096, 4097)).astype(np.uint32).view(np.float32))
+    sweep = np.arange(0, 0x40C91000, 97, dtype=np.uint32).view(np.float32)   # 1.1e7 floats across [0, 2 pi]
+    ang = np.concatenate([oracle.reachable_angles(20220131, 12_000_000), sweep] + around).astype(np.float32)
+    hs, hc = oracle.libm_sincos(ang)
+    for fused in (True, False):
+        ds, dc = orbx.debug_sincos(ang, fused)
+        assert ds.tobytes() == hs.tobytes(), "device sinf (fused=%s) != host libm at %r" % (
+            fused, ang[np.flatnonzero(ds.view(np.uint32) != hs.view(np.uint32))[:4]])
+        assert dc.tobytes() == hc.tobytes(), "device cosf (fused=%s) != host libm at %r" % (
+            fused, ang[np.flatnonzero(dc.view(np.uint32) != hc.view(np.uint32))[:4]])
+
+
 @pytest.mark.parametrize("nf,sf,nl,ini,mn,w,h", [
     (2000, 1.5, 5, 12, 5, 640, 480),      # other scale factor / thresholds / level count
     (700, 2.0, 3, 30, 10, 512, 384),      # exact 2x steps: OpenCV switches INTER_LINEAR to the 2x2 INTER_AREA fast

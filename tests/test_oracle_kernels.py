@@ -225,28 +225,40 @@ def test_cv_round_half_even(oracle):
 
 
 def test_sincos_vs_libm(oracle):
-    """Defined sin/cos = double evaluation rounded once; must stay within 1 ulp of this host's libm and
-    agree almost everywhere (the reference's libm result is itself machine dependent, see oracle)."""
-    libm = ctypes.CDLL(ctypes.util.find_library("m"))
-    libm.cosf.restype = ctypes.c_float
-    libm.cosf.argtypes = [ctypes.c_float]
-    libm.sinf.restype = ctypes.c_float
-    libm.sinf.argtypes = [ctypes.c_float]
-    rng = np.random.default_rng(4)
+    """The reference calls libm cosf / sinf (src/ORBextractor.cc:106-107); the oracle calls the host's libm, and its
+    restatement of glibc's two ifunc variants (the definition the device runs, csrc/orbx_sincos.h) must EQUAL the host
+    libm bit for bit: 1.2e7 angles drawn the way the path forms them (fastAtan2 of integer moments, times factorPI),
+    plus a strided sweep of all floats in [0, 2 pi] (tools/sincos_sweep.cpp is the exhaustive version: 1.09e9
+    arguments, 0 mismatches for either variant on glibc 2.35)."""
+    assert oracle.host_libm_variant() in (1, 2), "host libm is not a glibc >= 2.28 x86-64 sinf/cosf"
+    for fused in (1, 0):
+        bad, first = oracle.sincos_check(20220131, 12_000_000, fused)
+        assert bad == 0, "glibc model (fused=%d) differs from the host libm, first at angle %r" % (fused, first)
+    # spot values: exact quadrant angles as the path forms them, and agreement with float64 to half an ulp
     fpi = np.float32(np.pi / np.float32(180.0))
-    angs = (rng.random(20000).astype(np.float32) * np.float32(360.0)) * fpi
-    angs = np.concatenate([angs, np.array([0, 90, 180, 270, 360], np.float32) * fpi])
-    mism = 0
-    for a in angs:
-        s, c = oracle.sincosf(float(a))
-        ls, lc = libm.sinf(float(a)), libm.cosf(float(a))
-        for v, r in ((s, ls), (c, lc)):
-            if v != r:
-                mism += 1
-                assert abs(v - r) <= np.spacing(np.float32(abs(r))) * 1.01
-        ref_s, ref_c = np.sin(np.float64(a)), np.cos(np.float64(a))
-        assert abs(s - ref_s) < 6e-8 + abs(ref_s) * 6e-8 and abs(c - ref_c) < 6e-8 + abs(ref_c) * 6e-8
-    assert mism < 0.02 * 2 * len(angs)
+    for deg in (0, 45, 90, 135, 180, 225, 270, 315, 360):
+        a = float(np.float32(deg) * fpi)
+        s, c = oracle.sincosf(a)
+        assert (s, c) == oracle.sincos_model(a, 1) == oracle.sincos_model(a, 0)
+        assert abs(s - np.sin(np.float64(a))) < 6e-8 and abs(c - np.cos(np.float64(a))) < 6e-8
+    ang = oracle.reachable_angles(7, 100000)
+    ls, lc = oracle.libm_sincos(ang)
+    assert np.all(np.abs(ls - np.sin(ang.astype(np.float64))) <= 0.57 * np.spacing(np.abs(ls)) + 1e-45)  # glibc: < 0.56 ulp
+    assert np.all(np.abs(lc - np.cos(ang.astype(np.float64))) <= 0.57 * np.spacing(np.abs(lc)) + 1e-45)
+
+
+def test_sincos_modes_agree_in_descriptors(oracle):
+    """Descriptor bytes are the same whichever sin/cos definition is selected (host libm, FMA model, SSE2 model)."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    try:
+        out = []
+        for mode in (0, 1, 2):
+            oracle.set_sincos_mode(mode)
+            out.append([oracle.descriptor(img, 32, 32, float(a)).tobytes() for a in np.linspace(0, 359.9, 720, dtype=np.float32)])
+        assert out[0] == out[1] == out[2]
+    finally:
+        oracle.set_sincos_mode(0)
 
 
 # ------------------------------------------------------------------------------------------- A5 / A7
