@@ -4,12 +4,21 @@
 A step = one pass of the hot path over one batch of B synthetic 1280x720 rectified stereo pairs per GPU:
 both-eye ORBextractor::operator() (pyramid, per-cell FAST, quadtree, orientation, blur, rBRIEF) followed by
 Frame::ComputeStereoMatches, all in the hand-written HIP kernels of liborbx.so, inputs resident in HBM.
+Every pair of a batch comes from a DIFFERENT synthetic camera stream (--distinct = B) and consecutive steps take
+consecutive frames of those streams from a ring uploaded before the timed region (--ring).
 One process per GPU; frames are independent, so ranks share nothing on the data path ("scaling": "weak");
-torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only.
+torch.distributed (RCCL) is used for the barriers and the max-over-ranks time only (plus the optional descriptor
+all-gather of config C5, --config C5).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  "roofline":     dominant kernel, algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak
-  "cpu_baseline": the CPU oracle (single-thread port of the reference's serial semantics) on a bounded sample
+  "roofline":      dominant kernel: algorithmic bytes / HIP-event time vs the 8 TB/s HBM peak (the contract's fraction),
+                   roofline.valu = the same launch against the chip's VALU issue rate (what actually limits it),
+                   roofline.streaming = the three streaming kernels of SURVEY 8d against the HBM peak
+  "cpu_baseline":  the CPU oracle (port of the reference's serial semantics) frame-parallel on the host cores,
+  "cpu_mt":        the same port with the reference's thread structure (2 eye threads x per-level tasks), one pipeline
+  "latency_ms", "extract_ms", "stereo_ms": one 1280x720 stereo frame through the drop-in host API, timers placed like
+                   the reference's REGISTER_TIMES (src/Frame.cc:196-232)
+  "h2d_inclusive_value": the same batches with page-locked HOST frames uploaded every step and all results downloaded
 """
 import argparse
 import json
@@ -21,34 +30,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9        # peak shader clock; a wave64 VALU instruction holds its SIMD for 4 cycles
+BF, BASE = 0.12 * 532.03, 0.12  # ZED2-like rig: fx = 532.03 px, baseline 0.12 m
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # 100 steps = 0.1 s of GPU time: with two batches in flight the first and the last step have no partner to overlap
-    # with, which costs a 20-step run ~5 % (33.3 k vs 35.0 k pairs/s at 100 steps, 35.25 k at 300)
+    # with, which costs a 20-step run ~5 %
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=32, help="stereo pairs per step per GPU")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--nfeatures", type=int, default=1500)
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic streams generated per GPU")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic camera streams per GPU (0 = one per pair of the batch: nothing is tiled)")
+    ap.add_argument("--ring", type=int, default=3, help="frames of every stream resident in HBM; step i takes frame i mod ring")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency / H2D-inclusive / cpu legs (profiling runs)")
+    ap.add_argument("--latency-frames", type=int, default=200)
+    ap.add_argument("--h2d-steps", type=int, default=30)
     ap.add_argument("--handles", type=int, default=2,
                     help="extractor handles used round-robin (each owns streams + buffers); 2 = double buffering: the "
-                         "next batch's pyramid / FAST overlaps the tail of the previous one (+12%% over 1)")
+                         "next batch's pyramid / FAST overlaps the tail of the previous one")
     ap.add_argument("--mode", choices=("stereo", "mono", "fisheye"), default="stereo",
                     help="stereo = BASELINE config C3 (the headline metric); mono = extraction only (C2: --width 640 "
                          "--height 480 --nfeatures 1000), value counts single frames; fisheye = C4 (--width 512 --height 512):"
                          " lapping areas + ComputeStereoFishEyeMatches (2-NN + KB8 triangulation) on the device")
+    ap.add_argument("--config", choices=("C3", "C5"), default="C3",
+                    help="C5 = BASELINE config 5 as one GPU sees it: 8 distinct streams per GPU, --inflight consecutive frames "
+                         "of each per step (pairs = 8 x inflight), RCCL all-gather of the descriptor blocks every step "
+                         "(initialises RCCL even with one rank)")
+    ap.add_argument("--inflight", type=int, default=4, help="C5: frames of every stream per step")
     ap.add_argument("--allgather", action="store_true",
-                    help="config C5 extra: RCCL all-gather of every rank's descriptor blocks after each step")
-    return ap.parse_args()
+                    help="RCCL all-gather of every rank's descriptor blocks after each step (implied by --config C5)")
+    a = ap.parse_args(argv)
+    if a.config == "C5":
+        a.mode, a.allgather, a.distinct = "stereo", True, 8
+        a.pairs = 8 * max(1, a.inflight)
+    if a.distinct <= 0:
+        a.distinct = a.pairs
+    a.distinct = max(1, min(a.distinct, a.pairs))
+    a.ring = max(1, a.ring)
+    return a
 
 
 def usable_cores():
@@ -93,6 +123,89 @@ def algorithmic_bytes(stage, NI, P, plevels, ncand, nsel, nmatch_in, npairs):
     return 0
 
 
+class _Raw:  # zero-copy view of a liborbx device buffer as a torch tensor
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class Workload:
+    """Everything a timed step touches: the frame ring in HBM, the extractor handles, the step itself.
+    tests/test_bench_mode_parity.py drives exactly this object and checks its results against the oracle."""
+
+    def __init__(self, a, rank=0, local_rank=0, dist=None):
+        import numpy as np
+        import torch
+        import orb_slam3_fast_amd as orbx
+        from orb_slam3_fast_amd import synth
+        self.a, self.np, self.torch, self.orbx, self.dist = a, np, torch, orbx, dist
+        W, H, B = a.width, a.height, a.pairs
+        D, R = a.distinct, a.ring
+        # ---- synthetic streams (deterministic, SURVEY 8d).  C3: D distinct streams, pair p = stream p mod D, frame = ring
+        # slot.  C5: 8 streams x K consecutive frames per step: pair p = stream p // K, frame slot + p mod K.
+        self.K = max(1, a.inflight) if a.config == "C5" else 1
+        streams = [1000 * rank + i for i in range(D)]
+        frames = list(range(R + self.K - 1))
+        t0 = time.time()
+        gl, gr = synth.stereo_ring(W, H, streams, frames, workers=usable_cores())   # [F, D, H, W]
+        self.gen_s = time.time() - t0
+        self.streams = streams
+        lefts, rights = [], []
+        for slot in range(R):
+            if a.config == "C5":
+                idx = [(p // self.K, slot + p % self.K) for p in range(B)]
+            else:
+                idx = [(p % D, slot) for p in range(B)]
+            lefts.append(np.stack([gl[f, s] for s, f in idx]))
+            rights.append(np.stack([gr[f, s] for s, f in idx]))
+        self.host_left, self.host_right = np.stack(lefts), np.stack(rights)          # [R, B, H, W]
+        host = np.concatenate([self.host_left, self.host_right], axis=1)              # [R, 2B, H, W]: L0..LB-1 R0..RB-1
+        self.images = torch.from_numpy(host).cuda(local_rank)
+        torch.cuda.synchronize()
+        self.exs = [orbx.ORBextractor(a.nfeatures, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B,
+                                      device=local_rank) for _ in range(max(1, a.handles))]
+        self.step_no = 0
+        self.slot_bytes = 2 * B * H * W
+        self.lap = self.rig = None
+        if a.mode == "fisheye":  # TUM-VI-like lapping areas (Examples/Stereo-Inertial/TUM-VI.yaml:45-49 scaled to W)
+            self.lap = np.array([[W // 5, W - 1]] * B + [[0, (4 * W) // 5]] * B, np.int32)
+            self.rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM2, np.eye(3), [0.101, 0.002, 0.001])
+        self.gathered = [None] * len(self.exs)    # C5: (counts, desc) of all ranks, per handle
+        self.ext_streams = None
+        if a.allgather and dist is not None:
+            # the collective is queued on the handle's own stream, behind the extraction: no host synchronisation
+            self.ext_streams = [torch.cuda.ExternalStream(e.stream_handle(), device=torch.device("cuda", local_rank))
+                                for e in self.exs]
+        self.last_slot = [None] * len(self.exs)
+
+    def step(self):
+        a, orbx = self.a, self.orbx
+        h = self.step_no % len(self.exs)
+        slot = self.step_no % a.ring
+        ex = self.exs[h]
+        self.step_no += 1
+        self.last_slot[h] = slot
+        B = a.pairs
+        ex.extract_batch_device(self.images.data_ptr() + slot * self.slot_bytes, 2 * B, a.width, a.height, a.width,
+                                a.width * a.height, lap=self.lap)
+        if a.mode == "stereo":
+            orbx.stereo_match_async(ex, ex, BF, BASE, first_left=0, first_right=B, n_pairs=B)
+        elif a.mode == "fisheye":
+            orbx.fisheye_match_async(ex, ex, self.rig, first_left=0, first_right=B, n_pairs=B)
+        if self.ext_streams is not None:
+            # config C5: every GPU ends up with all cameras' descriptor blocks (RCCL all-gather over xGMI)
+            from orb_slam3_fast_amd import sharding
+            torch = self.torch
+            d_kps, d_desc, d_cnt, d_mono, cap = ex.results_device()
+            with torch.cuda.stream(self.ext_streams[h]):
+                desc = torch.as_tensor(_Raw(d_desc, (2 * B, cap, 32), "|u1"), device="cuda")
+                cnt = torch.as_tensor(_Raw(d_cnt, (2 * B,), "<i4"), device="cuda")
+                self.gathered[h] = sharding.allgather_descriptor_blocks(cnt, desc, cap)
+
+    def sync(self):
+        for e in self.exs:
+            e.sync()
+
+
 def main():
     a = parse()
     # Exactly ONE line on stdout: libraries (RCCL prints a version banner when NCCL_DEBUG=VERSION is set, HIP /
@@ -114,57 +227,20 @@ def main():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or os.environ.get("ORBX_FORCE_DIST") == "1":  # the env switch lets a 1-GPU box exercise the RCCL path
+    if world > 1 or a.config == "C5" or os.environ.get("ORBX_FORCE_DIST") == "1":  # C5 exercises RCCL even with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import orb_slam3_fast_amd as orbx
-    from orb_slam3_fast_amd import sharding, synth
+    from orb_slam3_fast_amd import sharding
 
     W, H, B, NF = a.width, a.height, a.pairs, a.nfeatures
-    # ---- synthetic streams (deterministic): D distinct pairs tiled to B per GPU
-    D = max(1, min(a.distinct, B))
-    pairs = [synth.stereo_pair(W, H, stream=1000 * rank + i, frame=0) for i in range(D)]
-    lefts = np.stack([pairs[i % D][0] for i in range(B)])
-    rights = np.stack([pairs[i % D][1] for i in range(B)])
-    images = torch.from_numpy(np.concatenate([lefts, rights])).cuda(local_rank)  # [2B, H, W]: L0..LB-1 R0..RB-1
-    torch.cuda.synchronize()
-
-    exs = [orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B, device=local_rank)
-           for _ in range(max(1, a.handles))]
-    ex = exs[0]
-    step_no = [0]
-    bf, b = 0.12 * 532.03, 0.12  # ZED2-like rig: fx = 532.03 px, baseline 0.12 m
-    ptr = images.data_ptr()
-
-    gather_out = None
-
-    class _Raw:  # zero-copy view of a liborbx device buffer as a torch tensor
-        def __init__(self, ptr, shape, typestr):
-            self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
-
-    lap = None
-    if a.mode == "fisheye":  # TUM-VI-like lapping areas (Examples/Stereo-Inertial/TUM-VI.yaml:45-49 scaled to W)
-        lap = np.array([[W // 5, W - 1]] * B + [[0, (4 * W) // 5]] * B, np.int32)
-        rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM2, np.eye(3), [0.101, 0.002, 0.001])
-
-    def step():
-        ex = exs[step_no[0] % len(exs)]
-        step_no[0] += 1
-        ex.extract_batch_device(ptr, 2 * B, W, H, W, W * H, lap=lap)
-        if a.mode == "stereo":
-            orbx.stereo_match_async(ex, ex, bf, b, first_left=0, first_right=B, n_pairs=B)
-        elif a.mode == "fisheye":
-            orbx.fisheye_match_async(ex, ex, rig, first_left=0, first_right=B, n_pairs=B)
-        if a.allgather and dist is not None:
-            # config C5 extra: every GPU ends up with all cameras' descriptor blocks (RCCL all-gather over xGMI)
-            ex.sync()
-            d_kps, d_desc, d_cnt, d_mono, cap = ex.results_device()
-            desc = torch.as_tensor(_Raw(d_desc, (2 * B, cap, 32), "|u1"), device="cuda")
-            cnt = torch.as_tensor(_Raw(d_cnt, (2 * B,), "<i4"), device="cuda")
-            nonlocal gather_out
-            gather_out = sharding.allgather_descriptor_blocks(cnt, desc, cap)
+    wl = Workload(a, rank, local_rank, dist)
+    exs, ex = wl.exs, wl.exs[0]
+    step = wl.step
 
     def barrier():
         if dist is not None:
@@ -192,8 +268,8 @@ def main():
             e.profile_enable(True, stage=dom)   # timed region: only the dominant kernel is bracketed
     barrier()
     # The host side of a step is ~60 us of Python; a generation-2 garbage collection (tens of ms with torch's object graph
-    # loaded) that happens to fall into the 20 timed steps would be billed to the GPU path -- it made C4 read 13 k instead
-    # of 63 k pairs/s in every process but the first one on a box.  Collect now, then keep the collector out of the region.
+    # loaded) that happens to fall into the timed steps would be billed to the GPU path.  Collect now, then keep the
+    # collector out of the region.
     import gc
     gc.collect()
     gc.disable()
@@ -211,12 +287,11 @@ def main():
     # sync after every step, so that the durations are those of the kernels alone (in the timed region the batches
     # of the two handles overlap on the GPU, which stretches every individual launch)
     prof = {}
+    nprof = max(3, min(a.steps, 10))
     if not a.no_profile:
         exs[0].profile_enable(True)
-        nprof = max(3, min(a.steps, 10))
-        step_no[0] = 0
-        for _ in range(nprof):
-            step_no[0] = 0
+        for i in range(nprof):
+            wl.step_no = i * len(exs)   # handle 0, ring slot rotates
             step()
             exs[0].sync()
         barrier()
@@ -228,8 +303,9 @@ def main():
     lw, lh, nc, ns = ex.level_stats(0)
     plevels = [int(x) * int(y) for x, y in zip(lw, lh)]
     P = sum(plevels)
-    ncand_mean = float(np.mean([ex.level_stats(i)[2].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
-    nsel_mean = float(np.mean([ex.level_stats(i)[3].sum() for i in range(0, 2 * B, max(1, 2 * B // 8))]))
+    probe = range(0, 2 * B, max(1, 2 * B // 16))
+    ncand_mean = float(np.mean([ex.level_stats(i)[2].sum() for i in probe]))
+    nsel_mean = float(np.mean([ex.level_stats(i)[3].sum() for i in probe]))
     if a.mode == "stereo":
         d_u = np.zeros((1, ex.capacity), np.float32)
         orbx._check(orbx.lib().orbx_stereo_download(ex._h, 0, orbx._p(d_u[0]), None, ex.capacity))
@@ -241,8 +317,9 @@ def main():
 
     units_per_step = 2 * B if a.mode == "mono" else B  # mono: every image is a frame
     value = a.gpus * units_per_step * a.steps / elapsed
+    c5 = a.config == "C5"
     out = {
-        "metric": {"stereo": "ORB extract+match frames/sec @%d\u00d7%d stereo (both-eye ORBextractor + ComputeStereoMatches)",
+        "metric": {"stereo": "ORB extract+match frames/sec @%d×%d stereo (both-eye ORBextractor + ComputeStereoMatches)",
                    "mono": "ORB extract mono frames/sec @%dx%d (ORBextractor::operator())",
                    "fisheye": "ORB extract+match fisheye stereo frames/sec @%dx%d (both-eye ORBextractor with lapping areas "
                               "+ ComputeStereoFishEyeMatches)"}[a.mode] % (W, H),
@@ -258,14 +335,20 @@ def main():
         "dtype": "u8",
         "data": "synthetic",
         "config": {
-            "workload": {"stereo": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
+            "workload": ("C5: %d independent synthetic %dx%d rectified stereo streams per GPU, %d consecutive frames of each per "
+                         "step, %d features, 8 levels, scale 1.2, FAST 20/7, ComputeStereoMatches, RCCL all-gather of the "
+                         "descriptor blocks every step" % (a.distinct, W, H, wl.K, NF)) if c5 else
+                        {"stereo": "C3: synthetic %dx%d rectified stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
                                    "ComputeStereoMatches (bf=0.12*532.03, b=0.12)",
                          "mono": "C2: synthetic %dx%d mono frames, %d features, 8 levels, scale 1.2, FAST 20/7",
                          "fisheye": "C4: synthetic %dx%d fisheye stereo pairs, %d features, 8 levels, scale 1.2, FAST 20/7, "
                                     "lapping areas, BF 2-NN + KannalaBrandt8 triangulation"}[a.mode] % (W, H, NF),
             "pairs_per_step_per_gpu": B,
             "handles": len(exs),
-            "distinct_streams_per_gpu": D,
+            "distinct_streams_per_gpu": a.distinct,
+            "frames_in_ring": a.ring,
+            "input_reuse": "step i processes frame (i mod %d) of every stream; %d distinct stereo pairs resident in HBM per GPU"
+                           % (a.ring, a.distinct * (a.ring + wl.K - 1)),
             "keypoints_per_image": round(nsel_mean, 1),
             "fast_candidates_per_image": round(ncand_mean, 1),
             "stereo_matches_pair0": nmatch,
@@ -273,9 +356,11 @@ def main():
                            + (" + RCCL all-gather of descriptor blocks" if a.allgather and dist else ""),
         },
     }
+    if c5 and wl.gathered[0] is not None:
+        torch.cuda.synchronize()
+        out["config"]["allgather_bytes_per_step_per_gpu"] = int(wl.gathered[0][1].numel() + 4 * wl.gathered[0][0].numel())
 
     if prof:
-        nprof = max(3, min(a.steps, 10))
         tot = sum(v[0] for v in prof.values())
         stages = {}
         for name, (ms, cnt) in prof.items():
@@ -289,56 +374,63 @@ def main():
         per_launch = algorithmic_bytes(dom, 2 * B, P, plevels, ncand_mean, nsel_mean, nmatch, B) / max(1, cnt // a.steps)
         ach = per_launch / (ms / cnt * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
-            try:
-                traffic = json.load(open(tfile)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        pmc = {}
+        try:  # HBM bytes / VALU instructions per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_insts.json")))
+        except Exception:
+            pmc = {}
+        full = (W, H, B, NF) == (1280, 720, 32, 1500)   # the PMC files describe the default workload only
         out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic if full else None,
                            "avg_launch_us": round(1000.0 * ms / cnt, 2), "launches_timed": cnt,
                            "algorithmic_bytes_per_launch": int(per_launch),
-                           "note": "k_detect is VALU-issue bound (PMC: ~80%% of the VALU issue slots), not HBM bound; with "
-                                   "%d handles in flight the launches of consecutive batches overlap, so avg_launch_us is "
-                                   "the duration under overlap; isolated_* is the same kernel alone (stage pass); see "
-                                   "DESIGN.md 5" % len(exs)}
+                           "limited_by": "VALU issue, not HBM (see roofline.valu): the contract's HBM fraction is reported "
+                                         "as asked, but this integer stencil / compare kernel saturates the vector ALUs "
+                                         "while moving less than its algorithmic bytes (DESIGN.md 5)",
+                           "note": "with %d handles in flight the launches of consecutive batches overlap, so avg_launch_us is "
+                                   "the duration under overlap; isolated_* is the same kernel alone (stage pass)" % len(exs)}
         if dom in stages:
             iso = stages[dom]["avg_us"]
             out["roofline"]["isolated_avg_launch_us"] = iso
             out["roofline"]["isolated_frac"] = round(per_launch / (iso * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        if full and dom in pmc and "SQ_INSTS_VALU" in pmc[dom] and dom in stages:
+            insts = pmc[dom]["SQ_INSTS_VALU"]
+            iso_s = stages[dom]["avg_us"] * 1e-6
+            out["roofline"]["valu"] = {
+                "bound": "valu-issue", "insts_per_launch": int(insts), "achieved": round(insts * 4 / iso_s / 1e12, 3),
+                "peak": round(N_SIMD * CLOCK_HZ / 1e12, 3), "unit": "T SIMD-cycles/s",
+                "frac": round(insts * 4 / (N_SIMD * CLOCK_HZ * iso_s), 4),
+                "source": "SQ_INSTS_VALU per launch from profiles/pmc_insts.json (rocprofv3 --pmc pass) x 4 cycles per wave64 "
+                          "instruction / (1024 SIMDs x 2.4 GHz x the kernel's isolated HIP-event duration of this run)"}
+        streaming = {}
+        for k in ("k_resize", "k_detect", "k_blur", "k_describe"):
+            if k in stages:
+                streaming[k] = {"algorithmic_GBps": stages[k]["algorithmic_GBps"],
+                                "frac": round(stages[k]["algorithmic_GBps"] / HBM_PEAK_GBS, 4)}
+                if full and k in pmc and "SQ_INSTS_VALU" in pmc[k]:
+                    us = stages[k]["ms_total"] * 1e3 / nprof   # all launches of the stage in one batch
+                    streaming[k]["valu_frac"] = round(pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1) * 4
+                                                      / (N_SIMD * CLOCK_HZ * us * 1e-6), 4)
+        out["roofline"]["streaming"] = streaming
         out["stages"] = stages
         out["stages_note"] = ("per-stage HIP-event table from %d extra single-handle steps (synchronised, no overlap "
                               "between batches) after the timed region" % nprof)
         a_pair = 2 * (2 * P + 60 * nsel_mean) + 120 * nsel_mean + 352 * nmatch
         out["end_to_end_algorithmic_GBps"] = round(a_pair * value / a.gpus / 1e9, 2)
 
-    # ---- CPU baseline: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
-    # Frame-parallel over the host cores in a separate process tree (`cpu_mt` of BASELINE.md), plus 1 core.
-    if rank == 0 and a.gpus == 1 and a.cpu_pairs > 0 and a.mode == "stereo":
-        import subprocess
-        import tempfile
-        tmp = os.path.join(tempfile.gettempdir(), "orbx_cpu_pairs_%d.npy" % os.getpid())
-        np.save(tmp, np.stack([np.stack(p) for p in pairs]))
-        cores = usable_cores() if a.cpu_cores <= 0 else a.cpu_cores
-        per = max(2, a.cpu_pairs // 8)  # ~ per * 0.3 s per worker
-        try:
-            r1 = json.loads(subprocess.run([sys.executable, "-m", "oracle.cpu_bench", tmp, str(NF), str(bf), str(b), "1",
-                                            str(max(4, a.cpu_pairs // 4))], cwd=ROOT, capture_output=True, text=True,
-                                           timeout=300).stdout.strip().splitlines()[-1])
-            rN = json.loads(subprocess.run([sys.executable, "-m", "oracle.cpu_bench", tmp, str(NF), str(bf), str(b),
-                                            str(cores), str(per)], cwd=ROOT, capture_output=True, text=True,
-                                           timeout=600).stdout.strip().splitlines()[-1])
-            out["cpu_baseline"] = {
-                "value": round(rN["pairs_per_s"], 2), "unit": "stereo frames/s", "cores": cores, "kind": "port",
-                "single_core_value": round(r1["pairs_per_s"], 3),
-                "sample": "oracle/liborb_oracle.so (g++ -O2 port of the reference's serial semantics), frame-parallel: "
-                          "%d worker processes x %d of the same synthetic %dx%d pairs, wall %.1f s; single worker: %d pairs "
-                          "in %.1f s; host reports %d cores, %d usable (affinity / cgroup quota)" % (
-                              cores, per, W, H, rN["wall_s"], r1["pairs"], r1["wall_s"], os.cpu_count(), usable_cores())}
-        finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
+    extras = rank == 0 and a.gpus == 1 and a.mode == "stereo" and not a.no_extras and not c5
+    if extras and a.latency_frames > 0:
+        out.update(latency_leg(a, wl, orbx, np))
+    if extras and a.h2d_steps > 0:
+        out.update(h2d_leg(a, wl, orbx, np, torch))
+
+    # ---- CPU baselines: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
+    if extras and a.cpu_pairs > 0:
+        out.update(cpu_legs(a, wl, np))
 
     if rank == 0:
         sys.stdout.flush()
@@ -346,6 +438,131 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _stats(v, np):
+    v = np.asarray(v, np.float64)
+    return {"mean": round(float(v.mean()), 4), "std": round(float(v.std()), 4), "p50": round(float(np.percentile(v, 50)), 4),
+            "p99": round(float(np.percentile(v, 99)), 4), "frames": int(len(v))}
+
+
+def latency_leg(a, wl, orbx, np):
+    """One stereo frame at a time through the drop-in host API (pageable host images in, host results out), distinct
+    frames, timers where the reference's REGISTER_TIMES puts them (src/Frame.cc:196-232): both-eye extraction (wall, one
+    synchronisation) and ComputeStereoMatches; latency_ms = orbx_extract_stereo doing both in one call."""
+    W, H, NF = a.width, a.height, a.nfeatures
+    ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2, device=wl.exs[0].device)
+    frames = [(wl.host_left[s, p], wl.host_right[s, p]) for s in range(a.ring) for p in range(a.pairs)]
+    import gc
+    gc.collect()
+    gc.disable()
+    for i in range(5):
+        ex.extract_stereo(*frames[i % len(frames)], bf=BF, b=BASE)
+    lat, te, ts = [], [], []
+    for i in range(a.latency_frames):
+        L, R = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        ex.extract_stereo(L, R, bf=BF, b=BASE)
+        lat.append(1e3 * (time.perf_counter() - t0))
+    for i in range(a.latency_frames):
+        L, R = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        ex.extract_stereo(L, R)                                              # Frame.cc:196-205: both eyes, threads joined
+        t1 = time.perf_counter()
+        orbx.ComputeStereoMatches(ex, ex, BF, BASE, first_left=0, first_right=1, n_pairs=1)  # Frame.cc:222-228
+        t2 = time.perf_counter()
+        te.append(1e3 * (t1 - t0))
+        ts.append(1e3 * (t2 - t1))
+    gc.enable()
+    note = ("single %dx%d stereo frame, pageable host images in, host keypoints / descriptors / uRight / depth out, %d "
+            "distinct frames; latency_ms = orbx_extract_stereo (both eyes + ComputeStereoMatches, one synchronisation); "
+            "extract_ms / stereo_ms = the two REGISTER_TIMES brackets as separate calls (Python wrapper included)"
+            % (W, H, len(frames)))
+    return {"latency_ms": _stats(lat, np), "extract_ms": _stats(te, np), "stereo_ms": _stats(ts, np), "latency_note": note}
+
+
+def h2d_leg(a, wl, orbx, np, torch):
+    """Whole-job rate when the frames start in page-locked HOST memory every step and every result returns to the
+    host: upload (orbx_extract_batch), extraction + stereo association, download of counts / keypoints / descriptors /
+    uRight / depth (orbx_batch_download_async); two handles double-buffer copies against kernels."""
+    W, H, B = a.width, a.height, a.pairs
+    ring = torch.from_numpy(np.concatenate([wl.host_left, wl.host_right], axis=1)).pin_memory()   # [R, 2B, H, W]
+    exs = wl.exs
+    cap = exs[0].capacity
+    res = []
+    for _ in exs:
+        res.append(dict(cnt=torch.zeros(2 * B, dtype=torch.int32).pin_memory(), mono=torch.zeros(2 * B, dtype=torch.int32).pin_memory(),
+                        kps=torch.zeros((2 * B, cap, 28), dtype=torch.uint8).pin_memory(),
+                        desc=torch.zeros((2 * B, cap, 32), dtype=torch.uint8).pin_memory(),
+                        ur=torch.zeros((B, cap), dtype=torch.float32).pin_memory(), dp=torch.zeros((B, cap), dtype=torch.float32).pin_memory()))
+
+    def hstep(i):
+        h = i % len(exs)
+        ex, r = exs[h], res[h]
+        ex.sync()   # the handle's previous results have been consumed (they sit in r[...])
+        ex.extract_batch_host(ring[i % a.ring].data_ptr(), 2 * B, W, H, W, W * H)
+        orbx.stereo_match_async(ex, ex, BF, BASE, first_left=0, first_right=B, n_pairs=B)
+        ex.download_async(r["cnt"].data_ptr(), r["mono"].data_ptr(), r["kps"].data_ptr(), r["desc"].data_ptr(),
+                          r["ur"].data_ptr(), r["dp"].data_ptr(), B)
+
+    for i in range(4):
+        hstep(i)
+    wl.sync()
+    t0 = time.perf_counter()
+    for i in range(a.h2d_steps):
+        hstep(i)
+    wl.sync()
+    dt = time.perf_counter() - t0
+    n0 = int(res[0]["cnt"][0])
+    up = 2 * B * W * H
+    down = 2 * B * (8 + cap * 60) + 2 * B * cap * 4
+    return {"h2d_inclusive_value": round(B * a.h2d_steps / dt, 1),
+            "h2d_inclusive": {"unit": "stereo frames/s", "steps": a.h2d_steps, "ms_per_step": round(1e3 * dt / a.h2d_steps, 4),
+                              "upload_MB_per_step": round(up / 1e6, 2), "download_MB_per_step": round(down / 1e6, 2),
+                              "pcie_GBps": round((up + down) * a.h2d_steps / dt / 1e9, 2), "keypoints_image0": n0,
+                              "note": "page-locked host frames -> orbx_extract_batch (async upload on the handle's stream) -> "
+                                      "extraction + ComputeStereoMatches -> orbx_batch_download_async of ALL results into "
+                                      "page-locked arrays; %d handles alternate so one batch's copies overlap the other's kernels"
+                                      % len(exs)}}
+
+
+def cpu_legs(a, wl, np):
+    import subprocess
+    import tempfile
+    W, H, NF = a.width, a.height, a.nfeatures
+    out = {}
+    tmp = os.path.join(tempfile.gettempdir(), "orbx_cpu_pairs_%d.npy" % os.getpid())
+    nd = min(a.pairs, 8)
+    np.save(tmp, np.stack([np.stack([wl.host_left[0, i], wl.host_right[0, i]]) for i in range(nd)]))
+    cores = usable_cores() if a.cpu_cores <= 0 else a.cpu_cores
+    per = max(2, a.cpu_pairs // 8)  # ~ per * 0.3 s per worker
+
+    def run(args, timeout):
+        r = subprocess.run([sys.executable, "-m", "oracle.cpu_bench"] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    try:
+        r1 = run([tmp, str(NF), str(BF), str(BASE), "1", str(max(4, a.cpu_pairs // 4))], 300)
+        rN = run([tmp, str(NF), str(BF), str(BASE), str(cores), str(per)], 600)
+        out["cpu_baseline"] = {
+            "value": round(rN["pairs_per_s"], 2), "unit": "stereo frames/s", "cores": cores, "kind": "port",
+            "single_core_value": round(r1["pairs_per_s"], 3),
+            "sample": "oracle/liborb_oracle.so (g++ -O2 port of the reference's serial semantics), frame-parallel: "
+                      "%d worker processes x %d of the same synthetic %dx%d pairs, wall %.1f s; single worker: %d pairs "
+                      "in %.1f s; host reports %d cores, %d usable (affinity / cgroup quota)" % (
+                          cores, per, W, H, rN["wall_s"], r1["pairs"], r1["wall_s"], os.cpu_count(), usable_cores())}
+        rM = run(["--mt", tmp, str(NF), str(BF), str(BASE), str(max(8, a.cpu_pairs // 2))], 600)
+        out["cpu_mt"] = {
+            "value": round(rM["pairs_per_s"], 2), "unit": "stereo frames/s", "threads": rM["threads"], "cores": min(cores, rM["threads"]),
+            "kind": "port", "extract_ms": {"mean": round(rM["extract_ms_mean"], 3), "std": round(rM["extract_ms_std"], 3)},
+            "stereo_ms": {"mean": round(rM["stereo_ms_mean"], 3), "std": round(rM["stereo_ms_std"], 3)},
+            "sample": "the same port with the reference's thread structure: one std::thread per eye (src/Frame.cc:200-203), one "
+                      "task per pyramid level and stage inside (src/ORBextractor.cc:764-846,1063-1101), then ComputeStereoMatches; "
+                      "ONE pipeline, %d consecutive frames, timers placed like REGISTER_TIMES (src/Frame.cc:196-232); the "
+                      "reference's own README quotes 9.83 + 2.75 ms for this on an unspecified CPU" % rM["frames"]}
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return out
 
 
 if __name__ == "__main__":

@@ -99,6 +99,21 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
 int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_images, int w, int h,
                               ptrdiff_t row_pitch, ptrdiff_t image_pitch, const int32_t* lap);
 int orbx_sync(orbx_extractor* ex);
+/* The HIP stream (hipStream_t, returned as void*) the handle enqueues on: lets a caller queue its own consumers of the
+ * device-resident results (a collective over the descriptor blocks, a copy) behind the extraction without a host
+ * synchronisation.  The stream belongs to the handle. */
+int orbx_stream_handle(const orbx_extractor* ex, void** stream);
+/* The same batch from HOST memory (ideally page-locked: then the upload overlaps other handles' kernels): the frames
+ * are uploaded into the handle's staging area with asynchronous copies on its stream, the extraction is enqueued behind
+ * them, nothing synchronises.  The host frames must stay valid until orbx_sync. */
+int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, int n_images, int w, int h, ptrdiff_t row_pitch,
+                       ptrdiff_t image_pitch, const int32_t* lap);
+/* All results of the last batch into HOST arrays with asynchronous copies on the handle's stream (page-locked arrays keep
+ * them asynchronous): counts[n] / mono[n], kps[n][cap], desc[n][cap][32] (cap = orbx_batch_results_device's cap) and, when
+ * n_pairs > 0 and a stereo association ran on this handle, uright / depth [n_pairs][cap].  NULL pointers are skipped.  The
+ * arrays are complete after orbx_sync. */
+int orbx_batch_download_async(orbx_extractor* ex, int32_t* counts, int32_t* mono, orbx_keypoint* kps, uint8_t* desc,
+                              float* uright, float* depth, int n_pairs);
 
 /* Device-resident results of the last (batch) extraction: keypoints [n_images][cap] and descriptors
  * [n_images][cap][32], counts[n_images] (n) and mono[n_images] (monoIndex), all on the device. */
@@ -438,6 +453,12 @@ void orbx_debug_set_detect_list_cap(int cap);
 /* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
  * than 16384 FAST candidates); 0 restores the register-resident path. */
 void orbx_debug_set_octree_global(int on);
+/* Test tap of k_detect: with enable != 0 every following extraction also writes, per pyramid level, the FAST score
+ * (cornerScore, 0 = not a corner) of every detectable pixel at iniThFAST -- the corner set of cv::FAST BEFORE non-max
+ * suppression (src/ORBextractor.cc:810-815).  orbx_debug_score_level copies one level (w x h bytes) to the host.
+ * tests/test_pin_skimage.py compares it with scikit-image's independent segment test. */
+int orbx_debug_score_map(orbx_extractor* ex, int enable);
+int orbx_debug_score_level(orbx_extractor* ex, int image, int level, uint8_t* dst, ptrdiff_t dst_stride);
 /* The device's sinf / cosf of the descriptor steering (computeOrbDescriptor, src/ORBextractor.cc:106-107: libm cosf / sinf;
  * csrc/orbx_sincos.h restates glibc's two x86-64 ifunc variants): evaluates n angles (radians, host arrays) with the FMA
  * (fused != 0) or the SSE2 variant.  tests/ compare both with the host's libm bit for bit. */

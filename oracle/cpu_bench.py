@@ -3,6 +3,7 @@ frame-parallel over P worker processes, one stereo pair at a time per worker —
 BASELINE.md §2.  TEST / MEASUREMENT INFRASTRUCTURE ONLY.
 
 usage: python -m oracle.cpu_bench <pairs.npy [D,2,H,W] u8> <nfeatures> <bf> <b> <procs> <pairs_per_proc> [--extract-only]
+       python -m oracle.cpu_bench --mt <pairs.npy> <nfeatures> <bf> <b> <frames>     (threaded single pipeline, see run_mt)
 Prints one JSON object: aggregate pairs/s (all workers start together; wall time of the slowest worker),
 single-worker pairs/s, procs.  --extract-only skips ComputeStereoMatches (mono configs: a "pair" is two frames).
 """
@@ -36,6 +37,31 @@ def _worker(args):
     return time.perf_counter() - t0
 
 
+def _pair_job(args):
+    L, R, nf, bf, b = args
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as oracle
+    oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+    _, kL, dL = oL.extract(L)
+    _, kR, dR = oR.extract(R)
+    u, dep = oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b)
+    return kL, dL, kR, dR, u, dep
+
+
+def oracle_pairs(lefts, rights, nf, bf, b, workers=None):
+    """The oracle on many stereo pairs in parallel (checker for the batched parity tests): per pair
+    (kpsL, descL, kpsR, descR, uRight, depth).  Spawned workers: safe next to an initialised HIP runtime."""
+    import concurrent.futures as cf
+    if workers is None:
+        workers = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    jobs = [(np.ascontiguousarray(l), np.ascontiguousarray(r), nf, bf, b) for l, r in zip(lefts, rights)]
+    workers = max(1, min(workers, len(jobs)))
+    if workers == 1:
+        return [_pair_job(j) for j in jobs]
+    with cf.ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_pair_job, jobs))
+
+
 def run(path, nf, bf, b, procs, pairs_per_proc, extract_only=False):
     start_at = time.time() + 3.0 + 0.01 * procs
     with mp.get_context("fork").Pool(procs) as pool:
@@ -44,7 +70,36 @@ def run(path, nf, bf, b, procs, pairs_per_proc, extract_only=False):
             "pairs_per_s": procs * pairs_per_proc / max(times), "per_worker_pairs_per_s": pairs_per_proc / (sum(times) / len(times))}
 
 
+def run_mt(path, nf, bf, b, frames):
+    """`cpu_mt`: ONE pipeline with the reference's thread structure (2 eye threads x 8 per-level tasks = 16 threads,
+    src/Frame.cc:200-203 + src/ORBextractor.cc:764-846) on consecutive stereo frames; timers placed like REGISTER_TIMES
+    (src/Frame.cc:196-232): wall time of the both-eye extraction and of ComputeStereoMatches, mean +- std over the frames."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as oracle
+    pairs = np.load(path, mmap_mode="r")
+    oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+    ext, ste = [], []
+    t0 = time.perf_counter()
+    for i in range(frames + 2):
+        p = pairs[i % len(pairs)]
+        r = oracle.stereo_frame_mt(oL, oR, np.ascontiguousarray(p[0]), np.ascontiguousarray(p[1]), bf, b)
+        if i == 1:
+            t0 = time.perf_counter()  # two warm-up frames
+        if i >= 2:
+            ext.append(r[6])
+            ste.append(r[7])
+    wall = time.perf_counter() - t0
+    ext, ste = np.array(ext), np.array(ste)
+    return {"frames": frames, "threads": 2 * oL.nlevels, "wall_s": wall, "pairs_per_s": frames / wall,
+            "extract_ms_mean": float(ext.mean()), "extract_ms_std": float(ext.std()),
+            "stereo_ms_mean": float(ste.mean()), "stereo_ms_std": float(ste.std())}
+
+
 if __name__ == "__main__":
+    if "--mt" in sys.argv:
+        a = [x for x in sys.argv if x != "--mt"]
+        print(json.dumps(run_mt(a[1], int(a[2]), float(a[3]), float(a[4]), int(a[5]))))
+        sys.exit(0)
     a = sys.argv
     eo = "--extract-only" in a
     a = [x for x in a if x != "--extract-only"]

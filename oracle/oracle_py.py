@@ -139,6 +139,14 @@ def fast(img, threshold, nms=True):
     return out[:n].copy()
 
 
+def fast_score_map(img, threshold):
+    """cornerScore of every pixel passing the FAST-9-16 segment test at `threshold`, 0 elsewhere (pre-NMS)."""
+    img = _u8(img)
+    out = np.zeros(img.shape, np.uint8)
+    lib().oro_fast_score_map(_p(img), img.strides[0], img.shape[1], img.shape[0], int(threshold), _p(out))
+    return out
+
+
 def blur(img, variant=451):
     img = _u8(img)
     dst = np.zeros_like(img)
@@ -216,6 +224,24 @@ def stereo_match(exL, exR, kL, dL, kR, dR, bf, b):
     lib().oro_stereo_match(exL.h, exR.h, _p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), C.c_float(bf),
                            C.c_float(b), _p(u), _p(d))
     return u, d
+
+
+def stereo_frame_mt(exL, exR, L, R, bf, b):
+    """One stereo frame with the reference's thread structure (2 eye threads x per-level tasks) and REGISTER_TIMES timer
+    placement: (kL, dL, kR, dR, uRight, depth, extract_ms, stereo_ms).  Results identical to the serial oracle."""
+    L, R = _u8(L), _u8(R)
+    h, w = L.shape
+    cap = exL.nfeatures + 3 * exL.nlevels + 64
+    kL, kR = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
+    dL, dR = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
+    u, dep = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    nL, nR = C.c_int(0), C.c_int(0)
+    ms = np.zeros(2, np.float64)
+    rc = lib().oro_stereo_frame_mt(exL.h, exR.h, _p(L), _p(R), w, h, C.c_long(L.strides[0]), C.c_float(bf), C.c_float(b),
+                                   _p(kL), _p(dL), C.byref(nL), _p(kR), _p(dR), C.byref(nR), cap, _p(u), _p(dep), _p(ms))
+    assert rc == 0
+    return (kL[:nL.value].copy(), dL[:nL.value].copy(), kR[:nR.value].copy(), dR[:nR.value].copy(), u[:nL.value].copy(),
+            dep[:nL.value].copy(), float(ms[0]), float(ms[1]))
 
 
 def bf_knn2(dQ, dT):

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <thread>
 
 namespace orbo {
 
@@ -851,6 +852,64 @@ int Extractor::extract(const uint8_t* img, int w, int h, ptrdiff_t stride, int l
       if (kp.x >= (float)lap0 && kp.x <= (float)lap1) slot = stereo--; else slot = mono++;
       kps[slot] = kp;
       std::memcpy(&desc[(size_t)slot * 32], d, 32);
+    }
+  }
+  return mono;
+}
+
+// The same operator() with the THREAD STRUCTURE of the fork (the `cpu_mt` timing baseline): pyramid serial (the
+// reference leaves it serial, "TODO" src/ORBextractor.cc:1109), then one task per level for FAST cells + quadtree
+// (tbb::parallel_for over levels, :764-846), one per level for the orientations (:876-884), one per level for blur +
+// descriptors (:1063-1101); the output assembly runs serially afterwards in level order, so the result is identical to
+// extract() (the fork's racy shared counters are not reproduced).
+int Extractor::extract_mt(const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
+                          std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc) {
+  if (!img || w <= 0 || h <= 0) return -1;
+  compute_pyramid(img, w, h, stride);
+  std::vector<std::vector<KeyPoint>> all(nlevels);
+  std::vector<std::vector<uint8_t>> dl(nlevels);
+  auto per_level = [&](auto&& body) {
+    std::vector<std::thread> th;
+    for (int l = 0; l < nlevels; l++) th.emplace_back([&, l]() { body(l); });
+    for (auto& t_ : th) t_.join();
+  };
+  per_level([&](int l) {
+    const int minBX = kEdge - 3, minBY = minBX;
+    const int maxBX = pyramid[l].w - kEdge + 3, maxBY = pyramid[l].h - kEdge + 3;
+    std::vector<KeyPoint> cand;
+    detect_level_candidates(l, cand);
+    all[l] = distribute_octtree(cand, minBX, maxBX, minBY, maxBY, t.nfeat_level[l]);
+    const int scaledPatch = (int)(kPatchSize * t.scale[l]);
+    for (KeyPoint& kp : all[l]) {
+      kp.x += minBX;
+      kp.y += minBY;
+      kp.octave = l;
+      kp.size = (float)scaledPatch;
+    }
+  });
+  per_level([&](int l) {
+    for (KeyPoint& kp : all[l]) kp.angle = ic_angle(pyramid[l], cv_round(kp.x), cv_round(kp.y), t.umax);
+  });
+  per_level([&](int l) {
+    if (all[l].empty()) return;
+    gaussian_blur7(pyramid[l], blurred[l], blur_taps);
+    dl[l].resize(all[l].size() * 32);
+    for (size_t i = 0; i < all[l].size(); i++) orb_descriptor(blurred[l], all[l][i].x, all[l][i].y, all[l][i].angle, &dl[l][i * 32]);
+  });
+  int n = 0;
+  for (int l = 0; l < nlevels; l++) n += (int)all[l].size();
+  kps.assign(n, KeyPoint{});
+  desc.assign((size_t)n * 32, 0);
+  int mono = 0, stereo = n - 1;
+  for (int l = 0; l < nlevels; l++) {
+    const float scale = t.scale[l];
+    for (size_t i = 0; i < all[l].size(); i++) {
+      KeyPoint kp = all[l][i];
+      if (l != 0) { kp.x *= scale; kp.y *= scale; }
+      int slot;
+      if (kp.x >= (float)lap0 && kp.x <= (float)lap1) slot = stereo--; else slot = mono++;
+      kps[slot] = kp;
+      std::memcpy(&desc[(size_t)slot * 32], &dl[l][i * 32], 32);
     }
   }
   return mono;

@@ -70,6 +70,10 @@ class Extractor {
   int extract(const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
               std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc);
 
+  // Same result with the fork's thread structure (one task per pyramid level and stage) -- the cpu_mt timing baseline.
+  int extract_mt(const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1, std::vector<KeyPoint>& kps,
+                 std::vector<uint8_t>& desc);
+
   // Stages, exposed for stage-level differential tests.
   void compute_pyramid(const uint8_t* img, int w, int h, ptrdiff_t stride);
   void detect_level_candidates(int level, std::vector<KeyPoint>& cand) const;  // literal per-cell FAST

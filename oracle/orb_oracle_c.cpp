@@ -7,6 +7,9 @@
 
 #include <math.h>
 
+#include <chrono>
+#include <thread>
+
 using namespace orbo;
 
 extern "C" {
@@ -44,6 +47,39 @@ int oro_extract(void* h, const uint8_t* img, int w, int h_, long stride, int lap
   std::memcpy(kps, k.data(), k.size() * sizeof(KeyPoint));
   std::memcpy(desc, d.data(), d.size());
   return mono;
+}
+
+// One stereo frame with the reference's thread structure and timer placement (`cpu_mt`): both eyes extracted
+// concurrently, one std::thread per eye (src/Frame.cc:200-203) with per-level tasks inside (Extractor::extract_mt), then
+// ComputeStereoMatches; ms[0] = wall time of the both-eye extraction, ms[1] = of the stereo association -- the two
+// brackets of REGISTER_TIMES (src/Frame.cc:196-232).  Results as oro_extract / oro_stereo_match.
+int oro_stereo_frame_mt(void* hl, void* hr, const uint8_t* imgL, const uint8_t* imgR, int w, int h_, long stride, float bf,
+                        float b, KeyPoint* kL, uint8_t* dL, int* nL, KeyPoint* kR, uint8_t* dR, int* nR, int cap,
+                        float* uRight, float* depth, double* ms) {
+  Extractor *L = (Extractor*)hl, *R = (Extractor*)hr;
+  std::vector<KeyPoint> kl, kr;
+  std::vector<uint8_t> dl, dr;
+  const auto t0 = std::chrono::steady_clock::now();
+  std::thread tl([&]() { L->extract_mt(imgL, w, h_, stride, 0, 0, kl, dl); });
+  std::thread tr([&]() { R->extract_mt(imgR, w, h_, stride, 0, 0, kr, dr); });
+  tl.join();
+  tr.join();
+  const auto t1 = std::chrono::steady_clock::now();
+  std::vector<float> u, d;
+  compute_stereo_matches(L->pyramid, R->pyramid, kl, dl.data(), kr, dr.data(), L->t.scale, L->t.inv_scale, bf, b, u, d);
+  const auto t2 = std::chrono::steady_clock::now();
+  ms[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  ms[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+  *nL = (int)kl.size();
+  *nR = (int)kr.size();
+  if ((int)kl.size() > cap || (int)kr.size() > cap) return -3;
+  std::memcpy(kL, kl.data(), kl.size() * sizeof(KeyPoint));
+  std::memcpy(dL, dl.data(), dl.size());
+  std::memcpy(kR, kr.data(), kr.size() * sizeof(KeyPoint));
+  std::memcpy(dR, dr.data(), dr.size());
+  std::memcpy(uRight, u.data(), u.size() * sizeof(float));
+  std::memcpy(depth, d.data(), d.size() * sizeof(float));
+  return 0;
 }
 
 void oro_compute_pyramid(void* h, const uint8_t* img, int w, int h_, long stride) {
@@ -90,6 +126,19 @@ int oro_fast(const uint8_t* img, int stride, int cols, int rows, int threshold, 
     xys[3 * i + 2] = out[i].score;
   }
   return n;
+}
+// cornerScore<16> of every pixel that passes the segment test at `threshold` (0 elsewhere): what cv::FAST writes into
+// its rolling score rows before non-max suppression.  img is a standalone cols x rows image.
+void oro_fast_score_map(const uint8_t* img, int stride, int cols, int rows, int threshold, uint8_t* out) {
+  std::memset(out, 0, (size_t)cols * rows);
+  std::vector<FastPt> pts;
+  fast9_16(img, stride, cols, rows, threshold, false, pts);
+  int pixel[25];
+  static const int dx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  static const int dy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+  for (int k = 0; k < 25; k++) pixel[k] = dy[k % 16] * stride + dx[k % 16];
+  for (const FastPt& q : pts)
+    out[(size_t)q.y * cols + q.x] = (uint8_t)fast_corner_score16(img + (size_t)q.y * stride + q.x, pixel, threshold);
 }
 void oro_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) {
   Image s(w, h), d;

@@ -72,6 +72,9 @@ def lib():
         L.orbx_extract.argtypes = [vp, vp, i, i, C.c_ssize_t, i, i, vp, vp, i, C.POINTER(i)]
         L.orbx_extract_batch_device.argtypes = [vp, vp, i, i, i, C.c_ssize_t, C.c_ssize_t, vp]
         L.orbx_sync.argtypes = [vp]
+        L.orbx_stream_handle.argtypes = [vp, C.POINTER(vp)]
+        L.orbx_extract_batch.argtypes = [vp, vp, i, i, i, C.c_ssize_t, C.c_ssize_t, vp]
+        L.orbx_batch_download_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, i]
         L.orbx_extract_stereo.argtypes = [vp, vp, vp, i, i, C.c_ssize_t, C.c_ssize_t, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, f, f, vp, vp]
         L.orbx_batch_results_device.argtypes = [vp] + [C.POINTER(vp)] * 4 + [C.POINTER(i)]
         L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
@@ -129,6 +132,8 @@ def lib():
         L.orbx_debug_set_octree_global.argtypes = [i]
         L.orbx_debug_set_octree_global.restype = None
         L.orbx_debug_sincos.argtypes = [i, vp, i, i, vp, vp]
+        L.orbx_debug_score_map.argtypes = [vp, i]
+        L.orbx_debug_score_level.argtypes = [vp, i, i, vp, C.c_ssize_t]
         _lib = L
     return _lib
 
@@ -164,6 +169,7 @@ class ORBextractor:
         h = C.c_void_p()
         _check(lib().orbx_extractor_create(C.byref(p), max_width, max_height, max_batch, device, C.byref(h)))
         self._h = h
+        self.device = device
         L = self.nlevels
         t = [np.zeros(L, np.float32) for _ in range(4)]
         self._nfeat = np.zeros(L, np.int32)
@@ -251,6 +257,21 @@ class ORBextractor:
         _check(lib().orbx_extract_batch_device(self._h, C.c_void_p(d_images_ptr), n_images, w, h, row_pitch,
                                                image_pitch, None if lap_arr is None else _p(lap_arr)))
 
+    def stream_handle(self):
+        """Address of the handle's hipStream_t (orbx_stream_handle), e.g. for torch.cuda.ExternalStream."""
+        st = C.c_void_p()
+        _check(lib().orbx_stream_handle(self._h, C.byref(st)))
+        return st.value or 0
+
+    def extract_batch_host(self, images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
+        """orbx_extract_batch: frames in HOST memory (page-locked for real overlap); asynchronous."""
+        lp = None if lap is None else _p(np.ascontiguousarray(lap, np.int32))
+        _check(lib().orbx_extract_batch(self._h, C.c_void_p(images_ptr), n_images, w, h, row_pitch, image_pitch, lp))
+
+    def download_async(self, counts_ptr, mono_ptr, kps_ptr, desc_ptr, uright_ptr=None, depth_ptr=None, n_pairs=0):
+        """orbx_batch_download_async into host arrays given by address (page-locked for real asynchrony)."""
+        _check(lib().orbx_batch_download_async(self._h, counts_ptr, mono_ptr, kps_ptr, desc_ptr, uright_ptr, depth_ptr, n_pairs))
+
     def extract_batch_raw_device(self, preproc, d_frames_ptr, n_frames, row_pitch, image_pitch, lap=None):
         """Pre-processing chain + extraction of device-resident RAW frames on this handle's stream.  Asynchronous."""
         lap_arr = None if lap is None else np.ascontiguousarray(lap, np.int32).reshape(n_frames, 2)
@@ -304,6 +325,17 @@ class ORBextractor:
         out = np.zeros((h.value, w.value), np.uint8)
         _check(lib().orbx_pyramid_level(self._h, image, level, int(blurred), _p(out), out.strides[0],
                                         C.byref(w), C.byref(h)))
+        return out
+
+    def debug_score_map(self, enable=True):
+        """Test tap: following extractions also keep k_detect's pre-NMS FAST scores at iniThFAST (orbx_debug_score_map)."""
+        _check(lib().orbx_debug_score_map(self._h, 1 if enable else 0))
+
+    def debug_score_level(self, level, image=0):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().orbx_pyramid_level(self._h, image, level, 0, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().orbx_debug_score_level(self._h, image, level, _p(out), w.value))
         return out
 
     def debug_candidates(self, level, image=0):

@@ -218,7 +218,10 @@ class ORBextractor {
       mvuRight->assign(ur.begin(), ur.begin() + nl);
       mvDepth->assign(dp.begin(), dp.begin() + nl);
     }
-    if (mbKeepHostPyramid) SyncImagePyramid();
+    if (mbKeepHostPyramid) {
+      SyncImagePyramid(0);
+      SyncImagePyramid(1);
+    }
   }
 
   int inline GetLevels() { return nlevels; }
@@ -228,22 +231,28 @@ class ORBextractor {
   std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-  // Public in the reference (include/ORBextractor.h:86) and read by Frame::ComputeStereoMatches.  The
-  // pyramid lives in HBM; host copies are made only on request (SyncImagePyramid / mbKeepHostPyramid),
-  // because the stereo matcher of this repo reads the device copy (ComputeStereoMatches in ORBmatcher.h).
+  // Public in the reference (include/ORBextractor.h:86) and read by an unmodified Frame::ComputeStereoMatches
+  // (src/Frame.cc:927,1011,1024,1029).  The pyramid lives in HBM; with mbKeepHostPyramid (the DEFAULT, so that
+  // unmodified readers of mvImagePyramid keep working) every operator() / ExtractStereo refreshes the host copies
+  // (one D2H per level, ~3 MB per 1280x720 eye).  A caller that has replaced ComputeStereoMatches by the device version
+  // of this repo (ORBmatcher.h) sets mbKeepHostPyramid = false and calls SyncImagePyramid() only when it needs pixels.
+  // After ExtractStereo, mvImagePyramid is the LEFT eye (image 0) and mvImagePyramidRight the right eye (image 1).
   std::vector<ocv::Mat> mvImagePyramid;
-  bool mbKeepHostPyramid = false;
-  void SyncImagePyramid() {
+  std::vector<ocv::Mat> mvImagePyramidRight;
+  bool mbKeepHostPyramid = true;
+  void SyncImagePyramid(int image = 0) {
+    std::vector<ocv::Mat>& dst = image == 0 ? mvImagePyramid : mvImagePyramidRight;
+    dst.resize(nlevels);
     for (int l = 0; l < nlevels; l++) {
       int w = 0, h = 0;
-      if (orbx_pyramid_level(h_, 0, l, 0, nullptr, 0, &w, &h) != ORBX_OK)
+      if (orbx_pyramid_level(h_, image, l, 0, nullptr, 0, &w, &h) != ORBX_OK)
         throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
 #ifdef ORBX_HAVE_OPENCV
-      mvImagePyramid[l].create(h, w, CV_8UC1);
+      dst[l].create(h, w, CV_8UC1);
 #else
-      mvImagePyramid[l].create(h, w);
+      dst[l].create(h, w);
 #endif
-      if (orbx_pyramid_level(h_, 0, l, 0, mvImagePyramid[l].ptr(0), (ptrdiff_t)mvImagePyramid[l].step, &w, &h) != ORBX_OK)
+      if (orbx_pyramid_level(h_, image, l, 0, dst[l].ptr(0), (ptrdiff_t)dst[l].step, &w, &h) != ORBX_OK)
         throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
     }
   }

@@ -203,6 +203,10 @@ void build_coefs(const Geom& g, std::vector<int>& xofs, std::vector<short>& xab,
 
 int configure(orbx_extractor* ex, int w, int h) {
   if (w == ex->curW && h == ex->curH) return ORBX_OK;
+  // every per-axis table (resize coefficients, row tables) is sized for max_width x max_height: a wide-and-short image
+  // can pass the aggregate buffer checks below and still overrun them
+  if (w > ex->maxW || h > ex->maxH)
+    return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
   Geom g;
   std::string why;
   int rc = build_geom(ex, w, h, g, why);
@@ -210,7 +214,8 @@ int configure(orbx_extractor* ex, int w, int h) {
   const Geom& m = ex->gmax;
   if (g.pyrImg > m.pyrImg || g.candImg > m.candImg || g.selImg > m.selImg || g.cellImg > m.cellImg ||
       g.totalCells > m.totalCells)
-    return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
+    return fail(ORBX_E_CAPACITY, "image within max_width x max_height but its pyramid / cell-grid rounding needs more "
+                                 "buffer than the handle's maximum size: create the handle with this size");
   g.outCap = m.outCap;  // keep result strides fixed for the life of the handle
   g.selImg = m.selImg;
   g.pyrImg = m.pyrImg;
@@ -269,7 +274,6 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->pyr.l0Row = row_pitch;
   ex->pyr.l0Img = image_pitch;
   ex->pyr.pyr = ex->d_pyr.p;
-  ex->pyr.blur = ex->d_blur.p;
   ex->lastN = n;
   ex->lastEvValid = false;
   hipStream_t s = ex->stream;
@@ -327,75 +331,38 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   return record_pipeline(ex, n, lapTrivial, false);
 }
 
-// The kernel launches of one extraction on the handle's two streams (also the body captured into the hipGraph).
+// The kernel launches of one extraction on the handle's stream (also the body captured into the hipGraph):
+// resize chain -> k_detect -> k_octree -> (k_slots) -> k_describe.  The 7x7 Gaussian of :1074-1076 is evaluated inside
+// k_describe on the keypoints' own windows (no blurred pyramid, no side stream); the round-1 schedule (k_blur over every
+// level on a side stream beside the quadtree) and the alternatives measured around it are in DESIGN.md 4.
 int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) {
   const Geom& g = ex->g;
   hipStream_t s = ex->stream;
-  static const bool serial = getenv("ORBX_SERIAL") != nullptr;  // measurement aid: no side stream
-  hipStream_t sb = serial ? s : ex->stream2;
-  // Experiment knob (default off): blur level 0 beside the resize chain.  Measured 1.063 vs 1.039 ms/step — the chain
-  // slows down more than the quadtree-side blur gains.
-  static const int blur0 = getenv("ORBX_BLUR0") ? atoi(getenv("ORBX_BLUR0")) : 0;
-  const int nb0 = serial ? 0 : std::min(blur0, 1);  // only level 0 exists before the chain
-  if (nb0 > 0) {  // level 0 is the caller's image: its blur runs beside the (latency-bound) resize chain
-    HIPC(hipEventRecord(ex->evStart, s));
-    HIPC(hipStreamWaitEvent(sb, ex->evStart, 0));
-    StageTimer t(ex, sb, ORBX_STAGE_BLUR);
-    HIPC(launch_blur(g, ex->pyr, n, 0, nb0, sb));
-  }
-  static const int splitEnv = getenv("ORBX_SPLIT") ? atoi(getenv("ORBX_SPLIT")) : 0;
-  const int split = (splitEnv > 0 && splitEnv < g.nlevels) ? splitEnv : g.nlevels;  // levels [split, L) on the side stream
-  for (int l = 1; l < split; l++) {
+  ex->blurValid = false;  // the blurred levels (orbx_pyramid_level blurred = 1) are produced on demand
+  for (int l = 1; l < g.nlevels; l++) {
     StageTimer t(ex, s, ORBX_STAGE_RESIZE);
     HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, s));
   }
-  if (split < g.nlevels) {
-    HIPC(hipEventRecord(ex->evStart, s));
-    HIPC(hipStreamWaitEvent(ex->stream2, ex->evStart, 0));
-    for (int l = split; l < g.nlevels; l++) {
-      StageTimer t(ex, ex->stream2, ORBX_STAGE_RESIZE);
-      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, ex->stream2));
-    }
-    {
-      StageTimer t(ex, ex->stream2, ORBX_STAGE_DETECT);
-      HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, split, g.nlevels, ex->stream2));
-    }
-    HIPC(hipEventRecord(ex->evDet0, ex->stream2));
-  }
+  if (ex->d_dbgScore.p) HIPC(hipMemsetAsync(ex->d_dbgScore.p, 0, ex->d_dbgScore.n, s));  // test tap only
   // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
   // each other.  A per-device token orders the k_detect launches of all handles one after the other, while each still
-  // overlaps the other handles' quadtree / describe / stereo / resize work.  (ORBX_DETECT_TOKEN=0 disables it.)
-  static const bool useToken = !(getenv("ORBX_DETECT_TOKEN") && atoi(getenv("ORBX_DETECT_TOKEN")) == 0);
-  DetectToken* tok = (useToken && !capturing) ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
+  // overlaps the other handles' quadtree / describe / stereo / resize work.
+  DetectToken* tok = !capturing ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
   if (tok) {
     std::lock_guard<std::mutex> lk(tok->mu);
     if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
     ex->lastEvValid = false;
     {
       StageTimer t(ex, s, ORBX_STAGE_DETECT);
-      HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, split, s));
+      HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, g.nlevels, ex->d_dbgScore.p, s));
     }
     HIPC(hipEventRecord(tok->ev, s));
     tok->valid = true;
     tok->last = ex;
   } else {
     StageTimer t(ex, s, ORBX_STAGE_DETECT);
-    HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, split, s));
+    HIPC(launch_detect(g, ex->pyr, n, ex->d_cellCand.p, ex->d_cellCount.p, 0, g.nlevels, ex->d_dbgScore.p, s));
   }
-  if (split < g.nlevels) {
-    HIPC(hipStreamWaitEvent(s, ex->evDet0, 0));
-    ex->lastEvValid = false;
-  }
-  // The blurred copies only depend on the pyramid.  They run on the side stream, released once k_detect (which
-  // fills the chip by itself) is done, so that the streaming blur shares the GPU with the latency-bound quadtree.
-  // (Also tried: FAST on level 0 beside the resize chain -- slower, 1.48 vs 1.33 ms/step: both just time-slice.)
-  HIPC(hipEventRecord(ex->evPyr, s));
-  HIPC(hipStreamWaitEvent(sb, ex->evPyr, 0));
-  {
-    StageTimer t(ex, sb, ORBX_STAGE_BLUR);
-    HIPC(launch_blur(g, ex->pyr, n, nb0, g.nlevels, sb));
-  }
-  HIPC(hipEventRecord(ex->evBlur, sb));
   {
     StageTimer t(ex, s, ORBX_STAGE_OCTREE);
     HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,
@@ -405,8 +372,6 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) 
     StageTimer t(ex, s, ORBX_STAGE_SLOTS);
     HIPC(launch_slots(g, n, ex->d_sel.p, ex->d_selCount.p, ex->d_lap.p, ex->d_slot.p, ex->d_nOut.p, ex->d_mono.p, s));
   }
-  HIPC(hipStreamWaitEvent(s, ex->evBlur, 0));
-  ex->lastEvValid = false;  // fresh start event: do not bill the wait for the side stream to k_describe
   {
     StageTimer t(ex, s, ORBX_STAGE_DESCRIBE);
     HIPC(launch_describe(g, ex->pyr, n, ex->d_sel.p, ex->d_selCount.p, lapTrivial ? nullptr : ex->d_slot.p, ex->d_kps.p,
@@ -470,21 +435,9 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   auto ok = [&](hipError_t r) {
     if (e == hipSuccess) e = r;
   };
-  {
-    // ORBX_PRIO (experiment knob): 0 = both default, 1 = side stream (blur) high, 2 = main stream (quadtree) high
-    static const int prio = getenv("ORBX_PRIO") ? atoi(getenv("ORBX_PRIO")) : 1;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    ok(hipStreamCreateWithPriority(&ex->stream, hipStreamNonBlocking, prio == 2 ? hi : 0));
-    ok(hipStreamCreateWithPriority(&ex->stream2, hipStreamNonBlocking, prio == 1 ? hi : (prio == 2 ? lo : 0)));
-  }
+  ok(hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking));
   ok(hipEventCreateWithFlags(&ex->done, hipEventDisableTiming));
-  ok(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
-  ok(hipEventCreateWithFlags(&ex->evBlur, hipEventDisableTiming));
-  ok(hipEventCreateWithFlags(&ex->evStart, hipEventDisableTiming));
-  ok(hipEventCreateWithFlags(&ex->evDet0, hipEventDisableTiming));
   ok(ex->d_pyr.alloc(B * m.pyrImg + 256));
-  ok(ex->d_blur.alloc(B * m.pyrImg + 256));
   ok(ex->d_stage.alloc(B * (size_t)ex->stagePitch * max_height + 256));
   ok(ex->d_cand.alloc(B * m.candImg));
   ok(ex->d_cellCand.alloc(B * m.cellImg));
@@ -527,18 +480,13 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->hostResults = nullptr;
   if (ex->h_lap) (void)hipHostFree(ex->h_lap);
   ex->h_lap = nullptr;
-  ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
+  ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
   ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xofs.free(); ex->d_yofs.free();
   ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
-  if (ex->evPyr) (void)hipEventDestroy(ex->evPyr);
-  if (ex->evBlur) (void)hipEventDestroy(ex->evBlur);
-  if (ex->evStart) (void)hipEventDestroy(ex->evStart);
-  if (ex->evDet0) (void)hipEventDestroy(ex->evDet0);
-  if (ex->stream2) (void)hipStreamDestroy(ex->stream2);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
   delete ex;
 }
@@ -566,6 +514,50 @@ int orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   return enqueue_extract(ex, d_images, n_images, w, h, row_pitch, image_pitch, lap);
+}
+
+int orbx_stream_handle(const orbx_extractor* ex, void** stream) {
+  if (!ex || !stream) return fail(ORBX_E_BADARG, "null argument");
+  *stream = reinterpret_cast<void*>(ex->stream);
+  return ORBX_OK;
+}
+
+int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, int n_images, int w, int h, ptrdiff_t row_pitch,
+                       ptrdiff_t image_pitch, const int32_t* lap) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (!images || n_images <= 0 || w <= 0 || h <= 0) return fail(ORBX_E_EMPTY, "empty image");
+  if (n_images > ex->maxB) return fail(ORBX_E_CAPACITY, "batch larger than max_batch");
+  if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
+  if (row_pitch < w || image_pitch < row_pitch * (ptrdiff_t)(h - 1) + w) return fail(ORBX_E_BADARG, "pitch too small");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int pitch = align_up(w, 64);
+  const size_t imgBytes = (size_t)pitch * h;
+  if (image_pitch == row_pitch * (ptrdiff_t)h) {  // frames back to back: one tall 2-D copy
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, images, row_pitch, w, (size_t)h * n_images, hipMemcpyHostToDevice, ex->stream));
+  } else {
+    for (int i = 0; i < n_images; i++)
+      HIPC(hipMemcpy2DAsync(ex->d_stage.p + i * imgBytes, pitch, images + (size_t)i * image_pitch, row_pitch, w, h,
+                            hipMemcpyHostToDevice, ex->stream));
+  }
+  return enqueue_extract(ex, ex->d_stage.p, n_images, w, h, pitch, (ptrdiff_t)imgBytes, lap);
+}
+
+int orbx_batch_download_async(orbx_extractor* ex, int32_t* counts, int32_t* mono, orbx_keypoint* kps, uint8_t* desc,
+                              float* uright, float* depth, int n_pairs) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (ex->lastN <= 0) return fail(ORBX_E_BADARG, "no batch has been extracted on this handle");
+  if (n_pairs < 0 || n_pairs > ex->stereoPairs) return fail(ORBX_E_BADARG, "more pairs than the last stereo association held");
+  HIPC(hipSetDevice(ex->device));
+  const size_t n = (size_t)ex->lastN, oc = (size_t)ex->gmax.outCap;
+  hipStream_t st = ex->stream;
+  if (counts) HIPC(hipMemcpyAsync(counts, ex->d_nOut.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (mono) HIPC(hipMemcpyAsync(mono, ex->d_mono.p, n * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (kps) HIPC(hipMemcpyAsync(kps, ex->d_kps.p, n * oc * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+  if (desc) HIPC(hipMemcpyAsync(desc, ex->d_desc.p, n * oc * 32, hipMemcpyDeviceToHost, st));
+  if (uright && n_pairs) HIPC(hipMemcpyAsync(uright, ex->d_uR.p, (size_t)n_pairs * oc * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (depth && n_pairs) HIPC(hipMemcpyAsync(depth, ex->d_depth.p, (size_t)n_pairs * oc * sizeof(float), hipMemcpyDeviceToHost, st));
+  return ORBX_OK;
 }
 
 int orbx_sync(orbx_extractor* ex) {
@@ -703,6 +695,15 @@ int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, ui
   const uint8_t* src;
   size_t pitch;
   if (blurred) {
+    // The extraction never materialises blurred levels (k_describe blurs the keypoints' own windows).  This reader of
+    // "the level as GaussianBlur leaves it" (:1074-1076) runs the full-image k_blur once per extraction, on demand.
+    if (!ex->blurValid) {
+      if (!ex->d_blur.p) HIPC(ex->d_blur.alloc((size_t)ex->maxB * ex->gmax.pyrImg + 256));
+      ex->pyr.blur = ex->d_blur.p;
+      HIPC(launch_blur(ex->g, ex->pyr, ex->lastN, 0, ex->g.nlevels, ex->stream));
+      HIPC(hipStreamSynchronize(ex->stream));
+      ex->blurValid = true;
+    }
     src = ex->pyr.blur + (long long)image * ex->g.pyrImg + L.off;
     pitch = L.pitch;
   } else {
@@ -959,6 +960,27 @@ int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
   if (e == hipSuccess) e = hipMemcpy(v, d.p, (size_t)n * 8, hipMemcpyDeviceToHost);
   d.free();
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return ORBX_OK;
+}
+
+int orbx_debug_score_map(orbx_extractor* ex, int enable) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  if (enable && !ex->d_dbgScore.p) HIPC(ex->d_dbgScore.alloc((size_t)ex->maxB * ex->gmax.pyrImg + 256));
+  if (!enable) ex->d_dbgScore.free();
+  return ORBX_OK;
+}
+
+int orbx_debug_score_level(orbx_extractor* ex, int image, int level, uint8_t* dst, ptrdiff_t dst_stride) {
+  if (!ex || !dst || !ex->d_dbgScore.p || ex->curW == 0 || image < 0 || image >= ex->lastN || level < 0 ||
+      level >= ex->g.nlevels)
+    return fail(ORBX_E_BADARG, "score map not enabled or no such level");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  const LevelDev& L = ex->g.lv[level];
+  HIPC(hipMemcpy2D(dst, dst_stride, ex->d_dbgScore.p + (long long)image * ex->g.pyrImg + L.off, L.pitch, L.w, L.h,
+                   hipMemcpyDeviceToHost));
   return ORBX_OK;
 }
 

@@ -437,9 +437,12 @@ int orbx_search_by_projection(int device, const orbx_keypoint* kps_un, const uin
   if (n < 0 || n_map_points < 0 || nlevels < 1 || !scale_factors || (n && (!kps_un || !desc || !occupied || !match)) ||
       (n_map_points && !map_points))
     return fail(ORBX_E_BADARG, "bad argument");
+  // mnTrackScaleLevel is only read for points with mbTrackInView set (src/ORBmatcher.cc:58-61) and is uninitialised in
+  // MapPoint's constructors otherwise: validate it only there (the kernels never read it for the other points)
   for (int i = 0; i < n_map_points; i++)
-    if (map_points[i].predicted_level < 0 || map_points[i].predicted_level >= nlevels)
-      return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+    if (map_points[i].in_view && !map_points[i].bad &&
+        (map_points[i].predicted_level < 0 || map_points[i].predicted_level >= nlevels))
+      return fail(ORBX_E_BADARG, "in-view map point with a predicted level outside [0, nlevels)");
   static const orbx_map_point_view dummy{};
   return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels,
                                    map_points ? map_points : &dummy, nullptr, n_map_points, th, far_points,

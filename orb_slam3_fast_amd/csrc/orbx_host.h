@@ -235,6 +235,7 @@ struct orbx_extractor {
   Pyr pyr{};
   int lastN = 0;
   DevBuf<uint8_t> d_pyr, d_blur, d_stage, d_desc;
+  DevBuf<uint8_t> d_dbgScore;      // test tap (orbx_debug_score_map): FAST scores at iniThFAST, pyramid layout; normally unallocated
   DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
   DevBuf<uint16_t> d_knode;
   DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
@@ -267,8 +268,7 @@ struct orbx_extractor {
   std::vector<EvRec> evLog;
   size_t lastEv = 0;
   bool lastEvValid = false;
-  hipStream_t stream2 = nullptr;   // side stream: k_blur overlaps detect / quadtree
-  hipEvent_t evPyr = nullptr, evBlur = nullptr, evStart = nullptr, evDet0 = nullptr;
+  bool blurValid = false;          // d_blur holds the blurred levels of the last extraction (filled on demand)
   hipEvent_t next_event() {
     if (evCursor == evPool.size()) {
       hipEvent_t e;

@@ -190,6 +190,7 @@ constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, 
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 constexpr int kListCap = 640;    // upper bound of the test hook orbx_debug_set_detect_list_cap
 constexpr int kSurvCap = 448;    // LDS list of compass-test survivors of k_detect (flushed before it would overflow)
+constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
 constexpr int kCornerCap = 256;  // LDS corner list (a cell with more corners takes the tile-scan NMS)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
@@ -316,8 +317,8 @@ __device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
-                                               int* __restrict__ cellCount, int ablate, int listCap,
-                                               int cellBegin, int xcdRun) {
+                                               int* __restrict__ cellCount, int listCap, int cellBegin, int xcdRun,
+                                               uint8_t* __restrict__ dbgScore) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
   const int img = blockIdx.y;
@@ -367,8 +368,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  if (ablate & 16) return;
-  if (!(ablate & 1)) {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
+  {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
     // lane = (row phase, dword column): 16 columns x 4 rows per pass, no index divisions in the loop
     const int mis = iniX & 3, xa = iniX - mis;
     const int dpr = (rw + 3) >> 2;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     };
     const int nq_round = (nq + 63) & ~63;
     for (int q = lane; q < nq_round; q += 64) {
-      const bool act = q < nq && !(ablate & 2);
+      const bool act = q < nq;
       const int qq = min(q, nq - 1);  // idle lanes of the last round redo the last quad (masked out below)
       const int yd = (int)(((float)qq + 0.5f) * inv_qpr);
       const int j = qq - yd * qpr;
@@ -477,8 +477,14 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     flush_survivors();
     const int nCorners = nList;
     // 3x3 non-max suppression (strict '>') inside the cell + emission
-    if (ablate & 4) kept = 1;
-    if (!(ablate & 4) && !overflowed) {
+    if (dbgScore && pass == 0) {  // test tap (orbx_debug_score_map): the cell's FAST scores at iniThFAST, 0 = no corner
+      uint8_t* dm = dbgScore + (long long)img * g.pyrImg + L.off;
+      for (int i = lane; i < dw * dh; i += 64) {
+        const int y = i / dw, x = i - y * dw;
+        dm[(long long)(iniY + 3 + y) * L.pitch + iniX + 3 + x] = score8[(y + 1) * g.scoreP + x + 4];
+      }
+    }
+    if (!overflowed) {
       // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each
       const int SP = g.scoreP;
       for (int base = 0; base < nCorners; base += 64) {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         }
         kept += __popcll(m);
       }
-    } else if (!(ablate & 4))
+    } else
     for (int q = lane; q < nq_round; q += 64) {
       uint32_t sw = 0;
       int yd = 0, j = 0;
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     if (kept > 0) break;
     __syncthreads();
   }
-  if (lane == 0) *myCount = (ablate & 4) ? 0 : min(kept, L.cellCap);
+  if (lane == 0) *myCount = min(kept, L.cellCap);
 }
 
 static int g_detect_list_cap = kListCap;
@@ -553,16 +559,14 @@ void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : 
 
 // Cells of levels [level0, level1) only: level 0 needs no resize and is launched beside the pyramid chain.
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
-                         int level1, hipStream_t s) {
+                         int level1, uint8_t* dbgScore, hipStream_t s) {
   const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 16;
   const int cellBegin = g.lv[level0].cellStart;
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
   dim3 grid(cellEnd - cellBegin, nimg);
-  static const int ablate = getenv("ORBX_DETECT_ABLATE") ? atoi(getenv("ORBX_DETECT_ABLATE")) : 0;
-  static const int xcdRun = getenv("ORBX_DETECT_XCD_RUN") ? atoi(getenv("ORBX_DETECT_XCD_RUN")) : 8;
-  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, ablate, g_detect_list_cap,
-                     cellBegin, xcdRun);
+  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
+                     kDetectXcdRun, dbgScore);
   return hipGetLastError();
 }
 
@@ -895,11 +899,10 @@ template <bool REG>
 __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, const OctCtx& c, int n, int cells,
                                             const uint32_t* __restrict__ sparse, uint32_t* __restrict__ keys,
                                             uint16_t* __restrict__ kn, uint32_t* __restrict__ out,
-                                            int* __restrict__ outCount, int ablate) {
-#define OCT_EXIT(stage) if (ablate == stage) { if (threadIdx.x == 0) *outCount = 0; return; }
+                                            int* __restrict__ outCount, int profLevel) {
   const int tid = threadIdx.x;
 #ifdef OCT_PROF  // section timing of one block (tools/octree_prof.py; build with -DOCT_PROF, select the level with
-                 // ORBX_OCTREE_ABLATE=100+level): thread 0 prints the 10 ns ticks between the MK() markers
+                 // ORBX_OCTREE_PROF_LEVEL): thread 0 prints the 10 ns ticks between the MK() markers
   long long tmk[96]; int nmk = 0;
 #define MK() do { if (nmk < 96) tmk[nmk++] = wall_clock64(); } while (0)
 #else
@@ -920,7 +923,6 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
     return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
   });
   MK();
-  OCT_EXIT(1)
   const int N = L.quota;
   struct Buf {  // nx0[b][i] etc. as before, by address arithmetic (no pointer arrays -> no scratch)
     char* base;
@@ -1004,7 +1006,6 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   __syncthreads();
 
   MK();
-  OCT_EXIT(2)
   bool finish = false;
   int nE = 0, ecur = 0;
   // ---- phase 1: split every expandable node per pass (:610-677)
@@ -1099,13 +1100,12 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   }
 
   MK();
-  OCT_EXIT(3)
   // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
   while (!finish) {
     const int prevSize = nA;
     uint64_t* E = c.ebuf + ecur * c.maxn;
     uint64_t* E2 = c.ebuf + (ecur ^ 1) * c.maxn;
-    if (tid < 64 && ablate != 5)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
+    if (tid < 64)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
       introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
                      reinterpret_cast<int*>(tsum), tid);
     MK();
@@ -1239,7 +1239,6 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   }
 
   MK();
-  OCT_EXIT(4)
   // ---- best response per node, first candidate (reference order) wins ties (:741-754): the canonical rank
   // (cell row, cell column, y, x) is unique per candidate, so exactly one candidate equals its node's maximum
   // and writes the node's output slot itself.
@@ -1281,21 +1280,20 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   if (tid == 0) *outCount = nOut;
   MK();
 #ifdef OCT_PROF
-  if (tid == 0 && blockIdx.y == 0 && (int)blockIdx.x == ablate - 100) {
+  if (tid == 0 && blockIdx.y == 0 && (int)blockIdx.x == profLevel) {
     printf("L%d n=%d nA=%d :", (int)blockIdx.x, n, nA);
     for (int i = 1; i < nmk; i++) printf(" %d", (int)(tmk[i] - tmk[i - 1]));
     printf("\n");
   }
 #endif
 #undef MK
-#undef OCT_EXIT
 }
 
 __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
                                                 uint32_t* __restrict__ cand, int* __restrict__ candCount,
                                                 uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
-                                                int* __restrict__ selCount, int ablate, int forceGlobal) {
+                                                int* __restrict__ selCount, int profLevel, int forceGlobal) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_i[8];
   const int tid = threadIdx.x;
@@ -1370,9 +1368,9 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
   int* outCount = selCount + img * g.nlevels + l;
   if (n <= OCT_KMAX * OCT_NT && !forceGlobal)
-    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, ablate);
+    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel);
   else
-    octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, ablate);
+    octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel);
 }
 
 static int g_octree_force_global_host = 0;
@@ -1382,9 +1380,13 @@ hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, cons
                          uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
                          hipStream_t s) {
   dim3 grid(g.nlevels, nimg);
-  static const int ablate = getenv("ORBX_OCTREE_ABLATE") ? atoi(getenv("ORBX_OCTREE_ABLATE")) : 0;
+#ifdef OCT_PROF
+  static const int profLevel = getenv("ORBX_OCTREE_PROF_LEVEL") ? atoi(getenv("ORBX_OCTREE_PROF_LEVEL")) : 0;
+#else
+  const int profLevel = -1;
+#endif
   hipLaunchKernelGGL(k_octree, grid, dim3(OCT_NT), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
-                     candCount, knode, sel, selCount, ablate, g_octree_force_global_host);
+                     candCount, knode, sel, selCount, profLevel, g_octree_force_global_host);
   return hipGetLastError();
 }
 
@@ -1526,8 +1528,7 @@ hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int le
   for (int l = level0; l < level1; l++)
     tiles += ((g.lv[l].w + BL_TW - 1) / BL_TW) * ((g.lv[l].h + BL_TH - 1) / BL_TH);
   if (tiles == 0) return hipSuccess;
-  static const int xcdRun = getenv("ORBX_BLUR_XCD_RUN") ? atoi(getenv("ORBX_BLUR_XCD_RUN")) : 1;
-  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, xcdRun);
+  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, 1);  // plain tile order (runs: slower)
   return hipGetLastError();
 }
 
@@ -1619,22 +1620,32 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
   return a;
 }
 
-// One wave per selected keypoint.
-//  * IC_Angle (:75-99): lanes run along patch COLUMNS so that every load instruction reads one 31-byte row
-//    segment (1-2 cache lines) — two half-waves take the upper / lower 15 rows; integer moments are reduced
-//    with DPP shuffles.
-//  * rBRIEF (:102-147): the 37x37 footprint of the blurred level is staged in LDS with aligned dword loads,
-//    then lane t evaluates tests t, t+64, t+128, t+192; each __ballot is 8 descriptor bytes already in the
-//    reference's byte/bit order.
-//  * the keypoint + descriptor are written to their serial-order output slot.
-#define DS_PITCH 48
+// One wave per selected keypoint; the 7x7 Gaussian of GaussianBlur (:1074-1076) is evaluated ONLY where descriptors read
+// it: the wave stages the raw 43x43 window of its keypoint (rows / columns -21..+21: the 37x37 rBRIEF footprint plus the
+// blur's 3-px reach, which also contains the 31x31 IC_Angle patch) in LDS with aligned dword loads and derives everything
+// from that one window:
+//  * IC_Angle (:75-99) on the unblurred pixels: 31 rows x 9 aligned dwords folded into the integer moments under the
+//    circle mask |u| <= umax[|v|], reduced with cross-lane shuffles; cv::fastAtan2; glibc sinf / cosf (orbx_sincos.h);
+//  * the blur, separable and exact like k_blur (taps 18,34,48,56,48,34,18; horizontal sums as u16, one rounding at the
+//    end): horizontal pass on two rows at once (v_alignbyte + v_dot4_u32_u8, results packed as vertical u16 pairs),
+//    vertical pass as 4 v_dot2_u32_u16 per output; BORDER_REFLECT_101 is applied when the window is loaded (only for the
+//    few keypoints within 21 px of the level's edge) -- bit-identical to blurring the whole level first;
+//  * rBRIEF (:102-147): lane t evaluates tests t, t+64, t+128, t+192 on the blurred 37x37 patch; each __ballot is 8
+//    descriptor bytes already in the reference's byte/bit order;
+//  * keypoint + descriptor go to their serial-order output slot.
+// Against the round-1 pipeline (k_blur over every level, then a kernel reading 31x31 raw + 37x37 blurred per keypoint):
+// no blurred pyramid is written or re-read (-0.6 GB of HBM traffic per 64-image batch), one window load instead of two
+// scattered ones, ~45 % fewer blur instructions (1369 blurred pixels per keypoint instead of every pixel of every level).
+constexpr int DW_ROWS = 43;   // raw window rows / columns
+constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 bytes of misalignment)
+constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
+constexpr int DW_BP = 40;     // blurred patch pitch in bytes
+constexpr int DW_WAVE_DW = 22 * DW_HP + DW_ROWS * DW_RP + 16;  // dwords of LDS per wave: row pairs | raw window (+ slack)
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                  int* __restrict__ nOut, int* __restrict__ mono, int ablate,
-                                                  int xcdImages) {
-  __shared__ uint32_t patch_all[4][37 * DS_PITCH / 4];
-  if (ablate == 1) return;
+                                                  int* __restrict__ nOut, int* __restrict__ mono, int xcdImages) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][DW_WAVE_DW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // The load phase of this kernel runs at HBM speed, and the keypoints of an image arrive in quadtree order (spatially
   // scattered): with workgroups dealt round-robin to the 8 XCDs every L2 ends up fetching most of every image.  With
@@ -1664,62 +1675,38 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   if (idx >= selCount[img * g.nlevels + l]) return;
   const uint32_t key = sel[(long long)img * g.selImg + s];
   const int X = key_x(key), Y = key_y(key);
-  if (ablate == 2) return;
-  uint32_t* patch = patch_all[wv];
-  const uint8_t* patch8 = reinterpret_cast<const uint8_t*>(patch);
-  // IC_Angle on the unblurred level (:75-99): the 31 rows x 9 aligned dwords covering the circular patch are
-  // loaded as 279 coalesced dword items (5 per lane, all issued up front); every lane folds its bytes into the
-  // integer moments (u * I, v * I) under the circle mask |u| <= umax[|v|].
+  uint32_t* hp = lds_all[wv];                  // [22 row pairs][DW_HP]: H(2j, x) | H(2j+1, x) << 16
+  uint32_t* raw = hp + 22 * DW_HP;             // [43 rows][DW_RP] raw window; reused for the blurred patch
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  int m10 = 0, m01 = 0;
-    const int xr = (X - 15) & ~3, misr = (X - 15) - xr;
-    uint32_t w[5];  // (loads issued before the footprint staging below, so 12 loads are in flight together)
-    int um[5];
+  // ---- raw window -> LDS: rows Y-21..Y+21, aligned dwords covering columns X-21..X+21 (LDS byte 0 = column xs)
+  const int xs = (X - 21) & ~3, mis = __builtin_amdgcn_readfirstlane((X - 21) - xs);
+  const bool interior = X >= 21 && Y >= 21 && X + 21 < L.w && Y + 21 < L.h;
+  if (interior) {
+    uint32_t w[9];
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      const int i = min(lane + 64 * t, 278);
-      const int r = i / 9, c = i - r * 9;
-      w[t] = *reinterpret_cast<const uint32_t*>(im + (long long)(Y - 15 + r) * pitch + xr + 4 * c);
-      um[t] = c_umax[r < 15 ? 15 - r : r - 15];
+    for (int t = 0; t < 9; t++) {  // 516 dword items, all loads in flight before the first LDS store
+      const int i = min(lane + 64 * t, DW_ROWS * DW_RP - 1);
+      const int r = (int)(((unsigned)i * 5462u) >> 16), c = i - r * DW_RP;  // i / 12 for i < 2^13
+      const int gx = xs + 4 * c;
+      w[t] = gx < L.w ? *reinterpret_cast<const uint32_t*>(im + (long long)(Y - 21 + r) * pitch + gx) : 0u;
     }
-  // stage the blurred 37x37 footprint: rows Y-18..Y+18, aligned dwords covering columns X-18..X+18
-  const uint8_t* bl = p.blur + (long long)img * g.pyrImg + L.off;
-  const int xs = (X - 18) & ~3, mis = (X - 18) - xs;  // level pitch is a multiple of 64 -> rows are dword aligned
-  for (int i = lane; i < 37 * 11; i += 64) {
-    const int r = i / 11, c = i - r * 11;
-    patch[r * (DS_PITCH / 4) + c] =
-        *reinterpret_cast<const uint32_t*>(bl + (long long)(Y - 18 + r) * L.pitch + xs + 4 * c);
-  }
-  if (ablate == 3) return;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      const int i = lane + 64 * t;
-      const int ii = min(i, 278);
-      const int r = ii / 9, c = ii - r * 9;
-      const int v = r - 15;
-      const int lim = i < 279 ? um[t] : -1;
-      int rs = 0;
+    for (int t = 0; t < 9; t++)
+      if (lane + 64 * t < DW_ROWS * DW_RP) raw[lane + 64 * t] = w[t];
+  } else {  // window crosses the level's edge: BORDER_REFLECT_101, byte by byte (coordinates further out are never used)
+    for (int i = lane; i < DW_ROWS * DW_RP; i += 64) {
+      const int r = i / DW_RP, c = i - r * DW_RP;
+      const int yy = reflect101(min(max(Y - 21 + r, -3), L.h + 2), L.h);
+      uint32_t v = 0;
 #pragma unroll
-      for (int bI = 0; bI < 4; bI++) {
-        const int u = 4 * c + bI - misr - 15;
-        const int au = u < 0 ? -u : u;
-        const int val = au <= lim ? (int)((w[t] >> (8 * bI)) & 0xFF) : 0;
-        rs += val;
-        m10 += u * val;
+      for (int k = 0; k < 4; k++) {
+        const int xx = reflect101(min(max(xs + 4 * c + k, -3), L.w + 2), L.w);
+        v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * k);
       }
-      m01 += v * rs;
+      raw[i] = v;
     }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m10 += __shfl_xor(m10, o);
-    m01 += __shfl_xor(m01, o);
   }
-  if (ablate == 4) { if (m10 == 12345 && lane == 0) kps[0].x = 1; return; }
-  const float angle = fast_atan2_dev((float)m01, (float)m10);
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  float a, b;
-  glibc_sincosf<true>(__fmul_rn(angle, factorPI), b, a);  // a = cosf, b = sinf (orbx_sincos.h)
   // slot == nullptr: no keypoint can lie in the lapping area (lap1 < 19 <= every x), so the serial-order slot is
   // simply (keypoints of the earlier levels) + idx and k_slots is not launched at all
   int n_out_slot;
@@ -1730,10 +1717,104 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     for (int q = 0; q < l; q++) before += selCount[img * g.nlevels + q];
     n_out_slot = before + idx;
   }
-  uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // patch writes of this wave before its own reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // window stores of this wave before its own reads
   __builtin_amdgcn_wave_barrier();
-  const uint8_t* centre = patch8 + 18 * DS_PITCH + 18 + mis;
+  // ---- IC_Angle: rows 6..36 of the window (v = -15..15), the 9 aligned dwords that cover columns X-15..X+15
+  int m10 = 0, m01 = 0;
+  {
+    const int c0 = (6 + mis) >> 2, misr = (6 + mis) & 3;
+#pragma unroll
+    for (int t = 0; t < 5; t++) {
+      const int i = lane + 64 * t;
+      const int ii = min(i, 278);
+      const int r = (int)(((unsigned)ii * 7282u) >> 16), c = ii - r * 9;  // ii / 9 for ii < 2^12
+      const uint32_t wd = raw[(6 + r) * DW_RP + c0 + c];
+      const int v = r - 15;
+      const int lim = i < 279 ? c_umax[v < 0 ? -v : v] : -1;
+      int rs = 0;
+#pragma unroll
+      for (int bI = 0; bI < 4; bI++) {
+        const int u = 4 * c + bI - misr - 15;
+        const int au = u < 0 ? -u : u;
+        const int val = au <= lim ? (int)((wd >> (8 * bI)) & 0xFF) : 0;
+        rs += val;
+        m10 += u * val;
+      }
+      m01 += v * rs;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      m10 += __shfl_xor(m10, o);
+      m01 += __shfl_xor(m01, o);
+    }
+  }
+  const float angle = fast_atan2_dev((float)m01, (float)m10);
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, b;
+  glibc_sincosf<true>(__fmul_rn(angle, factorPI), b, a);  // a = cosf, b = sinf (orbx_sincos.h)
+  // ---- horizontal pass: item = (row pair j, group of 4 output columns 4q..4q+3); output column x <-> window byte
+  // x + 3 + mis, its taps are window bytes x + mis .. x + mis + 6
+  for (int i = lane; i < 22 * 10; i += 64) {
+    const int j = (int)(((unsigned)i * 6554u) >> 16), q = i - j * 10;  // i / 10
+    uint32_t h[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+      const uint32_t* row = raw + min(2 * j + rr, DW_ROWS - 1) * DW_RP + q;
+      const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];  // (d3 of the last group only feeds unused columns)
+      const uint32_t A0 = __builtin_amdgcn_alignbyte(d1, d0, mis), A1 = __builtin_amdgcn_alignbyte(d2, d1, mis),
+                     A2 = __builtin_amdgcn_alignbyte(d3, d2, mis);  // 12 window bytes from the first tap of column 4q
+      const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps 0..3 and 4..6 (LSB = lowest x)
+      h[rr][0] = __builtin_amdgcn_udot4(A0, wA, __builtin_amdgcn_udot4(A1, wB, 0, false), false);
+      h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 1), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 1), wB, 0, false), false);
+      h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 2), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 2), wB, 0, false), false);
+      h[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 3), wA,
+                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 3), wB, 0, false), false);
+    }
+    uint4 pk;
+    pk.x = h[0][0] | (h[1][0] << 16);
+    pk.y = h[0][1] | (h[1][1] << 16);
+    pk.z = h[0][2] | (h[1][2] << 16);
+    pk.w = h[0][3] | (h[1][3] << 16);
+    *reinterpret_cast<uint4*>(hp + j * DW_HP + 4 * q) = pk;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- vertical pass: item = (column x, chunk of 8 output rows); blurred row y needs H rows y..y+6.  The blurred
+  // 37x37 patch overwrites the raw window (every lane has read its last raw byte before the barrier above).
+  uint8_t* bl = reinterpret_cast<uint8_t*>(raw);
+  for (int i = lane; i < 5 * 37; i += 64) {
+    const int ch = (int)(((unsigned)i * 1772u) >> 16), x = i - ch * 37;  // i / 37 for i < 2^11
+    uint32_t pr[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) pr[k] = hp[min(4 * ch + k, 21) * DW_HP + x];  // H rows 8ch .. 8ch+13
+    const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16), w6 = 18u;            // even y
+    const uint32_t v0 = 18u << 16, v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);      // odd y
+#pragma unroll
+    for (int yy = 0; yy < 8; yy++) {
+      const int k0 = yy >> 1;
+      uint32_t acc;
+      if ((yy & 1) == 0) {
+        acc = udot2_u16(pr[k0], w01, 32768u);
+        acc = udot2_u16(pr[k0 + 1], w23, acc);
+        acc = udot2_u16(pr[k0 + 2], w45, acc);
+        acc = udot2_u16(pr[k0 + 3], w6, acc);
+      } else {
+        acc = udot2_u16(pr[k0], v0, 32768u);
+        acc = udot2_u16(pr[k0 + 1], v12, acc);
+        acc = udot2_u16(pr[k0 + 2], v34, acc);
+        acc = udot2_u16(pr[k0 + 3], v56, acc);
+      }
+      const int y = 8 * ch + yy;
+      if (y < 37) bl[y * DW_BP + x] = (uint8_t)(acc >> 16);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // ---- rBRIEF on the blurred patch
+  uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
+  const uint8_t* centre = bl + 18 * DW_BP + 18;
 #pragma unroll
   for (int gI = 0; gI < 4; gI++) {
     const int8_t* pt = c_pattern + 4 * (64 * gI + lane);
@@ -1742,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     const int ix0 = rne_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int iy1 = rne_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
     const int ix1 = rne_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = centre[iy0 * DS_PITCH + ix0], t1 = centre[iy1 * DS_PITCH + ix1];
+    const int t0 = centre[iy0 * DW_BP + ix0], t1 = centre[iy1 * DW_BP + ix1];
     const uint64_t bits = __ballot(t0 < t1);
     if (lane == 0) *reinterpret_cast<uint64_t*>(dout + 8 * gI) = bits;
   }
@@ -1761,10 +1842,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
 
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s) {
-  static const int ablate = getenv("ORBX_DESC_ABLATE") ? atoi(getenv("ORBX_DESC_ABLATE")) : 0;
-  static const int xcdImages = getenv("ORBX_DESC_XCD") ? atoi(getenv("ORBX_DESC_XCD")) : 1;
   hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc, nOut, mono, ablate, nimg >= 8 ? xcdImages : 0);
+                     kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ def test_bench_refuses_to_run_without_a_gpu_or_prints_json():
 def test_bench_prints_one_contract_line(mode):
     size = ["--width", "256", "--height", "256"] if mode == "fisheye" else ["--width", "320", "--height", "240"]
     r = _run(["--mode", mode, "--steps", "3", "--warmup", "1", "--pairs", "2", "--nfeatures", "300", "--cpu-pairs",
-              "4" if mode == "stereo" else "0"] + size)
+              "4" if mode == "stereo" else "0", "--latency-frames", "12", "--h2d-steps", "4"] + size)
     assert r.returncode == 0, r.stderr[-600:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -40,6 +40,26 @@ def test_bench_prints_one_contract_line(mode):
     rf = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and rf["bound"] in ("hbm", "mfma")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert d["config"]["distinct_streams_per_gpu"] == 2 and d["config"]["frames_in_ring"] == 3
+    assert "streaming" in rf and "limited_by" in rf
     if mode == "stereo":
         cb = d["cpu_baseline"]
         assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
+        mt = d["cpu_mt"]
+        assert mt["threads"] == 16 and mt["value"] > 0 and mt["extract_ms"]["mean"] > 0 and mt["stereo_ms"]["mean"] > 0
+        for k in ("latency_ms", "extract_ms", "stereo_ms"):
+            assert {"mean", "std", "p50", "p99", "frames"} <= set(d[k]) and d[k]["frames"] == 12 and d[k]["mean"] > 0
+        assert d["h2d_inclusive_value"] > 0 and d["h2d_inclusive"]["steps"] == 4
+
+
+@pytest.mark.gpu
+def test_bench_c5_mode_prints_one_contract_line():
+    r = _run(["--config", "C5", "--inflight", "2", "--steps", "4", "--warmup", "1", "--nfeatures", "300", "--width", "320",
+              "--height", "240", "--ring", "2"])
+    assert r.returncode == 0, r.stderr[-600:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert KEYS <= set(d) and d["value"] > 0 and d["config"]["workload"].startswith("C5")
+    assert d["config"]["pairs_per_step_per_gpu"] == 16 and d["config"]["distinct_streams_per_gpu"] == 8
+    assert d["config"]["allgather_bytes_per_step_per_gpu"] > 0

@@ -1,0 +1,93 @@
+"""Parity of EXACTLY the mode bench.py times: bench.Workload with its default arguments -- 32 distinct
+1280x720 stereo streams per batch, a ring of 3 frames, two extractor handles alternating, 7 steps enqueued back to back with
+no synchronisation in between, stereo association queued behind each batch -- and then EVERY image of BOTH handles' last
+batches (keypoints, descriptors, uRight, depth) against the CPU oracle, bit for bit.  Cross-handle ordering bugs (the
+k_detect token, the side stream's events, buffers reused while the other batch is in flight) would show here.
+The C5 flavour (8 streams x 4 consecutive frames, RCCL all-gather queued on the handles' streams, 1-rank RCCL) checks the
+gathered {n, desc[cap][32]} blocks against orbx_batch_download of the same images."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _kb(k):
+    return np.ascontiguousarray(k).view(np.uint8).reshape(len(k), 28)
+
+
+def _check_handles(wl, bench, steps):
+    import orb_slam3_fast_amd as orbx
+    from oracle import cpu_bench
+    a = wl.a
+    B = a.pairs
+    for _ in range(steps):
+        wl.step()                      # no synchronisation between the steps: exactly the timed loop of bench.py
+    wl.sync()
+    checked = 0
+    for h, ex in enumerate(wl.exs):
+        slot = wl.last_slot[h]
+        assert slot is not None
+        ref = cpu_bench.oracle_pairs(wl.host_left[slot], wl.host_right[slot], a.nfeatures, bench.BF, bench.BASE)
+        u, dep = np.zeros((B, ex.capacity), np.float32), np.zeros((B, ex.capacity), np.float32)
+        for p in range(B):
+            orbx._check(orbx.lib().orbx_stereo_download(ex._h, p, orbx._p(u[p]), orbx._p(dep[p]), ex.capacity))
+        for p in range(B):
+            okL, odL, okR, odR, ou, od = ref[p]
+            _, kL, dL = ex.download(p)
+            _, kR, dR = ex.download(B + p)
+            assert np.array_equal(_kb(kL), _kb(okL)) and np.array_equal(dL, odL), (h, p, "left")
+            assert np.array_equal(_kb(kR), _kb(okR)) and np.array_equal(dR, odR), (h, p, "right")
+            n = len(kL)
+            assert np.array_equal(u[p, :n].view(np.uint32), ou.view(np.uint32)), (h, p, "uRight")
+            assert np.array_equal(dep[p, :n].view(np.uint32), od.view(np.uint32)), (h, p, "depth")
+            checked += 1
+    return checked
+
+
+def test_default_bench_workload_matches_the_oracle():
+    import bench
+    a = bench.parse([])                              # bench.py's defaults: that IS the point
+    assert (a.pairs, a.distinct, a.handles, a.width, a.height, a.nfeatures, a.ring) == (32, 32, 2, 1280, 720, 1500, 3)
+    wl = bench.Workload(a)
+    assert len({s for s in wl.streams}) == 32
+    # distinct inputs: no two pairs of a batch are the same image
+    assert len({wl.host_left[0, p].tobytes()[:4096 * 64] for p in range(a.pairs)}) == a.pairs
+    assert _check_handles(wl, bench, 7) == 64        # both handles' last batches: steps 5 and 6 (ring slots 2 and 0)
+
+
+def test_c5_allgather_blocks_equal_the_downloads():
+    """bench.py --config C5 on one GPU with a 1-rank RCCL group: 8 streams x 4 consecutive frames per step, the all-gather
+    of {n, desc[cap][32]} queued on the handle's stream behind the extraction (zero-copy views of liborbx's buffers)."""
+    import torch
+    import torch.distributed as dist
+    import bench
+    a = bench.parse(["--config", "C5", "--ring", "2"])
+    assert a.pairs == 32 and a.distinct == 8 and a.allgather
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    torch.cuda.set_device(0)
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        wl = bench.Workload(a, 0, 0, dist)
+        # consecutive frames of a stream sit side by side in the batch
+        assert not np.array_equal(wl.host_left[0, 0], wl.host_left[0, 1]) and np.array_equal(wl.host_left[0, 1], wl.host_left[1, 0])
+        assert _check_handles(wl, bench, 5) == 64
+        torch.cuda.synchronize()
+        for h, ex in enumerate(wl.exs):
+            cnt, desc = wl.gathered[h]
+            cnt, desc = cnt.cpu().numpy(), desc.cpu().numpy()
+            assert cnt.shape == (2 * a.pairs,) and desc.shape == (2 * a.pairs, ex.capacity, 32)
+            for i in range(2 * a.pairs):
+                _, k, d = ex.download(i)
+                assert cnt[i] == len(k) and np.array_equal(desc[i, :len(k)], d), (h, i)
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -219,6 +219,23 @@ def test_empty_and_unsupported(gpu):
     assert mono == 0 and len(k) == 0
 
 
+def test_batch_larger_than_the_handle_in_one_axis_is_rejected(gpu):
+    """A wide-and-short (or tall-and-narrow) device batch fits the handle's aggregate buffers but not its per-axis
+    tables: it must be refused with E_CAPACITY like orbx_extract does, not overrun them."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    ex = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=1920, max_height=1200, max_batch=1)
+    for w, h in ((3000, 600), (600, 3000)):
+        dbuf = DeviceBuffer.from_numpy(np.zeros((h, w), np.uint8))
+        with pytest.raises(orbx.OrbxError) as e:
+            ex.extract_batch_device(dbuf.ptr.value, 1, w, h, w, w * h)
+        assert e.value.code == orbx.E_CAPACITY
+        dbuf.free()
+    dbuf = DeviceBuffer.from_numpy(synth.mono_frame(1920, 1200, 5))   # the handle is still usable
+    ex.extract_batch_device(dbuf.ptr.value, 1, 1920, 1200, 1920, 1920 * 1200)
+    assert len(ex.download(0)[1]) > 400
+    dbuf.free()
+
+
 def test_strided_input_and_reuse(gpu, oracle):
     w, h = 400, 300
     big = synth.mono_frame(w + 40, h + 10, 22)

@@ -61,3 +61,23 @@ def test_python_assembly_of_operator_call_matches_oracle(oracle, w, h, nf, nl, l
     om, ok, od = oracle.OracleExtractor(nf, 1.2, nl, 20, 7).extract(img, lap)
     assert mono == om and len(k) == len(ok) > 100
     assert k.tobytes() == ok.tobytes() and np.array_equal(d, od)
+
+
+def test_threaded_oracle_equals_serial(oracle):
+    """oracle `cpu_mt` (2 eye threads x per-level tasks, the fork's structure) returns exactly the serial oracle's
+    keypoints, descriptors, uRight and depth -- it is only a timing baseline."""
+    import numpy as np
+    from orb_slam3_fast_amd import synth
+    L, R = synth.stereo_pair(400, 300, 77)
+    eL, eR = oracle.OracleExtractor(600), oracle.OracleExtractor(600)
+    _, kL, dL = eL.extract(L)
+    _, kR, dR = eR.extract(R)
+    bf, b = 0.12 * 532.03, 0.12
+    u, d = oracle.stereo_match(eL, eR, kL, dL, kR, dR, bf, b)
+    fL, fR = oracle.OracleExtractor(600), oracle.OracleExtractor(600)
+    for _ in range(2):
+        r = oracle.stereo_frame_mt(fL, fR, L, R, bf, b)
+        assert kL.tobytes() == r[0].tobytes() and np.array_equal(dL, r[1])
+        assert kR.tobytes() == r[2].tobytes() and np.array_equal(dR, r[3])
+        assert u.tobytes() == r[4].tobytes() and d.tobytes() == r[5].tobytes()
+        assert r[6] > 0 and r[7] > 0

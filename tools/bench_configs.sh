@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 summ='import json,sys; d=json.loads(sys.stdin.read()); print("%-8s %10.1f %-16s %7.4f ms/step  kp/img %6.1f  dominant %s %.1f us" % (sys.argv[1], d["value"], d["unit"], d["ms_per_step"], d["config"]["keypoints_per_image"], d["roofline"]["kernel"], d["roofline"]["avg_launch_us"]))'
-run() { tag=$1; shift; timeout 300 python bench.py --cpu-pairs 0 "$@" 2>/dev/null | python -c "$summ" $tag; }
+run() { tag=$1; shift; timeout 300 python bench.py --no-extras "$@" 2>/dev/null | python -c "$summ" $tag; }
 run C2      --mode mono --width 640 --height 480 --nfeatures 1000
 run C1size  --mode mono --width 752 --height 480 --nfeatures 1000
 run 640st   --mode stereo --width 640 --height 480 --nfeatures 1000

@@ -77,8 +77,8 @@ def main():
         pos, ang = orientations(im, corner_mask(im, 20), 1500, rng)
         out["ori_pos_" + name] = pos
         out["ori_rad_" + name] = ang
-    # full FAST-score maps (threshold sweep) on small inputs: crops of the synthetic frames, noise, a checkerboard with
-    # ramps (equal neighbouring scores), extremes 0 / 255
+    # full FAST-score maps (threshold sweep) on small inputs: crops of the synthetic frames, noise, flat rectangles
+    # (equal neighbouring scores), extremes 0 / 255
     crops = []
     big = imgs["g384"]
     for _ in range(4):
@@ -86,8 +86,11 @@ def main():
         crops.append(big[y:y + 64, x:x + 64].copy())
     crops.append(rng.integers(0, 256, (64, 64), dtype=np.uint8))
     crops.append((rng.integers(0, 2, (64, 64)) * 255).astype(np.uint8))
-    yy, xx = np.mgrid[0:64, 0:64]
-    crops.append(((((yy // 8) + (xx // 8)) % 2) * 120 + 40 + (yy + xx) // 4).astype(np.uint8))
+    rects = np.full((64, 64), 90, np.uint8)   # flat rectangles: runs of equal scores along their corners (NMS ties)
+    for _ in range(14):
+        y, x, hh, ww = (int(v) for v in rng.integers(2, 44, 4))
+        rects[y:y + 3 + hh // 3, x:x + 3 + ww // 3] = int(rng.integers(0, 256))
+    crops.append(rects)
     crops.append(np.clip(110 + 18 * rng.standard_normal((64, 64)), 0, 255).astype(np.uint8))
     crops = np.stack(crops)
     out["score_inputs"] = crops
