@@ -366,7 +366,7 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) 
   {
     StageTimer t(ex, s, ORBX_STAGE_OCTREE);
     HIPC(launch_octree(g, n, ex->d_cellCand.p, ex->d_cellCount.p, ex->d_cellPrefix.p, ex->d_cand.p,
-                       ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, s));
+                       ex->d_candCount.p, ex->d_knode.p, ex->d_sel.p, ex->d_selCount.p, 0, g.nlevels, s));
   }
   if (!lapTrivial) {
     StageTimer t(ex, s, ORBX_STAGE_SLOTS);

@@ -75,8 +75,8 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, uint8_t* dbgScore, hipStream_t s);
 hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
-                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
-                         hipStream_t s);
+                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount, int level0,
+                         int level1, hipStream_t s);
 hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int level1, hipStream_t s);
 hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int* selCount, const int* lap,
                         int* slot, int* nOut, int* mono, hipStream_t s);

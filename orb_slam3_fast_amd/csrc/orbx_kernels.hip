@@ -1280,8 +1280,8 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   if (tid == 0) *outCount = nOut;
   MK();
 #ifdef OCT_PROF
-  if (tid == 0 && blockIdx.y == 0 && (int)blockIdx.x == profLevel) {
-    printf("L%d n=%d nA=%d :", (int)blockIdx.x, n, nA);
+  if (tid == 0 && profLevel) {  // (the caller passes 1 for the selected level)
+    printf("n=%d nA=%d :", n, nA);
     for (int i = 1; i < nmk; i++) printf(" %d", (int)(tmk[i] - tmk[i - 1]));
     printf("\n");
   }
@@ -1293,11 +1293,15 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
                                                 const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
                                                 uint32_t* __restrict__ cand, int* __restrict__ candCount,
                                                 uint16_t* __restrict__ knode, uint32_t* __restrict__ sel,
-                                                int* __restrict__ selCount, int profLevel, int forceGlobal) {
+                                                int* __restrict__ selCount, int profLevel, int forceGlobal, int level0,
+                                                int nlv) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_i[8];
   const int tid = threadIdx.x;
-  const int l = blockIdx.x, img = blockIdx.y;
+  // Level-major block order (all images' level 0 first): the 2-per-CU residency then pairs a heavy level-0 / level-1
+  // workgroup with a light level-4+ one instead of with another heavy one.
+  const int nimg_ = gridDim.x / nlv;
+  const int l = level0 + blockIdx.x / nimg_, img = blockIdx.x % nimg_;
   const LevelDev L = g.lv[l];
   const int maxn = oct_maxn(g);
   const int nrep = oct_rep(g);
@@ -1368,25 +1372,26 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
   int* outCount = selCount + img * g.nlevels + l;
   if (n <= OCT_KMAX * OCT_NT && !forceGlobal)
-    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel);
+    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
   else
-    octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel);
+    octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
 }
 
 static int g_octree_force_global_host = 0;
 void debug_set_octree_global(int on) { g_octree_force_global_host = on ? 1 : 0; }
 
 hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
-                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount,
-                         hipStream_t s) {
-  dim3 grid(g.nlevels, nimg);
+                         uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount, int level0,
+                         int level1, hipStream_t s) {
+  if (level1 <= level0) return hipSuccess;
+  dim3 grid((level1 - level0) * nimg);
 #ifdef OCT_PROF
   static const int profLevel = getenv("ORBX_OCTREE_PROF_LEVEL") ? atoi(getenv("ORBX_OCTREE_PROF_LEVEL")) : 0;
 #else
   const int profLevel = -1;
 #endif
   hipLaunchKernelGGL(k_octree, grid, dim3(OCT_NT), octree_lds_bytes(g), s, g, cellCand, cellCount, cellPrefix, cand,
-                     candCount, knode, sel, selCount, profLevel, g_octree_force_global_host);
+                     candCount, knode, sel, selCount, profLevel, g_octree_force_global_host, level0, level1 - level0);
   return hipGetLastError();
 }
 
