@@ -1641,6 +1641,37 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 // Against the round-1 pipeline (k_blur over every level, then a kernel reading 31x31 raw + 37x37 blurred per keypoint):
 // no blurred pyramid is written or re-read (-0.6 GB of HBM traffic per 64-image batch), one window load instead of two
 // scattered ones, ~45 % fewer blur instructions (1369 blurred pixels per keypoint instead of every pixel of every level).
+// IC_Angle weights: for window dword item i = 9 r + c (row r = 0..30 <-> v = r - 15, aligned dword c = 0..8) and
+// misalignment m = (X - 15) & 3, byte b of the dword is patch column u = 4c + b - m - 15.  Entry .x = 0x01 per byte inside
+// the circle (|u| <= umax[|v|]), .y = (u + 16) per such byte (1..31), so that with wd = the four pixels
+//   sum(val) = v_dot4(wd, .x)      sum(u * val) = v_dot4(wd, .y) - 16 * sum(val)
+// -- two dot products per dword instead of four masked multiply-adds (the kernel is VALU-issue bound).
+struct IcTable {
+  uint2 e[4][280];
+};
+constexpr IcTable make_ic_table() {
+  IcTable t{};
+  const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  for (int m = 0; m < 4; m++)
+    for (int i = 0; i < 280; i++) {
+      uint32_t mk = 0, wt = 0;
+      if (i < 279) {
+        const int r = i / 9, c = i - 9 * r, v = r - 15, lim = um[v < 0 ? -v : v];
+        for (int b = 0; b < 4; b++) {
+          const int u = 4 * c + b - m - 15;
+          if (u >= -lim && u <= lim) {
+            mk |= 1u << (8 * b);
+            wt |= (uint32_t)(u + 16) << (8 * b);
+          }
+        }
+      }
+      t.e[m][i].x = mk;
+      t.e[m][i].y = wt;
+    }
+  return t;
+}
+__device__ const IcTable c_ic = make_ic_table();
+
 constexpr int DW_ROWS = 43;   // raw window rows / columns
 constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 bytes of misalignment)
 constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
@@ -1651,11 +1682,11 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                   int* __restrict__ nOut, int* __restrict__ mono, int xcdImages) {
   __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][DW_WAVE_DW];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // The load phase of this kernel runs at HBM speed, and the keypoints of an image arrive in quadtree order (spatially
-  // scattered): with workgroups dealt round-robin to the 8 XCDs every L2 ends up fetching most of every image.  With
-  // xcdImages set, all workgroups of an image go to ONE XCD (image i -> XCD i mod 8), so its pyramid lines are fetched into
-  // one L2 only.  Only for the first 8 * floor(nimg / 8) images; the rest keep the plain order.
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR
+  // The keypoints of an image arrive in quadtree order (spatially scattered): with workgroups dealt round-robin to the 8
+  // XCDs every L2 ends up fetching most of every image.  With xcdImages set, all workgroups of an image go to ONE XCD
+  // (image i -> XCD i mod 8), so its pyramid lines are fetched into one L2 only.  Only for the first 8 * floor(nimg / 8)
+  // images; the rest keep the plain order.
   int bx = blockIdx.x, img = blockIdx.y;
   if (xcdImages) {
     const unsigned nbx = gridDim.x, flat = blockIdx.y * nbx + blockIdx.x, full = (gridDim.y / 8u) * 8u;
@@ -1678,7 +1709,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     mono[img] = total;
   }
   if (idx >= selCount[img * g.nlevels + l]) return;
-  const uint32_t key = sel[(long long)img * g.selImg + s];
+  const uint32_t key = __builtin_amdgcn_readfirstlane(sel[(long long)img * g.selImg + s]);  // one keypoint per wave
   const int X = key_x(key), Y = key_y(key);
   uint32_t* hp = lds_all[wv];                  // [22 row pairs][DW_HP]: H(2j, x) | H(2j+1, x) << 16
   uint32_t* raw = hp + 22 * DW_HP;             // [43 rows][DW_RP] raw window; reused for the blurred patch
@@ -1689,12 +1720,13 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   const bool interior = X >= 21 && Y >= 21 && X + 21 < L.w && Y + 21 < L.h;
   if (interior) {
     uint32_t w[9];
+    const uint8_t* base = im + (long long)(Y - 21) * pitch + xs;  // uniform: SGPR base + 32-bit lane offsets
 #pragma unroll
     for (int t = 0; t < 9; t++) {  // 516 dword items, all loads in flight before the first LDS store
       const int i = min(lane + 64 * t, DW_ROWS * DW_RP - 1);
       const int r = (int)(((unsigned)i * 5462u) >> 16), c = i - r * DW_RP;  // i / 12 for i < 2^13
-      const int gx = xs + 4 * c;
-      w[t] = gx < L.w ? *reinterpret_cast<const uint32_t*>(im + (long long)(Y - 21 + r) * pitch + gx) : 0u;
+      const unsigned off = (unsigned)(r * pitch + 4 * c);
+      w[t] = xs + 4 * c < L.w ? *reinterpret_cast<const uint32_t*>(base + off) : 0u;
     }
 #pragma unroll
     for (int t = 0; t < 9; t++)
@@ -1724,29 +1756,25 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // window stores of this wave before its own reads
   __builtin_amdgcn_wave_barrier();
-  // ---- IC_Angle: rows 6..36 of the window (v = -15..15), the 9 aligned dwords that cover columns X-15..X+15
+  // ---- IC_Angle: rows 6..36 of the window (v = -15..15), the 9 aligned dwords that cover columns X-15..X+15;
+  // two dot products per dword against the precomputed circle mask / column weights (c_ic)
   int m10 = 0, m01 = 0;
   {
     const int c0 = (6 + mis) >> 2, misr = (6 + mis) & 3;
+    const uint2* tab = c_ic.e[misr];
+    int srs = 0, sw = 0;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-      const int i = lane + 64 * t;
-      const int ii = min(i, 278);
+      const int ii = min(lane + 64 * t, 279);  // entry 279 is all zero
       const int r = (int)(((unsigned)ii * 7282u) >> 16), c = ii - r * 9;  // ii / 9 for ii < 2^12
+      const uint2 e = tab[ii];
       const uint32_t wd = raw[(6 + r) * DW_RP + c0 + c];
-      const int v = r - 15;
-      const int lim = i < 279 ? c_umax[v < 0 ? -v : v] : -1;
-      int rs = 0;
-#pragma unroll
-      for (int bI = 0; bI < 4; bI++) {
-        const int u = 4 * c + bI - misr - 15;
-        const int au = u < 0 ? -u : u;
-        const int val = au <= lim ? (int)((wd >> (8 * bI)) & 0xFF) : 0;
-        rs += val;
-        m10 += u * val;
-      }
-      m01 += v * rs;
+      const int rs = (int)__builtin_amdgcn_udot4(wd, e.x, 0u, false);
+      sw = (int)__builtin_amdgcn_udot4(wd, e.y, (uint32_t)sw, false);
+      srs += rs;
+      m01 += (r - 15) * rs;
     }
+    m10 = sw - 16 * srs;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       m10 += __shfl_xor(m10, o);
@@ -1811,8 +1839,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
         acc = udot2_u16(pr[k0 + 2], v34, acc);
         acc = udot2_u16(pr[k0 + 3], v56, acc);
       }
-      const int y = 8 * ch + yy;
-      if (y < 37) bl[y * DW_BP + x] = (uint8_t)(acc >> 16);
+      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)(acc >> 16);  // rows 37..39 are padding (40 x 40 B fit the old window)
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
