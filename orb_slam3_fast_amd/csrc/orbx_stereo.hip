@@ -56,7 +56,7 @@ hipError_t launch_stereo_rows(const StereoArgs& a, int npairs, hipStream_t s) {
 // all right keypoints passing the same band/octave/disparity filters, which is what the lanes compute.
 __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
   const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // one left keypoint per wave: SGPR
   const int pair = blockIdx.y;
   const int imgL = a.firstL + pair, imgR = a.firstR + pair;
   const int nL = a.nL[imgL];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
   const float minU = __fsub_rn(uL, maxD), maxU = uL;
   const int row = (int)vL;
   uint32_t best = (100u << 16);  // TH_HIGH, strict '<'
+  float bestX = 0.f;             // u of this lane's best candidate (saves the dependent kR[best] load after the reduction)
   if (!(maxU < 0)) {
     const int* rowStart = a.rowStart + (long long)pair * (a.imgH + 1);
     const int* items = a.rowItems + (long long)pair * a.capR;
@@ -88,23 +89,33 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
       if (j < je) {
         const int iR = items[j];
         const orbx_keypoint k = kR[iR];
+        // the descriptor row is fetched together with the keypoint (both depend only on iR): one memory round trip
+        // instead of two on the kernel's critical path (it is latency-, not bandwidth-bound)
+        const uint4* dq = reinterpret_cast<const uint4*>(dR + (long long)iR * 8);
+        const uint4 q0 = dq[0], q1 = dq[1];
         const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
         const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
         const bool ok = !(k.y == 0.0f && k.x == 0.0f) && row >= minr && row <= maxr &&
                         k.octave >= levelL - 1 && k.octave <= levelL + 1 && k.x >= minU && k.x <= maxU;
         if (ok) {
-          const uint32_t cand = ((uint32_t)hamming256(dl, dR + (long long)iR * 8) << 16) | (uint32_t)iR;
-          best = min(best, cand);
+          const int d = __popc(dl[0] ^ q0.x) + __popc(dl[1] ^ q0.y) + __popc(dl[2] ^ q0.z) + __popc(dl[3] ^ q0.w) +
+                        __popc(dl[4] ^ q1.x) + __popc(dl[5] ^ q1.y) + __popc(dl[6] ^ q1.z) + __popc(dl[7] ^ q1.w);
+          const uint32_t cand = ((uint32_t)d << 16) | (uint32_t)iR;
+          if (cand < best) {
+            best = cand;
+            bestX = k.x;
+          }
         }
       }
     }
   }
+  const uint32_t mine = best;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
   const int bestDist = (int)(best >> 16);
   if (bestDist < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
-    const int bestIdxR = (int)(best & 0xFFFF);
-    const float uR0 = kR[bestIdxR].x;
+    const uint64_t owners = __ballot(mine == best);  // iR is unique per candidate: exactly the lane(s) that saw it
+    const float uR0 = __shfl(bestX, (int)__builtin_ctzll(owners));
     const float sf = 1.0f / g.lv[levelL].scale;  // mvInvScaleFactors
     const float su = roundf(__fmul_rn(kpL.x, sf)), sv = roundf(__fmul_rn(kpL.y, sf)), sr = roundf(__fmul_rn(uR0, sf));
     const LevelDev L = g.lv[levelL];
