@@ -158,6 +158,10 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
   g.pyrImg = off;
   g.candImg = candOff;
   g.cellImg = cellOff;
+  if (resize_lds_bytes(g) > 160 * 1024 - 2048) {
+    why = "scale factor too large for the LDS-staged resize footprint";
+    return ORBX_E_UNSUPPORTED;
+  }
   if (octree_lds_bytes(g) > 160 * 1024 - 2048) {
     why = "nfeatures too large for the LDS-resident quadtree";
     return ORBX_E_UNSUPPORTED;

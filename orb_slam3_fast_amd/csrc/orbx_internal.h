@@ -83,6 +83,7 @@ hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int*
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s);
 size_t octree_lds_bytes(const Geom& g);
+size_t resize_lds_bytes(const Geom& g);
 
 struct StereoArgs {
   const orbx_keypoint *kL, *kR;

@@ -57,35 +57,38 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   const int ce = min(xofs[D.xcoef + x1] + 1, S.w - 1);
   const int ndw = ((ce - cb) >> 2) + 1;
   {
-    // Footprint -> LDS.  All of a thread's global loads are issued before the first LDS store: with a plain loop
-    // every trip waited for its own load (7 serialized HBM latencies per block, the bulk of the kernel's time).
-    const float inv = 1.0f / (float)ndw;
-    const int n = nrows * ndw;
-    constexpr int kTrips = 8;  // one batch covers the footprint at scale 1.2 (21 x 78 dwords); larger scales loop
-    for (int base = 0; base < n; base += 256 * kTrips) {
-    uint32_t v[kTrips];
-    int slot[kTrips];
+    // Footprint -> LDS.  Thread = (row phase r0, dword column c): rpp = 256 / ndw source rows per pass, so a trip is a
+    // pointer increment, a bounds test and a load (no per-item index division); all of a thread's global loads are
+    // issued before its first LDS store (a plain copy loop serialised one HBM latency per trip).
+    for (int cbase = 0; cbase < ndw; cbase += 256) {          // one trip unless the scale factor exceeds ~3.9
+    const int nd = min(ndw - cbase, 256);
+    const int rpp = 256 / nd;                                  // rows per pass (3 at scale 1.2: 78 dwords per row)
+    const int r0 = (int)(((float)tid + 0.5f) / (float)nd);    // tid / nd, once per thread
+    const int c = cbase + tid - r0 * nd;
+    const bool lanes = r0 < rpp;                               // threads beyond rpp * nd idle
+    const int gx = cb + 4 * c;
+    const bool wide = gx + 4 <= S.w;
+    constexpr int kTrips = 8;  // one batch covers the footprint at scale 1.2 (21 rows / 3 per pass); larger scales loop
+    for (int rbase = 0; rbase < nrows; rbase += rpp * kTrips) {
+      uint32_t v[kTrips];
+      const uint8_t* q = src + (long long)(rb + rbase + r0) * sp + gx;
 #pragma unroll
-    for (int k = 0; k < kTrips; k++) {
-      const int i = base + tid + 256 * k;
-      slot[k] = -1;
-      v[k] = 0;
-      if (i < n) {
-        const int r = (int)(((float)i + 0.5f) * inv), c = i - r * ndw;
-        const int gx = cb + 4 * c;
-        const uint8_t* q = src + (long long)(rb + r) * sp + gx;
-        slot[k] = r * srcDwMax + c;
-        if (gx + 4 <= S.w) {
-          v[k] = *reinterpret_cast<const uint32_t*>(q);
-        } else {
-          for (int b = 0; b < 4; b++)
-            if (gx + b < S.w) v[k] |= (uint32_t)q[b] << (8 * b);
+      for (int k = 0; k < kTrips; k++) {
+        v[k] = 0;
+        if (lanes && rbase + r0 + k * rpp < nrows) {
+          if (wide) {
+            v[k] = *reinterpret_cast<const uint32_t*>(q);
+          } else {
+            for (int bI = 0; bI < 4; bI++)
+              if (gx + bI < S.w) v[k] |= (uint32_t)q[bI] << (8 * bI);
+          }
         }
+        q += (long long)rpp * sp;
       }
-    }
 #pragma unroll
-    for (int k = 0; k < kTrips; k++)
-      if (slot[k] >= 0) st[slot[k]] = v[k];
+      for (int k = 0; k < kTrips; k++)
+        if (lanes && rbase + r0 + k * rpp < nrows) st[(rbase + r0 + k * rpp) * srcDwMax + c] = v[k];
+    }
     }
   }
 #ifdef RS_PROF
@@ -164,14 +167,31 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
 #endif
 }
 
+// footprint bounds of a 256 x 16 dst block for this level's scale (+ slack for the floor/ceil of the taps)
+static void resize_footprint(const Geom& g, int level, int& srcRowsMax, int& srcDwMax, size_t& lds) {
+  const LevelDev& D = g.lv[level];
+  const LevelDev& S = g.lv[level - 1];
+  srcRowsMax = (int)((double)RS_DR * S.h / D.h) + 4;
+  srcDwMax = ((int)((double)RS_DW * S.w / D.w) + 12) / 4 + 1;
+  lds = (size_t)srcRowsMax * srcDwMax * 4 + (size_t)srcRowsMax * RS_DW * 2;
+}
+size_t resize_lds_bytes(const Geom& g) {
+  size_t m = 0;
+  for (int l = 1; l < g.nlevels; l++) {
+    int a, b;
+    size_t n;
+    resize_footprint(g, l, a, b, n);
+    m = n > m ? n : m;
+  }
+  return m;
+}
+
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
                          const int* yofs, const short* yab, hipStream_t s) {
   const LevelDev& D = g.lv[level];
-  const LevelDev& S = g.lv[level - 1];
-  // footprint bounds of a 256 x 8 dst block for this level's scale (+ slack for the floor/ceil of the taps)
-  const int srcRowsMax = (int)((double)RS_DR * S.h / D.h) + 4;
-  const int srcDwMax = ((int)((double)RS_DW * S.w / D.w) + 12) / 4 + 1;
-  const size_t lds = (size_t)srcRowsMax * srcDwMax * 4 + (size_t)srcRowsMax * RS_DW * 2;
+  int srcRowsMax, srcDwMax;
+  size_t lds;
+  resize_footprint(g, level, srcRowsMax, srcDwMax, lds);
   dim3 grid((D.w + RS_DW - 1) / RS_DW, (D.h + RS_DR - 1) / RS_DR, nimg);
   hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, s, g, p, level, xofs, xab, yofs, yab, srcRowsMax, srcDwMax);
   return hipGetLastError();
@@ -1885,6 +1905,11 @@ hipError_t prepare_kernels(const Geom& g) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;
+  if (g.nlevels > 1) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)std::max<size_t>(resize_lds_bytes(g), 1024));
+    if (e != hipSuccess) return e;
+  }
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_det);
 }

@@ -162,6 +162,8 @@ def test_device_sincos_equals_host_libm(gpu, oracle):
     (1000, 1.1, 12, 20, 7, 800, 600),     # 12 levels
     (300, 1.2, 1, 20, 7, 320, 240),       # single level
     (200, 1.2, 2, 20, 7, 101, 99),        # one 69 x 67 cell per level (cells wider than 64 px)
+    (400, 4.0, 2, 20, 7, 1600, 1200),     # scale 4: a 256-column resize block needs > 256 source dwords per row
+    (400, 3.0, 3, 20, 7, 1536, 1152),     # scale 3: 65 KB of LDS for the staged footprint
 ])
 def test_extractor_parameter_sweep(gpu, oracle, nf, sf, nl, ini, mn, w, h):
     img = synth.mono_frame(w, h, 90 + nl)
