@@ -336,6 +336,7 @@ __device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
 // The NMS needs no threshold masking: a neighbour that is not a corner at t has score < t <= the centre's.
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
+template <bool TAP>  // TAP: the test tap of orbx_debug_score_map, a separate instantiation (its registers cost the product kernel 3.5 %)
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
                                                int* __restrict__ cellCount, int listCap, int cellBegin, int xcdRun,
                                                uint8_t* __restrict__ dbgScore) {
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     flush_survivors();
     const int nCorners = nList;
     // 3x3 non-max suppression (strict '>') inside the cell + emission
-    if (dbgScore && pass == 0) {  // test tap (orbx_debug_score_map): the cell's FAST scores at iniThFAST, 0 = no corner
+    if (TAP && pass == 0) {  // test tap (orbx_debug_score_map): the cell's FAST scores at iniThFAST, 0 = no corner
       uint8_t* dm = dbgScore + (long long)img * g.pyrImg + L.off;
       for (int i = lane; i < dw * dh; i += 64) {
         const int y = i / dw, x = i - y * dw;
@@ -585,8 +586,12 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
   dim3 grid(cellEnd - cellBegin, nimg);
-  hipLaunchKernelGGL(k_detect, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
-                     kDetectXcdRun, dbgScore);
+  if (dbgScore)
+    hipLaunchKernelGGL(k_detect<true>, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
+                       kDetectXcdRun, dbgScore);
+  else
+    hipLaunchKernelGGL(k_detect<false>, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
+                       kDetectXcdRun, dbgScore);
   return hipGetLastError();
 }
 
@@ -1910,7 +1915,10 @@ hipError_t prepare_kernels(const Geom& g) {
                             (int)std::max<size_t>(resize_lds_bytes(g), 1024));
     if (e != hipSuccess) return e;
   }
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect), hipFuncAttributeMaxDynamicSharedMemorySize,
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_det);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)lds_det);
 }
 
