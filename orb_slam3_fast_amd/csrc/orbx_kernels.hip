@@ -56,6 +56,29 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   const int cb = xofs[D.xcoef + x0] & ~3;                                       // first source byte (dword aligned)
   const int ce = min(xofs[D.xcoef + x1] + 1, S.w - 1);
   const int ndw = ((ce - cb) >> 2) + 1;
+  // Every coefficient the two passes need is fetched HERE, together with the footprint: a block is a chain of dependent
+  // memory latencies (tile bounds -> footprint -> column coefficients -> row coefficients), and the kernel's time is that
+  // chain times the number of block generations, not bandwidth or issue slots.
+  const int qc = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  uint32_t sel[4], coef[4];
+  int dwi[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int dx = min(x0 + 4 * qc + j, D.w - 1);
+    const int o = xofs[D.xcoef + dx] - cb;  // S[sx + 1] is only weighted by a1 != 0 when it exists (build_coefs)
+    const int sh = o & 3;
+    dwi[j] = o >> 2;
+    sel[j] = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16);
+    coef[j] = reinterpret_cast<const uint32_t*>(xab)[D.xcoef + dx];  // a0 | a1 << 16
+  }
+  int vsy[RS_DR / 4];
+  uint32_t vbb[RS_DR / 4];
+#pragma unroll
+  for (int k = 0; k < RS_DR / 4; k++) {  // rows w, w + 4, ... of the block belong to this wave (wave-uniform: scalar loads)
+    const int dy = min(y0 + w + 4 * k, D.h - 1);
+    vsy[k] = yofs[D.ycoef + dy];
+    vbb[k] = reinterpret_cast<const uint32_t*>(yab)[D.ycoef + dy];
+  }
   {
     // Footprint -> LDS.  Thread = (row phase r0, dword column c): rpp = 256 / ndw source rows per pass, so a trip is a
     // pointer increment, a bounds test and a load (no per-item index division); all of a thread's global loads are
@@ -101,18 +124,6 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   {  // horizontal pass: lane = quad of 4 dst columns, wave = source-row phase (rows w, w + 4, ...).  Per output one
      // ds_read2_b32 (the aligned dword pair holding S[sx], S[sx+1]), one v_perm with a per-lane selector that spreads
      // the two bytes into u16 halves, one v_dot2_u32_u16 against (a0, a1), one shift; four results leave as one b64.
-    const int qc = tid & 63, w = tid >> 6;
-    uint32_t sel[4], coef[4];
-    int dwi[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int dx = min(x0 + 4 * qc + j, D.w - 1);
-      const int o = xofs[D.xcoef + dx] - cb;  // S[sx + 1] is only weighted by a1 != 0 when it exists (build_coefs)
-      const int sh = o & 3;
-      dwi[j] = o >> 2;
-      sel[j] = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16);
-      coef[j] = reinterpret_cast<const uint32_t*>(xab)[D.xcoef + dx];  // a0 | a1 << 16
-    }
     for (int r = w; r < nrows; r += 4) {
       const uint32_t* row = st + r * srcDwMax;
       uint32_t t[4];
@@ -138,11 +149,12 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   {
     const int qx = tid & 63;
     const int dx = x0 + 4 * qx;
-    for (int dyl = __builtin_amdgcn_readfirstlane(tid >> 6); dyl < RS_DR; dyl += 4) {
-      const int dy = y0 + dyl;
+#pragma unroll
+    for (int k = 0; k < RS_DR / 4; k++) {
+      const int dy = y0 + w + 4 * k;
       if (dy >= D.h) break;
-      const int sy = yofs[D.ycoef + dy];
-      const uint32_t bb = reinterpret_cast<const uint32_t*>(yab)[D.ycoef + dy];
+      const int sy = vsy[k];
+      const uint32_t bb = vbb[k];
       const int b0 = (int)(bb & 0xFFFF), b1 = (int)(bb >> 16);
       const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
       if (dx >= D.w) continue;
