@@ -348,7 +348,13 @@ __device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
 // The NMS needs no threshold masking: a neighbour that is not a corner at t has score < t <= the centre's.
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
-template <bool TAP>  // TAP: the test tap of orbx_debug_score_map, a separate instantiation (its registers cost the product kernel 3.5 %)
+// TAP: the test tap of orbx_debug_score_map, a separate instantiation (its registers cost the product kernel 3.5 %).
+// TPC: compile-time LDS pitch of the image tile (the score tile's is TPC - 4), 0 = run-time pitches.  With a constant
+// pitch the 16 ring offsets of the contrast pass and the 8 NMS neighbours fold into the ds_read immediate offsets instead
+// of costing one v_add each (34 of the 147 VALU instructions of a contrast pass).  The pitch must stay the tight one of
+// the geometry: padding it to 64 made the kernel 6 % SLOWER (378 vs 356 us) -- 0.8 KB more LDS per cell costs more
+// occupancy than 5 % fewer instructions buy.  Instantiated for the pitches of the usual cell widths (33..52 px).
+template <bool TAP, int TPC>
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
                                                int* __restrict__ cellCount, int listCap, int cellBegin, int xcdRun,
                                                uint8_t* __restrict__ dbgScore) {
@@ -387,7 +393,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     return;
   }
 
-  const int TPd = g.tileP >> 2, SPd = g.scoreP >> 2;  // pitches in dwords
+  const int TP = TPC ? TPC : g.tileP, SPB = TPC ? TPC - 4 : g.scoreP;  // tile pitches in bytes
+  const int TPd = TP >> 2, SPd = SPB >> 2;                          // and in dwords
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
   uint32_t* score = tile + TPd * g.tileH;
   uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
@@ -456,12 +463,12 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         const int eA = base + lane, eB = base + 64 + lane;
         const int yxA = slist[min(eA, nSurv - 1)], yxB = slist[min(eB, nSurv - 1)];
         const int yA = yxA >> 8, xA = yxA & 255, yB = yxB >> 8, xB = yxB & 255;
-        const orbx_h2 M = fast_contrast2_lds(tile8 + (yA + 3) * g.tileP + xA + 3, tile8 + (yB + 3) * g.tileP + xB + 3,
-                                            g.tileP);
+        const orbx_h2 M = fast_contrast2_lds(tile8 + __mul24(yA + 3, TP) + xA + 3, tile8 + __mul24(yB + 3, TP) + xB + 3,
+                                            TP);
         const bool cornerA = eA < nSurv && M.x > th2.x, cornerB = eB < nSurv && M.y > th2.y;
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
-        if (cornerA) score8[(yA + 1) * g.scoreP + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
-        if (cornerB) score8[(yB + 1) * g.scoreP + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
+        if (cornerA) score8[__mul24(yA + 1, SPB) + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
+        if (cornerB) score8[__mul24(yB + 1, SPB) + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
         const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
         const int oA = nList + prefix_count(mA);
         const int oB = nList + __popcll(mA) + prefix_count(mB);
@@ -481,11 +488,11 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       const bool act = q < nq;
       const int qq = min(q, nq - 1);  // idle lanes of the last round redo the last quad (masked out below)
       const int yd = (int)(((float)qq + 0.5f) * inv_qpr);
-      const int j = qq - yd * qpr;
+      const int j = qq - __mul24(yd, qpr);
       uint32_t r[7][3];
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        const uint32_t* row = tile + (yd + i) * TPd + j;
+        const uint32_t* row = tile + __mul24(yd + i, TPd) + j;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
         r[i][0] = row[0];
         r[i][1] = row[1];
         r[i][2] = row[2];
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       sm[1] = compass_wave<1>(r, t) & __ballot(act && valid > 1);
       sm[2] = compass_wave<2>(r, t) & __ballot(act && valid > 2);
       sm[3] = compass_wave<3>(r, t) & __ballot(act && valid > 3);
-      if (act) score[(yd + 1) * SPd + j + 1] = 0;
+      if (act) score[__mul24(yd + 1, SPd) + j + 1] = 0;
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (nSurv + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > survCap) flush_survivors();
 #pragma unroll
@@ -514,16 +521,16 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       uint8_t* dm = dbgScore + (long long)img * g.pyrImg + L.off;
       for (int i = lane; i < dw * dh; i += 64) {
         const int y = i / dw, x = i - y * dw;
-        dm[(long long)(iniY + 3 + y) * L.pitch + iniX + 3 + x] = score8[(y + 1) * g.scoreP + x + 4];
+        dm[(long long)(iniY + 3 + y) * L.pitch + iniX + 3 + x] = score8[(y + 1) * SPB + x + 4];
       }
     }
     if (!overflowed) {
       // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each
-      const int SP = g.scoreP;
+      const int SP = SPB;
       for (int base = 0; base < nCorners; base += 64) {
         const int e = base + lane;
         const int yx = list[min(e, nCorners - 1)], y = yx >> 8, x = yx & 255;
-        const uint8_t* c8 = score8 + (y + 1) * SP + x + 4;
+        const uint8_t* c8 = score8 + __mul24(y + 1, SP) + x + 4;
         const int sc = c8[0];
         const bool keep = e < nCorners && sc > c8[-1] && sc > c8[1] && sc > c8[-SP - 1] && sc > c8[-SP] &&
                           sc > c8[-SP + 1] && sc > c8[SP - 1] && sc > c8[SP] && sc > c8[SP + 1];
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       }
       uint32_t keepmask = 0;
       if (sw) {
-        const int SP = g.scoreP;
+        const int SP = SPB;
         const uint8_t* q8 = score8 + (yd + 1) * SP + 4 * (j + 1);
 #pragma unroll
         for (int pI = 0; pI < 4; pI++) {
@@ -598,12 +605,19 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
   dim3 grid(cellEnd - cellBegin, nimg);
-  if (dbgScore)
-    hipLaunchKernelGGL(k_detect<true>, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
-                       kDetectXcdRun, dbgScore);
-  else
-    hipLaunchKernelGGL(k_detect<false>, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin,
-                       kDetectXcdRun, dbgScore);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin, kDetectXcdRun,
+                       dbgScore);
+  };
+  const int tp = (!dbgScore && g.scoreP == g.tileP - 4) ? g.tileP : 0;
+  switch (tp) {
+    case 48: go(k_detect<false, 48>); break;
+    case 52: go(k_detect<false, 52>); break;
+    case 56: go(k_detect<false, 56>); break;
+    case 60: go(k_detect<false, 60>); break;
+    default:
+      if (dbgScore) go(k_detect<true, 0>); else go(k_detect<false, 0>);
+  }
   return hipGetLastError();
 }
 
@@ -1927,11 +1941,14 @@ hipError_t prepare_kernels(const Geom& g) {
                             (int)std::max<size_t>(resize_lds_bytes(g), 1024));
     if (e != hipSuccess) return e;
   }
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_det);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_detect<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)lds_det);
+  const void* dk[6] = {reinterpret_cast<const void*>(k_detect<true, 0>),   reinterpret_cast<const void*>(k_detect<false, 0>),
+                       reinterpret_cast<const void*>(k_detect<false, 48>), reinterpret_cast<const void*>(k_detect<false, 52>),
+                       reinterpret_cast<const void*>(k_detect<false, 56>), reinterpret_cast<const void*>(k_detect<false, 60>)};
+  for (const void* f : dk) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_det);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // Test entry: both glibc sinf/cosf variants on the device (compared with the host libm in tests).
