@@ -146,7 +146,8 @@ class Workload:
         streams = [1000 * rank + i for i in range(D)]
         frames = list(range(R + self.K - 1))
         t0 = time.time()
-        gl, gr = synth.stereo_ring(W, H, streams, frames, workers=usable_cores())   # [F, D, H, W]
+        world = int(os.environ.get("WORLD_SIZE", "1"))  # the ranks of a node share its cores
+        gl, gr = synth.stereo_ring(W, H, streams, frames, workers=max(1, usable_cores() // max(1, world)))   # [F, D, H, W]
         self.gen_s = time.time() - t0
         self.streams = streams
         lefts, rights = [], []

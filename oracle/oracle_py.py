@@ -352,6 +352,18 @@ def kb8_triangulate(rig, uv1, uv2, sigma1=1.0, sigma2=1.0):
     return float(d), p, gate
 
 
+def kb8_triangulate_ex(rig, uv1, uv2, sigma1=1.0, sigma2=1.0, xh=None):
+    """kb8_triangulate with the 4x4 system returned and, optionally, the null vector supplied (study hook)."""
+    rig = np.ascontiguousarray(rig, np.float32)
+    p, gate, A = np.zeros(3, np.float32), np.zeros(5, np.float32), np.zeros(16, np.float32)
+    x = None if xh is None else np.ascontiguousarray(xh, np.float32)
+    lib().oro_kb8_triangulate_ex.restype = C.c_float
+    lib().oro_kb8_triangulate_ex.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p] * 4
+    d = lib().oro_kb8_triangulate_ex(_p(rig), float(uv1[0]), float(uv1[1]), float(uv2[0]), float(uv2[1]), sigma1, sigma2,
+                                     None if x is None else _p(x), _p(A), _p(p), _p(gate))
+    return float(d), p, gate, A.reshape(4, 4)
+
+
 def fisheye_stereo_match(kL, dL, monoL, kR, dR, monoR, rig, level_sigma2):
     """-> nMatches, descMatches, leftToRight, rightToLeft, depth, p3D [nL,3], gates [nL,6]."""
     kL, kR = np.ascontiguousarray(kL), np.ascontiguousarray(kR)

@@ -1134,7 +1134,8 @@ void smallest_right_singular_vector(const float A[16], float v[4]) {
 }
 
 float kb8_triangulate_matches(const KB8& c1, const KB8& c2, float u1, float v1, float u2, float v2, const float R12[9],
-                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate) {
+                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate,
+                              const float* xh_override, float* A_out) {
   if (gate)
     for (int i = 0; i < 5; i++) gate[i] = NAN;
   float r1[3], r2[3], r21[3];
@@ -1161,7 +1162,9 @@ float kb8_triangulate_matches(const KB8& c1, const KB8& c2, float u1, float v1, 
     A[12 + j] = r2[1] * T2[2][j] - T2[1][j];
   }
   float xh[4];
-  smallest_right_singular_vector(A, xh);
+  if (A_out) std::memcpy(A_out, A, sizeof(A));
+  if (xh_override) std::memcpy(xh, xh_override, sizeof(xh));  // study hook: null vector from another SVD (tools/svd_gate_study.py)
+  else smallest_right_singular_vector(A, xh);
   const float x3D[3] = {xh[0] / xh[3], xh[1] / xh[3], xh[2] / xh[3]};
   const float z1 = x3D[2];
   if (gate) gate[1] = z1;

@@ -125,7 +125,8 @@ void smallest_right_singular_vector(const float A[16], float v[4]);
 // be null) receives the gated quantities {cosParallax, z1, z2, err1/(5.991 sigma1), err2/(5.991 sigma2)} so that a
 // tolerance test can tell borderline decisions from wrong ones.
 float kb8_triangulate_matches(const KB8& c1, const KB8& c2, float u1, float v1, float u2, float v2, const float R12[9],
-                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate);
+                              const float t12[3], float sigmaLevel, float unc, float p3D[3], float* gate,
+                              const float* xh_override = nullptr, float* A_out = nullptr);
 // Frame::ComputeStereoFishEyeMatches (src/Frame.cc:1273-1331): BF 2-NN on the lapping-area rows [mono, n) of both
 // eyes, Lowe 0.7, triangulation gates; serial order (a right keypoint claimed twice keeps the later left index).
 // Outputs sized nL / nR / nL / 3 nL; returns nMatches, *descMatches = pairs that passed the ratio test.

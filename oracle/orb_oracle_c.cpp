@@ -288,6 +288,13 @@ float oro_kb8_triangulate(const float* rig, float u1, float v1, float u2, float 
   return kb8_triangulate_matches(kb8_from(rig, rig[16]), kb8_from(rig + 8, rig[16]), u1, v1, u2, v2, rig + 17, rig + 26,
                                  sigma1, sigma2, p3D, gate);
 }
+// Study hook (tools/svd_gate_study.py): the same routine with the 4x4 system returned (A_out, may be null) and / or the
+// null vector supplied by the caller (xh, may be null) instead of the oracle's double-precision Jacobi.
+float oro_kb8_triangulate_ex(const float* rig, float u1, float v1, float u2, float v2, float sigma1, float sigma2,
+                             const float* xh, float* A_out, float* p3D, float* gate) {
+  return kb8_triangulate_matches(kb8_from(rig, rig[16]), kb8_from(rig + 8, rig[16]), u1, v1, u2, v2, rig + 17, rig + 26,
+                                 sigma1, sigma2, p3D, gate, xh, A_out);
+}
 int oro_fisheye_stereo_match(const KeyPoint* kL, const uint8_t* dL, int nL, int monoL, const KeyPoint* kR, const uint8_t* dR,
                              int nR, int monoR, const float* rig, const float* levelSigma2, int nLevels, int* leftToRight,
                              int* rightToLeft, float* depth, float* p3D, int* descMatches, float* gates /* nL x 6 or null */) {
