@@ -789,8 +789,9 @@ __host__ __device__ inline OctLds oct_layout(int maxn, int maxcells, int rep) {
     o.ny1[b] = take(maxn * 2);
     o.ncnt[b] = take(maxn * 4);
   }
-  o.cnt4 = take(maxn * 16);
-  o.cntr = take(maxn * 16 * rep);  // quadrant counters, `rep` replicas each (see OctCtx::cntr)
+  // (the floors are the histogram variant's tables for <= 2 roots: code -> node map in cnt4, histogram + leaf table in cntr)
+  o.cnt4 = take(maxn * 16 > 4096 ? maxn * 16 : 4096);
+  o.cntr = take(maxn * 16 * rep > 16400 ? maxn * 16 * rep : 16400);  // quadrant counters, `rep` replicas each (see OctCtx::cntr)
   o.cpos = take(maxn * 8);
   o.scan = take(maxn * 8);  // u64 scan values; reused as best[] at the end
   o.e[0] = take(maxn * 8);
@@ -1340,6 +1341,383 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
 #undef MK
 }
 
+// ---- quadtree from a path-code histogram ---------------------------------------------------------------------------
+// The child a candidate falls into depends only on the node's rectangle (DivideNode :494-495 halves it with ceil), never
+// on the other candidates, so every candidate's quadrant sequence down to depth OCT_HD can be computed in ONE sweep
+// (registers only) and the number of candidates in ANY node of depth <= OCT_HD is a prefix count: a histogram of the
+// depth-OCT_HD path codes plus its 4-ary sums.  All of DistributeOctTree then runs on the node lists alone (<= N + 3
+// nodes: the same list layout, phase-1 / phase-2 rules and std::sort replica as octree_body), and the candidates are
+// touched twice more at the end (winner per node, output) -- 3 candidate sweeps instead of ~26 with 12 rounds of LDS
+// atomics.  A node of depth OCT_HD that must be split (dense clusters) makes the block fall back to octree_body, which
+// gives the same result.  LDS: the histogram, the leaf table and the code -> node map reuse octree_body's counter areas.
+constexpr int OCT_HD = 5;
+__host__ __device__ inline int oct_hbase(int nIni, int d) { return nIni * (((1 << (2 * d)) - 1) / 3); }  // entries above depth d
+__host__ __device__ inline bool oct_hist_fits(int nIni) {  // oct_layout reserves the tables of up to 2 roots
+  return nIni <= 2 && oct_hbase(nIni, OCT_HD + 1) * 6 <= 16400 && nIni * (1 << (2 * OCT_HD)) * 2 <= 4096;
+}
+
+// returns false when a node deeper than the table had to be split (caller falls back to octree_body)
+__device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& L, const OctCtx& c, int n, int cells,
+                                                 const uint32_t* __restrict__ sparse, uint32_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ out, int* __restrict__ outCount) {
+  const int tid = threadIdx.x;
+  OctCands<true> cd;
+  cd.keys = keys;
+  cd.kn = nullptr;
+  cd.n = n;
+  cd.fill([&](int k) {
+    int lo = 0, hi = cells;  // largest cell with cellpre[cell] <= k
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (c.cellpre[mid] <= k) lo = mid; else hi = mid;
+    }
+    return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
+  });
+  const int N = L.quota;
+  struct Buf {
+    char* base;
+    int stride;
+    __device__ __forceinline__ int16_t* operator[](int b) const { return reinterpret_cast<int16_t*>(base + b * stride); }
+  };
+  struct BufU {
+    char* base;
+    int stride;
+    __device__ __forceinline__ uint32_t* operator[](int b) const { return reinterpret_cast<uint32_t*>(base + b * stride); }
+  };
+  const Buf nx0{(char*)c.nx0, c.nodeStride}, nx1{(char*)c.nx1, c.nodeStride}, ny0{(char*)c.ny0, c.nodeStride},
+      ny1{(char*)c.ny1, c.nodeStride};
+  const BufU ncnt{(char*)c.ncnt, c.nodeStride};
+  const int W = L.w - 2 * kBorder, H = L.h - 2 * kBorder;
+  const int nIni = (int)roundf((float)W / (float)H);  // :566
+  const float hX = (float)W / (float)nIni;             // :568
+  uint32_t* hist = c.cntr;                                                   // [oct_hbase(nIni, OCT_HD + 1)] counts by (depth, code)
+  uint16_t* leafAt = reinterpret_cast<uint16_t*>(hist + oct_hbase(nIni, OCT_HD + 1));  // same shape: final node index or 0xFFFF
+  uint16_t* t5 = reinterpret_cast<uint16_t*>(c.cnt4);                        // depth-OCT_HD code -> final node index
+  uint16_t* ndcBuf = c.cpos;                                                 // [2][maxn]: depth << 13 | code of every node
+  auto ndc = [&](int b) { return ndcBuf + b * c.maxn; };
+  uint64_t* scan = c.scan;
+  uint16_t* mark = c.mark;
+  uint64_t* tsum = c.tsum;
+  int* s_i = c.s_i;
+  const int nH = oct_hbase(nIni, OCT_HD + 1);
+  for (int i = tid; i < nH; i += OCT_NT) hist[i] = 0;
+  if (tid == 0) s_i[3] = 0;  // fallback flag
+  __syncthreads();
+  // ---- sweep 1: path code of every candidate, histogram at depth OCT_HD
+  {
+    uint32_t* h5 = hist + oct_hbase(nIni, OCT_HD);
+    cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+      const int x = key_x(key), y = key_y(key);
+      const int r = (int)((float)x / hX);
+      int x0 = (int)(hX * (float)r), x1 = (int)(hX * (float)(r + 1)), y0 = 0, y1 = H;
+      uint32_t code = (uint32_t)r;
+#pragma unroll
+      for (int d = 0; d < OCT_HD; d++) {
+        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
+        const int qx = x >= mx, qy = y >= my;
+        x0 = qx ? mx : x0;
+        x1 = qx ? x1 : mx;
+        y0 = qy ? my : y0;
+        y1 = qy ? y1 : my;
+        code = code * 4 + (uint32_t)(qx | (qy << 1));
+      }
+      nd = code;
+      atomicAdd(&h5[code], 1u);
+    });
+  }
+  __syncthreads();
+  for (int d = OCT_HD - 1; d >= 0; d--) {  // 4-ary sums
+    const uint32_t* ch = hist + oct_hbase(nIni, d + 1);
+    uint32_t* pa = hist + oct_hbase(nIni, d);
+    for (int i = tid; i < (nIni << (2 * d)); i += OCT_NT) pa[i] = ch[4 * i] + ch[4 * i + 1] + ch[4 * i + 2] + ch[4 * i + 3];
+    __syncthreads();
+  }
+  auto child_count = [&](uint32_t dc, int q) {  // candidates in child q of node (depth, code); depth < OCT_HD
+    const int d = (int)(dc >> 13);
+    return hist[oct_hbase(nIni, d + 1) + (int)(dc & 0x1FFF) * 4 + q];
+  };
+  // ---- roots (:575-601)
+  if (tid == 0) {
+    int na = 0;
+    for (int i = 0; i < nIni; i++) {
+      if (hist[i] == 0) continue;
+      nx0[0][na] = (int16_t)(int)(hX * (float)i);
+      nx1[0][na] = (int16_t)(int)(hX * (float)(i + 1));
+      ny0[0][na] = 0;
+      ny1[0][na] = (int16_t)H;
+      ncnt[0][na] = hist[i];
+      ndc(0)[na] = (uint16_t)i;
+      na++;
+    }
+    s_i[0] = na;
+  }
+  __syncthreads();
+  int nA = s_i[0];
+  int cur = 0;
+  bool finish = false;
+  int nE = 0, ecur = 0;
+  // ---- phase 1: split every expandable node per pass (:610-677)
+  while (!finish) {
+    const int prevSize = nA;
+    for (int i = tid; i < nA; i += OCT_NT) {
+      uint64_t cc = 0, nm = 1, ce = 0;
+      if (ncnt[cur][i] > 1) {
+        nm = 0;
+        const uint32_t dc = ndc(cur)[i];
+        if ((dc >> 13) >= (uint32_t)OCT_HD) {
+          s_i[3] = 1;
+        } else {
+          for (int q = 0; q < 4; q++) {
+            const uint32_t cq = child_count(dc, q);
+            cc += cq > 0;
+            ce += cq > 1;
+          }
+        }
+      }
+      scan[i] = cc | (nm << 21) | (ce << 42);
+    }
+    __syncthreads();
+    if (s_i[3]) return false;
+    const uint64_t tot = block_scan_u64(scan, nA, tsum);
+    const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
+    const int nxt = cur ^ 1;
+    for (int i = tid; i < nA; i += OCT_NT) {
+      const uint64_t pre = scan[i];
+      const int pc = (int)(pre & 0x1FFFFF), pnm = (int)((pre >> 21) & 0x1FFFFF), pce = (int)(pre >> 42);
+      if (ncnt[cur][i] > 1) {
+        const uint32_t dc = ndc(cur)[i];
+        const uint32_t cdc = (((dc >> 13) + 1) << 13) | ((dc & 0x1FFF) * 4);
+        const int x0 = nx0[cur][i], x1 = nx1[cur][i], y0 = ny0[cur][i], y1 = ny1[cur][i];
+        const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+        uint32_t cq4[4];
+        int cc = 0;
+        for (int q = 0; q < 4; q++) {
+          cq4[q] = child_count(dc, q);
+          cc += cq4[q] > 0;
+        }
+        const int base = tc - (pc + cc);
+        int after = 0, eb = pce;
+        for (int q = 0; q < 4; q++) {  // E entries in creation order n1..n4
+          if (cq4[q] > 1) {
+            int rank_after = 0;
+            for (int q2 = q + 1; q2 < 4; q2++) rank_after += cq4[q2] > 0;
+            const int cx0 = (q & 1) ? x0 + hx : x0;
+            (c.ebuf + ecur * c.maxn)[eb++] = ((uint64_t)cq4[q] << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+          }
+        }
+        for (int q = 3; q >= 0; q--) {  // list order n4,n3,n2,n1
+          if (cq4[q] == 0) continue;
+          const int pos = base + after++;
+          nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
+          nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
+          ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
+          ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
+          ncnt[nxt][pos] = cq4[q];
+          ndc(nxt)[pos] = (uint16_t)(cdc + q);
+        }
+      } else {
+        const int pos = tc + pnm;
+        nx0[nxt][pos] = nx0[cur][i];
+        nx1[nxt][pos] = nx1[cur][i];
+        ny0[nxt][pos] = ny0[cur][i];
+        ny1[nxt][pos] = ny1[cur][i];
+        ncnt[nxt][pos] = ncnt[cur][i];
+        ndc(nxt)[pos] = ndc(cur)[i];
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+    nA = tc + tnm;
+    nE = tce;
+    if (nA >= N || nA == prevSize) {
+      finish = true;
+    } else if (nA + 3 * nE > N) {
+      break;  // -> phase 2
+    }
+  }
+  // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
+  while (!finish) {
+    const int prevSize = nA;
+    uint64_t* E = c.ebuf + ecur * c.maxn;
+    uint64_t* E2 = c.ebuf + (ecur ^ 1) * c.maxn;
+    if (tid < 64)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
+      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
+                     reinterpret_cast<int*>(tsum), tid);
+    if (tid == 0) {
+      s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
+      s_i[2] = 0;   // broke
+    }
+    for (int i = tid; i < nA; i += OCT_NT) mark[i] = 0;
+    __syncthreads();
+    // scan over the processing order m (largest first): c (children), ce (expandable children)
+    for (int m = tid; m < nE; m += OCT_NT) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      mark[nd] = (uint16_t)(m + 1);
+      const uint32_t dc = ndc(cur)[nd];
+      uint64_t cc = 0, ce = 0;
+      if ((dc >> 13) >= (uint32_t)OCT_HD) {
+        s_i[3] = 1;
+      } else {
+        for (int q = 0; q < 4; q++) {
+          const uint32_t cq = child_count(dc, q);
+          cc += cq > 0;
+          ce += cq > 1;
+        }
+      }
+      scan[m] = cc | (ce << 21);
+    }
+    __syncthreads();
+    if (s_i[3]) return false;
+    block_scan_u64(scan, nE, tsum);
+    // first m at which the list reaches N nodes: size after m+1 expansions = nA + C_incl(m) - (m+1)
+    for (int m = tid; m < nE; m += OCT_NT) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      const uint32_t dc = ndc(cur)[nd];
+      int cc = 0;
+      for (int q = 0; q < 4; q++) cc += child_count(dc, q) > 0;
+      const int cincl = (int)(scan[m] & 0x1FFFFF) + cc;
+      if (nA + cincl - (m + 1) >= N) {
+        atomicMin(&s_i[1], m + 1);
+        s_i[2] = 1;
+      }
+    }
+    __syncthreads();
+    const int nP = s_i[1];  // nodes m < nP are expanded
+    const bool broke = s_i[2] != 0;
+    int tc, tce;
+    if (nP < nE) {
+      tc = (int)(scan[nP] & 0x1FFFFF);
+      tce = (int)(scan[nP] >> 21);
+    } else {
+      int cc = 0, ce = 0;
+      if (nE) {
+        const uint32_t dc = ndc(cur)[(int)(E[0] & 0xFFFF)];  // m = nE-1
+        for (int q = 0; q < 4; q++) {
+          const uint32_t cq = child_count(dc, q);
+          cc += cq > 0;
+          ce += cq > 1;
+        }
+      }
+      tc = nE ? (int)(scan[nE - 1] & 0x1FFFFF) + cc : 0;
+      tce = nE ? (int)(scan[nE - 1] >> 21) + ce : 0;
+    }
+    const int nxt = cur ^ 1;
+    // children of processed nodes: later processed first, each group n4..n1
+    for (int m = tid; m < nP; m += OCT_NT) {
+      const int nd = (int)(E[nE - 1 - m] & 0xFFFF);
+      const uint32_t dc = ndc(cur)[nd];
+      const uint32_t cdc = (((dc >> 13) + 1) << 13) | ((dc & 0x1FFF) * 4);
+      const int x0 = nx0[cur][nd], x1 = nx1[cur][nd], y0 = ny0[cur][nd], y1 = ny1[cur][nd];
+      const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+      uint32_t cq4[4];
+      int cc = 0;
+      for (int q = 0; q < 4; q++) {
+        cq4[q] = child_count(dc, q);
+        cc += cq4[q] > 0;
+      }
+      const int pc = (int)(scan[m] & 0x1FFFFF);
+      int eb = (int)(scan[m] >> 21);
+      const int base = tc - (pc + cc);
+      for (int q = 0; q < 4; q++) {
+        if (cq4[q] > 1) {
+          int rank_after = 0;
+          for (int q2 = q + 1; q2 < 4; q2++) rank_after += cq4[q2] > 0;
+          const int cx0 = (q & 1) ? x0 + hx : x0;
+          E2[eb++] = ((uint64_t)cq4[q] << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+        }
+      }
+      int after = 0;
+      for (int q = 3; q >= 0; q--) {
+        if (cq4[q] == 0) continue;
+        const int pos = base + after++;
+        nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
+        nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
+        ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
+        ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
+        ncnt[nxt][pos] = cq4[q];
+        ndc(nxt)[pos] = (uint16_t)(cdc + q);
+      }
+    }
+    __syncthreads();
+    // untouched nodes keep their relative order behind the new children
+    for (int i = tid; i < nA; i += OCT_NT) scan[i] = (mark[i] == 0 || mark[i] > nP) ? 1 : 0;
+    __syncthreads();
+    const int nKeep = (int)block_scan_u64(scan, nA, tsum);
+    for (int i = tid; i < nA; i += OCT_NT) {
+      if (mark[i] == 0 || mark[i] > nP) {
+        const int pos = tc + (int)scan[i];
+        nx0[nxt][pos] = nx0[cur][i];
+        nx1[nxt][pos] = nx1[cur][i];
+        ny0[nxt][pos] = ny0[cur][i];
+        ny1[nxt][pos] = ny1[cur][i];
+        ncnt[nxt][pos] = ncnt[cur][i];
+        ndc(nxt)[pos] = ndc(cur)[i];
+      }
+    }
+    __syncthreads();
+    cur = nxt;
+    nA = tc + nKeep;
+    nE = tce;
+    ecur ^= 1;
+    if (broke || nA == prevSize) finish = true;
+  }
+  // ---- candidate -> final node: every final node marks its (depth, code); a depth-OCT_HD code belongs to its deepest
+  // marked ancestor
+  for (int i = tid; i < nH; i += OCT_NT) leafAt[i] = 0xFFFF;
+  __syncthreads();
+  for (int i = tid; i < nA; i += OCT_NT) {
+    const uint32_t dc = ndc(cur)[i];
+    leafAt[oct_hbase(nIni, (int)(dc >> 13)) + (int)(dc & 0x1FFF)] = (uint16_t)i;
+  }
+  __syncthreads();
+  for (int c5 = tid; c5 < (nIni << (2 * OCT_HD)); c5 += OCT_NT) {
+    uint16_t v = 0xFFFF;
+#pragma unroll
+    for (int d = OCT_HD; d >= 0; d--) {
+      const uint16_t w = leafAt[oct_hbase(nIni, d) + (c5 >> (2 * (OCT_HD - d)))];
+      v = v == 0xFFFF ? w : v;
+    }
+    t5[c5] = v;
+  }
+  __syncthreads();
+  // ---- best response per node, first candidate (reference order) wins ties (:741-754), as in octree_body
+  uint64_t* best = scan;
+  uint64_t* bestr = reinterpret_cast<uint64_t*>(c.cntr);  // [node][nrepB]; overwrites the histogram (no longer needed)
+  const int nrepB = c.nrep >= 2 ? c.nrep * 2 : 1, repB = tid & (nrepB - 1);
+  if (nrepB > 1)
+    for (int i = tid; i < nA * nrepB; i += OCT_NT) bestr[i] = 0;
+  else
+    for (int i = tid; i < nA; i += OCT_NT) best[i] = 0;
+  __syncthreads();
+  const float invH = 1.0f / (float)L.hCell, invW = 1.0f / (float)L.wCell;
+  auto rank_key = [&](uint32_t key) {
+    const int xr = key_x(key) - 3, yr = key_y(key) - 3;  // relative to the first detectable pixel (19,19)
+    const int cy = (int)(((float)yr + 0.5f) * invH), cx = (int)(((float)xr + 0.5f) * invW);
+    const uint32_t rank = (uint32_t)(((cy * L.nCols + cx) * L.hCell + (yr - cy * L.hCell)) * L.wCell + (xr - cx * L.wCell));
+    return ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank);
+  };
+  cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+    nd = t5[nd];  // from here on the per-candidate id is the final node index
+    if (nrepB > 1) atomicMax((unsigned long long*)&bestr[nd * nrepB + repB], rank_key(key));
+    else atomicMax((unsigned long long*)&best[nd], rank_key(key));
+  });
+  __syncthreads();
+  if (nrepB > 1) {
+    for (int i = tid; i < nA; i += OCT_NT) {
+      uint64_t v = 0;
+      for (int r = 0; r < nrepB; r++) v = bestr[i * nrepB + r] > v ? bestr[i * nrepB + r] : v;
+      best[i] = v;
+    }
+    __syncthreads();
+  }
+  const int nOut = min(nA, L.selCap);
+  cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+    if ((int)nd < nOut && best[nd] == rank_key(key)) out[nd] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
+  });
+  if (tid == 0) *outCount = nOut;
+  return true;
+}
+
 __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __restrict__ cellCand,
                                                 const int* __restrict__ cellCount, int* __restrict__ cellPrefix,
                                                 uint32_t* __restrict__ cand, int* __restrict__ candCount,
@@ -1422,14 +1800,24 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   uint16_t* kn = knode + (long long)img * g.candImg + L.candOff;
   uint32_t* out = sel + (long long)img * g.selImg + L.selOff;
   int* outCount = selCount + img * g.nlevels + l;
-  if (n <= OCT_KMAX * OCT_NT && !forceGlobal)
-    octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
-  else
+  // forceGlobal (test hook): 0 = product path, 1 = global-memory candidates (octree_body<false>), 2 = register-resident
+  // per-pass sweeps (octree_body<true>, the fallback of the histogram variant)
+  if (n <= OCT_KMAX * OCT_NT && forceGlobal != 1) {
+    const int W = L.w - 2 * kBorder, H = L.h - 2 * kBorder;
+    const int nIni = (int)roundf((float)W / (float)H);
+    bool done = false;
+    if (forceGlobal == 0 && oct_hist_fits(nIni)) {
+      done = octree_hist_body(g, L, c, n, cells, sparse, keys, out, outCount);
+      __syncthreads();
+    }
+    if (!done) octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
+  } else {
     octree_body<false>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
+  }
 }
 
 static int g_octree_force_global_host = 0;
-void debug_set_octree_global(int on) { g_octree_force_global_host = on ? 1 : 0; }
+void debug_set_octree_global(int on) { g_octree_force_global_host = on < 0 ? 0 : (on > 2 ? 2 : on); }
 
 hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,
                          uint32_t* cand, int* candCount, uint16_t* knode, uint32_t* sel, int* selCount, int level0,

@@ -106,11 +106,45 @@ def test_octree_global_candidate_path(gpu, oracle):
     img = synth.mono_frame(w, h, 78)
     omono, ok_, od = oe.extract(img)
     try:
-        for forced in (1, 0):
+        for forced in (1, 2, 0):   # global-memory candidates, register-resident per-pass sweeps, path-code histogram
             orbx.lib().orbx_debug_set_octree_global(forced)
             mono, k, d = ex(img)
             assert ex.level_stats()[2][0] <= 16384
             assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
+    finally:
+        orbx.lib().orbx_debug_set_octree_global(0)
+
+
+def test_octree_histogram_variant_and_its_fallback(gpu, oracle):
+    """k_octree's product path derives the whole quadtree from a histogram of depth-5 path codes; a node of depth 5 that
+    still has to be split (dense clusters, few features wanted elsewhere) makes the block fall back to the per-pass
+    sweeps.  Scenes that stay shallow, scenes that force the fallback, tiny quotas, one-root (square) and two-root levels:
+    all three variants must give the oracle's keypoints in the oracle's order."""
+    rng = np.random.default_rng(5)
+    scenes = []
+    flat = np.full((480, 640), 120, np.uint8)
+    a = flat.copy()
+    a[200:260, 300:380] = rng.integers(0, 256, (60, 80), dtype=np.uint8)       # one dense cluster: deep subdivision
+    scenes.append(("cluster", a, 1000))
+    b = flat.copy()
+    for _ in range(40):                                                          # many small clusters
+        y, x = int(rng.integers(30, 440)), int(rng.integers(30, 600))
+        b[y:y + 12, x:x + 12] = rng.integers(0, 256, (12, 12), dtype=np.uint8)
+    scenes.append(("clusters", b, 1500))
+    scenes.append(("textured", synth.mono_frame(640, 480, 91), 1000))
+    scenes.append(("few", synth.mono_frame(640, 480, 92), 60))                 # tiny quotas (LDS floors of the tables)
+    scenes.append(("square", synth.mono_frame(512, 512, 93), 1500))            # one root
+    scenes.append(("many", synth.mono_frame(752, 480, 94), 5000))              # mono-init extractor (5 x nFeatures)
+    try:
+        for name, img, nf in scenes:
+            h, w = img.shape
+            oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+            omono, ok_, od = oe.extract(img)
+            ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+            for forced in (0, 2, 1):
+                orbx.lib().orbx_debug_set_octree_global(forced)
+                mono, k, d = ex(img)
+                assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od), (name, forced)
     finally:
         orbx.lib().orbx_debug_set_octree_global(0)
 

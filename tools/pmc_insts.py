@@ -10,17 +10,23 @@ import sqlite3
 import sys
 
 
+def _kname(k):
+    """'void orbx::k_detect<false, 52>(orbx::Geom, ...)' -> 'k_detect'"""
+    import re
+    return re.sub(r"<.*$", "", re.sub(r"^void\s+", "", k).split("(")[0].replace("orbx::", ""))
+
+
 def main(db, pat="", out=None):
     c = sqlite3.connect(db)
     rows = c.execute("select kernel_name, counter_name, avg(value) from counters_collection where kernel_name like ? "
                      "group by 1, 2", ("%" + pat + "%",)).fetchall()
     by = {}
     for k, n, v in rows:
-        by.setdefault(k.split("(")[0].replace("orbx::", ""), {})[n] = v
+        by.setdefault(_kname(k), {})[n] = v
     if out:
         n = dict(c.execute("select kernel_name, count(*) from counters_collection where kernel_name like ? and counter_name = "
                            "'SQ_INSTS_VALU' group by 1", ("%" + pat + "%",)).fetchall())
-        n = {k.split("(")[0].replace("orbx::", ""): v for k, v in n.items()}
+        n = {_kname(k): v for k, v in n.items()}
         base = min(n.values()) if n else 1
         res = {k: dict({c_: round(v, 1) for c_, v in d.items()}, launches_per_batch=max(1, round(n.get(k, base) / base)))
                for k, d in by.items()}

@@ -11,11 +11,17 @@ import sqlite3
 import sys
 
 
+def _kname(k):
+    """'void orbx::k_detect<false, 52>(orbx::Geom, ...)' -> 'k_detect'"""
+    import re
+    return re.sub(r"<.*$", "", re.sub(r"^void\s+", "", k).split("(")[0].replace("orbx::", ""))
+
+
 def per_kernel(db, counter):
     c = sqlite3.connect(db)
     rows = c.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? "
                      "group by kernel_name", (counter,)).fetchall()
-    return {r[0].split("(")[0].replace("orbx::", ""): (r[1], r[2]) for r in rows}
+    return {_kname(r[0]): (r[1], r[2]) for r in rows}
 
 
 def main(fdb, wdb, out, tag="r1"):
