@@ -1,6 +1,6 @@
 """Parity of EXACTLY the mode bench.py times: bench.Workload with its default arguments -- 32 distinct
-1280x720 stereo streams per batch, a ring of 3 frames, two extractor handles alternating, 7 steps enqueued back to back with
-no synchronisation in between, stereo association queued behind each batch -- and then EVERY image of BOTH handles' last
+1280x720 stereo streams per batch, a ring of 3 frames, three extractor handles rotating, 7 steps enqueued back to back with
+no synchronisation in between, stereo association queued behind each batch -- and then EVERY image of ALL handles' last
 batches (keypoints, descriptors, uRight, depth) against the CPU oracle, bit for bit.  Cross-handle ordering bugs (the
 k_detect token, the side stream's events, buffers reused while the other batch is in flight) would show here.
 The C5 flavour (8 streams x 4 consecutive frames, RCCL all-gather queued on the handles' streams, 1-rank RCCL) checks the
@@ -53,12 +53,12 @@ def _check_handles(wl, bench, steps):
 def test_default_bench_workload_matches_the_oracle():
     import bench
     a = bench.parse([])                              # bench.py's defaults: that IS the point
-    assert (a.pairs, a.distinct, a.handles, a.width, a.height, a.nfeatures, a.ring) == (32, 32, 2, 1280, 720, 1500, 3)
+    assert (a.pairs, a.distinct, a.handles, a.width, a.height, a.nfeatures, a.ring) == (32, 32, 3, 1280, 720, 1500, 3)
     wl = bench.Workload(a)
     assert len({s for s in wl.streams}) == 32
     # distinct inputs: no two pairs of a batch are the same image
     assert len({wl.host_left[0, p].tobytes()[:4096 * 64] for p in range(a.pairs)}) == a.pairs
-    assert _check_handles(wl, bench, 7) == 64        # both handles' last batches: steps 5 and 6 (ring slots 2 and 0)
+    assert _check_handles(wl, bench, 7) == 96        # every handle's last batch: steps 4, 5, 6 (ring slots 1, 2, 0)
 
 
 def test_c5_allgather_blocks_equal_the_downloads():
@@ -79,7 +79,7 @@ def test_c5_allgather_blocks_equal_the_downloads():
         wl = bench.Workload(a, 0, 0, dist)
         # consecutive frames of a stream sit side by side in the batch
         assert not np.array_equal(wl.host_left[0, 0], wl.host_left[0, 1]) and np.array_equal(wl.host_left[0, 1], wl.host_left[1, 0])
-        assert _check_handles(wl, bench, 5) == 64
+        assert _check_handles(wl, bench, 5) == 32 * len(wl.exs)
         torch.cuda.synchronize()
         for h, ex in enumerate(wl.exs):
             cnt, desc = wl.gathered[h]
