@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-bench (HIP events inside liborbx) without torch: B synthetic pairs, K steps.
-usage: python tools/kbench.py [pairs] [steps] [w] [h]   (env ORBX_* ablation switches are read by liborbx)"""
+usage: python tools/kbench.py [pairs] [steps] [w] [h]"""
 import os
 import sys
 import time
