@@ -10,7 +10,12 @@ implementations of the same published definitions:
   * the same call swept over t = 1..254 -- the FAST score of OpenCV's cornerScore<16> is the largest threshold at
     which the pixel is still a corner, so  score(p) = #{t : p is a corner at t}  (0 = never);
   * `corner_orientations(img, corners, OFAST_MASK)` -- atan2(m01, m10) over the 31x31 circular patch (749 px, the
-    same u_max table as ORBextractor.cc:456-468), the exact angle that cv::fastAtan2 approximates to 0.3 deg.
+    same u_max table as ORBextractor.cc:456-468), the exact angle that cv::fastAtan2 approximates to 0.3 deg;
+  * `skimage.feature.orb_cy._orb_loop(image, keypoints, orientations)` -- the steered-BRIEF sampling of skimage's own ORB:
+    256 tests  I(p + R(angle) a_j) < I(p + R(angle) b_j)  on its copy of the 31x31 pattern, row offset
+    round(sin x + cos y), column offset round(cos x - sin y) in double: an independent implementation of
+    computeOrbDescriptor (ORBextractor.cc:102-147) -- pattern pairing, rotation sense, comparison direction, bit order.
+    (Run on the raw frame: what is sampled does not matter for the sampling conventions.)
 
 Run in THIS container only (the GPU box has no skimage):   /opt/conda/bin/python3.9 tools/pin_skimage.py
 Writes tests/golden/fast9_skimage.npz (inputs + skimage's outputs, data only).  tests/test_pin_skimage.py checks the
@@ -25,6 +30,7 @@ import numpy as np
 warnings.filterwarnings("ignore")
 from skimage.feature import corner_fast, corner_orientations  # noqa: E402
 from skimage.feature.orb import OFAST_MASK  # noqa: E402
+from skimage.feature.orb_cy import _orb_loop  # noqa: E402
 import skimage  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -77,6 +83,18 @@ def main():
         pos, ang = orientations(im, corner_mask(im, 20), 1500, rng)
         out["ori_pos_" + name] = pos
         out["ori_rad_" + name] = ang
+        # descriptors at (up to) 600 of those corners that lie >= 20 px inside, for the angle the extractor would carry:
+        # float32 degrees in [0, 360) (the radians handed to skimage are that float32 value times pi / 180 in double),
+        # plus the exact quadrant angles on the first corners
+        h_, w_ = im.shape
+        ok = (pos[:, 0] >= 20) & (pos[:, 0] < h_ - 20) & (pos[:, 1] >= 20) & (pos[:, 1] < w_ - 20)
+        dpos = pos[ok][:600]
+        ddeg = np.float32(np.degrees(ang[ok][:600]) % 360.0)
+        ddeg[:8] = np.float32([0, 90, 180, 270, 45, 135, 225, 315])[:len(ddeg[:8])]
+        out["desc_pos_" + name] = dpos
+        out["desc_deg_" + name] = ddeg
+        out["desc_bits_" + name] = np.packbits(_orb_loop(im.astype(np.float64), dpos.astype(np.intp),
+                                                         np.deg2rad(ddeg.astype(np.float64))).astype(bool), axis=1, bitorder="little")
     # full FAST-score maps (threshold sweep) on small inputs: crops of the synthetic frames, noise, flat rectangles
     # (equal neighbouring scores), extremes 0 / 255
     crops = []
