@@ -83,3 +83,19 @@ def test_remap_matches_torch_grid_sample(oracle):
     inside = ok & (qx >= 0) & (qx <= w - 1) & (qy >= 0) & (qy <= h - 1)
     assert inside.mean() > 0.5
     assert np.abs(got - ref)[inside].max() <= 1.0 + 1e-9
+
+
+def test_gray_conversion_matches_pillow(oracle):
+    """cv::cvtColor(RGB2GRAY) (14-bit fixed point 4899 / 9617 / 1868, src/Tracking.cc:1394-1412) vs Pillow's ITU-R 601
+    conversion (16-bit fixed point 19595 / 38470 / 7471): the same luma weights to 4 decimals, so the two agree within one
+    grey level, and exactly on greys."""
+    from PIL import Image
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(rgb, "RGB").convert("L")).astype(np.int32)
+    got = oracle.cvt_gray(rgb, rgb=True).astype(np.int32)
+    assert np.abs(got - ref).max() <= 1 and (got != ref).mean() < 0.2
+    bgr = oracle.cvt_gray(rgb[:, :, ::-1].copy(), rgb=False).astype(np.int32)
+    assert np.array_equal(bgr, got)
+    grey = np.repeat(rng.integers(0, 256, (32, 32, 1), dtype=np.uint8), 3, axis=2)
+    assert np.array_equal(oracle.cvt_gray(grey, rgb=True), grey[:, :, 0])
