@@ -745,27 +745,89 @@ __device__ __forceinline__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp
   wsync();
 }
 
-// Test entry: sort n elements with the wave version (one block, dynamic LDS).
-__global__ __launch_bounds__(64) void k_debug_sort(uint64_t* v, int n) {
+// The same std::sort replica run by a WHOLE workgroup.  __introsort_loop is a binary tree of partitions: a segment
+// (first, last, depth) is partitioned, and both halves continue with depth - 1 -- nothing else is shared between them.
+// So the tree is walked breadth first: every wave takes segments of the current level (partition_wave on disjoint ranges
+// of `a`, stopper lists at the segment's own offset of Li / Ri), children longer than 16 go to the next level's list.
+// Identical result, log(n / 16) rounds instead of n / 16 sequential partitions (17 -> ~5 us for the ~130 expandable
+// nodes of a level-0 quadtree).  segs: 2 x 256 packed segments + 2 counters (u32).
+__device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tmp, uint16_t* Li, uint16_t* Ri, uint32_t* segs) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+  const KeyLess less;
+  if (n > 16) {  // (uniform)
+    uint32_t* cnt = segs + 512;
+    int lg = 0;
+    for (int t = n; t > 1; t >>= 1) lg++;
+    if (tid == 0) {
+      segs[0] = (uint32_t)n << 13 | (uint32_t)(2 * lg) << 26;  // first : 13 | last : 13 | depth : 6
+      cnt[0] = 1;
+      cnt[1] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (;;) {
+      const int ns = (int)cnt[cur];
+      if (ns == 0) break;
+      for (int k = wv; k < ns; k += nw) {
+        const uint32_t sg = segs[cur * 256 + k];
+        const int first = (int)(sg & 0x1FFF), last = (int)((sg >> 13) & 0x1FFF), depth = (int)(sg >> 26);
+        if (depth == 0) {
+          if (lane == 0) is_heapsort<uint64_t, KeyLess>(a, first, last, less);
+        } else {
+          const int cut = partition_wave(a, first, last, Li + first, Ri + first, lane);
+          if (lane == 0) {
+            const uint32_t d = (uint32_t)(depth - 1) << 26;
+            if (cut - first > 16) segs[(cur ^ 1) * 256 + atomicAdd(&cnt[cur ^ 1], 1u)] = (uint32_t)first | (uint32_t)cut << 13 | d;
+            if (last - cut > 16) segs[(cur ^ 1) * 256 + atomicAdd(&cnt[cur ^ 1], 1u)] = (uint32_t)cut | (uint32_t)last << 13 | d;
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) cnt[cur] = 0;
+      cur ^= 1;
+      __syncthreads();
+    }
+  }
+  // __final_insertion_sort == stable rank inside a +-16 window
+  for (int i = tid; i < n; i += nt) {
+    const uint64_t vi = a[i];
+    const int w0 = max(0, i - 16), w1 = min(n, i + 17);
+    int c = 0;
+    for (int j = w0; j < w1; j++) {
+      const uint64_t vj = a[j];
+      c += (less(vj, vi) || (!less(vi, vj) && j < i)) ? 1 : 0;
+    }
+    tmp[w0 + c] = vi;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) a[i] = tmp[i];
+  __syncthreads();
+}
+
+// Test entry: sort n elements (one block, dynamic LDS): 512 threads = the workgroup version the quadtree runs,
+// 64 threads = the single-wave version.
+__global__ __launch_bounds__(512) void k_debug_sort(uint64_t* v, int n) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint64_t* a = reinterpret_cast<uint64_t*>(smem);
   uint64_t* tmp = a + n;
-  uint16_t* Li = reinterpret_cast<uint16_t*>(tmp + n);
+  uint32_t* segs = reinterpret_cast<uint32_t*>(tmp + n);  // 514 u32, also the single-wave version's stack
+  uint16_t* Li = reinterpret_cast<uint16_t*>(segs + 516);
   uint16_t* Ri = Li + n + 4;
-  int* stk = reinterpret_cast<int*>(Ri + n + 4 + ((n & 1) ? 1 : 0) + 2);
-  const int lane = threadIdx.x;
-  for (int i = lane; i < n; i += 64) a[i] = v[i];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += blockDim.x) a[i] = v[i];
   __syncthreads();
-  introsort_wave(a, n, tmp, Li, Ri, stk, lane);
+  if (blockDim.x == 64) introsort_wave(a, n, tmp, Li, Ri, reinterpret_cast<int*>(segs), tid);
+  else introsort_block(a, n, tmp, Li, Ri, segs);
   __syncthreads();
-  for (int i = lane; i < n; i += 64) v[i] = a[i];
+  for (int i = tid; i < n; i += blockDim.x) v[i] = a[i];
 }
 hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s) {
-  const size_t lds = (size_t)n * 16 + (size_t)(2 * n + 16) * 2 + 3 * 64 * 4 + 64;
+  const size_t lds = (size_t)n * 16 + 516 * 4 + (size_t)(2 * n + 16) * 2 + 64;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_sort),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(64), lds, s, d_v, n);
+  static int flip = 0;  // alternate the two versions: the test calls this many times
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3((flip++ & 1) ? 64 : 512), lds, s, d_v, n);
   return hipGetLastError();
 }
 
@@ -1157,9 +1219,9 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
     const int prevSize = nA;
     uint64_t* E = c.ebuf + ecur * c.maxn;
     uint64_t* E2 = c.ebuf + (ecur ^ 1) * c.maxn;
-    if (tid < 64)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
-      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
-                     reinterpret_cast<int*>(tsum), tid);
+    // the whole workgroup sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (segment lists)
+    introsort_block(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
+                    reinterpret_cast<uint32_t*>(tsum));
     MK();
     if (tid == 0) {
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
@@ -1540,9 +1602,9 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     const int prevSize = nA;
     uint64_t* E = c.ebuf + ecur * c.maxn;
     uint64_t* E2 = c.ebuf + (ecur ^ 1) * c.maxn;
-    if (tid < 64)  // wave 0 sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (stack)
-      introsort_wave(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
-                     reinterpret_cast<int*>(tsum), tid);
+    // the whole workgroup sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (segment lists)
+    introsort_block(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
+                    reinterpret_cast<uint32_t*>(tsum));
     if (tid == 0) {
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
