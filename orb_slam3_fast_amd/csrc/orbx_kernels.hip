@@ -223,6 +223,7 @@ constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2,
 constexpr int kListCap = 640;    // upper bound of the test hook orbx_debug_set_detect_list_cap
 constexpr int kSurvCap = 448;    // LDS list of compass-test survivors of k_detect (flushed before it would overflow)
 constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
+constexpr int kLoadRows = 12;   // rows per lane the tile loader of k_detect keeps in flight
 constexpr int kCornerCap = 256;  // LDS corner list (a cell with more corners takes the tile-scan NMS)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
@@ -298,12 +299,17 @@ __device__ __forceinline__ orbx_h2 pk_min3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
 __device__ __forceinline__ orbx_h2 pk_max3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
   return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
+// a8 / b8 point at the TOP-LEFT corner of each pixel's 7x7 window, so every ring offset is a non-negative ds_read immediate.
+typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
   orbx_h2 r[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int off = kRingDY[k] * TP + kRingDX[k];
-    r[k] = __builtin_bit_cast(orbx_h2, (uint32_t)a8[off] | ((uint32_t)b8[off] << 16));  // one v_perm
+    const int off = (kRingDY[k] + 3) * TP + kRingDX[k] + 3;
+    orbx_us2 v;
+    v.x = a8[off];
+    v.y = b8[off];  // ds_read_u8_d16_hi: the pair is packed by the loads
+    r[k] = __builtin_bit_cast(orbx_h2, v);
   }
   orbx_h2 lo3[16], hi3[16];
 #pragma unroll
@@ -325,8 +331,16 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
   }
   maxmin = __builtin_elementwise_maximum(maxmin, lo9[15]);
   minmax = __builtin_elementwise_minimum(minmax, hi9[15]);
-  const orbx_h2 c = __builtin_bit_cast(orbx_h2, (uint32_t)a8[0] | ((uint32_t)b8[0] << 16));
+  orbx_us2 cv;
+  cv.x = a8[3 * TP + 3];
+  cv.y = b8[3 * TP + 3];
+  const orbx_h2 c = __builtin_bit_cast(orbx_h2, cv);
   return __builtin_elementwise_maximum(maxmin - c, c - minmax);
+}
+
+// wave mask of the lanes below n (n <= 0: none, n >= 64: all) -- scalar ALU only
+__device__ __forceinline__ uint64_t low_lanes(int n) {
+  return n >= 64 ? ~0ull : (n > 0 ? (1ull << n) - 1ull : 0ull);
 }
 
 // XCD-aware block -> tile mapping.  Workgroups go to the 8 XCDs round-robin by flat workgroup id, so neighbouring
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   const int TP = TPC ? TPC : g.tileP, SPB = TPC ? TPC - 4 : g.scoreP;  // tile pitches in bytes
   const int TPd = TP >> 2, SPd = SPB >> 2;                          // and in dwords
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* score = tile + TPd * g.tileH;
+  uint32_t* score = tile + ((TPd * g.tileH + 3) & ~3);  // 16-byte aligned: cleared with b128 stores
   uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
   uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kCornerCap corner positions (y << 8 | x)
   uint16_t* slist = list + kCornerCap;                                   // kSurvCap compass-test survivors
@@ -409,72 +423,92 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
-    // lane = (row phase, dword column): 16 columns x 4 rows per pass, no index divisions in the loop
+    // lane = (row phase, dword column): 16 columns x 4 rows per pass, no index divisions in the loop.  All of a lane's
+    // rows (kLoadRows per batch = 48 tile rows) are requested before the first one is consumed: one memory latency
+    // per cell instead of one per row pass.
     const int mis = iniX & 3, xa = iniX - mis;
     const int dpr = (rw + 3) >> 2;
     const int r0 = lane >> 4;
+    const uint8_t* rowBase = im + (long long)iniY * pitch + xa;  // wave-uniform: the loads take it as their scalar base
+    const uint32_t pitch4 = 4u * (uint32_t)pitch;
     for (int cc = lane & 15; cc < dpr; cc += 16) {  // one trip unless the cell is wider than 58 px (tiny levels)
       const int gx = xa + 4 * cc;
-      const bool wide = gx + 8 <= L.w;
-      const uint8_t* src = im + (long long)(iniY + r0) * pitch + gx;
-      uint32_t* dstw = tile + r0 * TPd + cc;
-      for (int r = r0; r < rh; r += 4, src += 4 * (long long)pitch, dstw += 4 * TPd) {
-        uint32_t lo, hi = 0;
-        if (wide) {
-          lo = reinterpret_cast<const uint32_t*>(src)[0];
-          hi = reinterpret_cast<const uint32_t*>(src)[1];
-        } else {
+      const uint8_t* src0 = rowBase + 4 * cc;
+      if (gx + 8 <= L.w) {
+        // rows past the ROI are clamped to its last row on both sides (load and store): the same bytes land on the
+        // same LDS dword again, and the loop body needs no predicate
+        const uint32_t offLast = (uint32_t)__mul24(rh - 1, pitch) + 4u * (uint32_t)cc;
+        const int idxLast = 4 * (__mul24(rh - 1, TPd) + cc);  // LDS byte offsets
+        for (int rb = r0; rb < rh; rb += 4 * kLoadRows) {
+          const uint32_t off0 = (uint32_t)__mul24(rb, pitch) + 4u * (uint32_t)cc;
+          const int idx0 = 4 * (__mul24(rb, TPd) + cc);
+          uint32_t lo[kLoadRows], hi[kLoadRows];
+#pragma unroll
+          for (int u = 0; u < kLoadRows; u++) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(rowBase + min(off0 + (uint32_t)u * pitch4, offLast));
+            lo[u] = src[0];
+            hi[u] = src[1];
+          }
+#pragma unroll
+          for (int u = 0; u < kLoadRows; u++)
+            *reinterpret_cast<uint32_t*>(smem + min(idx0 + u * 4 * TP, idxLast)) = __builtin_amdgcn_alignbyte(hi[u], lo[u], mis);
+        }
+      } else {  // last dword columns of the level: byte loads inside the image
+        for (int r = r0; r < rh; r += 4) {
+          const uint8_t* src = src0 + __mul24(r, pitch);
           uint64_t v = 0;
           for (int k = 0; k < 8; k++)
             if (gx + k < L.w) v |= (uint64_t)src[k] << (8 * k);
-          lo = (uint32_t)v;
-          hi = (uint32_t)(v >> 32);
+          tile[__mul24(r, TPd) + cc] = __builtin_amdgcn_alignbyte((uint32_t)(v >> 32), (uint32_t)v, mis);
         }
-        *dstw = __builtin_amdgcn_alignbyte(hi, lo, mis);
       }
     }
-    // zero ring of the score tile: rows 0 and dh+1, dword columns 0 and qpr+1
-    for (int idx = lane; idx < SPd; idx += 64) {
-      score[idx] = 0;
-      score[(dh + 1) * SPd + idx] = 0;
-    }
-    for (int idx = lane; idx < dh; idx += 64) {
-      score[(idx + 1) * SPd] = 0;
-      score[(idx + 1) * SPd + qpr + 1] = 0;
-    }
   }
-  __syncthreads();
-
   uint32_t* out = cellCand + (long long)img * g.cellImg + L.cellOff + (long long)cell * L.cellCap;
   int kept = 0;
+  // a round of 64 quads advances a lane by dq rows and rq quads (no division per round)
+  const int dq = __builtin_amdgcn_readfirstlane((int)(64.5f * inv_qpr)), rq = 64 - dq * qpr;
+  const int vlast = dw - 4 * (qpr - 1);  // pixels of a row's last quad inside the detectable window (1..4)
+  const int yd0 = (int)(((float)lane + 0.5f) * inv_qpr), j0 = lane - __mul24(yd0, qpr);
+  const int nScore16 = (SPd * (dh + 2) + 3) >> 2;
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? g.iniTh : g.minTh;
+    // clear the score tile (16-byte stores; its zero ring is part of it).  The barrier also publishes the image tile.
+    for (int i = lane; i < nScore16; i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
     // dense corner test, 4 pixels per lane; corners are compacted into an LDS list and scored with dense
     // lanes (the score needs ~110 min/max ops: running it under per-lane divergence would dominate).
     // Stage 1 (4 pixels per lane, registers): compass pre-test -> survivor list.
     // Stage 2 (dense lanes over survivors): contrast M from the 16 ring pixels; corner iff M > t, score M - 1
     //          goes to the u8 score tile and the corner to the corner list (for the list-based NMS).
+    // Lane validity is wave-uniform knowledge (entries base .. n-1 of a list are valid): it lives in scalar masks that
+    // are ANDed with the v_cmp results, never in per-lane predicates.
     int nList = 0, nSurv = 0;
     bool overflowed = false;  // more corners than the list holds: the NMS falls back to scanning the score tile
     auto flush_survivors = [&]() {
       __syncthreads();
       const orbx_h2 th2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);  // t in the same subnormal encoding
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
-        const int eA = base + lane, eB = base + 64 + lane;
-        const int yxA = slist[min(eA, nSurv - 1)], yxB = slist[min(eB, nSurv - 1)];
+        const int rem = nSurv - base;
+        const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
+        const int yxA = slist[min(base + lane, nSurv - 1)], yxB = slist[min(base + 64 + lane, nSurv - 1)];
         const int yA = yxA >> 8, xA = yxA & 255, yB = yxB >> 8, xB = yxB & 255;
-        const orbx_h2 M = fast_contrast2_lds(tile8 + __mul24(yA + 3, TP) + xA + 3, tile8 + __mul24(yB + 3, TP) + xB + 3,
-                                            TP);
-        const bool cornerA = eA < nSurv && M.x > th2.x, cornerB = eB < nSurv && M.y > th2.y;
+        const int oA = __mul24(yA, TP) + xA, oB = __mul24(yB, TP) + xB;  // top-left corners of the 7x7 windows
+        const orbx_h2 M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
-        if (cornerA) score8[__mul24(yA + 1, SPB) + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
-        if (cornerB) score8[__mul24(yB + 1, SPB) + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
-        const uint64_t mA = __ballot(cornerA), mB = __ballot(cornerB);
-        const int oA = nList + prefix_count(mA);
-        const int oB = nList + __popcll(mA) + prefix_count(mB);
-        if (cornerA && oA < cornerCap) list[oA] = (uint16_t)yxA;
-        if (cornerB && oB < cornerCap) list[oB] = (uint16_t)yxB;
-        nList += __popcll(mA) + __popcll(mB);
+        const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
+        if (__builtin_amdgcn_inverse_ballot_w64(mA)) {
+          score8[TPC ? oA - 4 * yA + (SPB + 4) : __mul24(yA + 1, SPB) + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
+          const int o = nList + prefix_count(mA);
+          if (o < cornerCap) list[o] = (uint16_t)yxA;
+        }
+        nList += __popcll(mA);
+        if (__builtin_amdgcn_inverse_ballot_w64(mB)) {
+          score8[TPC ? oB - 4 * yB + (SPB + 4) : __mul24(yB + 1, SPB) + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
+          const int o = nList + prefix_count(mB);
+          if (o < cornerCap) list[o] = (uint16_t)yxB;
+        }
+        nList += __popcll(mB);
       }
       if (nList > cornerCap) {
         overflowed = true;
@@ -483,35 +517,39 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       __syncthreads();
       nSurv = 0;
     };
-    const int nq_round = (nq + 63) & ~63;
-    for (int q = lane; q < nq_round; q += 64) {
-      const bool act = q < nq;
-      const int qq = min(q, nq - 1);  // idle lanes of the last round redo the last quad (masked out below)
-      const int yd = (int)(((float)qq + 0.5f) * inv_qpr);
-      const int j = qq - __mul24(yd, qpr);
+    int yd = yd0, j = j0;
+    for (int qb = 0; qb < nq; qb += 64) {
+      const uint64_t actM = low_lanes(nq - qb);
+      const int ydc = min(yd, dh - 1);  // idle lanes of the last round stay inside the tile (masked out below)
+      const uint32_t* row0 = tile + __mul24(ydc, TPd) + j;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
       uint32_t r[7][3];
 #pragma unroll
       for (int i = 0; i < 7; i++) {
-        const uint32_t* row = tile + __mul24(yd + i, TPd) + j;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
-        r[i][0] = row[0];
-        r[i][1] = row[1];
-        r[i][2] = row[2];
+        r[i][0] = row0[i * TPd];
+        r[i][1] = row0[i * TPd + 1];
+        r[i][2] = row0[i * TPd + 2];
       }
-      const int valid = dw - 4 * j;  // pixels of this quad inside the detectable window
+      const uint64_t notLast = ~__ballot(j == qpr - 1);  // a row's last quad may reach past the detectable window
       uint64_t sm[4];
-      sm[0] = compass_wave<0>(r, t) & __ballot(act);
-      sm[1] = compass_wave<1>(r, t) & __ballot(act && valid > 1);
-      sm[2] = compass_wave<2>(r, t) & __ballot(act && valid > 2);
-      sm[3] = compass_wave<3>(r, t) & __ballot(act && valid > 3);
-      if (act) score[__mul24(yd + 1, SPd) + j + 1] = 0;
+      sm[0] = compass_wave<0>(r, t) & actM;
+      sm[1] = compass_wave<1>(r, t) & (vlast > 1 ? actM : actM & notLast);
+      sm[2] = compass_wave<2>(r, t) & (vlast > 2 ? actM : actM & notLast);
+      sm[3] = compass_wave<3>(r, t) & (vlast > 3 ? actM : actM & notLast);
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (nSurv + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > survCap) flush_survivors();
+      const int yx = (ydc << 8) | (4 * j);
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
         if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
-          slist[nSurv + prefix_count(m)] = (uint16_t)((yd << 8) | (4 * j + pI));
+          slist[nSurv + prefix_count(m)] = (uint16_t)(yx | pI);
         nSurv += __popcll(m);
+      }
+      j += rq;
+      yd += dq;
+      if (j >= qpr) {
+        j -= qpr;
+        yd++;
       }
     }
     flush_survivors();
@@ -525,24 +563,25 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       }
     }
     if (!overflowed) {
-      // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each
+      // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each, no branches
       const int SP = SPB;
       for (int base = 0; base < nCorners; base += 64) {
-        const int e = base + lane;
-        const int yx = list[min(e, nCorners - 1)], y = yx >> 8, x = yx & 255;
-        const uint8_t* c8 = score8 + __mul24(y + 1, SP) + x + 4;
-        const int sc = c8[0];
-        const bool keep = e < nCorners && sc > c8[-1] && sc > c8[1] && sc > c8[-SP - 1] && sc > c8[-SP] &&
-                          sc > c8[-SP + 1] && sc > c8[SP - 1] && sc > c8[SP] && sc > c8[SP + 1];
-        const uint64_t m = __ballot(keep);
-        if (keep) {
+        const int yx = list[min(base + lane, nCorners - 1)], y = yx >> 8, x = yx & 255;
+        const uint8_t* c8 = score8 + __mul24(y, SP) + x + 3;  // top-left of the 3x3 neighbourhood
+        const int sc = c8[SP + 1];
+        const int n0 = max(max((int)c8[0], (int)c8[1]), (int)c8[2]);
+        const int n1 = max(max((int)c8[SP], (int)c8[SP + 2]), (int)c8[2 * SP]);
+        const int n2 = max(max((int)c8[2 * SP + 1], (int)c8[2 * SP + 2]), n0);
+        const uint64_t m = __ballot(sc > max(n1, n2)) & low_lanes(nCorners - base);
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
           const int o = kept + prefix_count(m);
           if (o < L.cellCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, sc);
         }
         kept += __popcll(m);
       }
     } else
-    for (int q = lane; q < nq_round; q += 64) {
+    for (int qb = 0; qb < nq; qb += 64) {
+      const int q = qb + lane;
       uint32_t sw = 0;
       int yd = 0, j = 0;
       if (q < nq) {
@@ -600,7 +639,7 @@ void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : 
 // Cells of levels [level0, level1) only: level 0 needs no resize and is launched beside the pyramid chain.
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, uint8_t* dbgScore, hipStream_t s) {
-  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 16;
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 32;
   const int cellBegin = g.lv[level0].cellStart;
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
@@ -2382,7 +2421,7 @@ hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t
 
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
-  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 16;
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;
