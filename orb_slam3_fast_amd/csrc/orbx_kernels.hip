@@ -20,9 +20,19 @@
 
 namespace orbx {
 
-__constant__ int8_t c_pattern[1024] = {
-#include "orb_pattern31.inc"
+// the same table as floats (x0, y0, x1, y1 per test): k_describe rotates it without a conversion per coordinate
+struct PatternF {
+  float v[1024];
 };
+constexpr PatternF make_pattern_f() {
+  constexpr int8_t src[1024] = {
+#include "orb_pattern31.inc"
+  };
+  PatternF t{};
+  for (int i = 0; i < 1024; i++) t.v[i] = (float)src[i];
+  return t;
+}
+__device__ const PatternF c_pattern_f = make_pattern_f();
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // ================================================================================================ resize
@@ -2187,27 +2197,31 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 //   sum(val) = v_dot4(wd, .x)      sum(u * val) = v_dot4(wd, .y) - 16 * sum(val)
 // -- two dot products per dword instead of four masked multiply-adds (the kernel is VALU-issue bound).
 struct IcTable {
-  uint2 e[4][280];
+  uint2 e[4][5 * 64];
 };
+// Item (trip t, lane): lanes 0..62 = (row phase r0 = lane / 9, dword c = lane % 9), patch row r = r0 + 7 t; items past row 30
+// and lane 63 are zero.  No index division at run time, and a lane's window reads are one address plus immediates.
 constexpr IcTable make_ic_table() {
   IcTable t{};
   const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
   for (int m = 0; m < 4; m++)
-    for (int i = 0; i < 280; i++) {
-      uint32_t mk = 0, wt = 0;
-      if (i < 279) {
-        const int r = i / 9, c = i - 9 * r, v = r - 15, lim = um[v < 0 ? -v : v];
-        for (int b = 0; b < 4; b++) {
-          const int u = 4 * c + b - m - 15;
-          if (u >= -lim && u <= lim) {
-            mk |= 1u << (8 * b);
-            wt |= (uint32_t)(u + 16) << (8 * b);
+    for (int tt = 0; tt < 5; tt++)
+      for (int ln = 0; ln < 64; ln++) {
+        uint32_t mk = 0, wt = 0;
+        const int r = ln / 9 + 7 * tt, c = ln % 9;
+        if (ln < 63 && r < 31) {
+          const int v = r - 15, lim = um[v < 0 ? -v : v];
+          for (int b = 0; b < 4; b++) {
+            const int u = 4 * c + b - m - 15;
+            if (u >= -lim && u <= lim) {
+              mk |= 1u << (8 * b);
+              wt |= (uint32_t)(u + 16) << (8 * b);
+            }
           }
         }
+        t.e[m][tt * 64 + ln].x = mk;
+        t.e[m][tt * 64 + ln].y = wt;
       }
-      t.e[m][i].x = mk;
-      t.e[m][i].y = wt;
-    }
   return t;
 }
 __device__ const IcTable c_ic = make_ic_table();
@@ -2259,18 +2273,22 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   const int xs = (X - 21) & ~3, mis = __builtin_amdgcn_readfirstlane((X - 21) - xs);
   const bool interior = X >= 21 && Y >= 21 && X + 21 < L.w && Y + 21 < L.h;
   if (interior) {
-    uint32_t w[9];
+    // lane = (row phase r0 = lane / 12, dword column c = lane % 12): 60 lanes cover 5 window rows per trip, so a trip is
+    // one address increment; all 9 loads are in flight before the first LDS store.  Columns past the level's last dword
+    // (they only feed unused outputs) re-read that last dword.
+    const int r0 = (lane * 5462) >> 16, c = lane - 12 * r0;
+    const int cl = min(c, (L.w - 1 - xs) >> 2);
     const uint8_t* base = im + (long long)(Y - 21) * pitch + xs;  // uniform: SGPR base + 32-bit lane offsets
+    const unsigned off0 = (unsigned)(__mul24(r0, pitch) + 4 * cl), step = 5u * (unsigned)pitch;
+    if (lane < 60) {
+      uint32_t w[9];
 #pragma unroll
-    for (int t = 0; t < 9; t++) {  // 516 dword items, all loads in flight before the first LDS store
-      const int i = min(lane + 64 * t, DW_ROWS * DW_RP - 1);
-      const int r = (int)(((unsigned)i * 5462u) >> 16), c = i - r * DW_RP;  // i / 12 for i < 2^13
-      const unsigned off = (unsigned)(r * pitch + 4 * c);
-      w[t] = xs + 4 * c < L.w ? *reinterpret_cast<const uint32_t*>(base + off) : 0u;
+      for (int t = 0; t < 9; t++)  // (rows 43, 44 of the last trip: clamped to row 42, not stored)
+        w[t] = *reinterpret_cast<const uint32_t*>(base + (t < 8 ? off0 + (unsigned)t * step : min(off0 + 8u * step, 42u * (unsigned)pitch + 4u * (unsigned)cl)));
+#pragma unroll
+      for (int t = 0; t < 8; t++) raw[lane + 60 * t] = w[t];
+      if (r0 < 3) raw[lane + 480] = w[8];
     }
-#pragma unroll
-    for (int t = 0; t < 9; t++)
-      if (lane + 64 * t < DW_ROWS * DW_RP) raw[lane + 64 * t] = w[t];
   } else {  // window crosses the level's edge: BORDER_REFLECT_101, byte by byte (coordinates further out are never used)
     for (int i = lane; i < DW_ROWS * DW_RP; i += 64) {
       const int r = i / DW_RP, c = i - r * DW_RP;
@@ -2301,18 +2319,19 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   int m10 = 0, m01 = 0;
   {
     const int c0 = (6 + mis) >> 2, misr = (6 + mis) & 3;
-    const uint2* tab = c_ic.e[misr];
-    int srs = 0, sw = 0;
+    const uint2* tab = c_ic.e[misr] + lane;
+    const int r0 = (lane * 7282) >> 16, c = lane - 9 * r0;  // lane / 9
+    const uint32_t* wp = raw + (6 + r0) * DW_RP + c0 + c;
+    int srs = 0, sw = 0, rv = r0 - 15;
 #pragma unroll
     for (int t = 0; t < 5; t++) {
-      const int ii = min(lane + 64 * t, 279);  // entry 279 is all zero
-      const int r = (int)(((unsigned)ii * 7282u) >> 16), c = ii - r * 9;  // ii / 9 for ii < 2^12
-      const uint2 e = tab[ii];
-      const uint32_t wd = raw[(6 + r) * DW_RP + c0 + c];
+      const uint2 e = tab[64 * t];
+      const uint32_t wd = wp[7 * DW_RP * t];
       const int rs = (int)__builtin_amdgcn_udot4(wd, e.x, 0u, false);
       sw = (int)__builtin_amdgcn_udot4(wd, e.y, (uint32_t)sw, false);
       srs += rs;
-      m01 += (r - 15) * rs;
+      m01 += __mul24(rv, rs);
+      rv += 7;
     }
     m10 = sw - 16 * srs;
 #pragma unroll
@@ -2389,8 +2408,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   const uint8_t* centre = bl + 18 * DW_BP + 18;
 #pragma unroll
   for (int gI = 0; gI < 4; gI++) {
-    const int8_t* pt = c_pattern + 4 * (64 * gI + lane);
-    const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+    const float4 pt = *reinterpret_cast<const float4*>(c_pattern_f.v + 4 * (64 * gI + lane));
+    const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
     const int iy0 = rne_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
     const int ix0 = rne_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
     const int iy1 = rne_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
