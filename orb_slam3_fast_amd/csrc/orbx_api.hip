@@ -132,7 +132,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     sel += v.selCap;
     v.xcoef = xc;
     v.ycoef = yc;
-    xc += v.w;
+    xc += align_up(v.w, 256);  // k_resize reads whole 256-column blocks of the x table
     yc += v.h;
     v.scale = ex->scale[l];
     v.patch = (float)(int)(31 * ex->scale[l]);
@@ -170,15 +170,15 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
 }
 
 // ---- resize coefficient tables, cv::resize INTER_LINEAR 8U -------------------------------
-void build_coefs(const Geom& g, std::vector<int>& xofs, std::vector<short>& xab, std::vector<int>& yofs,
-                 std::vector<short>& yab) {
+// x table: one uint4 per dst column {sx, sx & ~3, v_perm selector of the byte pair, a0 | a1 << 16}; every level is padded
+// to a multiple of 256 entries with copies of its last column.
+void build_coefs(const Geom& g, std::vector<uint4>& xtab, std::vector<int>& yofs, std::vector<short>& yab) {
   int nx = 0, ny = 0;
   for (int l = 0; l < g.nlevels; l++) {
-    nx += g.lv[l].w;
+    nx += align_up(g.lv[l].w, 256);
     ny += g.lv[l].h;
   }
-  xofs.assign(nx, 0);
-  xab.assign(2 * nx, 0);
+  xtab.assign(nx, make_uint4(0, 0, 0, 0));
   yofs.assign(ny, 0);
   yab.assign(2 * ny, 0);
   for (int l = 1; l < g.nlevels; l++) {
@@ -190,10 +190,11 @@ void build_coefs(const Geom& g, std::vector<int>& xofs, std::vector<short>& xab,
       fx -= sx;
       if (sx < 0) { fx = 0; sx = 0; }
       if (sx >= S.w - 1) { fx = 0; sx = S.w - 1; }
-      xofs[D.xcoef + dx] = sx;
-      xab[2 * (D.xcoef + dx)] = sat_short((1.f - fx) * 2048.f);
-      xab[2 * (D.xcoef + dx) + 1] = sat_short(fx * 2048.f);
+      const uint32_t a0 = (uint16_t)sat_short((1.f - fx) * 2048.f), a1 = (uint16_t)sat_short(fx * 2048.f);
+      const uint32_t sh = (uint32_t)sx & 3u;
+      xtab[D.xcoef + dx] = make_uint4((uint32_t)sx, (uint32_t)sx & ~3u, sh | 0x0c000c00u | ((sh + 1u) << 16), a0 | (a1 << 16));
     }
+    for (int dx = D.w; dx < align_up(D.w, 256); dx++) xtab[D.xcoef + dx] = xtab[D.xcoef + D.w - 1];
     for (int dy = 0; dy < D.h; dy++) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);
       int sy = cv_floor(fy);
@@ -225,12 +226,12 @@ int configure(orbx_extractor* ex, int w, int h) {
   g.pyrImg = m.pyrImg;
   g.candImg = m.candImg;
   g.cellImg = m.cellImg;
-  std::vector<int> xofs, yofs;
-  std::vector<short> xab, yab;
-  build_coefs(g, xofs, xab, yofs, yab);
+  std::vector<uint4> xtab;
+  std::vector<int> yofs;
+  std::vector<short> yab;
+  build_coefs(g, xtab, yofs, yab);
   HIPC(hipStreamSynchronize(ex->stream));
-  HIPC(hipMemcpy(ex->d_xofs.p, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
-  HIPC(hipMemcpy(ex->d_xab.p, xab.data(), xab.size() * sizeof(short), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ex->d_xtab.p, xtab.data(), xtab.size() * sizeof(uint4), hipMemcpyHostToDevice));
   HIPC(hipMemcpy(ex->d_yofs.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPC(hipMemcpy(ex->d_yab.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
   HIPC(prepare_kernels(g));
@@ -345,7 +346,7 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) 
   ex->blurValid = false;  // the blurred levels (orbx_pyramid_level blurred = 1) are produced on demand
   for (int l = 1; l < g.nlevels; l++) {
     StageTimer t(ex, s, ORBX_STAGE_RESIZE);
-    HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xofs.p, ex->d_xab.p, ex->d_yofs.p, ex->d_yab.p, s));
+    HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
   }
   if (ex->d_dbgScore.p) HIPC(hipMemsetAsync(ex->d_dbgScore.p, 0, ex->d_dbgScore.n, s));  // test tap only
   // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
@@ -432,7 +433,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ex->stagePitch = align_up(max_width, 64);
   int nx = 0, ny = 0;
   for (int l = 0; l < m.nlevels; l++) {
-    nx += m.lv[l].w;
+    nx += align_up(m.lv[l].w, 256);
     ny += m.lv[l].h;
   }
   hipError_t e = hipSuccess;
@@ -458,8 +459,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_mono.alloc(B));
   ok(ex->d_lap.alloc(B * 2));
   ok(hipHostMalloc(reinterpret_cast<void**>(&ex->h_lap), (size_t)B * 2 * sizeof(int), hipHostMallocDefault));
-  ok(ex->d_xofs.alloc(nx + 64));
-  ok(ex->d_xab.alloc(2 * nx + 64));
+  ok(ex->d_xtab.alloc(nx + 64));
   ok(ex->d_yofs.alloc(ny + 64));
   ok(ex->d_yab.alloc(2 * ny + 64));
   ok(hipHostMalloc(reinterpret_cast<void**>(&ex->hostResults), host_results_bytes(m.outCap), hipHostMallocDefault));
@@ -487,8 +487,8 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
-  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xofs.free(); ex->d_yofs.free();
-  ex->d_xab.free(); ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
+  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_yofs.free();
+  ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);

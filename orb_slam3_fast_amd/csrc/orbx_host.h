@@ -238,8 +238,9 @@ struct orbx_extractor {
   DevBuf<uint8_t> d_dbgScore;      // test tap (orbx_debug_score_map): FAST scores at iniThFAST, pyramid layout; normally unallocated
   DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
   DevBuf<uint16_t> d_knode;
-  DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_xofs, d_yofs, d_sad;
-  DevBuf<short> d_xab, d_yab;
+  DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
+  DevBuf<short> d_yab;
+  DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;

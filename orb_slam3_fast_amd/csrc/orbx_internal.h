@@ -70,8 +70,8 @@ __host__ __device__ inline int key_y(uint32_t k) { return (k >> 12) & 0xFFF; }
 __host__ __device__ inline int key_r(uint32_t k) { return k >> 24; }
 
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
-hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
-                         const int* yofs, const short* yab, hipStream_t s);
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,
+                         const short* yab, hipStream_t s);
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, uint8_t* dbgScore, hipStream_t s);
 hipError_t launch_octree(const Geom& g, int nimg, const uint32_t* cellCand, const int* cellCount, int* cellPrefix,

@@ -43,10 +43,17 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // in LDS; the vertical pass emits 4 pixels per thread with one u32 store.
 #define RS_DW 256
 #define RS_DR 16
-__global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int* __restrict__ xofs,
-                                                const short* __restrict__ xab, const int* __restrict__ yofs,
-                                                const short* __restrict__ yab, int srcRowsMax, int srcDwMax) {
+#define RS_HROWS 6  // footprint rows per wave in the unrolled part of the horizontal pass (4 waves: 24 rows)
+// NDW: compile-time footprint row pitch in dwords (0 = run time).  With a constant pitch a wave's six footprint rows are
+// one LDS address per output column plus ds_read2 immediates.
+// xtab: one uint4 per dst column {sx, sx & ~3, v_perm selector, a0 | a1 << 16}, each level padded to a multiple of
+// RS_DW entries with copies of its last column (a block reads its 256 entries unconditionally).
+template <int NDW>
+__global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const uint4* __restrict__ xtab,
+                                                const int* __restrict__ yofs, const short* __restrict__ yab,
+                                                int srcRowsMax, int srcDwMaxRt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int SDW = NDW ? NDW : srcDwMaxRt;
   const LevelDev D = g.lv[l];
   const LevelDev S = g.lv[l - 1];
   const int tid = threadIdx.x;
@@ -55,31 +62,29 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
   const int x1 = min(x0 + RS_DW, D.w) - 1, y1 = min(y0 + RS_DR, D.h) - 1;  // last dst column / row of the block
   int sp;
   const uint8_t* src = level_ptr(g, p, img, l - 1, sp);
-  uint32_t* st = reinterpret_cast<uint32_t*>(smem);                            // [srcRowsMax][srcDwMax] dwords
-  uint16_t* ht = reinterpret_cast<uint16_t*>(st + srcRowsMax * srcDwMax);      // [srcRowsMax][RS_DW] u16
+  uint32_t* st = reinterpret_cast<uint32_t*>(smem);                        // [srcRowsMax][SDW] dwords
+  uint8_t* ht8 = smem + (size_t)srcRowsMax * SDW * 4;                      // [srcRowsMax][RS_DW] u16
 #ifdef RS_PROF
   long long tq0 = wall_clock64();
 #endif
   const int rb = min(max(yofs[D.ycoef + y0], 0), S.h - 1);                      // first source row needed
   const int re = min(max(yofs[D.ycoef + y1] + 1, 0), S.h - 1);                  // last source row needed
   const int nrows = re - rb + 1;
-  const int cb = xofs[D.xcoef + x0] & ~3;                                       // first source byte (dword aligned)
-  const int ce = min(xofs[D.xcoef + x1] + 1, S.w - 1);
+  const int cb = (int)xtab[D.xcoef + x0].y;                                     // first source byte (dword aligned)
+  const int ce = min((int)xtab[D.xcoef + x1].x + 1, S.w - 1);
   const int ndw = ((ce - cb) >> 2) + 1;
   // Every coefficient the two passes need is fetched HERE, together with the footprint: a block is a chain of dependent
   // memory latencies (tile bounds -> footprint -> column coefficients -> row coefficients), and the kernel's time is that
   // chain times the number of block generations, not bandwidth or issue slots.
   const int qc = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t sel[4], coef[4];
-  int dwi[4];
+  int ba[4];  // byte offset, inside a footprint row, of the aligned dword pair that holds S[sx], S[sx + 1]
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int dx = min(x0 + 4 * qc + j, D.w - 1);
-    const int o = xofs[D.xcoef + dx] - cb;  // S[sx + 1] is only weighted by a1 != 0 when it exists (build_coefs)
-    const int sh = o & 3;
-    dwi[j] = o >> 2;
-    sel[j] = (uint32_t)sh | 0x0c000c00u | ((uint32_t)(sh + 1) << 16);
-    coef[j] = reinterpret_cast<const uint32_t*>(xab)[D.xcoef + dx];  // a0 | a1 << 16
+    const uint4 e = xtab[D.xcoef + x0 + 4 * qc + j];  // S[sx + 1] is only weighted by a1 != 0 when it exists (build_coefs)
+    ba[j] = (int)e.y - cb;
+    sel[j] = e.z;
+    coef[j] = e.w;
   }
   int vsy[RS_DR / 4];
   uint32_t vbb[RS_DR / 4];
@@ -90,37 +95,57 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
     vbb[k] = reinterpret_cast<const uint32_t*>(yab)[D.ycoef + dy];
   }
   {
-    // Footprint -> LDS.  Thread = (row phase r0, dword column c): rpp = 256 / ndw source rows per pass, so a trip is a
-    // pointer increment, a bounds test and a load (no per-item index division); all of a thread's global loads are
-    // issued before its first LDS store (a plain copy loop serialised one HBM latency per trip).
+    // Footprint -> LDS.  Thread = (row phase r0, dword column c): rpp = 256 / ndw source rows per pass, so a trip is an
+    // offset increment and a load (no per-item index division); all of a thread's global loads are issued before its
+    // first LDS store (a plain copy loop serialised one HBM latency per trip).  Rows past the footprint are clamped to its
+    // last row on both sides (the same bytes land on the same LDS dword again): no predicates in the loop.
+    // Only a level-0 source (the caller's buffer) may end with its last pixel: then the last dword is read byte-wise.
+    const bool whole = l > 1 || cb + 4 * ndw <= S.w;
     for (int cbase = 0; cbase < ndw; cbase += 256) {          // one trip unless the scale factor exceeds ~3.9
     const int nd = min(ndw - cbase, 256);
-    const int rpp = 256 / nd;                                  // rows per pass (3 at scale 1.2: 78 dwords per row)
-    const int r0 = (int)(((float)tid + 0.5f) / (float)nd);    // tid / nd, once per thread
+    // (v_rcp_f32 is good to 1 ulp; the quotients below stay >= 0.5 / nd away from the next integer)
+    const float inv_nd = __builtin_amdgcn_rcpf((float)nd);
+    const int rpp = __builtin_amdgcn_readfirstlane((int)(256.5f * inv_nd));  // rows per pass (3 at scale 1.2: 78 dwords per row)
+    const int r0 = (int)(((float)tid + 0.5f) * inv_nd);                      // tid / nd, once per thread
     const int c = cbase + tid - r0 * nd;
-    const bool lanes = r0 < rpp;                               // threads beyond rpp * nd idle
-    const int gx = cb + 4 * c;
-    const bool wide = gx + 4 <= S.w;
     constexpr int kTrips = 8;  // one batch covers the footprint at scale 1.2 (21 rows / 3 per pass); larger scales loop
-    for (int rbase = 0; rbase < nrows; rbase += rpp * kTrips) {
-      uint32_t v[kTrips];
-      const uint8_t* q = src + (long long)(rb + rbase + r0) * sp + gx;
+    if (whole) {
+      const uint8_t* fb = src + (long long)rb * sp + cb;       // wave-uniform base, 32-bit lane offsets
+      const uint32_t offLast = (uint32_t)(__mul24(nrows - 1, sp) + 4 * c), offStep = (uint32_t)(rpp * sp);
+      const int idxLast = 4 * (__mul24(nrows - 1, SDW) + c), idxStep = 4 * rpp * SDW;
+      for (int rbase = 0; rbase < nrows; rbase += rpp * kTrips) {
+        const uint32_t off0 = (uint32_t)(__mul24(rbase + r0, sp) + 4 * c);
+        const int idx0 = 4 * (__mul24(rbase + r0, SDW) + c);
+        uint32_t v[kTrips];
 #pragma unroll
-      for (int k = 0; k < kTrips; k++) {
-        v[k] = 0;
-        if (lanes && rbase + r0 + k * rpp < nrows) {
-          if (wide) {
-            v[k] = *reinterpret_cast<const uint32_t*>(q);
-          } else {
-            for (int bI = 0; bI < 4; bI++)
-              if (gx + bI < S.w) v[k] |= (uint32_t)q[bI] << (8 * bI);
-          }
-        }
-        q += (long long)rpp * sp;
+        for (int k = 0; k < kTrips; k++) v[k] = *reinterpret_cast<const uint32_t*>(fb + min(off0 + (uint32_t)k * offStep, offLast));
+#pragma unroll
+        for (int k = 0; k < kTrips; k++) *reinterpret_cast<uint32_t*>(smem + min(idx0 + k * idxStep, idxLast)) = v[k];
       }
+    } else {
+      const bool lanes = r0 < rpp;                               // threads beyond rpp * nd idle
+      const int gx = cb + 4 * c;
+      const bool wide = gx + 4 <= S.w;
+      for (int rbase = 0; rbase < nrows; rbase += rpp * kTrips) {
+        uint32_t v[kTrips];
+        const uint8_t* q = src + (long long)(rb + rbase + r0) * sp + gx;
 #pragma unroll
-      for (int k = 0; k < kTrips; k++)
-        if (lanes && rbase + r0 + k * rpp < nrows) st[(rbase + r0 + k * rpp) * srcDwMax + c] = v[k];
+        for (int k = 0; k < kTrips; k++) {
+          v[k] = 0;
+          if (lanes && rbase + r0 + k * rpp < nrows) {
+            if (wide) {
+              v[k] = *reinterpret_cast<const uint32_t*>(q);
+            } else {
+              for (int bI = 0; bI < 4; bI++)
+                if (gx + bI < S.w) v[k] |= (uint32_t)q[bI] << (8 * bI);
+            }
+          }
+          q += (long long)rpp * sp;
+        }
+#pragma unroll
+        for (int k = 0; k < kTrips; k++)
+          if (lanes && rbase + r0 + k * rpp < nrows) st[(rbase + r0 + k * rpp) * SDW + c] = v[k];
+      }
     }
     }
   }
@@ -131,22 +156,31 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
 #ifdef RS_PROF
   long long tq2 = wall_clock64();
 #endif
-  {  // horizontal pass: lane = quad of 4 dst columns, wave = source-row phase (rows w, w + 4, ...).  Per output one
+  {  // horizontal pass: lane = quad of 4 dst columns; wave w takes footprint rows 6w .. 6w+5 (consecutive rows: their LDS
+     // offsets fit the ds_read2 immediates), rows from 24 on (scale factors above 1.3) go round-robin.  Per output one
      // ds_read2_b32 (the aligned dword pair holding S[sx], S[sx+1]), one v_perm with a per-lane selector that spreads
      // the two bytes into u16 halves, one v_dot2_u32_u16 against (a0, a1), one shift; four results leave as one b64.
-    for (int r = w; r < nrows; r += 4) {
-      const uint32_t* row = st + r * srcDwMax;
+    auto hrow = [&](const uint8_t* rowp, uint8_t* outp) {
       uint32_t t[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const uint32_t lo = row[dwi[j]], hi = row[dwi[j] + 1];
-        t[j] = udot2_u16(__builtin_amdgcn_perm(hi, lo, sel[j]), coef[j], 0u) >> 4;
+        const uint32_t* pr = reinterpret_cast<const uint32_t*>(rowp + ba[j]);
+        t[j] = udot2_u16(__builtin_amdgcn_perm(pr[1], pr[0], sel[j]), coef[j], 0u);
       }
-      uint2 pk;
-      pk.x = t[0] | (t[1] << 16);
-      pk.y = t[2] | (t[3] << 16);
-      *reinterpret_cast<uint2*>(ht + r * RS_DW + 4 * qc) = pk;
+      uint2 pk;  // (t >> 4) as u16 pairs: bytes 0, 1 of t_even >> 4 and bytes 2, 3 of t_odd << 12
+      pk.x = __builtin_amdgcn_perm(t[1] << 12, t[0] >> 4, 0x07060100u);
+      pk.y = __builtin_amdgcn_perm(t[3] << 12, t[2] >> 4, 0x07060100u);
+      *reinterpret_cast<uint2*>(outp) = pk;
+    };
+    const int rw0 = RS_HROWS * w;
+    const uint8_t* rowp = smem + rw0 * SDW * 4;
+    uint8_t* outp = ht8 + rw0 * (RS_DW * 2) + 8 * qc;
+#pragma unroll
+    for (int i = 0; i < RS_HROWS; i++) {
+      if (rw0 + i >= nrows) break;
+      hrow(rowp + i * SDW * 4, outp + i * (RS_DW * 2));
     }
+    for (int r = 4 * RS_HROWS + w; r < nrows; r += 4) hrow(smem + r * SDW * 4, ht8 + r * (RS_DW * 2) + 8 * qc);
   }
 #ifdef RS_PROF
   long long tq3 = wall_clock64();
@@ -157,6 +191,7 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const int*
 #endif
   // vertical pass: lane = quad, wave w owns dst rows w, w + 4, ... of the block: the row constants are wave-uniform
   {
+    const uint16_t* ht = reinterpret_cast<const uint16_t*>(ht8);
     const int qx = tid & 63;
     const int dx = x0 + 4 * qx;
 #pragma unroll
@@ -208,14 +243,18 @@ size_t resize_lds_bytes(const Geom& g) {
   return m;
 }
 
-hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const int* xofs, const short* xab,
-                         const int* yofs, const short* yab, hipStream_t s) {
+constexpr int kResizeNdw = 80;  // footprint pitch of the compile-time instantiation (every level of a 1.2 pyramid)
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,
+                         const short* yab, hipStream_t s) {
   const LevelDev& D = g.lv[level];
   int srcRowsMax, srcDwMax;
   size_t lds;
   resize_footprint(g, level, srcRowsMax, srcDwMax, lds);
   dim3 grid((D.w + RS_DW - 1) / RS_DW, (D.h + RS_DR - 1) / RS_DR, nimg);
-  hipLaunchKernelGGL(k_resize, grid, dim3(256), lds, s, g, p, level, xofs, xab, yofs, yab, srcRowsMax, srcDwMax);
+  if (srcDwMax == kResizeNdw)
+    hipLaunchKernelGGL(k_resize<kResizeNdw>, grid, dim3(256), lds, s, g, p, level, xtab, yofs, yab, srcRowsMax, srcDwMax);
+  else
+    hipLaunchKernelGGL(k_resize<0>, grid, dim3(256), lds, s, g, p, level, xtab, yofs, yab, srcRowsMax, srcDwMax);
   return hipGetLastError();
 }
 
@@ -2445,7 +2484,10 @@ hipError_t prepare_kernels(const Geom& g) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;
   if (g.nlevels > 1) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)std::max<size_t>(resize_lds_bytes(g), 1024));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize<kResizeNdw>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)std::max<size_t>(resize_lds_bytes(g), 1024));
     if (e != hipSuccess) return e;
   }
