@@ -2385,30 +2385,41 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   glibc_sincosf<true>(__fmul_rn(angle, factorPI), b, a);  // a = cosf, b = sinf (orbx_sincos.h)
   // ---- horizontal pass: item = (row pair j, group of 4 output columns 4q..4q+3); output column x <-> window byte
   // x + 3 + mis, its taps are window bytes x + mis .. x + mis + 6
-  for (int i = lane; i < 22 * 10; i += 64) {
-    const int j = (int)(((unsigned)i * 6554u) >> 16), q = i - j * 10;  // i / 10
-    uint32_t h[2][4];
+  // lane = (pair phase j0 = lane / 10, group q = lane % 10): 60 lanes cover 6 row pairs per trip, so a trip's window and
+  // output addresses are the lane's base plus immediates (no index arithmetic inside the loop)
+  {
+    const int j0 = (lane * 6554) >> 16, q = lane - 10 * j0;  // lane / 10
+    const uint32_t* rbase = raw + 2 * j0 * DW_RP + q;
+    uint32_t* hbase = hp + j0 * DW_HP + 4 * q;
+    if (lane < 60) {
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-      const uint32_t* row = raw + min(2 * j + rr, DW_ROWS - 1) * DW_RP + q;
-      const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];  // (d3 of the last group only feeds unused columns)
-      const uint32_t A0 = __builtin_amdgcn_alignbyte(d1, d0, mis), A1 = __builtin_amdgcn_alignbyte(d2, d1, mis),
-                     A2 = __builtin_amdgcn_alignbyte(d3, d2, mis);  // 12 window bytes from the first tap of column 4q
-      const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps 0..3 and 4..6 (LSB = lowest x)
-      h[rr][0] = __builtin_amdgcn_udot4(A0, wA, __builtin_amdgcn_udot4(A1, wB, 0, false), false);
-      h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 1), wA,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 1), wB, 0, false), false);
-      h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 2), wA,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 2), wB, 0, false), false);
-      h[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 3), wA,
-                                        __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 3), wB, 0, false), false);
+      for (int t = 0; t < 4; t++) {
+        if (t == 3 && j0 >= 4) break;  // pairs 22, 23 do not exist
+        uint32_t h[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          // (row 43 = second row of pair 21 lies in the slack behind the window: it only feeds H row 43, which nothing reads)
+          const uint32_t* row = rbase + (12 * t + rr) * DW_RP;
+          const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];  // (d3 of the last group only feeds unused columns)
+          const uint32_t A0 = __builtin_amdgcn_alignbyte(d1, d0, mis), A1 = __builtin_amdgcn_alignbyte(d2, d1, mis),
+                         A2 = __builtin_amdgcn_alignbyte(d3, d2, mis);  // 12 window bytes from the first tap of column 4q
+          const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps 0..3 and 4..6 (LSB = lowest x)
+          h[rr][0] = __builtin_amdgcn_udot4(A0, wA, __builtin_amdgcn_udot4(A1, wB, 0, false), false);
+          h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 1), wA,
+                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 1), wB, 0, false), false);
+          h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 2), wA,
+                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 2), wB, 0, false), false);
+          h[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 3), wA,
+                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 3), wB, 0, false), false);
+        }
+        uint4 pk;
+        pk.x = h[0][0] | (h[1][0] << 16);
+        pk.y = h[0][1] | (h[1][1] << 16);
+        pk.z = h[0][2] | (h[1][2] << 16);
+        pk.w = h[0][3] | (h[1][3] << 16);
+        *reinterpret_cast<uint4*>(hbase + 6 * DW_HP * t) = pk;
+      }
     }
-    uint4 pk;
-    pk.x = h[0][0] | (h[1][0] << 16);
-    pk.y = h[0][1] | (h[1][1] << 16);
-    pk.z = h[0][2] | (h[1][2] << 16);
-    pk.w = h[0][3] | (h[1][3] << 16);
-    *reinterpret_cast<uint4*>(hp + j * DW_HP + 4 * q) = pk;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -2419,7 +2430,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     const int ch = (int)(((unsigned)i * 1772u) >> 16), x = i - ch * 37;  // i / 37 for i < 2^11
     uint32_t pr[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) pr[k] = hp[min(4 * ch + k, 21) * DW_HP + x];  // H rows 8ch .. 8ch+13
+    for (int k = 0; k < 7; k++) pr[k] = hp[(4 * ch + k) * DW_HP + x];  // H rows 8ch .. 8ch+13 (pair 22 = the first window dwords: feeds padding rows only)
     const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16), w6 = 18u;            // even y
     const uint32_t v0 = 18u << 16, v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);      // odd y
 #pragma unroll
