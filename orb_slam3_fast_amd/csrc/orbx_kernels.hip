@@ -2341,6 +2341,10 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
       raw[i] = v;
     }
   }
+  // the lane's four rBRIEF tests (x0, y0, x1, y1 each), requested now: they arrive under the window / blur work
+  float4 pat[4];
+#pragma unroll
+  for (int gI = 0; gI < 4; gI++) pat[gI] = *reinterpret_cast<const float4*>(c_pattern_f.v + 4 * (64 * gI + lane));
   // slot == nullptr: no keypoint can lie in the lapping area (lap1 < 19 <= every x), so the serial-order slot is
   // simply (keypoints of the earlier levels) + idx and k_slots is not launched at all
   int n_out_slot;
@@ -2455,16 +2459,20 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   __builtin_amdgcn_wave_barrier();
   // ---- rBRIEF on the blurred patch
   uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
+  // cvRound by the 1.5 * 2^23 trick: the float sum's bit pattern is 0x4B400000 + n (n = the half-even rounded value), so
+  // row * pitch + column comes out of one 24-bit multiply-add on the two patterns, the constants folded into the base
+  const float kMagic = 12582912.0f;
   const uint8_t* centre = bl + 18 * DW_BP + 18;
+  const uint32_t kFold = 0x400000u * DW_BP + 0x4B400000u;  // (unsigned wrap-around is exact here)
 #pragma unroll
   for (int gI = 0; gI < 4; gI++) {
-    const float4 pt = *reinterpret_cast<const float4*>(c_pattern_f.v + 4 * (64 * gI + lane));
-    const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-    const int iy0 = rne_f(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-    const int ix0 = rne_f(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-    const int iy1 = rne_f(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-    const int ix1 = rne_f(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-    const int t0 = centre[iy0 * DW_BP + ix0], t1 = centre[iy1 * DW_BP + ix1];
+    const float x0 = pat[gI].x, y0 = pat[gI].y, x1 = pat[gI].z, y1 = pat[gI].w;
+    const uint32_t iy0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), kMagic));
+    const uint32_t ix0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), kMagic));
+    const uint32_t iy1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), kMagic));
+    const uint32_t ix1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), kMagic));
+    const int t0 = centre[(int)((uint32_t)__mul24((int)iy0, DW_BP) + ix0 - kFold)],
+              t1 = centre[(int)((uint32_t)__mul24((int)iy1, DW_BP) + ix1 - kFold)];
     const uint64_t bits = __ballot(t0 < t1);
     if (lane == 0) *reinterpret_cast<uint64_t*>(dout + 8 * gI) = bits;
   }
