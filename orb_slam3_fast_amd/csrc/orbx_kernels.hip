@@ -285,24 +285,23 @@ __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits
 }
 
 // Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
-// polarity.  v_cmp leaves each comparison as a 64-lane mask in SGPRs, so the combination is scalar-ALU work:
-// per pixel slot 8 VALU compares + 7 scalar ops.  Returns the wave mask of lanes whose pixel survives.
+// polarity.  Per pixel slot 10 VALU operations and one scalar OR.  Returns the wave mask of lanes whose pixel survives.
 template <int P>
 __device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int t) {
   const int c = (r[3][(3 + P) >> 2] >> (8 * ((3 + P) & 3))) & 0xFF;
-  const int hi = c + t, lo = c - t;
-  uint64_t B[4], D[4];
+  int v[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int k = 4 * q;
     const int col = 3 + P + kRingDX[k];
-    const int v = (r[3 + kRingDY[k]][col >> 2] >> (8 * (col & 3))) & 0xFF;
-    B[q] = __ballot(v > hi);
-    D[q] = __ballot(v < lo);
+    v[q] = (r[3 + kRingDY[k]][col >> 2] >> (8 * (col & 3))) & 0xFF;
   }
-  // two cyclically adjacent compass points set  <=>  one of {0, 2} and one of {1, 3} set (in a 4-cycle every even
-  // position is adjacent to every odd one): 7 scalar ops instead of 15
-  return ((B[0] | B[2]) & (B[1] | B[3])) | ((D[0] | D[2]) & (D[1] | D[3]));
+  // two cyclically adjacent compass points above c + t  <=>  one of {0, 2} and one of {1, 3} (in a 4-cycle every even
+  // position is adjacent to every odd one)  <=>  min(max(v0, v2), max(v1, v3)) > c + t; likewise below c - t.  The byte
+  // selects ride on the SDWA operands of v_max / v_min, and only two masks reach the scalar ALU (it is nearly as busy
+  // as the vector ALU in this kernel).
+  const int hiMin = min(max(v[0], v[2]), max(v[1], v[3])), loMax = max(min(v[0], v[2]), min(v[1], v[3]));
+  return __ballot(hiMin > c + t) | __ballot(loMax < c - t);
 }
 
 // FAST contrast of one pixel from the LDS tile: M = max over the 16 nine-pixel arcs of the arc's minimum
