@@ -89,6 +89,7 @@ void build_tables(orbx_extractor* ex) {
 int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why) {
   std::memset(&g, 0, sizeof(g));
   const int L = ex->prm.nlevels;
+  for (int l = 0; l < ORBX_MAX_LEVELS; l++) g.levelCell[l] = INT_MAX;
   g.nlevels = L;
   g.iniTh = ex->prm.ini_th_fast;
   g.minTh = ex->prm.min_th_fast;
@@ -114,6 +115,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     v.wCell = (int)std::ceil(width / v.nCols);
     v.hCell = (int)std::ceil(height / v.nRows);
     v.cellStart = cells;
+    g.levelCell[l] = cells;
     cells += v.nCols * v.nRows;
     v.quota = ex->nfeat[l];
     const int nIni = (int)std::round(width / height);

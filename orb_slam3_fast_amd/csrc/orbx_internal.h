@@ -40,6 +40,7 @@ struct Geom {
   long long pyrImg;              // bytes per image of the internal pyramid block
   long long candImg;             // dense candidate entries per image
   long long cellImg;             // per-cell slot entries per image
+  int levelCell[ORBX_MAX_LEVELS];  // lv[l].cellStart again, contiguous (INT_MAX past the last level): k_detect's level lookup
   LevelDev lv[ORBX_MAX_LEVELS];
 };
 

@@ -388,7 +388,10 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
 
 // wave mask of the lanes below n (n <= 0: none, n >= 64: all) -- scalar ALU only
 __device__ __forceinline__ uint64_t low_lanes(int n) {
-  return n >= 64 ? ~0ull : (n > 0 ? (1ull << n) - 1ull : 0ull);
+  return n > 0 ? ~0ull >> (64 - min(n, 64)) : 0ull;
+}
+__device__ __forceinline__ uint64_t low_lanes_pos(int n) {  // n >= 1
+  return ~0ull >> (64 - min(n, 64));
 }
 
 // XCD-aware block -> tile mapping.  Workgroups go to the 8 XCDs round-robin by flat workgroup id, so neighbouring
@@ -396,10 +399,20 @@ __device__ __forceinline__ uint64_t low_lanes(int n) {
 // the dispatch order balanced (every aligned chunk of 8*K flat ids still covers the same 8*K tiles) but hands each
 // XCD a run of K consecutive tiles.  `by` is the slower grid index (image); chunks cut by an image boundary keep
 // the identity order.
-__device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
+__device__ __forceinline__ int xcd_run_remap_rt(int bx, int nbx, int by, int K) {  // run length chosen at run time
   if (K <= 1) return bx;
   const int o = (int)(((unsigned)by * (unsigned)nbx) & 7u), xs = bx + o, ch = 8 * K;
   const int c0 = (xs / ch) * ch;
+  if (c0 < o || c0 + ch > nbx + o) return bx;
+  const int r = xs - c0;
+  return c0 + (r & 7) * K + (r >> 3) - o;
+}
+template <int K>
+__device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by) {
+  if (K <= 1) return bx;
+  constexpr int ch = 8 * K;  // (K a power of two: the chunk arithmetic is shifts and masks)
+  const int o = (int)(((unsigned)by * (unsigned)nbx) & 7u), xs = bx + o;
+  const int c0 = xs & ~(ch - 1);
   if (c0 < o || c0 + ch > nbx + o) return bx;
   const int r = xs - c0;
   return c0 + (r & 7) * K + (r >> 3) - o;
@@ -418,7 +431,7 @@ __device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by, int K) {
 // occupancy than 5 % fewer instructions buy.  Instantiated for the pitches of the usual cell widths (33..52 px).
 template <bool TAP, int TPC>
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
-                                               int* __restrict__ cellCount, int listCap, int cellBegin, int xcdRun,
+                                               int* __restrict__ cellCount, int listCap, int cellBegin,
                                                uint8_t* __restrict__ dbgScore) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x;
@@ -438,13 +451,16 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 #endif
   // Runs of xcdRun horizontally consecutive cells share an XCD and therefore the L2 lines of their common halo
   // columns (HBM-side fetch 410 -> 151 MB per 64-image launch; same duration, the kernel is VALU-bound).
-  int cell = cellBegin + xcd_run_remap(blockIdx.x, gridDim.x, blockIdx.y, xcdRun);
-  int l = 0;
-  while (l + 1 < g.nlevels && cell >= g.lv[l + 1].cellStart) l++;
+  int cell = cellBegin + xcd_run_remap<kDetectXcdRun>(blockIdx.x, gridDim.x, blockIdx.y);
+  int l = 0;  // the scalar ALU is nearly as busy as the vector ALU in this kernel: no search loop, no integer divisions
+#pragma unroll
+  for (int q = 1; q < ORBX_MAX_LEVELS; q++) l += cell >= g.levelCell[q] ? 1 : 0;
   const LevelDev L = g.lv[l];
   int* myCount = cellCount + (long long)img * g.totalCells + cell;
   cell -= L.cellStart;
-  const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+  // cell / nCols by a 1-ulp reciprocal: (cell + 0.5) / nCols stays 0.5 / nCols away from the next integer
+  const int ci = __builtin_amdgcn_readfirstlane((int)(((float)cell + 0.5f) * __builtin_amdgcn_rcpf((float)L.nCols))),
+            cj = cell - ci * L.nCols;
   const int maxBX = L.w - kBorder, maxBY = L.h - kBorder;
   const int iniY = kBorder + ci * L.hCell, iniX = kBorder + cj * L.wCell;
   const int maxY = min(iniY + L.hCell + 6, maxBY), maxX = min(iniX + L.wCell + 6, maxBX);
@@ -517,6 +533,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   // a round of 64 quads advances a lane by dq rows and rq quads (no division per round)
   const int dq = __builtin_amdgcn_readfirstlane((int)(64.5f * inv_qpr)), rq = 64 - dq * qpr;
   const int vlast = dw - 4 * (qpr - 1);  // pixels of a row's last quad inside the detectable window (1..4)
+  const uint64_t keep1 = vlast > 1 ? ~0ull : 0ull, keep2 = vlast > 2 ? ~0ull : 0ull, keep3 = vlast > 3 ? ~0ull : 0ull;
   const int yd0 = (int)(((float)lane + 0.5f) * inv_qpr), j0 = lane - __mul24(yd0, qpr);
   const int nScore16 = (SPd * (dh + 2) + 3) >> 2;
   for (int pass = 0; pass < 2; pass++) {
@@ -567,7 +584,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     };
     int yd = yd0, j = j0;
     for (int qb = 0; qb < nq; qb += 64) {
-      const uint64_t actM = low_lanes(nq - qb);
+      const uint64_t actM = low_lanes_pos(nq - qb);
       const int ydc = min(yd, dh - 1);  // idle lanes of the last round stay inside the tile (masked out below)
       const uint32_t* row0 = tile + __mul24(ydc, TPd) + j;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
       uint32_t r[7][3];
@@ -580,9 +597,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       const uint64_t notLast = ~__ballot(j == qpr - 1);  // a row's last quad may reach past the detectable window
       uint64_t sm[4];
       sm[0] = compass_wave<0>(r, t) & actM;
-      sm[1] = compass_wave<1>(r, t) & (vlast > 1 ? actM : actM & notLast);
-      sm[2] = compass_wave<2>(r, t) & (vlast > 2 ? actM : actM & notLast);
-      sm[3] = compass_wave<3>(r, t) & (vlast > 3 ? actM : actM & notLast);
+      sm[1] = compass_wave<1>(r, t) & actM & (notLast | keep1);
+      sm[2] = compass_wave<2>(r, t) & actM & (notLast | keep2);
+      sm[3] = compass_wave<3>(r, t) & actM & (notLast | keep3);
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (nSurv + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > survCap) flush_survivors();
       const int yx = (ydc << 8) | (4 * j);
@@ -590,7 +607,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
         if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
-          slist[nSurv + prefix_count(m)] = (uint16_t)(yx | pI);
+          slist[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)nSurv))] =
+              (uint16_t)(yx | pI);  // (the running count rides in v_mbcnt's accumulator operand)
         nSurv += __popcll(m);
       }
       j += rq;
@@ -693,8 +711,7 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
   if (cellEnd <= cellBegin) return hipSuccess;
   dim3 grid(cellEnd - cellBegin, nimg);
   auto go = [&](auto kern) {
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin, kDetectXcdRun,
-                       dbgScore);
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin, dbgScore);
   };
   const int tp = (!dbgScore && g.scoreP == g.tileP - 4) ? g.tileP : 0;
   switch (tp) {
@@ -2005,7 +2022,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
                                                            // (quad-transposed columns: both passes bank-conflict free)
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  int tile = xcd_run_remap(blockIdx.x, gridDim.x, blockIdx.z, xcdRun);
+  int tile = xcd_run_remap_rt(blockIdx.x, gridDim.x, blockIdx.z, xcdRun);
   int l = level0;
   for (;; l++) {  // tiles of levels [level0, level1) are enumerated in one grid dimension
     const int tx = (g.lv[l].w + BL_TW - 1) / BL_TW, ty = (g.lv[l].h + BL_TH - 1) / BL_TH;
