@@ -417,6 +417,28 @@ def main():
                     streaming[k]["valu_frac"] = round(pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1) * 4
                                                       / (N_SIMD * CLOCK_HZ * us * 1e-6), 4)
         out["roofline"]["streaming"] = streaming
+        if rank == 0:  # "also report against a measured device-copy peak" -- a 512 MiB device-to-device copy
+            try:
+                src_t = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+                dst_t = torch.empty_like(src_t)
+                src_t.fill_(3)
+                for _ in range(3):
+                    dst_t.copy_(src_t)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    dst_t.copy_(src_t)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 10 * 2 * src_t.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9   # bytes read + bytes written
+                del src_t, dst_t
+                out["roofline"]["measured_copy_GBps"] = round(copy_gbs, 1)
+                out["roofline"]["frac_of_measured_copy"] = round(ach / copy_gbs, 5)
+                for k in streaming:
+                    streaming[k]["frac_of_measured_copy"] = round(streaming[k]["algorithmic_GBps"] / copy_gbs, 4)
+            except Exception as ex_:  # the copy is context, never a reason to lose the line
+                out["roofline"]["measured_copy_GBps"] = None
+                out["roofline"]["measured_copy_error"] = str(ex_)[:120]
         out["stages"] = stages
         out["stages_note"] = ("per-stage HIP-event table from %d extra single-handle steps (synchronised, no overlap "
                               "between batches) after the timed region" % nprof)

@@ -447,8 +447,9 @@ void orbx_debug_introsort(uint64_t* v, int n);
 /* The wave-cooperative device version the quadtree kernel actually runs (n <= 4000). */
 int orbx_debug_introsort_device(int device, uint64_t* v, int n);
 
-/* Shrinks (>= 320) or restores (1024) the capacity of k_detect's LDS survivor / corner lists so that tests can
- * force the list-overflow paths (mid-cell flushes, tile-scan NMS) that natural images never reach. */
+/* Shrinks (>= 320 entries) or restores (any larger value) the capacity of k_detect's LDS corner + survivor list so
+ * that tests can force the paths natural images rarely reach: mid-cell flushes, the corner limit and the tile-scan
+ * NMS behind it. */
 void orbx_debug_set_detect_list_cap(int cap);
 /* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
  * than 16384 FAST candidates); 0 restores the register-resident path. */

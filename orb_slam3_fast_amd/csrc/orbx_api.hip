@@ -150,7 +150,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
     return ORBX_E_UNSUPPORTED;
   }
   g.totalCells = cells;
-  g.tileP = 4 * ((maxCW + 3) / 4 + 3);   // quads per row + 2 dwords of read-ahead + 1
+  g.tileP = 4 * ((maxCW + 3) / 4 + 2);   // quads per row + 2 dwords (the 6 px halo = the 2 dwords a lane reads past its quad)
   g.tileH = maxCH + 6;
   g.scoreP = 4 * ((maxCW + 3) / 4 + 2);  // 1 dword zero pad left + quads + 1 dword zero pad right
   g.scoreH = maxCH + 2;

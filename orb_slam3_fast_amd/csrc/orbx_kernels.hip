@@ -269,11 +269,9 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 // mask has 9 contiguous ones (shift-and ladder).
 constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-constexpr int kListCap = 640;    // upper bound of the test hook orbx_debug_set_detect_list_cap
-constexpr int kSurvCap = 448;    // LDS list of compass-test survivors of k_detect (flushed before it would overflow)
+constexpr int kListTotal = 704;  // u16 entries of k_detect's one LDS list: corners [0, nList), then compass survivors [nList, sEnd)
 constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
 constexpr int kLoadRows = 12;   // rows per lane the tile loader of k_detect keeps in flight
-constexpr int kCornerCap = 256;  // LDS corner list (a cell with more corners takes the tile-scan NMS)
 
 __device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
   uint32_t d = m | (m << 16);
@@ -359,26 +357,34 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
     v.y = b8[off];  // ds_read_u8_d16_hi: the pair is packed by the loads
     r[k] = __builtin_bit_cast(orbx_h2, v);
   }
-  orbx_h2 lo3[16], hi3[16];
+  // one polarity after the other (the scheduling barrier keeps them apart): 16 ring values + 16 three-windows live at a
+  // time instead of both polarities' windows -- the kernel's register peak is here, and 64 VGPRs mean 8 waves per SIMD
+  orbx_h2 maxmin, minmax;
+  {
+    orbx_h2 w3[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo3[i] = pk_min3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
-    hi3[i] = pk_max3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
-  }
-  orbx_h2 lo9[16], hi9[16];
+    for (int i = 0; i < 16; i++) w3[i] = pk_min3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+    orbx_h2 w9[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo9[i] = pk_min3(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
-    hi9[i] = pk_max3(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
-  }
-  orbx_h2 maxmin = pk_max3(lo9[0], lo9[1], lo9[2]), minmax = pk_min3(hi9[0], hi9[1], hi9[2]);
+    for (int i = 0; i < 16; i++) w9[i] = pk_min3(w3[i], w3[(i + 3) & 15], w3[(i + 6) & 15]);
+    maxmin = pk_max3(w9[0], w9[1], w9[2]);
 #pragma unroll
-  for (int i = 3; i < 15; i += 2) {
-    maxmin = pk_max3(maxmin, lo9[i], lo9[i + 1]);
-    minmax = pk_min3(minmax, hi9[i], hi9[i + 1]);
+    for (int i = 3; i < 15; i += 2) maxmin = pk_max3(maxmin, w9[i], w9[i + 1]);
+    maxmin = __builtin_elementwise_maximum(maxmin, w9[15]);
   }
-  maxmin = __builtin_elementwise_maximum(maxmin, lo9[15]);
-  minmax = __builtin_elementwise_minimum(minmax, hi9[15]);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    orbx_h2 w3[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w3[i] = pk_max3(r[i], r[(i + 1) & 15], r[(i + 2) & 15]);
+    orbx_h2 w9[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w9[i] = pk_max3(w3[i], w3[(i + 3) & 15], w3[(i + 6) & 15]);
+    minmax = pk_min3(w9[0], w9[1], w9[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) minmax = pk_min3(minmax, w9[i], w9[i + 1]);
+    minmax = __builtin_elementwise_minimum(minmax, w9[15]);
+  }
   orbx_us2 cv;
   cv.x = a8[3 * TP + 3];
   cv.y = b8[3 * TP + 3];
@@ -471,14 +477,19 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     return;
   }
 
-  const int TP = TPC ? TPC : g.tileP, SPB = TPC ? TPC - 4 : g.scoreP;  // tile pitches in bytes
+  const int TP = TPC ? TPC : g.tileP, SPB = TP;  // pitch of the image tile and of the score tile, bytes (tileP == scoreP)
   const int TPd = TP >> 2, SPd = SPB >> 2;                          // and in dwords
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
   uint32_t* score = tile + ((TPd * g.tileH + 3) & ~3);  // 16-byte aligned: cleared with b128 stores
   uint8_t* score8 = reinterpret_cast<uint8_t*>(score);
-  uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);  // kCornerCap corner positions (y << 8 | x)
-  uint16_t* slist = list + kCornerCap;                                   // kSurvCap compass-test survivors
-  const int survCap = min(listCap, kSurvCap), cornerCap = min(listCap, kCornerCap);
+  // One list of positions (y << 8 | x): the cell's corners so far in front, the survivors waiting for the contrast pass
+  // behind them.  A flush turns survivors into (fewer) corners in place -- entry k of the survivors is read before corner
+  // k is written -- so the 704 entries that used to be 256 corners + 448 survivors now hold up to 448 corners (busy cells
+  // of the benchmark frames exceed 256 and paid for the tile-scan NMS) or ~650 survivors.  A round appends at most 256
+  // survivors, hence the corner limit of total - 256.  Measured: 480 entries (32 cells per CU instead of 29) 270 us, 704
+  // entries 245 us, 832 entries 246 us, 1024 entries (26 cells) 261 us.
+  uint16_t* list = reinterpret_cast<uint16_t*>(score + SPd * g.scoreH);
+  const int listTotal = min(listCap, kListTotal), cornerCap = listTotal - 256;
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile);
   const int qpr = (dw + 3) >> 2;  // quads per detect row
   const int nq = qpr * dh;
@@ -548,28 +559,29 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     //          goes to the u8 score tile and the corner to the corner list (for the list-based NMS).
     // Lane validity is wave-uniform knowledge (entries base .. n-1 of a list are valid): it lives in scalar masks that
     // are ANDed with the v_cmp results, never in per-lane predicates.
-    int nList = 0, nSurv = 0;
+    int nList = 0, sEnd = 0;
     bool overflowed = false;  // more corners than the list holds: the NMS falls back to scanning the score tile
     auto flush_survivors = [&]() {
       __syncthreads();
       const orbx_h2 th2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);  // t in the same subnormal encoding
+      const int s0 = nList, nSurv = sEnd - s0;
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
         const int rem = nSurv - base;
         const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
-        const int yxA = slist[min(base + lane, nSurv - 1)], yxB = slist[min(base + 64 + lane, nSurv - 1)];
+        const int yxA = list[s0 + min(base + lane, nSurv - 1)], yxB = list[s0 + min(base + 64 + lane, nSurv - 1)];
         const int yA = yxA >> 8, xA = yxA & 255, yB = yxB >> 8, xB = yxB & 255;
         const int oA = __mul24(yA, TP) + xA, oB = __mul24(yB, TP) + xB;  // top-left corners of the 7x7 windows
         const orbx_h2 M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
         const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
         if (__builtin_amdgcn_inverse_ballot_w64(mA)) {
-          score8[TPC ? oA - 4 * yA + (SPB + 4) : __mul24(yA + 1, SPB) + xA + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);
-          const int o = nList + prefix_count(mA);
+          score8[oA + SPB + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);  // (y + 1) * pitch + x + 4: same pitch as the image tile
+          const int o = nList + prefix_count(mA);  // <= the position of the survivor it replaces
           if (o < cornerCap) list[o] = (uint16_t)yxA;
         }
         nList += __popcll(mA);
         if (__builtin_amdgcn_inverse_ballot_w64(mB)) {
-          score8[TPC ? oB - 4 * yB + (SPB + 4) : __mul24(yB + 1, SPB) + xB + 4] = (uint8_t)((Mbits >> 16) - 1);
+          score8[oB + SPB + 4] = (uint8_t)((Mbits >> 16) - 1);
           const int o = nList + prefix_count(mB);
           if (o < cornerCap) list[o] = (uint16_t)yxB;
         }
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         nList = cornerCap;
       }
       __syncthreads();
-      nSurv = 0;
+      sEnd = nList;
     };
     int yd = yd0, j = j0;
     for (int qb = 0; qb < nq; qb += 64) {
@@ -601,15 +613,15 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       sm[2] = compass_wave<2>(r, t) & actM & (notLast | keep2);
       sm[3] = compass_wave<3>(r, t) & actM & (notLast | keep3);
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
-      if (nSurv + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > survCap) flush_survivors();
+      if (sEnd + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > listTotal) flush_survivors();
       const int yx = (ydc << 8) | (4 * j);
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
         if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
-          slist[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)nSurv))] =
-              (uint16_t)(yx | pI);  // (the running count rides in v_mbcnt's accumulator operand)
-        nSurv += __popcll(m);
+          list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)sEnd))] =
+              (uint16_t)(yx | pI);  // (the running end of the list rides in v_mbcnt's accumulator operand)
+        sEnd += __popcll(m);
       }
       j += rq;
       yd += dq;
@@ -699,13 +711,13 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   if (lane == 0) *myCount = min(kept, L.cellCap);
 }
 
-static int g_detect_list_cap = kListCap;
-void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : (cap > kListCap ? kListCap : cap); }
+static int g_detect_list_cap = kListTotal;  // test hook: a smaller list forces the flush / carry / corner-overflow paths
+void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : (cap > kListTotal ? kListTotal : cap); }
 
 // Cells of levels [level0, level1) only: level 0 needs no resize and is launched beside the pyramid chain.
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, uint8_t* dbgScore, hipStream_t s) {
-  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 32;
+  const size_t lds = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListTotal + 32;
   const int cellBegin = g.lv[level0].cellStart;
   const int cellEnd = level1 < g.nlevels ? g.lv[level1].cellStart : g.totalCells;
   if (cellEnd <= cellBegin) return hipSuccess;
@@ -713,12 +725,12 @@ hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCa
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, dim3(64), lds, s, g, p, cellCand, cellCount, g_detect_list_cap, cellBegin, dbgScore);
   };
-  const int tp = (!dbgScore && g.scoreP == g.tileP - 4) ? g.tileP : 0;
+  const int tp = (!dbgScore && g.scoreP == g.tileP) ? g.tileP : 0;
   switch (tp) {
+    case 44: go(k_detect<false, 44>); break;
     case 48: go(k_detect<false, 48>); break;
     case 52: go(k_detect<false, 52>); break;
     case 56: go(k_detect<false, 56>); break;
-    case 60: go(k_detect<false, 60>); break;
     default:
       if (dbgScore) go(k_detect<true, 0>); else go(k_detect<false, 0>);
   }
@@ -2514,7 +2526,7 @@ hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t
 
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
-  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * (kSurvCap + kCornerCap) + 32;
+  const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListTotal + 32;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
   if (e != hipSuccess) return e;
@@ -2527,8 +2539,8 @@ hipError_t prepare_kernels(const Geom& g) {
     if (e != hipSuccess) return e;
   }
   const void* dk[6] = {reinterpret_cast<const void*>(k_detect<true, 0>),   reinterpret_cast<const void*>(k_detect<false, 0>),
-                       reinterpret_cast<const void*>(k_detect<false, 48>), reinterpret_cast<const void*>(k_detect<false, 52>),
-                       reinterpret_cast<const void*>(k_detect<false, 56>), reinterpret_cast<const void*>(k_detect<false, 60>)};
+                       reinterpret_cast<const void*>(k_detect<false, 44>), reinterpret_cast<const void*>(k_detect<false, 48>),
+                       reinterpret_cast<const void*>(k_detect<false, 52>), reinterpret_cast<const void*>(k_detect<false, 56>)};
   for (const void* f : dk) {
     e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_det);
     if (e != hipSuccess) return e;

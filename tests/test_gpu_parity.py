@@ -70,8 +70,9 @@ def test_stages_and_end_to_end(gpu, oracle, w, h, nf, nl, stream):
 
 
 def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
-    """White noise puts ~340 corners in a 36x37 cell; with the LDS lists shrunk to 320 entries that forces the
-    survivor-list and corner-list flushes and the tile-scan NMS fallback of k_detect."""
+    """White noise puts ~340 corners in a 36x37 cell; with the LDS list shrunk to its minimum (320 entries: 64 corners,
+    the rest survivors) that forces mid-cell flushes, the corner limit and the tile-scan NMS fallback of k_detect; the
+    default capacity (704) takes the same images through the common paths."""
     rng = np.random.default_rng(9)
     w, h = 400, 300
     noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
@@ -80,7 +81,7 @@ def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
     ex = orbx.ORBextractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h)
     oe = oracle.OracleExtractor(800, 1.2, 8, 20, 7)
     try:
-        for cap in (320, 1024):
+        for cap in (320, 512, 1024):
             orbx.lib().orbx_debug_set_detect_list_cap(cap)
             for img in (noise, mixed):
                 mono, k, d = ex(img)
