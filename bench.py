@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--h2d-steps", type=int, default=30)
     ap.add_argument("--handles", type=int, default=3,
                     help="extractor handles used round-robin (each owns a stream + buffers); batches of different handles overlap on the GPU: the "
-                         "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others (1: 41.1 k, 2: 43.5 k, 3: 44.6 k pairs/s)")
+                         "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others (1: 52.6 k, 2: 60.7 k, 3: 60.8 k, 4: 57.0 k pairs/s)")
     ap.add_argument("--mode", choices=("stereo", "mono", "fisheye"), default="stereo",
                     help="stereo = BASELINE config C3 (the headline metric); mono = extraction only (C2: --width 640 "
                          "--height 480 --nfeatures 1000), value counts single frames; fisheye = C4 (--width 512 --height 512):"

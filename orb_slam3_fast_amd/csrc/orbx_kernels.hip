@@ -430,11 +430,10 @@ __device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by) {
 // Output: no atomics.  Every cell owns cellCap slots of the sparse store (an NMS survivor set has at most
 // ceil(w/2)*ceil(h/2) members) and writes its count; k_octree scans the counts and compacts.
 // TAP: the test tap of orbx_debug_score_map, a separate instantiation (its registers cost the product kernel 3.5 %).
-// TPC: compile-time LDS pitch of the image tile (the score tile's is TPC - 4), 0 = run-time pitches.  With a constant
-// pitch the 16 ring offsets of the contrast pass and the 8 NMS neighbours fold into the ds_read immediate offsets instead
-// of costing one v_add each (34 of the 147 VALU instructions of a contrast pass).  The pitch must stay the tight one of
-// the geometry: padding it to 64 made the kernel 6 % SLOWER (378 vs 356 us) -- 0.8 KB more LDS per cell costs more
-// occupancy than 5 % fewer instructions buy.  Instantiated for the pitches of the usual cell widths (33..52 px).
+// TPC: compile-time LDS pitch of the image tile and of the score tile (the same), 0 = run-time pitch.  With a constant
+// pitch the ring offsets of the contrast pass, the NMS neighbours and the three rows of a stage-1 quad fold into the
+// ds_read immediate offsets instead of costing one v_add each.  The pitch must stay the tight one of the geometry:
+// padding it to 64 made the kernel 6 % SLOWER.  Instantiated for the pitches of the usual cell widths (33..48 px).
 template <bool TAP, int TPC>
 __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restrict__ cellCand,
                                                int* __restrict__ cellCount, int listCap, int cellBegin,
