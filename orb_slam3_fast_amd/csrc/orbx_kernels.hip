@@ -259,28 +259,19 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 }
 
 // ================================================================================================ detect
-// FAST-9-16 on an LDS tile, four horizontally adjacent pixels per lane.
+// FAST-9-16 on an LDS tile, in two stages (k_detect).
 //
 // Layout: the cell ROI (cell + 3 px FAST halo each side) sits in LDS with ROI column 0 on a dword boundary
-// (the loader funnel-shifts the unaligned global row).  A lane owns a "quad" of 4 detectable pixels; the 7x10
-// byte neighbourhood it needs is 7 rows x 3 dwords, read with 21 ds_read_b32 and kept in registers, so every
-// ring byte is a compile-time (register, byte) pair.  Per ring pixel and polarity: one subtract and one
-// v_alignbit funnel shift that appends the sign bit to a 16-bit arc mask; a 9-arc exists iff the doubled
-// mask has 9 contiguous ones (shift-and ladder).
+// (the loader funnel-shifts the unaligned global row).  Stage 1: a lane owns a "quad" of 4 detectable pixels and reads
+// the three rows that hold ring pixels 0 / 4 / 8 / 12 of the quad (7 dwords, kept in registers, every ring byte a
+// compile-time (register, byte) pair -> SDWA operands) for the compass pre-test; survivors go to an LDS list.
+// Stage 2: dense lanes, two survivors per lane in packed f16: the exact contrast M from the 16 ring pixels (sliding
+// 9-windows of minima / maxima built from 3-windows); corner iff M > t, score M - 1.  Then list-based 3x3 NMS.
 constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
 constexpr int kListTotal = 704;  // u16 entries of k_detect's one LDS list: corners [0, nList), then compass survivors [nList, sEnd)
 constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
 constexpr int kLoadRows = 12;   // rows per lane the tile loader of k_detect keeps in flight
-
-__device__ __forceinline__ bool has_arc9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
-  uint32_t d = m | (m << 16);
-  uint32_t x = d & (d >> 1);
-  x &= x >> 2;
-  x &= x >> 4;
-  x &= d >> 8;
-  return (x & 0xFFFFu) != 0;
-}
 
 // Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
 // polarity.  Per pixel slot 10 VALU operations and one scalar OR.  Returns the wave mask of lanes whose pixel survives.
@@ -302,37 +293,11 @@ __device__ __forceinline__ uint64_t compass_wave(const uint32_t (&r)[7][3], int 
   return __ballot(hiMin > c + t) | __ballot(loMax < c - t);
 }
 
-// FAST contrast of one pixel from the LDS tile: M = max over the 16 nine-pixel arcs of the arc's minimum
-// one-signed contrast = max( max_s min(arc_s) - c , c - min_s max(arc_s) ).  Sliding 9-windows are built from
-// 3-windows (v_min3 / v_max3): 16 + 16 + 8 three-input ops per polarity.  The pixel is a corner at threshold t
-// iff M > t, and its cornerScore is M - 1 — one pass gives both the decision and the score.
-__device__ __forceinline__ int fast_contrast_lds(const uint8_t* c8, int TP) {
-  int r[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) r[k] = c8[kRingDY[k] * TP + kRingDX[k]];
-  int lo3[16], hi3[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo3[i] = min(min(r[i], r[(i + 1) & 15]), r[(i + 2) & 15]);
-    hi3[i] = max(max(r[i], r[(i + 1) & 15]), r[(i + 2) & 15]);
-  }
-  int lo9[16], hi9[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    lo9[i] = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);
-    hi9[i] = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
-  }
-  int maxmin = lo9[0], minmax = hi9[0];
-#pragma unroll
-  for (int i = 1; i < 16; i++) {
-    maxmin = max(maxmin, lo9[i]);
-    minmax = min(minmax, hi9[i]);
-  }
-  const int c = c8[0];
-  return max(maxmin - c, c - minmax);
-}
-
-// Two pixels per lane: the same contrast computation in packed half precision.  A pixel value v (0..255) is used
+// FAST contrast of a pixel: M = max over the 16 nine-pixel arcs of the arc's minimum one-signed contrast
+// = max( max_s min(arc_s) - c , c - min_s max(arc_s) ).  Sliding 9-windows are built from 3-windows: 16 + 16 + 8
+// three-input operations per polarity.  The pixel is a corner at threshold t iff M > t, and its cornerScore is M - 1
+//  -- one pass gives both the decision and the score.
+// Two pixels per lane in packed half precision.  A pixel value v (0..255) is used
 // as the f16 BIT PATTERN v, i.e. the subnormal v * 2^-24 (kernels run with f16 denormals preserved,
 // .amdhsa_float_denorm_mode_16_64 3): order preserving, and sums / differences of such values (|d| <= 255) are exact
 // multiples of 2^-24, so v_pk_minimum3_f16 / v_pk_maximum3_f16 / v_pk_add_f16 give bit-exact integer results for two
