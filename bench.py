@@ -22,6 +22,7 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -286,8 +287,11 @@ def main():
     # workload run for --preheat-ms first; the W warm-up steps follow, then the timed region, with no host-side pause.
     preheat_steps = 0
     if a.preheat_ms > 0:
+        # with a collective inside the step (config C5) every rank must run the SAME number of steps: a fixed count then
+        fixed_rounds = int(math.ceil(a.preheat_ms / 0.55 / len(exs))) if (a.allgather and dist is not None) else 0
         tp = time.perf_counter()
-        while (time.perf_counter() - tp) * 1000.0 < a.preheat_ms and preheat_steps < 2000:
+        while (preheat_steps < fixed_rounds * len(exs)) if fixed_rounds else \
+                ((time.perf_counter() - tp) * 1000.0 < a.preheat_ms and preheat_steps < 2000):
             for _ in range(len(exs)):
                 step()
             preheat_steps += len(exs)
