@@ -42,6 +42,9 @@ def test_bench_prints_one_contract_line(mode):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert d["config"]["distinct_streams_per_gpu"] == 2 and d["config"]["frames_in_ring"] == 3
     assert "streaming" in rf and "limited_by" in rf
+    # the preheat (untimed steps before the warm-up: GPU clock ramp) is reported, the warm-up count stays the caller's
+    assert d["warmup"] == 1 and d["preheat_steps"] >= len(lines) and d["preheat_steps"] % d["config"]["handles"] == 0
+    assert rf["measured_copy_GBps"] is None or (rf["measured_copy_GBps"] > 100 and rf["frac_of_measured_copy"] > 0)
     if mode == "stereo":
         cb = d["cpu_baseline"]
         assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and cb["kind"] == "port" and cb["value"] > 0
@@ -63,3 +66,5 @@ def test_bench_c5_mode_prints_one_contract_line():
     assert KEYS <= set(d) and d["value"] > 0 and d["config"]["workload"].startswith("C5")
     assert d["config"]["pairs_per_step_per_gpu"] == 16 and d["config"]["distinct_streams_per_gpu"] == 8
     assert d["config"]["allgather_bytes_per_step_per_gpu"] > 0
+    # a collective inside the step: the preheat runs a FIXED number of steps (all ranks must issue the same all-gathers)
+    assert d["preheat_steps"] == 3 * ((int(40.0 / 0.55 / 3) + 1))
