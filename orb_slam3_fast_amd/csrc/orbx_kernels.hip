@@ -2408,11 +2408,11 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
           h[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 3), wA,
                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 3), wB, 0, false), false);
         }
-        uint4 pk;
-        pk.x = h[0][0] | (h[1][0] << 16);
-        pk.y = h[0][1] | (h[1][1] << 16);
-        pk.z = h[0][2] | (h[1][2] << 16);
-        pk.w = h[0][3] | (h[1][3] << 16);
+        uint4 pk;  // H(2j, x) | H(2j + 1, x) << 16: one v_perm per column (sums of 7 taps x 255 fit 16 bits)
+        pk.x = __builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u);
+        pk.y = __builtin_amdgcn_perm(h[1][1], h[0][1], 0x05040100u);
+        pk.z = __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u);
+        pk.w = __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u);
         *reinterpret_cast<uint4*>(hbase + 6 * DW_HP * t) = pk;
       }
     }
