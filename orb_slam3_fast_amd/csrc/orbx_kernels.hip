@@ -2227,6 +2227,18 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 // the circle (|u| <= umax[|v|]), .y = (u + 16) per such byte (1..31), so that with wd = the four pixels
 //   sum(val) = v_dot4(wd, .x)      sum(u * val) = v_dot4(wd, .y) - 16 * sum(val)
 // -- two dot products per dword instead of four masked multiply-adds (the kernel is VALU-issue bound).
+// Sum over the 64 lanes of a wave, returned wave-uniform: prefix sums inside each row of 16 lanes by DPP row shifts,
+// then the row totals travel down with row_bcast:15 / row_bcast:31 and lane 63 holds the total.
+__device__ __forceinline__ int wave_sum_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct IcTable {
   uint2 e[4][5 * 64];
 };
@@ -2369,11 +2381,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
       rv += 7;
     }
     m10 = sw - 16 * srs;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      m10 += __shfl_xor(m10, o);
-      m01 += __shfl_xor(m01, o);
-    }
+    m10 = wave_sum_dpp(m10);  // (six v_add_dpp each; __shfl_xor would be a ds_bpermute + address arithmetic per step)
+    m01 = wave_sum_dpp(m01);
   }
   const float angle = fast_atan2_dev((float)m01, (float)m10);
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
