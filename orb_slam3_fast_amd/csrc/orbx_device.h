@@ -18,6 +18,49 @@ __device__ __forceinline__ uint32_t udot2_u16(uint32_t a, uint32_t b, uint32_t c
   return __builtin_amdgcn_udot2(__builtin_bit_cast(orbx_us2, a), __builtin_bit_cast(orbx_us2, b), c, false);
 }
 
+// ---- cross-lane sums / scans / minima by DPP (gfx9 row shifts + row broadcasts): one VALU instruction per step, where
+// __shfl_up / __shfl_xor cost a ds_bpermute round trip through the LDS pipe plus its address arithmetic.
+// Inclusive prefix sum over the 64 lanes: prefix sums inside each row of 16 lanes (row_shr 1, 2, 4, 8), then the row
+// totals travel down with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).
+__device__ __forceinline__ int wave_scan_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ int wave_sum_dpp(int v) {  // sum over the wave, wave-uniform
+  return __builtin_amdgcn_readlane(wave_scan_dpp(v), 63);
+}
+__device__ __forceinline__ uint64_t wave_scan_dpp_u64(uint64_t v) {
+#define ORBX_DPP_STEP64(CTRL, ROWMASK, BOUND)                                                              \
+  {                                                                                                         \
+    const uint32_t tl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWMASK, 0xf, BOUND);        \
+    const uint32_t th = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWMASK, 0xf, BOUND); \
+    v += ((uint64_t)th << 32) | tl;                                                                         \
+  }
+  ORBX_DPP_STEP64(0x111, 0xf, true)
+  ORBX_DPP_STEP64(0x112, 0xf, true)
+  ORBX_DPP_STEP64(0x114, 0xf, true)
+  ORBX_DPP_STEP64(0x118, 0xf, true)
+  ORBX_DPP_STEP64(0x142, 0xa, false)
+  ORBX_DPP_STEP64(0x143, 0xc, false)
+#undef ORBX_DPP_STEP64
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {  // minimum over the wave, wave-uniform
+  // (lanes without a source keep their own value: `old` = v)
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* b) {
   int d = 0;
 #pragma unroll

@@ -967,7 +967,7 @@ size_t octree_lds_bytes(const Geom& g) { return (size_t)oct_layout(oct_maxn(g), 
 constexpr int OCT_NT = 512;  // threads per quadtree block: halves the key-loop trip counts vs 256, 2 blocks/CU stay resident
 // Exclusive scan of n u64 values in LDS (in place) by an OCT_NT-thread block; returns the total.
 // Packed fields must not overflow into each other (callers keep each field < 2^21).
-// Per-thread chunk sums are scanned inside each wave with DPP/bpermute shuffles (no barriers); only the four
+// Per-thread chunk sums are scanned inside each wave with DPP row shifts / broadcasts (no barriers); only the
 // wave totals go through LDS: 2 barriers per call instead of the 18 of a Hillis-Steele scan over 256 threads.
 __device__ __forceinline__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -975,12 +975,7 @@ __device__ __forceinline__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t*
   const int b = min(tid * per, n), e = min(b + per, n);
   uint64_t s = 0;
   for (int i = b; i < e; i++) s += v[i];
-  uint64_t incl = s;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint64_t t = __shfl_up((unsigned long long)incl, d);
-    if (lane >= d) incl += t;
-  }
+  const uint64_t incl = wave_scan_dpp_u64(s);
   if (lane == 63) tsum[wv] = incl;
   __syncthreads();
   uint64_t wbase = 0, total = 0;
@@ -1907,16 +1902,8 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
     const int cb = min(tid * per, cells), ce = min(cb + per, cells);
     int sum = 0;
     for (int ci = cb; ci < ce; ci++) sum += cc[ci];
-    int incl = sum;
-    {
-      const int lane = tid & 63;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-      }
-      if (lane == 63) c.tsum[tid >> 6] = (uint64_t)incl;
-    }
+    const int incl = wave_scan_dpp(sum);
+    if ((tid & 63) == 63) c.tsum[tid >> 6] = (uint64_t)incl;
     __syncthreads();
     int wbase = 0, total = 0;
 #pragma unroll
@@ -2227,18 +2214,6 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 // the circle (|u| <= umax[|v|]), .y = (u + 16) per such byte (1..31), so that with wd = the four pixels
 //   sum(val) = v_dot4(wd, .x)      sum(u * val) = v_dot4(wd, .y) - 16 * sum(val)
 // -- two dot products per dword instead of four masked multiply-adds (the kernel is VALU-issue bound).
-// Sum over the 64 lanes of a wave, returned wave-uniform: prefix sums inside each row of 16 lanes by DPP row shifts,
-// then the row totals travel down with row_bcast:15 / row_bcast:31 and lane 63 holds the total.
-__device__ __forceinline__ int wave_sum_dpp(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
 struct IcTable {
   uint2 e[4][5 * 64];
 };

@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
     }
   }
   const uint32_t mine = best;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o));
+  best = wave_min_dpp(best);
   const int bestDist = (int)(best >> 16);
   if (bestDist < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
     const uint64_t owners = __ballot(mine == best);  // iR is unique per candidate: exactly the lane(s) that saw it
@@ -136,9 +135,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, St
       for (int inc = 0; inc < 11; inc++) {
         int s = abs(l0 - (int)imR[(long long)(yl + y0) * pitchR + xr0 + (inc - 5) + x0]);
         if (p1 < 121) s += abs(l1 - (int)imR[(long long)(yl + y1) * pitchR + xr0 + (inc - 5) + x1]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        sadv[inc] = s;
+        sadv[inc] = wave_sum_dpp(s);  // (six v_add_dpp; the 11 sums are independent chains)
       }
       int bestSad = 0x7FFFFFFF, bestinc = 0;
 #pragma unroll
