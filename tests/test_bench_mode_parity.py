@@ -11,6 +11,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # at COLLECTION time, i.e. before any test has loaded liborbx.so: liborbx then binds to the HIP runtime torch brings
+    import torch  # noqa: F401  (whatever the order the tests run in; loaded the other way round torch finds no GPU)
+except ImportError:  # pragma: no cover
+    torch = None
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
