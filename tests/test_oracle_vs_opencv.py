@@ -11,8 +11,11 @@ import pytest
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 FIX = os.path.join(G, "opencv_pins.npz")
-pytestmark = pytest.mark.skipif(not os.path.exists(FIX), reason="tests/golden/opencv_pins.npz absent: run "
-                                "tools/gen_golden_opencv.py on a box with opencv-python >= 4.5.1")
+pytestmark = pytest.mark.skipif(not os.path.exists(FIX), reason="tests/golden/opencv_pins.npz absent: neither the build "
+                                "container nor the MI355X box holds OpenCV or reaches a package index "
+                                "(profiles/r3_opencv_probe_{buildbox,gpubox}.txt) -- PARITY UNPINNED for the OpenCV "
+                                "fixed-point kernels; tools/gen_golden_opencv.py writes the fixture on any box with "
+                                "opencv-python >= 4.5.1")
 
 
 @pytest.fixture(scope="module")
