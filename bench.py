@@ -39,7 +39,13 @@ BF, BASE = 0.12 * 532.03, 0.12  # ZED2-like rig: fx = 532.03 px, baseline 0.12 m
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks (= GPUs) of this node.  Started by torch.distributed.run, the world size is authoritative; "
+                         "started plainly with --gpus N > 1, bench.py re-executes itself under torch.distributed.run "
+                         "with N ranks (and refuses when the node shows fewer than N devices): n_gpus in the JSON line "
+                         "is always the size of the process group that ran, never this flag")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="re-execute under torch.distributed.run even for --gpus 1 (exercises the launcher + RCCL path)")
     # 100 steps = 55 ms of GPU time.  With three batches in flight the first and the last steps have no partners to
     # overlap with: after the preheat a 20-step run is within ~2 % of a 100-step run
     ap.add_argument("--steps", type=int, default=100)
@@ -210,8 +216,33 @@ class Workload:
             e.sync()
 
 
+def self_launch(a):
+    """Started without a launcher but asked for N > 1 ranks (or --self-launch): become `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N bench.py ...` -- one process per GPU, RCCL rendezvous on 127.0.0.1.  Refuses (exit 2)
+    when the node does not show N devices: a single process must never print an n_gpus = N line."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run (no rank is ever simulated; "
+                         "start it on a node with %d GPUs, or under torch.distributed.run)\n" % (a.gpus, have, a.gpus))
+        raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [x for x in sys.argv[1:] if x != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, ORBX_BENCH_SELF_LAUNCHED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or a.self_launch):
+        self_launch(a)   # does not return
     # Exactly ONE line on stdout: libraries (RCCL prints a version banner when NCCL_DEBUG=VERSION is set, HIP /
     # libdrm print warnings) must not interleave with it, so fd 1 is pointed at stderr for the run and the JSON
     # line is written to the saved descriptor at the end.
@@ -221,8 +252,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
+    # the process group that actually runs decides n_gpus; --gpus is only a request (and is fatal when it disagrees
+    # with a launcher's world size in the other direction: one process cannot stand for N GPUs)
+    if world != a.gpus:
+        if world == 1:
+            raise SystemExit("bench.py: --gpus %d inside a 1-rank launch: refusing to scale one GPU's number by %d" % (a.gpus, a.gpus))
         a.gpus = world
+    launched = os.environ.get("ORBX_BENCH_SELF_LAUNCHED") == "1"
 
     import numpy as np
     import torch  # first: liborbx.so then binds to the same HIP runtime as torch (SONAME libamdhip64.so.7)
@@ -231,7 +267,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the ORB front-end has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or a.config == "C5" or os.environ.get("ORBX_FORCE_DIST") == "1":  # C5 exercises RCCL even with one rank
+    if world > 1 or launched or a.config == "C5" or os.environ.get("ORBX_FORCE_DIST") == "1":  # C5 / self-launch: RCCL even with one rank
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist_
@@ -345,7 +381,9 @@ def main():
         nmatch = 0
 
     units_per_step = 2 * B if a.mode == "mono" else B  # mono: every image is a frame
-    value = a.gpus * units_per_step * a.steps / elapsed
+    n_ranks = dist.get_world_size() if dist is not None else 1   # never the CLI value
+    assert n_ranks == world
+    value = n_ranks * units_per_step * a.steps / elapsed
     c5 = a.config == "C5"
     out = {
         "metric": {"stereo": "ORB extract+match frames/sec @%d×%d stereo (both-eye ORBextractor + ComputeStereoMatches)",
@@ -354,7 +392,9 @@ def main():
                               "+ ComputeStereoFishEyeMatches)"}[a.mode] % (W, H),
         "value": round(value, 2),
         "unit": "frames/s" if a.mode == "mono" else "stereo frames/s",
-        "n_gpus": a.gpus,
+        "n_gpus": n_ranks,
+        "rccl_ranks": dist.get_world_size() if dist is not None else 0,   # size of the initialised RCCL group (0: none)
+        "launcher": "self (torch.distributed.run re-exec)" if launched else ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain"),
         "steps": a.steps,
         "warmup": a.warmup,
         "preheat_steps": preheat_steps,
@@ -472,9 +512,9 @@ def main():
         out["stages_note"] = ("per-stage HIP-event table from %d extra single-handle steps (synchronised, no overlap "
                               "between batches) after the timed region" % nprof)
         a_pair = 2 * (2 * P + 60 * nsel_mean) + 120 * nsel_mean + 352 * nmatch
-        out["end_to_end_algorithmic_GBps"] = round(a_pair * value / a.gpus / 1e9, 2)
+        out["end_to_end_algorithmic_GBps"] = round(a_pair * value / n_ranks / 1e9, 2)
 
-    extras = rank == 0 and a.gpus == 1 and a.mode == "stereo" and not a.no_extras and not c5
+    extras = rank == 0 and n_ranks == 1 and a.mode == "stereo" and not a.no_extras and not c5
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
     if extras and a.h2d_steps > 0:

@@ -254,7 +254,13 @@ static Entry entries[] = {
   } while (0)
 
 int main(int argc, char** argv) {
-  const bool json = argc > 1 && !strcmp(argv[1], "--json");
+  bool json = false, sat_only = false;
+  const char* only = nullptr;  // comma-separated list of instruction names
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--json")) json = true;
+    else if (!strcmp(argv[i], "--sat")) sat_only = true;  // only the saturated launch (for rocprofv3 --pmc passes)
+    else if (!strcmp(argv[i], "--only") && i + 1 < argc) only = argv[++i];
+  }
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount;
@@ -274,17 +280,27 @@ int main(int argc, char** argv) {
     printf("{\"device\": \"%s\", \"cus\": %d, \"rows\": [\n", prop.gcnArchName, cus);
   bool first = true;
   for (const Entry& en : entries) {
+    if (only) {
+      const size_t L = strlen(en.name);
+      bool hit = false;
+      for (const char* q = only; q && *q; q = strchr(q, ',') ? strchr(q, ',') + 1 : nullptr)
+        if (!strncmp(q, en.name, L) && (q[L] == ',' || q[L] == 0)) hit = true;
+      if (!hit) continue;
+    }
     // warm
     hipLaunchKernelGGL(en.fn, dim3(cus), dim3(256), 0, 0, d, 20, 1u, 0xffff);
     CK(hipDeviceSynchronize());
-    // w1: one wave
-    hipLaunchKernelGGL(en.fn, dim3(1), dim3(64), 0, 0, d, iters1, 1u, 0xffff);
-    CK(hipMemcpy(h.data(), d, sizeof(Rec), hipMemcpyDeviceToHost));
-    const double w1 = (double)h[0].cyc / (iters1 * per_iter);
-    // w2: two waves on one SIMD (waves 0 and 4 of a 512-thread block)
-    hipLaunchKernelGGL(en.fn, dim3(1), dim3(512), 0, 0, d, iters1, 1u, 0x11);
-    CK(hipMemcpy(h.data(), d, sizeof(Rec) * 8, hipMemcpyDeviceToHost));
-    const double w2 = (double)(h[0].cyc > h[4].cyc ? h[0].cyc : h[4].cyc) / (2.0 * iters1 * per_iter);
+    double w1 = 0, w2 = 0;
+    if (!sat_only) {
+      // w1: one wave
+      hipLaunchKernelGGL(en.fn, dim3(1), dim3(64), 0, 0, d, iters1, 1u, 0xffff);
+      CK(hipMemcpy(h.data(), d, sizeof(Rec), hipMemcpyDeviceToHost));
+      w1 = (double)h[0].cyc / (iters1 * per_iter);
+      // w2: two waves on one SIMD (waves 0 and 4 of a 512-thread block)
+      hipLaunchKernelGGL(en.fn, dim3(1), dim3(512), 0, 0, d, iters1, 1u, 0x11);
+      CK(hipMemcpy(h.data(), d, sizeof(Rec) * 8, hipMemcpyDeviceToHost));
+      w2 = (double)(h[0].cyc > h[4].cyc ? h[0].cyc : h[4].cyc) / (2.0 * iters1 * per_iter);
+    }
     // w8: 8 waves per SIMD on every CU
     const int blocks = cus * 32;  // 256-thread blocks: one wave per SIMD each, 8 resident per CU, 4 rounds
     CK(hipEventRecord(e0));
