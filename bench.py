@@ -180,11 +180,12 @@ class Workload:
             self.lap = np.array([[W // 5, W - 1]] * B + [[0, (4 * W) // 5]] * B, np.int32)
             self.rig = orbx.kb8_rig(synth.TUMVI_CAM1, synth.TUMVI_CAM2, np.eye(3), [0.101, 0.002, 0.001])
         self.gathered = [None] * len(self.exs)    # C5: (counts, desc) of all ranks, per handle
-        self.ext_streams = None
+        self.exchange = None
         if a.allgather and dist is not None:
-            # the collective is queued on the handle's own stream, behind the extraction: no host synchronisation
-            self.ext_streams = [torch.cuda.ExternalStream(e.stream_handle(), device=torch.device("cuda", local_rank))
-                                for e in self.exs]
+            # the collective goes through the C ABI (orbx_allgather_descriptors): one grouped RCCL call per step, straight from
+            # the handle's result arrays, queued on the handle's own stream behind the extraction -- no host synchronisation
+            from orb_slam3_fast_amd import sharding
+            self.exchange = [sharding.DescriptorExchange(2 * B, e.capacity, local_rank) for e in self.exs]
         self.last_slot = [None] * len(self.exs)
 
     def step(self):
@@ -201,15 +202,9 @@ class Workload:
             orbx.stereo_match_async(ex, ex, BF, BASE, first_left=0, first_right=B, n_pairs=B)
         elif a.mode == "fisheye":
             orbx.fisheye_match_async(ex, ex, self.rig, first_left=0, first_right=B, n_pairs=B)
-        if self.ext_streams is not None:
+        if self.exchange is not None:
             # config C5: every GPU ends up with all cameras' descriptor blocks (RCCL all-gather over xGMI)
-            from orb_slam3_fast_amd import sharding
-            torch = self.torch
-            d_kps, d_desc, d_cnt, d_mono, cap = ex.results_device()
-            with torch.cuda.stream(self.ext_streams[h]):
-                desc = torch.as_tensor(_Raw(d_desc, (2 * B, cap, 32), "|u1"), device="cuda")
-                cnt = torch.as_tensor(_Raw(d_cnt, (2 * B,), "<i4"), device="cuda")
-                self.gathered[h] = sharding.allgather_descriptor_blocks(cnt, desc, cap)
+            self.gathered[h] = self.exchange[h].gather(ex)
 
     def sync(self):
         for e in self.exs:

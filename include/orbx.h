@@ -115,6 +115,31 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, int n_images, 
 int orbx_batch_download_async(orbx_extractor* ex, int32_t* counts, int32_t* mono, orbx_keypoint* kps, uint8_t* desc,
                               float* uright, float* depth, int n_pairs);
 
+/* ---- Cross-camera descriptor exchange of the batched many-camera mode (BASELINE config C5).
+ * The reference has no counterpart: it drives ONE rig per process (Frame's process-global statics,
+ * include/Frame.h:230-235,314-319); north_star adds "RCCL over xGMI only for the optional cross-camera descriptor
+ * all-gather", one process per GPU.  orbx_comm wraps an RCCL communicator (ncclComm_t):
+ *   rank 0: orbx_comm_unique_id(id); the caller ships the 128 bytes to the other ranks (MPI, a file, torch.distributed);
+ *   every rank: orbx_comm_create(id, n_ranks, rank, device, &comm)            (collective: all ranks must call it)
+ *   or, for a process that already owns an ncclComm_t: orbx_comm_adopt(comm, device, &c) (not destroyed by liborbx).
+ * orbx_allgather_descriptors enqueues, on the handle's own stream (behind the extraction, no host synchronisation),
+ * ONE grouped RCCL call that gathers the first n_images images' results of the last batch from every rank, straight
+ * from the handle's result arrays (no pack step, no staging copy):
+ *   d_all_desc   [n_ranks][n_images][cap][32] u8    (cap = orbx_batch_results_device's cap; rows >= count are stale)
+ *   d_all_counts [n_ranks][n_images] int32
+ * ordered by rank, then by the rank's local image index.  Both destinations are DEVICE arrays owned by the caller and are
+ * complete after orbx_sync (or for any work queued later on orbx_stream_handle's stream).  Every rank must call it with the
+ * same n_images and a handle of the same capacity.  Errors: ORBX_E_UNSUPPORTED when no RCCL library can be loaded,
+ * ORBX_E_NODEVICE without a GPU, ORBX_E_HIP for an RCCL failure (orbx_last_error holds ncclGetErrorString). */
+#define ORBX_COMM_ID_BYTES 128
+typedef struct orbx_comm orbx_comm;
+int orbx_comm_unique_id(uint8_t id[ORBX_COMM_ID_BYTES]);
+int orbx_comm_create(const uint8_t id[ORBX_COMM_ID_BYTES], int n_ranks, int rank, int device, orbx_comm** out);
+int orbx_comm_adopt(void* nccl_comm, int device, orbx_comm** out);
+void orbx_comm_destroy(orbx_comm* c);
+int orbx_comm_size(const orbx_comm* c, int* n_ranks, int* rank);
+int orbx_allgather_descriptors(orbx_extractor* ex, orbx_comm* c, int n_images, uint8_t* d_all_desc, int32_t* d_all_counts);
+
 /* Device-resident results of the last (batch) extraction: keypoints [n_images][cap] and descriptors
  * [n_images][cap][32], counts[n_images] (n) and mono[n_images] (monoIndex), all on the device. */
 int orbx_batch_results_device(const orbx_extractor* ex, const orbx_keypoint** d_kps, const uint8_t** d_desc,

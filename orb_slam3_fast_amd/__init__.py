@@ -119,6 +119,13 @@ def lib():
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
+        L.orbx_comm_unique_id.argtypes = [vp]
+        L.orbx_comm_create.argtypes = [vp, i, i, i, C.POINTER(vp)]
+        L.orbx_comm_adopt.argtypes = [vp, i, C.POINTER(vp)]
+        L.orbx_comm_destroy.argtypes = [vp]
+        L.orbx_comm_destroy.restype = None
+        L.orbx_comm_size.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+        L.orbx_allgather_descriptors.argtypes = [vp, vp, i, vp, vp]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
         L.orbx_stage_name.restype = C.c_char_p
@@ -263,6 +270,12 @@ class ORBextractor:
         _check(lib().orbx_stream_handle(self._h, C.byref(st)))
         return st.value or 0
 
+    def allgather_descriptors(self, comm, n_images, d_all_desc_ptr, d_all_counts_ptr):
+        """orbx_allgather_descriptors: one grouped RCCL all-gather of the last batch's descriptor blocks (desc rows + counts)
+        of every rank into the caller's DEVICE arrays, enqueued on this handle's stream.  Asynchronous."""
+        _check(lib().orbx_allgather_descriptors(self._h, comm._h, n_images, C.c_void_p(d_all_desc_ptr),
+                                                C.c_void_p(d_all_counts_ptr)))
+
     def extract_batch_host(self, images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
         """orbx_extract_batch: frames in HOST memory (page-locked for real overlap); asynchronous."""
         lp = None if lap is None else _p(np.ascontiguousarray(lap, np.int32))
@@ -343,6 +356,38 @@ class ORBextractor:
         out = np.zeros((cap, 3), np.int32)
         n = _check(lib().orbx_debug_candidates(self._h, image, level, _p(out), cap))
         return out[:n].copy()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """orbx_comm_unique_id: the 128-byte RCCL id rank 0 creates and ships to the other ranks."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().orbx_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (orbx_comm_create: collective over all ranks; one rank per GPU)."""
+
+    def __init__(self, unique_id, n_ranks, rank, device=0):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().orbx_comm_create(buf, n_ranks, rank, device, C.byref(self._h)))
+        self.n_ranks, self.rank = n_ranks, rank
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().orbx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ComputeStereoMatches(left, right, bf, b, first_left=0, first_right=0, n_pairs=1):

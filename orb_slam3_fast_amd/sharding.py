@@ -42,6 +42,33 @@ def allgather_descriptor_blocks(counts, desc, cap, group=None):
     return unpack_descriptor_blocks(out.reshape(world * local.shape[0], local.shape[1]), cap)
 
 
+class DescriptorExchange:
+    """Config C5's exchange step through the C ABI: orbx_allgather_descriptors (one grouped RCCL call straight from the
+    handle's result arrays, on the handle's stream) -- the product path on the GPUs.  torch.distributed only ferries the
+    128-byte RCCL id from rank 0 to the other ranks at construction; the destination arrays are torch allocations
+    (device memory plumbing) reused every step.  allgather_descriptor_blocks above is the torch-only twin the gloo CPU
+    tests use to check the block order."""
+
+    def __init__(self, n_images, cap, device, group=None):
+        import orb_slam3_fast_amd as orbx
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = [orbx.comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(uid, src=0, group=group)
+        self.comm = orbx.Comm(uid[0], self.world, self.rank, device)
+        self.n_images, self.cap = n_images, cap
+        dev = torch.device("cuda", device)
+        self.desc = torch.empty((self.world * n_images, cap, 32), dtype=torch.uint8, device=dev)
+        self.counts = torch.empty((self.world * n_images,), dtype=torch.int32, device=dev)
+
+    def gather(self, ex):
+        """Enqueue the all-gather of ex's last batch behind its extraction; returns (counts [G*I], desc [G*I, cap, 32]),
+        complete once ex's stream reaches this point (ex.sync())."""
+        ex.allgather_descriptors(self.comm, self.n_images, self.desc.data_ptr(), self.counts.data_ptr())
+        return self.counts, self.desc
+
+
 def max_over_ranks(seconds, device="cpu", group=None):
     """bench.py contract: the step time is the MAX over ranks."""
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)

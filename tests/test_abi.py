@@ -54,6 +54,48 @@ def test_no_cpu_fallback_without_device():
                                                       (0, 0, 640, 480), np.zeros((4, 2), np.float32), 100)
 
 
+def test_comm_entry_points_fail_loudly_without_device():
+    """orbx_comm_* (RCCL behind the C ABI): argument errors are reported, and without a GPU the communicator is refused
+    (one rank per GPU; there is no CPU collective behind this entry)."""
+    lib = orbx.lib()
+    h = C.c_void_p()
+    assert lib.orbx_comm_create(None, 1, 0, 0, C.byref(h)) == orbx.E_BADARG
+    buf = (C.c_uint8 * orbx.COMM_ID_BYTES)()
+    assert lib.orbx_comm_create(buf, 2, 5, 0, C.byref(h)) == orbx.E_BADARG
+    assert lib.orbx_allgather_descriptors(None, None, 1, None, None) == orbx.E_BADARG
+    if orbx.device_count() == 0:
+        assert lib.orbx_comm_create(buf, 1, 0, 0, C.byref(h)) == orbx.E_NODEVICE
+        assert b"GPU" in lib.orbx_last_error()
+
+
+@pytest.mark.gpu
+def test_allgather_descriptors_through_the_c_abi_one_rank():
+    """A 1-rank RCCL communicator created through the C ABI alone (no torch.distributed): the gathered blocks equal the
+    handle's own results, and the call is ordered behind the extraction on the handle's stream."""
+    import torch
+    from orb_slam3_fast_amd import synth
+    w, h, n = 320, 240, 4
+    imgs = np.stack([synth.stereo_pair(w, h, 40 + i)[0] for i in range(n)])
+    d = torch.from_numpy(imgs).cuda()
+    ex = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n)
+    comm = orbx.Comm(orbx.comm_unique_id(), 1, 0, 0)
+    nr, rk = C.c_int(), C.c_int()
+    assert orbx.lib().orbx_comm_size(comm._h, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (1, 0)
+    all_desc = torch.full((n, ex.capacity, 32), 255, dtype=torch.uint8, device="cuda")
+    all_cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ex.extract_batch_device(d.data_ptr(), n, w, h, w, w * h)
+    ex.allgather_descriptors(comm, n, all_desc.data_ptr(), all_cnt.data_ptr())   # no sync in between
+    ex.sync()
+    cnt, desc = all_cnt.cpu().numpy(), all_desc.cpu().numpy()
+    for i in range(n):
+        _, k, dd = ex.download(i)
+        assert cnt[i] == len(k) > 50 and np.array_equal(desc[i, :len(k)], dd)
+    with pytest.raises(orbx.OrbxError):
+        ex.allgather_descriptors(comm, n + 1, all_desc.data_ptr(), all_cnt.data_ptr())
+    comm.close()
+
+
 def test_bad_parameters_rejected():
     lib = orbx.lib()
     p = orbx._Params(0, 1.2, 8, 20, 7)

@@ -68,7 +68,8 @@ def test_default_bench_workload_matches_the_oracle():
 
 def test_c5_allgather_blocks_equal_the_downloads():
     """bench.py --config C5 on one GPU with a 1-rank RCCL group: 8 streams x 4 consecutive frames per step, the all-gather
-    of {n, desc[cap][32]} queued on the handle's stream behind the extraction (zero-copy views of liborbx's buffers)."""
+    of {n, desc[cap][32]} through the C ABI (orbx_allgather_descriptors: one grouped RCCL call straight from the handle's result
+    arrays, queued on the handle's stream behind the extraction; sharding.DescriptorExchange is the thin caller)."""
     import torch
     import torch.distributed as dist
     import bench

@@ -11,7 +11,7 @@
 __global__ __launch_bounds__(256) void k_rd_1B(const uint8_t* s, size_t n, uint32_t* sink) {
   uint32_t acc = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc ^= s[i];
-  if (acc == 0x12345677u) sink[threadIdx.x] = acc;
+  if (acc == 0x77u) sink[threadIdx.x] = acc;  // a byte XOR stays below 256: keep the test satisfiable or the loop is deleted
 }
 __global__ __launch_bounds__(256) void k_rd_4B(const uint32_t* s, size_t n, uint32_t* sink) {
   uint32_t acc = 0;
