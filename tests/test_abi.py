@@ -72,27 +72,25 @@ def test_comm_entry_points_fail_loudly_without_device():
 def test_allgather_descriptors_through_the_c_abi_one_rank():
     """A 1-rank RCCL communicator created through the C ABI alone (no torch.distributed): the gathered blocks equal the
     handle's own results, and the call is ordered behind the extraction on the handle's stream."""
-    import torch
     from orb_slam3_fast_amd import synth
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
     w, h, n = 320, 240, 4
-    imgs = np.stack([synth.stereo_pair(w, h, 40 + i)[0] for i in range(n)])
-    d = torch.from_numpy(imgs).cuda()
+    d = DeviceBuffer.from_numpy(np.stack([synth.stereo_pair(w, h, 40 + i)[0] for i in range(n)]))
     ex = orbx.ORBextractor(500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n)
     comm = orbx.Comm(orbx.comm_unique_id(), 1, 0, 0)
     nr, rk = C.c_int(), C.c_int()
     assert orbx.lib().orbx_comm_size(comm._h, C.byref(nr), C.byref(rk)) == 0 and (nr.value, rk.value) == (1, 0)
-    all_desc = torch.full((n, ex.capacity, 32), 255, dtype=torch.uint8, device="cuda")
-    all_cnt = torch.full((n,), -1, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    ex.extract_batch_device(d.data_ptr(), n, w, h, w, w * h)
-    ex.allgather_descriptors(comm, n, all_desc.data_ptr(), all_cnt.data_ptr())   # no sync in between
+    all_desc = DeviceBuffer.from_numpy(np.full((n, ex.capacity, 32), 255, np.uint8))
+    all_cnt = DeviceBuffer.from_numpy(np.full((n,), -1, np.int32))
+    ex.extract_batch_device(d.ptr.value, n, w, h, w, w * h)
+    ex.allgather_descriptors(comm, n, all_desc.ptr.value, all_cnt.ptr.value)   # no sync in between
     ex.sync()
-    cnt, desc = all_cnt.cpu().numpy(), all_desc.cpu().numpy()
+    cnt, desc = all_cnt.to_numpy(np.int32, (n,)), all_desc.to_numpy(np.uint8, (n, ex.capacity, 32))
     for i in range(n):
         _, k, dd = ex.download(i)
         assert cnt[i] == len(k) > 50 and np.array_equal(desc[i, :len(k)], dd)
     with pytest.raises(orbx.OrbxError):
-        ex.allgather_descriptors(comm, n + 1, all_desc.data_ptr(), all_cnt.data_ptr())
+        ex.allgather_descriptors(comm, n + 1, all_desc.ptr.value, all_cnt.ptr.value)
     comm.close()
 
 

@@ -72,6 +72,9 @@ def main():
         "g160": np.load(os.path.join(G, "extract_160x120_L3.npz"))["image"],
         "g400L": np.load(os.path.join(G, "stereo_400x300.npz"))["left"],
         "g400R": np.load(os.path.join(G, "stereo_400x300.npz"))["right"],
+        # natural photographs (tools/gen_natural_fixture.py): corner density, ties and low-contrast regions of real texture
+        "nat_cam": np.load(os.path.join(G, "natural_images.npz"))["camera"],
+        "nat_moto": np.load(os.path.join(G, "natural_images.npz"))["moto_left"],
     }
     out = {"skimage_version": np.array(skimage.__version__), "names": np.array(sorted(imgs))}
     for name, im in sorted(imgs.items()):
