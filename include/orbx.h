@@ -150,9 +150,19 @@ int orbx_batch_download(orbx_extractor* ex, int image, orbx_keypoint* kps, uint8
 /* Replaces reads of the public member ORBextractor::mvImagePyramid (include/ORBextractor.h:86;
  * used by src/Frame.cc:927,1011,1024,1029): copies level `level` of image `image` of the last extraction
  * to dst (dst_stride bytes per row; dst may be NULL to query the size only). blurred != 0 returns the
- * 7x7 Gaussian-blurred working copy (src/ORBextractor.cc:1074-1076) instead. */
+ * 7x7 Gaussian-blurred working copy (src/ORBextractor.cc:1074-1076) instead (computed on demand, once per extraction).
+ * Lifetime: level 0 of a batch extracted with orbx_extract_batch_device IS the caller's device buffer (never copied), so
+ * reading level 0 -- plain or blurred -- requires that buffer to be alive and unchanged; levels >= 1 and every level of the
+ * host entry points (orbx_extract, orbx_extract_stereo, orbx_extract_batch) live in handle-owned memory until the next
+ * extraction on the handle. */
 int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, uint8_t* dst,
                        ptrdiff_t dst_stride, int* w, int* h);
+/* All (n_levels <= nlevels) levels of one image of the last extraction into caller buffers with ONE synchronisation:
+ * dst[l] receives level l (w_l x h_l bytes, rows dst_stride[l] apart; NULL entries are skipped); the copies are queued
+ * asynchronously on the handle's stream and the call returns after a single stream synchronisation.  This is what the C++
+ * mirror's mvImagePyramid refresh uses (one call per eye instead of 2 x nlevels blocking copies).
+ * Level 0 of a batch extracted with orbx_extract_batch_device is the CALLER's device buffer: it must still be alive. */
+int orbx_pyramid_download(orbx_extractor* ex, int image, int n_levels, uint8_t* const* dst, const ptrdiff_t* dst_stride);
 
 /* Stage taps for differential tests: FAST candidates handed to DistributeOctTree for (image, level), in
  * unspecified order (x, y relative to the (16,16) window origin as in src/ORBextractor.cc:965-967;

@@ -40,7 +40,7 @@ int cv_round(float v);
 int cv_round(double v);
 float fast_atan2(float y, float x);                                   // B5
 void orb_sincosf(float ang, float* s, float* c);                      // B8: host libm sinf/cosf (mode 0) or a glibc model
-void orb_set_sincos_mode(int mode);  // 0 = host libm (default), 1 = glibc FMA-variant model, 2 = glibc SSE2-variant model
+void orb_set_sincos_mode(int mode);  // 0 = host libm, 1 = glibc FMA-variant model (default: deterministic, = the device), 2 = glibc SSE2-variant model
 int orb_get_sincos_mode();
 float glibc_sinf_model(float y, bool fused);
 float glibc_cosf_model(float y, bool fused);

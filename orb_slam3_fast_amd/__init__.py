@@ -79,6 +79,7 @@ def lib():
         L.orbx_batch_results_device.argtypes = [vp] + [C.POINTER(vp)] * 4 + [C.POINTER(i)]
         L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
         L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, C.c_ssize_t, C.POINTER(i), C.POINTER(i)]
+        L.orbx_pyramid_download.argtypes = [vp, i, i, vp, vp]
         L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
         L.orbx_hamming256.argtypes = [vp, vp]
         L.orbx_stereo_match_batch.argtypes = [vp, i, vp, i, i, f, f]

@@ -243,18 +243,23 @@ class ORBextractor {
   void SyncImagePyramid(int image = 0) {
     std::vector<ocv::Mat>& dst = image == 0 ? mvImagePyramid : mvImagePyramidRight;
     dst.resize(nlevels);
+    std::vector<uint8_t*> ptrs(nlevels);
+    std::vector<ptrdiff_t> strides(nlevels);
     for (int l = 0; l < nlevels; l++) {
       int w = 0, h = 0;
-      if (orbx_pyramid_level(h_, image, l, 0, nullptr, 0, &w, &h) != ORBX_OK)
+      if (orbx_pyramid_level(h_, image, l, 0, nullptr, 0, &w, &h) != ORBX_OK)   // size query only: no copy, no sync
         throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
 #ifdef ORBX_HAVE_OPENCV
       dst[l].create(h, w, CV_8UC1);
 #else
       dst[l].create(h, w);
 #endif
-      if (orbx_pyramid_level(h_, image, l, 0, dst[l].ptr(0), (ptrdiff_t)dst[l].step, &w, &h) != ORBX_OK)
-        throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+      ptrs[l] = dst[l].ptr(0);
+      strides[l] = (ptrdiff_t)dst[l].step;
     }
+    // all levels with asynchronous copies and ONE synchronisation (was: 2 x nlevels blocking calls)
+    if (orbx_pyramid_download(h_, image, nlevels, ptrs.data(), strides.data()) != ORBX_OK)
+      throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
   }
 
   orbx_extractor* handle() { return h_; }

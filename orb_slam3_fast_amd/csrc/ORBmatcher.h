@@ -13,6 +13,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -57,6 +58,28 @@ class ORBmatcher {
         mbCheckOrientation ? 1 : 0);
     if (n < 0) throw std::runtime_error(std::string("SearchForInitialization: ") + orbx_last_error());
     return n;
+  }
+
+  // The reference's own call shape -- matcher.SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize),
+  // include/ORBmatcher.h:97-101, called from Tracking::MonocularInitialization (src/Tracking.cc:2438-2440) -- for any
+  // Frame-like type that exposes the members the routine reads: mvKeysUn (std::vector<cv::KeyPoint>), mDescriptors
+  // (N x 32 CV_8U Mat, continuous), N, and the image bounds mnMinX / mnMinY / mnMaxX / mnMaxY (static members of Frame,
+  // include/Frame.h:314-319).  ORB_SLAM3::Frame itself satisfies this, so the call site compiles unchanged.
+  template <class FrameT, class = decltype(std::declval<const FrameT&>().mvKeysUn.data())>
+  int SearchForInitialization(FrameT& F1, FrameT& F2, std::vector<ocv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12,
+                              int windowSize = 10) {
+    return SearchForInitialization(ViewOf(F1), ViewOf(F2), vbPrevMatched, vnMatches12, windowSize);
+  }
+  template <class FrameT>
+  static FrameView ViewOf(const FrameT& F) {
+    if (F.N > 1 && (size_t)F.mDescriptors.step != 32) throw std::invalid_argument("mDescriptors must be a continuous N x 32 matrix");
+    if ((int)F.mvKeysUn.size() < F.N || F.mDescriptors.rows < F.N) throw std::invalid_argument("Frame holds fewer than N features");
+    FrameView v;
+    v.mvKeysUn = F.mvKeysUn.data();
+    v.mDescriptors = F.mDescriptors.ptr(0);
+    v.N = F.N;
+    v.mnMinX = F.mnMinX; v.mnMinY = F.mnMinY; v.mnMaxX = F.mnMaxX; v.mnMaxY = F.mnMaxY;
+    return v;
   }
 
   // SearchByProjection(Frame& F, const vector<MapPoint*>&, th, bFarPoints, thFarPoints), src/ORBmatcher.cc:41-221,

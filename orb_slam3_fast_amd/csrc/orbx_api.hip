@@ -283,6 +283,8 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->pyr.pyr = ex->d_pyr.p;
   ex->lastN = n;
   ex->lastEvValid = false;
+  ex->blurValid = false;       // per-extraction state is reset HERE: a hipGraph replay never runs record_pipeline
+  ex->lastStereoPairs = 0;     // results of an earlier batch's stereo association are not this batch's
   hipStream_t s = ex->stream;
   // Keypoint x is >= 19 at every level (16-px border + the 3-px FAST ring, scaled by >= 1), so a lapping area that
   // ends below 19 -- the rectified-stereo {0, 0} in particular -- can hold no keypoint: the output order is then
@@ -553,7 +555,8 @@ int orbx_batch_download_async(orbx_extractor* ex, int32_t* counts, int32_t* mono
                               float* uright, float* depth, int n_pairs) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
   if (ex->lastN <= 0) return fail(ORBX_E_BADARG, "no batch has been extracted on this handle");
-  if (n_pairs < 0 || n_pairs > ex->stereoPairs) return fail(ORBX_E_BADARG, "more pairs than the last stereo association held");
+  if (n_pairs < 0 || n_pairs > ex->lastStereoPairs)
+    return fail(ORBX_E_BADARG, "n_pairs exceeds the stereo association run on this handle since its last extraction");
   HIPC(hipSetDevice(ex->device));
   const size_t n = (size_t)ex->lastN, oc = (size_t)ex->gmax.outCap;
   hipStream_t st = ex->stream;
@@ -721,6 +724,23 @@ int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, ui
   return ORBX_OK;
 }
 
+int orbx_pyramid_download(orbx_extractor* ex, int image, int n_levels, uint8_t* const* dst, const ptrdiff_t* dst_stride) {
+  if (!ex || !dst || !dst_stride) return fail(ORBX_E_BADARG, "null argument");
+  if (ex->curW == 0 || image < 0 || image >= ex->lastN || n_levels < 0 || n_levels > ex->g.nlevels)
+    return fail(ORBX_E_BADARG, "no such pyramid");
+  HIPC(hipSetDevice(ex->device));
+  for (int l = 0; l < n_levels; l++) {
+    if (!dst[l]) continue;
+    const LevelDev& L = ex->g.lv[l];
+    if (dst_stride[l] < L.w) return fail(ORBX_E_BADARG, "destination stride smaller than the level width");
+    int p;
+    const uint8_t* src = level_ptr(ex->g, ex->pyr, image, l, p);
+    HIPC(hipMemcpy2DAsync(dst[l], dst_stride[l], src, p, L.w, L.h, hipMemcpyDeviceToHost, ex->stream));
+  }
+  HIPC(hipStreamSynchronize(ex->stream));
+  return ORBX_OK;
+}
+
 int orbx_debug_candidates(orbx_extractor* ex, int image, int level, int32_t* xys, int cap) {
   if (!ex || image < 0 || image >= ex->lastN || level < 0 || level >= ex->g.nlevels)
     return fail(ORBX_E_BADARG, "bad argument");
@@ -771,6 +791,7 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
     HIPC(left->d_rowItems.alloc((size_t)n_pairs * right->gmax.outCap));
     left->stereoPairs = n_pairs;
   }
+  left->lastStereoPairs = n_pairs;
   if (right != left) {  // order left's stream after right's extraction
     HIPC(hipEventRecord(right->done, right->stream));
     HIPC(hipStreamWaitEvent(left->stream, right->done, 0));
@@ -818,7 +839,8 @@ int orbx_stereo_results_device(const orbx_extractor* left, const float** d_urigh
 }
 
 int orbx_stereo_download(orbx_extractor* left, int pair, float* uright, float* depth, int cap) {
-  if (!left || pair < 0 || pair >= left->stereoPairs) return fail(ORBX_E_BADARG, "bad pair index");
+  if (!left || pair < 0 || pair >= left->lastStereoPairs)
+    return fail(ORBX_E_BADARG, "no such pair in the stereo association run since the handle's last extraction");
   HIPC(hipSetDevice(left->device));
   HIPC(hipStreamSynchronize(left->stream));
   const size_t capL = (size_t)left->gmax.outCap;
@@ -973,6 +995,9 @@ int orbx_debug_score_map(orbx_extractor* ex, int enable) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
   HIPC(hipSetDevice(ex->device));
   HIPC(hipStreamSynchronize(ex->stream));
+  // the tap's pointer and its memset are part of a captured pipeline: graphs recorded with the other setting are dropped
+  // (a replay would keep writing a freed buffer, or never write a new one)
+  drop_graphs(ex);
   if (enable && !ex->d_dbgScore.p) HIPC(ex->d_dbgScore.alloc((size_t)ex->maxB * ex->gmax.pyrImg + 256));
   if (!enable) ex->d_dbgScore.free();
   return ORBX_OK;

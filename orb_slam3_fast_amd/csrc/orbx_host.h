@@ -244,7 +244,8 @@ struct orbx_extractor {
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
-  int stereoPairs = 0;
+  int stereoPairs = 0;             // high-water allocation of d_uR / d_depth / d_sad (pairs)
+  int lastStereoPairs = 0;         // pairs of the stereo association run since the last extraction (0: none)
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   int32_t* h_lap = nullptr;        // pinned copy of the lapping areas the device currently holds (lapN images)
   int lapN = 0;

@@ -2,6 +2,8 @@
 // instances called from two threads, then ComputeStereoMatches; optional SearchForInitialization between
 // two mono frames.  Reads raw u8 images, writes results as flat binary files for the pytest to diff
 // against the oracle.   usage: frame_like <w> <h> <nfeat> <left.raw> <right.raw> <outprefix>
+// Built twice by tests/test_cpp_mirror.py: with -DORBX_NO_OPENCV (the cvlite stand-ins) and with
+// -Itests/cpp/opencv_stub (the cv::InputArray / cv::OutputArray / cv::Mat branch = the reference's own signatures).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +18,24 @@
 #include "../../orb_slam3_fast_amd/csrc/Preprocess.h"
 
 using namespace ORB_SLAM3;
+
+// a gray image header over caller-owned pixels, in whichever Mat the mirror was built with
+static ocv::Mat wrap(int h, int w, uint8_t* p) {
+#ifdef ORBX_HAVE_OPENCV
+  return cv::Mat(h, w, CV_8UC1, p, (size_t)w);
+#else
+  return ocv::Mat(h, w, p, (size_t)w);
+#endif
+}
+// The slice of ORB_SLAM3::Frame that ORBmatcher::SearchForInitialization(Frame&, Frame&, ...) reads
+// (include/Frame.h:249-272: mvKeysUn, mDescriptors, N; :314-319: the static image bounds).
+struct FrameLike {
+  std::vector<ocv::KeyPoint> mvKeysUn;
+  ocv::Mat mDescriptors;
+  int N = 0;
+  static float mnMinX, mnMinY, mnMaxX, mnMaxY;
+};
+float FrameLike::mnMinX = 0, FrameLike::mnMinY = 0, FrameLike::mnMaxX = 0, FrameLike::mnMaxY = 0;
 
 static std::vector<uint8_t> slurp(const char* path) {
   std::ifstream f(path, std::ios::binary);
@@ -75,7 +95,7 @@ int main(int argc, char** argv) {
     const std::string out = argv[9];
     const float* m = reinterpret_cast<const float*>(mb.data());
     const size_t per = (size_t)dw * dh;
-    ocv::Mat L(sh, sw, Lb.data(), (size_t)sw), R(sh, sw, Rb.data(), (size_t)sw), eqL, eqR, a, b, c, d;
+    ocv::Mat L = wrap(sh, sw, Lb.data()), R = wrap(sh, sw, Rb.data()), eqL, eqR, a, b, c, d;
     auto clahe = createCLAHE(3.0, 8, 8);  // Examples/Stereo/stereo_tum_vi.cc:100,142-143
     clahe->apply(L, eqL);
     clahe->apply(R, eqR);
@@ -88,6 +108,16 @@ int main(int argc, char** argv) {
     dump(out + ".b", b.data, per);
     dump(out + ".c", c.data, per);
     dump(out + ".d", d.data, per);
+#ifdef ORBX_HAVE_OPENCV
+    {  // the reference's call shape: cv::remap(imLeft, imLeftToFeed, M1l, M2l, cv::INTER_LINEAR)  (src/System.cc:294)
+      cv::Mat M1(dh, dw, CV_32FC1, const_cast<float*>(m)), M2(dh, dw, CV_32FC1, const_cast<float*>(m + per)), e;
+      remap(eqL, e, M1, M2, cv::INTER_LINEAR);
+      if (e.rows != dh || e.cols != dw || std::memcmp(e.data, a.data, per) != 0) {
+        std::printf("cv::remap overload differs from the pointer form\n");
+        return 5;
+      }
+    }
+#endif
     return 0;
   }
   if (std::string(argv[1]) == "fisheye") {
@@ -119,7 +149,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> L = slurp(argv[4]), R = slurp(argv[5]);
   const std::string out = argv[6];
   ORBextractor exL(nf, 1.2f, 8, 20, 7, w, h), exR(nf, 1.2f, 8, 20, 7, w, h);
-  ocv::Mat imL(h, w, L.data(), (size_t)w), imR(h, w, R.data(), (size_t)w), mask;
+  ocv::Mat imL = wrap(h, w, L.data()), imR = wrap(h, w, R.data()), mask;
   std::vector<ocv::KeyPoint> kL, kR;
   ocv::Mat dL, dR;
   std::vector<int> lap = {0, 0};
@@ -149,6 +179,21 @@ int main(int argc, char** argv) {
   ORBmatcher matcher(0.9f, true);
   const int nm = matcher.SearchForInitialization(F1, F2, prev, m12, 100);
   dump(out + ".m12", m12.data(), m12.size());
+  {  // the same match through the reference's own signature: SearchForInitialization(Frame& F1, Frame& F2, ...)
+    FrameLike G1, G2;
+    G1.mvKeysUn = kL; G1.mDescriptors = dL; G1.N = (int)kL.size();
+    G2.mvKeysUn = kR; G2.mDescriptors = dR; G2.N = (int)kR.size();
+    FrameLike::mnMaxX = (float)w; FrameLike::mnMaxY = (float)h;
+    std::vector<ocv::Point2f> prev2(kL.size());
+    for (size_t i = 0; i < kL.size(); i++) prev2[i] = kL[i].pt;
+    std::vector<int> m12b;
+    const int nm2 = matcher.SearchForInitialization(G1, G2, prev2, m12b, 100);
+    if (nm2 != nm || m12b != m12 || std::memcmp(prev2.data(), prev.data(), prev.size() * sizeof(prev[0])) != 0) {
+      std::printf("SearchForInitialization(Frame&, Frame&) differs from the FrameView form\n");
+      return 6;
+    }
+    if (ORBmatcher::DescriptorDistance(dL, dL) != 0) return 7;   // static int DescriptorDistance(const cv::Mat&, const cv::Mat&)
+  }
   {  // the single-call stereo path must give the same keypoints, descriptors and depths
     ORBextractor exP(nf, 1.2f, 8, 20, 7, w, h);
     std::vector<ocv::KeyPoint> pL, pR;

@@ -8,21 +8,29 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "frame_like")
+STUB = os.path.join(ROOT, "tests", "cpp", "opencv_stub")
 
 
-def build_exe():
+def build_exe(cv=False):
+    """cv=False: the cvlite stand-in types (-DORBX_NO_OPENCV).  cv=True: the `#ifdef ORBX_HAVE_OPENCV` branch of the mirror
+    headers -- the reference's own signatures, int operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&,
+    cv::OutputArray, std::vector<int>&) (include/ORBextractor.h:64-68) -- compiled against tests/cpp/opencv_stub (a test-only
+    model of the few <opencv2/core.hpp> members those branches touch; the image has no OpenCV)."""
     src = os.path.join(ROOT, "tests", "cpp", "frame_like.cpp")
     libdir = os.path.join(ROOT, "orb_slam3_fast_amd")
+    exe = EXE + ("_cv" if cv else "")
     hdrs = [os.path.join(libdir, "csrc", h) for h in ("ORBextractor.h", "ORBmatcher.h", "Preprocess.h", "ORBVocabulary.h")]
-    if (not os.path.exists(EXE)) or any(os.path.getmtime(p) > os.path.getmtime(EXE) for p in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-DORBX_NO_OPENCV", src, "-o", EXE, "-L" + libdir,
-                               "-lorbx", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    return EXE
+    hdrs.append(os.path.join(STUB, "opencv2", "core.hpp"))
+    if (not os.path.exists(exe)) or any(os.path.getmtime(p) > os.path.getmtime(exe) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + STUB if cv else "-DORBX_NO_OPENCV", src, "-o", exe,
+                               "-L" + libdir, "-lorbx", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
 
 
-def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
+@pytest.mark.parametrize("cv", [False, True])
+def test_cpp_mirror_compiles_and_fails_loudly_without_gpu(cv):
     import orb_slam3_fast_amd as orbx
-    exe = build_exe()
+    exe = build_exe(cv)
     r = subprocess.run([exe], capture_output=True, text=True)
     if orbx.device_count() == 0:
         assert r.returncode == 3 and "no-device error" in r.stdout
@@ -31,11 +39,12 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_matches_oracle(oracle, tmp_path):
+@pytest.mark.parametrize("cv", [False, True])
+def test_cpp_mirror_matches_oracle(oracle, tmp_path, cv):
     import orb_slam3_fast_amd as orbx
     from orb_slam3_fast_amd import synth
     assert orbx.device_count() > 0
-    exe = build_exe()
+    exe = build_exe(cv)
     w, h, nf = 640, 480, 1000
     L, R = synth.stereo_pair(w, h, 61)
     L.tofile(tmp_path / "L.raw")
@@ -89,10 +98,12 @@ def test_cpp_mirror_fisheye_matches_python_binding(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_rectify_clahe_matches_oracle(oracle, tmp_path):
-    """ORB_SLAM3::remap / CLAHE / StereoRectifier (csrc/Preprocess.h) against the oracle's cv::remap / CLAHE restatement."""
+@pytest.mark.parametrize("cv", [False, True])
+def test_cpp_mirror_rectify_clahe_matches_oracle(oracle, tmp_path, cv):
+    """ORB_SLAM3::remap / CLAHE / StereoRectifier (csrc/Preprocess.h) against the oracle's cv::remap / CLAHE restatement;
+    cv=True also drives the cv::remap(InputArray, OutputArray, InputArray, InputArray, int) overload (src/System.cc:294)."""
     from orb_slam3_fast_amd import synth
-    exe = build_exe()
+    exe = build_exe(cv)
     sw, sh, dw, dh = 512, 512, 480, 470
     L, R = synth.stereo_pair(sw, sh, 71)
     ml = synth.rectify_maps(dw, dh, sw, sh, seed=3)

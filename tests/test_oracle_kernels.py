@@ -225,12 +225,13 @@ def test_cv_round_half_even(oracle):
 
 
 def test_sincos_vs_libm(oracle):
-    """The reference calls libm cosf / sinf (src/ORBextractor.cc:106-107); the oracle calls the host's libm, and its
-    restatement of glibc's two ifunc variants (the definition the device runs, csrc/orbx_sincos.h) must EQUAL the host
-    libm bit for bit: 1.2e7 angles drawn the way the path forms them (fastAtan2 of integer moments, times factorPI),
+    """The reference calls libm cosf / sinf (src/ORBextractor.cc:106-107); the oracle's default is its restatement of
+    glibc's two ifunc variants (the definition the device runs, csrc/orbx_sincos.h), which must EQUAL the host libm bit
+    for bit on a glibc >= 2.28 x86-64 host (skipped on any other libm: there the restatement, not the host, is the oracle): 1.2e7 angles drawn the way the path forms them (fastAtan2 of integer moments, times factorPI),
     plus a strided sweep of all floats in [0, 2 pi] (tools/sincos_sweep.cpp is the exhaustive version: 1.09e9
     arguments, 0 mismatches for either variant on glibc 2.35)."""
-    assert oracle.host_libm_variant() in (1, 2), "host libm is not a glibc >= 2.28 x86-64 sinf/cosf"
+    if oracle.host_libm_variant() not in (1, 2):
+        pytest.skip("host libm is not a glibc >= 2.28 x86-64 sinf/cosf: nothing to compare the restatement with")
     for fused in (1, 0):
         bad, first = oracle.sincos_check(20220131, 12_000_000, fused)
         assert bad == 0, "glibc model (fused=%d) differs from the host libm, first at angle %r" % (fused, first)
@@ -256,9 +257,11 @@ def test_sincos_modes_agree_in_descriptors(oracle):
         for mode in (0, 1, 2):
             oracle.set_sincos_mode(mode)
             out.append([oracle.descriptor(img, 32, 32, float(a)).tobytes() for a in np.linspace(0, 359.9, 720, dtype=np.float32)])
-        assert out[0] == out[1] == out[2]
+        assert out[1] == out[2]
+        if oracle.host_libm_variant() in (1, 2):
+            assert out[0] == out[1]
     finally:
-        oracle.set_sincos_mode(0)
+        oracle.set_sincos_mode(1)   # the default: glibc model = the device's definition
 
 
 # ------------------------------------------------------------------------------------------- A5 / A7
