@@ -65,6 +65,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip latency / H2D-inclusive / cpu legs (profiling runs)")
     ap.add_argument("--latency-frames", type=int, default=200)
     ap.add_argument("--h2d-steps", type=int, default=30)
+    ap.add_argument("--other-steps", type=int, default=20,
+                    help="timed steps of each secondary configuration in the other_configs leg (C2 640x480 mono, 640x480 stereo, "
+                         "C4 512x512 fisheye stereo; 8-pair batches; 0 = skip)")
     ap.add_argument("--handles", type=int, default=3,
                     help="extractor handles used round-robin (each owns a stream + buffers); batches of different handles overlap on the GPU: the "
                          "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others (1: 52.6 k, 2: 60.7 k, 3: 60.8 k, 4: 57.0 k pairs/s)")
@@ -343,6 +346,16 @@ def main():
     if dist is not None:
         elapsed = sharding.max_over_ranks(elapsed, device="cuda")
     dom_prof = collect() if not a.no_profile else {}
+    # shader clock under THIS load: a one-wave probe spins for 2 ms on its own stream while further steps run
+    shader_ghz = None
+    try:
+        probe = orbx.clock_probe_start(local_rank, 2000)
+        for _ in range(2 * len(exs)):
+            step()
+        wl.sync()
+        shader_ghz = orbx.clock_probe_finish(probe)
+    except Exception:
+        shader_ghz = None
     # per-stage table: a short extra pass outside the timed region with every kernel bracketed, on ONE handle with a
     # sync after every step, so that the durations are those of the kernels alone (in the timed region the batches
     # of the two handles overlap on the GPU, which stretches every individual launch)
@@ -453,24 +466,42 @@ def main():
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic if full else None,
                            "avg_launch_us": round(1000.0 * ms / cnt, 2), "launches_timed": cnt,
                            "algorithmic_bytes_per_launch": int(per_launch),
+                           "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json): "
+                                           "2 x FETCH_SIZE + WRITE_SIZE -- gfx950 tallies every 128-byte read request at 64 bytes "
+                                           "(calibrated per access shape: profiles/r3_pmc_calibration.json)",
                            "limited_by": "VALU issue, not HBM (see roofline.valu): the contract's HBM fraction is reported "
-                                         "as asked, but this integer stencil / compare kernel saturates the vector ALUs "
-                                         "while moving less than its algorithmic bytes (DESIGN.md 5)",
+                                         "as asked, but this integer stencil / compare kernel is bound by the vector ALUs' issue "
+                                         "rate (DESIGN.md 5)",
                            "note": "with %d handles in flight the launches of consecutive batches overlap, so avg_launch_us is "
                                    "the duration under overlap; isolated_* is the same kernel alone (stage pass)" % len(exs)}
         if dom in stages:
             iso = stages[dom]["avg_us"]
             out["roofline"]["isolated_avg_launch_us"] = iso
             out["roofline"]["isolated_frac"] = round(per_launch / (iso * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+        try:   # static instruction mix by measured issue class (tools/isa_valu_classes.py; profiles/r3_valu_issue.txt)
+            mix = json.load(open(os.path.join(ROOT, "profiles", "valu_class_mix.json")))
+        except Exception:
+            mix = {}
+        clk = (shader_ghz or CLOCK_HZ / 1e9) * 1e9
+        out["roofline"]["shader_clock_ghz"] = round(shader_ghz, 3) if shader_ghz else None
+        out["roofline"]["shader_clock_note"] = ("measured by a one-wave s_memtime / s_memrealtime probe running beside further "
+                                                "steps of this workload right after the timed region; the VALU fractions below "
+                                                "use it (2.4 GHz peak only if the probe failed)")
         if full and dom in pmc and "SQ_INSTS_VALU" in pmc[dom] and dom in stages:
             insts = pmc[dom]["SQ_INSTS_VALU"]
             iso_s = stages[dom]["avg_us"] * 1e-6
+            cyc = mix.get(dom, {}).get("mean_cycles_per_valu_inst", 4.0)
             out["roofline"]["valu"] = {
-                "bound": "valu-issue", "insts_per_launch": int(insts), "achieved": round(insts * 4 / iso_s / 1e12, 3),
-                "peak": round(N_SIMD * CLOCK_HZ / 1e12, 3), "unit": "T SIMD-cycles/s",
-                "frac": round(insts * 4 / (N_SIMD * CLOCK_HZ * iso_s), 4),
-                "source": "SQ_INSTS_VALU per launch from profiles/pmc_insts.json (rocprofv3 --pmc pass) x 4 cycles per wave64 "
-                          "instruction / (1024 SIMDs x 2.4 GHz x the kernel's isolated HIP-event duration of this run)"}
+                "bound": "valu-issue", "insts_per_launch": int(insts), "mean_cycles_per_inst": cyc,
+                "achieved": round(insts * cyc / iso_s / 1e12, 3), "peak": round(N_SIMD * clk / 1e12, 3), "unit": "T SIMD-cycles/s",
+                "frac": round(insts * cyc / (N_SIMD * clk * iso_s), 4),
+                "frac_if_every_inst_took_4_cycles": round(insts * 4 / (N_SIMD * clk * iso_s), 4),
+                "source": "SQ_INSTS_VALU per launch (profiles/pmc_insts.json, rocprofv3 --pmc pass) x the kernel's mean issue "
+                          "cost per wave64 VALU instruction (profiles/valu_class_mix.json: static mix of the 2- / 4- / 8-cycle "
+                          "classes MEASURED in profiles/r3_valu_issue.txt -- SDWA, packed-f16, v_perm, v_dot4, 3-operand and "
+                          "SGPR-operand forms issue in 4 cycles on gfx950, only plain VGPR add / logic / shift-right / 16-bit and "
+                          "f32 add / mul / fma in 2) / (1024 SIMDs x the measured shader clock x the kernel's isolated HIP-event "
+                          "duration of this run)"}
         streaming = {}
         for k in ("k_resize", "k_detect", "k_blur", "k_describe"):
             if k in stages:
@@ -478,8 +509,9 @@ def main():
                                 "frac": round(stages[k]["algorithmic_GBps"] / HBM_PEAK_GBS, 4)}
                 if full and k in pmc and "SQ_INSTS_VALU" in pmc[k]:
                     us = stages[k]["ms_total"] * 1e3 / nprof   # all launches of the stage in one batch
-                    streaming[k]["valu_frac"] = round(pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1) * 4
-                                                      / (N_SIMD * CLOCK_HZ * us * 1e-6), 4)
+                    streaming[k]["valu_frac"] = round(pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1)
+                                                      * mix.get(k, {}).get("mean_cycles_per_valu_inst", 4.0)
+                                                      / (N_SIMD * clk * us * 1e-6), 4)
         out["roofline"]["streaming"] = streaming
         if rank == 0:  # "also report against a measured device-copy peak" -- a 512 MiB device-to-device copy
             try:
@@ -510,6 +542,9 @@ def main():
         out["end_to_end_algorithmic_GBps"] = round(a_pair * value / n_ranks / 1e9, 2)
 
     extras = rank == 0 and n_ranks == 1 and a.mode == "stereo" and not a.no_extras and not c5
+    if extras and a.other_steps > 0 and (W, H) == (1280, 720):
+        # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
+        out["other_configs"] = other_configs_leg(a, local_rank, torch)
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
     if extras and a.h2d_steps > 0:
@@ -525,6 +560,46 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs_leg(a, local_rank, torch):
+    """The non-headline BASELINE configurations, timed like the headline (inputs resident in HBM, three handles, steps bracketed
+    by synchronisations) but small: 8 pairs (16 images) per step, --other-steps steps after a short preheat.  `value` of
+    the JSON line stays config C3."""
+    res = {}
+    specs = [("C2_640x480_mono", ["--mode", "mono", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
+             ("640x480_stereo", ["--mode", "stereo", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
+             ("C4_512x512_fisheye_stereo", ["--mode", "fisheye", "--width", "512", "--height", "512", "--nfeatures", "1500"])]
+    for name, argv in specs:
+        b = parse(argv + ["--pairs", "8", "--handles", str(a.handles), "--ring", "3"])
+        w2 = Workload(b, 0, local_rank, None)
+        t_end = time.perf_counter() + 0.03
+        while time.perf_counter() < t_end:      # preheat: the clocks dropped while the frames were generated
+            for _ in range(len(w2.exs)):
+                w2.step()
+            w2.exs[0].sync()
+        for _ in range(len(w2.exs)):
+            w2.step()
+        w2.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.other_steps):
+            w2.step()
+        w2.sync()
+        dt = time.perf_counter() - t0
+        units = (2 * b.pairs if b.mode == "mono" else b.pairs) * a.other_steps
+        _, _, _, ns = w2.exs[0].level_stats(0)
+        res[name] = {"value": round(units / dt, 1), "unit": "frames/s" if b.mode == "mono" else "stereo frames/s",
+                     "ms_per_step": round(1e3 * dt / a.other_steps, 4), "steps": a.other_steps,
+                     ("frames_per_step" if b.mode == "mono" else "pairs_per_step"): 2 * b.pairs if b.mode == "mono" else b.pairs,
+                     "nfeatures": b.nfeatures, "keypoints_image0": int(ns.sum())}
+        for e in w2.exs:
+            e.close()
+        del w2
+    res["note"] = ("same measurement as the headline (inputs resident, %d handles, timed steps bracketed by synchronisations) on "
+                   "small batches: 8 pairs / 16 frames per step; larger batches are faster (tools/bench_configs.sh, "
+                   "profiles/*_configs.txt)" % a.handles)
+    return res
 
 
 def _stats(v, np):
@@ -560,12 +635,27 @@ def latency_leg(a, wl, orbx, np):
         t2 = time.perf_counter()
         te.append(1e3 * (t1 - t0))
         ts.append(1e3 * (t2 - t1))
+    # the drop-in C++ class's DEFAULT (mbKeepHostPyramid = true, csrc/ORBextractor.h): every call also refreshes the host copy
+    # of both eyes' pyramids (the public mvImagePyramid of the reference) -- orbx_pyramid_download, one synchronisation per eye
+    lp = []
+    ex.extract_stereo(*frames[0], bf=BF, b=BASE)
+    bufs = [ex.pyramid_download(0), ex.pyramid_download(1)]
+    for i in range(max(10, a.latency_frames // 2)):
+        L, R = frames[i % len(frames)]
+        t0 = time.perf_counter()
+        ex.extract_stereo(L, R, bf=BF, b=BASE)
+        ex.pyramid_download(0, bufs[0])
+        ex.pyramid_download(1, bufs[1])
+        lp.append(1e3 * (time.perf_counter() - t0))
     gc.enable()
     note = ("single %dx%d stereo frame, pageable host images in, host keypoints / descriptors / uRight / depth out, %d "
-            "distinct frames; latency_ms = orbx_extract_stereo (both eyes + ComputeStereoMatches, one synchronisation); "
+            "distinct frames; latency_ms = orbx_extract_stereo (both eyes + ComputeStereoMatches, one synchronisation), i.e. the "
+            "C++ mirror with mbKeepHostPyramid = false; latency_with_host_pyramid_ms = the same plus the refresh of both eyes' "
+            "host pyramids (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep working); "
             "extract_ms / stereo_ms = the two REGISTER_TIMES brackets as separate calls (Python wrapper included)"
             % (W, H, len(frames)))
-    return {"latency_ms": _stats(lat, np), "extract_ms": _stats(te, np), "stereo_ms": _stats(ts, np), "latency_note": note}
+    return {"latency_ms": _stats(lat, np), "latency_with_host_pyramid_ms": _stats(lp, np), "extract_ms": _stats(te, np),
+            "stereo_ms": _stats(ts, np), "latency_note": note}
 
 
 def h2d_leg(a, wl, orbx, np, torch):

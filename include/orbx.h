@@ -475,6 +475,13 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 
 /* ---- test hooks -------------------------------------------------------------------------------------- */
 
+/* Measurement aid: the shader clock while other work runs.  _start launches ONE wave on a private stream that spins for
+ * spin_us microseconds between readings of s_memtime (shader cycles) and s_memrealtime (100 MHz); _finish waits for it and
+ * returns cycles / ns = GHz of the shader clock domain during that interval (the probe handle is consumed).  bench.py
+ * prints it as roofline.shader_clock_ghz instead of assuming the 2.4 GHz peak. */
+int orbx_clock_probe_start(int device, int spin_us, void** probe);
+int orbx_clock_probe_finish(void* probe, double* ghz);
+
 /* Runs the quadtree's host/device introsort replica (csrc/orbx_introsort.h) on the host: sorts n 64-bit
  * elements by their key bits 16..63, payload bits 0..15 ride along.  tests/ compare it with std::sort
  * (the tie order DistributeOctTree depends on, src/ORBextractor.cc:686). */

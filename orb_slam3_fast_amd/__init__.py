@@ -127,6 +127,8 @@ def lib():
         L.orbx_comm_destroy.restype = None
         L.orbx_comm_size.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
         L.orbx_allgather_descriptors.argtypes = [vp, vp, i, vp, vp]
+        L.orbx_clock_probe_start.argtypes = [i, i, C.POINTER(vp)]
+        L.orbx_clock_probe_finish.argtypes = [vp, C.POINTER(C.c_double)]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
         L.orbx_stage_name.restype = C.c_char_p
@@ -341,6 +343,21 @@ class ORBextractor:
                                         C.byref(w), C.byref(h)))
         return out
 
+    def pyramid_download(self, image=0, out=None):
+        """orbx_pyramid_download: every level of one image of the last extraction with ONE synchronisation (what the C++
+        mirror's mvImagePyramid refresh does).  `out` = list of preallocated [h_l, w_l] uint8 arrays to reuse."""
+        nl = self.GetLevels()
+        if out is None:
+            out = []
+            w, h = C.c_int(), C.c_int()
+            for l in range(nl):
+                _check(lib().orbx_pyramid_level(self._h, image, l, 0, None, 0, C.byref(w), C.byref(h)))
+                out.append(np.empty((h.value, w.value), np.uint8))
+        ptrs = (C.c_void_p * nl)(*[a.ctypes.data for a in out])
+        strides = (C.c_ssize_t * nl)(*[a.strides[0] for a in out])
+        _check(lib().orbx_pyramid_download(self._h, image, nl, ptrs, strides))
+        return out
+
     def debug_score_map(self, enable=True):
         """Test tap: following extractions also keep k_detect's pre-NMS FAST scores at iniThFAST (orbx_debug_score_map)."""
         _check(lib().orbx_debug_score_map(self._h, 1 if enable else 0))
@@ -357,6 +374,19 @@ class ORBextractor:
         out = np.zeros((cap, 3), np.int32)
         n = _check(lib().orbx_debug_candidates(self._h, image, level, _p(out), cap))
         return out[:n].copy()
+
+
+def clock_probe_start(device=0, spin_us=2000):
+    """orbx_clock_probe_start: one wave spins for spin_us on a private stream; finish() returns the shader clock in GHz."""
+    h = C.c_void_p()
+    _check(lib().orbx_clock_probe_start(device, int(spin_us), C.byref(h)))
+    return h
+
+
+def clock_probe_finish(probe):
+    g = C.c_double()
+    _check(lib().orbx_clock_probe_finish(probe, C.byref(g)))
+    return g.value
 
 
 COMM_ID_BYTES = 128

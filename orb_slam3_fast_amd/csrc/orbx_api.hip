@@ -486,6 +486,8 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   }
   if (ex->hostResults) (void)hipHostFree(ex->hostResults);
   ex->hostResults = nullptr;
+  if (ex->hostPyr) (void)hipHostFree(ex->hostPyr);
+  ex->hostPyr = nullptr;
   if (ex->h_lap) (void)hipHostFree(ex->h_lap);
   ex->h_lap = nullptr;
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
@@ -728,16 +730,48 @@ int orbx_pyramid_download(orbx_extractor* ex, int image, int n_levels, uint8_t* 
   if (!ex || !dst || !dst_stride) return fail(ORBX_E_BADARG, "null argument");
   if (ex->curW == 0 || image < 0 || image >= ex->lastN || n_levels < 0 || n_levels > ex->g.nlevels)
     return fail(ORBX_E_BADARG, "no such pyramid");
+  for (int l = 0; l < n_levels; l++)
+    if (dst[l] && dst_stride[l] < ex->g.lv[l].w) return fail(ORBX_E_BADARG, "destination stride smaller than the level width");
   HIPC(hipSetDevice(ex->device));
+  // A 2-D device-to-host copy into pageable memory is executed row by row by the runtime (2 800 rows per 1280x720 eye:
+  // 17 ms).  The pyramid is therefore fetched as TWO contiguous blocks -- level 0 (pitch x h) and the image's block of
+  // levels 1.. (pyrImg bytes) -- into a page-locked staging area with asynchronous 1-D copies, one synchronisation, and
+  // the rows are then laid out in the caller's arrays by the CPU (3 MB: ~0.2 ms).
+  const Geom& g = ex->g;
+  int p0 = 0;
+  const uint8_t* l0 = level_ptr(g, ex->pyr, image, 0, p0);
+  const size_t l0Bytes = (size_t)p0 * (g.lv[0].h - 1) + g.lv[0].w;
+  // the image's block holds an unused level-0 slot first: fetch [start of level 1, end of the last level)
+  const LevelDev& LL = g.lv[g.nlevels - 1];
+  const size_t restOff = g.nlevels > 1 ? (size_t)g.lv[1].off : 0;
+  const size_t restBytes = g.nlevels > 1 ? (size_t)LL.off + (size_t)LL.pitch * LL.h - restOff : 0;
+  const size_t need = l0Bytes + restBytes + 64;
+  if (ex->hostPyrBytes < need) {
+    if (ex->hostPyr) (void)hipHostFree(ex->hostPyr);
+    ex->hostPyr = nullptr;
+    ex->hostPyrBytes = 0;
+    HIPC(hipHostMalloc(reinterpret_cast<void**>(&ex->hostPyr), need, hipHostMallocDefault));
+    ex->hostPyrBytes = need;
+  }
+  uint8_t* H = ex->hostPyr;
+  const bool want0 = n_levels > 0 && dst[0];
+  bool wantRest = false;
+  for (int l = 1; l < n_levels; l++) wantRest = wantRest || dst[l];
+  if (want0) HIPC(hipMemcpyAsync(H, l0, l0Bytes, hipMemcpyDeviceToHost, ex->stream));
+  if (wantRest)
+    HIPC(hipMemcpyAsync(H + l0Bytes, ex->pyr.pyr + (long long)image * g.pyrImg + restOff, restBytes, hipMemcpyDeviceToHost, ex->stream));
+  HIPC(hipStreamSynchronize(ex->stream));
   for (int l = 0; l < n_levels; l++) {
     if (!dst[l]) continue;
-    const LevelDev& L = ex->g.lv[l];
-    if (dst_stride[l] < L.w) return fail(ORBX_E_BADARG, "destination stride smaller than the level width");
-    int p;
-    const uint8_t* src = level_ptr(ex->g, ex->pyr, image, l, p);
-    HIPC(hipMemcpy2DAsync(dst[l], dst_stride[l], src, p, L.w, L.h, hipMemcpyDeviceToHost, ex->stream));
+    const LevelDev& L = g.lv[l];
+    const uint8_t* src = l == 0 ? H : H + l0Bytes + ((size_t)L.off - restOff);
+    const size_t sp = l == 0 ? (size_t)p0 : (size_t)L.pitch;
+    if ((size_t)dst_stride[l] == sp && sp == (size_t)L.w) {
+      std::memcpy(dst[l], src, sp * L.h);
+    } else {
+      for (int y = 0; y < L.h; y++) std::memcpy(dst[l] + (size_t)y * dst_stride[l], src + (size_t)y * sp, (size_t)L.w);
+    }
   }
-  HIPC(hipStreamSynchronize(ex->stream));
   return ORBX_OK;
 }
 

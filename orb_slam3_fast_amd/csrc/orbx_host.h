@@ -247,6 +247,8 @@ struct orbx_extractor {
   int stereoPairs = 0;             // high-water allocation of d_uR / d_depth / d_sad (pairs)
   int lastStereoPairs = 0;         // pairs of the stereo association run since the last extraction (0: none)
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
+  uint8_t* hostPyr = nullptr;      // pinned staging of orbx_pyramid_download (one image's pyramid), allocated on first use
+  size_t hostPyrBytes = 0;
   int32_t* h_lap = nullptr;        // pinned copy of the lapping areas the device currently holds (lapN images)
   int lapN = 0;
   // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)

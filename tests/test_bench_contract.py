@@ -89,6 +89,8 @@ def test_bench_prints_one_contract_line(mode):
         for k in ("latency_ms", "extract_ms", "stereo_ms"):
             assert {"mean", "std", "p50", "p99", "frames"} <= set(d[k]) and d[k]["frames"] == 12 and d[k]["mean"] > 0
         assert d["h2d_inclusive_value"] > 0 and d["h2d_inclusive"]["steps"] == 4
+        assert d["latency_with_host_pyramid_ms"]["mean"] >= d["latency_ms"]["p50"] * 0.9
+    assert 0.5 < rf["shader_clock_ghz"] < 2.6    # measured, not assumed
 
 
 @pytest.mark.gpu

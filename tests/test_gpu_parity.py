@@ -69,6 +69,34 @@ def test_stages_and_end_to_end(gpu, oracle, w, h, nf, nl, stream):
     assert np.array_equal(d, od)
 
 
+def test_pyramid_download_equals_the_per_level_reads(gpu, oracle):
+    """orbx_pyramid_download (all levels, one synchronisation, pinned staging; the C++ mirror's mvImagePyramid refresh) returns
+    the bytes of orbx_pyramid_level for every level: host entry (handle-owned level 0), batched device entry (level 0 = the
+    caller's buffer, image 1 of 2), and a strided destination."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h = 752, 480
+    a, b = synth.mono_frame(w, h, 91), synth.mono_frame(w, h, 92)
+    ex = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    ex(a, (0, 0))
+    oe = oracle.OracleExtractor(1000)
+    oe.extract(a)
+    got = ex.pyramid_download(0)
+    for l in range(8):
+        assert np.array_equal(got[l], oe.level(l)) and np.array_equal(got[l], ex.image_pyramid(l)), l
+    d = DeviceBuffer.from_numpy(np.stack([a, b]))
+    ex.extract_batch_device(d.ptr.value, 2, w, h, w, w * h)
+    oe.extract(b)
+    wide = [np.full((lv.shape[0], lv.shape[1] + 13), 7, np.uint8) for lv in got]      # strided destinations
+    views = [x[:, 5:5 + lv.shape[1]] for x, lv in zip(wide, got)]
+    import ctypes as C
+    ptrs = (C.c_void_p * 8)(*[v.ctypes.data for v in views])
+    strides = (C.c_ssize_t * 8)(*[v.strides[0] for v in views])
+    orbx._check(orbx.lib().orbx_pyramid_download(ex._h, 1, 8, ptrs, strides))
+    for l in range(8):
+        assert np.array_equal(views[l], oe.level(l)), l
+        assert (wide[l][:, :5] == 7).all() and (wide[l][:, 5 + views[l].shape[1]:] == 7).all()   # nothing outside the rows
+
+
 def test_dense_corner_images_and_list_overflow_paths(gpu, oracle):
     """White noise puts ~340 corners in a 36x37 cell; with the LDS list shrunk to its minimum (320 entries: 64 corners,
     the rest survivors) that forces mid-cell flushes, the corner limit and the tile-scan NMS fallback of k_detect; the

@@ -46,6 +46,11 @@ def classify(line):
 
 
 def main(pats):
+    out_json = None
+    if "--json" in pats:
+        i = pats.index("--json")
+        out_json = pats[i + 1]
+        pats = pats[:i] + pats[i + 2:]
     res = {}
     with tempfile.TemporaryDirectory() as td:
         for f in sorted(os.listdir(CSRC)):
@@ -73,6 +78,22 @@ def main(pats):
             continue
         n = sum(d.values())
         print("%-70s %6d %6d %6d  %.2f" % (k[:70], d[2], d[4], d[8], (2 * d[2] + 4 * d[4] + 8 * d[8]) / max(1, n)))
+    if out_json:
+        import json
+        short = {}
+        for k, d in sorted(res.items()):
+            m = re.match(r"_ZN4orbx\d+(k_[a-z_0-9]+?)(I|E)", k)
+            if not m:
+                continue
+            n = sum(d.values())
+            e = {"static_2cycle": d[2], "static_4cycle": d[4], "static_8cycle": d[8],
+                 "mean_cycles_per_valu_inst": round((2 * d[2] + 4 * d[4] + 8 * d[8]) / max(1, n), 3)}
+            # several instantiations of one kernel: keep the one with the most instructions seen last (they differ by < 2 %)
+            if m.group(1) not in short or "ILb0ELi48" in k or "ILi80" in k:
+                short[m.group(1)] = e
+        short["_note"] = ("static VALU instruction mix of the product kernels by measured issue class (profiles/r3_valu_issue.txt): "
+                          "mean cycles per wave64 VALU instruction; bench.py's roofline.valu multiplies SQ_INSTS_VALU by it")
+        json.dump(short, open(out_json, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
