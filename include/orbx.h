@@ -496,6 +496,13 @@ void orbx_debug_set_detect_list_cap(int cap);
 /* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
  * than 16384 FAST candidates); 0 restores the register-resident path. */
 void orbx_debug_set_octree_global(int on);
+/* Test hook of the pyramid's fused small-level launches (k_resize_tail: up to three consecutive levels of
+ * ComputePyramid, src/ORBextractor.cc:1108-1145, per launch).  first_level: -1 = the library's policy, 0 = no fusion (every
+ * level through k_resize), >= 2 = fuse from that level on; max_levels / band_rows: levels per launch and rows of the last
+ * level per workgroup (<= 0: defaults).  Applies to handles (re)configured afterwards, i.e. to the next image SIZE a handle
+ * sees.  orbx_debug_resize_plan reports the fused segments of the handle's current size (returns their number). */
+void orbx_debug_set_resize_tail(int first_level, int max_levels, int band_rows);
+int orbx_debug_resize_plan(const orbx_extractor* ex, int32_t* first_level, int32_t* n_levels, int32_t* n_bands, int cap);
 /* Test tap of k_detect: with enable != 0 every following extraction also writes, per pyramid level, the FAST score
  * (cornerScore, 0 = not a corner) of every detectable pixel at iniThFAST -- the corner set of cv::FAST BEFORE non-max
  * suppression (src/ORBextractor.cc:810-815).  orbx_debug_score_level copies one level (w x h bytes) to the host.

@@ -141,6 +141,9 @@ def lib():
         L.orbx_debug_set_detect_list_cap.restype = None
         L.orbx_debug_set_octree_global.argtypes = [i]
         L.orbx_debug_set_octree_global.restype = None
+        L.orbx_debug_set_resize_tail.argtypes = [i, i, i]
+        L.orbx_debug_set_resize_tail.restype = None
+        L.orbx_debug_resize_plan.argtypes = [vp, vp, vp, vp, i]
         L.orbx_debug_sincos.argtypes = [i, vp, i, i, vp, vp]
         L.orbx_debug_score_map.argtypes = [vp, i]
         L.orbx_debug_score_level.argtypes = [vp, i, i, vp, C.c_ssize_t]
@@ -368,6 +371,12 @@ class ORBextractor:
         out = np.zeros((h.value, w.value), np.uint8)
         _check(lib().orbx_debug_score_level(self._h, image, level, _p(out), w.value))
         return out
+
+    def debug_resize_plan(self):
+        """Fused small-level resize launches of the handle's current image size: [(first_level, n_levels, n_bands), ...]."""
+        a, b, c = (np.zeros(16, np.int32) for _ in range(3))
+        n = _check(lib().orbx_debug_resize_plan(self._h, _p(a), _p(b), _p(c), 16))
+        return [(int(a[i]), int(b[i]), int(c[i])) for i in range(n)]
 
     def debug_candidates(self, level, image=0):
         cap = 1 << 20

@@ -208,6 +208,122 @@ void build_coefs(const Geom& g, std::vector<uint4>& xtab, std::vector<int>& yofs
   }
 }
 
+
+// ---- fused small levels of the resize chain (orbx_resize_tail.hip) ----------------------------------
+// The last levels of the pyramid -- at most kTailLevels of them, and only levels whose SOURCE has at most kTailSrcPx pixels
+// (levels 5-7 of a 1280x720 pyramid: level 4 has 214 k pixels; levels 4-7 of a 640x480 one) -- are resized in ONE fused
+// launch; a workgroup owns a band of kTailRows rows of the last level.  A segment shrinks (and a level falls back to
+// k_resize) when the cascade's LDS tiles do not fit (large scale factors).  The hook / ORBX_RESIZE_TAIL can ask for any
+// chain of segments.  Measured, step time of bench.py with three handles: 1280x720 x 64 images: no fusion 0.518 ms; levels
+// 5-7 with bands of 13 / 20 / 26 / 34 rows 0.505 / 0.503 / 0.499 / 0.500 ms; levels 4-7 0.509 ms at 13 rows, slower above;
+// levels 6-7 0.514 ms.  640x480 x 64: no fusion 0.2434 ms; levels 2-4 + 5-7 0.2484; 4-7 0.2400; 5-7 0.2415; 2-7 0.2453.
+constexpr int kTailSrcPx = 230 * 1000, kTailLevels = 4, kTailRows = 26, kTailLdsMax = 96 * 1024;
+static int g_tail_first = -1, g_tail_levels = kTailLevels, g_tail_rows = kTailRows;  // test hook (orbx_debug_set_resize_tail)
+
+// One segment: levels lA .. lA+nT-1 from level lA-1.  Returns false when it cannot be built (LDS, quad limit).
+static bool build_tail_segment(const Geom& g, const std::vector<int>& yofs, int lA, int nT, int R, TailPlan& tp,
+                               std::vector<TailBand>& nd) {
+  std::memset(&tp, 0, sizeof(tp));
+  nd.clear();
+  if (lA < 2 || nT < 2 || lA + nT > g.nlevels || nT > ORBX_MAX_LEVELS) return false;
+  const int hTop = g.lv[lA + nT - 1].h;
+  const int nB = (hTop + R - 1) / R;
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  // nd[b][t + 1] = rows of level lA + t band b computes, nd[b][0] = rows of level lA - 1 it stages
+  nd.assign((size_t)nB * (nT + 1), TailBand{0, 0, 0, 0});
+  for (int b = 0; b < nB; b++) nd[(size_t)b * (nT + 1) + nT] = {b * R, std::min((b + 1) * R, hTop) - 1, 0, 0};
+  for (int t = nT - 1; t >= 0; t--) {  // rows of cascade position t (level lA + t - 1) from those of position t + 1
+    const LevelDev &D = g.lv[lA + t], &S = g.lv[lA + t - 1];
+    for (int b = 0; b < nB; b++) {
+      const TailBand& d = nd[(size_t)b * (nT + 1) + t + 1];
+      TailBand& s = nd[(size_t)b * (nT + 1) + t];
+      s.first = clampi(yofs[D.ycoef + d.first], 0, S.h - 1);
+      s.last = clampi(yofs[D.ycoef + d.last] + 1, 0, S.h - 1);
+      if (t > 0) {  // an output level: every row must be produced by somebody
+        if (b == 0) s.first = 0;
+        if (b == nB - 1) s.last = S.h - 1;
+      }
+    }
+    if (t > 0)
+      for (int b = 0; b + 1 < nB; b++) {  // no gaps between consecutive bands (scale factors > 2 skip source rows)
+        TailBand& s = nd[(size_t)b * (nT + 1) + t];
+        s.last = std::max(s.last, nd[(size_t)(b + 1) * (nT + 1) + t].first - 1);
+      }
+  }
+  int maxRows[ORBX_MAX_LEVELS + 1] = {0};
+  for (int b = 0; b < nB; b++)
+    for (int t = 0; t <= nT; t++) {
+      TailBand& e = nd[(size_t)b * (nT + 1) + t];
+      e.ownEnd = t == 0 ? 0 : (b + 1 < nB ? nd[(size_t)(b + 1) * (nT + 1) + t].first : g.lv[lA + t - 1].h);
+      maxRows[t] = std::max(maxRows[t], e.last - e.first + 1);
+    }
+  size_t tile[2] = {0, 0};
+  int rtab = 0;
+  for (int t = 0; t <= nT; t++) {
+    const LevelDev& V = g.lv[lA + t - 1];
+    tp.pitch[t] = align_up(V.w + 8, 16);
+    if (t < nT) tile[t & 1] = std::max(tile[t & 1], (size_t)maxRows[t] * tp.pitch[t]);  // the last level is not kept
+    if (t > 0) {
+      if ((V.w + 3) / 4 > 512) return false;  // a thread of k_resize_tail owns one quad of columns
+      tp.rtOff[t - 1] = rtab;
+      rtab += maxRows[t];
+    }
+    if ((long long)maxRows[t] * (V.w + 16) >= (1 << 20)) return false;  // (the kernel's float index split)
+  }
+  const size_t lds = (size_t)align_up(tile[0], 16) + align_up(tile[1], 16) + (size_t)rtab * 16;
+  if (lds > (size_t)kTailLdsMax) return false;
+  tp.rtTotal = rtab;
+  tp.lA = lA;
+  tp.nT = nT;
+  tp.nBands = nB;
+  tp.tileBytes[0] = align_up(tile[0], 16);
+  tp.tileBytes[1] = align_up(tile[1], 16);
+  tp.ldsBytes = (unsigned)lds;
+  return true;
+}
+
+// All segments of the current geometry, in level order; tp.bandOff = first entry of the segment in `bands`.
+void build_tail_plans(const Geom& g, const std::vector<int>& yofs, std::vector<TailPlan>& plans, std::vector<TailBand>& bands) {
+  plans.clear();
+  bands.clear();
+  static const bool envRead = [] {  // diagnostic knob, same meaning as the hook: ORBX_RESIZE_TAIL=first[,levels[,rows]]
+    if (const char* e = getenv("ORBX_RESIZE_TAIL")) {
+      int a = -1, b = 0, c = 0;
+      if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 1) {
+        g_tail_first = a;
+        if (b > 0) g_tail_levels = b;
+        if (c > 0) g_tail_rows = c;
+      }
+    }
+    return true;
+  }();
+  (void)envRead;
+  if (g_tail_first == 0) return;  // (fusion off)
+  const int L = g.nlevels;
+  int l = 2;
+  if (g_tail_first > 0) {
+    l = std::max(2, g_tail_first);
+  } else {  // the library's policy: one segment, the last (at most kTailLevels) small levels
+    while (l < L && (long long)g.lv[l - 1].w * g.lv[l - 1].h > kTailSrcPx) l++;
+    l = std::max(l, L - kTailLevels);
+  }
+  while (L - l >= 2) {
+    TailPlan tp;
+    std::vector<TailBand> nd;
+    int nT = std::min(g_tail_levels, L - l);
+    if (L - l - nT == 1) nT = (L - l >= 4 && g_tail_levels >= 2) ? nT - 1 : nT + 1;  // never leave a single level behind
+    while (nT >= 2 && !build_tail_segment(g, yofs, l, nT, g_tail_rows, tp, nd)) nT--;
+    if (nT < 2) {  // this level through k_resize, try again from the next one
+      l++;
+      continue;
+    }
+    tp.bandOff = (int)bands.size();
+    bands.insert(bands.end(), nd.begin(), nd.end());
+    plans.push_back(tp);
+    l += nT;
+  }
+}
+
 int configure(orbx_extractor* ex, int w, int h) {
   if (w == ex->curW && h == ex->curH) return ORBX_OK;
   // every per-axis table (resize coefficients, row tables) is sized for max_width x max_height: a wide-and-short image
@@ -237,6 +353,17 @@ int configure(orbx_extractor* ex, int w, int h) {
   HIPC(hipMemcpy(ex->d_yofs.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
   HIPC(hipMemcpy(ex->d_yab.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
   HIPC(prepare_kernels(g));
+  std::vector<TailPlan> plans;
+  std::vector<TailBand> bands;
+  build_tail_plans(g, yofs, plans, bands);
+  if (!plans.empty()) {
+    if (ex->d_tailBands.n < bands.size()) HIPC(ex->d_tailBands.alloc(bands.size()));
+    HIPC(hipMemcpy(ex->d_tailBands.p, bands.data(), bands.size() * sizeof(TailBand), hipMemcpyHostToDevice));
+    unsigned lds = 0;
+    for (const TailPlan& tp : plans) lds = std::max(lds, tp.ldsBytes);
+    HIPC(prepare_resize_tail(lds));
+  }
+  ex->tails = plans;
   ex->g = g;
   ex->curW = w;
   ex->curH = h;
@@ -348,9 +475,17 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) 
   const Geom& g = ex->g;
   hipStream_t s = ex->stream;
   ex->blurValid = false;  // the blurred levels (orbx_pyramid_level blurred = 1) are produced on demand
-  for (int l = 1; l < g.nlevels; l++) {
+  size_t seg = 0;  // next fused segment of small levels (ex->tails, in level order)
+  for (int l = 1; l < g.nlevels;) {
     StageTimer t(ex, s, ORBX_STAGE_RESIZE);
-    HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+    if (seg < ex->tails.size() && ex->tails[seg].lA == l) {
+      const TailPlan& tp = ex->tails[seg++];
+      HIPC(launch_resize_tail(g, ex->pyr, tp, ex->d_tailBands.p + tp.bandOff, n, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+      l += tp.nT;
+    } else {
+      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+      l++;
+    }
   }
   if (ex->d_dbgScore.p) HIPC(hipMemsetAsync(ex->d_dbgScore.p, 0, ex->d_dbgScore.n, s));  // test tap only
   // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
@@ -493,7 +628,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
-  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_yofs.free();
+  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
@@ -1009,6 +1144,24 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
 void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
 void orbx_debug_set_octree_global(int on) { debug_set_octree_global(on); }
+void orbx_debug_set_resize_tail(int first_level, int max_levels, int band_rows) {
+  orbx_host::g_tail_first = first_level;
+  orbx_host::g_tail_levels = max_levels > 0 ? max_levels : orbx_host::kTailLevels;
+  orbx_host::g_tail_rows = band_rows > 0 ? band_rows : orbx_host::kTailRows;
+}
+int orbx_debug_resize_plan(const orbx_extractor* ex, int32_t* first_level, int32_t* n_levels, int32_t* n_bands, int cap) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  int n = 0;
+  for (const TailPlan& tp : ex->tails) {
+    if (n < cap) {
+      if (first_level) first_level[n] = tp.lA;
+      if (n_levels) n_levels[n] = tp.nT;
+      if (n_bands) n_bands[n] = tp.nBands;
+    }
+    n++;
+  }
+  return n;
+}
 int orbx_debug_introsort_device(int device, uint64_t* v, int n) {
   if (!v || n < 0 || n > 4000) return fail(ORBX_E_BADARG, "bad argument");
   if (n == 0) return ORBX_OK;

@@ -241,6 +241,8 @@ struct orbx_extractor {
   DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
   DevBuf<short> d_yab;
   DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
+  std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)
+  DevBuf<orbx::TailBand> d_tailBands;
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;

@@ -70,6 +70,24 @@ __host__ __device__ inline int key_x(uint32_t k) { return k & 0xFFF; }
 __host__ __device__ inline int key_y(uint32_t k) { return (k >> 12) & 0xFFF; }
 __host__ __device__ inline int key_r(uint32_t k) { return k >> 24; }
 
+// Fused small levels of the resize chain (orbx_resize_tail.hip): levels lA .. lA+nT-1 in one launch, a workgroup per band of
+// rows of the segment's last level.  bands[band * (nT + 1) + 0] = rows of level lA-1 the band stages; [.. + 1 + t] = rows of
+// level lA+t it computes (first..last) and writes to the pyramid (first..ownEnd-1).
+struct TailBand {
+  int first, last, ownEnd, pad_;
+};
+struct TailPlan {
+  int lA, nT, nBands, bandOff;         // bandOff: the segment's first entry in the handle's band table (host side)
+  int tileBytes[2];                    // ping-pong LDS tiles (even / odd cascade position)
+  int pitch[ORBX_MAX_LEVELS + 1];      // LDS row pitch of cascade position t (0 = level lA-1)
+  int rtOff[ORBX_MAX_LEVELS];          // first row-table entry of fused level t
+  int rtTotal;                         // row-table entries of all fused levels
+  unsigned ldsBytes;
+};
+hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int nimg,
+                              const uint4* xtab, const int* yofs, const short* yab, hipStream_t s);
+hipError_t prepare_resize_tail(unsigned ldsBytes);
+
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,
                          const short* yab, hipStream_t s);

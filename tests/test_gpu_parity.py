@@ -240,6 +240,49 @@ def test_extractor_parameter_sweep(gpu, oracle, nf, sf, nl, ini, mn, w, h):
         assert np.array_equal(ex.image_pyramid(l), oe.level(l))
 
 
+@pytest.mark.parametrize("w,h,sf,nl,first,levels,rows,plan", [
+    (1280, 720, 1.2, 8, -1, 0, 0, [(5, 3)]),            # the library's policy at the benchmark size: levels 5-7 in one launch
+    (640, 480, 1.2, 8, -1, 0, 0, [(4, 4)]),             # small images: the last four levels
+    (752, 480, 1.2, 8, 3, 3, 0, [(3, 3), (6, 2)]),      # EuRoC size, hook: a three- and a two-level segment
+    (1280, 720, 1.2, 8, 0, 0, 0, []),                    # fusion off: every level through k_resize
+    (640, 480, 1.2, 8, 2, 6, 7, [(2, 6)]),              # six levels in one cascade, 7-row bands (20 bands)
+    (640, 480, 1.2, 8, 3, 2, 60, [(3, 2), (5, 3)]),     # tall bands (3 per image); a remainder of 3 levels is taken whole
+    (800, 600, 1.1, 12, -1, 0, 0, None),                 # 12 levels at 1.1
+    (1024, 768, 1.5, 6, 2, 4, 9, None),                  # scale 1.5
+    (1536, 1152, 2.5, 4, 2, 2, 5, [(2, 2)]),             # scale 2.5: source rows no destination row needs (gap rows)
+    (2700, 2100, 3.0, 4, 2, 2, 4, [(2, 2)]),             # scale 3
+    (333, 517, 1.2, 6, 2, 4, 3, None),                   # portrait, odd sizes, widths not a multiple of 4
+])
+def test_fused_small_level_resize(gpu, oracle, w, h, sf, nl, first, levels, rows, plan):
+    """k_resize_tail (several consecutive pyramid levels per launch, row bands with recomputed halos) produces the bytes of
+    cv::resize level by level (src/ORBextractor.cc:1108-1145), for every segmentation the policy or the hook can pick; the
+    batched entry (3 images) goes through the same launches."""
+    lib = orbx.lib()
+    lib.orbx_debug_set_resize_tail(first, levels, rows)
+    try:
+        ex = orbx.ORBextractor(500, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+        oe = oracle.OracleExtractor(500, sf, nl, 20, 7)
+        imgs = np.stack([synth.mono_frame(w, h, 300 + i) for i in range(3)])
+        from orb_slam3_fast_amd.hipmem import DeviceBuffer
+        pitch = (w + 3) // 4 * 4  # (device batches want 4-byte aligned rows)
+        padded = np.zeros((3, h, pitch), np.uint8)
+        padded[:, :, :w] = imgs
+        d = DeviceBuffer.from_numpy(padded)
+        ex.extract_batch_device(d.ptr.value, 3, w, h, pitch, pitch * h)
+        ex.sync()
+        got = ex.debug_resize_plan()
+        if plan is not None:
+            assert [(a, b) for a, b, _ in got] == plan
+        else:
+            assert got, "the fused path was expected to apply here"
+        for i in (0, 2):
+            oe.extract(imgs[i], (0, 0))
+            for l in range(nl):
+                assert np.array_equal(ex.image_pyramid(l, image=i), oe.level(l)), "image %d level %d (plan %r)" % (i, l, got)
+    finally:
+        lib.orbx_debug_set_resize_tail(-1, 0, 0)
+
+
 def test_fisheye_stereo_flow(gpu, oracle):
     """TUM-VI-like config C4: 512x512, 1500 features, lapping areas, then the brute-force kNN of
     ComputeStereoFishEyeMatches on the lapping descriptors [mono, N) of both eyes (src/Frame.cc:1275-1302)."""
