@@ -629,7 +629,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
   ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free();
-  ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_rowItems.free();
+  ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
   if (ex->stream) (void)hipStreamDestroy(ex->stream);
@@ -956,8 +956,10 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
     HIPC(left->d_uR.alloc((size_t)n_pairs * capL));
     HIPC(left->d_depth.alloc((size_t)n_pairs * capL));
     HIPC(left->d_sad.alloc((size_t)n_pairs * capL));
-    HIPC(left->d_rowStart.alloc((size_t)n_pairs * (left->maxH + 2)));
-    HIPC(left->d_rowItems.alloc((size_t)n_pairs * right->gmax.outCap));
+    const size_t capS = std::max(capL, (size_t)right->gmax.outCap);
+    HIPC(left->d_rowStart.alloc((size_t)n_pairs * 2 * (left->maxH + 2)));
+    HIPC(left->d_srec.alloc((size_t)n_pairs * 2 * capS));
+    HIPC(left->d_sdesc.alloc((size_t)n_pairs * 2 * capS * 2));
     left->stereoPairs = n_pairs;
   }
   left->lastStereoPairs = n_pairs;
@@ -982,12 +984,14 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
   a.depth = left->d_depth.p;
   a.sad = left->d_sad.p;
   a.rowStart = left->d_rowStart.p;
-  a.rowItems = left->d_rowItems.p;
+  a.srec = left->d_srec.p;
+  a.sdesc = left->d_sdesc.p;
+  a.cap = (int)std::max(capL, (size_t)right->gmax.outCap);
   a.imgH = left->curH;
   a.band = (int)std::ceil(2.0f * left->scale.back()) + 2;
   {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
-    HIPC(launch_stereo_rows(a, n_pairs, left->stream));
+    HIPC(launch_stereo_sort(left->g, a, n_pairs, left->stream));
   }
   {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);

@@ -238,9 +238,10 @@ struct orbx_extractor {
   DevBuf<uint8_t> d_dbgScore;      // test tap (orbx_debug_score_map): FAST scores at iniThFAST, pyramid layout; normally unallocated
   DevBuf<uint32_t> d_cand, d_cellCand, d_sel;
   DevBuf<uint16_t> d_knode;
-  DevBuf<int> d_rowStart, d_rowItems, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
+  DevBuf<int> d_rowStart, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
   DevBuf<short> d_yab;
   DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
+  DevBuf<uint4> d_srec, d_sdesc;   // row-sorted keypoint records / descriptors of both eyes (k_stereo_sort)
   std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)
   DevBuf<orbx::TailBand> d_tailBands;
   DevBuf<orbx_keypoint> d_kps;

@@ -114,12 +114,14 @@ struct StereoArgs {
   float* uRight;                 // [pairs][capL]
   float* depth;
   int* sad;                      // [pairs][capL] best SAD or -1
-  int* rowStart;                 // [pairs][imgH + 1] CSR of right keypoints by integer row
-  int* rowItems;                 // [pairs][capR] right keypoint indices, grouped by row
+  int* rowStart;                 // [pairs][2][imgH + 1] CSR of the left / right keypoints by integer row (k_stereo_sort)
+  uint4* srec;                   // [pairs][2][cap] row-sorted records {x, y, octave | index << 8, minr | maxr << 16}
+  uint4* sdesc;                  // [pairs][2][cap][2] the descriptors in the same order
+  int cap;                       // max(capL, capR): stride of srec / sdesc
   int imgH;                      // level-0 height
   int band;                      // max rows a right keypoint's +-2*scale band can be away from its own row
 };
-hipError_t launch_stereo_rows(const StereoArgs& a, int npairs, hipStream_t s);
+hipError_t launch_stereo_sort(const Geom& g, const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
                                hipStream_t s);
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);

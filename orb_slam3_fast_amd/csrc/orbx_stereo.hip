@@ -6,241 +6,490 @@ namespace orbx {
 
 // ================================================================================================ stereo
 
-// Right keypoints bucketed by integer row (counting sort, one block per pair): the analogue of the
-// reference's vRowIndices table (src/Frame.cc:930-949), but one entry per keypoint; the +-2*scale band is
-// applied by the matcher, which only has to visit rows [vL - band, vL + band].
-__global__ __launch_bounds__(256) void k_stereo_rows(StereoArgs a) {
+// Both eyes' keypoints sorted by integer row (counting sort, one block per (pair, eye)): the analogue of the reference's
+// vRowIndices table (src/Frame.cc:930-949).  Next to the CSR row table the block writes what the matcher reads, in row
+// order: one 16-byte record per keypoint {x, y, octave | index << 8, minr | maxr << 16} -- [minr, maxr] = the +-2*scale row
+// band of a RIGHT keypoint (:944-948); maxr = -1 marks the (0,0) points the reference skips (:943) -- and its descriptor.
+// A band of left rows then finds its own keypoints and its candidates as two contiguous, coalesced ranges.
+constexpr int kSortNT = 512, kSortItems = 4;  // register-resident path: up to 2048 keypoints per image
+__global__ __launch_bounds__(kSortNT) void k_stereo_sort(Geom g, StereoArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int* hist = reinterpret_cast<int*>(smem);  // imgH + 1 counters, then running offsets
-  __shared__ int tsum[256];
-  const int tid = threadIdx.x, pair = blockIdx.x;
-  const int imgR = a.firstR + pair;
-  const int nR = a.nR[imgR];
-  const orbx_keypoint* kR = a.kR + (long long)imgR * a.capR;
-  int* rowStart = a.rowStart + (long long)pair * (a.imgH + 1);
-  int* items = a.rowItems + (long long)pair * a.capR;
-  for (int r = tid; r <= a.imgH; r += 256) hist[r] = 0;
+  __shared__ int wsum[kSortNT / 64];
+  const int tid = threadIdx.x, pair = blockIdx.x >> 1, eye = blockIdx.x & 1;
+#ifdef ST_PROF
+  long long sq[12]; int nsq = 0;
+#define SS_MK() do { if (nsq < 12) sq[nsq++] = wall_clock64(); } while (0)
+#else
+#define SS_MK() do {} while (0)
+#endif
+  SS_MK();
+  const int img = (eye ? a.firstR : a.firstL) + pair;
+  const int cap = eye ? a.capR : a.capL;
+  const int n = (eye ? a.nR : a.nL)[img];
+  const orbx_keypoint* kp = (eye ? a.kR : a.kL) + (long long)img * cap;
+  const uint4* dsc = reinterpret_cast<const uint4*>((eye ? a.dR : a.dL) + (long long)img * cap * 32);
+  int* rowStart = a.rowStart + (long long)(pair * 2 + eye) * (a.imgH + 1);
+  uint4* rec = a.srec + (long long)(pair * 2 + eye) * a.cap;
+  uint4* sd = a.sdesc + (long long)(pair * 2 + eye) * a.cap * 2;
+  // everything the scatter needs is requested up front, beside the load of n (one memory round trip for the whole kernel
+  // when n <= 2048)
+  __shared__ float lvS[ORBX_MAX_LEVELS];
+  if (tid < g.nlevels) lvS[tid] = g.lv[tid].scale;
+  float kx[kSortItems], ky[kSortItems];
+  int ko[kSortItems];
+  uint4 kd0[kSortItems], kd1[kSortItems];
+  {
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+      const int i = min(tid + j * kSortNT, cap - 1);  // (entries past n are inside the buffer and never used)
+      kx[j] = kp[i].x;
+      ky[j] = kp[i].y;
+      ko[j] = kp[i].octave;
+      kd0[j] = dsc[2 * i];
+      kd1[j] = dsc[2 * i + 1];
+    }
+  }
+  SS_MK();
+  for (int r = tid; r <= a.imgH; r += kSortNT) hist[r] = 0;
+  const bool inRegs = n <= kSortNT * kSortItems;
   __syncthreads();
-  for (int i = tid; i < nR; i += 256) atomicAdd(&hist[min(max((int)kR[i].y, 0), a.imgH - 1)], 1);
+  auto row_of = [&](float y) { return min(max((int)y, 0), a.imgH - 1); };
+  if (inRegs) {
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++)
+      if (tid + j * kSortNT < n) atomicAdd(&hist[row_of(ky[j])], 1);
+  } else {
+    for (int i = tid; i < n; i += kSortNT) atomicAdd(&hist[row_of(kp[i].y)], 1);
+  }
+  SS_MK();
   __syncthreads();
-  const int per = (a.imgH + 256) >> 8;
+  SS_MK();
+  // exclusive prefix over the rows: a contiguous chunk per thread, wave scans of the chunk sums, wave totals through LDS
+  const int per = (a.imgH + kSortNT) / kSortNT;
   const int b = min(tid * per, a.imgH + 1), e = min(b + per, a.imgH + 1);
   int sum = 0;
   for (int r = b; r < e; r++) sum += hist[r];
-  tsum[tid] = sum;
+  const int incl = wave_scan_dpp(sum);
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int t = tid >= d ? tsum[tid - d] : 0;
-    __syncthreads();
-    tsum[tid] += t;
-    __syncthreads();
-  }
-  int run = tid ? tsum[tid - 1] : 0;
+  int run = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
   for (int r = b; r < e; r++) {
     const int c = hist[r];
     hist[r] = run;
     rowStart[r] = run;
     run += c;
   }
+  SS_MK();
   __syncthreads();
-  for (int i = tid; i < nR; i += 256) items[atomicAdd(&hist[min(max((int)kR[i].y, 0), a.imgH - 1)], 1)] = i;
+  SS_MK();
+  // the permutation happens in LDS (when n <= 2048): 16-byte stores scattered over global memory, three per keypoint, were
+  // half of the kernel's time; the sorted arrays then leave as linear, coalesced copies
+  uint4* srecL = reinterpret_cast<uint4*>(smem + (((size_t)(a.imgH + 2) * 4 + 15) & ~(size_t)15));  // [kSortNT * kSortItems]
+  uint4* sdL = srecL + kSortNT * kSortItems;                                                          // [.. * 2]
+  auto emit = [&](int i, float x, float y, int oct, const uint4& d0, const uint4& d1, uint4* orec, uint4* odesc) {
+    const int pos = atomicAdd(&hist[row_of(y)], 1);
+    const float r = __fmul_rn(2.0f, lvS[oct]);
+    int maxr = (int)ceilf(__fadd_rn(y, r)), minr = (int)floorf(__fsub_rn(y, r));
+    if (y == 0.0f && x == 0.0f) maxr = -1;
+    orec[pos] = make_uint4(__float_as_uint(x), __float_as_uint(y), (uint32_t)oct | ((uint32_t)i << 8),
+                           ((uint32_t)minr & 0xFFFFu) | ((uint32_t)maxr << 16));
+    odesc[2 * pos] = d0;
+    odesc[2 * pos + 1] = d1;
+  };
+  if (inRegs) {
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++)
+      if (tid + j * kSortNT < n) emit(tid + j * kSortNT, kx[j], ky[j], ko[j], kd0[j], kd1[j], srecL, sdL);
+    __syncthreads();
+    for (int i = tid; i < n; i += kSortNT) rec[i] = srecL[i];
+    for (int i = tid; i < 2 * n; i += kSortNT) sd[i] = sdL[i];
+  } else {
+    for (int i = tid; i < n; i += kSortNT) {
+      const orbx_keypoint k = kp[i];
+      emit(i, k.x, k.y, k.octave, dsc[2 * i], dsc[2 * i + 1], rec, sd);
+    }
+  }
+  SS_MK();
+#ifdef ST_PROF
+  if (tid == 0 && blockIdx.x == 9) {
+    printf("k_stereo_sort n %d:", n);
+    for (int i = 1; i < nsq; i++) printf(" %d", (int)(sq[i] - sq[i - 1]));
+    printf("  (x10 ns: issue loads | zero+hist | bar | scan | bar | scatter)\n");
+  }
+#endif
 }
 
-hipError_t launch_stereo_rows(const StereoArgs& a, int npairs, hipStream_t s) {
-  hipLaunchKernelGGL(k_stereo_rows, dim3(npairs), dim3(256), (size_t)(a.imgH + 2) * 4, s, a);
+hipError_t launch_stereo_sort(const Geom& g, const StereoArgs& a, int npairs, hipStream_t s) {
+  const size_t lds = (((size_t)(a.imgH + 2) * 4 + 15) & ~(size_t)15) + (size_t)kSortNT * kSortItems * 48;
+  static bool prepared = false;  // (> 64 KB of dynamic LDS needs the attribute; idempotent, so a race sets it twice at worst)
+  if (!prepared) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+    if (e != hipSuccess) return e;
+    prepared = true;
+  }
+  hipLaunchKernelGGL(k_stereo_sort, dim3(2 * npairs), dim3(kSortNT), lds, s, g, a);
   return hipGetLastError();
 }
 
-// One wave per left keypoint.  The reference scans vRowIndices[vL] (right keypoints whose +-2*scale row band
-// covers row vL, ascending iR) and keeps the first strict minimum; that is the minimum of (dist, iR) over
-// all right keypoints passing the same band/octave/disparity filters, which is what the lanes compute.
-__global__ __launch_bounds__(256) void k_stereo_match(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // one left keypoint per wave: SGPR
-  const int pair = blockIdx.y;
-  const int imgL = a.firstL + pair, imgR = a.firstR + pair;
-  const int nL = a.nL[imgL];
-  if (iL >= nL) return;
-  const long long oL = (long long)pair * a.capL + iL;
-  const orbx_keypoint kpL = a.kL[(long long)imgL * a.capL + iL];
-  const orbx_keypoint* kR = a.kR + (long long)imgR * a.capR;
-  const uint32_t* dR = reinterpret_cast<const uint32_t*>(a.dR + (long long)imgR * a.capR * 32);
-  uint32_t dl[8];
-  {
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(a.dL + ((long long)imgL * a.capL + iL) * 32);
-#pragma unroll
-    for (int i = 0; i < 8; i++) dl[i] = q[i];
+// Median-of-SAD outlier cut (:1072-1083): median = element size/2 of the ascending (SAD, iL) list, i.e. the (size/2)-th
+// smallest SAD; matches with SAD >= 1.5*1.4*median are dropped.  One 256-thread workgroup per pair, its own launch: run
+// instead by the pair's last k_stereo_band workgroup to finish (arrival counter + __threadfence) it was bit-exact and 25x
+// slower -- a device-scope release writes the XCD's L2 back, once per workgroup (k_stereo_band 23 -> 612 us).
+// The order statistic is found exactly with a two-level LDS histogram (SAD <= 121*255 < 2^15: high 8 bits, low 7 bits); the
+// bucket holding a rank is located with a block-wide prefix sum.
+// first bucket k with hist[0] + .. + hist[k] > rank; returns (k, rank - (hist[0] + .. + hist[k-1])) through s_v[0], s_v[1]
+__device__ __forceinline__ void bucket_of_rank(const int* hist, int rank, int* wsum, int* s_v, int tid) {
+  const int h = hist[tid];
+  const int incl = wave_scan_dpp(h);
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+  const int hi = base + incl, lo = hi - h;
+  if (lo <= rank && rank < hi) {
+    s_v[0] = tid;
+    s_v[1] = rank - lo;
   }
-  float uR_out = -1.f, depth_out = -1.f;
-  int sad_out = -1;
-  const float uL = kpL.x, vL = kpL.y;
-  const int levelL = kpL.octave;
-  const float maxD = __fdiv_rn(a.bf, a.b);
-  const float minU = __fsub_rn(uL, maxD), maxU = uL;
-  const int row = (int)vL;
-  uint32_t best = (100u << 16);  // TH_HIGH, strict '<'
-  float bestX = 0.f;             // u of this lane's best candidate (saves the dependent kR[best] load after the reduction)
-  if (!(maxU < 0)) {
-    const int* rowStart = a.rowStart + (long long)pair * (a.imgH + 1);
-    const int* items = a.rowItems + (long long)pair * a.capR;
-    const int jb = rowStart[min(max(row - a.band, 0), a.imgH)], je = rowStart[min(max(row + a.band + 1, 0), a.imgH)];
-    for (int base = jb; base < je; base += 64) {
-      const int j = base + lane;
-      if (j < je) {
-        const int iR = items[j];
-        const orbx_keypoint k = kR[iR];
-        // the descriptor row is fetched together with the keypoint (both depend only on iR): one memory round trip
-        // instead of two on the kernel's critical path (it is latency-, not bandwidth-bound)
-        const uint4* dq = reinterpret_cast<const uint4*>(dR + (long long)iR * 8);
-        const uint4 q0 = dq[0], q1 = dq[1];
-        const float r = __fmul_rn(2.0f, g.lv[k.octave].scale);
-        const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));
-        const bool ok = !(k.y == 0.0f && k.x == 0.0f) && row >= minr && row <= maxr &&
-                        k.octave >= levelL - 1 && k.octave <= levelL + 1 && k.x >= minU && k.x <= maxU;
-        if (ok) {
-          const int d = __popc(dl[0] ^ q0.x) + __popc(dl[1] ^ q0.y) + __popc(dl[2] ^ q0.z) + __popc(dl[3] ^ q0.w) +
-                        __popc(dl[4] ^ q1.x) + __popc(dl[5] ^ q1.y) + __popc(dl[6] ^ q1.z) + __popc(dl[7] ^ q1.w);
-          const uint32_t cand = ((uint32_t)d << 16) | (uint32_t)iR;
-          if (cand < best) {
-            best = cand;
-            bestX = k.x;
-          }
-        }
-      }
-    }
-  }
-  const uint32_t mine = best;
-  best = wave_min_dpp(best);
-  const int bestDist = (int)(best >> 16);
-  if (bestDist < 75) {  // thOrbDist = (TH_HIGH + TH_LOW) / 2
-    const uint64_t owners = __ballot(mine == best);  // iR is unique per candidate: exactly the lane(s) that saw it
-    const float uR0 = __shfl(bestX, (int)__builtin_ctzll(owners));
-    const float sf = 1.0f / g.lv[levelL].scale;  // mvInvScaleFactors
-    const float su = roundf(__fmul_rn(kpL.x, sf)), sv = roundf(__fmul_rn(kpL.y, sf)), sr = roundf(__fmul_rn(uR0, sf));
-    const LevelDev L = g.lv[levelL];
-    const float endu = sr + 11.0f;
-    if (!(sr < 0 || endu >= (float)L.w)) {
-      int pitchL, pitchR;
-      const uint8_t* imL = level_ptr(g, pl, imgL, levelL, pitchL);
-      const uint8_t* imR = level_ptr(g, pr, imgR, levelL, pitchR);
-      const int yl = (int)sv - 5, xl = (int)su - 5, xr0 = (int)sr - 5;
-      // 11x11 SAD for the 11 shifts; lanes cover the 121 pixels
-      int sadv[11];
-      int l0 = 0, l1 = 0;
-      const int p0 = lane, p1 = lane + 64;
-      const int y0 = p0 / 11, x0 = p0 - y0 * 11, y1 = p1 / 11, x1 = p1 - y1 * 11;
-      l0 = imL[(long long)(yl + y0) * pitchL + xl + x0];
-      if (p1 < 121) l1 = imL[(long long)(yl + y1) * pitchL + xl + x1];
-#pragma unroll
-      for (int inc = 0; inc < 11; inc++) {
-        int s = abs(l0 - (int)imR[(long long)(yl + y0) * pitchR + xr0 + (inc - 5) + x0]);
-        if (p1 < 121) s += abs(l1 - (int)imR[(long long)(yl + y1) * pitchR + xr0 + (inc - 5) + x1]);
-        sadv[inc] = wave_sum_dpp(s);  // (six v_add_dpp; the 11 sums are independent chains)
-      }
-      int bestSad = 0x7FFFFFFF, bestinc = 0;
-#pragma unroll
-      for (int inc = 0; inc < 11; inc++)
-        if (sadv[inc] < bestSad) {
-          bestSad = sadv[inc];
-          bestinc = inc - 5;
-        }
-      if (bestinc != -5 && bestinc != 5) {
-        float d1 = 0, d2 = 0, d3 = 0;
-#pragma unroll
-        for (int inc = 1; inc < 10; inc++)
-          if (inc - 5 == bestinc) {
-            d1 = (float)sadv[inc - 1];
-            d2 = (float)sadv[inc];
-            d3 = (float)sadv[inc + 1];
-          }
-        const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
-        const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
-        if (!(deltaR < -1 || deltaR > 1)) {
-          float bestuR = __fmul_rn(g.lv[levelL].scale, __fadd_rn(__fadd_rn(sr, (float)bestinc), deltaR));
-          float disparity = __fsub_rn(uL, bestuR);
-          if (disparity >= 0 && disparity < maxD) {
-            if (disparity <= 0) {
-              disparity = 0.01f;
-              bestuR = (float)__dsub_rn((double)uL, 0.01);
-            }
-            depth_out = __fdiv_rn(a.bf, disparity);
-            uR_out = bestuR;
-            sad_out = bestSad;
-          }
-        }
-      }
-    }
-  }
-  if (lane == 0) {
-    a.uRight[oL] = uR_out;
-    a.depth[oL] = depth_out;
-    a.sad[oL] = sad_out;
-  }
+  __syncthreads();
 }
-
-// Median-of-SAD outlier cut (:1072-1083): median = element size/2 of the ascending (SAD, iL) list, i.e. the
-// (size/2)-th smallest SAD; matches with SAD >= 1.5*1.4*median are dropped.  One block per pair; the order
-// statistic is found exactly with a two-level LDS histogram (SAD <= 121*255 < 2^15: high 8 bits, low 7 bits).
-__global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a) {
-  __shared__ int hist[256];
-  __shared__ int s_v[4];
-  const int tid = threadIdx.x, pair = blockIdx.x;
+constexpr int kFiltItems = 8;  // register-resident path: up to 2048 left keypoints per pair
+__device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair, int tid, int* hist, int* wsum, int* s_v) {
   const int nL = a.nL[a.firstL + pair];
   const int* sad = a.sad + (long long)pair * a.capL;
+  const bool inRegs = nL <= 256 * kFiltItems;
+  int sv[kFiltItems];  // this thread's SADs (-1: no match / past the end): one memory round trip for all three passes
+#pragma unroll
+  for (int j = 0; j < kFiltItems; j++) sv[j] = (inRegs && tid + j * 256 < nL) ? sad[tid + j * 256] : -1;
   hist[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < nL; i += 256) {
-    const int s = sad[i];
-    if (s >= 0) atomicAdd(&hist[min(s >> 7, 255)], 1);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int m = 0;
-    for (int k = 0; k < 256; k++) m += hist[k];
-    int target = m / 2, k = 0, cum = 0;  // 0-based rank of the median
-    if (m > 0) {
-      while (cum + hist[k] <= target) cum += hist[k++];
+  int cnt = 0;
+  if (inRegs) {
+#pragma unroll
+    for (int j = 0; j < kFiltItems; j++)
+      if (sv[j] >= 0) {
+        atomicAdd(&hist[min(sv[j] >> 7, 255)], 1);
+        cnt++;
+      }
+  } else {
+    for (int i = tid; i < nL; i += 256) {
+      const int s = sad[i];
+      if (s >= 0) {
+        atomicAdd(&hist[min(s >> 7, 255)], 1);
+        cnt++;
+      }
     }
-    s_v[0] = m;
-    s_v[1] = k;
-    s_v[2] = target - cum;  // rank inside the bucket
   }
+  cnt = wave_sum_dpp(cnt);
+  if ((tid & 63) == 0) wsum[4 + (tid >> 6)] = cnt;
   __syncthreads();
-  const int m = s_v[0];
+  const int m = wsum[4] + wsum[5] + wsum[6] + wsum[7];
   if (m == 0) return;  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
-  const int bucket = s_v[1];
+  bucket_of_rank(hist, m / 2, wsum, s_v, tid);  // 0-based rank of the median
+  const int bucket = s_v[0], rankIn = s_v[1];
   __syncthreads();
   hist[tid] = 0;
   __syncthreads();
-  for (int i = tid; i < nL; i += 256) {
-    const int s = sad[i];
-    if (s >= 0 && min(s >> 7, 255) == bucket) atomicAdd(&hist[s & 127], 1);
+  if (inRegs) {
+#pragma unroll
+    for (int j = 0; j < kFiltItems; j++)
+      if (sv[j] >= 0 && min(sv[j] >> 7, 255) == bucket) atomicAdd(&hist[sv[j] & 127], 1);
+  } else {
+    for (int i = tid; i < nL; i += 256) {
+      const int s = sad[i];
+      if (s >= 0 && min(s >> 7, 255) == bucket) atomicAdd(&hist[s & 127], 1);
+    }
   }
   __syncthreads();
-  if (tid == 0) {
-    int k = 0, cum = 0;
-    while (cum + hist[k] <= s_v[2]) cum += hist[k++];
-    s_v[3] = (bucket << 7) | k;
-  }
-  __syncthreads();
-  const float median = (float)s_v[3];
+  bucket_of_rank(hist, rankIn, wsum, s_v, tid);
+  const float median = (float)((bucket << 7) | s_v[0]);
   const float th = __fmul_rn(1.5f * 1.4f, median);
-  for (int i = tid; i < nL; i += 256) {
-    const int s = sad[i];
+  auto cut = [&](int i, int s) {
     if (s >= 0 && !((float)s < th)) {
       a.uRight[(long long)pair * a.capL + i] = -1.f;
       a.depth[(long long)pair * a.capL + i] = -1.f;
     }
+  };
+  if (inRegs) {
+#pragma unroll
+    for (int j = 0; j < kFiltItems; j++) cut(tid + j * 256, sv[j]);
+  } else {
+    for (int i = tid; i < nL; i += 256) cut(i, sad[i]);
   }
+}
+
+// ComputeStereoMatches (src/Frame.cc:951-1068) for a band of kStereoBand left rows per workgroup.
+//   1. the band's left keypoints (<= 64 per trip) and the right keypoints of rows [r0 - band, r0 + kStereoBand + band)
+//      (<= kStereoRC per trip) come from the row-sorted arrays into LDS: two dependent memory round trips per workgroup
+//      where the wave-per-keypoint kernel of rounds 1-2 made four per keypoint;
+//   2. a wave per left keypoint, lanes over the staged candidates: the reference scans vRowIndices[vL] in ascending iR and
+//      keeps the first strict minimum -- the minimum of (dist, iR) over the candidates passing the row-band / octave /
+//      disparity tests, which is what the lanes compute (descriptor words are stored word-major: conflict-free);
+//   3. the 11 x 11 SAD refinement (:1007-1062) with 16 lanes per matched keypoint, four keypoints per wave: a lane owns one
+//      window row -- the left row's 11 bytes and the 21 right bytes all 11 shifts touch sit in registers (aligned dword
+//      loads + v_alignbyte), three v_sad_u8 per shift -- and the 11 row sums meet in lane 15 by DPP row shifts.
+template <int kStereoBand, int NT, int kStereoRC, int kStereoLC>
+__global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
+  __shared__ uint4 Lrec[kStereoLC];
+  __shared__ uint32_t Ldesc[kStereoLC][8];
+  __shared__ uint32_t Lbest[kStereoLC];
+  __shared__ float Lbx[kStereoLC];
+  __shared__ uint8_t Lq[kStereoLC];  // entries with an ORB match, in entry order
+  __shared__ int nQ, nQw[2];
+  __shared__ uint4 Rrec[kStereoRC];
+  __shared__ uint32_t Rdesc[8][kStereoRC];
+  __shared__ int lvW[ORBX_MAX_LEVELS], lvP[ORBX_MAX_LEVELS];
+  __shared__ long long lvO[ORBX_MAX_LEVELS];
+  __shared__ float lvS[ORBX_MAX_LEVELS];
+  const int tid = threadIdx.x;
+  const int pair = blockIdx.y, r0 = blockIdx.x * kStereoBand;
+#ifdef ST_PROF
+  long long tq[16]; int nq_ = 0;
+#define ST_MK() do { if (nq_ < 16) tq[nq_++] = wall_clock64(); } while (0)
+#else
+#define ST_MK() do {} while (0)
+#endif
+  ST_MK();
+  const int imgL = a.firstL + pair, imgR = a.firstR + pair;
+  const int* rsL = a.rowStart + (long long)(pair * 2) * (a.imgH + 1);
+  const int* rsR = rsL + (a.imgH + 1);
+  const int jLb = rsL[r0], jLe = rsL[min(r0 + kStereoBand, a.imgH)];
+  if (jLb == jLe) return;  // no left keypoint in these rows
+  const int jRb = rsR[max(r0 - a.band, 0)], jRe = rsR[min(r0 + kStereoBand + a.band, a.imgH)];
+  const uint4* recL = a.srec + (long long)(pair * 2) * a.cap;
+  const uint4* recR = recL + a.cap;
+  const uint4* sdL = a.sdesc + (long long)(pair * 2) * a.cap * 2;
+  const uint4* sdR = sdL + (long long)a.cap * 2;
+  if (tid < g.nlevels) {
+    lvW[tid] = g.lv[tid].w;
+    lvP[tid] = tid ? g.lv[tid].pitch : (int)pl.l0Row;
+    lvO[tid] = g.lv[tid].off;
+    lvS[tid] = g.lv[tid].scale;
+  }
+  const float maxD = __fdiv_rn(a.bf, a.b);
+  ST_MK();
+  for (int lc = jLb; lc < jLe; lc += kStereoLC) {
+    const int nl = min(kStereoLC, jLe - lc);
+    __syncthreads();  // (the previous trip's SAD stage has read Lrec / Lbest)
+    if (tid < nl) {
+      Lrec[tid] = recL[lc + tid];
+      Lbest[tid] = 100u << 16;  // TH_HIGH, strict '<'
+      Lbx[tid] = 0.f;
+    }
+    for (int i = tid; i < 2 * nl; i += NT) {
+      const uint4 d = sdL[2 * lc + i];
+      uint32_t* q = &Ldesc[i >> 1][(i & 1) * 4];
+      q[0] = d.x; q[1] = d.y; q[2] = d.z; q[3] = d.w;
+    }
+    for (int rc = jRb; rc < jRe; rc += kStereoRC) {
+      const int nr = min(kStereoRC, jRe - rc);
+      __syncthreads();  // (the previous trip's match stage has read Rrec / Rdesc)
+      for (int i = tid; i < nr; i += NT) Rrec[i] = recR[rc + i];
+      for (int i = tid; i < 2 * nr; i += NT) {
+        const uint4 d = sdR[2 * rc + i];
+        const int c = i >> 1, k0 = (i & 1) * 4;
+        Rdesc[k0][c] = d.x; Rdesc[k0 + 1][c] = d.y; Rdesc[k0 + 2][c] = d.z; Rdesc[k0 + 3][c] = d.w;
+      }
+      ST_MK();
+      __syncthreads();
+      ST_MK();
+      // 16 lanes per left keypoint (four keypoints per wave side by side), lane s takes candidates s, s + 16, ...
+      for (int li = tid >> 4; li < nl; li += NT / 16) {
+        const uint4 lr = Lrec[li];
+        const float uL = __uint_as_float(lr.x), vL = __uint_as_float(lr.y);
+        const int levelL = (int)(lr.z & 0xFF);
+        const float minU = __fsub_rn(uL, maxD), maxU = uL;
+        const int row = (int)vL;
+        uint32_t best = 100u << 16;
+        float bestX = 0.f;
+        if (!(maxU < 0)) {
+          uint32_t dl[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) dl[k] = Ldesc[li][k];
+          for (int c = tid & 15; c < nr; c += 16) {
+            const uint4 rr = Rrec[c];
+            const float x = __uint_as_float(rr.x);
+            const int oct = (int)(rr.z & 0xFF);
+            const int minr = (int)(int16_t)(rr.w & 0xFFFF), maxr = (int)rr.w >> 16;
+            if (row >= minr && row <= maxr && oct >= levelL - 1 && oct <= levelL + 1 && x >= minU && x <= maxU) {
+              int d = 0;
+#pragma unroll
+              for (int k = 0; k < 8; k++) d += __popc(dl[k] ^ Rdesc[k][c]);
+              const uint32_t cand = ((uint32_t)d << 16) | (rr.z >> 8);
+              if (cand < best) {
+                best = cand;
+                bestX = x;
+              }
+            }
+          }
+        }
+        // minimum over the 16 lanes of the row (lanes without a source keep their own value), then lane 15's total back
+        // to every lane of the row; keys are unique (iR), so exactly one lane owns the minimum
+        uint32_t m = best;
+        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x111, 0xf, 0xf, false));
+        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x112, 0xf, 0xf, false));
+        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x114, 0xf, 0xf, false));
+        m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x118, 0xf, 0xf, false));
+        m = (uint32_t)__shfl((int)m, 15, 16);
+        if (best == m && m < Lbest[li]) {  // (this row of lanes is the only writer of entry li)
+          Lbest[li] = m;
+          Lbx[li] = bestX;
+        }
+      }
+    }
+    ST_MK();
+    __syncthreads();
+    ST_MK();
+    // ---- left keypoints without an ORB match are finished; the others queue for the SAD refinement
+    {
+      const bool matched = tid < nl && (int)(Lbest[min(tid, kStereoLC - 1)] >> 16) < 75;  // thOrbDist = (TH_HIGH + TH_LOW) / 2
+      const uint64_t mm = __ballot(matched);  // (entries live in the first kStereoLC / 64 waves)
+      if (kStereoLC > 64) {
+        if (tid < kStereoLC && (tid & 63) == 0) nQw[tid >> 6] = (int)__popcll(mm);
+        __syncthreads();
+      }
+      const int base = (kStereoLC > 64 && tid >= 64) ? nQw[0] : 0;
+      if (matched) Lq[base + prefix_count(mm)] = (uint8_t)tid;
+      if (tid == 0) nQ = kStereoLC > 64 ? nQw[0] + nQw[1] : (int)__popcll(mm);
+      if (tid < nl && !matched) {
+        const long long o = (long long)pair * a.capL + (int)(Lrec[tid].z >> 8);
+        a.uRight[o] = -1.f;
+        a.depth[o] = -1.f;
+        a.sad[o] = -1;
+      }
+    }
+    __syncthreads();
+    // ---- SAD refinement: group = 16 lanes, lane r < 11 = window row r; groups take queue entries grp, grp + NT/16, ...
+    const int grp = tid >> 4, r = tid & 15;
+    const int nq = nQ;
+    for (int qi = grp; qi < nq; qi += NT / 16) {
+      const int li = Lq[qi];
+      const uint4 lr = Lrec[li];
+      const uint32_t bestKey = Lbest[li];
+      const float uL = __uint_as_float(lr.x), vL = __uint_as_float(lr.y), uR0 = Lbx[li];
+      const int levelL = (int)(lr.z & 0xFF), iL = (int)(lr.z >> 8);
+      float uR_out = -1.f, depth_out = -1.f;
+      int sad_out = -1;
+      (void)bestKey;
+      {
+        const float scl = lvS[levelL];
+        const float sf = 1.0f / scl;  // mvInvScaleFactors
+        const float su = roundf(__fmul_rn(uL, sf)), sv = roundf(__fmul_rn(vL, sf)), sr = roundf(__fmul_rn(uR0, sf));
+        const float endu = sr + 11.0f;
+        if (!(sr < 0 || endu >= (float)lvW[levelL])) {
+          const int pitchL = lvP[levelL], pitchR = levelL ? pitchL : (int)pr.l0Row;
+          const uint8_t* imL = levelL ? pl.pyr + (long long)imgL * g.pyrImg + lvO[levelL] : pl.l0 + (long long)imgL * pl.l0Img;
+          const uint8_t* imR = levelL ? pr.pyr + (long long)imgR * g.pyrImg + lvO[levelL] : pr.l0 + (long long)imgR * pr.l0Img;
+          const int yl = (int)sv - 5, xl = (int)su - 5, xr = (int)sr - 10;  // right window of shift inc starts at xr + inc
+          int sadv[11];
+          {
+            uint32_t L0 = 0, L1 = 0, L2 = 0, R[6] = {0, 0, 0, 0, 0, 0};
+            if (r < 11) {
+              const int oL = (yl + r) * pitchL + xl, oR = (yl + r) * pitchR + xr;
+              const uint32_t* qL = reinterpret_cast<const uint32_t*>(imL + (oL & ~3));
+              const uint32_t* qR = reinterpret_cast<const uint32_t*>(imR + (oR & ~3));
+              const uint32_t l0 = qL[0], l1 = qL[1], l2 = qL[2], l3 = qL[3];
+              const uint32_t e0 = qR[0], e1 = qR[1], e2 = qR[2], e3 = qR[3], e4 = qR[4], e5 = qR[5];
+              const uint32_t shL = (uint32_t)(oL & 3), shR = (uint32_t)(oR & 3);
+              L0 = __builtin_amdgcn_alignbyte(l1, l0, shL);
+              L1 = __builtin_amdgcn_alignbyte(l2, l1, shL);
+              L2 = __builtin_amdgcn_alignbyte(l3, l2, shL) & 0x00FFFFFFu;  // bytes 8..10
+              R[0] = __builtin_amdgcn_alignbyte(e1, e0, shR);
+              R[1] = __builtin_amdgcn_alignbyte(e2, e1, shR);
+              R[2] = __builtin_amdgcn_alignbyte(e3, e2, shR);
+              R[3] = __builtin_amdgcn_alignbyte(e4, e3, shR);
+              R[4] = __builtin_amdgcn_alignbyte(e5, e4, shR);
+              R[5] = __builtin_amdgcn_alignbyte(0u, e5, shR);
+            }
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++) {
+              const int k = inc >> 2, sh = inc & 3;
+              const uint32_t W0 = sh ? __builtin_amdgcn_alignbyte(R[k + 1], R[k], (uint32_t)sh) : R[k];
+              const uint32_t W1 = sh ? __builtin_amdgcn_alignbyte(R[k + 2], R[k + 1], (uint32_t)sh) : R[k + 1];
+              const uint32_t W2 = (sh ? __builtin_amdgcn_alignbyte(R[k + 3], R[k + 2], (uint32_t)sh) : R[k + 2]) & 0x00FFFFFFu;
+              uint32_t sum = __builtin_amdgcn_sad_u8(L0, W0, 0u);
+              sum = __builtin_amdgcn_sad_u8(L1, W1, sum);
+              sum = __builtin_amdgcn_sad_u8(L2, W2, sum);
+              int v = (int)sum;  // rows 11..15 hold zeros: L* = R* = 0
+              v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1 .. 8: lane 15 = the row's total
+              v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+              v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+              v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+              sadv[inc] = v;
+            }
+          }
+          if (r == 15) {
+            int bestSad = 0x7FFFFFFF, bestinc = 0;
+#pragma unroll
+            for (int inc = 0; inc < 11; inc++)
+              if (sadv[inc] < bestSad) {
+                bestSad = sadv[inc];
+                bestinc = inc - 5;
+              }
+            if (bestinc != -5 && bestinc != 5) {
+              float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+              for (int inc = 1; inc < 10; inc++)
+                if (inc - 5 == bestinc) {
+                  d1 = (float)sadv[inc - 1];
+                  d2 = (float)sadv[inc];
+                  d3 = (float)sadv[inc + 1];
+                }
+              const float den = __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2)));
+              const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), den);
+              if (!(deltaR < -1 || deltaR > 1)) {
+                float bestuR = __fmul_rn(scl, __fadd_rn(__fadd_rn(sr, (float)bestinc), deltaR));
+                float disparity = __fsub_rn(uL, bestuR);
+                if (disparity >= 0 && disparity < maxD) {
+                  if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = (float)__dsub_rn((double)uL, 0.01);
+                  }
+                  depth_out = __fdiv_rn(a.bf, disparity);
+                  uR_out = bestuR;
+                  sad_out = bestSad;
+                }
+              }
+            }
+          }
+        }
+      }
+      if (r == 15) {
+        const long long o = (long long)pair * a.capL + iL;
+        a.uRight[o] = uR_out;
+        a.depth[o] = depth_out;
+        a.sad[o] = sad_out;
+      }
+    }
+    ST_MK();
+  }
+#ifdef ST_PROF
+  if (tid == 0 && (pair % 8) == 5 && (blockIdx.x % 9) == 4) {
+    char buf[200]; (void)buf;
+    printf("band %2d pair %2d nL %2d nR %2d start %5lld: tab %d | stage %d bar %d match %d bar %d queue+SAD %d  (x10 ns; total %d)\n", (int)blockIdx.x, pair,
+           jLe - jLb, jRe - jRb, tq[0] % 100000, (int)(tq[1] - tq[0]), (int)(tq[2] - tq[1]), (int)(tq[3] - tq[2]), (int)(tq[4] - tq[3]),
+           (int)(tq[5] - tq[4]), (int)(tq[6] - tq[5]), (int)(tq[nq_ - 1] - tq[0]));
+  }
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_stereo_filter(StereoArgs a) {
+  __shared__ int fhist[256], fw[8], fv[2];
+  stereo_filter_pair(a, blockIdx.x, threadIdx.x, fhist, fw, fv);
+}
+hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
                                hipStream_t s) {
-  hipLaunchKernelGGL(k_stereo_match, dim3((a.capL + 3) / 4, npairs), dim3(256), 0, s, g, pl, pr, a);
-  return hipGetLastError();
-}
-hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) {
-  hipLaunchKernelGGL(k_stereo_filter, dim3(npairs), dim3(256), 0, s, a);
+  // band rows / threads / right-trip / left-trip sizes measured at 1280x720, 32 pairs (kernel alone): 8/256/256/64 22.9 us,
+  // 16/256/256/64 26.5, 16/512/256/64 24.7, 24/512/256/128 20.7, 32/512/256/128 20.3, 32/1024/512/128 23.6, 8/128/256/64 28.8
+#define ORBX_SB(BR, NT, RC, LC) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a)
+  ORBX_SB(24, 512, 256, 128);
+#undef ORBX_SB
   return hipGetLastError();
 }
 

@@ -356,9 +356,17 @@ def test_strided_input_and_reuse(gpu, oracle):
         assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)) and np.array_equal(d, od)
 
 
-@pytest.mark.parametrize("w,h,nf,stream", [(640, 480, 1000, 31), (1280, 720, 1500, 32)])
-def test_stereo_matches(gpu, oracle, w, h, nf, stream):
+@pytest.mark.parametrize("w,h,nf,stream,stripe", [
+    (640, 480, 1000, 31, None), (1280, 720, 1500, 32, None),
+    (1280, 720, 4000, 33, None),         # > 2048 keypoints per eye: the loop paths of k_stereo_sort / k_stereo_filter
+    (1280, 720, 1500, 34, (300, 380)),   # all texture in 80 rows: several left and right trips per band in k_stereo_band
+])
+def test_stereo_matches(gpu, oracle, w, h, nf, stream, stripe):
     L, R = synth.stereo_pair(w, h, stream)
+    if stripe:
+        for im in (L, R):
+            im[:stripe[0]] = 128
+            im[stripe[1]:] = 128
     exL = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
     exR = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
     oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
@@ -372,6 +380,9 @@ def test_stereo_matches(gpu, oracle, w, h, nf, stream):
     ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
     n = len(kL)
     assert (ou >= 0).sum() > n // 5
+    if stripe:
+        rows = np.bincount(okL["y"].astype(int), minlength=h)
+        assert np.convolve(rows, np.ones(8, int)).max() > 64, "the case should put more than 64 left keypoints into one band"
     assert np.array_equal(u[0, :n].view(np.uint32), ou.view(np.uint32))
     assert np.array_equal(dep[0, :n].view(np.uint32), od.view(np.uint32))
 
