@@ -1082,7 +1082,40 @@ struct OctCtx {  // node tables are double buffered: buffer b of table T sits at
   int* cellpre;
   int* s_i;
   int maxn;
+  uint16_t* owner;  // gather only: candidate k -> FAST cell, aliasing every table in front of tsum (ownerBytes)
+  int ownerBytes;
 };
+
+// Dense candidate k -> (cell, index in cell) for the gather.  Every cell writes its index over its range of an LDS map
+// (a few fire-and-forget ds_write per thread), so a candidate's slot address is two LDS reads; the binary search over the
+// cell prefix it replaces was ten DEPENDENT reads per candidate, 12 of a level-0 workgroup's 46 us.  The map aliases the
+// node tables, which nothing uses yet; levels with more candidates than it holds keep the search.
+template <class CD>
+__device__ __forceinline__ void octree_gather(CD& cd, const OctCtx& c, const LevelDev& L, int n, int cells,
+                                              const uint32_t* __restrict__ sparse) {
+  if (2 * n <= c.ownerBytes) {  // (uniform)
+    for (int cell = threadIdx.x; cell < cells; cell += OCT_NT) {
+      const int b = c.cellpre[cell], e = min(c.cellpre[cell + 1], n);
+      for (int i = b; i < e; i++) c.owner[i] = (uint16_t)cell;
+    }
+    __syncthreads();
+    cd.fill([&](int k) {
+      const int cell = c.owner[k];
+      return sparse[(long long)cell * L.cellCap + (k - c.cellpre[cell])];
+    });
+    __syncthreads();  // the map's bytes become node tables again
+  } else {
+    // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
+    cd.fill([&](int k) {
+      int lo = 0, hi = cells;  // largest cell with cellpre[cell] <= k
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (c.cellpre[mid] <= k) lo = mid; else hi = mid;
+      }
+      return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
+    });
+  }
+}
 
 template <bool REG>
 __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, const OctCtx& c, int n, int cells,
@@ -1102,15 +1135,7 @@ __device__ __forceinline__ void octree_body(const Geom& g, const LevelDev& L, co
   cd.keys = keys;
   cd.kn = kn;
   cd.n = n;
-  // dense index k -> (cell, i) by binary search over the LDS-resident prefix: balanced, no per-cell loops
-  cd.fill([&](int k) {
-    int lo = 0, hi = cells;  // largest cell with cellpre[cell] <= k
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (c.cellpre[mid] <= k) lo = mid; else hi = mid;
-    }
-    return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
-  });
+  octree_gather(cd, c, L, n, cells, sparse);
   MK();
   const int N = L.quota;
   struct Buf {  // nx0[b][i] etc. as before, by address arithmetic (no pointer arrays -> no scratch)
@@ -1496,20 +1521,21 @@ __host__ __device__ inline bool oct_hist_fits(int nIni) {  // oct_layout reserve
 // returns false when a node deeper than the table had to be split (caller falls back to octree_body)
 __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& L, const OctCtx& c, int n, int cells,
                                                  const uint32_t* __restrict__ sparse, uint32_t* __restrict__ keys,
-                                                 uint32_t* __restrict__ out, int* __restrict__ outCount) {
+                                                 uint32_t* __restrict__ out, int* __restrict__ outCount, int prof) {
   const int tid = threadIdx.x;
+#ifdef OCT_PROF  // section timing of the selected level's block of image 0 (tools/octree_prof.py)
+  long long hmk[48]; int nhmk = 0;
+#define HMK() do { if (nhmk < 48) hmk[nhmk++] = wall_clock64(); } while (0)
+#else
+#define HMK() do {} while (0)
+#endif
+  HMK();
   OctCands<true> cd;
   cd.keys = keys;
   cd.kn = nullptr;
   cd.n = n;
-  cd.fill([&](int k) {
-    int lo = 0, hi = cells;  // largest cell with cellpre[cell] <= k
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (c.cellpre[mid] <= k) lo = mid; else hi = mid;
-    }
-    return sparse[(long long)lo * L.cellCap + (k - c.cellpre[lo])];
-  });
+  octree_gather(cd, c, L, n, cells, sparse);
+  HMK();  // gather
   const int N = L.quota;
   struct Buf {
     char* base;
@@ -1563,6 +1589,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     });
   }
   __syncthreads();
+  HMK();  // sweep 1 (path codes + depth-5 histogram)
   for (int d = OCT_HD - 1; d >= 0; d--) {  // 4-ary sums
     const uint32_t* ch = hist + oct_hbase(nIni, d + 1);
     uint32_t* pa = hist + oct_hbase(nIni, d);
@@ -1593,6 +1620,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
   int cur = 0;
   bool finish = false;
   int nE = 0, ecur = 0;
+  HMK();  // 4-ary sums + roots
   // ---- phase 1: split every expandable node per pass (:610-677)
   while (!finish) {
     const int prevSize = nA;
@@ -1672,6 +1700,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
       break;  // -> phase 2
     }
   }
+  HMK();  // phase 1
   // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
   while (!finish) {
     const int prevSize = nA;
@@ -1680,6 +1709,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     // the whole workgroup sorts; scratch: scan (stopper lists), E2 (rank scatter), tsum (segment lists)
     introsort_block(E, nE, E2, reinterpret_cast<uint16_t*>(scan), reinterpret_cast<uint16_t*>(scan) + c.maxn + 4,
                     reinterpret_cast<uint32_t*>(tsum));
+    HMK();  // sort
     if (tid == 0) {
       s_i[1] = nE;  // cut (exclusive count of processed) defaults to all
       s_i[2] = 0;   // broke
@@ -1797,6 +1827,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     nE = tce;
     ecur ^= 1;
     if (broke || nA == prevSize) finish = true;
+    HMK();  // rest of the phase-2 round
   }
   // ---- candidate -> final node: every final node marks its (depth, code); a depth-OCT_HD code belongs to its deepest
   // marked ancestor
@@ -1817,6 +1848,7 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     t5[c5] = v;
   }
   __syncthreads();
+  HMK();  // leaf table
   // ---- best response per node, first candidate (reference order) wins ties (:741-754), as in octree_body
   uint64_t* best = scan;
   uint64_t* bestr = reinterpret_cast<uint64_t*>(c.cntr);  // [node][nrepB]; overwrites the histogram (no longer needed)
@@ -1852,6 +1884,15 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     if ((int)nd < nOut && best[nd] == rank_key(key)) out[nd] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
   });
   if (tid == 0) *outCount = nOut;
+  HMK();  // best-response sweeps
+#ifdef OCT_PROF
+  if (tid == 0 && prof) {
+    printf("hist n=%d nA=%d :", n, nA);
+    for (int i = 1; i < nhmk; i++) printf(" %d", (int)(hmk[i] - hmk[i - 1]));
+    printf("  (x10 ns: gather | sweep1 | sums+roots | phase 1 | {sort, rest} per phase-2 round | leaf table | best sweeps)\n");
+  }
+#endif
+#undef HMK
   return true;
 }
 
@@ -1891,6 +1932,8 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   c.cellpre = (int*)(smem + o.cellpre);
   c.s_i = s_i;
   c.maxn = maxn;
+  c.owner = (uint16_t*)smem;
+  c.ownerBytes = o.tsum;
 
   // ---- exclusive scan of the level's per-cell counts (the sparse per-cell slots are compacted by octree_body;
   // candidate order is irrelevant: ties are broken by the canonical rank)
@@ -1936,7 +1979,7 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
     const int nIni = (int)roundf((float)W / (float)H);
     bool done = false;
     if (forceGlobal == 0 && oct_hist_fits(nIni)) {
-      done = octree_hist_body(g, L, c, n, cells, sparse, keys, out, outCount);
+      done = octree_hist_body(g, L, c, n, cells, sparse, keys, out, outCount, profLevel == l && img == 0);
       __syncthreads();
     }
     if (!done) octree_body<true>(g, L, c, n, cells, sparse, keys, kn, out, outCount, profLevel == l && img == 0);
