@@ -488,6 +488,9 @@ hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, cons
   // band rows / threads / right-trip / left-trip sizes measured at 1280x720, 32 pairs (kernel alone): 8/256/256/64 22.9 us,
   // 16/256/256/64 26.5, 16/512/256/64 24.7, 24/512/256/128 20.7, 32/512/256/128 20.3, 32/1024/512/128 23.6, 8/128/256/64 28.8
 #define ORBX_SB(BR, NT, RC, LC) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a)
+  // (64-thread workgroups -- 4 rows / 64 candidates per trip -- run 41 us alone and the 3-handle step of bench.py is 0.8 %
+  // SHORTER with them, 0.4853 vs 0.4895 ms: small workgroups get scheduled between k_detect's one-wave cells, large ones
+  // wait for it to drain; not adopted, the single-frame latency matters more than 0.8 %)
   ORBX_SB(24, 512, 256, 128);
 #undef ORBX_SB
   return hipGetLastError();
