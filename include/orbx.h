@@ -417,6 +417,41 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                     const orbx_projected_point* points, int n_points, int check_orientation,
                                     uint8_t* occupied, int32_t* match);
 
+/* Replaces the matching part of the relocalisation matcher ORBmatcher::SearchByProjection(Frame& CurrentFrame,
+ * KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1808-1918; callers
+ * src/Tracking.cc:3631-3632,3645-3646 with (th, ORBdist) = (10, 100) and (3, 64)).  points[i] = the key frame's i-th
+ * map point after the caller's pose / camera projection and gates (:1826-1851): valid = 0 for a missing / bad /
+ * already-found point, a projection outside the image bounds or a distance outside the scale-invariance range; (u, v);
+ * radius = th * mvScaleFactors[nPredictedLevel]; (min_level, max_level) = (nPredictedLevel - 1, nPredictedLevel + 1);
+ * angle = pKF->mvKeysUn[i].angle; desc = pMP->GetDescriptor().  ur and has_observations are not read: this flavour has
+ * no stereo gate, and its occupancy gate is a plain non-null test (:1871), so EVERY assignment occupies its keypoint.
+ * occupied[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL (in/out: on return also set for the new matches and
+ * clear again for the ones the rotation-consistency cull removed, :1910-1913).  Best Hamming < 256 by strict first
+ * minimum over the free candidates, accepted if <= orb_dist (0..255).  match[i2] = index i of the assigned point or -1.
+ * Returns nmatches after the cull, or a negative error. */
+int orbx_search_by_projection_keyframe(int device, const orbx_keypoint* kps_un, const uint8_t* desc, int n, float min_x,
+                                       float min_y, float max_x, float max_y, const orbx_projected_point* points,
+                                       int n_points, int orb_dist, int check_orientation, uint8_t* occupied,
+                                       int32_t* match);
+
+/* Replaces ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t, size_t>>& vMatchedPairs,
+ * bOnlyStereo, bCoarse) (src/ORBmatcher.cc:886-1106; caller LocalMapping::CreateNewMapPoints) for single-camera key frames
+ * (mpCamera2 == NULL in both; NLeft == -1).  *_1 / *_2 = pKF1 / pKF2: mFeatVec as CSR (ascending node ids, as orbx_bow_transform
+ * returns it), mvKeysUn, mDescriptors, has_map_point[i] = (GetMapPoint(i) != NULL), u_right = mvuRight (NULL: no stereo
+ * observations, i.e. monocular).  scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2 (nlevels2 entries);
+ * ep = pKF2->mpCamera->project(T2w * pKF1->GetCameraCenter()) (:897-901); F12 = the fundamental matrix
+ * Pinhole::epipolarConstrain forms on every call, K1^-T [t12]x R12 K2^-1 (src/CameraModels/Pinhole.cpp:130-133), row-major,
+ * computed once by the caller (not read when coarse != 0).  matches12[idx1] = idx2 or -1; vMatchedPairs = its non-negative
+ * entries in ascending idx1 (:1095-1103).  Like the reference (vbMatched2 is never set, :933,976) one feature of pKF2 may be
+ * paired with several of pKF1.  Returns nmatches after the rotation-consistency cull, or a negative error. */
+int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                  int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
+                                  const float* u_right1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,
+                                  const uint32_t* feature_idx2, int n_nodes2, const orbx_keypoint* kps2, const uint8_t* desc2,
+                                  const uint8_t* has_map_point2, const float* u_right2, int n2, const float* scale_factors2,
+                                  const float* level_sigma2_2, int nlevels2, const float ep[2], const float F12[9], int only_stereo,
+                                  int coarse, int check_orientation, int32_t* matches12);
+
 /* Stereo-fisheye frames (F.Nleft != -1): the frame holds N = n_left + n_right keypoints (mvKeys then mvKeysRight), one
  * descriptor row each in the same order, mGrid over the left and mGridRight over the right keypoints, and the stereo
  * association mvLeftToRightMatch / mvRightToLeftMatch (orbx_fisheye_stereo_match).  orbx_map_point_right carries the

@@ -535,3 +535,36 @@ def search_by_bow(kf_fv, kf_desc, kf_angle, kf_valid, f_fv, f_desc, f_angle, n_l
     n = lib().oro_search_by_bow(_p(kn), len(kn), _p(ks), _p(kf), _p(kd), _p(ka), _p(kv), _p(fn), len(fn), _p(fs), _p(ff), _p(fd), _p(fa),
                                 len(fd), int(n_left_f), C.c_float(nnratio), int(check_ori), _p(match))
     return n, match
+
+
+def search_by_projection_keyframe(k, desc, bounds, pts, orb_dist, check_ori, occupied):
+    """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1808-1918."""
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    pts = np.ascontiguousarray(pts, PP_DTYPE)
+    occ = np.ascontiguousarray(occupied, np.uint8).copy()
+    match = np.zeros(len(k), np.int32)
+    n = lib().oro_search_by_projection_keyframe(_p(k), _p(desc), len(k), C.c_float(bounds[0]), C.c_float(bounds[1]),
+                                                C.c_float(bounds[2]), C.c_float(bounds[3]), _p(pts), len(pts), int(orb_dist),
+                                                int(check_ori), _p(occ), _p(match))
+    return n, match, occ
+
+
+def search_for_triangulation(fv1, k1, d1, has_mp1, uright1, fv2, k2, d2, has_mp2, uright2, scale_factors2, level_sigma2_2, ep, F12,
+                             only_stereo=False, coarse=False, check_ori=True):
+    """ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:886-1106 (single-camera key frames).  fv = (nodes, start, features)."""
+    n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+    n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+    k1, k2 = np.ascontiguousarray(k1), np.ascontiguousarray(k2)
+    d1, d2 = _u8(d1), _u8(d2)
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    u1 = None if uright1 is None else np.ascontiguousarray(uright1, np.float32)
+    u2 = None if uright2 is None else np.ascontiguousarray(uright2, np.float32)
+    sf, sg = np.ascontiguousarray(scale_factors2, np.float32), np.ascontiguousarray(level_sigma2_2, np.float32)
+    epa, Fa = np.ascontiguousarray(ep, np.float32), np.ascontiguousarray(F12, np.float32).reshape(9)
+    m = np.zeros(len(k1), np.int32)
+    n = lib().oro_search_for_triangulation(_p(n1n), len(n1n), _p(s1), _p(f1), _p(k1), _p(d1), _p(h1), None if u1 is None else _p(u1),
+                                           len(k1), _p(n2n), len(n2n), _p(s2), _p(f2), _p(k2), _p(d2), _p(h2),
+                                           None if u2 is None else _p(u2), len(k2), _p(sf), _p(sg), len(sf), _p(epa), _p(Fa),
+                                           int(only_stereo), int(coarse), int(check_ori), _p(m))
+    return n, m

@@ -1509,6 +1509,150 @@ int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t
   return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+// (relocalisation), src/ORBmatcher.cc:1808-1918: the loop over pKF's map points from the window search on (:1855-1916).
+int search_by_projection_keyframe(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const FrameGrid& grid,
+                                  const std::vector<ProjectedPoint>& pts, int ORBdist, bool checkOri,
+                                  std::vector<uint8_t>& occupied, std::vector<int>& match) {
+  const int HISTO = 30;
+  int nmatches = 0;
+  // CurrentFrame.mvpMapPoints as seen by this routine: -1 = NULL, -2 = a pointer that was there before, i >= 0 = pKF's point i
+  std::vector<int> mvpMapPoints(kpsUn.size());
+  for (size_t i = 0; i < kpsUn.size(); i++) mvpMapPoints[i] = occupied[i] ? -2 : -1;
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  for (size_t i = 0; i < pts.size(); i++) {
+    const ProjectedPoint& p = pts[i];
+    if (!p.valid) continue;  // :1823-1845 on the caller's side
+    const std::vector<int> vIndices2 = grid.features_in_area(kpsUn, p.u, p.v, p.radius, p.min_level, p.max_level);  // :1855
+    if (vIndices2.empty()) continue;
+    int bestDist = 256, bestIdx2 = -1;
+    for (int i2 : vIndices2) {
+      if (mvpMapPoints[i2] != -1) continue;  // :1871
+      const int dist = descriptor_distance(p.desc, desc + (size_t)i2 * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= ORBdist) {  // :1886
+      mvpMapPoints[bestIdx2] = (int)i;
+      nmatches++;
+      if (checkOri) {
+        float rot = p.angle - kpsUn[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        mvpMapPoints[idx] = -1;  // :1911
+        nmatches--;
+      }
+    }
+  }
+  match.assign(kpsUn.size(), -1);
+  for (size_t i = 0; i < kpsUn.size(); i++) {
+    occupied[i] = mvpMapPoints[i] != -1;
+    if (mvpMapPoints[i] >= 0) match[i] = mvpMapPoints[i];
+  }
+  return nmatches;
+}
+
+// Pinhole::epipolarConstrain (src/CameraModels/Pinhole.cpp:122-149) with F12 already formed (:130-133 is the caller's
+// Eigen product); built without contraction like the reference's x86-64 baseline build.
+static bool pinhole_epipolar_constrain(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, float unc) {
+  const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+  const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+  const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+  const float num = a * kp2.x + b * kp2.y + c;
+  const float den = a * a + b * b;
+  if (den == 0) return false;
+  const float dsqr = num * num / den;
+  return dsqr < 3.84 * unc;
+}
+
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106) for single-camera key frames (mpCamera2 == NULL in both).
+int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                             const std::vector<KeyPoint>& k1, const uint8_t* d1, const uint8_t* hasMP1, const float* uRight1,
+                             const std::vector<uint32_t>& nodes2, const std::vector<int>& start2, const std::vector<uint32_t>& feat2,
+                             const std::vector<KeyPoint>& k2, const uint8_t* d2, const uint8_t* hasMP2, const float* uRight2,
+                             const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, const float ep[2],
+                             const float F12[9], bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12) {
+  const int HISTO = 30, TH_LOW = 50;
+  int nmatches = 0;
+  std::vector<bool> vbMatched2(k2.size(), false);  // never set by the reference either (:933): a keypoint of pKF2 can be taken twice
+  vMatches12.assign(k1.size(), -1);
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  size_t f1 = 0, f2 = 0;
+  while (f1 < nodes1.size() && f2 < nodes2.size()) {
+    if (nodes1[f1] == nodes2[f2]) {
+      for (int i1 = start1[f1]; i1 < start1[f1 + 1]; i1++) {
+        const size_t idx1 = feat1[i1];
+        if (hasMP1[idx1]) continue;  // :953
+        const bool bStereo1 = uRight1 && uRight1[idx1] >= 0;
+        if (bOnlyStereo && !bStereo1) continue;
+        const KeyPoint& kp1 = k1[idx1];
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int i2 = start2[f2]; i2 < start2[f2 + 1]; i2++) {
+          const size_t idx2 = feat2[i2];
+          if (vbMatched2[idx2] || hasMP2[idx2]) continue;  // :976
+          const bool bStereo2 = uRight2 && uRight2[idx2] >= 0;
+          if (bOnlyStereo)
+            if (!bStereo2) continue;
+          const int dist = descriptor_distance(d1 + idx1 * 32, d2 + idx2 * 32);
+          if (dist > TH_LOW || dist > bestDist) continue;  // ties replace: the LAST of the best candidates wins
+          const KeyPoint& kp2 = k2[idx2];
+          if (!bStereo1 && !bStereo2) {  // && !pKF1->mpCamera2
+            const float distex = ep[0] - kp2.x;
+            const float distey = ep[1] - kp2.y;
+            if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+          }
+          if (bCoarse || pinhole_epipolar_constrain(kp1, kp2, F12, levelSigma2_2[kp2.octave])) {
+            bestIdx2 = (int)idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          const KeyPoint& kp2 = k2[bestIdx2];
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (checkOri) {
+            float rot = kp1.angle - kp2.angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      f1++;
+      f2++;
+    } else if (nodes1[f1] < nodes2[f2]) {
+      f1 = std::lower_bound(nodes1.begin(), nodes1.end(), nodes2[f2]) - nodes1.begin();
+    } else {
+      f2 = std::lower_bound(nodes2.begin(), nodes2.end(), nodes1[f1]) - nodes2.begin();
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        vMatches12[idx] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 // ---- stereo-fisheye branches ------------------------------------------------------------------------------------------------
 int search_by_projection_map_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
                                      const FrameGrid& gridR, const std::vector<float>& scaleFactors,

@@ -220,6 +220,27 @@ int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t
                                const FrameGrid& grid, const std::vector<ProjectedPoint>& pts, bool checkOri,
                                std::vector<uint8_t>& occupied, std::vector<int>& match);
 
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist)
+// (src/ORBmatcher.cc:1808-1918, relocalisation).  pts[i] = pKF's i-th map point after the caller's projection and gates
+// (:1823-1851): valid, (u, v), radius = th * mvScaleFactors[nPredictedLevel], level window (nPredictedLevel -/+ 1), angle =
+// pKF->mvKeysUn[i].angle, descriptor; ur / has_observations are not read.  occupied[i2] <=> CurrentFrame.mvpMapPoints[i2] != NULL
+// (in/out; every assignment occupies, culled slots are free again).  match[i2] = point index or -1.  Returns nmatches.
+int search_by_projection_keyframe(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const FrameGrid& grid,
+                                  const std::vector<ProjectedPoint>& pts, int ORBdist, bool checkOri,
+                                  std::vector<uint8_t>& occupied, std::vector<int>& match);
+
+// ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:886-1106) for
+// single-camera key frames.  Feature vectors as CSR (ascending node ids); k1 / k2 = mvKeysUn; hasMP = GetMapPoint(idx) != NULL;
+// uRight = mvuRight (nullptr: no stereo observations); scaleFactors2 / levelSigma2_2 = pKF2's tables; ep = pKF2's projection
+// of pKF1's camera centre (:897-901); F12 row-major = K1^-T [t12]x R12 K2^-1 (Pinhole.cpp:130-133).  vMatches12[idx1] = idx2
+// or -1 (vMatchedPairs = its non-negative entries in ascending idx1).  Returns nmatches.
+int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                             const std::vector<KeyPoint>& k1, const uint8_t* d1, const uint8_t* hasMP1, const float* uRight1,
+                             const std::vector<uint32_t>& nodes2, const std::vector<int>& start2, const std::vector<uint32_t>& feat2,
+                             const std::vector<KeyPoint>& k2, const uint8_t* d2, const uint8_t* hasMP2, const float* uRight2,
+                             const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, const float ep[2],
+                             const float F12[9], bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12);
+
 // ---- stereo-fisheye (F.Nleft != -1) branches of the two SearchByProjection matchers ---------------------------------------
 // The frame holds N = nLeft + nRight keypoints (mvKeys then mvKeysRight), descriptors in the same order, two grids
 // (mGrid over the left keypoints, mGridRight over the right ones with indices relative to mvKeysRight), and the stereo

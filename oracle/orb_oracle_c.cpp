@@ -436,4 +436,36 @@ int oro_search_by_bow(const uint32_t* kfNodes, int nKfNodes, const int* kfStart,
   return n;
 }
 
+int oro_search_by_projection_keyframe(const KeyPoint* k, const uint8_t* desc, int n, float minX, float minY, float maxX,
+                                      float maxY, const ProjectedPoint* pts, int npts, int orbDist, int checkOri,
+                                      uint8_t* occupied, int* match) {
+  std::vector<KeyPoint> a(k, k + n);
+  FrameGrid g;
+  g.build(a, minX, minY, maxX, maxY);
+  std::vector<ProjectedPoint> p(pts, pts + npts);
+  std::vector<uint8_t> occ(occupied, occupied + n);
+  std::vector<int> mt;
+  const int nm = search_by_projection_keyframe(a, desc, g, p, orbDist, checkOri != 0, occ, mt);
+  std::memcpy(occupied, occ.data(), n);
+  std::memcpy(match, mt.data(), n * sizeof(int));
+  return nm;
+}
+
+int oro_search_for_triangulation(const uint32_t* nodes1, int nNodes1, const int* start1, const uint32_t* feat1, const KeyPoint* k1,
+                                 const uint8_t* d1, const uint8_t* hasMP1, const float* uRight1, int n1, const uint32_t* nodes2,
+                                 int nNodes2, const int* start2, const uint32_t* feat2, const KeyPoint* k2, const uint8_t* d2,
+                                 const uint8_t* hasMP2, const float* uRight2, int n2, const float* scaleFactors2,
+                                 const float* levelSigma2_2, int nLevels2, const float* ep, const float* F12, int onlyStereo,
+                                 int coarse, int checkOri, int* matches12) {
+  std::vector<uint32_t> a(nodes1, nodes1 + nNodes1), af(feat1, feat1 + start1[nNodes1]);
+  std::vector<uint32_t> b(nodes2, nodes2 + nNodes2), bf(feat2, feat2 + start2[nNodes2]);
+  std::vector<int> as(start1, start1 + nNodes1 + 1), bs(start2, start2 + nNodes2 + 1), m;
+  std::vector<KeyPoint> ka(k1, k1 + n1), kb(k2, k2 + n2);
+  std::vector<float> sf(scaleFactors2, scaleFactors2 + nLevels2), sg(levelSigma2_2, levelSigma2_2 + nLevels2);
+  const int n = search_for_triangulation(a, as, af, ka, d1, hasMP1, uRight1, b, bs, bf, kb, d2, hasMP2, uRight2, sf, sg, ep, F12,
+                                         onlyStereo != 0, coarse != 0, checkOri != 0, m);
+  std::copy(m.begin(), m.end(), matches12);
+  return n;
+}
+
 }  // extern "C"

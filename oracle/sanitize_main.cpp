@@ -85,6 +85,32 @@ int main() {
   const int np1 = search_by_projection_map(kR, dR.data(), uRv.data(), g, eL.t.scale, mps, 3.f, true, 60.f, 0.8f, occ, match);
   occ.assign(kR.size(), 0);
   const int np2 = search_by_projection_frame(kR, dR.data(), uRv.data(), g, pts, true, occ, match);
+  // relocalisation flavour + SearchForTriangulation (feature vectors: node = first descriptor byte / 8)
+  occ.assign(kR.size(), 0);
+  for (size_t i = 0; i < occ.size(); i += 5) occ[i] = 1;
+  const int np5 = search_by_projection_keyframe(kR, dR.data(), g, pts, 100, true, occ, match);
+  auto make_fv = [](const std::vector<uint8_t>& d, std::vector<uint32_t>& nodes, std::vector<int>& start, std::vector<uint32_t>& feat) {
+    start.assign(1, 0);
+    for (uint32_t nid = 0; nid < 32; nid++) {
+      const size_t before = feat.size();
+      for (size_t i = 0; i < d.size() / 32; i++)
+        if ((uint32_t)(d[i * 32] >> 3) == nid && (i % 29) != 0) feat.push_back((uint32_t)i);
+      if (feat.size() > before && nid != 7) { nodes.push_back(nid * 3 + 1); start.push_back((int)feat.size()); }
+      else feat.resize(before);
+    }
+  };
+  std::vector<uint32_t> n1, f1, n2, f2;
+  std::vector<int> s1, s2, tri12;
+  make_fv(dL, n1, s1, f1);
+  make_fv(dR, n2, s2, f2);
+  std::vector<uint8_t> hm1(kL.size(), 0), hm2(kR.size(), 0);
+  for (size_t i = 0; i < hm1.size(); i += 4) hm1[i] = 1;
+  for (size_t i = 1; i < hm2.size(); i += 4) hm2[i] = 1;
+  const float epi[2] = {0.5f * w, 0.5f * h}, F12[9] = {1e-6f, 2e-6f, 0.f, -2e-6f, 1e-6f, -1.f, 1e-4f, 1.f, -3.f};
+  const int np6 = search_for_triangulation(n1, s1, f1, kL, dL.data(), hm1.data(), nullptr, n2, s2, f2, kR, dR.data(), hm2.data(),
+                                           uRv.data(), eL.t.scale, eL.t.sigma2, epi, F12, false, false, true, tri12) +
+                  search_for_triangulation(n1, s1, f1, kL, dL.data(), hm1.data(), nullptr, n2, s2, f2, kR, dR.data(), hm2.data(),
+                                           nullptr, eL.t.scale, eL.t.sigma2, epi, F12, false, true, true, tri12);
   // stereo-fisheye flavours on the concatenated frame
   std::vector<KeyPoint> kk(kR);
   kk.insert(kk.end(), kL.begin(), kL.end());
@@ -174,6 +200,6 @@ int main() {
                             (int)(kL.size() + kR.size()), (int)kL.size(), 0.7f, true, bm);
   }
   std::printf("ok %d %d %zu %zu stereo %d knn %d init %d proj %d %d fe %d %d fisheye %d/%d un %.2f b %.1f g %d\n", mL, mR, kL.size(),
-              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow);
+              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow + np5 + np6);
   return 0;
 }

@@ -119,6 +119,9 @@ def lib():
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
+        L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
+        L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
+                                                    vp, vp, i, i, i, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_comm_unique_id.argtypes = [vp]
         L.orbx_comm_create.argtypes = [vp, i, i, i, C.POINTER(vp)]
@@ -765,6 +768,44 @@ class ORBmatcher:
             self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
             bounds[3], _p(pp), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
+
+    def SearchByProjectionKeyFrame(self, kpsUn, desc, bounds, projectedPoints, occupied, ORBdist=100):
+        """Matching part of the relocalisation matcher SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)
+        (src/ORBmatcher.cc:1808-1918); projectedPoints: PP_DTYPE records of pKF's map points after the caller's projection
+        and gates; occupied[i2] <=> CurrentFrame.mvpMapPoints[i2] != NULL.
+        Returns (nmatches, match[n] = point index or -1, updated occupied[n])."""
+        k = np.ascontiguousarray(kpsUn, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        pp = np.ascontiguousarray(projectedPoints, PP_DTYPE)
+        occ = np.ascontiguousarray(occupied, np.uint8).copy()
+        match = np.full(len(k), -1, np.int32)
+        n = _check(lib().orbx_search_by_projection_keyframe(
+            self.device, _p(k), _p(d), len(k), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp), len(pp), int(ORBdist),
+            int(self.mbCheckOrientation), _p(occ), _p(match)))
+        return n, match, occ
+
+    def SearchForTriangulation(self, fv1, kps1, desc1, hasMapPoint1, uRight1, fv2, kps2, desc2, hasMapPoint2, uRight2,
+                               scaleFactors2, levelSigma2_2, ep, F12, bOnlyStereo=False, bCoarse=False):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse) (src/ORBmatcher.cc:886-1106),
+        single-camera key frames; fv = (node ids, node start, feature indices) as ORBVocabulary.transform returns them.
+        Returns (nmatches, vMatchedPairs as an [nmatches, 2] array in ascending idx1, vMatches12[n1])."""
+        n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+        n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+        k1, k2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        h1, h2 = np.ascontiguousarray(hasMapPoint1, np.uint8), np.ascontiguousarray(hasMapPoint2, np.uint8)
+        u1 = None if uRight1 is None else np.ascontiguousarray(uRight1, np.float32)
+        u2 = None if uRight2 is None else np.ascontiguousarray(uRight2, np.float32)
+        sf, sg = np.ascontiguousarray(scaleFactors2, np.float32), np.ascontiguousarray(levelSigma2_2, np.float32)
+        epa = np.ascontiguousarray(ep, np.float32)
+        Fa = None if F12 is None else np.ascontiguousarray(F12, np.float32).reshape(9)
+        m = np.full(len(k1), -1, np.int32)
+        n = _check(lib().orbx_search_for_triangulation(
+            self.device, _p(n1n), _p(s1), _p(f1), len(n1n), _p(k1), _p(d1), _p(h1), None if u1 is None else _p(u1), len(k1),
+            _p(n2n), _p(s2), _p(f2), len(n2n), _p(k2), _p(d2), _p(h2), None if u2 is None else _p(u2), len(k2), _p(sf), _p(sg),
+            len(sf), _p(epa), None if Fa is None else _p(Fa), int(bOnlyStereo), int(bCoarse), int(self.mbCheckOrientation), _p(m)))
+        idx1 = np.nonzero(m >= 0)[0]
+        return n, np.stack([idx1, m[idx1]], axis=1).astype(np.int64), m
 
     def SearchByProjectionFisheye(self, kps, desc, n_left, bounds, scaleFactors, mapPoints, mapPointsRight, leftToRight,
                                   rightToLeft, occupied, th=1.0, bFarPoints=False, thFarPoints=50.0):

@@ -101,5 +101,60 @@ inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVecKF, const std::vector
   return n;
 }
 
+// The members of a KeyFrame that ORBmatcher::SearchForTriangulation reads (single-camera key frames: mpCamera2 == NULL,
+// NLeft == -1): mFeatVec, mvKeysUn, mDescriptors (N x 32, continuous), hasMapPoint[i] = (GetMapPoint(i) != NULL), mvuRight (empty:
+// no stereo observations), mvScaleFactors, mvLevelSigma2.
+struct KeyFrameView {
+  const DBoW2::FeatureVector* mFeatVec = nullptr;
+  const std::vector<ocv::KeyPoint>* mvKeysUn = nullptr;
+  const uint8_t* mDescriptors = nullptr;
+  const std::vector<uint8_t>* hasMapPoint = nullptr;
+  const std::vector<float>* mvuRight = nullptr;
+  const std::vector<float>* mvScaleFactors = nullptr;
+  const std::vector<float>* mvLevelSigma2 = nullptr;
+};
+
+// ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, vector<pair<size_t, size_t>>& vMatchedPairs, bOnlyStereo,
+// bCoarse) (src/ORBmatcher.cc:886-1106; LocalMapping::CreateNewMapPoints).  ep = pKF2->mpCamera->project(T2w * Cw1) (:897-901);
+// F12 = K1^-T [t12]x R12 K2^-1, the matrix Pinhole::epipolarConstrain forms per candidate (src/CameraModels/Pinhole.cpp:130-133),
+// row-major -- with Eigen: `Eigen::Matrix<float, 3, 3, Eigen::RowMajor> F = K1.transpose().inverse() * Sophus::SO3f::hat(t12) * R12
+// * K2.inverse();` and F.data().  Returns nmatches; vMatchedPairs in ascending idx1 like :1095-1103.
+inline int SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& KF2, const float ep[2], const float F12[9],
+                                  std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse,
+                                  bool mbCheckOrientation = true, int device = 0) {
+  auto flatten = [](const DBoW2::FeatureVector& fv, std::vector<uint32_t>& nodes, std::vector<int32_t>& start,
+                    std::vector<uint32_t>& feats) {
+    start.assign(1, 0);
+    for (const auto& e : fv) {
+      nodes.push_back(e.first);
+      feats.insert(feats.end(), e.second.begin(), e.second.end());
+      start.push_back((int32_t)feats.size());
+    }
+  };
+  std::vector<uint32_t> n1, f1, n2, f2;
+  std::vector<int32_t> s1, s2;
+  flatten(*KF1.mFeatVec, n1, s1, f1);
+  flatten(*KF2.mFeatVec, n2, s2, f2);
+  const int N1 = (int)KF1.mvKeysUn->size(), N2 = (int)KF2.mvKeysUn->size();
+  if ((int)KF1.hasMapPoint->size() != N1 || (int)KF2.hasMapPoint->size() != N2)
+    throw std::invalid_argument("SearchForTriangulation: one hasMapPoint flag per keypoint");
+  if (KF2.mvScaleFactors->size() != KF2.mvLevelSigma2->size()) throw std::invalid_argument("SearchForTriangulation: level tables differ");
+  const float* u1 = KF1.mvuRight && (int)KF1.mvuRight->size() == N1 && N1 ? KF1.mvuRight->data() : nullptr;
+  const float* u2 = KF2.mvuRight && (int)KF2.mvuRight->size() == N2 && N2 ? KF2.mvuRight->data() : nullptr;
+  std::vector<int> vMatches12(N1, -1);
+  const int n = orbx_search_for_triangulation(
+      device, n1.data(), s1.data(), f1.data(), (int)n1.size(), reinterpret_cast<const orbx_keypoint*>(KF1.mvKeysUn->data()),
+      KF1.mDescriptors, KF1.hasMapPoint->data(), u1, N1, n2.data(), s2.data(), f2.data(), (int)n2.size(),
+      reinterpret_cast<const orbx_keypoint*>(KF2.mvKeysUn->data()), KF2.mDescriptors, KF2.hasMapPoint->data(), u2, N2,
+      KF2.mvScaleFactors->data(), KF2.mvLevelSigma2->data(), (int)KF2.mvScaleFactors->size(), ep, F12, bOnlyStereo ? 1 : 0,
+      bCoarse ? 1 : 0, mbCheckOrientation ? 1 : 0, vMatches12.data());
+  if (n < 0) throw std::runtime_error(std::string("SearchForTriangulation: ") + orbx_last_error());
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(n);
+  for (size_t i = 0; i < vMatches12.size(); i++)
+    if (vMatches12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+  return n;
+}
+
 }  // namespace ORB_SLAM3
 #endif

@@ -113,6 +113,23 @@ class ORBmatcher {
     return n;
   }
 
+  // Matching part of the relocalisation matcher SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF,
+  // const set<MapPoint*>& sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1808-1918 (Tracking::Relocalization,
+  // src/Tracking.cc:3631-3632,3645-3646): the caller keeps the projection and its gates (:1823-1851) and passes one
+  // orbx_projected_point per map point of pKF (valid = 0 for the skipped ones; radius = th * mvScaleFactors[nPredictedLevel],
+  // levels nPredictedLevel -/+ 1, angle = pKF->mvKeysUn[i].angle).  occupied[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL
+  // (updated); match[i2] = index into pKF's map points or -1.
+  int SearchByProjection(const FrameView& CurrentFrame, const std::vector<orbx_projected_point>& keyFramePoints,
+                         const int ORBdist, std::vector<uint8_t>& occupied, std::vector<int>& match) {
+    match.assign(CurrentFrame.N, -1);
+    const int n = orbx_search_by_projection_keyframe(
+        device_, reinterpret_cast<const orbx_keypoint*>(CurrentFrame.mvKeysUn), CurrentFrame.mDescriptors, CurrentFrame.N,
+        CurrentFrame.mnMinX, CurrentFrame.mnMinY, CurrentFrame.mnMaxX, CurrentFrame.mnMaxY, keyFramePoints.data(),
+        (int)keyFramePoints.size(), ORBdist, mbCheckOrientation ? 1 : 0, occupied.data(), match.data());
+    if (n < 0) throw std::runtime_error(std::string("SearchByProjection: ") + orbx_last_error());
+    return n;
+  }
+
   // The same two searches for stereo-fisheye frames (F.Nleft != -1, src/ORBmatcher.cc:41-221 / :1594-1806): F holds
   // N = Nleft + Nright keypoints (mvKeys then mvKeysRight; FrameView::mvKeysUn points at that array, N at the total),
   // vpMapPointsRight the right-camera members of every MapPoint, and the stereo association of the frame.

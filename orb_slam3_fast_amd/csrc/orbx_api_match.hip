@@ -322,7 +322,8 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
                              float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
                              const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
                              float th, int far_points, float th_far_points, float nnratio, int check_ori,
-                             uint8_t* occupied, int32_t* match, int cand_cap, int* needed, bool serial, bool* converged) {
+                             uint8_t* occupied, int32_t* match, int cand_cap, int* needed, bool serial, bool* converged,
+                             int max_dist, int claim_all) {
   const int mode = points ? 1 : 0;
   *needed = 0;
   *converged = true;
@@ -358,7 +359,7 @@ int search_by_projection_try(const orbx_keypoint* kps_un, const uint8_t* desc, c
   a.grid.cellStart = cellStart.p; a.grid.cellItems = cellItems.p; a.grid.matchedDist = mdist.p; a.grid.matches21 = m21.p;
   a.grid.matches12 = m12.p; a.grid.result = result.p; a.grid.candOff = candOff.p; a.grid.candCap = 1 << 30;
   a.desc = d.p; a.uRight = u_right ? ur.p : nullptr; a.scale = sf.p; a.mps = mp.p; a.pts = pp.p; a.nmp = n_points;
-  a.mode = mode; a.checkOri = check_ori;
+  a.mode = mode; a.checkOri = check_ori; a.maxDist = max_dist; a.claimAll = claim_all;
   a.th = th; a.thFar = th_far_points; a.nnratio = nnratio; a.far = far_points;
   a.occupied = occ.p; a.match = mt.p; a.candOff = candOff.p; a.result = result.p;
   chk(candIdx.alloc((size_t)cand_cap));
@@ -403,7 +404,7 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
                               float min_x, float min_y, float max_x, float max_y, const float* scale_factors, int nlevels,
                               const orbx_map_point_view* map_points, const orbx_projected_point* points, int n_points,
                               float th, int far_points, float th_far_points, float nnratio, int check_ori,
-                              uint8_t* occupied, int32_t* match) {
+                              uint8_t* occupied, int32_t* match, int max_dist = 100 /* TH_HIGH */, int claim_all = 0) {
   if (n == 0) return 0;
   int rc = set_device(device);
   if (rc != ORBX_OK) return rc;
@@ -416,7 +417,7 @@ int search_by_projection_impl(int device, const orbx_keypoint* kps_un, const uin
   for (int attempt = 0; attempt < 3; attempt++) {  // at most: capacity retry, then serial retry
     rc = search_by_projection_try(kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, scale_factors, nlevels, map_points, points,
                                   n_points, th, far_points, th_far_points, nnratio, check_ori, occupied, match, cap, &needed,
-                                  serial, &converged);
+                                  serial, &converged, max_dist, claim_all);
     if (rc < 0) break;
     if (needed > cap) { cap = needed; continue; }
     if (!converged) {
@@ -459,6 +460,91 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
   static const orbx_projected_point dummy{};
   return search_by_projection_impl(device, kps_un, desc, u_right, n, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
+}
+
+int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                  int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
+                                  const float* u_right1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,
+                                  const uint32_t* feature_idx2, int n_nodes2, const orbx_keypoint* kps2, const uint8_t* desc2,
+                                  const uint8_t* has_map_point2, const float* u_right2, int n2, const float* scale_factors2,
+                                  const float* level_sigma2_2, int nlevels2, const float ep[2], const float F12[9], int only_stereo,
+                                  int coarse, int check_orientation, int32_t* matches12) {
+  if (n1 < 0 || n2 < 0 || n_nodes1 < 0 || n_nodes2 < 0 || nlevels2 < 1 || !scale_factors2 || !level_sigma2_2 || !ep ||
+      (!coarse && !F12) || (n1 && (!matches12 || !kps1 || !desc1 || !has_map_point1)) || (n2 && (!kps2 || !desc2 || !has_map_point2)) ||
+      (n_nodes1 && (!node_ids1 || !node_start1 || !feature_idx1)) || (n_nodes2 && (!node_ids2 || !node_start2 || !feature_idx2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  const int nl1 = n_nodes1 ? node_start1[n_nodes1] : 0, nl2 = n_nodes2 ? node_start2[n_nodes2] : 0;
+  if (nl1 < 0 || nl1 > n1 || nl2 < 0 || nl2 > n2) return fail(ORBX_E_BADARG, "feature vector larger than the key frame");
+  if (nl2 >= (1 << 24)) return fail(ORBX_E_CAPACITY, "more than 2^24 features");
+  for (int j = 0; j < n_nodes1; j++)
+    if (node_start1[j] < 0 || node_start1[j] > node_start1[j + 1] || (j && node_ids1[j] <= node_ids1[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 1: node ids must ascend and offsets must be monotone");
+  for (int j = 0; j < n_nodes2; j++)
+    if (node_start2[j] < 0 || node_start2[j] > node_start2[j + 1] || (j && node_ids2[j] <= node_ids2[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 2: node ids must ascend and offsets must be monotone");
+  for (int i = 0; i < nl1; i++)
+    if (feature_idx1[i] >= (uint32_t)n1) return fail(ORBX_E_BADARG, "feature index 1 out of range");
+  for (int i = 0; i < nl2; i++)
+    if (feature_idx2[i] >= (uint32_t)n2) return fail(ORBX_E_BADARG, "feature index 2 out of range");
+  for (int i = 0; i < n2; i++)  // kp2.octave indexes mvScaleFactors / mvLevelSigma2 (:1001,1054)
+    if (kps2[i].octave < 0 || kps2[i].octave >= nlevels2) return fail(ORBX_E_BADARG, "keypoint octave outside [0, nlevels2)");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (nl1 == 0 || nl2 == 0) return 0;
+  Pack pk;
+  const size_t oN1 = pk.add(node_ids1, (size_t)n_nodes1 * 4), oS1 = pk.add(node_start1, ((size_t)n_nodes1 + 1) * 4);
+  const size_t oF1 = pk.add(feature_idx1, (size_t)nl1 * 4), oD1 = pk.add(desc1, (size_t)n1 * 32);
+  const size_t oM1 = pk.add(has_map_point1, n1), oK1 = pk.add(kps1, (size_t)n1 * sizeof(orbx_keypoint));
+  const size_t oU1 = pk.add(u_right1, (size_t)n1 * 4);
+  const size_t oN2 = pk.add(node_ids2, (size_t)n_nodes2 * 4), oS2 = pk.add(node_start2, ((size_t)n_nodes2 + 1) * 4);
+  const size_t oF2 = pk.add(feature_idx2, (size_t)nl2 * 4), oD2 = pk.add(desc2, (size_t)n2 * 32);
+  const size_t oM2 = pk.add(has_map_point2, n2), oK2 = pk.add(kps2, (size_t)n2 * sizeof(orbx_keypoint));
+  const size_t oU2 = pk.add(u_right2, (size_t)n2 * 4);
+  const size_t oSf = pk.add(scale_factors2, (size_t)nlevels2 * 4), oSg = pk.add(level_sigma2_2, (size_t)nlevels2 * 4);
+  const size_t oFlags = pk.add(nullptr, 32 * 4);
+  const size_t oOut = pk.add(nullptr, ((size_t)n1 + 1) * 4);  // result, then vMatches12: one copy back
+  hipError_t e = pk.commit();
+  TriArgs a{};
+  a.nodes1 = pk.ptr<uint32_t>(oN1); a.start1 = pk.ptr<int>(oS1); a.feat1 = pk.ptr<uint32_t>(oF1); a.nNodes1 = n_nodes1; a.nList1 = nl1;
+  a.nodes2 = pk.ptr<uint32_t>(oN2); a.start2 = pk.ptr<int>(oS2); a.feat2 = pk.ptr<uint32_t>(oF2); a.nNodes2 = n_nodes2;
+  a.k1 = pk.ptr<orbx_keypoint>(oK1); a.k2 = pk.ptr<orbx_keypoint>(oK2);
+  a.d1 = pk.ptr<uint32_t>(oD1); a.d2 = pk.ptr<uint32_t>(oD2); a.mp1 = pk.ptr<uint8_t>(oM1); a.mp2 = pk.ptr<uint8_t>(oM2);
+  a.ur1 = u_right1 ? pk.ptr<float>(oU1) : nullptr; a.ur2 = u_right2 ? pk.ptr<float>(oU2) : nullptr;
+  a.n1 = n1; a.n2 = n2; a.scale2 = pk.ptr<float>(oSf); a.sigma2 = pk.ptr<float>(oSg);
+  a.ep0 = ep[0]; a.ep1 = ep[1];
+  for (int i = 0; i < 9; i++) a.F[i] = F12 ? F12[i] : 0.f;
+  a.onlyStereo = only_stereo ? 1 : 0; a.coarse = coarse ? 1 : 0; a.checkOri = check_orientation ? 1 : 0;
+  a.flags = pk.ptr<int>(oFlags); a.result = pk.ptr<int>(oOut); a.match = pk.ptr<int>(oOut) + 1;
+  if (e == hipSuccess) e = launch_search_for_triangulation(a, nullptr);
+  int n = 0;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, ((size_t)n1 + 1) * 4, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&n, h, 4);
+      std::memcpy(matches12, h + 4, (size_t)n1 * 4);
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return n;
+}
+
+int orbx_search_by_projection_keyframe(int device, const orbx_keypoint* kps_un, const uint8_t* desc, int n, float min_x,
+                                       float min_y, float max_x, float max_y, const orbx_projected_point* points,
+                                       int n_points, int orb_dist, int check_orientation, uint8_t* occupied,
+                                       int32_t* match) {
+  if (n < 0 || n_points < 0 || (n && (!kps_un || !desc || !occupied || !match)) || (n_points && !points))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_points > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 projected points");
+  // bestDist starts at 256 and is only replaced by a strictly smaller distance (src/ORBmatcher.cc:1864-1882): no candidate
+  // ever yields 256, and with no free candidate bestIdx2 stays -1 -- the reference would then index mvpMapPoints[-1] for
+  // ORBdist >= 256; the thresholds it is called with are 100 and 64 (src/Tracking.cc:3631-3632,3645-3646)
+  if (orb_dist < 0 || orb_dist > 255) return fail(ORBX_E_BADARG, "ORBdist outside [0, 255]");
+  static const orbx_projected_point dummy{};
+  return search_by_projection_impl(device, kps_un, desc, nullptr, n, min_x, min_y, max_x, max_y, nullptr, 0, nullptr,
+                                   points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match,
+                                   orb_dist, 1);
 }
 
 namespace {

@@ -392,4 +392,137 @@ hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106), single-camera key frames -------------------------------
+// vbMatched2 is declared and tested but never set (:933,976), so a feature of pKF1 only depends on the features of pKF2 in its own
+// vocabulary node: all features are independent.  The serial scan keeps a candidate when dist <= min(TH_LOW, bestDist) and the
+// geometric gates pass, and the gates do not depend on bestDist, so the result is the LAST candidate of minimal distance among the
+// gate-passers = the minimum of (dist, -position).  16 lanes per feature of pKF1 (a node holds ~15 features of a 1500-feature
+// frame at levelsup 4), wave64 = 4 features.
+__global__ __launch_bounds__(256) void k_tri_init(TriArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n1) a.match[i] = -1;
+  if (i < 32) a.flags[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_tri_match(TriArgs a) {
+  const int sub = threadIdx.x & 15;
+  const int g = blockIdx.x * 16 + (threadIdx.x >> 4);  // position in pKF1's feature lists
+  if (g >= a.nList1) return;
+  // node of this list entry: last j with start1[j] <= g; its partner in pKF2's vector (the lower_bound walk of :943-1085 visits
+  // exactly the node ids present in both maps)
+  int lo = 0, hi = a.nNodes1 - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.start1[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t node = a.nodes1[lo];
+  int l2 = 0, h2 = a.nNodes2;
+  while (l2 < h2) {
+    const int mid = (l2 + h2) >> 1;
+    if (a.nodes2[mid] < node) l2 = mid + 1; else h2 = mid;
+  }
+  if (l2 >= a.nNodes2 || a.nodes2[l2] != node) return;
+  const int b = a.start2[l2], e = a.start2[l2 + 1];
+  const int idx1 = (int)a.feat1[g];
+  if (a.mp1[idx1]) return;  // :953
+  const bool stereo1 = a.ur1 && a.ur1[idx1] >= 0;
+  if (a.onlyStereo && !stereo1) return;
+  const orbx_keypoint kp1 = a.k1[idx1];
+  // epipolar line of kp1 in image 2, Pinhole.cpp:136-138 (separately rounded, left to right)
+  const float la = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[0]), __fmul_rn(kp1.y, a.F[3])), a.F[6]);
+  const float lb = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[1]), __fmul_rn(kp1.y, a.F[4])), a.F[7]);
+  const float lc = __fadd_rn(__fadd_rn(__fmul_rn(kp1.x, a.F[2]), __fmul_rn(kp1.y, a.F[5])), a.F[8]);
+  const float den = __fadd_rn(__fmul_rn(la, la), __fmul_rn(lb, lb));
+  uint32_t d1[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) d1[i] = a.d1[(long long)idx1 * 8 + i];
+  uint32_t best = 0xFFFFFFFFu;  // (dist << 24) | (0xFFFFFF - position)
+  for (int pos = b + sub; pos < e; pos += 16) {
+    const int idx2 = (int)a.feat2[pos];
+    if (a.mp2[idx2]) continue;  // :976
+    const bool stereo2 = a.ur2 && a.ur2[idx2] >= 0;
+    if (a.onlyStereo && !stereo2) continue;
+    const int dist = hamming256(d1, a.d2 + (long long)idx2 * 8);
+    if (dist > 50) continue;  // TH_LOW
+    const orbx_keypoint kp2 = a.k2[idx2];
+    if (!stereo1 && !stereo2) {  // too close to the epipole, :997-1004
+      const float ex = __fsub_rn(a.ep0, kp2.x), ey = __fsub_rn(a.ep1, kp2.y);
+      if (__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)) < __fmul_rn(100.0f, a.scale2[kp2.octave])) continue;
+    }
+    if (!a.coarse) {  // Pinhole::epipolarConstrain, Pinhole.cpp:140-148
+      const float num = __fadd_rn(__fadd_rn(__fmul_rn(la, kp2.x), __fmul_rn(lb, kp2.y)), lc);
+      if (den == 0) continue;
+      const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+      if (!((double)dsqr < 3.84 * (double)a.sigma2[kp2.octave])) continue;
+    }
+    const uint32_t key = ((uint32_t)dist << 24) | (0xFFFFFFu - (uint32_t)(pos - b));
+    best = min(best, key);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 16));
+  if (sub == 0 && best != 0xFFFFFFFFu) {
+    const int idx2 = (int)a.feat2[b + (int)(0xFFFFFFu - (best & 0xFFFFFFu))];
+    a.match[idx1] = idx2;
+    atomicAdd(&a.flags[0], 1);
+    if (a.checkOri) {
+      float rot = __fsub_rn(kp1.angle, a.k2[idx2].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      atomicAdd(&a.flags[2 + bin], 1);
+    }
+  }
+}
+
+// rotation-consistency cull (:1087-1102, ComputeThreeMaxima :1920-1955) + the count; one workgroup
+__global__ __launch_bounds__(1024) void k_tri_cull(TriArgs a) {
+  __shared__ int s_removed;
+  if (threadIdx.x == 0) s_removed = 0;
+  __syncthreads();
+  if (a.checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < 30; i++) {
+      const int s = a.flags[2 + i];
+      if (s > max1) {
+        max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i;
+      } else if (s > max2) {
+        max3 = max2; max2 = s; ind3 = ind2; ind2 = i;
+      } else if (s > max3) {
+        max3 = s; ind3 = i;
+      }
+    }
+    if ((float)max2 < __fmul_rn(0.1f, (float)max1)) {
+      ind2 = -1;
+      ind3 = -1;
+    } else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) {
+      ind3 = -1;
+    }
+    int removed = 0;
+    for (int i = threadIdx.x; i < a.n1; i += 1024) {
+      const int m = a.match[i];
+      if (m < 0) continue;
+      float rot = __fsub_rn(a.k1[i].angle, a.k2[m].angle);
+      if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+      int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+      if (bin == 30) bin = 0;
+      if (bin != ind1 && bin != ind2 && bin != ind3) {
+        a.match[i] = -1;
+        removed++;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    if ((threadIdx.x & 63) == 0 && removed) atomicAdd(&s_removed, removed);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.result[0] = a.flags[0] - s_removed;
+}
+
+hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_tri_init, dim3((max(a.n1, 32) + 255) / 256), dim3(256), 0, s, a);
+  if (a.nList1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_tri_match, dim3((a.nList1 + 15) / 16), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_tri_cull, dim3(1), dim3(1024), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace orbx

@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
     if (best == ~0ull) continue;
     const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
     bool accept = false;
-    if (bestDist <= 100) {  // TH_HIGH
+    if (bestDist <= a.maxDist) {  // TH_HIGH, or ORBdist (:1886)
       if (a.mode == 0) {
         const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
         const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
       if (lane == 0) {
         const int bestIdx = a.candIdx[b + bestPos];
         a.match[bestIdx] = im;
-        a.occupied[bestIdx] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+        a.occupied[bestIdx] = a.mode == 0 ? a.mps[im].has_observations : (uint8_t)(a.claimAll | a.pts[im].has_observations);
         if (a.mode == 1 && a.checkOri) {
           float rot = __fsub_rn(a.pts[im].angle, a.grid.k2[bestIdx].angle);
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
@@ -711,6 +711,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
       const int bn = binIdx[i] >> 24, idx = binIdx[i] & 0xFFFFFF;
       if (bn != ind1 && bn != ind2 && bn != ind3) {
         a.match[idx] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL (even if a later point re-took the slot)
+        if (a.claimAll) a.occupied[idx] = 0;
         removed++;
       }
     }
@@ -769,7 +770,7 @@ __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   if (best != ~0ull) {
     const int bestDist = (int)(best >> 40), bestPos = (int)((best >> 8) & 0xFFFFFFFFu), bestLevel = (int)(best & 0xFF);
     bool accept = false;
-    if (bestDist <= 100) {  // TH_HIGH
+    if (bestDist <= a.maxDist) {  // TH_HIGH, or ORBdist (:1886)
       if (a.mode == 0) {
         const int bestDist2 = second == ~0ull ? 256 : (int)(second >> 40);
         const int bestLevel2 = second == ~0ull ? -1 : (int)(second & 0xFF);
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   if (lane == 0) {
     if (round_no == 0 || a.choice[im] != chosen) a.flags[kProjChanged + round_no] = 1;
     a.choice[im] = chosen;
-    if (chosen >= 0 && (a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations))
+    if (chosen >= 0 && (a.mode == 0 ? a.mps[im].has_observations : (a.claimAll | a.pts[im].has_observations)))
       atomicMin(&takerNew[chosen], im);
   }
 }
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256) void k_proj_cull(ProjArgs a) {
   // occupied: set by the last chooser (a keypoint whose first chooser has observations has no later chooser)
   for (int k = blockIdx.x * 256 + threadIdx.x; k < a.grid.n2; k += gridDim.x * 256) {
     const int im = a.match[k];
-    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
+    if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : (uint8_t)(a.claimAll | a.pts[im].has_observations);
   }
 }
 
@@ -858,6 +859,7 @@ __global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-c
       if (bin == 30) bin = 0;
       if (bin != ind1 && bin != ind2 && bin != ind3) {
         a.match[k] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL, even if a later point re-took the slot
+        if (a.claimAll) a.occupied[k] = 0;
         rem = true;
       }
     }

@@ -210,6 +210,25 @@ struct BowMatchArgs {
 };
 hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s);
 
+// ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106), single-camera key frames (k_tri_*)
+struct TriArgs {
+  const uint32_t* nodes1; const int* start1; const uint32_t* feat1; int nNodes1, nList1;  // pKF1->mFeatVec as CSR
+  const uint32_t* nodes2; const int* start2; const uint32_t* feat2; int nNodes2;          // pKF2->mFeatVec
+  const orbx_keypoint* k1; const orbx_keypoint* k2;   // mvKeysUn
+  const uint32_t* d1; const uint32_t* d2;             // mDescriptors
+  const uint8_t* mp1; const uint8_t* mp2;             // GetMapPoint(idx) != NULL
+  const float* ur1; const float* ur2;                 // mvuRight or nullptr
+  int n1, n2;
+  const float* scale2; const float* sigma2;           // pKF2->mvScaleFactors, mvLevelSigma2
+  float ep0, ep1;                                     // epipole in image 2 (:901)
+  float F[9];                                         // F12 row-major (Pinhole.cpp:133)
+  int onlyStereo, coarse, checkOri;
+  int* match;    // n1: vMatches12
+  int* flags;    // [0] accepted, [1] removed, [2..31] rotation histogram
+  int* result;   // nmatches
+};
+hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s);
+
 // cv::remap INTER_LINEAR with float maps (k_remap): batch of nimg images, image i uses map i % nMaps.
 struct RemapArgs {
   const uint8_t* src; int sw, sh, cn; long long srcPitch, srcImgPitch;
@@ -279,6 +298,10 @@ struct ProjArgs {
   const orbx_map_point_view* mps;        // mode 0: local map points
   const orbx_projected_point* pts;       // mode 1: projected LastFrame points
   int mode, checkOri;
+  int maxDist;                    // acceptance threshold on the best Hamming distance: TH_HIGH (100), or ORBdist of the
+                                  // relocalisation flavour SearchByProjection(Frame&, KeyFrame*, ...) (src/ORBmatcher.cc:1886)
+  int claimAll;                   // 1: every assignment occupies its keypoint (the gate there is a plain non-null test,
+                                  // src/ORBmatcher.cc:1871) and a culled slot is free again; 0: only points with observations do
   int nmp;
   float th, thFar, nnratio;
   int far;

@@ -88,6 +88,51 @@ int main(int argc, char** argv) {
     std::printf("bow %u words, %zu / %zu nodes, %d matches\n", voc.size(), vk.size(), vf.size(), n);
     return 0;
   }
+  if (std::string(argv[1]) == "reloc_tri") {
+    // frame_like reloc_tri <prefix> <w> <h> <ORBdist>: the relocalisation SearchByProjection(Frame&, KeyFrame*, ...) overload and
+    // SearchForTriangulation on <prefix>.{k1,d1,k2,d2,pts,occ,n1,s1,f1,n2,s2,f2,mp1,mp2,sf,sg,epF}; writes <prefix>.{rmatch,rocc,m12}
+    const std::string pre = argv[2];
+    auto rd = [&](const char* ext) { return slurp((pre + "." + ext).c_str()); };
+    std::vector<uint8_t> k1b = rd("k1"), d1 = rd("d1"), k2b = rd("k2"), d2 = rd("d2"), ptsb = rd("pts"), occ = rd("occ");
+    std::vector<uint8_t> mp1 = rd("mp1"), mp2 = rd("mp2"), sfb = rd("sf"), sgb = rd("sg"), epFb = rd("epF");
+    std::vector<ocv::KeyPoint> k1(k1b.size() / 28), k2(k2b.size() / 28);
+    std::memcpy(static_cast<void*>(k1.data()), k1b.data(), k1b.size());
+    std::memcpy(static_cast<void*>(k2.data()), k2b.data(), k2b.size());
+    std::vector<orbx_projected_point> pts(ptsb.size() / sizeof(orbx_projected_point));
+    std::memcpy(static_cast<void*>(pts.data()), ptsb.data(), ptsb.size());
+    FrameView cur;
+    cur.mvKeysUn = k2.data(); cur.mDescriptors = d2.data(); cur.N = (int)k2.size();
+    cur.mnMinX = 0; cur.mnMinY = 0; cur.mnMaxX = (float)std::atoi(argv[3]); cur.mnMaxY = (float)std::atoi(argv[4]);
+    ORBmatcher matcher(0.75f, true);
+    std::vector<int> rmatch;
+    const int nr = matcher.SearchByProjection(cur, pts, std::atoi(argv[5]), occ, rmatch);
+    dump(pre + ".rmatch", rmatch.data(), rmatch.size());
+    dump(pre + ".rocc", occ.data(), occ.size());
+    auto fv = [&](const char* n, const char* st, const char* f) {
+      std::vector<uint8_t> nb = rd(n), sb = rd(st), fb = rd(f);
+      const uint32_t* nodes = reinterpret_cast<const uint32_t*>(nb.data());
+      const int32_t* start = reinterpret_cast<const int32_t*>(sb.data());
+      const uint32_t* feats = reinterpret_cast<const uint32_t*>(fb.data());
+      DBoW2::FeatureVector v;
+      for (size_t j = 0; j < nb.size() / 4; j++) v[nodes[j]].assign(feats + start[j], feats + start[j + 1]);
+      return v;
+    };
+    const DBoW2::FeatureVector fv1 = fv("n1", "s1", "f1"), fv2 = fv("n2", "s2", "f2");
+    std::vector<float> sf(sfb.size() / 4), sg(sgb.size() / 4), epF(11);
+    std::memcpy(sf.data(), sfb.data(), sfb.size());
+    std::memcpy(sg.data(), sgb.data(), sgb.size());
+    std::memcpy(epF.data(), epFb.data(), 44);
+    KeyFrameView a, b;
+    a.mFeatVec = &fv1; a.mvKeysUn = &k1; a.mDescriptors = d1.data(); a.hasMapPoint = &mp1; a.mvScaleFactors = &sf; a.mvLevelSigma2 = &sg;
+    b.mFeatVec = &fv2; b.mvKeysUn = &k2; b.mDescriptors = d2.data(); b.hasMapPoint = &mp2; b.mvScaleFactors = &sf; b.mvLevelSigma2 = &sg;
+    std::vector<std::pair<size_t, size_t>> pairs;
+    const int nt = SearchForTriangulation(a, b, epF.data(), epF.data() + 2, pairs, false, false);
+    std::vector<int> m12(k1.size(), -1);
+    for (const auto& pr : pairs) m12[pr.first] = (int)pr.second;
+    dump(pre + ".m12", m12.data(), m12.size());
+    std::printf("%d %d %zu\n", nr, nt, pairs.size());
+    return 0;
+  }
   if (std::string(argv[1]) == "rectify") {
     // frame_like rectify <sw> <sh> <dw> <dh> <L.raw> <R.raw> <maps.raw (M1l M2l M1r M2r, dw*dh floats each)> <outprefix>
     const int sw = std::atoi(argv[2]), sh = std::atoi(argv[3]), dw = std::atoi(argv[4]), dh = std::atoi(argv[5]);

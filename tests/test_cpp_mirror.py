@@ -146,3 +146,31 @@ def test_cpp_mirror_bow_matches_oracle(oracle, tmp_path):
     assert np.array_equal(np.fromfile(out + ".values", np.float64).view(np.uint64), values.view(np.uint64))
     assert np.array_equal(np.fromfile(out + ".match", np.int32), m)
     assert ("%d matches" % n) in r.stdout and n > 50
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_relocalisation_and_triangulation_match_oracle(oracle, tmp_path):
+    """ORBmatcher::SearchByProjection(CurrentFrame, keyFramePoints, ORBdist, ...) (csrc/ORBmatcher.h) and SearchForTriangulation
+    (csrc/ORBVocabulary.h, DBoW2::FeatureVector in, vMatchedPairs out) against the oracle."""
+    import orb_slam3_fast_amd as orbx
+    import test_reloc_triangulation as T
+    exe = build_exe()
+    f = T._frames(oracle, 752, 480, 1500, 72)
+    rng = np.random.default_rng(55)
+    pts = T._kf_points(orbx, rng, f, 10.0)
+    occ = (rng.random(len(f["k2"])) < 0.3).astype(np.uint8)
+    fv1, mp1, _, fv2, mp2, _, ep, F = T._tri_inputs(f, rng, True)
+    pre = str(tmp_path / "rt")
+    for ext, arr in (("k1", f["k1"]), ("d1", f["d1"]), ("k2", f["k2"]), ("d2", f["d2"]), ("pts", pts), ("occ", occ), ("n1", fv1[0]),
+                     ("s1", fv1[1]), ("f1", fv1[2]), ("n2", fv2[0]), ("s2", fv2[1]), ("f2", fv2[2]), ("mp1", mp1), ("mp2", mp2),
+                     ("sf", f["sf"]), ("sg", f["sigma2"]), ("epF", np.concatenate([ep, F.reshape(9)]).astype(np.float32))):
+        np.ascontiguousarray(arr).tofile(pre + "." + ext)
+    r = subprocess.run([exe, "reloc_tri", pre, "752", "480", "100"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    nr, nt, npairs = map(int, r.stdout.split())
+    onr, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 100, True, occ)
+    ont, om12 = oracle.search_for_triangulation(fv1, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, f["sf"], f["sigma2"],
+                                                ep, F, False, False, True)
+    assert nr == onr > 100 and np.array_equal(np.fromfile(pre + ".rmatch", np.int32), omatch)
+    assert np.array_equal(np.fromfile(pre + ".rocc", np.uint8), oocc)
+    assert nt == ont == npairs and ont > 50 and np.array_equal(np.fromfile(pre + ".m12", np.int32), om12)

@@ -1,0 +1,358 @@
+"""Widening past SURVEY 8f: the next consumers of the device-resident descriptors.
+  ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)   src/ORBmatcher.cc:1808-1918 (relocalisation)
+  ORBmatcher::SearchForTriangulation(pKF1, pKF2, vMatchedPairs, bOnlyStereo, bCoarse)   src/ORBmatcher.cc:886-1106
+CPU part: literal Python transcriptions (numpy float32 where the reference computes in float) against the C++ oracle.
+GPU part (-m gpu): the HIP kernels through the C ABI against the oracle, bit for bit."""
+import bisect
+
+import numpy as np
+import pytest
+
+import orb_slam3_fast_amd as orbx
+from orb_slam3_fast_amd import synth
+from test_oracle_matchers import Grid, HISTO, TH_LOW, f32, hamming, rot_bin, three_maxima
+
+
+# ---- literal transcriptions -------------------------------------------------------------------------------------------------
+def search_by_projection_keyframe_py(kps, desc, bounds, pts, orb_dist, check_ori, occupied):
+    grid = Grid(kps, bounds)
+    mvp = [-2 if o else -1 for o in occupied]  # CurrentFrame.mvpMapPoints: -1 NULL, -2 there before, >= 0 pKF's point
+    hist = [[] for _ in range(HISTO)]
+    nmatches = 0
+    for i in range(len(pts)):
+        p = pts[i]
+        if not p["valid"]:
+            continue
+        cand = grid.area(p["u"], p["v"], p["radius"], int(p["min_level"]), int(p["max_level"]))
+        if not cand:
+            continue
+        best, best_idx = 256, -1
+        for i2 in cand:
+            if mvp[i2] != -1:
+                continue
+            d = hamming(p["desc"], desc[i2])
+            if d < best:
+                best, best_idx = d, i2
+        if best <= orb_dist:
+            mvp[best_idx] = i
+            nmatches += 1
+            if check_ori:
+                hist[rot_bin(p["angle"], kps["angle"][best_idx])].append(best_idx)
+    if check_ori:
+        keep = three_maxima(hist)
+        for b in range(HISTO):
+            if b in keep:
+                continue
+            for idx in hist[b]:
+                mvp[idx] = -1
+                nmatches -= 1
+    match = np.array([m if m >= 0 else -1 for m in mvp], np.int32)
+    occ = np.array([m != -1 for m in mvp], np.uint8)
+    return nmatches, match, occ
+
+
+def epipolar_constrain_py(kp1, kp2, F, unc):
+    """Pinhole::epipolarConstrain, src/CameraModels/Pinhole.cpp:136-148 (F = F12 row-major, float arithmetic)."""
+    x1, y1, x2, y2 = f32(kp1["x"]), f32(kp1["y"]), f32(kp2["x"]), f32(kp2["y"])
+    a = x1 * F[0] + y1 * F[3] + F[6]
+    b = x1 * F[1] + y1 * F[4] + F[7]
+    c = x1 * F[2] + y1 * F[5] + F[8]
+    num = a * x2 + b * y2 + c
+    den = a * a + b * b
+    if den == 0:
+        return False
+    dsqr = num * num / den
+    return float(dsqr) < 3.84 * float(unc)
+
+
+def search_for_triangulation_py(fv1, k1, d1, mp1, ur1, fv2, k2, d2, mp2, ur2, sf2, sg2, ep, F, only_stereo, coarse, check_ori):
+    F = np.asarray(F, np.float32).reshape(9)
+    m1 = {int(n): [int(x) for x in fv1[2][fv1[1][j]:fv1[1][j + 1]]] for j, n in enumerate(fv1[0])}   # std::map: ascending keys
+    m2 = {int(n): [int(x) for x in fv2[2][fv2[1][j]:fv2[1][j + 1]]] for j, n in enumerate(fv2[0])}
+    keys1, keys2 = sorted(m1), sorted(m2)
+    matches12 = np.full(len(k1), -1, np.int32)
+    matched2 = [False] * len(k2)   # vbMatched2: tested, never set
+    hist = [[] for _ in range(HISTO)]
+    nmatches = 0
+    i, j = 0, 0
+    while i < len(keys1) and j < len(keys2):
+        if keys1[i] == keys2[j]:
+            for idx1 in m1[keys1[i]]:
+                if mp1[idx1]:
+                    continue
+                stereo1 = ur1 is not None and ur1[idx1] >= 0
+                if only_stereo and not stereo1:
+                    continue
+                best, best_idx2 = TH_LOW, -1
+                for idx2 in m2[keys2[j]]:
+                    if matched2[idx2] or mp2[idx2]:
+                        continue
+                    stereo2 = ur2 is not None and ur2[idx2] >= 0
+                    if only_stereo and not stereo2:
+                        continue
+                    dist = hamming(d1[idx1], d2[idx2])
+                    if dist > TH_LOW or dist > best:
+                        continue
+                    kp2 = k2[idx2]
+                    if not stereo1 and not stereo2:
+                        ex, ey = f32(ep[0]) - f32(kp2["x"]), f32(ep[1]) - f32(kp2["y"])
+                        if ex * ex + ey * ey < f32(100) * f32(sf2[kp2["octave"]]):
+                            continue
+                    if coarse or epipolar_constrain_py(k1[idx1], kp2, F, sg2[kp2["octave"]]):
+                        best_idx2, best = idx2, dist
+                if best_idx2 >= 0:
+                    matches12[idx1] = best_idx2
+                    nmatches += 1
+                    if check_ori:
+                        hist[rot_bin(k1["angle"][idx1], k2["angle"][best_idx2])].append(idx1)
+            i += 1
+            j += 1
+        elif keys1[i] < keys2[j]:
+            i = bisect.bisect_left(keys1, keys2[j])
+        else:
+            j = bisect.bisect_left(keys2, keys1[i])
+    if check_ori:
+        keep = three_maxima(hist)
+        for b in range(HISTO):
+            if b in keep:
+                continue
+            for idx in hist[b]:
+                matches12[idx] = -1
+                nmatches -= 1
+    return nmatches, matches12
+
+
+# ---- inputs -----------------------------------------------------------------------------------------------------------------
+def _frames(oracle, w, h, nf, stream):
+    f0, f1 = synth.mono_frame(w, h, stream, 0), synth.mono_frame(w, h, stream, 2)
+    ex = oracle.OracleExtractor(nf)
+    _, k1, d1 = ex.extract(f0)
+    _, k2, d2 = ex.extract(f1)
+    t = ex.tables()
+    return dict(w=w, h=h, k1=k1, d1=d1, k2=k2, d2=d2, sf=t["scale"], sigma2=(t["scale"] * t["scale"]).astype(np.float32),
+                bounds=(0.0, 0.0, float(w), float(h)))
+
+
+@pytest.fixture(scope="module")
+def small(oracle):
+    return _frames(oracle, 480, 360, 500, 310)
+
+
+def _kf_points(mod, rng, f, th):
+    """pKF's map points (key frame = frame 1 of the pair) projected into the current frame (= frame 2)."""
+    k1, d1, sf = f["k1"], f["d1"], f["sf"]
+    n = len(k1)
+    pts = np.zeros(n, mod.PP_DTYPE)
+    pts["u"], pts["v"] = k1["x"] + rng.normal(0, 3.0, n), k1["y"] + rng.normal(0, 3.0, n)
+    lvl = np.clip(k1["octave"] + rng.integers(-1, 2, n), 0, 7)    # nPredictedLevel
+    pts["radius"] = (np.float32(th) * sf[lvl]).astype(np.float32)
+    pts["min_level"], pts["max_level"] = lvl - 1, lvl + 1
+    pts["angle"] = k1["angle"]
+    pts["valid"] = rng.random(n) < 0.8
+    pts["has_observations"] = rng.random(n) < 0.5                 # must not matter
+    pts["ur"] = rng.uniform(-50, 500, n)                          # must not matter
+    pts["desc"] = d1 ^ np.packbits(rng.random((n, 32, 8)) < 0.06, axis=2).reshape(n, 32)
+    return pts
+
+
+def _feature_vector(desc, rng, nodes=48, drop=0.1, stop=0.03):
+    """A FeatureVector as CSR: node = a hash of the descriptor's first bits (similar descriptors share nodes, like a vocabulary
+    node at level L - levelsup), some node ids absent from one of the two frames, a few features in no node (stopped words)."""
+    node = (desc[:, 0].astype(np.uint32) * 7 + (desc[:, 1] >> 6)) % nodes * 5 + 3
+    keep = rng.random(len(desc)) >= stop
+    gone = rng.choice(np.unique(node), max(1, int(drop * nodes)), replace=False)
+    keep &= ~np.isin(node, gone)
+    ids = np.unique(node[keep])
+    start, feats = [0], []
+    for nid in ids:
+        idx = np.nonzero(keep & (node == nid))[0]
+        feats.extend(idx.tolist())
+        start.append(len(feats))
+    return ids.astype(np.uint32), np.array(start, np.int32), np.array(feats, np.uint32)
+
+
+def _tri_inputs(f, rng, mono=False):
+    k1, d1, k2, d2 = f["k1"], f["d1"], f["k2"], f["d2"]
+    # frame 2 of a synthetic stream is frame 0 shifted by a few pixels: the image motion of a camera translating parallel to the
+    # image plane, F12 = [t]x with t along the shift (+ a perturbation so that all nine entries are exercised)
+    dist = np.unpackbits(d1[:, None, :] ^ d2[None, :, :], axis=2).sum(2)
+    j = dist.argmin(1)
+    good = dist[np.arange(len(k1)), j] < 30
+    dx = float(np.median((k2["x"][j] - k1["x"])[good])); dy = float(np.median((k2["y"][j] - k1["y"])[good]))
+    nrm = max(1e-6, (dx * dx + dy * dy) ** 0.5)
+    tx, ty = dx / nrm, dy / nrm
+    F = np.array([[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]], np.float64) + rng.normal(0, 2e-5, (3, 3)) * [[1, 1, 300], [1, 1, 300], [300, 300, 1]]
+    F = F.astype(np.float32)
+    ep = np.array([f["w"] * 0.5, f["h"] * 0.45], np.float32)
+    mp1 = (rng.random(len(k1)) < 0.25).astype(np.uint8)
+    mp2 = (rng.random(len(k2)) < 0.25).astype(np.uint8)
+    ur1 = None if mono else np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(0, 30, len(k1)), -1).astype(np.float32)
+    ur2 = None if mono else np.where(rng.random(len(k2)) < 0.5, k2["x"] - rng.uniform(0, 30, len(k2)), -1).astype(np.float32)
+    fv1, fv2 = _feature_vector(d1, rng), _feature_vector(d2, rng)
+    return fv1, mp1, ur1, fv2, mp2, ur2, ep, F
+
+
+TRI_MODES = [(False, False, True), (False, True, True), (True, False, True), (False, False, False)]   # onlyStereo, coarse, checkOri
+
+
+# ---- CPU: transcription == oracle -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(1, 10.0, 100, True), (2, 3.0, 64, True), (3, 10.0, 100, False)])
+def test_python_search_by_projection_keyframe_matches_oracle(oracle, small, seed, th, orb_dist, ori):
+    f = small
+    rng = np.random.default_rng(seed)
+    pts = _kf_points(oracle, rng, f, th)
+    occ = (rng.random(len(f["k2"])) < 0.3).astype(np.uint8)    # relocalisation: the PnP inliers already hold their points
+    e = search_by_projection_keyframe_py(f["k2"], f["d2"], f["bounds"], pts, orb_dist, ori, occ)
+    o = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, orb_dist, ori, occ)
+    assert e[0] == o[0] and np.array_equal(e[1], o[1]) and np.array_equal(e[2], o[2]) and o[0] > 20
+    # what distinguishes this flavour: a keypoint is taken at most once, pre-occupied ones never, culled ones are free again
+    taken = o[1] >= 0
+    assert not (taken & (occ != 0)).any() and np.array_equal(o[2] != 0, taken | (occ != 0))
+    assert len(np.unique(o[1][taken])) == taken.sum() == o[0]
+
+
+@pytest.mark.parametrize("seed,mono", [(4, False), (5, True)])
+def test_python_search_for_triangulation_matches_oracle(oracle, small, seed, mono):
+    f = small
+    rng = np.random.default_rng(seed)
+    fv1, mp1, ur1, fv2, mp2, ur2, ep, F = _tri_inputs(f, rng, mono)
+    total = 0
+    for only_stereo, coarse, ori in TRI_MODES:
+        e = search_for_triangulation_py(fv1, f["k1"], f["d1"], mp1, ur1, fv2, f["k2"], f["d2"], mp2, ur2, f["sf"], f["sigma2"], ep, F,
+                                        only_stereo, coarse, ori)
+        o = oracle.search_for_triangulation(fv1, f["k1"], f["d1"], mp1, ur1, fv2, f["k2"], f["d2"], mp2, ur2, f["sf"], f["sigma2"],
+                                            ep, F, only_stereo, coarse, ori)
+        assert e[0] == o[0] and np.array_equal(e[1], o[1]) and o[0] == (o[1] >= 0).sum()
+        assert not (mp1[o[1] >= 0]).any() and not mp2[o[1][o[1] >= 0]].any()
+        if only_stereo:
+            assert mono and o[0] == 0 or (not mono and (ur1[o[1] >= 0] >= 0).all())
+        total += o[0]
+    assert total > 60
+
+
+def test_triangulation_epipolar_gate_is_active(oracle, small):
+    """The epipolar test must actually reject: coarse (no test) finds strictly more than the fine search, and a wrong F almost none."""
+    f = small
+    rng = np.random.default_rng(6)
+    fv1, mp1, ur1, fv2, mp2, ur2, ep, F = _tri_inputs(f, rng, True)
+    args = (fv1, f["k1"], f["d1"], mp1, ur1, fv2, f["k2"], f["d2"], mp2, ur2, f["sf"], f["sigma2"], ep)
+    fine = oracle.search_for_triangulation(*args, F, False, False, False)[0]
+    coarse = oracle.search_for_triangulation(*args, F, False, True, False)[0]
+    wrong = oracle.search_for_triangulation(*args, np.ascontiguousarray(F.T[::-1]) * 50, False, False, False)[0]
+    assert coarse > fine > 30 and wrong < fine // 2
+
+
+# ---- GPU: HIP == oracle through the C ABI -----------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu():
+    if orbx.device_count() < 1:
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on the MI355X box")
+    return True
+
+
+@pytest.fixture(scope="module")
+def big(oracle):
+    return _frames(oracle, 752, 480, 1500, 72)
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_projection_keyframe(gpu, oracle, big):
+    f = big
+    rng = np.random.default_rng(21)
+    for th, orb_dist, ori, pocc, least in [(10.0, 100, True, 0.3, 100), (3.0, 64, True, 0.6, 1), (10.0, 100, False, 0.0, 100),
+                                           (25.0, 255, True, 0.1, 100), (10.0, 0, True, 0.0, 0)]:
+        pts = _kf_points(orbx, rng, f, th)
+        occ = (rng.random(len(f["k2"])) < pocc).astype(np.uint8)
+        m = orbx.ORBmatcher(0.9, ori)
+        nm, match, o2 = m.SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts, occ, orb_dist)
+        onm, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, orb_dist, ori, occ)
+        assert onm >= least
+        assert nm == onm and np.array_equal(match, omatch) and np.array_equal(o2, oocc)
+    m = orbx.ORBmatcher(0.9, True)
+    nm, match, o2 = m.SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts[:0], occ, 100)
+    assert nm == 0 and (match == -1).all() and np.array_equal(o2, occ)
+    with pytest.raises(orbx.OrbxError):
+        m.SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts, occ, 256)
+
+
+@pytest.mark.gpu
+def test_gpu_keyframe_flavour_under_serial_walk_and_small_capacity(gpu, oracle, big):
+    """The relocalisation flavour through the fallback paths of the projection search (one-wave serial walk, capacity retry)."""
+    import json, os, subprocess, sys
+    code = r"""
+import json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import orb_slam3_fast_amd as orbx
+from oracle import oracle_py as oracle
+import test_reloc_triangulation as T
+f = T._frames(oracle, 752, 480, 1500, 72)
+rng = np.random.default_rng(33)
+pts = T._kf_points(orbx, rng, f, 10.0)
+occ = (rng.random(len(f["k2"])) < 0.3).astype(np.uint8)
+a = orbx.ORBmatcher(0.9, True).SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts, occ, 100)
+b = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 100, True, occ)
+print(json.dumps(dict(ok=bool(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])), n=int(b[0]))))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"ORBX_PROJ_SERIAL": "1"}, {"ORBX_PROJ_CAND_CAP": "64"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        assert r["ok"] and r["n"] > 100, (env, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,mono", [(41, False), (42, True)])
+def test_gpu_search_for_triangulation(gpu, oracle, big, seed, mono):
+    f = big
+    rng = np.random.default_rng(seed)
+    fv1, mp1, ur1, fv2, mp2, ur2, ep, F = _tri_inputs(f, rng, mono)
+    total = 0
+    for only_stereo, coarse, ori in TRI_MODES:
+        m = orbx.ORBmatcher(0.6, ori)
+        n, pairs, m12 = m.SearchForTriangulation(fv1, f["k1"], f["d1"], mp1, ur1, fv2, f["k2"], f["d2"], mp2, ur2, f["sf"], f["sigma2"], ep, F,
+                                                 only_stereo, coarse)
+        on, om12 = oracle.search_for_triangulation(fv1, f["k1"], f["d1"], mp1, ur1, fv2, f["k2"], f["d2"], mp2, ur2, f["sf"], f["sigma2"],
+                                                   ep, F, only_stereo, coarse, ori)
+        assert n == on and np.array_equal(m12, om12)
+        assert len(pairs) == n and np.array_equal(pairs[:, 1], om12[pairs[:, 0]]) and (np.diff(pairs[:, 0]) > 0).all()
+        total += on
+    assert total > 200
+
+
+@pytest.mark.gpu
+def test_gpu_search_for_triangulation_edges(gpu, oracle, big):
+    f = big
+    rng = np.random.default_rng(43)
+    fv1, mp1, ur1, fv2, mp2, ur2, ep, F = _tri_inputs(f, rng, True)
+    m = orbx.ORBmatcher(0.6, True)
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    common = (f["sf"], f["sigma2"], ep, F)
+    n, pairs, m12 = m.SearchForTriangulation(empty, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, *common)
+    assert n == 0 and len(pairs) == 0 and (m12 == -1).all()
+    n, pairs, m12 = m.SearchForTriangulation(fv1, f["k1"], f["d1"], mp1, None, empty, f["k2"], f["d2"], mp2, None, *common)
+    assert n == 0 and (m12 == -1).all()
+    # every feature of pKF2 already holds a map point: nothing to pair; no feature of pKF1 is free: nothing either
+    n, _, _ = m.SearchForTriangulation(fv1, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], np.ones_like(mp2), None, *common)
+    assert n == 0
+    n, _, _ = m.SearchForTriangulation(fv1, f["k1"], f["d1"], np.ones_like(mp1), None, fv2, f["k2"], f["d2"], mp2, None, *common)
+    assert n == 0
+    # disjoint node sets (the lower_bound walk never meets)
+    a = (fv1[0] * 2, fv1[1], fv1[2])
+    b = (fv2[0] * 2 + 1, fv2[1], fv2[2])
+    n, _, m12 = m.SearchForTriangulation(a, f["k1"], f["d1"], mp1, None, b, f["k2"], f["d2"], mp2, None, *common)
+    on, om12 = oracle.search_for_triangulation(a, f["k1"], f["d1"], mp1, None, b, f["k2"], f["d2"], mp2, None, f["sf"], f["sigma2"], ep, F)
+    assert n == on == 0 and np.array_equal(m12, om12)
+    # one node holding every feature of both frames (the largest candidate lists the call can see)
+    one1 = (np.array([9], np.uint32), np.array([0, len(f["k1"])], np.int32), np.arange(len(f["k1"]), dtype=np.uint32))
+    one2 = (np.array([9], np.uint32), np.array([0, len(f["k2"])], np.int32), np.arange(len(f["k2"]), dtype=np.uint32))
+    n, _, m12 = m.SearchForTriangulation(one1, f["k1"], f["d1"], mp1, None, one2, f["k2"], f["d2"], mp2, None, *common)
+    on, om12 = oracle.search_for_triangulation(one1, f["k1"], f["d1"], mp1, None, one2, f["k2"], f["d2"], mp2, None, f["sf"], f["sigma2"],
+                                               ep, F)
+    assert n == on and on > 100 and np.array_equal(m12, om12)
+    # argument checks: descending node ids, a feature index outside the frame
+    bad = (fv1[0][::-1].copy(), fv1[1], fv1[2])
+    with pytest.raises(orbx.OrbxError):
+        m.SearchForTriangulation(bad, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, *common)
+    bad = (fv1[0], fv1[1], np.where(np.arange(len(fv1[2])) == 3, len(f["k1"]), fv1[2]).astype(np.uint32))
+    with pytest.raises(orbx.OrbxError):
+        m.SearchForTriangulation(bad, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, *common)
