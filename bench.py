@@ -545,6 +545,8 @@ def main():
     if extras and a.other_steps > 0 and (W, H) == (1280, 720):
         # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
         out["other_configs"] = other_configs_leg(a, local_rank, torch)
+    if extras:
+        out.update(natural_pair_leg(orbx, np))
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
     if extras and a.h2d_steps > 0:
@@ -560,6 +562,29 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def natural_pair_leg(orbx, np):
+    """Sanity field on a NATURAL stereo pair (the rectified Middlebury `motorcycle` pair, 741x500, committed as arrays in
+    tests/golden/natural_images.npz by tools/gen_natural_fixture.py): keypoints per eye and stereo matches of the product path.
+    tests/test_natural_images.py pins the same numbers on the oracle (1504 / 1508 keypoints, 595 matches) and compares bit for bit."""
+    fix = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "natural_images.npz")
+    if not os.path.exists(fix):
+        return {"natural_pair": None}
+    z = np.load(fix)
+    L, R = np.ascontiguousarray(z["moto_left"]), np.ascontiguousarray(z["moto_right"])
+    h, w = L.shape
+    exL = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    exR = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    _, kL, _ = exL(L)
+    _, kR, _ = exR(R)
+    u, dep = orbx.ComputeStereoMatches(exL, exR, BF, BASE)
+    ok = u[0, :len(kL)] >= 0
+    disp = (kL["x"] - u[0, :len(kL)])[ok]
+    return {"natural_pair": {"image": "Middlebury motorcycle (rectified), %dx%d" % (w, h), "keypoints_left": int(len(kL)),
+                             "keypoints_right": int(len(kR)), "stereo_matches": int(ok.sum()),
+                             "median_disparity_px": round(float(np.median(disp)), 2) if ok.any() else None,
+                             "expected": "1504 / 1508 keypoints, 595 matches (oracle, tests/test_natural_images.py)"}}
 
 
 def other_configs_leg(a, local_rank, torch):
@@ -693,10 +718,28 @@ def h2d_leg(a, wl, orbx, np, torch):
     n0 = int(res[0]["cnt"][0])
     up = 2 * B * W * H
     down = 2 * B * (8 + cap * 60) + 2 * B * cap * 4
+    # the link's own rate on this box: the same upload alone, 10 times back to back (the leg cannot be faster than this)
+    dev = torch.empty(up, dtype=torch.uint8, device="cuda")
+    flat = ring[0].reshape(-1)
+    dev.copy_(flat, non_blocking=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        dev.copy_(flat, non_blocking=True)
+    torch.cuda.synchronize()
+    link = up * 10 / (time.perf_counter() - t1)
+    del dev
     return {"h2d_inclusive_value": round(B * a.h2d_steps / dt, 1),
             "h2d_inclusive": {"unit": "stereo frames/s", "steps": a.h2d_steps, "ms_per_step": round(1e3 * dt / a.h2d_steps, 4),
                               "upload_MB_per_step": round(up / 1e6, 2), "download_MB_per_step": round(down / 1e6, 2),
                               "pcie_GBps": round((up + down) * a.h2d_steps / dt / 1e9, 2), "keypoints_image0": n0,
+                              "link_upload_GBps": round(link / 1e9, 2),
+                              "link_bound_value": round(B * link / up, 1),
+                              "frac_of_link_bound": round(B * a.h2d_steps / dt / (B * link / up), 3),
+                              "link_note": "link_upload_GBps = the same %.0f MB of frames uploaded alone, 10 times back to back, in this run; "
+                                           "link_bound_value = pairs/s if the uploads were the only cost (the downloads travel in the other "
+                                           "direction); a copy trace of this leg shows the uploads back to back with 7 us gaps "
+                                           "(tools/dump_copies.py)" % (up / 1e6),
                               "note": "page-locked host frames -> orbx_extract_batch (async upload on the handle's stream) -> "
                                       "extraction + ComputeStereoMatches -> orbx_batch_download_async of ALL results into "
                                       "page-locked arrays; %d handles alternate so one batch's copies overlap the other's kernels"
