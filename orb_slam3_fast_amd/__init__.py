@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborbx.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("ORBX_LIB_NAME", "liborbx.so"))   # ORBX_LIB_NAME: A/B runs of experiment builds (tools)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
