@@ -69,6 +69,37 @@ def test_stages_and_end_to_end(gpu, oracle, w, h, nf, nl, stream):
     assert np.array_equal(d, od)
 
 
+def test_fused_blur_border_zone_is_exercised_and_exact(gpu, oracle):
+    """ADVICE (round 2): the product never blurs a level -- k_describe evaluates the 7x7 Gaussian on each keypoint's own 43x43
+    window, and keypoints within 21 px of a level's edge (the window leaves the level: 18 px of pattern reach + 3 of the blur,
+    keypoints may sit 19 px from the edge) take its BORDER_REFLECT_101 path.  Here: frames textured up to the border, the
+    border-zone keypoints are counted per side, and their descriptors -- which the oracle computes from a level blurred as a
+    whole, as the reference does (src/ORBextractor.cc:1074-1076) -- are compared on their own."""
+    sides = np.zeros(4, int)
+    for (w, h, stream) in ((640, 480, 5), (752, 480, 6), (400, 300, 7)):
+        img = synth.mono_frame(w, h, stream)
+        rng = np.random.default_rng(stream)
+        for (ys, xs) in ((slice(0, 40), slice(None)), (slice(h - 40, h), slice(None)), (slice(None), slice(0, 40)), (slice(None), slice(w - 40, w))):
+            img[ys, xs] = np.where(rng.random(img[ys, xs].shape) < 0.5, 40, 200).astype(np.uint8)   # corners right up to the edge
+        img = np.ascontiguousarray(img)
+        ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h)
+        oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
+        _, k, d = ex(img, (0, 0))
+        _, ok_, od = oe.extract(img, (0, 0))
+        assert np.array_equal(_kp_bytes(k), _kp_bytes(ok_))
+        sf = oe.tables()["scale"]
+        lx, ly = ok_["x"] / sf[ok_["octave"]], ok_["y"] / sf[ok_["octave"]]
+        lw = np.array([oe.level(l).shape[1] for l in range(8)])[ok_["octave"]]
+        lh = np.array([oe.level(l).shape[0] for l in range(8)])[ok_["octave"]]
+        zone = np.stack([lx < 21, ly < 21, lx > lw - 1 - 21, ly > lh - 1 - 21])
+        sides += zone.sum(1)
+        sel = zone.any(0)
+        assert sel.sum() >= 20
+        assert np.array_equal(d[sel], od[sel])
+        assert np.array_equal(d, od)
+    assert (sides >= 10).all(), sides   # left, top, right and bottom reflections all taken
+
+
 def test_pyramid_download_equals_the_per_level_reads(gpu, oracle):
     """orbx_pyramid_download (all levels, one synchronisation, pinned staging; the C++ mirror's mvImagePyramid refresh) returns
     the bytes of orbx_pyramid_level for every level: host entry (handle-owned level 0), batched device entry (level 0 = the
