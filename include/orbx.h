@@ -452,6 +452,31 @@ int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const i
                                   const float* level_sigma2_2, int nlevels2, const float ep[2], const float F12[9], int only_stereo,
                                   int coarse, int check_orientation, int32_t* matches12);
 
+/* One map point of ORBmatcher::Fuse after the reference's projection and gates (src/ORBmatcher.cc:1141-1192: not bad, not already
+ * in the key frame, positive depth, inside the image, distance inside the scale-invariance range, viewing angle below 60 degrees):
+ * uv, ur = u - mbf * invz, radius = th * mvScaleFactors[nPredictedLevel], nPredictedLevel, GetDescriptor().  valid = 0 for the
+ * points the reference skips.  56 bytes. */
+typedef struct orbx_fuse_point {
+  float u, v, ur, radius;
+  int32_t predicted_level;
+  uint8_t valid, pad_[3];
+  uint8_t desc[32];
+} orbx_fuse_point;
+
+/* Replaces the search of ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight)
+ * (src/ORBmatcher.cc:1108-1277; LocalMapping::SearchInNeighbors): per map point KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:
+ * 705-749), the level window [nPredictedLevel - 1, nPredictedLevel], the chi-square gate on the reprojection error (5.99
+ * monocular, 7.8 with mvuRight[idx] >= 0; float arithmetic as :1217-1237) and the first strict minimum of the descriptor distance
+ * (:1195-1256).  kps / desc / u_right = the camera searched: mvKeysUn + mvuRight, or mvKeys / mvKeysRight of a two-camera rig
+ * with u_right = NULL (the caller adds NLeft to the indices of the right camera, :1239); bounds = mnMinX .. mnMaxY;
+ * inv_level_sigma2 = mvInvLevelSigma2.  best_idx[i] = the keypoint point i fuses into (distance <= TH_LOW) or -1; best_dist[i]
+ * (optional) = the minimum over the gated candidates, 256 if there were none.  The Replace / AddObservation / AddMapPoint
+ * bookkeeping of a hit (:1259-1271) does not feed back into the search and stays with the caller, in point order.
+ * Returns nFused or a negative error. */
+int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, const float* u_right, int n, float min_x,
+                     float min_y, float max_x, float max_y, const float* inv_level_sigma2, int nlevels,
+                     const orbx_fuse_point* points, int n_points, int32_t* best_idx, int32_t* best_dist);
+
 /* Stereo-fisheye frames (F.Nleft != -1): the frame holds N = n_left + n_right keypoints (mvKeys then mvKeysRight), one
  * descriptor row each in the same order, mGrid over the left and mGridRight over the right keypoints, and the stereo
  * association mvLeftToRightMatch / mvRightToLeftMatch (orbx_fisheye_stereo_match).  orbx_map_point_right carries the

@@ -568,3 +568,21 @@ def search_for_triangulation(fv1, k1, d1, has_mp1, uright1, fv2, k2, d2, has_mp2
                                            None if u2 is None else _p(u2), len(k2), _p(sf), _p(sg), len(sf), _p(epa), _p(Fa),
                                            int(only_stereo), int(coarse), int(check_ori), _p(m))
     return n, m
+
+
+FP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("predicted_level", "<i4"), ("valid", "u1"),
+                     ("pad_", "u1", (3,)), ("desc", "u1", (32,))])
+assert FP_DTYPE.itemsize == 56
+
+
+def fuse_search(k, desc, uright, bounds, inv_level_sigma2, pts):
+    """Search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight), src/ORBmatcher.cc:1195-1256 -> (nFused, bestIdx, bestDist)."""
+    k = np.ascontiguousarray(k)
+    desc = _u8(desc)
+    pts = np.ascontiguousarray(pts, FP_DTYPE)
+    ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+    isg = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    bi, bd = np.zeros(len(pts), np.int32), np.zeros(len(pts), np.int32)
+    n = lib().oro_fuse_search(_p(k), _p(desc), None if ur is None else _p(ur), len(k), C.c_float(bounds[0]), C.c_float(bounds[1]),
+                              C.c_float(bounds[2]), C.c_float(bounds[3]), _p(isg), len(isg), _p(pts), len(pts), _p(bi), _p(bd))
+    return n, bi, bd

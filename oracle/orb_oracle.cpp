@@ -1653,6 +1653,51 @@ int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vec
   return nmatches;
 }
 
+// ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight) (src/ORBmatcher.cc:1108-1277): the search part
+// of the loop body (:1195-1256) -- KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:705-749: the frame grid without a level filter),
+// the level window, the chi-square gate on the reprojection error and the first strict minimum of the descriptor distance.
+int fuse_search(const std::vector<KeyPoint>& kps, const uint8_t* desc, const float* uRight, const FrameGrid& grid,
+                const std::vector<float>& invLevelSigma2, const std::vector<FusePoint>& pts, std::vector<int>& bestIdxOut,
+                std::vector<int>& bestDistOut) {
+  const int TH_LOW = 50;
+  int nFused = 0;
+  bestIdxOut.assign(pts.size(), -1);
+  bestDistOut.assign(pts.size(), 256);
+  for (size_t i = 0; i < pts.size(); i++) {
+    const FusePoint& p = pts[i];
+    if (!p.valid) continue;  // :1141-1192 on the caller's side
+    const int nPredictedLevel = p.predicted_level;
+    const std::vector<int> vIndices = grid.features_in_area(kps, p.u, p.v, p.radius, -1, -1);
+    if (vIndices.empty()) continue;
+    int bestDist = 256, bestIdx = -1;
+    for (int idx : vIndices) {
+      const KeyPoint& kp = kps[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (uRight && uRight[idx] >= 0) {
+        const float ex = p.u - kp.x;
+        const float ey = p.v - kp.y;
+        const float er = p.ur - uRight[idx];
+        const float e2 = ex * ex + ey * ey + er * er;
+        if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+      } else {
+        const float ex = p.u - kp.x;
+        const float ey = p.v - kp.y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+      }
+      const int dist = descriptor_distance(p.desc, desc + (size_t)idx * 32);
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    bestDistOut[i] = bestDist;
+    if (bestDist <= TH_LOW) {
+      bestIdxOut[i] = bestIdx;
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
 // ---- stereo-fisheye branches ------------------------------------------------------------------------------------------------
 int search_by_projection_map_fisheye(const std::vector<KeyPoint>& kps, const uint8_t* desc, int nLeft, const FrameGrid& gridL,
                                      const FrameGrid& gridR, const std::vector<float>& scaleFactors,

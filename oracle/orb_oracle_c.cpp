@@ -468,4 +468,18 @@ int oro_search_for_triangulation(const uint32_t* nodes1, int nNodes1, const int*
   return n;
 }
 
+int oro_fuse_search(const KeyPoint* k, const uint8_t* desc, const float* uRight, int n, float minX, float minY, float maxX, float maxY,
+                    const float* invSigma2, int nLevels, const FusePoint* pts, int npts, int* bestIdx, int* bestDist) {
+  std::vector<KeyPoint> a(k, k + n);
+  FrameGrid g;
+  g.build(a, minX, minY, maxX, maxY);
+  std::vector<FusePoint> p(pts, pts + npts);
+  std::vector<float> is(invSigma2, invSigma2 + nLevels);
+  std::vector<int> bi, bd;
+  const int nf = fuse_search(a, desc, uRight, g, is, p, bi, bd);
+  std::copy(bi.begin(), bi.end(), bestIdx);
+  std::copy(bd.begin(), bd.end(), bestDist);
+  return nf;
+}
+
 }  // extern "C"

@@ -30,6 +30,9 @@ PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"
                      ("max_level", "<i4"), ("valid", "u1"), ("has_observations", "u1"), ("pad_", "u1", (2,)),
                      ("desc", "u1", (32,))])   # orbx_projected_point
 assert PP_DTYPE.itemsize == 64
+FP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("predicted_level", "<i4"), ("valid", "u1"),
+                     ("pad_", "u1", (3,)), ("desc", "u1", (32,))])   # orbx_fuse_point
+assert FP_DTYPE.itemsize == 56
 MPR_DTYPE = np.dtype([("proj_yr", "<f4"), ("view_cos_r", "<f4"), ("predicted_level_r", "<i4"), ("in_view_r", "u1"),
                       ("pad_", "u1", (3,))])   # orbx_map_point_right
 assert MPR_DTYPE.itemsize == 16
@@ -122,6 +125,7 @@ def lib():
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
+        L.orbx_fuse_search.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_comm_unique_id.argtypes = [vp]
         L.orbx_comm_create.argtypes = [vp, i, i, i, C.POINTER(vp)]
@@ -783,6 +787,20 @@ class ORBmatcher:
             self.device, _p(k), _p(d), len(k), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp), len(pp), int(ORBdist),
             int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
+
+    def FuseSearch(self, kps, desc, uRight, bounds, invLevelSigma2, points):
+        """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1195-1256); points: FP_DTYPE records
+        of the map points after the caller's projection and gates.  Returns (nFused, bestIdx[n_points] = keypoint index or -1,
+        bestDist[n_points])."""
+        k = np.ascontiguousarray(kps, KP_DTYPE)
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        pp = np.ascontiguousarray(points, FP_DTYPE)
+        ur = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        isg = np.ascontiguousarray(invLevelSigma2, np.float32)
+        bi, bd = np.full(len(pp), -1, np.int32), np.full(len(pp), 256, np.int32)
+        n = _check(lib().orbx_fuse_search(self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1],
+                                          bounds[2], bounds[3], _p(isg), len(isg), _p(pp), len(pp), _p(bi), _p(bd)))
+        return n, bi, bd
 
     def SearchForTriangulation(self, fv1, kps1, desc1, hasMapPoint1, uRight1, fv2, kps2, desc2, hasMapPoint2, uRight2,
                                scaleFactors2, levelSigma2_2, ep, F12, bOnlyStereo=False, bCoarse=False):

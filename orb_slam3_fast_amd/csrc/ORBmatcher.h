@@ -130,6 +130,22 @@ class ORBmatcher {
     return n;
   }
 
+  // The search of Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight), src/ORBmatcher.cc:1108-1277
+  // (LocalMapping::SearchInNeighbors): KF = the members of the key frame's searched camera (mvKeysUn or mvKeys / mvKeysRight,
+  // mDescriptors rows of that camera, mvuRight, bounds), mvInvLevelSigma2, one orbx_fuse_point per map point after the caller's
+  // projection and gates (:1141-1192).  bestIdx[i] = keypoint the point fuses into or -1: the caller then runs the reference's
+  // bookkeeping in point order -- `MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx[i]); if (pMPinKF) {...Replace...} else
+  // {pMP->AddObservation(pKF, bestIdx[i]); pKF->AddMapPoint(pMP, bestIdx[i]);}` (:1259-1271).  Returns nFused.
+  int Fuse(const FrameView& KF, const std::vector<float>& mvInvLevelSigma2, const std::vector<orbx_fuse_point>& vpMapPoints,
+           std::vector<int>& bestIdx) {
+    bestIdx.assign(vpMapPoints.size(), -1);
+    const int n = orbx_fuse_search(device_, reinterpret_cast<const orbx_keypoint*>(KF.mvKeysUn), KF.mDescriptors, KF.mvuRight, KF.N,
+                                   KF.mnMinX, KF.mnMinY, KF.mnMaxX, KF.mnMaxY, mvInvLevelSigma2.data(), (int)mvInvLevelSigma2.size(),
+                                   vpMapPoints.data(), (int)vpMapPoints.size(), bestIdx.data(), nullptr);
+    if (n < 0) throw std::runtime_error(std::string("Fuse: ") + orbx_last_error());
+    return n;
+  }
+
   // The same two searches for stereo-fisheye frames (F.Nleft != -1, src/ORBmatcher.cc:41-221 / :1594-1806): F holds
   // N = Nleft + Nright keypoints (mvKeys then mvKeysRight; FrameView::mvKeysUn points at that array, N at the total),
   // vpMapPointsRight the right-camera members of every MapPoint, and the stereo association of the frame.

@@ -462,6 +462,59 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
+int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, const float* u_right, int n, float min_x,
+                     float min_y, float max_x, float max_y, const float* inv_level_sigma2, int nlevels,
+                     const orbx_fuse_point* points, int n_points, int32_t* best_idx, int32_t* best_dist) {
+  if (n < 0 || n_points < 0 || nlevels < 1 || !inv_level_sigma2 || (n && (!kps || !desc)) || (n_points && (!points || !best_idx)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n >= (1 << 20)) return fail(ORBX_E_CAPACITY, "more than 2^20 keypoints");
+  for (int i = 0; i < n; i++)  // kp.octave indexes mvInvLevelSigma2 (:1227,1236)
+    if (kps[i].octave < 0 || kps[i].octave >= nlevels) return fail(ORBX_E_BADARG, "keypoint octave outside [0, nlevels)");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  for (int i = 0; i < n_points; i++) {
+    best_idx[i] = -1;
+    if (best_dist) best_dist[i] = 256;
+  }
+  if (n == 0 || n_points == 0) return 0;
+  ScratchBuf<int> cellStart, cellItems, mdist, m21, m12;
+  hipError_t e = hipSuccess;
+  auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  Pack pk;
+  const size_t oK = pk.add(kps, (size_t)n * sizeof(orbx_keypoint)), oD = pk.add(desc, (size_t)n * 32);
+  const size_t oU = pk.add(u_right, (size_t)n * 4), oS = pk.add(inv_level_sigma2, (size_t)nlevels * 4);
+  const size_t oP = pk.add(points, (size_t)n_points * sizeof(orbx_fuse_point));
+  static const int zero4[4] = {0, 0, 0, 0};
+  const size_t oRes = pk.add(zero4, sizeof(zero4));  // [0] nFused, [2..3] the grid kernel's own result words; then best_idx | best_dist: one copy back
+  const size_t oBi = pk.add(nullptr, (size_t)n_points * 4), oBd = pk.add(nullptr, (size_t)n_points * 4);
+  const size_t outBytes = oBd + (size_t)n_points * 4 - oRes;
+  chk(pk.commit());
+  chk(cellStart.alloc(64 * 48 + 1)); chk(cellItems.alloc(n)); chk(mdist.alloc(n)); chk(m21.alloc(n)); chk(m12.alloc(1));
+  FuseArgs a{};
+  a.grid.k2 = pk.ptr<orbx_keypoint>(oK); a.grid.n2 = n; a.grid.n1 = 0;
+  a.grid.minX = min_x; a.grid.minY = min_y;
+  a.grid.invW = 64.f / (max_x - min_x);
+  a.grid.invH = 48.f / (max_y - min_y);
+  a.grid.cellStart = cellStart.p; a.grid.cellItems = cellItems.p; a.grid.matchedDist = mdist.p; a.grid.matches21 = m21.p;
+  a.grid.matches12 = m12.p; a.grid.result = pk.ptr<int>(oRes) + 2; a.grid.candCap = 1 << 30;
+  a.desc = pk.ptr<uint32_t>(oD); a.uRight = u_right ? pk.ptr<float>(oU) : nullptr; a.invSigma2 = pk.ptr<float>(oS);
+  a.pts = pk.ptr<orbx_fuse_point>(oP); a.npts = n_points;
+  a.bestIdx = pk.ptr<int>(oBi); a.bestDist = pk.ptr<int>(oBd); a.result = pk.ptr<int>(oRes);
+  if (e == hipSuccess) chk(launch_fuse_search(a, nullptr));
+  int nf = 0;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oRes, outBytes, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&nf, h, 4);
+      std::memcpy(best_idx, h + (oBi - oRes), (size_t)n_points * 4);
+      if (best_dist) std::memcpy(best_dist, h + (oBd - oRes), (size_t)n_points * 4);
+    }
+  }
+  pk.release(); cellStart.free(); cellItems.free(); mdist.free(); m21.free(); m12.free();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return nf;
+}
+
 int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
                                   int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
                                   const float* u_right1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,

@@ -327,6 +327,77 @@ hipError_t launch_grid_build(const InitArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a);
   return hipGetLastError();
 }
+// ---- ORBmatcher::Fuse, the search of the loop body (src/ORBmatcher.cc:1195-1256) -----------------------------------------------
+// Every map point is independent (the Replace / AddObservation bookkeeping after a hit does not feed back into the search).
+// 16 lanes per point walk the window's grid columns (a column of cells is one contiguous CSR range, already in the reference's
+// ix-outer / iy-inner / in-cell order); "first strict minimum" = minimum of (distance, position in that order).
+__global__ __launch_bounds__(256) void k_fuse_search(FuseArgs a) {
+  const int sub = threadIdx.x & 15;
+  const int ip = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (ip >= a.npts) return;
+  const InitArgs& g = a.grid;
+  const orbx_fuse_point& p = a.pts[ip];
+  uint64_t best = ~0ull;  // (dist << 52) | (position << 32) | keypoint index
+  if (p.valid) {
+    const float x = p.u, y = p.v, r = p.radius, ur = p.ur;
+    const int lvl = p.predicted_level;
+    const int cx0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cx1 = min(63, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, g.minX), r), g.invW)));
+    const int cy0 = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    const int cy1 = min(47, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, g.minY), r), g.invH)));
+    if (cx0 < 64 && cx1 >= 0 && cy0 < 48 && cy1 >= 0) {
+      uint32_t d1[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d1[i] = reinterpret_cast<const uint32_t*>(p.desc)[i];
+      int seen = 0;
+      for (int ix = cx0; ix <= cx1; ix++) {
+        const int b = g.cellStart[ix * 48 + cy0], e = g.cellStart[ix * 48 + cy1 + 1];
+        for (int j = b + sub; j < e; j += 16) {
+          const int idx = g.cellItems[j];
+          const orbx_keypoint kp = g.k2[idx];
+          if (!(fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r)) continue;  // KeyFrame.cc:739-743
+          if (kp.octave < lvl - 1 || kp.octave > lvl) continue;                             // :1215
+          const float ex = __fsub_rn(x, kp.x), ey = __fsub_rn(y, kp.y);
+          float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+          const float kr = a.uRight ? a.uRight[idx] : -1.0f;
+          double lim = 5.99;
+          if (kr >= 0) {  // stereo observation: three residuals, chi-square with 3 dof (:1217-1227)
+            const float er = __fsub_rn(ur, kr);
+            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+            lim = 7.8;
+          }
+          if ((double)__fmul_rn(e2, a.invSigma2[kp.octave]) > lim) continue;
+          const int dist = hamming256(d1, a.desc + (long long)idx * 8);
+          const uint64_t key = ((uint64_t)(uint32_t)dist << 52) | ((uint64_t)(uint32_t)(seen + (j - b)) << 32) | (uint32_t)idx;
+          best = key < best ? key : best;
+        }
+        seen += e - b;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const uint64_t ob = __shfl_xor((unsigned long long)best, o, 16);
+    best = ob < best ? ob : best;
+  }
+  bool hit = false;
+  if (sub == 0) {
+    const int dist = best == ~0ull ? 256 : (int)(best >> 52);
+    a.bestDist[ip] = dist;
+    hit = dist <= 50;  // TH_LOW
+    a.bestIdx[ip] = hit ? (int)(uint32_t)best : -1;
+  }
+  const uint64_t m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.result[0], __popcll(m));
+}
+
+hipError_t launch_fuse_search(const FuseArgs& a, hipStream_t s) {
+  hipError_t e = launch_grid_build(a.grid, s);
+  if (e != hipSuccess) return e;
+  if (a.npts > 0) hipLaunchKernelGGL(k_fuse_search, dim3((a.npts + 15) / 16), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s) {
   if (nq > 0) hipLaunchKernelGGL(k_area_query, dim3((nq + 3) / 4), dim3(256), 0, s, a, q, nq, qOff, out, pass);
   return hipGetLastError();

@@ -325,6 +325,21 @@ hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hi
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s);     // match / occupied / cull / count
 hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s);             // the one-wave walk (fallback)
 
+// Search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1195-1256): k_fuse_search
+struct FuseArgs {
+  InitArgs grid;                 // k2/n2/minX/minY/invW/invH/cellStart/cellItems describe the key frame's camera
+  const uint32_t* desc;          // mDescriptors rows of that camera
+  const float* uRight;           // mvuRight or nullptr
+  const float* invSigma2;        // mvInvLevelSigma2
+  const orbx_fuse_point* pts;
+  int npts;
+  int* bestIdx;                  // npts
+  int* bestDist;                 // npts
+  int* result;                   // [0] = nFused
+};
+hipError_t launch_fuse_search(const FuseArgs& a, hipStream_t s);
+
+
 // Stereo-fisheye resolve: one wave walks the points, left then right camera, with the partner-slot assignments.
 struct ProjFeArgs {
   const int *offL, *idxL, *distL;   // candidate lists against the left / right grid (k_proj_cands)

@@ -122,6 +122,63 @@ def search_for_triangulation_py(fv1, k1, d1, mp1, ur1, fv2, k2, d2, mp2, ur2, sf
     return nmatches, matches12
 
 
+def fuse_search_py(kps, desc, ur, bounds, inv_sigma2, pts):
+    """ORBmatcher::Fuse, src/ORBmatcher.cc:1195-1256 (+ KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:705-749)."""
+    grid = Grid(kps, bounds)
+    best_idx = np.full(len(pts), -1, np.int32)
+    best_dist = np.full(len(pts), 256, np.int32)
+    nfused = 0
+    for i in range(len(pts)):
+        p = pts[i]
+        if not p["valid"]:
+            continue
+        lvl = int(p["predicted_level"])
+        cand = grid.area(p["u"], p["v"], p["radius"], -1, -1)
+        if not cand:
+            continue
+        b, bi = 256, -1
+        for idx in cand:
+            kp = kps[idx]
+            if kp["octave"] < lvl - 1 or kp["octave"] > lvl:
+                continue
+            ex, ey = f32(p["u"]) - f32(kp["x"]), f32(p["v"]) - f32(kp["y"])
+            if ur is not None and ur[idx] >= 0:
+                er = f32(p["ur"]) - f32(ur[idx])
+                e2 = ex * ex + ey * ey + er * er
+                if float(e2 * f32(inv_sigma2[kp["octave"]])) > 7.8:
+                    continue
+            else:
+                e2 = ex * ex + ey * ey
+                if float(e2 * f32(inv_sigma2[kp["octave"]])) > 5.99:
+                    continue
+            d = hamming(p["desc"], desc[idx])
+            if d < b:
+                b, bi = d, idx
+        best_dist[i] = b
+        if b <= TH_LOW:
+            best_idx[i] = bi
+            nfused += 1
+    return nfused, best_idx, best_dist
+
+
+def _fuse_points(mod, rng, f, th, noise):
+    """Map points near the key frame's own keypoints (k2: position noise, a level off, flipped descriptor bits) plus the other
+    frame's keypoints (k1: displaced by the stream's motion, mostly rejected by the chi-square gate)."""
+    k1 = np.concatenate([f["k2"], f["k1"][::3]])
+    d1 = np.concatenate([f["d2"], f["d1"][::3]])
+    sf = f["sf"]
+    n = len(k1)
+    pts = np.zeros(n, mod.FP_DTYPE)
+    pts["u"], pts["v"] = k1["x"] + rng.normal(0, noise, n), k1["y"] + rng.normal(0, noise, n)
+    pts["ur"] = pts["u"] - rng.uniform(2, 40, n).astype(np.float32)
+    lvl = np.clip(k1["octave"] + rng.integers(0, 2, n), 0, 7)
+    pts["predicted_level"] = lvl
+    pts["radius"] = (np.float32(th) * sf[lvl]).astype(np.float32)
+    pts["valid"] = rng.random(n) < 0.85
+    pts["desc"] = d1 ^ np.packbits(rng.random((n, 32, 8)) < 0.05, axis=2).reshape(n, 32)
+    return pts
+
+
 # ---- inputs -----------------------------------------------------------------------------------------------------------------
 def _frames(oracle, w, h, nf, stream):
     f0, f1 = synth.mono_frame(w, h, stream, 0), synth.mono_frame(w, h, stream, 2)
@@ -242,6 +299,22 @@ def test_triangulation_epipolar_gate_is_active(oracle, small):
     assert coarse > fine > 30 and wrong < fine // 2
 
 
+@pytest.mark.parametrize("seed,th,stereo", [(7, 3.0, True), (8, 5.0, False)])
+def test_python_fuse_search_matches_oracle(oracle, small, seed, th, stereo):
+    f = small
+    rng = np.random.default_rng(seed)
+    pts = _fuse_points(oracle, rng, f, th, 1.0)
+    k2 = f["k2"]
+    ur = np.where(rng.random(len(k2)) < 0.5, k2["x"] - rng.uniform(2, 40, len(k2)), -1).astype(np.float32) if stereo else None
+    inv = (1.0 / f["sigma2"]).astype(np.float32)
+    e = fuse_search_py(k2, f["d2"], ur, f["bounds"], inv, pts)
+    o = oracle.fuse_search(k2, f["d2"], ur, f["bounds"], inv, pts)
+    assert e[0] == o[0] and np.array_equal(e[1], o[1]) and np.array_equal(e[2], o[2]) and o[0] > 15
+    assert o[0] == (o[1] >= 0).sum() and ((o[2] <= TH_LOW) == (o[1] >= 0)).all()
+    # several map points may fuse into one keypoint (the search keeps no occupancy): the bookkeeping that resolves it is the caller's
+    assert stereo or len(np.unique(o[1][o[1] >= 0])) <= o[0]
+
+
 # ---- GPU: HIP == oracle through the C ABI -----------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def gpu():
@@ -356,3 +429,35 @@ def test_gpu_search_for_triangulation_edges(gpu, oracle, big):
     bad = (fv1[0], fv1[1], np.where(np.arange(len(fv1[2])) == 3, len(f["k1"]), fv1[2]).astype(np.uint32))
     with pytest.raises(orbx.OrbxError):
         m.SearchForTriangulation(bad, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, *common)
+
+
+@pytest.mark.gpu
+def test_gpu_fuse_search(gpu, oracle, big):
+    f = big
+    k2 = f["k2"]
+    inv = (1.0 / f["sigma2"]).astype(np.float32)
+    rng = np.random.default_rng(61)
+    m = orbx.ORBmatcher(0.6, True)
+    for th, noise, stereo, least in [(3.0, 1.0, True, 50), (4.0, 0.7, False, 100), (25.0, 3.0, True, 20), (0.5, 0.2, False, 1)]:
+        pts = _fuse_points(orbx, rng, f, th, noise)
+        ur = np.where(rng.random(len(k2)) < 0.5, k2["x"] - rng.uniform(2, 40, len(k2)), -1).astype(np.float32) if stereo else None
+        n, bi, bd = m.FuseSearch(k2, f["d2"], ur, f["bounds"], inv, pts)
+        on, obi, obd = oracle.fuse_search(k2, f["d2"], ur, f["bounds"], inv, pts)
+        assert on >= least, (th, on)
+        assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    # points outside the image bounds / windows that leave the grid, no points, no keypoints
+    pts = _fuse_points(orbx, rng, f, 3.0, 1.0)
+    pts["u"][::3] = -500
+    pts["v"][1::3] = 5000
+    pts["u"][2::7] = f["w"] - 0.01
+    n, bi, bd = m.FuseSearch(k2, f["d2"], None, f["bounds"], inv, pts)
+    on, obi, obd = oracle.fuse_search(k2, f["d2"], None, f["bounds"], inv, pts)
+    assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    n, bi, bd = m.FuseSearch(k2, f["d2"], None, f["bounds"], inv, pts[:0])
+    assert n == 0 and len(bi) == 0
+    n, bi, bd = m.FuseSearch(k2[:0], f["d2"][:0], None, f["bounds"], inv, pts)
+    assert n == 0 and (bi == -1).all() and (bd == 256).all()
+    bad = k2.copy()
+    bad["octave"][5] = 8
+    with pytest.raises(orbx.OrbxError):
+        m.FuseSearch(bad, f["d2"], None, f["bounds"], inv, pts)
