@@ -97,6 +97,29 @@ cases += [
      lambda: orbx.SearchByBoW(kf_fv, kp, dp, kvalid, f_fv, kc, dc, -1, 0.7, True),
      lambda: O.search_by_bow(kf_fv, dp, kp["angle"], kvalid, f_fv, dc, kc["angle"], -1, 0.7, True)),
 ]
+# round 3: relocalisation search, SearchForTriangulation on the two frames' feature vectors, Fuse's search
+occk = (rng.random(len(kc)) < 0.3).astype(np.uint8)
+hm1, hm2 = (rng.random(n) < 0.25).astype(np.uint8), (rng.random(len(kc)) < 0.25).astype(np.uint8)
+sigma2 = (sf * sf).astype(np.float32)
+F12 = np.array([[1e-6, 2e-6, 0.45], [-2e-6, 1e-6, -0.9], [-0.45, 0.9, 3.0]], np.float32)
+epi = np.array([0.5 * w, 0.45 * h], np.float32)
+fpts = np.zeros(n, orbx.FP_DTYPE)
+fpts["u"], fpts["v"], fpts["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+fpts["predicted_level"] = mps["predicted_level"]
+fpts["radius"] = np.float32(3.0) * sf[mps["predicted_level"]]
+fpts["valid"], fpts["desc"] = mps["in_view"], desc
+inv_sigma2 = (1.0 / sigma2).astype(np.float32)
+cases += [
+    ("SearchByProjection(Cur, KeyFrame, ORBdist) (relocalisation)  %d pts x %d kps" % (n, len(kc)),
+     lambda: m.SearchByProjectionKeyFrame(kc, dc, bounds, pts, occk, 100),
+     lambda: O.search_by_projection_keyframe(kc, dc, bounds, opts, 100, True, occk)),
+    ("SearchForTriangulation(KF1, KF2)  %d x %d kps, %d / %d nodes" % (n, len(kc), len(kf_fv[0]), len(f_fv[0])),
+     lambda: mb.SearchForTriangulation(kf_fv, kp, dp, hm1, None, f_fv, kc, dc, hm2, uR, sf, sigma2, epi, F12),
+     lambda: O.search_for_triangulation(kf_fv, kp, dp, hm1, None, f_fv, kc, dc, hm2, uR, sf, sigma2, epi, F12)),
+    ("Fuse(KF, MapPoints): the search   %d pts x %d kps" % (n, len(kc)),
+     lambda: m.FuseSearch(kc, dc, uR, bounds, inv_sigma2, fpts),
+     lambda: O.fuse_search(kc, dc, uR, bounds, inv_sigma2, fpts.view(O.FP_DTYPE))),
+]
 import gc
 gc.collect()
 gc.disable()  # a generation-2 collection inside a millisecond timing window would dominate it
