@@ -509,9 +509,12 @@ def main():
                                 "frac": round(stages[k]["algorithmic_GBps"] / HBM_PEAK_GBS, 4)}
                 if full and k in pmc and "SQ_INSTS_VALU" in pmc[k]:
                     us = stages[k]["ms_total"] * 1e3 / nprof   # all launches of the stage in one batch
-                    streaming[k]["valu_frac"] = round(pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1)
-                                                      * mix.get(k, {}).get("mean_cycles_per_valu_inst", 4.0)
-                                                      / (N_SIMD * clk * us * 1e-6), 4)
+                    cycles = (pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1)
+                              * mix.get(k, {}).get("mean_cycles_per_valu_inst", 4.0))
+                    if k == "k_resize" and "k_resize_tail" in pmc:   # the stage bracket holds the whole chain: levels 1-4 + the fused tail
+                        cycles += (pmc["k_resize_tail"]["SQ_INSTS_VALU"] * pmc["k_resize_tail"].get("launches_per_batch", 1)
+                                   * mix.get("k_resize_tail", {}).get("mean_cycles_per_valu_inst", 4.0))
+                    streaming[k]["valu_frac"] = round(cycles / (N_SIMD * clk * us * 1e-6), 4)
         out["roofline"]["streaming"] = streaming
         if rank == 0:  # "also report against a measured device-copy peak" -- a 512 MiB device-to-device copy
             try:

@@ -13,6 +13,7 @@ import sys
 def _kname(k):
     """'void orbx::k_detect<false, 52>(orbx::Geom, ...)' -> 'k_detect'"""
     import re
+    k = k.replace("(anonymous namespace)::", "")
     return re.sub(r"<.*$", "", re.sub(r"^void\s+", "", k).split("(")[0].replace("orbx::", ""))
 
 
@@ -27,7 +28,8 @@ def main(db, pat="", out=None):
         n = dict(c.execute("select kernel_name, count(*) from counters_collection where kernel_name like ? and counter_name = "
                            "'SQ_INSTS_VALU' group by 1", ("%" + pat + "%",)).fetchall())
         n = {_kname(k): v for k, v in n.items()}
-        base = min(n.values()) if n else 1
+        steps = [v for k, v in n.items() if k in ("k_detect", "k_describe", "k_octree")]   # one launch per step each (not the clock probe)
+        base = min(steps) if steps else (min(n.values()) if n else 1)
         res = {k: dict({c_: round(v, 1) for c_, v in d.items()}, launches_per_batch=max(1, round(n.get(k, base) / base)))
                for k, d in by.items()}
         res["_note"] = ("per-launch averages of one rocprofv3 --pmc pass over the default bench workload (64 images 1280x720 per "
