@@ -362,6 +362,7 @@ def main():
     prof = {}
     nprof = max(3, min(a.steps, 10))
     if not a.no_profile:
+        collect()   # drop the dominant kernel's events of the clock-probe steps above: the stage table covers nprof steps exactly
         exs[0].profile_enable(True)
         for i in range(nprof):
             wl.step_no = i * len(exs)   # handle 0, ring slot rotates
@@ -508,7 +509,11 @@ def main():
                 streaming[k] = {"algorithmic_GBps": stages[k]["algorithmic_GBps"],
                                 "frac": round(stages[k]["algorithmic_GBps"] / HBM_PEAK_GBS, 4)}
                 if full and k in pmc and "SQ_INSTS_VALU" in pmc[k]:
-                    us = stages[k]["ms_total"] * 1e3 / nprof   # all launches of the stage in one batch
+                    # all launches of the stage in ONE batch: the bracket's average x the launches per batch (the dominant kernel
+                    # is also bracketed during the timed steps, so its ms_total spans more than the nprof stage-pass steps)
+                    nl = pmc[k].get("launches_per_batch", 1) + (pmc.get("k_resize_tail", {}).get("launches_per_batch", 1)
+                                                                  if k == "k_resize" and "k_resize_tail" in pmc else 0)
+                    us = stages[k]["avg_us"] * nl
                     cycles = (pmc[k]["SQ_INSTS_VALU"] * pmc[k].get("launches_per_batch", 1)
                               * mix.get(k, {}).get("mean_cycles_per_valu_inst", 4.0))
                     if k == "k_resize" and "k_resize_tail" in pmc:   # the stage bracket holds the whole chain: levels 1-4 + the fused tail
