@@ -428,7 +428,12 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
  * occupied[i2] != 0 <=> CurrentFrame.mvpMapPoints[i2] != NULL (in/out: on return also set for the new matches and
  * clear again for the ones the rotation-consistency cull removed, :1910-1913).  Best Hamming < 256 by strict first
  * minimum over the free candidates, accepted if <= orb_dist (0..255).  match[i2] = index i of the assigned point or -1.
- * Returns nmatches after the cull, or a negative error. */
+ * Returns nmatches after the cull, or a negative error.
+ * The loop-closing searches SearchByProjection(KeyFrame* pKF, Sim3f& Scw, vpPoints, vpMatched, th, ratioHamming) and its
+ * vpMatchedKF twin (src/ORBmatcher.cc:406-503, :505-612) run the same loop -- occupancy = vpMatched[idx] != NULL, level window
+ * [nPredictedLevel - 1, nPredictedLevel], `bestDist <= TH_LOW * ratioHamming`, no orientation check -- and are served by this
+ * entry with (min_level, max_level) = (nPredictedLevel - 1, nPredictedLevel), check_orientation = 0 and
+ * orb_dist = floor(TH_LOW * ratioHamming) (tests/test_reloc_triangulation.py checks a literal transcription of that loop). */
 int orbx_search_by_projection_keyframe(int device, const orbx_keypoint* kps_un, const uint8_t* desc, int n, float min_x,
                                        float min_y, float max_x, float max_y, const orbx_projected_point* points,
                                        int n_points, int orb_dist, int check_orientation, uint8_t* occupied,
@@ -472,7 +477,9 @@ typedef struct orbx_fuse_point {
  * inv_level_sigma2 = mvInvLevelSigma2.  best_idx[i] = the keypoint point i fuses into (distance <= TH_LOW) or -1; best_dist[i]
  * (optional) = the minimum over the gated candidates, 256 if there were none.  The Replace / AddObservation / AddMapPoint
  * bookkeeping of a hit (:1259-1271) does not feed back into the search and stays with the caller, in point order.
- * Returns nFused or a negative error. */
+ * Returns nFused or a negative error.
+ * Fuse(KeyFrame* pKF, Sim3f& Scw, vpPoints, th, vpReplacePoint) of loop closing (:1279-1390) runs the same search without the
+ * chi-square gate: pass inv_level_sigma2 = 0 for every level (e2 * 0 > 5.99 never holds). */
 int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, const float* u_right, int n, float min_x,
                      float min_y, float max_x, float max_y, const float* inv_level_sigma2, int nlevels,
                      const orbx_fuse_point* points, int n_points, int32_t* best_idx, int32_t* best_dist);

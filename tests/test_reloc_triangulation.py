@@ -179,6 +179,36 @@ def _fuse_points(mod, rng, f, th, noise):
     return pts
 
 
+def search_by_projection_sim3_py(kps, desc, bounds, pts, pred_level, ratio_hamming, matched):
+    """The loop-closing SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming), src/ORBmatcher.cc:406-503, from the
+    window search on (:464-499): KeyFrame::GetFeaturesInArea without levels, `if (vpMatched[idx]) continue`, the level window
+    [nPredictedLevel - 1, nPredictedLevel] inside the loop, `bestDist <= TH_LOW * ratioHamming` (float), no orientation check."""
+    grid = Grid(kps, bounds)
+    vp = [-2 if o else -1 for o in matched]
+    nmatches = 0
+    for i in range(len(pts)):
+        p = pts[i]
+        if not p["valid"]:
+            continue
+        cand = grid.area(p["u"], p["v"], p["radius"], -1, -1)
+        if not cand:
+            continue
+        best, best_idx = 256, -1
+        for idx in cand:
+            if vp[idx] != -1:
+                continue
+            lvl = kps["octave"][idx]
+            if lvl < pred_level[i] - 1 or lvl > pred_level[i]:
+                continue
+            d = hamming(p["desc"], desc[idx])
+            if d < best:
+                best, best_idx = d, idx
+        if f32(best) <= f32(TH_LOW) * f32(ratio_hamming):
+            vp[best_idx] = i
+            nmatches += 1
+    return nmatches, np.array([m if m >= 0 else -1 for m in vp], np.int32), np.array([m != -1 for m in vp], np.uint8)
+
+
 # ---- inputs -----------------------------------------------------------------------------------------------------------------
 def _frames(oracle, w, h, nf, stream):
     f0, f1 = synth.mono_frame(w, h, stream, 0), synth.mono_frame(w, h, stream, 2)
@@ -315,6 +345,32 @@ def test_python_fuse_search_matches_oracle(oracle, small, seed, th, stereo):
     assert stereo or len(np.unique(o[1][o[1] >= 0])) <= o[0]
 
 
+@pytest.mark.parametrize("seed,ratio", [(9, 1.0), (10, 0.75)])
+def test_loop_closing_flavours_are_served_by_the_same_entries(oracle, small, seed, ratio):
+    """SearchByProjection(pKF, Scw, vpPoints, vpMatched, th, ratioHamming) (src/ORBmatcher.cc:406-503; its vpMatchedKF twin :505-612
+    has the same loop) is the relocalisation entry with levels (nPredictedLevel - 1, nPredictedLevel), no orientation check and
+    ORBdist = floor(TH_LOW * ratioHamming); Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1279-1390) is the Fuse search without
+    the chi-square gate (inv_level_sigma2 = 0).  Checked here on the oracle against literal transcriptions of those loops."""
+    f = small
+    rng = np.random.default_rng(seed)
+    pts = _kf_points(oracle, rng, f, 4.0)
+    pred = np.asarray(pts["max_level"] - 1)                   # _kf_points stores (lvl - 1, lvl + 1)
+    pts["max_level"] = pred                                   # -> the window [pred - 1, pred]
+    occ = (rng.random(len(f["k2"])) < 0.2).astype(np.uint8)   # vpMatched[idx] != NULL
+    e = search_by_projection_sim3_py(f["k2"], f["d2"], f["bounds"], pts, pred, ratio, occ)
+    o = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, int(np.floor(np.float32(TH_LOW) * np.float32(ratio))),
+                                             False, occ)
+    assert e[0] == o[0] and np.array_equal(e[1], o[1]) and np.array_equal(e[2], o[2]) and o[0] > 10
+    fp = _fuse_points(oracle, rng, f, 4.0, 2.5)
+    zero = np.zeros(8, np.float32)
+    inv = (1.0 / f["sigma2"]).astype(np.float32)
+    a = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], zero, fp)
+    b = fuse_search_py(f["k2"], f["d2"], None, f["bounds"], zero, fp)
+    g = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], inv, fp)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[0] > g[0] > 10                                   # the gate was really switched off
+
+
 # ---- GPU: HIP == oracle through the C ABI -----------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def gpu():
@@ -341,6 +397,12 @@ def test_gpu_search_by_projection_keyframe(gpu, oracle, big):
         onm, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, orb_dist, ori, occ)
         assert onm >= least
         assert nm == onm and np.array_equal(match, omatch) and np.array_equal(o2, oocc)
+    # the loop-closing usage: window [pred - 1, pred], no orientation check, ORBdist = floor(TH_LOW * ratioHamming)
+    pts = _kf_points(orbx, rng, f, 4.0)
+    pts["max_level"] = pts["max_level"] - 1
+    nm, match, o2 = orbx.ORBmatcher(0.9, False).SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts, occ, 37)
+    onm, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 37, False, occ)
+    assert nm == onm > 50 and np.array_equal(match, omatch) and np.array_equal(o2, oocc)
     m = orbx.ORBmatcher(0.9, True)
     nm, match, o2 = m.SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts[:0], occ, 100)
     assert nm == 0 and (match == -1).all() and np.array_equal(o2, occ)
@@ -445,6 +507,12 @@ def test_gpu_fuse_search(gpu, oracle, big):
         on, obi, obd = oracle.fuse_search(k2, f["d2"], ur, f["bounds"], inv, pts)
         assert on >= least, (th, on)
         assert n == on and np.array_equal(bi, obi) and np.array_equal(bd, obd)
+    # Fuse(pKF, Scw, ...) of loop closing: the same search without the chi-square gate
+    pts = _fuse_points(orbx, rng, f, 4.0, 2.5)
+    zero = np.zeros(8, np.float32)
+    n, bi, bd = m.FuseSearch(k2, f["d2"], None, f["bounds"], zero, pts)
+    on, obi, obd = oracle.fuse_search(k2, f["d2"], None, f["bounds"], zero, pts)
+    assert n == on > 100 and np.array_equal(bi, obi) and np.array_equal(bd, obd)
     # points outside the image bounds / windows that leave the grid, no points, no keypoints
     pts = _fuse_points(orbx, rng, f, 3.0, 1.0)
     pts["u"][::3] = -500
