@@ -457,6 +457,18 @@ int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const i
                                   const float* level_sigma2_2, int nlevels2, const float ep[2], const float F12[9], int only_stereo,
                                   int coarse, int check_orientation, int32_t* matches12);
 
+/* Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884;
+ * LoopClosing).  *_1 / *_2 = pKF1 / pKF2: mFeatVec as CSR, mvKeysUn (the angle is read), mDescriptors and valid[i] =
+ * (vpMapPoints[i] && !vpMapPoints[i]->isBad() && !(NLeft != -1 && i >= mvKeysUn.size())) (:799-806,:817-825).  matches12[idx1] =
+ * the feature of pKF2 whose map point vpMatches12[idx1] receives, or -1: per vocabulary node, pKF1's features in list order, best
+ * and second best over the partner node's features that are valid and not taken yet (vbMatched2), accepted if bestDist1 < TH_LOW
+ * (strict) and bestDist1 < nnratio * bestDist2; then the rotation-consistency cull.  Returns nmatches or a negative error. */
+int orbx_search_by_bow_keyframes(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                 int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* valid1, int n1,
+                                 const uint32_t* node_ids2, const int32_t* node_start2, const uint32_t* feature_idx2, int n_nodes2,
+                                 const orbx_keypoint* kps2, const uint8_t* desc2, const uint8_t* valid2, int n2, float nnratio,
+                                 int check_orientation, int32_t* matches12);
+
 /* One map point of ORBmatcher::Fuse after the reference's projection and gates (src/ORBmatcher.cc:1141-1192: not bad, not already
  * in the key frame, positive depth, inside the image, distance inside the scale-invariance range, viewing angle below 60 degrees):
  * uv, ur = u - mbf * invz, radius = th * mvScaleFactors[nPredictedLevel], nPredictedLevel, GetDescriptor().  valid = 0 for the
@@ -474,15 +486,19 @@ typedef struct orbx_fuse_point {
  * monocular, 7.8 with mvuRight[idx] >= 0; float arithmetic as :1217-1237) and the first strict minimum of the descriptor distance
  * (:1195-1256).  kps / desc / u_right = the camera searched: mvKeysUn + mvuRight, or mvKeys / mvKeysRight of a two-camera rig
  * with u_right = NULL (the caller adds NLeft to the indices of the right camera, :1239); bounds = mnMinX .. mnMaxY;
- * inv_level_sigma2 = mvInvLevelSigma2.  best_idx[i] = the keypoint point i fuses into (distance <= TH_LOW) or -1; best_dist[i]
+ * inv_level_sigma2 = mvInvLevelSigma2; max_dist = TH_LOW (50).  best_idx[i] = the keypoint point i fuses into (distance <=
+ * max_dist) or -1; best_dist[i]
  * (optional) = the minimum over the gated candidates, 256 if there were none.  The Replace / AddObservation / AddMapPoint
  * bookkeeping of a hit (:1259-1271) does not feed back into the search and stays with the caller, in point order.
  * Returns nFused or a negative error.
  * Fuse(KeyFrame* pKF, Sim3f& Scw, vpPoints, th, vpReplacePoint) of loop closing (:1279-1390) runs the same search without the
- * chi-square gate: pass inv_level_sigma2 = 0 for every level (e2 * 0 > 5.99 never holds). */
+ * chi-square gate: pass inv_level_sigma2 = 0 for every level (e2 * 0 > 5.99 never holds).
+ * ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, S12, th) (:1392-1592) is two such searches -- pKF1's map points in pKF2
+ * (:1437-1497) and pKF2's in pKF1 (:1499-1567), no chi-square gate, max_dist = TH_HIGH (100) -- followed by the agreement
+ * check vnMatch2[vnMatch1[i1]] == i1 (:1569-1583) on the caller's side (ORB_SLAM3::SearchBySim3 in csrc/ORBmatcher.h). */
 int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, const float* u_right, int n, float min_x,
                      float min_y, float max_x, float max_y, const float* inv_level_sigma2, int nlevels,
-                     const orbx_fuse_point* points, int n_points, int32_t* best_idx, int32_t* best_dist);
+                     const orbx_fuse_point* points, int n_points, int max_dist, int32_t* best_idx, int32_t* best_dist);
 
 /* Stereo-fisheye frames (F.Nleft != -1): the frame holds N = n_left + n_right keypoints (mvKeys then mvKeysRight), one
  * descriptor row each in the same order, mGrid over the left and mGridRight over the right keypoints, and the stereo

@@ -575,7 +575,7 @@ FP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"
 assert FP_DTYPE.itemsize == 56
 
 
-def fuse_search(k, desc, uright, bounds, inv_level_sigma2, pts):
+def fuse_search(k, desc, uright, bounds, inv_level_sigma2, pts, max_dist=50):
     """Search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight), src/ORBmatcher.cc:1195-1256 -> (nFused, bestIdx, bestDist)."""
     k = np.ascontiguousarray(k)
     desc = _u8(desc)
@@ -584,5 +584,18 @@ def fuse_search(k, desc, uright, bounds, inv_level_sigma2, pts):
     isg = np.ascontiguousarray(inv_level_sigma2, np.float32)
     bi, bd = np.zeros(len(pts), np.int32), np.zeros(len(pts), np.int32)
     n = lib().oro_fuse_search(_p(k), _p(desc), None if ur is None else _p(ur), len(k), C.c_float(bounds[0]), C.c_float(bounds[1]),
-                              C.c_float(bounds[2]), C.c_float(bounds[3]), _p(isg), len(isg), _p(pts), len(pts), _p(bi), _p(bd))
+                              C.c_float(bounds[2]), C.c_float(bounds[3]), _p(isg), len(isg), _p(pts), len(pts), int(max_dist), _p(bi), _p(bd))
     return n, bi, bd
+
+
+def search_by_bow_keyframes(fv1, d1, angle1, valid1, fv2, d2, angle2, valid2, nnratio=0.75, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12), src/ORBmatcher.cc:766-884 -> (nmatches, matches12[n1])."""
+    n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+    n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+    d1, d2 = _u8(d1), _u8(d2)
+    a1, a2 = np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(angle2, np.float32)
+    v1, v2 = np.ascontiguousarray(valid1, np.uint8), np.ascontiguousarray(valid2, np.uint8)
+    m = np.zeros(len(d1), np.int32)
+    n = lib().oro_search_by_bow_keyframes(_p(n1n), len(n1n), _p(s1), _p(f1), _p(d1), _p(a1), _p(v1), len(d1), _p(n2n), len(n2n), _p(s2),
+                                          _p(f2), _p(d2), _p(a2), _p(v2), len(d2), C.c_float(nnratio), int(check_ori), _p(m))
+    return n, m

@@ -1657,9 +1657,8 @@ int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vec
 // of the loop body (:1195-1256) -- KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:705-749: the frame grid without a level filter),
 // the level window, the chi-square gate on the reprojection error and the first strict minimum of the descriptor distance.
 int fuse_search(const std::vector<KeyPoint>& kps, const uint8_t* desc, const float* uRight, const FrameGrid& grid,
-                const std::vector<float>& invLevelSigma2, const std::vector<FusePoint>& pts, std::vector<int>& bestIdxOut,
-                std::vector<int>& bestDistOut) {
-  const int TH_LOW = 50;
+                const std::vector<float>& invLevelSigma2, const std::vector<FusePoint>& pts, int maxDist,
+                std::vector<int>& bestIdxOut, std::vector<int>& bestDistOut) {
   int nFused = 0;
   bestIdxOut.assign(pts.size(), -1);
   bestDistOut.assign(pts.size(), 256);
@@ -1690,12 +1689,79 @@ int fuse_search(const std::vector<KeyPoint>& kps, const uint8_t* desc, const flo
       if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
     }
     bestDistOut[i] = bestDist;
-    if (bestDist <= TH_LOW) {
+    if (bestDist <= maxDist) {  // TH_LOW (Fuse, :1258,1357), TH_HIGH (SearchBySim3, :1494,1564)
       bestIdxOut[i] = bestIdx;
       nFused++;
     }
   }
   return nFused;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:766-884.
+int search_by_bow_keyframes(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                            const uint8_t* d1, const float* angle1, const uint8_t* valid1, int n1, const std::vector<uint32_t>& nodes2,
+                            const std::vector<int>& start2, const std::vector<uint32_t>& feat2, const uint8_t* d2, const float* angle2,
+                            const uint8_t* valid2, int n2, float nnratio, bool checkOri, std::vector<int>& vMatches12) {
+  const int HISTO = 30, TH_LOW = 50;
+  vMatches12.assign(n1, -1);
+  std::vector<bool> vbMatched2(n2, false);
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  int nmatches = 0;
+  size_t f1 = 0, f2 = 0;
+  while (f1 < nodes1.size() && f2 < nodes2.size()) {
+    if (nodes1[f1] == nodes2[f2]) {
+      for (int i1 = start1[f1]; i1 < start1[f1 + 1]; i1++) {
+        const size_t idx1 = feat1[i1];
+        if (!valid1[idx1]) continue;  // :799-806
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int i2 = start2[f2]; i2 < start2[f2 + 1]; i2++) {
+          const size_t idx2 = feat2[i2];
+          if (vbMatched2[idx2] || !valid2[idx2]) continue;  // :817-825
+          const int dist = descriptor_distance(d1 + idx1 * 32, d2 + idx2 * 32);
+          if (dist < bestDist1) {
+            bestDist2 = bestDist1;
+            bestDist1 = dist;
+            bestIdx2 = (int)idx2;
+          } else if (dist < bestDist2) {
+            bestDist2 = dist;
+          }
+        }
+        if (bestDist1 < TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            vMatches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = true;
+            if (checkOri) {
+              float rot = angle1[idx1] - angle2[bestIdx2];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)std::round(rot * factor);
+              if (bin == HISTO) bin = 0;
+              rotHist[bin].push_back((int)idx1);
+            }
+            nmatches++;
+          }
+        }
+      }
+      f1++;
+      f2++;
+    } else if (nodes1[f1] < nodes2[f2]) {
+      f1 = std::lower_bound(nodes1.begin(), nodes1.end(), nodes2[f2]) - nodes1.begin();
+    } else {
+      f2 = std::lower_bound(nodes2.begin(), nodes2.end(), nodes1[f1]) - nodes2.begin();
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        vMatches12[idx] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
 }
 
 // ---- stereo-fisheye branches ------------------------------------------------------------------------------------------------

@@ -241,11 +241,18 @@ int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vec
                              const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, const float ep[2],
                              const float F12[9], bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12);
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884).  valid =
+// the feature holds a good map point (and lies below mvKeysUn.size() for two-camera rigs); vMatches12[idx1] = idx2 or -1.
+int search_by_bow_keyframes(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                            const uint8_t* d1, const float* angle1, const uint8_t* valid1, int n1, const std::vector<uint32_t>& nodes2,
+                            const std::vector<int>& start2, const std::vector<uint32_t>& feat2, const uint8_t* d2, const float* angle2,
+                            const uint8_t* valid2, int n2, float nnratio, bool checkOri, std::vector<int>& vMatches12);
+
 // ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th, bRight) (src/ORBmatcher.cc:1108-1277): the per-point
 // search (:1195-1256).  FusePoint = a map point after the caller's projection and gates (:1141-1192): valid, uv, ur = u - bf * invz,
 // radius = th * mvScaleFactors[nPredictedLevel], nPredictedLevel, GetDescriptor().  kps / desc / uRight = the camera searched
 // (mvKeysUn + mvuRight; mvKeys or mvKeysRight of a two-camera rig).  bestIdx[i] = the keypoint point i fuses into (bestDist <=
-// TH_LOW) or -1; bestDist[i] = the minimum over the gated candidates (256: none).  Returns nFused (:1262: counted for every hit).
+// maxDist = TH_LOW) or -1; bestDist[i] = the minimum over the gated candidates (256: none).  Returns nFused (:1262: counted for every hit).
 // The map-point bookkeeping that follows a hit (Replace / AddObservation / AddMapPoint, :1259-1271) does not feed back into the
 // search and stays with the caller.
 struct FusePoint {
@@ -256,8 +263,8 @@ struct FusePoint {
 };
 static_assert(sizeof(FusePoint) == 56, "POD layout shared with orbx_fuse_point");
 int fuse_search(const std::vector<KeyPoint>& kps, const uint8_t* desc, const float* uRight, const FrameGrid& grid,
-                const std::vector<float>& invLevelSigma2, const std::vector<FusePoint>& pts, std::vector<int>& bestIdx,
-                std::vector<int>& bestDist);
+                const std::vector<float>& invLevelSigma2, const std::vector<FusePoint>& pts, int maxDist,
+                std::vector<int>& bestIdx, std::vector<int>& bestDist);
 
 // ---- stereo-fisheye (F.Nleft != -1) branches of the two SearchByProjection matchers ---------------------------------------
 // The frame holds N = nLeft + nRight keypoints (mvKeys then mvKeysRight), descriptors in the same order, two grids

@@ -469,17 +469,29 @@ int oro_search_for_triangulation(const uint32_t* nodes1, int nNodes1, const int*
 }
 
 int oro_fuse_search(const KeyPoint* k, const uint8_t* desc, const float* uRight, int n, float minX, float minY, float maxX, float maxY,
-                    const float* invSigma2, int nLevels, const FusePoint* pts, int npts, int* bestIdx, int* bestDist) {
+                    const float* invSigma2, int nLevels, const FusePoint* pts, int npts, int maxDist, int* bestIdx, int* bestDist) {
   std::vector<KeyPoint> a(k, k + n);
   FrameGrid g;
   g.build(a, minX, minY, maxX, maxY);
   std::vector<FusePoint> p(pts, pts + npts);
   std::vector<float> is(invSigma2, invSigma2 + nLevels);
   std::vector<int> bi, bd;
-  const int nf = fuse_search(a, desc, uRight, g, is, p, bi, bd);
+  const int nf = fuse_search(a, desc, uRight, g, is, p, maxDist, bi, bd);
   std::copy(bi.begin(), bi.end(), bestIdx);
   std::copy(bd.begin(), bd.end(), bestDist);
   return nf;
+}
+
+int oro_search_by_bow_keyframes(const uint32_t* nodes1, int nNodes1, const int* start1, const uint32_t* feat1, const uint8_t* d1,
+                                const float* angle1, const uint8_t* valid1, int n1, const uint32_t* nodes2, int nNodes2,
+                                const int* start2, const uint32_t* feat2, const uint8_t* d2, const float* angle2, const uint8_t* valid2,
+                                int n2, float nnratio, int checkOri, int* matches12) {
+  std::vector<uint32_t> a(nodes1, nodes1 + nNodes1), af(feat1, feat1 + start1[nNodes1]);
+  std::vector<uint32_t> b(nodes2, nodes2 + nNodes2), bf(feat2, feat2 + start2[nNodes2]);
+  std::vector<int> as(start1, start1 + nNodes1 + 1), bs(start2, start2 + nNodes2 + 1), m;
+  const int n = search_by_bow_keyframes(a, as, af, d1, angle1, valid1, n1, b, bs, bf, d2, angle2, valid2, n2, nnratio, checkOri != 0, m);
+  std::copy(m.begin(), m.end(), matches12);
+  return n;
 }
 
 }  // extern "C"

@@ -111,6 +111,26 @@ int main() {
                                            uRv.data(), eL.t.scale, eL.t.sigma2, epi, F12, false, false, true, tri12) +
                   search_for_triangulation(n1, s1, f1, kL, dL.data(), hm1.data(), nullptr, n2, s2, f2, kR, dR.data(), hm2.data(),
                                            nullptr, eL.t.scale, eL.t.sigma2, epi, F12, false, true, true, tri12);
+  // SearchByBoW(KeyFrame*, KeyFrame*) and the Fuse / SearchBySim3 search on the same feature vectors / points
+  std::vector<float> angL(kL.size()), angR(kR.size());
+  for (size_t i = 0; i < kL.size(); i++) angL[i] = kL[i].angle;
+  for (size_t i = 0; i < kR.size(); i++) angR[i] = kR[i].angle;
+  std::vector<uint8_t> good1(kL.size(), 1), good2(kR.size(), 1);
+  for (size_t i = 0; i < good1.size(); i += 6) good1[i] = 0;
+  for (size_t i = 2; i < good2.size(); i += 6) good2[i] = 0;
+  std::vector<int> bow12;
+  const int np7 = search_by_bow_keyframes(n1, s1, f1, dL.data(), angL.data(), good1.data(), (int)kL.size(), n2, s2, f2, dR.data(),
+                                          angR.data(), good2.data(), (int)kR.size(), 0.75f, true, bow12);
+  std::vector<FusePoint> fps(kL.size());
+  for (size_t i = 0; i < kL.size(); i++) {
+    FusePoint& p = fps[i];
+    p.u = kL[i].x + 0.5f; p.v = kL[i].y - 0.5f; p.ur = p.u - 8.f; p.predicted_level = kL[i].octave;
+    p.radius = 3.f * eL.t.scale[kL[i].octave]; p.valid = (i % 7) != 0; p.pad_[0] = p.pad_[1] = p.pad_[2] = 0;
+    for (int b = 0; b < 32; b++) p.desc[b] = dL[i * 32 + b];
+  }
+  std::vector<int> fbi, fbd;
+  const int np8 = fuse_search(kR, dR.data(), uRv.data(), g, eL.t.inv_sigma2, fps, 50, fbi, fbd) +
+                  fuse_search(kR, dR.data(), nullptr, g, std::vector<float>(8, 0.f), fps, 100, fbi, fbd);
   // stereo-fisheye flavours on the concatenated frame
   std::vector<KeyPoint> kk(kR);
   kk.insert(kk.end(), kL.begin(), kL.end());
@@ -200,6 +220,6 @@ int main() {
                             (int)(kL.size() + kR.size()), (int)kL.size(), 0.7f, true, bm);
   }
   std::printf("ok %d %d %zu %zu stereo %d knn %d init %d proj %d %d fe %d %d fisheye %d/%d un %.2f b %.1f g %d\n", mL, mR, kL.size(),
-              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow + np5 + np6);
+              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow + np5 + np6 + np7 + np8);
   return 0;
 }

@@ -125,7 +125,8 @@ def lib():
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
-        L.orbx_fuse_search.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, vp, vp]
+        L.orbx_search_by_bow_keyframes.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, f, i, vp]
+        L.orbx_fuse_search.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, i, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
         L.orbx_comm_unique_id.argtypes = [vp]
         L.orbx_comm_create.argtypes = [vp, i, i, i, C.POINTER(vp)]
@@ -691,6 +692,21 @@ def SearchByBoW(kf_fv, kf_kps, kf_desc, kf_valid, f_fv, f_kps, f_desc, n_left_f=
     return n, match
 
 
+def SearchByBoWKeyFrames(fv1, kps1, desc1, valid1, fv2, kps2, desc2, valid2, nnratio=0.75, check_ori=True, device=0):
+    """ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) (src/ORBmatcher.cc:766-884) ->
+    (nmatches, matches12[n1] = feature of pKF2 or -1)."""
+    n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+    n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+    k1, k2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+    d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+    v1, v2 = np.ascontiguousarray(valid1, np.uint8), np.ascontiguousarray(valid2, np.uint8)
+    m = np.full(len(k1), -1, np.int32)
+    n = _check(lib().orbx_search_by_bow_keyframes(device, _p(n1n), _p(s1), _p(f1), len(n1n), _p(k1), _p(d1), _p(v1), len(k1), _p(n2n),
+                                                  _p(s2), _p(f2), len(n2n), _p(k2), _p(d2), _p(v2), len(k2), float(nnratio),
+                                                  int(bool(check_ori)), _p(m)))
+    return n, m
+
+
 def UndistortKeyPoints(kps, K, dist, device=0):
     """Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys; K = (fx, fy, cx, cy), dist = mDistCoef."""
     k = np.ascontiguousarray(kps, KP_DTYPE)
@@ -788,7 +804,7 @@ class ORBmatcher:
             int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
 
-    def FuseSearch(self, kps, desc, uRight, bounds, invLevelSigma2, points):
+    def FuseSearch(self, kps, desc, uRight, bounds, invLevelSigma2, points, maxDist=TH_LOW):
         """The search of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1195-1256); points: FP_DTYPE records
         of the map points after the caller's projection and gates.  Returns (nFused, bestIdx[n_points] = keypoint index or -1,
         bestDist[n_points])."""
@@ -799,8 +815,22 @@ class ORBmatcher:
         isg = np.ascontiguousarray(invLevelSigma2, np.float32)
         bi, bd = np.full(len(pp), -1, np.int32), np.full(len(pp), 256, np.int32)
         n = _check(lib().orbx_fuse_search(self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1],
-                                          bounds[2], bounds[3], _p(isg), len(isg), _p(pp), len(pp), _p(bi), _p(bd)))
+                                          bounds[2], bounds[3], _p(isg), len(isg), _p(pp), len(pp), int(maxDist), _p(bi), _p(bd)))
         return n, bi, bd
+
+    def SearchBySim3(self, kps1, desc1, bounds1, kps2, desc2, bounds2, points1in2, points2in1):
+        """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1392-1592): pKF1's map points searched in pKF2 and pKF2's in pKF1 (FP_DTYPE
+        records after the caller's Sim3 projections; one record per feature of the key frame they come from), TH_HIGH, no
+        chi-square gate, then the agreement check.  Returns (nFound, vnMatch12[N1] = feature of pKF2 or -1)."""
+        nl1 = int(np.max(np.ascontiguousarray(kps1, KP_DTYPE)["octave"], initial=0)) + 1
+        nl2 = int(np.max(np.ascontiguousarray(kps2, KP_DTYPE)["octave"], initial=0)) + 1
+        _, m1, _ = self.FuseSearch(kps2, desc2, None, bounds2, np.zeros(nl2, np.float32), points1in2, TH_HIGH)
+        _, m2, _ = self.FuseSearch(kps1, desc1, None, bounds1, np.zeros(nl1, np.float32), points2in1, TH_HIGH)
+        i1 = np.arange(len(m1))
+        ok = (m1 >= 0) & (m1 < len(m2))
+        ok[ok] = m2[m1[ok]] == i1[ok]
+        out = np.where(ok, m1, -1).astype(np.int32)
+        return int(ok.sum()), out
 
     def SearchForTriangulation(self, fv1, kps1, desc1, hasMapPoint1, uRight1, fv2, kps2, desc2, hasMapPoint2, uRight2,
                                scaleFactors2, levelSigma2_2, ep, F12, bOnlyStereo=False, bCoarse=False):

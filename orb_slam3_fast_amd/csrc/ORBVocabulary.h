@@ -101,6 +101,39 @@ inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVecKF, const std::vector
   return n;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884; LoopClosing)
+// on plain views: hasGoodMapPoint[i] = vpMapPoints[i] && !isBad() (&& i < mvKeysUn.size() for two-camera rigs);
+// vnMatches12[idx1] = the feature of pKF2 whose map point vpMatches12[idx1] receives (-1: none).
+inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVec1, const std::vector<ocv::KeyPoint>& vKeysUn1, const uint8_t* Descriptors1,
+                       const std::vector<uint8_t>& hasGoodMapPoint1, const DBoW2::FeatureVector& vFeatVec2,
+                       const std::vector<ocv::KeyPoint>& vKeysUn2, const uint8_t* Descriptors2,
+                       const std::vector<uint8_t>& hasGoodMapPoint2, float mfNNratio, bool mbCheckOrientation,
+                       std::vector<int>& vnMatches12, int device = 0) {
+  auto flatten = [](const DBoW2::FeatureVector& fv, std::vector<uint32_t>& nodes, std::vector<int32_t>& start,
+                    std::vector<uint32_t>& feats) {
+    start.assign(1, 0);
+    for (const auto& e : fv) {
+      nodes.push_back(e.first);
+      feats.insert(feats.end(), e.second.begin(), e.second.end());
+      start.push_back((int32_t)feats.size());
+    }
+  };
+  std::vector<uint32_t> n1, f1, n2, f2;
+  std::vector<int32_t> s1, s2;
+  flatten(vFeatVec1, n1, s1, f1);
+  flatten(vFeatVec2, n2, s2, f2);
+  if (hasGoodMapPoint1.size() != vKeysUn1.size() || hasGoodMapPoint2.size() != vKeysUn2.size())
+    throw std::invalid_argument("SearchByBoW: one map-point flag per keypoint");
+  vnMatches12.assign(vKeysUn1.size(), -1);
+  const int n = orbx_search_by_bow_keyframes(
+      device, n1.data(), s1.data(), f1.data(), (int)n1.size(), reinterpret_cast<const orbx_keypoint*>(vKeysUn1.data()), Descriptors1,
+      hasGoodMapPoint1.data(), (int)vKeysUn1.size(), n2.data(), s2.data(), f2.data(), (int)n2.size(),
+      reinterpret_cast<const orbx_keypoint*>(vKeysUn2.data()), Descriptors2, hasGoodMapPoint2.data(), (int)vKeysUn2.size(), mfNNratio,
+      mbCheckOrientation ? 1 : 0, vnMatches12.data());
+  if (n < 0) throw std::runtime_error(std::string("SearchByBoW: ") + orbx_last_error());
+  return n;
+}
+
 // The members of a KeyFrame that ORBmatcher::SearchForTriangulation reads (single-camera key frames: mpCamera2 == NULL,
 // NLeft == -1): mFeatVec, mvKeysUn, mDescriptors (N x 32, continuous), hasMapPoint[i] = (GetMapPoint(i) != NULL), mvuRight (empty:
 // no stereo observations), mvScaleFactors, mvLevelSigma2.

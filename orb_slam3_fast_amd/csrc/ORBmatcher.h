@@ -11,6 +11,7 @@
 #ifndef ORBX_SHIM_ORBMATCHER_H
 #define ORBX_SHIM_ORBMATCHER_H
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -141,9 +142,45 @@ class ORBmatcher {
     bestIdx.assign(vpMapPoints.size(), -1);
     const int n = orbx_fuse_search(device_, reinterpret_cast<const orbx_keypoint*>(KF.mvKeysUn), KF.mDescriptors, KF.mvuRight, KF.N,
                                    KF.mnMinX, KF.mnMinY, KF.mnMaxX, KF.mnMaxY, mvInvLevelSigma2.data(), (int)mvInvLevelSigma2.size(),
-                                   vpMapPoints.data(), (int)vpMapPoints.size(), bestIdx.data(), nullptr);
+                                   vpMapPoints.data(), (int)vpMapPoints.size(), TH_LOW, bestIdx.data(), nullptr);
     if (n < 0) throw std::runtime_error(std::string("Fuse: ") + orbx_last_error());
     return n;
+  }
+
+  // SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const Sim3f& S12, th), src/ORBmatcher.cc:1392-1592
+  // (LoopClosing): two Fuse-type searches without the chi-square gate and with TH_HIGH -- pKF1's map points in pKF2 (:1437-1497),
+  // pKF2's in pKF1 (:1499-1567) -- and the agreement check (:1569-1583).  points1in2[i1] = map point i1 of pKF1 after the caller's
+  // Sim3 projection into pKF2 and its gates (valid = 0 for !pMP, vbAlreadyMatched1[i1], isBad(), negative depth, outside the image,
+  // distance outside the invariance range); points2in1 likewise.  vnMatch12[i1] = the feature of pKF2 whose map point
+  // vpMatches12[i1] receives, or -1.  Returns nFound.
+  int SearchBySim3(const FrameView& KF1, const FrameView& KF2, const std::vector<orbx_fuse_point>& points1in2,
+                   const std::vector<orbx_fuse_point>& points2in1, std::vector<int>& vnMatch12) {
+    auto levels = [](const FrameView& KF) {
+      int m = 0;
+      for (int i = 0; i < KF.N; i++) m = std::max(m, KF.mvKeysUn[i].octave);
+      return m + 1;
+    };
+    auto search = [&](const FrameView& KF, const std::vector<orbx_fuse_point>& pts, std::vector<int>& best) {
+      const std::vector<float> noGate((size_t)levels(KF), 0.0f);
+      best.assign(pts.size(), -1);
+      const int n = orbx_fuse_search(device_, reinterpret_cast<const orbx_keypoint*>(KF.mvKeysUn), KF.mDescriptors, nullptr, KF.N, KF.mnMinX,
+                                     KF.mnMinY, KF.mnMaxX, KF.mnMaxY, noGate.data(), (int)noGate.size(), pts.data(), (int)pts.size(),
+                                     TH_HIGH, best.data(), nullptr);
+      if (n < 0) throw std::runtime_error(std::string("SearchBySim3: ") + orbx_last_error());
+    };
+    std::vector<int> vnMatch1, vnMatch2;
+    search(KF2, points1in2, vnMatch1);
+    search(KF1, points2in1, vnMatch2);
+    vnMatch12.assign(points1in2.size(), -1);
+    int nFound = 0;
+    for (size_t i1 = 0; i1 < vnMatch1.size(); i1++) {
+      const int idx2 = vnMatch1[i1];
+      if (idx2 >= 0 && idx2 < (int)vnMatch2.size() && vnMatch2[idx2] == (int)i1) {
+        vnMatch12[i1] = idx2;
+        nFound++;
+      }
+    }
+    return nFound;
   }
 
   // The same two searches for stereo-fisheye frames (F.Nleft != -1, src/ORBmatcher.cc:41-221 / :1594-1806): F holds

