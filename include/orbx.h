@@ -457,6 +457,32 @@ int orbx_search_for_triangulation(int device, const uint32_t* node_ids1, const i
                                   const float* level_sigma2_2, int nlevels2, const float ep[2], const float F12[9], int only_stereo,
                                   int coarse, int check_orientation, int32_t* matches12);
 
+/* The two-camera members ORBmatcher::SearchForTriangulation reads when pKF1->mpCamera2 && pKF2->mpCamera2
+ * (src/ORBmatcher.cc:906-923, 1007-1042): cam[0..3] = the KannalaBrandt8 mvParameters (fx fy cx cy k0..k3) of pKF1->mpCamera,
+ * pKF1->mpCamera2, pKF2->mpCamera, pKF2->mpCamera2; precision = KannalaBrandt8::precision; R[c] / t[c] = rotation (row-major) and
+ * translation of Tll = T1w * Tw2, Tlr = T1w * Twr2, Trl = Tr1w * Tw2, Trr = Tr1w * Twr2.  81 floats. */
+typedef struct orbx_tri_rig {
+  float cam[4][8];
+  float precision;
+  float R[4][9], t[4][3];
+} orbx_tri_rig;
+
+/* ORBmatcher::SearchForTriangulation for two-camera (stereo-fisheye) key frames: kps / desc / has_map_point hold the N = NLeft +
+ * NRight features of each key frame (mvKeys then mvKeysRight, n_left = KeyFrame::NLeft); the epipolar test is
+ * KannalaBrandt8::epipolarConstrain = TriangulateMatches(...) > 0.0001f (src/CameraModels/KannalaBrandt8.cpp:240-250, :341-417)
+ * with (R12, t12, cameras) chosen by the eyes the two features sit in (:1007-1042), sigmaLevel = level_sigma2_1[kp1.octave], unc =
+ * level_sigma2_2[kp2.octave]; there is no epipole gate and bStereo is false for every feature, so only_stereo != 0 matches
+ * nothing (:957-959).  Float arithmetic in the reference's expression order, the 4x4 null vector by a double one-sided Jacobi
+ * instead of Eigen::JacobiSVD<Matrix4f>: accept / reject decisions equal the oracle's unless a gated quantity lies within
+ * rounding noise of its threshold (tolerance parity, like orbx_fisheye_stereo_match).  Returns nmatches or a negative error. */
+int orbx_search_for_triangulation_rig(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                      int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
+                                      int n_left1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,
+                                      const uint32_t* feature_idx2, int n_nodes2, const orbx_keypoint* kps2, const uint8_t* desc2,
+                                      const uint8_t* has_map_point2, int n_left2, int n2, const float* level_sigma2_1,
+                                      const float* level_sigma2_2, int nlevels, const orbx_tri_rig* rig, int only_stereo, int coarse,
+                                      int check_orientation, int32_t* matches12);
+
 /* Replaces ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884;
  * LoopClosing).  *_1 / *_2 = pKF1 / pKF2: mFeatVec as CSR, mvKeysUn (the angle is read), mDescriptors and valid[i] =
  * (vpMapPoints[i] && !vpMapPoints[i]->isBad() && !(NLeft != -1 && i >= mvKeysUn.size())) (:799-806,:817-825).  matches12[idx1] =

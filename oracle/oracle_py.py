@@ -599,3 +599,25 @@ def search_by_bow_keyframes(fv1, d1, angle1, valid1, fv2, d2, angle2, valid2, nn
     n = lib().oro_search_by_bow_keyframes(_p(n1n), len(n1n), _p(s1), _p(f1), _p(d1), _p(a1), _p(v1), len(d1), _p(n2n), len(n2n), _p(s2),
                                           _p(f2), _p(d2), _p(a2), _p(v2), len(d2), C.c_float(nnratio), int(check_ori), _p(m))
     return n, m
+
+
+TRI_RIG_DTYPE = np.dtype([("cam", "<f4", (4, 8)), ("precision", "<f4"), ("R", "<f4", (4, 9)), ("t", "<f4", (4, 3))])
+assert TRI_RIG_DTYPE.itemsize == 4 * (32 + 1 + 36 + 12)
+
+
+def search_for_triangulation_rig(fv1, k1, d1, has_mp1, n_left1, fv2, k2, d2, has_mp2, n_left2, sigma1, sigma2, rig,
+                                 only_stereo=False, coarse=False, check_ori=True):
+    """Two-camera-rig branch of ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:906-923,1007-1064) ->
+    (nmatches, matches12[n1], borderline[n1])."""
+    n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+    n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+    k1, k2 = np.ascontiguousarray(k1), np.ascontiguousarray(k2)
+    d1, d2 = _u8(d1), _u8(d2)
+    h1, h2 = np.ascontiguousarray(has_mp1, np.uint8), np.ascontiguousarray(has_mp2, np.uint8)
+    sg1, sg2 = np.ascontiguousarray(sigma1, np.float32), np.ascontiguousarray(sigma2, np.float32)
+    rig = np.ascontiguousarray(rig, TRI_RIG_DTYPE)
+    m, bl = np.zeros(len(k1), np.int32), np.zeros(len(k1), np.uint8)
+    n = lib().oro_search_for_triangulation_rig(_p(n1n), len(n1n), _p(s1), _p(f1), _p(k1), _p(d1), _p(h1), int(n_left1), len(k1), _p(n2n),
+                                               len(n2n), _p(s2), _p(f2), _p(k2), _p(d2), _p(h2), int(n_left2), len(k2), _p(sg1), _p(sg2),
+                                               len(sg1), _p(rig), int(only_stereo), int(coarse), int(check_ori), _p(m), _p(bl))
+    return n, m, bl

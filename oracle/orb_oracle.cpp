@@ -1697,6 +1697,99 @@ int fuse_search(const std::vector<KeyPoint>& kps, const uint8_t* desc, const flo
   return nFused;
 }
 
+// ORBmatcher::SearchForTriangulation, the two-camera-rig branch (src/ORBmatcher.cc:906-923, 1007-1064).
+int search_for_triangulation_rig(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                                 const std::vector<KeyPoint>& k1, const uint8_t* d1, const uint8_t* hasMP1, int nLeft1,
+                                 const std::vector<uint32_t>& nodes2, const std::vector<int>& start2, const std::vector<uint32_t>& feat2,
+                                 const std::vector<KeyPoint>& k2, const uint8_t* d2, const uint8_t* hasMP2, int nLeft2,
+                                 const std::vector<float>& levelSigma2_1, const std::vector<float>& levelSigma2_2, const TriRig& rig,
+                                 bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12,
+                                 std::vector<uint8_t>* borderline) {
+  const int HISTO = 30, TH_LOW = 50;
+  int nmatches = 0;
+  vMatches12.assign(k1.size(), -1);
+  if (borderline) borderline->assign(k1.size(), 0);
+  std::vector<int> rotHist[HISTO];
+  const float factor = 1.0f / HISTO;
+  KB8 cam[4];
+  for (int c = 0; c < 4; c++) {
+    for (int i = 0; i < 8; i++) cam[c].p[i] = rig.cam[c][i];
+    cam[c].precision = rig.precision;
+  }
+  size_t f1 = 0, f2 = 0;
+  while (f1 < nodes1.size() && f2 < nodes2.size()) {
+    if (nodes1[f1] == nodes2[f2]) {
+      for (int i1 = start1[f1]; i1 < start1[f1 + 1]; i1++) {
+        const size_t idx1 = feat1[i1];
+        if (hasMP1[idx1]) continue;
+        // bStereo1 = (!pKF1->mpCamera2 && ...) is false for a rig: bOnlyStereo skips every feature (:957-959)
+        if (bOnlyStereo) continue;
+        const KeyPoint& kp1 = k1[idx1];
+        const bool bRight1 = (int)idx1 >= nLeft1;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int i2 = start2[f2]; i2 < start2[f2 + 1]; i2++) {
+          const size_t idx2 = feat2[i2];
+          if (hasMP2[idx2]) continue;
+          const int dist = descriptor_distance(d1 + idx1 * 32, d2 + idx2 * 32);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const KeyPoint& kp2 = k2[idx2];
+          const bool bRight2 = (int)idx2 >= nLeft2;
+          // (no epipole gate: `!pKF1->mpCamera2` is false, :997)
+          const int sel = (bRight1 ? 2 : 0) + (bRight2 ? 1 : 0);  // ll, lr, rl, rr (:1008-1041)
+          bool ok = bCoarse;
+          if (!ok) {
+            float P[3], gate[5];
+            const float z = kb8_triangulate_matches(cam[bRight1 ? 1 : 0], cam[bRight2 ? 3 : 2], kp1.x, kp1.y, kp2.x, kp2.y, rig.R[sel],
+                                                    rig.t[sel], levelSigma2_1[kp1.octave], levelSigma2_2[kp2.octave], P, gate);
+            ok = z > 0.0001f;
+            if (borderline) {
+              bool near = std::fabs(gate[0] - 0.9998f) < 1e-5f;
+              if (!std::isnan(gate[1])) near = near || std::fabs(gate[1]) < 1e-3f;
+              if (!std::isnan(gate[2])) near = near || std::fabs(gate[2]) < 1e-3f;
+              if (!std::isnan(gate[3])) near = near || std::fabs(gate[3] - 1.0f) < 1e-2f;
+              if (!std::isnan(gate[4])) near = near || std::fabs(gate[4] - 1.0f) < 1e-2f;
+              if (near) (*borderline)[idx1] = 1;
+            }
+          }
+          if (ok) {
+            bestIdx2 = (int)idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (checkOri) {
+            float rot = kp1.angle - k2[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      f1++;
+      f2++;
+    } else if (nodes1[f1] < nodes2[f2]) {
+      f1 = std::lower_bound(nodes1.begin(), nodes1.end(), nodes2[f2]) - nodes1.begin();
+    } else {
+      f2 = std::lower_bound(nodes2.begin(), nodes2.end(), nodes1[f1]) - nodes2.begin();
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO, ind1, ind2, ind3);
+    for (int b = 0; b < HISTO; b++) {
+      if (b == ind1 || b == ind2 || b == ind3) continue;
+      for (int idx : rotHist[b]) {
+        vMatches12[idx] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 // ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12), src/ORBmatcher.cc:766-884.
 int search_by_bow_keyframes(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
                             const uint8_t* d1, const float* angle1, const uint8_t* valid1, int n1, const std::vector<uint32_t>& nodes2,

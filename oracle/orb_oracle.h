@@ -241,6 +241,26 @@ int search_for_triangulation(const std::vector<uint32_t>& nodes1, const std::vec
                              const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2, const float ep[2],
                              const float F12[9], bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12);
 
+// ORBmatcher::SearchForTriangulation for two-camera rigs (pKF1->mpCamera2 && pKF2->mpCamera2; src/ORBmatcher.cc:906-923,1007-1064):
+// k1 / k2 = mvKeys | mvKeysRight (nLeft = KeyFrame::NLeft), the epipolar test is KannalaBrandt8::epipolarConstrain =
+// TriangulateMatches(...) > 0.0001f (src/CameraModels/KannalaBrandt8.cpp:240-250) with (R12, t12, cameras) picked by which eye each
+// of the two features sits in.  TriRig: cam[0..3] = pKF1->mpCamera, pKF1->mpCamera2, pKF2->mpCamera, pKF2->mpCamera2; R / t [0..3] =
+// Tll = T1w * Tw2, Tlr = T1w * Twr2, Trl = Tr1w * Tw2, Trr = Tr1w * Twr2 (rotation row-major, translation).  FLOAT: tolerance
+// parity like compute_stereo_fisheye_matches; borderline[idx1] (may be null) = some evaluated candidate's gated quantity lies
+// within the tolerance of tests/test_fisheye.py of its threshold.
+struct TriRig {
+  float cam[4][8];
+  float precision;
+  float R[4][9], t[4][3];
+};
+int search_for_triangulation_rig(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,
+                                 const std::vector<KeyPoint>& k1, const uint8_t* d1, const uint8_t* hasMP1, int nLeft1,
+                                 const std::vector<uint32_t>& nodes2, const std::vector<int>& start2, const std::vector<uint32_t>& feat2,
+                                 const std::vector<KeyPoint>& k2, const uint8_t* d2, const uint8_t* hasMP2, int nLeft2,
+                                 const std::vector<float>& levelSigma2_1, const std::vector<float>& levelSigma2_2, const TriRig& rig,
+                                 bool bOnlyStereo, bool bCoarse, bool checkOri, std::vector<int>& vMatches12,
+                                 std::vector<uint8_t>* borderline);
+
 // ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884).  valid =
 // the feature holds a good map point (and lies below mvKeysUn.size() for two-camera rigs); vMatches12[idx1] = idx2 or -1.
 int search_by_bow_keyframes(const std::vector<uint32_t>& nodes1, const std::vector<int>& start1, const std::vector<uint32_t>& feat1,

@@ -494,4 +494,22 @@ int oro_search_by_bow_keyframes(const uint32_t* nodes1, int nNodes1, const int* 
   return n;
 }
 
+int oro_search_for_triangulation_rig(const uint32_t* nodes1, int nNodes1, const int* start1, const uint32_t* feat1, const KeyPoint* k1,
+                                     const uint8_t* d1, const uint8_t* hasMP1, int nLeft1, int n1, const uint32_t* nodes2, int nNodes2,
+                                     const int* start2, const uint32_t* feat2, const KeyPoint* k2, const uint8_t* d2,
+                                     const uint8_t* hasMP2, int nLeft2, int n2, const float* sigma1, const float* sigma2, int nLevels,
+                                     const TriRig* rig, int onlyStereo, int coarse, int checkOri, int* matches12, uint8_t* borderline) {
+  std::vector<uint32_t> a(nodes1, nodes1 + nNodes1), af(feat1, feat1 + start1[nNodes1]);
+  std::vector<uint32_t> b(nodes2, nodes2 + nNodes2), bf(feat2, feat2 + start2[nNodes2]);
+  std::vector<int> as(start1, start1 + nNodes1 + 1), bs(start2, start2 + nNodes2 + 1), m;
+  std::vector<KeyPoint> ka(k1, k1 + n1), kb(k2, k2 + n2);
+  std::vector<float> s1(sigma1, sigma1 + nLevels), s2(sigma2, sigma2 + nLevels);
+  std::vector<uint8_t> bl;
+  const int n = search_for_triangulation_rig(a, as, af, ka, d1, hasMP1, nLeft1, b, bs, bf, kb, d2, hasMP2, nLeft2, s1, s2, *rig,
+                                             onlyStereo != 0, coarse != 0, checkOri != 0, m, &bl);
+  std::copy(m.begin(), m.end(), matches12);
+  if (borderline) std::copy(bl.begin(), bl.end(), borderline);
+  return n;
+}
+
 }  // extern "C"

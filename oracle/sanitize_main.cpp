@@ -131,6 +131,29 @@ int main() {
   std::vector<int> fbi, fbd;
   const int np8 = fuse_search(kR, dR.data(), uRv.data(), g, eL.t.inv_sigma2, fps, 50, fbi, fbd) +
                   fuse_search(kR, dR.data(), nullptr, g, std::vector<float>(8, 0.f), fps, 100, fbi, fbd);
+  int np6r = 0;
+  {  // two-camera-rig branch of SearchForTriangulation on the concatenated (left | right) features
+    TriRig tr;
+    const float camp[8] = {190.97f, 190.97f, 200.f, 150.f, 0.0035f, 0.0007f, -0.002f, 0.0002f};
+    for (int c = 0; c < 4; c++)
+      for (int i = 0; i < 8; i++) tr.cam[c][i] = camp[i];
+    tr.precision = 1e-6f;
+    const float I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int c = 0; c < 4; c++) {
+      for (int i = 0; i < 9; i++) tr.R[c][i] = I9[i];
+      tr.t[c][0] = (c == 1) ? 0.1f : (c == 2 ? -0.1f : 0.f); tr.t[c][1] = 0.f; tr.t[c][2] = 0.f;
+    }
+    std::vector<KeyPoint> kk2(kL);
+    kk2.insert(kk2.end(), kR.begin(), kR.end());
+    std::vector<uint8_t> dd2(dL), hm(kk2.size(), 0);
+    dd2.insert(dd2.end(), dR.begin(), dR.end());
+    std::vector<uint32_t> nn, ff;
+    std::vector<int> ss, rigm;
+    make_fv(dd2, nn, ss, ff);
+    std::vector<uint8_t> bl;
+    np6r = search_for_triangulation_rig(nn, ss, ff, kk2, dd2.data(), hm.data(), (int)kL.size(), nn, ss, ff, kk2, dd2.data(), hm.data(),
+                                            (int)kL.size(), eL.t.sigma2, eL.t.sigma2, tr, false, false, true, rigm, &bl);
+  }
   // stereo-fisheye flavours on the concatenated frame
   std::vector<KeyPoint> kk(kR);
   kk.insert(kk.end(), kL.begin(), kL.end());
@@ -220,6 +243,6 @@ int main() {
                             (int)(kL.size() + kR.size()), (int)kL.size(), 0.7f, true, bm);
   }
   std::printf("ok %d %d %zu %zu stereo %d knn %d init %d proj %d %d fe %d %d fisheye %d/%d un %.2f b %.1f g %d\n", mL, mR, kL.size(),
-              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow + np5 + np6 + np7 + np8);
+              kR.size(), (int)u.size(), (int)ok.size(), ni, np1, np2, np3, np4, nfm, nd, un.empty() ? 0.f : un[0].x, bounds[0], gray[5] + eq[7] + nfm_bow + np5 + np6 + np6r + np7 + np8);
   return 0;
 }

@@ -33,6 +33,8 @@ assert PP_DTYPE.itemsize == 64
 FP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("predicted_level", "<i4"), ("valid", "u1"),
                      ("pad_", "u1", (3,)), ("desc", "u1", (32,))])   # orbx_fuse_point
 assert FP_DTYPE.itemsize == 56
+TRI_RIG_DTYPE = np.dtype([("cam", "<f4", (4, 8)), ("precision", "<f4"), ("R", "<f4", (4, 9)), ("t", "<f4", (4, 3))])   # orbx_tri_rig
+assert TRI_RIG_DTYPE.itemsize == 324
 MPR_DTYPE = np.dtype([("proj_yr", "<f4"), ("view_cos_r", "<f4"), ("predicted_level_r", "<i4"), ("in_view_r", "u1"),
                       ("pad_", "u1", (3,))])   # orbx_map_point_right
 assert MPR_DTYPE.itemsize == 16
@@ -125,6 +127,8 @@ def lib():
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
+        L.orbx_search_for_triangulation_rig.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, i, vp,
+                                                        i, i, i, vp]
         L.orbx_search_by_bow_keyframes.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, f, i, vp]
         L.orbx_fuse_search.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, i, vp, vp]
         L.orbx_features_in_area.argtypes = [i, vp, i, f, f, f, f, vp, i, vp, vp, i, vp, vp]
@@ -831,6 +835,24 @@ class ORBmatcher:
         ok[ok] = m2[m1[ok]] == i1[ok]
         out = np.where(ok, m1, -1).astype(np.int32)
         return int(ok.sum()), out
+
+    def SearchForTriangulationRig(self, fv1, kps1, desc1, hasMapPoint1, nLeft1, fv2, kps2, desc2, hasMapPoint2, nLeft2, levelSigma2_1,
+                                  levelSigma2_2, rig, bOnlyStereo=False, bCoarse=False):
+        """ORBmatcher::SearchForTriangulation for two-camera key frames (src/ORBmatcher.cc:906-923,1007-1064): kps / desc hold
+        mvKeys | mvKeysRight, rig = a TRI_RIG_DTYPE record.  Returns (nmatches, vMatches12[n1])."""
+        n1n, s1, f1 = (np.ascontiguousarray(fv1[0], np.uint32), np.ascontiguousarray(fv1[1], np.int32), np.ascontiguousarray(fv1[2], np.uint32))
+        n2n, s2, f2 = (np.ascontiguousarray(fv2[0], np.uint32), np.ascontiguousarray(fv2[1], np.int32), np.ascontiguousarray(fv2[2], np.uint32))
+        k1, k2 = np.ascontiguousarray(kps1, KP_DTYPE), np.ascontiguousarray(kps2, KP_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        h1, h2 = np.ascontiguousarray(hasMapPoint1, np.uint8), np.ascontiguousarray(hasMapPoint2, np.uint8)
+        g1, g2 = np.ascontiguousarray(levelSigma2_1, np.float32), np.ascontiguousarray(levelSigma2_2, np.float32)
+        rg = np.ascontiguousarray(rig, TRI_RIG_DTYPE)
+        m = np.full(len(k1), -1, np.int32)
+        n = _check(lib().orbx_search_for_triangulation_rig(
+            self.device, _p(n1n), _p(s1), _p(f1), len(n1n), _p(k1), _p(d1), _p(h1), int(nLeft1), len(k1), _p(n2n), _p(s2), _p(f2), len(n2n),
+            _p(k2), _p(d2), _p(h2), int(nLeft2), len(k2), _p(g1), _p(g2), len(g1), _p(rg), int(bOnlyStereo), int(bCoarse),
+            int(self.mbCheckOrientation), _p(m)))
+        return n, m
 
     def SearchForTriangulation(self, fv1, kps1, desc1, hasMapPoint1, uRight1, fv2, kps2, desc2, hasMapPoint2, uRight2,
                                scaleFactors2, levelSigma2_2, ep, F12, bOnlyStereo=False, bCoarse=False):

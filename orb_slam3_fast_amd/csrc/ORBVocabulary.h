@@ -189,5 +189,43 @@ inline int SearchForTriangulation(const KeyFrameView& KF1, const KeyFrameView& K
   return n;
 }
 
+// The same call for two-camera (stereo-fisheye) key frames, src/ORBmatcher.cc:906-923,1007-1064: the views hold mvKeys | mvKeysRight
+// (mvKeysUn points at the concatenation, NLeft = KeyFrame::NLeft), rig = both key frames' KannalaBrandt8 parameters and the four
+// relative poses Tll, Tlr, Trl, Trr; mvLevelSigma2 of BOTH key frames is read (sigmaLevel / unc of TriangulateMatches).
+inline int SearchForTriangulation(const KeyFrameView& KF1, int NLeft1, const KeyFrameView& KF2, int NLeft2, const orbx_tri_rig& rig,
+                                  std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo, const bool bCoarse,
+                                  bool mbCheckOrientation = true, int device = 0) {
+  auto flatten = [](const DBoW2::FeatureVector& fv, std::vector<uint32_t>& nodes, std::vector<int32_t>& start,
+                    std::vector<uint32_t>& feats) {
+    start.assign(1, 0);
+    for (const auto& e : fv) {
+      nodes.push_back(e.first);
+      feats.insert(feats.end(), e.second.begin(), e.second.end());
+      start.push_back((int32_t)feats.size());
+    }
+  };
+  std::vector<uint32_t> n1, f1, n2, f2;
+  std::vector<int32_t> s1, s2;
+  flatten(*KF1.mFeatVec, n1, s1, f1);
+  flatten(*KF2.mFeatVec, n2, s2, f2);
+  const int N1 = (int)KF1.mvKeysUn->size(), N2 = (int)KF2.mvKeysUn->size();
+  if ((int)KF1.hasMapPoint->size() != N1 || (int)KF2.hasMapPoint->size() != N2)
+    throw std::invalid_argument("SearchForTriangulation: one hasMapPoint flag per keypoint");
+  if (KF1.mvLevelSigma2->size() != KF2.mvLevelSigma2->size()) throw std::invalid_argument("SearchForTriangulation: level tables differ");
+  std::vector<int> vMatches12(N1, -1);
+  const int n = orbx_search_for_triangulation_rig(
+      device, n1.data(), s1.data(), f1.data(), (int)n1.size(), reinterpret_cast<const orbx_keypoint*>(KF1.mvKeysUn->data()),
+      KF1.mDescriptors, KF1.hasMapPoint->data(), NLeft1, N1, n2.data(), s2.data(), f2.data(), (int)n2.size(),
+      reinterpret_cast<const orbx_keypoint*>(KF2.mvKeysUn->data()), KF2.mDescriptors, KF2.hasMapPoint->data(), NLeft2, N2,
+      KF1.mvLevelSigma2->data(), KF2.mvLevelSigma2->data(), (int)KF1.mvLevelSigma2->size(), &rig, bOnlyStereo ? 1 : 0, bCoarse ? 1 : 0,
+      mbCheckOrientation ? 1 : 0, vMatches12.data());
+  if (n < 0) throw std::runtime_error(std::string("SearchForTriangulation: ") + orbx_last_error());
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(n);
+  for (size_t i = 0; i < vMatches12.size(); i++)
+    if (vMatches12[i] >= 0) vMatchedPairs.push_back(std::make_pair(i, (size_t)vMatches12[i]));
+  return n;
+}
+
 }  // namespace ORB_SLAM3
 #endif

@@ -462,6 +462,74 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
+int orbx_search_for_triangulation_rig(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
+                                      int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
+                                      int n_left1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,
+                                      const uint32_t* feature_idx2, int n_nodes2, const orbx_keypoint* kps2, const uint8_t* desc2,
+                                      const uint8_t* has_map_point2, int n_left2, int n2, const float* level_sigma2_1,
+                                      const float* level_sigma2_2, int nlevels, const orbx_tri_rig* rig, int only_stereo, int coarse,
+                                      int check_orientation, int32_t* matches12) {
+  if (n1 < 0 || n2 < 0 || n_nodes1 < 0 || n_nodes2 < 0 || nlevels < 1 || !level_sigma2_1 || !level_sigma2_2 || !rig ||
+      n_left1 < 0 || n_left1 > n1 || n_left2 < 0 || n_left2 > n2 || (n1 && (!matches12 || !kps1 || !desc1 || !has_map_point1)) ||
+      (n2 && (!kps2 || !desc2 || !has_map_point2)) || (n_nodes1 && (!node_ids1 || !node_start1 || !feature_idx1)) ||
+      (n_nodes2 && (!node_ids2 || !node_start2 || !feature_idx2)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  const int nl1 = n_nodes1 ? node_start1[n_nodes1] : 0, nl2 = n_nodes2 ? node_start2[n_nodes2] : 0;
+  if (nl1 < 0 || nl1 > n1 || nl2 < 0 || nl2 > n2) return fail(ORBX_E_BADARG, "feature vector larger than the key frame");
+  if (nl2 >= (1 << 24)) return fail(ORBX_E_CAPACITY, "more than 2^24 features");
+  for (int j = 0; j < n_nodes1; j++)
+    if (node_start1[j] < 0 || node_start1[j] > node_start1[j + 1] || (j && node_ids1[j] <= node_ids1[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 1: node ids must ascend and offsets must be monotone");
+  for (int j = 0; j < n_nodes2; j++)
+    if (node_start2[j] < 0 || node_start2[j] > node_start2[j + 1] || (j && node_ids2[j] <= node_ids2[j - 1]))
+      return fail(ORBX_E_BADARG, "feature vector 2: node ids must ascend and offsets must be monotone");
+  for (int i = 0; i < nl1; i++)
+    if (feature_idx1[i] >= (uint32_t)n1) return fail(ORBX_E_BADARG, "feature index 1 out of range");
+  for (int i = 0; i < nl2; i++)
+    if (feature_idx2[i] >= (uint32_t)n2) return fail(ORBX_E_BADARG, "feature index 2 out of range");
+  for (int i = 0; i < n1; i++)
+    if (kps1[i].octave < 0 || kps1[i].octave >= nlevels) return fail(ORBX_E_BADARG, "keypoint octave outside [0, nlevels)");
+  for (int i = 0; i < n2; i++)
+    if (kps2[i].octave < 0 || kps2[i].octave >= nlevels) return fail(ORBX_E_BADARG, "keypoint octave outside [0, nlevels)");
+  int rc = set_device(device);
+  if (rc != ORBX_OK) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (nl1 == 0 || nl2 == 0) return 0;
+  Pack pk;
+  const size_t oN1 = pk.add(node_ids1, (size_t)n_nodes1 * 4), oS1 = pk.add(node_start1, ((size_t)n_nodes1 + 1) * 4);
+  const size_t oF1 = pk.add(feature_idx1, (size_t)nl1 * 4), oD1 = pk.add(desc1, (size_t)n1 * 32);
+  const size_t oM1 = pk.add(has_map_point1, n1), oK1 = pk.add(kps1, (size_t)n1 * sizeof(orbx_keypoint));
+  const size_t oN2 = pk.add(node_ids2, (size_t)n_nodes2 * 4), oS2 = pk.add(node_start2, ((size_t)n_nodes2 + 1) * 4);
+  const size_t oF2 = pk.add(feature_idx2, (size_t)nl2 * 4), oD2 = pk.add(desc2, (size_t)n2 * 32);
+  const size_t oM2 = pk.add(has_map_point2, n2), oK2 = pk.add(kps2, (size_t)n2 * sizeof(orbx_keypoint));
+  const size_t oG1 = pk.add(level_sigma2_1, (size_t)nlevels * 4), oG2 = pk.add(level_sigma2_2, (size_t)nlevels * 4);
+  const size_t oRig = pk.add(rig, sizeof(orbx_tri_rig));
+  const size_t oFlags = pk.add(nullptr, 33 * 4);
+  const size_t oOut = pk.add(nullptr, ((size_t)n1 + 1) * 4);
+  hipError_t e = pk.commit();
+  TriArgs a{};
+  a.nodes1 = pk.ptr<uint32_t>(oN1); a.start1 = pk.ptr<int>(oS1); a.feat1 = pk.ptr<uint32_t>(oF1); a.nNodes1 = n_nodes1; a.nList1 = nl1;
+  a.nodes2 = pk.ptr<uint32_t>(oN2); a.start2 = pk.ptr<int>(oS2); a.feat2 = pk.ptr<uint32_t>(oF2); a.nNodes2 = n_nodes2;
+  a.k1 = pk.ptr<orbx_keypoint>(oK1); a.k2 = pk.ptr<orbx_keypoint>(oK2);
+  a.d1 = pk.ptr<uint32_t>(oD1); a.d2 = pk.ptr<uint32_t>(oD2); a.mp1 = pk.ptr<uint8_t>(oM1); a.mp2 = pk.ptr<uint8_t>(oM2);
+  a.n1 = n1; a.n2 = n2; a.nLeft1 = n_left1; a.nLeft2 = n_left2;
+  a.sigma1 = pk.ptr<float>(oG1); a.sigma2 = pk.ptr<float>(oG2); a.rig = pk.ptr<orbx_tri_rig>(oRig);
+  a.onlyStereo = only_stereo ? 1 : 0; a.coarse = coarse ? 1 : 0; a.checkOri = check_orientation ? 1 : 0;
+  a.flags = pk.ptr<int>(oFlags); a.result = pk.ptr<int>(oOut); a.match = pk.ptr<int>(oOut) + 1;
+  if (e == hipSuccess) e = launch_search_for_triangulation(a, nullptr);
+  int n = 0;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, ((size_t)n1 + 1) * 4, &e);
+    if (e == hipSuccess) {
+      std::memcpy(&n, h, 4);
+      std::memcpy(matches12, h + 4, (size_t)n1 * 4);
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  return n;
+}
+
 int orbx_search_by_bow_keyframes(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
                                  int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* valid1, int n1,
                                  const uint32_t* node_ids2, const int32_t* node_start2, const uint32_t* feature_idx2, int n_nodes2,

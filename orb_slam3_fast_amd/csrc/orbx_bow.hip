@@ -631,7 +631,10 @@ hipError_t launch_search_by_bow_keyframes(const TriArgs& a, hipStream_t s) {
 
 hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_tri_init, dim3((max(a.n1, 33) + 255) / 256), dim3(256), 0, s, a);
-  if (a.nList1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_tri_match, dim3((a.nList1 + 15) / 16), dim3(256), 0, s, a);
+  if (a.rig) {  // two-camera rigs: the match kernel lives beside the KB8 triangulation
+    const hipError_t e = launch_tri_match_rig(a, s);
+    if (e != hipSuccess) return e;
+  } else if (a.nList1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_tri_match, dim3((a.nList1 + 15) / 16), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_tri_cull, dim3(1), dim3(1024), 0, s, a);
   return hipGetLastError();
 }

@@ -224,11 +224,13 @@ struct TriArgs {
   float F[9];                                         // F12 row-major (Pinhole.cpp:133)
   int onlyStereo, coarse, checkOri;
   float nnratio; // SearchByBoW(KeyFrame*, KeyFrame*) only
+  int nLeft1, nLeft2; const float* sigma1; const orbx_tri_rig* rig;  // two-camera rigs only (k_tri_match_rig): NLeft, pKF1's mvLevelSigma2
   int* match;    // n1: vMatches12
   int* flags;    // [0] accepted, [1] removed, [2..31] rotation histogram, [32] a node's list exceeded kBowNodeCap
   int* result;   // nmatches
 };
 hipError_t launch_search_for_triangulation(const TriArgs& a, hipStream_t s);
+hipError_t launch_tri_match_rig(const TriArgs& a, hipStream_t s);  // orbx_stereo.hip (next to kb8_triangulate_matches)
 // ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (src/ORBmatcher.cc:766-884) on the same argument block:
 // mp1 / mp2 = "holds a good map point" flags, match = the feature of pKF2 whose map point vpMatches12[idx1] receives
 hipError_t launch_search_by_bow_keyframes(const TriArgs& a, hipStream_t s);

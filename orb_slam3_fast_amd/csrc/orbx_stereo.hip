@@ -778,6 +778,80 @@ __global__ __launch_bounds__(64) void k_fisheye_triangulate(FisheyeArgs a) {
   }
 }
 
+// ORBmatcher::SearchForTriangulation, two-camera-rig branch (src/ORBmatcher.cc:906-923, 1007-1064): k_tri_match's walk (16 lanes per
+// feature of pKF1, minimum of (distance, -position) over the gate-passers) with KannalaBrandt8::epipolarConstrain as the gate --
+// TriangulateMatches(...) > 0.0001f on the (R12, t12, cameras) of the eyes the two features sit in.
+__global__ __launch_bounds__(256) void k_tri_match_rig(TriArgs a) {
+  const int sub = threadIdx.x & 15;
+  const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (g >= a.nList1) return;
+  int lo = 0, hi = a.nNodes1 - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.start1[mid] <= g) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t node = a.nodes1[lo];
+  int l2 = 0, h2 = a.nNodes2;
+  while (l2 < h2) {
+    const int mid = (l2 + h2) >> 1;
+    if (a.nodes2[mid] < node) l2 = mid + 1; else h2 = mid;
+  }
+  if (l2 >= a.nNodes2 || a.nodes2[l2] != node) return;
+  const int b = a.start2[l2], e = a.start2[l2 + 1];
+  const int idx1 = (int)a.feat1[g];
+  if (a.mp1[idx1] || a.onlyStereo) return;  // bStereo1 is false for a rig: bOnlyStereo skips every feature (:957-959)
+  const orbx_keypoint kp1 = a.k1[idx1];
+  const bool right1 = idx1 >= a.nLeft1;
+  KB8Cam c1;
+#pragma unroll
+  for (int i = 0; i < 8; i++) c1.p[i] = a.rig->cam[right1 ? 1 : 0][i];
+  c1.precision = a.rig->precision;
+  const float sigma1 = a.sigma1[kp1.octave];
+  uint32_t d1[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) d1[i] = a.d1[(long long)idx1 * 8 + i];
+  uint32_t best = 0xFFFFFFFFu;  // (dist << 24) | (0xFFFFFF - position)
+  for (int pos = b + sub; pos < e; pos += 16) {
+    const int idx2 = (int)a.feat2[pos];
+    if (a.mp2[idx2]) continue;
+    const int dist = hamming256(d1, a.d2 + (long long)idx2 * 8);
+    if (dist > 50) continue;  // TH_LOW
+    if (!a.coarse) {
+      const orbx_keypoint kp2 = a.k2[idx2];
+      const bool right2 = idx2 >= a.nLeft2;
+      const int sel = (right1 ? 2 : 0) + (right2 ? 1 : 0);  // ll, lr, rl, rr (:1008-1041)
+      KB8Cam c2;
+#pragma unroll
+      for (int i = 0; i < 8; i++) c2.p[i] = a.rig->cam[right2 ? 3 : 2][i];
+      c2.precision = a.rig->precision;
+      float P[3];
+      const float z = kb8_triangulate_matches(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, a.rig->R[sel], a.rig->t[sel], sigma1,
+                                              a.sigma2[kp2.octave], P);
+      if (!(z > 0.0001f)) continue;  // KannalaBrandt8.cpp:248-249
+    }
+    best = min(best, ((uint32_t)dist << 24) | (0xFFFFFFu - (uint32_t)(pos - b)));
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, o, 16));
+  if (sub == 0 && best != 0xFFFFFFFFu) {
+    const int idx2 = (int)a.feat2[b + (int)(0xFFFFFFu - (best & 0xFFFFFFu))];
+    a.match[idx1] = idx2;
+    atomicAdd(&a.flags[0], 1);
+    if (a.checkOri) {
+      float rot = kp1.angle - a.k2[idx2].angle;
+      if (rot < 0.0f) rot = rot + 360.0f;
+      int bin = (int)roundf(rot * (1.0f / 30));
+      if (bin == 30) bin = 0;
+      atomicAdd(&a.flags[2 + bin], 1);
+    }
+  }
+}
+
+hipError_t launch_tri_match_rig(const TriArgs& a, hipStream_t s) {
+  if (a.nList1 > 0 && a.nNodes2 > 0) hipLaunchKernelGGL(k_tri_match_rig, dim3((a.nList1 + 15) / 16), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // Batched variant on the extractors' device-resident results: thread per lapping-area left keypoint of pair
 // blockIdx.y does the 2-NN over the pair's right lapping rows (256-row LDS tiles, as k_bf_knn2), the Lowe test and the
 // triangulation in one go.

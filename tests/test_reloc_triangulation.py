@@ -680,3 +680,72 @@ def test_gpu_search_by_bow_keyframes(gpu, oracle, big):
     assert n == 0 and (m == -1).all()
     n, m = orbx.SearchByBoWKeyFrames(one1, f["k1"], f["d1"], v1, one2, f["k2"], f["d2"], np.zeros_like(v2))
     assert n == 0 and (m == -1).all()
+
+
+# ---- two-camera rigs: SearchForTriangulation through KannalaBrandt8::epipolarConstrain (float: tolerance parity) ------------
+def _rig_inputs(mod, seed):
+    """One stereo-fisheye frame as BOTH key frames (features = left | right): a left feature and the right feature that observes the
+    same point triangulate under Tlr = the rig's extrinsics (and right -> left under its inverse), while left-left / right-right
+    pairs have T = identity, no parallax, and are rejected at the first gate -- all four (R12, t12, camera) selections are used."""
+    sc = synth.fisheye_stereo_scene(seed, 700, 650, 100, 80)
+    kk, dd = np.concatenate([sc["kL"], sc["kR"]]), np.concatenate([sc["dL"], sc["dR"]])
+    nL = len(sc["kL"])
+    R, t = sc["R12"].astype(np.float64), sc["t12"].astype(np.float64)
+    rig = np.zeros((), mod.TRI_RIG_DTYPE)
+    rig["cam"] = np.stack([sc["cam1"], sc["cam2"], sc["cam1"], sc["cam2"]])
+    rig["precision"] = 1e-6
+    eye = np.eye(3)
+    rig["R"] = np.stack([eye.ravel(), R.ravel(), R.T.ravel(), eye.ravel()]).astype(np.float32)        # ll, lr, rl, rr
+    rig["t"] = np.stack([np.zeros(3), t, -R.T @ t, np.zeros(3)]).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    # feature vector over all N features: true pairs share descriptors up to 3 % flipped bits, so hash the node from a majority of
+    # stable bits (the first byte's high nibble) -- most pairs land in the same node, as with a real vocabulary
+    node = (dd[:, 0] >> 4).astype(np.uint32) * 3 + 1
+    ids = np.unique(node)
+    start, feats = [0], []
+    for nid in ids:
+        feats.extend(np.nonzero(node == nid)[0].tolist())
+        start.append(len(feats))
+    fv = (ids, np.array(start, np.int32), np.array(feats, np.uint32))
+    mp = (rng.random(len(kk)) < 0.15).astype(np.uint8)
+    return sc, kk, dd, nL, rig, fv, mp
+
+
+def test_oracle_rig_triangulation_selects_the_cross_camera_pairs(oracle):
+    sc, kk, dd, nL, rig, fv, mp = _rig_inputs(oracle, 3)
+    s2 = sc["level_sigma2"]
+    n, m, bl = oracle.search_for_triangulation_rig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig, False, False, False)
+    got = np.nonzero(m >= 0)[0]
+    assert n == len(got) > 100
+    # every accepted pair crosses the cameras (same-camera pairs have no parallax), and most are the generating correspondences
+    assert ((got < nL) != (m[got] < nL)).all()
+    truth = {int(a): int(b) + nL for a, b in zip(sc["true_left"], sc["true_right"])}
+    hit = sum(1 for i in got if i < nL and truth.get(int(i)) == int(m[i]))
+    assert hit > 0.6 * sum(1 for i in got if i < nL)
+    nc, mc, _ = oracle.search_for_triangulation_rig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig, False, True, False)
+    assert nc > n                                   # bCoarse skips the epipolar test: a feature also pairs with itself (distance 0)
+    assert oracle.search_for_triangulation_rig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig, True, False, False)[0] == 0
+    assert bl.sum() < 0.1 * len(bl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 4])
+def test_gpu_search_for_triangulation_rig(gpu, oracle, seed):
+    sc, kk, dd, nL, rig, fv, mp = _rig_inputs(orbx, seed)
+    s2 = sc["level_sigma2"]
+    for coarse, ori in ((False, True), (False, False), (True, True)):
+        n, m = orbx.ORBmatcher(0.6, ori).SearchForTriangulationRig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig, False, coarse)
+        on, om, bl = oracle.search_for_triangulation_rig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig.view(oracle.TRI_RIG_DTYPE),
+                                                         False, coarse, ori)
+        assert on > (15 if ori else 100)              # (the scene's keypoint angles are random: the rotation cull keeps ~3 of 30 bins)
+        if coarse:                                    # no float gate: exact
+            assert n == on and np.array_equal(m, om)
+            continue
+        diff = np.nonzero(m != om)[0]
+        # tolerance parity: a decision may only differ where the oracle's gated quantity sits within rounding noise of its threshold
+        assert all(bl[i] for i in diff), ("decision differs away from every gate", diff[:10], m[diff[:10]], om[diff[:10]])
+        assert len(diff) <= 3
+        if not ori:
+            assert abs(n - on) <= len(diff)
+    n, m = orbx.ORBmatcher(0.6, True).SearchForTriangulationRig(fv, kk, dd, mp, nL, fv, kk, dd, mp, nL, s2, s2, rig, True, False)
+    assert n == 0 and (m == -1).all()
