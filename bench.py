@@ -300,7 +300,7 @@ def main():
     gc.collect()
     gc.disable()
     # Which kernel dominates: two steps on ONE handle, synchronised, every kernel bracketed with HIP events (the kernels
-    # alone: under overlap the seven small resize launches stretch more than the one FAST launch).  From here on only
+    # alone: under overlap the small resize launches stretch more than the one FAST launch).  From here on only
     # that kernel is bracketed.
     dom = None
     if not a.no_profile:
