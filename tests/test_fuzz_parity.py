@@ -88,7 +88,8 @@ def test_fuzz_extract_and_stereo(oracle):
 
 
 def test_fuzz_matchers(oracle):
-    """SearchForInitialization, both SearchByProjection flavours, GetFeaturesInArea and kNN on random frame pairs."""
+    """SearchForInitialization, every SearchByProjection flavour, SearchForTriangulation, the Fuse / SearchBySim3 search, SearchByBoW on
+    two key frames, GetFeaturesInArea and kNN on random frame pairs."""
     ncases = int(os.environ.get("ORBX_FUZZ_CASES", "60")) // 3 + 1
     seed0 = int(os.environ.get("ORBX_FUZZ_SEED", "12345")) + 5000
     fails = []
@@ -173,6 +174,49 @@ def test_fuzz_matchers(oracle):
         n4, m4, o4 = orbx.ORBmatcher(ratio, ori).SearchByProjectionFrameFisheye(kk, dd, nL, bounds, pts, uvr, occf)
         on4, om4, oo4 = oracle.search_by_projection_frame_fisheye(kk, dd, nL, bounds, pts.view(oracle.PP_DTYPE), uvr, ori, occf)
         ok = ok and n4 == on4 and np.array_equal(m4, om4) and np.array_equal(o4, oo4)
+        # round-3 matchers: relocalisation flavour, SearchForTriangulation (pinhole), Fuse / SearchBySim3 search, SearchByBoW(KF, KF)
+        orb_dist = int(rng.choice([37, 64, 100, 255]))
+        occk = (rng.random(len(k2)) < float(rng.choice([0.0, 0.3, 0.7]))).astype(np.uint8)
+        n5, m5, o5 = orbx.ORBmatcher(ratio, ori).SearchByProjectionKeyFrame(k2, d2, bounds, pts, occk, orb_dist)
+        on5, om5, oo5 = oracle.search_by_projection_keyframe(k2, d2, bounds, pts.view(oracle.PP_DTYPE), orb_dist, ori, occk)
+        ok = ok and n5 == on5 and np.array_equal(m5, om5) and np.array_equal(o5, oo5)
+
+        def fvec(desc, nodes):
+            node = (desc[:, 0].astype(np.uint32) * 7 + (desc[:, 1] >> 6)) % nodes * 3 + 2
+            keep = rng.random(len(desc)) >= 0.05
+            ids = np.unique(node[keep])
+            ids = ids[rng.random(len(ids)) >= 0.1] if len(ids) > 2 else ids
+            start, feats = [0], []
+            for nid in ids:
+                feats.extend(np.nonzero(keep & (node == nid))[0].tolist())
+                start.append(len(feats))
+            return ids.astype(np.uint32), np.array(start, np.int32), np.array(feats, np.uint32)
+        nodes = int(rng.choice([2, 16, 64, 200]))
+        fv1, fv2 = fvec(d1, nodes), fvec(d2, nodes)
+        hm1, hm2 = (rng.random(len(k1)) < 0.3).astype(np.uint8), (rng.random(len(k2)) < 0.3).astype(np.uint8)
+        ur1 = None if rng.random() < 0.3 else np.where(rng.random(len(k1)) < 0.5, k1["x"] - 5, -1).astype(np.float32)
+        ur2 = None if rng.random() < 0.3 else uR
+        F12 = (np.array([[0, 0, 0.6], [0, 0, -0.8], [-0.6, 0.8, 0]]) + rng.normal(0, 3e-5, (3, 3)) * [[1, 1, 300], [1, 1, 300], [300, 300, 1]]).astype(np.float32)
+        epi = np.array([rng.uniform(0, w), rng.uniform(0, h)], np.float32)
+        sigma2 = (sf * sf).astype(np.float32)
+        only_st, coarse = bool(rng.random() < 0.2), bool(rng.random() < 0.3)
+        n6, _, m6 = orbx.ORBmatcher(ratio, ori).SearchForTriangulation(fv1, k1, d1, hm1, ur1, fv2, k2, d2, hm2, ur2, sf, sigma2, epi, F12,
+                                                                       only_st, coarse)
+        on6, om6 = oracle.search_for_triangulation(fv1, k1, d1, hm1, ur1, fv2, k2, d2, hm2, ur2, sf, sigma2, epi, F12, only_st, coarse, ori)
+        ok = ok and n6 == on6 and np.array_equal(m6, om6)
+        fp = np.zeros(nmp, orbx.FP_DTYPE)
+        fp["u"], fp["v"], fp["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+        fp["predicted_level"] = mps["predicted_level"]
+        fp["radius"] = (np.float32(rng.choice([3.0, 7.5])) * sf[mps["predicted_level"]]).astype(np.float32)
+        fp["valid"], fp["desc"] = mps["in_view"], mps["desc"]
+        gate = (1.0 / sigma2).astype(np.float32) if rng.random() < 0.6 else np.zeros(8, np.float32)
+        md = int(rng.choice([50, 100]))
+        n7, b7, d7 = orbx.ORBmatcher(ratio, ori).FuseSearch(k2, d2, ur2, bounds, gate, fp, md)
+        on7, ob7, od7 = oracle.fuse_search(k2, d2, ur2, bounds, gate, fp.view(oracle.FP_DTYPE), md)
+        ok = ok and n7 == on7 and np.array_equal(b7, ob7) and np.array_equal(d7, od7)
+        n8, m8 = orbx.SearchByBoWKeyFrames(fv1, k1, d1, 1 - hm1, fv2, k2, d2, 1 - hm2, ratio, ori)
+        on8, om8 = oracle.search_by_bow_keyframes(fv1, d1, k1["angle"], 1 - hm1, fv2, d2, k2["angle"], 1 - hm2, ratio, ori)
+        ok = ok and n8 == on8 and np.array_equal(m8, om8)
         idx, dist, okk = orbx.bf_knn2(d1[: min(400, len(d1))], d2)
         oidx, odist, ookk = oracle.bf_knn2(d1[: min(400, len(d1))], d2)
         ok = ok and np.array_equal(idx, oidx) and np.array_equal(dist, odist) and np.array_equal(okk, ookk)
