@@ -130,7 +130,25 @@ int main(int argc, char** argv) {
     std::vector<int> m12(k1.size(), -1);
     for (const auto& pr : pairs) m12[pr.first] = (int)pr.second;
     dump(pre + ".m12", m12.data(), m12.size());
-    std::printf("%d %d %zu\n", nr, nt, pairs.size());
+    // Fuse (search), SearchBySim3 and SearchByBoW(KeyFrame*, KeyFrame*) on <prefix>.{fp,isg,p12,p21,good1,good2}
+    std::vector<uint8_t> fpb = rd("fp"), isgb = rd("isg"), p12b = rd("p12"), p21b = rd("p21"), good1 = rd("good1"), good2 = rd("good2");
+    auto fpts = [](const std::vector<uint8_t>& b) {
+      std::vector<orbx_fuse_point> v(b.size() / sizeof(orbx_fuse_point));
+      std::memcpy(static_cast<void*>(v.data()), b.data(), v.size() * sizeof(orbx_fuse_point));
+      return v;
+    };
+    std::vector<float> isg(isgb.size() / 4);
+    std::memcpy(isg.data(), isgb.data(), isgb.size());
+    std::vector<int> fuseIdx, sim12, bow12;
+    const int nf = matcher.Fuse(cur, isg, fpts(fpb), fuseIdx);
+    FrameView kf1 = cur;
+    kf1.mvKeysUn = k1.data(); kf1.mDescriptors = d1.data(); kf1.N = (int)k1.size();
+    const int ns = matcher.SearchBySim3(kf1, cur, fpts(p12b), fpts(p21b), sim12);
+    const int nb = SearchByBoW(fv1, k1, d1.data(), good1, fv2, k2, d2.data(), good2, 0.75f, true, bow12);
+    dump(pre + ".fuse", fuseIdx.data(), fuseIdx.size());
+    dump(pre + ".sim3", sim12.data(), sim12.size());
+    dump(pre + ".bowkf", bow12.data(), bow12.size());
+    std::printf("%d %d %zu %d %d %d\n", nr, nt, pairs.size(), nf, ns, nb);
     return 0;
   }
   if (std::string(argv[1]) == "rectify") {

@@ -165,12 +165,29 @@ def test_cpp_mirror_relocalisation_and_triangulation_match_oracle(oracle, tmp_pa
                      ("s1", fv1[1]), ("f1", fv1[2]), ("n2", fv2[0]), ("s2", fv2[1]), ("f2", fv2[2]), ("mp1", mp1), ("mp2", mp2),
                      ("sf", f["sf"]), ("sg", f["sigma2"]), ("epF", np.concatenate([ep, F.reshape(9)]).astype(np.float32))):
         np.ascontiguousarray(arr).tofile(pre + "." + ext)
+    fp = T._fuse_points(orbx, rng, f, 3.0, 1.0)
+    inv = (1.0 / f["sigma2"]).astype(np.float32)
+    p12, p21 = T._sim3_inputs(orbx, rng, f)
+    good1, good2 = (1 - mp1).astype(np.uint8), (1 - mp2).astype(np.uint8)
+    for ext, arr in (("fp", fp), ("isg", inv), ("p12", p12), ("p21", p21), ("good1", good1), ("good2", good2)):
+        np.ascontiguousarray(arr).tofile(pre + "." + ext)
     r = subprocess.run([exe, "reloc_tri", pre, "752", "480", "100"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
-    nr, nt, npairs = map(int, r.stdout.split())
+    nr, nt, npairs, nfz, nsim, nbow = map(int, r.stdout.split())
     onr, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 100, True, occ)
     ont, om12 = oracle.search_for_triangulation(fv1, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, f["sf"], f["sigma2"],
                                                 ep, F, False, False, True)
     assert nr == onr > 100 and np.array_equal(np.fromfile(pre + ".rmatch", np.int32), omatch)
     assert np.array_equal(np.fromfile(pre + ".rocc", np.uint8), oocc)
     assert nt == ont == npairs and ont > 50 and np.array_equal(np.fromfile(pre + ".m12", np.int32), om12)
+    # ORBmatcher::Fuse (search), SearchBySim3, SearchByBoW(KeyFrame*, KeyFrame*) through the mirror
+    onf, obi, _ = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], inv, fp)
+    assert nfz == onf > 50 and np.array_equal(np.fromfile(pre + ".fuse", np.int32), obi)
+    z = np.zeros(8, np.float32)
+    _, m1, _ = oracle.fuse_search(f["k2"], f["d2"], None, f["bounds"], z, p12, 100)
+    _, m2, _ = oracle.fuse_search(f["k1"], f["d1"], None, f["bounds"], z, p21, 100)
+    agree = m1 >= 0
+    agree[agree] = m2[m1[agree]] == np.arange(len(m1))[agree]
+    assert nsim == agree.sum() > 100 and np.array_equal(np.fromfile(pre + ".sim3", np.int32), np.where(agree, m1, -1))
+    onb, omb = oracle.search_by_bow_keyframes(fv1, f["d1"], f["k1"]["angle"], good1, fv2, f["d2"], f["k2"]["angle"], good2, 0.75, True)
+    assert nbow == onb > 20 and np.array_equal(np.fromfile(pre + ".bowkf", np.int32), omb)
