@@ -48,20 +48,30 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // one LDS address per output column plus ds_read2 immediates.
 // xtab: one uint4 per dst column {sx, sx & ~3, v_perm selector, a0 | a1 << 16}, each level padded to a multiple of
 // RS_DW entries with copies of its last column (a block reads its 256 entries unconditionally).
+// The level pair of one launch, by value: the kernel's first scalar loads are its only kernel-argument loads (indexing Geom::lv with
+// the run-time level cost a second, dependent trip and ~40 scalar instructions of address arithmetic per wave).
+struct ResizeLv {
+  struct { int w, h, pitch, xcoef, ycoef; } D;
+  struct { int w, h; } S;
+  int sp, l;                      // source row pitch; destination level (1 = the source is the caller's level 0)
+  const uint8_t* src; long long srcImg;   // level l-1 of image 0, bytes between images
+  uint8_t* dst; long long dstImg;         // level l of image 0
+};
 template <int NDW>
-__global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const uint4* __restrict__ xtab,
+__global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __restrict__ xtab,
                                                 const int* __restrict__ yofs, const short* __restrict__ yab,
                                                 int srcRowsMax, int srcDwMaxRt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int SDW = NDW ? NDW : srcDwMaxRt;
-  const LevelDev D = g.lv[l];
-  const LevelDev S = g.lv[l - 1];
+  const auto D = rl.D;
+  const auto S = rl.S;
+  const int l = rl.l;
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
   const int x0 = blockIdx.x * RS_DW, y0 = blockIdx.y * RS_DR;
   const int x1 = min(x0 + RS_DW, D.w) - 1, y1 = min(y0 + RS_DR, D.h) - 1;  // last dst column / row of the block
-  int sp;
-  const uint8_t* src = level_ptr(g, p, img, l - 1, sp);
+  const int sp = rl.sp;
+  const uint8_t* src = rl.src + (long long)img * rl.srcImg;
   uint32_t* st = reinterpret_cast<uint32_t*>(smem);                        // [srcRowsMax][SDW] dwords
   uint8_t* ht8 = smem + (size_t)srcRowsMax * SDW * 4;                      // [srcRowsMax][RS_DW] u16
 #ifdef RS_PROF
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, Pyr p, int l, const uint
         const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
         outw |= (uint32_t)(v & 255) << (8 * j);
       }
-      uint8_t* dst = p.pyr + (long long)img * g.pyrImg + D.off + (long long)dy * D.pitch;
+      uint8_t* dst = rl.dst + (long long)img * rl.dstImg + (long long)dy * D.pitch;
       *reinterpret_cast<uint32_t*>(dst + dx) = outw;
     }
   }
@@ -251,10 +261,21 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
   size_t lds;
   resize_footprint(g, level, srcRowsMax, srcDwMax, lds);
   dim3 grid((D.w + RS_DW - 1) / RS_DW, (D.h + RS_DR - 1) / RS_DR, nimg);
+  const LevelDev& S = g.lv[level - 1];
+  ResizeLv rl;
+  rl.D.w = D.w; rl.D.h = D.h; rl.D.pitch = D.pitch; rl.D.xcoef = D.xcoef; rl.D.ycoef = D.ycoef;
+  rl.S.w = S.w; rl.S.h = S.h;
+  rl.l = level;
+  if (level == 1) {
+    rl.sp = (int)p.l0Row; rl.src = p.l0; rl.srcImg = p.l0Img;
+  } else {
+    rl.sp = S.pitch; rl.src = p.pyr + S.off; rl.srcImg = g.pyrImg;
+  }
+  rl.dst = p.pyr + D.off; rl.dstImg = g.pyrImg;
   if (srcDwMax == kResizeNdw)
-    hipLaunchKernelGGL(k_resize<kResizeNdw>, grid, dim3(256), lds, s, g, p, level, xtab, yofs, yab, srcRowsMax, srcDwMax);
+    hipLaunchKernelGGL(k_resize<kResizeNdw>, grid, dim3(256), lds, s, rl, xtab, yofs, yab, srcRowsMax, srcDwMax);
   else
-    hipLaunchKernelGGL(k_resize<0>, grid, dim3(256), lds, s, g, p, level, xtab, yofs, yab, srcRowsMax, srcDwMax);
+    hipLaunchKernelGGL(k_resize<0>, grid, dim3(256), lds, s, rl, xtab, yofs, yab, srcRowsMax, srcDwMax);
   return hipGetLastError();
 }
 
