@@ -119,3 +119,18 @@ def test_introsort_replica_matches_libstdcxx(oracle):
         orbx.lib().orbx_debug_introsort(a.ctypes.data_as(C.c_void_p), n)
         osort(b.ctypes.data_as(C.c_void_p), n)
         assert np.array_equal(a, b)
+
+
+def test_header_is_plain_c99_and_struct_sizes(tmp_path):
+    """include/orbx.h is the boundary a C, cgo or JNI binding would include: it must compile as C99 (no C++ in it), and the POD views
+    keep the sizes the kernels and the oracle assume."""
+    import subprocess
+    src = tmp_path / "hc.c"
+    src.write_text('#include "orbx.h"\n'
+                   'int main(void) { return sizeof(orbx_keypoint) == 28 && sizeof(orbx_map_point_view) == 60 && '
+                   'sizeof(orbx_projected_point) == 64 && sizeof(orbx_fuse_point) == 56 && sizeof(orbx_tri_rig) == 324 && '
+                   'sizeof(orbx_kb8_rig) == 116 ? 0 : 1; }\n')
+    exe = tmp_path / "hc"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + inc, str(src), "-o", str(exe)])
+    assert subprocess.run([str(exe)]).returncode == 0
