@@ -210,6 +210,19 @@ struct BowMatchArgs {
 };
 hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s);
 
+// Results of up to two images gathered into the handle's PINNED host block by one kernel (the single-frame host entries
+// orbx_extract / orbx_extract_stereo): counts and mono indices, then the first n_i keypoint records / descriptor rows of every
+// image and the left image's uRight / depth -- count-trimmed, written straight over PCIe, instead of six D2H copies.
+struct ResultPack {
+  const int* nOut; const int* mono;
+  const uint32_t* kps; const uint32_t* desc; const uint32_t* uR; const uint32_t* depth;   // device arrays ([img][cap] rows)
+  uint32_t* hCnt; uint32_t* hKps; uint32_t* hDesc; uint32_t* hUr; uint32_t* hDepth;        // host-block sections (device-visible)
+  int nimg, cap, stereo;
+  int mask;      // sections to gather: bit 0 / 1 keypoints of image 0 / 1, 2 / 3 descriptors, 4 uRight, 5 depth, 6 counts
+  int fixedN;    // >= 0: copy this many uRight / depth entries instead of nOut[0] (orbx_stereo_download: the caller's capacity)
+};
+hipError_t launch_result_pack(const ResultPack& a, hipStream_t s);
+
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106), single-camera key frames (k_tri_*)
 struct TriArgs {
   const uint32_t* nodes1; const int* start1; const uint32_t* feat1; int nNodes1, nList1;  // pKF1->mFeatVec as CSR

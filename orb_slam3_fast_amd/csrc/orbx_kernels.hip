@@ -2536,6 +2536,39 @@ hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t
   return hipGetLastError();
 }
 
+// One launch instead of six device-to-host copies for the single-frame host entries: section = blockIdx.y
+// (0 / 1: keypoints of image 0 / 1, 2 / 3: descriptors, 4: uRight, 5: depth, 6: counts); dword copies, count-trimmed.
+__global__ __launch_bounds__(256) void k_result_pack(ResultPack a) {
+  const int sec = blockIdx.y;
+  if (!((a.mask >> sec) & 1)) return;
+  if (sec == 6) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+      const int t = threadIdx.x;
+      a.hCnt[t] = t < a.nimg ? (uint32_t)a.nOut[t] : 0u;
+      a.hCnt[2 + t] = t < a.nimg ? (uint32_t)a.mono[t] : 0u;
+    }
+    return;
+  }
+  const int img = sec < 4 ? (sec & 1) : 0;
+  if (img >= a.nimg || (sec >= 4 && !a.stereo)) return;
+  const int n = (sec >= 4 && a.fixedN >= 0) ? min(a.fixedN, a.cap) : min(a.nOut[img], a.cap);
+  const uint32_t* src;
+  uint32_t* dst;
+  int len;
+  if (sec < 2) {
+    src = a.kps + (size_t)img * a.cap * 7; dst = a.hKps + (size_t)img * a.cap * 7; len = n * 7;
+  } else if (sec < 4) {
+    src = a.desc + (size_t)img * a.cap * 8; dst = a.hDesc + (size_t)img * a.cap * 8; len = n * 8;
+  } else {
+    src = sec == 4 ? a.uR : a.depth; dst = sec == 4 ? a.hUr : a.hDepth; len = n;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t launch_result_pack(const ResultPack& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_result_pack, dim3(12, 7), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t prepare_kernels(const Geom& g) {
   const size_t lds_oct = octree_lds_bytes(g);
   const size_t lds_det = (size_t)g.tileP * g.tileH + (size_t)g.scoreP * g.scoreH + 2 * kListTotal + 32;
