@@ -97,3 +97,52 @@ def test_c5_allgather_blocks_equal_the_downloads():
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_h2d_inclusive_mode_matches_oracle(oracle):
+    """The mode bench.py's `h2d_inclusive_value` times: frames in HOST memory every step (orbx_extract_batch: upload on the handle's
+    stream), extraction + ComputeStereoMatches, ALL results back through orbx_batch_download_async into host arrays, handles
+    alternating without a synchronisation in between -- every pair of the last two steps against the oracle; dense frames (the
+    tall 2-D upload) and a strided source (one 2-D copy per image)."""
+    import bench
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd import synth
+    from oracle import cpu_bench
+    BF, BASE = bench.BF, bench.BASE
+    assert orbx.device_count() > 0
+    W, H, B, NF = 640, 480, 4, 1000
+    pairs = [synth.stereo_pair(W, H, 400 + i) for i in range(2 * B)]
+    exs = [orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B) for _ in range(2)]
+    cap = exs[0].capacity
+    outs = []
+    for step in range(2):
+        ex = exs[step]
+        sel = pairs[step * B:(step + 1) * B]
+        if step == 0:   # dense [2B, H, W]
+            host = np.ascontiguousarray(np.stack([p[0] for p in sel] + [p[1] for p in sel]))
+            row_pitch, img_pitch = W, W * H
+        else:           # strided rows and a gap between images
+            host = np.zeros((2 * B, H + 3, W + 24), np.uint8)
+            for i, im in enumerate([p[0] for p in sel] + [p[1] for p in sel]):
+                host[i, :H, :W] = im
+            row_pitch, img_pitch = W + 24, (H + 3) * (W + 24)
+        r = dict(cnt=np.zeros(2 * B, np.int32), mono=np.zeros(2 * B, np.int32), kps=np.zeros((2 * B, cap), orbx.KP_DTYPE),
+                 desc=np.zeros((2 * B, cap, 32), np.uint8), ur=np.zeros((B, cap), np.float32), dp=np.zeros((B, cap), np.float32), host=host)
+        ex.extract_batch_host(host.ctypes.data, 2 * B, W, H, row_pitch, img_pitch)
+        orbx.stereo_match_async(ex, ex, BF, BASE, first_left=0, first_right=B, n_pairs=B)
+        ex.download_async(r["cnt"].ctypes.data, r["mono"].ctypes.data, r["kps"].ctypes.data, r["desc"].ctypes.data,
+                          r["ur"].ctypes.data, r["dp"].ctypes.data, B)
+        outs.append(r)                       # no synchronisation between the two steps
+    for ex in exs:
+        ex.sync()
+    for step in range(2):
+        r = outs[step]
+        sel = pairs[step * B:(step + 1) * B]
+        ref = cpu_bench.oracle_pairs([p[0] for p in sel], [p[1] for p in sel], NF, BF, BASE)
+        for p, (kL, dL, kR, dR, u, dep) in enumerate(ref):
+            nL, nR = int(r["cnt"][p]), int(r["cnt"][B + p])
+            assert (nL, nR) == (len(kL), len(kR)) and nL > 900
+            assert r["kps"][p, :nL].tobytes() == kL.tobytes() and np.array_equal(r["desc"][p, :nL], dL)
+            assert r["kps"][B + p, :nR].tobytes() == kR.tobytes() and np.array_equal(r["desc"][B + p, :nR], dR)
+            assert r["ur"][p, :nL].tobytes() == u.tobytes() and r["dp"][p, :nL].tobytes() == dep.tobytes()
