@@ -146,3 +146,51 @@ def test_h2d_inclusive_mode_matches_oracle(oracle):
             assert r["kps"][p, :nL].tobytes() == kL.tobytes() and np.array_equal(r["desc"][p, :nL], dL)
             assert r["kps"][B + p, :nR].tobytes() == kR.tobytes() and np.array_equal(r["desc"][B + p, :nR], dR)
             assert r["ur"][p, :nL].tobytes() == u.tobytes() and r["dp"][p, :nL].tobytes() == dep.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,w,h,nf", [("mono", 640, 480, 1000), ("fisheye", 512, 512, 1500), ("stereo", 640, 480, 1000)])
+def test_other_configs_workloads_match_the_oracle(oracle, mode, w, h, nf):
+    """The workloads behind bench.py's `other_configs` legs (C2 640x480 mono, 640x480 stereo, C4 512x512 fisheye stereo with
+    lapping areas + the batched 2-NN / KB8 association): bench.Workload with exactly the arguments that leg passes, steps enqueued
+    without a synchronisation, then every image of every handle's last batch against the oracle; the fisheye association's integer
+    outputs against the oracle on the same keypoints (its float tail has its own tolerance tests, tests/test_fisheye.py)."""
+    import bench
+    import orb_slam3_fast_amd as orbx
+    a = bench.parse(["--mode", mode, "--width", str(w), "--height", str(h), "--nfeatures", str(nf), "--pairs", "8", "--distinct", "8"])
+    wl = bench.Workload(a)
+    for _ in range(5):
+        wl.step()
+    wl.sync()
+    B = a.pairs
+    checked = 0
+    for hnd, ex in enumerate(wl.exs):
+        slot = wl.last_slot[hnd]
+        if slot is None:
+            continue
+        imgs = list(wl.host_left[slot]) + list(wl.host_right[slot])
+        got = [ex.download(i) for i in range(2 * B)]
+        for i, img in enumerate(imgs):
+            lap = (0, 0) if wl.lap is None else tuple(int(v) for v in wl.lap[i])
+            oe = oracle.OracleExtractor(nf)
+            om, ok_, od = oe.extract(np.ascontiguousarray(img), lap)
+            m, k, d = got[i]
+            assert m == om and np.array_equal(_kb(k), _kb(ok_)) and np.array_equal(d, od), (mode, hnd, i)
+            checked += 1
+        if mode == "fisheye":
+            sig2 = oracle.OracleExtractor(nf).tables()["sigma2"]
+            for p in range(B):
+                n, nd, l2r, r2l, dep, pts = orbx.fisheye_download(ex, ex, p)
+                (mL, kL, dL), (mR, kR, dR) = got[p], got[B + p]
+                on, ond, ol2r, or2l, odep, opts, gates = oracle.fisheye_stereo_match(kL, dL, mL, kR, dR, mR, wl.rig, sig2)
+                assert nd == ond                      # ratio-test survivors: integer work, exact
+                same = l2r[:len(kL)] == ol2r
+                assert same.mean() > 0.995 and abs(n - on) <= 2   # accept / reject may flip only at a gate (tests/test_fisheye.py)
+        elif mode == "stereo":
+            ref = __import__("oracle.cpu_bench", fromlist=["x"]).oracle_pairs(wl.host_left[slot], wl.host_right[slot], nf, bench.BF, bench.BASE)
+            for p in range(B):
+                u, dep = np.zeros(ex.capacity, np.float32), np.zeros(ex.capacity, np.float32)
+                orbx._check(orbx.lib().orbx_stereo_download(ex._h, p, orbx._p(u), orbx._p(dep), ex.capacity))
+                n = len(ref[p][0])
+                assert u[:n].tobytes() == ref[p][4].tobytes() and dep[:n].tobytes() == ref[p][5].tobytes()
+    assert checked == 2 * B * len(wl.exs)
