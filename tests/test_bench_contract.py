@@ -92,7 +92,7 @@ def test_bench_prints_one_contract_line(mode):
         assert d["h2d_inclusive"]["link_upload_GBps"] > 0 and d["h2d_inclusive"]["frac_of_link_bound"] > 0   # (tiny frames here: latency, not bandwidth)
         npair = d["natural_pair"]   # the Middlebury pair through the product path: the oracle's numbers (tests/test_natural_images.py)
         assert (npair["keypoints_left"], npair["keypoints_right"], npair["stereo_matches"]) == (1504, 1508, 595)
-        assert d["latency_with_host_pyramid_ms"]["mean"] >= d["latency_ms"]["p50"] * 0.9
+        assert d["latency_with_host_pyramid_ms"]["mean"] >= d["latency_ms"]["p50"] * 0.5   # (more work, never less: a loose bound, not a timing test)
     assert 0.5 < rf["shader_clock_ghz"] < 2.6    # measured, not assumed
 
 
