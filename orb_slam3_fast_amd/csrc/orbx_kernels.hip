@@ -293,6 +293,22 @@ constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2,
 constexpr int kListTotal = 704;  // u16 entries of k_detect's one LDS list: corners [0, nList), then compass survivors [nList, sEnd)
 constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
 constexpr int kLoadRows = 12;   // rows per lane the tile loader of k_detect keeps in flight
+#ifndef ORBX_DETECT_WIDE_LOAD
+#define ORBX_DETECT_WIDE_LOAD 1
+#endif
+constexpr bool kDetectWideLoad = ORBX_DETECT_WIDE_LOAD != 0;   // unaligned 16 / 8 / 4-byte tile loads for the compile-time pitches
+struct __attribute__((packed, aligned(1))) U128Unaligned { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 load_u128_unaligned(const uint8_t* p) {  // one global_load_dwordx4 at any byte address (HSA runs
+  const U128Unaligned t = *reinterpret_cast<const U128Unaligned*>(p);     // the memory pipeline in unaligned-access mode)
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+struct __attribute__((packed, aligned(1))) U64Unaligned { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) U32Unaligned { uint32_t x; };
+__device__ __forceinline__ uint2 load_u64_unaligned(const uint8_t* p) {
+  const U64Unaligned t = *reinterpret_cast<const U64Unaligned*>(p);
+  return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { return reinterpret_cast<const U32Unaligned*>(p)->x; }
 
 // Necessary condition for a 9-arc: two cyclically adjacent compass pixels (ring 0, 4, 8, 12) of the same
 // polarity.  Per pixel slot 10 VALU operations and one scalar OR.  Returns the wave mask of lanes whose pixel survives.
@@ -482,6 +498,44 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
+  bool tileDone = false;
+  if (TPC != 0 && kDetectWideLoad) {
+    // Fast loader for the compile-time tile pitches: a row is TPC / P pieces of P = 16, 8 or 4 bytes (the largest power of two that
+    // divides the pitch: 48 -> 3 x 16, 56 -> 7 x 8, 44 / 52 -> 11 / 13 x 4); lane = (row, piece), one UNALIGNED global load
+    // straight from the ROI's first byte and one aligned LDS store per piece -- no funnel shift, no second dword, a third (16-byte
+    // pieces) to two thirds (dwords) of the dword loader's trips.  Only when all TPC bytes of a row lie inside the image row
+    // (every cell but the last column of a level); bytes past the ROI width are never consumed (masked lanes).
+    constexpr int P = (TPC % 16 == 0) ? 16 : (TPC % 8 == 0) ? 8 : 4, PPR = TPC ? TPC / P : 1;
+    constexpr uint32_t kInv = (65536u + PPR - 1) / PPR;   // it / PPR == (it * kInv) >> 16 for it < 4096 (checked below)
+    static_assert(PPR * ((4095u * kInv) >> 16) <= 4095u && (4095u / PPR) == ((4095u * kInv) >> 16), "reciprocal division");
+    if (iniX + TPC <= L.w) {
+      const uint8_t* rowBase = im + (long long)iniY * pitch + iniX;   // wave-uniform
+      const int nItems = rh * PPR;                                    // <= 78 rows x 13 pieces
+      constexpr int kB = 3;   // loads in flight per lane and batch
+      for (int base = 0; base < nItems; base += 64 * kB) {
+        uint4 v[kB];
+        int dst[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+          const int it = min(base + lane + 64 * u, nItems - 1);   // the tail re-writes the last item
+          const int r = (int)(((uint32_t)it * kInv) >> 16), c = it - PPR * r;
+          const uint8_t* src = rowBase + (uint32_t)(__mul24(r, pitch) + P * c);
+          if (P == 16) v[u] = load_u128_unaligned(src);
+          else if (P == 8) { const uint2 t = load_u64_unaligned(src); v[u] = make_uint4(t.x, t.y, 0, 0); }
+          else v[u] = make_uint4(load_u32_unaligned(src), 0, 0, 0);
+          dst[u] = r * TPC + P * c;
+        }
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+          if (P == 16) *reinterpret_cast<uint4*>(smem + dst[u]) = v[u];
+          else if (P == 8) *reinterpret_cast<uint2*>(smem + dst[u]) = make_uint2(v[u].x, v[u].y);
+          else *reinterpret_cast<uint32_t*>(smem + dst[u]) = v[u].x;
+        }
+      }
+      tileDone = true;
+    }
+  }
+  if (!tileDone)
   {  // tile load: ROI column 0 -> LDS byte 0 of the row (funnel shift of two aligned global dwords)
     // lane = (row phase, dword column): 16 columns x 4 rows per pass, no index divisions in the loop.  All of a lane's
     // rows (kLoadRows per batch = 48 tile rows) are requested before the first one is consumed: one memory latency
