@@ -495,6 +495,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   const int qpr = (dw + 3) >> 2;  // quads per detect row
   const int nq = qpr * dh;
   const float inv_qpr = 1.0f / (float)qpr;
+  const float inv_tp = __builtin_amdgcn_rcpf((float)TP);
 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
@@ -607,22 +608,22 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
         const int rem = nSurv - base;
         const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
-        const int yxA = list[s0 + min(base + lane, nSurv - 1)], yxB = list[s0 + min(base + 64 + lane, nSurv - 1)];
-        const int yA = yxA >> 8, xA = yxA & 255, yB = yxB >> 8, xB = yxB & 255;
-        const int oA = __mul24(yA, TP) + xA, oB = __mul24(yB, TP) + xB;  // top-left corners of the 7x7 windows
+        // a list entry IS the tile byte offset y * TP + x of the pixel's 7x7 window corner (image and score tile share the
+        // pitch): no unpacking of (y, x) and no multiply per survivor / corner; (x, y) is only recovered when a corner is emitted
+        const int oA = list[s0 + min(base + lane, nSurv - 1)], oB = list[s0 + min(base + 64 + lane, nSurv - 1)];
         const orbx_h2 M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
         const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
         if (__builtin_amdgcn_inverse_ballot_w64(mA)) {
           score8[oA + SPB + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);  // (y + 1) * pitch + x + 4: same pitch as the image tile
           const int o = nList + prefix_count(mA);  // <= the position of the survivor it replaces
-          if (o < cornerCap) list[o] = (uint16_t)yxA;
+          if (o < cornerCap) list[o] = (uint16_t)oA;
         }
         nList += __popcll(mA);
         if (__builtin_amdgcn_inverse_ballot_w64(mB)) {
           score8[oB + SPB + 4] = (uint8_t)((Mbits >> 16) - 1);
           const int o = nList + prefix_count(mB);
-          if (o < cornerCap) list[o] = (uint16_t)yxB;
+          if (o < cornerCap) list[o] = (uint16_t)oB;
         }
         nList += __popcll(mB);
       }
@@ -637,7 +638,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     for (int qb = 0; qb < nq; qb += 64) {
       const uint64_t actM = low_lanes_pos(nq - qb);
       const int ydc = min(yd, dh - 1);  // idle lanes of the last round stay inside the tile (masked out below)
-      const uint32_t* row0 = tile + __mul24(ydc, TPd) + j;  // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+      const int q0 = __mul24(ydc, TPd) + j;                 // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+      const uint32_t* row0 = tile + q0;
       uint32_t r[7][3];
 #pragma unroll
       for (int i = 0; i < 7; i++) {
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       sm[3] = compass_wave<3>(r, t) & actM & (notLast | keep3);
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (sEnd + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > listTotal) flush_survivors();
-      const int yx = (ydc << 8) | (4 * j);
+      const int yx = q0 << 2;   // tile byte offset of the quad's first pixel window (a multiple of 4: | pI adds the pixel)
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
@@ -683,8 +685,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       // common case: every corner of the cell is still in the list -> dense lanes, 9 LDS byte reads each, no branches
       const int SP = SPB;
       for (int base = 0; base < nCorners; base += 64) {
-        const int yx = list[min(base + lane, nCorners - 1)], y = yx >> 8, x = yx & 255;
-        const uint8_t* c8 = score8 + __mul24(y, SP) + x + 3;  // top-left of the 3x3 neighbourhood
+        const int oc = list[min(base + lane, nCorners - 1)];
+        const uint8_t* c8 = score8 + oc + 3;  // top-left of the 3x3 neighbourhood
         const int sc = c8[SP + 1];
         const int n0 = max(max((int)c8[0], (int)c8[1]), (int)c8[2]);
         const int n1 = max(max((int)c8[SP], (int)c8[SP + 2]), (int)c8[2 * SP]);
@@ -692,6 +694,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         const uint64_t m = __ballot(sc > max(n1, n2)) & low_lanes(nCorners - base);
         if (__builtin_amdgcn_inverse_ballot_w64(m)) {
           const int o = kept + prefix_count(m);
+          // (x, y) from the offset: oc / TP by a 1-ulp reciprocal ((oc + 0.5) / TP stays 0.5 / TP away from the next integer)
+          const int y = (int)(((float)oc + 0.5f) * inv_tp), x = oc - __mul24(y, SP);
           if (o < L.cellCap) out[o] = pack_key(iniX + 3 + x - kBorder, iniY + 3 + y - kBorder, sc);
         }
         kept += __popcll(m);
