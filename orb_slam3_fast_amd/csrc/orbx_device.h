@@ -61,6 +61,30 @@ __device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {  // minimum over 
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// XCD-aware block -> tile mapping.  Workgroups go to the 8 XCDs round-robin by flat workgroup id, so neighbouring
+// tiles land in 8 different L2s and every shared halo line is fetched from HBM once per XCD.  This permutation keeps
+// the dispatch order balanced (every aligned chunk of 8*K flat ids still covers the same 8*K tiles) but hands each
+// XCD a run of K consecutive tiles.  `by` is the slower grid index (image); chunks cut by an image boundary keep
+// the identity order.
+__device__ __forceinline__ int xcd_run_remap_rt(int bx, int nbx, int by, int K) {  // run length chosen at run time
+  if (K <= 1) return bx;
+  const int o = (int)(((unsigned)by * (unsigned)nbx) & 7u), xs = bx + o, ch = 8 * K;
+  const int c0 = (xs / ch) * ch;
+  if (c0 < o || c0 + ch > nbx + o) return bx;
+  const int r = xs - c0;
+  return c0 + (r & 7) * K + (r >> 3) - o;
+}
+template <int K>
+__device__ __forceinline__ int xcd_run_remap(int bx, int nbx, int by) {
+  if (K <= 1) return bx;
+  constexpr int ch = 8 * K;  // (K a power of two: the chunk arithmetic is shifts and masks)
+  const int o = (int)(((unsigned)by * (unsigned)nbx) & 7u), xs = bx + o;
+  const int c0 = xs & ~(ch - 1);
+  if (c0 < o || c0 + ch > nbx + o) return bx;
+  const int r = xs - c0;
+  return c0 + (r & 7) * K + (r >> 3) - o;
+}
+
 __device__ __forceinline__ int hamming256(const uint32_t* a, const uint32_t* b) {
   int d = 0;
 #pragma unroll

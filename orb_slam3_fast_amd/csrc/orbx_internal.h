@@ -383,6 +383,7 @@ hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
 hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s);
 hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s);
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
+hipError_t prepare_detect(const Geom& g);                              // (orbx_detect.hip)
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);
 void debug_set_octree_global(int on);
