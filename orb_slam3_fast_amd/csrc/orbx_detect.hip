@@ -20,6 +20,12 @@ namespace orbx {
 // 9-windows of minima / maxima built from 3-windows); corner iff M > t, score M - 1.  Then list-based 3x3 NMS.
 constexpr int kRingDX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 constexpr int kRingDY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#ifndef ORBX_COMPASS_PAIRS
+#define ORBX_COMPASS_PAIRS 1
+#endif
+#ifndef ORBX_ROW_ROUNDS
+#define ORBX_ROW_ROUNDS 1
+#endif
 constexpr int kListTotal = 704;  // u16 entries of k_detect's one LDS list: corners [0, nList), then compass survivors [nList, sEnd)
 constexpr int kDetectXcdRun = 8;  // cells per XCD run of k_detect's block order (1 = plain order fetched 2.7x the bytes)
 constexpr int kLoadRows = 12;   // rows per lane the tile loader of k_detect keeps in flight
@@ -77,6 +83,25 @@ __device__ __forceinline__ orbx_h2 pk_min3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
 __device__ __forceinline__ orbx_h2 pk_max3(orbx_h2 a, orbx_h2 b, orbx_h2 c) {
   return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c);
 }
+// The same necessary condition on TWO horizontally adjacent pixels (P, P + 1) in packed f16 (round 4): the five operands of
+// the pair -- centre, ring 0 / 8 (rows 6 / 0, same columns), ring 4 / 12 (row 3, columns +3 / -3) -- are spread from the row
+// dwords by one v_perm each ([b, 0, b', 0] = two f16 subnormal patterns), then 6 packed min / max, two packed subtractions, one
+// packed max and two compares: 16 instructions per pair instead of 20.  M' = max(hiMin - c, c - loMax) > t, exact like stage 2.
+template <int P>
+__device__ __forceinline__ void compass_pair(const uint32_t (&r)[7][3], orbx_h2 th2, uint64_t& m0, uint64_t& m1) {
+  auto spread = [&](int row, int b) {  // bytes b, b + 1 of the 12-byte row -> (f16 pattern, f16 pattern)
+    const int d = (b + 1 <= 7) ? 0 : 1, i = b - 4 * d;
+    const uint32_t sel = 0x0c000c00u | (uint32_t)i | ((uint32_t)(i + 1) << 16);
+    return __builtin_bit_cast(orbx_h2, __builtin_amdgcn_perm(r[row][d + 1], r[row][d], sel));
+  };
+  const orbx_h2 c = spread(3, 3 + P), v0 = spread(6, 3 + P), v8 = spread(0, 3 + P), v4 = spread(3, 6 + P), v12 = spread(3, P);
+  const orbx_h2 hiMin = __builtin_elementwise_minimum(__builtin_elementwise_maximum(v0, v8), __builtin_elementwise_maximum(v4, v12));
+  const orbx_h2 loMax = __builtin_elementwise_maximum(__builtin_elementwise_minimum(v0, v8), __builtin_elementwise_minimum(v4, v12));
+  const orbx_h2 M = __builtin_elementwise_maximum(hiMin - c, c - loMax);
+  m0 = __ballot(M.x > th2.x);
+  m1 = __ballot(M.y > th2.y);
+}
+
 // a8 / b8 point at the TOP-LEFT corner of each pixel's 7x7 window, so every ring offset is a non-negative ds_read immediate.
 typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
@@ -192,6 +217,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   }
 
   const int TP = TPC ? TPC : g.tileP, SPB = TP;  // pitch of the image tile and of the score tile, bytes (tileP == scoreP)
+  constexpr bool kRowRounds = ORBX_ROW_ROUNDS && (TPC == 44 || TPC == 48 || TPC == 56);
   const int TPd = TP >> 2, SPd = SPB >> 2;                          // and in dwords
   uint32_t* tile = reinterpret_cast<uint32_t*>(smem);
   uint32_t* score = tile + ((TPd * g.tileH + 3) & ~3);  // 16-byte aligned: cleared with b128 stores
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   const int nScore16 = (SPd * (dh + 2) + 3) >> 2;
   for (int pass = 0; pass < 2; pass++) {
     const int t = pass == 0 ? g.iniTh : g.minTh;
+    const orbx_h2 tc2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);  // t as two f16 subnormal patterns
     // clear the score tile (16-byte stores; its zero ring is part of it).  The barrier also publishes the image tile.
     for (int i = lane; i < nScore16; i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -347,11 +374,26 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       __syncthreads();
       sEnd = nList;
     };
+    // Rounds.  kRowRounds (round 4, the pitches whose rows fill a wave well): a round is dq = floor(64 / qpr) WHOLE detect rows, a
+    // lane keeps its (row in round, quad) and a round is one address increment -- no per-round stepping of (row, quad), no
+    // clamp, the last-quad mask is loop invariant; 1 .. 4 lanes idle (9 / 10 / 12 quads per row: 63 / 60 / 60 lanes).  Otherwise
+    // the quads are dealt to the lanes flat.  Lanes past the window read rows below the tile (still this block's LDS: masked).
     int yd = yd0, j = j0;
-    for (int qb = 0; qb < nq; qb += 64) {
-      const uint64_t actM = low_lanes_pos(nq - qb);
-      const int ydc = min(yd, dh - 1);  // idle lanes of the last round stay inside the tile (masked out below)
-      const int q0 = __mul24(ydc, TPd) + j;                 // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+    int q0r = __mul24(yd0, TPd) + j0;
+    const uint64_t notLastR = ~__ballot(j0 == qpr - 1);
+    const int nRounds = kRowRounds ? (dh + dq - 1) / dq * 64 : nq;  // (as a quad count, so that one loop serves both schemes)
+    for (int qb = 0; qb < nRounds; qb += 64) {
+      uint64_t actM;
+      int q0;
+      if (kRowRounds) {
+        actM = low_lanes_pos(min(dq, dh - (qb >> 6) * dq) * qpr);
+        q0 = q0r;
+        q0r += dq * TPd;
+      } else {
+        actM = low_lanes_pos(nq - qb);
+        const int ydc = min(yd, dh - 1);  // idle lanes of the last round stay inside the tile (masked out below)
+        q0 = __mul24(ydc, TPd) + j;       // (24-bit multiplies are full rate, v_mul_lo_u32 a quarter)
+      }
       const uint32_t* row0 = tile + q0;
       uint32_t r[7][3];
 #pragma unroll
@@ -360,12 +402,21 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         r[i][1] = row0[i * TPd + 1];
         r[i][2] = row0[i * TPd + 2];
       }
-      const uint64_t notLast = ~__ballot(j == qpr - 1);  // a row's last quad may reach past the detectable window
+      const uint64_t notLast = kRowRounds ? notLastR : ~__ballot(j == qpr - 1);  // a row's last quad may reach past the detectable window
       uint64_t sm[4];
+#if ORBX_COMPASS_PAIRS
+      compass_pair<0>(r, tc2, sm[0], sm[1]);
+      compass_pair<2>(r, tc2, sm[2], sm[3]);
+      sm[0] &= actM;
+      sm[1] &= actM & (notLast | keep1);
+      sm[2] &= actM & (notLast | keep2);
+      sm[3] &= actM & (notLast | keep3);
+#else
       sm[0] = compass_wave<0>(r, t) & actM;
       sm[1] = compass_wave<1>(r, t) & actM & (notLast | keep1);
       sm[2] = compass_wave<2>(r, t) & actM & (notLast | keep2);
       sm[3] = compass_wave<3>(r, t) & actM & (notLast | keep3);
+#endif
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (sEnd + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > listTotal) flush_survivors();
       const int yx = q0 << 2;   // tile byte offset of the quad's first pixel window (a multiple of 4: | pI adds the pixel)
@@ -377,11 +428,13 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
               (uint16_t)(yx | pI);  // (the running end of the list rides in v_mbcnt's accumulator operand)
         sEnd += __popcll(m);
       }
-      j += rq;
-      yd += dq;
-      if (j >= qpr) {
-        j -= qpr;
-        yd++;
+      if (!kRowRounds) {
+        j += rq;
+        yd += dq;
+        if (j >= qpr) {
+          j -= qpr;
+          yd++;
+        }
       }
     }
     flush_survivors();
@@ -670,10 +723,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(ORBX_STACK_SGPRS
           r[i][2] = row0[i * TPd + 2];
         }
         const uint64_t notLast = ~__ballot(j == qpr - 1);  // a row's last quad may reach past the detectable window
+#if ORBX_COMPASS_PAIRS
+        const orbx_h2 tc2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);
+        compass_pair<0>(r, tc2, sm[0], sm[1]);
+        compass_pair<2>(r, tc2, sm[2], sm[3]);
+        sm[0] &= actM;
+        sm[1] &= actM & (vlast > 1 ? ~0ull : notLast);
+        sm[2] &= actM & (vlast > 2 ? ~0ull : notLast);
+        sm[3] &= actM & (vlast > 3 ? ~0ull : notLast);
+#else
         sm[0] = compass_wave<0>(r, t) & actM;
         sm[1] = compass_wave<1>(r, t) & actM & (vlast > 1 ? ~0ull : notLast);
         sm[2] = compass_wave<2>(r, t) & actM & (vlast > 2 ? ~0ull : notLast);
         sm[3] = compass_wave<3>(r, t) & actM & (vlast > 3 ? ~0ull : notLast);
+#endif
         cnt = (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3]));
         yx = q0 << 2;  // tile byte offset of the quad's first pixel window (a multiple of 4: | pI adds the pixel)
       }
@@ -874,11 +937,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(ORBX_STACK_SGPRS
 static int g_detect_list_cap = 1 << 20;  // test hook: a smaller list forces the flush / carry / corner-overflow paths
 void debug_set_detect_list_cap(int cap) { g_detect_list_cap = cap < 320 ? 320 : cap; }
 
-// cells per stack of k_detect_stack: ORBX_DETECT_NC = 0 (one-wave-per-cell kernel only), 1, 2 (default), 3; read once
+// cells per stack of k_detect_stack: ORBX_DETECT_NC = 0 (default: one wave per cell only), 1, 2, 3 (experimental); read once
 static int detect_nc() {
   static const int nc = [] {
     const char* e = getenv("ORBX_DETECT_NC");
-    const int v = e ? atoi(e) : 2;
+    const int v = e ? atoi(e) : 0;
     return v < 0 ? 0 : (v > 3 ? 3 : v);
   }();
   return nc;
