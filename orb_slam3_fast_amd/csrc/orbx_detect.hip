@@ -233,7 +233,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(tile);
   const int qpr = (dw + 3) >> 2;  // quads per detect row
   const int nq = qpr * dh;
-  const float inv_qpr = 1.0f / (float)qpr;
+  // 1-ulp reciprocals suffice: (lane + 0.5) / qpr and 64.5 / qpr stay 0.5 / qpr away from the next integer (an IEEE division is 12
+  // instructions, an integer division ~ 30)
+  const float inv_qpr = __builtin_amdgcn_rcpf((float)qpr);
   const float inv_tp = __builtin_amdgcn_rcpf((float)TP);
 
   int pitch;
@@ -356,14 +358,14 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
         if (__builtin_amdgcn_inverse_ballot_w64(mA)) {
           score8[oA + SPB + 4] = (uint8_t)((Mbits & 0xFFFFu) - 1);  // (y + 1) * pitch + x + 4: same pitch as the image tile
-          const int o = nList + prefix_count(mA);  // <= the position of the survivor it replaces
-          if (o < cornerCap) list[o] = (uint16_t)oA;
+          const int k = prefix_count(mA);  // nList + k <= the position of the survivor it replaces
+          if (k < cornerCap - nList) (list + nList)[k] = (uint16_t)oA;
         }
         nList += __popcll(mA);
         if (__builtin_amdgcn_inverse_ballot_w64(mB)) {
           score8[oB + SPB + 4] = (uint8_t)((Mbits >> 16) - 1);
-          const int o = nList + prefix_count(mB);
-          if (o < cornerCap) list[o] = (uint16_t)oB;
+          const int k = prefix_count(mB);
+          if (k < cornerCap - nList) (list + nList)[k] = (uint16_t)oB;
         }
         nList += __popcll(mB);
       }
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     int yd = yd0, j = j0;
     int q0r = __mul24(yd0, TPd) + j0;
     const uint64_t notLastR = ~__ballot(j0 == qpr - 1);
-    const int nRounds = kRowRounds ? (dh + dq - 1) / dq * 64 : nq;  // (as a quad count, so that one loop serves both schemes)
+    // ceil(dh / dq) = floor((dh - 0.5) / dq) + 1; as a quad count, so that one loop serves both schemes
+    const int nRounds = kRowRounds ? ((int)(((float)dh - 0.5f) * __builtin_amdgcn_rcpf((float)dq)) + 1) * 64 : nq;
     for (int qb = 0; qb < nRounds; qb += 64) {
       uint64_t actM;
       int q0;
@@ -424,8 +427,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
         if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
-          list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)sEnd))] =
-              (uint16_t)(yx | pI);  // (the running end of the list rides in v_mbcnt's accumulator operand)
+          (list + sEnd)[prefix_count(m)] = (uint16_t)(yx | pI);  // (the running end of the list is the store's scalar base)
         sEnd += __popcll(m);
       }
       if (!kRowRounds) {
