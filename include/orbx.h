@@ -70,6 +70,14 @@ void orbx_extractor_destroy(orbx_extractor* ex);
 int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2,
                     float* inv_sigma2, int32_t* nfeatures_per_level, int32_t* umax16);
 
+/* Which OpenCV the reference build links decides the descriptor bits: cv::GaussianBlur(7x7, sigma 2) of ORBextractor::operator()
+ * (src/ORBextractor.cc:1074-1076) runs on 8-bit fixed-point taps that changed between releases -- {18,34,49,55,49,34,18} / 256 in
+ * OpenCV 4.0 .. 4.5.0 (the README's "tested with 4.4.0", README.md:101; the taps sum to 257, results saturate at 255) and
+ * {18,34,48,56,48,34,18} / 256 from 4.5.1 on (CMakeLists.txt:38-41 asks for "> 4.4"; what distributions ship).
+ * opencv_version = 440 or 451 (the default); anything else is ORBX_E_BADARG.  Applies to every later extraction of the handle
+ * (k_describe's per-keypoint blur and the blurred levels of orbx_pyramid_level).  OpenCV 3.x's float filter is not modelled. */
+int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version);
+
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:1015-1106) for ONE host image (CV_8UC1, `stride`
  * bytes per row).  lap0/lap1 = vLappingArea.  Writes *n_out keypoints (serial-order slots: mono from the
  * front, lapping from the back) and n_out x 32 descriptor bytes.  Returns monoIndex (>= 0), ORBX_E_EMPTY for

@@ -76,6 +76,10 @@ class OracleExtractor:
             lib().oro_destroy(self.h)
             self.h = None
 
+    def set_blur_taps(self, variant):
+        """GaussianBlur taps of OpenCV 4.0 .. 4.5.0 (440) or >= 4.5.1 (451, the default): orb_oracle.cpp kBlurTaps440 / 451."""
+        lib().oro_set_blur_taps(self.h, int(variant))
+
     def tables(self):
         L = self.nlevels
         f = [np.zeros(L, np.float32) for _ in range(4)]

@@ -158,6 +158,7 @@ def lib():
         L.orbx_debug_resize_plan.argtypes = [vp, vp, vp, vp, i]
         L.orbx_debug_sincos.argtypes = [i, vp, i, i, vp, vp]
         L.orbx_debug_score_map.argtypes = [vp, i]
+        L.orbx_set_opencv_compat.argtypes = [vp, i]
         L.orbx_debug_score_level.argtypes = [vp, i, i, vp, C.c_ssize_t]
         _lib = L
     return _lib
@@ -350,6 +351,11 @@ class ORBextractor:
         return w, h, nc, ns
 
     # ---- mvImagePyramid (include/ORBextractor.h:86)
+    def set_opencv_compat(self, opencv_version):
+        """Gaussian taps of the reference build's OpenCV (include/orbx.h: orbx_set_opencv_compat): 440 = OpenCV 4.0 .. 4.5.0
+        (README.md:101 "tested with 4.4.0"), 451 = OpenCV >= 4.5.1 (the default)."""
+        _check(lib().orbx_set_opencv_compat(self._h, int(opencv_version)))
+
     def image_pyramid(self, level, image=0, blurred=False):
         w, h = C.c_int(), C.c_int()
         _check(lib().orbx_pyramid_level(self._h, image, level, int(blurred), None, 0, C.byref(w), C.byref(h)))

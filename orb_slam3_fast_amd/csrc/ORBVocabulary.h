@@ -8,6 +8,7 @@
 #ifndef ORBX_SHIM_ORBVOCABULARY_H
 #define ORBX_SHIM_ORBVOCABULARY_H
 
+#include <algorithm>
 #include <map>
 
 #include "ORBextractor.h"
@@ -102,7 +103,7 @@ inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVecKF, const std::vector
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (src/ORBmatcher.cc:766-884; LoopClosing)
-// on plain views: hasGoodMapPoint[i] = vpMapPoints[i] && !isBad() (&& i < mvKeysUn.size() for two-camera rigs);
+// on plain views: hasGoodMapPoint[i] = vpMapPoints[i] && !isBad(), one per feature (two-camera rigs: NLeft + NRight >= mvKeysUn.size());
 // vnMatches12[idx1] = the feature of pKF2 whose map point vpMatches12[idx1] receives (-1: none).
 inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVec1, const std::vector<ocv::KeyPoint>& vKeysUn1, const uint8_t* Descriptors1,
                        const std::vector<uint8_t>& hasGoodMapPoint1, const DBoW2::FeatureVector& vFeatVec2,
@@ -122,14 +123,25 @@ inline int SearchByBoW(const DBoW2::FeatureVector& vFeatVec1, const std::vector<
   std::vector<int32_t> s1, s2;
   flatten(vFeatVec1, n1, s1, f1);
   flatten(vFeatVec2, n2, s2, f2);
-  if (hasGoodMapPoint1.size() != vKeysUn1.size() || hasGoodMapPoint2.size() != vKeysUn2.size())
-    throw std::invalid_argument("SearchByBoW: one map-point flag per keypoint");
-  vnMatches12.assign(vKeysUn1.size(), -1);
+  // One flag per FEATURE (= GetMapPointMatches().size() = descriptor rows).  A two-camera key frame has more features (NLeft +
+  // NRight, all in mFeatVec) than mvKeysUn entries: the reference skips idx >= mvKeysUn.size() (:799, :816), so those features
+  // are flagged invalid here and the keypoint array is padded to the feature count (only matched features' angles are read).
+  if (hasGoodMapPoint1.size() < vKeysUn1.size() || hasGoodMapPoint2.size() < vKeysUn2.size())
+    throw std::invalid_argument("SearchByBoW: one map-point flag per feature (at least one per keypoint)");
+  const size_t N1 = hasGoodMapPoint1.size(), N2 = hasGoodMapPoint2.size();
+  std::vector<uint8_t> v1(hasGoodMapPoint1), v2(hasGoodMapPoint2);
+  std::fill(v1.begin() + (std::ptrdiff_t)vKeysUn1.size(), v1.end(), (uint8_t)0);
+  std::fill(v2.begin() + (std::ptrdiff_t)vKeysUn2.size(), v2.end(), (uint8_t)0);
+  std::vector<ocv::KeyPoint> k1pad, k2pad;
+  const ocv::KeyPoint* k1 = vKeysUn1.data();
+  const ocv::KeyPoint* k2 = vKeysUn2.data();
+  if (N1 > vKeysUn1.size()) { k1pad = vKeysUn1; k1pad.resize(N1); k1 = k1pad.data(); }
+  if (N2 > vKeysUn2.size()) { k2pad = vKeysUn2; k2pad.resize(N2); k2 = k2pad.data(); }
+  vnMatches12.assign(N1, -1);
   const int n = orbx_search_by_bow_keyframes(
-      device, n1.data(), s1.data(), f1.data(), (int)n1.size(), reinterpret_cast<const orbx_keypoint*>(vKeysUn1.data()), Descriptors1,
-      hasGoodMapPoint1.data(), (int)vKeysUn1.size(), n2.data(), s2.data(), f2.data(), (int)n2.size(),
-      reinterpret_cast<const orbx_keypoint*>(vKeysUn2.data()), Descriptors2, hasGoodMapPoint2.data(), (int)vKeysUn2.size(), mfNNratio,
-      mbCheckOrientation ? 1 : 0, vnMatches12.data());
+      device, n1.data(), s1.data(), f1.data(), (int)n1.size(), reinterpret_cast<const orbx_keypoint*>(k1), Descriptors1, v1.data(),
+      (int)N1, n2.data(), s2.data(), f2.data(), (int)n2.size(), reinterpret_cast<const orbx_keypoint*>(k2), Descriptors2, v2.data(),
+      (int)N2, mfNNratio, mbCheckOrientation ? 1 : 0, vnMatches12.data());
   if (n < 0) throw std::runtime_error(std::string("SearchByBoW: ") + orbx_last_error());
   return n;
 }

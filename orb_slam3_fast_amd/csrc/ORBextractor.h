@@ -224,6 +224,13 @@ class ORBextractor {
     }
   }
 
+  // Not in the reference (its OpenCV is chosen at link time): which OpenCV's GaussianBlur taps the descriptors follow --
+  // 440 = OpenCV 4.0 .. 4.5.0 (README.md:101 "tested with 4.4.0"), 451 = OpenCV >= 4.5.1 (default).  include/orbx.h.
+  void SetOpenCVCompat(int opencv_version) {
+    if (orbx_set_opencv_compat(h_, opencv_version) != ORBX_OK)
+      throw std::invalid_argument(std::string("ORBextractor::SetOpenCVCompat: ") + orbx_last_error());
+  }
+
   int inline GetLevels() { return nlevels; }
   float inline GetScaleFactor() { return (float)scaleFactor; }
   std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }

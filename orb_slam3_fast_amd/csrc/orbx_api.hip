@@ -93,6 +93,7 @@ int build_geom(const orbx_extractor* ex, int w, int h, Geom& g, std::string& why
   g.nlevels = L;
   g.iniTh = ex->prm.ini_th_fast;
   g.minTh = ex->prm.min_th_fast;
+  g.cv440 = ex->cv440;
   long long off = 0, candOff = 0, cellOff = 0;
   int cells = 0, sel = 0, xc = 0, yc = 0;
   int maxCW = 0, maxCH = 0;
@@ -646,6 +647,23 @@ int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, fl
   if (inv_sigma2) std::memcpy(inv_sigma2, ex->invsig2.data(), L * sizeof(float));
   if (nfeatures_per_level) std::memcpy(nfeatures_per_level, ex->nfeat.data(), L * sizeof(int));
   if (umax16) std::memcpy(umax16, ex->umax, sizeof(ex->umax));
+  return ORBX_OK;
+}
+
+int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (opencv_version != 440 && opencv_version != 451)
+    return fail(ORBX_E_BADARG, "opencv_version: 440 (OpenCV 4.0 .. 4.5.0) or 451 (OpenCV >= 4.5.1)");
+  const int v = opencv_version == 440 ? 1 : 0;
+  if (v == ex->cv440) return ORBX_OK;
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  HIPC(hipStreamSynchronize(ex->stream));  // queued work keeps the arithmetic it was enqueued with
+  ex->cv440 = v;
+  ex->g.cv440 = v;
+  ex->gmax.cv440 = v;
+  ex->blurValid = false;
+  drop_graphs(ex);  // (a captured pipeline holds the other k_describe instantiation)
   return ORBX_OK;
 }
 

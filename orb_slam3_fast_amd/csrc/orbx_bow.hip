@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void k_bow_vote(BowMatchArgs a) {  // rotHist[
   if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
   int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
   if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
   a.bin[i] = bin;
   atomicAdd(&a.flags[2 + bin], 1);
 }
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(256) void k_tri_match(TriArgs a) {
       if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
       int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
       if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
       atomicAdd(&a.flags[2 + bin], 1);
     }
   }
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(1024) void k_tri_cull(TriArgs a) {
       if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
       int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
       if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
       if (bin != ind1 && bin != ind2 && bin != ind3) {
         a.match[i] = -1;
         removed++;
@@ -611,6 +614,7 @@ __global__ __launch_bounds__(64) void k_bow_match_kf(TriArgs a) {
             if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
             int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
             if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
             atomicAdd(&a.flags[2 + bin], 1);
           }
         }

@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64) void k_init_resolve(InitArgs a) {
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
           int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
           if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
           bins[i1] = (int8_t)bin;
           hist[bin]++;
         }
@@ -503,6 +504,7 @@ __device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
   if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
   int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
   if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
   return bin;
 }
 
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
           int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
           if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
           binIdx[nBin] = (bin << 24) | bestIdx;
           hist[bin]++;
         }
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(256) void k_proj_assign(ProjArgs a) {
         if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
         int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
         if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
         atomicAdd(&a.flags[3 + bin], 1);
       }
     }
@@ -928,6 +932,7 @@ __global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-c
       if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
       int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
       if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
       if (bin != ind1 && bin != ind2 && bin != ind3) {
         a.match[k] = -1;  // CurrentFrame.mvpMapPoints[idx] = NULL, even if a later point re-took the slot
         if (a.claimAll) a.occupied[k] = 0;
@@ -1024,6 +1029,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve_fe(ProjFeArgs a) {
           if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
           int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
           if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
           binIdx[nBin] = (bin << 24) | slot;
           hist[bin]++;
         }
@@ -1297,6 +1303,7 @@ __device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
   if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
   int bin = (int)roundf(__fmul_rn(rot, 1.0f / 30));
   if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
   return bin;
 }
 

@@ -36,7 +36,7 @@ struct Geom {
   int listCap;                   // max pixels in one cell's detectable window
   int selImg;                    // selected-keypoint slots per image (sum of selCap)
   int outCap;                    // output keypoint capacity per image
-  int pad_;
+  int cv440;                     // 1: Gaussian taps of OpenCV 4.0 .. 4.5.0 (orbx_set_opencv_compat), 0: OpenCV >= 4.5.1
   long long pyrImg;              // bytes per image of the internal pyramid block
   long long candImg;             // dense candidate entries per image
   long long cellImg;             // per-cell slot entries per image

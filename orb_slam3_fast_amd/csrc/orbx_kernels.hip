@@ -1601,7 +1601,11 @@ __device__ __forceinline__ int reflect101(int p, int n) {
 // 18,34,48,56 | 48,34,18,0) for TWO vertically adjacent rows and stores them as u16 pairs (row r | row r+1 << 16;
 // max 255*256 fits).  Vertical pass: a thread owns a 4x4 output block; with rows packed in pairs the 7-tap
 // column filter is 3 v_dot2_u32_u16 + 1 mad per output.  All integer, exact; one rounding (+32768 >> 16).
+// T440: the taps of OpenCV 4.0 .. 4.5.0 {18,34,49,55,49,34,18} (they sum to 257: the result saturates at 255) instead of
+// {18,34,48,56,48,34,18} (OpenCV >= 4.5.1) -- orbx_set_opencv_compat, Geom::cv440.
+template <bool T440>
 __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int level1, int xcdRun) {
+  constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
   __shared__ uint32_t in[BL_TH + 6][BL_TW / 4 + 2 + 1];    // +1: pad against bank conflicts
   __shared__ uint32_t hp[(BL_TH + 6) / 2][BL_TW + 1];      // [row pair][32*(x%4) + x/4] = H(2j, x) | H(2j+1, x) << 16
                                                            // (quad-transposed columns: both passes bank-conflict free)
@@ -1659,7 +1663,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
 #pragma unroll
     for (int rr = 0; rr < 2; rr++) {
       const uint32_t Lw = in[2 * j + rr][c], C = in[2 * j + rr][c + 1], R = in[2 * j + rr][c + 2];
-      const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps -3..0 and +1..+3 (LSB = lowest x)
+      const uint32_t wA = 18u | (34u << 8) | (kT2 << 16) | (kT3 << 24), wB = kT2 | (34u << 8) | (18u << 16);  // taps -3..0 and +1..+3 (LSB = lowest x)
       h[rr][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 1), wA,
                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(R, C, 1), wB, 0, false), false);
       h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(C, Lw, 2), wA,
@@ -1684,8 +1688,8 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
       for (int k = 0; k < 5; k++) pr[k] = hp[2 * br + k][32 * cI + bc];  // lanes read consecutive dwords
       // taps {18,34,48,56,48,34,18} on rows r..r+6; the lone 7th tap is a dot2 with a zero partner and the rounding
       // constant rides in as the first accumulator, so an output is 4 v_dot2_u32_u16
-      const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16), w6 = 18u;  // even r
-      const uint32_t v0 = 18u << 16, v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);  // odd r
+      const uint32_t w01 = 18u | (34u << 16), w23 = kT2 | (kT3 << 16), w45 = kT2 | (34u << 16), w6 = 18u;  // even r
+      const uint32_t v0 = 18u << 16, v12 = 34u | (kT2 << 16), v34 = kT3 | (kT2 << 16), v56 = 34u | (18u << 16);  // odd r
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int k0 = rr >> 1;
@@ -1701,7 +1705,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
           acc = udot2_u16(pr[k0 + 2], v34, acc);
           acc = udot2_u16(pr[k0 + 3], v56, acc);
         }
-        accs[rr][cI] = acc;  // result byte = bits 16..23
+        accs[rr][cI] = T440 ? min(acc, 0x00FFFFFFu) : acc;  // result byte = bits 16..23 (257-sum taps: saturated at 255)
       }
     }
 #pragma unroll
@@ -1723,7 +1727,8 @@ hipError_t launch_blur(const Geom& g, const Pyr& p, int nimg, int level0, int le
   for (int l = level0; l < level1; l++)
     tiles += ((g.lv[l].w + BL_TW - 1) / BL_TW) * ((g.lv[l].h + BL_TH - 1) / BL_TH);
   if (tiles == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_blur, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, 1);  // plain tile order (runs: slower)
+  if (g.cv440) hipLaunchKernelGGL(k_blur<true>, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, 1);
+  else hipLaunchKernelGGL(k_blur<false>, dim3(tiles, 1, nimg), dim3(256), 0, s, g, p, level0, level1, 1);  // plain tile order (runs: slower)
   return hipGetLastError();
 }
 
@@ -1871,6 +1876,7 @@ constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 byt
 constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
 constexpr int DW_BP = 40;     // blurred patch pitch in bytes
 constexpr int DW_WAVE_DW = 22 * DW_HP + DW_ROWS * DW_RP + 16;  // dwords of LDS per wave: row pairs | raw window (+ slack)
+template <bool T440>  // (the Gaussian taps of OpenCV 4.0 .. 4.5.0, see k_blur)
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
                                                   orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
@@ -2005,7 +2011,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
           const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];  // (d3 of the last group only feeds unused columns)
           const uint32_t A0 = __builtin_amdgcn_alignbyte(d1, d0, mis), A1 = __builtin_amdgcn_alignbyte(d2, d1, mis),
                          A2 = __builtin_amdgcn_alignbyte(d3, d2, mis);  // 12 window bytes from the first tap of column 4q
-          const uint32_t wA = 0x38302212u, wB = 0x00122230u;  // taps 0..3 and 4..6 (LSB = lowest x)
+          constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
+          const uint32_t wA = 18u | (34u << 8) | (kT2 << 16) | (kT3 << 24), wB = kT2 | (34u << 8) | (18u << 16);  // taps 0..3 and 4..6 (LSB = lowest x)
           h[rr][0] = __builtin_amdgcn_udot4(A0, wA, __builtin_amdgcn_udot4(A1, wB, 0, false), false);
           h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 1), wA,
                                             __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 1), wB, 0, false), false);
@@ -2033,8 +2040,9 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
     uint32_t pr[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) pr[k] = hp[(4 * ch + k) * DW_HP + x];  // H rows 8ch .. 8ch+13 (pair 22 = the first window dwords: feeds padding rows only)
-    const uint32_t w01 = 18u | (34u << 16), w23 = 48u | (56u << 16), w45 = 48u | (34u << 16), w6 = 18u;            // even y
-    const uint32_t v0 = 18u << 16, v12 = 34u | (48u << 16), v34 = 56u | (48u << 16), v56 = 34u | (18u << 16);      // odd y
+    constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
+    const uint32_t w01 = 18u | (34u << 16), w23 = kT2 | (kT3 << 16), w45 = kT2 | (34u << 16), w6 = 18u;            // even y
+    const uint32_t v0 = 18u << 16, v12 = 34u | (kT2 << 16), v34 = kT3 | (kT2 << 16), v56 = 34u | (18u << 16);      // odd y
 #pragma unroll
     for (int yy = 0; yy < 8; yy++) {
       const int k0 = yy >> 1;
@@ -2050,7 +2058,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
         acc = udot2_u16(pr[k0 + 2], v34, acc);
         acc = udot2_u16(pr[k0 + 3], v56, acc);
       }
-      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)(acc >> 16);  // rows 37..39 are padding (40 x 40 B fit the old window)
+      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)((T440 ? min(acc, 0x00FFFFFFu) : acc) >> 16);  // rows 37..39 are padding (40 x 40 B fit the old window); 257-sum taps saturate
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2089,7 +2097,9 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
 
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s) {
-  hipLaunchKernelGGL(k_describe, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
+  if (g.cv440) hipLaunchKernelGGL(k_describe<true>, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
+                     kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
+  else hipLaunchKernelGGL(k_describe<false>, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
                      kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
   return hipGetLastError();
 }

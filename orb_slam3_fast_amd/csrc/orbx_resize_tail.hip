@@ -191,9 +191,12 @@ hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, c
   return hipGetLastError();
 }
 
+// The limit is per device and shared by every handle on it: it is set to the largest plan build_tail_plans can produce
+// (kTailLdsMax) and never lowered -- a second handle configuring a smaller geometry used to shrink it under the first.
 hipError_t prepare_resize_tail(unsigned ldsBytes) {
+  constexpr unsigned kTailLdsCeil = 96 * 1024;  // == kTailLdsMax (orbx_api.hip)
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)ldsBytes);
+                             (int)(ldsBytes > kTailLdsCeil ? ldsBytes : kTailLdsCeil));
 }
 
 }  // namespace orbx

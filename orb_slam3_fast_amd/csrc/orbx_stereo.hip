@@ -1,5 +1,7 @@
 // orbx_stereo.hip — association kernels of liborbx: Frame::ComputeStereoMatches (src/Frame.cc:921-1084), BFMatcher kNN-2
 // (:1293-1302) and ComputeStereoFishEyeMatches with the KannalaBrandt8 triangulation (:1273-1331).
+#include <mutex>
+
 #include "orbx_device.h"
 
 namespace orbx {
@@ -123,11 +125,20 @@ __global__ __launch_bounds__(kSortNT) void k_stereo_sort(Geom g, StereoArgs a) {
 
 hipError_t launch_stereo_sort(const Geom& g, const StereoArgs& a, int npairs, hipStream_t s) {
   const size_t lds = (((size_t)(a.imgH + 2) * 4 + 15) & ~(size_t)15) + (size_t)kSortNT * kSortItems * 48;
-  static bool prepared = false;  // (> 64 KB of dynamic LDS needs the attribute; idempotent, so a race sets it twice at worst)
-  if (!prepared) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+  // > 64 KB of dynamic LDS needs the attribute, and the attribute is PER DEVICE (a process may hold handles on several GPUs):
+  // one flag per device, set under a lock (two threads call the matcher concurrently)
+  {
+    static std::mutex mu;
+    static bool prepared[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    prepared = true;
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || !prepared[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_sort), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) prepared[dev] = true;
+    }
   }
   hipLaunchKernelGGL(k_stereo_sort, dim3(2 * npairs), dim3(kSortNT), lds, s, g, a);
   return hipGetLastError();
@@ -842,6 +853,7 @@ __global__ __launch_bounds__(256) void k_tri_match_rig(TriArgs a) {
       if (rot < 0.0f) rot = rot + 360.0f;
       int bin = (int)roundf(rot * (1.0f / 30));
       if (bin == 30) bin = 0;
+  bin = min(max(bin, 0), 29);  // (angles outside [0, 360) or NaN: the reference asserts; here the vote stays inside the histogram)
       atomicAdd(&a.flags[2 + bin], 1);
     }
   }

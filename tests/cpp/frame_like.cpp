@@ -148,7 +148,14 @@ int main(int argc, char** argv) {
     dump(pre + ".fuse", fuseIdx.data(), fuseIdx.size());
     dump(pre + ".sim3", sim12.data(), sim12.size());
     dump(pre + ".bowkf", bow12.data(), bow12.size());
-    std::printf("%d %d %zu %d %d %d\n", nr, nt, pairs.size(), nf, ns, nb);
+    // two-camera key frames: mFeatVec / the map-point flags cover NLeft + NRight features, mvKeysUn only the first part;
+    // the reference skips idx >= mvKeysUn.size() (src/ORBmatcher.cc:799,816)
+    std::vector<ocv::KeyPoint> k1r(k1.begin(), k1.begin() + (std::ptrdiff_t)(k1.size() * 3 / 4)),
+        k2r(k2.begin(), k2.begin() + (std::ptrdiff_t)(k2.size() * 3 / 4));
+    std::vector<int> bowRig;
+    const int nbr = SearchByBoW(fv1, k1r, d1.data(), good1, fv2, k2r, d2.data(), good2, 0.75f, true, bowRig);
+    dump(pre + ".bowkf_rig", bowRig.data(), bowRig.size());
+    std::printf("%d %d %zu %d %d %d %d\n", nr, nt, pairs.size(), nf, ns, nb, nbr);
     return 0;
   }
   if (std::string(argv[1]) == "rectify") {

@@ -27,6 +27,12 @@ def test_library_exports_every_declared_symbol():
     assert lib.orbx_abi_version() == 1
 
 
+def test_opencv_compat_rejects_a_null_handle():
+    lib = orbx.lib()
+    assert lib.orbx_set_opencv_compat(None, 440) == orbx.E_BADARG
+    assert b"null handle" in lib.orbx_last_error()
+
+
 def test_keypoint_layout_is_cv_keypoint():
     assert orbx.KP_DTYPE.itemsize == 28
     assert [orbx.KP_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == \

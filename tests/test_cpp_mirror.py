@@ -173,7 +173,7 @@ def test_cpp_mirror_relocalisation_and_triangulation_match_oracle(oracle, tmp_pa
         np.ascontiguousarray(arr).tofile(pre + "." + ext)
     r = subprocess.run([exe, "reloc_tri", pre, "752", "480", "100"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
-    nr, nt, npairs, nfz, nsim, nbow = map(int, r.stdout.split())
+    nr, nt, npairs, nfz, nsim, nbow, nbow_rig = map(int, r.stdout.split())
     onr, omatch, oocc = oracle.search_by_projection_keyframe(f["k2"], f["d2"], f["bounds"], pts, 100, True, occ)
     ont, om12 = oracle.search_for_triangulation(fv1, f["k1"], f["d1"], mp1, None, fv2, f["k2"], f["d2"], mp2, None, f["sf"], f["sigma2"],
                                                 ep, F, False, False, True)
@@ -191,3 +191,10 @@ def test_cpp_mirror_relocalisation_and_triangulation_match_oracle(oracle, tmp_pa
     assert nsim == agree.sum() > 100 and np.array_equal(np.fromfile(pre + ".sim3", np.int32), np.where(agree, m1, -1))
     onb, omb = oracle.search_by_bow_keyframes(fv1, f["d1"], f["k1"]["angle"], good1, fv2, f["d2"], f["k2"]["angle"], good2, 0.75, True)
     assert nbow == onb > 20 and np.array_equal(np.fromfile(pre + ".bowkf", np.int32), omb)
+    # rig key frames: features past mvKeysUn.size() (here the last quarter) are skipped like src/ORBmatcher.cc:799,816
+    g1r, g2r = good1.copy(), good2.copy()
+    g1r[len(g1r) * 3 // 4:] = 0
+    g2r[len(g2r) * 3 // 4:] = 0
+    onr_, ombr = oracle.search_by_bow_keyframes(fv1, f["d1"], f["k1"]["angle"], g1r, fv2, f["d2"], f["k2"]["angle"], g2r, 0.75, True)
+    got = np.fromfile(pre + ".bowkf_rig", np.int32)
+    assert nbow_rig == onr_ > 10 and len(got) == len(good1) and np.array_equal(got, ombr)

@@ -100,6 +100,35 @@ def test_fused_blur_border_zone_is_exercised_and_exact(gpu, oracle):
     assert (sides >= 10).all(), sides   # left, top, right and bottom reflections all taken
 
 
+@pytest.mark.parametrize("w,h,nf,stream", [(640, 480, 1000, 21), (1280, 720, 1500, 22)])
+def test_opencv_compat_selects_the_gaussian_taps(gpu, oracle, w, h, nf, stream):
+    """VERDICT (round 3): the reference README names OpenCV 4.4.0 (README.md:101), whose GaussianBlur taps {18,34,49,55,49,34,18}
+    differ from the >= 4.5.1 set {18,34,48,56,48,34,18} the product used to hard-code.  orbx_set_opencv_compat(440 | 451) selects
+    them in k_describe and k_blur; both are compared with the oracle's oro_set_blur_taps on the C2 / C3 sizes, and a saturated
+    patch exercises the 257-sum clamp (255, not 257 & 255)."""
+    img = synth.mono_frame(w, h, stream)
+    img[h // 2 - 40:h // 2 + 40, w // 2 - 60:w // 2 + 60] = np.where(
+        np.random.default_rng(stream).random((80, 120)) < 0.5, 255, 250).astype(np.uint8)   # blurred values reach 255 / 256+
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
+    res = {}
+    for variant in (451, 440, 451):
+        ex.set_opencv_compat(variant)
+        oe.set_blur_taps(variant)
+        mono, k, d = ex(img, (0, 0))
+        omono, ok_, od = oe.extract(img, (0, 0))
+        assert mono == omono and np.array_equal(_kp_bytes(k), _kp_bytes(ok_)), variant
+        assert np.array_equal(d, od), variant
+        for l in (0, 3, 7):
+            assert np.array_equal(ex.image_pyramid(l, blurred=True), oracle.blur(oe.level(l), variant)), (variant, l)
+        res.setdefault(variant, d.copy())
+        assert np.array_equal(res[variant], d)
+    assert not np.array_equal(res[440], res[451])            # the two OpenCV generations do give different descriptors
+    assert (oracle.blur(oe.level(0), 440) == 255).any()
+    with pytest.raises(orbx.OrbxError):
+        ex.set_opencv_compat(320)
+
+
 def test_pyramid_download_equals_the_per_level_reads(gpu, oracle):
     """orbx_pyramid_download (all levels, one synchronisation, pinned staging; the C++ mirror's mvImagePyramid refresh) returns
     the bytes of orbx_pyramid_level for every level: host entry (handle-owned level 0), batched device entry (level 0 = the
