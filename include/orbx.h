@@ -599,6 +599,11 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 int orbx_clock_probe_start(int device, int spin_us, void** probe);
 int orbx_clock_probe_finish(void* probe, double* ghz);
 
+/* Measurement aid: the device-copy rate the roofline fractions are ALSO quoted against.  Copies `bytes` (a multiple
+ * of 16, >= 1 MiB) device to device `iters` times with a 16-byte-per-lane kernel and returns (bytes read + bytes written) / time in
+ * GB/s -- the hardware guide measures 6.29 TB/s this way on MI355X (79 % of the 8 TB/s HBM3E peak). */
+int orbx_copy_probe(int device, size_t bytes, int iters, double* gbps);
+
 /* Runs the quadtree's host/device introsort replica (csrc/orbx_introsort.h) on the host: sorts n 64-bit
  * elements by their key bits 16..63, payload bits 0..15 ride along.  tests/ compare it with std::sort
  * (the tie order DistributeOctTree depends on, src/ORBextractor.cc:686). */

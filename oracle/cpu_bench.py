@@ -95,7 +95,27 @@ def run_mt(path, nf, bf, b, frames):
             "stereo_ms_mean": float(ste.mean()), "stereo_ms_std": float(ste.std())}
 
 
+def digest(path, nf, bf, b):
+    """sha256 over everything the oracle returns for the first pair: two builds of the oracle (ORB_ORACLE_LIB) must agree."""
+    import hashlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import oracle_py as oracle
+    p = np.load(path, mmap_mode="r")[0]
+    oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+    _, kL, dL = oL.extract(np.ascontiguousarray(p[0]))
+    _, kR, dR = oR.extract(np.ascontiguousarray(p[1]))
+    u, dep = oracle.stereo_match(oL, oR, kL, dL, kR, dR, bf, b)
+    h = hashlib.sha256()
+    for x in (kL, dL, kR, dR, u, dep):
+        h.update(np.ascontiguousarray(x).tobytes())
+    return {"digest": h.hexdigest(), "keypoints": int(len(kL) + len(kR))}
+
+
 if __name__ == "__main__":
+    if "--digest" in sys.argv:
+        a = [x for x in sys.argv if x != "--digest"]
+        print(json.dumps(digest(a[1], int(a[2]), float(a[3]), float(a[4]))))
+        sys.exit(0)
     if "--mt" in sys.argv:
         a = [x for x in sys.argv if x != "--mt"]
         print(json.dumps(run_mt(a[1], int(a[2]), float(a[3]), float(a[4]), int(a[5]))))

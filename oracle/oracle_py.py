@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liborb_oracle.so")
+_DEFAULT_LIB = os.path.join(_HERE, "liborb_oracle.so")
+# ORB_ORACLE_LIB: another build of the same sources (bench.py's cpu_baseline leg times the -O3 -march=native build, `make fast`)
+_LIB = os.environ.get("ORB_ORACLE_LIB") or _DEFAULT_LIB
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -19,6 +21,8 @@ assert KP_DTYPE.itemsize == 28
 
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "orb_oracle_c.cpp", "orb_oracle.h")]
+    if _LIB != _DEFAULT_LIB:
+        return _LIB
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB

@@ -141,6 +141,7 @@ def lib():
         L.orbx_allgather_descriptors.argtypes = [vp, vp, i, vp, vp]
         L.orbx_clock_probe_start.argtypes = [i, i, C.POINTER(vp)]
         L.orbx_clock_probe_finish.argtypes = [vp, C.POINTER(C.c_double)]
+        L.orbx_copy_probe.argtypes = [i, C.c_size_t, i, C.POINTER(C.c_double)]
         L.orbx_profile_enable.argtypes = [vp, i]
         L.orbx_profile_collect.argtypes = [vp, vp, vp]
         L.orbx_stage_name.restype = C.c_char_p

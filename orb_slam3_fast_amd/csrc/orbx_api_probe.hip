@@ -4,6 +4,8 @@
 // array (one clock domain), i.e. of whatever kernels ran beside the probe.  bench.py starts it right after the timed
 // region, enqueues a few more steps, and divides by this clock instead of assuming the 2.4 GHz peak (DVFS: the dense
 // integer kernels of this path hold 2.1 - 2.3 GHz, profiles/r3_valu_issue.txt).
+#include <algorithm>
+
 #include "orbx_host.h"
 
 using namespace orbx_host;
@@ -22,6 +24,22 @@ __global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, uns
   if (threadIdx.x == 0) {
     out[0] = t1 - t0;
     out[1] = r1 - r0;
+  }
+}
+// Device-to-device copy with 16-byte accesses, four loads in flight per thread: the "measured copy peak" SURVEY 8d asks the
+// roofline fractions to be quoted against as well (a uint8 torch copy_ reached 4.7 - 5.3 TB/s on this chip, the hardware
+// guide's float4 copy kernel 6.29 TB/s: MI355X_MICROARCH.md:35).
+typedef unsigned int probe_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_probe(const probe_u4* __restrict__ src, probe_u4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+    probe_u4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (i + 256 * k < n16) v[k] = __builtin_nontemporal_load(src + i + 256 * k);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (i + 256 * k < n16) __builtin_nontemporal_store(v[k], dst + i + 256 * k);
   }
 }
 struct Probe {
@@ -47,6 +65,39 @@ int orbx_clock_probe_start(int device, int spin_us, void** probe) {
   hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, p->stream, p->d, (unsigned long long)spin_us * 100ull);
   HIPC(hipGetLastError());
   *probe = p.release();
+  return ORBX_OK;
+}
+
+int orbx_copy_probe(int device, size_t bytes, int iters, double* gbps) {
+  if (!gbps || iters <= 0 || iters > 1000 || bytes < (1u << 20) || (bytes & 15)) return fail(ORBX_E_BADARG, "bad copy-probe arguments");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return fail(ORBX_E_NODEVICE, "no HIP device");
+  if (device < 0 || device >= nd) return fail(ORBX_E_BADARG, "device index out of range");
+  HIPC(hipSetDevice(device));
+  probe_u4 *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc((void**)&src, bytes);
+  if (e == hipSuccess) e = hipMalloc((void**)&dst, bytes);
+  if (e == hipSuccess) e = hipMemset(src, 3, bytes);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  float ms = 0.f;
+  if (e == hipSuccess) {
+    const size_t n16 = bytes / 16;
+    const int blocks = (int)std::min<size_t>((n16 + 1023) / 1024, 256 * 16);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_copy_probe, dim3(blocks), dim3(256), 0, nullptr, src, dst, n16);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy_probe, dim3(blocks), dim3(256), 0, nullptr, src, dst, n16);
+    (void)hipEventRecord(e1, nullptr);
+    e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(src);
+  (void)hipFree(dst);
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  *gbps = ms > 0.f ? 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9 : 0.0;  // bytes read + bytes written
   return ORBX_OK;
 }
 

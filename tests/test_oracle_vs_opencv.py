@@ -11,7 +11,10 @@ import pytest
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 FIX = os.path.join(G, "opencv_pins.npz")
-pytestmark = pytest.mark.skipif(not os.path.exists(FIX), reason="tests/golden/opencv_pins.npz absent: neither the build "
+# ORBX_REQUIRE_OPENCV_PINS=1 (CI of a box that is SUPPOSED to hold the fixture): an absent fixture FAILS every test below instead
+# of skipping it -- "parity unpinned" must not pass silently where a pin is expected.
+REQUIRE = os.environ.get("ORBX_REQUIRE_OPENCV_PINS", "0") == "1"
+pytestmark = pytest.mark.skipif(not os.path.exists(FIX) and not REQUIRE, reason="tests/golden/opencv_pins.npz absent: neither the build "
                                 "container nor the MI355X box holds OpenCV or reaches a package index "
                                 "(profiles/r3_opencv_probe_{buildbox,gpubox}.txt) -- PARITY UNPINNED for the OpenCV "
                                 "fixed-point kernels; tools/gen_golden_opencv.py writes the fixture on any box with "
@@ -20,6 +23,9 @@ pytestmark = pytest.mark.skipif(not os.path.exists(FIX), reason="tests/golden/op
 
 @pytest.fixture(scope="module")
 def cvp():
+    if not os.path.exists(FIX):
+        pytest.fail("ORBX_REQUIRE_OPENCV_PINS=1 but tests/golden/opencv_pins.npz is absent: run `python tools/gen_golden_opencv.py` "
+                    "on a box with opencv-python >= 4.5.1 and commit the fixture (PARITY UNPINNED until then)")
     return np.load(FIX)
 
 
