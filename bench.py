@@ -189,7 +189,11 @@ class Workload:
             # the collective goes through the C ABI (orbx_allgather_descriptors): one grouped RCCL call per step, straight from
             # the handle's result arrays, queued on the handle's own stream behind the extraction -- no host synchronisation
             from orb_slam3_fast_amd import sharding
-            self.exchange = [sharding.DescriptorExchange(2 * B, e.capacity, local_rank) for e in self.exs]
+            # ONE communicator per rank, shared by the handles: the gathers of a rank are chained in issue order (handle = step mod
+            # H on every rank), see the ordering rule in include/orbx.h
+            first = sharding.DescriptorExchange(2 * B, self.exs[0].capacity, local_rank)
+            self.exchange = [first] + [sharding.DescriptorExchange(2 * B, e.capacity, local_rank, comm=first.comm)
+                                       for e in self.exs[1:]]
         self.last_slot = [None] * len(self.exs)
 
     def step(self):
@@ -211,6 +215,9 @@ class Workload:
             self.gathered[h] = self.exchange[h].gather(ex)
 
     def sync(self):
+        if self.exchange is not None:
+            # bounded: a missing / out-of-order rank raises E_TIMEOUT here instead of hanging hipStreamSynchronize below
+            self.exchange[0].comm.wait(int(os.environ.get("ORBX_COMM_TIMEOUT_MS", "120000")))
         for e in self.exs:
             e.sync()
 

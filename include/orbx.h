@@ -30,6 +30,7 @@ extern "C" {
 #define ORBX_E_HIP (-4)
 #define ORBX_E_NODEVICE (-5)
 #define ORBX_E_UNSUPPORTED (-6) /* image too small for the pyramid or aspect (Q11) */
+#define ORBX_E_TIMEOUT (-7)     /* orbx_comm_wait: a collective did not complete in time (a rank missing / out of order) */
 
 /* Layout-identical to cv::KeyPoint (28 bytes): pt.x pt.y size angle response octave class_id
  * (SURVEY 8a row a13). */
@@ -147,6 +148,14 @@ int orbx_comm_adopt(void* nccl_comm, int device, orbx_comm** out);
 void orbx_comm_destroy(orbx_comm* c);
 int orbx_comm_size(const orbx_comm* c, int* n_ranks, int* rank);
 int orbx_allgather_descriptors(orbx_extractor* ex, orbx_comm* c, int n_images, uint8_t* d_all_desc, int32_t* d_all_counts);
+/* ORDERING RULE: one communicator per rank may (and should) serve every handle of that rank.  RCCL matches a communicator's
+ * collectives by issue order, so every rank must make the same orbx_allgather_descriptors calls in the same order; the calls of
+ * one communicator are chained on the device (each waits, stream-side, for the previous one's completion event), so handles
+ * on different streams never run two collectives of the communicator concurrently.  orbx_comm_wait blocks the HOST until the
+ * communicator's most recent collective has completed, at most timeout_ms: ORBX_OK, or ORBX_E_TIMEOUT with a message that
+ * names the collective's sequence number and the likely causes -- a bounded wait in place of a hang in orbx_sync when a
+ * rank is missing or out of order.  n_collectives (optional) receives the number of collectives enqueued so far. */
+int orbx_comm_wait(orbx_comm* c, int timeout_ms, unsigned long long* n_collectives);
 
 /* Device-resident results of the last (batch) extraction: keypoints [n_images][cap] and descriptors
  * [n_images][cap][32], counts[n_images] (n) and mono[n_images] (monoIndex), all on the device. */

@@ -19,7 +19,7 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
                      ("octave", "<i4"), ("class_id", "<i4")])
 assert KP_DTYPE.itemsize == 28  # cv::KeyPoint
 
-OK, E_EMPTY, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, E_EMPTY, E_BADARG, E_CAPACITY, E_HIP, E_NODEVICE, E_UNSUPPORTED, E_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30  # src/ORBmatcher.cc:35-37
 NUM_STAGES = 8
 MP_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("track_depth", "<f4"),
@@ -139,6 +139,7 @@ def lib():
         L.orbx_comm_destroy.restype = None
         L.orbx_comm_size.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
         L.orbx_allgather_descriptors.argtypes = [vp, vp, i, vp, vp]
+        L.orbx_comm_wait.argtypes = [vp, i, C.POINTER(C.c_ulonglong)]
         L.orbx_clock_probe_start.argtypes = [i, i, C.POINTER(vp)]
         L.orbx_clock_probe_finish.argtypes = [vp, C.POINTER(C.c_double)]
         L.orbx_copy_probe.argtypes = [i, C.c_size_t, i, C.POINTER(C.c_double)]
@@ -436,6 +437,13 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
         _check(lib().orbx_comm_create(buf, n_ranks, rank, device, C.byref(self._h)))
         self.n_ranks, self.rank = n_ranks, rank
+
+    def wait(self, timeout_ms=60000):
+        """Block until the communicator's most recent collective has completed (OrbxError E_TIMEOUT after timeout_ms: a rank
+        is missing or out of order).  Returns the number of collectives enqueued so far."""
+        n = C.c_ulonglong(0)
+        _check(lib().orbx_comm_wait(self._h, int(timeout_ms), C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -13,6 +13,10 @@
 // The reference has no counterpart (single rig, process-global Frame statics, include/Frame.h:230-235).
 #include <dlfcn.h>
 
+#include <chrono>
+#include <mutex>
+#include <thread>
+
 #include "orbx_host.h"
 
 using namespace orbx_host;
@@ -74,9 +78,19 @@ Rccl* rccl() {
   } while (0)
 }  // namespace
 
+// ORDERING RULE.  One communicator per rank serves every handle of that rank.  RCCL matches the collectives of a
+// communicator by ISSUE ORDER, so every rank must call orbx_allgather_descriptors in the same order (bench.py: step i uses
+// handle i mod H on every rank), and two collectives of one communicator must not run concurrently from two streams: each
+// call therefore waits (stream-side, hipStreamWaitEvent -- the host never blocks) for the event the previous call of this
+// communicator recorded behind its collective.  The chain is what makes "three handles, three streams" legal by construction
+// instead of by luck; `seq` counts the calls so that a rank-order mismatch can be reported (orbx_comm_wait).
 struct orbx_comm {
   ncclComm_t comm = nullptr;
   int device = 0, ranks = 0, rank = 0;
+  std::mutex mu;
+  hipEvent_t last = nullptr;   // behind the most recent collective of this communicator
+  bool lastValid = false;
+  unsigned long long seq = 0;  // collectives enqueued so far
 };
 
 extern "C" {
@@ -105,6 +119,7 @@ int orbx_comm_create(const uint8_t id[ORBX_COMM_ID_BYTES], int n_ranks, int rank
   std::unique_ptr<orbx_comm> c(new (std::nothrow) orbx_comm);
   if (!c) return fail(ORBX_E_HIP, "out of memory");
   RCCLC(R->CommInitRank(&c->comm, n_ranks, u, rank));
+  HIPC(hipEventCreateWithFlags(&c->last, hipEventDisableTiming));
   c->device = device;
   c->ranks = n_ranks;
   c->rank = rank;
@@ -122,6 +137,8 @@ int orbx_comm_adopt(void* nccl_comm, int device, orbx_comm** out) {
   RCCLC(R->CommCount(c->comm, &c->ranks));
   RCCLC(R->CommUserRank(c->comm, &c->rank));
   c->device = -1 - device;  // negative: not owned, orbx_comm_destroy leaves the ncclComm_t alone
+  if (device >= 0) HIPC(hipSetDevice(device));
+  HIPC(hipEventCreateWithFlags(&c->last, hipEventDisableTiming));
   *out = c.release();
   return ORBX_OK;
 }
@@ -129,10 +146,9 @@ int orbx_comm_adopt(void* nccl_comm, int device, orbx_comm** out) {
 void orbx_comm_destroy(orbx_comm* c) {
   if (!c) return;
   Rccl* R = rccl();
-  if (c->device >= 0 && c->comm && R->CommDestroy) {
-    (void)hipSetDevice(c->device);
-    (void)R->CommDestroy(c->comm);
-  }
+  (void)hipSetDevice(c->device >= 0 ? c->device : -1 - c->device);
+  if (c->last) (void)hipEventDestroy(c->last);
+  if (c->device >= 0 && c->comm && R->CommDestroy) (void)R->CommDestroy(c->comm);
   delete c;
 }
 
@@ -151,6 +167,9 @@ int orbx_allgather_descriptors(orbx_extractor* ex, orbx_comm* c, int n_images, u
   if (!R->err.empty()) return fail(ORBX_E_UNSUPPORTED, R->err);
   HIPC(hipSetDevice(ex->device));
   const size_t block = (size_t)ex->gmax.outCap * 32;
+  std::lock_guard<std::mutex> lk(c->mu);  // (issue order = lock order; all ranks must use the same)
+  // behind the previous collective of this communicator, whichever handle's stream it ran on (ordering rule above)
+  if (c->lastValid) HIPC(hipStreamWaitEvent(ex->stream, c->last, 0));
   // both members of every block in ONE RCCL launch, on the handle's stream: ordered behind k_describe, nothing waits on the host
   RCCLC(R->GroupStart());
   ncclResult_t e1 = R->AllGather(ex->d_desc.p, d_all_desc, (size_t)n_images * block, ncclUint8, c->comm, ex->stream);
@@ -158,7 +177,37 @@ int orbx_allgather_descriptors(orbx_extractor* ex, orbx_comm* c, int n_images, u
   RCCLC(R->GroupEnd());
   RCCLC(e1);
   RCCLC(e2);
+  HIPC(hipEventRecord(c->last, ex->stream));
+  c->lastValid = true;
+  c->seq++;
   return ORBX_OK;
+}
+
+int orbx_comm_wait(orbx_comm* c, int timeout_ms, unsigned long long* n_collectives) {
+  if (!c || timeout_ms < 0) return fail(ORBX_E_BADARG, "bad arguments");
+  hipEvent_t ev;
+  unsigned long long seq;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    ev = c->last;
+    seq = c->seq;
+    if (n_collectives) *n_collectives = seq;
+    if (!c->lastValid) return ORBX_OK;
+  }
+  HIPC(hipSetDevice(c->device >= 0 ? c->device : -1 - c->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return ORBX_OK;
+    if (e != hipErrorNotReady) return fail(ORBX_E_HIP, hipGetErrorString(e));
+    const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (ms >= timeout_ms)
+      return fail(ORBX_E_TIMEOUT, "collective #" + std::to_string(seq) + " of rank " + std::to_string(c->rank) + " / " +
+                                      std::to_string(c->ranks) + " has not completed after " + std::to_string(timeout_ms) +
+                                      " ms: a rank is missing, or the ranks issued their all-gathers in different orders / with "
+                                      "different sizes (every rank must make the same orbx_allgather_descriptors calls in the same order)");
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
 }
 
 }  // extern "C"

@@ -49,14 +49,18 @@ class DescriptorExchange:
     (device memory plumbing) reused every step.  allgather_descriptor_blocks above is the torch-only twin the gloo CPU
     tests use to check the block order."""
 
-    def __init__(self, n_images, cap, device, group=None):
+    def __init__(self, n_images, cap, device, group=None, comm=None):
+        """comm: an orbx.Comm to share -- ONE communicator per rank serves all handles (include/orbx.h, ordering rule: every
+        rank issues the same gathers in the same order; the C ABI chains them on the device).  None creates it (collective)."""
         import orb_slam3_fast_amd as orbx
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        uid = [orbx.comm_unique_id() if self.rank == 0 else None]
-        if self.world > 1:
-            dist.broadcast_object_list(uid, src=0, group=group)
-        self.comm = orbx.Comm(uid[0], self.world, self.rank, device)
+        if comm is None:
+            uid = [orbx.comm_unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(uid, src=0, group=group)
+            comm = orbx.Comm(uid[0], self.world, self.rank, device)
+        self.comm = comm
         self.n_images, self.cap = n_images, cap
         dev = torch.device("cuda", device)
         self.desc = torch.empty((self.world * n_images, cap, 32), dtype=torch.uint8, device=dev)
