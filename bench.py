@@ -620,11 +620,60 @@ def other_configs_leg(a, local_rank, torch):
         w2.sync()
         dt = time.perf_counter() - t0
         units = (2 * b.pairs if b.mode == "mono" else b.pairs) * a.other_steps
-        _, _, _, ns = w2.exs[0].level_stats(0)
+        lw, lh, nc, ns = w2.exs[0].level_stats(0)
         res[name] = {"value": round(units / dt, 1), "unit": "frames/s" if b.mode == "mono" else "stereo frames/s",
                      "ms_per_step": round(1e3 * dt / a.other_steps, 4), "steps": a.other_steps,
                      ("frames_per_step" if b.mode == "mono" else "pairs_per_step"): 2 * b.pairs if b.mode == "mono" else b.pairs,
                      "nfeatures": b.nfeatures, "keypoints_image0": int(ns.sum())}
+        # ---- roofline of this configuration's dominant kernel: a stage pass like the headline's -- every launch
+        # of handle 0 bracketed with HIP events on its stream, steps synchronised (no overlap between batches) -- and the
+        # algorithmic bytes of SURVEY 8d for the kernel that takes the largest share
+        try:
+            import numpy as np
+            ex0, Hn, NP = w2.exs[0], len(w2.exs), 6
+            ex0.profile_enable(True)
+            ex0.profile_collect()
+            for _ in range(NP * Hn):
+                w2.step()
+                w2.sync()
+            prof = {k: v for k, v in ex0.profile_collect().items() if v[1] > 0}
+            ex0.profile_enable(False)
+            plevels = [int(x) * int(y) for x, y in zip(lw, lh)]
+            P, NI = sum(plevels), 2 * b.pairs
+            ncand, nsel = float(nc.sum()), float(ns.sum())
+            nq = nt = nmatch = 0
+            if b.mode == "stereo":
+                d_u = np.zeros((1, ex0.capacity), np.float32)
+                w2.orbx._check(w2.orbx.lib().orbx_stereo_download(ex0._h, 0, w2.orbx._p(d_u[0]), None, ex0.capacity))
+                nmatch = int((d_u >= 0).sum())
+            elif b.mode == "fisheye":
+                mL, kL, _ = ex0.download(0)
+                mR, kR, _ = ex0.download(b.pairs)
+                nq, nt = len(kL) - mL, len(kR) - mR      # the lapping rows BFMatcher::knnMatch sees (src/Frame.cc:1293)
+            tot = sum(v[0] for v in prof.values())
+            st = {}
+            for kname, (ms, cnt) in prof.items():
+                if kname == "k_stereo_match" and b.mode == "fisheye":   # SURVEY 8d bf_knn2: 32 (nQ + nT) + 16 nQ per pair
+                    nb, shown = b.pairs * (32 * (nq + nt) + 16 * nq), "k_fisheye_batch"
+                else:
+                    nb, shown = algorithmic_bytes(kname, NI, P, plevels, ncand, nsel, nmatch, b.pairs), kname
+                per_launch_group = nb * NP / cnt        # bytes of one launch (k_resize: the chain's bytes / its launches)
+                st[shown] = {"avg_us": round(1e3 * ms / cnt, 2), "launches_per_step": cnt // NP, "share": round(ms / tot, 4),
+                             "algorithmic_GBps": round(nb * NP / (ms * 1e-3) / 1e9, 1), "_per_launch": per_launch_group}
+            domk = max(st, key=lambda k_: st[k_]["share"])
+            ach = st[domk]["algorithmic_GBps"]
+            res[name]["roofline"] = {"kernel": domk, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                                     "avg_launch_us": st[domk]["avg_us"], "share_of_step": st[domk]["share"],
+                                     "algorithmic_bytes_per_launch": int(st[domk].pop("_per_launch")),
+                                     "note": "isolated (synchronised single-handle steps); PMC traffic for this configuration: "
+                                             "profiles/r4_*_pmc_traffic.json"}
+            for v in st.values():
+                v.pop("_per_launch", None)
+            res[name]["stages"] = st
+        except Exception as ex_:
+            res[name]["roofline"] = None
+            res[name]["roofline_error"] = str(ex_)[:160]
         for e in w2.exs:
             e.close()
         del w2
