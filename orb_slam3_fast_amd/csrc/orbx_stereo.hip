@@ -645,6 +645,21 @@ __device__ __forceinline__ void kb8_unproject(const KB8Cam& c, float u, float v,
   ray[2] = 1.f;
 }
 
+// 1 / x and 1 / sqrt(x) in double from the hardware seeds (v_rcp_f64 / v_rsq_f64) and two Newton steps each: relative error
+// ~1e-16 instead of correctly rounded, at a fifth of the IEEE division / square-root expansions (the Jacobi sweeps below are a
+// serial chain of them per triangulated match: round 4 measured 35 us of k_fisheye_batch's 60 us there).  The rotation angles of
+// a one-sided Jacobi may be off by an ulp without changing what it converges to.
+__device__ __forceinline__ double rcp64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ double rsqrt64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * __builtin_fma(-0.5 * x * y, y, 1.5);
+  return y * __builtin_fma(-0.5 * x * y, y, 1.5);
+}
+
 // Right singular vector of the smallest singular value (= JacobiSVD::matrixV().col(3), :429-431) of a row-major 4x4.
 __device__ void null_vector4(const float A[16], float v[4]) {
   double U[4][4], V[4][4];
@@ -668,11 +683,12 @@ __device__ void null_vector4(const float A[16], float v[4]) {
           be += U[i][q] * U[i][q];
           ga += U[i][p] * U[i][q];
         }
-        if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+        if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) continue;  // |ga| <= 1e-15 sqrt(al be)
         rotated = true;
-        const double zeta = (be - al) / (2.0 * ga);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+        const double zeta = (be - al) * (0.5 * rcp64(ga));
+        const double s1 = __builtin_fma(zeta, zeta, 1.0);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) * rcp64(fabs(zeta) + s1 * rsqrt64(s1));
+        const double cs = rsqrt64(__builtin_fma(t, t, 1.0)), sn = cs * t;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           const double up = U[i][p], uq = U[i][q];
@@ -867,12 +883,15 @@ hipError_t launch_tri_match_rig(const TriArgs& a, hipStream_t s) {
 // Batched variant on the extractors' device-resident results: thread per lapping-area left keypoint of pair
 // blockIdx.y does the 2-NN over the pair's right lapping rows (256-row LDS tiles, as k_bf_knn2), the Lowe test and the
 // triangulation in one go.
-__global__ __launch_bounds__(256) void k_fisheye_batch(FisheyeBatchArgs a) {
-  // 64 queries per block; wave w scans the train rows t = w (mod 4) of every 256-row LDS tile (all lanes read the same
-  // row: broadcast, 2 x ds_read_b128), the four partial (distance, index) top-2 lists are merged lexicographically --
-  // exactly the stable first-minimum order of the serial scan -- and wave 0 triangulates.
-  __shared__ uint4 tile[256 * 2];
-  __shared__ uint32_t part[3][64][2];  // waves 1..3: packed (distance << 16 | index) best / second
+constexpr int kFeWaves = 8;  // waves per 64-query block of k_fisheye_batch
+__global__ __launch_bounds__(64 * kFeWaves) void k_fisheye_batch(FisheyeBatchArgs a) {
+  // 64 queries per block (lane = query); wave w scans the train rows t = w (mod 8) of every 256-row LDS tile (all lanes read the
+  // same row: broadcast, 2 x ds_read_b128), the eight partial (distance, index) top-2 lists are merged lexicographically --
+  // exactly the stable first-minimum order of the serial scan -- and wave 0 triangulates.  Round 4: eight waves instead of four
+  // (the 608 blocks of a 32-pair batch left most SIMDs with two waves) and the next tile is in flight, one uint4 per thread,
+  // while the current one is scanned: k_fisheye_batch 109 -> see DESIGN.md 4.
+  __shared__ uint4 tile[2][256 * 2];
+  __shared__ uint32_t part[kFeWaves - 1][64][2];  // waves 1..7: packed (distance << 16 | index) best / second
   const int pr = blockIdx.y;
   const int imL = a.firstL + pr, imR = a.firstR + pr;
   const int nL = min(a.nL[imL], a.capL), nR = min(a.nR[imR], a.capR);
@@ -889,13 +908,19 @@ __global__ __launch_bounds__(256) void k_fisheye_batch(FisheyeBatchArgs a) {
     qb = dQ[(long long)q * 2 + 1];
   }
   uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // (distance << 16 | train index): lexicographic order, nT < 65536
-  for (int t0 = 0; t0 < nT; t0 += 256) {
-    const int nt = min(256, nT - t0);
+  const int nTiles = (nT + 255) >> 8;
+  const int tid = threadIdx.x;  // 512 threads = the 512 uint4 of a tile
+  uint4 nx = tid < 2 * min(256, nT) ? dT[tid] : make_uint4(0, 0, 0, 0);
+  for (int ti = 0; ti < nTiles; ti++) {
+    const int t0 = ti << 8, nt = min(256, nT - t0), buf = ti & 1;
+    tile[buf][tid] = nx;  // (the other buffer is still being read by slower waves: two barriers per tile would serialise them)
     __syncthreads();
-    for (int i = threadIdx.x; i < nt * 2; i += 256) tile[i] = dT[(long long)t0 * 2 + i];
-    __syncthreads();
-    for (int t = w; t < nt; t += 4) {
-      const uint4 ta = tile[2 * t], tb = tile[2 * t + 1];
+    if (ti + 1 < nTiles) {
+      const int i2 = 2 * (t0 + 256) + tid;
+      nx = i2 < 2 * nT ? dT[i2] : make_uint4(0, 0, 0, 0);
+    }
+    for (int t = w; t < nt; t += kFeWaves) {
+      const uint4 ta = tile[buf][2 * t], tb = tile[buf][2 * t + 1];
       const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
                     __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
       const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + t);
@@ -912,7 +937,7 @@ __global__ __launch_bounds__(256) void k_fisheye_batch(FisheyeBatchArgs a) {
   bool desc = false, matched = false;
   if (w == 0) {
 #pragma unroll
-    for (int o = 0; o < 3; o++) {
+    for (int o = 0; o < kFeWaves - 1; o++) {
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         const uint32_t key = part[o][lane][e];
@@ -974,7 +999,7 @@ hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream
   const long long work = (long long)npairs * (a.capL > a.capR ? a.capL : a.capR) * 3;
   hipLaunchKernelGGL(k_fisheye_init, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, s, a,
                      npairs);
-  hipLaunchKernelGGL(k_fisheye_batch, dim3((a.capL + 63) / 64, npairs), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_fisheye_batch, dim3((a.capL + 63) / 64, npairs), dim3(64 * kFeWaves), 0, s, a);
   return hipGetLastError();
 }
 
