@@ -434,6 +434,25 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                     const orbx_projected_point* points, int n_points, int check_orientation,
                                     uint8_t* occupied, int32_t* match);
 
+/* The two pinhole SearchByProjection flavours above on the frames of an extraction BATCH (the many-camera mode: one tracking step
+ * of n_frames cameras).  Frame f = image first_image + f of `ex`'s last batch: its keypoints (taken as mvKeysUn: pinhole without
+ * distortion / rectified input, like the batch itself) and descriptors stay in HBM; points / map points of frame f are
+ * points[f * points_stride .. + n_points[f]); bounds = mnMinX .. mnMaxY; scale factors = the handle's; stereo_pair0 >= 0 takes
+ * mvuRight of frame f from pair stereo_pair0 + f of the handle's last orbx_stereo_match_batch (-1: monocular, no consistency
+ * check); occupied_in (may be NULL = all free) / occupied / match are [n_frames][cap] with cap = orbx_batch_results_device's cap,
+ * n_matches [n_frames].  Every kernel of the chain runs ONCE for all frames (blockIdx.y = frame) with a fixed number of
+ * fixed-point rounds enqueued blindly; a frame that needs more (or larger candidate lists) is redone through the one-shot path:
+ * results are those of n_frames separate calls.  Returns the total number of matches or a negative error. */
+int orbx_search_by_projection_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
+                                    float max_y, const orbx_map_point_view* map_points, const int32_t* n_map_points,
+                                    int points_stride, float th, int far_points, float th_far_points, float nnratio,
+                                    int stereo_pair0, const uint8_t* occupied_in, uint8_t* occupied, int32_t* match,
+                                    int32_t* n_matches);
+int orbx_search_by_projection_frame_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
+                                          float max_y, const orbx_projected_point* points, const int32_t* n_points,
+                                          int points_stride, int check_orientation, int stereo_pair0, const uint8_t* occupied_in,
+                                          uint8_t* occupied, int32_t* match, int32_t* n_matches);
+
 /* Replaces the matching part of the relocalisation matcher ORBmatcher::SearchByProjection(Frame& CurrentFrame,
  * KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1808-1918; callers
  * src/Tracking.cc:3631-3632,3645-3646 with (th, ORBdist) = (10, 100) and (3, 64)).  points[i] = the key frame's i-th

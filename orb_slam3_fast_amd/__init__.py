@@ -124,6 +124,8 @@ def lib():
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
+        L.orbx_search_by_projection_frame_batch.argtypes = [vp, i, i, f, f, f, f, vp, vp, i, i, i, vp, vp, vp, vp]
+        L.orbx_search_by_projection_batch.argtypes = [vp, i, i, f, f, f, f, vp, vp, i, f, i, f, f, i, vp, vp, vp, vp]
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
@@ -807,6 +809,39 @@ class ORBmatcher:
             self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
             bounds[3], _p(pp), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
+
+    def SearchByProjectionFrameBatch(self, ex, first_image, n_frames, bounds, points, n_points, occupied=None, stereo_pair0=-1):
+        """SearchByProjectionFrame on the frames of ex's last extraction batch in one call (include/orbx.h:
+        orbx_search_by_projection_frame_batch): points [n_frames][stride] PP_DTYPE, n_points [n_frames].
+        Returns (n_matches [n_frames], match [n_frames][cap], occupied [n_frames][cap])."""
+        pp = np.ascontiguousarray(points, PP_DTYPE).reshape(n_frames, -1)
+        npts = np.ascontiguousarray(n_points, np.int32)
+        cap = ex.capacity
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, cap)
+        occ = np.zeros((n_frames, cap), np.uint8)
+        match = np.full((n_frames, cap), -1, np.int32)
+        nm = np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_frame_batch(
+            ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp), _p(npts), pp.shape[1],
+            int(self.mbCheckOrientation), int(stereo_pair0), None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
+
+    def SearchByProjectionBatch(self, ex, first_image, n_frames, bounds, mapPoints, n_map_points, occupied=None, th=1.0,
+                                bFarPoints=False, thFarPoints=50.0, stereo_pair0=-1):
+        """SearchByProjection (local map points) on the frames of ex's last extraction batch in one call
+        (orbx_search_by_projection_batch): mapPoints [n_frames][stride] MP_DTYPE.  Returns (n_matches, match, occupied)."""
+        mp = np.ascontiguousarray(mapPoints, MP_DTYPE).reshape(n_frames, -1)
+        npts = np.ascontiguousarray(n_map_points, np.int32)
+        cap = ex.capacity
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, cap)
+        occ = np.zeros((n_frames, cap), np.uint8)
+        match = np.full((n_frames, cap), -1, np.int32)
+        nm = np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_batch(
+            ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(mp), _p(npts), mp.shape[1],
+            float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, int(stereo_pair0),
+            None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
 
     def SearchByProjectionKeyFrame(self, kpsUn, desc, bounds, projectedPoints, occupied, ORBdist=100):
         """Matching part of the relocalisation matcher SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist)

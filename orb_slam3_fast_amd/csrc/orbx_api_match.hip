@@ -462,6 +462,178 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
                                    points ? points : &dummy, n_points, 1.0f, 0, 0.f, 0.f, check_orientation, occupied, match);
 }
 
+namespace {
+// The pinhole SearchByProjection flavours on the frames of an extraction batch: keypoints and
+// descriptors of frame f are image first_image + f of the handle's last batch and never leave HBM; only the points (and the
+// occupancy flags) are uploaded, in one copy; every kernel of the chain is launched ONCE for all frames (blockIdx.y = frame,
+// launch_proj_batch) with kProjBlindRounds fixed-point rounds enqueued without looking; match / occupied / counts come back in
+// one copy.  A frame whose candidate lists overflowed the first guess or whose claims did not settle within the blind rounds
+// (pathological chains) is redone through the one-shot path -- same result by construction, checked by the tests.
+int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x, float max_y, int mode,
+                    const orbx_map_point_view* mps, const orbx_projected_point* pts, const int32_t* n_points, int stride, float th,
+                    int far_points, float th_far, float nnratio, int check_ori, int stereo_pair0, const uint8_t* occupied_in,
+                    uint8_t* occupied, int32_t* match, int32_t* n_matches) {
+  if (!ex || n_frames < 0 || first_image < 0 || !n_points || stride < 0 || (n_frames && (!occupied || !match || !n_matches)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_frames == 0) return 0;
+  if (ex->lastN <= 0 || first_image + n_frames > ex->lastN) return fail(ORBX_E_BADARG, "frames outside the handle's last batch");
+  if (stereo_pair0 >= 0 && stereo_pair0 + n_frames > ex->lastStereoPairs)
+    return fail(ORBX_E_BADARG, "u_right requested but the handle's last stereo association does not cover these frames");
+  int maxPts = 0;
+  for (int f = 0; f < n_frames; f++) {
+    if (n_points[f] < 0 || n_points[f] > stride) return fail(ORBX_E_BADARG, "n_points[f] outside [0, points_stride]");
+    if (n_points[f] > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 points in a frame");
+    maxPts = std::max(maxPts, n_points[f]);
+  }
+  if (maxPts && (mode == 0 ? !mps : !pts)) return fail(ORBX_E_BADARG, "null points");
+  const int nlevels = ex->prm.nlevels;
+  if (mode == 0)
+    for (int f = 0; f < n_frames; f++)
+      for (int i = 0; i < n_points[f]; i++) {
+        const orbx_map_point_view& m = mps[(size_t)f * stride + i];
+        if (m.in_view && !m.bad && (m.predicted_level < 0 || m.predicted_level >= nlevels))
+          return fail(ORBX_E_BADARG, "in-view map point with a predicted level outside [0, nlevels)");
+      }
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int cap = ex->gmax.outCap, F = n_frames;
+  // the frames' keypoint counts live on the device: one small copy behind the extraction
+  std::vector<int> n2(F);
+  HIPC(hipStreamSynchronize(ex->stream));
+  HIPC(hipMemcpy(n2.data(), ex->d_nOut.p + first_image, (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  int maxN2 = 0;
+  for (int f = 0; f < F; f++) {
+    n2[f] = std::min(std::max(n2[f], 0), cap);
+    maxN2 = std::max(maxN2, n2[f]);
+  }
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  static const int kBlind = getenv("ORBX_PROJ_BLIND") ? std::min(48, std::max(1, atoi(getenv("ORBX_PROJ_BLIND")))) : 16;
+  const int nm = std::max(maxPts, 1), candCap = capEnv > 0 ? capEnv : nm * 96;
+  const size_t ptBytes = mode == 0 ? sizeof(orbx_map_point_view) : sizeof(orbx_projected_point);
+  constexpr int kFlags = 40 + 48;
+  // ---- one device block: inputs | outputs (occupied, match, result, flags: one copy back) | scratch
+  Pack pk;
+  std::vector<ProjArgs> frames(F);
+  std::vector<uint8_t> occ0;
+  if (!occupied_in) occ0.assign((size_t)F * cap, 0);
+  const size_t oPts = pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr, (size_t)F * std::max(stride, 1) * ptBytes);
+  const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
+  const size_t oFr = pk.add(frames.data(), (size_t)F * sizeof(ProjArgs));
+  const size_t oOcc = pk.add(occupied_in ? occupied_in : occ0.data(), (size_t)F * cap);
+  const size_t oMt = pk.add(nullptr, (size_t)F * cap * sizeof(int)), oRes = pk.add(nullptr, (size_t)F * 2 * sizeof(int));
+  const size_t oFlags = pk.add(nullptr, (size_t)F * kFlags * sizeof(int));
+  const size_t outBytes = oFlags + (size_t)F * kFlags * sizeof(int) - oOcc;
+  auto per = [&](size_t ints) { return pk.add(nullptr, (size_t)F * ints * sizeof(int)); };
+  const size_t cs = 64 * 48 + 4, oCs = per(cs), oCi = per(cap), oMd = per(cap), oM21 = per(cap), oM12 = per(4);
+  const size_t oCo = per((size_t)nm + 4), oCx = per(candCap), oCd = per(candCap);
+  const size_t oT0 = per(cap), oT1 = per(cap), oT2 = per(cap), oCh = per(nm);
+  hipError_t e = pk.reserve();
+  if (e != hipSuccess) { pk.release(); return fail(ORBX_E_HIP, hipGetErrorString(e)); }
+  for (int f = 0; f < F; f++) {
+    ProjArgs a{};
+    const int img = first_image + f;
+    a.grid.k2 = ex->d_kps.p + (size_t)img * cap;
+    a.grid.n2 = n2[f];
+    a.grid.n1 = 0;
+    a.grid.minX = min_x; a.grid.minY = min_y;
+    a.grid.invW = 64.f / (max_x - min_x);
+    a.grid.invH = 48.f / (max_y - min_y);
+    a.grid.cellStart = pk.ptr<int>(oCs) + (size_t)f * cs;
+    a.grid.cellItems = pk.ptr<int>(oCi) + (size_t)f * cap;
+    a.grid.matchedDist = pk.ptr<int>(oMd) + (size_t)f * cap;
+    a.grid.matches21 = pk.ptr<int>(oM21) + (size_t)f * cap;
+    a.grid.matches12 = pk.ptr<int>(oM12) + (size_t)f * 4;
+    a.grid.result = pk.ptr<int>(oRes) + (size_t)f * 2;
+    a.grid.candOff = pk.ptr<int>(oCo) + (size_t)f * (nm + 4);
+    a.grid.candCap = 1 << 30;
+    a.desc = ex->d_desc.p + (size_t)img * cap * 32;
+    a.uRight = stereo_pair0 >= 0 ? ex->d_uR.p + (size_t)(stereo_pair0 + f) * cap : nullptr;
+    a.scale = pk.ptr<float>(oSf);
+    a.mps = mode == 0 ? pk.ptr<orbx_map_point_view>(oPts) + (size_t)f * stride : nullptr;
+    a.pts = mode == 1 ? pk.ptr<orbx_projected_point>(oPts) + (size_t)f * stride : nullptr;
+    a.nmp = n_points[f];
+    a.mode = mode; a.checkOri = check_ori; a.maxDist = 100 /* TH_HIGH */; a.claimAll = 0;
+    a.th = th; a.thFar = th_far; a.nnratio = nnratio; a.far = far_points;
+    a.occupied = pk.ptr<uint8_t>(oOcc) + (size_t)f * cap;
+    a.match = pk.ptr<int>(oMt) + (size_t)f * cap;
+    a.candOff = a.grid.candOff;
+    a.candIdx = pk.ptr<int>(oCx) + (size_t)f * candCap;
+    a.candDist = pk.ptr<int>(oCd) + (size_t)f * candCap;
+    a.candCap = candCap;
+    a.result = a.grid.result;
+    a.taker[0] = pk.ptr<int>(oT0) + (size_t)f * cap; a.taker[1] = pk.ptr<int>(oT1) + (size_t)f * cap;
+    a.taker[2] = pk.ptr<int>(oT2) + (size_t)f * cap;
+    a.choice = pk.ptr<int>(oCh) + (size_t)f * nm;
+    a.flags = pk.ptr<int>(oFlags) + (size_t)f * kFlags;
+    frames[f] = a;
+  }
+  e = pk.commit();  // points, scale factors, the argument blocks (now complete) and the occupancy flags: one upload
+  if (e == hipSuccess) e = launch_proj_batch(pk.ptr<ProjArgs>(oFr), F, maxPts, maxN2, mode, check_ori, kBlind, nullptr);
+  std::vector<int> redo;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      for (int f = 0; f < F; f++) {
+        int res[2], lastChanged = 0;
+        std::memcpy(res, h + (oRes - oOcc) + (size_t)f * 2 * sizeof(int), sizeof res);
+        std::memcpy(&lastChanged, h + (oFlags - oOcc) + ((size_t)f * kFlags + 40 + kBlind - 1) * sizeof(int), sizeof(int));
+        if (n_points[f] > 0 && (res[1] > candCap || lastChanged)) {
+          redo.push_back(f);
+          continue;
+        }
+        std::memcpy(occupied + (size_t)f * cap, h + (size_t)f * cap, cap);
+        std::memcpy(match + (size_t)f * cap, h + (oMt - oOcc) + (size_t)f * cap * sizeof(int), (size_t)cap * sizeof(int));
+        for (int i = n2[f]; i < cap; i++) match[(size_t)f * cap + i] = -1;   // rows past the frame's keypoints
+        n_matches[f] = res[0];
+      }
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  // ---- the rare frames the blind batch could not finish: the one-shot path on a host copy of the frame
+  for (int f : redo) {
+    const int img = first_image + f, n = n2[f];
+    std::vector<orbx_keypoint> k(std::max(n, 1));
+    std::vector<uint8_t> d((size_t)std::max(n, 1) * 32);
+    std::vector<float> ur(std::max(n, 1));
+    HIPC(hipMemcpy(k.data(), ex->d_kps.p + (size_t)img * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(d.data(), ex->d_desc.p + (size_t)img * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (stereo_pair0 >= 0)
+      HIPC(hipMemcpy(ur.data(), ex->d_uR.p + (size_t)(stereo_pair0 + f) * cap, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    uint8_t* occ = occupied + (size_t)f * cap;
+    int32_t* mt = match + (size_t)f * cap;
+    if (occupied_in) std::memcpy(occ, occupied_in + (size_t)f * cap, cap); else std::memset(occ, 0, cap);
+    for (int i = 0; i < cap; i++) mt[i] = -1;
+    rc = search_by_projection_impl(ex->device, k.data(), d.data(), stereo_pair0 >= 0 ? ur.data() : nullptr, n, min_x, min_y, max_x,
+                                   max_y, ex->scale.data(), nlevels, mode == 0 ? mps + (size_t)f * stride : nullptr,
+                                   mode == 1 ? pts + (size_t)f * stride : nullptr, n_points[f], th, far_points, th_far, nnratio,
+                                   check_ori, occ, mt);
+    if (rc < 0) return rc;
+    n_matches[f] = rc;
+  }
+  int total = 0;
+  for (int f = 0; f < F; f++) total += n_matches[f];
+  return total;
+}
+}  // namespace
+
+int orbx_search_by_projection_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
+                                    float max_y, const orbx_map_point_view* map_points, const int32_t* n_map_points,
+                                    int points_stride, float th, int far_points, float th_far_points, float nnratio,
+                                    int stereo_pair0, const uint8_t* occupied_in, uint8_t* occupied, int32_t* match,
+                                    int32_t* n_matches) {
+  return proj_batch_impl(ex, first_image, n_frames, min_x, min_y, max_x, max_y, 0, map_points, nullptr, n_map_points, points_stride,
+                         th, far_points, th_far_points, nnratio, 0, stereo_pair0, occupied_in, occupied, match, n_matches);
+}
+
+int orbx_search_by_projection_frame_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
+                                          float max_y, const orbx_projected_point* points, const int32_t* n_points,
+                                          int points_stride, int check_orientation, int stereo_pair0, const uint8_t* occupied_in,
+                                          uint8_t* occupied, int32_t* match, int32_t* n_matches) {
+  return proj_batch_impl(ex, first_image, n_frames, min_x, min_y, max_x, max_y, 1, nullptr, points, n_points, points_stride, 1.0f, 0,
+                         0.f, 0.f, check_orientation, stereo_pair0, occupied_in, occupied, match, n_matches);
+}
+
 int orbx_search_for_triangulation_rig(int device, const uint32_t* node_ids1, const int32_t* node_start1, const uint32_t* feature_idx1,
                                       int n_nodes1, const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* has_map_point1,
                                       int n_left1, int n1, const uint32_t* node_ids2, const int32_t* node_start2,

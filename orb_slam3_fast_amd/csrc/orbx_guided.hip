@@ -1,5 +1,7 @@
 // orbx_guided.hip — grid-guided matchers: ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:618-764) and the two
 // SearchByProjection flavours (:41-221, :1594-1806), pinhole and stereo-fisheye.
+#include <algorithm>
+
 #include "orbx_device.h"
 
 namespace orbx {
@@ -17,7 +19,41 @@ __device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs&
 // flags[kProjChanged + r] = round r of a fixed-point resolve changed a choice (the flag arrays hold 40 + 48 entries)
 constexpr int kProjChanged = 40;
 constexpr int kGridThreads = 1024;
-__global__ __launch_bounds__(kGridThreads) void k_init_grid(InitArgs a) {  // single block
+// Kernel-argument views (round 4): the one-shot entry points pass their argument block by value (kernel arguments); the batched
+// SearchByProjection entries launch every kernel ONCE for all frames of an extraction batch with blockIdx.y = frame and the
+// frames' argument blocks in a device array.  The kernel bodies are the same code.
+struct GridVal {
+  InitArgs v;
+  __device__ __forceinline__ const InitArgs& get() const { return v; }
+};
+struct GridOfProj {  // the frame grid of frame blockIdx.y
+  const ProjArgs* p;
+  __device__ __forceinline__ const InitArgs& get() const { return p[blockIdx.y].grid; }
+};
+struct ScanOfProj {  // k_init_scan over frame blockIdx.y's candidate counts
+  const ProjArgs* p;
+  __device__ __forceinline__ InitArgs get() const {
+    const ProjArgs& a = p[blockIdx.y];
+    InitArgs sc = a.grid;
+    sc.candOff = a.candOff;
+    sc.n1 = a.nmp;
+    sc.candCap = a.candCap;
+    return sc;
+  }
+};
+template <bool B> struct ProjRef;
+template <> struct ProjRef<false> {
+  ProjArgs v;
+  __device__ __forceinline__ const ProjArgs& get() const { return v; }
+};
+template <> struct ProjRef<true> {
+  const ProjArgs* p;
+  __device__ __forceinline__ const ProjArgs& get() const { return p[blockIdx.y]; }
+};
+
+template <class R>
+__global__ __launch_bounds__(kGridThreads) void k_init_grid(R ar) {  // single block (per frame)
+  const InitArgs& a = ar.get();
   // Counting sort of the keypoints by grid cell, ascending keypoint index inside a cell (mGrid[i][j].push_back order,
   // src/Frame.cc:536-546): count -> block scan -> unordered atomic fill -> per-cell insertion sort of the short lists.
   // One workgroup, pure latency: 1024 threads so that the keypoints are read in one or two trips, and the cell of a
@@ -150,7 +186,9 @@ __global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
   if (!pass && lane == 0) a.candOff[i1] = total;
 }
 
-__global__ __launch_bounds__(256) void k_init_scan(InitArgs a) {  // single block: exclusive scan of candOff
+template <class R>
+__global__ __launch_bounds__(256) void k_init_scan(R ar) {  // single block: exclusive scan of candOff
+  const InitArgs& a = ar.get();
   __shared__ int tsum[256];
   const int tid = threadIdx.x, n = a.n1;
   const int per = (n + 255) >> 8, b = min(tid * per, n), e = min(b + per, n);
@@ -325,7 +363,7 @@ __global__ __launch_bounds__(256) void k_area_query(InitArgs a, const float* __r
 }
 
 hipError_t launch_grid_build(const InitArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a);
+  hipLaunchKernelGGL(k_init_grid<GridVal>, dim3(1), dim3(kGridThreads), 0, s, GridVal{a});
   return hipGetLastError();
 }
 // ---- ORBmatcher::Fuse, the search of the loop body (src/ORBmatcher.cc:1195-1256) -----------------------------------------------
@@ -404,15 +442,15 @@ hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOf
   return hipGetLastError();
 }
 hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s) {  // exclusive scan of a.candOff[0..n1] (n1 = #queries)
-  hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_init_scan<GridVal>, dim3(1), dim3(256), 0, s, GridVal{a});
   return hipGetLastError();
 }
 
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a);
+  hipLaunchKernelGGL(k_init_grid<GridVal>, dim3(1), dim3(kGridThreads), 0, s, GridVal{a});
   if (a.n1 > 0) {
     hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 0);
-    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_init_scan<GridVal>, dim3(1), dim3(256), 0, s, GridVal{a});
   }
   return hipGetLastError();
 }
@@ -637,7 +675,9 @@ __device__ __forceinline__ bool proj_query(const ProjArgs& a, int im, ProjQuery&
   return true;
 }
 
-__global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_cands(ProjRef<B> ar, int pass) {
+  const ProjArgs& a = ar.get();
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (im >= a.nmp) return;
@@ -690,7 +730,9 @@ __global__ __launch_bounds__(256) void k_proj_cands(ProjArgs a, int pass) {
   if (!pass && lane == 0) a.candOff[im] = total;
 }
 
-__global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
+template <bool B>
+__global__ __launch_bounds__(64) void k_proj_resolve(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();
   __shared__ int hist[30];
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int* binIdx = reinterpret_cast<int*>(smem);  // mode 1: (bin << 24 | keypoint index) per accepted match, in order
@@ -804,7 +846,9 @@ __global__ __launch_bounds__(64) void k_proj_resolve(ProjArgs a) {
 // index).  By induction point t is final after round t + 1, and a round that changes nothing has reached the fixed
 // point, which is the serial result; on real inputs a handful of rounds suffice (a claim only matters when two points
 // compete for one keypoint).  Wave per point.
-__global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_round(ProjRef<B> ar, int round_no) {
+  const ProjArgs& a = ar.get();
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
   // the host enqueues a fixed number of rounds without looking: once a round has changed nothing the fixed point is reached
@@ -865,7 +909,9 @@ __global__ __launch_bounds__(256) void k_proj_round(ProjArgs a, int round_no) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a) {  // before round 0: taker[1] = +inf, no matches, flags 0
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_reset(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();  // before round 0: taker[1] = +inf, no matches, flags 0
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.grid.n2; i += gridDim.x * 256) {
     a.taker[1][i] = 0x7FFFFFFF;
     a.match[i] = -1;
@@ -875,7 +921,9 @@ __global__ __launch_bounds__(256) void k_proj_reset(ProjArgs a) {  // before rou
 
 // After convergence: match[k] = the LAST point that chose k (later assignments overwrite), occupied[k] = that point's
 // observation flag, orientation histogram of the accepted pairs (mode 1).
-__global__ __launch_bounds__(256) void k_proj_assign(ProjArgs a) {
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_assign(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();
   const int im = blockIdx.x * 256 + threadIdx.x;
   bool acc = false;
   if (im < a.nmp) {
@@ -897,7 +945,9 @@ __global__ __launch_bounds__(256) void k_proj_assign(ProjArgs a) {
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[1], __popcll(m));
 }
 
-__global__ __launch_bounds__(256) void k_proj_cull(ProjArgs a) {
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_cull(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();
   // occupied: set by the last chooser (a keypoint whose first chooser has observations has no later chooser)
   for (int k = blockIdx.x * 256 + threadIdx.x; k < a.grid.n2; k += gridDim.x * 256) {
     const int im = a.match[k];
@@ -905,7 +955,9 @@ __global__ __launch_bounds__(256) void k_proj_cull(ProjArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-consistency cull (:1780-1800, :1920-1955)
+template <bool B>
+__global__ __launch_bounds__(256) void k_proj_cull2(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();  // rotation-consistency cull (:1780-1800, :1920-1955)
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   for (int i = 0; i < 30; i++) {
     const int s = a.flags[3 + i];
@@ -944,32 +996,36 @@ __global__ __launch_bounds__(256) void k_proj_cull2(ProjArgs a) {  // rotation-c
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[2], __popcll(m));
 }
 
-__global__ void k_proj_result(ProjArgs a) { a.result[0] = a.flags[1] - a.flags[2]; }
+template <bool B>
+__global__ void k_proj_result(ProjRef<B> ar) {
+  const ProjArgs& a = ar.get();
+  a.result[0] = a.flags[1] - a.flags[2];
+}
 
 hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s) {
-  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, 1);
   return hipGetLastError();
 }
 hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s) {
   if (a.nmp <= 0) return hipSuccess;
-  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, a);
+  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset<false>, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, ProjRef<false>{a});
   for (int r = first_round; r < first_round + rounds; r++)
-    hipLaunchKernelGGL(k_proj_round, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, r);
+    hipLaunchKernelGGL(k_proj_round<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, r);
   return hipGetLastError();
 }
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s) {
   (void)last_round;
   if (a.nmp > 0) {
-    hipLaunchKernelGGL(k_proj_assign, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_proj_cull, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, a);
-    if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull2, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_proj_assign<false>, dim3((a.nmp + 255) / 256), dim3(256), 0, s, ProjRef<false>{a});
+    hipLaunchKernelGGL(k_proj_cull<false>, dim3((a.grid.n2 + 255) / 256), dim3(256), 0, s, ProjRef<false>{a});
+    if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull2<false>, dim3((a.nmp + 255) / 256), dim3(256), 0, s, ProjRef<false>{a});
   }
-  hipLaunchKernelGGL(k_proj_result, dim3(1), dim3(1), 0, s, a);
+  hipLaunchKernelGGL(k_proj_result<false>, dim3(1), dim3(1), 0, s, ProjRef<false>{a});
   return hipGetLastError();
 }
 hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s) {
   const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;
-  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(64), lds, s, ProjRef<false>{a});
   return hipGetLastError();
 }
 
@@ -1399,21 +1455,43 @@ hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_proj_count(const ProjArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_init_grid, dim3(1), dim3(kGridThreads), 0, s, a.grid);
+  hipLaunchKernelGGL(k_init_grid<GridVal>, dim3(1), dim3(kGridThreads), 0, s, GridVal{a.grid});
   if (a.nmp > 0) {
-    hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_proj_cands<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, 0);
     InitArgs sc = a.grid;  // k_init_scan scans candOff[0 .. n1]
     sc.candOff = a.candOff;
     sc.n1 = a.nmp;
     sc.candCap = a.candCap;
-    hipLaunchKernelGGL(k_init_scan, dim3(1), dim3(256), 0, s, sc);
+    hipLaunchKernelGGL(k_init_scan<GridVal>, dim3(1), dim3(256), 0, s, GridVal{sc});
   }
   return hipGetLastError();
 }
+// Every frame of a batch through the whole pinhole SearchByProjection chain, one launch per kernel (blockIdx.y = frame): grid,
+// candidate counts, scan, candidate fill, `rounds` blind fixed-point rounds, assignment, occupancy, orientation cull, count.
+// d_frames: device array of nFrames argument blocks (same mode / checkOri); maxPts / maxN2: the largest point / keypoint count.
+hipError_t launch_proj_batch(const ProjArgs* d_frames, int nFrames, int maxPts, int maxN2, int mode, int checkOri, int rounds,
+                             hipStream_t s) {
+  if (nFrames <= 0) return hipSuccess;
+  const dim3 one(1, nFrames), pts4((std::max(maxPts, 1) + 3) / 4, nFrames), pts256((std::max(maxPts, 1) + 255) / 256, nFrames),
+      n2b((std::max(maxN2, 1) + 255) / 256, nFrames);
+  const ProjRef<true> r{d_frames};
+  hipLaunchKernelGGL(k_init_grid<GridOfProj>, one, dim3(kGridThreads), 0, s, GridOfProj{d_frames});
+  hipLaunchKernelGGL(k_proj_cands<true>, pts4, dim3(256), 0, s, r, 0);
+  hipLaunchKernelGGL(k_init_scan<ScanOfProj>, one, dim3(256), 0, s, ScanOfProj{d_frames});
+  hipLaunchKernelGGL(k_proj_cands<true>, pts4, dim3(256), 0, s, r, 1);
+  hipLaunchKernelGGL(k_proj_reset<true>, n2b, dim3(256), 0, s, r);
+  for (int i = 0; i < rounds; i++) hipLaunchKernelGGL(k_proj_round<true>, pts4, dim3(256), 0, s, r, i);
+  hipLaunchKernelGGL(k_proj_assign<true>, pts256, dim3(256), 0, s, r);
+  hipLaunchKernelGGL(k_proj_cull<true>, n2b, dim3(256), 0, s, r);
+  if (mode == 1 && checkOri) hipLaunchKernelGGL(k_proj_cull2<true>, pts256, dim3(256), 0, s, r);
+  hipLaunchKernelGGL(k_proj_result<true>, one, dim3(1), 0, s, r);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
-  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, 1);
+  if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, 1);
   const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;  // one int per accepted match
-  hipLaunchKernelGGL(k_proj_resolve, dim3(1), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(k_proj_resolve<false>, dim3(1), dim3(64), lds, s, ProjRef<false>{a});
   return hipGetLastError();
 }
 

@@ -152,8 +152,15 @@ class Pack {
     if (src && bytes) inputEnd_ = total_;
     return off;
   }
+  // allocates the device block for everything added so far: ptr<>() is valid from here on, while the input items' host
+  // sources are still only read by commit() -- an argument block that holds device pointers INTO the pack can be filled in
+  // between (the batched matchers).  No item may be added after it.
+  hipError_t reserve() {
+    if (dev_.p) return hipSuccess;
+    return dev_.alloc(std::max<size_t>(total_, 256));
+  }
   hipError_t commit() {
-    hipError_t e = dev_.alloc(std::max<size_t>(total_, 256));
+    hipError_t e = reserve();
     if (e != hipSuccess) return e;
     if (inputEnd_) {
       uint8_t* h = pinned(inputEnd_);

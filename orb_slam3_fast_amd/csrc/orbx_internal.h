@@ -343,6 +343,8 @@ hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s);            
 hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s);  // fixed-point rounds
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s);     // match / occupied / cull / count
 hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s);             // the one-wave walk (fallback)
+hipError_t launch_proj_batch(const ProjArgs* d_frames, int nFrames, int maxPts, int maxN2, int mode, int checkOri, int rounds,
+                             hipStream_t s);                                        // all frames of a batch, one launch per kernel
 
 // Search part of ORBmatcher::Fuse(pKF, vpMapPoints, th, bRight) (src/ORBmatcher.cc:1195-1256): k_fuse_search
 struct FuseArgs {
