@@ -161,3 +161,26 @@ for _ in range(reps):
     exb.sync()
 tb = (time.perf_counter() - t0) / reps * 1e3
 print("%-62s %12.3f   (%.1f us per image, results stay in HBM)" % ("ComputeBoW, batch of %d extracted images" % B, tb, tb * 1e3 / B))
+
+# batched SearchByProjection on the frames of an extraction batch (round 4): 32 frames, ~1500 points each, keypoints and
+# descriptors device-resident; one call = one upload of the points, one launch per kernel of the chain, one download
+FB = 32
+stride = len(pts)
+ptsB = np.stack([pts] * FB)
+mpsB = np.stack([mps] * FB)
+nptsB = np.full(FB, len(pts), np.int32)
+for i in range(FB):   # (different points per frame: shift the projections a little)
+    ptsB[i]["u"] += np.float32(0.25 * i)
+    mpsB[i]["proj_x"] += np.float32(0.25 * i)
+occB = np.stack([np.pad(occ, (0, exb.capacity - len(occ)))] * FB)
+for name, fn in (("SearchByProjection(Cur, Last), batch of %d frames" % FB,
+                  lambda: m.SearchByProjectionFrameBatch(exb, 0, FB, bounds, ptsB, nptsB, occB)),
+                 ("SearchByProjection(F, MapPoints), batch of %d frames" % FB,
+                  lambda: m.SearchByProjectionBatch(exb, 0, FB, bounds, mpsB, nptsB, occB, 3.0, True, 60.0))):
+    for _ in range(3):
+        r = fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    tb = (time.perf_counter() - t0) / reps * 1e3
+    print("%-62s %12.3f   (%.3f ms per frame, %d matches in frame 0; one-shot call above: per frame)" % (name, tb, tb / FB, int(r[0][0])))
