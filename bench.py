@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--sustain-ms", type=float, default=3000.0,
+                    help="extras: repeat the timed step back to back for this long and report the sustained rate (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / H2D-inclusive / cpu legs (profiling runs)")
     ap.add_argument("--latency-frames", type=int, default=200)
     ap.add_argument("--h2d-steps", type=int, default=30)
@@ -558,6 +560,21 @@ def main():
         out["other_configs"] = other_configs_leg(a, local_rank, torch)
     if extras:
         out.update(natural_pair_leg(orbx, np))
+    if extras and a.sustain_ms > 0:
+        # The timed region of the default run is ~10 - 50 ms: too short for an outside sampler (the driver polls GPU activity every
+        # few seconds) and open to the question whether it is a burst.  The same steps, back to back, for --sustain-ms of wall time
+        # (synchronised every 64 steps so that the host cannot run ahead without bound); reported, never the headline value.
+        wl.sync()
+        t0 = time.perf_counter()
+        ns = 0
+        while (time.perf_counter() - t0) * 1e3 < a.sustain_ms:
+            for _ in range(64):
+                wl.step()
+            wl.sync()
+            ns += 64
+        dt = time.perf_counter() - t0
+        out["sustained"] = {"value": round(units_per_step * ns / dt, 1), "unit": out["unit"], "steps": ns, "seconds": round(dt, 2),
+                            "note": "the timed step repeated back to back for --sustain-ms (synchronised every 64 steps)"}
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
     if extras and a.h2d_steps > 0:
