@@ -57,6 +57,30 @@ struct ResizeLv {
   const uint8_t* src; long long srcImg;   // level l-1 of image 0, bytes between images
   uint8_t* dst; long long dstImg;         // level l of image 0
 };
+// Vertical blend of cv::resize for four pixels: (((b0 * u0) >> 16) + ((b1 * u1) >> 16) + 2) >> 2 with u0 / u1 = the u16 halves of
+// t0 / t1 (horizontal results >> 4, < 2^15) and bb = b0 | b1 << 16 (wave-uniform, an SGPR).  Hand-assembled (the compiler spent
+// 24 instructions per four pixels on it: unpacking shifts, per-pixel shift-and-insert with materialised constants): the products
+// are v_mad_u32_u16 on the halves picked by op_sel, the rounding 2 rides in the first product as 2 << 16 (exact: it is added below
+// the truncation), the two high words are summed and laid down as u16 pairs by SDWA selects (sum <= 1022), a packed shift by 2 and
+// one v_perm collect the four bytes: 15 instructions.
+__device__ __forceinline__ uint32_t vblend4(uint2 t0, uint2 t1, uint32_t bb, uint32_t kRound) {
+  uint32_t p0, p1, p2, p3, q0, q1, q2, q3, w01, w23;
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(p0) : "v"(t0.x), "s"(bb), "v"(kRound));
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(p1) : "v"(t0.x), "s"(bb), "v"(kRound));
+  asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(p2) : "v"(t0.y), "s"(bb), "v"(kRound));
+  asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(p3) : "v"(t0.y), "s"(bb), "v"(kRound));
+  asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v"(q0) : "v"(t1.x), "s"(bb));
+  asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v"(q1) : "v"(t1.x), "s"(bb));
+  asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v"(q2) : "v"(t1.y), "s"(bb));
+  asm("v_mad_u32_u16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v"(q3) : "v"(t1.y), "s"(bb));
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(w01) : "v"(p0), "v"(q0));
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(w01) : "v"(p1), "v"(q1));
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(w23) : "v"(p2), "v"(q2));
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(w23) : "v"(p3), "v"(q3));
+  asm("v_pk_lshrrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(w01) : "v"(w01));
+  asm("v_pk_lshrrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(w23) : "v"(w23));
+  return __builtin_amdgcn_perm(w23, w01, 0x06040200u);
+}
 template <int NDW>
 __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __restrict__ xtab,
                                                 const int* __restrict__ yofs, const short* __restrict__ yab,
@@ -177,9 +201,11 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
         const uint32_t* pr = reinterpret_cast<const uint32_t*>(rowp + ba[j]);
         t[j] = udot2_u16(__builtin_amdgcn_perm(pr[1], pr[0], sel[j]), coef[j], 0u);
       }
-      uint2 pk;  // (t >> 4) as u16 pairs: bytes 0, 1 of t_even >> 4 and bytes 2, 3 of t_odd << 12
-      pk.x = __builtin_amdgcn_perm(t[1] << 12, t[0] >> 4, 0x07060100u);
-      pk.y = __builtin_amdgcn_perm(t[3] << 12, t[2] >> 4, 0x07060100u);
+      uint2 pk;  // (t >> 4) as u16 pairs: the even result by a plain shift (t < 2^19: the high half comes out zero), the odd
+      pk.x = t[0] >> 4;  // one shifted INTO the high half by an SDWA destination select (2 instead of 3 instructions per pair)
+      pk.y = t[2] >> 4;
+      asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk.x) : "v"(t[1]));
+      asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk.y) : "v"(t[3]));
       *reinterpret_cast<uint2*>(outp) = pk;
     };
     const int rw0 = RS_HROWS * w;
@@ -201,30 +227,27 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
 #endif
   // vertical pass: lane = quad, wave w owns dst rows w, w + 4, ... of the block: the row constants are wave-uniform
   {
-    const uint16_t* ht = reinterpret_cast<const uint16_t*>(ht8);
     const int qx = tid & 63;
     const int dx = x0 + 4 * qx;
+    uint32_t kRound = 0x20000u;                // the "+ 2" of the vertical blend, added below the first product's truncation
+    asm volatile("" : "+v"(kRound));           // (a VGPR: the products' one scalar operand is the row's coefficient pair)
+    if (dx < D.w) {                            // lane-invariant over the rows: tested once, the row loop only has uniform exits
+      const uint8_t* htq = ht8 + 8 * qx;
+      uint8_t* dstImg = rl.dst + (long long)img * rl.dstImg;   // wave-uniform: the stores take row base + 32-bit lane offset
 #pragma unroll
-    for (int k = 0; k < RS_DR / 4; k++) {
-      const int dy = y0 + w + 4 * k;
-      if (dy >= D.h) break;
-      const int sy = vsy[k];
-      const uint32_t bb = vbb[k];
-      const int b0 = (int)(bb & 0xFFFF), b1 = (int)(bb >> 16);
-      const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
-      if (dx >= D.w) continue;
-      const uint2 t0 = *reinterpret_cast<const uint2*>(ht + r0 * RS_DW + 4 * qx);
-      const uint2 t1 = *reinterpret_cast<const uint2*>(ht + r1 * RS_DW + 4 * qx);
-      const int u0[4] = {(int)(t0.x & 0xFFFF), (int)(t0.x >> 16), (int)(t0.y & 0xFFFF), (int)(t0.y >> 16)};
-      const int u1[4] = {(int)(t1.x & 0xFFFF), (int)(t1.x >> 16), (int)(t1.y & 0xFFFF), (int)(t1.y >> 16)};
-      uint32_t outw = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int v = (((b0 * u0[j]) >> 16) + ((b1 * u1[j]) >> 16) + 2) >> 2;
-        outw |= (uint32_t)(v & 255) << (8 * j);
+      for (int k = 0; k < RS_DR / 4; k++) {
+        const int dy = y0 + w + 4 * k;
+        if (dy >= D.h) break;
+        const int sy = vsy[k];
+        const uint32_t bb = vbb[k];
+        const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
+        const uint2 t0 = *reinterpret_cast<const uint2*>(htq + r0 * (RS_DW * 2));
+        const uint2 t1 = *reinterpret_cast<const uint2*>(htq + r1 * (RS_DW * 2));
+        const uint32_t outw = vblend4(t0, t1, bb, kRound);
+        uint8_t* dstRow = dstImg + (long long)dy * D.pitch;   // wave-uniform: scalar base + 32-bit lane offset (left to itself the
+        // compiler folds dx into the pointer and multiplies dy * pitch per lane in 64 bits)
+        asm volatile("global_store_dword %0, %1, %2" : : "v"((uint32_t)dx), "v"(outw), "s"(dstRow) : "memory");
       }
-      uint8_t* dst = rl.dst + (long long)img * rl.dstImg + (long long)dy * D.pitch;
-      *reinterpret_cast<uint32_t*>(dst + dx) = outw;
     }
   }
 #ifdef RS_PROF
