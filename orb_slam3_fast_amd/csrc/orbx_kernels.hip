@@ -135,6 +135,31 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
     // last row on both sides (the same bytes land on the same LDS dword again): no predicates in the loop.
     // Only a level-0 source (the caller's buffer) may end with its last pixel: then the last dword is read byte-wise.
     const bool whole = l > 1 || cb + 4 * ndw <= S.w;
+    constexpr int kFastTrips = 8;
+    if (NDW != 0 && whole && ndw > 64 && ndw <= 85 && nrows <= 3 * kFastTrips && rb + 3 * kFastTrips + 4 <= S.h) {
+      // The usual block (1.2 pyramid; not the level's last rows or a narrow last column block): 65 .. 85 dwords per footprint row,
+      // i.e. three rows per trip of the 256 threads, so the trips are SCALAR base increments of the loads and immediate offsets of
+      // the LDS stores -- no per-trip address arithmetic, no clamps, and straight-line code (inside the general loops below the
+      // compiler drains the coefficient loads before it issues the first footprint load).  Rows past the footprint (up to row
+      // 3 + 21 + 3: threads beyond 3 * ndw duplicate the next trip's rows) are real image rows (tested above) and land behind the
+      // footprint area, in the horizontal pass's output buffer, which is only written after the barrier.
+      const float inv_nd = __builtin_amdgcn_rcpf((float)ndw);
+      const int r0 = (int)(((float)tid + 0.5f) * inv_nd);      // tid / ndw (0 .. 3)
+      const int c = tid - __mul24(r0, ndw);
+      const uint8_t* fb = src + (long long)rb * sp + cb;       // wave-uniform base, 32-bit lane offset
+      const uint32_t off0 = (uint32_t)(__mul24(r0, sp) + 4 * c);
+      uint8_t* sdst = smem + 4 * (__mul24(r0, NDW) + c);
+      uint32_t v[kFastTrips];
+#pragma unroll
+      for (int k = 0; k < kFastTrips; k++) {
+        const uint8_t* fbk = fb + (size_t)(3 * k) * (size_t)sp;   // scalar
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(off0), "s"(fbk) : "memory");
+      }
+      // the compiler does not count these loads: wait for them here (its own later waits can only be stricter than needed)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+#pragma unroll
+      for (int k = 0; k < kFastTrips; k++) *reinterpret_cast<uint32_t*>(sdst + k * (12 * NDW)) = v[k];
+    } else
     for (int cbase = 0; cbase < ndw; cbase += 256) {          // one trip unless the scale factor exceeds ~3.9
     const int nd = min(ndw - cbase, 256);
     // (v_rcp_f32 is good to 1 ulp; the quotients below stay >= 0.5 / nd away from the next integer)

@@ -54,4 +54,4 @@ dt = time.perf_counter() - t0
 prof = ex.profile_collect()
 tag = os.environ.get("KB_TAG", "")
 print("%s pairs/s %.0f  ms/step %.3f | " % (tag, B * K / dt, 1e3 * dt / K) +
-      "  ".join("%s %.0f" % (k[2:], 1e3 * v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]))
+      "  ".join("%s %.1f" % (k[2:], 1e3 * v[0] / max(v[1], 1)) for k, v in prof.items() if v[1]))
