@@ -14,6 +14,7 @@
 // Integer/bitwise work: no MFMA.  Float steps that decide bits (fastAtan2, the rotated sampling
 // coordinates, sub-pixel disparity) use IEEE ops without contraction (-ffp-contract=off for this TU) and
 // round-half-even conversions, mirroring the x86-64 baseline (no FMA) build of the reference.
+#include <type_traits>
 #include "orbx_device.h"
 #include "orbx_introsort.h"
 #include "orbx_sincos.h"
@@ -1924,6 +1925,18 @@ constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 byt
 constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
 constexpr int DW_BP = 40;     // blurred patch pitch in bytes
 constexpr int DW_WAVE_DW = 22 * DW_HP + DW_ROWS * DW_RP + 16;  // dwords of LDS per wave: row pairs | raw window (+ slack)
+// weight dword of the fused blur's horizontal pass: byte i of window dword m carries tap k = 4 m + i - s (s = the byte the first tap
+// of the output column sits at), 0 outside the seven taps
+template <bool T440>
+__host__ __device__ constexpr uint32_t blur_w(int s, int m) {
+  const uint32_t tap[7] = {18u, 34u, T440 ? 49u : 48u, T440 ? 55u : 56u, T440 ? 49u : 48u, 34u, 18u};
+  uint32_t w = 0;
+  for (int i = 0; i < 4; i++) {
+    const int k = 4 * m + i - s;
+    if (k >= 0 && k <= 6) w |= tap[k] << (8 * i);
+  }
+  return w;
+}
 template <bool T440>  // (the Gaussian taps of OpenCV 4.0 .. 4.5.0, see k_blur)
 __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
                                                   const int* __restrict__ selCount, const int* __restrict__ slot,
@@ -2043,31 +2056,42 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   // x + 3 + mis, its taps are window bytes x + mis .. x + mis + 6
   // lane = (pair phase j0 = lane / 10, group q = lane % 10): 60 lanes cover 6 row pairs per trip, so a trip's window and
   // output addresses are the lane's base plus immediates (no index arithmetic inside the loop)
+  // The taps of output column 4q + j start at byte s = j + mis of the 16 window bytes d0..d3 the item reads (mis = the window's
+  // misalignment, wave-uniform): instead of shifting the bytes into place (3 + 6 v_alignbyte per row) the WEIGHTS are shifted --
+  // tap k sits at byte s + k of a per-(s, dword) weight constant (blur_w) -- and a column is the 2 or 3 v_dot4 over the dwords
+  // its taps touch: 10 v_dot4 per row and four columns whatever mis is (8 v_dot4 + 9 v_alignbyte before), one code variant per
+  // mis (uniform switch), the constants in SGPRs.
   {
     const int j0 = (lane * 6554) >> 16, q = lane - 10 * j0;  // lane / 10
-    const uint32_t* rbase = raw + 2 * j0 * DW_RP + q;
+    const int rbi = 22 * DW_HP + 2 * j0 * DW_RP + q;   // dword index of the item's first window dword (raw = hp + 22 * DW_HP)
     uint32_t* hbase = hp + j0 * DW_HP + 4 * q;
-    if (lane < 60) {
+    auto hpass = [&](auto misTag) {
+      constexpr int MIS = decltype(misTag)::value;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         if (t == 3 && j0 >= 4) break;  // pairs 22, 23 do not exist
         uint32_t h[2][4];
+        int ti = rbi + 12 * t * DW_RP;          // opaque per trip: the reads below are one address per trip plus small immediates
+        asm volatile("" : "+v"(ti));            // (folded onto the wave's LDS base the offsets exceed ds_read2's range: 2 v_add per row)
+        const uint32_t* rowt = hp + ti;
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
           // (row 43 = second row of pair 21 lies in the slack behind the window: it only feeds H row 43, which nothing reads)
-          const uint32_t* row = rbase + (12 * t + rr) * DW_RP;
-          const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3];  // (d3 of the last group only feeds unused columns)
-          const uint32_t A0 = __builtin_amdgcn_alignbyte(d1, d0, mis), A1 = __builtin_amdgcn_alignbyte(d2, d1, mis),
-                         A2 = __builtin_amdgcn_alignbyte(d3, d2, mis);  // 12 window bytes from the first tap of column 4q
-          constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
-          const uint32_t wA = 18u | (34u << 8) | (kT2 << 16) | (kT3 << 24), wB = kT2 | (34u << 8) | (18u << 16);  // taps 0..3 and 4..6 (LSB = lowest x)
-          h[rr][0] = __builtin_amdgcn_udot4(A0, wA, __builtin_amdgcn_udot4(A1, wB, 0, false), false);
-          h[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 1), wA,
-                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 1), wB, 0, false), false);
-          h[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 2), wA,
-                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 2), wB, 0, false), false);
-          h[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A1, A0, 3), wA,
-                                            __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(A2, A1, 3), wB, 0, false), false);
+          const uint32_t* row = rowt + rr * DW_RP;
+          uint32_t d[4];
+#pragma unroll
+          for (int m = 0; m < 4; m++) d[m] = (4 * m < MIS + 3 + 7) ? row[m] : 0u;  // (the last dword only when a tap reaches it)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int sft = j + MIS;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int m = 3; m >= 0; m--)
+              if (4 * m + 3 >= sft && 4 * m <= sft + 6) acc = __builtin_amdgcn_udot4(d[m], blur_w<T440>(sft, m), acc, false);
+            h[rr][j] = acc;
+          }
         }
         uint4 pk;  // H(2j, x) | H(2j + 1, x) << 16: one v_perm per column (sums of 7 taps x 255 fit 16 bits)
         pk.x = __builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u);
@@ -2075,6 +2099,14 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
         pk.z = __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u);
         pk.w = __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u);
         *reinterpret_cast<uint4*>(hbase + 6 * DW_HP * t) = pk;
+      }
+    };
+    if (lane < 60) {
+      switch (mis) {
+        case 0: hpass(std::integral_constant<int, 0>{}); break;
+        case 1: hpass(std::integral_constant<int, 1>{}); break;
+        case 2: hpass(std::integral_constant<int, 2>{}); break;
+        default: hpass(std::integral_constant<int, 3>{}); break;
       }
     }
   }
