@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
   int cell = cellBegin + xcd_run_remap<kDetectXcdRun>(blockIdx.x, gridDim.x, blockIdx.y);
   int l = 0;  // the scalar ALU is nearly as busy as the vector ALU in this kernel: no search loop, no integer divisions
 #pragma unroll
-  for (int q = 1; q < ORBX_MAX_LEVELS; q++) l += cell >= g.levelCell[q] ? 1 : 0;
+  for (int q = 1; q < ORBX_MAX_LEVELS; q++) l -= (g.levelCell[q] - 1 - cell) >> 31;   // += (cell >= levelCell[q]), on the scalar ALU
+  // (written as a select the compiler went through v_cndmask + v_readfirstlane for every level)
   const LevelDev L = g.lv[l];
   int* myCount = cellCount + (long long)img * g.totalCells + cell;
   cell -= L.cellStart;
