@@ -332,7 +332,11 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         // a list entry IS the tile byte offset y * TP + x of the pixel's 7x7 window corner (image and score tile share the
         // pitch): no unpacking of (y, x) and no multiply per survivor / corner; (x, y) is only recovered when a corner is emitted
         const int oA = list[s0 + min(base + lane, nSurv - 1)], oB = list[s0 + min(base + 64 + lane, nSurv - 1)];
-        const orbx_h2 M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
+        // a last pass of <= 64 survivors gathers one pixel per lane only (17 instead of 34 byte reads: the LDS pipe is this
+        // kernel's busiest); the packed network then carries the same pixel in both halves
+        orbx_h2 M;
+        if (rem <= 64) M = fast_contrast2_lds(tile8 + oA, tile8 + oA, TP);
+        else M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
         const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
         if (__builtin_amdgcn_inverse_ballot_w64(mA)) {
