@@ -399,11 +399,24 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       // flush first when this round's survivors (<= 256) would not fit: the list then only needs room for a typical cell
       if (sEnd + (int)(__popcll(sm[0]) + __popcll(sm[1]) + __popcll(sm[2]) + __popcll(sm[3])) > listTotal) flush_survivors();
       const int yx = q0 << 2;   // tile byte offset of the quad's first pixel window (a multiple of 4: | pI adds the pixel)
+      // ROW-MAJOR list order (second half of round 4): a survivor goes behind the survivors of the lower lanes -- all four pixels of
+      // their quads: one chain of four mbcnt pairs -- and behind the lane's own lower pixels (a pointer bumped under the pixel's
+      // lane mask).  The per-pixel segments of rounds 1 - 4 (all pixel-0 survivors of the round's seven rows, then all pixel-1 ...)
+      // made the 32 lanes of a contrast-pass byte gather span seven tile rows: 2.04 LDS cycles per half-wave gather in a simulation on
+      // the benchmark frames, against 1.31 for row-major order -- the gathers are the largest part of this kernel's LDS time, and
+      // the LDS pipe is its busiest.  (Nothing downstream depends on the order of a cell's candidates.)
+      uint32_t below = 0;
+#pragma unroll
+      for (int pI = 0; pI < 4; pI++)
+        below = __builtin_amdgcn_mbcnt_hi((uint32_t)(sm[pI] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm[pI], below));
+      uint16_t* wp = list + sEnd + below;
 #pragma unroll
       for (int pI = 0; pI < 4; pI++) {
         const uint64_t m = sm[pI];
-        if (__builtin_amdgcn_inverse_ballot_w64(m))  // this lane's bit of the SGPR mask, without a 64-bit vector shift
-          (list + sEnd)[prefix_count(m)] = (uint16_t)(yx | pI);  // (the running end of the list is the store's scalar base)
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // this lane's bit of the SGPR mask, without a 64-bit vector shift
+          *wp = (uint16_t)(yx | pI);
+          wp++;
+        }
         sEnd += __popcll(m);
       }
       if (!kRowRounds) {
