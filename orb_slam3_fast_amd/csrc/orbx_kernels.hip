@@ -1924,7 +1924,21 @@ constexpr int DW_ROWS = 43;   // raw window rows / columns
 constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 bytes of misalignment)
 constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
 constexpr int DW_BP = 40;     // blurred patch pitch in bytes
-constexpr int DW_WAVE_DW = 22 * DW_HP + DW_ROWS * DW_RP + 16;  // dwords of LDS per wave: row pairs | raw window (+ slack)
+// LDS of a wave (round 4, second half): ONE region of 23 row pairs x DW_HP dwords in which the three tenants overlap in time.
+//   raw window   [DW_RAW0, DW_RAW0 + 43 x 12 + slack)   written first, read by the IC moments and the horizontal pass
+//   row pairs hp [0, 22 x 40)                             written by the horizontal pass, read by the vertical pass
+//   blurred patch [0, 40 x 10)                            written by the vertical pass, read by rBRIEF
+// The horizontal pass writes row pair p while rows >= 12 (p / 6 + 1) of the window are still to be read: with the window at
+// DW_RAW0 = 288 the pairs of trip t end at 240 (t + 1) <= 288 + 144 (t + 1), the first byte of the next trip's rows (t <= 2; after
+// trip 3 nothing is read); inside a trip all lanes read before any lane writes (one wave, LDS operations complete in order).  The
+// vertical pass writes patch rows 8 ch .. 8 ch + 7 (dwords < 160 after its first iteration, < 320 after the second) and its later
+// iterations read row pairs >= 4 / >= 12 (dwords >= 160 / >= 480).  5648 -> 3696 bytes per wave: a workgroup takes 12 of the CU's
+// 128 LDS granules instead of 18, so EIGHT workgroups (all 32 wave slots) are resident instead of seven -- the kernel loses 13 % when
+// it is held to six (profiles/r4_experiments).
+constexpr int DW_RAW0 = 288;
+constexpr int DW_WAVE_DW = 23 * DW_HP + 4;  // (row pair 22 only feeds padding rows of the patch: it must merely be addressable)
+static_assert(DW_RAW0 + DW_ROWS * DW_RP + 16 <= 23 * DW_HP, "window + slack inside the wave's region");
+static_assert(240 * 3 <= DW_RAW0 + 144 * 3, "row pairs of trip t must end before the window rows of trip t + 1");
 // weight dword of the fused blur's horizontal pass: byte i of window dword m carries tap k = 4 m + i - s (s = the byte the first tap
 // of the output column sits at), 0 outside the seven taps
 template <bool T440>
@@ -1972,8 +1986,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   if (idx >= selCount[img * g.nlevels + l]) return;
   const uint32_t key = __builtin_amdgcn_readfirstlane(sel[(long long)img * g.selImg + s]);  // one keypoint per wave
   const int X = key_x(key), Y = key_y(key);
-  uint32_t* hp = lds_all[wv];                  // [22 row pairs][DW_HP]: H(2j, x) | H(2j+1, x) << 16
-  uint32_t* raw = hp + 22 * DW_HP;             // [43 rows][DW_RP] raw window; reused for the blurred patch
+  uint32_t* hp = lds_all[wv];                  // [22 row pairs][DW_HP]: H(2j, x) | H(2j+1, x) << 16; its head is reused for the blurred patch
+  uint32_t* raw = hp + DW_RAW0;                // [43 rows][DW_RP] raw window, overlapping the row pairs (see DW_RAW0)
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   // ---- raw window -> LDS: rows Y-21..Y+21, aligned dwords covering columns X-21..X+21 (LDS byte 0 = column xs)
@@ -2063,7 +2077,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   // mis (uniform switch), the constants in SGPRs.
   {
     const int j0 = (lane * 6554) >> 16, q = lane - 10 * j0;  // lane / 10
-    const int rbi = 22 * DW_HP + 2 * j0 * DW_RP + q;   // dword index of the item's first window dword (raw = hp + 22 * DW_HP)
+    const int rbi = DW_RAW0 + 2 * j0 * DW_RP + q;   // dword index of the item's first window dword (raw = hp + DW_RAW0)
     uint32_t* hbase = hp + j0 * DW_HP + 4 * q;
     auto hpass = [&](auto misTag) {
       constexpr int MIS = decltype(misTag)::value;
@@ -2113,13 +2127,13 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // ---- vertical pass: item = (column x, chunk of 8 output rows); blurred row y needs H rows y..y+6.  The blurred
-  // 37x37 patch overwrites the raw window (every lane has read its last raw byte before the barrier above).
-  uint8_t* bl = reinterpret_cast<uint8_t*>(raw);
+  // 37x37 patch overwrites the head of the row pairs (iteration by iteration behind the pairs still to be read: see DW_RAW0).
+  uint8_t* bl = reinterpret_cast<uint8_t*>(hp);
   for (int i = lane; i < 5 * 37; i += 64) {
     const int ch = (int)(((unsigned)i * 1772u) >> 16), x = i - ch * 37;  // i / 37 for i < 2^11
     uint32_t pr[7];
 #pragma unroll
-    for (int k = 0; k < 7; k++) pr[k] = hp[(4 * ch + k) * DW_HP + x];  // H rows 8ch .. 8ch+13 (pair 22 = the first window dwords: feeds padding rows only)
+    for (int k = 0; k < 7; k++) pr[k] = hp[(4 * ch + k) * DW_HP + x];  // H rows 8ch .. 8ch+13 (pair 22 only feeds padding rows)
     constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
     const uint32_t w01 = 18u | (34u << 16), w23 = kT2 | (kT3 << 16), w45 = kT2 | (34u << 16), w6 = 18u;            // even y
     const uint32_t v0 = 18u << 16, v12 = 34u | (kT2 << 16), v34 = kT3 | (kT2 << 16), v56 = 34u | (18u << 16);      // odd y
@@ -2138,7 +2152,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t*
         acc = udot2_u16(pr[k0 + 2], v34, acc);
         acc = udot2_u16(pr[k0 + 3], v56, acc);
       }
-      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)((T440 ? min(acc, 0x00FFFFFFu) : acc) >> 16);  // rows 37..39 are padding (40 x 40 B fit the old window); 257-sum taps saturate
+      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)((T440 ? min(acc, 0x00FFFFFFu) : acc) >> 16);  // rows 37..39 are padding; 257-sum taps saturate
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
