@@ -583,10 +583,11 @@ __host__ __device__ inline int oct_maxcells(const Geom& g) {
   for (int l = 0; l < g.nlevels; l++) c = g.lv[l].nCols * g.lv[l].nRows > c ? g.lv[l].nCols * g.lv[l].nRows : c;
   return c;
 }
-// Counter replicas: 4 when two blocks still fit one CU's 160 KB of LDS, fewer for very large per-level quotas.
+// Counter replicas: 2 (1 for very large per-level quotas).  Four replicas (rounds 1 - 4) cost 56 KB = 44 of a CU's 128 LDS
+// granules per workgroup; with two it is 50 KB = 40 granules, the workgroup itself is 1.5 us faster (fewer replicas to sum) and the
+// kernels that run beside it have room for one more workgroup per CU (+ 0.4 % pairs/s with three handles, A/B on one box).
 __host__ __device__ inline int oct_rep(const Geom& g) {
   const int maxn = oct_maxn(g), maxcells = oct_maxcells(g);
-  if (oct_layout(maxn, maxcells, 4).total <= 78 * 1024) return 4;
   if (oct_layout(maxn, maxcells, 2).total <= 78 * 1024) return 2;
   return 1;
 }
