@@ -492,7 +492,8 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) 
   // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
   // each other.  A per-device token orders the k_detect launches of all handles one after the other, while each still
   // overlaps the other handles' quadtree / describe / stereo / resize work.
-  DetectToken* tok = !capturing ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
+  static const bool noToken = getenv("ORBX_NO_DETECT_TOKEN") && atoi(getenv("ORBX_NO_DETECT_TOKEN")) != 0;   // measurement aid
+  DetectToken* tok = (!capturing && !noToken) ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
   if (tok) {
     std::lock_guard<std::mutex> lk(tok->mu);
     if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
