@@ -180,6 +180,18 @@ int orbx_pyramid_level(orbx_extractor* ex, int image, int level, int blurred, ui
  * mirror's mvImagePyramid refresh uses (one call per eye instead of 2 x nlevels blocking copies).
  * Level 0 of a batch extracted with orbx_extract_batch_device is the CALLER's device buffer: it must still be alive. */
 int orbx_pyramid_download(orbx_extractor* ex, int image, int n_levels, uint8_t* const* dst, const ptrdiff_t* dst_stride);
+/* The reference keeps its pyramid in host memory and an UNMODIFIED Frame::ComputeStereoMatches reads it there
+ * (`mpORBextractorLeft->mvImagePyramid[l]`, src/Frame.cc:927,1011,1024,1029; include/ORBextractor.h:86).
+ * orbx_set_host_pyramid(handle, 1) makes the single-frame host entries (orbx_extract, orbx_extract_stereo) keep such a
+ * host copy current: every level of their image(s) is copied into page-locked memory owned by the handle, by the DMA
+ * engines on a side stream BESIDE the frame's kernels (orbx_extract_stereo: from the moment both pyramids exist), and the
+ * call returns after both.  orbx_host_pyramid_level then hands out the level in place -- pointer, size and row stride,
+ * exactly what a `cv::Mat(h, w, CV_8UC1, data, stride)` header needs -- with no further copy and no synchronisation.
+ * Lifetime = the reference's: until the next extraction on the handle (src/ORBextractor.cc:1108-1145 overwrites
+ * mvImagePyramid on every call).  image = 0 (orbx_extract; the left eye) or 1 (the right eye of orbx_extract_stereo). */
+int orbx_set_host_pyramid(orbx_extractor* ex, int enable);
+int orbx_host_pyramid_level(const orbx_extractor* ex, int image, int level, const uint8_t** data, int* w, int* h,
+                            ptrdiff_t* stride);
 
 /* Stage taps for differential tests: FAST candidates handed to DistributeOctTree for (image, level), in
  * unspecified order (x, y relative to the (16,16) window origin as in src/ORBextractor.cc:965-967;

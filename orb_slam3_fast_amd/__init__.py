@@ -85,6 +85,8 @@ def lib():
         L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
         L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, C.c_ssize_t, C.POINTER(i), C.POINTER(i)]
         L.orbx_pyramid_download.argtypes = [vp, i, i, vp, vp]
+        L.orbx_set_host_pyramid.argtypes = [vp, i]
+        L.orbx_host_pyramid_level.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_ssize_t)]
         L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
         L.orbx_hamming256.argtypes = [vp, vp]
         L.orbx_stereo_match_batch.argtypes = [vp, i, vp, i, i, f, f]
@@ -247,6 +249,30 @@ class ORBextractor:
         return self._umax.copy()
 
     # ---- operator()
+    def _host_bufs(self):
+        """Result arrays of the single-frame entries, allocated once per handle (a per-call np.zeros of a structured array and
+        a structured slice copy cost more than the GPU work of a frame: the wrapper's share of a 1280x720 stereo frame was 80 us).
+        Returned results are copies of the valid prefix (byte-wise: numpy copies structured records field by field)."""
+        b = getattr(self, "_hb", None)
+        if b is None:
+            cap = self.capacity
+            b = {}
+            for e in (0, 1):
+                k, d = np.zeros(cap, KP_DTYPE), np.zeros((cap, 32), np.uint8)
+                b[e] = (k, k.view(np.uint8).reshape(cap, 28), d, k.ctypes.data, d.ctypes.data)
+            ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+            b["st"] = (ur, dp, ur.ctypes.data, dp.ctypes.data)
+            b["n"] = [C.c_int() for _ in range(4)]
+            b["nref"] = [C.byref(x) for x in b["n"]]
+            b["lap"] = np.zeros(4, np.int32)
+            b["lapp"] = (b["lap"].ctypes.data, b["lap"].ctypes.data + 8)
+            self._hb = b
+        return b
+
+    @staticmethod
+    def _take(buf, n):
+        return buf[1][:n].copy().view(KP_DTYPE).reshape(n), buf[2][:n].copy()
+
     def __call__(self, image, vLappingArea=(0, 0)):
         if image is None or image.size == 0:
             return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
@@ -254,32 +280,35 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        kps = np.zeros(self.capacity, KP_DTYPE)
-        desc = np.zeros((self.capacity, 32), np.uint8)
-        n = C.c_int()
-        mono = _check(lib().orbx_extract(self._h, _p(image), w, h, image.strides[0], int(vLappingArea[0]),
-                                         int(vLappingArea[1]), _p(kps), _p(desc), self.capacity, C.byref(n)))
-        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+        b = self._host_bufs()
+        mono = _check(lib().orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
+                                         int(vLappingArea[1]), b[0][3], b[0][4], self.capacity, b["nref"][0]))
+        return (mono,) + self._take(b[0], b["n"][0].value)
 
     # ---- batched many-camera mode
     def extract_stereo(self, left, right, lap_left=(0, 0), lap_right=(0, 0), bf=0.0, b=0.0):
         """Both eyes of one stereo frame in one batched pipeline (orbx_extract_stereo; the handle needs max_batch >= 2).
         Returns ((monoL, kpsL, descL), (monoR, kpsR, descR)) and, when bf > 0, also (mvuRight, mvDepth) of the left eye."""
-        L, R = np.ascontiguousarray(left, np.uint8), np.ascontiguousarray(right, np.uint8)
+        L, R = left, right
+        if L.dtype != np.uint8 or L.strides[-1] != 1:
+            L = np.ascontiguousarray(L, np.uint8)
+        if R.dtype != np.uint8 or R.strides[-1] != 1:
+            R = np.ascontiguousarray(R, np.uint8)
         if L.shape != R.shape or L.ndim != 2:
             raise ValueError("two gray images of the same size")
         h, w = L.shape
+        hb = self._host_bufs()
+        lap = hb["lap"]
+        lap[0], lap[1], lap[2], lap[3] = lap_left[0], lap_left[1], lap_right[0], lap_right[1]
+        nl, nr, ml, mr = hb["n"]
+        rl, rr, rml, rmr = hb["nref"]
+        st = hb["st"]
         cap = self.capacity
-        kl, kr = np.zeros(cap, KP_DTYPE), np.zeros(cap, KP_DTYPE)
-        dl, dr = np.zeros((cap, 32), np.uint8), np.zeros((cap, 32), np.uint8)
-        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
-        nl, nr, ml, mr = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        ll, lr = np.array(lap_left, np.int32), np.array(lap_right, np.int32)
-        _check(lib().orbx_extract_stereo(self._h, _p(L), _p(R), w, h, L.strides[0], R.strides[0], _p(ll), _p(lr), _p(kl), _p(dl),
-                                         cap, C.byref(nl), C.byref(ml), _p(kr), _p(dr), cap, C.byref(nr), C.byref(mr), float(bf),
-                                         float(b), _p(ur), _p(dp)))
-        out = ((ml.value, kl[:nl.value].copy(), dl[:nl.value].copy()), (mr.value, kr[:nr.value].copy(), dr[:nr.value].copy()))
-        return out + ((ur[:nl.value].copy(), dp[:nl.value].copy()),) if bf > 0 else out
+        _check(lib().orbx_extract_stereo(self._h, L.ctypes.data, R.ctypes.data, w, h, L.strides[0], R.strides[0], hb["lapp"][0],
+                                         hb["lapp"][1], hb[0][3], hb[0][4], cap, rl, rml, hb[1][3], hb[1][4], cap, rr, rmr,
+                                         float(bf), float(b), st[2], st[3]))
+        out = ((ml.value,) + self._take(hb[0], nl.value), (mr.value,) + self._take(hb[1], nr.value))
+        return out + ((st[0][:nl.value].copy(), st[1][:nl.value].copy()),) if bf > 0 else out
 
     def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
         """Enqueue extraction of device-resident images (raw device pointer).  Asynchronous."""
@@ -381,6 +410,33 @@ class ORBextractor:
         ptrs = (C.c_void_p * nl)(*[a.ctypes.data for a in out])
         strides = (C.c_ssize_t * nl)(*[a.strides[0] for a in out])
         _check(lib().orbx_pyramid_download(self._h, image, nl, ptrs, strides))
+        return out
+
+    def set_host_pyramid(self, enable=True):
+        """orbx_set_host_pyramid: the single-frame entries (`ex(image)`, `extract_stereo`) keep a host copy of the pyramid --
+        the reference's public mvImagePyramid (include/ORBextractor.h:86) -- current, copied beside the frame's kernels."""
+        _check(lib().orbx_set_host_pyramid(self._h, 1 if enable else 0))
+        self._hpv = {}
+
+    def host_pyramid(self, image=0):
+        """orbx_host_pyramid_level for every level: numpy VIEWS of the handle's page-locked copy (no copy, no synchronisation;
+        valid until the next extraction on this handle, like mvImagePyramid)."""
+        key = None
+        views = getattr(self, "_hpv", None)
+        if views is None:
+            views = self._hpv = {}
+        p, w, h, st = C.c_void_p(), C.c_int(), C.c_int(), C.c_ssize_t()
+        _check(lib().orbx_host_pyramid_level(self._h, image, 0, C.byref(p), C.byref(w), C.byref(h), C.byref(st)))
+        key = (image, p.value, w.value, h.value, st.value)
+        if key in views:   # the block and the geometry are unchanged: the views of the previous frame are this frame's
+            return views[key]
+        out = []
+        for l in range(self.GetLevels()):
+            _check(lib().orbx_host_pyramid_level(self._h, image, l, C.byref(p), C.byref(w), C.byref(h), C.byref(st)))
+            buf = (C.c_uint8 * (st.value * (h.value - 1) + w.value)).from_address(p.value)
+            a = np.frombuffer(buf, np.uint8)
+            out.append(np.lib.stride_tricks.as_strided(a, (h.value, w.value), (st.value, 1), writeable=False))
+        views[key] = out
         return out
 
     def debug_score_map(self, enable=True):

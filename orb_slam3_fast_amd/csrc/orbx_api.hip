@@ -223,10 +223,10 @@ static int g_tail_first = -1, g_tail_levels = kTailLevels, g_tail_rows = kTailRo
 
 // One segment: levels lA .. lA+nT-1 from level lA-1.  Returns false when it cannot be built (LDS, quad limit).
 static bool build_tail_segment(const Geom& g, const std::vector<int>& yofs, int lA, int nT, int R, TailPlan& tp,
-                               std::vector<TailBand>& nd) {
+                               std::vector<TailBand>& nd, int minLA = 2, int minT = 2, size_t ldsMax = kTailLdsMax) {
   std::memset(&tp, 0, sizeof(tp));
   nd.clear();
-  if (lA < 2 || nT < 2 || lA + nT > g.nlevels || nT > ORBX_MAX_LEVELS) return false;
+  if (lA < minLA || nT < minT || lA + nT > g.nlevels || nT > ORBX_MAX_LEVELS) return false;
   const int hTop = g.lv[lA + nT - 1].h;
   const int nB = (hTop + R - 1) / R;
   auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -272,7 +272,7 @@ static bool build_tail_segment(const Geom& g, const std::vector<int>& yofs, int 
     if ((long long)maxRows[t] * (V.w + 16) >= (1 << 20)) return false;  // (the kernel's float index split)
   }
   const size_t lds = (size_t)align_up(tile[0], 16) + align_up(tile[1], 16) + (size_t)rtab * 16;
-  if (lds > (size_t)kTailLdsMax) return false;
+  if (lds > ldsMax) return false;
   tp.rtTotal = rtab;
   tp.lA = lA;
   tp.nT = nT;
@@ -325,6 +325,47 @@ void build_tail_plans(const Geom& g, const std::vector<int>& yofs, std::vector<T
   }
 }
 
+// The single-frame plans (orbx_extract / orbx_extract_stereo, and device batches of <= kLatMaxImages images): the WHOLE chain
+// from level 0 as one or two cascade launches.  Five dependent launches cost 37 us of a 1280x720 stereo frame's ~210 us of GPU
+// time for ~3 us of arithmetic (profiles/r5a_frame_trace.txt); with a couple of images the chip is empty, so the halo rows a
+// deep cascade recomputes (a band of 2 rows of level 7 needs ~38 rows of level 0) cost nothing that matters.  Segments are
+// as long as the LDS admits (kLatLdsMax); ORBX_LAT_TAIL=levels,rows overrides (levels = 0 switches the plans off).
+constexpr int kLatLdsMax = 156 * 1024, kLatMaxImages = 2;
+static int g_lat_levels = ORBX_MAX_LEVELS, g_lat_rows = 2;
+void build_latency_plans(const Geom& g, const std::vector<int>& yofs, std::vector<TailPlan>& plans, std::vector<TailBand>& bands) {
+  plans.clear();
+  bands.clear();
+  static const bool envRead = [] {
+    if (const char* e = getenv("ORBX_LAT_TAIL")) {
+      int a = -1, b = 0;
+      if (sscanf(e, "%d,%d", &a, &b) >= 1) {
+        g_lat_levels = a;
+        if (b > 0) g_lat_rows = b;
+      }
+    }
+    return true;
+  }();
+  (void)envRead;
+  if (g_lat_levels <= 0) return;
+  const int L = g.nlevels;
+  int l = 1;
+  while (l < L) {
+    TailPlan tp;
+    std::vector<TailBand> nd;
+    int nT = std::min(g_lat_levels, L - l);
+    while (nT >= 1 && !build_tail_segment(g, yofs, l, nT, g_lat_rows, tp, nd, 1, 1, (size_t)kLatLdsMax)) nT--;
+    if (nT < 1) {  // (a level the cascade kernel cannot take: no single-frame plan, the level kernels serve every batch size)
+      plans.clear();
+      bands.clear();
+      return;
+    }
+    tp.bandOff = (int)bands.size();
+    bands.insert(bands.end(), nd.begin(), nd.end());
+    plans.push_back(tp);
+    l += nT;
+  }
+}
+
 int configure(orbx_extractor* ex, int w, int h) {
   if (w == ex->curW && h == ex->curH) return ORBX_OK;
   // every per-axis table (resize coefficients, row tables) is sized for max_width x max_height: a wide-and-short image
@@ -365,6 +406,19 @@ int configure(orbx_extractor* ex, int w, int h) {
     HIPC(prepare_resize_tail(lds));
   }
   ex->tails = plans;
+  {
+    std::vector<TailPlan> lp;
+    std::vector<TailBand> lb;
+    build_latency_plans(g, yofs, lp, lb);
+    if (!lp.empty()) {
+      if (ex->d_latBands.n < lb.size()) HIPC(ex->d_latBands.alloc(lb.size()));
+      HIPC(hipMemcpy(ex->d_latBands.p, lb.data(), lb.size() * sizeof(TailBand), hipMemcpyHostToDevice));
+      unsigned lds = 0;
+      for (const TailPlan& tp : lp) lds = std::max(lds, tp.ldsBytes);
+      HIPC(prepare_resize_tail(lds));
+    }
+    ex->latTails = lp;
+  }
   ex->g = g;
   ex->curW = w;
   ex->curH = h;
@@ -393,7 +447,7 @@ static DetectToken* detect_token(int device) {  // one per device, created on fi
   return toks[device];
 }
 
-int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing);
+int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing, bool pyrDone = false);
 static void drop_graphs(orbx_extractor* ex) {
   for (auto& e : ex->graphExec) {
     if (e) (void)hipGraphExecDestroy(e);
@@ -401,8 +455,19 @@ static void drop_graphs(orbx_extractor* ex) {
   }
 }
 
-int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
-                    ptrdiff_t image_pitch, const int32_t* lap) {
+// May the images at `d_images` go through the single-frame cascade plans?  k_resize_tail stages level 0 with 16-byte loads of
+// whole rows: 16-byte aligned rows, and the last row's last load must stay inside the buffer (the handle's own staging buffer
+// is padded; a caller's buffer is only trusted when the width is a multiple of 16).
+static bool latency_plan_ok(const orbx_extractor* ex, const uint8_t* d_images, int n, int w, ptrdiff_t row_pitch,
+                            ptrdiff_t image_pitch) {
+  if (ex->latTails.empty() || n > kLatMaxImages) return false;
+  if (((uintptr_t)d_images & 15) || (row_pitch & 15) || (image_pitch & 15)) return false;
+  return (w & 15) == 0 || d_images == ex->d_stage.p;
+}
+
+// Everything of an extraction that precedes its kernels: geometry, per-extraction state, lapping areas.
+static int prepare_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
+                           ptrdiff_t image_pitch, const int32_t* lap, bool& lapTrivial) {
   int rc = configure(ex, w, h);
   if (rc != ORBX_OK) return rc;
   ex->pyr.l0 = d_images;
@@ -413,11 +478,13 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
   ex->lastEvValid = false;
   ex->blurValid = false;       // per-extraction state is reset HERE: a hipGraph replay never runs record_pipeline
   ex->lastStereoPairs = 0;     // results of an earlier batch's stereo association are not this batch's
+  ex->hostPyrImages = 0;       // (the host copy of the pyramid, orbx_set_host_pyramid, belongs to the previous extraction)
+  ex->useLat = latency_plan_ok(ex, d_images, n, w, row_pitch, image_pitch);
   hipStream_t s = ex->stream;
   // Keypoint x is >= 19 at every level (16-px border + the 3-px FAST ring, scaled by >= 1), so a lapping area that
   // ends below 19 -- the rectified-stereo {0, 0} in particular -- can hold no keypoint: the output order is then
   // just level-major list order, k_slots is skipped and k_describe derives its slot from the level counts.
-  bool lapTrivial = true;
+  lapTrivial = true;
   if (lap)
     for (int i = 0; i < n; i++) lapTrivial = lapTrivial && lap[2 * i + 1] < 19;
   if (!lapTrivial) {
@@ -431,6 +498,41 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
       HIPC(hipMemcpyAsync(ex->d_lap.p, ex->h_lap, nb, hipMemcpyHostToDevice, s));
     }
   }
+  return ORBX_OK;
+}
+
+// The resize chain of images [img0, img0 + n) on stream s: the single-frame cascade plans (ex->useLat) or, for batches, the
+// level kernels + the fused small levels.  (The level kernels take whole batches only: img0 = 0.)
+static int enqueue_pyramid(orbx_extractor* ex, hipStream_t s, int img0, int n) {
+  const Geom& g = ex->g;
+  if (ex->useLat) {
+    for (const TailPlan& tp : ex->latTails) {
+      StageTimer t(ex, s, ORBX_STAGE_RESIZE);
+      HIPC(launch_resize_tail(g, ex->pyr, tp, ex->d_latBands.p + tp.bandOff, img0, n, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+    }
+    return ORBX_OK;
+  }
+  size_t seg = 0;  // next fused segment of small levels (ex->tails, in level order)
+  for (int l = 1; l < g.nlevels;) {
+    StageTimer t(ex, s, ORBX_STAGE_RESIZE);
+    if (seg < ex->tails.size() && ex->tails[seg].lA == l) {
+      const TailPlan& tp = ex->tails[seg++];
+      HIPC(launch_resize_tail(g, ex->pyr, tp, ex->d_tailBands.p + tp.bandOff, 0, n, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+      l += tp.nT;
+    } else {
+      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+      l++;
+    }
+  }
+  return ORBX_OK;
+}
+
+int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, int h, ptrdiff_t row_pitch,
+                    ptrdiff_t image_pitch, const int32_t* lap) {
+  bool lapTrivial = true;
+  int rc = prepare_extract(ex, d_images, n, w, h, row_pitch, image_pitch, lap, lapTrivial);
+  if (rc != ORBX_OK) return rc;
+  hipStream_t s = ex->stream;
   // Single images through the host API are launch-bound (12 small kernels on two streams), so the pipeline can be
   // captured once per image size into a hipGraph and replayed (ORBX_GRAPH=1).  Measured on ROCm 7.2 / MI355X it is
   // SLOWER than the plain launches -- one 1280x720 eye 0.487 vs 0.310 ms, a stereo frame 0.823 vs 0.711 ms (640x480:
@@ -472,28 +574,22 @@ int enqueue_extract(orbx_extractor* ex, const uint8_t* d_images, int n, int w, i
 // resize chain -> k_detect -> k_octree -> (k_slots) -> k_describe.  The 7x7 Gaussian of :1074-1076 is evaluated inside
 // k_describe on the keypoints' own windows (no blurred pyramid, no side stream); the round-1 schedule (k_blur over every
 // level on a side stream beside the quadtree) and the alternatives measured around it are in DESIGN.md 4.
-int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing) {
+int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing, bool pyrDone) {
   const Geom& g = ex->g;
   hipStream_t s = ex->stream;
   ex->blurValid = false;  // the blurred levels (orbx_pyramid_level blurred = 1) are produced on demand
-  size_t seg = 0;  // next fused segment of small levels (ex->tails, in level order)
-  for (int l = 1; l < g.nlevels;) {
-    StageTimer t(ex, s, ORBX_STAGE_RESIZE);
-    if (seg < ex->tails.size() && ex->tails[seg].lA == l) {
-      const TailPlan& tp = ex->tails[seg++];
-      HIPC(launch_resize_tail(g, ex->pyr, tp, ex->d_tailBands.p + tp.bandOff, n, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
-      l += tp.nT;
-    } else {
-      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
-      l++;
-    }
+  if (!pyrDone) {         // (orbx_extract_stereo builds the two eyes' pyramids itself, each behind its own upload)
+    const int rc = enqueue_pyramid(ex, s, 0, n);
+    if (rc != ORBX_OK) return rc;
   }
   if (ex->d_dbgScore.p) HIPC(hipMemsetAsync(ex->d_dbgScore.p, 0, ex->d_dbgScore.n, s));  // test tap only
   // k_detect fills every VALU of the chip by itself: two of them side by side (two handles in flight) only stretch
   // each other.  A per-device token orders the k_detect launches of all handles one after the other, while each still
   // overlaps the other handles' quadtree / describe / stereo / resize work.
   static const bool noToken = getenv("ORBX_NO_DETECT_TOKEN") && atoi(getenv("ORBX_NO_DETECT_TOKEN")) != 0;   // measurement aid
-  DetectToken* tok = (!capturing && !noToken) ? detect_token(ex->device) : nullptr;  // (a graph cannot wait on it)
+  // (a graph cannot wait on it; a launch of one or two images does not fill the chip: no ordering, no event record between
+  // k_detect and k_octree of a single frame)
+  DetectToken* tok = (!capturing && !noToken && n > kLatMaxImages) ? detect_token(ex->device) : nullptr;
   if (tok) {
     std::lock_guard<std::mutex> lk(tok->mu);
     if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
@@ -625,12 +721,21 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->hostResults = nullptr;
   if (ex->hostPyr) (void)hipHostFree(ex->hostPyr);
   ex->hostPyr = nullptr;
+  if (ex->stream2) (void)hipStreamSynchronize(ex->stream2);
+  if (ex->streamPyr) (void)hipStreamSynchronize(ex->streamPyr);
+  if (ex->hostPyrAll) (void)hipHostFree(ex->hostPyrAll);
+  ex->hostPyrAll = nullptr;
+  for (hipEvent_t* e : {&ex->evA, &ex->evR, &ex->evPyr})
+    if (*e) (void)hipEventDestroy(*e);
+  if (ex->stream2) (void)hipStreamDestroy(ex->stream2);
+  if (ex->streamPyr) (void)hipStreamDestroy(ex->streamPyr);
   if (ex->h_lap) (void)hipHostFree(ex->h_lap);
   ex->h_lap = nullptr;
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
   ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free();
+  ex->d_latBands.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
   if (ex->done) (void)hipEventDestroy(ex->done);
@@ -779,6 +884,79 @@ static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo)
   return launch_result_pack(a, ex->stream);
 }
 
+// ---- host copy of the pyramid (the reference's public mvImagePyramid) -----------------------------------------------
+static size_t host_pyr_image_bytes(const orbx_extractor* ex) {
+  return (((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255) + (((size_t)ex->gmax.pyrImg + 255) & ~(size_t)255);
+}
+static int ensure_side_streams(orbx_extractor* ex) {
+  if (!ex->stream2) HIPC(hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking));
+  if (!ex->evA) HIPC(hipEventCreateWithFlags(&ex->evA, hipEventDisableTiming));
+  if (!ex->evR) HIPC(hipEventCreateWithFlags(&ex->evR, hipEventDisableTiming));
+  return ORBX_OK;
+}
+// Copies of every level of images [0, nimg) of the current extraction into hostPyrAll, on streamPyr behind `after` (an event
+// recorded once the pyramids are complete): the copies run on the DMA engines beside k_detect .. k_describe.
+static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after) {
+  if (!ex->streamPyr) HIPC(hipStreamCreateWithFlags(&ex->streamPyr, hipStreamNonBlocking));
+  const size_t per = host_pyr_image_bytes(ex);
+  if (ex->hostPyrAllBytes < 2 * per) {
+    if (ex->hostPyrAll) (void)hipHostFree(ex->hostPyrAll);
+    ex->hostPyrAll = nullptr;
+    ex->hostPyrAllBytes = 0;
+    HIPC(hipHostMalloc(reinterpret_cast<void**>(&ex->hostPyrAll), 2 * per, hipHostMallocDefault));
+    ex->hostPyrAllBytes = 2 * per;
+  }
+  const Geom& g = ex->g;
+  const size_t l0Off = 0, restDst = ((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255;
+  const LevelDev& LL = g.lv[g.nlevels - 1];
+  const size_t restOff = g.nlevels > 1 ? (size_t)g.lv[1].off : 0;
+  const size_t restBytes = g.nlevels > 1 ? (size_t)LL.off + (size_t)LL.pitch * LL.h - restOff : 0;
+  HIPC(hipStreamWaitEvent(ex->streamPyr, after, 0));
+  for (int i = 0; i < nimg; i++) {
+    int p0 = 0;
+    const uint8_t* l0 = level_ptr(g, ex->pyr, i, 0, p0);
+    const size_t l0Bytes = (size_t)p0 * (g.lv[0].h - 1) + g.lv[0].w;
+    if (l0Bytes > restDst) return fail(ORBX_E_CAPACITY, "level-0 pitch larger than the handle's staging pitch");
+    uint8_t* H = ex->hostPyrAll + (size_t)i * per;
+    HIPC(hipMemcpyAsync(H + l0Off, l0, l0Bytes, hipMemcpyDeviceToHost, ex->streamPyr));
+    if (restBytes)
+      HIPC(hipMemcpyAsync(H + restDst, ex->pyr.pyr + (long long)i * g.pyrImg + restOff, restBytes, hipMemcpyDeviceToHost, ex->streamPyr));
+  }
+  ex->hostPyrImages = nimg;
+  ex->hostPyrL0Pitch = (int)ex->pyr.l0Row;
+  return ORBX_OK;
+}
+
+int orbx_set_host_pyramid(orbx_extractor* ex, int enable) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  ex->keepHostPyr = enable != 0;
+  if (!ex->keepHostPyr) ex->hostPyrImages = 0;
+  return ORBX_OK;
+}
+
+int orbx_host_pyramid_level(const orbx_extractor* ex, int image, int level, const uint8_t** data, int* w, int* h,
+                            ptrdiff_t* stride) {
+  if (!ex || !data) return fail(ORBX_E_BADARG, "null argument");
+  *data = nullptr;
+  if (!ex->keepHostPyr) return fail(ORBX_E_BADARG, "orbx_set_host_pyramid(handle, 1) first");
+  if (image < 0 || image >= ex->hostPyrImages || level < 0 || level >= ex->g.nlevels)
+    return fail(ORBX_E_BADARG, "no such level in the host copy of the last single-frame extraction");
+  const LevelDev& L = ex->g.lv[level];
+  const size_t per = host_pyr_image_bytes(ex);
+  const size_t restDst = ((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255;
+  const uint8_t* H = ex->hostPyrAll + (size_t)image * per;
+  if (level == 0) {
+    *data = H;
+    if (stride) *stride = ex->hostPyrL0Pitch;
+  } else {
+    *data = H + restDst + ((size_t)L.off - (size_t)ex->g.lv[1].off);
+    if (stride) *stride = L.pitch;
+  }
+  if (w) *w = L.w;
+  if (h) *h = L.h;
+  return ORBX_OK;
+}
+
 int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
@@ -798,7 +976,17 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   uint8_t* H = ex->hostResults;
   hipStream_t st = ex->stream;
   HIPC(enqueue_result_pack(ex, 1, false));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
+  if (ex->keepHostPyr) {
+    // (the whole pipeline is on one stream here: the copies wait for its END -- the mono entry has nothing to hide them under
+    // without a second event; they still cost only the copy time, not the row-by-row host layout of orbx_pyramid_download)
+    rc = ensure_side_streams(ex);
+    if (rc != ORBX_OK) return rc;
+    HIPC(hipEventRecord(ex->evA, st));
+    rc = enqueue_host_pyramid(ex, 1, ex->evA);
+    if (rc != ORBX_OK) return rc;
+  }
   HIPC(hipStreamSynchronize(st));
+  if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
   const int n = *reinterpret_cast<const int*>(H), mono = *reinterpret_cast<const int*>(H + 8);
   *n_out = n;
   if (n > cap) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
@@ -823,12 +1011,52 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   if (rc != ORBX_OK) return rc;
   const int pitch = align_up(w, 64);
   const size_t imgBytes = (size_t)pitch * h;
-  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, ex->stream));
-  HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, ex->stream));
   const int32_t lap[4] = {lap_left ? lap_left[0] : 0, lap_left ? lap_left[1] : 0, lap_right ? lap_right[0] : 0,
                           lap_right ? lap_right[1] : 0};
-  rc = enqueue_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap);
-  if (rc != ORBX_OK) return rc;
+  hipStream_t st = ex->stream;
+  // Two streams: the right eye's upload and pyramid run beside the left eye's (a 1280x720 frame spent 55 us in two serial
+  // uploads before its first kernel, profiles/r5a_frame_trace.txt); the left stream joins before k_detect, which takes both
+  // eyes in one launch like every later stage.  While profiling (stage events live on ONE stream) and under ORBX_GRAPH the
+  // frame keeps the single-stream order.
+  static const bool oneStream = (getenv("ORBX_GRAPH") && atoi(getenv("ORBX_GRAPH")) != 0) ||
+                                (getenv("ORBX_ONE_STREAM") && atoi(getenv("ORBX_ONE_STREAM")) != 0);
+  bool pyrEvent = false;
+  if (!oneStream && !ex->profiling) {
+    bool lapTrivial = true;
+    rc = prepare_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap, lapTrivial);
+    if (rc != ORBX_OK) return rc;
+    rc = ensure_side_streams(ex);
+    if (rc != ORBX_OK) return rc;
+    hipStream_t sb = ex->stream2;
+    HIPC(hipEventRecord(ex->evA, st));          // whatever the handle still has queued reads the buffers the right eye overwrites
+    HIPC(hipStreamWaitEvent(sb, ex->evA, 0));
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, sb));
+    if (ex->useLat) {  // per-eye cascade launches, each right behind its own upload
+      rc = enqueue_pyramid(ex, st, 0, 1);
+      if (rc != ORBX_OK) return rc;
+      rc = enqueue_pyramid(ex, sb, 1, 1);
+      if (rc != ORBX_OK) return rc;
+      HIPC(hipEventRecord(ex->evR, sb));
+      HIPC(hipStreamWaitEvent(st, ex->evR, 0));
+      if (ex->keepHostPyr) {  // both pyramids exist from here on: the host copies may start (enqueued further down)
+        if (!ex->evPyr) HIPC(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
+        HIPC(hipEventRecord(ex->evPyr, st));
+      }
+      rc = record_pipeline(ex, 2, lapTrivial, false, true);
+    } else {           // the level kernels take both eyes per launch: join first
+      HIPC(hipEventRecord(ex->evR, sb));
+      HIPC(hipStreamWaitEvent(st, ex->evR, 0));
+      rc = record_pipeline(ex, 2, lapTrivial, false, false);
+    }
+    if (rc != ORBX_OK) return rc;
+    pyrEvent = ex->useLat;
+  } else {
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
+    rc = enqueue_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap);
+    if (rc != ORBX_OK) return rc;
+  }
   const bool stereo = bf > 0.f && uright && depth;
   if (stereo) {
     rc = orbx_stereo_match_batch(ex, 0, ex, 1, 1, bf, b);
@@ -837,9 +1065,23 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   // all results travel with asynchronous copies into pinned memory behind the kernels: one synchronisation in total
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* H = ex->hostResults;
-  hipStream_t st = ex->stream;
   HIPC(enqueue_result_pack(ex, 2, stereo));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
+  if (ex->keepHostPyr) {
+    // enqueued AFTER the frame's kernels (the host's time belongs to the critical chain first); on the device the copies start
+    // as soon as both pyramids exist (evPyr, recorded at the join of the two eyes) and run beside k_detect .. k_describe --
+    // without the cascade plans, behind the frame's last kernel
+    rc = ensure_side_streams(ex);
+    if (rc != ORBX_OK) return rc;
+    if (pyrEvent) {
+      rc = enqueue_host_pyramid(ex, 2, ex->evPyr);
+    } else {
+      HIPC(hipEventRecord(ex->evA, st));
+      rc = enqueue_host_pyramid(ex, 2, ex->evA);
+    }
+    if (rc != ORBX_OK) return rc;
+  }
   HIPC(hipStreamSynchronize(st));
+  if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
   const int* cnt = reinterpret_cast<const int*>(H);
   const int* mono = reinterpret_cast<const int*>(H + 8);
   *n_left = cnt[0]; *n_right = cnt[1];

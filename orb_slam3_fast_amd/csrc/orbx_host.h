@@ -251,6 +251,8 @@ struct orbx_extractor {
   DevBuf<uint4> d_srec, d_sdesc;   // row-sorted keypoint records / descriptors of both eyes (k_stereo_sort)
   std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)
   DevBuf<orbx::TailBand> d_tailBands;
+  std::vector<orbx::TailPlan> latTails;  // single-frame plans: the whole chain from level 0 as cascade launches (build_latency_plans)
+  DevBuf<orbx::TailBand> d_latBands;
   DevBuf<orbx_keypoint> d_kps;
   DevBuf<float> d_uR, d_depth;
   int stagePitch = 0;
@@ -259,6 +261,16 @@ struct orbx_extractor {
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   uint8_t* hostPyr = nullptr;      // pinned staging of orbx_pyramid_download (one image's pyramid), allocated on first use
   size_t hostPyrBytes = 0;
+  // single-frame host entries (orbx_extract / orbx_extract_stereo): the right eye's upload + pyramid run on stream2 beside the
+  // left eye's; with orbx_set_host_pyramid the levels are copied to page-locked memory on streamPyr beside the kernels
+  bool useLat = false;             // this extraction's resize chain = the cascade plans (latTails)
+  hipStream_t stream2 = nullptr, streamPyr = nullptr;
+  hipEvent_t evA = nullptr, evR = nullptr, evPyr = nullptr;
+  bool keepHostPyr = false;        // orbx_set_host_pyramid
+  uint8_t* hostPyrAll = nullptr;   // pinned: [2] x {level 0 (stagePitch x maxH), levels 1.. (gmax.pyrImg)}
+  size_t hostPyrAllBytes = 0;
+  int hostPyrImages = 0;           // images of the LAST extraction whose levels are in hostPyrAll (0: none)
+  int hostPyrL0Pitch = 0;          // row pitch of level 0 in that copy (= the staging pitch of the extraction)
   int32_t* h_lap = nullptr;        // pinned copy of the lapping areas the device currently holds (lapN images)
   int lapN = 0;
   // hipGraph of the single-image pipeline (host API orbx_extract): index = lapTrivial; valid for (graphW, graphH)

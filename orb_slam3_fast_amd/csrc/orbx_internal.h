@@ -84,7 +84,7 @@ struct TailPlan {
   int rtTotal;                         // row-table entries of all fused levels
   unsigned ldsBytes;
 };
-hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int nimg,
+hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int img0, int nimg,
                               const uint4* xtab, const int* yofs, const short* yab, hipStream_t s);
 hipError_t prepare_resize_tail(unsigned ldsBytes);
 

@@ -23,10 +23,10 @@ constexpr int kTailNT = 512;  // threads per workgroup
 
 __global__ __launch_bounds__(kTailNT) void k_resize_tail(Geom g, Pyr p, TailPlan tp, const TailBand* __restrict__ bands,
                                                          const uint4* __restrict__ xtab, const int* __restrict__ yofs,
-                                                         const short* __restrict__ yab) {
+                                                         const short* __restrict__ yab, int img0) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
-  const int band = blockIdx.x, img = blockIdx.y;
+  const int band = blockIdx.x, img = img0 + blockIdx.y;
   const TailBand* tb = bands + (size_t)band * (tp.nT + 1);
   // (tile offsets, not a pointer array: pointers selected at run time decay to generic addresses and the tile reads
   // become flat_load instead of ds_read)
@@ -47,7 +47,10 @@ __global__ __launch_bounds__(kTailNT) void k_resize_tail(Geom g, Pyr p, TailPlan
     const int r0 = tb[0].first, nr = tb[0].last - r0 + 1;
     const int nq = (S.w + 15) >> 4;  // uint4s per row
     const int sp = tp.pitch[0];
-    const uint8_t* src = p.pyr + (long long)img * g.pyrImg + S.off + (long long)r0 * S.pitch;
+    // (a segment that starts at level 1 -- the single-frame plans -- stages the caller's level 0: its own buffer and pitches,
+    // 16-byte aligned rows guaranteed by the host side before it picks such a plan)
+    const long long spitch = ls ? (long long)S.pitch : p.l0Row;
+    const uint8_t* src = (ls ? p.pyr + (long long)img * g.pyrImg + S.off : p.l0 + (long long)img * p.l0Img) + (long long)r0 * spitch;
     const float inv_nq = __builtin_amdgcn_rcpf((float)nq);
     const int total = nr * nq;
     constexpr int kB = 3;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(kTailNT) void k_resize_tail(Geom g, Pyr p, TailPlan
       for (int k = 0; k < kB; k++) {
         const int i = min(base + k * kTailNT + tid, total - 1);   // clamped: the tail re-writes the last element
         const int r = (int)(((float)i + 0.5f) * inv_nq), c = i - r * nq;
-        v[k] = *reinterpret_cast<const uint4*>(src + (long long)r * S.pitch + 16 * c);
+        v[k] = *reinterpret_cast<const uint4*>(src + (long long)r * spitch + 16 * c);
         dst[k] = r * sp + 16 * c;
       }
 #pragma unroll
@@ -185,16 +188,16 @@ __global__ __launch_bounds__(kTailNT) void k_resize_tail(Geom g, Pyr p, TailPlan
 #endif
 }
 
-hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int nimg,
+hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int img0, int nimg,
                               const uint4* xtab, const int* yofs, const short* yab, hipStream_t s) {
-  hipLaunchKernelGGL(k_resize_tail, dim3(tp.nBands, nimg), dim3(kTailNT), tp.ldsBytes, s, g, p, tp, bands, xtab, yofs, yab);
+  hipLaunchKernelGGL(k_resize_tail, dim3(tp.nBands, nimg), dim3(kTailNT), tp.ldsBytes, s, g, p, tp, bands, xtab, yofs, yab, img0);
   return hipGetLastError();
 }
 
 // The limit is per device and shared by every handle on it: it is set to the largest plan build_tail_plans can produce
 // (kTailLdsMax) and never lowered -- a second handle configuring a smaller geometry used to shrink it under the first.
 hipError_t prepare_resize_tail(unsigned ldsBytes) {
-  constexpr unsigned kTailLdsCeil = 96 * 1024;  // == kTailLdsMax (orbx_api.hip)
+  constexpr unsigned kTailLdsCeil = 156 * 1024;  // == kLatLdsMax >= kTailLdsMax (orbx_api.hip)
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)(ldsBytes > kTailLdsCeil ? ldsBytes : kTailLdsCeil));
 }

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Section timing of k_octree's product path (histogram variant) inside a SINGLE stereo frame (orbx_extract_stereo):
+build `make -C orb_slam3_fast_amd/csrc prof`, run with ORBX_OCTREE_PROF_LEVEL=<level>."""
+import sys, os
+sys.path.insert(0, '.')
+import orb_slam3_fast_amd as orbx
+orbx.LIB_PATH = os.path.join(os.path.dirname(orbx.__file__), os.environ.get("ORBX_PROF_LIB", "liborbx_prof.so"))
+from orb_slam3_fast_amd import synth
+L, R = synth.stereo_pair(1280, 720, 5)
+ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=1280, max_height=720, max_batch=2)
+for i in range(3):
+    ex.extract_stereo(L, R, bf=63.8, b=0.12)
+    print("----", flush=True)
