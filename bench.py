@@ -737,23 +737,26 @@ def latency_leg(a, wl, orbx, np):
         t2 = time.perf_counter()
         te.append(1e3 * (t1 - t0))
         ts.append(1e3 * (t2 - t1))
-    # the drop-in C++ class's DEFAULT (mbKeepHostPyramid = true, csrc/ORBextractor.h): every call also refreshes the host copy
-    # of both eyes' pyramids (the public mvImagePyramid of the reference) -- orbx_pyramid_download, one synchronisation per eye
+    # the drop-in C++ class's DEFAULT (mbKeepHostPyramid = true, csrc/ORBextractor.h): every call also keeps the host copy of both
+    # eyes' pyramids current (the public mvImagePyramid of the reference, read by an unmodified Frame::ComputeStereoMatches) --
+    # orbx_set_host_pyramid: DMA copies into page-locked memory beside the frame's kernels, the levels handed out in place
     lp = []
+    ex.set_host_pyramid(True)
     ex.extract_stereo(*frames[0], bf=BF, b=BASE)
-    bufs = [ex.pyramid_download(0), ex.pyramid_download(1)]
     for i in range(max(10, a.latency_frames // 2)):
         L, R = frames[i % len(frames)]
         t0 = time.perf_counter()
         ex.extract_stereo(L, R, bf=BF, b=BASE)
-        ex.pyramid_download(0, bufs[0])
-        ex.pyramid_download(1, bufs[1])
+        pl, pr = ex.host_pyramid(0), ex.host_pyramid(1)
         lp.append(1e3 * (time.perf_counter() - t0))
+    assert pl[0].shape == (H, W) and np.array_equal(pl[0], L) and np.array_equal(pr[0], R)   # (level 0 = the frame itself)
+    ex.set_host_pyramid(False)
     gc.enable()
     note = ("single %dx%d stereo frame, pageable host images in, host keypoints / descriptors / uRight / depth out, %d "
             "distinct frames; latency_ms = orbx_extract_stereo (both eyes + ComputeStereoMatches, one synchronisation), i.e. the "
-            "C++ mirror with mbKeepHostPyramid = false; latency_with_host_pyramid_ms = the same plus the refresh of both eyes' "
-            "host pyramids (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep working); "
+            "C++ mirror with mbKeepHostPyramid = false; latency_with_host_pyramid_ms = the same with the host copy of both eyes' "
+            "pyramids kept current (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep "
+            "working; orbx_set_host_pyramid: 5.8 MB of DMA copies per frame beside the kernels, levels handed out in place); "
             "extract_ms / stereo_ms = the two REGISTER_TIMES brackets as separate calls (Python wrapper included)"
             % (W, H, len(frames)))
     return {"latency_ms": _stats(lat, np), "latency_with_host_pyramid_ms": _stats(lp, np), "extract_ms": _stats(te, np),

@@ -143,6 +143,7 @@ class ORBextractor {
     int n = 0;
     const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0;
     const int lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+    ApplyHostPyramidMode();
     const int mono = orbx_extract(h_, data, w, h, step, lap0, lap1, kp_.data(), desc_.data(), cap, &n);
     if (mono == ORBX_E_EMPTY) return -1;
     if (mono < 0) throw std::runtime_error(std::string("ORBextractor::operator(): ") + orbx_last_error());
@@ -160,7 +161,7 @@ class ORBextractor {
       std::memcpy(_descriptors.data, desc_.data(), (size_t)n * 32);
 #endif
     }
-    if (mbKeepHostPyramid) SyncImagePyramid();
+    if (mbKeepHostPyramid) ViewImagePyramid(0);
     return mono;
   }
 
@@ -186,9 +187,13 @@ class ORBextractor {
     if (imRight.cols != w || imRight.rows != h) throw std::invalid_argument("ExtractStereo: image sizes differ");
 #endif
     const int cap = nfeatures + 40 * nlevels;
-    std::vector<orbx_keypoint> kl(cap), kr(cap);
-    std::vector<uint8_t> dl((size_t)cap * 32), dr((size_t)cap * 32);
-    std::vector<float> ur(cap), dp(cap);
+    std::vector<orbx_keypoint>&kl = kp_, &kr = kpR_;   // (member scratch: no per-frame allocations)
+    std::vector<uint8_t>&dl = desc_, &dr = descR_;
+    std::vector<float>&ur = ur_, &dp = dp_;
+    kl.resize(cap); kr.resize(cap);
+    dl.resize((size_t)cap * 32); dr.resize((size_t)cap * 32);
+    ur.resize(cap); dp.resize(cap);
+    ApplyHostPyramidMode();
     const int32_t ll[2] = {lapLeft.size() > 0 ? lapLeft[0] : 0, lapLeft.size() > 1 ? lapLeft[1] : 0};
     const int32_t lr[2] = {lapRight.size() > 0 ? lapRight[0] : 0, lapRight.size() > 1 ? lapRight[1] : 0};
     int nl = 0, nr = 0;
@@ -219,8 +224,8 @@ class ORBextractor {
       mvDepth->assign(dp.begin(), dp.begin() + nl);
     }
     if (mbKeepHostPyramid) {
-      SyncImagePyramid(0);
-      SyncImagePyramid(1);
+      ViewImagePyramid(0);
+      ViewImagePyramid(1);
     }
   }
 
@@ -240,13 +245,33 @@ class ORBextractor {
 
   // Public in the reference (include/ORBextractor.h:86) and read by an unmodified Frame::ComputeStereoMatches
   // (src/Frame.cc:927,1011,1024,1029).  The pyramid lives in HBM; with mbKeepHostPyramid (the DEFAULT, so that
-  // unmodified readers of mvImagePyramid keep working) every operator() / ExtractStereo refreshes the host copies
-  // (one D2H per level, ~3 MB per 1280x720 eye).  A caller that has replaced ComputeStereoMatches by the device version
-  // of this repo (ORBmatcher.h) sets mbKeepHostPyramid = false and calls SyncImagePyramid() only when it needs pixels.
-  // After ExtractStereo, mvImagePyramid is the LEFT eye (image 0) and mvImagePyramidRight the right eye (image 1).
+  // unmodified readers of mvImagePyramid keep working) every operator() / ExtractStereo keeps a host copy current:
+  // orbx_set_host_pyramid -- the library copies the levels (~2.9 MB per 1280x720 eye) into page-locked memory with the DMA
+  // engines BESIDE the frame's kernels, and mvImagePyramid[l] is a cv::Mat HEADER over that memory (no host-side copy;
+  // valid until the next call on this extractor, which is the reference's own lifetime: ComputePyramid overwrites it,
+  // src/ORBextractor.cc:1108-1145 -- clone() a level to keep it longer).  A caller that has replaced ComputeStereoMatches
+  // by the device version of this repo (ORBmatcher.h) may set mbKeepHostPyramid = false and call SyncImagePyramid() only
+  // when it needs pixels.  After ExtractStereo, mvImagePyramid is the LEFT eye (image 0) and mvImagePyramidRight the
+  // right eye (image 1).
   std::vector<ocv::Mat> mvImagePyramid;
   std::vector<ocv::Mat> mvImagePyramidRight;
   bool mbKeepHostPyramid = true;
+  void ViewImagePyramid(int image = 0) {
+    std::vector<ocv::Mat>& dst = image == 0 ? mvImagePyramid : mvImagePyramidRight;
+    dst.resize(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+      const uint8_t* p = nullptr;
+      int w = 0, h = 0;
+      ptrdiff_t st = 0;
+      if (orbx_host_pyramid_level(h_, image, l, &p, &w, &h, &st) != ORBX_OK)
+        throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+#ifdef ORBX_HAVE_OPENCV
+      dst[l] = cv::Mat(h, w, CV_8UC1, const_cast<uint8_t*>(p), (size_t)st);
+#else
+      dst[l] = ocv::Mat(h, w, const_cast<uint8_t*>(p), (size_t)st);
+#endif
+    }
+  }
   void SyncImagePyramid(int image = 0) {
     std::vector<ocv::Mat>& dst = image == 0 ? mvImagePyramid : mvImagePyramidRight;
     dst.resize(nlevels);
@@ -256,6 +281,7 @@ class ORBextractor {
       int w = 0, h = 0;
       if (orbx_pyramid_level(h_, image, l, 0, nullptr, 0, &w, &h) != ORBX_OK)   // size query only: no copy, no sync
         throw std::runtime_error(std::string("mvImagePyramid: ") + orbx_last_error());
+      dst[l].release();  // (a header over the library's page-locked copy, ViewImagePyramid, must not be written through)
 #ifdef ORBX_HAVE_OPENCV
       dst[l].create(h, w, CV_8UC1);
 #else
@@ -285,9 +311,17 @@ class ORBextractor {
   std::vector<float> mvInvLevelSigma2;
 
  private:
+  void ApplyHostPyramidMode() {  // (mbKeepHostPyramid is a public flag: follow it lazily)
+    if ((int)mbKeepHostPyramid != keepSet_) {
+      orbx_set_host_pyramid(h_, mbKeepHostPyramid ? 1 : 0);
+      keepSet_ = (int)mbKeepHostPyramid;
+    }
+  }
   orbx_extractor* h_ = nullptr;
-  std::vector<orbx_keypoint> kp_;
-  std::vector<uint8_t> desc_;
+  int keepSet_ = -1;
+  std::vector<orbx_keypoint> kp_, kpR_;
+  std::vector<uint8_t> desc_, descR_;
+  std::vector<float> ur_, dp_;
 };
 
 }  // namespace ORB_SLAM3

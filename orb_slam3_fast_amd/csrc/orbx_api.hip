@@ -331,7 +331,7 @@ void build_tail_plans(const Geom& g, const std::vector<int>& yofs, std::vector<T
 // deep cascade recomputes (a band of 2 rows of level 7 needs ~38 rows of level 0) cost nothing that matters.  Segments are
 // as long as the LDS admits (kLatLdsMax); ORBX_LAT_TAIL=levels,rows overrides (levels = 0 switches the plans off).
 constexpr int kLatLdsMax = 156 * 1024, kLatMaxImages = 2;
-static int g_lat_levels = ORBX_MAX_LEVELS, g_lat_rows = 2;
+static int g_lat_levels = 4, g_lat_rows = 2;  // 1280x720: levels 1-4 + 5-7, 14.3 + 7.6 us (one launch for 1-7: 24; 2 + 2 + 2 + 1: 27)
 void build_latency_plans(const Geom& g, const std::vector<int>& yofs, std::vector<TailPlan>& plans, std::vector<TailBand>& bands) {
   plans.clear();
   bands.clear();
@@ -721,13 +721,10 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->hostResults = nullptr;
   if (ex->hostPyr) (void)hipHostFree(ex->hostPyr);
   ex->hostPyr = nullptr;
-  if (ex->stream2) (void)hipStreamSynchronize(ex->stream2);
   if (ex->streamPyr) (void)hipStreamSynchronize(ex->streamPyr);
   if (ex->hostPyrAll) (void)hipHostFree(ex->hostPyrAll);
   ex->hostPyrAll = nullptr;
-  for (hipEvent_t* e : {&ex->evA, &ex->evR, &ex->evPyr})
-    if (*e) (void)hipEventDestroy(*e);
-  if (ex->stream2) (void)hipStreamDestroy(ex->stream2);
+  if (ex->evPyr) (void)hipEventDestroy(ex->evPyr);
   if (ex->streamPyr) (void)hipStreamDestroy(ex->streamPyr);
   if (ex->h_lap) (void)hipHostFree(ex->h_lap);
   ex->h_lap = nullptr;
@@ -888,12 +885,25 @@ static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo)
 static size_t host_pyr_image_bytes(const orbx_extractor* ex) {
   return (((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255) + (((size_t)ex->gmax.pyrImg + 255) & ~(size_t)255);
 }
-static int ensure_side_streams(orbx_extractor* ex) {
-  if (!ex->stream2) HIPC(hipStreamCreateWithFlags(&ex->stream2, hipStreamNonBlocking));
-  if (!ex->evA) HIPC(hipEventCreateWithFlags(&ex->evA, hipEventDisableTiming));
-  if (!ex->evR) HIPC(hipEventCreateWithFlags(&ex->evR, hipEventDisableTiming));
-  return ORBX_OK;
+// The kernels of a single-frame host entry behind its upload(s), on the handle's stream: resize chain, then -- when the host
+// copy of the pyramid is kept -- the event its copies wait for, then k_detect .. k_describe.  (The hipGraph replay of
+// ORBX_GRAPH=1 keeps the plain order of enqueue_extract; its host copies start behind the frame's last kernel.)
+static int enqueue_frame(orbx_extractor* ex, int n, bool lapTrivial, const int32_t* lap) {
+  static const bool useGraph = getenv("ORBX_GRAPH") && atoi(getenv("ORBX_GRAPH")) != 0;
+  hipStream_t st = ex->stream;
+  if (ex->keepHostPyr && !ex->evPyr) HIPC(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
+  if (useGraph && n == 1) {
+    int rc = enqueue_extract(ex, ex->pyr.l0, n, ex->curW, ex->curH, (ptrdiff_t)ex->pyr.l0Row, (ptrdiff_t)ex->pyr.l0Img, lap);
+    if (rc != ORBX_OK) return rc;
+    if (ex->keepHostPyr) HIPC(hipEventRecord(ex->evPyr, st));
+    return ORBX_OK;
+  }
+  int rc = enqueue_pyramid(ex, st, 0, n);
+  if (rc != ORBX_OK) return rc;
+  if (ex->keepHostPyr) HIPC(hipEventRecord(ex->evPyr, st));
+  return record_pipeline(ex, n, lapTrivial, false, true);
 }
+
 // Copies of every level of images [0, nimg) of the current extraction into hostPyrAll, on streamPyr behind `after` (an event
 // recorded once the pyramids are complete): the copies run on the DMA engines beside k_detect .. k_describe.
 static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after) {
@@ -967,22 +977,20 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   const int pitch = align_up(w, 64);
-  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img, stride, w, h, hipMemcpyHostToDevice, ex->stream));
   const int32_t lap[2] = {lap0, lap1};
-  rc = enqueue_extract(ex, ex->d_stage.p, 1, w, h, pitch, (ptrdiff_t)pitch * h, lap);
-  if (rc != ORBX_OK) return rc;
   if (!n_out) return fail(ORBX_E_BADARG, "null argument");
+  hipStream_t st = ex->stream;
+  bool lapTrivial = true;
+  rc = prepare_extract(ex, ex->d_stage.p, 1, w, h, pitch, (ptrdiff_t)pitch * h, lap, lapTrivial);
+  if (rc != ORBX_OK) return rc;
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img, stride, w, h, hipMemcpyHostToDevice, st));
+  rc = enqueue_frame(ex, 1, lapTrivial, lap);
+  if (rc != ORBX_OK) return rc;
   const size_t oc = (size_t)ex->gmax.outCap;  // results through pinned memory: async copies, one synchronisation
   uint8_t* H = ex->hostResults;
-  hipStream_t st = ex->stream;
   HIPC(enqueue_result_pack(ex, 1, false));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
   if (ex->keepHostPyr) {
-    // (the whole pipeline is on one stream here: the copies wait for its END -- the mono entry has nothing to hide them under
-    // without a second event; they still cost only the copy time, not the row-by-row host layout of orbx_pyramid_download)
-    rc = ensure_side_streams(ex);
-    if (rc != ORBX_OK) return rc;
-    HIPC(hipEventRecord(ex->evA, st));
-    rc = enqueue_host_pyramid(ex, 1, ex->evA);
+    rc = enqueue_host_pyramid(ex, 1, ex->evPyr);
     if (rc != ORBX_OK) return rc;
   }
   HIPC(hipStreamSynchronize(st));
@@ -1014,49 +1022,16 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   const int32_t lap[4] = {lap_left ? lap_left[0] : 0, lap_left ? lap_left[1] : 0, lap_right ? lap_right[0] : 0,
                           lap_right ? lap_right[1] : 0};
   hipStream_t st = ex->stream;
-  // Two streams: the right eye's upload and pyramid run beside the left eye's (a 1280x720 frame spent 55 us in two serial
-  // uploads before its first kernel, profiles/r5a_frame_trace.txt); the left stream joins before k_detect, which takes both
-  // eyes in one launch like every later stage.  While profiling (stage events live on ONE stream) and under ORBX_GRAPH the
-  // frame keeps the single-stream order.
-  static const bool oneStream = (getenv("ORBX_GRAPH") && atoi(getenv("ORBX_GRAPH")) != 0) ||
-                                (getenv("ORBX_ONE_STREAM") && atoi(getenv("ORBX_ONE_STREAM")) != 0);
-  bool pyrEvent = false;
-  if (!oneStream && !ex->profiling) {
-    bool lapTrivial = true;
-    rc = prepare_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap, lapTrivial);
-    if (rc != ORBX_OK) return rc;
-    rc = ensure_side_streams(ex);
-    if (rc != ORBX_OK) return rc;
-    hipStream_t sb = ex->stream2;
-    HIPC(hipEventRecord(ex->evA, st));          // whatever the handle still has queued reads the buffers the right eye overwrites
-    HIPC(hipStreamWaitEvent(sb, ex->evA, 0));
-    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, sb));
-    if (ex->useLat) {  // per-eye cascade launches, each right behind its own upload
-      rc = enqueue_pyramid(ex, st, 0, 1);
-      if (rc != ORBX_OK) return rc;
-      rc = enqueue_pyramid(ex, sb, 1, 1);
-      if (rc != ORBX_OK) return rc;
-      HIPC(hipEventRecord(ex->evR, sb));
-      HIPC(hipStreamWaitEvent(st, ex->evR, 0));
-      if (ex->keepHostPyr) {  // both pyramids exist from here on: the host copies may start (enqueued further down)
-        if (!ex->evPyr) HIPC(hipEventCreateWithFlags(&ex->evPyr, hipEventDisableTiming));
-        HIPC(hipEventRecord(ex->evPyr, st));
-      }
-      rc = record_pipeline(ex, 2, lapTrivial, false, true);
-    } else {           // the level kernels take both eyes per launch: join first
-      HIPC(hipEventRecord(ex->evR, sb));
-      HIPC(hipStreamWaitEvent(st, ex->evR, 0));
-      rc = record_pipeline(ex, 2, lapTrivial, false, false);
-    }
-    if (rc != ORBX_OK) return rc;
-    pyrEvent = ex->useLat;
-  } else {
-    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
-    HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
-    rc = enqueue_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap);
-    if (rc != ORBX_OK) return rc;
-  }
+  // ONE stream.  (Measured: the right eye's upload + pyramid on a second stream beside the left eye's -- 0.243 ms per frame
+  // against 0.220 ms for this order, profiles/r5b_frame_trace*.txt: the two uploads do not overlap on this runtime, the right
+  // eye's chain is the critical one either way, and the cross-stream join costs 10 us.)
+  bool lapTrivial = true;
+  rc = prepare_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap, lapTrivial);
+  if (rc != ORBX_OK) return rc;
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
+  HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
+  rc = enqueue_frame(ex, 2, lapTrivial, lap);
+  if (rc != ORBX_OK) return rc;
   const bool stereo = bf > 0.f && uright && depth;
   if (stereo) {
     rc = orbx_stereo_match_batch(ex, 0, ex, 1, 1, bf, b);
@@ -1067,17 +1042,7 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   uint8_t* H = ex->hostResults;
   HIPC(enqueue_result_pack(ex, 2, stereo));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
   if (ex->keepHostPyr) {
-    // enqueued AFTER the frame's kernels (the host's time belongs to the critical chain first); on the device the copies start
-    // as soon as both pyramids exist (evPyr, recorded at the join of the two eyes) and run beside k_detect .. k_describe --
-    // without the cascade plans, behind the frame's last kernel
-    rc = ensure_side_streams(ex);
-    if (rc != ORBX_OK) return rc;
-    if (pyrEvent) {
-      rc = enqueue_host_pyramid(ex, 2, ex->evPyr);
-    } else {
-      HIPC(hipEventRecord(ex->evA, st));
-      rc = enqueue_host_pyramid(ex, 2, ex->evA);
-    }
+    rc = enqueue_host_pyramid(ex, 2, ex->evPyr);
     if (rc != ORBX_OK) return rc;
   }
   HIPC(hipStreamSynchronize(st));

@@ -261,11 +261,11 @@ struct orbx_extractor {
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   uint8_t* hostPyr = nullptr;      // pinned staging of orbx_pyramid_download (one image's pyramid), allocated on first use
   size_t hostPyrBytes = 0;
-  // single-frame host entries (orbx_extract / orbx_extract_stereo): the right eye's upload + pyramid run on stream2 beside the
-  // left eye's; with orbx_set_host_pyramid the levels are copied to page-locked memory on streamPyr beside the kernels
+  // single-frame host entries (orbx_extract / orbx_extract_stereo): with orbx_set_host_pyramid the levels are copied to
+  // page-locked memory on streamPyr, behind evPyr (recorded once the pyramids exist), beside the frame's kernels
   bool useLat = false;             // this extraction's resize chain = the cascade plans (latTails)
-  hipStream_t stream2 = nullptr, streamPyr = nullptr;
-  hipEvent_t evA = nullptr, evR = nullptr, evPyr = nullptr;
+  hipStream_t streamPyr = nullptr;
+  hipEvent_t evPyr = nullptr;
   bool keepHostPyr = false;        // orbx_set_host_pyramid
   uint8_t* hostPyrAll = nullptr;   // pinned: [2] x {level 0 (stagePitch x maxH), levels 1.. (gmax.pyrImg)}
   size_t hostPyrAllBytes = 0;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kTailNT) void k_resize_tail(Geom g, Pyr p, TailPlan
     RT_MK();
   }
 #ifdef RT_PROF
-  if (tid == 0 && img == 7 && band == 1) {  // load + tables | per level: {barrier, rows, barrier}
+  if (tid == 0 && img == 0 && band == 1) {  // load + tables | per level: {barrier, rows, barrier}
     printf("k_resize_tail L%d..%d band 1:", tp.lA, tp.lA + tp.nT - 1);
     for (int i = 1; i < nq_; i++) printf(" %d", (int)(tq[i] - tq[i - 1]));
     printf("  (x10 ns; workgroup %d)\n", (int)(tq[nq_ - 1] - tq[0]));

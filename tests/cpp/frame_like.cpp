@@ -230,6 +230,12 @@ int main(int argc, char** argv) {
   tr.join();
   std::vector<float> uR, depth;
   ComputeStereoMatches(exL, exR, (int)kL.size(), 0.12f * 532.03f, 0.12f, uR, depth);
+  {  // mbKeepHostPyramid (the default): mvImagePyramid[l] is a header over the library's page-locked copy, rows `step` apart
+    const ocv::Mat& v = exL.mvImagePyramid[3];
+    std::vector<uint8_t> rows((size_t)v.rows * v.cols);
+    for (int y = 0; y < v.rows; y++) std::memcpy(rows.data() + (size_t)y * v.cols, v.ptr(y), (size_t)v.cols);
+    dump(out + ".vpyr3", rows.data(), rows.size());
+  }
   exL.SyncImagePyramid();
   dump(out + ".kL", kL.data(), kL.size());
   dump(out + ".dL", dL.data, (size_t)dL.rows * 32);
@@ -271,6 +277,16 @@ int main(int argc, char** argv) {
     std::vector<float> puR, pdepth;
     int pmL = 0, pmR = 0;
     exP.ExtractStereo(imL, imR, pL, pdL, pR, pdR, lap, lap, pmL, pmR, 0.12f * 532.03f, 0.12f, &puR, &pdepth);
+    {  // the right eye's pyramid of the single-call path (mvImagePyramidRight), level 5, and the left eye's level 0
+      const ocv::Mat& v = exP.mvImagePyramidRight[5];
+      std::vector<uint8_t> rows((size_t)v.rows * v.cols);
+      for (int y = 0; y < v.rows; y++) std::memcpy(rows.data() + (size_t)y * v.cols, v.ptr(y), (size_t)v.cols);
+      dump(out + ".vpyrR5", rows.data(), rows.size());
+      const ocv::Mat& z = exP.mvImagePyramid[0];
+      if (z.rows != h || z.cols != w) return 8;
+      for (int y = 0; y < h; y++)
+        if (std::memcmp(z.ptr(y), imL.ptr(y), (size_t)w) != 0) return 9;
+    }
     dump(out + ".pkL", pL.data(), pL.size());
     dump(out + ".pdR", pdR.data, (size_t)pdR.rows * 32);
     dump(out + ".puR", puR.data(), puR.size());

@@ -63,6 +63,8 @@ def test_cpp_mirror_matches_oracle(oracle, tmp_path, cv):
     ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, np.float32(0.12) * np.float32(532.03), 0.12)
     assert open(out + ".uR", "rb").read() == ou.tobytes() and open(out + ".depth", "rb").read() == od.tobytes()
     assert open(out + ".pyr3", "rb").read() == oL.level(3).tobytes()
+    assert open(out + ".vpyr3", "rb").read() == oL.level(3).tobytes()        # the in-place view of the kept host pyramid
+    assert open(out + ".vpyrR5", "rb").read() == oR.level(5).tobytes()       # ExtractStereo: right eye's view
     prev = np.stack([okL["x"], okL["y"]], 1)
     on, om12, _ = oracle.search_init(okL, odL, okR, odR, (0, 0, w, h), prev, 100, 0.9, True)
     assert nm == on and np.fromfile(out + ".m12", np.int32).tolist() == om12.tolist()

@@ -896,3 +896,61 @@ def test_extract_stereo_single_call(gpu, oracle):
     assert (mL, mR) == (omL, omR) and np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dR, odR)
     with pytest.raises(orbx.OrbxError):
         orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h).extract_stereo(L, R)
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl", [(1280, 720, 1500, 1.2, 8), (640, 480, 1000, 1.2, 8), (752, 480, 1000, 1.2, 8), (512, 512, 1500, 1.2, 8),
+                                           (333, 517, 400, 1.2, 6), (800, 600, 800, 1.5, 5), (1000, 700, 600, 2.0, 4)])
+def test_single_frame_cascade_plans_and_host_pyramid(gpu, oracle, w, h, nf, sf, nl):
+    """The single-frame host entries (orbx_extract, orbx_extract_stereo: <= 2 images) build the WHOLE pyramid with cascade
+    launches from level 0 (k_resize_tail, build_latency_plans) instead of the level kernels; a batch of three images of the same
+    size goes through the level kernels.  Every level of both routes equals cv::resize's chain (src/ORBextractor.cc:1108-1145)
+    byte for byte, and so do the keypoints / descriptors / stereo results.  With orbx_set_host_pyramid the levels also arrive
+    in the handle's page-locked copy (the reference's host-resident mvImagePyramid, include/ORBextractor.h:86), read in place."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    L, R = synth.stereo_pair(w, h, 400 + nl)
+    third = synth.mono_frame(w, h, 410 + nl)
+    ex = orbx.ORBextractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+    oL, oR = oracle.OracleExtractor(nf, sf, nl, 20, 7), oracle.OracleExtractor(nf, sf, nl, 20, 7)
+    omL, okL, odL = oL.extract(L)
+    omR, okR, odR = oR.extract(R)
+    bf, b = np.float32(0.12) * np.float32(532.03), 0.12
+    ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
+    ex.set_host_pyramid(True)
+    for rep in range(2):   # (second round: the views of the first are reused)
+        (mL, kL, dL), (mR, kR, dR), (u, dep) = ex.extract_stereo(L, R, bf=float(bf), b=b)
+        assert (mL, mR) == (omL, omR)
+        assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(dL, odL)
+        assert np.array_equal(_kp_bytes(kR), _kp_bytes(okR)) and np.array_equal(dR, odR)
+        assert u.tobytes() == ou.tobytes() and dep.tobytes() == od.tobytes()
+        hl, hr = ex.host_pyramid(0), ex.host_pyramid(1)
+        for l in range(nl):
+            assert np.array_equal(hl[l], oL.level(l)) and np.array_equal(hr[l], oR.level(l)), l
+            assert np.array_equal(ex.image_pyramid(l, image=1), oR.level(l)), l
+    m1, k1, d1 = ex(R)                      # mono entry: image 0 of the host copy is now R
+    assert m1 == omR and np.array_equal(_kp_bytes(k1), _kp_bytes(okR)) and np.array_equal(d1, odR)
+    h1 = ex.host_pyramid(0)
+    for l in range(nl):
+        assert np.array_equal(h1[l], oR.level(l)), l
+    with pytest.raises(orbx.OrbxError):
+        ex.host_pyramid(1)                  # the mono call left no second image
+    ex.set_host_pyramid(False)
+    with pytest.raises(orbx.OrbxError):
+        ex.host_pyramid(0)
+    # the same frames as a device batch of three: the level kernels
+    pitch = (w + 15) // 16 * 16
+    padded = np.zeros((3, h, pitch), np.uint8)
+    padded[0, :, :w], padded[1, :, :w], padded[2, :, :w] = L, R, third
+    dbuf = DeviceBuffer.from_numpy(padded)
+    ex.extract_batch_device(dbuf.ptr.value, 3, w, h, pitch, pitch * h)
+    ex.sync()
+    for l in range(nl):
+        assert np.array_equal(ex.image_pyramid(l, image=0), oL.level(l)) and np.array_equal(ex.image_pyramid(l, image=1), oR.level(l)), l
+    m0, k0, d0 = ex.download(0)
+    assert m0 == omL and np.array_equal(_kp_bytes(k0), _kp_bytes(okL)) and np.array_equal(d0, odL)
+    # ... and as a device batch of two (cascade plans from the caller's buffer when its rows are 16-byte aligned)
+    ex.extract_batch_device(dbuf.ptr.value, 2, w, h, pitch, pitch * h)
+    ex.sync()
+    for l in range(nl):
+        assert np.array_equal(ex.image_pyramid(l, image=1), oR.level(l)), l
+    m1b, k1b, d1b = ex.download(1)
+    assert m1b == omR and np.array_equal(_kp_bytes(k1b), _kp_bytes(okR)) and np.array_equal(d1b, odR)
