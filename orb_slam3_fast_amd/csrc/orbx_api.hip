@@ -1151,19 +1151,25 @@ int orbx_debug_candidates(orbx_extractor* ex, int image, int level, int32_t* xys
     return fail(ORBX_E_BADARG, "bad argument");
   HIPC(hipSetDevice(ex->device));
   HIPC(hipStreamSynchronize(ex->stream));
-  int n = 0;
-  HIPC(hipMemcpy(&n, ex->d_candCount.p + image * ex->g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+  // read from k_detect's per-cell slots (the quadtree keeps its dense copy in registers: it is not written back), in the cell
+  // order the quadtree gathers them, truncated like it (candCap)
   const LevelDev& L = ex->g.lv[level];
-  if (n > L.candCap) n = L.candCap;
-  std::vector<uint32_t> v(n);
-  if (n)
-    HIPC(hipMemcpy(v.data(), ex->d_cand.p + (long long)image * ex->g.candImg + L.candOff, (size_t)n * 4,
-                   hipMemcpyDeviceToHost));
-  for (int i = 0; i < n && i < cap; i++) {
-    xys[3 * i] = key_x(v[i]);
-    xys[3 * i + 1] = key_y(v[i]);
-    xys[3 * i + 2] = key_r(v[i]);
-  }
+  const int cells = L.nCols * L.nRows;
+  std::vector<int> cnt(cells);
+  HIPC(hipMemcpy(cnt.data(), ex->d_cellCount.p + (long long)image * ex->g.totalCells + L.cellStart, (size_t)cells * sizeof(int),
+                 hipMemcpyDeviceToHost));
+  std::vector<uint32_t> v((size_t)cells * L.cellCap);
+  if (!v.empty())
+    HIPC(hipMemcpy(v.data(), ex->d_cellCand.p + (long long)image * ex->g.cellImg + L.cellOff, v.size() * 4, hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int c = 0; c < cells; c++)
+    for (int i = 0; i < cnt[c] && n < L.candCap; i++, n++) {
+      if (n >= cap) continue;
+      const uint32_t k = v[(size_t)c * L.cellCap + i];
+      xys[3 * n] = key_x(k);
+      xys[3 * n + 1] = key_y(k);
+      xys[3 * n + 2] = key_r(k);
+    }
   return n;
 }
 

@@ -562,8 +562,8 @@ __host__ __device__ inline OctLds oct_layout(int maxn, int maxcells, int rep) {
   // (the floors are the histogram variant's tables for <= 2 roots: code -> node map in cnt4, histogram + leaf table in cntr)
   o.cnt4 = take(maxn * 16 > 4096 ? maxn * 16 : 4096);
   o.cntr = take(maxn * 16 * rep > 16400 ? maxn * 16 * rep : 16400);  // quadrant counters, `rep` replicas each (see OctCtx::cntr)
-  o.cpos = take(maxn * 8);
   o.scan = take(maxn * 8);  // u64 scan values; reused as best[] at the end
+  o.cpos = take(maxn * 8);  // [cpos, tsum) is also the histogram variant's coordinate-table region (OctCtx::tab): keep contiguous
   o.e[0] = take(maxn * 8);
   o.e[1] = take(maxn * 8);
   o.mark = take(maxn * 2);
@@ -648,6 +648,7 @@ struct OctCands {
     if constexpr (REG) {
 #pragma unroll
       for (int j0 = 0; j0 < OCT_KMAX; j0 += OCT_GROUP) {  // (no early exit: its phi copies double the live arrays)
+        if (j0 * OCT_NT >= n) continue;  // whole group past the last candidate (uniform): a level-4 workgroup fills 9 of 32 slots
 #pragma unroll
         for (int j = j0; j < j0 + OCT_GROUP; j++)  // padding entries carry the sentinel node id (a per-j `k < n`
         {                                          // test would be hoisted out of every pass: 64 live SGPRs)
@@ -682,7 +683,6 @@ struct OctCands {
       for (int j = 0; j < OCT_KMAX; j++) {
         const int k = (int)threadIdx.x + j * OCT_NT;
         const uint32_t nd = k < n ? 0u : kNoCand;
-        if (k < n) keys[k] = rk[j];  // kept for orbx_debug_candidates
         rn2[j >> 1] = (j & 1) ? rn2[j >> 1] | (nd << 16) : nd;
       }
     } else {
@@ -713,6 +713,8 @@ struct OctCtx {  // node tables are double buffered: buffer b of table T sits at
   int maxn;
   uint16_t* owner;  // gather only: candidate k -> FAST cell, aliasing every table in front of tsum (ownerBytes)
   int ownerBytes;
+  uint8_t* tab;     // histogram variant: per-coordinate tables (path codes for sweep 1, canonical ranks for the winner sweeps),
+  int tabBytes;     // aliasing cpos / e / mark / bestk at times those are idle
 };
 
 // Dense candidate k -> (cell, index in cell) for the gather.  Every cell writes its index over its range of an LDS map
@@ -1194,28 +1196,64 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
   const int nH = oct_hbase(nIni, OCT_HD + 1);
   for (int i = tid; i < nH; i += OCT_NT) hist[i] = 0;
   if (tid == 0) s_i[3] = 0;  // fallback flag
+  // The quadrant sequence of a candidate separates: its x bits depend on x alone (root column included), its y bits on y
+  // alone -- DivideNode halves a rectangle's sides independently (:494-495).  So the depth-OCT_HD path code is px[x] + py[y]
+  // with two small per-coordinate tables (W + H entries) instead of ~90 instructions per candidate (an IEEE division for
+  // the root and five rounds of midpoints / selects): sweep 1 was 7.7 of a level-1 workgroup's 46 us
+  // (profiles/r5a_octree_sections.txt).  The tables sit in LDS that is idle until the node lists start.
+  const bool pathTab = 2 * (W + H) + 8 <= c.tabBytes;  // (uniform; very large levels keep the arithmetic form)
+  uint16_t* px = reinterpret_cast<uint16_t*>(c.tab);
+  uint16_t* py = px + ((W + 3) & ~3);
+  auto x_path = [&](int x) {
+    const int r = (int)((float)x / hX);
+    int x0 = (int)(hX * (float)r), x1 = (int)(hX * (float)(r + 1));
+    uint32_t code = (uint32_t)r;
+#pragma unroll
+    for (int d = 0; d < OCT_HD; d++) {
+      const int mx = x0 + ((x1 - x0 + 1) >> 1);
+      const int qx = x >= mx;
+      x0 = qx ? mx : x0;
+      x1 = qx ? x1 : mx;
+      code = code * 4 + (uint32_t)qx;
+    }
+    return code;
+  };
+  auto y_path = [&](int y) {
+    int y0 = 0, y1 = H;
+    uint32_t code = 0;
+#pragma unroll
+    for (int d = 0; d < OCT_HD; d++) {
+      const int my = y0 + ((y1 - y0 + 1) >> 1);
+      const int qy = y >= my;
+      y0 = qy ? my : y0;
+      y1 = qy ? y1 : my;
+      code = code * 4 + (uint32_t)(qy << 1);
+    }
+    return code;
+  };
+  if (pathTab) {
+    for (int i = tid; i < W + H; i += OCT_NT) {
+      if (i < W) px[i] = (uint16_t)x_path(i);
+      else py[i - W] = (uint16_t)y_path(i - W);
+    }
+  }
   __syncthreads();
   // ---- sweep 1: path code of every candidate, histogram at depth OCT_HD
   {
     uint32_t* h5 = hist + oct_hbase(nIni, OCT_HD);
-    cd.sweep([&](int, uint32_t key, uint32_t& nd) {
-      const int x = key_x(key), y = key_y(key);
-      const int r = (int)((float)x / hX);
-      int x0 = (int)(hX * (float)r), x1 = (int)(hX * (float)(r + 1)), y0 = 0, y1 = H;
-      uint32_t code = (uint32_t)r;
-#pragma unroll
-      for (int d = 0; d < OCT_HD; d++) {
-        const int mx = x0 + ((x1 - x0 + 1) >> 1), my = y0 + ((y1 - y0 + 1) >> 1);
-        const int qx = x >= mx, qy = y >= my;
-        x0 = qx ? mx : x0;
-        x1 = qx ? x1 : mx;
-        y0 = qy ? my : y0;
-        y1 = qy ? y1 : my;
-        code = code * 4 + (uint32_t)(qx | (qy << 1));
-      }
-      nd = code;
-      atomicAdd(&h5[code], 1u);
-    });
+    if (pathTab) {
+      cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+        const uint32_t code = (uint32_t)px[key_x(key)] + (uint32_t)py[key_y(key)];
+        nd = code;
+        atomicAdd(&h5[code], 1u);
+      });
+    } else {
+      cd.sweep([&](int, uint32_t key, uint32_t& nd) {
+        const uint32_t code = x_path(key_x(key)) + y_path(key_y(key));
+        nd = code;
+        atomicAdd(&h5[code], 1u);
+      });
+    }
   }
   __syncthreads();
   HMK();  // sweep 1 (path codes + depth-5 histogram)
@@ -1488,6 +1526,10 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     for (int i = tid; i < nA; i += OCT_NT) best[i] = 0;
   __syncthreads();
   const float invH = 1.0f / (float)L.hCell, invW = 1.0f / (float)L.wCell;
+  // canonical rank of a candidate = the reference's candidate order (cell row, cell column, y, x).  The winner of a node is
+  // then DECODED from the node's maximum (the rank determines the pixel), one thread per node: no second candidate sweep
+  // ("am I my node's maximum?", rounds 2 - 4).  (Rank tables per coordinate like the path tables were measured and are
+  // slower than the arithmetic here: the sweep waits for its LDS reads, t5[nd] first.)
   auto rank_key = [&](uint32_t key) {
     const int xr = key_x(key) - 3, yr = key_y(key) - 3;  // relative to the first detectable pixel (19,19)
     const int cy = (int)(((float)yr + 0.5f) * invH), cx = (int)(((float)xr + 0.5f) * invW);
@@ -1495,23 +1537,23 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
     return ((unsigned long long)key_r(key) << 32) | (0xFFFFFFFFu - rank);
   };
   cd.sweep([&](int, uint32_t key, uint32_t& nd) {
-    nd = t5[nd];  // from here on the per-candidate id is the final node index
-    if (nrepB > 1) atomicMax((unsigned long long*)&bestr[nd * nrepB + repB], rank_key(key));
-    else atomicMax((unsigned long long*)&best[nd], rank_key(key));
+    const uint32_t fn = t5[nd];  // final node index
+    if (nrepB > 1) atomicMax((unsigned long long*)&bestr[fn * nrepB + repB], rank_key(key));
+    else atomicMax((unsigned long long*)&best[fn], rank_key(key));
   });
   __syncthreads();
-  if (nrepB > 1) {
-    for (int i = tid; i < nA; i += OCT_NT) {
-      uint64_t v = 0;
-      for (int r = 0; r < nrepB; r++) v = bestr[i * nrepB + r] > v ? bestr[i * nrepB + r] : v;
-      best[i] = v;
-    }
-    __syncthreads();
-  }
   const int nOut = min(nA, L.selCap);
-  cd.sweep([&](int, uint32_t key, uint32_t& nd) {
-    if ((int)nd < nOut && best[nd] == rank_key(key)) out[nd] = pack_key(key_x(key) + kBorder, key_y(key) + kBorder, key_r(key));
-  });
+  for (int i = tid; i < nOut; i += OCT_NT) {
+    uint64_t v = nrepB > 1 ? 0 : best[i];
+    if (nrepB > 1)
+      for (int r = 0; r < nrepB; r++) v = bestr[i * nrepB + r] > v ? bestr[i * nrepB + r] : v;
+    // (every final node holds >= 1 candidate, so v != 0)
+    const uint32_t rank = 0xFFFFFFFFu - (uint32_t)v, resp = (uint32_t)(v >> 32);
+    const uint32_t xloc = rank % (uint32_t)L.wCell, t1 = rank / (uint32_t)L.wCell;
+    const uint32_t yloc = t1 % (uint32_t)L.hCell, t2 = t1 / (uint32_t)L.hCell;
+    const uint32_t cx = t2 % (uint32_t)L.nCols, cy = t2 / (uint32_t)L.nCols;
+    out[i] = pack_key((int)(cx * L.wCell + xloc) + 3 + kBorder, (int)(cy * L.hCell + yloc) + 3 + kBorder, (int)resp);
+  }
   if (tid == 0) *outCount = nOut;
   HMK();  // best-response sweeps
 #ifdef OCT_PROF
@@ -1563,6 +1605,8 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   c.maxn = maxn;
   c.owner = (uint16_t*)smem;
   c.ownerBytes = o.tsum;
+  c.tab = smem + o.cpos;
+  c.tabBytes = o.tsum - o.cpos;
 
   // ---- exclusive scan of the level's per-cell counts (the sparse per-cell slots are compacted by octree_body;
   // candidate order is irrelevant: ties are broken by the canonical rank)
