@@ -453,6 +453,80 @@ __device__ __forceinline__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp
   wsync();
 }
 
+// __introsort_loop of a segment of <= 64 elements carried through ALL of its partitions in registers by one wave: lane i
+// holds element first + i, a partition is ballots + six cross-lane moves (the stopper lists of partition_wave become "lane k
+// receives the k-th stopper" by ds_permute with the stopper's rank as destination; lane 63 never is a destination -- at most 63
+// stoppers exist, the pivot slot is excluded -- and takes the pushes of the non-stoppers), the sub-segments are walked depth
+// first with a three-entry stack of uniform values.  No LDS traffic, no barrier: the 128-node sort of a level-0 quadtree took
+// 10 us as five workgroup-wide rounds of LDS partitions (profiles/r5a_octree_sections.txt).
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ void introsort_seg_reg(uint64_t* a, int first, int last, int depth0, int lane) {
+  const KeyLess less;
+  const int n = last - first;  // 17 .. 64 (uniform)
+  uint64_t v = a[first + min(lane, n - 1)];
+  uint32_t stk[3];  // f | l << 8 | depth << 16 of the pending right-hand segments (> 16 elements each: at most three exist)
+  int sp = 0;
+  int f = 0, l = n, d = depth0;
+  for (;;) {
+    while (l - f > 16) {
+      if (d == 0) {  // depth budget exhausted (adversarial inputs only): __partial_sort on this range, serial, through LDS
+        if (lane < n) a[first + lane] = v;
+        wsync();
+        if (lane == 0) is_heapsort<uint64_t, KeyLess>(a, first + f, first + l, less);
+        wsync();
+        v = a[first + min(lane, n - 1)];
+        break;
+      }
+      --d;
+      const int mid = f + (l - f) / 2;
+      const uint64_t va = readlane_u64(v, f + 1), vb = readlane_u64(v, mid), vc = readlane_u64(v, l - 1);
+      int sel;
+      if (less(va, vb)) sel = less(vb, vc) ? mid : (less(va, vc) ? l - 1 : f + 1);
+      else if (less(va, vc)) sel = f + 1;
+      else sel = less(vb, vc) ? l - 1 : mid;
+      const uint64_t vf = readlane_u64(v, f), pivot = readlane_u64(v, sel);
+      if (lane == f) v = pivot;
+      if (lane == sel) v = vf;
+      const bool in = lane > f && lane < l;
+      const bool stL = in && !less(v, pivot), stR = in && !less(pivot, v);
+      const uint64_t mL = __ballot(stL), mR = __ballot(stR);
+      const int nL = __popcll(mL), nR = __popcll(mR), nmin = min(nL, nR);
+      const int rankL = __popcll(mL & lanemask_lt()), rankR = __popcll(mR & ~(lanemask_lt() | (1ull << lane)));
+      // lane k <- k-th left stopper (ascending) / k-th right stopper (descending)
+      const int LiK = __builtin_amdgcn_ds_permute(4 * (stL ? rankL : 63), lane);
+      const int RiK = __builtin_amdgcn_ds_permute(4 * (stR ? rankR : 63), lane);
+      const int K = __popcll(__ballot(lane < nmin && LiK < RiK));  // (monotone: true for k < K)
+      const int INF = 1 << 30;
+      const int lk = K < nL ? __builtin_amdgcn_readlane(LiK, K) : INF;
+      const int rk = K > 0 ? __builtin_amdgcn_readlane(RiK, K - 1) : INF;
+      const int cut = min(lk, rk);
+      // pairs k < K swap: a left stopper of rank k takes the element of Ri[k] and vice versa (no lane is both: see DESIGN)
+      const int pL = __builtin_amdgcn_ds_bpermute(4 * rankL, RiK), pR = __builtin_amdgcn_ds_bpermute(4 * rankR, LiK);
+      const int src = (stL && rankL < K) ? pL : ((stR && rankR < K) ? pR : lane);
+      const uint32_t nlo = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * src, (int)(uint32_t)v);
+      const uint32_t nhi = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * src, (int)(uint32_t)(v >> 32));
+      v = ((uint64_t)nhi << 32) | nlo;
+      if (l - cut > 16) {
+        const uint32_t e = (uint32_t)cut | ((uint32_t)l << 8) | ((uint32_t)d << 16);
+        if (sp == 0) stk[0] = e; else if (sp == 1) stk[1] = e; else stk[2] = e;
+        ++sp;
+      }
+      l = cut;
+    }
+    if (sp == 0) break;
+    --sp;
+    const uint32_t e = sp == 0 ? stk[0] : (sp == 1 ? stk[1] : stk[2]);
+    f = (int)(e & 0xFF);
+    l = (int)((e >> 8) & 0xFF);
+    d = (int)(e >> 16);
+  }
+  if (lane < n) a[first + lane] = v;
+}
+
 // The same std::sort replica run by a WHOLE workgroup.  __introsort_loop is a binary tree of partitions: a segment
 // (first, last, depth) is partitioned, and both halves continue with depth - 1 -- nothing else is shared between them.
 // So the tree is walked breadth first: every wave takes segments of the current level (partition_wave on disjoint ranges
@@ -462,6 +536,13 @@ __device__ __forceinline__ void introsort_wave(uint64_t* a, int n, uint64_t* tmp
 __device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tmp, uint16_t* Li, uint16_t* Ri, uint32_t* segs) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
   const KeyLess less;
+#ifdef OCT_PROF
+  long long smk[24]; int nsmk = 0;
+#define SMK() do { if (nsmk < 24) smk[nsmk++] = wall_clock64(); } while (0)
+#else
+#define SMK() do {} while (0)
+#endif
+  SMK();
   if (n > 16) {  // (uniform)
     uint32_t* cnt = segs + 512;
     int lg = 0;
@@ -479,7 +560,9 @@ __device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tm
       for (int k = wv; k < ns; k += nw) {
         const uint32_t sg = segs[cur * 256 + k];
         const int first = (int)(sg & 0x1FFF), last = (int)((sg >> 13) & 0x1FFF), depth = (int)(sg >> 26);
-        if (depth == 0) {
+        if (last - first <= 64) {
+          introsort_seg_reg(a, first, last, depth, lane);  // the whole sub-tree of this segment, in registers
+        } else if (depth == 0) {
           if (lane == 0) is_heapsort<uint64_t, KeyLess>(a, first, last, less);
         } else {
           const int cut = partition_wave(a, first, last, Li + first, Ri + first, lane);
@@ -490,26 +573,49 @@ __device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tm
           }
         }
       }
+      SMK();
       __syncthreads();
       if (tid == 0) cnt[cur] = 0;
       cur ^= 1;
       __syncthreads();
+      SMK();
     }
   }
+  SMK();
   // __final_insertion_sort == stable rank inside a +-16 window
-  for (int i = tid; i < n; i += nt) {
-    const uint64_t vi = a[i];
-    const int w0 = max(0, i - 16), w1 = min(n, i + 17);
-    int c = 0;
-    for (int j = w0; j < w1; j++) {
-      const uint64_t vj = a[j];
-      c += (less(vj, vi) || (!less(vi, vj) && j < i)) ? 1 : 0;
+  // (these node-list steps are latency chains of one wave's instructions: the window's 33 comparisons are dealt to 4 / 2
+  // lanes per element when the workgroup has lanes to spare, partial counts meet by DPP quad / pair exchanges)
+  {
+    const int per = (4 * n <= nt) ? 4 : ((2 * n <= nt) ? 2 : 1);  // lanes per element (uniform)
+    const int chunk = (33 + per - 1) / per;                        // 9, 17 or 33 window positions per lane
+    for (int i0 = 0; i0 < n * per; i0 += nt) {
+      const int t = i0 + tid, i = min(t / per, n - 1), sub = t % per;
+      const uint64_t vi = a[i];
+      int c = 0;
+      const int jb = i - 16 + sub * chunk, je = min(jb + chunk, i + 17);
+      for (int j = jb; j < je; j++) {
+        const uint64_t vj = a[min(max(j, 0), n - 1)];
+        const bool inw = j >= 0 && j < n;
+        c += (inw && (less(vj, vi) || (!less(vi, vj) && j < i))) ? 1 : 0;
+      }
+      if (per >= 2) c += __shfl_xor(c, 1);
+      if (per >= 4) c += __shfl_xor(c, 2);
+      if (t < n * per && sub == 0) tmp[max(0, i - 16) + c] = vi;
     }
-    tmp[w0 + c] = vi;
   }
+  SMK();
   __syncthreads();
   for (int i = tid; i < n; i += nt) a[i] = tmp[i];
   __syncthreads();
+  SMK();
+#ifdef OCT_PROF
+  if (tid == 0 && blockIdx.x == 0 && gridDim.x > 1) {
+    printf("sort n=%d:", n);
+    for (int i = 1; i < nsmk; i++) printf(" %d", (int)(smk[i] - smk[i - 1]));
+    printf("  (x10 ns: init | {work, barriers} per round | - | final rank | copy back)\n");
+  }
+#endif
+#undef SMK
 }
 
 // Test entry: sort n elements (one block, dynamic LDS): 512 threads = the workgroup version the quadtree runs,

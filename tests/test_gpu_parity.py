@@ -245,18 +245,23 @@ def test_device_introsort_matches_libstdcxx(gpu, oracle):
     import ctypes as C
     rng = np.random.default_rng(3)
     osort = oracle.lib().oro_std_sort_keys
-    sizes = [1, 2, 15, 16, 17, 31, 33, 64, 65, 100, 250, 333, 1000, 2500, 4000] + [int(v) for v in rng.integers(18, 900, 60)]
+    sizes = ([1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 250, 333, 342, 1000, 2500, 4000] + [int(v) for v in rng.integers(18, 900, 60)]
+             + [int(v) for v in rng.integers(17, 65, 40)] + [int(v) for v in rng.integers(65, 350, 60)])
     for trial, n in enumerate(sizes):
         mode = trial % 4
         cnt = rng.integers(2, 2 + [3, 1, 100, 8][mode], n).astype(np.uint64)
         ulx = rng.integers(0, [4, 2, 1200, 1][mode], n).astype(np.uint64)
         if trial % 7 == 0:
             cnt = np.sort(cnt)[::-1].copy()                    # descending input
+        if trial % 11 == 5:
+            cnt = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.uint64) + np.uint64(2)   # organ pipe
         v = (cnt << np.uint64(28)) | (ulx << np.uint64(16)) | np.arange(n, dtype=np.uint64)
-        a, b = v.copy(), v.copy()
-        assert orbx.lib().orbx_debug_introsort_device(0, a.ctypes.data_as(C.c_void_p), n) == 0
+        b = v.copy()
         osort(b.ctypes.data_as(C.c_void_p), n)
-        assert np.array_equal(a, b), "n=%d mode=%d" % (n, mode)
+        for version in range(2):   # consecutive calls alternate the one-wave and the workgroup form (segments <= 64 in registers)
+            a = v.copy()
+            assert orbx.lib().orbx_debug_introsort_device(0, a.ctypes.data_as(C.c_void_p), n) == 0
+            assert np.array_equal(a, b), "n=%d mode=%d version=%d" % (n, mode, version)
 
 
 def test_device_sincos_equals_host_libm(gpu, oracle):

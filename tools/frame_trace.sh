@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timeline of one single-frame orbx_extract_stereo call (run on the GPU box):  tools/frame_trace.sh [out.txt] [script.py]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=${1:-$R/gpurun_out/frame_trace.txt}
+OUT=${1:-$R/gpurun_out/frame_trace.txt}; case "$OUT" in /*) ;; *) OUT=$R/$OUT;; esac; mkdir -p "$(dirname "$OUT")"
 SCRIPT=${2:-$R/tools/lat_trace.py}
 D=$(mktemp -d /tmp/ftrace.XXXXXX)
 cd /tmp && export TMPDIR=/tmp
