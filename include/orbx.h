@@ -83,7 +83,7 @@ int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version);
  * bytes per row).  lap0/lap1 = vLappingArea.  Writes *n_out keypoints (serial-order slots: mono from the
  * front, lapping from the back) and n_out x 32 descriptor bytes.  Returns monoIndex (>= 0), ORBX_E_EMPTY for
  * an empty image, or another negative error.  cap = capacity of kps / desc rows (nfeatures + 3*nlevels
- * always suffices). */
+ * always suffices).  kps / desc may be NULL: the results stay in the handle's result block (orbx_host_results). */
 int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
 
@@ -92,13 +92,23 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
  * ComputeStereoMatches that follows them (:921-1084; b = baseline, maxD = bf / b).  The handle needs max_batch >= 2; the
  * left eye becomes image 0 and the right eye image 1 of the extraction (orbx_pyramid_level, orbx_stereo_match_batch with
  * left == right handle, first_left 0, first_right 1).  Outputs as orbx_extract for each eye (n_* keypoints, mono_* =
- * monoIndex); uright / depth (cap_left floats each, -1 = no match) may be NULL and are ignored when bf <= 0.
+ * monoIndex); uright / depth (cap_left floats each, -1 = no match) are ignored when bf <= 0.  Any of the output ARRAYS
+ * (kps_*, desc_*, uright, depth) may be NULL: the results then stay in the handle's page-locked result block, where
+ * orbx_host_results hands them out in place (one copy less per frame for a caller that converts them anyway).
  * Returns ORBX_OK, ORBX_E_EMPTY for an empty image, or another negative error. */
 int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8_t* img_right, int w, int h,
                         ptrdiff_t stride_left, ptrdiff_t stride_right, const int32_t lap_left[2],
                         const int32_t lap_right[2], orbx_keypoint* kps_left, uint8_t* desc_left, int cap_left,
                         int* n_left, int* mono_left, orbx_keypoint* kps_right, uint8_t* desc_right, int cap_right,
                         int* n_right, int* mono_right, float bf, float b, float* uright, float* depth);
+
+/* Results of the last orbx_extract / orbx_extract_stereo call IN PLACE.  Those entries gather everything into one page-locked
+ * block owned by the handle (one kernel, one synchronisation) and then copy into the caller's arrays; this accessor exposes
+ * the block itself: n keypoints (28-byte cv::KeyPoint records, src/ORBextractor.cc:1053-1104 order) and n x 32 descriptor
+ * bytes of image 0 (left eye) or 1 (right eye), monoIndex, and -- image 0 after a call with bf > 0 -- mvuRight / mvDepth
+ * (src/Frame.cc:921-1084), n floats each.  Any output pointer may be NULL.  Valid until the next call on the handle. */
+int orbx_host_results(const orbx_extractor* ex, int image, const orbx_keypoint** kps, const uint8_t** desc, int* n, int* mono,
+                      const float** uright, const float** depth);
 
 /* Batched many-camera mode: n_images device-resident images (image i at d_images + i*image_pitch, rows
  * row_pitch bytes apart; base and pitches 4-byte aligned), all w x h.  d_lap = n_images x 2 int32 lapping

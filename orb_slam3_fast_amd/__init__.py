@@ -85,6 +85,7 @@ def lib():
         L.orbx_batch_download.argtypes = [vp, i, vp, vp, i, C.POINTER(i)]
         L.orbx_pyramid_level.argtypes = [vp, i, i, i, vp, C.c_ssize_t, C.POINTER(i), C.POINTER(i)]
         L.orbx_pyramid_download.argtypes = [vp, i, i, vp, vp]
+        L.orbx_host_results.argtypes = [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(vp), C.POINTER(vp)]
         L.orbx_set_host_pyramid.argtypes = [vp, i]
         L.orbx_host_pyramid_level.argtypes = [vp, i, i, C.POINTER(vp), C.POINTER(i), C.POINTER(i), C.POINTER(C.c_ssize_t)]
         L.orbx_debug_candidates.argtypes = [vp, i, i, vp, i]
@@ -250,28 +251,42 @@ class ORBextractor:
 
     # ---- operator()
     def _host_bufs(self):
-        """Result arrays of the single-frame entries, allocated once per handle (a per-call np.zeros of a structured array and
-        a structured slice copy cost more than the GPU work of a frame: the wrapper's share of a 1280x720 stereo frame was 80 us).
-        Returned results are copies of the valid prefix (byte-wise: numpy copies structured records field by field)."""
+        """Views of the handle's page-locked result block (orbx_host_results): the single-frame entries are called with NULL
+        output arrays and the valid prefix is copied ONCE, byte-wise (numpy copies structured records field by field; with the
+        per-call np.zeros of six arrays the wrapper's share of a 1280x720 stereo frame was 80 us)."""
         b = getattr(self, "_hb", None)
         if b is None:
-            cap = self.capacity
-            b = {}
-            for e in (0, 1):
-                k, d = np.zeros(cap, KP_DTYPE), np.zeros((cap, 32), np.uint8)
-                b[e] = (k, k.view(np.uint8).reshape(cap, 28), d, k.ctypes.data, d.ctypes.data)
-            ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
-            b["st"] = (ur, dp, ur.ctypes.data, dp.ctypes.data)
-            b["n"] = [C.c_int() for _ in range(4)]
+            b = {"n": [C.c_int() for _ in range(4)], "lap": np.zeros(4, np.int32), "views": None}
             b["nref"] = [C.byref(x) for x in b["n"]]
-            b["lap"] = np.zeros(4, np.int32)
             b["lapp"] = (b["lap"].ctypes.data, b["lap"].ctypes.data + 8)
             self._hb = b
         return b
 
+    def _result_views(self, hb, nimg, stereo):
+        """numpy views over the result block (its address is fixed for the life of the handle: a section is mapped the first
+        time a call has filled it)."""
+        v = hb["views"]
+        if v is None:
+            v = hb["views"] = {}
+        cap = self.capacity
+        for img in range(nimg):
+            need_st = stereo and img == 0 and "ur" not in v
+            if img in v and not need_st:
+                continue
+            pk, pd, pu, pz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _check(lib().orbx_host_results(self._h, img, C.byref(pk), C.byref(pd), None, None, C.byref(pu), C.byref(pz)))
+            if img not in v:
+                kb = np.frombuffer((C.c_uint8 * (cap * 28)).from_address(pk.value), np.uint8).reshape(cap, 28)
+                db = np.frombuffer((C.c_uint8 * (cap * 32)).from_address(pd.value), np.uint8).reshape(cap, 32)
+                v[img] = (kb, db)
+            if need_st:
+                v["ur"] = np.frombuffer((C.c_float * cap).from_address(pu.value), np.float32)
+                v["dp"] = np.frombuffer((C.c_float * cap).from_address(pz.value), np.float32)
+        return v
+
     @staticmethod
-    def _take(buf, n):
-        return buf[1][:n].copy().view(KP_DTYPE).reshape(n), buf[2][:n].copy()
+    def _take(view, n):
+        return view[0][:n].copy().view(KP_DTYPE).reshape(n), view[1][:n].copy()
 
     def __call__(self, image, vLappingArea=(0, 0)):
         if image is None or image.size == 0:
@@ -282,8 +297,8 @@ class ORBextractor:
         h, w = image.shape
         b = self._host_bufs()
         mono = _check(lib().orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
-                                         int(vLappingArea[1]), b[0][3], b[0][4], self.capacity, b["nref"][0]))
-        return (mono,) + self._take(b[0], b["n"][0].value)
+                                         int(vLappingArea[1]), None, None, self.capacity, b["nref"][0]))
+        return (mono,) + self._take(self._result_views(b, 1, False)[0], b["n"][0].value)
 
     # ---- batched many-camera mode
     def extract_stereo(self, left, right, lap_left=(0, 0), lap_right=(0, 0), bf=0.0, b=0.0):
@@ -302,13 +317,13 @@ class ORBextractor:
         lap[0], lap[1], lap[2], lap[3] = lap_left[0], lap_left[1], lap_right[0], lap_right[1]
         nl, nr, ml, mr = hb["n"]
         rl, rr, rml, rmr = hb["nref"]
-        st = hb["st"]
         cap = self.capacity
         _check(lib().orbx_extract_stereo(self._h, L.ctypes.data, R.ctypes.data, w, h, L.strides[0], R.strides[0], hb["lapp"][0],
-                                         hb["lapp"][1], hb[0][3], hb[0][4], cap, rl, rml, hb[1][3], hb[1][4], cap, rr, rmr,
-                                         float(bf), float(b), st[2], st[3]))
-        out = ((ml.value,) + self._take(hb[0], nl.value), (mr.value,) + self._take(hb[1], nr.value))
-        return out + ((st[0][:nl.value].copy(), st[1][:nl.value].copy()),) if bf > 0 else out
+                                         hb["lapp"][1], None, None, cap, rl, rml, None, None, cap, rr, rmr,
+                                         float(bf), float(b), None, None))
+        v = self._result_views(hb, 2, bf > 0)
+        out = ((ml.value,) + self._take(v[0], nl.value), (mr.value,) + self._take(v[1], nr.value))
+        return out + ((v["ur"][:nl.value].copy(), v["dp"][:nl.value].copy()),) if bf > 0 else out
 
     def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
         """Enqueue extraction of device-resident images (raw device pointer).  Asynchronous."""

@@ -137,30 +137,19 @@ class ORBextractor {
     const int w = _image.cols, h = _image.rows;
     const ptrdiff_t step = (ptrdiff_t)_image.step;
 #endif
-    const int cap = nfeatures + 40 * nlevels;
-    kp_.resize(cap);
-    desc_.resize((size_t)cap * 32);
     int n = 0;
     const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0;
     const int lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
     ApplyHostPyramidMode();
-    const int mono = orbx_extract(h_, data, w, h, step, lap0, lap1, kp_.data(), desc_.data(), cap, &n);
+    // (NULL output arrays: the results stay in the handle's page-locked block and are copied ONCE, into the caller's containers)
+    const int mono = orbx_extract(h_, data, w, h, step, lap0, lap1, nullptr, nullptr, 0, &n);
     if (mono == ORBX_E_EMPTY) return -1;
     if (mono < 0) throw std::runtime_error(std::string("ORBextractor::operator(): ") + orbx_last_error());
-    _keypoints.resize(n);
-    if (n) std::memcpy(static_cast<void*>(_keypoints.data()), kp_.data(), (size_t)n * sizeof(orbx_keypoint));
-    if (n == 0) {
-      _descriptors.release();
-    } else {
-#ifdef ORBX_HAVE_OPENCV
-      _descriptors.create(n, 32, CV_8U);
-      cv::Mat d = _descriptors.getMat();
-      for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc_[(size_t)i * 32], 32);
-#else
-      _descriptors.create(n, 32);
-      std::memcpy(_descriptors.data, desc_.data(), (size_t)n * 32);
-#endif
-    }
+    const orbx_keypoint* rk = nullptr;
+    const uint8_t* rd = nullptr;
+    if (orbx_host_results(h_, 0, &rk, &rd, nullptr, nullptr, nullptr, nullptr) != ORBX_OK)
+      throw std::runtime_error(std::string("ORBextractor::operator(): ") + orbx_last_error());
+    FillOutputs(_keypoints, _descriptors, rk, rd, n);
     if (mbKeepHostPyramid) ViewImagePyramid(0);
     return mono;
   }
@@ -186,42 +175,25 @@ class ORBextractor {
     const ptrdiff_t sl = (ptrdiff_t)imLeft.step, sr = (ptrdiff_t)imRight.step;
     if (imRight.cols != w || imRight.rows != h) throw std::invalid_argument("ExtractStereo: image sizes differ");
 #endif
-    const int cap = nfeatures + 40 * nlevels;
-    std::vector<orbx_keypoint>&kl = kp_, &kr = kpR_;   // (member scratch: no per-frame allocations)
-    std::vector<uint8_t>&dl = desc_, &dr = descR_;
-    std::vector<float>&ur = ur_, &dp = dp_;
-    kl.resize(cap); kr.resize(cap);
-    dl.resize((size_t)cap * 32); dr.resize((size_t)cap * 32);
-    ur.resize(cap); dp.resize(cap);
-    ApplyHostPyramidMode();
     const int32_t ll[2] = {lapLeft.size() > 0 ? lapLeft[0] : 0, lapLeft.size() > 1 ? lapLeft[1] : 0};
     const int32_t lr[2] = {lapRight.size() > 0 ? lapRight[0] : 0, lapRight.size() > 1 ? lapRight[1] : 0};
     int nl = 0, nr = 0;
     const bool stereo = mbf > 0.f && mvuRight && mvDepth;
-    if (orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, kl.data(), dl.data(), cap, &nl, &monoLeft, kr.data(), dr.data(),
-                            cap, &nr, &monoRight, stereo ? mbf : 0.f, mb, ur.data(), dp.data()) != ORBX_OK)
+    ApplyHostPyramidMode();
+    if (orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, nullptr, nullptr, 0, &nl, &monoLeft, nullptr, nullptr, 0, &nr,
+                            &monoRight, stereo ? mbf : 0.f, mb, nullptr, nullptr) != ORBX_OK)
       throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
-    auto fill = [](std::vector<ocv::KeyPoint>& keys, ocv::OutputArray desc, const orbx_keypoint* k, const uint8_t* d, int n) {
-      keys.resize(n);
-      if (n) std::memcpy(static_cast<void*>(keys.data()), k, (size_t)n * sizeof(orbx_keypoint));
-      if (n == 0) {
-        desc.release();
-        return;
-      }
-#ifdef ORBX_HAVE_OPENCV
-      desc.create(n, 32, CV_8U);
-      cv::Mat m = desc.getMat();
-      for (int i = 0; i < n; i++) std::memcpy(m.ptr(i), d + (size_t)i * 32, 32);
-#else
-      desc.create(n, 32);
-      std::memcpy(desc.data, d, (size_t)n * 32);
-#endif
-    };
-    fill(keysLeft, descLeft, kl.data(), dl.data(), nl);
-    fill(keysRight, descRight, kr.data(), dr.data(), nr);
+    const orbx_keypoint *kl = nullptr, *kr = nullptr;
+    const uint8_t *dl = nullptr, *dr = nullptr;
+    const float *ur = nullptr, *dp = nullptr;
+    if (orbx_host_results(h_, 0, &kl, &dl, nullptr, nullptr, &ur, &dp) != ORBX_OK ||
+        orbx_host_results(h_, 1, &kr, &dr, nullptr, nullptr, nullptr, nullptr) != ORBX_OK)
+      throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
+    FillOutputs(keysLeft, descLeft, kl, dl, nl);
+    FillOutputs(keysRight, descRight, kr, dr, nr);
     if (stereo) {
-      mvuRight->assign(ur.begin(), ur.begin() + nl);
-      mvDepth->assign(dp.begin(), dp.begin() + nl);
+      mvuRight->assign(ur, ur + nl);
+      mvDepth->assign(dp, dp + nl);
     }
     if (mbKeepHostPyramid) {
       ViewImagePyramid(0);
@@ -311,6 +283,22 @@ class ORBextractor {
   std::vector<float> mvInvLevelSigma2;
 
  private:
+  static void FillOutputs(std::vector<ocv::KeyPoint>& keys, ocv::OutputArray desc, const orbx_keypoint* k, const uint8_t* d, int n) {
+    keys.resize(n);
+    if (n) std::memcpy(static_cast<void*>(keys.data()), k, (size_t)n * sizeof(orbx_keypoint));
+    if (n == 0) {
+      desc.release();
+      return;
+    }
+#ifdef ORBX_HAVE_OPENCV
+    desc.create(n, 32, CV_8U);
+    cv::Mat m = desc.getMat();
+    for (int i = 0; i < n; i++) std::memcpy(m.ptr(i), d + (size_t)i * 32, 32);
+#else
+    desc.create(n, 32);
+    std::memcpy(desc.data, d, (size_t)n * 32);
+#endif
+  }
   void ApplyHostPyramidMode() {  // (mbKeepHostPyramid is a public flag: follow it lazily)
     if ((int)mbKeepHostPyramid != keepSet_) {
       orbx_set_host_pyramid(h_, mbKeepHostPyramid ? 1 : 0);
@@ -319,9 +307,6 @@ class ORBextractor {
   }
   orbx_extractor* h_ = nullptr;
   int keepSet_ = -1;
-  std::vector<orbx_keypoint> kp_, kpR_;
-  std::vector<uint8_t> desc_, descR_;
-  std::vector<float> ur_, dp_;
 };
 
 }  // namespace ORB_SLAM3

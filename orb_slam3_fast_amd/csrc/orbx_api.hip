@@ -864,7 +864,10 @@ int orbx_batch_download(orbx_extractor* ex, int image, orbx_keypoint* kps, uint8
 // The single-frame host entries fetch their results with ONE kernel that writes the handle's pinned host block over PCIe
 // (hipHostMalloc memory is device-visible and host-coherent): a single-frame trace showed the six D2H copies of the results
 // taking 57 us of a 270 us frame, against ~10 us for the gather.
-static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo) {
+static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut);
+// fuseFilter != nullptr: the stereo association's median cut (pair 0) runs inside the gather launch (k_stereo_filter_pack)
+static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo, const StereoArgs* fuseFilter = nullptr) {
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* hd = nullptr;
   hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), ex->hostResults, 0);
@@ -878,6 +881,7 @@ static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo)
   a.hUr = reinterpret_cast<uint32_t*>(hd + hr_ur(oc)); a.hDepth = reinterpret_cast<uint32_t*>(hd + hr_depth(oc));
   a.nimg = nimg; a.cap = (int)oc; a.stereo = stereo ? 1 : 0;
   a.mask = 0x7F; a.fixedN = -1;
+  if (fuseFilter && stereo && nimg == 2) return launch_stereo_filter_pack(*fuseFilter, a, ex->stream);
   return launch_result_pack(a, ex->stream);
 }
 
@@ -997,7 +1001,9 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
   const int n = *reinterpret_cast<const int*>(H), mono = *reinterpret_cast<const int*>(H + 8);
   *n_out = n;
-  if (n > cap) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
+  ex->hostResImages = 1;
+  ex->hostResStereo = false;
+  if ((kps || desc) && n > cap) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
   if (n > 0 && kps) std::memcpy(kps, H + hr_kps(oc), (size_t)n * sizeof(orbx_keypoint));
   if (n > 0 && desc) std::memcpy(desc, H + hr_desc(oc), (size_t)n * 32);
   return mono;
@@ -1032,15 +1038,17 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
   rc = enqueue_frame(ex, 2, lapTrivial, lap);
   if (rc != ORBX_OK) return rc;
-  const bool stereo = bf > 0.f && uright && depth;
+  const bool stereo = bf > 0.f;   // (uright / depth NULL: the results stay in the host block, orbx_host_results)
+  StereoArgs sargs;
+  const bool fuse = stereo && !ex->profiling;  // (the stage table keeps the filter as its own launch)
   if (stereo) {
-    rc = orbx_stereo_match_batch(ex, 0, ex, 1, 1, bf, b);
+    rc = enqueue_stereo_match(ex, 0, ex, 1, 1, bf, b, !fuse, &sargs);
     if (rc != ORBX_OK) return rc;
   }
   // all results travel with asynchronous copies into pinned memory behind the kernels: one synchronisation in total
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* H = ex->hostResults;
-  HIPC(enqueue_result_pack(ex, 2, stereo));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
+  HIPC(enqueue_result_pack(ex, 2, stereo, fuse ? &sargs : nullptr));   // one gather kernel writes the pinned block (count-trimmed)
   if (ex->keepHostPyr) {
     rc = enqueue_host_pyramid(ex, 2, ex->evPyr);
     if (rc != ORBX_OK) return rc;
@@ -1051,15 +1059,35 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   const int* mono = reinterpret_cast<const int*>(H + 8);
   *n_left = cnt[0]; *n_right = cnt[1];
   *mono_left = mono[0]; *mono_right = mono[1];
-  if (cnt[0] > cap_left || cnt[1] > cap_right) return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
+  ex->hostResImages = 2;
+  ex->hostResStereo = stereo;
+  if (((kps_left || desc_left || uright || depth) && cnt[0] > cap_left) || ((kps_right || desc_right) && cnt[1] > cap_right))
+    return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
   if (cnt[0] > 0 && kps_left) std::memcpy(kps_left, H + hr_kps(oc), (size_t)cnt[0] * sizeof(orbx_keypoint));
   if (cnt[0] > 0 && desc_left) std::memcpy(desc_left, H + hr_desc(oc), (size_t)cnt[0] * 32);
   if (cnt[1] > 0 && kps_right) std::memcpy(kps_right, H + hr_kps(oc) + oc * sizeof(orbx_keypoint), (size_t)cnt[1] * sizeof(orbx_keypoint));
   if (cnt[1] > 0 && desc_right) std::memcpy(desc_right, H + hr_desc(oc) + oc * 32, (size_t)cnt[1] * 32);
   if (stereo && cnt[0] > 0) {
-    std::memcpy(uright, H + hr_ur(oc), (size_t)cnt[0] * sizeof(float));
-    std::memcpy(depth, H + hr_depth(oc), (size_t)cnt[0] * sizeof(float));
+    if (uright) std::memcpy(uright, H + hr_ur(oc), (size_t)cnt[0] * sizeof(float));
+    if (depth) std::memcpy(depth, H + hr_depth(oc), (size_t)cnt[0] * sizeof(float));
   }
+  return ORBX_OK;
+}
+
+int orbx_host_results(const orbx_extractor* ex, int image, const orbx_keypoint** kps, const uint8_t** desc, int* n, int* mono,
+                      const float** uright, const float** depth) {
+  if (!ex) return fail(ORBX_E_BADARG, "null handle");
+  if (image < 0 || image >= ex->hostResImages)
+    return fail(ORBX_E_BADARG, "no such image in the result block of the last orbx_extract / orbx_extract_stereo call");
+  const size_t oc = (size_t)ex->gmax.outCap;
+  const uint8_t* H = ex->hostResults;
+  if (n) *n = reinterpret_cast<const int*>(H)[image];
+  if (mono) *mono = reinterpret_cast<const int*>(H + 8)[image];
+  if (kps) *kps = reinterpret_cast<const orbx_keypoint*>(H + hr_kps(oc)) + (size_t)image * oc;
+  if (desc) *desc = H + hr_desc(oc) + (size_t)image * oc * 32;
+  const bool st = image == 0 && ex->hostResStereo;
+  if (uright) *uright = st ? reinterpret_cast<const float*>(H + hr_ur(oc)) : nullptr;
+  if (depth) *depth = st ? reinterpret_cast<const float*>(H + hr_depth(oc)) : nullptr;
   return ORBX_OK;
 }
 
@@ -1181,8 +1209,10 @@ int orbx_hamming256(const void* a, const void* b) {
   return d;
 }
 
-int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
-                            int n_pairs, float bf, float b) {
+// withFilter = false: the caller runs the median cut itself (orbx_extract_stereo: fused with the result gather); *argsOut
+// receives the kernels' argument block
+static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut) {
   if (!left || !right) return fail(ORBX_E_BADARG, "null handle");
   if (n_pairs <= 0 || first_left < 0 || first_right < 0 || first_left + n_pairs > left->lastN ||
       first_right + n_pairs > right->lastN)
@@ -1239,11 +1269,17 @@ int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
     HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));
   }
-  {
+  if (withFilter) {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_FILTER);
     HIPC(launch_stereo_filter(a, n_pairs, left->stream));
   }
+  if (argsOut) *argsOut = a;
   return ORBX_OK;
+}
+
+int orbx_stereo_match_batch(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
+                            int n_pairs, float bf, float b) {
+  return enqueue_stereo_match(left, first_left, right, first_right, n_pairs, bf, b, true, nullptr);
 }
 
 int orbx_stereo_results_device(const orbx_extractor* left, const float** d_uright, const float** d_depth) {

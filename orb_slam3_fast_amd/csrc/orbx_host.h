@@ -259,6 +259,8 @@ struct orbx_extractor {
   int stereoPairs = 0;             // high-water allocation of d_uR / d_depth / d_sad (pairs)
   int lastStereoPairs = 0;         // pairs of the stereo association run since the last extraction (0: none)
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
+  int hostResImages = 0;           // images of the last single-frame host entry in that block (orbx_host_results)
+  bool hostResStereo = false;      // ... and whether uRight / depth of image 0 are there
   uint8_t* hostPyr = nullptr;      // pinned staging of orbx_pyramid_download (one image's pyramid), allocated on first use
   size_t hostPyrBytes = 0;
   // single-frame host entries (orbx_extract / orbx_extract_stereo): with orbx_set_host_pyramid the levels are copied to

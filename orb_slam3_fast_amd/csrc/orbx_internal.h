@@ -222,6 +222,7 @@ struct ResultPack {
   int fixedN;    // >= 0: copy this many uRight / depth entries instead of nOut[0] (orbx_stereo_download: the caller's capacity)
 };
 hipError_t launch_result_pack(const ResultPack& a, hipStream_t s);
+hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s);   // (orbx_stereo.hip)
 
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106), single-camera key frames (k_tri_*)
 struct TriArgs {

@@ -494,6 +494,52 @@ hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) 
   return hipGetLastError();
 }
 
+// Single stereo frame through the host API (orbx_extract_stereo): the median cut of pair 0 and the gather of every result into
+// the handle's page-locked host block (k_result_pack, orbx_kernels.hip) in ONE launch -- the two were 4.6 + 5.9 us of dependent
+// launches at the end of a 0.2 ms frame.  Sections as in k_result_pack (blockIdx.y: 0 / 1 keypoints, 2 / 3 descriptors of the
+// two eyes, 6 counts) run beside block (0, 4), which filters and then copies uRight and depth itself.
+__global__ __launch_bounds__(256) void k_stereo_filter_pack(StereoArgs sa, ResultPack a) {
+  __shared__ int fhist[256], fw[8], fv[2];
+  const int sec = blockIdx.y;
+  if (sec == 6) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) {
+      const int t = threadIdx.x;
+      a.hCnt[t] = t < a.nimg ? (uint32_t)a.nOut[t] : 0u;
+      a.hCnt[2 + t] = t < a.nimg ? (uint32_t)a.mono[t] : 0u;
+    }
+    return;
+  }
+  if (sec == 5) return;
+  if (sec == 4) {
+    if (blockIdx.x != 0) return;
+    stereo_filter_pair(sa, 0, threadIdx.x, fhist, fw, fv);
+    __threadfence_block();
+    __syncthreads();  // the cut entries (written by other threads of this block) are visible to the copy below
+    const int n = min(a.nOut[0], a.cap);
+    for (int i = threadIdx.x; i < n; i += 256) {
+      a.hUr[i] = a.uR[i];
+      a.hDepth[i] = a.depth[i];
+    }
+    return;
+  }
+  const int img = sec & 1;
+  if (img >= a.nimg) return;
+  const int n = min(a.nOut[img], a.cap);
+  const uint32_t* src;
+  uint32_t* dst;
+  int len;
+  if (sec < 2) {
+    src = a.kps + (size_t)img * a.cap * 7; dst = a.hKps + (size_t)img * a.cap * 7; len = n * 7;
+  } else {
+    src = a.desc + (size_t)img * a.cap * 8; dst = a.hDesc + (size_t)img * a.cap * 8; len = n * 8;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_stereo_filter_pack, dim3(12, 7), dim3(256), 0, s, sa, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
                                hipStream_t s) {
   // band rows / threads / right-trip / left-trip sizes measured at 1280x720, 32 pairs (kernel alone): 8/256/256/64 22.9 us,

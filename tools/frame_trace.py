@@ -41,7 +41,7 @@ def main(db, back=3):
         if rg and st:
             api = c.execute(f"select s.string, r.start, r.end from {rg[0]} r join {st[0]} s on r.name_id = s.id order by r.start").fetchall()
     # frames are delimited by the result-pack kernel (last kernel of a frame)
-    packs = [k for k in kern if "k_result_pack" in k[0]]
+    packs = [k for k in kern if "k_result_pack" in k[0] or "k_stereo_filter_pack" in k[0]]
     if len(packs) < back + 1:
         print("not enough frames in the trace")
         return

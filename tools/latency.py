@@ -53,14 +53,34 @@ for _ in range(reps):
     exL(L)
 seq = (time.perf_counter() - t0) / reps * 1e3
 exP = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
-for _ in range(5):
-    exP.extract_stereo(L, R, bf=bf, b=b)
-t0 = time.perf_counter()
-for _ in range(reps):
-    exP.extract_stereo(L, R, bf=bf, b=b)
-pair = (time.perf_counter() - t0) / reps * 1e3
-print("%dx%d N=%d  orbx_extract_stereo (both eyes + ComputeStereoMatches, one batched pipeline, one thread): %.3f ms (%.0f fps)"
-      % (w, h, nf, pair, 1e3 / pair))
+frames = [synth.stereo_pair(w, h, 5 + i) for i in range(8)]
+for i in range(20):
+    exP.extract_stereo(*frames[i % 8], bf=bf, b=b)
+ts = []
+for i in range(4 * reps):
+    Li, Ri = frames[i % 8]
+    t0 = time.perf_counter()
+    exP.extract_stereo(Li, Ri, bf=bf, b=b)
+    ts.append((time.perf_counter() - t0) * 1e3)
+ts = np.array(ts)
+pair = ts.mean()
+print("%dx%d N=%d  orbx_extract_stereo (both eyes + ComputeStereoMatches, one batched pipeline, one thread): %.3f ms (%.0f fps)  "
+      "[p10 %.3f p50 %.3f p90 %.3f over %d frames]" % (w, h, nf, pair, 1e3 / pair, np.percentile(ts, 10), np.percentile(ts, 50),
+                                                        np.percentile(ts, 90), len(ts)))
+exP.set_host_pyramid(True)
+for i in range(10):
+    exP.extract_stereo(*frames[i % 8], bf=bf, b=b)
+ts = []
+for i in range(2 * reps):
+    Li, Ri = frames[i % 8]
+    t0 = time.perf_counter()
+    exP.extract_stereo(Li, Ri, bf=bf, b=b)
+    pl, pr = exP.host_pyramid(0), exP.host_pyramid(1)
+    ts.append((time.perf_counter() - t0) * 1e3)
+exP.set_host_pyramid(False)
+ts = np.array(ts)
+print("%dx%d N=%d  the same with the host copy of both pyramids kept current (orbx_set_host_pyramid, the C++ mirror's default): "
+      "%.3f ms  [p10 %.3f p50 %.3f p90 %.3f]" % (w, h, nf, ts.mean(), np.percentile(ts, 10), np.percentile(ts, 50), np.percentile(ts, 90)))
 from orb_slam3_fast_amd.hipmem import pinned_like
 Lp, Rp = pinned_like(L), pinned_like(R)
 for _ in range(5):
