@@ -795,6 +795,7 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, int n_images, 
   if (n_images > ex->maxB) return fail(ORBX_E_CAPACITY, "batch larger than max_batch");
   if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
   if (row_pitch < w || image_pitch < row_pitch * (ptrdiff_t)(h - 1) + w) return fail(ORBX_E_BADARG, "pitch too small");
+  const auto tq0 = std::chrono::steady_clock::now();
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   const int pitch = align_up(w, 64);
@@ -910,7 +911,8 @@ static int enqueue_frame(orbx_extractor* ex, int n, bool lapTrivial, const int32
 
 // Copies of every level of images [0, nimg) of the current extraction into hostPyrAll, on streamPyr behind `after` (an event
 // recorded once the pyramids are complete): the copies run on the DMA engines beside k_detect .. k_describe.
-static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after) {
+static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after, const uint8_t* const* hostImg,
+                                const ptrdiff_t* hostStride) {
   if (!ex->streamPyr) HIPC(hipStreamCreateWithFlags(&ex->streamPyr, hipStreamNonBlocking));
   const size_t per = host_pyr_image_bytes(ex);
   if (ex->hostPyrAllBytes < 2 * per) {
@@ -921,23 +923,44 @@ static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after) 
     ex->hostPyrAllBytes = 2 * per;
   }
   const Geom& g = ex->g;
-  const size_t l0Off = 0, restDst = ((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255;
+  const size_t restDst = ((size_t)ex->stagePitch * ex->maxH + 255) & ~(size_t)255;
   const LevelDev& LL = g.lv[g.nlevels - 1];
   const size_t restOff = g.nlevels > 1 ? (size_t)g.lv[1].off : 0;
   const size_t restBytes = g.nlevels > 1 ? (size_t)LL.off + (size_t)LL.pitch * LL.h - restOff : 0;
-  HIPC(hipStreamWaitEvent(ex->streamPyr, after, 0));
+  const int p0 = (int)ex->pyr.l0Row;
+  if ((size_t)p0 * g.lv[0].h > restDst) return fail(ORBX_E_CAPACITY, "level-0 pitch larger than the handle's staging pitch");
+  // level 0 IS the caller's image: the host thread copies it itself while the GPU works (it would only wait otherwise) -- a
+  // third of the bytes never cross the link a second time
   for (int i = 0; i < nimg; i++) {
-    int p0 = 0;
-    const uint8_t* l0 = level_ptr(g, ex->pyr, i, 0, p0);
-    const size_t l0Bytes = (size_t)p0 * (g.lv[0].h - 1) + g.lv[0].w;
-    if (l0Bytes > restDst) return fail(ORBX_E_CAPACITY, "level-0 pitch larger than the handle's staging pitch");
     uint8_t* H = ex->hostPyrAll + (size_t)i * per;
-    HIPC(hipMemcpyAsync(H + l0Off, l0, l0Bytes, hipMemcpyDeviceToHost, ex->streamPyr));
-    if (restBytes)
-      HIPC(hipMemcpyAsync(H + restDst, ex->pyr.pyr + (long long)i * g.pyrImg + restOff, restBytes, hipMemcpyDeviceToHost, ex->streamPyr));
+    const uint8_t* src = hostImg[i];
+    const size_t w = (size_t)g.lv[0].w;
+    if ((size_t)hostStride[i] == (size_t)p0 && (size_t)p0 == w) {
+      std::memcpy(H, src, w * g.lv[0].h);
+    } else {
+      for (int y = 0; y < g.lv[0].h; y++) std::memcpy(H + (size_t)y * p0, src + (size_t)y * hostStride[i], w);
+    }
   }
+  // levels 1.. : one DMA copy per image of its block of the device pyramid (4 MB per 1280x720 stereo frame: the ~100 us
+  // between the pyramid and the frame's last kernel are just enough for them on a PCIe 5 x16 link).  The HOST waits for the
+  // pyramid event (polling: it has nothing else to do until the frame's synchronisation) and then issues the copies --
+  // a hipStreamWaitEvent on the copy stream was resolved ~90 us late by this runtime (the copies started when the frame's
+  // kernels were over: +82 us per frame, profiles/r5b_host_pyramid.txt).
+  static const bool streamWait = getenv("ORBX_PYR_STREAM_WAIT") != nullptr;  // (the measured alternative)
+  if (streamWait) {
+    HIPC(hipStreamWaitEvent(ex->streamPyr, after, 0));
+  } else {
+    hipError_t q;
+    while ((q = hipEventQuery(after)) == hipErrorNotReady) {
+    }
+    if (q != hipSuccess) return fail(ORBX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
+  for (int i = 0; i < nimg; i++)
+    if (restBytes)
+      HIPC(hipMemcpyAsync(ex->hostPyrAll + (size_t)i * per + restDst, ex->pyr.pyr + (long long)i * g.pyrImg + restOff, restBytes,
+                          hipMemcpyDeviceToHost, ex->streamPyr));
   ex->hostPyrImages = nimg;
-  ex->hostPyrL0Pitch = (int)ex->pyr.l0Row;
+  ex->hostPyrL0Pitch = p0;
   return ORBX_OK;
 }
 
@@ -994,7 +1017,9 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
   uint8_t* H = ex->hostResults;
   HIPC(enqueue_result_pack(ex, 1, false));   // one gather kernel writes the pinned block (count-trimmed), no D2H copies
   if (ex->keepHostPyr) {
-    rc = enqueue_host_pyramid(ex, 1, ex->evPyr);
+    const ptrdiff_t hs[1] = {stride};
+    const uint8_t* const hi[1] = {img};
+    rc = enqueue_host_pyramid(ex, 1, ex->evPyr, hi, hs);
     if (rc != ORBX_OK) return rc;
   }
   HIPC(hipStreamSynchronize(st));
@@ -1021,6 +1046,7 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   if (ex->maxB < 2) return fail(ORBX_E_CAPACITY, "orbx_extract_stereo needs a handle created with max_batch >= 2");
   if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's maximum");
   if (stride_left < w || stride_right < w) return fail(ORBX_E_BADARG, "stride < width");
+  const auto tq0 = std::chrono::steady_clock::now();
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   const int pitch = align_up(w, 64);
@@ -1049,12 +1075,26 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* H = ex->hostResults;
   HIPC(enqueue_result_pack(ex, 2, stereo, fuse ? &sargs : nullptr));   // one gather kernel writes the pinned block (count-trimmed)
+  const auto tqp = std::chrono::steady_clock::now();
   if (ex->keepHostPyr) {
-    rc = enqueue_host_pyramid(ex, 2, ex->evPyr);
+    const ptrdiff_t hs[2] = {stride_left, stride_right};
+    const uint8_t* const hi[2] = {img_left, img_right};
+    rc = enqueue_host_pyramid(ex, 2, ex->evPyr, hi, hs);
     if (rc != ORBX_OK) return rc;
   }
+  static const bool latTimes = getenv("ORBX_LAT_TIMES") != nullptr;   // measurement aid: host-side phases of the call
+  const auto tq1 = std::chrono::steady_clock::now();
   HIPC(hipStreamSynchronize(st));
+  const auto tq2 = std::chrono::steady_clock::now();
   if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
+  if (latTimes) {
+    const auto tq3 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    std::fprintf(stderr, "orbx_extract_stereo: enqueue %.1f us (of which host pyramid %.1f), sync %.1f, pyramid sync %.1f\n",
+                 us(tq0, tq1), us(tqp, tq1), us(tq1, tq2), us(tq2, tq3));
+  }
   const int* cnt = reinterpret_cast<const int*>(H);
   const int* mono = reinterpret_cast<const int*>(H + 8);
   *n_left = cnt[0]; *n_right = cnt[1];
