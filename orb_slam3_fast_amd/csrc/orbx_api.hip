@@ -331,6 +331,7 @@ void build_tail_plans(const Geom& g, const std::vector<int>& yofs, std::vector<T
 // deep cascade recomputes (a band of 2 rows of level 7 needs ~38 rows of level 0) cost nothing that matters.  Segments are
 // as long as the LDS admits (kLatLdsMax); ORBX_LAT_TAIL=levels,rows overrides (levels = 0 switches the plans off).
 constexpr int kLatLdsMax = 156 * 1024, kLatMaxImages = 2;
+static int g_lat_max_images = kLatMaxImages;   // ORBX_LAT_MAX_IMAGES (measurement aid)
 static int g_lat_levels = 4, g_lat_rows = 2;  // 1280x720: levels 1-4 + 5-7, 14.3 + 7.6 us (one launch for 1-7: 24; 2 + 2 + 2 + 1: 27)
 void build_latency_plans(const Geom& g, const std::vector<int>& yofs, std::vector<TailPlan>& plans, std::vector<TailBand>& bands) {
   plans.clear();
@@ -343,6 +344,7 @@ void build_latency_plans(const Geom& g, const std::vector<int>& yofs, std::vecto
         if (b > 0) g_lat_rows = b;
       }
     }
+    if (const char* e = getenv("ORBX_LAT_MAX_IMAGES")) g_lat_max_images = atoi(e);
     return true;
   }();
   (void)envRead;
@@ -460,7 +462,7 @@ static void drop_graphs(orbx_extractor* ex) {
 // is padded; a caller's buffer is only trusted when the width is a multiple of 16).
 static bool latency_plan_ok(const orbx_extractor* ex, const uint8_t* d_images, int n, int w, ptrdiff_t row_pitch,
                             ptrdiff_t image_pitch) {
-  if (ex->latTails.empty() || n > kLatMaxImages) return false;
+  if (ex->latTails.empty() || n > g_lat_max_images) return false;
   if (((uintptr_t)d_images & 15) || (row_pitch & 15) || (image_pitch & 15)) return false;
   return (w & 15) == 0 || d_images == ex->d_stage.p;
 }
