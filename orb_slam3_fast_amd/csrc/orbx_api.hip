@@ -797,7 +797,6 @@ int orbx_extract_batch(orbx_extractor* ex, const uint8_t* images, int n_images, 
   if (n_images > ex->maxB) return fail(ORBX_E_CAPACITY, "batch larger than max_batch");
   if (w > ex->maxW || h > ex->maxH) return fail(ORBX_E_CAPACITY, "image larger than the handle's max_width x max_height");
   if (row_pitch < w || image_pitch < row_pitch * (ptrdiff_t)(h - 1) + w) return fail(ORBX_E_BADARG, "pitch too small");
-  const auto tq0 = std::chrono::steady_clock::now();
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   const int pitch = align_up(w, 64);

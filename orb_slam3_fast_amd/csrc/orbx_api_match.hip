@@ -516,7 +516,10 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
   std::vector<ProjArgs> frames(F);
   std::vector<uint8_t> occ0;
   if (!occupied_in) occ0.assign((size_t)F * cap, 0);
-  const size_t oPts = pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr, (size_t)F * std::max(stride, 1) * ptBytes);
+  // (the header only promises points[f * stride .. f * stride + n_points[f]) of every frame: the last frame's padding is not read)
+  const size_t ptsRead = ((size_t)(F - 1) * std::max(stride, 1) + (size_t)std::max(n_points[F - 1], 0)) * ptBytes;
+  const size_t oPts = pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr, (size_t)F * std::max(stride, 1) * ptBytes,
+                             ptsRead);
   const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
   const size_t oFr = pk.add(frames.data(), (size_t)F * sizeof(ProjArgs));
   const size_t oOcc = pk.add(occupied_in ? occupied_in : occ0.data(), (size_t)F * cap);

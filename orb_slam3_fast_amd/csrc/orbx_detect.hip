@@ -80,6 +80,55 @@ __device__ __forceinline__ void compass_pair(const uint32_t (&r)[7][3], orbx_h2 
   m1 = __ballot(M.y > th2.y);
 }
 
+// EXPERIMENT (round 5, -DORBX_EVEN_FILTER=1; measured and rejected): a second necessary test on the dense survivor
+// list, in front of the 16-pixel contrast pass.  A 9-arc covers at least four CONSECUTIVE even ring positions (0, 2, .., 14), so
+// a corner has four cyclically consecutive even-ring pixels all > c + t or all < c - t: with e[q] = ring pixel 2q,
+// hi = max_q min(e[q], e[q+1], e[q+2], e[q+3]), lo = min_q max(...), the pixel can only be a corner if max(hi - c, c - lo) > t.
+// Two survivors per lane in packed f16 like the contrast pass: 9 byte reads + 9 v_perm per pair, 8 + 8 + 3 packed operations per
+// polarity, 3 + 2 to decide.
+#ifndef ORBX_EVEN_FILTER
+#define ORBX_EVEN_FILTER 0
+#endif
+__device__ __forceinline__ orbx_h2 even_ring_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
+  orbx_h2 e[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int off = (kRingDY[2 * q] + 3) * TP + kRingDX[2 * q] + 3;
+    orbx_us2 v;
+    v.x = a8[off];
+    v.y = b8[off];
+    e[q] = __builtin_bit_cast(orbx_h2, v);
+  }
+  orbx_h2 hi, lo;
+  {
+    orbx_h2 p2[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) p2[q] = __builtin_elementwise_minimum(e[q], e[(q + 1) & 7]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) w[q] = __builtin_elementwise_minimum(p2[q], p2[(q + 2) & 7]);
+    hi = pk_max3(w[0], w[1], w[2]);
+    hi = pk_max3(hi, w[3], w[4]);
+    hi = pk_max3(hi, w[5], w[6]);
+    hi = __builtin_elementwise_maximum(hi, w[7]);
+  }
+  {
+    orbx_h2 p2[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) p2[q] = __builtin_elementwise_maximum(e[q], e[(q + 1) & 7]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) w[q] = __builtin_elementwise_maximum(p2[q], p2[(q + 2) & 7]);
+    lo = pk_min3(w[0], w[1], w[2]);
+    lo = pk_min3(lo, w[3], w[4]);
+    lo = pk_min3(lo, w[5], w[6]);
+    lo = __builtin_elementwise_minimum(lo, w[7]);
+  }
+  orbx_us2 cv;
+  cv.x = a8[3 * TP + 3];
+  cv.y = b8[3 * TP + 3];
+  const orbx_h2 c = __builtin_bit_cast(orbx_h2, cv);
+  return __builtin_elementwise_maximum(hi - c, c - lo);
+}
+
 // a8 / b8 point at the TOP-LEFT corner of each pixel's 7x7 window, so every ring offset is a non-negative ds_read immediate.
 typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
@@ -325,7 +374,27 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     auto flush_survivors = [&]() {
       __syncthreads();
       const orbx_h2 th2 = __builtin_bit_cast(orbx_h2, (uint32_t)t * 0x00010001u);  // t in the same subnormal encoding
-      const int s0 = nList, nSurv = sEnd - s0;
+      const int s0 = nList;
+      int nSurv = sEnd - s0;
+#if ORBX_EVEN_FILTER
+      {  // compaction of the survivor list in place by the even-ring test (entry k is read before entry k' <= k is written:
+         // one wave, LDS operations complete in order)
+        int wpos = 0;
+        for (int base = 0; base < nSurv; base += 128) {
+          const int rem = nSurv - base;
+          const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
+          const int oA = list[s0 + min(base + lane, nSurv - 1)], oB = list[s0 + min(base + 64 + lane, nSurv - 1)];
+          const orbx_h2 M = even_ring_contrast2_lds(tile8 + oA, tile8 + oB, TP);
+          const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
+          if (__builtin_amdgcn_inverse_ballot_w64(mA)) (list + s0 + wpos)[prefix_count(mA)] = (uint16_t)oA;
+          wpos += __popcll(mA);
+          if (__builtin_amdgcn_inverse_ballot_w64(mB)) (list + s0 + wpos)[prefix_count(mB)] = (uint16_t)oB;
+          wpos += __popcll(mB);
+        }
+        nSurv = wpos;
+        __syncthreads();
+      }
+#endif
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
         const int rem = nSurv - base;
         const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
@@ -551,7 +620,7 @@ hipError_t prepare_detect(const Geom& g) {
                        reinterpret_cast<const void*>(k_detect<false, 44>), reinterpret_cast<const void*>(k_detect<false, 48>),
                        reinterpret_cast<const void*>(k_detect<false, 52>), reinterpret_cast<const void*>(k_detect<false, 56>)};
   for (const void* f : dk) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_det);
+    hipError_t e = raise_dynamic_lds(f, lds_det);   // (per device, never lowered by another handle: orbx_kernels.hip)
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

@@ -145,9 +145,11 @@ class Pack {
  public:
   // reserves `bytes` (256-byte aligned); src != nullptr: filled from the host.  All inputs must be added before any
   // scratch / output area so that one prefix copy covers them.
-  size_t add(const void* src, size_t bytes) {
+  // copyBytes < bytes: only that prefix of the area is read from the host (the rest is reserved, e.g. the unused tail of a
+  // strided per-frame array whose last frame the caller need not have padded)
+  size_t add(const void* src, size_t bytes, size_t copyBytes = (size_t)-1) {
     const size_t off = (total_ + 255) & ~(size_t)255;
-    items_.push_back({src, bytes, off});
+    items_.push_back({src, src ? (copyBytes < bytes ? copyBytes : bytes) : bytes, off});
     total_ = off + bytes;
     if (src && bytes) inputEnd_ = total_;
     return off;

@@ -87,6 +87,7 @@ struct TailPlan {
 hipError_t launch_resize_tail(const Geom& g, const Pyr& p, const TailPlan& tp, const TailBand* bands, int img0, int nimg,
                               const uint4* xtab, const int* yofs, const short* yab, hipStream_t s);
 hipError_t prepare_resize_tail(unsigned ldsBytes);
+hipError_t raise_dynamic_lds(const void* fn, size_t bytes);   // per-device running maximum of a kernel's dynamic-LDS limit
 
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,

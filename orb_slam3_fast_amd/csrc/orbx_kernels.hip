@@ -15,6 +15,9 @@
 // coordinates, sub-pixel disparity) use IEEE ops without contraction (-ffp-contract=off for this TU) and
 // round-half-even conversions, mirroring the x86-64 baseline (no FMA) build of the reference.
 #include <type_traits>
+#include <map>
+#include <mutex>
+
 #include "orbx_device.h"
 #include "orbx_introsort.h"
 #include "orbx_sincos.h"
@@ -55,6 +58,7 @@ struct ResizeLv {
   struct { int w, h, pitch, xcoef, ycoef; } D;
   struct { int w, h; } S;
   int sp, l;                      // source row pitch; destination level (1 = the source is the caller's level 0)
+  int nbx, xcdRun;                // tiles per row of tiles; run length of the XCD-aware tile order (<= 1: plain order)
   const uint8_t* src; long long srcImg;   // level l-1 of image 0, bytes between images
   uint8_t* dst; long long dstImg;         // level l of image 0
 };
@@ -93,7 +97,14 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
   const int l = rl.l;
   const int tid = threadIdx.x;
   const int img = blockIdx.z;
-  const int x0 = blockIdx.x * RS_DW, y0 = blockIdx.y * RS_DR;
+  // Tile order: the grid is flat over (tile row, tile column) and runs of xcdRun consecutive tiles -- x-adjacent first -- share
+  // an XCD, i.e. an L2: the 307-byte source-row segments of x-adjacent blocks meet inside 128-byte lines, and in the plain
+  // (x, y, z) grid order those neighbours sat on different XCDs and each fetched the shared line from HBM (k_resize fetched
+  // 1.74 x its algorithmic read bytes, profiles/r4e_pmc_traffic.json; k_detect has had the same remap since round 2).
+  const int tIdx = xcd_run_remap_rt((int)blockIdx.x, (int)gridDim.x, (int)blockIdx.z, rl.xcdRun);
+  const int tby = __builtin_amdgcn_readfirstlane((int)(((float)tIdx + 0.5f) * __builtin_amdgcn_rcpf((float)rl.nbx)));
+  const int tbx = tIdx - tby * rl.nbx;
+  const int x0 = tbx * RS_DW, y0 = tby * RS_DR;
   const int x1 = min(x0 + RS_DW, D.w) - 1, y1 = min(y0 + RS_DR, D.h) - 1;  // last dst column / row of the block
   const int sp = rl.sp;
   const uint8_t* src = rl.src + (long long)img * rl.srcImg;
@@ -151,13 +162,26 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
       const uint32_t off0 = (uint32_t)(__mul24(r0, sp) + 4 * c);
       uint8_t* sdst = smem + 4 * (__mul24(r0, NDW) + c);
       uint32_t v[kFastTrips];
+      const uint8_t* fbk[kFastTrips];
 #pragma unroll
-      for (int k = 0; k < kFastTrips; k++) {
-        const uint8_t* fbk = fb + (size_t)(3 * k) * (size_t)sp;   // scalar
-        asm volatile("global_load_dword %0, %1, %2" : "=v"(v[k]) : "v"(off0), "s"(fbk) : "memory");
-      }
-      // the compiler does not count these loads: wait for them here (its own later waits can only be stricter than needed)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+      for (int k = 0; k < kFastTrips; k++) fbk[k] = fb + (size_t)(3 * k) * (size_t)sp;   // scalar
+      static_assert(kFastTrips == 8, "the asm below issues eight loads");
+      // ONE asm statement: the eight loads and the wait for them.  The compiler does not know that the destination registers are
+      // written asynchronously; as separate statements (round 4) nothing kept it from copying or spilling a v[k] between the
+      // load and the wait.  Early-clobber outputs: no destination may share a register with the lane offset.
+      asm volatile(
+          "global_load_dword %0, %8, %9\n\t"
+          "global_load_dword %1, %8, %10\n\t"
+          "global_load_dword %2, %8, %11\n\t"
+          "global_load_dword %3, %8, %12\n\t"
+          "global_load_dword %4, %8, %13\n\t"
+          "global_load_dword %5, %8, %14\n\t"
+          "global_load_dword %6, %8, %15\n\t"
+          "global_load_dword %7, %8, %16\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+          : "v"(off0), "s"(fbk[0]), "s"(fbk[1]), "s"(fbk[2]), "s"(fbk[3]), "s"(fbk[4]), "s"(fbk[5]), "s"(fbk[6]), "s"(fbk[7])
+          : "memory");
 #pragma unroll
       for (int k = 0; k < kFastTrips; k++) *reinterpret_cast<uint32_t*>(sdst + k * (12 * NDW)) = v[k];
     } else
@@ -277,8 +301,8 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
     }
   }
 #ifdef RS_PROF
-  if (tid == 0 && blockIdx.z == 7 && blockIdx.x == 1 && (blockIdx.y % 9) == 3)
-    printf("L%d by %d: load %d wait %d horiz %d wait %d vert %d (x10ns)\n", l, (int)blockIdx.y, (int)(tq1 - tq0), (int)(tq2 - tq1),
+  if (tid == 0 && blockIdx.z == 7 && tbx == 1 && (tby % 9) == 3)
+    printf("L%d by %d: load %d wait %d horiz %d wait %d vert %d (x10ns)\n", l, tby, (int)(tq1 - tq0), (int)(tq2 - tq1),
            (int)(tq3 - tq2), (int)(tq4 - tq3), (int)(wall_clock64() - tq4));
 #endif
 }
@@ -309,9 +333,13 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
   int srcRowsMax, srcDwMax;
   size_t lds;
   resize_footprint(g, level, srcRowsMax, srcDwMax, lds);
-  dim3 grid((D.w + RS_DW - 1) / RS_DW, (D.h + RS_DR - 1) / RS_DR, nimg);
+  const int nbx = (D.w + RS_DW - 1) / RS_DW, nby = (D.h + RS_DR - 1) / RS_DR;
+  dim3 grid(nbx * nby, 1, nimg);
   const LevelDev& S = g.lv[level - 1];
+  static const int xcdRun = getenv("ORBX_RESIZE_XCD_RUN") ? atoi(getenv("ORBX_RESIZE_XCD_RUN")) : 8;   // A/B aid (1 = plain order)
   ResizeLv rl;
+  rl.nbx = nbx;
+  rl.xcdRun = xcdRun;
   rl.D.w = D.w; rl.D.h = D.h; rl.D.pitch = D.pitch; rl.D.xcoef = D.xcoef; rl.D.ycoef = D.ycoef;
   rl.S.w = S.w; rl.S.h = S.h;
   rl.l = level;
@@ -2382,17 +2410,30 @@ hipError_t launch_result_pack(const ResultPack& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// The dynamic-LDS limit of a kernel is a property of the DEVICE's copy of the function, shared by every handle on it: a second
+// handle with a smaller geometry (the reference constructs mpIniORBextractor with 5 x nFeatures beside the left extractor,
+// src/Tracking.cc:628-637) must not lower it under the first.  Per device and kernel the largest value ever asked for is kept.
+hipError_t raise_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> high;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& h = high[{dev, fn}];
+  if (bytes <= h) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) h = bytes;
+  return e;
+}
+
 hipError_t prepare_kernels(const Geom& g) {
-  const size_t lds_oct = octree_lds_bytes(g);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_octree),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_oct);
+  hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(k_octree), octree_lds_bytes(g));
   if (e != hipSuccess) return e;
   if (g.nlevels > 1) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max<size_t>(resize_lds_bytes(g), 1024));
+    e = raise_dynamic_lds(reinterpret_cast<const void*>(k_resize<0>), std::max<size_t>(resize_lds_bytes(g), 1024));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize<kResizeNdw>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)std::max<size_t>(resize_lds_bytes(g), 1024));
+    e = raise_dynamic_lds(reinterpret_cast<const void*>(k_resize<kResizeNdw>), std::max<size_t>(resize_lds_bytes(g), 1024));
     if (e != hipSuccess) return e;
   }
   return prepare_detect(g);
