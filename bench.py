@@ -62,8 +62,10 @@ def parse(argv=None):
     ap.add_argument("--ring", type=int, default=3, help="frames of every stream resident in HBM; step i takes frame i mod ring")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all cores)")
+    ap.add_argument("--cpu-mt-frames", type=int, default=200,
+                    help="frames of the cpu_mt leg (one pipeline with the reference's thread structure; SURVEY 8d: mean +- std over >= 200)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--sustain-ms", type=float, default=3000.0,
+    ap.add_argument("--sustain-ms", type=float, default=6000.0,
                     help="extras: repeat the timed step back to back for this long and report the sustained rate (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip latency / H2D-inclusive / cpu legs (profiling runs)")
     ap.add_argument("--latency-frames", type=int, default=200)
@@ -555,15 +557,11 @@ def main():
         out["end_to_end_algorithmic_GBps"] = round(a_pair * value / n_ranks / 1e9, 2)
 
     extras = rank == 0 and n_ranks == 1 and a.mode == "stereo" and not a.no_extras and not c5
-    if extras and a.other_steps > 0 and (W, H) == (1280, 720):
-        # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
-        out["other_configs"] = other_configs_leg(a, local_rank, torch)
-    if extras:
-        out.update(natural_pair_leg(orbx, np))
     if extras and a.sustain_ms > 0:
         # The timed region of the default run is ~10 - 50 ms: too short for an outside sampler (the driver polls GPU activity every
         # few seconds) and open to the question whether it is a burst.  The same steps, back to back, for --sustain-ms of wall time
-        # (synchronised every 64 steps so that the host cannot run ahead without bound); reported, never the headline value.
+        # (synchronised every 64 steps so that the host cannot run ahead without bound); reported, never the headline value.  FIRST of the extra legs (right behind the timed region) and 6 s long, so that a sampler
+        # with a 5 s period sees the GPU busy with exactly the workload that was timed.
         wl.sync()
         t0 = time.perf_counter()
         ns = 0
@@ -575,6 +573,11 @@ def main():
         dt = time.perf_counter() - t0
         out["sustained"] = {"value": round(units_per_step * ns / dt, 1), "unit": out["unit"], "steps": ns, "seconds": round(dt, 2),
                             "note": "the timed step repeated back to back for --sustain-ms (synchronised every 64 steps)"}
+    if extras and a.other_steps > 0 and (W, H) == (1280, 720):
+        # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
+        out["other_configs"] = other_configs_leg(a, local_rank, torch)
+    if extras:
+        out.update(natural_pair_leg(orbx, np))
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
     if extras and a.h2d_steps > 0:
@@ -620,11 +623,12 @@ def other_configs_leg(a, local_rank, torch):
     by synchronisations) but small: 8 pairs (16 images) per step, --other-steps steps after a short preheat.  `value` of
     the JSON line stays config C3."""
     res = {}
+    PROFILE_TAG = {"C2_640x480_mono": "C2", "C4_512x512_fisheye_stereo": "C4"}   # committed rocprofv3 PMC passes at the full batch
     specs = [("C2_640x480_mono", ["--mode", "mono", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
              ("640x480_stereo", ["--mode", "stereo", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
              ("C4_512x512_fisheye_stereo", ["--mode", "fisheye", "--width", "512", "--height", "512", "--nfeatures", "1500"])]
-    for name, argv in specs:
-        b = parse(argv + ["--pairs", "8", "--handles", str(a.handles), "--ring", "3"])
+    def measure(name, argv, pairs, res):
+        b = parse(argv + ["--pairs", str(pairs), "--handles", str(a.handles), "--ring", "3"])
         w2 = Workload(b, 0, local_rank, None)
         t_end = time.perf_counter() + 0.03
         while time.perf_counter() < t_end:      # preheat: the clocks dropped while the frames were generated
@@ -683,12 +687,24 @@ def other_configs_leg(a, local_rank, torch):
                              "algorithmic_GBps": round(nb * NP / (ms * 1e-3) / 1e9, 1), "_per_launch": per_launch_group}
             domk = max(st, key=lambda k_: st[k_]["share"])
             ach = st[domk]["algorithmic_GBps"]
+            traffic, tsrc = None, None
+            if pairs == 32 and name in PROFILE_TAG:   # the PMC passes were collected at this batch (64 images per launch)
+                for tag in ("r5", "r4a"):
+                    f = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, PROFILE_TAG[name]))
+                    if os.path.exists(f):
+                        try:
+                            traffic = json.load(open(f)).get("k_fisheye_batch" if domk == "k_fisheye_batch" else domk, {}).get("hbm_bytes_per_launch")
+                            tsrc = "profiles/" + os.path.basename(f)
+                        except Exception:
+                            traffic = None
+                        break
             res[name]["roofline"] = {"kernel": domk, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                                      "avg_launch_us": st[domk]["avg_us"], "share_of_step": st[domk]["share"],
                                      "algorithmic_bytes_per_launch": int(st[domk].pop("_per_launch")),
-                                     "note": "isolated (synchronised single-handle steps); PMC traffic for this configuration: "
-                                             "profiles/r4_*_pmc_traffic.json"}
+                                     "note": "isolated (synchronised single-handle steps); traffic = HBM-side bytes per launch of this "
+                                             "kernel from separate rocprofv3 --pmc passes at the same batch (%s), null at the small "
+                                             "batch (not collected there)" % (tsrc or "tools/collect_config_profiles.sh")}
             for v in st.values():
                 v.pop("_per_launch", None)
             res[name]["stages"] = st
@@ -698,9 +714,18 @@ def other_configs_leg(a, local_rank, torch):
         for e in w2.exs:
             e.close()
         del w2
-    res["note"] = ("same measurement as the headline (inputs resident, %d handles, timed steps bracketed by synchronisations) on "
-                   "small batches: 8 pairs / 16 frames per step; larger batches are faster (tools/bench_configs.sh, "
-                   "profiles/*_configs.txt)" % a.handles)
+
+    for name, argv in specs:
+        measure(name, argv, 8, res)
+        full = {}
+        try:
+            measure(name, argv, 32, full)     # the same configuration at the headline's batch: 32 pairs / 64 frames per step
+            res[name]["full_batch"] = full[name]
+        except Exception as ex_:
+            res[name]["full_batch"] = {"error": str(ex_)[:160]}
+    res["note"] = ("same measurement as the headline (inputs resident, %d handles, timed steps bracketed by synchronisations): every "
+                   "entry on a small batch (8 pairs / 16 frames per step) and, under full_batch, on the headline's batch (32 pairs / "
+                   "64 frames per step) with its own stage table and roofline" % a.handles)
     return res
 
 
@@ -826,6 +851,34 @@ def h2d_leg(a, wl, orbx, np, torch):
                                       % len(exs)}}
 
 
+def cpu_info():
+    """What SURVEY 8d asks to be stated beside the CPU baseline: the host CPU's model string, the cores this process may run on
+    (affinity set) and the cgroup quota that caps them."""
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    rng, i = [], 0
+    while i < len(aff):   # compact "0-15,32-47" form
+        j = i
+        while j + 1 < len(aff) and aff[j + 1] == aff[j] + 1:
+            j += 1
+        rng.append("%d" % aff[i] if i == j else "%d-%d" % (aff[i], aff[j]))
+        i = j + 1
+    quota = ""
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except Exception:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "affinity": ",".join(rng), "affinity_count": len(aff),
+            "cgroup_cpu_max": quota, "usable_cores": usable_cores()}
+
+
 def cpu_legs(a, wl, np):
     import subprocess
     import tempfile
@@ -866,6 +919,9 @@ def cpu_legs(a, wl, np):
             "value": round(rN["pairs_per_s"], 2), "unit": "stereo frames/s", "cores": cores, "kind": "port",
             "single_core_value": round(r1["pairs_per_s"], 3),
             "build": build,
+            "host": cpu_info(),
+            "pinning": "every worker process pinned to one core of the affinity set (sched_setaffinity, round robin over the "
+                       "set: oracle/cpu_bench.py); the cgroup quota, not the pinning, caps the cores actually used",
             "reference_readme_ms": {"orb_extraction": 9.83, "stereo_matching": 2.75,
                                     "note": "the reference's own figures for this stage pair on an unspecified desktop CPU with SIMD OpenCV "
                                             "(README.md:21-25): ~79 pairs/s per pipeline -- this port is scalar, quote the ratio to it with care"},
@@ -873,11 +929,14 @@ def cpu_legs(a, wl, np):
                       "%d worker processes x %d of the same synthetic %dx%d pairs, wall %.1f s; single worker: %d pairs "
                       "in %.1f s; host reports %d cores, %d usable (affinity / cgroup quota)" % (
                           cores, per, W, H, rN["wall_s"], r1["pairs"], r1["wall_s"], os.cpu_count(), usable_cores())}
-        rM = run(["--mt", tmp, str(NF), str(BF), str(BASE), str(max(8, a.cpu_pairs // 2))], 600)
+        rM = run(["--mt", tmp, str(NF), str(BF), str(BASE), str(a.cpu_mt_frames)], 900)
         out["cpu_mt"] = {
             "value": round(rM["pairs_per_s"], 2), "unit": "stereo frames/s", "threads": rM["threads"], "cores": min(cores, rM["threads"]),
-            "kind": "port", "extract_ms": {"mean": round(rM["extract_ms_mean"], 3), "std": round(rM["extract_ms_std"], 3)},
+            "kind": "port", "frames": rM["frames"],
+            "extract_ms": {"mean": round(rM["extract_ms_mean"], 3), "std": round(rM["extract_ms_std"], 3)},
             "stereo_ms": {"mean": round(rM["stereo_ms_mean"], 3), "std": round(rM["stereo_ms_std"], 3)},
+            "frame_ms": {"mean": round(rM.get("frame_ms_mean", 0.0), 3), "std": round(rM.get("frame_ms_std", 0.0), 3)},
+            "host": cpu_info(), "pinning": "none (16 threads of one process, scheduled by the kernel inside the affinity set / quota)",
             "sample": "the same port with the reference's thread structure: one std::thread per eye (src/Frame.cc:200-203), one "
                       "task per pyramid level and stage inside (src/ORBextractor.cc:764-846,1063-1101), then ComputeStereoMatches; "
                       "ONE pipeline, %d consecutive frames, timers placed like REGISTER_TIMES (src/Frame.cc:196-232); the "

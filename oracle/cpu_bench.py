@@ -16,8 +16,22 @@ import time
 import numpy as np
 
 
+def _pin(wid):
+    """Pin worker `wid` to ONE core of the process's affinity set (round robin): the baseline's core count is then the number
+    of distinct cores in use, and workers do not migrate.  Returns the core or -1 (no sched_setaffinity / pinning failed)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        core = cores[wid % len(cores)]
+        os.sched_setaffinity(0, {core})
+        return core
+    except Exception:
+        return -1
+
+
 def _worker(args):
     path, nf, bf, b, n_pairs, wid, start_at, extract_only = args
+    if os.environ.get("ORB_ORACLE_PIN", "1") != "0":
+        _pin(wid)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import oracle_py as oracle
     pairs = np.load(path, mmap_mode="r")
@@ -90,9 +104,11 @@ def run_mt(path, nf, bf, b, frames):
             ste.append(r[7])
     wall = time.perf_counter() - t0
     ext, ste = np.array(ext), np.array(ste)
+    tot = ext + ste
     return {"frames": frames, "threads": 2 * oL.nlevels, "wall_s": wall, "pairs_per_s": frames / wall,
             "extract_ms_mean": float(ext.mean()), "extract_ms_std": float(ext.std()),
-            "stereo_ms_mean": float(ste.mean()), "stereo_ms_std": float(ste.std())}
+            "stereo_ms_mean": float(ste.mean()), "stereo_ms_std": float(ste.std()),
+            "frame_ms_mean": float(tot.mean()), "frame_ms_std": float(tot.std())}
 
 
 def digest(path, nf, bf, b):
