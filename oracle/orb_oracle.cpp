@@ -193,32 +193,37 @@ long long orb_sincos_check(uint64_t seed, long long n, int fused, float* first_b
 // cv::resize(INTER_LINEAR) CV_8UC1, generic fixed-point path (11-bit coefficients).
 // (For an exact 2x reduction OpenCV takes the INTER_AREA fast path instead; with fx = fy = 0.5 the formula below
 // reduces to the same (s00 + s01 + s10 + s11 + 2) >> 2, see tests/test_oracle_kernels.py.)
+// The per-axis tables of cv::resize's linear path: source index floor(f) and the 11-bit weights of S[ofs], S[ofs + 1], with
+// f = (float)((d + 0.5) * scale - 0.5) -- a DOUBLE product rounded to float once.  clampX: the x axis folds the image edges into
+// the table (first / last source column with weight 2048); the y axis clamps rows where they are read instead.  Exported as
+// oro_resize_coefs so that tests/test_thirdparty_pins.py can hold the tables against an exact-rational model.
+void resize_axis_coefs(int s, int d, bool clampX, std::vector<int>& ofs, std::vector<short>& ab, std::vector<uint8_t>* plain) {
+  const double scale = 1.0 / ((double)d / s);
+  ofs.assign(d, 0);
+  ab.assign(2 * (size_t)d, 0);
+  if (plain) plain->assign(d, 0);
+  for (int i = 0; i < d; i++) {
+    float f = (float)((i + 0.5) * scale - 0.5);
+    int si = cv_floor(f);
+    f -= si;
+    if (clampX) {
+      if (si < 0) { f = 0; si = 0; }
+      if (si >= s - 1) { f = 0; si = s - 1; if (plain) (*plain)[i] = 1; }
+    }
+    ofs[i] = si;
+    ab[2 * i] = sat_short_from_float((1.f - f) * 2048.f);
+    ab[2 * i + 1] = sat_short_from_float(f * 2048.f);
+  }
+}
+
 void resize_linear_u8(const Image& src, Image& dst, int dw, int dh) {
   dst = Image(dw, dh);
   const int sw = src.w, sh = src.h;
-  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
-  const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;
-  std::vector<int> xofs(dw), yofs(dh);
-  std::vector<short> alpha(2 * dw), beta(2 * dh);
-  std::vector<uint8_t> xplain(dw, 0);  // dx >= xmax: D = S[sx] * 2048
-  for (int dx = 0; dx < dw; dx++) {
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
-    int sx = cv_floor(fx);
-    fx -= sx;
-    if (sx < 0) { fx = 0; sx = 0; }
-    if (sx >= sw - 1) { fx = 0; sx = sw - 1; xplain[dx] = 1; }
-    xofs[dx] = sx;
-    alpha[2 * dx] = sat_short_from_float((1.f - fx) * 2048.f);
-    alpha[2 * dx + 1] = sat_short_from_float(fx * 2048.f);
-  }
-  for (int dy = 0; dy < dh; dy++) {
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    int sy = cv_floor(fy);
-    fy -= sy;
-    yofs[dy] = sy;
-    beta[2 * dy] = sat_short_from_float((1.f - fy) * 2048.f);
-    beta[2 * dy + 1] = sat_short_from_float(fy * 2048.f);
-  }
+  std::vector<int> xofs, yofs;
+  std::vector<short> alpha, beta;
+  std::vector<uint8_t> xplain;  // dx >= xmax: D = S[sx] * 2048
+  resize_axis_coefs(sw, dw, true, xofs, alpha, &xplain);
+  resize_axis_coefs(sh, dh, false, yofs, beta, nullptr);
   std::vector<int> r0(dw), r1(dw);
   auto hrow = [&](int sy, std::vector<int>& out) {
     sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);

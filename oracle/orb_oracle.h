@@ -47,6 +47,7 @@ float glibc_cosf_model(float y, bool fused);
 int orb_host_libm_variant();         // 1 = FMA, 2 = SSE2, 0 = no model matches the host libm
 long long orb_sincos_check(uint64_t seed, long long n, int fused, float* first_bad);
 void resize_linear_u8(const Image& src, Image& dst, int dw, int dh);  // B2
+void resize_axis_coefs(int s, int d, bool clampX, std::vector<int>& ofs, std::vector<short>& ab, std::vector<uint8_t>* plain);  // B2: one axis's tables
 // FAST-9-16 with non-max suppression on a standalone image (ROI already cut); out: x,y,score triples.
 struct FastPt { int x, y, score; };
 void fast9_16(const uint8_t* img, int stride, int cols, int rows, int threshold, bool nms,

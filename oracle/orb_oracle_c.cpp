@@ -147,6 +147,17 @@ void oro_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) {
   std::memcpy(dst, d.px.data(), (size_t)w * h);
 }
 float oro_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void oro_fast_atan2_n(const float* y, const float* x, float* out, long n) {
+  for (long i = 0; i < n; i++) out[i] = fast_atan2(y[i], x[i]);
+}
+// the tables cv::resize's linear path builds for one axis (see resize_axis_coefs): ofs[d], ab[2 d] = {a0, a1} per destination index
+void oro_resize_coefs(int s, int d, int clamp_x, int* ofs, short* ab) {
+  std::vector<int> o;
+  std::vector<short> a;
+  resize_axis_coefs(s, d, clamp_x != 0, o, a, nullptr);
+  std::memcpy(ofs, o.data(), (size_t)d * sizeof(int));
+  std::memcpy(ab, a.data(), (size_t)2 * d * sizeof(short));
+}
 void oro_sincosf(float a, float* s, float* c) { orb_sincosf(a, s, c); }
 void oro_set_sincos_mode(int mode) { orb_set_sincos_mode(mode); }
 int oro_get_sincos_mode() { return orb_get_sincos_mode(); }
