@@ -914,14 +914,20 @@ def cpu_legs(a, wl, np):
         env.pop("ORB_ORACLE_LIB", None)
     try:
         r1 = run([tmp, str(NF), str(BF), str(BASE), "1", str(max(4, a.cpu_pairs // 4))], 300)
-        rN = run([tmp, str(NF), str(BF), str(BASE), str(cores), str(per)], 600)
+        rP = run([tmp, str(NF), str(BF), str(BASE), str(cores), str(per)], 600)           # workers pinned, one core each
+        env["ORB_ORACLE_PIN"] = "0"
+        rU = run([tmp, str(NF), str(BF), str(BASE), str(cores), str(per)], 600)           # workers placed by the kernel's scheduler
+        env.pop("ORB_ORACLE_PIN")
+        rN = rP if rP["pairs_per_s"] >= rU["pairs_per_s"] else rU                         # the baseline is the better of the two
         out["cpu_baseline"] = {
             "value": round(rN["pairs_per_s"], 2), "unit": "stereo frames/s", "cores": cores, "kind": "port",
             "single_core_value": round(r1["pairs_per_s"], 3),
             "build": build,
             "host": cpu_info(),
-            "pinning": "every worker process pinned to one core of the affinity set (sched_setaffinity, round robin over the "
-                       "set: oracle/cpu_bench.py); the cgroup quota, not the pinning, caps the cores actually used",
+            "pinned_value": round(rP["pairs_per_s"], 2), "unpinned_value": round(rU["pairs_per_s"], 2),
+            "pinning": "measured twice: every worker process pinned to one core of the affinity set (sched_setaffinity, round robin "
+                       "over the set: oracle/cpu_bench.py) and unpinned (the scheduler places the workers; on a shared host the "
+                       "first cores of the set are not the idle ones); value = the better of the two",
             "reference_readme_ms": {"orb_extraction": 9.83, "stereo_matching": 2.75,
                                     "note": "the reference's own figures for this stage pair on an unspecified desktop CPU with SIMD OpenCV "
                                             "(README.md:21-25): ~79 pairs/s per pipeline -- this port is scalar, quote the ratio to it with care"},
