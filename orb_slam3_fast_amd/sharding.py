@@ -42,6 +42,21 @@ def allgather_descriptor_blocks(counts, desc, cap, group=None):
     return unpack_descriptor_blocks(out.reshape(world * local.shape[0], local.shape[1]), cap)
 
 
+def allgather_members(counts, desc, group=None):
+    """The two collectives orbx_allgather_descriptors issues (csrc/orbx_api_comm.hip: ncclGroupStart, ncclAllGather of the
+    descriptor rows [I * cap * 32 bytes], ncclAllGather of the counts [I int32], ncclGroupEnd) as torch.distributed calls on the
+    same buffers: the block {n, desc[cap][32]} travels as its two members, each rank's slice lands at rank * slice.  Used by the
+    world-size-2 gloo test to show that this layout and the packed-block twin above agree, so that on an 8-GPU node the only
+    step never exercised is RCCL itself."""
+    world = dist.get_world_size(group)
+    I, cap = desc.shape[0], desc.shape[1]
+    out_d = torch.empty(world * desc.numel(), dtype=torch.uint8, device=desc.device)
+    out_c = torch.empty(world * I, dtype=torch.int32, device=counts.device)
+    dist.all_gather_into_tensor(out_d, desc.contiguous().reshape(-1), group=group)
+    dist.all_gather_into_tensor(out_c, counts.to(torch.int32).contiguous(), group=group)
+    return out_c, out_d.reshape(world * I, cap, 32)
+
+
 class DescriptorExchange:
     """Config C5's exchange step through the C ABI: orbx_allgather_descriptors (one grouped RCCL call straight from the
     handle's result arrays, on the handle's stream) -- the product path on the GPUs.  torch.distributed only ferries the

@@ -91,9 +91,24 @@ def test_c5_allgather_blocks_equal_the_downloads():
             cnt, desc = wl.gathered[h]
             cnt, desc = cnt.cpu().numpy(), desc.cpu().numpy()
             assert cnt.shape == (2 * a.pairs,) and desc.shape == (2 * a.pairs, ex.capacity, 32)
+            mine_c, mine_d = np.zeros(2 * a.pairs, np.int32), np.zeros((2 * a.pairs, ex.capacity, 32), np.uint8)
             for i in range(2 * a.pairs):
                 _, k, d = ex.download(i)
                 assert cnt[i] == len(k) and np.array_equal(desc[i, :len(k)], d), (h, i)
+                mine_c[i] = len(k)
+                mine_d[i, :len(k)] = d
+            if h == 0:
+                # the torch twins the gloo CPU test runs at world size 2 (tests/test_sharding_gloo.py), on the SAME inputs through
+                # RCCL: packed blocks and the two-member form give what orbx_allgather_descriptors wrote (valid rows compared;
+                # rows past n are whatever the device arrays hold)
+                from orb_slam3_fast_amd import sharding
+                tc, td = torch.from_numpy(mine_c).cuda(), torch.from_numpy(mine_d).cuda()
+                for fn in (lambda: sharding.allgather_descriptor_blocks(tc, td, ex.capacity), lambda: sharding.allgather_members(tc, td)):
+                    gc, gd = fn()
+                    gc, gd = gc.cpu().numpy(), gd.cpu().numpy()
+                    assert np.array_equal(gc, cnt)
+                    for i in range(2 * a.pairs):
+                        assert np.array_equal(gd[i, :cnt[i]], desc[i, :cnt[i]]), i
     finally:
         if own:
             dist.destroy_process_group()

@@ -33,6 +33,8 @@ def _worker(rank, world, port, q):
             for r in range(min(s + 1, cap)):
                 desc[i, r] = 10 * s + r
         gc, gd = sharding.allgather_descriptor_blocks(counts, desc, cap)
+        mc, md = sharding.allgather_members(counts, desc)          # the two collectives the C ABI issues, on the same buffers
+        assert torch.equal(mc, gc) and torch.equal(md, gd)
         t = sharding.max_over_ranks(1.0 + rank)
         rate = sharding.whole_job_rate(units_per_rank=4, steps=10, seconds=t)
         q.put((rank, mine, gc.tolist(), gd[:, :, 0].tolist(), t, rate))
