@@ -86,6 +86,9 @@ __device__ __forceinline__ void compass_pair(const uint32_t (&r)[7][3], orbx_h2 
 // hi = max_q min(e[q], e[q+1], e[q+2], e[q+3]), lo = min_q max(...), the pixel can only be a corner if max(hi - c, c - lo) > t.
 // Two survivors per lane in packed f16 like the contrast pass: 9 byte reads + 9 v_perm per pair, 8 + 8 + 3 packed operations per
 // polarity, 3 + 2 to decide.
+#ifndef ORBX_D16_PAIRS
+#define ORBX_D16_PAIRS 0   // measured: bit-exact, 17 v_perm -> 17 v_or per pass, and NO faster (216.5 vs 218.4 us: one wait for all 34 loads loses the overlap the compiler's staged waits had); profiles/r5_d16_pairs_ab.txt
+#endif
 #ifndef ORBX_EVEN_FILTER
 #define ORBX_EVEN_FILTER 0
 #endif
@@ -131,16 +134,7 @@ __device__ __forceinline__ orbx_h2 even_ring_contrast2_lds(const uint8_t* a8, co
 
 // a8 / b8 point at the TOP-LEFT corner of each pixel's 7x7 window, so every ring offset is a non-negative ds_read immediate.
 typedef unsigned short orbx_us2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
-  orbx_h2 r[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int off = (kRingDY[k] + 3) * TP + kRingDX[k] + 3;
-    orbx_us2 v;
-    v.x = a8[off];
-    v.y = b8[off];  // ds_read_u8_d16_hi: the pair is packed by the loads
-    r[k] = __builtin_bit_cast(orbx_h2, v);
-  }
+__device__ __forceinline__ orbx_h2 fast_contrast_network(const orbx_h2 (&r)[16], orbx_h2 c) {
   // max over the 16 arcs of the arc's minimum, 36 packed operations per polarity instead of 40 (round 4): for even k the arcs
   // starting at k and k + 1 share the 8-window W = r[k+1 .. k+8], and max(min(W, r[k]), min(W, r[k+9])) = min(W, max(r[k], r[k+9])):
   // pair minima p (8), 4-windows w4 (8), e = max of the two end points (8), f = min3(w4[j], w4[j+2], e[j]) (8), max over f (4).
@@ -175,11 +169,60 @@ __device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const u
     minmax = pk_min3(minmax, f[5], f[6]);
     minmax = __builtin_elementwise_minimum(minmax, f[7]);
   }
+  return __builtin_elementwise_maximum(maxmin - c, c - minmax);
+}
+
+__device__ __forceinline__ orbx_h2 fast_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
+  orbx_h2 r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int off = (kRingDY[k] + 3) * TP + kRingDX[k] + 3;
+    orbx_us2 v;
+    v.x = a8[off];
+    v.y = b8[off];  // ds_read_u8_d16_hi: the pair is packed by the loads
+    r[k] = __builtin_bit_cast(orbx_h2, v);
+  }
   orbx_us2 cv;
   cv.x = a8[3 * TP + 3];
   cv.y = b8[3 * TP + 3];
-  const orbx_h2 c = __builtin_bit_cast(orbx_h2, cv);
-  return __builtin_elementwise_maximum(maxmin - c, c - minmax);
+  return fast_contrast_network(r, __builtin_bit_cast(orbx_h2, cv));
+}
+
+// The same contrast for a pair of DIFFERENT survivors with the byte pairs packed by the LOADS (round 5).  On gfx950 a d16 load
+// zeroes the other half of its destination (tools/ubench/d16_probe.hip: ds_read_u8_d16 -> 0x000000bb, ds_read_u8_d16_hi ->
+// 0x00bb0000), which is why the compiler will not merge two of them into one register -- but it also means that the pair is
+// lo | hi: a 2-cycle v_or_b32 instead of the 4-cycle v_perm_b32 the compiler's ds_read_u8 pairs need (17 per pass; VALU issue is
+// this kernel's limit).  The loads are inline asm (the compiler never selects the d16 forms on an SRAM-ECC target):
+// it does not count them, so all 34 are issued, ONE s_waitcnt follows, and the registers only become visible to later code
+// through the "+v" ties behind it.  Compile-time pitch only (the offsets are ds_read immediates).
+template <int OFF>
+__device__ __forceinline__ void lds_byte_pair_d16(uint32_t aA, uint32_t aB, uint32_t& lo, uint32_t& hi) {
+  asm volatile("ds_read_u8_d16 %0, %2 offset:%4\n\tds_read_u8_d16_hi %1, %3 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(aA), "v"(aB), "n"(OFF));
+}
+template <int TP, int K>
+__device__ __forceinline__ void ring_pairs_d16(uint32_t aA, uint32_t aB, uint32_t (&lo)[17], uint32_t (&hi)[17]) {
+  if constexpr (K < 16) {
+    lds_byte_pair_d16<(kRingDY[K] + 3) * TP + kRingDX[K] + 3>(aA, aB, lo[K], hi[K]);
+    ring_pairs_d16<TP, K + 1>(aA, aB, lo, hi);
+  } else {
+    lds_byte_pair_d16<3 * TP + 3>(aA, aB, lo[16], hi[16]);   // the centre
+  }
+}
+template <int TP>
+__device__ __forceinline__ orbx_h2 fast_contrast2_lds_d16(const uint8_t* a8, const uint8_t* b8) {
+  uint32_t lo[17], hi[17];
+  ring_pairs_d16<TP, 0>((uint32_t)(uintptr_t)a8, (uint32_t)(uintptr_t)b8, lo, hi);
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]), "+v"(lo[8]),
+                 "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(lo[12]), "+v"(lo[13]), "+v"(lo[14]));
+  asm volatile("" : "+v"(lo[15]), "+v"(lo[16]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]),
+                     "+v"(hi[6]), "+v"(hi[7]), "+v"(hi[8]), "+v"(hi[9]), "+v"(hi[10]), "+v"(hi[11]), "+v"(hi[12]));
+  asm volatile("" : "+v"(hi[13]), "+v"(hi[14]), "+v"(hi[15]), "+v"(hi[16]));
+  orbx_h2 r[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) r[k] = __builtin_bit_cast(orbx_h2, lo[k] | hi[k]);
+  const orbx_h2 c = __builtin_bit_cast(orbx_h2, lo[16] | hi[16]);
+  return fast_contrast_network(r, c);
 }
 
 // wave mask of the lanes below n (n <= 0: none, n >= 64: all) -- scalar ALU only
@@ -405,6 +448,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         // kernel's busiest); the packed network then carries the same pixel in both halves
         orbx_h2 M;
         if (rem <= 64) M = fast_contrast2_lds(tile8 + oA, tile8 + oA, TP);
+        else if constexpr (TPC != 0 && ORBX_D16_PAIRS) M = fast_contrast2_lds_d16<TPC>(tile8 + oA, tile8 + oB);
         else M = fast_contrast2_lds(tile8 + oA, tile8 + oB, TP);
         const uint32_t Mbits = __builtin_bit_cast(uint32_t, M);  // a corner has M > t >= 0: the pattern is the integer
         const uint64_t mA = __ballot(M.x > th2.x) & vA, mB = __ballot(M.y > th2.y) & vB;
