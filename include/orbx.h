@@ -76,7 +76,11 @@ int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, fl
  * OpenCV 4.0 .. 4.5.0 (the README's "tested with 4.4.0", README.md:101; the taps sum to 257, results saturate at 255) and
  * {18,34,48,56,48,34,18} / 256 from 4.5.1 on (CMakeLists.txt:38-41 asks for "> 4.4"; what distributions ship).
  * opencv_version = 440 or 451 (the default); anything else is ORBX_E_BADARG.  Applies to every later extraction of the handle
- * (k_describe's per-keypoint blur and the blurred levels of orbx_pyramid_level).  OpenCV 3.x's float filter is not modelled. */
+ * (k_describe's per-keypoint blur and the blurred levels of orbx_pyramid_level).  OpenCV 3.x's float filter is not modelled.
+ * STATUS: both settings follow this repo's restatement of OpenCV's fixed-point path with exact accumulation and ONE rounding
+ * (oracle/orb_oracle.cpp gaussian_blur7), which is not pinned against any real OpenCV build (none exists in this environment).
+ * For 440 in particular the model is the SCALAR ufixedpoint path: OpenCV 4.0 .. 4.5.0's SIMD vertical pass may differ from it
+ * in rounding on the 257-sum taps (unverified; tools/gen_golden_opencv.py with opencv-python 4.4.0 would settle it). */
 int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version);
 
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:1015-1106) for ONE host image (CV_8UC1, `stride`
