@@ -404,6 +404,17 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
                                    const orbx_keypoint* kps2, const uint8_t* desc2, int n2, float min_x,
                                    float min_y, float max_x, float max_y, float* prev_matched,
                                    int32_t* matches12, int window_size, float nnratio, int check_orientation);
+/* The same search for the frames of an extraction BATCH (many-camera mode: every camera still initialising its map matches its
+ * initial frame against its current one, src/Tracking.cc:2438-2440, in one call).  Pair f: F2 = image first_image + f of `ex`'s
+ * last batch (keypoints taken as mvKeysUn and descriptors stay in HBM), F1 = kps1 / desc1 [f * stride .. f * stride + n1[f]) on
+ * the host; prev_matched is [n_frames][stride][2] (in/out), matches12 [n_frames][stride], n_matches [n_frames].  Every kernel
+ * of the chain runs ONCE for all pairs (blockIdx.y = pair) with a fixed number of fixed-point rounds enqueued without reading
+ * a convergence flag; a pair that needs more rounds or larger candidate lists is redone through the one-shot call: results are
+ * those of n_frames separate orbx_search_for_initialization calls.  Returns the total number of matches or a negative error. */
+int orbx_search_for_initialization_batch(orbx_extractor* ex, int first_image, int n_frames, const orbx_keypoint* kps1,
+                                         const uint8_t* desc1, const int32_t* n1, int stride, float min_x, float min_y,
+                                         float max_x, float max_y, float* prev_matched, int32_t* matches12, int window_size,
+                                         float nnratio, int check_orientation, int32_t* n_matches);
 
 /* Replaces Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:520-547,833-844: 64 x 48 grid, round-to-cell) and
  * Frame::GetFeaturesInArea (src/Frame.cc:765-831) for a batch of queries.  kps = mvKeysUn (n), bounds = mnMinX/Y,

@@ -125,6 +125,7 @@ def lib():
         L.orbx_fisheye_results_device.argtypes = [vp, vp, vp, vp, vp, vp]
         L.orbx_fisheye_download.argtypes = [vp, i, vp, vp, vp, vp, i, i, vp]
         L.orbx_search_for_initialization.argtypes = [i, vp, vp, i, vp, vp, i, f, f, f, f, vp, vp, i, f, i]
+        L.orbx_search_for_initialization_batch.argtypes = [vp, i, i, vp, vp, vp, i, f, f, f, f, vp, vp, i, f, i, vp]
         L.orbx_search_by_projection.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, vp, i, f, i, f, f, vp, vp]
         L.orbx_search_by_projection_frame.argtypes = [i, vp, vp, vp, i, f, f, f, f, vp, i, i, vp, vp]
         L.orbx_search_by_projection_frame_batch.argtypes = [vp, i, i, f, f, f, f, vp, vp, i, i, i, vp, vp, vp, vp]
@@ -880,6 +881,27 @@ class ORBmatcher:
             self.device, _p(k), _p(d), None if ur is None else _p(ur), len(k), bounds[0], bounds[1], bounds[2],
             bounds[3], _p(pp), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
+
+    def SearchForInitializationBatch(self, ex, first_image, kps1, desc1, bounds2, vbPrevMatched, windowSize=10):
+        """SearchForInitialization for the frames of ex's last extraction batch in one call (orbx_search_for_initialization_batch):
+        pair f matches F1 = (kps1[f], desc1[f]) -- lists of per-pair arrays -- against image first_image + f of the batch.
+        Returns (n_matches [F], list of vnMatches12, list of updated vbPrevMatched)."""
+        F = len(kps1)
+        n1 = np.array([len(k) for k in kps1], np.int32)
+        stride = max(int(n1.max()) if F else 0, 1)
+        K = np.zeros((F, stride), KP_DTYPE)
+        D = np.zeros((F, stride, 32), np.uint8)
+        P = np.zeros((F, stride, 2), np.float32)
+        for f in range(F):
+            K[f, :n1[f]] = kps1[f]
+            D[f, :n1[f]] = np.asarray(desc1[f], np.uint8).reshape(-1, 32)
+            P[f, :n1[f]] = np.asarray(vbPrevMatched[f], np.float32).reshape(-1, 2)
+        M = np.full((F, stride), -1, np.int32)
+        nm = np.zeros(F, np.int32)
+        _check(lib().orbx_search_for_initialization_batch(
+            ex._h, int(first_image), F, _p(K), _p(D), _p(n1), stride, bounds2[0], bounds2[1], bounds2[2], bounds2[3], _p(P), _p(M),
+            int(windowSize), self.mfNNratio, int(self.mbCheckOrientation), _p(nm)))
+        return nm, [M[f, :n1[f]].copy() for f in range(F)], [P[f, :n1[f]].copy() for f in range(F)]
 
     def SearchByProjectionFrameBatch(self, ex, first_image, n_frames, bounds, points, n_points, occupied=None, stereo_pair0=-1):
         """SearchByProjectionFrame on the frames of ex's last extraction batch in one call (include/orbx.h:

@@ -263,6 +263,131 @@ int orbx_search_for_initialization(int device, const orbx_keypoint* kps1, const 
   return rc;
 }
 
+// SearchForInitialization on the frames of an extraction batch (round 5; the batched form of the call above, like
+// proj_batch_impl for the projection matchers): F2 of pair f = image first_image + f of the handle's last batch -- keypoints
+// and descriptors stay in HBM --, F1 of pair f = kps1 / desc1 [f * stride .. + n1[f]) from the host (the initial frame of that
+// camera).  One upload, every kernel launched ONCE for all pairs (launch_search_init_batch), kInitBlind fixed-point rounds
+// enqueued without reading a convergence flag, one download.  A pair whose candidate lists overflowed the first guess, whose
+// claimer lists overflowed or whose claims did not settle within the blind rounds is redone through the one-shot call.
+int orbx_search_for_initialization_batch(orbx_extractor* ex, int first_image, int n_frames, const orbx_keypoint* kps1,
+                                         const uint8_t* desc1, const int32_t* n1, int stride, float min_x, float min_y,
+                                         float max_x, float max_y, float* prev_matched, int32_t* matches12, int window_size,
+                                         float nnratio, int check_orientation, int32_t* n_matches) {
+  if (!ex || n_frames < 0 || first_image < 0 || !n1 || stride < 0 || (n_frames && (!n_matches)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_frames == 0) return 0;
+  if (ex->lastN <= 0 || first_image + n_frames > ex->lastN) return fail(ORBX_E_BADARG, "frames outside the handle's last batch");
+  int maxN1 = 0;
+  for (int f = 0; f < n_frames; f++) {
+    if (n1[f] < 0 || n1[f] > stride) return fail(ORBX_E_BADARG, "n1[f] outside [0, stride]");
+    maxN1 = std::max(maxN1, n1[f]);
+  }
+  if (maxN1 && (!kps1 || !desc1 || !prev_matched || !matches12)) return fail(ORBX_E_BADARG, "null argument");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int cap = ex->gmax.outCap, F = n_frames, st = std::max(stride, 1);
+  std::vector<int> n2(F);
+  HIPC(hipStreamSynchronize(ex->stream));
+  HIPC(hipMemcpy(n2.data(), ex->d_nOut.p + first_image, (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  int maxN2 = 0;
+  for (int f = 0; f < F; f++) {
+    n2[f] = std::min(std::max(n2[f], 0), cap);
+    maxN2 = std::max(maxN2, n2[f]);
+  }
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  static const int kBlind = getenv("ORBX_PROJ_BLIND") ? std::min(48, std::max(1, atoi(getenv("ORBX_PROJ_BLIND")))) : 16;
+  const int nm = std::max(maxN1, 1), candCap = capEnv > 0 ? capEnv : nm * 128;
+  constexpr int kFlags = 40 + 48;
+  Pack pk;
+  std::vector<InitArgs> frames(F);
+  const size_t rows = (size_t)(F - 1) * st + (size_t)n1[F - 1];   // (the last pair's padding is not read: see proj_batch_impl)
+  const size_t oK1 = pk.add(maxN1 ? kps1 : nullptr, (size_t)F * st * sizeof(orbx_keypoint), rows * sizeof(orbx_keypoint));
+  const size_t oD1 = pk.add(maxN1 ? desc1 : nullptr, (size_t)F * st * 32, rows * 32);
+  const size_t oFr = pk.add(frames.data(), (size_t)F * sizeof(InitArgs));
+  const size_t oPrev = pk.add(maxN1 ? prev_matched : nullptr, (size_t)F * st * 2 * sizeof(float), rows * 2 * sizeof(float));
+  const size_t oM12 = pk.add(nullptr, (size_t)F * st * sizeof(int)), oRes = pk.add(nullptr, (size_t)F * 2 * sizeof(int));
+  const size_t oFlags = pk.add(nullptr, (size_t)F * kFlags * sizeof(int));
+  const size_t outBytes = oFlags + (size_t)F * kFlags * sizeof(int) - oPrev;
+  auto per = [&](size_t ints) { return pk.add(nullptr, (size_t)F * ints * sizeof(int)); };
+  const size_t cs = 64 * 48 + 4, oCs = per(cs), oCi = per(cap), oMd = per(cap), oM21 = per(cap);
+  const size_t oCo = per((size_t)nm + 4), oCx = per(candCap), oCd = per(candCap);
+  const size_t oCl0 = per(2 * (size_t)nm), oCl1 = per(2 * (size_t)nm);
+  const size_t oCr0 = per(2 * (size_t)cap * kFeWriters), oCr1 = per(2 * (size_t)cap * kFeWriters), oCr2 = per(2 * (size_t)cap * kFeWriters);
+  const size_t oNc0 = per(cap), oNc1 = per(cap), oNc2 = per(cap);
+  hipError_t e = pk.reserve();
+  if (e != hipSuccess) { pk.release(); return fail(ORBX_E_HIP, hipGetErrorString(e)); }
+  for (int f = 0; f < F; f++) {
+    InitArgs a{};
+    const int img = first_image + f;
+    a.k1 = pk.ptr<orbx_keypoint>(oK1) + (size_t)f * st;
+    a.d1 = pk.ptr<uint8_t>(oD1) + (size_t)f * st * 32;
+    a.k2 = ex->d_kps.p + (size_t)img * cap;
+    a.d2 = ex->d_desc.p + (size_t)img * cap * 32;
+    a.n1 = n1[f]; a.n2 = n2[f];
+    a.minX = min_x; a.minY = min_y;
+    a.invW = 64.f / (max_x - min_x);
+    a.invH = 48.f / (max_y - min_y);
+    a.prev = pk.ptr<float>(oPrev) + (size_t)f * st * 2;
+    a.matches12 = pk.ptr<int>(oM12) + (size_t)f * st;
+    a.window = window_size; a.nnratio = nnratio; a.checkOri = check_orientation;
+    a.cellStart = pk.ptr<int>(oCs) + (size_t)f * cs;
+    a.cellItems = pk.ptr<int>(oCi) + (size_t)f * cap;
+    a.candOff = pk.ptr<int>(oCo) + (size_t)f * (nm + 4);
+    a.candIdx = pk.ptr<int>(oCx) + (size_t)f * candCap;
+    a.candDist = pk.ptr<int>(oCd) + (size_t)f * candCap;
+    a.candCap = candCap;
+    a.matchedDist = pk.ptr<int>(oMd) + (size_t)f * cap;
+    a.matches21 = pk.ptr<int>(oM21) + (size_t)f * cap;
+    a.result = pk.ptr<int>(oRes) + (size_t)f * 2;
+    a.claim[0] = pk.ptr<int2>(oCl0) + (size_t)f * nm; a.claim[1] = pk.ptr<int2>(oCl1) + (size_t)f * nm;
+    a.claimers[0] = pk.ptr<int2>(oCr0) + (size_t)f * cap * kFeWriters; a.claimers[1] = pk.ptr<int2>(oCr1) + (size_t)f * cap * kFeWriters;
+    a.claimers[2] = pk.ptr<int2>(oCr2) + (size_t)f * cap * kFeWriters;
+    a.nclaimers[0] = pk.ptr<int>(oNc0) + (size_t)f * cap; a.nclaimers[1] = pk.ptr<int>(oNc1) + (size_t)f * cap;
+    a.nclaimers[2] = pk.ptr<int>(oNc2) + (size_t)f * cap;
+    a.flags = pk.ptr<int>(oFlags) + (size_t)f * kFlags;
+    frames[f] = a;
+  }
+  e = pk.commit();
+  if (e == hipSuccess) e = launch_search_init_batch(pk.ptr<InitArgs>(oFr), F, maxN1, maxN2, kBlind, nullptr);
+  std::vector<int> redo;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oPrev, outBytes, &e);  // synchronises
+    if (e == hipSuccess) {
+      for (int f = 0; f < F; f++) {
+        int res[2];
+        std::memcpy(res, h + (oRes - oPrev) + (size_t)f * 2 * sizeof(int), sizeof res);
+        const int* fl = reinterpret_cast<const int*>(h + (oFlags - oPrev)) + (size_t)f * kFlags;
+        if (n1[f] > 0 && (res[1] > candCap || fl[1] || fl[40 + kBlind - 1] || n2[f] == 0)) {
+          redo.push_back(f);
+          continue;
+        }
+        if (n1[f] > 0) {
+          std::memcpy(prev_matched + (size_t)f * st * 2, h + (size_t)f * st * 2 * sizeof(float), (size_t)n1[f] * 2 * sizeof(float));
+          std::memcpy(matches12 + (size_t)f * st, h + (oM12 - oPrev) + (size_t)f * st * sizeof(int), (size_t)n1[f] * sizeof(int));
+        }
+        n_matches[f] = n1[f] > 0 ? res[0] : 0;
+      }
+    }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  for (int f : redo) {   // the one-shot call on a host copy of F2 (prev_matched / matches12 of this pair are still the caller's input)
+    const int img = first_image + f, n = n2[f];
+    std::vector<orbx_keypoint> k(std::max(n, 1));
+    std::vector<uint8_t> d((size_t)std::max(n, 1) * 32);
+    HIPC(hipMemcpy(k.data(), ex->d_kps.p + (size_t)img * cap, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(d.data(), ex->d_desc.p + (size_t)img * cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    rc = orbx_search_for_initialization(ex->device, kps1 + (size_t)f * st, desc1 + (size_t)f * st * 32, n1[f], k.data(), d.data(), n,
+                                        min_x, min_y, max_x, max_y, prev_matched + (size_t)f * st * 2, matches12 + (size_t)f * st,
+                                        window_size, nnratio, check_orientation);
+    if (rc < 0) return rc;
+    n_matches[f] = rc;
+  }
+  int total = 0;
+  for (int f = 0; f < F; f++) total += n_matches[f];
+  return total;
+}
+
 int orbx_features_in_area(int device, const orbx_keypoint* kps, int n, float min_x, float min_y, float max_x,
                           float max_y, const float* queries, int n_queries, int32_t* offsets, int32_t* indices,
                           int indices_cap, int32_t* grid_cell_start, int32_t* grid_items) {

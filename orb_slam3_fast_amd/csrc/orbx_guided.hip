@@ -41,6 +41,10 @@ struct ScanOfProj {  // k_init_scan over frame blockIdx.y's candidate counts
     return sc;
   }
 };
+struct InitOfArr {  // SearchForInitialization on the frames of a batch: frame blockIdx.y's argument block (round 5)
+  const InitArgs* p;
+  __device__ __forceinline__ const InitArgs& get() const { return p[blockIdx.y]; }
+};
 template <bool B> struct ProjRef;
 template <> struct ProjRef<false> {
   ProjArgs v;
@@ -139,7 +143,9 @@ __global__ __launch_bounds__(kGridThreads) void k_init_grid(R ar) {  // single b
 
 // GetFeaturesInArea(x, y, r, 0, 0) (src/Frame.cc:765-831) for one level-0 keypoint of F1 per wave, in the
 // reference's candidate order (ix outer, iy inner, in-cell order).  pass 0 counts, pass 1 writes (i2, dist).
-__global__ __launch_bounds__(256) void k_init_cands(InitArgs a, int pass) {
+template <class R>
+__global__ __launch_bounds__(256) void k_init_cands(R ar, int pass) {
+  const InitArgs& a = ar.get();
   const int lane = threadIdx.x & 63;
   const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i1 >= a.n1) return;
@@ -449,7 +455,7 @@ hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s) {  // exclusive
 hipError_t launch_search_init(const InitArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_init_grid<GridVal>, dim3(1), dim3(kGridThreads), 0, s, GridVal{a});
   if (a.n1 > 0) {
-    hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 0);
+    hipLaunchKernelGGL(k_init_cands<GridVal>, dim3((a.n1 + 3) / 4), dim3(256), 0, s, GridVal{a}, 0);
     hipLaunchKernelGGL(k_init_scan<GridVal>, dim3(1), dim3(256), 0, s, GridVal{a});
   }
   return hipGetLastError();
@@ -474,7 +480,9 @@ __device__ __forceinline__ int init_matched_dist(const InitArgs& a, int prev, in
   return ld;
 }
 
-__global__ __launch_bounds__(256) void k_init_round(InitArgs a, int round_no) {
+template <class R>
+__global__ __launch_bounds__(256) void k_init_round(R ar, int round_no) {
+  const InitArgs& a = ar.get();
   const int lane = threadIdx.x & 63;
   const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6);
   // claimer lists rotate through three buffers (read [r % 3], append to [(r + 1) % 3], clear [(r + 2) % 3] for the next
@@ -529,7 +537,9 @@ __global__ __launch_bounds__(256) void k_init_round(InitArgs a, int round_no) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_init_reset(InitArgs a) {  // before round 0: empty claimer lists, no owners
+template <class R>
+__global__ __launch_bounds__(256) void k_init_reset(R ar) {  // before round 0: empty claimer lists, no owners
+  const InitArgs& a = ar.get();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) {
     a.nclaimers[1][i] = 0;
     a.matches21[i] = -1;
@@ -546,7 +556,9 @@ __device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
   return bin;
 }
 
-__global__ __launch_bounds__(256) void k_init_owner(InitArgs a, int last) {  // vnMatches21 = the last claimer; votes
+template <class R>
+__global__ __launch_bounds__(256) void k_init_owner(R ar, int last) {  // vnMatches21 = the last claimer; votes
+  const InitArgs& a = ar.get();
   const int i1 = blockIdx.x * 256 + threadIdx.x;
   if (i1 >= a.n1) return;
   const int2 cl = a.claim[last][i1];
@@ -555,7 +567,9 @@ __global__ __launch_bounds__(256) void k_init_owner(InitArgs a, int last) {  // 
   if (a.checkOri) atomicAdd(&a.flags[4 + init_bin(a, i1, cl.x)], 1);  // stolen matches stay in rotHist (:712-719)
 }
 
-__global__ __launch_bounds__(256) void k_init_finish(InitArgs a, int last) {
+template <class R>
+__global__ __launch_bounds__(256) void k_init_finish(R ar, int last) {
+  const InitArgs& a = ar.get();
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   if (a.checkOri) {
     for (int i = 0; i < 30; i++) {
@@ -599,24 +613,49 @@ __global__ __launch_bounds__(256) void k_init_finish(InitArgs a, int last) {
   if ((threadIdx.x & 63) == 0 && kept) atomicAdd(&a.flags[2], kept);
 }
 
-__global__ void k_init_result(InitArgs a) { a.result[0] = a.flags[2]; }
+template <class R>
+__global__ void k_init_result(R ar) {
+  const InitArgs& a = ar.get();
+  a.result[0] = a.flags[2];
+}
 
 hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s) {
-  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands<GridVal>, dim3((a.n1 + 3) / 4), dim3(256), 0, s, GridVal{a}, 1);
   return hipGetLastError();
 }
 hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s) {
   const int gb = (a.n2 + 255) / 256 > 0 ? (a.n2 + 255) / 256 : 1;
-  if (first_round == 0) hipLaunchKernelGGL(k_init_reset, dim3(gb), dim3(256), 0, s, a);
+  if (first_round == 0) hipLaunchKernelGGL(k_init_reset<GridVal>, dim3(gb), dim3(256), 0, s, GridVal{a});
   for (int r = first_round; r < first_round + rounds; r++)
-    hipLaunchKernelGGL(k_init_round, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, r);
+    hipLaunchKernelGGL(k_init_round<GridVal>, dim3((a.n1 + 3) / 4), dim3(256), 0, s, GridVal{a}, r);
   return hipGetLastError();
 }
 hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s) {
   const int last = (last_round & 1) ^ 1;
-  hipLaunchKernelGGL(k_init_owner, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
-  hipLaunchKernelGGL(k_init_finish, dim3((a.n1 + 255) / 256), dim3(256), 0, s, a, last);
-  hipLaunchKernelGGL(k_init_result, dim3(1), dim3(1), 0, s, a);
+  hipLaunchKernelGGL(k_init_owner<GridVal>, dim3((a.n1 + 255) / 256), dim3(256), 0, s, GridVal{a}, last);
+  hipLaunchKernelGGL(k_init_finish<GridVal>, dim3((a.n1 + 255) / 256), dim3(256), 0, s, GridVal{a}, last);
+  hipLaunchKernelGGL(k_init_result<GridVal>, dim3(1), dim3(1), 0, s, GridVal{a});
+  return hipGetLastError();
+}
+// SearchForInitialization for every frame of a batch, one launch per kernel (blockIdx.y = frame): frame grid, candidate counts,
+// scan, candidate fill, `rounds` blind fixed-point rounds (no convergence flag is read in between: flags[kProjChanged + r] of
+// every frame travel back with the results), last-claimer ownership + rotation votes, cull + vbPrevMatched update, count.
+// d_frames: device array of nFrames argument blocks; maxN1 / maxN2: the largest keypoint counts of F1 / F2.
+hipError_t launch_search_init_batch(const InitArgs* d_frames, int nFrames, int maxN1, int maxN2, int rounds, hipStream_t s) {
+  if (nFrames <= 0) return hipSuccess;
+  const dim3 one(1, nFrames), n1w((std::max(maxN1, 1) + 3) / 4, nFrames), n1t((std::max(maxN1, 1) + 255) / 256, nFrames),
+      n2t((std::max(maxN2, 1) + 255) / 256, nFrames);
+  const InitOfArr r{d_frames};
+  hipLaunchKernelGGL(k_init_grid<InitOfArr>, one, dim3(kGridThreads), 0, s, r);
+  hipLaunchKernelGGL(k_init_cands<InitOfArr>, n1w, dim3(256), 0, s, r, 0);
+  hipLaunchKernelGGL(k_init_scan<InitOfArr>, one, dim3(256), 0, s, r);
+  hipLaunchKernelGGL(k_init_cands<InitOfArr>, n1w, dim3(256), 0, s, r, 1);
+  hipLaunchKernelGGL(k_init_reset<InitOfArr>, n2t, dim3(256), 0, s, r);
+  for (int i = 0; i < rounds; i++) hipLaunchKernelGGL(k_init_round<InitOfArr>, n1w, dim3(256), 0, s, r, i);
+  const int last = ((rounds - 1) & 1) ^ 1;
+  hipLaunchKernelGGL(k_init_owner<InitOfArr>, n1t, dim3(256), 0, s, r, last);
+  hipLaunchKernelGGL(k_init_finish<InitOfArr>, n1t, dim3(256), 0, s, r, last);
+  hipLaunchKernelGGL(k_init_result<InitOfArr>, one, dim3(1), 0, s, r);
   return hipGetLastError();
 }
 hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s) {
@@ -625,7 +664,7 @@ hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_search_init_fill(const InitArgs& a, hipStream_t s) {
-  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands, dim3((a.n1 + 3) / 4), dim3(256), 0, s, a, 1);
+  if (a.n1 > 0) hipLaunchKernelGGL(k_init_cands<GridVal>, dim3((a.n1 + 3) / 4), dim3(256), 0, s, GridVal{a}, 1);
   hipLaunchKernelGGL(k_init_resolve, dim3(1), dim3(64), (size_t)((a.n1 + 15) & ~15) + 16, s, a);
   return hipGetLastError();
 }

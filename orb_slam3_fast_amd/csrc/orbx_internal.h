@@ -305,6 +305,7 @@ hipError_t launch_search_init_cands_fill(const InitArgs& a, hipStream_t s);
 hipError_t launch_search_init_rounds(const InitArgs& a, int first_round, int rounds, hipStream_t s);
 hipError_t launch_search_init_finish(const InitArgs& a, int last_round, hipStream_t s);
 hipError_t launch_search_init_resolve_serial(const InitArgs& a, hipStream_t s);
+hipError_t launch_search_init_batch(const InitArgs* d_frames, int nFrames, int maxN1, int maxN2, int rounds, hipStream_t s);
 hipError_t launch_grid_build(const InitArgs& a, hipStream_t s);        // AssignFeaturesToGrid of (k2, n2) as CSR
 hipError_t launch_area_query(const InitArgs& a, const float* q, int nq, int* qOff, int* out, int pass, hipStream_t s);
 hipError_t launch_scan_offsets(const InitArgs& a, hipStream_t s);

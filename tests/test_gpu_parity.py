@@ -959,3 +959,51 @@ def test_single_frame_cascade_plans_and_host_pyramid(gpu, oracle, w, h, nf, sf, 
         assert np.array_equal(ex.image_pyramid(l, image=1), oR.level(l)), l
     m1b, k1b, d1b = ex.download(1)
     assert m1b == omR and np.array_equal(_kp_bytes(k1b), _kp_bytes(okR)) and np.array_equal(d1b, odR)
+
+
+def test_search_for_initialization_batched_over_an_extraction_batch(gpu, oracle):
+    """VERDICT (round 4), item 5: SearchForInitialization (src/ORBmatcher.cc:618-764) for the frames of an extraction batch in one
+    call -- F2 of every pair stays in HBM, every kernel of the chain runs once for all pairs (blockIdx.y = pair), the fixed-point
+    rounds are enqueued without a convergence-flag read.  Per pair the result is the oracle's (= that of separate one-shot calls):
+    pairs with different keypoint counts, one empty F1, both orientation settings; then the redo path (tiny candidate capacity and
+    a single blind round) in a fresh process."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h, nf, F = 752, 480, 2500, 5
+    first = [synth.mono_frame(w, h, 60 + f, 0) for f in range(F)]
+    cur = np.stack([synth.mono_frame(w, h, 60 + f, 1) for f in range(F)])
+    dev = DeviceBuffer.from_numpy(cur)
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=F)
+    ex1 = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    ex.extract_batch_device(dev.ptr.value, F, w, h, w, w * h)
+    ex.sync()
+    bounds = (0.0, 0.0, float(w), float(h))
+    k1s, d1s, prevs, k2s, d2s = [], [], [], [], []
+    for f in range(F):
+        _, k1, d1 = ex1(first[f], (0, 1000))
+        n = 0 if f == 2 else len(k1) - 31 * f
+        k1s.append(k1[:n]); d1s.append(d1[:n]); prevs.append(np.stack([k1["x"][:n], k1["y"][:n]], 1).astype(np.float32))
+        _, k2, d2 = ex.download(f)
+        k2s.append(k2); d2s.append(d2)
+    m = orbx.ORBmatcher(0.9, True)
+    for check in (True, False):
+        m.mbCheckOrientation = check
+        nm, m12, newprev = m.SearchForInitializationBatch(ex, 0, k1s, d1s, bounds, prevs, 100)
+        total = 0
+        for f in range(F):
+            if len(k1s[f]) == 0:
+                assert nm[f] == 0 and len(m12[f]) == 0
+                continue
+            on, om12, oprev = oracle.search_init(k1s[f], d1s[f], k2s[f], d2s[f], bounds, prevs[f], 100, 0.9, check)
+            assert nm[f] == on and np.array_equal(m12[f], om12), (f, check, nm[f], on)
+            assert np.array_equal(newprev[f].reshape(-1).view(np.uint32), oprev.reshape(-1).view(np.uint32)), (f, check)
+            n1, m1, p1 = m.SearchForInitialization(k1s[f], d1s[f], k2s[f], d2s[f], bounds, prevs[f], 100)   # the one-shot call agrees
+            assert n1 == on and np.array_equal(m1, om12)
+            total += on
+        assert total > 200
+    if os.environ.get("ORBX_PROJ_CAND_CAP") is None:   # (the child below runs this test once more with the redo path forced)
+        import subprocess
+        import sys
+        e = dict(os.environ, ORBX_PROJ_CAND_CAP="64", ORBX_PROJ_BLIND="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__),
+                            "-k", "test_search_for_initialization_batched_over_an_extraction_batch"], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
