@@ -184,3 +184,16 @@ for name, fn in (("SearchByProjection(Cur, Last), batch of %d frames" % FB,
         r = fn()
     tb = (time.perf_counter() - t0) / reps * 1e3
     print("%-62s %12.3f   (%.3f ms per frame, %d matches in frame 0; one-shot call above: per frame)" % (name, tb, tb / FB, int(r[0][0])))
+
+# batched SearchForInitialization on the frames of an extraction batch (round 5): F1 = the previous frame's keypoints from the
+# host for every pair, F2 = the batch's images (exb holds L1, R1 alternating: even images are the frame `kc` came from)
+k1B, d1B, prevB = [kp] * FB, [dp] * FB, [prev] * FB
+fn = lambda: mi.SearchForInitializationBatch(exb, 0, k1B, d1B, bounds, prevB, 100)
+for _ in range(3):
+    r = fn()
+t0 = time.perf_counter()
+for _ in range(reps):
+    r = fn()
+tb = (time.perf_counter() - t0) / reps * 1e3
+print("%-62s %12.3f   (%.3f ms per pair, %d matches in pair 0; Python packing of the %d host arrays included)"
+      % ("SearchForInitialization, batch of %d pairs" % FB, tb, tb / FB, int(r[0][0]), FB))
