@@ -382,6 +382,18 @@ int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* k
                        const uint32_t* f_node_ids, const int32_t* f_node_start, const uint32_t* f_feature_idx, int n_f_nodes,
                        const orbx_keypoint* f_kps, const uint8_t* f_desc, int n_f, int n_left_f, float nnratio,
                        int check_orientation, int32_t* matches);
+/* The same search for the frames of an extraction BATCH: frame f = image first_image + f of `ex`'s last batch, whose keypoints,
+ * descriptors and feature vector (orbx_bow_transform_batch must have run on that extraction) stay in HBM; the key frame of pair f
+ * comes from the host as strided arrays -- kf_node_ids [n_frames][nodes_stride], kf_node_start [n_frames][nodes_stride + 1],
+ * kf_feature_idx / kf_kps / kf_desc / kf_valid [n_frames][kf_stride](x 32) with n_kf_nodes[f] / n_kf[f] valid entries.
+ * matches is [n_frames][cap] (cap = orbx_batch_results_device's cap; -1 past a frame's keypoints), n_matches [n_frames].
+ * Every kernel runs ONCE for all pairs (blockIdx.y = pair); results are those of n_frames separate calls.
+ * Returns the total number of matches or a negative error. */
+int orbx_search_by_bow_batch(orbx_extractor* ex, int first_image, int n_frames, const uint32_t* kf_node_ids,
+                             const int32_t* kf_node_start, const int32_t* n_kf_nodes, int nodes_stride,
+                             const uint32_t* kf_feature_idx, const orbx_keypoint* kf_kps, const uint8_t* kf_desc,
+                             const uint8_t* kf_valid, const int32_t* n_kf, int kf_stride, int n_left_f, float nnratio,
+                             int check_orientation, int32_t* matches, int32_t* n_matches);
 
 /* Replaces Frame::UndistortKeyPoints (src/Frame.cc:853-885): mvKeysUn from mvKeys through
  * cv::undistortPoints(mat, mat, K, mDistCoef, cv::Mat(), mK) -- five fixed-point iterations of the inverse distortion

@@ -119,6 +119,7 @@ def lib():
         L.orbx_bow_results_device.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i)]
         L.orbx_bow_download.argtypes = [vp, i, vp, vp, C.POINTER(i), vp, vp, vp, C.POINTER(i), i]
         L.orbx_search_by_bow.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, f, i, vp]
+        L.orbx_search_by_bow_batch.argtypes = [vp, i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, i, f, i, vp, vp]
         L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
         L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
         L.orbx_compute_image_bounds.argtypes = [i, i, i, vp, vp, i, vp]
@@ -783,6 +784,33 @@ def SearchByBoW(kf_fv, kf_kps, kf_desc, kf_valid, f_fv, f_kps, f_desc, n_left_f=
                                         _p(ffi), len(fn), _p(fk), _p(fd), len(fk), int(n_left_f), float(nnratio), int(bool(check_ori)),
                                         _p(match)))
     return n, match
+
+
+def SearchByBoWBatch(ex, first_image, kf_fvs, kf_kps, kf_descs, kf_valids, n_left_f=-1, nnratio=0.7, check_ori=True):
+    """SearchByBoW(KeyFrame, Frame) for the frames of ex's last extraction batch in one call (orbx_search_by_bow_batch): the frames'
+    keypoints, descriptors and feature vectors (ORBVocabulary.transform_batch) stay on the device; the key frame of pair f comes
+    as kf_fvs[f] = (node_ids, node_start, feature_idx), kf_kps[f], kf_descs[f], kf_valids[f].
+    Returns (n_matches [F], list of match arrays [n_f])."""
+    F = len(kf_fvs)
+    nn = np.array([len(fv[0]) for fv in kf_fvs], np.int32)
+    nk = np.array([len(k) for k in kf_kps], np.int32)
+    ns, ks = max(int(nn.max()) if F else 0, 1), max(int(nk.max()) if F else 0, 1)
+    ids, st = np.zeros((F, ns), np.uint32), np.zeros((F, ns + 1), np.int32)
+    fi, K = np.zeros((F, ks), np.uint32), np.zeros((F, ks), KP_DTYPE)
+    D, V = np.zeros((F, ks, 32), np.uint8), np.zeros((F, ks), np.uint8)
+    for f in range(F):
+        ids[f, :nn[f]] = kf_fvs[f][0]
+        st[f, :nn[f] + 1] = kf_fvs[f][1]
+        fi[f, :len(kf_fvs[f][2])] = kf_fvs[f][2]
+        K[f, :nk[f]] = kf_kps[f]
+        D[f, :nk[f]] = np.asarray(kf_descs[f], np.uint8).reshape(-1, 32)
+        V[f, :nk[f]] = kf_valids[f]
+    cap = ex.capacity
+    match = np.full((F, cap), -1, np.int32)
+    nm = np.zeros(F, np.int32)
+    _check(lib().orbx_search_by_bow_batch(ex._h, int(first_image), F, _p(ids), _p(st), _p(nn), ns, _p(fi), _p(K), _p(D), _p(V), _p(nk), ks,
+                                          int(n_left_f), float(nnratio), int(bool(check_ori)), _p(match), _p(nm)))
+    return nm, match
 
 
 def SearchByBoWKeyFrames(fv1, kps1, desc1, valid1, fv2, kps2, desc2, valid2, nnratio=0.75, check_ori=True, device=0):

@@ -158,6 +158,107 @@ int orbx_search_by_bow(int device, const uint32_t* kf_node_ids, const int32_t* k
   return n;
 }
 
+// SearchByBoW(KeyFrame, Frame) for the frames of an extraction batch (round 5): frame f = image first_image + f of the handle's
+// last batch, whose keypoints / descriptors AND feature vector (orbx_bow_transform_batch) stay in HBM; the key frame of pair f
+// comes from the host as strided arrays.  One upload, one launch per kernel for all pairs (blockIdx.y = pair), one download.
+// The search has no iteration: results are those of n_frames separate orbx_search_by_bow calls.
+int orbx_search_by_bow_batch(orbx_extractor* ex, int first_image, int n_frames, const uint32_t* kf_node_ids,
+                             const int32_t* kf_node_start, const int32_t* n_kf_nodes, int nodes_stride,
+                             const uint32_t* kf_feature_idx, const orbx_keypoint* kf_kps, const uint8_t* kf_desc,
+                             const uint8_t* kf_valid, const int32_t* n_kf, int kf_stride, int n_left_f, float nnratio,
+                             int check_orientation, int32_t* matches, int32_t* n_matches) {
+  if (!ex || n_frames < 0 || first_image < 0 || !n_kf_nodes || !n_kf || nodes_stride < 0 || kf_stride < 0 ||
+      (n_frames && (!matches || !n_matches)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_frames == 0) return 0;
+  if (ex->lastN <= 0 || first_image + n_frames > ex->lastN) return fail(ORBX_E_BADARG, "frames outside the handle's last batch");
+  if (!ex->d_bowWord.p || ex->bowImages < first_image + n_frames)
+    return fail(ORBX_E_BADARG, "orbx_bow_transform_batch has not run on the handle's last extraction");
+  const int F = n_frames, ns = std::max(nodes_stride, 1), ks = std::max(kf_stride, 1);
+  int maxNodes = 0, maxKf = 0;
+  for (int f = 0; f < F; f++) {
+    if (n_kf_nodes[f] < 0 || n_kf_nodes[f] > nodes_stride || n_kf[f] < 0 || n_kf[f] > kf_stride)
+      return fail(ORBX_E_BADARG, "n_kf_nodes[f] / n_kf[f] outside their strides");
+    maxNodes = std::max(maxNodes, n_kf_nodes[f]);
+    maxKf = std::max(maxKf, n_kf[f]);
+  }
+  if (maxNodes && (!kf_node_ids || !kf_node_start || !kf_feature_idx || !kf_kps || !kf_desc || !kf_valid))
+    return fail(ORBX_E_BADARG, "null key-frame array");
+  for (int f = 0; f < F; f++) {   // the same trust boundary as the one-shot call
+    const uint32_t* ids = kf_node_ids + (size_t)f * ns;
+    const int32_t* stt = kf_node_start + (size_t)f * (ns + 1);
+    const int nn = n_kf_nodes[f], nkl = nn ? stt[nn] : 0;
+    if (nkl < 0 || nkl > n_kf[f]) return fail(ORBX_E_BADARG, "feature vector larger than the key frame");
+    for (int j = 0; j < nn; j++)
+      if (stt[j] < 0 || stt[j] > stt[j + 1] || (j && ids[j] <= ids[j - 1]))
+        return fail(ORBX_E_BADARG, "keyframe feature vector: node ids must ascend and offsets must be monotone");
+    for (int i = 0; i < nkl; i++)
+      if (kf_feature_idx[(size_t)f * ks + i] >= (uint32_t)n_kf[f]) return fail(ORBX_E_BADARG, "keyframe feature index out of range");
+  }
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const int cap = ex->gmax.outCap;
+  std::vector<int> nF(F), cnt(3 * (size_t)F);
+  HIPC(hipStreamSynchronize(ex->stream));
+  HIPC(hipMemcpy(nF.data(), ex->d_nOut.p + first_image, (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(cnt.data(), ex->d_bowCounts.p + 3 * (size_t)first_image, 3 * (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  int maxNF = 0;
+  for (int f = 0; f < F; f++) {
+    nF[f] = std::min(std::max(nF[f], 0), cap);
+    maxNF = std::max(maxNF, nF[f]);
+  }
+  Pack pk;
+  std::vector<BowMatchArgs> frames(F);
+  auto rows = [&](const int32_t* n, int stride) { return (size_t)(F - 1) * stride + (size_t)n[F - 1]; };  // (last pair's padding unread)
+  const size_t oKn = pk.add(maxNodes ? kf_node_ids : nullptr, (size_t)F * ns * 4, rows(n_kf_nodes, ns) * 4);
+  const size_t oKs = pk.add(maxNodes ? kf_node_start : nullptr, (size_t)F * (ns + 1) * 4, ((size_t)(F - 1) * (ns + 1) + n_kf_nodes[F - 1] + 1) * 4);
+  const size_t oKf = pk.add(maxNodes ? kf_feature_idx : nullptr, (size_t)F * ks * 4, rows(n_kf, ks) * 4);
+  const size_t oKd = pk.add(maxNodes ? kf_desc : nullptr, (size_t)F * ks * 32, rows(n_kf, ks) * 32);
+  const size_t oKv = pk.add(maxNodes ? kf_valid : nullptr, (size_t)F * ks, rows(n_kf, ks));
+  const size_t oKk = pk.add(maxNodes ? kf_kps : nullptr, (size_t)F * ks * sizeof(orbx_keypoint), rows(n_kf, ks) * sizeof(orbx_keypoint));
+  const size_t oFr = pk.add(frames.data(), (size_t)F * sizeof(BowMatchArgs));
+  const size_t oOut = pk.add(nullptr, (size_t)F * ((size_t)cap + 1) * 4);   // per pair: result, then cap matches
+  const size_t oBin = pk.add(nullptr, (size_t)F * cap * 4), oFlags = pk.add(nullptr, (size_t)F * 36 * 4);
+  hipError_t e = pk.reserve();
+  if (e != hipSuccess) { pk.release(); return fail(ORBX_E_HIP, hipGetErrorString(e)); }
+  for (int f = 0; f < F; f++) {
+    BowMatchArgs a{};
+    const int img = first_image + f;
+    a.kfNodes = pk.ptr<uint32_t>(oKn) + (size_t)f * ns; a.kfStart = pk.ptr<int>(oKs) + (size_t)f * (ns + 1);
+    a.kfFeat = pk.ptr<uint32_t>(oKf) + (size_t)f * ks; a.nKfNodes = n_kf_nodes[f];
+    a.kfDesc = pk.ptr<uint32_t>(oKd) + (size_t)f * ks * 8; a.kfKps = pk.ptr<orbx_keypoint>(oKk) + (size_t)f * ks;
+    a.kfValid = pk.ptr<uint8_t>(oKv) + (size_t)f * ks;
+    a.fNodes = ex->d_bowNodes.p + (size_t)img * cap; a.fStart = ex->d_bowStart.p + (size_t)img * (cap + 1);
+    a.fFeat = ex->d_bowFeats.p + (size_t)img * cap; a.nFNodes = cnt[3 * f + 1];
+    a.fDesc = reinterpret_cast<const uint32_t*>(ex->d_desc.p + (size_t)img * cap * 32); a.fKps = ex->d_kps.p + (size_t)img * cap;
+    a.nF = nF[f]; a.nLeftF = n_left_f;
+    a.nnratio = nnratio; a.checkOri = check_orientation ? 1 : 0;
+    a.result = pk.ptr<int>(oOut) + (size_t)f * (cap + 1); a.match = a.result + 1;
+    a.bin = pk.ptr<int>(oBin) + (size_t)f * cap; a.flags = pk.ptr<int>(oFlags) + (size_t)f * 36;
+    frames[f] = a;
+  }
+  e = pk.commit();
+  if (e == hipSuccess) e = launch_bow_match_batch(pk.ptr<BowMatchArgs>(oFr), F, maxNodes, maxNF, check_orientation ? 1 : 0, nullptr);
+  int total = 0;
+  bool tooLarge = false;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOut, (size_t)F * ((size_t)cap + 1) * 4, &e);
+    if (e == hipSuccess)
+      for (int f = 0; f < F; f++) {
+        const int* r = reinterpret_cast<const int*>(h) + (size_t)f * (cap + 1);
+        if (r[0] < 0) tooLarge = true;
+        n_matches[f] = r[0];
+        std::memcpy(matches + (size_t)f * cap, r + 1, (size_t)nF[f] * 4);
+        for (int i = nF[f]; i < cap; i++) matches[(size_t)f * cap + i] = -1;
+        total += std::max(r[0], 0);
+      }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  if (tooLarge) return fail(ORBX_E_UNSUPPORTED, "a vocabulary node holds more than 4096 frame features");
+  return total;
+}
+
 namespace {
 // One attempt with candidate arrays of cand_cap entries; see search_by_projection_try.
 int search_for_initialization_try(const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const orbx_keypoint* kps2,

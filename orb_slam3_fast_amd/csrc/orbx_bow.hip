@@ -232,9 +232,22 @@ hipError_t launch_bow_transform(const BowArgs& a, int nimg, hipStream_t s) {
 // by the serial rule (first minimum; an equal later distance becomes the second).  The right-eye branch keeps the
 // reference's "|| true" (:363-365): no ratio test, and only inside "bestDist1 <= TH_LOW".
 constexpr int kBowNodeCap = 4096;  // frame features of one node tracked in LDS (a node above this: serial fallback on lane 0)
-__global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
+// Kernel-argument views: the one-shot call passes its argument block by value; orbx_search_by_bow_batch (round 5) launches every
+// kernel ONCE for all frames of an extraction batch with blockIdx.y = frame and the argument blocks in a device array.
+struct BowVal {
+  BowMatchArgs v;
+  __device__ __forceinline__ const BowMatchArgs& get() const { return v; }
+};
+struct BowOfArr {
+  const BowMatchArgs* p;
+  __device__ __forceinline__ const BowMatchArgs& get() const { return p[blockIdx.y]; }
+};
+template <class R>
+__global__ __launch_bounds__(64) void k_bow_match(R ar) {
+  const BowMatchArgs& a = ar.get();
   __shared__ uint8_t taken[kBowNodeCap];
   const int lane = threadIdx.x, ia = blockIdx.x;
+  if (ia >= a.nKfNodes || a.nFNodes <= 0) return;  // (batched launches are sized for the largest key frame)
   const uint32_t node = a.kfNodes[ia];
   int lo = 0, hi = a.nFNodes;
   while (lo < hi) {
@@ -331,7 +344,9 @@ __global__ __launch_bounds__(64) void k_bow_match(BowMatchArgs a) {
   if (lane == 0 && made) atomicAdd(&a.flags[0], made);
 }
 
-__global__ __launch_bounds__(256) void k_bow_vote(BowMatchArgs a) {  // rotHist[bin].push_back(bestIdxF), :336-346 / :367-377
+template <class R>
+__global__ __launch_bounds__(256) void k_bow_vote(R ar) {  // rotHist[bin].push_back(bestIdxF), :336-346 / :367-377
+  const BowMatchArgs& a = ar.get();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.nF) return;
   const int iKF = a.match[i];
@@ -345,7 +360,9 @@ __global__ __launch_bounds__(256) void k_bow_vote(BowMatchArgs a) {  // rotHist[
   atomicAdd(&a.flags[2 + bin], 1);
 }
 
-__global__ __launch_bounds__(256) void k_bow_cull(BowMatchArgs a) {  // :384-401 with ComputeThreeMaxima :1920-1955
+template <class R>
+__global__ __launch_bounds__(256) void k_bow_cull(R ar) {  // :384-401 with ComputeThreeMaxima :1920-1955
+  const BowMatchArgs& a = ar.get();
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   for (int i = 0; i < 30; i++) {
     const int s = a.flags[2 + i];
@@ -375,21 +392,43 @@ __global__ __launch_bounds__(256) void k_bow_cull(BowMatchArgs a) {  // :384-401
   const uint64_t m = __ballot(rem);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.flags[1], __popcll(m));
 }
-__global__ void k_bow_result(BowMatchArgs a) { a.result[0] = a.flags[32] ? -1 : a.flags[0] - a.flags[1]; }
-__global__ __launch_bounds__(256) void k_bow_match_reset(BowMatchArgs a) {
+template <class R>
+__global__ void k_bow_result(R ar) {
+  const BowMatchArgs& a = ar.get();
+  a.result[0] = a.flags[32] ? -1 : a.flags[0] - a.flags[1];
+}
+template <class R>
+__global__ __launch_bounds__(256) void k_bow_match_reset(R ar) {
+  const BowMatchArgs& a = ar.get();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < a.nF) a.match[i] = -1;
   if (i < 33) a.flags[i] = 0;
 }
 
 hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_bow_match_reset, dim3((max(a.nF, 33) + 255) / 256), dim3(256), 0, s, a);
-  if (a.nKfNodes > 0 && a.nFNodes > 0) hipLaunchKernelGGL(k_bow_match, dim3(a.nKfNodes), dim3(64), 0, s, a);
+  const BowVal r{a};
+  hipLaunchKernelGGL(k_bow_match_reset<BowVal>, dim3((max(a.nF, 33) + 255) / 256), dim3(256), 0, s, r);
+  if (a.nKfNodes > 0 && a.nFNodes > 0) hipLaunchKernelGGL(k_bow_match<BowVal>, dim3(a.nKfNodes), dim3(64), 0, s, r);
   if (a.checkOri && a.nF > 0) {
-    hipLaunchKernelGGL(k_bow_vote, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bow_cull, dim3((a.nF + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_bow_vote<BowVal>, dim3((a.nF + 255) / 256), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_bow_cull<BowVal>, dim3((a.nF + 255) / 256), dim3(256), 0, s, r);
   }
-  hipLaunchKernelGGL(k_bow_result, dim3(1), dim3(1), 0, s, a);
+  hipLaunchKernelGGL(k_bow_result<BowVal>, dim3(1), dim3(1), 0, s, r);
+  return hipGetLastError();
+}
+// SearchByBoW(KeyFrame, Frame) for every frame of a batch, one launch per kernel (blockIdx.y = frame): d_frames = device array of
+// nFrames argument blocks, maxKfNodes / maxNF the largest key-frame node count / frame keypoint count.
+hipError_t launch_bow_match_batch(const BowMatchArgs* d_frames, int nFrames, int maxKfNodes, int maxNF, int checkOri, hipStream_t s) {
+  if (nFrames <= 0) return hipSuccess;
+  const BowOfArr r{d_frames};
+  const dim3 nft((max(maxNF, 33) + 255) / 256, nFrames);
+  hipLaunchKernelGGL(k_bow_match_reset<BowOfArr>, nft, dim3(256), 0, s, r);
+  if (maxKfNodes > 0) hipLaunchKernelGGL(k_bow_match<BowOfArr>, dim3(maxKfNodes, nFrames), dim3(64), 0, s, r);
+  if (checkOri) {
+    hipLaunchKernelGGL(k_bow_vote<BowOfArr>, nft, dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_bow_cull<BowOfArr>, nft, dim3(256), 0, s, r);
+  }
+  hipLaunchKernelGGL(k_bow_result<BowOfArr>, dim3(1, nFrames), dim3(1), 0, s, r);
   return hipGetLastError();
 }
 

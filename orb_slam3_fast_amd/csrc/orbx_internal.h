@@ -210,6 +210,7 @@ struct BowMatchArgs {
   int* match; int* bin; int* flags; int* result;
 };
 hipError_t launch_bow_match(const BowMatchArgs& a, hipStream_t s);
+hipError_t launch_bow_match_batch(const BowMatchArgs* d_frames, int nFrames, int maxKfNodes, int maxNF, int checkOri, hipStream_t s);
 
 // Results of up to two images gathered into the handle's PINNED host block by one kernel (the single-frame host entries
 // orbx_extract / orbx_extract_stereo): counts and mono indices, then the first n_i keypoint records / descriptor rows of every

@@ -373,3 +373,47 @@ def test_hip_search_by_bow_matches_oracle(oracle, seed, n_left):
     n, m = orbx.SearchByBoW(kf0, _kps(ka), kd, kv, f0, _kps(fa), fd, n_left, 0.7, True)
     on, om = oracle.search_by_bow(kf0, kd, ka, kv, f0, fd, fa, n_left, 0.7, True)
     assert n == on and np.array_equal(m, om)
+
+
+@pytest.mark.gpu
+def test_hip_search_by_bow_batched_over_an_extraction_batch(oracle):
+    """VERDICT (round 4), item 5: SearchByBoW(KeyFrame, Frame) (src/ORBmatcher.cc:230-404) for the frames of an extraction batch in
+    one call -- the frames' keypoints, descriptors and feature vectors (ComputeBoW on the device) never leave HBM, every kernel
+    runs once for all pairs (blockIdx.y = pair).  Per pair the result is the oracle's and the one-shot call's: key frames of
+    different sizes (one without features), both orientation settings."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    cols = synth.make_vocabulary(10, 3, seed=21)
+    ovoc, voc = oracle.Vocabulary(10, 3, *cols), orbx.ORBVocabulary(10, 3, *cols)
+    w, h, F, lu = 512, 384, 4, 1
+    cur = np.stack([synth.mono_frame(w, h, 120 + i, 1) for i in range(F)])
+    ex = orbx.ORBextractor(700, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=F)
+    ex1 = orbx.ORBextractor(700, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    buf = DeviceBuffer.from_numpy(cur)
+    ex.extract_batch_device(buf.ptr.value, F, w, h, w, w * h)
+    voc.transform_batch(ex, lu)
+    rng = np.random.default_rng(5)
+    kfv, kk, kd, kv, frames = [], [], [], [], []
+    for f in range(F):
+        _, k, d = ex1(synth.mono_frame(w, h, 120 + f, 0))          # the key frame: the same stream one frame earlier
+        n = 0 if f == 1 else len(k) - 40 * f
+        k, d = k[:n], d[:n]
+        kfv.append(ovoc.transform(d, lu)[1] if n else (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32)))
+        kk.append(k); kd.append(d); kv.append((rng.random(n) < 0.8).astype(np.uint8))
+        _, fk, fd = ex.download(f)
+        frames.append((fk, fd, ovoc.transform(fd, lu)[1]))
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        nm, match = orbx.SearchByBoWBatch(ex, 0, kfv, kk, kd, kv, -1, ratio, ori)
+        total = 0
+        for f in range(F):
+            fk, fd, ffv = frames[f]
+            if len(kk[f]) == 0:
+                assert nm[f] == 0 and (match[f] == -1).all()
+                continue
+            on, om = oracle.search_by_bow(kfv[f], kd[f], kk[f]["angle"], kv[f], ffv, fd, fk["angle"], -1, ratio, ori)
+            assert nm[f] == on and np.array_equal(match[f, :len(fk)], om), (f, ratio, ori, nm[f], on)
+            assert (match[f, len(fk):] == -1).all()
+            n1, m1 = orbx.SearchByBoW(kfv[f], kk[f], kd[f], kv[f], ffv, fk, fd, -1, ratio, ori)
+            assert n1 == on and np.array_equal(m1, om)
+            total += on
+        assert total > 100

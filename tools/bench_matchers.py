@@ -197,3 +197,17 @@ for _ in range(reps):
 tb = (time.perf_counter() - t0) / reps * 1e3
 print("%-62s %12.3f   (%.3f ms per pair, %d matches in pair 0; Python packing of the %d host arrays included)"
       % ("SearchForInitialization, batch of %d pairs" % FB, tb, tb / FB, int(r[0][0]), FB))
+
+# batched SearchByBoW(KeyFrame, Frame) on the frames of an extraction batch (round 5): the frames' feature vectors were computed on
+# the device above (voc.transform_batch(exb, 4)); the key frame of every pair comes from the host
+voc.transform_batch(exb, 4)
+exb.sync()
+fn = lambda: orbx.SearchByBoWBatch(exb, 0, [kf_fv] * FB, [kp] * FB, [dp] * FB, [kvalid] * FB, -1, 0.7, True)
+for _ in range(3):
+    r = fn()
+t0 = time.perf_counter()
+for _ in range(reps):
+    r = fn()
+tb = (time.perf_counter() - t0) / reps * 1e3
+print("%-62s %12.3f   (%.3f ms per pair, %d matches in pair 0; Python packing of the %d key frames included)"
+      % ("SearchByBoW(KeyFrame, Frame), batch of %d pairs" % FB, tb, tb / FB, int(r[0][0]), FB))
