@@ -641,6 +641,26 @@ int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps
                                             int n_right, float min_x, float min_y, float max_x, float max_y,
                                             const orbx_projected_point* points, const float* uv_right, int n_points,
                                             int check_orientation, uint8_t* occupied, int32_t* match);
+/* The two stereo-fisheye flavours above on the two-camera frames of an extraction BATCH: frame f = left image first_left + f and
+ * right image first_right + f of `ex`'s last batch (keypoints / descriptors stay in HBM; scale factors = the handle's).  Points of
+ * frame f are [f * points_stride .. + n_points[f]) of map_points / map_points_right (points / uv_right [.][2] for the frame
+ * flavour); left_to_right / right_to_left are [n_frames][cap] (mvLeftToRightMatch / mvRightToLeftMatch of every frame, cap =
+ * orbx_batch_results_device's cap); occupied_in (may be NULL = all free) / occupied / match are [n_frames][2 cap], row = [left
+ * keypoints | right keypoints] like the one-shot calls' N = Nleft + Nright arrays; n_matches [n_frames].  Every kernel of the
+ * chain runs ONCE for all frames and both cameras with a fixed number of fixed-point rounds enqueued blindly; a frame that needs
+ * more (or larger candidate / writer lists) is redone through the one-shot path: results are those of n_frames separate calls.
+ * Returns the total number of matches or a negative error. */
+int orbx_search_by_projection_fisheye_batch(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x, float min_y,
+                                            float max_x, float max_y, const orbx_map_point_view* map_points,
+                                            const orbx_map_point_right* map_points_right, const int32_t* n_map_points,
+                                            int points_stride, float th, int far_points, float th_far_points, float nnratio,
+                                            const int32_t* left_to_right, const int32_t* right_to_left, const uint8_t* occupied_in,
+                                            uint8_t* occupied, int32_t* match, int32_t* n_matches);
+int orbx_search_by_projection_frame_fisheye_batch(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x,
+                                                  float min_y, float max_x, float max_y, const orbx_projected_point* points,
+                                                  const float* uv_right, const int32_t* n_points, int points_stride,
+                                                  int check_orientation, const uint8_t* occupied_in, uint8_t* occupied,
+                                                  int32_t* match, int32_t* n_matches);
 
 
 /* ---- measurement ------------------------------------------------------------------------------------ */

@@ -119,6 +119,8 @@ def lib():
         L.orbx_bow_results_device.argtypes = [vp] + [C.POINTER(vp)] * 6 + [C.POINTER(i)]
         L.orbx_bow_download.argtypes = [vp, i, vp, vp, C.POINTER(i), vp, vp, vp, C.POINTER(i), i]
         L.orbx_search_by_bow.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, i, vp, vp, i, i, f, i, vp]
+        L.orbx_search_by_projection_fisheye_batch.argtypes = [vp, i, i, i, f, f, f, f, vp, vp, vp, i, f, i, f, f, vp, vp, vp, vp, vp, vp]
+        L.orbx_search_by_projection_frame_fisheye_batch.argtypes = [vp, i, i, i, f, f, f, f, vp, vp, vp, i, i, vp, vp, vp, vp]
         L.orbx_search_by_bow_batch.argtypes = [vp, i, i, vp, vp, vp, i, vp, vp, vp, vp, vp, i, i, f, i, vp, vp]
         L.orbx_search_by_projection_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, i, vp, vp, i, f, i, f, f, vp, vp, vp, vp]
         L.orbx_search_by_projection_frame_fisheye.argtypes = [i, vp, vp, i, i, f, f, f, f, vp, vp, i, i, vp, vp]
@@ -1078,6 +1080,41 @@ class ORBmatcher:
             self.device, _p(k), _p(d), int(n_left), len(k) - int(n_left), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp),
             _p(uv), len(pp), int(self.mbCheckOrientation), _p(occ), _p(match)))
         return n, match, occ
+
+    def SearchByProjectionFisheyeBatch(self, ex, first_left, first_right, n_frames, bounds, mapPoints, mapPointsRight, n_points,
+                                       leftToRight, rightToLeft, occupied=None, th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """SearchByProjectionFisheye on the two-camera frames of ex's last extraction batch in one call
+        (orbx_search_by_projection_fisheye_batch): frame f = images first_left + f / first_right + f; mapPoints / mapPointsRight
+        [n_frames][stride], leftToRight / rightToLeft [n_frames][cap], occupied [n_frames][2 cap] (rows [left | right]).
+        Returns (n_matches [n_frames], match [n_frames][2 cap], occupied [n_frames][2 cap])."""
+        cap = ex.capacity
+        mp = np.ascontiguousarray(mapPoints, MP_DTYPE).reshape(n_frames, -1)
+        mr = np.ascontiguousarray(mapPointsRight, MPR_DTYPE).reshape(n_frames, -1)
+        npts = np.ascontiguousarray(n_points, np.int32)
+        l2r = np.ascontiguousarray(leftToRight, np.int32).reshape(n_frames, cap)
+        r2l = np.ascontiguousarray(rightToLeft, np.int32).reshape(n_frames, cap)
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, 2 * cap)
+        occ, match, nm = np.zeros((n_frames, 2 * cap), np.uint8), np.full((n_frames, 2 * cap), -1, np.int32), np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_fisheye_batch(
+            ex._h, int(first_left), int(first_right), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(mp), _p(mr), _p(npts),
+            mp.shape[1], float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, _p(l2r), _p(r2l),
+            None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
+
+    def SearchByProjectionFrameFisheyeBatch(self, ex, first_left, first_right, n_frames, bounds, points, uvRight, n_points, occupied=None):
+        """SearchByProjectionFrameFisheye on the two-camera frames of ex's last extraction batch in one call
+        (orbx_search_by_projection_frame_fisheye_batch): points [n_frames][stride] PP_DTYPE, uvRight [n_frames][stride][2].
+        Returns (n_matches, match [n_frames][2 cap], occupied [n_frames][2 cap])."""
+        cap = ex.capacity
+        pp = np.ascontiguousarray(points, PP_DTYPE).reshape(n_frames, -1)
+        uv = np.ascontiguousarray(uvRight, np.float32).reshape(n_frames, pp.shape[1], 2)
+        npts = np.ascontiguousarray(n_points, np.int32)
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, 2 * cap)
+        occ, match, nm = np.zeros((n_frames, 2 * cap), np.uint8), np.full((n_frames, 2 * cap), -1, np.int32), np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_frame_fisheye_batch(
+            ex._h, int(first_left), int(first_right), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp), _p(uv), _p(npts),
+            pp.shape[1], int(self.mbCheckOrientation), None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
 
     def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds2, vbPrevMatched, windowSize=10):
         """src/ORBmatcher.cc:618-764.  kps = mvKeysUn of F1 / F2, bounds2 = (mnMinX, mnMinY, mnMaxX, mnMaxY)

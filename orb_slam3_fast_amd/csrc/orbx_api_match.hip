@@ -1339,4 +1339,247 @@ int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps
                                            0, 0.f, 0.f, check_orientation, nullptr, nullptr, occupied, match);
 }
 
+namespace {
+// The two stereo-fisheye SearchByProjection flavours on the two-camera frames of an extraction batch (round 5; the last one-shot
+// matchers of VERDICT round 4, item 5).  Frame f = left image first_left + f and right image first_right + f of the handle's last
+// batch; their keypoints / descriptors are laid side by side on the device ([left | right], k_fe_concat) and never visit the host.
+// One upload (views / points of both cameras, left-right matches, occupancy), one launch per kernel for all frames and cameras
+// (launch_proj_fisheye_batch), kBlind fixed-point rounds without a convergence-flag read, one download.  A frame whose candidate
+// lists or writer lists overflowed or whose writes did not settle is redone through the one-shot path.
+int proj_fisheye_batch_impl(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x, float min_y, float max_x,
+                            float max_y, int mode, const orbx_map_point_view* viewsL, const orbx_map_point_view* viewsR,
+                            const orbx_projected_point* ptsL, const orbx_projected_point* ptsR, const int32_t* n_points, int stride,
+                            float th, int far_points, float th_far, float nnratio, int check_ori, const int32_t* l2r,
+                            const int32_t* r2l, const uint8_t* occupied_in, uint8_t* occupied, int32_t* match, int32_t* n_matches) {
+  const int F = n_frames, cap = ex->gmax.outCap, nlevels = ex->prm.nlevels, st = std::max(stride, 1);
+  int maxPts = 0;
+  for (int f = 0; f < F; f++) maxPts = std::max(maxPts, n_points[f]);
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  std::vector<int> nL(F), nR(F);
+  HIPC(hipStreamSynchronize(ex->stream));
+  HIPC(hipMemcpy(nL.data(), ex->d_nOut.p + first_left, (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  HIPC(hipMemcpy(nR.data(), ex->d_nOut.p + first_right, (size_t)F * sizeof(int), hipMemcpyDeviceToHost));
+  int maxN = 0;
+  for (int f = 0; f < F; f++) {
+    nL[f] = std::min(std::max(nL[f], 0), cap);
+    nR[f] = std::min(std::max(nR[f], 0), cap);
+    maxN = std::max(maxN, nL[f] + nR[f]);
+    if (mode == 0) {
+      for (int i = 0; i < nL[f]; i++)
+        if (l2r[(size_t)f * cap + i] < -1 || l2r[(size_t)f * cap + i] >= nR[f]) return fail(ORBX_E_BADARG, "left_to_right entry out of range");
+      for (int i = 0; i < nR[f]; i++)
+        if (r2l[(size_t)f * cap + i] < -1 || r2l[(size_t)f * cap + i] >= nL[f]) return fail(ORBX_E_BADARG, "right_to_left entry out of range");
+    }
+  }
+  static const int capEnv = getenv("ORBX_PROJ_CAND_CAP") ? atoi(getenv("ORBX_PROJ_CAND_CAP")) : 0;
+  static const int kBlind = getenv("ORBX_PROJ_BLIND") ? std::min(48, std::max(1, atoi(getenv("ORBX_PROJ_BLIND")))) : 16;
+  const int nm = std::max(maxPts, 1), candCap = capEnv > 0 ? capEnv : nm * 96, n2c = 2 * cap;
+  const size_t ptBytes = mode == 0 ? sizeof(orbx_map_point_view) : sizeof(orbx_projected_point);
+  constexpr int kFlags = 40 + 48;
+  Pack pk;
+  std::vector<ProjArgs> sides(2 * (size_t)F);
+  std::vector<ProjFeArgs> frames(F);
+  std::vector<uint8_t> occ0;
+  if (!occupied_in) occ0.assign((size_t)F * n2c, 0);
+  const size_t ptsRead = ((size_t)(F - 1) * st + (size_t)n_points[F - 1]) * ptBytes;
+  const void* srcL = mode == 0 ? (const void*)viewsL : (const void*)ptsL;
+  const void* srcR = mode == 0 ? (const void*)viewsR : (const void*)ptsR;
+  const size_t oPL = pk.add(maxPts ? srcL : nullptr, (size_t)F * st * ptBytes, ptsRead);
+  const size_t oPR = pk.add(maxPts ? srcR : nullptr, (size_t)F * st * ptBytes, ptsRead);
+  const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
+  const size_t oA12 = pk.add(mode == 0 ? l2r : nullptr, (size_t)F * cap * 4), oA21 = pk.add(mode == 0 ? r2l : nullptr, (size_t)F * cap * 4);
+  const size_t oSd = pk.add(sides.data(), sides.size() * sizeof(ProjArgs)), oFr = pk.add(frames.data(), (size_t)F * sizeof(ProjFeArgs));
+  const size_t oOcc = pk.add(occupied_in ? occupied_in : occ0.data(), (size_t)F * n2c);
+  const size_t oMt = pk.add(nullptr, (size_t)F * n2c * sizeof(int)), oRes = pk.add(nullptr, (size_t)F * 2 * sizeof(int));
+  const size_t oSideRes = pk.add(nullptr, (size_t)F * 4 * sizeof(int)), oFlags = pk.add(nullptr, (size_t)F * kFlags * sizeof(int));
+  const size_t outBytes = oFlags + (size_t)F * kFlags * sizeof(int) - oOcc;
+  auto per = [&](size_t ints) { return pk.add(nullptr, (size_t)F * ints * sizeof(int)); };
+  const size_t oKc = pk.add(nullptr, (size_t)F * n2c * sizeof(orbx_keypoint)), oDc = pk.add(nullptr, (size_t)F * n2c * 32);
+  const size_t cs = 64 * 48 + 4;
+  size_t oCs[2], oCi[2], oMd[2], oM21[2], oM12[2], oCo[2], oCx[2], oCd[2];
+  for (int sd = 0; sd < 2; sd++) {
+    oCs[sd] = per(cs); oCi[sd] = per(cap); oMd[sd] = per(cap); oM21[sd] = per(cap); oM12[sd] = per(4);
+    oCo[sd] = per((size_t)nm + 4); oCx[sd] = per(candCap); oCd[sd] = per(candCap);
+  }
+  const size_t oW0 = per(4 * (size_t)nm), oW1 = per(4 * (size_t)nm);
+  const size_t oWl0 = per((size_t)n2c * kFeWriters), oWl1 = per((size_t)n2c * kFeWriters), oWl2 = per((size_t)n2c * kFeWriters);
+  const size_t oWc0 = per(n2c), oWc1 = per(n2c), oWc2 = per(n2c);
+  hipError_t e = pk.reserve();
+  if (e != hipSuccess) { pk.release(); return fail(ORBX_E_HIP, hipGetErrorString(e)); }
+  for (int f = 0; f < F; f++) {
+    orbx_keypoint* kc = pk.ptr<orbx_keypoint>(oKc) + (size_t)f * n2c;
+    uint8_t* dc = pk.ptr<uint8_t>(oDc) + (size_t)f * n2c * 32;
+    uint8_t* occ = pk.ptr<uint8_t>(oOcc) + (size_t)f * n2c;
+    int* mt = pk.ptr<int>(oMt) + (size_t)f * n2c;
+    for (int sd = 0; sd < 2; sd++) {
+      ProjArgs a{};
+      const int ns = sd ? nR[f] : nL[f], first = sd ? nL[f] : 0;
+      int* sideRes = pk.ptr<int>(oSideRes) + (size_t)f * 4 + 2 * sd;
+      a.grid.k2 = kc + first; a.grid.n2 = ns; a.grid.n1 = 0;
+      a.grid.minX = min_x; a.grid.minY = min_y;
+      a.grid.invW = 64.f / (max_x - min_x);
+      a.grid.invH = 48.f / (max_y - min_y);
+      a.grid.cellStart = pk.ptr<int>(oCs[sd]) + (size_t)f * cs; a.grid.cellItems = pk.ptr<int>(oCi[sd]) + (size_t)f * cap;
+      a.grid.matchedDist = pk.ptr<int>(oMd[sd]) + (size_t)f * cap; a.grid.matches21 = pk.ptr<int>(oM21[sd]) + (size_t)f * cap;
+      a.grid.matches12 = pk.ptr<int>(oM12[sd]) + (size_t)f * 4; a.grid.result = sideRes;
+      a.grid.candOff = pk.ptr<int>(oCo[sd]) + (size_t)f * (nm + 4); a.grid.candCap = 1 << 30;
+      a.desc = dc + (size_t)first * 32; a.uRight = nullptr;   // no mvuRight gate when F.Nleft != -1 (:90, :1667)
+      a.scale = pk.ptr<float>(oSf);
+      const size_t oP = sd ? oPR : oPL;
+      a.mps = mode == 0 ? pk.ptr<orbx_map_point_view>(oP) + (size_t)f * st : nullptr;
+      a.pts = mode == 1 ? pk.ptr<orbx_projected_point>(oP) + (size_t)f * st : nullptr;
+      a.nmp = n_points[f]; a.mode = mode; a.checkOri = check_ori;
+      a.th = sd ? 1.0f : th;   // the right-camera radius is not scaled by th (:144)
+      a.thFar = th_far; a.nnratio = nnratio; a.far = far_points;
+      a.occupied = occ + first; a.match = mt + first;
+      a.candOff = a.grid.candOff; a.result = sideRes; a.candCap = candCap;
+      a.candIdx = pk.ptr<int>(oCx[sd]) + (size_t)f * candCap; a.candDist = pk.ptr<int>(oCd[sd]) + (size_t)f * candCap;
+      sides[2 * (size_t)f + sd] = a;
+    }
+    ProjFeArgs q{};
+    const ProjArgs &sl = sides[2 * (size_t)f], &sr = sides[2 * (size_t)f + 1];
+    q.offL = sl.candOff; q.idxL = sl.candIdx; q.distL = sl.candDist;
+    q.offR = sr.candOff; q.idxR = sr.candIdx; q.distR = sr.candDist;
+    q.nLeft = nL[f]; q.n = nL[f] + nR[f]; q.nmp = n_points[f]; q.mode = mode; q.checkOri = check_ori; q.nnratio = nnratio;
+    q.mps = sl.mps; q.pts = sl.pts; q.kps = kc;
+    q.l2r = pk.ptr<int>(oA12) + (size_t)f * cap; q.r2l = pk.ptr<int>(oA21) + (size_t)f * cap;
+    q.occupied = occ; q.match = mt; q.result = pk.ptr<int>(oRes) + (size_t)f * 2;
+    q.writes[0] = pk.ptr<int4>(oW0) + (size_t)f * nm; q.writes[1] = pk.ptr<int4>(oW1) + (size_t)f * nm;
+    q.writers[0] = pk.ptr<int>(oWl0) + (size_t)f * n2c * kFeWriters; q.writers[1] = pk.ptr<int>(oWl1) + (size_t)f * n2c * kFeWriters;
+    q.writers[2] = pk.ptr<int>(oWl2) + (size_t)f * n2c * kFeWriters;
+    q.nwriters[0] = pk.ptr<int>(oWc0) + (size_t)f * n2c; q.nwriters[1] = pk.ptr<int>(oWc1) + (size_t)f * n2c;
+    q.nwriters[2] = pk.ptr<int>(oWc2) + (size_t)f * n2c;
+    q.flags = pk.ptr<int>(oFlags) + (size_t)f * kFlags;
+    frames[f] = q;
+  }
+  e = pk.commit();
+  if (e == hipSuccess) e = hipMemsetAsync(pk.ptr<int>(oSideRes), 0, (size_t)F * 4 * sizeof(int), nullptr);
+  FeConcatArgs ca{ex->d_kps.p, ex->d_desc.p, ex->d_nOut.p, first_left, first_right, cap, pk.ptr<orbx_keypoint>(oKc), pk.ptr<uint8_t>(oDc)};
+  if (e == hipSuccess) e = launch_fe_concat(ca, F, nullptr);
+  if (e == hipSuccess)
+    e = launch_proj_fisheye_batch(pk.ptr<ProjArgs>(oSd), pk.ptr<ProjFeArgs>(oFr), F, maxPts, maxN, mode, check_ori, kBlind, nullptr);
+  std::vector<int> redo;
+  if (e == hipSuccess) {
+    const uint8_t* h = pk.fetch(oOcc, outBytes, &e);  // synchronises
+    if (e == hipSuccess)
+      for (int f = 0; f < F; f++) {
+        const int n = nL[f] + nR[f];
+        int res[2], sres[4];
+        std::memcpy(res, h + (oRes - oOcc) + (size_t)f * 2 * sizeof(int), sizeof res);
+        std::memcpy(sres, h + (oSideRes - oOcc) + (size_t)f * 4 * sizeof(int), sizeof sres);
+        const int* fl = reinterpret_cast<const int*>(h + (oFlags - oOcc)) + (size_t)f * kFlags;
+        if (n_points[f] > 0 && n > 0 && (std::max(sres[1], sres[3]) > candCap || fl[1] || fl[40 + kBlind - 1])) {
+          redo.push_back(f);
+          continue;
+        }
+        std::memcpy(occupied + (size_t)f * n2c, h + (size_t)f * n2c, n2c);
+        std::memcpy(match + (size_t)f * n2c, h + (oMt - oOcc) + (size_t)f * n2c * sizeof(int), (size_t)n * sizeof(int));
+        for (int i = n; i < n2c; i++) match[(size_t)f * n2c + i] = -1;
+        n_matches[f] = (n_points[f] > 0 && n > 0) ? res[0] : 0;
+      }
+  }
+  pk.release();
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  for (int f : redo) {   // the one-shot path on a host copy of the frame's two cameras
+    const int n = nL[f] + nR[f];
+    std::vector<orbx_keypoint> k(std::max(n, 1));
+    std::vector<uint8_t> d((size_t)std::max(n, 1) * 32);
+    HIPC(hipMemcpy(k.data(), ex->d_kps.p + (size_t)(first_left + f) * cap, (size_t)nL[f] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(k.data() + nL[f], ex->d_kps.p + (size_t)(first_right + f) * cap, (size_t)nR[f] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(d.data(), ex->d_desc.p + (size_t)(first_left + f) * cap * 32, (size_t)nL[f] * 32, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(d.data() + (size_t)nL[f] * 32, ex->d_desc.p + (size_t)(first_right + f) * cap * 32, (size_t)nR[f] * 32, hipMemcpyDeviceToHost));
+    uint8_t* occ = occupied + (size_t)f * n2c;
+    int32_t* mt = match + (size_t)f * n2c;
+    if (occupied_in) std::memcpy(occ, occupied_in + (size_t)f * n2c, n2c); else std::memset(occ, 0, n2c);
+    for (int i = 0; i < n2c; i++) mt[i] = -1;
+    rc = search_by_projection_fisheye_impl(ex->device, k.data(), d.data(), nL[f], nR[f], min_x, min_y, max_x, max_y, ex->scale.data(),
+                                           nlevels, mode == 0 ? viewsL + (size_t)f * st : nullptr, mode == 0 ? viewsR + (size_t)f * st : nullptr,
+                                           mode == 1 ? ptsL + (size_t)f * st : nullptr, mode == 1 ? ptsR + (size_t)f * st : nullptr,
+                                           n_points[f], th, far_points, th_far, nnratio, check_ori,
+                                           mode == 0 ? l2r + (size_t)f * cap : nullptr, mode == 0 ? r2l + (size_t)f * cap : nullptr, occ, mt);
+    if (rc < 0) return rc;
+    n_matches[f] = rc;
+  }
+  int total = 0;
+  for (int f = 0; f < F; f++) total += n_matches[f];
+  return total;
+}
+
+int fisheye_batch_checks(orbx_extractor* ex, int first_left, int first_right, int n_frames, const int32_t* n_points, int stride,
+                         const void* occupied, const void* match, const void* n_matches) {
+  if (!ex || n_frames < 0 || first_left < 0 || first_right < 0 || !n_points || stride < 0 || (n_frames && (!occupied || !match || !n_matches)))
+    return fail(ORBX_E_BADARG, "bad argument");
+  if (n_frames && (ex->lastN <= 0 || first_left + n_frames > ex->lastN || first_right + n_frames > ex->lastN))
+    return fail(ORBX_E_BADARG, "frames outside the handle's last batch");
+  for (int f = 0; f < n_frames; f++) {
+    if (n_points[f] < 0 || n_points[f] > stride) return fail(ORBX_E_BADARG, "n_points[f] outside [0, points_stride]");
+    if (n_points[f] > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 points in a frame");
+  }
+  return ORBX_OK;
+}
+}  // namespace
+
+int orbx_search_by_projection_fisheye_batch(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x, float min_y,
+                                            float max_x, float max_y, const orbx_map_point_view* map_points,
+                                            const orbx_map_point_right* map_points_right, const int32_t* n_map_points,
+                                            int points_stride, float th, int far_points, float th_far_points, float nnratio,
+                                            const int32_t* left_to_right, const int32_t* right_to_left, const uint8_t* occupied_in,
+                                            uint8_t* occupied, int32_t* match, int32_t* n_matches) {
+  int rc = fisheye_batch_checks(ex, first_left, first_right, n_frames, n_map_points, points_stride, occupied, match, n_matches);
+  if (rc != ORBX_OK) return rc;
+  if (n_frames == 0) return 0;
+  if (!left_to_right || !right_to_left) return fail(ORBX_E_BADARG, "null left / right match arrays");
+  const int nlevels = ex->prm.nlevels, st = std::max(points_stride, 1);
+  int maxPts = 0;
+  for (int f = 0; f < n_frames; f++) maxPts = std::max(maxPts, n_map_points[f]);
+  if (maxPts && (!map_points || !map_points_right)) return fail(ORBX_E_BADARG, "null map points");
+  // the right camera as a second list of views, exactly as the one-shot call builds it (:141-144)
+  std::vector<orbx_map_point_view> left((size_t)n_frames * st), right((size_t)n_frames * st);
+  for (int f = 0; f < n_frames; f++)
+    for (int i = 0; i < n_map_points[f]; i++) {
+      const size_t o = (size_t)f * st + i;
+      const orbx_map_point_right& r = map_points_right[o];
+      left[o] = map_points[o];
+      right[o] = map_points[o];
+      if ((left[o].in_view && (left[o].predicted_level < 0 || left[o].predicted_level >= nlevels)) ||
+          (r.in_view_r && (r.predicted_level_r < -1 || r.predicted_level_r >= nlevels)))
+        return fail(ORBX_E_BADARG, "map point with a predicted level outside [0, nlevels)");
+      if (!left[o].in_view) left[o].predicted_level = 0;
+      right[o].proj_x = map_points[o].proj_xr;
+      right[o].proj_y = r.proj_yr;
+      right[o].view_cos = r.view_cos_r;
+      right[o].predicted_level = r.predicted_level_r < 0 ? 0 : r.predicted_level_r;
+      right[o].in_view = (r.in_view_r && r.predicted_level_r != -1) ? 1 : 0;
+    }
+  return proj_fisheye_batch_impl(ex, first_left, first_right, n_frames, min_x, min_y, max_x, max_y, 0, left.data(), right.data(), nullptr,
+                                 nullptr, n_map_points, points_stride, th, far_points, th_far_points, nnratio, 0, left_to_right,
+                                 right_to_left, occupied_in, occupied, match, n_matches);
+}
+
+int orbx_search_by_projection_frame_fisheye_batch(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x,
+                                                  float min_y, float max_x, float max_y, const orbx_projected_point* points,
+                                                  const float* uv_right, const int32_t* n_points, int points_stride,
+                                                  int check_orientation, const uint8_t* occupied_in, uint8_t* occupied,
+                                                  int32_t* match, int32_t* n_matches) {
+  int rc = fisheye_batch_checks(ex, first_left, first_right, n_frames, n_points, points_stride, occupied, match, n_matches);
+  if (rc != ORBX_OK) return rc;
+  if (n_frames == 0) return 0;
+  const int st = std::max(points_stride, 1);
+  int maxPts = 0;
+  for (int f = 0; f < n_frames; f++) maxPts = std::max(maxPts, n_points[f]);
+  if (maxPts && (!points || !uv_right)) return fail(ORBX_E_BADARG, "null points");
+  std::vector<orbx_projected_point> right((size_t)n_frames * st);
+  for (int f = 0; f < n_frames; f++)
+    for (int i = 0; i < n_points[f]; i++) {
+      const size_t o = (size_t)f * st + i;
+      right[o] = points[o];
+      right[o].u = uv_right[2 * o];
+      right[o].v = uv_right[2 * o + 1];
+    }
+  return proj_fisheye_batch_impl(ex, first_left, first_right, n_frames, min_x, min_y, max_x, max_y, 1, nullptr, nullptr, points,
+                                 right.data(), n_points, points_stride, 1.0f, 0, 0.f, 0.f, check_orientation, nullptr, nullptr,
+                                 occupied_in, occupied, match, n_matches);
+}
+
 }  // extern "C"

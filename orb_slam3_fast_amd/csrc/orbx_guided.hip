@@ -1279,7 +1279,19 @@ __device__ __forceinline__ void fe_best2(const ProjFeArgs& a, int prev, int roun
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int round_no) {
+// Kernel-argument views of the stereo-fisheye resolve (round 5): by value for the one-shot calls, frame blockIdx.y of a device
+// array for orbx_search_by_projection[_frame]_fisheye_batch.
+struct FeVal {
+  ProjFeArgs v;
+  __device__ __forceinline__ const ProjFeArgs& get() const { return v; }
+};
+struct FeOfArr {
+  const ProjFeArgs* p;
+  __device__ __forceinline__ const ProjFeArgs& get() const { return p[blockIdx.y]; }
+};
+template <class R>
+__global__ __launch_bounds__(256) void k_proj_round_fe(R ar, int round_no) {
+  const ProjFeArgs& a = ar.get();
   const int lane = threadIdx.x & 63;
   const int im = blockIdx.x * 4 + (threadIdx.x >> 6);
   // writer lists rotate through three buffers: round r reads [r % 3], appends to [(r + 1) % 3] and clears the counts of
@@ -1385,7 +1397,9 @@ __global__ __launch_bounds__(256) void k_proj_round_fe(ProjFeArgs a, int round_n
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_reset_fe(ProjFeArgs a) {  // before round 0: empty writer lists, no matches
+template <class R>
+__global__ __launch_bounds__(256) void k_proj_reset_fe(R ar) {  // before round 0: empty writer lists, no matches
+  const ProjFeArgs& a = ar.get();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
     a.nwriters[1][i] = 0;
     a.match[i] = -1;
@@ -1402,7 +1416,9 @@ __device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
   return bin;
 }
 
-__global__ __launch_bounds__(256) void k_proj_assign_fe(ProjFeArgs a, int last) {  // last writer wins every slot
+template <class R>
+__global__ __launch_bounds__(256) void k_proj_assign_fe(R ar, int last) {  // last writer wins every slot
+  const ProjFeArgs& a = ar.get();
   const int im = blockIdx.x * 256 + threadIdx.x;
   int nw = 0;
   if (im < a.nmp) {
@@ -1425,14 +1441,18 @@ __global__ __launch_bounds__(256) void k_proj_assign_fe(ProjFeArgs a, int last) 
   if ((threadIdx.x & 63) == 0 && nw) atomicAdd(&a.flags[2], nw);
 }
 
-__global__ __launch_bounds__(256) void k_proj_occ_fe(ProjFeArgs a) {
+template <class R>
+__global__ __launch_bounds__(256) void k_proj_occ_fe(R ar) {
+  const ProjFeArgs& a = ar.get();
   for (int k = blockIdx.x * 256 + threadIdx.x; k < a.n; k += gridDim.x * 256) {
     const int im = a.match[k];
     if (im >= 0) a.occupied[k] = a.mode == 0 ? a.mps[im].has_observations : a.pts[im].has_observations;
   }
 }
 
-__global__ __launch_bounds__(256) void k_proj_cull_fe(ProjFeArgs a, int last) {
+template <class R>
+__global__ __launch_bounds__(256) void k_proj_cull_fe(R ar, int last) {
+  const ProjFeArgs& a = ar.get();
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   for (int i = 0; i < 30; i++) {
     const int s = a.flags[4 + i];
@@ -1469,21 +1489,49 @@ __global__ __launch_bounds__(256) void k_proj_cull_fe(ProjFeArgs a, int last) {
   if ((threadIdx.x & 63) == 0 && rem) atomicAdd(&a.flags[3], rem);
 }
 
-__global__ void k_proj_result_fe(ProjFeArgs a) { a.result[0] = a.flags[2] - a.flags[3]; }
+template <class R>
+__global__ void k_proj_result_fe(R ar) {
+  const ProjFeArgs& a = ar.get();
+  a.result[0] = a.flags[2] - a.flags[3];
+}
 
 hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s) {
   if (a.nmp <= 0) return hipSuccess;
-  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset_fe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  if (first_round == 0) hipLaunchKernelGGL(k_proj_reset_fe<FeVal>, dim3((a.n + 255) / 256), dim3(256), 0, s, FeVal{a});
   for (int r = first_round; r < first_round + rounds; r++)
-    hipLaunchKernelGGL(k_proj_round_fe, dim3((a.nmp + 3) / 4), dim3(256), 0, s, a, r);
+    hipLaunchKernelGGL(k_proj_round_fe<FeVal>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, FeVal{a}, r);
   return hipGetLastError();
 }
 hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s) {
   const int last = (last_round & 1) ^ 1;  // round r wrote writes[(r & 1) ^ 1]
-  hipLaunchKernelGGL(k_proj_assign_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
-  hipLaunchKernelGGL(k_proj_occ_fe, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-  if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull_fe, dim3((a.nmp + 255) / 256), dim3(256), 0, s, a, last);
-  hipLaunchKernelGGL(k_proj_result_fe, dim3(1), dim3(1), 0, s, a);
+  hipLaunchKernelGGL(k_proj_assign_fe<FeVal>, dim3((a.nmp + 255) / 256), dim3(256), 0, s, FeVal{a}, last);
+  hipLaunchKernelGGL(k_proj_occ_fe<FeVal>, dim3((a.n + 255) / 256), dim3(256), 0, s, FeVal{a});
+  if (a.mode == 1 && a.checkOri) hipLaunchKernelGGL(k_proj_cull_fe<FeVal>, dim3((a.nmp + 255) / 256), dim3(256), 0, s, FeVal{a}, last);
+  hipLaunchKernelGGL(k_proj_result_fe<FeVal>, dim3(1), dim3(1), 0, s, FeVal{a});
+  return hipGetLastError();
+}
+// The stereo-fisheye SearchByProjection chain for every frame of a batch, one launch per kernel.  d_sides: 2 * nFrames per-camera
+// argument blocks (frame f: left = 2 f, right = 2 f + 1) for the grids / candidate lists (the pinhole batch's kernels with
+// blockIdx.y = side), d_frames: nFrames resolve blocks; `rounds` blind fixed-point rounds, then assignment / occupancy / cull.
+hipError_t launch_proj_fisheye_batch(const ProjArgs* d_sides, const ProjFeArgs* d_frames, int nFrames, int maxPts, int maxN, int mode,
+                                     int checkOri, int rounds, hipStream_t s) {
+  if (nFrames <= 0) return hipSuccess;
+  const int P = std::max(maxPts, 1);
+  const dim3 oneS(1, 2 * nFrames), pts4S((P + 3) / 4, 2 * nFrames);
+  const ProjRef<true> rs{d_sides};
+  hipLaunchKernelGGL(k_init_grid<GridOfProj>, oneS, dim3(kGridThreads), 0, s, GridOfProj{d_sides});
+  hipLaunchKernelGGL(k_proj_cands<true>, pts4S, dim3(256), 0, s, rs, 0);
+  hipLaunchKernelGGL(k_init_scan<ScanOfProj>, oneS, dim3(256), 0, s, ScanOfProj{d_sides});
+  hipLaunchKernelGGL(k_proj_cands<true>, pts4S, dim3(256), 0, s, rs, 1);
+  const FeOfArr rf{d_frames};
+  const dim3 nT((std::max(maxN, 1) + 255) / 256, nFrames), pts4((P + 3) / 4, nFrames), ptsT((P + 255) / 256, nFrames);
+  hipLaunchKernelGGL(k_proj_reset_fe<FeOfArr>, nT, dim3(256), 0, s, rf);
+  for (int r = 0; r < rounds; r++) hipLaunchKernelGGL(k_proj_round_fe<FeOfArr>, pts4, dim3(256), 0, s, rf, r);
+  const int last = ((rounds - 1) & 1) ^ 1;
+  hipLaunchKernelGGL(k_proj_assign_fe<FeOfArr>, ptsT, dim3(256), 0, s, rf, last);
+  hipLaunchKernelGGL(k_proj_occ_fe<FeOfArr>, nT, dim3(256), 0, s, rf);
+  if (mode == 1 && checkOri) hipLaunchKernelGGL(k_proj_cull_fe<FeOfArr>, ptsT, dim3(256), 0, s, rf, last);
+  hipLaunchKernelGGL(k_proj_result_fe<FeOfArr>, dim3(1, nFrames), dim3(1), 0, s, rf);
   return hipGetLastError();
 }
 
@@ -1524,6 +1572,28 @@ hipError_t launch_proj_batch(const ProjArgs* d_frames, int nFrames, int maxPts, 
   hipLaunchKernelGGL(k_proj_cull<true>, n2b, dim3(256), 0, s, r);
   if (mode == 1 && checkOri) hipLaunchKernelGGL(k_proj_cull2<true>, pts256, dim3(256), 0, s, r);
   hipLaunchKernelGGL(k_proj_result<true>, one, dim3(1), 0, s, r);
+  return hipGetLastError();
+}
+
+// The keypoints / descriptors of a two-camera frame as ONE array [left | right] (mvKeys | mvKeysRight, the indexing the resolve
+// uses: slot < Nleft = left camera) from the two images of an extraction batch: frame blockIdx.y, words copied by the whole grid.
+__global__ __launch_bounds__(256) void k_fe_concat(FeConcatArgs a) {
+  const int f = blockIdx.y;
+  const int nL = min(max(a.nOut[a.firstL + f], 0), a.cap), nR = min(max(a.nOut[a.firstR + f], 0), a.cap);
+  const uint32_t* kL = reinterpret_cast<const uint32_t*>(a.kps + (size_t)(a.firstL + f) * a.cap);
+  const uint32_t* kR = reinterpret_cast<const uint32_t*>(a.kps + (size_t)(a.firstR + f) * a.cap);
+  const uint32_t* dL = reinterpret_cast<const uint32_t*>(a.desc + (size_t)(a.firstL + f) * a.cap * 32);
+  const uint32_t* dR = reinterpret_cast<const uint32_t*>(a.desc + (size_t)(a.firstR + f) * a.cap * 32);
+  uint32_t* ko = reinterpret_cast<uint32_t*>(a.kcat + (size_t)f * 2 * a.cap);
+  uint32_t* dout = reinterpret_cast<uint32_t*>(a.dcat + (size_t)f * 2 * a.cap * 32);
+  const int t0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+  for (int i = t0; i < nL * 7; i += step) ko[i] = kL[i];
+  for (int i = t0; i < nR * 7; i += step) ko[nL * 7 + i] = kR[i];
+  for (int i = t0; i < nL * 8; i += step) dout[i] = dL[i];
+  for (int i = t0; i < nR * 8; i += step) dout[nL * 8 + i] = dR[i];
+}
+hipError_t launch_fe_concat(const FeConcatArgs& a, int nFrames, hipStream_t s) {
+  if (nFrames > 0) hipLaunchKernelGGL(k_fe_concat, dim3(16, nFrames), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

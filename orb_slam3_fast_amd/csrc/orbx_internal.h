@@ -388,6 +388,14 @@ struct ProjFeArgs {
 hipError_t launch_proj_resolve_fisheye(const ProjFeArgs& a, hipStream_t s);
 hipError_t launch_proj_rounds_fisheye(const ProjFeArgs& a, int first_round, int rounds, hipStream_t s);
 hipError_t launch_proj_finish_fisheye(const ProjFeArgs& a, int last_round, hipStream_t s);
+struct FeConcatArgs {   // k_fe_concat: [left | right] keypoints / descriptors of the two-camera frames of an extraction batch
+  const orbx_keypoint* kps; const uint8_t* desc; const int* nOut;   // the handle's result arrays ([image][cap] rows) and counts
+  int firstL, firstR, cap;
+  orbx_keypoint* kcat; uint8_t* dcat;                               // [frame][2 cap] rows
+};
+hipError_t launch_fe_concat(const FeConcatArgs& a, int nFrames, hipStream_t s);
+hipError_t launch_proj_fisheye_batch(const ProjArgs* d_sides, const ProjFeArgs* d_frames, int nFrames, int maxPts, int maxN, int mode,
+                                     int checkOri, int rounds, hipStream_t s);
 hipError_t prepare_kernels(const Geom& g);                             // raises the dynamic-LDS limits
 hipError_t prepare_detect(const Geom& g);                              // (orbx_detect.hip)
 void debug_introsort_host(uint64_t* v, int n);

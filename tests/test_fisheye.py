@@ -398,3 +398,66 @@ def test_hip_single_call_fisheye_frame(oracle):
                                       ex.GetScaleSigmaSquares())
     hip = (n, nd, l2r[: len(kL)], r2l[: len(kR)], dep[: len(kL)], pts[: len(kL)])
     assert compare_float_results(hip, ora[:6], ora[6], mL) <= 2 and nd > 20
+
+
+@pytest.mark.gpu
+def test_hip_fisheye_projection_matchers_batched_over_an_extraction_batch(oracle):
+    """VERDICT (round 4), item 5: both stereo-fisheye SearchByProjection flavours (src/ORBmatcher.cc:41-221, 1594-1806 with
+    Nleft != -1) on the two-camera frames of an extraction batch in one call each -- the keypoints / descriptors of both cameras stay
+    in HBM (laid side by side on the device), every kernel of the chain runs once for all frames and cameras, the fixed-point rounds
+    are enqueued without a convergence-flag read.  Per frame the result is the oracle's (= the one-shot call's); frames with
+    different point counts incl. none; then the redo path (tiny candidate capacity, a single blind round) in a fresh process."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    F, w, h = 3, 640, 480
+    fr = [_fisheye_frame(orbx, 10 + i, w, h) for i in range(F)]
+    imgs = np.stack([synth.stereo_pair(w, h, 140 + 10 + i)[0] for i in range(F)] + [synth.stereo_pair(w, h, 140 + 10 + i)[1] for i in range(F)])
+    dev = DeviceBuffer.from_numpy(imgs)
+    ex = orbx.ORBextractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * F)
+    ex.extract_batch_device(dev.ptr.value, 2 * F, w, h, w, w * h)
+    ex.sync()
+    cap = ex.capacity
+    stride = 900
+    mps, mpr = np.zeros((F, stride), orbx.MP_DTYPE), np.zeros((F, stride), orbx.MPR_DTYPE)
+    pts, uvr = np.zeros((F, stride), orbx.PP_DTYPE), np.zeros((F, stride, 2), np.float32)
+    l2r, r2l = np.full((F, cap), -1, np.int32), np.full((F, cap), -1, np.int32)
+    occ = np.zeros((F, 2 * cap), np.uint8)
+    npts = np.zeros(F, np.int32)
+    for f in range(F):
+        g = fr[f]
+        nL, n = g["nL"], len(g["kps"])
+        _, kL, dL = ex.download(f)
+        _, kR, dR = ex.download(F + f)
+        assert np.array_equal(np.concatenate([kL, kR]).view(np.uint8), g["kps"].view(np.uint8)) and np.array_equal(np.concatenate([dL, dR]), g["desc"])
+        npts[f] = 0 if f == 1 else 900 - 100 * f
+        mps[f], mpr[f], pts[f], uvr[f] = g["mps"], g["mpr"], g["pts"], g["uvr"]
+        l2r[f, :nL], r2l[f, :n - nL] = g["l2r"], g["r2l"]
+        occ[f, :n] = g["occ"]
+    for th, far in ((3.0, True), (1.0, False)):
+        m = orbx.ORBmatcher(0.8, True)
+        nm, match, oc = m.SearchByProjectionFisheyeBatch(ex, 0, F, F, fr[0]["bounds"], mps, mpr, npts, l2r, r2l, occ, th, far, 60.0)
+        for f in range(F):
+            g, k = fr[f], int(npts[f])
+            n = len(g["kps"])
+            exp = oracle.search_by_projection_fisheye(g["kps"], g["desc"], g["nL"], g["bounds"], g["sf"], g["mps"][:k].view(oracle.MP_DTYPE),
+                                                      g["mpr"][:k].view(oracle.MPR_DTYPE), th, far, 60.0, 0.8, g["l2r"], g["r2l"], g["occ"])
+            assert nm[f] == exp[0] and np.array_equal(match[f, :n], exp[1]) and np.array_equal(oc[f, :n], exp[2]), (f, th, nm[f], exp[0])
+            assert (match[f, n:] == -1).all()
+        assert nm.sum() > 150
+    for ori in (True, False):
+        mm = orbx.ORBmatcher(0.8, ori)
+        nm, match, oc = mm.SearchByProjectionFrameFisheyeBatch(ex, 0, F, F, fr[0]["bounds"], pts, uvr, npts, occ)
+        for f in range(F):
+            g, k = fr[f], int(npts[f])
+            n = len(g["kps"])
+            exp = oracle.search_by_projection_frame_fisheye(g["kps"], g["desc"], g["nL"], g["bounds"], g["pts"][:k].view(oracle.PP_DTYPE),
+                                                            g["uvr"][:k], ori, g["occ"])
+            assert nm[f] == exp[0] and np.array_equal(match[f, :n], exp[1]) and np.array_equal(oc[f, :n], exp[2]), (f, ori, nm[f], exp[0])
+        assert nm.sum() > 100
+    if os.environ.get("ORBX_PROJ_CAND_CAP") is None:
+        import subprocess
+        import sys
+        e = dict(os.environ, ORBX_PROJ_CAND_CAP="64", ORBX_PROJ_BLIND="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.abspath(__file__),
+                            "-k", "test_hip_fisheye_projection_matchers_batched_over_an_extraction_batch"], env=e, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
