@@ -18,6 +18,10 @@ __device__ __forceinline__ int grid_cell(const orbx_keypoint& k, const InitArgs&
 
 // flags[kProjChanged + r] = round r of a fixed-point resolve changed a choice (the flag arrays hold 40 + 48 entries)
 constexpr int kProjChanged = 40;
+// flags[kProjLast] = which of the two alternating claim / write buffers the LAST EXECUTED round of a fixed-point resolve filled
+// (SearchForInitialization, stereo-fisheye SearchByProjection): rounds enqueued behind the fixed point return at once (round 5),
+// so the finishing kernels take the buffer from here, not from the number of rounds the host enqueued
+constexpr int kProjLast = 34;
 constexpr int kGridThreads = 1024;
 // Kernel-argument views (round 4): the one-shot entry points pass their argument block by value (kernel arguments); the batched
 // SearchByProjection entries launch every kernel ONCE for all frames of an extraction batch with blockIdx.y = frame and the
@@ -488,6 +492,8 @@ __global__ __launch_bounds__(256) void k_init_round(R ar, int round_no) {
   // claimer lists rotate through three buffers (read [r % 3], append to [(r + 1) % 3], clear [(r + 2) % 3] for the next
   // round): one launch per round; claim[] is rewritten completely every round and alternates between two
   const int prev = round_no % 3, next = (round_no + 1) % 3, c2 = round_no & 1;
+  if (round_no > 0 && a.flags[kProjChanged + round_no - 1] == 0) return;  // the previous round changed nothing: fixed point reached
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.flags[kProjLast] = c2 ^ 1;
   {
     int* clr = a.nclaimers[(round_no + 2) % 3];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n2; i += gridDim.x * 256) clr[i] = 0;
@@ -557,8 +563,9 @@ __device__ __forceinline__ int init_bin(const InitArgs& a, int i1, int i2) {
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void k_init_owner(R ar, int last) {  // vnMatches21 = the last claimer; votes
+__global__ __launch_bounds__(256) void k_init_owner(R ar, int) {  // vnMatches21 = the last claimer; votes
   const InitArgs& a = ar.get();
+  const int last = a.flags[kProjLast];
   const int i1 = blockIdx.x * 256 + threadIdx.x;
   if (i1 >= a.n1) return;
   const int2 cl = a.claim[last][i1];
@@ -568,8 +575,9 @@ __global__ __launch_bounds__(256) void k_init_owner(R ar, int last) {  // vnMatc
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void k_init_finish(R ar, int last) {
+__global__ __launch_bounds__(256) void k_init_finish(R ar, int) {
   const InitArgs& a = ar.get();
+  const int last = a.flags[kProjLast];
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   if (a.checkOri) {
     for (int i = 0; i < 30; i++) {
@@ -1298,6 +1306,8 @@ __global__ __launch_bounds__(256) void k_proj_round_fe(R ar, int round_no) {
   // [(r + 2) % 3] for the next round (nobody touches that one now) -- one launch per round; writes[] (fully rewritten every
   // round) alternates between two
   const int prev = round_no % 3, next = (round_no + 1) % 3, w2 = round_no & 1;
+  if (round_no > 0 && a.flags[kProjChanged + round_no - 1] == 0) return;  // the previous round changed nothing: fixed point reached
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.flags[kProjLast] = w2 ^ 1;
   {
     int* clr = a.nwriters[(round_no + 2) % 3];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) clr[i] = 0;
@@ -1417,8 +1427,9 @@ __device__ __forceinline__ int fe_bin(const ProjFeArgs& a, int im, int slot) {
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void k_proj_assign_fe(R ar, int last) {  // last writer wins every slot
+__global__ __launch_bounds__(256) void k_proj_assign_fe(R ar, int) {  // last writer wins every slot
   const ProjFeArgs& a = ar.get();
+  const int last = a.flags[kProjLast];
   const int im = blockIdx.x * 256 + threadIdx.x;
   int nw = 0;
   if (im < a.nmp) {
@@ -1451,8 +1462,9 @@ __global__ __launch_bounds__(256) void k_proj_occ_fe(R ar) {
 }
 
 template <class R>
-__global__ __launch_bounds__(256) void k_proj_cull_fe(R ar, int last) {
+__global__ __launch_bounds__(256) void k_proj_cull_fe(R ar, int) {
   const ProjFeArgs& a = ar.get();
+  const int last = a.flags[kProjLast];
   int ind1 = -1, ind2 = -1, ind3 = -1, max1 = 0, max2 = 0, max3 = 0;
   for (int i = 0; i < 30; i++) {
     const int s = a.flags[4 + i];

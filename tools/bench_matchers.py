@@ -211,3 +211,25 @@ for _ in range(reps):
 tb = (time.perf_counter() - t0) / reps * 1e3
 print("%-62s %12.3f   (%.3f ms per pair, %d matches in pair 0; Python packing of the %d key frames included)"
       % ("SearchByBoW(KeyFrame, Frame), batch of %d pairs" % FB, tb, tb / FB, int(r[0][0]), FB))
+
+# batched stereo-fisheye SearchByProjection (round 5): 32 two-camera frames, left images 0..31, right images 32..63 of the batch
+imgs2 = DeviceBuffer.from_numpy(np.stack([L1] * FB + [R1] * FB))
+exb.extract_batch_device(imgs2.ptr.value, 2 * FB, w, h, w, w * h)
+exb.sync()
+capb = exb.capacity
+l2rB, r2lB = np.full((FB, capb), -1, np.int32), np.full((FB, capb), -1, np.int32)
+l2rB[:, :nLk], r2lB[:, :nRk] = l2r, r2l
+occfB = np.zeros((FB, 2 * capb), np.uint8)
+occfB[:, :nLk + nRk] = occf
+mprB, uvrB = np.stack([mpr] * FB), np.stack([uvr] * FB)
+for name, fn in (("SearchByProjection(F, MapPoints), Nleft != -1, batch of %d frames" % FB,
+                  lambda: m.SearchByProjectionFisheyeBatch(exb, 0, FB, FB, bounds, mpsB, mprB, nptsB, l2rB, r2lB, occfB, 3.0, True, 60.0)),
+                 ("SearchByProjection(Cur, Last), Nleft != -1, batch of %d frames" % FB,
+                  lambda: m.SearchByProjectionFrameFisheyeBatch(exb, 0, FB, FB, bounds, ptsB, uvrB, nptsB, occfB))):
+    for _ in range(3):
+        r = fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    tb = (time.perf_counter() - t0) / reps * 1e3
+    print("%-62s %12.3f   (%.3f ms per frame, %d matches in frame 0)" % (name, tb, tb / FB, int(r[0][0])))
