@@ -28,6 +28,12 @@ import os
 import sys
 import time
 
+# The HIP runtime maps streams onto FOUR hardware queues by default; the null stream + four extractor handles need five, and two
+# handles sharing a queue serialise (profiles/r5_small_batch_handles.txt: 16 frames 640x480 per step, 4 handles: 185 k frames/s on
+# 4 queues, 272 - 279 k on 8).  Read once, when the runtime initialises: set here, before anything touches HIP; an explicit
+# setting of the caller wins.  Reported in the JSON line (config.env).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -73,9 +79,11 @@ def parse(argv=None):
     ap.add_argument("--other-steps", type=int, default=20,
                     help="timed steps of each secondary configuration in the other_configs leg (C2 640x480 mono, 640x480 stereo, "
                          "C4 512x512 fisheye stereo; 8-pair batches; 0 = skip)")
-    ap.add_argument("--handles", type=int, default=3,
+    ap.add_argument("--handles", type=int, default=4,
                     help="extractor handles used round-robin (each owns a stream + buffers); batches of different handles overlap on the GPU: the "
-                         "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others (1: 52.6 k, 2: 60.7 k, 3: 60.8 k, 4: 57.0 k pairs/s)")
+                         "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others.  Round 5, "
+                         "GPU_MAX_HW_QUEUES=8: 1280x720 x 32 pairs 3 / 4 handles 75.0 / 75.8 k pairs/s; 16 frames 640x480 252 / 272 k frames/s; "
+                         "8 pairs 512x512 fisheye 85 / 100 k pairs/s (with the runtime's default of 4 queues a fourth handle LOSES: 72.0 / 186 / 64)")
     ap.add_argument("--mode", choices=("stereo", "mono", "fisheye"), default="stereo",
                     help="stereo = BASELINE config C3 (the headline metric); mono = extraction only (C2: --width 640 "
                          "--height 480 --nfeatures 1000), value counts single frames; fisheye = C4 (--width 512 --height 512):"
@@ -436,6 +444,7 @@ def main():
                                     "lapping areas, BF 2-NN + KannalaBrandt8 triangulation"}[a.mode] % (W, H, NF),
             "pairs_per_step_per_gpu": B,
             "handles": len(exs),
+            "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             "distinct_streams_per_gpu": a.distinct,
             "frames_in_ring": a.ring,
             "input_reuse": "step i processes frame (i mod %d) of every stream; %d distinct stereo pairs resident in HBM per GPU"
@@ -573,9 +582,6 @@ def main():
         dt = time.perf_counter() - t0
         out["sustained"] = {"value": round(units_per_step * ns / dt, 1), "unit": out["unit"], "steps": ns, "seconds": round(dt, 2),
                             "note": "the timed step repeated back to back for --sustain-ms (synchronised every 64 steps)"}
-    if extras and a.other_steps > 0 and (W, H) == (1280, 720):
-        # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
-        out["other_configs"] = other_configs_leg(a, local_rank, torch)
     if extras:
         out.update(natural_pair_leg(orbx, np))
     if extras and a.latency_frames > 0:
@@ -583,6 +589,13 @@ def main():
     if extras and a.h2d_steps > 0:
         out.update(h2d_leg(a, wl, orbx, np, torch))
 
+    if extras and a.other_steps > 0 and (W, H) == (1280, 720):
+        # north_star asks for 640x480 AND 1280x720; BASELINE configs C2 / C4: small driver-timed legs beside the headline
+        # (last of the GPU legs, with the headline's handles closed: every live stream holds a place on the runtime's hardware queues,
+        # and the small-batch configurations are the ones that feel a shared queue -- 205 k instead of 272 k frames/s with them open)
+        for e_ in wl.exs:
+            e_.close()
+        out["other_configs"] = other_configs_leg(a, local_rank, torch)
     # ---- CPU baselines: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
     if extras and a.cpu_pairs > 0:
         out.update(cpu_legs(a, wl, np))

@@ -1061,8 +1061,14 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   bool lapTrivial = true;
   rc = prepare_extract(ex, ex->d_stage.p, 2, w, h, pitch, (ptrdiff_t)imgBytes, lap, lapTrivial);
   if (rc != ORBX_OK) return rc;
-  HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
-  HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
+  static const bool copy1d = getenv("ORBX_UPLOAD_1D") != nullptr;   // measurement aid
+  if (copy1d && stride_left == w && stride_right == w && pitch == w) {
+    HIPC(hipMemcpyAsync(ex->d_stage.p, img_left, imgBytes, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpyAsync(ex->d_stage.p + imgBytes, img_right, imgBytes, hipMemcpyHostToDevice, st));
+  } else {
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p, pitch, img_left, stride_left, w, h, hipMemcpyHostToDevice, st));
+    HIPC(hipMemcpy2DAsync(ex->d_stage.p + imgBytes, pitch, img_right, stride_right, w, h, hipMemcpyHostToDevice, st));
+  }
   rc = enqueue_frame(ex, 2, lapTrivial, lap);
   if (rc != ORBX_OK) return rc;
   const bool stereo = bf > 0.f;   // (uright / depth NULL: the results stay in the host block, orbx_host_results)

@@ -108,4 +108,5 @@ def test_bench_c5_mode_prints_one_contract_line():
     assert d["config"]["pairs_per_step_per_gpu"] == 16 and d["config"]["distinct_streams_per_gpu"] == 8
     assert d["config"]["allgather_bytes_per_step_per_gpu"] > 0
     # a collective inside the step: the preheat runs a FIXED number of steps (all ranks must issue the same all-gathers)
-    assert d["preheat_steps"] == 3 * ((int(40.0 / 0.55 / 3) + 1))
+    nh = d["config"]["handles"]
+    assert d["preheat_steps"] == nh * ((int(40.0 / 0.55 / nh) + 1))

@@ -1,5 +1,5 @@
 """Parity of EXACTLY the mode bench.py times: bench.Workload with its default arguments -- 32 distinct
-1280x720 stereo streams per batch, a ring of 3 frames, three extractor handles rotating, 7 steps enqueued back to back with
+1280x720 stereo streams per batch, a ring of 3 frames, four extractor handles rotating, 7 steps enqueued back to back with
 no synchronisation in between, stereo association queued behind each batch -- and then EVERY image of ALL handles' last
 batches (keypoints, descriptors, uRight, depth) against the CPU oracle, bit for bit.  Cross-handle ordering bugs (the
 k_detect token, the side stream's events, buffers reused while the other batch is in flight) would show here.
@@ -58,12 +58,12 @@ def _check_handles(wl, bench, steps):
 def test_default_bench_workload_matches_the_oracle():
     import bench
     a = bench.parse([])                              # bench.py's defaults: that IS the point
-    assert (a.pairs, a.distinct, a.handles, a.width, a.height, a.nfeatures, a.ring) == (32, 32, 3, 1280, 720, 1500, 3)
+    assert (a.pairs, a.distinct, a.handles, a.width, a.height, a.nfeatures, a.ring) == (32, 32, 4, 1280, 720, 1500, 3)
     wl = bench.Workload(a)
     assert len({s for s in wl.streams}) == 32
     # distinct inputs: no two pairs of a batch are the same image
     assert len({wl.host_left[0, p].tobytes()[:4096 * 64] for p in range(a.pairs)}) == a.pairs
-    assert _check_handles(wl, bench, 7) == 96        # every handle's last batch: steps 4, 5, 6 (ring slots 1, 2, 0)
+    assert _check_handles(wl, bench, 7) == 128       # every handle's last batch: steps 3, 4, 5, 6 (ring slots 0, 1, 2, 0)
 
 
 def test_c5_allgather_blocks_equal_the_downloads():
