@@ -6,8 +6,11 @@ sys.path.insert(0, '.')
 import orb_slam3_fast_amd as orbx
 orbx.LIB_PATH = os.path.join(os.path.dirname(orbx.__file__), os.environ.get("ORBX_PROF_LIB", "liborbx_prof.so"))
 from orb_slam3_fast_amd import synth
-L, R = synth.stereo_pair(1280, 720, 5)
-ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=1280, max_height=720, max_batch=2)
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 1280
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 720
+NF = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
+L, R = synth.stereo_pair(W, H, 5)
+ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
 for i in range(3):
     ex.extract_stereo(L, R, bf=63.8, b=0.12)
     print("----", flush=True)
