@@ -395,6 +395,18 @@ int configure(orbx_extractor* ex, int w, int h) {
   HIPC(hipStreamSynchronize(ex->stream));
   HIPC(hipMemcpy(ex->d_xtab.p, xtab.data(), xtab.size() * sizeof(uint4), hipMemcpyHostToDevice));
   HIPC(hipMemcpy(ex->d_yofs.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+  {  // k_resize's row table: the two source rows of every destination row, clamped to the source level, as u16 halves
+    std::vector<uint32_t> yrow(yofs.size(), 0);
+    for (int l = 1; l < g.nlevels; l++) {
+      const int Sh = g.lv[l - 1].h;
+      for (int dy = 0; dy < g.lv[l].h; dy++) {
+        const int sy = yofs[g.lv[l].ycoef + dy];
+        const int a = std::min(std::max(sy, 0), Sh - 1), b = std::min(std::max(sy + 1, 0), Sh - 1);
+        yrow[g.lv[l].ycoef + dy] = (uint32_t)a | ((uint32_t)b << 16);
+      }
+    }
+    HIPC(hipMemcpy(ex->d_yrow.p, yrow.data(), yrow.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   HIPC(hipMemcpy(ex->d_yab.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
   HIPC(prepare_kernels(g));
   std::vector<TailPlan> plans;
@@ -522,7 +534,7 @@ static int enqueue_pyramid(orbx_extractor* ex, hipStream_t s, int img0, int n) {
       HIPC(launch_resize_tail(g, ex->pyr, tp, ex->d_tailBands.p + tp.bandOff, 0, n, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
       l += tp.nT;
     } else {
-      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yofs.p, ex->d_yab.p, s));
+      HIPC(launch_resize(g, ex->pyr, n, l, ex->d_xtab.p, ex->d_yrow.p, ex->d_yab.p, s));
       l++;
     }
   }
@@ -700,6 +712,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(hipHostMalloc(reinterpret_cast<void**>(&ex->h_lap), (size_t)B * 2 * sizeof(int), hipHostMallocDefault));
   ok(ex->d_xtab.alloc(nx + 64));
   ok(ex->d_yofs.alloc(ny + 64));
+  ok(ex->d_yrow.alloc(ny + 64));
   ok(ex->d_yab.alloc(2 * ny + 64));
   ok(hipHostMalloc(reinterpret_cast<void**>(&ex->hostResults), host_results_bytes(m.outCap), hipHostMallocDefault));
   if (e != hipSuccess) {
@@ -733,7 +746,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
-  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free();
+  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free(); ex->d_yrow.free();
   ex->d_latBands.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);

@@ -250,6 +250,7 @@ struct orbx_extractor {
   DevBuf<int> d_rowStart, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
   DevBuf<short> d_yab;
   DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
+  DevBuf<uint32_t> d_yrow;  // k_resize's per-row table: clamped source row pair of every destination row (u16 halves)
   DevBuf<uint4> d_srec, d_sdesc;   // row-sorted keypoint records / descriptors of both eyes (k_stereo_sort)
   std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)
   DevBuf<orbx::TailBand> d_tailBands;

@@ -90,7 +90,7 @@ hipError_t prepare_resize_tail(unsigned ldsBytes);
 hipError_t raise_dynamic_lds(const void* fn, size_t bytes);   // per-device running maximum of a kernel's dynamic-LDS limit
 
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
-hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const uint32_t* yofs /* clamped row pairs */,
                          const short* yab, hipStream_t s);
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,
                          int level1, uint8_t* dbgScore, hipStream_t s);

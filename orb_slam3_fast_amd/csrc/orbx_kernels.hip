@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t vblend4(uint2 t0, uint2 t1, uint32_t bb, uin
 }
 template <int NDW>
 __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __restrict__ xtab,
-                                                const int* __restrict__ yofs, const short* __restrict__ yab,
+                                                const uint32_t* __restrict__ yrow, const short* __restrict__ yab,
                                                 int srcRowsMax, int srcDwMaxRt) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int SDW = NDW ? NDW : srcDwMaxRt;
@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
 #ifdef RS_PROF
   long long tq0 = wall_clock64();
 #endif
-  const int rb = min(max(yofs[D.ycoef + y0], 0), S.h - 1);                      // first source row needed
-  const int re = min(max(yofs[D.ycoef + y1] + 1, 0), S.h - 1);                  // last source row needed
+  // yrow[dy] = the two source rows of destination row dy, already clamped to the level (low / high half; built on the host):
+  // no s_max / s_min chains per row on the scalar ALU, this kernel's busiest pipe (round 5)
+  const int rb = (int)(yrow[D.ycoef + y0] & 0xFFFFu);                           // first source row needed
+  const int re = (int)(yrow[D.ycoef + y1] >> 16);                               // last source row needed
   const int nrows = re - rb + 1;
   const int cb = (int)xtab[D.xcoef + x0].y;                                     // first source byte (dword aligned)
   const int ce = min((int)xtab[D.xcoef + x1].x + 1, S.w - 1);
@@ -132,12 +134,12 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
     sel[j] = e.z;
     coef[j] = e.w;
   }
-  int vsy[RS_DR / 4];
+  uint32_t vsy[RS_DR / 4];
   uint32_t vbb[RS_DR / 4];
 #pragma unroll
   for (int k = 0; k < RS_DR / 4; k++) {  // rows w, w + 4, ... of the block belong to this wave (wave-uniform: scalar loads)
     const int dy = min(y0 + w + 4 * k, D.h - 1);
-    vsy[k] = yofs[D.ycoef + dy];
+    vsy[k] = yrow[D.ycoef + dy];
     vbb[k] = reinterpret_cast<const uint32_t*>(yab)[D.ycoef + dy];
   }
   {
@@ -283,20 +285,22 @@ __global__ __launch_bounds__(256) void k_resize(ResizeLv rl, const uint4* __rest
     asm volatile("" : "+v"(kRound));           // (a VGPR: the products' one scalar operand is the row's coefficient pair)
     if (dx < D.w) {                            // lane-invariant over the rows: tested once, the row loop only has uniform exits
       const uint8_t* htq = ht8 + 8 * qx;
-      uint8_t* dstImg = rl.dst + (long long)img * rl.dstImg;   // wave-uniform: the stores take row base + 32-bit lane offset
+      // wave-uniform: the stores take row base + 32-bit lane offset; the row base advances by four rows per trip
+      uint8_t* dstRow = rl.dst + (long long)img * rl.dstImg + (long long)(y0 + w) * D.pitch;
+      const long long dstStep = 4ll * D.pitch;
 #pragma unroll
       for (int k = 0; k < RS_DR / 4; k++) {
         const int dy = y0 + w + 4 * k;
         if (dy >= D.h) break;
-        const int sy = vsy[k];
         const uint32_t bb = vbb[k];
-        const int r0 = min(max(sy, 0), S.h - 1) - rb, r1 = min(max(sy + 1, 0), S.h - 1) - rb;
+        const int r0 = (int)(vsy[k] & 0xFFFFu) - rb, r1 = (int)(vsy[k] >> 16) - rb;
         const uint2 t0 = *reinterpret_cast<const uint2*>(htq + r0 * (RS_DW * 2));
         const uint2 t1 = *reinterpret_cast<const uint2*>(htq + r1 * (RS_DW * 2));
         const uint32_t outw = vblend4(t0, t1, bb, kRound);
-        uint8_t* dstRow = dstImg + (long long)dy * D.pitch;   // wave-uniform: scalar base + 32-bit lane offset (left to itself the
-        // compiler folds dx into the pointer and multiplies dy * pitch per lane in 64 bits)
+        // scalar base + 32-bit lane offset (left to itself the compiler folds dx into the pointer and multiplies dy * pitch
+        // per lane in 64 bits)
         asm volatile("global_store_dword %0, %1, %2" : : "v"((uint32_t)dx), "v"(outw), "s"(dstRow) : "memory");
+        dstRow += dstStep;
       }
     }
   }
@@ -327,7 +331,7 @@ size_t resize_lds_bytes(const Geom& g) {
 }
 
 constexpr int kResizeNdw = 80;  // footprint pitch of the compile-time instantiation (every level of a 1.2 pyramid)
-hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const int* yofs,
+hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const uint32_t* yofs,
                          const short* yab, hipStream_t s) {
   const LevelDev& D = g.lv[level];
   int srcRowsMax, srcDwMax;
