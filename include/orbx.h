@@ -715,6 +715,11 @@ void orbx_debug_set_detect_list_cap(int cap);
 /* Test hook: != 0 forces k_octree's global-memory candidate path (normally taken only when one (image, level) has more
  * than 16384 FAST candidates); 0 restores the register-resident path. */
 void orbx_debug_set_octree_global(int on);
+/* Test hook of ComputeStereoMatches' two forms (src/Frame.cc:921-1084): calls with up to max_pairs pairs (and at most 4096
+ * result slots per image) run the DIRECT form -- k_stereo_band selects its keypoints from the unsorted arrays itself, no
+ * k_stereo_sort launch in front --, larger ones the row-sorted form.  Default 1 (the single-frame path); 0 = never; < 0
+ * restores the default.  Environment: ORBX_STEREO_DIRECT_PAIRS. */
+void orbx_debug_set_stereo_direct(int max_pairs);
 /* Test hook of the pyramid's fused small-level launches (k_resize_tail: up to three consecutive levels of
  * ComputePyramid, src/ORBextractor.cc:1108-1145, per launch).  first_level: -1 = the library's policy, 0 = no fusion (every
  * level through k_resize), >= 2 = fuse from that level on; max_levels / band_rows: levels per launch and rows of the last

@@ -1321,13 +1321,14 @@ static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extra
   a.cap = (int)std::max(capL, (size_t)right->gmax.outCap);
   a.imgH = left->curH;
   a.band = (int)std::ceil(2.0f * left->scale.back()) + 2;
-  {
+  const bool direct = stereo_direct_ok(a, n_pairs);  // a single pair: the band workgroups select their keypoints themselves
+  if (!direct) {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
     HIPC(launch_stereo_sort(left->g, a, n_pairs, left->stream));
   }
   {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
-    HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream));
+    HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream, direct));
   }
   if (withFilter) {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_FILTER);
@@ -1496,6 +1497,7 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
 void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
 void orbx_debug_set_octree_global(int on) { debug_set_octree_global(on); }
+void orbx_debug_set_stereo_direct(int max_pairs) { debug_set_stereo_direct(max_pairs); }
 void orbx_debug_set_resize_tail(int first_level, int max_levels, int band_rows) {
   orbx_host::g_tail_first = first_level;
   orbx_host::g_tail_levels = max_levels > 0 ? max_levels : orbx_host::kTailLevels;

@@ -123,8 +123,11 @@ struct StereoArgs {
   int band;                      // max rows a right keypoint's +-2*scale band can be away from its own row
 };
 hipError_t launch_stereo_sort(const Geom& g, const StereoArgs& a, int npairs, hipStream_t s);
+// direct: k_stereo_band selects its keypoints from the unsorted arrays itself (no launch_stereo_sort in front; needs stereo_direct_ok)
+bool stereo_direct_ok(const StereoArgs& a, int npairs);
+void debug_set_stereo_direct(int max_pairs);
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                               hipStream_t s);
+                               hipStream_t s, bool direct = false);
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
                           uint8_t* ok, hipStream_t s);

@@ -240,8 +240,25 @@ __device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair
 //   3. the 11 x 11 SAD refinement (:1007-1062) with 16 lanes per matched keypoint, four keypoints per wave: a lane owns one
 //      window row -- the left row's 11 bytes and the 21 right bytes all 11 shifts touch sit in registers (aligned dword
 //      loads + v_alignbyte), three v_sad_u8 per shift -- and the 11 row sums meet in lane 15 by DPP row shifts.
-template <int kStereoBand, int NT, int kStereoRC, int kStereoLC>
+//
+// kDirect (round 5, the single-frame path): no k_stereo_sort in front.  Every workgroup scans the two UNSORTED keypoint arrays of
+// its pair itself (x, y, octave of <= 2 x cap keypoints: L2-resident, one memory round trip beside the counts), keeps the indices of
+// the left keypoints of its rows and of the right keypoints whose +-2*scale band touches those rows in two LDS lists, and stages
+// records and descriptors through the lists.  Nothing below depends on the order of either list: the winner is the minimum of
+// the unique keys (dist, iR), results are written by iL.  In a 0.2 ms frame the sort was 7.6 us of dependent launch; in a batch
+// it is shared by the pair's 30 workgroups and stays.
+constexpr int kStereoSelCap = 4096;  // per-image keypoint capacity the direct form's index lists hold
+__device__ __forceinline__ uint32_t stereo_right_band(float x, float y, int oct, const float* lvS) {  // minr | maxr << 16 (:943-948)
+  const float r = __fmul_rn(2.0f, lvS[oct]);
+  int maxr = (int)ceilf(__fadd_rn(y, r));
+  const int minr = (int)floorf(__fsub_rn(y, r));
+  if (y == 0.0f && x == 0.0f) maxr = -1;
+  return ((uint32_t)minr & 0xFFFFu) | ((uint32_t)maxr << 16);
+}
+template <int kStereoBand, int NT, int kStereoRC, int kStereoLC, bool kDirect>
 __global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
+  __shared__ uint16_t selL[kDirect ? kStereoSelCap : 1], selR[kDirect ? kStereoSelCap : 1];
+  __shared__ int cntSel[2];
   __shared__ uint4 Lrec[kStereoLC];
   __shared__ uint32_t Ldesc[kStereoLC][8];
   __shared__ uint32_t Lbest[kStereoLC];
@@ -263,15 +280,28 @@ __global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, Ster
 #endif
   ST_MK();
   const int imgL = a.firstL + pair, imgR = a.firstR + pair;
-  const int* rsL = a.rowStart + (long long)(pair * 2) * (a.imgH + 1);
-  const int* rsR = rsL + (a.imgH + 1);
-  const int jLb = rsL[r0], jLe = rsL[min(r0 + kStereoBand, a.imgH)];
-  if (jLb == jLe) return;  // no left keypoint in these rows
-  const int jRb = rsR[max(r0 - a.band, 0)], jRe = rsR[min(r0 + kStereoBand + a.band, a.imgH)];
-  const uint4* recL = a.srec + (long long)(pair * 2) * a.cap;
-  const uint4* recR = recL + a.cap;
-  const uint4* sdL = a.sdesc + (long long)(pair * 2) * a.cap * 2;
-  const uint4* sdR = sdL + (long long)a.cap * 2;
+  int jLb, jLe, jRb, jRe;
+  const uint4 *recL = nullptr, *recR = nullptr, *sdL, *sdR;
+  const uint32_t *kwL = nullptr, *kwR = nullptr;  // (direct) the keypoint records as 7 dwords: x, y, .., octave at 5
+  if (!kDirect) {
+    const int* rsL = a.rowStart + (long long)(pair * 2) * (a.imgH + 1);
+    const int* rsR = rsL + (a.imgH + 1);
+    jLb = rsL[r0];
+    jLe = rsL[min(r0 + kStereoBand, a.imgH)];
+    if (jLb == jLe) return;  // no left keypoint in these rows
+    jRb = rsR[max(r0 - a.band, 0)];
+    jRe = rsR[min(r0 + kStereoBand + a.band, a.imgH)];
+    recL = a.srec + (long long)(pair * 2) * a.cap;
+    recR = recL + a.cap;
+    sdL = a.sdesc + (long long)(pair * 2) * a.cap * 2;
+    sdR = sdL + (long long)a.cap * 2;
+  } else {
+    kwL = reinterpret_cast<const uint32_t*>(a.kL + (long long)imgL * a.capL);
+    kwR = reinterpret_cast<const uint32_t*>(a.kR + (long long)imgR * a.capR);
+    sdL = reinterpret_cast<const uint4*>(a.dL + (long long)imgL * a.capL * 32);
+    sdR = reinterpret_cast<const uint4*>(a.dR + (long long)imgR * a.capR * 32);
+    if (tid < 2) cntSel[tid] = 0;
+  }
   if (tid < g.nlevels) {
     lvW[tid] = g.lv[tid].w;
     lvP[tid] = tid ? g.lv[tid].pitch : (int)pl.l0Row;
@@ -279,26 +309,77 @@ __global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, Ster
     lvS[tid] = g.lv[tid].scale;
   }
   const float maxD = __fdiv_rn(a.bf, a.b);
+  if (kDirect) {
+    const int nL = a.nL[imgL], nR = a.nR[imgR];
+    constexpr int kIt = 4;  // keypoints per thread and trip: one trip up to NT * 4 keypoints per image
+    for (int base = 0; base == 0 || base < max(nL, nR); base += NT * kIt) {
+      uint32_t yl[kIt], xr[kIt], yr[kIt], oc[kIt];
+#pragma unroll
+      for (int j = 0; j < kIt; j++) {  // (entries past n are inside the buffers and never used)
+        const int i = base + tid + j * NT;
+        yl[j] = kwL[min(i, a.capL - 1) * 7 + 1];
+        const uint32_t* q = kwR + min(i, a.capR - 1) * 7;
+        xr[j] = q[0];
+        yr[j] = q[1];
+        oc[j] = q[5];
+      }
+      if (base == 0) __syncthreads();  // the level table and the two counters
+#pragma unroll
+      for (int j = 0; j < kIt; j++) {
+        const int i = base + tid + j * NT;
+        if (i < nL) {
+          const int row = min(max((int)__uint_as_float(yl[j]), 0), a.imgH - 1);  // k_stereo_sort's row_of
+          if (row >= r0 && row < r0 + kStereoBand) selL[atomicAdd(&cntSel[0], 1)] = (uint16_t)i;
+        }
+        if (i < nR) {
+          const uint32_t mm = stereo_right_band(__uint_as_float(xr[j]), __uint_as_float(yr[j]), (int)oc[j], lvS);
+          const int minr = (int)(int16_t)(mm & 0xFFFF), maxr = (int)mm >> 16;
+          if (maxr >= r0 && minr < r0 + kStereoBand) selR[atomicAdd(&cntSel[1], 1)] = (uint16_t)i;
+        }
+      }
+    }
+    __syncthreads();
+    jLb = 0;
+    jLe = cntSel[0];
+    jRb = 0;
+    jRe = cntSel[1];
+    if (jLe == 0) return;  // no left keypoint in these rows
+  }
   ST_MK();
   for (int lc = jLb; lc < jLe; lc += kStereoLC) {
     const int nl = min(kStereoLC, jLe - lc);
     __syncthreads();  // (the previous trip's SAD stage has read Lrec / Lbest)
     if (tid < nl) {
-      Lrec[tid] = recL[lc + tid];
+      if (kDirect) {
+        const uint32_t k = selL[lc + tid];
+        const uint32_t* q = kwL + k * 7;
+        Lrec[tid] = make_uint4(q[0], q[1], q[5] | (k << 8), 0u);
+      } else {
+        Lrec[tid] = recL[lc + tid];
+      }
       Lbest[tid] = 100u << 16;  // TH_HIGH, strict '<'
       Lbx[tid] = 0.f;
     }
     for (int i = tid; i < 2 * nl; i += NT) {
-      const uint4 d = sdL[2 * lc + i];
+      const uint4 d = kDirect ? sdL[2 * (int)selL[lc + (i >> 1)] + (i & 1)] : sdL[2 * lc + i];
       uint32_t* q = &Ldesc[i >> 1][(i & 1) * 4];
       q[0] = d.x; q[1] = d.y; q[2] = d.z; q[3] = d.w;
     }
     for (int rc = jRb; rc < jRe; rc += kStereoRC) {
       const int nr = min(kStereoRC, jRe - rc);
       __syncthreads();  // (the previous trip's match stage has read Rrec / Rdesc)
-      for (int i = tid; i < nr; i += NT) Rrec[i] = recR[rc + i];
+      for (int i = tid; i < nr; i += NT) {
+        if (kDirect) {
+          const uint32_t k = selR[rc + i];
+          const uint32_t* q = kwR + k * 7;
+          const uint32_t x = q[0], y = q[1], oct = q[5];
+          Rrec[i] = make_uint4(x, y, oct | (k << 8), stereo_right_band(__uint_as_float(x), __uint_as_float(y), (int)oct, lvS));
+        } else {
+          Rrec[i] = recR[rc + i];
+        }
+      }
       for (int i = tid; i < 2 * nr; i += NT) {
-        const uint4 d = sdR[2 * rc + i];
+        const uint4 d = kDirect ? sdR[2 * (int)selR[rc + (i >> 1)] + (i & 1)] : sdR[2 * rc + i];
         const int c = i >> 1, k0 = (i & 1) * 4;
         Rdesc[k0][c] = d.x; Rdesc[k0 + 1][c] = d.y; Rdesc[k0 + 2][c] = d.z; Rdesc[k0 + 3][c] = d.w;
       }
@@ -540,11 +621,18 @@ hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, 
   return hipGetLastError();
 }
 
+// pairs per call up to which the direct form runs (default 1: the single-frame path; ORBX_STEREO_DIRECT_PAIRS / test hook)
+static int g_stereo_direct_pairs = getenv("ORBX_STEREO_DIRECT_PAIRS") ? atoi(getenv("ORBX_STEREO_DIRECT_PAIRS")) : 1;
+void debug_set_stereo_direct(int max_pairs) { g_stereo_direct_pairs = max_pairs < 0 ? 1 : max_pairs; }
+bool stereo_direct_ok(const StereoArgs& a, int npairs) {
+  return npairs <= g_stereo_direct_pairs && a.capL <= kStereoSelCap && a.capR <= kStereoSelCap;
+}
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                               hipStream_t s) {
+                               hipStream_t s, bool direct) {
   // band rows / threads / right-trip / left-trip sizes measured at 1280x720, 32 pairs (kernel alone): 8/256/256/64 22.9 us,
   // 16/256/256/64 26.5, 16/512/256/64 24.7, 24/512/256/128 20.7, 32/512/256/128 20.3, 32/1024/512/128 23.6, 8/128/256/64 28.8
-#define ORBX_SB(BR, NT, RC, LC) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a)
+#define ORBX_SB(BR, NT, RC, LC) do { if (direct) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, true>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a); \
+    else hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, false>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a); } while (0)
   // (64-thread workgroups -- 4 rows / 64 candidates per trip -- run 41 us alone and the 3-handle step of bench.py is 0.8 %
   // SHORTER with them, 0.4853 vs 0.4895 ms: small workgroups get scheduled between k_detect's one-wave cells, large ones
   // wait for it to drain; not adopted, the single-frame latency matters more than 0.8 %)

@@ -443,15 +443,22 @@ def test_stereo_matches(gpu, oracle, w, h, nf, stream, stripe):
     _, okR, odR = oR.extract(R)
     assert np.array_equal(_kp_bytes(kL), _kp_bytes(okL)) and np.array_equal(_kp_bytes(kR), _kp_bytes(okR))
     bf, b = 0.12 * 532.03, 0.12
-    u, dep = orbx.ComputeStereoMatches(exL, exR, bf, b)
     ou, od = oracle.stereo_match(oL, oR, okL, odL, okR, odR, bf, b)
     n = len(kL)
     assert (ou >= 0).sum() > n // 5
     if stripe:
         rows = np.bincount(okL["y"].astype(int), minlength=h)
         assert np.convolve(rows, np.ones(8, int)).max() > 64, "the case should put more than 64 left keypoints into one band"
-    assert np.array_equal(u[0, :n].view(np.uint32), ou.view(np.uint32))
-    assert np.array_equal(dep[0, :n].view(np.uint32), od.view(np.uint32))
+    # both forms of the association: row-sorted (k_stereo_sort in front; batches) and direct (k_stereo_band selects from the
+    # unsorted arrays itself; the single-frame default when the handle has <= 4096 result slots per image)
+    try:
+        for direct in (0, 1):
+            orbx.lib().orbx_debug_set_stereo_direct(direct)
+            u, dep = orbx.ComputeStereoMatches(exL, exR, bf, b)
+            assert np.array_equal(u[0, :n].view(np.uint32), ou.view(np.uint32)), direct
+            assert np.array_equal(dep[0, :n].view(np.uint32), od.view(np.uint32)), direct
+    finally:
+        orbx.lib().orbx_debug_set_stereo_direct(-1)
 
 
 def test_batched_pairs_one_handle(gpu, oracle):
@@ -465,6 +472,12 @@ def test_batched_pairs_one_handle(gpu, oracle):
     ex.extract_batch_device(dbuf.ptr.value, 2 * npairs, w, h, w, w * h)
     bf, b = 0.12 * 532.03, 0.12
     u, dep = orbx.ComputeStereoMatches(ex, ex, bf, b, first_left=0, first_right=npairs, n_pairs=npairs)
+    try:  # the same batch through the direct form (normally single pairs only)
+        orbx.lib().orbx_debug_set_stereo_direct(npairs)
+        u2, dep2 = orbx.ComputeStereoMatches(ex, ex, bf, b, first_left=0, first_right=npairs, n_pairs=npairs)
+    finally:
+        orbx.lib().orbx_debug_set_stereo_direct(-1)
+    assert np.array_equal(u.view(np.uint32), u2.view(np.uint32)) and np.array_equal(dep.view(np.uint32), dep2.view(np.uint32))
     for i in range(npairs):
         oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
         _, okL, odL = oL.extract(pairs[i][0])
