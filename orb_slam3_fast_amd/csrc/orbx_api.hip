@@ -880,9 +880,9 @@ int orbx_batch_download(orbx_extractor* ex, int image, orbx_keypoint* kps, uint8
 // (hipHostMalloc memory is device-visible and host-coherent): a single-frame trace showed the six D2H copies of the results
 // taking 57 us of a 270 us frame, against ~10 us for the gather.
 static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
-                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut);
-// fuseFilter != nullptr: the stereo association's median cut (pair 0) runs inside the gather launch (k_stereo_filter_pack)
-static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo, const StereoArgs* fuseFilter = nullptr) {
+                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut,
+                                const ResultPack* packWithBand = nullptr, bool* packedOut = nullptr);
+static hipError_t make_result_pack(orbx_extractor* ex, int nimg, bool stereo, ResultPack* out) {
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* hd = nullptr;
   hipError_t e = hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), ex->hostResults, 0);
@@ -896,7 +896,17 @@ static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo,
   a.hUr = reinterpret_cast<uint32_t*>(hd + hr_ur(oc)); a.hDepth = reinterpret_cast<uint32_t*>(hd + hr_depth(oc));
   a.nimg = nimg; a.cap = (int)oc; a.stereo = stereo ? 1 : 0;
   a.mask = 0x7F; a.fixedN = -1;
-  if (fuseFilter && stereo && nimg == 2) return launch_stereo_filter_pack(*fuseFilter, a, ex->stream);
+  *out = a;
+  return hipSuccess;
+}
+// fuseFilter != nullptr: the stereo association's median cut (pair 0) runs inside the gather launch (k_stereo_filter_pack);
+// kpsPacked: keypoints and descriptors have already left with the association's launch
+static hipError_t enqueue_result_pack(orbx_extractor* ex, int nimg, bool stereo, const StereoArgs* fuseFilter = nullptr,
+                                      bool kpsPacked = false) {
+  ResultPack a{};
+  hipError_t e = make_result_pack(ex, nimg, stereo, &a);
+  if (e != hipSuccess) return e;
+  if (fuseFilter && stereo && nimg == 2) return launch_stereo_filter_pack(*fuseFilter, a, ex->stream, kpsPacked);
   return launch_result_pack(a, ex->stream);
 }
 
@@ -1087,14 +1097,17 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   const bool stereo = bf > 0.f;   // (uright / depth NULL: the results stay in the host block, orbx_host_results)
   StereoArgs sargs;
   const bool fuse = stereo && !ex->profiling;  // (the stage table keeps the filter as its own launch)
+  bool kpsPacked = false;
   if (stereo) {
-    rc = enqueue_stereo_match(ex, 0, ex, 1, 1, bf, b, !fuse, &sargs);
+    ResultPack rp{};
+    if (fuse) HIPC(make_result_pack(ex, 2, true, &rp));
+    rc = enqueue_stereo_match(ex, 0, ex, 1, 1, bf, b, !fuse, &sargs, fuse ? &rp : nullptr, &kpsPacked);
     if (rc != ORBX_OK) return rc;
   }
   // all results travel with asynchronous copies into pinned memory behind the kernels: one synchronisation in total
   const size_t oc = (size_t)ex->gmax.outCap;
   uint8_t* H = ex->hostResults;
-  HIPC(enqueue_result_pack(ex, 2, stereo, fuse ? &sargs : nullptr));   // one gather kernel writes the pinned block (count-trimmed)
+  HIPC(enqueue_result_pack(ex, 2, stereo, fuse ? &sargs : nullptr, kpsPacked));   // one gather kernel writes the pinned block (count-trimmed)
   const auto tqp = std::chrono::steady_clock::now();
   if (ex->keepHostPyr) {
     const ptrdiff_t hs[2] = {stride_left, stride_right};
@@ -1272,7 +1285,9 @@ int orbx_hamming256(const void* a, const void* b) {
 // withFilter = false: the caller runs the median cut itself (orbx_extract_stereo: fused with the result gather); *argsOut
 // receives the kernels' argument block
 static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extractor* right, int first_right,
-                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut) {
+                                int n_pairs, float bf, float b, bool withFilter, StereoArgs* argsOut,
+                                const ResultPack* packWithBand, bool* packedOut) {
+  if (packedOut) *packedOut = false;
   if (!left || !right) return fail(ORBX_E_BADARG, "null handle");
   if (n_pairs <= 0 || first_left < 0 || first_right < 0 || first_left + n_pairs > left->lastN ||
       first_right + n_pairs > right->lastN)
@@ -1328,7 +1343,9 @@ static int enqueue_stereo_match(orbx_extractor* left, int first_left, orbx_extra
   }
   {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_MATCH);
-    HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream, direct));
+    const bool pack = direct && packWithBand && n_pairs == 1;
+    HIPC(launch_stereo_match(left->g, left->pyr, right->pyr, a, n_pairs, left->stream, direct, pack ? packWithBand : nullptr));
+    if (pack && packedOut) *packedOut = true;
   }
   if (withFilter) {
     StageTimer t(left, left->stream, ORBX_STAGE_STEREO_FILTER);

@@ -264,6 +264,13 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     }
   } clkPrint{clk0, wall0, (int)(lane == 0 && blockIdx.y == 31 && (blockIdx.x % 400) == 7)};
 #endif
+#ifdef DET_PROF  // measurement aid (make prof PROF_FLAGS=-DDET_PROF): the life of a few cell-waves inside one launch, x10 ns
+  long long dq_[8]; int ndq_ = 0;
+#define DET_MK() do { if (ndq_ < 8) dq_[ndq_++] = wall_clock64(); } while (0)
+#else
+#define DET_MK() do {} while (0)
+#endif
+  DET_MK();
   // Runs of xcdRun horizontally consecutive cells share an XCD and therefore the L2 lines of their common halo
   // columns (HBM-side fetch 410 -> 151 MB per 64-image launch; same duration, the kernel is VALU-bound).
   int cell = cellBegin + xcd_run_remap<kDetectXcdRun>(blockIdx.x, gridDim.x, blockIdx.y);
@@ -391,6 +398,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
       }
     }
   }
+  DET_MK();
   uint32_t* out = cellCand + (long long)img * g.cellImg + L.cellOff + (long long)cell * L.cellCap;
   int kept = 0;
   // a round of 64 quads advances a lane by dq rows and rq quads (no division per round)
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     // clear the score tile (16-byte stores; its zero ring is part of it).  The barrier also publishes the image tile.
     for (int i = lane; i < nScore16; i += 64) reinterpret_cast<uint4*>(score)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    if (pass == 0) DET_MK();
     // dense corner test, 4 pixels per lane; corners are compacted into an LDS list and scored with dense
     // lanes (the score needs ~110 min/max ops: running it under per-lane divergence would dominate).
     // Stage 1 (4 pixels per lane, registers): compass pre-test -> survivor list.
@@ -541,7 +550,9 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         }
       }
     }
+    if (pass == 0) DET_MK();
     flush_survivors();
+    if (pass == 0) DET_MK();
     const int nCorners = nList;
     // 3x3 non-max suppression (strict '>') inside the cell + emission
     if (TAP && pass == 0) {  // test tap (orbx_debug_score_map): the cell's FAST scores at iniThFAST, 0 = no corner
@@ -622,6 +633,14 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     __syncthreads();
   }
   if (lane == 0) *myCount = min(kept, L.cellCap);
+#ifdef DET_PROF
+  DET_MK();
+  if (lane == 0 && (blockIdx.x % 16) == 3) printf("detw %d %d %lld %lld\n", l, kept, dq_[0] % 100000000, dq_[ndq_ - 1] % 100000000);
+  if (lane == 0 && ((blockIdx.x % 293) == 7 || blockIdx.x + 1 == gridDim.x || blockIdx.x == 0) && ndq_ >= 6)
+    printf("det img %d blk %4d level %d start %6lld: issue tile loads %d | tile in LDS + clear %d | stage 1 %d | flush (stage 2) %d | "
+           "NMS + emit%s %d | total %d  kept %d\n", img, (int)blockIdx.x, l, dq_[0] % 1000000, (int)(dq_[1] - dq_[0]), (int)(dq_[2] - dq_[1]),
+           (int)(dq_[3] - dq_[2]), (int)(dq_[4] - dq_[3]), ndq_ > 6 ? " + pass 2" : "", (int)(dq_[ndq_ - 1] - dq_[4]), (int)(dq_[ndq_ - 1] - dq_[0]), kept);
+#endif
 }
 
 static int g_detect_list_cap = kListTotal;  // test hook: a smaller list forces the flush / carry / corner-overflow paths

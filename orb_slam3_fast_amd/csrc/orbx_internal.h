@@ -126,8 +126,10 @@ hipError_t launch_stereo_sort(const Geom& g, const StereoArgs& a, int npairs, hi
 // direct: k_stereo_band selects its keypoints from the unsorted arrays itself (no launch_stereo_sort in front; needs stereo_direct_ok)
 bool stereo_direct_ok(const StereoArgs& a, int npairs);
 void debug_set_stereo_direct(int max_pairs);
+struct ResultPack;
+// pack (direct form, one pair): extra workgroups of the launch gather both eyes' keypoints and descriptors into the host block
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                               hipStream_t s, bool direct = false);
+                               hipStream_t s, bool direct = false, const ResultPack* pack = nullptr);
 hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s);
 hipError_t launch_bf_knn2(const uint8_t* dQ, int nQ, const uint8_t* dT, int nT, int* idx2, int* dist2,
                           uint8_t* ok, hipStream_t s);
@@ -227,7 +229,8 @@ struct ResultPack {
   int fixedN;    // >= 0: copy this many uRight / depth entries instead of nOut[0] (orbx_stereo_download: the caller's capacity)
 };
 hipError_t launch_result_pack(const ResultPack& a, hipStream_t s);
-hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s);   // (orbx_stereo.hip)
+// (orbx_stereo.hip)  stereoOnly: keypoints / descriptors are already in the host block (launch_stereo_match's pack workgroups)
+hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s, bool stereoOnly = false);
 
 // ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:886-1106), single-camera key frames (k_tri_*)
 struct TriArgs {

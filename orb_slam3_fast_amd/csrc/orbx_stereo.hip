@@ -255,8 +255,27 @@ __device__ __forceinline__ uint32_t stereo_right_band(float x, float y, int oct,
   if (y == 0.0f && x == 0.0f) maxr = -1;
   return ((uint32_t)minr & 0xFFFFu) | ((uint32_t)maxr << 16);
 }
+// Workgroups behind the last band (direct form, rp.hKps != nullptr): the single-frame entry's gather of both eyes' keypoints and
+// descriptors into the page-locked result block (k_result_pack's sections 0 - 3, orbx_kernels.hip) -- 180 KB of PCIe writes that do
+// not depend on the association and so leave beside it instead of behind it, in the frame's last launch.
 template <int kStereoBand, int NT, int kStereoRC, int kStereoLC, bool kDirect>
-__global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, StereoArgs a) {
+__global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, StereoArgs a, ResultPack rp) {
+  if (kDirect) {
+    const int nBands = (a.imgH + kStereoBand - 1) / kStereoBand;
+    if ((int)blockIdx.x >= nBands) {
+      const int nx = (int)gridDim.x - nBands, bx = (int)blockIdx.x - nBands;
+      for (int sec = 0; sec < 4; sec++) {
+        const int img = sec & 1;
+        if (img >= rp.nimg) continue;
+        const int n = min(rp.nOut[img], rp.cap);
+        const uint32_t* src = sec < 2 ? rp.kps + (size_t)img * rp.cap * 7 : rp.desc + (size_t)img * rp.cap * 8;
+        uint32_t* dst = sec < 2 ? rp.hKps + (size_t)img * rp.cap * 7 : rp.hDesc + (size_t)img * rp.cap * 8;
+        const int len = n * (sec < 2 ? 7 : 8);
+        for (int i = bx * NT + (int)threadIdx.x; i < len; i += nx * NT) dst[i] = src[i];
+      }
+      return;
+    }
+  }
   __shared__ uint16_t selL[kDirect ? kStereoSelCap : 1], selR[kDirect ? kStereoSelCap : 1];
   __shared__ int cntSel[2];
   __shared__ uint4 Lrec[kStereoLC];
@@ -581,7 +600,13 @@ hipError_t launch_stereo_filter(const StereoArgs& a, int npairs, hipStream_t s) 
 // two eyes, 6 counts) run beside block (0, 4), which filters and then copies uRight and depth itself.
 __global__ __launch_bounds__(256) void k_stereo_filter_pack(StereoArgs sa, ResultPack a) {
   __shared__ int fhist[256], fw[8], fv[2];
-  const int sec = blockIdx.y;
+  // (grid (1, 1): keypoints and descriptors have left with k_stereo_band's extra workgroups; this one publishes the counts too)
+  const int sec = gridDim.y == 1 ? 4 : blockIdx.y;
+  if (gridDim.y == 1 && threadIdx.x < 2) {
+    const int t = threadIdx.x;
+    a.hCnt[t] = t < a.nimg ? (uint32_t)a.nOut[t] : 0u;
+    a.hCnt[2 + t] = t < a.nimg ? (uint32_t)a.mono[t] : 0u;
+  }
   if (sec == 6) {
     if (blockIdx.x == 0 && threadIdx.x < 2) {
       const int t = threadIdx.x;
@@ -616,8 +641,8 @@ __global__ __launch_bounds__(256) void k_stereo_filter_pack(StereoArgs sa, Resul
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < len; i += gridDim.x * 256) dst[i] = src[i];
 }
-hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_stereo_filter_pack, dim3(12, 7), dim3(256), 0, s, sa, a);
+hipError_t launch_stereo_filter_pack(const StereoArgs& sa, const ResultPack& a, hipStream_t s, bool stereoOnly) {
+  hipLaunchKernelGGL(k_stereo_filter_pack, stereoOnly ? dim3(1, 1) : dim3(12, 7), dim3(256), 0, s, sa, a);
   return hipGetLastError();
 }
 
@@ -628,11 +653,14 @@ bool stereo_direct_ok(const StereoArgs& a, int npairs) {
   return npairs <= g_stereo_direct_pairs && a.capL <= kStereoSelCap && a.capR <= kStereoSelCap;
 }
 hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, const StereoArgs& a, int npairs,
-                               hipStream_t s, bool direct) {
+                               hipStream_t s, bool direct, const ResultPack* pack) {
+  const int packBlocks = (direct && pack && npairs == 1) ? 8 : 0;   // (workgroups behind the bands: the result gather)
+  ResultPack rp{};
+  if (packBlocks) rp = *pack;
   // band rows / threads / right-trip / left-trip sizes measured at 1280x720, 32 pairs (kernel alone): 8/256/256/64 22.9 us,
   // 16/256/256/64 26.5, 16/512/256/64 24.7, 24/512/256/128 20.7, 32/512/256/128 20.3, 32/1024/512/128 23.6, 8/128/256/64 28.8
-#define ORBX_SB(BR, NT, RC, LC) do { if (direct) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, true>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a); \
-    else hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, false>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a); } while (0)
+#define ORBX_SB(BR, NT, RC, LC) do { if (direct) hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, true>), dim3((a.imgH + BR - 1) / BR + packBlocks, npairs), dim3(NT), 0, s, g, pl, pr, a, rp); \
+    else hipLaunchKernelGGL((k_stereo_band<BR, NT, RC, LC, false>), dim3((a.imgH + BR - 1) / BR, npairs), dim3(NT), 0, s, g, pl, pr, a, rp); } while (0)
   // (64-thread workgroups -- 4 rows / 64 candidates per trip -- run 41 us alone and the 3-handle step of bench.py is 0.8 %
   // SHORTER with them, 0.4853 vs 0.4895 ms: small workgroups get scheduled between k_detect's one-wave cells, large ones
   // wait for it to drain; not adopted, the single-frame latency matters more than 0.8 %)
