@@ -16,8 +16,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    roofline.streaming = the three streaming kernels of SURVEY 8d against the HBM peak
   "cpu_baseline":  the CPU oracle (port of the reference's serial semantics) frame-parallel on the host cores,
   "cpu_mt":        the same port with the reference's thread structure (2 eye threads x per-level tasks), one pipeline
-  "latency_ms", "extract_ms", "stereo_ms": one 1280x720 stereo frame through the drop-in host API, timers placed like
-                   the reference's REGISTER_TIMES (src/Frame.cc:196-232)
+  "latency_ms":    one 1280x720 stereo frame at a time through the drop-in C ABI call (orbx_extract_stereo with caller output
+                   arrays); "latency_python_ms" the same through the Python wrapper (rounds 1-5's latency_ms);
+                   "extract_ms", "stereo_ms": timers placed like the reference's REGISTER_TIMES (src/Frame.cc:196-232)
   "h2d_inclusive_value": the same batches with page-locked HOST frames uploaded every step and all results downloaded
 """
 import argparse
@@ -750,8 +751,12 @@ def _stats(v, np):
 
 def latency_leg(a, wl, orbx, np):
     """One stereo frame at a time through the drop-in host API (pageable host images in, host results out), distinct
-    frames, timers where the reference's REGISTER_TIMES puts them (src/Frame.cc:196-232): both-eye extraction (wall, one
-    synchronisation) and ComputeStereoMatches; latency_ms = orbx_extract_stereo doing both in one call."""
+    frames.  latency_ms = the C ABI call itself, orbx_extract_stereo with the caller's output arrays (both eyes +
+    ComputeStereoMatches, keypoints / descriptors / uRight / depth copied into the caller's memory: what the C++ caller of
+    src/Frame.cc:196-232 sees), timed around the foreign call with prebuilt arguments; latency_python_ms = the same frame
+    through the Python wrapper of this package (ctypes marshalling + numpy result copies on top: rounds 1-5 reported this as
+    latency_ms); extract_ms / stereo_ms = timers where the reference's REGISTER_TIMES puts them, as two wrapper calls."""
+    import ctypes as C
     W, H, NF = a.width, a.height, a.nfeatures
     ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2, device=wl.exs[0].device)
     frames = [(wl.host_left[s, p], wl.host_right[s, p]) for s in range(a.ring) for p in range(a.pairs)]
@@ -760,12 +765,43 @@ def latency_leg(a, wl, orbx, np):
     gc.disable()
     for i in range(5):
         ex.extract_stereo(*frames[i % len(frames)], bf=BF, b=BASE)
-    lat, te, ts = [], [], []
+    # ---- the C ABI call with caller output arrays
+    cap = ex.capacity
+    fn = orbx.lib().orbx_extract_stereo
+    lap = (C.c_int32 * 2)(0, 0)
+    cnt = [C.c_int() for _ in range(4)]
+    kL, kR = np.empty((cap, 28), np.uint8), np.empty((cap, 28), np.uint8)
+    dL, dR = np.empty((cap, 32), np.uint8), np.empty((cap, 32), np.uint8)
+    ur, dp = np.empty(cap, np.float32), np.empty(cap, np.float32)
+    cargs = [(ex._h, L.ctypes.data, R.ctypes.data, W, H, L.strides[0], R.strides[0], lap, lap, kL.ctypes.data, dL.ctypes.data, cap,
+              C.byref(cnt[0]), C.byref(cnt[1]), kR.ctypes.data, dR.ctypes.data, cap, C.byref(cnt[2]), C.byref(cnt[3]),
+              C.c_float(BF), C.c_float(BASE), ur.ctypes.data, dp.ctypes.data) for L, R in frames]
+
+    def c_loop(n):
+        out = []
+        for i in range(n):
+            ca = cargs[i % len(cargs)]
+            t0 = time.perf_counter()
+            rc = fn(*ca)
+            out.append(1e3 * (time.perf_counter() - t0))
+            assert rc == 0
+        return out
+    c_loop(5)
+    lat = c_loop(a.latency_frames)
+    # (the call's results are the wrapper's results: last frame of the loop against the wrapper on the same frame)
+    il = (a.latency_frames - 1) % len(frames)
+    (mL, wkL, wdL), (mR, wkR, wdR), (wu, wd) = ex.extract_stereo(*frames[il], bf=BF, b=BASE)
+    fn(*cargs[il])
+    nl, nr = cnt[0].value, cnt[2].value
+    assert nl == len(wkL) and nr == len(wkR) and np.array_equal(kL[:nl].reshape(-1), wkL.view(np.uint8)) and np.array_equal(dR[:nr], wdR)
+    assert ur[:nl].tobytes() == wu.tobytes() and dp[:nl].tobytes() == wd.tobytes()
+    # ---- through the Python wrapper
+    latp, te, ts = [], [], []
     for i in range(a.latency_frames):
         L, R = frames[i % len(frames)]
         t0 = time.perf_counter()
         ex.extract_stereo(L, R, bf=BF, b=BASE)
-        lat.append(1e3 * (time.perf_counter() - t0))
+        latp.append(1e3 * (time.perf_counter() - t0))
     for i in range(a.latency_frames):
         L, R = frames[i % len(frames)]
         t0 = time.perf_counter()
@@ -778,9 +814,11 @@ def latency_leg(a, wl, orbx, np):
     # the drop-in C++ class's DEFAULT (mbKeepHostPyramid = true, csrc/ORBextractor.h): every call also keeps the host copy of both
     # eyes' pyramids current (the public mvImagePyramid of the reference, read by an unmodified Frame::ComputeStereoMatches) --
     # orbx_set_host_pyramid: DMA copies into page-locked memory beside the frame's kernels, the levels handed out in place
-    lp = []
     ex.set_host_pyramid(True)
     ex.extract_stereo(*frames[0], bf=BF, b=BASE)
+    c_loop(3)
+    lpc = c_loop(max(10, a.latency_frames // 2))
+    lp = []
     for i in range(max(10, a.latency_frames // 2)):
         L, R = frames[i % len(frames)]
         t0 = time.perf_counter()
@@ -791,14 +829,18 @@ def latency_leg(a, wl, orbx, np):
     ex.set_host_pyramid(False)
     gc.enable()
     note = ("single %dx%d stereo frame, pageable host images in, host keypoints / descriptors / uRight / depth out, %d "
-            "distinct frames; latency_ms = orbx_extract_stereo (both eyes + ComputeStereoMatches, one synchronisation), i.e. the "
-            "C++ mirror with mbKeepHostPyramid = false; latency_with_host_pyramid_ms = the same with the host copy of both eyes' "
-            "pyramids kept current (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep "
-            "working; orbx_set_host_pyramid: 5.8 MB of DMA copies per frame beside the kernels, levels handed out in place); "
-            "extract_ms / stereo_ms = the two REGISTER_TIMES brackets as separate calls (Python wrapper included)"
-            % (W, H, len(frames)))
-    return {"latency_ms": _stats(lat, np), "latency_with_host_pyramid_ms": _stats(lp, np), "extract_ms": _stats(te, np),
-            "stereo_ms": _stats(ts, np), "latency_note": note}
+            "distinct frames; latency_ms = the C ABI call orbx_extract_stereo with the caller's output arrays (both eyes + "
+            "ComputeStereoMatches, one synchronisation, results copied into the caller's memory; the C++ mirror with "
+            "mbKeepHostPyramid = false), timed around the foreign call with prebuilt ctypes arguments; latency_python_ms = the same "
+            "frame through this package's Python wrapper (argument marshalling and numpy result copies on top; this is what rounds "
+            "1-5 reported as latency_ms); latency_with_host_pyramid_ms = the C ABI call with the host copy of both eyes' pyramids "
+            "kept current (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep working; "
+            "orbx_set_host_pyramid: 5.8 MB of DMA copies per frame beside the kernels, levels handed out in place), "
+            "latency_with_host_pyramid_python_ms through the wrapper incl. the level views; extract_ms / stereo_ms = the two "
+            "REGISTER_TIMES brackets as separate wrapper calls" % (W, H, len(frames)))
+    return {"latency_ms": _stats(lat, np), "latency_python_ms": _stats(latp, np), "latency_with_host_pyramid_ms": _stats(lpc, np),
+            "latency_with_host_pyramid_python_ms": _stats(lp, np), "extract_ms": _stats(te, np), "stereo_ms": _stats(ts, np),
+            "latency_note": note}
 
 
 def h2d_leg(a, wl, orbx, np, torch):

@@ -713,6 +713,8 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_xtab.alloc(nx + 64));
   ok(ex->d_yofs.alloc(ny + 64));
   ok(ex->d_yrow.alloc(ny + 64));
+  ok(ex->d_packCtr.alloc(4));
+  if (e == hipSuccess) e = hipMemset(ex->d_packCtr.p, 0, 4 * sizeof(int));
   ok(ex->d_yab.alloc(2 * ny + 64));
   ok(hipHostMalloc(reinterpret_cast<void**>(&ex->hostResults), host_results_bytes(m.outCap), hipHostMallocDefault));
   if (e != hipSuccess) {
@@ -720,6 +722,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
     orbx_extractor_destroy(ex);
     return fail(ORBX_E_HIP, msg);
   }
+  std::memset(ex->hostResults, 0, 64);   // counts and the gather's sequence word
   *out = ex;
   return ORBX_OK;
 }
@@ -746,7 +749,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
-  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free(); ex->d_yrow.free();
+  ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free(); ex->d_yrow.free(); ex->d_packCtr.free();
   ex->d_latBands.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);
@@ -896,6 +899,7 @@ static hipError_t make_result_pack(orbx_extractor* ex, int nimg, bool stereo, Re
   a.hUr = reinterpret_cast<uint32_t*>(hd + hr_ur(oc)); a.hDepth = reinterpret_cast<uint32_t*>(hd + hr_depth(oc));
   a.nimg = nimg; a.cap = (int)oc; a.stereo = stereo ? 1 : 0;
   a.mask = 0x7F; a.fixedN = -1;
+  a.packCtr = nullptr; a.hFlag = nullptr; a.seq = 0;
   *out = a;
   return hipSuccess;
 }
@@ -1100,7 +1104,13 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   bool kpsPacked = false;
   if (stereo) {
     ResultPack rp{};
-    if (fuse) HIPC(make_result_pack(ex, 2, true, &rp));
+    if (fuse) {
+      HIPC(make_result_pack(ex, 2, true, &rp));
+      rp.packCtr = ex->d_packCtr.p;
+      rp.hFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(rp.hCnt) + hr_flag());
+      rp.seq = ++ex->packSeq;
+      if (rp.seq == 0) rp.seq = ++ex->packSeq;   // (0 is the block's initial value)
+    }
     rc = enqueue_stereo_match(ex, 0, ex, 1, 1, bf, b, !fuse, &sargs, fuse ? &rp : nullptr, &kpsPacked);
     if (rc != ORBX_OK) return rc;
   }
@@ -1117,6 +1127,33 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   }
   static const bool latTimes = getenv("ORBX_LAT_TIMES") != nullptr;   // measurement aid: host-side phases of the call
   const auto tq1 = std::chrono::steady_clock::now();
+  // Keypoints and descriptors reach the host block with the association's launch (launch_stereo_match's gather workgroups), two
+  // launches before the frame ends: a caller that wants them in its own arrays gets them copied WHILE the association and the
+  // median cut run (7 us of reads from memory the GPU has just written, off the end of the call).  The block's sequence word is
+  // the gather's last write; the stream is polled beside it so that a failed launch cannot leave this thread spinning.
+  bool copiedEarly = false;
+  static const bool earlyOut = !(getenv("ORBX_EARLY_COPYOUT") && atoi(getenv("ORBX_EARLY_COPYOUT")) == 0);
+  if (kpsPacked && earlyOut && (kps_left || desc_left || kps_right || desc_right)) {
+    const volatile uint32_t* flag = reinterpret_cast<const volatile uint32_t*>(H + hr_flag());
+    const uint32_t want = ex->packSeq;
+    bool seen = false;
+    for (unsigned spin = 1;; spin++) {
+      if (*flag == want) { seen = true; break; }
+      if ((spin & 1023u) == 0 && hipStreamQuery(st) != hipErrorNotReady) { seen = *flag == want; break; }
+    }
+    if (seen) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const int* c0 = reinterpret_cast<const int*>(H);
+      const int nl = c0[0], nr = c0[1];
+      if (nl <= cap_left && nr <= cap_right) {
+        if (nl > 0 && kps_left) std::memcpy(kps_left, H + hr_kps(oc), (size_t)nl * sizeof(orbx_keypoint));
+        if (nl > 0 && desc_left) std::memcpy(desc_left, H + hr_desc(oc), (size_t)nl * 32);
+        if (nr > 0 && kps_right) std::memcpy(kps_right, H + hr_kps(oc) + oc * sizeof(orbx_keypoint), (size_t)nr * sizeof(orbx_keypoint));
+        if (nr > 0 && desc_right) std::memcpy(desc_right, H + hr_desc(oc) + oc * 32, (size_t)nr * 32);
+        copiedEarly = true;
+      }
+    }
+  }
   HIPC(hipStreamSynchronize(st));
   const auto tq2 = std::chrono::steady_clock::now();
   if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
@@ -1136,10 +1173,12 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
   ex->hostResStereo = stereo;
   if (((kps_left || desc_left || uright || depth) && cnt[0] > cap_left) || ((kps_right || desc_right) && cnt[1] > cap_right))
     return fail(ORBX_E_CAPACITY, "keypoint buffer too small");
-  if (cnt[0] > 0 && kps_left) std::memcpy(kps_left, H + hr_kps(oc), (size_t)cnt[0] * sizeof(orbx_keypoint));
-  if (cnt[0] > 0 && desc_left) std::memcpy(desc_left, H + hr_desc(oc), (size_t)cnt[0] * 32);
-  if (cnt[1] > 0 && kps_right) std::memcpy(kps_right, H + hr_kps(oc) + oc * sizeof(orbx_keypoint), (size_t)cnt[1] * sizeof(orbx_keypoint));
-  if (cnt[1] > 0 && desc_right) std::memcpy(desc_right, H + hr_desc(oc) + oc * 32, (size_t)cnt[1] * 32);
+  if (!copiedEarly) {
+    if (cnt[0] > 0 && kps_left) std::memcpy(kps_left, H + hr_kps(oc), (size_t)cnt[0] * sizeof(orbx_keypoint));
+    if (cnt[0] > 0 && desc_left) std::memcpy(desc_left, H + hr_desc(oc), (size_t)cnt[0] * 32);
+    if (cnt[1] > 0 && kps_right) std::memcpy(kps_right, H + hr_kps(oc) + oc * sizeof(orbx_keypoint), (size_t)cnt[1] * sizeof(orbx_keypoint));
+    if (cnt[1] > 0 && desc_right) std::memcpy(desc_right, H + hr_desc(oc) + oc * 32, (size_t)cnt[1] * 32);
+  }
   if (stereo && cnt[0] > 0) {
     if (uright) std::memcpy(uright, H + hr_ur(oc), (size_t)cnt[0] * sizeof(float));
     if (depth) std::memcpy(depth, H + hr_depth(oc), (size_t)cnt[0] * sizeof(float));

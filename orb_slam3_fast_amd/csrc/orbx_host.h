@@ -223,6 +223,7 @@ using namespace orbx_host;
 
 // Layout of orbx_extractor::hostResults for the host entry points (one or two images):
 //   [0,16)  counts[2], mono[2]   | keypoints 2 x cap | descriptors 2 x cap x 32 | uRight cap | depth cap
+static inline size_t hr_flag() { return 32; }   // sequence number of the frame whose counts / keypoints / descriptors are in the block
 static inline size_t hr_kps(size_t) { return 64; }
 static inline size_t hr_desc(size_t cap) { return hr_kps(cap) + 2 * cap * sizeof(orbx_keypoint); }
 static inline size_t hr_ur(size_t cap) { return hr_desc(cap) + 2 * cap * 32; }
@@ -250,6 +251,8 @@ struct orbx_extractor {
   DevBuf<int> d_rowStart, d_cellCount, d_cellPrefix, d_candCount, d_selCount, d_slot, d_nOut, d_mono, d_lap, d_yofs, d_sad;
   DevBuf<short> d_yab;
   DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
+  DevBuf<int> d_packCtr;    // arrival counter of the single-frame gather workgroups (launch_stereo_match)
+  uint32_t packSeq = 0;     // sequence number of the last single stereo frame (hostResults + hr_flag())
   DevBuf<uint32_t> d_yrow;  // k_resize's per-row table: clamped source row pair of every destination row (u16 halves)
   DevBuf<uint4> d_srec, d_sdesc;   // row-sorted keypoint records / descriptors of both eyes (k_stereo_sort)
   std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)

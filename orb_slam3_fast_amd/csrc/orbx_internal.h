@@ -227,6 +227,11 @@ struct ResultPack {
   int nimg, cap, stereo;
   int mask;      // sections to gather: bit 0 / 1 keypoints of image 0 / 1, 2 / 3 descriptors, 4 uRight, 5 depth, 6 counts
   int fixedN;    // >= 0: copy this many uRight / depth entries instead of nOut[0] (orbx_stereo_download: the caller's capacity)
+  // launch_stereo_match's gather workgroups: arrival counter (device, zero between frames), and the word of the host block that
+  // receives `seq` once counts, keypoints and descriptors of both eyes are in the block (the host copies them out meanwhile)
+  int* packCtr;
+  uint32_t* hFlag;
+  uint32_t seq;
 };
 hipError_t launch_result_pack(const ResultPack& a, hipStream_t s);
 // (orbx_stereo.hip)  stereoOnly: keypoints / descriptors are already in the host block (launch_stereo_match's pack workgroups)

@@ -273,6 +273,21 @@ __global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, Ster
         const int len = n * (sec < 2 ? 7 : 8);
         for (int i = bx * NT + (int)threadIdx.x; i < len; i += nx * NT) dst[i] = src[i];
       }
+      if (rp.hFlag) {  // the last gather workgroup to arrive publishes the counts and then the frame's sequence number
+        __threadfence_system();   // this workgroup's writes to the host block are complete before its arrival counts
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const int prev = __hip_atomic_fetch_add(rp.packCtr, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          if (prev == nx - 1) {
+            __hip_atomic_store(rp.packCtr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int t = 0; t < 2; t++) {
+              rp.hCnt[t] = t < rp.nimg ? (uint32_t)rp.nOut[t] : 0u;
+              rp.hCnt[2 + t] = t < rp.nimg ? (uint32_t)rp.mono[t] : 0u;
+            }
+            __hip_atomic_store(rp.hFlag, rp.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+      }
       return;
     }
   }

@@ -916,6 +916,42 @@ def test_extract_stereo_single_call(gpu, oracle):
         orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h).extract_stereo(L, R)
 
 
+def test_extract_stereo_caller_arrays(gpu, oracle):
+    """orbx_extract_stereo with the caller's OUTPUT ARRAYS (the C++ caller's form): keypoints and descriptors are copied out of the
+    page-locked block while the stereo association still runs (the gather rides on k_stereo_band's launch and publishes a sequence
+    word).  Alternating frames on one handle: a copy taken before the gather finished, or from the previous frame, would differ."""
+    import ctypes as C
+    w, h, nf = 640, 480, 800
+    bf, b = 0.12 * 532.03, 0.12
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    cap = ex.capacity
+    frames = [synth.stereo_pair(w, h, 90 + i) for i in range(3)]
+    want = []
+    for L, R in frames:
+        oL, oR = oracle.OracleExtractor(nf), oracle.OracleExtractor(nf)
+        omL, okL, odL = oL.extract(L)
+        omR, okR, odR = oR.extract(R)
+        want.append((okL, odL, okR, odR) + tuple(oracle.stereo_match(oL, oR, okL, odL, okR, odR, np.float32(bf), np.float32(b))))
+    lap = (C.c_int32 * 2)(0, 0)
+    n = [C.c_int() for _ in range(4)]
+    for rep in range(12):
+        L, R = frames[rep % 3]
+        kL, kR = np.full((cap, 28), 0xEE, np.uint8), np.full((cap, 28), 0xEE, np.uint8)
+        dL, dR = np.full((cap, 32), 0xEE, np.uint8), np.full((cap, 32), 0xEE, np.uint8)
+        ur, dp = np.full(cap, -7, np.float32), np.full(cap, -7, np.float32)
+        rc = orbx.lib().orbx_extract_stereo(ex._h, L.ctypes.data, R.ctypes.data, w, h, w, w, lap, lap, kL.ctypes.data, dL.ctypes.data, cap,
+                                            C.byref(n[0]), C.byref(n[1]), kR.ctypes.data, dR.ctypes.data, cap, C.byref(n[2]), C.byref(n[3]),
+                                            C.c_float(bf), C.c_float(b), ur.ctypes.data, dp.ctypes.data)
+        assert rc == 0
+        okL, odL, okR, odR, ou, od = want[rep % 3]
+        nl, nr = n[0].value, n[2].value
+        assert (nl, nr) == (len(okL), len(okR))
+        assert np.array_equal(kL[:nl].reshape(-1), _kp_bytes(okL).reshape(-1)) and np.array_equal(dL[:nl], odL)
+        assert np.array_equal(kR[:nr].reshape(-1), _kp_bytes(okR).reshape(-1)) and np.array_equal(dR[:nr], odR)
+        assert ur[:nl].tobytes() == ou.tobytes() and dp[:nl].tobytes() == od.tobytes()
+        assert (kL[nl:] == 0xEE).all() and (dR[nr:] == 0xEE).all()
+
+
 @pytest.mark.parametrize("w,h,nf,sf,nl", [(1280, 720, 1500, 1.2, 8), (640, 480, 1000, 1.2, 8), (752, 480, 1000, 1.2, 8), (512, 512, 1500, 1.2, 8),
                                            (333, 517, 400, 1.2, 6), (800, 600, 800, 1.5, 5), (1000, 700, 600, 2.0, 4)])
 def test_single_frame_cascade_plans_and_host_pyramid(gpu, oracle, w, h, nf, sf, nl):
