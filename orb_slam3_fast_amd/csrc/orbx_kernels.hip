@@ -736,6 +736,14 @@ constexpr int OCT_NT = 512;  // threads per quadtree block: halves the key-loop 
 // Packed fields must not overflow into each other (callers keep each field < 2^21).
 // Per-thread chunk sums are scanned inside each wave with DPP row shifts / broadcasts (no barriers); only the
 // wave totals go through LDS: 2 barriers per call instead of the 18 of a Hillis-Steele scan over 256 threads.
+// the same scan by wave 0 alone (n <= 64, called by its 64 lanes only): exclusive prefix in place, returns the total
+__device__ __forceinline__ uint64_t wave0_scan_u64(uint64_t* v, int n) {
+  const int lane = threadIdx.x;
+  const uint64_t s = lane < n ? v[lane] : 0;
+  const uint64_t incl = wave_scan_dpp_u64(s);
+  if (lane < n) v[lane] = incl - s;
+  return readlane_u64(incl, 63);
+}
 __device__ __forceinline__ uint64_t block_scan_u64(uint64_t* v, int n, uint64_t* tsum) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int per = (n + OCT_NT - 1) / OCT_NT;
@@ -1427,84 +1435,115 @@ __device__ __forceinline__ bool octree_hist_body(const Geom& g, const LevelDev& 
   int nE = 0, ecur = 0;
   HMK();  // 4-ary sums + roots
   // ---- phase 1: split every expandable node per pass (:610-677)
-  while (!finish) {
-    const int prevSize = nA;
-    for (int i = tid; i < nA; i += OCT_NT) {
-      uint64_t cc = 0, nm = 1, ce = 0;
-      if (ncnt[cur][i] > 1) {
-        nm = 0;
-        const uint32_t dc = ndc(cur)[i];
-        if ((dc >> 13) >= (uint32_t)OCT_HD) {
-          s_i[3] = 1;
-        } else {
-          for (int q = 0; q < 4; q++) {
-            const uint32_t cq = child_count(dc, q);
-            cc += cq > 0;
-            ce += cq > 1;
-          }
-        }
-      }
-      scan[i] = cc | (nm << 21) | (ce << 42);
-    }
-    __syncthreads();
-    if (s_i[3]) return false;
-    const uint64_t tot = block_scan_u64(scan, nA, tsum);
-    const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
-    const int nxt = cur ^ 1;
-    for (int i = tid; i < nA; i += OCT_NT) {
-      const uint64_t pre = scan[i];
-      const int pc = (int)(pre & 0x1FFFFF), pnm = (int)((pre >> 21) & 0x1FFFFF), pce = (int)(pre >> 42);
-      if (ncnt[cur][i] > 1) {
-        const uint32_t dc = ndc(cur)[i];
-        const uint32_t cdc = (((dc >> 13) + 1) << 13) | ((dc & 0x1FFF) * 4);
-        const int x0 = nx0[cur][i], x1 = nx1[cur][i], y0 = ny0[cur][i], y1 = ny1[cur][i];
-        const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
-        uint32_t cq4[4];
-        int cc = 0;
-        for (int q = 0; q < 4; q++) {
-          cq4[q] = child_count(dc, q);
-          cc += cq4[q] > 0;
-        }
-        const int base = tc - (pc + cc);
-        int after = 0, eb = pce;
-        for (int q = 0; q < 4; q++) {  // E entries in creation order n1..n4
-          if (cq4[q] > 1) {
-            int rank_after = 0;
-            for (int q2 = q + 1; q2 < 4; q2++) rank_after += cq4[q2] > 0;
-            const int cx0 = (q & 1) ? x0 + hx : x0;
-            (c.ebuf + ecur * c.maxn)[eb++] = ((uint64_t)cq4[q] << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
-          }
-        }
-        for (int q = 3; q >= 0; q--) {  // list order n4,n3,n2,n1
-          if (cq4[q] == 0) continue;
-          const int pos = base + after++;
-          nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
-          nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
-          ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
-          ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
-          ncnt[nxt][pos] = cq4[q];
-          ndc(nxt)[pos] = (uint16_t)(cdc + q);
-        }
+  // One pass = flags, scan, scatter of the next list.  While the list fits one wave (the first passes: 1 - 2 roots -> 8 -> 32 nodes)
+  // wave 0 runs the passes ALONE, in program order on the LDS lists -- no workgroup barriers (four per pass, ~1 us of a 16-wave
+  // barrier chain each pass for a handful of nodes); the other waves wait at one barrier for the result.
+  // returns 0 = continue, 1 = finished, 2 = -> phase 2, 3 = a node deeper than the table (caller falls back)
+  auto pass = [&](auto waveTag) -> int {
+    constexpr bool kWave = decltype(waveTag)::value;
+    auto sync = [&]() {
+      if (kWave) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
       } else {
-        const int pos = tc + pnm;
-        nx0[nxt][pos] = nx0[cur][i];
-        nx1[nxt][pos] = nx1[cur][i];
-        ny0[nxt][pos] = ny0[cur][i];
-        ny1[nxt][pos] = ny1[cur][i];
-        ncnt[nxt][pos] = ncnt[cur][i];
-        ndc(nxt)[pos] = ndc(cur)[i];
+        __syncthreads();
       }
-    }
-    __syncthreads();
+    };
+    const int prevSize = nA;
+      for (int i = tid; i < nA; i += OCT_NT) {
+        uint64_t cc = 0, nm = 1, ce = 0;
+        if (ncnt[cur][i] > 1) {
+          nm = 0;
+          const uint32_t dc = ndc(cur)[i];
+          if ((dc >> 13) >= (uint32_t)OCT_HD) {
+            s_i[3] = 1;
+          } else {
+            for (int q = 0; q < 4; q++) {
+              const uint32_t cq = child_count(dc, q);
+              cc += cq > 0;
+              ce += cq > 1;
+            }
+          }
+        }
+        scan[i] = cc | (nm << 21) | (ce << 42);
+      }
+      sync();
+      if (s_i[3]) return 3;
+      const uint64_t tot = kWave ? wave0_scan_u64(scan, nA) : block_scan_u64(scan, nA, tsum);
+      const int tc = (int)(tot & 0x1FFFFF), tnm = (int)((tot >> 21) & 0x1FFFFF), tce = (int)(tot >> 42);
+      const int nxt = cur ^ 1;
+      for (int i = tid; i < nA; i += OCT_NT) {
+        const uint64_t pre = scan[i];
+        const int pc = (int)(pre & 0x1FFFFF), pnm = (int)((pre >> 21) & 0x1FFFFF), pce = (int)(pre >> 42);
+        if (ncnt[cur][i] > 1) {
+          const uint32_t dc = ndc(cur)[i];
+          const uint32_t cdc = (((dc >> 13) + 1) << 13) | ((dc & 0x1FFF) * 4);
+          const int x0 = nx0[cur][i], x1 = nx1[cur][i], y0 = ny0[cur][i], y1 = ny1[cur][i];
+          const int hx = (x1 - x0 + 1) >> 1, hy = (y1 - y0 + 1) >> 1;
+          uint32_t cq4[4];
+          int cc = 0;
+          for (int q = 0; q < 4; q++) {
+            cq4[q] = child_count(dc, q);
+            cc += cq4[q] > 0;
+          }
+          const int base = tc - (pc + cc);
+          int after = 0, eb = pce;
+          for (int q = 0; q < 4; q++) {  // E entries in creation order n1..n4
+            if (cq4[q] > 1) {
+              int rank_after = 0;
+              for (int q2 = q + 1; q2 < 4; q2++) rank_after += cq4[q2] > 0;
+              const int cx0 = (q & 1) ? x0 + hx : x0;
+              (c.ebuf + ecur * c.maxn)[eb++] = ((uint64_t)cq4[q] << 28) | ((uint64_t)(uint32_t)cx0 << 16) | (uint64_t)(base + rank_after);
+            }
+          }
+          for (int q = 3; q >= 0; q--) {  // list order n4,n3,n2,n1
+            if (cq4[q] == 0) continue;
+            const int pos = base + after++;
+            nx0[nxt][pos] = (int16_t)((q & 1) ? x0 + hx : x0);
+            nx1[nxt][pos] = (int16_t)((q & 1) ? x1 : x0 + hx);
+            ny0[nxt][pos] = (int16_t)((q & 2) ? y0 + hy : y0);
+            ny1[nxt][pos] = (int16_t)((q & 2) ? y1 : y0 + hy);
+            ncnt[nxt][pos] = cq4[q];
+            ndc(nxt)[pos] = (uint16_t)(cdc + q);
+          }
+        } else {
+          const int pos = tc + pnm;
+          nx0[nxt][pos] = nx0[cur][i];
+          nx1[nxt][pos] = nx1[cur][i];
+          ny0[nxt][pos] = ny0[cur][i];
+          ny1[nxt][pos] = ny1[cur][i];
+          ncnt[nxt][pos] = ncnt[cur][i];
+          ndc(nxt)[pos] = ndc(cur)[i];
+        }
+      }
+    sync();
     cur = nxt;
     nA = tc + tnm;
     nE = tce;
-    if (nA >= N || nA == prevSize) {
-      finish = true;
-    } else if (nA + 3 * nE > N) {
-      break;  // -> phase 2
+    if (nA >= N || nA == prevSize) return 1;
+    if (nA + 3 * nE > N) return 2;  // -> phase 2
+    return 0;
+  };
+  int state = 0;
+  if (nA <= 64) {  // (uniform)
+    if (tid < 64) {
+      while (state == 0 && nA <= 64) state = pass(std::true_type{});
+      if (tid == 0) {
+        s_i[4] = state;
+        s_i[5] = nA;
+        s_i[6] = nE;
+        s_i[7] = cur;
+      }
     }
+    __syncthreads();
+    state = s_i[4];
+    nA = s_i[5];
+    nE = s_i[6];
+    cur = s_i[7];
   }
+  while (state == 0) state = pass(std::false_type{});
+  if (state == 3) return false;
+  finish = state == 1;
   HMK();  // phase 1
   // ---- phase 2: expand the largest nodes first until the quota is reached (:678-735)
   while (!finish) {

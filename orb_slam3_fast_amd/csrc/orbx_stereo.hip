@@ -166,13 +166,22 @@ __device__ __forceinline__ void bucket_of_rank(const int* hist, int rank, int* w
   __syncthreads();
 }
 constexpr int kFiltItems = 8;  // register-resident path: up to 2048 left keypoints per pair
-__device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair, int tid, int* hist, int* wsum, int* s_v) {
+// hUr / hDepth (the single-frame entry): the filtered uRight / depth of the pair also go to the host block, from the thread that
+// decides the cut -- its values are fetched beside the SADs, so the copy costs no second pass and no further memory round trip.
+__device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair, int tid, int* hist, int* wsum, int* s_v,
+                                                   float* hUr = nullptr, float* hDepth = nullptr) {
   const int nL = a.nL[a.firstL + pair];
   const int* sad = a.sad + (long long)pair * a.capL;
   const bool inRegs = nL <= 256 * kFiltItems;
   int sv[kFiltItems];  // this thread's SADs (-1: no match / past the end): one memory round trip for all three passes
+  float pu[kFiltItems], pd[kFiltItems];
 #pragma unroll
-  for (int j = 0; j < kFiltItems; j++) sv[j] = (inRegs && tid + j * 256 < nL) ? sad[tid + j * 256] : -1;
+  for (int j = 0; j < kFiltItems; j++) {
+    const bool in = inRegs && tid + j * 256 < nL;
+    sv[j] = in ? sad[tid + j * 256] : -1;
+    pu[j] = (in && hUr) ? a.uRight[(long long)pair * a.capL + tid + j * 256] : -1.f;
+    pd[j] = (in && hUr) ? a.depth[(long long)pair * a.capL + tid + j * 256] : -1.f;
+  }
   hist[tid] = 0;
   __syncthreads();
   int cnt = 0;
@@ -196,7 +205,15 @@ __device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair
   if ((tid & 63) == 0) wsum[4 + (tid >> 6)] = cnt;
   __syncthreads();
   const int m = wsum[4] + wsum[5] + wsum[6] + wsum[7];
-  if (m == 0) return;  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
+  if (m == 0) {  // the reference reads vDistIdx[0] of an empty vector here (UB) — guarded
+    if (hUr) {
+      for (int i = tid; i < nL; i += 256) {
+        hUr[i] = a.uRight[(long long)pair * a.capL + i];
+        hDepth[i] = a.depth[(long long)pair * a.capL + i];
+      }
+    }
+    return;
+  }
   bucket_of_rank(hist, m / 2, wsum, s_v, tid);  // 0-based rank of the median
   const int bucket = s_v[0], rankIn = s_v[1];
   __syncthreads();
@@ -217,16 +234,30 @@ __device__ __forceinline__ void stereo_filter_pair(const StereoArgs& a, int pair
   const float median = (float)((bucket << 7) | s_v[0]);
   const float th = __fmul_rn(1.5f * 1.4f, median);
   auto cut = [&](int i, int s) {
-    if (s >= 0 && !((float)s < th)) {
+    const bool c = s >= 0 && !((float)s < th);
+    if (c) {
       a.uRight[(long long)pair * a.capL + i] = -1.f;
       a.depth[(long long)pair * a.capL + i] = -1.f;
     }
+    return c;
   };
   if (inRegs) {
 #pragma unroll
-    for (int j = 0; j < kFiltItems; j++) cut(tid + j * 256, sv[j]);
+    for (int j = 0; j < kFiltItems; j++) {
+      const bool c = cut(tid + j * 256, sv[j]);
+      if (hUr && tid + j * 256 < nL) {
+        hUr[tid + j * 256] = c ? -1.f : pu[j];
+        hDepth[tid + j * 256] = c ? -1.f : pd[j];
+      }
+    }
   } else {
-    for (int i = tid; i < nL; i += 256) cut(i, sad[i]);
+    for (int i = tid; i < nL; i += 256) {
+      const bool c = cut(i, sad[i]);
+      if (hUr) {
+        hUr[i] = c ? -1.f : a.uRight[(long long)pair * a.capL + i];
+        hDepth[i] = c ? -1.f : a.depth[(long long)pair * a.capL + i];
+      }
+    }
   }
 }
 
@@ -633,14 +664,8 @@ __global__ __launch_bounds__(256) void k_stereo_filter_pack(StereoArgs sa, Resul
   if (sec == 5) return;
   if (sec == 4) {
     if (blockIdx.x != 0) return;
-    stereo_filter_pair(sa, 0, threadIdx.x, fhist, fw, fv);
-    __threadfence_block();
-    __syncthreads();  // the cut entries (written by other threads of this block) are visible to the copy below
-    const int n = min(a.nOut[0], a.cap);
-    for (int i = threadIdx.x; i < n; i += 256) {
-      a.hUr[i] = a.uR[i];
-      a.hDepth[i] = a.depth[i];
-    }
+    // (nL of pair 0 == nOut[0] <= cap: the filter's own threads write the host copies of uRight / depth)
+    stereo_filter_pair(sa, 0, threadIdx.x, fhist, fw, fv, reinterpret_cast<float*>(a.hUr), reinterpret_cast<float*>(a.hDepth));
     return;
   }
   const int img = sec & 1;
@@ -679,7 +704,19 @@ hipError_t launch_stereo_match(const Geom& g, const Pyr& pl, const Pyr& pr, cons
   // (64-thread workgroups -- 4 rows / 64 candidates per trip -- run 41 us alone and the 3-handle step of bench.py is 0.8 %
   // SHORTER with them, 0.4853 vs 0.4895 ms: small workgroups get scheduled between k_detect's one-wave cells, large ones
   // wait for it to drain; not adopted, the single-frame latency matters more than 0.8 %)
-  ORBX_SB(24, 512, 256, 128);
+#ifdef ORBX_BAND_SWEEP   // measurement aid (make prof PROF_FLAGS=-DORBX_BAND_SWEEP): band shapes of the direct form, ORBX_BAND_SHAPE=0..5
+  static const int shape = getenv("ORBX_BAND_SHAPE") ? atoi(getenv("ORBX_BAND_SHAPE")) : 0;
+  if (direct && shape == 1) ORBX_SB(12, 256, 256, 64);
+  else if (direct && shape == 2) ORBX_SB(24, 512, 256, 128);
+  else if (direct && shape == 3) ORBX_SB(12, 512, 256, 64);
+  else if (direct && shape == 4) ORBX_SB(8, 256, 128, 64);
+  else if (direct && shape == 5) ORBX_SB(32, 1024, 256, 128);
+  else
+#endif
+  // the direct form (one pair): 16-row bands -- the C call of a 1280x720 frame 0.1923 (24 rows) / 0.1900 (16) / 0.1902 (12 rows, 64 left
+  // entries) / 0.1905 ms (8 rows, 256 threads), tools/lat_c.py on one box, three runs each within 0.5 us
+  if (direct) ORBX_SB(16, 512, 256, 128);
+  else ORBX_SB(24, 512, 256, 128);
 #undef ORBX_SB
   return hipGetLastError();
 }
