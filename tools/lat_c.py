@@ -35,3 +35,16 @@ for i in range(calls):
     t0 = time.perf_counter(); f(*a); ts.append((time.perf_counter() - t0) * 1e3)
 ts = np.array(ts)
 print("orbx_extract_stereo (C ABI, caller arrays): mean %.4f p50 %.4f p90 %.4f ms over %d calls  %s" % (ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90), calls, os.environ.get("LAT_TAG", "")))
+if os.environ.get("LAT_EXTRA_HANDLES"):
+    # the same with other handles (and their streams) alive, idle: bench.py's latency leg runs beside the headline's four handles
+    extra = [orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=64) for _ in range(int(os.environ["LAT_EXTRA_HANDLES"]))]
+    for e in extra:
+        e(base[0][0])
+    gc.collect(); gc.disable()
+    for i in range(30): f(*args[i % nfr])
+    ts = []
+    for i in range(calls):
+        a = args[i % nfr]
+        t0 = time.perf_counter(); f(*a); ts.append((time.perf_counter() - t0) * 1e3)
+    ts = np.array(ts)
+    print("  with %d idle handles alive: mean %.4f p50 %.4f p90 %.4f ms" % (len(extra), ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90)))
