@@ -77,9 +77,11 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip latency / H2D-inclusive / cpu legs (profiling runs)")
     ap.add_argument("--latency-frames", type=int, default=200)
     ap.add_argument("--h2d-steps", type=int, default=30)
-    ap.add_argument("--other-steps", type=int, default=20,
+    ap.add_argument("--other-steps", type=int, default=400,
                     help="timed steps of each secondary configuration in the other_configs leg (C2 640x480 mono, 640x480 stereo, "
-                         "C4 512x512 fisheye stereo; 8-pair batches; 0 = skip)")
+                         "C4 512x512 fisheye stereo; 8-pair batches; 0 = skip).  400 since the second half of round 5: a 16-frame step is "
+                         "52 us and four batches are in flight, so the 20 steps of rounds 3 - 5 timed 1 ms of which a fifth was the drain "
+                         "of the pipeline (285 k frames/s against 308 k over 400 steps, profiles/r5c_c2_cascade_sweep.txt)")
     ap.add_argument("--handles", type=int, default=4,
                     help="extractor handles used round-robin (each owns a stream + buffers); batches of different handles overlap on the GPU: the "
                          "latency-bound quadtree and stereo kernels of one batch run under the FAST / describe kernels of the others.  Round 5, "
