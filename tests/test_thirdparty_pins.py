@@ -5,7 +5,10 @@ OpenCV fixture -- parity stays "partial" -- but each holds a piece of the restat
 * the coefficient tables of cv::resize's linear path (src/ORBextractor.cc:1122) against an exact-rational model
   (fractions.Fraction) of the sampling position (d + 1/2) * (src / dst) - 1/2;
 * cv::FAST's non-maximum suppression rule and output order (src/ORBextractor.cc:810-826) against a brute-force numpy 3x3 strict
-  maximum over a score map that tests/test_pin_skimage.py pins to scikit-image.
+  maximum over a score map that tests/test_pin_skimage.py pins to scikit-image;
+* (second half of round 5) the OUTPUTS of cv::resize (src/ORBextractor.cc:1122), GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101
+  (:1074-1076, both tap generations) and cv::remap INTER_LINEAR (src/System.cc:294) against real-valued models in double precision
+  (numpy, scipy.ndimage.correlate1d / map_coordinates): within the fixed-point quantisation and unbiased.
 """
 import ctypes as C
 from fractions import Fraction
@@ -104,3 +107,93 @@ def test_nms_rule_and_output_order_against_bruteforce_strict_maximum(oracle):
         # equal neighbours suppress each other: among the pre-NMS corners some have an equal-score neighbour and none of them is kept
         eq = (S > 0) & (S == nb.max(0))
         assert eq.any() and not (eq & keep).any()
+
+
+# ---- second set (round 5): the OUTPUTS of the three image filters the oracle restates from memory, against float models that share
+# no code with it (numpy / scipy.ndimage in double precision).  A fixed-point filter may differ from the exact real-valued filter
+# only by its documented quantisation, so the bounds below are tight enough to catch a wrong sampling position, a wrong border rule,
+# a wrong tap or a shifted kernel -- the failure modes of a restatement -- though not a different rounding of the last bit.
+
+def _bilinear_float(src, dw, dh):
+    """cv::resize INTER_LINEAR in real arithmetic: sample at ((i + 1/2) * s / d - 1/2), clamp coordinates to the image."""
+    sh, sw = src.shape
+    x = (np.arange(dw) + 0.5) * (sw / dw) - 0.5
+    y = (np.arange(dh) + 0.5) * (sh / dh) - 0.5
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+    fx, fy = x - x0, y - y0
+    xa, xb = np.clip(x0, 0, sw - 1), np.clip(x0 + 1, 0, sw - 1)
+    ya, yb = np.clip(y0, 0, sh - 1), np.clip(y0 + 1, 0, sh - 1)
+    s = src.astype(np.float64)
+    top = s[ya][:, xa] * (1 - fx) + s[ya][:, xb] * fx
+    bot = s[yb][:, xa] * (1 - fx) + s[yb][:, xb] * fx
+    return top * (1 - fy)[:, None] + bot * fy[:, None]
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(1280, 720, 1067, 600), (640, 480, 533, 400), (357, 201, 298, 167), (333, 517, 278, 431),
+                                         (400, 300, 200, 150), (300, 200, 75, 50)])
+def test_resize_output_within_quantisation_of_real_bilinear(oracle, sw, sh, dw, dh):
+    """ComputePyramid's cv::resize (src/ORBextractor.cc:1122): 11-bit weights per axis, intermediate >> 4, two >> 16 products and a
+    final (+2) >> 2.  Against the real-valued bilinear sample the result may be off by the weight rounding (255 * 2 * 2^-12), the
+    truncations (< 1 gray level in total) and the final rounding (1/2): |oracle - real| < 1.25 everywhere, and unbiased."""
+    rng = np.random.default_rng(sw * 31 + dw)
+    src = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+    src[: sh // 3] = np.clip(np.add.outer(np.arange(sh // 3), np.arange(sw)) % 256, 0, 255).astype(np.uint8)  # a smooth part too
+    got = oracle.resize(src, dw, dh).astype(np.float64)
+    want = _bilinear_float(src, dw, dh)
+    d = got - want
+    assert np.abs(d).max() < 1.25, np.abs(d).max()
+    assert abs(d.mean()) < 0.2, d.mean()
+
+
+def test_gaussian_blur_against_real_gaussian_and_reflect101(oracle):
+    """GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) of src/ORBextractor.cc:1074-1076: cv::getGaussianKernel(7, 2) = exp(-x^2 / 8)
+    normalised; the 8-bit path uses 8.8 fixed-point taps per axis.  scipy.ndimage.correlate1d with the REAL kernel and
+    mode='mirror' (= REFLECT_101: the edge pixel is not repeated) is the reference.  The current taps (18 34 48 56 48 34 18, sum
+    256: OpenCV >= 4.5.1) stay within the taps' rounding and are unbiased; the taps of OpenCV 4.0 .. 4.5.0 (18 34 49 55 49 34 18)
+    sum to 257 -- a constant image of 100 comes out as 101 -- i.e. they follow the real filter scaled by (257 / 256)^2."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (97, 123), dtype=np.uint8)
+    img[40:60, 30:90] = 255
+    img[:5, :] = 0
+    k = np.exp(-(np.arange(-3, 4) ** 2) / 8.0)
+    k /= k.sum()
+    f64 = img.astype(np.float64)
+    want = ndi.correlate1d(ndi.correlate1d(f64, k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    wrong = ndi.correlate1d(ndi.correlate1d(f64, k, axis=1, mode="reflect"), k, axis=0, mode="reflect")   # BORDER_REFLECT: edge repeated
+    edge = np.zeros(img.shape, bool)
+    edge[:3, :] = edge[-3:, :] = edge[:, :3] = edge[:, -3:] = True
+    for variant, scale in ((451, 1.0), (440, (257.0 / 256.0) ** 2)):
+        got = oracle.blur(img, variant).astype(np.float64)
+        d = got - np.minimum(want * scale, 255.0)
+        assert np.abs(d).max() < 1.5, (variant, np.abs(d).max())
+        assert np.abs(d).mean() < 0.35 and abs(d.mean()) < 0.02, (variant, np.abs(d).mean(), d.mean())
+        # the border rule alone: the model with the edge pixel repeated is ten times further away along the border
+        assert np.abs(d)[edge].mean() * 5 < np.abs(got - np.minimum(wrong * scale, 255.0))[edge].mean()
+    assert (oracle.blur(np.full((40, 40), 100, np.uint8), 451) == 100).all()
+    assert (oracle.blur(np.full((40, 40), 100, np.uint8), 440) == 101).all()
+
+
+def test_remap_within_quantisation_of_real_bilinear(oracle):
+    """cv::remap INTER_LINEAR with CV_32FC1 maps (initUndistortRectifyMap + remap of the stereo examples, src/System.cc:294): the
+    fractional position is quantised to 1/32, weights to 15 bits.  Against scipy.ndimage.map_coordinates(order=1) on the same float
+    maps, inside the image: the 1/32 quantisation moves a sample by at most 1/64 px per axis, i.e. by at most (1/64 + 1/64) * the
+    local gradient -- on a smooth image (gradient <= 4 per px) well under 1 gray level."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    h, w = 120, 160
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (2.0 * xx + 1.5 * yy + 20 * np.sin(xx / 9.0) + 15 * np.cos(yy / 7.0)) % 256
+    img = np.clip(np.where(np.abs(np.diff(img, axis=1, append=img[:, -1:])) > 100, 128, img), 0, 255).astype(np.uint8)
+    rng = np.random.default_rng(3)
+    mapx = (xx + 3.0 * np.sin(yy / 17.0) + rng.uniform(-0.5, 0.5, (h, w))).astype(np.float32)
+    mapy = (yy + 2.0 * np.cos(xx / 23.0) + rng.uniform(-0.5, 0.5, (h, w))).astype(np.float32)
+    got = oracle.remap(img, mapx, mapy).astype(np.float64)
+    want = ndi.map_coordinates(img.astype(np.float64), [mapy.astype(np.float64), mapx.astype(np.float64)], order=1, mode="nearest")
+    inside = (mapx >= 1) & (mapx <= w - 2) & (mapy >= 1) & (mapy <= h - 2)
+    g = np.maximum(np.abs(np.diff(img.astype(float), axis=1, append=0)), np.abs(np.diff(img.astype(float), axis=0, append=0)))
+    iy, ix = np.clip(np.rint(mapy).astype(int), 0, h - 1), np.clip(np.rint(mapx).astype(int), 0, w - 1)
+    smooth = inside & (ndi.maximum_filter(g, 5)[iy, ix] <= 8)        # (the gradient around the SOURCE position of the sample)
+    d = (got - want)[smooth]
+    assert smooth.sum() > 8000
+    assert np.abs(d).max() < 1.0, np.abs(d).max()
+    assert abs(d.mean()) < 0.2
