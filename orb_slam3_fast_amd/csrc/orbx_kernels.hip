@@ -640,7 +640,7 @@ __device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tm
   for (int i = tid; i < n; i += nt) a[i] = tmp[i];
   __syncthreads();
   SMK();
-#ifdef OCT_PROF
+#if defined(OCT_PROF) && !defined(OCT_NO_SORT_PRINT)
   if (tid == 0 && blockIdx.x == 0 && gridDim.x > 1) {
     printf("sort n=%d:", n);
     for (int i = 1; i < nsmk; i++) printf(" %d", (int)(smk[i] - smk[i - 1]));
@@ -1753,10 +1753,24 @@ __global__ __launch_bounds__(OCT_NT, 4) void k_octree(Geom g, const uint32_t* __
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_i[8];
   const int tid = threadIdx.x;
+#ifdef OCT_WG_PROF  // measurement aid: life of every (image, level) workgroup of one launch, x10 ns (make prof PROF_FLAGS=-DOCT_WG_PROF,
+                    // tools/octree_frame_prof.py + tools/octwg_summary.py: resolves 0.1 us where the frame's wall time resolves 1 us)
+  struct WgPrint {
+    long long t0;
+    int l, img, on;
+    __device__ ~WgPrint() {
+      if (on) printf("octwg level %d img %d start %lld end %lld\n", l, img, t0 % 100000000, wall_clock64() % 100000000);
+    }
+  } wgPrint{wall_clock64(), 0, 0, (int)(threadIdx.x == 0)};
+#endif
   // Level-major block order (all images' level 0 first): the 2-per-CU residency then pairs a heavy level-0 / level-1
   // workgroup with a light level-4+ one instead of with another heavy one.
   const int nimg_ = gridDim.x / nlv;
   const int l = level0 + blockIdx.x / nimg_, img = blockIdx.x % nimg_;
+#ifdef OCT_WG_PROF
+  wgPrint.l = l;
+  wgPrint.img = img;
+#endif
   const LevelDev L = g.lv[l];
   const int maxn = oct_maxn(g);
   const int nrep = oct_rep(g);

@@ -11,6 +11,6 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 720
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 1500
 L, R = synth.stereo_pair(W, H, 5)
 ex = orbx.ORBextractor(NF, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2)
-for i in range(3):
+for i in range(int(os.environ.get("PROF_FRAMES", "3"))):
     ex.extract_stereo(L, R, bf=63.8, b=0.12)
     print("----", flush=True)
