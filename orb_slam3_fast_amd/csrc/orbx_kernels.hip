@@ -559,6 +559,63 @@ __device__ void introsort_seg_reg(uint64_t* a, int first, int last, int depth0, 
   if (lane < n) a[first + lane] = v;
 }
 
+// One __unguarded_partition_pivot of a segment of 65 .. 128 elements with the segment in REGISTERS (two elements per lane: lane i holds
+// first + i and first + 64 + i), the twin of partition_wave for the sizes introsort_seg_reg cannot take.  partition_wave builds the two
+// stopper lists in LDS, counts the crossing point K over them and swaps pairs through them -- six dependent LDS round trips and three
+// wave syncs, 1.5 - 1.8 us for the 128 expandable nodes of a level-0 quadtree.  Here nothing is listed: with L ascending and R
+// descending, "L[k] < R[k]" is monotone in k, so a left stopper at index i with rank r (left stoppers below it) swaps iff MORE than r
+// right stoppers lie above i, a right stopper at j with rank s (right stoppers above it) iff more than s left stoppers lie below j --
+// prefix popcounts of four ballots.  The partners meet through a mailbox (the swapping left stopper of rank r posts to box[r] and
+// collects box[half + r], its partner the other way round; K <= (n - 1) / 2 pairs, so both boxes fit the segment's own n entries of
+// the scratch array): ONE LDS round trip.  cut = min(first non-swapping left stopper, last swapping right stopper) as before.
+__device__ int partition_reg2(uint64_t* a, int first, int last, uint64_t* box, int lane) {
+  const KeyLess less;
+  const int n = last - first;  // 65 .. 128 (uniform)
+  uint64_t v0 = a[first + lane], v1 = a[first + min(64 + lane, n - 1)];
+  const bool in0 = lane >= 1, in1 = 64 + lane < n;   // (index 0 is the pivot's slot)
+  auto get = [&](int i) { return i < 64 ? readlane_u64(v0, i) : readlane_u64(v1, i - 64); };  // i uniform, relative to first
+  const int mid = n / 2;
+  const uint64_t va = get(1), vb = get(mid), vc = get(n - 1);
+  int sel;
+  if (less(va, vb)) sel = less(vb, vc) ? mid : (less(va, vc) ? n - 1 : 1);
+  else if (less(va, vc)) sel = 1;
+  else sel = less(vb, vc) ? n - 1 : mid;
+  const uint64_t vf = get(0), pivot = get(sel);
+  if (lane == 0) v0 = pivot;
+  if (sel < 64) {
+    if (lane == sel) v0 = vf;
+  } else if (lane == sel - 64) {
+    v1 = vf;
+  }
+  const bool stL0 = in0 && !less(v0, pivot), stL1 = in1 && !less(v1, pivot);
+  const bool stR0 = in0 && !less(pivot, v0), stR1 = in1 && !less(pivot, v1);
+  const uint64_t mL0 = __ballot(stL0), mL1 = __ballot(stL1), mR0 = __ballot(stR0), mR1 = __ballot(stR1);
+  const uint64_t lt = lanemask_lt(), gt = ~(lt | (1ull << lane));
+  const int belowL0 = __popcll(mL0 & lt), belowL1 = __popcll(mL0) + __popcll(mL1 & lt);   // left stoppers below this element
+  const int aboveR0 = __popcll(mR0 & gt) + __popcll(mR1), aboveR1 = __popcll(mR1 & gt);   // right stoppers above it
+  const bool swL0 = stL0 && aboveR0 > belowL0, swL1 = stL1 && aboveR1 > belowL1;
+  const bool swR0 = stR0 && belowL0 > aboveR0, swR1 = stR1 && belowL1 > aboveR1;
+  const uint64_t sL0 = __ballot(swL0), sL1 = __ballot(swL1), sR0 = __ballot(swR0), sR1 = __ballot(swR1);
+  const uint64_t nsL0 = mL0 & ~sL0, nsL1 = mL1 & ~sL1;
+  const int INF = 1 << 30;
+  const int lk = nsL0 ? (int)__builtin_ctzll(nsL0) : (nsL1 ? 64 + (int)__builtin_ctzll(nsL1) : INF);
+  const int rk = sR0 ? (int)__builtin_ctzll(sR0) : (sR1 ? 64 + (int)__builtin_ctzll(sR1) : INF);
+  const int half = n / 2;
+  if (swL0) box[belowL0] = v0;
+  if (swL1) box[belowL1] = v1;
+  if (swR0) box[half + aboveR0] = v0;
+  if (swR1) box[half + aboveR1] = v1;
+  wsync();
+  if (swL0) v0 = box[half + belowL0];
+  if (swL1) v1 = box[half + belowL1];
+  if (swR0) v0 = box[aboveR0];
+  if (swR1) v1 = box[aboveR1];
+  a[first + lane] = v0;
+  if (in1) a[first + 64 + lane] = v1;
+  wsync();
+  return first + min(lk, rk);
+}
+
 // The same std::sort replica run by a WHOLE workgroup.  __introsort_loop is a binary tree of partitions: a segment
 // (first, last, depth) is partitioned, and both halves continue with depth - 1 -- nothing else is shared between them.
 // So the tree is walked breadth first: every wave takes segments of the current level (partition_wave on disjoint ranges
@@ -597,7 +654,8 @@ __device__ __forceinline__ void introsort_block(uint64_t* a, int n, uint64_t* tm
         } else if (depth == 0) {
           if (lane == 0) is_heapsort<uint64_t, KeyLess>(a, first, last, less);
         } else {
-          const int cut = partition_wave(a, first, last, Li + first, Ri + first, lane);
+          const int cut = last - first <= 128 ? partition_reg2(a, first, last, tmp + first, lane)
+                                              : partition_wave(a, first, last, Li + first, Ri + first, lane);
           if (lane == 0) {
             const uint32_t d = (uint32_t)(depth - 1) << 26;
             if (cut - first > 16) segs[(cur ^ 1) * 256 + atomicAdd(&cnt[cur ^ 1], 1u)] = (uint32_t)first | (uint32_t)cut << 13 | d;
