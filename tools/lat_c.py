@@ -48,3 +48,13 @@ if os.environ.get("LAT_EXTRA_HANDLES"):
         t0 = time.perf_counter(); f(*a); ts.append((time.perf_counter() - t0) * 1e3)
     ts = np.array(ts)
     print("  with %d idle handles alive: mean %.4f p50 %.4f p90 %.4f ms" % (len(extra), ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90)))
+if os.environ.get("LAT_HOST_PYRAMID"):
+    ex.set_host_pyramid(True)
+    for i in range(30): f(*args[i % nfr])
+    ts = []
+    for i in range(calls):
+        a = args[i % nfr]
+        t0 = time.perf_counter(); f(*a); ts.append((time.perf_counter() - t0) * 1e3)
+    ts = np.array(ts)
+    print("  with the host pyramid kept: mean %.4f p50 %.4f p90 %.4f ms" % (ts.mean(), np.percentile(ts, 50), np.percentile(ts, 90)))
+    ex.set_host_pyramid(False)
