@@ -622,7 +622,7 @@ __global__ __launch_bounds__(NT) void k_stereo_band(Geom g, Pyr pl, Pyr pr, Ster
     ST_MK();
   }
 #ifdef ST_PROF
-  if (tid == 0 && (pair % 8) == 5 && (blockIdx.x % 9) == 4) {
+  if (tid == 0 && ((pair % 8) == 5 || gridDim.y == 1) && (blockIdx.x % 9) == 4) {
     char buf[200]; (void)buf;
     printf("band %2d pair %2d nL %2d nR %2d start %5lld: tab %d | stage %d bar %d match %d bar %d queue+SAD %d  (x10 ns; total %d)\n", (int)blockIdx.x, pair,
            jLe - jLb, jRe - jRb, tq[0] % 100000, (int)(tq[1] - tq[0]), (int)(tq[2] - tq[1]), (int)(tq[3] - tq[2]), (int)(tq[4] - tq[3]),
