@@ -16,8 +16,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                    roofline.streaming = the three streaming kernels of SURVEY 8d against the HBM peak
   "cpu_baseline":  the CPU oracle (port of the reference's serial semantics) frame-parallel on the host cores,
   "cpu_mt":        the same port with the reference's thread structure (2 eye threads x per-level tasks), one pipeline
-  "latency_ms":    one 1280x720 stereo frame at a time through the drop-in C ABI call (orbx_extract_stereo with caller output
-                   arrays); "latency_python_ms" the same through the Python wrapper (rounds 1-5's latency_ms);
+  "latency_ms":    one 1280x720 stereo frame at a time through the C++ drop-in class, timed in C++ (tests/cpp/frame_like);
+                   "latency_ctypes_ms" the C ABI call from this process, "latency_python_ms" the Python wrapper (rounds 1-5's latency_ms);
                    "extract_ms", "stereo_ms": timers placed like the reference's REGISTER_TIMES (src/Frame.cc:196-232)
   "h2d_inclusive_value": the same batches with page-locked HOST frames uploaded every step and all results downloaded
 """
@@ -831,18 +831,61 @@ def latency_leg(a, wl, orbx, np):
     ex.set_host_pyramid(False)
     gc.enable()
     note = ("single %dx%d stereo frame, pageable host images in, host keypoints / descriptors / uRight / depth out, %d "
-            "distinct frames; latency_ms = the C ABI call orbx_extract_stereo with the caller's output arrays (both eyes + "
-            "ComputeStereoMatches, one synchronisation, results copied into the caller's memory; the C++ mirror with "
-            "mbKeepHostPyramid = false), timed around the foreign call with prebuilt ctypes arguments; latency_python_ms = the same "
-            "frame through this package's Python wrapper (argument marshalling and numpy result copies on top; this is what rounds "
-            "1-5 reported as latency_ms); latency_with_host_pyramid_ms = the C ABI call with the host copy of both eyes' pyramids "
-            "kept current (the mirror's default, mbKeepHostPyramid = true: unmodified readers of mvImagePyramid keep working; "
-            "orbx_set_host_pyramid: 5.8 MB of DMA copies per frame beside the kernels, levels handed out in place), "
-            "latency_with_host_pyramid_python_ms through the wrapper incl. the level views; extract_ms / stereo_ms = the two "
+            "distinct frames.  latency_ms = ORB_SLAM3::ORBextractor::ExtractStereo of the C++ drop-in class (both eyes + "
+            "ComputeStereoMatches, results in std::vector<cv::KeyPoint> / cv::Mat / mvuRight / mvDepth: what the stereo Frame constructor "
+            "of src/Frame.cc:196-232 calls), timed with std::chrono inside a C++ program (tests/cpp/frame_like latency, built here "
+            "with g++ against the shipped liborbx.so; mbKeepHostPyramid = false), latency_with_host_pyramid_ms = the same with the "
+            "class's default mbKeepHostPyramid = true (the host copy of both eyes' pyramids kept current: unmodified readers of "
+            "mvImagePyramid keep working; 5.8 MB of DMA copies per frame beside the kernels, levels handed out in place); "
+            "latency_source says which measurement the two keys hold (ctypes when no C++ compiler is present).  latency_ctypes_ms / "
+            "latency_with_host_pyramid_ctypes_ms = the C ABI call orbx_extract_stereo with caller output arrays from THIS process "
+            "(prebuilt ctypes arguments, timed around the foreign call: the interpreter's and torch's threads share the cores with the "
+            "calling thread); latency_python_ms / latency_with_host_pyramid_python_ms = through this package's Python wrapper (argument "
+            "marshalling and numpy result copies on top: what rounds 1-5 reported as latency_ms); extract_ms / stereo_ms = the two "
             "REGISTER_TIMES brackets as separate wrapper calls" % (W, H, len(frames)))
-    return {"latency_ms": _stats(lat, np), "latency_python_ms": _stats(latp, np), "latency_with_host_pyramid_ms": _stats(lpc, np),
-            "latency_with_host_pyramid_python_ms": _stats(lp, np), "extract_ms": _stats(te, np), "stereo_ms": _stats(ts, np),
-            "latency_note": note}
+    out = {"latency_ctypes_ms": _stats(lat, np), "latency_python_ms": _stats(latp, np), "latency_with_host_pyramid_ctypes_ms": _stats(lpc, np),
+           "latency_with_host_pyramid_python_ms": _stats(lp, np), "extract_ms": _stats(te, np), "stereo_ms": _stats(ts, np),
+           "latency_note": note}
+    cpp = cpp_mirror_latency(frames[:32], W, H, NF, a.latency_frames, np)
+    out.update(cpp)
+    # latency_ms = the call as the reference makes it: the C++ class, timed in C++ (its own process: no interpreter threads beside the
+    # calling thread); without a C++ compiler on the box, the C ABI call from this process
+    out["latency_ms"] = cpp.get("latency_cpp_mirror_ms") or out["latency_ctypes_ms"]
+    out["latency_with_host_pyramid_ms"] = cpp.get("latency_cpp_mirror_with_host_pyramid_ms") or out["latency_with_host_pyramid_ctypes_ms"]
+    out["latency_source"] = "cpp_mirror" if cpp.get("latency_cpp_mirror_ms") else "ctypes"
+    return out
+
+
+def cpp_mirror_latency(frames, W, H, NF, calls, np):
+    """The same frames through the C++ drop-in class (csrc/ORBextractor.h ExtractStereo: std::vector<cv::KeyPoint>, cv::Mat,
+    mvuRight / mvDepth filled like the reference's Frame members), timed INSIDE a C++ program (tests/cpp/frame_like latency,
+    compiled here with g++ against the shipped liborbx.so): no Python in the measurement.  None when g++ is missing."""
+    import re
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    try:
+        sys.path.insert(0, os.path.join(root, "tests"))
+        import test_cpp_mirror
+        exe = test_cpp_mirror.build_exe(False)
+        path = os.path.join(tempfile.gettempdir(), "orbx_bench_lat_frames_%d.raw" % os.getpid())
+        np.stack([np.stack([L, R]) for L, R in frames]).tofile(path)
+        try:
+            r = subprocess.run([exe, "latency", str(W), str(H), str(NF), path, str(len(frames)), str(max(50, calls))],
+                               capture_output=True, text=True, timeout=120)
+        finally:
+            os.remove(path)
+        res = {}
+        for keep, key in ((0, "latency_cpp_mirror_ms"), (1, "latency_cpp_mirror_with_host_pyramid_ms")):
+            m = re.search(r"mbKeepHostPyramid=%d: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)  std ([0-9.]+)  p99 ([0-9.]+)" % keep, r.stdout)
+            res[key] = {"mean": float(m.group(1)), "std": float(m.group(4)), "p50": float(m.group(2)), "p99": float(m.group(5)),
+                        "frames": max(50, calls)} if m else None
+        res["latency_cpp_mirror_note"] = ("ORB_SLAM3::ORBextractor::ExtractStereo of csrc/ORBextractor.h (cvlite types) on %d distinct frames, timed "
+                                          "with std::chrono inside tests/cpp/frame_like; with_host_pyramid = the class's default "
+                                          "mbKeepHostPyramid = true" % len(frames))
+        return res
+    except Exception as ex_:   # (context, never a reason to lose the line)
+        return {"latency_cpp_mirror_ms": None, "latency_cpp_mirror_error": str(ex_)[:160]}
 
 
 def h2d_leg(a, wl, orbx, np, torch):

@@ -180,20 +180,47 @@ class ORBextractor {
     int nl = 0, nr = 0;
     const bool stereo = mbf > 0.f && mvuRight && mvDepth;
     ApplyHostPyramidMode();
-    if (orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, nullptr, nullptr, 0, &nl, &monoLeft, nullptr, nullptr, 0, &nr,
-                            &monoRight, stereo ? mbf : 0.f, mb, nullptr, nullptr) != ORBX_OK)
-      throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
-    const orbx_keypoint *kl = nullptr, *kr = nullptr;
-    const uint8_t *dl = nullptr, *dr = nullptr;
-    const float *ur = nullptr, *dp = nullptr;
-    if (orbx_host_results(h_, 0, &kl, &dl, nullptr, nullptr, &ur, &dp) != ORBX_OK ||
-        orbx_host_results(h_, 1, &kr, &dr, nullptr, nullptr, nullptr, nullptr) != ORBX_OK)
-      throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
-    FillOutputs(keysLeft, descLeft, kl, dl, nl);
-    FillOutputs(keysRight, descRight, kr, dr, nr);
-    if (stereo) {
-      mvuRight->assign(ur, ur + nl);
-      mvDepth->assign(dp, dp + nl);
+    // The outputs are handed to the library as ITS output arrays, sized to the extractor's capacity and trimmed afterwards: the
+    // library copies keypoints and descriptors into them while the stereo association still runs (include/orbx.h), so the copies
+    // cost nothing at the end of the call.  (Descriptor outputs that are not plain matrices take the copy-after path below.)
+    const int cap = nfeatures + 3 * nlevels;
+    uint8_t* dl = DescBuffer(descLeft, cap);
+    uint8_t* dr = dl ? DescBuffer(descRight, cap) : nullptr;
+    if (dl && dr) {
+      keysLeft.resize((size_t)cap);
+      keysRight.resize((size_t)cap);
+      if (stereo) {
+        mvuRight->resize((size_t)cap);
+        mvDepth->resize((size_t)cap);
+      }
+      const int rc = orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, reinterpret_cast<orbx_keypoint*>(keysLeft.data()), dl, cap, &nl,
+                                         &monoLeft, reinterpret_cast<orbx_keypoint*>(keysRight.data()), dr, cap, &nr, &monoRight,
+                                         stereo ? mbf : 0.f, mb, stereo ? mvuRight->data() : nullptr, stereo ? mvDepth->data() : nullptr);
+      if (rc != ORBX_OK) throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
+      keysLeft.resize((size_t)nl);
+      keysRight.resize((size_t)nr);
+      TrimDesc(descLeft, nl);
+      TrimDesc(descRight, nr);
+      if (stereo) {
+        mvuRight->resize((size_t)nl);
+        mvDepth->resize((size_t)nl);
+      }
+    } else {
+      if (orbx_extract_stereo(h_, pl, pr, w, h, sl, sr, ll, lr, nullptr, nullptr, 0, &nl, &monoLeft, nullptr, nullptr, 0, &nr,
+                              &monoRight, stereo ? mbf : 0.f, mb, nullptr, nullptr) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
+      const orbx_keypoint *kl = nullptr, *kr = nullptr;
+      const uint8_t *dl2 = nullptr, *dr2 = nullptr;
+      const float *ur = nullptr, *dp = nullptr;
+      if (orbx_host_results(h_, 0, &kl, &dl2, nullptr, nullptr, &ur, &dp) != ORBX_OK ||
+          orbx_host_results(h_, 1, &kr, &dr2, nullptr, nullptr, nullptr, nullptr) != ORBX_OK)
+        throw std::runtime_error(std::string("ORBextractor::ExtractStereo: ") + orbx_last_error());
+      FillOutputs(keysLeft, descLeft, kl, dl2, nl);
+      FillOutputs(keysRight, descRight, kr, dr2, nr);
+      if (stereo) {
+        mvuRight->assign(ur, ur + nl);
+        mvDepth->assign(dp, dp + nl);
+      }
     }
     if (mbKeepHostPyramid) {
       ViewImagePyramid(0);
@@ -283,6 +310,30 @@ class ORBextractor {
   std::vector<float> mvInvLevelSigma2;
 
  private:
+  // a cap x 32 byte descriptor matrix behind `desc` for the library to fill (nullptr: `desc` is not a plain matrix), and its trim to n rows
+  static uint8_t* DescBuffer(ocv::OutputArray desc, int cap) {
+#ifdef ORBX_HAVE_OPENCV
+    if (!desc.isMat()) return nullptr;
+    desc.create(cap, 32, CV_8U);
+    cv::Mat& m = desc.getMatRef();
+    return m.isContinuous() ? m.data : nullptr;
+#else
+    desc.create(cap, 32);
+    return desc.data;
+#endif
+  }
+  static void TrimDesc(ocv::OutputArray desc, int n) {
+    if (n == 0) {
+      desc.release();
+      return;
+    }
+#ifdef ORBX_HAVE_OPENCV
+    cv::Mat& m = desc.getMatRef();
+    m = m.rowRange(0, n);   // (a header over the first n rows: no copy)
+#else
+    desc.rows = n;
+#endif
+  }
   static void FillOutputs(std::vector<ocv::KeyPoint>& keys, ocv::OutputArray desc, const orbx_keypoint* k, const uint8_t* d, int n) {
     keys.resize(n);
     if (n) std::memcpy(static_cast<void*>(keys.data()), k, (size_t)n * sizeof(orbx_keypoint));

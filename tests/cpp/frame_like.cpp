@@ -4,6 +4,9 @@
 // against the oracle.   usage: frame_like <w> <h> <nfeat> <left.raw> <right.raw> <outprefix>
 // Built twice by tests/test_cpp_mirror.py: with -DORBX_NO_OPENCV (the cvlite stand-ins) and with
 // -Itests/cpp/opencv_stub (the cv::InputArray / cv::OutputArray / cv::Mat branch = the reference's own signatures).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -213,6 +216,45 @@ int main(int argc, char** argv) {
     dump(out + ".p3d", p3d.data(), p3d.size());
     dump(out + ".uR", uR.data(), uR.size());
     std::printf("%d\n", n);
+    return 0;
+  }
+  if (std::string(argv[1]) == "latency") {
+    // frame_like latency <w> <h> <nfeatures> <frames.raw: n x (left, right) gray images> <n> <calls>: the stereo Frame constructor's
+    // extraction + ComputeStereoMatches (src/Frame.cc:196-232) through the drop-in class, one frame at a time, timed in C++ --
+    // ExtractStereo fills std::vector<cv::KeyPoint> / cv::Mat / mvuRight / mvDepth like the reference's members.  Prints the mean
+    // and median per frame with mbKeepHostPyramid = false and with the class's default (true: mvImagePyramid kept current).
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), nf = std::atoi(argv[4]), n = std::atoi(argv[6]), calls = std::atoi(argv[7]);
+    std::vector<uint8_t> frames = slurp(argv[5]);
+    if (frames.size() < (size_t)n * 2 * w * h) return 4;
+    ORBextractor ex(nf, 1.2f, 8, 20, 7, w, h);
+    std::vector<int> lap = {0, 0};
+    for (int keep = 0; keep < 2; keep++) {
+      ex.mbKeepHostPyramid = keep != 0;
+      std::vector<double> ms;
+      size_t nk = 0;
+      for (int i = -20; i < calls; i++) {
+        uint8_t* pl = frames.data() + (size_t)((i + 20) % n) * 2 * w * h;
+        ocv::Mat imL = wrap(h, w, pl), imR = wrap(h, w, pl + (size_t)w * h);
+        std::vector<ocv::KeyPoint> kL, kR;
+        ocv::Mat dL, dR;
+        std::vector<float> uR, depth;
+        int mL = 0, mR = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        ex.ExtractStereo(imL, imR, kL, dL, kR, dR, lap, lap, mL, mR, 0.12f * 532.03f, 0.12f, &uR, &depth);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (i >= 0) ms.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        nk += kL.size();
+        if (keep && (ex.mvImagePyramid.size() != 8 || ex.mvImagePyramid[0].rows != h)) return 5;
+      }
+      double mean = 0, var = 0;
+      for (double v : ms) mean += v;
+      mean /= (double)ms.size();
+      for (double v : ms) var += (v - mean) * (v - mean);
+      std::sort(ms.begin(), ms.end());
+      std::printf("ExtractStereo mbKeepHostPyramid=%d: mean %.4f ms  p50 %.4f  p90 %.4f  std %.4f  p99 %.4f  (%d calls, %d distinct frames, %.0f keypoints per left image)\n",
+                  keep, mean, ms[ms.size() / 2], ms[ms.size() * 9 / 10], std::sqrt(var / (double)ms.size()), ms[std::min(ms.size() - 1, ms.size() * 99 / 100)],
+                  calls, n, (double)nk / (calls + 20));
+    }
     return 0;
   }
   const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), nf = std::atoi(argv[3]);

@@ -103,6 +103,12 @@ class Mat {
   const uint8_t* ptr(int r = 0) const { return data + (size_t)r * (size_t)step; }
   template <class T> T* ptr(int r = 0) { return reinterpret_cast<T*>(ptr(r)); }
   template <class T> const T* ptr(int r = 0) const { return reinterpret_cast<const T*>(ptr(r)); }
+  Mat rowRange(int r0, int r1) const {   // header over rows [r0, r1) of the same pixels
+    Mat m = *this;
+    m.data = data + (size_t)r0 * (size_t)step;
+    m.rows = r1 - r0;
+    return m;
+  }
   Mat clone() const {
     Mat m;
     m.create(rows, cols, type());
@@ -120,6 +126,7 @@ class _InputArray {
   _InputArray() {}
   _InputArray(const Mat& m) : m_(&m) {}
   Mat getMat() const { return m_ ? *m_ : Mat(); }
+  bool isMat() const { return m_ != nullptr; }
   bool empty() const { return !m_ || m_->empty(); }
   int type() const { return m_ ? m_->type() : 0; }
 
@@ -138,6 +145,10 @@ class _OutputArray : public _InputArray {
     if (w_) w_->release();
   }
   Mat getMat() const { return w_ ? *w_ : Mat(); }  // shares the pixels with the caller's Mat
+  Mat& getMatRef() const {
+    if (!w_) throw Exception("getMatRef() on noArray()");
+    return *w_;
+  }
  private:
   Mat* w_ = nullptr;
 };
