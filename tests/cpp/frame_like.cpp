@@ -246,6 +246,33 @@ int main(int argc, char** argv) {
         nk += kL.size();
         if (keep && (ex.mvImagePyramid.size() != 8 || ex.mvImagePyramid[0].rows != h)) return 5;
       }
+      if (keep == 0 && std::getenv("ORBX_LAT_TWO_THREADS")) {
+        // the UNMODIFIED reference flow (src/Frame.cc:200-232): two threads, one operator() each, then ComputeStereoMatches
+        ORBextractor exL(nf, 1.2f, 8, 20, 7, w, h), exR(nf, 1.2f, 8, 20, 7, w, h);
+        exL.mbKeepHostPyramid = exR.mbKeepHostPyramid = false;
+        std::vector<double> m2;
+        ocv::Mat mask;
+        for (int i = -20; i < calls; i++) {
+          uint8_t* pl = frames.data() + (size_t)((i + 20) % n) * 2 * w * h;
+          ocv::Mat imL = wrap(h, w, pl), imR = wrap(h, w, pl + (size_t)w * h);
+          std::vector<ocv::KeyPoint> kL, kR;
+          ocv::Mat dL, dR;
+          std::vector<float> uR, depth;
+          const auto t0 = std::chrono::steady_clock::now();
+          std::thread tl([&] { exL(imL, mask, kL, dL, lap); });
+          std::thread tr([&] { exR(imR, mask, kR, dR, lap); });
+          tl.join();
+          tr.join();
+          ComputeStereoMatches(exL, exR, (int)kL.size(), 0.12f * 532.03f, 0.12f, uR, depth);
+          const auto t1 = std::chrono::steady_clock::now();
+          if (i >= 0) m2.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        }
+        double mean2 = 0;
+        for (double v : m2) mean2 += v;
+        std::sort(m2.begin(), m2.end());
+        std::printf("two threads x operator() + ComputeStereoMatches (the unmodified Frame constructor): mean %.4f ms  p50 %.4f  p90 %.4f\n",
+                    mean2 / (double)m2.size(), m2[m2.size() / 2], m2[m2.size() * 9 / 10]);
+      }
       double mean = 0, var = 0;
       for (double v : ms) mean += v;
       mean /= (double)ms.size();
