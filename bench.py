@@ -872,7 +872,7 @@ def cpp_mirror_latency(frames, W, H, NF, calls, np):
         np.stack([np.stack([L, R]) for L, R in frames]).tofile(path)
         try:
             r = subprocess.run([exe, "latency", str(W), str(H), str(NF), path, str(len(frames)), str(max(50, calls))],
-                               capture_output=True, text=True, timeout=120)
+                               capture_output=True, text=True, timeout=180, env=dict(os.environ, ORBX_LAT_TWO_THREADS="1"))
         finally:
             os.remove(path)
         res = {}
@@ -880,6 +880,10 @@ def cpp_mirror_latency(frames, W, H, NF, calls, np):
             m = re.search(r"mbKeepHostPyramid=%d: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)  std ([0-9.]+)  p99 ([0-9.]+)" % keep, r.stdout)
             res[key] = {"mean": float(m.group(1)), "std": float(m.group(4)), "p50": float(m.group(2)), "p99": float(m.group(5)),
                         "frames": max(50, calls)} if m else None
+        m = re.search(r"two threads x operator\(\) \+ ComputeStereoMatches[^:]*: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)", r.stdout)
+        # the reference's UNMODIFIED flow (src/Frame.cc:200-232): two std::threads per frame, one operator() each, then ComputeStereoMatches
+        res["latency_cpp_two_thread_flow_ms"] = {"mean": float(m.group(1)), "p50": float(m.group(2)), "p90": float(m.group(3)),
+                                                  "frames": max(50, calls)} if m else None
         res["latency_cpp_mirror_note"] = ("ORB_SLAM3::ORBextractor::ExtractStereo of csrc/ORBextractor.h (cvlite types) on %d distinct frames, timed "
                                           "with std::chrono inside tests/cpp/frame_like; with_host_pyramid = the class's default "
                                           "mbKeepHostPyramid = true" % len(frames))
