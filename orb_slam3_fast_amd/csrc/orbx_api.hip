@@ -702,7 +702,7 @@ int orbx_extractor_create(const orbx_params* p, int max_width, int max_height, i
   ok(ex->d_knode.alloc(B * m.candImg));
   ok(ex->d_candCount.alloc(B * m.nlevels));
   ok(ex->d_sel.alloc(B * m.selImg));
-  ok(ex->d_selCount.alloc(B * m.nlevels));
+  ok(ex->d_selCount.alloc(B * m.nlevels + ORBX_MAX_LEVELS));   // (k_describe2 reads ORBX_MAX_LEVELS counts of an image unconditionally)
   ok(ex->d_slot.alloc(B * m.selImg));
   ok(ex->d_kps.alloc(B * m.outCap));
   ok(ex->d_desc.alloc(B * m.outCap * 32));

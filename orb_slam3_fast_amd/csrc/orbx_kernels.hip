@@ -11,7 +11,8 @@
 // (the association kernels live in orbx_stereo.hip, the grid-guided matchers in orbx_guided.hip, pre-processing in
 // orbx_preproc.hip, bag of words in orbx_bow.hip)
 //
-// Integer/bitwise work: no MFMA.  Float steps that decide bits (fastAtan2, the rotated sampling
+// Integer/bitwise work; the one contraction on the path -- k_describe's separable 7x7 Gaussian, two banded integer GEMMs per
+// keypoint window -- runs on v_mfma_i32_16x16x64_i8 (orbx_blur_mfma.h, exact in i32).  Float steps that decide bits (fastAtan2, the rotated sampling
 // coordinates, sub-pixel disparity) use IEEE ops without contraction (-ffp-contract=off for this TU) and
 // round-half-even conversions, mirroring the x86-64 baseline (no FMA) build of the reference.
 #include <type_traits>
@@ -21,22 +22,10 @@
 #include "orbx_device.h"
 #include "orbx_introsort.h"
 #include "orbx_sincos.h"
+#include "orbx_blur_mfma.h"
 
 namespace orbx {
 
-// the same table as floats (x0, y0, x1, y1 per test): k_describe rotates it without a conversion per coordinate
-struct PatternF {
-  float v[1024];
-};
-constexpr PatternF make_pattern_f() {
-  constexpr int8_t src[1024] = {
-#include "orb_pattern31.inc"
-  };
-  PatternF t{};
-  for (int i = 0; i < 1024; i++) t.v[i] = (float)src[i];
-  return t;
-}
-__device__ const PatternF c_pattern_f = make_pattern_f();
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // ================================================================================================ resize
@@ -2141,49 +2130,12 @@ hipError_t launch_slots(const Geom& g, int nimg, const uint32_t* sel, const int*
 }
 
 // ================================================================================================ describe
-// cv::fastAtan2: every product / sum rounded separately.
-__device__ __forceinline__ float fast_atan2_dev(float y, float x) {
-  const float s = (float)(180.0 / 3.1415926535897932384626433832795);
-  const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s,
-              p7 = -0.04432655554792128f * s;
-  const float eps = (float)2.2204460492503131e-16;
-  const float ax = fabsf(x), ay = fabsf(y);
-  float a, c, c2;
-  if (ax >= ay) {
-    c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-  } else {
-    c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-    c2 = __fmul_rn(c, c);
-    a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-  }
-  if (x < 0) a = __fsub_rn(180.f, a);
-  if (y < 0) a = __fsub_rn(360.f, a);
-  return a;
-}
-
-// One wave per selected keypoint; the 7x7 Gaussian of GaussianBlur (:1074-1076) is evaluated ONLY where descriptors read
-// it: the wave stages the raw 43x43 window of its keypoint (rows / columns -21..+21: the 37x37 rBRIEF footprint plus the
-// blur's 3-px reach, which also contains the 31x31 IC_Angle patch) in LDS with aligned dword loads and derives everything
-// from that one window:
-//  * IC_Angle (:75-99) on the unblurred pixels: 31 rows x 9 aligned dwords folded into the integer moments under the
-//    circle mask |u| <= umax[|v|], reduced with cross-lane shuffles; cv::fastAtan2; glibc sinf / cosf (orbx_sincos.h);
-//  * the blur, separable and exact like k_blur (taps 18,34,48,56,48,34,18; horizontal sums as u16, one rounding at the
-//    end): horizontal pass on two rows at once (v_alignbyte + v_dot4_u32_u8, results packed as vertical u16 pairs),
-//    vertical pass as 4 v_dot2_u32_u16 per output; BORDER_REFLECT_101 is applied when the window is loaded (only for the
-//    few keypoints within 21 px of the level's edge) -- bit-identical to blurring the whole level first;
-//  * rBRIEF (:102-147): lane t evaluates tests t, t+64, t+128, t+192 on the blurred 37x37 patch; each __ballot is 8
-//    descriptor bytes already in the reference's byte/bit order;
-//  * keypoint + descriptor go to their serial-order output slot.
-// Against the round-1 pipeline (k_blur over every level, then a kernel reading 31x31 raw + 37x37 blurred per keypoint):
-// no blurred pyramid is written or re-read (-0.6 GB of HBM traffic per 64-image batch), one window load instead of two
-// scattered ones, ~45 % fewer blur instructions (1369 blurred pixels per keypoint instead of every pixel of every level).
+// (the kernel and its design notes follow the tables)
 // IC_Angle weights: for window dword item i = 9 r + c (row r = 0..30 <-> v = r - 15, aligned dword c = 0..8) and
 // misalignment m = (X - 15) & 3, byte b of the dword is patch column u = 4c + b - m - 15.  Entry .x = 0x01 per byte inside
 // the circle (|u| <= umax[|v|]), .y = (u + 16) per such byte (1..31), so that with wd = the four pixels
 //   sum(val) = v_dot4(wd, .x)      sum(u * val) = v_dot4(wd, .y) - 16 * sum(val)
-// -- two dot products per dword instead of four masked multiply-adds (the kernel is VALU-issue bound).
+// -- two dot products per dword instead of four masked multiply-adds.
 struct IcTable {
   uint2 e[4][5 * 64];
 };
@@ -2216,279 +2168,385 @@ __device__ const IcTable c_ic = make_ic_table();
 
 constexpr int DW_ROWS = 43;   // raw window rows / columns
 constexpr int DW_RP = 12;     // raw row pitch in dwords (48 bytes >= 43 + 3 bytes of misalignment)
-constexpr int DW_HP = 40;     // horizontal-pass row-pair pitch in dwords (columns)
-constexpr int DW_BP = 40;     // blurred patch pitch in bytes
-// LDS of a wave (round 4, second half): ONE region of 23 row pairs x DW_HP dwords in which the three tenants overlap in time.
-//   raw window   [DW_RAW0, DW_RAW0 + 43 x 12 + slack)   written first, read by the IC moments and the horizontal pass
-//   row pairs hp [0, 22 x 40)                             written by the horizontal pass, read by the vertical pass
-//   blurred patch [0, 40 x 10)                            written by the vertical pass, read by rBRIEF
-// The horizontal pass writes row pair p while rows >= 12 (p / 6 + 1) of the window are still to be read: with the window at
-// DW_RAW0 = 288 the pairs of trip t end at 240 (t + 1) <= 288 + 144 (t + 1), the first byte of the next trip's rows (t <= 2; after
-// trip 3 nothing is read); inside a trip all lanes read before any lane writes (one wave, LDS operations complete in order).  The
-// vertical pass writes patch rows 8 ch .. 8 ch + 7 (dwords < 160 after its first iteration, < 320 after the second) and its later
-// iterations read row pairs >= 4 / >= 12 (dwords >= 160 / >= 480).  5648 -> 3696 bytes per wave: a workgroup takes 12 of the CU's
-// 128 LDS granules instead of 18, so EIGHT workgroups (all 32 wave slots) are resident instead of seven -- the kernel loses 13 % when
-// it is held to six (profiles/r4_experiments).
-constexpr int DW_RAW0 = 288;
-constexpr int DW_WAVE_DW = 23 * DW_HP + 4;  // (row pair 22 only feeds padding rows of the patch: it must merely be addressable)
-static_assert(DW_RAW0 + DW_ROWS * DW_RP + 16 <= 23 * DW_HP, "window + slack inside the wave's region");
-static_assert(240 * 3 <= DW_RAW0 + 144 * 3, "row pairs of trip t must end before the window rows of trip t + 1");
-// weight dword of the fused blur's horizontal pass: byte i of window dword m carries tap k = 4 m + i - s (s = the byte the first tap
-// of the output column sits at), 0 outside the seven taps
-template <bool T440>
-__host__ __device__ constexpr uint32_t blur_w(int s, int m) {
-  const uint32_t tap[7] = {18u, 34u, T440 ? 49u : 48u, T440 ? 55u : 56u, T440 ? 49u : 48u, 34u, 18u};
-  uint32_t w = 0;
-  for (int i = 0; i < 4; i++) {
-    const int k = 4 * m + i - s;
-    if (k >= 0 && k <= 6) w |= tap[k] << (8 * i);
-  }
-  return w;
+typedef int orbx_v4i __attribute__((ext_vector_type(4)));
+__device__ const BlurMfmaTab c_blur_tab_451 = make_blur_mfma_tab<false>();
+__device__ const BlurMfmaTab c_blur_tab_440 = make_blur_mfma_tab<true>();
+static_assert(DW_RP * 4 == BM_P && DW_ROWS == BM_ROWS, "window pitch of the loader == pitch of the MFMA operand reads");
+
+// k_describe (round 6 form).  IC_Angle + the 7x7 Gaussian + rBRIEF of src/ORBextractor.cc:75-147,1074-1076 on each selected
+// keypoint's own 43x43 window (rows / columns -21..+21: the 37x37 rBRIEF footprint plus the blur's 3-px reach; it contains the
+// 31x31 IC patch); the Gaussian is evaluated ONLY where descriptors read it, bit-identical to blurring the level first
+// (BORDER_REFLECT_101 is applied while a window that leaves the level is loaded).
+// An ablation of the rounds 2 - 5 kernel (one keypoint per wave; profiles/r6_describe_ablation.txt) showed what its 98 us per 64
+// images were: 30 the scalar front of a wave, 20 the wait for its window, 16 the serial IC -> atan -> sincos chain, 23 the blur,
+// 7 rBRIEF -- a chain of latencies per wave, with the launch bound by how many chains a CU holds.  Hence:
+//   * a wave owns NK consecutive selected slots of ONE (image, level): the front -- task decode, level geometry, the image's
+//     per-level counts, the wave's keys with one vector load -- is paid once per wave, and the constant MFMA operands of the blur and
+//     the rBRIEF pattern (packed as signed bytes: 4 registers) stay in registers across its keypoints;
+//   * the raw window of keypoint k + 1 is fetched by LDS-DMA (global_load_lds_dwordx4: 129 16-byte chunks = 3 instructions, no
+//     registers, no LDS stores) as soon as the window of keypoint k has been read into registers, so it arrives under keypoint
+//     k's blur / angle / rBRIEF; results are stored one keypoint late, under the next one's matrix work;
+//   * the blur is two banded integer GEMMs on the matrix pipe (orbx_blur_mfma.h);
+//   * fastAtan2 and glibc's sincosf are written branch-free (same operations, selects instead of branches);
+//   * one wave per workgroup: a finished wave frees its slot at once.
+// NK is a launch parameter: 8 for batches (fewer, longer waves), 1 for the single-frame entries (latency: all keypoints at once).
+// 108 VGPRs = four waves per SIMD: with the windows prefetched the waves no longer need eight per SIMD to hide their loads
+// (alone 102 -> 95 us per 64 images; under three handles 76.4 -> 78.5 k pairs/s, profiles/r6_describe_ab.txt).
+struct DescPlan {
+  int taskOff[ORBX_MAX_LEVELS];   // first task of level l (INT_MAX past the last level); a task = nk consecutive selected slots
+  int tasks;                      // per image
+  int nk;                         // keypoints per wave (<= 64: the keys ride in the lanes of one register)
+  unsigned magic;                 // j / tasks == umulhi(j, magic) for every flat workgroup index of the launch (host-checked; 0: no XCD remap)
+};
+struct PatternB {
+  uint32_t v[256];   // test i: x0 | y0 << 8 | x1 << 16 | y1 << 24 as signed bytes
+};
+constexpr PatternB make_pattern_b() {
+  constexpr int8_t src[1024] = {
+#include "orb_pattern31.inc"
+  };
+  PatternB t{};
+  for (int i = 0; i < 256; i++)
+    t.v[i] = (uint32_t)(uint8_t)src[4 * i] | ((uint32_t)(uint8_t)src[4 * i + 1] << 8) | ((uint32_t)(uint8_t)src[4 * i + 2] << 16) |
+             ((uint32_t)(uint8_t)src[4 * i + 3] << 24);
+  return t;
 }
-template <bool T440>  // (the Gaussian taps of OpenCV 4.0 .. 4.5.0, see k_blur)
-__global__ __launch_bounds__(256) void k_describe(Geom g, Pyr p, const uint32_t* __restrict__ sel,
-                                                  const int* __restrict__ selCount, const int* __restrict__ slot,
-                                                  orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-                                                  int* __restrict__ nOut, int* __restrict__ mono, int xcdImages) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds_all[4][DW_WAVE_DW];
-  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR
-  // The keypoints of an image arrive in quadtree order (spatially scattered): with workgroups dealt round-robin to the 8
-  // XCDs every L2 ends up fetching most of every image.  With xcdImages set, all workgroups of an image go to ONE XCD
-  // (image i -> XCD i mod 8), so its pyramid lines are fetched into one L2 only.  Only for the first 8 * floor(nimg / 8)
-  // images; the rest keep the plain order.
-  int bx = blockIdx.x, img = blockIdx.y;
-  if (xcdImages) {
+__device__ const PatternB c_pattern_b = make_pattern_b();
+
+// cv::fastAtan2: every product / sum rounded separately; branch-free (the two cases of |x| >= |y| by selects)
+__device__ __forceinline__ float fast_atan2_sel(float y, float x) {
+  const float s = (float)(180.0 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s,
+              p7 = -0.04432655554792128f * s;
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  const bool xge = ax >= ay;
+  const float num = xge ? ay : ax, den = xge ? ax : ay;
+  const float c = __fdiv_rn(num, __fadd_rn(den, eps));
+  const float c2 = __fmul_rn(c, c);
+  const float pa = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+  float a = xge ? pa : __fsub_rn(90.f, pa);
+  a = x < 0 ? __fsub_rn(180.f, a) : a;
+  a = y < 0 ? __fsub_rn(360.f, a) : a;
+  return a;
+}
+// glibc sinf / cosf (orbx_sincos.h, the FMA variant), branch-free: the |y| < pi/4 path is the n = 0 case of the reduction
+// (n = round(y * 2/pi) = 0 below 0.75, r = y - 0 * pi/2 = y, sign +1: the same operands reach the same polynomials), the
+// |y| < 2^-12 case a select; one sine and one cosine polynomial are evaluated either way, the quadrant picks which is which.
+__device__ __forceinline__ void glibc_sincosf_sel(float y, float& s_out, float& c_out) {
+#pragma clang fp contract(off)
+  const uint32_t top = (__builtin_bit_cast(uint32_t, y) >> 20) & 0x7ffu;
+  const double x0 = (double)y;
+  const double r = x0 * 0x1.45F306DC9C883p+23;
+  const int n = top < 0x3f4u ? 0 : (((int)r + 0x800000) >> 24);
+  const double hpi = 0x1.921FB54442D18p0;
+  const double x = top < 0x3f4u ? x0 : __builtin_fma(-(double)n, hpi, x0);
+  const double sgn = ((n + 1) & 2) ? -1.0 : 1.0;
+  const bool neg = (n & 2) != 0;
+  const double xs = x * sgn, x2 = x * x;
+  // sine polynomial of xs
+  const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+  const double x3 = xs * x2;
+  const double s1 = __builtin_fma(x2, S3, S2);
+  const double x7 = x3 * x2;
+  const double sp = __builtin_fma(x3, S1, xs);
+  const float fs = (float)__builtin_fma(x7, s1, sp);
+  // cosine polynomial (coefficients negated for neg: exact sign flips)
+  const double sg = neg ? -1.0 : 1.0;
+  const double C0 = sg * 0x1p0, C1 = sg * -0x1.ffffffd0c621cp-2, C2 = sg * 0x1.55553e1068f19p-5, C3 = sg * -0x1.6c087e89a359dp-10,
+               C4 = sg * 0x1.99343027bf8c3p-16;
+  const double x4 = x2 * x2;
+  const double c2 = __builtin_fma(x2, C4, C3);
+  const double c1 = __builtin_fma(x2, C1, C0);
+  const double x6 = x4 * x2;
+  const double cc = __builtin_fma(x4, C2, c1);
+  const float fc = (float)__builtin_fma(x6, c2, cc);
+  const bool odd = (n & 1) != 0, tiny = top < 0x398u;
+  s_out = tiny ? y : (odd ? fc : fs);
+  c_out = tiny ? 1.0f : (odd ? fs : fc);
+}
+
+template <bool T440>
+__global__ __launch_bounds__(64, 4) void k_describe(Geom g, Pyr p, DescPlan dp, const uint32_t* __restrict__ sel,
+                                                                     const int* __restrict__ selCount, const int* __restrict__ slot,
+                                                                     orbx_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                                     int* __restrict__ nOut, int* __restrict__ mono, int xcdImages) {
+  __shared__ __attribute__((aligned(16))) uint32_t ldsW[BM_WAVE_BYTES / 4];   // raw window [43 rows][48 B] (+ rows the operands over-read)
+  __shared__ __attribute__((aligned(16))) uint32_t ldsP[48 * BM_P / 4];       // blurred patch [37 (48 written) rows][48 B]
+  const int NK = dp.nk;
+  const int lane = threadIdx.x;
+  int t = blockIdx.x, img = blockIdx.y;
+  if (xcdImages && dp.magic) {  // all workgroups of an image on ONE XCD (image i -> XCD i mod 8), see k_describe
     const unsigned nbx = gridDim.x, flat = blockIdx.y * nbx + blockIdx.x, full = (gridDim.y / 8u) * 8u;
     if (flat < full * nbx) {
-      const unsigned c = flat & 7u, j = flat >> 3;  // j-th workgroup of XCD c
-      img = (int)(c + 8u * (j / nbx));
-      bx = (int)(j % nbx);
+      const unsigned c = flat & 7u, j = flat >> 3, jq = __umulhi(j, dp.magic);
+      img = (int)(c + 8u * jq);
+      t = (int)(j - jq * nbx);
     }
   }
-  const int s = bx * 4 + wv;
-  if (s >= g.selImg) return;
-  int l = 0;
-  while (l + 1 < g.nlevels && s >= g.lv[l + 1].selOff) l++;
+  // ---- front, once per wave: level of the task, the image's counts, the task's keys
+  int l = 0, tbase = 0;
+#pragma unroll
+  for (int q = 1; q < ORBX_MAX_LEVELS; q++) {
+    const bool ge = t >= dp.taskOff[q];
+    l += ge ? 1 : 0;
+    tbase = ge ? dp.taskOff[q] : tbase;
+  }
   const LevelDev L = g.lv[l];
-  const int idx = s - L.selOff;
-  if (!slot && s == 0 && lane == 0) {  // k_slots skipped: this wave publishes the image's counts
-    int total = 0;
-    for (int q = 0; q < g.nlevels; q++) total += selCount[img * g.nlevels + q];
+  const int idx0 = (t - tbase) * NK;
+  const int* sc = selCount + img * g.nlevels;   // (the array is over-allocated by ORBX_MAX_LEVELS entries: unconditional loads)
+  int before = 0, total = 0, cntL = 0;
+#pragma unroll
+  for (int q = 0; q < ORBX_MAX_LEVELS; q++) {
+    const int c = q < g.nlevels ? sc[q] : 0;
+    total += c;
+    before += q < l ? c : 0;
+    cntL = q == l ? c : cntL;
+  }
+  if (!slot && t == 0 && lane == 0) {  // k_slots skipped: this wave publishes the image's counts
     nOut[img] = total;
     mono[img] = total;
   }
-  if (idx >= selCount[img * g.nlevels + l]) return;
-  const uint32_t key = __builtin_amdgcn_readfirstlane(sel[(long long)img * g.selImg + s]);  // one keypoint per wave
-  const int X = key_x(key), Y = key_y(key);
-  uint32_t* hp = lds_all[wv];                  // [22 row pairs][DW_HP]: H(2j, x) | H(2j+1, x) << 16; its head is reused for the blurred patch
-  uint32_t* raw = hp + DW_RAW0;                // [43 rows][DW_RP] raw window, overlapping the row pairs (see DW_RAW0)
+  const int nk = min(NK, cntL - idx0);
+  if (nk <= 0) return;
+  const long long sbase = (long long)img * g.selImg + L.selOff + idx0;
+  const int lk = min(lane, nk - 1);
+  const uint32_t keyv = sel[sbase + lk];
+  // slot == nullptr: no keypoint can lie in the lapping area, the serial-order slot is (keypoints of the earlier levels) + idx
+  const int slotv = slot ? slot[sbase + lk] : before + idx0 + lane;
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  // ---- raw window -> LDS: rows Y-21..Y+21, aligned dwords covering columns X-21..X+21 (LDS byte 0 = column xs)
-  const int xs = (X - 21) & ~3, mis = __builtin_amdgcn_readfirstlane((X - 21) - xs);
-  const bool interior = X >= 21 && Y >= 21 && X + 21 < L.w && Y + 21 < L.h;
-  if (interior) {
-    // lane = (row phase r0 = lane / 12, dword column c = lane % 12): 60 lanes cover 5 window rows per trip, so a trip is
-    // one address increment; all 9 loads are in flight before the first LDS store.  Columns past the level's last dword
-    // (they only feed unused outputs) re-read that last dword.
-    const int r0 = (lane * 5462) >> 16, c = lane - 12 * r0;
-    const int cl = min(c, (L.w - 1 - xs) >> 2);
-    const uint8_t* base = im + (long long)(Y - 21) * pitch + xs;  // uniform: SGPR base + 32-bit lane offsets
-    const unsigned off0 = (unsigned)(__mul24(r0, pitch) + 4 * cl), step = 5u * (unsigned)pitch;
-    if (lane < 60) {
-      uint32_t w[9];
+  const int rowValid = l ? L.pitch : L.w;   // bytes of an image row that may be read (level 0 is the caller's buffer)
+  // constant operands, resident across the wave's keypoints
+  const BlurMfmaTab& tab = T440 ? c_blur_tab_440 : c_blur_tab_451;
+  orbx_v4i bh[3], av[3];
 #pragma unroll
-      for (int t = 0; t < 9; t++)  // (rows 43, 44 of the last trip: clamped to row 42, not stored)
-        w[t] = *reinterpret_cast<const uint32_t*>(base + (t < 8 ? off0 + (unsigned)t * step : min(off0 + 8u * step, 42u * (unsigned)pitch + 4u * (unsigned)cl)));
-#pragma unroll
-      for (int t = 0; t < 8; t++) raw[lane + 60 * t] = w[t];
-      if (r0 < 3) raw[lane + 480] = w[8];
-    }
-  } else {  // window crosses the level's edge: BORDER_REFLECT_101, byte by byte (coordinates further out are never used)
-    for (int i = lane; i < DW_ROWS * DW_RP; i += 64) {
-      const int r = i / DW_RP, c = i - r * DW_RP;
-      const int yy = reflect101(min(max(Y - 21 + r, -3), L.h + 2), L.h);
-      uint32_t v = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int xx = reflect101(min(max(xs + 4 * c + k, -3), L.w + 2), L.w);
-        v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * k);
-      }
-      raw[i] = v;
-    }
+  for (int i = 0; i < 3; i++) {
+    bh[i] = *reinterpret_cast<const orbx_v4i*>(tab.bh[i][lane]);
+    av[i] = *reinterpret_cast<const orbx_v4i*>(tab.av[i][lane]);
   }
-  // the lane's four rBRIEF tests (x0, y0, x1, y1 each), requested now: they arrive under the window / blur work
-  float4 pat[4];
+  uint32_t patb[4];
 #pragma unroll
-  for (int gI = 0; gI < 4; gI++) pat[gI] = *reinterpret_cast<const float4*>(c_pattern_f.v + 4 * (64 * gI + lane));
-  // slot == nullptr: no keypoint can lie in the lapping area (lap1 < 19 <= every x), so the serial-order slot is
-  // simply (keypoints of the earlier levels) + idx and k_slots is not launched at all
-  int n_out_slot;
-  if (slot) {
-    n_out_slot = slot[(long long)img * g.selImg + s];
-  } else {
-    int before = 0;
-    for (int q = 0; q < l; q++) before += selCount[img * g.nlevels + q];
-    n_out_slot = before + idx;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // window stores of this wave before its own reads
-  __builtin_amdgcn_wave_barrier();
-  // ---- IC_Angle: rows 6..36 of the window (v = -15..15), the 9 aligned dwords that cover columns X-15..X+15;
-  // two dot products per dword against the precomputed circle mask / column weights (c_ic)
-  int m10 = 0, m01 = 0;
+  for (int gI = 0; gI < 4; gI++) patb[gI] = c_pattern_b.v[64 * gI + lane];
+  // lane constants
+  const int li = lane & 15, lg = lane >> 4;
+  const uint8_t* arow = reinterpret_cast<const uint8_t*>(ldsW) + li * BM_P + 16 * lg;
+  uint8_t* bl = reinterpret_cast<uint8_t*>(ldsP);
+  uint8_t* prow = bl + li * BM_P + 4 * lg;
+  const int icr0 = (lane * 7282) >> 16, icc = lane - 9 * icr0;   // lane / 9, lane % 9
+  // DMA chunks of a window: q = lane + 64 j -> (row q / 3, 16-byte part q % 3); chunk 128 (row 42, part 2) by lane 0
+  const int q1 = lane + 64, dr0 = (lane * 43691) >> 17, dr1 = (q1 * 43691) >> 17;
+  const unsigned doff0 = (unsigned)(__mul24(dr0, pitch) + 16 * (lane - 3 * dr0)), doff1 = (unsigned)(__mul24(dr1, pitch) + 16 * (q1 - 3 * dr1));
+  auto win = [&](int k, int& X, int& Y, int& xs, int& mis, bool& interior, bool& dma) {
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)keyv, k);
+    X = key_x(key);
+    Y = key_y(key);
+    xs = (X - 21) & ~3;
+    mis = (X - 21) - xs;
+    interior = X >= 21 && Y >= 21 && X + 21 < L.w && Y + 21 < L.h;
+    dma = interior && xs + 48 <= rowValid;
+    return key;
+  };
+  // LDS-DMA by hand: the compiler's own tracking of global_load_lds serialises the three loads of a window (a vmcnt(0) in front
+  // of each) and waits for them right behind their issue -- and missed the wait in front of the first window read.  As inline asm
+  // it does not see them at all: its waits for its own loads can only become stricter, and the waits for a window are ours.
+  const unsigned ldsWaddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)ldsW;
+  auto issue_dma = [&](int Y, int xs) {
+    const uint8_t* base = im + (long long)(Y - 21) * pitch + xs;   // uniform
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsWaddr), "v"(doff0), "s"(base) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsWaddr + 1024u), "v"(doff1), "s"(base) : "memory");
+    if (lane == 0)
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsWaddr + 2048u), "v"(42u * (unsigned)pitch + 32u), "s"(base) : "memory");
+  };
+  int X, Y, xs, mis;
+  bool interior, dma;
+  uint32_t key = win(0, X, Y, xs, mis, interior, dma);
+  if (dma) issue_dma(Y, xs);
+  // IC table of a keypoint (depends on its window's misalignment): requested one keypoint ahead, behind the matrix work
+  uint2 ice[5];
   {
-    const int c0 = (6 + mis) >> 2, misr = (6 + mis) & 3;
-    const uint2* tab = c_ic.e[misr] + lane;
-    const int r0 = (lane * 7282) >> 16, c = lane - 9 * r0;  // lane / 9
-    const uint32_t* wp = raw + (6 + r0) * DW_RP + c0 + c;
-    int srs = 0, sw = 0, rv = r0 - 15;
+    const uint2* ictab = c_ic.e[(6 + mis) & 3] + lane;
 #pragma unroll
-    for (int t = 0; t < 5; t++) {
-      const uint2 e = tab[64 * t];
-      const uint32_t wd = wp[7 * DW_RP * t];
-      const int rs = (int)__builtin_amdgcn_udot4(wd, e.x, 0u, false);
-      sw = (int)__builtin_amdgcn_udot4(wd, e.y, (uint32_t)sw, false);
-      srs += rs;
-      m01 += __mul24(rv, rs);
-      rv += 7;
-    }
-    m10 = sw - 16 * srs;
-    m10 = wave_sum_dpp(m10);  // (six v_add_dpp each; __shfl_xor would be a ds_bpermute + address arithmetic per step)
-    m01 = wave_sum_dpp(m01);
+    for (int tt = 0; tt < 5; tt++) ice[tt] = ictab[64 * tt];
   }
-  const float angle = fast_atan2_dev((float)m01, (float)m10);
-  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-  float a, b;
-  glibc_sincosf<true>(__fmul_rn(angle, factorPI), b, a);  // a = cosf, b = sinf (orbx_sincos.h)
-  // ---- horizontal pass: item = (row pair j, group of 4 output columns 4q..4q+3); output column x <-> window byte
-  // x + 3 + mis, its taps are window bytes x + mis .. x + mis + 6
-  // lane = (pair phase j0 = lane / 10, group q = lane % 10): 60 lanes cover 6 row pairs per trip, so a trip's window and
-  // output addresses are the lane's base plus immediates (no index arithmetic inside the loop)
-  // The taps of output column 4q + j start at byte s = j + mis of the 16 window bytes d0..d3 the item reads (mis = the window's
-  // misalignment, wave-uniform): instead of shifting the bytes into place (3 + 6 v_alignbyte per row) the WEIGHTS are shifted --
-  // tap k sits at byte s + k of a per-(s, dword) weight constant (blur_w) -- and a column is the 2 or 3 v_dot4 over the dwords
-  // its taps touch: 10 v_dot4 per row and four columns whatever mis is (8 v_dot4 + 9 v_alignbyte before), one code variant per
-  // mis (uniform switch), the constants in SGPRs.
-  {
-    const int j0 = (lane * 6554) >> 16, q = lane - 10 * j0;  // lane / 10
-    const int rbi = DW_RAW0 + 2 * j0 * DW_RP + q;   // dword index of the item's first window dword (raw = hp + DW_RAW0)
-    uint32_t* hbase = hp + j0 * DW_HP + 4 * q;
-    auto hpass = [&](auto misTag) {
-      constexpr int MIS = decltype(misTag)::value;
+  // results of a keypoint are stored one keypoint later, under the next one's matrix work (loads and stores share the wave's
+  // memory counter and may complete out of order with respect to each other: the wait for a window is a wait for everything)
+  uint32_t pendKp = 0, pendDescLo = 0, pendDescHi = 0;
+  int pendSlot = -1;
+  auto store_pending = [&]() {
+    if (pendSlot >= 0) {
+      if (lane < 7) reinterpret_cast<uint32_t*>(kps + ((long long)img * g.outCap + pendSlot))[lane] = pendKp;
+      if (lane < 4) reinterpret_cast<uint2*>(desc + ((long long)img * g.outCap + pendSlot) * 32)[lane] = make_uint2(pendDescLo, pendDescHi);
+    }
+  };
+  for (int k = 0; k < nk; k++) {
+    const int c0 = (6 + mis) >> 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // window k (DMA) has landed
+    if (!dma) {
+      if (interior) {  // the 48-byte span of the window's rows ends past the row: dword loads, the last columns clamped (they only feed unused outputs)
+        const int r0 = (lane * 5462) >> 16, c = lane - 12 * r0;
+        const int cl = min(c, (L.w - 1 - xs) >> 2);
+        const uint8_t* base = im + (long long)(Y - 21) * pitch + xs;
+        const unsigned off0 = (unsigned)(__mul24(r0, pitch) + 4 * cl), step = 5u * (unsigned)pitch;
+        if (lane < 60) {
+          uint32_t w[9];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if (t == 3 && j0 >= 4) break;  // pairs 22, 23 do not exist
-        uint32_t h[2][4];
-        int ti = rbi + 12 * t * DW_RP;          // opaque per trip: the reads below are one address per trip plus small immediates
-        asm volatile("" : "+v"(ti));            // (folded onto the wave's LDS base the offsets exceed ds_read2's range: 2 v_add per row)
-        const uint32_t* rowt = hp + ti;
+          for (int tt = 0; tt < 9; tt++)
+            w[tt] = *reinterpret_cast<const uint32_t*>(base + (tt < 8 ? off0 + (unsigned)tt * step : min(off0 + 8u * step, 42u * (unsigned)pitch + 4u * (unsigned)cl)));
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-          // (row 43 = second row of pair 21 lies in the slack behind the window: it only feeds H row 43, which nothing reads)
-          const uint32_t* row = rowt + rr * DW_RP;
-          uint32_t d[4];
-#pragma unroll
-          for (int m = 0; m < 4; m++) d[m] = (4 * m < MIS + 3 + 7) ? row[m] : 0u;  // (the last dword only when a tap reaches it)
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int sft = j + MIS;
-            uint32_t acc = 0;
-#pragma unroll
-            for (int m = 3; m >= 0; m--)
-              if (4 * m + 3 >= sft && 4 * m <= sft + 6) acc = __builtin_amdgcn_udot4(d[m], blur_w<T440>(sft, m), acc, false);
-            h[rr][j] = acc;
-          }
+          for (int tt = 0; tt < 8; tt++) ldsW[lane + 60 * tt] = w[tt];
+          if (r0 < 3) ldsW[lane + 480] = w[8];
         }
-        uint4 pk;  // H(2j, x) | H(2j + 1, x) << 16: one v_perm per column (sums of 7 taps x 255 fit 16 bits)
-        pk.x = __builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u);
-        pk.y = __builtin_amdgcn_perm(h[1][1], h[0][1], 0x05040100u);
-        pk.z = __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u);
-        pk.w = __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u);
-        *reinterpret_cast<uint4*>(hbase + 6 * DW_HP * t) = pk;
+      } else {  // window crosses the level's edge: BORDER_REFLECT_101, byte by byte (coordinates further out are never used)
+        for (int i = lane; i < DW_ROWS * DW_RP; i += 64) {
+          const int r = i / DW_RP, c = i - r * DW_RP;
+          const int yy = reflect101(min(max(Y - 21 + r, -3), L.h + 2), L.h);
+          uint32_t v = 0;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const int xx = reflect101(min(max(xs + 4 * c + kk, -3), L.w + 2), L.w);
+            v |= (uint32_t)im[(long long)yy * pitch + xx] << (8 * kk);
+          }
+          ldsW[i] = v;
+        }
       }
-    };
-    if (lane < 60) {
-      switch (mis) {
-        case 0: hpass(std::integral_constant<int, 0>{}); break;
-        case 1: hpass(std::integral_constant<int, 1>{}); break;
-        case 2: hpass(std::integral_constant<int, 2>{}); break;
-        default: hpass(std::integral_constant<int, 3>{}); break;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the window into registers: matrix operands (pixel - 128 as signed bytes) and the IC dwords
+    orbx_v4i ah[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) ah[rt] = *reinterpret_cast<const orbx_v4i*>(arow + 16 * rt * BM_P);
+    uint32_t icw[5];
+    {
+      const uint32_t* wp = ldsW + (6 + icr0) * DW_RP + c0 + icc;
+#pragma unroll
+      for (int tt = 0; tt < 5; tt++) icw[tt] = wp[7 * DW_RP * tt];
+    }
+    const int n_out_slot = __builtin_amdgcn_readlane(slotv, k);
+    const int Xk = X, Yk = Y, misk = mis;
+    const uint32_t keyk = key;
+    // ---- the window is dead: fetch the next one under this keypoint's work
+    if (k + 1 < nk) {
+      key = win(k + 1, X, Y, xs, mis, interior, dma);
+          if (dma) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every read of the window has returned before the DMA may overwrite it
+        issue_dma(Y, xs);
       }
     }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- vertical pass: item = (column x, chunk of 8 output rows); blurred row y needs H rows y..y+6.  The blurred
-  // 37x37 patch overwrites the head of the row pairs (iteration by iteration behind the pairs still to be read: see DW_RAW0).
-  uint8_t* bl = reinterpret_cast<uint8_t*>(hp);
-  for (int i = lane; i < 5 * 37; i += 64) {
-    const int ch = (int)(((unsigned)i * 1772u) >> 16), x = i - ch * 37;  // i / 37 for i < 2^11
-    uint32_t pr[7];
+    // ---- IC_Angle moments on the window dwords read above (the angle itself is evaluated beside the matrix work)
+    int m10, m01;
+    {
+      int srs = 0, sw = 0, rv = icr0 - 15;
+      m01 = 0;
 #pragma unroll
-    for (int k = 0; k < 7; k++) pr[k] = hp[(4 * ch + k) * DW_HP + x];  // H rows 8ch .. 8ch+13 (pair 22 only feeds padding rows)
-    constexpr uint32_t kT2 = T440 ? 49u : 48u, kT3 = T440 ? 55u : 56u;
-    const uint32_t w01 = 18u | (34u << 16), w23 = kT2 | (kT3 << 16), w45 = kT2 | (34u << 16), w6 = 18u;            // even y
-    const uint32_t v0 = 18u << 16, v12 = 34u | (kT2 << 16), v34 = kT3 | (kT2 << 16), v56 = 34u | (18u << 16);      // odd y
-#pragma unroll
-    for (int yy = 0; yy < 8; yy++) {
-      const int k0 = yy >> 1;
-      uint32_t acc;
-      if ((yy & 1) == 0) {
-        acc = udot2_u16(pr[k0], w01, 32768u);
-        acc = udot2_u16(pr[k0 + 1], w23, acc);
-        acc = udot2_u16(pr[k0 + 2], w45, acc);
-        acc = udot2_u16(pr[k0 + 3], w6, acc);
-      } else {
-        acc = udot2_u16(pr[k0], v0, 32768u);
-        acc = udot2_u16(pr[k0 + 1], v12, acc);
-        acc = udot2_u16(pr[k0 + 2], v34, acc);
-        acc = udot2_u16(pr[k0 + 3], v56, acc);
+      for (int tt = 0; tt < 5; tt++) {
+        const int rs = (int)__builtin_amdgcn_udot4(icw[tt], ice[tt].x, 0u, false);
+        sw = (int)__builtin_amdgcn_udot4(icw[tt], ice[tt].y, (uint32_t)sw, false);
+        srs += rs;
+        m01 += __mul24(rv, rs);
+        rv += 7;
       }
-      bl[(8 * ch + yy) * DW_BP + x] = (uint8_t)((T440 ? min(acc, 0x00FFFFFFu) : acc) >> 16);  // rows 37..39 are padding; 257-sum taps saturate
+      m10 = wave_sum_dpp(sw - 16 * srs);
+      m01 = wave_sum_dpp(m01);
+    }
+    store_pending();
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) ah[rt] ^= (int)0x80808080;
+    // ---- blur (orbx_blur_mfma.h; see k_describe)
+    constexpr int kBias = BlurMfmaConst<T440>::bias, kKc = BlurMfmaConst<T440>::kc;
+    const orbx_v4i cz = {0, 0, 0, 0}, cb = {kBias, kBias, kBias, kBias};
+#pragma unroll
+    for (int ct = 0; ct < 3; ct++) {
+      orbx_v4i lo = cz, hi = cz;
+#pragma unroll
+      for (int rt = 0; rt < 3; rt++) {
+        const orbx_v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah[rt], bh[ct], T440 ? cb : cz, 0, 0, 0);
+        const uint32_t pa = __builtin_amdgcn_perm((uint32_t)x[1], (uint32_t)x[0], 0x05010400u);
+        const uint32_t pb = __builtin_amdgcn_perm((uint32_t)x[3], (uint32_t)x[2], 0x05010400u);
+        lo[rt] = (int)(__builtin_amdgcn_perm(pb, pa, 0x05040100u) ^ 0x80808080u);
+        hi[rt] = (int)__builtin_amdgcn_perm(pb, pa, 0x07060302u);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 3; mt++) {
+        const orbx_v4i HI = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, av[mt], cz, 0, 0, 0);
+        orbx_v4i cin;
+#pragma unroll
+        for (int r = 0; r < 4; r++) cin[r] = (int)(((uint32_t)HI[r] << 8) + (uint32_t)kKc);
+        const orbx_v4i V = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, av[mt], cin, 0, 0, 0);
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = T440 ? min((uint32_t)V[r], 0x00FFFFFFu) : (uint32_t)V[r];
+        const uint32_t t0 = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), t1 = __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
+        *reinterpret_cast<uint32_t*>(prow + 16 * mt * BM_P + 16 * ct) = t0 | t1;
+      }
+    }
+    {  // the next keypoint's IC table (the last keypoint re-reads its own: no branch in this block)
+      const uint2* ictab = c_ic.e[(6 + mis) & 3] + lane;
+#pragma unroll
+      for (int tt = 0; tt < 5; tt++) ice[tt] = ictab[64 * tt];
+    }
+    const float angle = fast_atan2_sel((float)m01, (float)m10);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    glibc_sincosf_sel(__fmul_rn(angle, factorPI), b, a);   // a = cosf, b = sinf
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- rBRIEF on the blurred patch (blurred (y, x) = patch[y][x + mis])
+    const float kMagic = 12582912.0f;
+    const uint8_t* centre = bl + 18 * BM_P + 18 + misk;
+    const uint32_t kFold = 0x400000u * BM_P + 0x4B400000u;
+#pragma unroll
+    for (int gI = 0; gI < 4; gI++) {
+      const uint32_t pw = patb[gI];
+      const float x0 = (float)(int)(int8_t)pw, y0 = (float)(int)(int8_t)(pw >> 8), x1 = (float)(int)(int8_t)(pw >> 16), y1 = (float)((int)pw >> 24);
+      const uint32_t iy0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), kMagic));
+      const uint32_t ix0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), kMagic));
+      const uint32_t iy1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), kMagic));
+      const uint32_t ix1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), kMagic));
+      const int t0 = centre[(int)((uint32_t)__mul24((int)iy0, BM_P) + ix0 - kFold)],
+                t1 = centre[(int)((uint32_t)__mul24((int)iy1, BM_P) + ix1 - kFold)];
+      const uint64_t bits = __ballot(t0 < t1);   // 8 descriptor bytes in the reference's byte / bit order; lane gI keeps them
+      pendDescLo = lane == gI ? (uint32_t)bits : pendDescLo;
+      pendDescHi = lane == gI ? (uint32_t)(bits >> 32) : pendDescHi;
+    }
+    {  // the 28-byte keypoint record, dword i in lane i
+      const float kx = l ? __fmul_rn((float)Xk, L.scale) : (float)Xk, ky = l ? __fmul_rn((float)Yk, L.scale) : (float)Yk;
+      uint32_t v = __builtin_bit_cast(uint32_t, kx);
+      v = lane == 1 ? __builtin_bit_cast(uint32_t, ky) : v;
+      v = lane == 2 ? __builtin_bit_cast(uint32_t, L.patch) : v;
+      v = lane == 3 ? __builtin_bit_cast(uint32_t, angle) : v;
+      v = lane == 4 ? __builtin_bit_cast(uint32_t, (float)key_r(keyk)) : v;
+      v = lane == 5 ? (uint32_t)l : v;
+      v = lane == 6 ? 0xFFFFFFFFu : v;
+      pendKp = v;
+      pendSlot = n_out_slot;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // ---- rBRIEF on the blurred patch
-  uint8_t* dout = desc + ((long long)img * g.outCap + n_out_slot) * 32;
-  // cvRound by the 1.5 * 2^23 trick: the float sum's bit pattern is 0x4B400000 + n (n = the half-even rounded value), so
-  // row * pitch + column comes out of one 24-bit multiply-add on the two patterns, the constants folded into the base
-  const float kMagic = 12582912.0f;
-  const uint8_t* centre = bl + 18 * DW_BP + 18;
-  const uint32_t kFold = 0x400000u * DW_BP + 0x4B400000u;  // (unsigned wrap-around is exact here)
-#pragma unroll
-  for (int gI = 0; gI < 4; gI++) {
-    const float x0 = pat[gI].x, y0 = pat[gI].y, x1 = pat[gI].z, y1 = pat[gI].w;
-    const uint32_t iy0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), kMagic));
-    const uint32_t ix0 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), kMagic));
-    const uint32_t iy1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), kMagic));
-    const uint32_t ix1 = __builtin_bit_cast(uint32_t, __fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), kMagic));
-    const int t0 = centre[(int)((uint32_t)__mul24((int)iy0, DW_BP) + ix0 - kFold)],
-              t1 = centre[(int)((uint32_t)__mul24((int)iy1, DW_BP) + ix1 - kFold)];
-    const uint64_t bits = __ballot(t0 < t1);
-    if (lane == 0) *reinterpret_cast<uint64_t*>(dout + 8 * gI) = bits;
+  store_pending();
+}
+
+static DescPlan make_desc_plan(const Geom& g, int nimg) {
+  DescPlan dp{};
+  dp.nk = nimg >= 8 ? 8 : 1;
+  int tks = 0;
+  for (int l = 0; l < ORBX_MAX_LEVELS; l++) {
+    dp.taskOff[l] = l < g.nlevels ? tks : 0x7fffffff;
+    if (l < g.nlevels) tks += (g.lv[l].selCap + dp.nk - 1) / dp.nk;
   }
-  if (lane == 0) {
-    orbx_keypoint kp;
-    kp.x = l ? __fmul_rn((float)X, L.scale) : (float)X;
-    kp.y = l ? __fmul_rn((float)Y, L.scale) : (float)Y;
-    kp.size = L.patch;
-    kp.angle = angle;
-    kp.response = (float)key_r(key);
-    kp.octave = l;
-    kp.class_id = -1;
-    kps[(long long)img * g.outCap + n_out_slot] = kp;
-  }
+  dp.tasks = tks;
+  // j / tasks by a multiply: m = floor(2^32 / d) + 1 is exact while j * (m * d - 2^32) < 2^32
+  const uint64_t d = (uint64_t)tks, m = (1ull << 32) / d + 1, e = m * d - (1ull << 32), jmax = (uint64_t)nimg * d;
+  dp.magic = (d > 1 && m < (1ull << 32) && jmax * e < (1ull << 32)) ? (unsigned)m : 0u;
+  return dp;
 }
 
 hipError_t launch_describe(const Geom& g, const Pyr& p, int nimg, const uint32_t* sel, const int* selCount,
                            const int* slot, orbx_keypoint* kps, uint8_t* desc, int* nOut, int* mono, hipStream_t s) {
-  if (g.cv440) hipLaunchKernelGGL(k_describe<true>, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
-  else hipLaunchKernelGGL(k_describe<false>, dim3((g.selImg + 3) / 4, nimg), dim3(256), 0, s, g, p, sel, selCount, slot,
-                     kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
+  const DescPlan dp = make_desc_plan(g, nimg);
+  const dim3 grid(dp.tasks, nimg), block(64);
+  if (g.cv440) hipLaunchKernelGGL(k_describe<true>, grid, block, 0, s, g, p, dp, sel, selCount, slot, kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
+  else hipLaunchKernelGGL(k_describe<false>, grid, block, 0, s, g, p, dp, sel, selCount, slot, kps, desc, nOut, mono, nimg >= 8 ? 1 : 0);
   return hipGetLastError();
 }
 
