@@ -121,10 +121,16 @@ __global__ __launch_bounds__(256) void k_remap(RemapArgs a) {
 // thread, so the 8 B / pixel of map data and the fixed-point weights are fetched / built once per group instead of once per
 // image -- the maps, not the pixels, are the kernel's HBM traffic.
 constexpr int kRemapGroup = 8;
-__global__ __launch_bounds__(256) void k_remap1(RemapArgs a, int nimg) {
-  const int x0 = 4 * (blockIdx.x * 64 + (threadIdx.x & 63)), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb, int yb, int nblk) {
+  // Tile order (round 6): workgroups go to the 8 XCDs round-robin by flat id, so the 4-row tiles of one column strip -- which
+  // share two of the three source rows a window touches -- used to land in eight different L2s.  XCD c now walks the c-th
+  // eighth of the tiles in (map / group, column strip, row) order: vertical neighbours meet in one L2.
+  const int chunk = (nblk + 7) >> 3, T = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+  if (T >= nblk) return;
+  const int tz = T / (xb * yb), txy = T - tz * (xb * yb), tx = txy / yb, ty = txy - tx * yb;
+  const int x0 = 4 * (tx * 64 + (threadIdx.x & 63)), y = ty * 4 + (threadIdx.x >> 6);
   if (x0 >= a.dw || y >= a.dh) return;
-  const int m = blockIdx.z % a.nMaps, grp = blockIdx.z / a.nMaps;
+  const int m = tz % a.nMaps, grp = tz / a.nMaps;
   const float* MX = a.mapx + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
   const float* MY = a.mapy + (long long)m * a.mapImgPitch + (long long)y * a.mapPitch + x0;
   float mx[4], my[4];
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void k_remap1(RemapArgs a, int nimg) {
   const int bx = min(min(min(sxc[0], sxc[1]), min(sxc[2], sxc[3])), a.sw - 8);
   const int by = min(min(syc0[0], syc0[1]), min(syc0[2], syc0[3]));
   bool fast = true;
-  uint32_t selTop[4], selBot[4];  // v_perm selectors: byte d -> bits 0..7, byte d + 1 -> bits 16..23 of the 8-byte window
+  uint32_t selTop[4];             // v_perm selector: byte d -> bits 0..7, byte d + 1 -> bits 16..23 of the 8-byte window (both rows)
   int e0[4], e1[4];               // window row of the top / bottom pair
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -188,32 +194,69 @@ __global__ __launch_bounds__(256) void k_remap1(RemapArgs a, int nimg) {
     e0[k] = syc0[k] - by;
     e1[k] = syc1[k] - by;
     fast = fast && d <= 6 && e0[k] <= 1 && e1[k] <= 2;
-    selTop[k] = selBot[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
+    selTop[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
   }
   const int wo0 = by * pitch + bx, wo1 = min(by + 1, a.sh - 1) * pitch + bx, wo2 = min(by + 2, a.sh - 1) * pitch + bx;
   const uint8_t* __restrict__ src = a.src;
   uint8_t* __restrict__ dst = a.dst;
   const int first = grp * kRemapGroup, perMap = (nimg - m + a.nMaps - 1) / a.nMaps;
   const int count = min(kRemapGroup, perMap - first);
-  for (int g = 0; g < count; g++) {
-    const int img = m + a.nMaps * (first + g);
-    const uint8_t* S = src + (long long)img * a.srcImgPitch;
-    uint2 r0, r1, r2;
-    __builtin_memcpy(&r0, S + wo0, 8);
-    __builtin_memcpy(&r1, S + wo1, 8);
-    __builtin_memcpy(&r2, S + wo2, 8);
+  auto blend_fast = [&](const uint2& r0, const uint2& r1, const uint2& r2) {
     uint32_t packed = 0;
-    if (fast) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t tlo = e0[k] ? r1.x : r0.x, thi = e0[k] ? r1.y : r0.y;
-        const uint32_t blo = e1[k] == 0 ? r0.x : (e1[k] == 1 ? r1.x : r2.x), bhi = e1[k] == 0 ? r0.y : (e1[k] == 1 ? r1.y : r2.y);
-        // two v_dot2_u32_u16: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3); every weight is below 2^15
-        uint32_t acc = udot2_u16(__builtin_amdgcn_perm(thi, tlo, selTop[k]), wlo[k], 16384u);
-        acc = udot2_u16(__builtin_amdgcn_perm(bhi, blo, selBot[k]), whi[k], acc);
-        packed |= (acc >> 15) << (8 * k);
-      }
+    for (int k = 0; k < 4; k++) {
+      const uint32_t tlo = e0[k] ? r1.x : r0.x, thi = e0[k] ? r1.y : r0.y;
+      const uint32_t blo = e1[k] == 0 ? r0.x : (e1[k] == 1 ? r1.x : r2.x), bhi = e1[k] == 0 ? r0.y : (e1[k] == 1 ? r1.y : r2.y);
+      // two v_dot2_u32_u16: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3); every weight is below 2^15
+      uint32_t acc = udot2_u16(__builtin_amdgcn_perm(thi, tlo, selTop[k]), wlo[k], 16384u);
+      acc = udot2_u16(__builtin_amdgcn_perm(bhi, blo, selTop[k]), whi[k], acc);
+      packed |= (acc >> 15) << (8 * k);
+    }
+    return packed;
+  };
+  auto put = [&](int img, uint32_t packed) {
+    uint8_t* D = dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+    if (full && a.dstVec4) {
+      *reinterpret_cast<uint32_t*>(D) = packed;
     } else {
+      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+  };
+  // The loop over the group's images is a chain load -> blend -> store per image, and a wave's time is that chain's memory
+  // latency (round 6: 57 registers = eight waves per SIMD, 6.3 k cycles per image and wave): two images per trip, all six window
+  // loads in flight before the first blend (four at once cost a wave per SIMD and lost).
+  // (wave-uniform choice: in the fast branch the per-pixel offsets of the slow path are dead, which keeps the kernel at eight
+  // waves per SIMD; a wave with one seam thread takes the per-pixel loads for all of its lanes)
+  if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+    int g = 0;
+    for (; g + 1 < count; g += 2) {
+      const int imgA = m + a.nMaps * (first + g), imgB = imgA + a.nMaps;
+      const uint8_t* SA = src + (long long)imgA * a.srcImgPitch;
+      const uint8_t* SB = src + (long long)imgB * a.srcImgPitch;
+      uint2 a0, a1, a2, b0, b1, b2;
+      __builtin_memcpy(&a0, SA + wo0, 8);
+      __builtin_memcpy(&a1, SA + wo1, 8);
+      __builtin_memcpy(&a2, SA + wo2, 8);
+      __builtin_memcpy(&b0, SB + wo0, 8);
+      __builtin_memcpy(&b1, SB + wo1, 8);
+      __builtin_memcpy(&b2, SB + wo2, 8);
+      put(imgA, blend_fast(a0, a1, a2));
+      put(imgB, blend_fast(b0, b1, b2));
+    }
+    if (g < count) {
+      const int img = m + a.nMaps * (first + g);
+      const uint8_t* S = src + (long long)img * a.srcImgPitch;
+      uint2 r0, r1, r2;
+      __builtin_memcpy(&r0, S + wo0, 8);
+      __builtin_memcpy(&r1, S + wo1, 8);
+      __builtin_memcpy(&r2, S + wo2, 8);
+      put(img, blend_fast(r0, r1, r2));
+    }
+  } else {
+    for (int g = 0; g < count; g++) {
+      const int img = m + a.nMaps * (first + g);
+      const uint8_t* S = src + (long long)img * a.srcImgPitch;
+      uint32_t packed = 0;
       uint16_t t[4], b[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -226,19 +269,15 @@ __global__ __launch_bounds__(256) void k_remap1(RemapArgs a, int nimg) {
         acc = udot2_u16(__builtin_amdgcn_perm(0u, (uint32_t)b[k], 0x0c010c00u), whi[k], acc);
         packed |= (acc >> 15) << (8 * k);
       }
-    }
-    uint8_t* D = dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
-    if (full && a.dstVec4) {
-      *reinterpret_cast<uint32_t*>(D) = packed;
-    } else {
-      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+      put(img, packed);
     }
   }
 }
 hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s) {
   if (a.cn == 1 && a.sw >= 8) {
     const int perMap = (nimg + a.nMaps - 1) / a.nMaps, groups = (perMap + kRemapGroup - 1) / kRemapGroup;
-    hipLaunchKernelGGL(k_remap1, dim3((a.dw + 255) / 256, (a.dh + 3) / 4, a.nMaps * groups), dim3(256), 0, s, a, nimg);
+    const int xb = (a.dw + 255) / 256, yb = (a.dh + 3) / 4, nblk = xb * yb * a.nMaps * groups;
+    hipLaunchKernelGGL(k_remap1, dim3(8 * ((nblk + 7) / 8)), dim3(256), 0, s, a, nimg, xb, yb, nblk);
   } else {
     hipLaunchKernelGGL(k_remap, dim3((a.dw + 255) / 256, (a.dh + 3) / 4, nimg), dim3(256), 0, s, a);
   }
@@ -268,6 +307,26 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
   const int qpr = (a.tw + 3) >> 2, nquads = qpr * a.th;
   const float inv_qpr = 1.0f / (float)qpr;
   const int hcopy = (lane & 15) * 257;
+  // (round 6) tiles that lie inside the image with 16-byte aligned rows: 16 pixels per thread and trip -- a 64 x 64 tile is ONE
+  // 16-byte load per thread instead of four dependent dword trips
+  const bool wideTile = (a.tw & 15) == 0 && (tx + 1) * a.tw <= a.w && (ty + 1) * a.th <= a.h && (a.srcPitch & 15) == 0 &&
+                        (a.srcImgPitch & 15) == 0 && ((uintptr_t)a.src & 15) == 0;
+  if (wideTile) {
+    const int spr = a.tw >> 4, nseg = spr * a.th;
+    const uint8_t* T0 = S + (long long)(ty * a.th) * a.srcPitch + tx * a.tw;
+    for (int i = tid; i < nseg; i += 256) {
+      const int yy = i / spr, xsg = i - yy * spr;
+      const uint4 q = *reinterpret_cast<const uint4*>(T0 + (long long)yy * a.srcPitch + 16 * xsg);
+      const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        atomicAdd(&hist[hcopy + (qw[k] & 255)], 1);
+        atomicAdd(&hist[hcopy + ((qw[k] >> 8) & 255)], 1);
+        atomicAdd(&hist[hcopy + ((qw[k] >> 16) & 255)], 1);
+        atomicAdd(&hist[hcopy + (qw[k] >> 24)], 1);
+      }
+    }
+  } else
   for (int i = tid; i < nquads; i += 256) {
     int yy = (int)((float)i * inv_qpr);
     int xq = i - yy * qpr;
@@ -419,6 +478,39 @@ __global__ __launch_bounds__(256) void k_clahe_apply4(ClaheArgs a, const uint32_
     for (int k = 0; k < 4 && x0 + k < a.w; k++) D[k] = (uint8_t)(packed >> (8 * k));
   }
 }
+// Round 6: 16 pixels per thread (one 16-byte load, sixteen table gathers in flight, one 16-byte store) when the rows allow it
+// (width a multiple of 16, 16-byte aligned rows): a 4-pixel thread was one dependent load -> gather -> store chain per wave and
+// the launch ran at 1.7 TB/s of its 6 -- latency, not bandwidth.  Same arithmetic, same order.
+__global__ __launch_bounds__(256) void k_clahe_apply16(ClaheArgs a, const uint32_t* __restrict__ cells, int tpr) {
+  const int t = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+  const int y = t / tpr, x0 = 16 * (t - y * tpr);
+  if (y >= a.h) return;
+  const float tyf = (float)y * a.invTh - 0.5f;
+  const int ty1 = (int)floorf(tyf);
+  const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+  const int ncx = a.tilesX + 1;
+  const uint32_t* C = cells + ((long long)img * (a.tilesY + 1) + min(max(ty1 + 1, 0), a.tilesY)) * ncx * 256;
+  const uint4 in = *reinterpret_cast<const uint4*>(a.src + (long long)img * a.srcImgPitch + (long long)y * a.srcPitch + x0);
+  const uint32_t inw[4] = {in.x, in.y, in.z, in.w};
+  uint32_t e[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    const int tx1 = (int)floorf(txf);
+    e[k] = C[min(max(tx1 + 1, 0), a.tilesX) * 256 + ((inw[k >> 2] >> (8 * (k & 3))) & 255)];
+  }
+  uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    const int tx1 = (int)floorf(txf);
+    const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    const float l11 = (float)(e[k] & 255), l12 = (float)((e[k] >> 8) & 255), l21 = (float)((e[k] >> 16) & 255), l22 = (float)(e[k] >> 24);
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    outw[k >> 2] |= (uint32_t)min(max(__float2int_rn(res), 0), 255) << (8 * (k & 3));
+  }
+  *reinterpret_cast<uint4*>(a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+}
 size_t clahe_cells_bytes(const ClaheArgs& a, int nimg) {
   return (size_t)nimg * (a.tilesY + 1) * (a.tilesX + 1) * 256 * sizeof(uint32_t);
 }
@@ -427,6 +519,12 @@ hipError_t launch_clahe(const ClaheArgs& a, int nimg, uint32_t* cells, hipStream
   const dim3 grid((a.w + 255) / 256, (a.h + 3) / 4, nimg);
   if (cells) {
     hipLaunchKernelGGL(k_clahe_pack, dim3((a.tilesX + 1) * (a.tilesY + 1), nimg), dim3(256), 0, s, a, cells);
+    const bool wide = a.w % 16 == 0 && a.srcPitch % 16 == 0 && a.dstPitch % 16 == 0 && a.srcImgPitch % 16 == 0 && a.dstImgPitch % 16 == 0 &&
+                      ((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.dst & 15) == 0;
+    if (wide) {
+      const int tpr = a.w / 16;
+      hipLaunchKernelGGL(k_clahe_apply16, dim3((tpr * a.h + 255) / 256, nimg), dim3(256), 0, s, a, cells, tpr);
+    } else
     hipLaunchKernelGGL(k_clahe_apply4, grid, dim3(256), 0, s, a, cells);
   } else {
     hipLaunchKernelGGL(k_clahe_apply, grid, dim3(256), 0, s, a);
