@@ -723,6 +723,10 @@ void orbx_debug_set_octree_global(int on);
  * k_stereo_sort launch in front --, larger ones the row-sorted form.  Default 1 (the single-frame path); 0 = never; < 0
  * restores the default.  Environment: ORBX_STEREO_DIRECT_PAIRS. */
 void orbx_debug_set_stereo_direct(int max_pairs);
+/* Test hook of orbx_clahe's two apply forms (cv::CLAHE::apply, Examples/Stereo/stereo_tum_vi.cc:100,142-143): 1 (default) = one
+ * workgroup per interpolation cell with the cell's table in LDS where the geometry allows it, 0 = the per-pixel table gathers
+ * everywhere. */
+void orbx_debug_set_clahe_cell_kernel(int on);
 /* Test hook of the pyramid's fused small-level launches (k_resize_tail: up to three consecutive levels of
  * ComputePyramid, src/ORBextractor.cc:1108-1145, per launch).  first_level: -1 = the library's policy, 0 = no fusion (every
  * level through k_resize), >= 2 = fuse from that level on; max_levels / band_rows: levels per launch and rows of the last

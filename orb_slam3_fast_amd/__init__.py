@@ -166,6 +166,8 @@ def lib():
         L.orbx_debug_set_octree_global.restype = None
         L.orbx_debug_set_stereo_direct.argtypes = [i]
         L.orbx_debug_set_stereo_direct.restype = None
+        L.orbx_debug_set_clahe_cell_kernel.argtypes = [i]
+        L.orbx_debug_set_clahe_cell_kernel.restype = None
         L.orbx_debug_set_resize_tail.argtypes = [i, i, i]
         L.orbx_debug_set_resize_tail.restype = None
         L.orbx_debug_resize_plan.argtypes = [vp, vp, vp, vp, i]

@@ -411,6 +411,7 @@ hipError_t prepare_kernels(const Geom& g);                             // raises
 hipError_t prepare_detect(const Geom& g);                              // (orbx_detect.hip)
 void debug_introsort_host(uint64_t* v, int n);
 void debug_set_detect_list_cap(int cap);
+void debug_set_clahe_cell_kernel(int on);
 void debug_set_octree_global(int on);
 hipError_t launch_debug_sort(uint64_t* d_v, int n, hipStream_t s);
 hipError_t launch_debug_sincos(const float* ang, int n, int fused, float* s, float* c, hipStream_t st);

@@ -187,26 +187,36 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
   const int by = min(min(syc0[0], syc0[1]), min(syc0[2], syc0[3]));
   bool fast = true;
   uint32_t selTop[4];             // v_perm selector: byte d -> bits 0..7, byte d + 1 -> bits 16..23 of the 8-byte window (both rows)
-  int e0[4], e1[4];               // window row of the top / bottom pair
+  uint32_t mT[4], mB1[4], mB2[4]; // all-ones masks: top pair in window row 1; bottom pair in row 1 / row 2 (row 0 otherwise)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const int d = sxc[k] - bx;
-    e0[k] = syc0[k] - by;
-    e1[k] = syc1[k] - by;
-    fast = fast && d <= 6 && e0[k] <= 1 && e1[k] <= 2;
+    const int d = sxc[k] - bx, e0 = syc0[k] - by, e1 = syc1[k] - by;
+    fast = fast && d <= 6 && e0 <= 1 && e1 <= 2;
     selTop[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
+    mT[k] = e0 ? ~0u : 0u;
+    mB1[k] = e1 == 1 ? ~0u : 0u;
+    mB2[k] = e1 == 2 ? ~0u : 0u;
   }
-  const int wo0 = by * pitch + bx, wo1 = min(by + 1, a.sh - 1) * pitch + bx, wo2 = min(by + 2, a.sh - 1) * pitch + bx;
+  // Round 6 (PMC: the texture addresser was busy 70 % of the launch at 45 cycles per UNALIGNED 8-byte load, and the per-pixel row
+  // selects had been compiled into exec-mask branches: 1188 scalar against 901 vector instructions per wave): a row of the window
+  // is three ALIGNED dwords from bx & ~3, shifted into place by two v_alignbyte, and the row selects are v_bfi on precomputed masks.
+  const int bs = bx & 3, bxa = bx - bs;
+  fast = fast && bxa + 12 <= a.sw;   // (the three dwords stay inside the row)
+  const int wo0 = by * pitch + bxa, wo1 = min(by + 1, a.sh - 1) * pitch + bxa, wo2 = min(by + 2, a.sh - 1) * pitch + bxa;
   const uint8_t* __restrict__ src = a.src;
   uint8_t* __restrict__ dst = a.dst;
   const int first = grp * kRemapGroup, perMap = (nimg - m + a.nMaps - 1) / a.nMaps;
   const int count = min(kRemapGroup, perMap - first);
-  auto blend_fast = [&](const uint2& r0, const uint2& r1, const uint2& r2) {
+  struct Row3 { uint32_t w[3]; };
+  auto shift_row = [&](const Row3& r) { return make_uint2(__builtin_amdgcn_alignbyte(r.w[1], r.w[0], bs), __builtin_amdgcn_alignbyte(r.w[2], r.w[1], bs)); };
+  auto bfi = [](uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); };   // v_bfi_b32
+  auto blend_fast = [&](const Row3& q0, const Row3& q1, const Row3& q2) {
+    const uint2 r0 = shift_row(q0), r1 = shift_row(q1), r2 = shift_row(q2);
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t tlo = e0[k] ? r1.x : r0.x, thi = e0[k] ? r1.y : r0.y;
-      const uint32_t blo = e1[k] == 0 ? r0.x : (e1[k] == 1 ? r1.x : r2.x), bhi = e1[k] == 0 ? r0.y : (e1[k] == 1 ? r1.y : r2.y);
+      const uint32_t tlo = bfi(mT[k], r1.x, r0.x), thi = bfi(mT[k], r1.y, r0.y);
+      const uint32_t blo = bfi(mB2[k], r2.x, bfi(mB1[k], r1.x, r0.x)), bhi = bfi(mB2[k], r2.y, bfi(mB1[k], r1.y, r0.y));
       // two v_dot2_u32_u16: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3); every weight is below 2^15
       uint32_t acc = udot2_u16(__builtin_amdgcn_perm(thi, tlo, selTop[k]), wlo[k], 16384u);
       acc = udot2_u16(__builtin_amdgcn_perm(bhi, blo, selTop[k]), whi[k], acc);
@@ -222,9 +232,8 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
       for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
     }
   };
-  // The loop over the group's images is a chain load -> blend -> store per image, and a wave's time is that chain's memory
-  // latency (round 6: 57 registers = eight waves per SIMD, 6.3 k cycles per image and wave): two images per trip, all six window
-  // loads in flight before the first blend (four at once cost a wave per SIMD and lost).
+  // The loop over the group's images is a chain load -> blend -> store per image: two images per trip, all six row loads in
+  // flight before the first blend.
   // (wave-uniform choice: in the fast branch the per-pixel offsets of the slow path are dead, which keeps the kernel at eight
   // waves per SIMD; a wave with one seam thread takes the per-pixel loads for all of its lanes)
   if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
@@ -233,23 +242,23 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
       const int imgA = m + a.nMaps * (first + g), imgB = imgA + a.nMaps;
       const uint8_t* SA = src + (long long)imgA * a.srcImgPitch;
       const uint8_t* SB = src + (long long)imgB * a.srcImgPitch;
-      uint2 a0, a1, a2, b0, b1, b2;
-      __builtin_memcpy(&a0, SA + wo0, 8);
-      __builtin_memcpy(&a1, SA + wo1, 8);
-      __builtin_memcpy(&a2, SA + wo2, 8);
-      __builtin_memcpy(&b0, SB + wo0, 8);
-      __builtin_memcpy(&b1, SB + wo1, 8);
-      __builtin_memcpy(&b2, SB + wo2, 8);
+      Row3 a0, a1, a2, b0, b1, b2;
+      __builtin_memcpy(&a0, SA + wo0, 12);
+      __builtin_memcpy(&a1, SA + wo1, 12);
+      __builtin_memcpy(&a2, SA + wo2, 12);
+      __builtin_memcpy(&b0, SB + wo0, 12);
+      __builtin_memcpy(&b1, SB + wo1, 12);
+      __builtin_memcpy(&b2, SB + wo2, 12);
       put(imgA, blend_fast(a0, a1, a2));
       put(imgB, blend_fast(b0, b1, b2));
     }
     if (g < count) {
       const int img = m + a.nMaps * (first + g);
       const uint8_t* S = src + (long long)img * a.srcImgPitch;
-      uint2 r0, r1, r2;
-      __builtin_memcpy(&r0, S + wo0, 8);
-      __builtin_memcpy(&r1, S + wo1, 8);
-      __builtin_memcpy(&r2, S + wo2, 8);
+      Row3 r0, r1, r2;
+      __builtin_memcpy(&r0, S + wo0, 12);
+      __builtin_memcpy(&r1, S + wo1, 12);
+      __builtin_memcpy(&r2, S + wo2, 12);
       put(img, blend_fast(r0, r1, r2));
     }
   } else {
@@ -299,24 +308,32 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = blockIdx.x, img = blockIdx.y;
   const int ty = tile / a.tilesX, tx = tile - ty * a.tilesX;
+  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
+  // (round 6) a 64 x 64 tile is one 16-byte load per thread: requested BEFORE the histograms are cleared, so that the clear and
+  // its barrier run under the load's latency
+  const bool wideTile = (a.tw & 15) == 0 && (tx + 1) * a.tw <= a.w && (ty + 1) * a.th <= a.h && (a.srcPitch & 15) == 0 &&
+                        (a.srcImgPitch & 15) == 0 && ((uintptr_t)a.src & 15) == 0;
+  const int spr = a.tw >> 4, nseg = spr * a.th;
+  const uint8_t* T0 = S + (long long)(ty * a.th) * a.srcPitch + tx * a.tw;
+  uint4 q0 = make_uint4(0, 0, 0, 0);
+  if (wideTile && tid < nseg) {
+    const int yy = tid / spr, xsg = tid - yy * spr;
+    q0 = *reinterpret_cast<const uint4*>(T0 + (long long)yy * a.srcPitch + 16 * xsg);
+  }
   for (int k = tid; k < 16 * 257; k += 256) hist[k] = 0;
   __syncthreads();
-  const uint8_t* S = a.src + (long long)img * a.srcImgPitch;
   // thread per 4 pixels of a tile row (sub-dword loads run at a fraction of the dword rate); quads that touch the tile's right
   // edge or the reflected extension go pixel by pixel
   const int qpr = (a.tw + 3) >> 2, nquads = qpr * a.th;
   const float inv_qpr = 1.0f / (float)qpr;
   const int hcopy = (lane & 15) * 257;
-  // (round 6) tiles that lie inside the image with 16-byte aligned rows: 16 pixels per thread and trip -- a 64 x 64 tile is ONE
-  // 16-byte load per thread instead of four dependent dword trips
-  const bool wideTile = (a.tw & 15) == 0 && (tx + 1) * a.tw <= a.w && (ty + 1) * a.th <= a.h && (a.srcPitch & 15) == 0 &&
-                        (a.srcImgPitch & 15) == 0 && ((uintptr_t)a.src & 15) == 0;
   if (wideTile) {
-    const int spr = a.tw >> 4, nseg = spr * a.th;
-    const uint8_t* T0 = S + (long long)(ty * a.th) * a.srcPitch + tx * a.tw;
     for (int i = tid; i < nseg; i += 256) {
-      const int yy = i / spr, xsg = i - yy * spr;
-      const uint4 q = *reinterpret_cast<const uint4*>(T0 + (long long)yy * a.srcPitch + 16 * xsg);
+      uint4 q = q0;
+      if (i != tid) {
+        const int yy = i / spr, xsg = i - yy * spr;
+        q = *reinterpret_cast<const uint4*>(T0 + (long long)yy * a.srcPitch + 16 * xsg);
+      }
       const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
   if (a.clip > 0) {
     int ex = max(v - a.clip, 0);
     v -= ex;
-    for (int o = 32; o > 0; o >>= 1) ex += __shfl_xor(ex, o);
+    ex = wave_sum_dpp(ex);   // (DPP row shifts: a __shfl_xor step is a ds_bpermute round trip)
     if (lane == 0) wsum[wave] = ex;
     __syncthreads();
     const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -369,11 +386,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(ClaheArgs a) {
       if (tid % step == 0 && tid / step < residual) v++;
     }
   }
-  int sum = v;  // inclusive prefix sum over the 256 bins
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(sum, o);
-    if (lane >= o) sum += t;
-  }
+  int sum = wave_scan_dpp(v);  // inclusive prefix sum over the 256 bins
   if (lane == 63) wsum[wave] = sum;
   __syncthreads();
   for (int k = 0; k < wave; k++) sum += wsum[k];
@@ -511,16 +524,85 @@ __global__ __launch_bounds__(256) void k_clahe_apply16(ClaheArgs a, const uint32
   }
   *reinterpret_cast<uint4*>(a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
 }
+// Round 6, the product path for the usual geometry (tile width a multiple of 32, 16-byte aligned rows): ONE workgroup per
+// interpolation cell.  PMC of the per-pixel table gathers above (profiles/r6a_preproc_pmc.txt): the texture addresser was busy 76 %
+// of k_clahe_apply16 -- a wave's 64 scattered dword gathers cost it 37 cycles -- so the cell's table (256 dwords: the four
+// neighbouring tiles' lut bytes of every grey value, packed) is built in LDS by the workgroup itself from the four luts (no
+// k_clahe_pack launch, no cell-table buffer) and the 16 look-ups of a thread are LDS reads.  A cell is tw x th pixels (half that at
+// the image border) = tw / 16 segments per row; thread = (segment, row phase).  Same float blend in OpenCV's expression order.
+__global__ __launch_bounds__(256) void k_clahe_apply_cell(ClaheArgs a) {
+  __shared__ uint32_t tab[256];
+  const int ncx = a.tilesX + 1, cx = blockIdx.x % ncx, cy = blockIdx.x / ncx, img = blockIdx.y, tid = threadIdx.x;
+  {
+    const int tx1 = max(cx - 1, 0), tx2 = min(cx, a.tilesX - 1), ty1 = max(cy - 1, 0), ty2 = min(cy, a.tilesY - 1);
+    const uint8_t* L = a.lut + (long long)img * a.tilesX * a.tilesY * 256;
+    const uint32_t l11 = L[(ty1 * a.tilesX + tx1) * 256 + tid], l12 = L[(ty1 * a.tilesX + tx2) * 256 + tid];
+    const uint32_t l21 = L[(ty2 * a.tilesX + tx1) * 256 + tid], l22 = L[(ty2 * a.tilesX + tx2) * 256 + tid];
+    tab[tid] = l11 | (l12 << 8) | (l21 << 16) | (l22 << 24);
+  }
+  // pixel (x, y) belongs to cell (floor(x / tw - 0.5) + 1, floor(y / th - 0.5) + 1): columns [cx tw - tw / 2, cx tw + tw / 2)
+  const int xb = max(cx * a.tw - (a.tw >> 1), 0), xe = min(cx * a.tw + (a.tw >> 1), a.w);
+  const int yb = max(cy * a.th - (a.th >> 1), 0), ye = min(cy * a.th + (a.th >> 1), a.h);
+  const int spr = (xe - xb) >> 4;               // 16-pixel segments per row of the cell (tw % 32 == 0: xb, xe are multiples of 16)
+  __syncthreads();
+  if (spr <= 0) return;
+  const int rpp = 256 / spr;                    // rows per pass (spr <= 16 is checked on the host)
+  const int sg = tid % spr, r0 = tid / spr;
+  if (r0 >= rpp) return;
+  const int x0 = xb + 16 * sg;
+  float xa[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const float txf = (float)(x0 + k) * a.invTw - 0.5f;
+    xa[k] = txf - (float)(int)floorf(txf);
+  }
+  for (int y = yb + r0; y < ye; y += rpp) {
+    const float tyf = (float)y * a.invTh - 0.5f;
+    const float ya = tyf - (float)(int)floorf(tyf), ya1 = 1.0f - ya;
+    const uint4 in = *reinterpret_cast<const uint4*>(a.src + (long long)img * a.srcImgPitch + (long long)y * a.srcPitch + x0);
+    const uint32_t inw[4] = {in.x, in.y, in.z, in.w};
+    uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t e = tab[(inw[k >> 2] >> (8 * (k & 3))) & 255];
+      const float xa1 = 1.0f - xa[k];
+      const float l11 = (float)(e & 255), l12 = (float)((e >> 8) & 255), l21 = (float)((e >> 16) & 255), l22 = (float)(e >> 24);
+      const float res = (l11 * xa1 + l12 * xa[k]) * ya1 + (l21 * xa1 + l22 * xa[k]) * ya;
+      outw[k >> 2] |= (uint32_t)min(max(__float2int_rn(res), 0), 255) << (8 * (k & 3));
+    }
+    *reinterpret_cast<uint4*>(a.dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0) = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+  }
+}
 size_t clahe_cells_bytes(const ClaheArgs& a, int nimg) {
   return (size_t)nimg * (a.tilesY + 1) * (a.tilesX + 1) * 256 * sizeof(uint32_t);
 }
+// The per-cell kernel cuts the image into cells with integer arithmetic; the reference's rule is floor((float)x * invTw - 0.5f)
+// evaluated per pixel in float.  They agree when the float expression changes exactly at x = k tw + tw / 2 (always for power-of-two
+// tiles); checked here on both sides of every boundary with the kernel's own float operations, otherwise the gather kernels run.
+static bool clahe_cells_exact(int n, int t, int tiles, float inv) {
+  for (int c = 0; c <= tiles; c++) {
+    const int b = max(c * t - (t >> 1), 0), e = min(c * t + (t >> 1), n);
+    if (b >= e) continue;
+    for (int x : {b, e - 1}) {
+      const float f = (float)x * inv - 0.5f;
+      if (min(max((int)floorf(f) + 1, 0), tiles) != c) return false;
+    }
+  }
+  return true;
+}
+static int g_clahe_cell_kernel = 1;   // test hook: 0 = the gather kernels also where the per-cell kernel applies
+void debug_set_clahe_cell_kernel(int on) { g_clahe_cell_kernel = on; }
 hipError_t launch_clahe(const ClaheArgs& a, int nimg, uint32_t* cells, hipStream_t s) {
   hipLaunchKernelGGL(k_clahe_lut, dim3(a.tilesX * a.tilesY, nimg), dim3(256), 0, s, a);
   const dim3 grid((a.w + 255) / 256, (a.h + 3) / 4, nimg);
-  if (cells) {
+  // (the reflect-101 extension of k_clahe_lut keeps tw * tilesX >= w: a cell never reaches past the image by more than it is clipped)
+  const bool wide = a.w % 16 == 0 && a.srcPitch % 16 == 0 && a.dstPitch % 16 == 0 && a.srcImgPitch % 16 == 0 && a.dstImgPitch % 16 == 0 &&
+                    ((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.dst & 15) == 0;
+  if (wide && a.tw % 32 == 0 && a.tw <= 256 && g_clahe_cell_kernel && clahe_cells_exact(a.w, a.tw, a.tilesX, a.invTw) &&
+      clahe_cells_exact(a.h, a.th, a.tilesY, a.invTh)) {
+    hipLaunchKernelGGL(k_clahe_apply_cell, dim3((a.tilesX + 1) * (a.tilesY + 1), nimg), dim3(256), 0, s, a);
+  } else if (cells) {
     hipLaunchKernelGGL(k_clahe_pack, dim3((a.tilesX + 1) * (a.tilesY + 1), nimg), dim3(256), 0, s, a, cells);
-    const bool wide = a.w % 16 == 0 && a.srcPitch % 16 == 0 && a.dstPitch % 16 == 0 && a.srcImgPitch % 16 == 0 && a.dstImgPitch % 16 == 0 &&
-                      ((uintptr_t)a.src & 15) == 0 && ((uintptr_t)a.dst & 15) == 0;
     if (wide) {
       const int tpr = a.w / 16;
       hipLaunchKernelGGL(k_clahe_apply16, dim3((tpr * a.h + 255) / 256, nimg), dim3(256), 0, s, a, cells, tpr);

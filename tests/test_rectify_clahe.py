@@ -210,6 +210,17 @@ def test_hip_clahe_matches_oracle(oracle):
     for img, clip, tiles in cases:
         got = orbx.CLAHE(clip, tiles).apply(img)
         assert np.array_equal(got, oracle.clahe(img, clip, tiles)), (img.shape, clip, tiles)
+    # both apply forms (round 6: one workgroup per interpolation cell with the table in LDS / per-pixel table gathers), incl. tile
+    # sizes whose cell boundaries are not exact in float (96, 160 px: the host falls back unless the float rule agrees)
+    cases2 = [cases[0], cases[-1], (synth.mono_frame(768, 512, 8), 3.0, (8, 8)), (synth.mono_frame(1024, 768, 9), 2.0, (4, 4)),
+              (synth.mono_frame(256, 256, 10), 3.0, (8, 8))]
+    try:
+        for hook in (0, 1):
+            orbx.lib().orbx_debug_set_clahe_cell_kernel(hook)
+            for img, clip, tiles in cases2:
+                assert np.array_equal(orbx.CLAHE(clip, tiles).apply(img), oracle.clahe(img, clip, tiles)), (hook, img.shape, clip, tiles)
+    finally:
+        orbx.lib().orbx_debug_set_clahe_cell_kernel(1)
     with pytest.raises(orbx.OrbxError):
         orbx.CLAHE(3.0, (0, 8)).apply(np.zeros((32, 32), np.uint8))
     with pytest.raises(orbx.OrbxError):
