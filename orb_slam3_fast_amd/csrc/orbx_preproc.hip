@@ -187,19 +187,19 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
   const int by = min(min(syc0[0], syc0[1]), min(syc0[2], syc0[3]));
   bool fast = true;
   uint32_t selTop[4];             // v_perm selector: byte d -> bits 0..7, byte d + 1 -> bits 16..23 of the 8-byte window (both rows)
-  uint32_t mT[4], mB1[4], mB2[4]; // all-ones masks: top pair in window row 1; bottom pair in row 1 / row 2 (row 0 otherwise)
+  uint32_t wrow[4][3];            // the pixel's weight pairs by WINDOW ROW: (w0, w1) on the row of its top pair, (w2, w3) on the row of its
+                                  // bottom pair, 0 on the third -- a pixel is three perm + dot2 over the rows, no row selects
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int d = sxc[k] - bx, e0 = syc0[k] - by, e1 = syc1[k] - by;
     fast = fast && d <= 6 && e0 <= 1 && e1 <= 2;
     selTop[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
-    mT[k] = e0 ? ~0u : 0u;
-    mB1[k] = e1 == 1 ? ~0u : 0u;
-    mB2[k] = e1 == 2 ? ~0u : 0u;
+#pragma unroll
+    for (int j = 0; j < 3; j++) wrow[k][j] = (e0 == j ? wlo[k] : 0u) + (e1 == j ? whi[k] : 0u);   // (both on one row only when a clamped row carries weight 0)
   }
   // Round 6 (PMC: the texture addresser was busy 70 % of the launch at 45 cycles per UNALIGNED 8-byte load, and the per-pixel row
   // selects had been compiled into exec-mask branches: 1188 scalar against 901 vector instructions per wave): a row of the window
-  // is three ALIGNED dwords from bx & ~3, shifted into place by two v_alignbyte, and the row selects are v_bfi on precomputed masks.
+  // is three ALIGNED dwords from bx & ~3, shifted into place by two v_alignbyte, and the row selects are gone: the weights are laid out per window row.
   const int bs = bx & 3, bxa = bx - bs;
   fast = fast && bxa + 12 <= a.sw;   // (the three dwords stay inside the row)
   const int wo0 = by * pitch + bxa, wo1 = min(by + 1, a.sh - 1) * pitch + bxa, wo2 = min(by + 2, a.sh - 1) * pitch + bxa;
@@ -209,17 +209,15 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
   const int count = min(kRemapGroup, perMap - first);
   struct Row3 { uint32_t w[3]; };
   auto shift_row = [&](const Row3& r) { return make_uint2(__builtin_amdgcn_alignbyte(r.w[1], r.w[0], bs), __builtin_amdgcn_alignbyte(r.w[2], r.w[1], bs)); };
-  auto bfi = [](uint32_t m, uint32_t x, uint32_t y) { return (m & x) | (~m & y); };   // v_bfi_b32
   auto blend_fast = [&](const Row3& q0, const Row3& q1, const Row3& q2) {
     const uint2 r0 = shift_row(q0), r1 = shift_row(q1), r2 = shift_row(q2);
     uint32_t packed = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const uint32_t tlo = bfi(mT[k], r1.x, r0.x), thi = bfi(mT[k], r1.y, r0.y);
-      const uint32_t blo = bfi(mB2[k], r2.x, bfi(mB1[k], r1.x, r0.x)), bhi = bfi(mB2[k], r2.y, bfi(mB1[k], r1.y, r0.y));
-      // two v_dot2_u32_u16: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3); every weight is below 2^15
-      uint32_t acc = udot2_u16(__builtin_amdgcn_perm(thi, tlo, selTop[k]), wlo[k], 16384u);
-      acc = udot2_u16(__builtin_amdgcn_perm(bhi, blo, selTop[k]), whi[k], acc);
+      // three v_dot2_u32_u16 over the window rows: (p00, p01) . (w0, w1) + (p10, p11) . (w2, w3) + 0; every weight is below 2^15
+      uint32_t acc = udot2_u16(__builtin_amdgcn_perm(r0.y, r0.x, selTop[k]), wrow[k][0], 16384u);
+      acc = udot2_u16(__builtin_amdgcn_perm(r1.y, r1.x, selTop[k]), wrow[k][1], acc);
+      acc = udot2_u16(__builtin_amdgcn_perm(r2.y, r2.x, selTop[k]), wrow[k][2], acc);
       packed |= (acc >> 15) << (8 * k);
     }
     return packed;
