@@ -33,7 +33,8 @@ import time
 # handles sharing a queue serialise (profiles/r5_small_batch_handles.txt: 16 frames 640x480 per step, 4 handles: 185 k frames/s on
 # 4 queues, 272 - 279 k on 8).  Read once, when the runtime initialises: set here, before anything touches HIP; an explicit
 # setting of the caller wins.  Reported in the JSON line (config.env).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if os.environ.get("ORBX_BENCH_KEEP_QUEUES") != "1":   # (default_queue_leg re-runs the headline with the runtime's own default)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -431,6 +432,9 @@ def main():
         "warmup": a.warmup,
         "preheat_steps": preheat_steps,
         "ms_per_step": round(1000.0 * elapsed / a.steps, 4),
+        # compact copies of the numbers a reader needs first (filled by the legs below; the full objects follow further down the line)
+        "latency": None,
+        "cpu_c1": None,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -589,6 +593,12 @@ def main():
         out.update(natural_pair_leg(orbx, np))
     if extras and a.latency_frames > 0:
         out.update(latency_leg(a, wl, orbx, np))
+        pick = lambda d: None if not d else {k: d[k] for k in ("mean", "std", "p50", "p99") if k in d}
+        out["latency"] = {"unit": "ms per 1280x720 stereo frame (host images in, host results out)", "source": out.get("latency_source"),
+                          "extract_stereo": pick(out.get("latency_ms")),
+                          "extract_stereo_with_host_pyramid": pick(out.get("latency_with_host_pyramid_ms")),
+                          "unmodified_two_thread_flow": pick(out.get("latency_cpp_two_thread_flow_ms")),
+                          "c_abi_call_from_this_process": pick(out.get("latency_ctypes_ms"))}
     if extras and a.h2d_steps > 0:
         out.update(h2d_leg(a, wl, orbx, np, torch))
 
@@ -599,9 +609,19 @@ def main():
         for e_ in wl.exs:
             e_.close()
         out["other_configs"] = other_configs_leg(a, local_rank, torch)
+        try:
+            out["other_configs"]["preproc"] = preproc_leg(orbx, np)
+        except Exception as ex_:
+            out["other_configs"]["preproc"] = {"error": str(ex_)[:160]}
+        try:
+            out["natural"] = natural_throughput_leg(a, orbx, np)
+        except Exception as ex_:
+            out["natural"] = {"error": str(ex_)[:160]}
+        out["config"]["default_queues"] = default_queue_leg(a)
     # ---- CPU baselines: the oracle (port of the reference's serial semantics), rank 0, N=1 only.
     if extras and a.cpu_pairs > 0:
         out.update(cpu_legs(a, wl, np))
+        out["cpu_c1"] = out.pop("cpu_c1_full", None)
 
     if rank == 0:
         sys.stdout.flush()
@@ -745,6 +765,133 @@ def other_configs_leg(a, local_rank, torch):
     return res
 
 
+def natural_throughput_leg(a, orbx, np):
+    """The headline step on NATURAL texture: 32 pairs 1280x720 cut out of mosaics of the committed natural images (skimage camera /
+    astronaut / the Middlebury motorcycle pair, tests/golden/natural_images.npz), right eye = left shifted by a per-pair disparity;
+    device-resident, the headline's number of handles, stereo association included."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    W, H, B, K = 1280, 720, 32, 60
+    z = np.load(os.path.join(ROOT, "tests", "golden", "natural_images.npz"))
+    tiles = [z["camera"], z["astronaut"], z["moto_left"], z["moto_right"]]
+    rng = np.random.default_rng(7)
+
+    def mosaic(seed):
+        r = np.random.default_rng(seed)
+        canvas = np.zeros((H + 64, W + 256), np.uint8)
+        y = 0
+        while y < canvas.shape[0]:
+            x, rowh = 0, 0
+            while x < canvas.shape[1]:
+                t = tiles[int(r.integers(0, 4))]
+                if r.random() < 0.5:
+                    t = t[:, ::-1]
+                h, w = min(t.shape[0], canvas.shape[0] - y), min(t.shape[1], canvas.shape[1] - x)
+                canvas[y:y + h, x:x + w] = t[:h, :w]
+                x += w
+                rowh = max(rowh, h)
+            y += rowh
+        return canvas
+    lefts, rights = [], []
+    for i in range(B):
+        c = mosaic(100 + i)
+        d = int(rng.integers(8, 96))
+        lefts.append(c[32:32 + H, 128:128 + W])
+        rights.append(c[32:32 + H, 128 + d:128 + d + W])
+    dbuf = DeviceBuffer.from_numpy(np.ascontiguousarray(np.concatenate([np.stack(lefts), np.stack(rights)])))
+    exs = [orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=2 * B) for _ in range(a.handles)]
+    it = [0]
+
+    def step():
+        e = exs[it[0] % len(exs)]
+        it[0] += 1
+        e.extract_batch_device(dbuf.ptr.value, 2 * B, W, H, W, W * H)
+        orbx.stereo_match_async(e, e, BF, BASE, 0, B, B)
+    for _ in range(40):
+        step()
+    for e in exs:
+        e.sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    for e in exs:
+        e.sync()
+    dt = time.perf_counter() - t0
+    _, _, nc, ns = exs[0].level_stats(0)
+    res = {"value": round(B * K / dt, 1), "unit": "stereo frames/s", "ms_per_step": round(1e3 * dt / K, 4), "pairs_per_step": B,
+           "steps": K, "handles": len(exs), "fast_candidates_image0": int(nc.sum()), "keypoints_image0": int(ns.sum()),
+           "data": "1280x720 pairs cut out of mosaics of natural images (tests/golden/natural_images.npz), integer disparities 8..95"}
+    for e in exs:
+        e.close()
+    return res
+
+
+def preproc_leg(orbx, np):
+    """SURVEY 8f row f2 in front of the extractor, device-resident: cv::remap rectification of 64 x 1280x720 frames with two float
+    maps (src/System.cc:288-302) and cv::CLAHE(3.0, 8x8) of 64 x 512x512 frames (TUM-VI front ends).  Wall clock around
+    synchronised runs; algorithmic bytes = 2 B per pixel (+ 8 B per map pixel, once per 8-image group) for remap, 3 B per pixel
+    for CLAHE (histogram read, apply read, write); traffic = HBM-side bytes per launch from the committed rocprofv3 PMC passes
+    (profiles/r6_preproc_traffic.json)."""
+    from orb_slam3_fast_amd import synth
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+
+    def timed(fn, iters=30, warm=5):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        return (time.perf_counter() - t0) / iters
+    traf = {}
+    try:
+        traf = json.load(open(os.path.join(ROOT, "profiles", "r6_preproc_traffic.json")))
+    except Exception:
+        traf = {}
+    out = {}
+    B, w, h = 64, 1280, 720
+    L, R = synth.stereo_pair(w, h, 5)
+    frames = DeviceBuffer.from_numpy(np.stack([L, R] * (B // 2)))
+    ml, mr = synth.rectify_maps(w, h, seed=1), synth.rectify_maps(w, h, seed=2, rot_deg=(-0.3, 0.5, -0.2))
+    pp = orbx.Preproc(w, h, maps=(np.stack([ml[0], mr[0]]), np.stack([ml[1], mr[1]])), max_batch=B)
+    t = timed(lambda: pp.run_device(frames.ptr.value, B, w, w * h))
+    nb = B * 2 * w * h + 2 * 8 * w * h
+    out["rectify_1280x720"] = {"value": round(B / t, 1), "unit": "frames/s", "us_per_batch": round(t * 1e6, 2), "batch": B,
+                               "roofline": {"kernel": "k_remap1", "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
+                                            "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_remap1")}}
+    w2 = h2 = 512
+    f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
+    pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)
+    t = timed(lambda: pc.run_device(f2.ptr.value, B, w2, w2 * h2))
+    nb = B * 3 * w2 * h2
+    out["clahe_512x512"] = {"value": round(B / t, 1), "unit": "frames/s", "us_per_batch": round(t * 1e6, 2), "batch": B,
+                            "roofline": {"kernel": "k_clahe_lut + k_clahe_apply_cell", "bound": "hbm", "achieved": round(nb / t / 1e9, 1),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
+                                         "algorithmic_bytes_per_launch": nb,
+                                         "traffic": (traf.get("k_clahe_lut", 0) + traf.get("k_clahe_apply_cell", 0)) or None}}
+    out["note"] = ("wall clock of synchronised runs (two launches for CLAHE: their boundary is inside); kernel durations and PMC passes: "
+                   "profiles/r6_preproc_*")
+    return out
+
+
+def default_queue_leg(a):
+    """The headline with the runtime's DEFAULT number of hardware queues and three handles: what a process that cannot set
+    GPU_MAX_HW_QUEUES before HIP initialises gets from the library (the knob is the launcher's, not the library's).  A subprocess:
+    the variable is read once, when the runtime starts."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    env["ORBX_BENCH_KEEP_QUEUES"] = "1"
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", "--handles", "3", "--steps", str(a.steps),
+                            "--warmup", str(a.warmup)], capture_output=True, text=True, timeout=300, env=env)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "handles": 3,
+                "GPU_MAX_HW_QUEUES": d["config"]["env"]["GPU_MAX_HW_QUEUES"],
+                "note": "same workload in a fresh process WITHOUT the GPU_MAX_HW_QUEUES knob (runtime default: four hardware queues), three handles"}
+    except Exception as ex_:
+        return {"error": str(ex_)[:160]}
+
+
 def _stats(v, np):
     v = np.asarray(v, np.float64)
     return {"mean": round(float(v.mean()), 4), "std": round(float(v.std()), 4), "p50": round(float(np.percentile(v, 50)), 4),
@@ -865,9 +1012,9 @@ def cpp_mirror_latency(frames, W, H, NF, calls, np):
     import tempfile
     root = os.path.dirname(os.path.abspath(__file__))
     try:
-        sys.path.insert(0, os.path.join(root, "tests"))
-        import test_cpp_mirror
-        exe = test_cpp_mirror.build_exe(False)
+        sys.path.insert(0, os.path.join(root, "tools"))
+        import build_cpp
+        exe = build_cpp.build_exe(False)
         path = os.path.join(tempfile.gettempdir(), "orbx_bench_lat_frames_%d.raw" % os.getpid())
         np.stack([np.stack([L, R]) for L, R in frames]).tofile(path)
         try:
@@ -880,15 +1027,17 @@ def cpp_mirror_latency(frames, W, H, NF, calls, np):
             m = re.search(r"mbKeepHostPyramid=%d: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)  std ([0-9.]+)  p99 ([0-9.]+)" % keep, r.stdout)
             res[key] = {"mean": float(m.group(1)), "std": float(m.group(4)), "p50": float(m.group(2)), "p99": float(m.group(5)),
                         "frames": max(50, calls)} if m else None
-        m = re.search(r"two threads x operator\(\) \+ ComputeStereoMatches[^:]*: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)", r.stdout)
+        m = re.search(r"two threads x operator\(\) \+ ComputeStereoMatches[^:]*: mean ([0-9.]+) ms  p50 ([0-9.]+)  p90 ([0-9.]+)  std ([0-9.]+)  p99 ([0-9.]+)", r.stdout)
         # the reference's UNMODIFIED flow (src/Frame.cc:200-232): two std::threads per frame, one operator() each, then ComputeStereoMatches
-        res["latency_cpp_two_thread_flow_ms"] = {"mean": float(m.group(1)), "p50": float(m.group(2)), "p90": float(m.group(3)),
-                                                  "frames": max(50, calls)} if m else None
+        res["latency_cpp_two_thread_flow_ms"] = {"mean": float(m.group(1)), "std": float(m.group(4)), "p50": float(m.group(2)),
+                                                  "p90": float(m.group(3)), "p99": float(m.group(5)), "frames": max(50, calls)} if m else None
         res["latency_cpp_mirror_note"] = ("ORB_SLAM3::ORBextractor::ExtractStereo of csrc/ORBextractor.h (cvlite types) on %d distinct frames, timed "
                                           "with std::chrono inside tests/cpp/frame_like; with_host_pyramid = the class's default "
                                           "mbKeepHostPyramid = true" % len(frames))
         return res
-    except Exception as ex_:   # (context, never a reason to lose the line)
+    except Exception as ex_:   # (context, never a reason to lose the line -- but never silently either)
+        sys.stderr.write("bench.py: WARNING: the C++ latency leg did not run (%s): latency_ms FALLS BACK to the ctypes timing, "
+                         "latency_source = ctypes\n" % str(ex_)[:200])
         return {"latency_cpp_mirror_ms": None, "latency_cpp_mirror_error": str(ex_)[:160]}
 
 
@@ -1039,6 +1188,20 @@ def cpu_legs(a, wl, np):
                       "%d worker processes x %d of the same synthetic %dx%d pairs, wall %.1f s; single worker: %d pairs "
                       "in %.1f s; host reports %d cores, %d usable (affinity / cgroup quota)" % (
                           cores, per, W, H, rN["wall_s"], r1["pairs"], r1["wall_s"], os.cpu_count(), usable_cores())}
+        try:   # BASELINE config C1: the reference's own CPU-runnable case (752x480 mono, 1000 features), frame-parallel port
+            from orb_slam3_fast_amd import synth
+            fr = np.stack([synth.mono_frame(752, 480, 500 + i) for i in range(4)])
+            tmp1 = os.path.join(tempfile.gettempdir(), "orbx_c1_%d.npy" % os.getpid())
+            np.save(tmp1, np.stack([fr, fr], 1))        # cpu_bench times pairs: (L, R) = two mono frames
+            try:
+                rc = run([tmp1, "1000", "1.0", "1.0", str(cores), "10", "--extract-only"], 300)
+            finally:
+                os.remove(tmp1)
+            out["cpu_c1_full"] = {"value": round(rc["frames_per_s"], 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                                  "workload": "C1: synthetic 752x480 mono, 1000 features, 8 levels (CPU oracle, no GPU)",
+                                  "sample": "%d worker processes x 20 frames, wall %.1f s; build: %s" % (cores, rc["wall_s"], build)}
+        except Exception as ex_:
+            out["cpu_c1_full"] = {"error": str(ex_)[:160]}
         rM = run(["--mt", tmp, str(NF), str(BF), str(BASE), str(a.cpu_mt_frames)], 900)
         out["cpu_mt"] = {
             "value": round(rM["pairs_per_s"], 2), "unit": "stereo frames/s", "threads": rM["threads"], "cores": min(cores, rM["threads"]),

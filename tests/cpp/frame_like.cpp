@@ -270,11 +270,14 @@ int main(int argc, char** argv) {
           if (i >= 0) m2.push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
           if (i >= 0) csm += std::chrono::duration<double, std::milli>(t1 - tj).count();
         }
-        double mean2 = 0;
+        double mean2 = 0, var2 = 0;
         for (double v : m2) mean2 += v;
+        mean2 /= (double)m2.size();
+        for (double v : m2) var2 += (v - mean2) * (v - mean2);
         std::sort(m2.begin(), m2.end());
-        std::printf("two threads x operator() + ComputeStereoMatches (the unmodified Frame constructor): mean %.4f ms  p50 %.4f  p90 %.4f  (ComputeStereoMatches alone %.4f)\n",
-                    mean2 / (double)m2.size(), m2[m2.size() / 2], m2[m2.size() * 9 / 10], csm / (double)m2.size());
+        std::printf("two threads x operator() + ComputeStereoMatches (the unmodified Frame constructor): mean %.4f ms  p50 %.4f  p90 %.4f  std %.4f  p99 %.4f  (ComputeStereoMatches alone %.4f)\n",
+                    mean2, m2[m2.size() / 2], m2[m2.size() * 9 / 10], std::sqrt(var2 / (double)m2.size()),
+                    m2[std::min(m2.size() - 1, m2.size() * 99 / 100)], csm / (double)m2.size());
       }
       double mean = 0, var = 0;
       for (double v : ms) mean += v;
