@@ -86,8 +86,11 @@ int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version);
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:1015-1106) for ONE host image (CV_8UC1, `stride`
  * bytes per row).  lap0/lap1 = vLappingArea.  Writes *n_out keypoints (serial-order slots: mono from the
  * front, lapping from the back) and n_out x 32 descriptor bytes.  Returns monoIndex (>= 0), ORBX_E_EMPTY for
- * an empty image, or another negative error.  cap = capacity of kps / desc rows (nfeatures + 3*nlevels
- * always suffices).  kps / desc may be NULL: the results stay in the handle's result block (orbx_host_results). */
+ * an empty image, or another negative error.  cap = capacity of kps / desc rows: the handle's own row count
+ * (orbx_batch_results_device's *capacity = nfeatures + 36 per level) always suffices; the reference returns at most
+ * nfeatures + 3 per level for the usual quotas, but a level whose quota is below 4 x its initial quadtree roots can keep up
+ * to 4 * nIni nodes (src/ORBextractor.cc:575-601), so nfeatures + 3 * nlevels is NOT a bound for tiny nfeatures.  ORBX_E_CAPACITY
+ * when the result does not fit.  kps / desc may be NULL: the results stay in the handle's result block (orbx_host_results). */
 int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t stride, int lap0, int lap1,
                  orbx_keypoint* kps, uint8_t* desc, int cap, int* n_out);
 
@@ -96,7 +99,9 @@ int orbx_extract(orbx_extractor* ex, const uint8_t* img, int w, int h, ptrdiff_t
  * ComputeStereoMatches that follows them (:921-1084; b = baseline, maxD = bf / b).  The handle needs max_batch >= 2; the
  * left eye becomes image 0 and the right eye image 1 of the extraction (orbx_pyramid_level, orbx_stereo_match_batch with
  * left == right handle, first_left 0, first_right 1).  Outputs as orbx_extract for each eye (n_* keypoints, mono_* =
- * monoIndex); uright / depth (cap_left floats each, -1 = no match) are ignored when bf <= 0.  Any of the output ARRAYS
+ * monoIndex); uright / depth (cap_left floats each, -1 = no match) are ignored when bf <= 0.  COMPATIBILITY (since round 5): bf > 0
+ * runs the stereo association also when uright / depth are NULL -- the results then wait in the result block
+ * (orbx_host_results) --; pass bf = 0 to skip it.  Any of the output ARRAYS
  * (kps_*, desc_*, uright, depth) may be NULL: the results then stay in the handle's page-locked result block, where
  * orbx_host_results hands them out in place (one copy less per frame for a caller that converts them anyway).  Arrays that ARE
  * passed cost nothing at the end of the call: keypoints and descriptors of both eyes reach the block two launches before the frame

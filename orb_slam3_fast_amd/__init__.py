@@ -312,13 +312,13 @@ class ORBextractor:
     def extract_stereo(self, left, right, lap_left=(0, 0), lap_right=(0, 0), bf=0.0, b=0.0):
         """Both eyes of one stereo frame in one batched pipeline (orbx_extract_stereo; the handle needs max_batch >= 2).
         Returns ((monoL, kpsL, descL), (monoR, kpsR, descR)) and, when bf > 0, also (mvuRight, mvDepth) of the left eye."""
-        L, R = left, right
+        L, R = np.asarray(left), np.asarray(right)
+        if L.ndim != 2 or L.shape != R.shape:
+            raise ValueError("two gray images of the same size")
         if L.dtype != np.uint8 or L.strides[-1] != 1:
             L = np.ascontiguousarray(L, np.uint8)
         if R.dtype != np.uint8 or R.strides[-1] != 1:
             R = np.ascontiguousarray(R, np.uint8)
-        if L.shape != R.shape or L.ndim != 2:
-            raise ValueError("two gray images of the same size")
         h, w = L.shape
         hb = self._host_bufs()
         lap = hb["lap"]

@@ -114,6 +114,9 @@ class ORBextractor {
     orbx_get_tables(h_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
                     mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data());
     mvImagePyramid.resize(nlevels);
+    // rows of the handle's own result arrays: nfeatures + (4 * 8 + 4) per level -- the reference's first DistributeOctTree pass
+    // can leave up to 4 * nIni nodes on a level whose quota is smaller (src/ORBextractor.cc:575-601)
+    orbx_batch_results_device(h_, nullptr, nullptr, nullptr, nullptr, &capacity_);
   }
   ~ORBextractor() { orbx_extractor_destroy(h_); }
   ORBextractor(const ORBextractor&) = delete;
@@ -183,7 +186,7 @@ class ORBextractor {
     // The outputs are handed to the library as ITS output arrays, sized to the extractor's capacity and trimmed afterwards: the
     // library copies keypoints and descriptors into them while the stereo association still runs (include/orbx.h), so the copies
     // cost nothing at the end of the call.  (Descriptor outputs that are not plain matrices take the copy-after path below.)
-    const int cap = nfeatures + 3 * nlevels;
+    const int cap = capacity_;   // (nfeatures + 3 * nlevels is too small for tiny quotas)
     uint8_t* dl = DescBuffer(descLeft, cap);
     uint8_t* dr = dl ? DescBuffer(descRight, cap) : nullptr;
     if (dl && dr) {
@@ -358,6 +361,7 @@ class ORBextractor {
   }
   orbx_extractor* h_ = nullptr;
   int keepSet_ = -1;
+  int capacity_ = 0;
 };
 
 }  // namespace ORB_SLAM3

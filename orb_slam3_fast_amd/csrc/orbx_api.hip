@@ -603,7 +603,7 @@ int record_pipeline(orbx_extractor* ex, int n, bool lapTrivial, bool capturing, 
   static const bool noToken = getenv("ORBX_NO_DETECT_TOKEN") && atoi(getenv("ORBX_NO_DETECT_TOKEN")) != 0;   // measurement aid
   // (a graph cannot wait on it; a launch of one or two images does not fill the chip: no ordering, no event record between
   // k_detect and k_octree of a single frame)
-  DetectToken* tok = (!capturing && !noToken && n > kLatMaxImages) ? detect_token(ex->device) : nullptr;
+  DetectToken* tok = (!capturing && !noToken && n > g_lat_max_images) ? detect_token(ex->device) : nullptr;
   if (tok) {
     std::lock_guard<std::mutex> lk(tok->mu);
     if (tok->valid && tok->last != ex) HIPC(hipStreamWaitEvent(s, tok->ev, 0));
@@ -978,10 +978,18 @@ static int enqueue_host_pyramid(orbx_extractor* ex, int nimg, hipEvent_t after, 
   if (streamWait) {
     HIPC(hipStreamWaitEvent(ex->streamPyr, after, 0));
   } else {
-    hipError_t q;
-    while ((q = hipEventQuery(after)) == hipErrorNotReady) {
+    // bounded poll: ~200 us of polling with a pause between the queries -- four frames' worth of kernels --, then
+    // the blocking wait (a wedged stream must not spin a core forever; two eye threads poll at once in the reference's flow)
+    hipError_t q = hipErrorNotReady;
+    const auto tp0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1; (q = hipEventQuery(after)) == hipErrorNotReady; spin++) {
+      cpu_pause();
+      if ((spin & 63u) == 0 && std::chrono::steady_clock::now() - tp0 > std::chrono::microseconds(200)) {
+        q = hipEventSynchronize(after);
+        break;
+      }
     }
-    if (q != hipSuccess) return fail(ORBX_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    if (q != hipSuccess) return fail(ORBX_E_HIP, std::string("pyramid event: ") + hipGetErrorString(q));
   }
   for (int i = 0; i < nimg; i++)
     if (restBytes)
@@ -1106,6 +1114,10 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
     ResultPack rp{};
     if (fuse) {
       HIPC(make_result_pack(ex, 2, true, &rp));
+      // the gather workgroups count their arrivals in d_packCtr and the last one resets it: a frame that failed between launch
+      // and synchronisation may have left it non-zero -- cleared on the stream before the next fused launch
+      if (ex->packCtrDirty) HIPC(hipMemsetAsync(ex->d_packCtr.p, 0, 4 * sizeof(int), st));
+      ex->packCtrDirty = true;
       rp.packCtr = ex->d_packCtr.p;
       rp.hFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(rp.hCnt) + hr_flag());
       rp.seq = ++ex->packSeq;
@@ -1137,9 +1149,14 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
     const volatile uint32_t* flag = reinterpret_cast<const volatile uint32_t*>(H + hr_flag());
     const uint32_t want = ex->packSeq;
     bool seen = false;
-    for (unsigned spin = 1;; spin++) {
+    const auto ts0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; spin++) {   // bounded: a pause per poll, the stream's state every 1024 polls, at most ~300 us in all
       if (*flag == want) { seen = true; break; }
-      if ((spin & 1023u) == 0 && hipStreamQuery(st) != hipErrorNotReady) { seen = *flag == want; break; }
+      cpu_pause();
+      if ((spin & 1023u) == 0) {
+        if (hipStreamQuery(st) != hipErrorNotReady) { seen = *flag == want; break; }
+        if (std::chrono::steady_clock::now() - ts0 > std::chrono::microseconds(300)) break;   // (the copy-after path below takes over)
+      }
     }
     if (seen) {
       std::atomic_thread_fence(std::memory_order_acquire);
@@ -1155,6 +1172,7 @@ int orbx_extract_stereo(orbx_extractor* ex, const uint8_t* img_left, const uint8
     }
   }
   HIPC(hipStreamSynchronize(st));
+  ex->packCtrDirty = false;   // the frame completed: the arrival counter is back at zero
   const auto tq2 = std::chrono::steady_clock::now();
   if (ex->keepHostPyr) HIPC(hipStreamSynchronize(ex->streamPyr));
   if (latTimes) {

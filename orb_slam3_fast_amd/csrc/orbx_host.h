@@ -2,6 +2,12 @@
 // buffers, the per-call scratch pool and packed staging, and the extractor handle.
 #ifndef ORBX_HOST_H
 #define ORBX_HOST_H
+#if defined(__x86_64__) || defined(__i386__)
+#include <immintrin.h>
+static inline void cpu_pause() { _mm_pause(); }
+#else
+static inline void cpu_pause() {}
+#endif
 #include <memory>
 #include <new>
 #include <chrono>
@@ -253,6 +259,7 @@ struct orbx_extractor {
   DevBuf<uint4> d_xtab;  // k_resize's per-column table (build_coefs)
   DevBuf<int> d_packCtr;    // arrival counter of the single-frame gather workgroups (launch_stereo_match)
   uint32_t packSeq = 0;     // sequence number of the last single stereo frame (hostResults + hr_flag())
+  bool packCtrDirty = false; // a fused single-frame launch is (or may be, after a failure) in flight: d_packCtr is cleared before the next one
   DevBuf<uint32_t> d_yrow;  // k_resize's per-row table: clamped source row pair of every destination row (u16 halves)
   DevBuf<uint4> d_srec, d_sdesc;   // row-sorted keypoint records / descriptors of both eyes (k_stereo_sort)
   std::vector<orbx::TailPlan> tails;  // fused small-level resize segments, in level order (empty: every level through k_resize)

@@ -2189,7 +2189,8 @@ static_assert(DW_RP * 4 == BM_P && DW_ROWS == BM_ROWS, "window pitch of the load
 //   * the blur is two banded integer GEMMs on the matrix pipe (orbx_blur_mfma.h);
 //   * fastAtan2 and glibc's sincosf are written branch-free (same operations, selects instead of branches);
 //   * one wave per workgroup: a finished wave frees its slot at once.
-// NK is a launch parameter: 8 for batches (fewer, longer waves), 1 for the single-frame entries (latency: all keypoints at once).
+// NK is a launch parameter (make_desc_plan): 8 for full batches (fewer, longer waves), down to 1 for small batches and the
+// single-frame entries (latency: all keypoints at once).
 // 108 VGPRs = four waves per SIMD: with the windows prefetched the waves no longer need eight per SIMD to hide their loads
 // (alone 102 -> 95 us per 64 images; under three handles 76.4 -> 78.5 k pairs/s, profiles/r6_describe_ab.txt).
 struct DescPlan {
@@ -2528,7 +2529,9 @@ __global__ __launch_bounds__(64, 4) void k_describe(Geom g, Pyr p, DescPlan dp, 
 
 static DescPlan make_desc_plan(const Geom& g, int nimg) {
   DescPlan dp{};
-  dp.nk = nimg >= 8 ? 8 : 1;
+  // keypoints per wave: as many as keep >= ~12 k waves in the launch (64 images x 1788 slots: 8; 16 images x 1288: 1 -- at small
+  // batches the launch is its longest wave, and eight keypoints in a row made a 16-frame step's k_describe 26 -> 33 us)
+  dp.nk = (int)std::min<long long>(8, std::max<long long>(1, (long long)nimg * g.selImg / 12288));
   int tks = 0;
   for (int l = 0; l < ORBX_MAX_LEVELS; l++) {
     dp.taskOff[l] = l < g.nlevels ? tks : 0x7fffffff;

@@ -875,61 +875,57 @@ __device__ __forceinline__ double rsqrt64(double x) {
 }
 
 // Right singular vector of the smallest singular value (= JacobiSVD::matrixV().col(3), :429-431) of a row-major 4x4.
+// Round 6: shifted inverse iteration on B = A^T A in double instead of the one-sided Jacobi sweeps of rounds 1 - 5 (a serial chain
+// of ~4000 double operations per triangulating lane: half of k_fisheye_batch).  The vector is the eigenvector of B's smallest
+// eigenvalue; B + mu I (mu = 1e-14 trace: keeps the LDL^T pivots positive) is factored once, each solve multiplies the wanted
+// component by (s3^2 + mu) / (s4^2 + mu) >= 10^2 .. 10^4 for a pair that passes the parallax gate (:356), and the iteration stops
+// when the normalised vector has settled to 1e-13.  Against the Jacobi vector: the eigenvector of A^T A carries
+// eps (s1 / s3)^2 ~ 1e-11 of relative error, far inside the 2e-4 of the float-tail parity (tests/test_fisheye.py).
 __device__ void null_vector4(const float A[16], float v[4]) {
-  double U[4][4], V[4][4];
+  double B[4][4];
 #pragma unroll
   for (int i = 0; i < 4; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      U[i][j] = (double)A[4 * i + j];
-      V[i][j] = i == j ? 1.0 : 0.0;
+    for (int j = i; j < 4; j++) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) sum = __builtin_fma((double)A[4 * k + i], (double)A[4 * k + j], sum);
+      B[i][j] = sum;
     }
-  for (int sweep = 0; sweep < 60; sweep++) {
-    bool rotated = false;
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-      for (int q = p + 1; q < 4; q++) {
-        double al = 0, be = 0, ga = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          al += U[i][p] * U[i][p];
-          be += U[i][q] * U[i][q];
-          ga += U[i][p] * U[i][q];
-        }
-        if (ga == 0.0 || ga * ga <= 1e-30 * (al * be)) continue;  // |ga| <= 1e-15 sqrt(al be)
-        rotated = true;
-        const double zeta = (be - al) * (0.5 * rcp64(ga));
-        const double s1 = __builtin_fma(zeta, zeta, 1.0);
-        const double t = (zeta >= 0 ? 1.0 : -1.0) * rcp64(fabs(zeta) + s1 * rsqrt64(s1));
-        const double cs = rsqrt64(__builtin_fma(t, t, 1.0)), sn = cs * t;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const double up = U[i][p], uq = U[i][q];
-          U[i][p] = cs * up - sn * uq;
-          U[i][q] = sn * up + cs * uq;
-          const double vp = V[i][p], vq = V[i][q];
-          V[i][p] = cs * vp - sn * vq;
-          V[i][q] = sn * vp + cs * vq;
-        }
-      }
-    if (!rotated) break;
+  const double mu = 1e-14 * (B[0][0] + B[1][1] + B[2][2] + B[3][3]) + 1e-300;
+  // LDL^T of the symmetric positive definite B + mu I (upper triangle in, unit lower L and 1 / d out)
+  double L10, L20, L30, L21, L31, L32, id0, id1, id2, id3;
+  {
+    const double d0 = B[0][0] + mu;
+    id0 = rcp64(d0);
+    L10 = B[0][1] * id0; L20 = B[0][2] * id0; L30 = B[0][3] * id0;
+    const double d1 = B[1][1] + mu - L10 * B[0][1];
+    id1 = rcp64(d1);
+    const double t21 = B[1][2] - L10 * B[0][2], t31 = B[1][3] - L10 * B[0][3];
+    L21 = t21 * id1; L31 = t31 * id1;
+    const double d2 = B[2][2] + mu - L20 * B[0][2] - L21 * t21;
+    id2 = rcp64(d2);
+    const double t32 = B[2][3] - L20 * B[0][3] - L21 * t31;
+    L32 = t32 * id2;
+    const double d3 = B[3][3] + mu - L30 * B[0][3] - L31 * t31 - L32 * t32;
+    id3 = rcp64(d3);
   }
-  double n[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) n[j] = U[0][j] * U[0][j] + U[1][j] * U[1][j] + U[2][j] * U[2][j] + U[3][j] * U[3][j];
-  int best = 0;
-#pragma unroll
-  for (int j = 1; j < 4; j++)
-    if (n[j] < n[best]) best = j;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double x = V[i][0];
-    x = best == 1 ? V[i][1] : x;
-    x = best == 2 ? V[i][2] : x;
-    x = best == 3 ? V[i][3] : x;
-    v[i] = (float)x;
+  double x0 = 0.5, x1 = 0.5, x2 = 0.5, x3 = 0.5;
+  for (int it = 0; it < 30; it++) {   // (3 - 4 solves; a start vector that happens to be orthogonal to the answer needs ~10)
+    // L y = x, z = y / d, L^T w = z
+    const double y0 = x0, y1 = x1 - L10 * y0, y2 = x2 - L20 * y0 - L21 * y1, y3 = x3 - L30 * y0 - L31 * y1 - L32 * y2;
+    const double w3 = y3 * id3, w2 = y2 * id2 - L32 * w3, w1 = y1 * id1 - L21 * w2 - L31 * w3, w0 = y0 * id0 - L10 * w1 - L20 * w2 - L30 * w3;
+    const double rn = rsqrt64(w0 * w0 + w1 * w1 + w2 * w2 + w3 * w3);
+    const double n0 = w0 * rn, n1 = w1 * rn, n2 = w2 * rn, n3 = w3 * rn;
+    // (the sign is fixed by the solve itself: (B + mu I)^-1 is positive definite, consecutive iterates never flip)
+    const double dx = fabs(n0 - x0) + fabs(n1 - x1) + fabs(n2 - x2) + fabs(n3 - x3);
+    x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+    if (it > 0 && dx < 1e-13) break;
   }
+  v[0] = (float)x0;
+  v[1] = (float)x1;
+  v[2] = (float)x2;
+  v[3] = (float)x3;
 }
 
 __device__ float kb8_triangulate_matches(const KB8Cam& c1, const KB8Cam& c2, float u1, float v1, float u2, float v2,
