@@ -97,6 +97,10 @@ def parse(argv=None):
                          "of each per step (pairs = 8 x inflight), RCCL all-gather of the descriptor blocks every step "
                          "(initialises RCCL even with one rank)")
     ap.add_argument("--inflight", type=int, default=4, help="C5: frames of every stream per step")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="no GPU work: every rank builds its plan (streams, handle / ring-slot of every step), the ranks meet on a gloo "
+                         "group (barrier, max-over-ranks of a fake step time) and rank 0 prints a contract-shaped line -- the rank logic "
+                         "of an N-GPU launch up to the first HIP call, testable on a CPU box (tests/test_bench_contract.py)")
     ap.add_argument("--allgather", action="store_true",
                     help="RCCL all-gather of every rank's descriptor blocks after each step (implied by --config C5)")
     a = ap.parse_args(argv)
@@ -157,6 +161,43 @@ class _Raw:  # zero-copy view of a liborbx device buffer as a torch tensor
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def rank_streams(rank, distinct):
+    """Synthetic camera streams of a rank: stream s -> rank s div 1000 (whole streams stay on one GPU)."""
+    return [1000 * rank + i for i in range(distinct)]
+
+
+def step_plan(step_no, handles, ring):
+    """(handle, ring slot) of step i -- the SAME on every rank: with --allgather the collectives of one communicator must be
+    issued in the same order everywhere (include/orbx.h, orbx_allgather_descriptors)."""
+    return step_no % handles, step_no % ring
+
+
+def dry_run_ranks(a, rank, world, real_stdout):
+    """--dry-run-ranks: the rank logic of main() without a device."""
+    import torch
+    import torch.distributed as dist
+    from orb_slam3_fast_amd import sharding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = {"rank": rank, "streams": rank_streams(rank, a.distinct),
+            "steps": [step_plan(i, max(1, a.handles), a.ring) for i in range(a.warmup + a.steps)]}
+    plans = [None] * world
+    dist.all_gather_object(plans, plan)
+    dist.barrier()
+    elapsed = sharding.max_over_ranks(0.001 * (rank + 1), device="cpu")    # rank r "took" r + 1 ms
+    units = 2 * a.pairs if a.mode == "mono" else a.pairs
+    n_ranks = dist.get_world_size()
+    if rank == 0:
+        out = {"dry_run": True, "metric": "rank logic only (no GPU work)", "value": round(n_ranks * units * a.steps / elapsed, 2),
+               "unit": "frames/s" if a.mode == "mono" else "stereo frames/s", "n_gpus": n_ranks, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * elapsed / a.steps, 6), "scaling": "weak", "elapsed_max_s": elapsed,
+               "plans": plans}
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 class Workload:
     """Everything a timed step touches: the frame ring in HBM, the extractor handles, the step itself.
     tests/test_bench_mode_parity.py drives exactly this object and checks its results against the oracle."""
@@ -172,7 +213,7 @@ class Workload:
         # ---- synthetic streams (deterministic).  C3: D distinct streams, pair p = stream p mod D, frame = ring
         # slot.  C5: 8 streams x K consecutive frames per step: pair p = stream p // K, frame slot + p mod K.
         self.K = max(1, a.inflight) if a.config == "C5" else 1
-        streams = [1000 * rank + i for i in range(D)]
+        streams = rank_streams(rank, D)
         frames = list(range(R + self.K - 1))
         t0 = time.time()
         world = int(os.environ.get("WORLD_SIZE", "1"))  # the ranks of a node share its cores
@@ -214,8 +255,7 @@ class Workload:
 
     def step(self):
         a, orbx = self.a, self.orbx
-        h = self.step_no % len(self.exs)
-        slot = self.step_no % a.ring
+        h, slot = step_plan(self.step_no, len(self.exs), a.ring)
         ex = self.exs[h]
         self.step_no += 1
         self.last_slot[h] = slot
@@ -281,6 +321,9 @@ def main():
             raise SystemExit("bench.py: --gpus %d inside a 1-rank launch: refusing to scale one GPU's number by %d" % (a.gpus, a.gpus))
         a.gpus = world
     launched = os.environ.get("ORBX_BENCH_SELF_LAUNCHED") == "1"
+    if a.dry_run_ranks:
+        dry_run_ranks(a, rank, world, real_stdout)
+        return
 
     import numpy as np
     import torch  # first: liborbx.so then binds to the same HIP runtime as torch (SONAME libamdhip64.so.7)

@@ -114,3 +114,28 @@ def test_bench_c5_mode_prints_one_contract_line():
     # a collective inside the step: the preheat runs a FIXED number of steps (all ranks must issue the same all-gathers)
     nh = d["config"]["handles"]
     assert d["preheat_steps"] == nh * ((int(40.0 / 0.55 / nh) + 1))
+
+
+def test_two_rank_launch_rank_logic_on_gloo():
+    """bench.py's rank logic under the driver's own launch line with two ranks, up to the first HIP call --
+    world size from the environment (n_gpus = the group that ran, never the flag), whole streams per rank, the same (handle, ring
+    slot) order of steps on every rank (the all-gather ordering rule), barrier + max-over-ranks time, one line from rank 0.  gloo
+    on CPU: the only step an 8-GPU node adds is RCCL itself."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "3",
+           "--dry-run-ranks", "--handles", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-500:], r.stderr[-800:])
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["steps"] == 7 and d["scaling"] == "weak"
+    p0, p1 = d["plans"]
+    assert (p0["rank"], p1["rank"]) == (0, 1)
+    assert not set(p0["streams"]) & set(p1["streams"]) and len(p0["streams"]) == len(p1["streams"]) == 32
+    assert p0["steps"] == p1["steps"] and [h for h, _ in p0["steps"][:6]] == [0, 1, 2, 0, 1, 2]
+    assert abs(d["elapsed_max_s"] - 0.002) < 1e-12                      # the slower rank's time
+    assert abs(d["value"] - 2 * 32 * 7 / 0.002) < 1e-3                  # units of ALL ranks / max-over-ranks time
