@@ -499,7 +499,9 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
  * check); occupied_in (may be NULL = all free) / occupied / match are [n_frames][cap] with cap = orbx_batch_results_device's cap,
  * n_matches [n_frames].  Every kernel of the chain runs ONCE for all frames (blockIdx.y = frame) with a fixed number of
  * fixed-point rounds enqueued blindly; a frame that needs more (or larger candidate lists) is redone through the one-shot path:
- * results are those of n_frames separate calls.  Returns the total number of matches or a negative error. */
+ * results are those of n_frames separate calls.  map_points == NULL (round 6): the views come from the handle's last
+ * orbx_project_map_points_batch and never touch the host (points_stride and every n_map_points[f] must equal its n).
+ * Returns the total number of matches or a negative error. */
 int orbx_search_by_projection_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
                                     float max_y, const orbx_map_point_view* map_points, const int32_t* n_map_points,
                                     int points_stride, float th, int far_points, float th_far_points, float nnratio,
@@ -509,6 +511,31 @@ int orbx_search_by_projection_frame_batch(orbx_extractor* ex, int first_image, i
                                           float max_y, const orbx_projected_point* points, const int32_t* n_points,
                                           int points_stride, int check_orientation, int stereo_pair0, const uint8_t* occupied_in,
                                           uint8_t* occupied, int32_t* match, int32_t* n_matches);
+
+/* ---- device-side projection for the batched local-map matcher (round 6) -----------------------------------------------------
+ * Tracking::SearchLocalPoints (src/Tracking.cc:3303-3328) calls Frame::isInFrustum (src/Frame.cc:632-690) for every local map
+ * point, which stores mTrackProjX / Y / XR, mTrackDepth, mnTrackScaleLevel (MapPoint::PredictScale, src/MapPoint.cc:559-573),
+ * mTrackViewCos and mbTrackInView in the MapPoint; SearchByProjection then reads them back (src/ORBmatcher.cc:62-76).  Here the
+ * local map is uploaded ONCE as structure-of-arrays, every frame of the batch contributes its pose, and the projection, the frustum
+ * / distance / viewing-angle gates and the level prediction run on the device: the views never exist on the host.
+ * Pose of a pinhole frame = the members isInFrustum reads: mRcw (row-major), mtcw, mOw, the Pinhole parameters fx fy cx cy, mbf. */
+typedef struct orbx_frame_pose {
+  float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, bf;
+} orbx_frame_pose;
+/* n local map points: GetWorldPos(), GetNormal() (n x 3 each), mfMinDistance / mfMaxDistance (the 0.8 / 1.2 factors of
+ * Get{Min,Max}DistanceInvariance are applied by the library), GetDescriptor() (n x 32), flags bit 0 = isBad(), bit 1 =
+ * Observations() > 0.  Copied into the handle; stays valid until the next upload. */
+int orbx_map_upload(orbx_extractor* ex, int n, const float* world_pos, const float* normal, const float* min_distance,
+                    const float* max_distance, const uint8_t* desc, const uint8_t* flags);
+/* isInFrustum(pMP, viewing_cos_limit) of all n uploaded points for n_frames frames (bounds = mnMinX .. mnMaxY); skip (may be NULL)
+ * is [n_frames][n], != 0 = the point is not offered to this frame (already matched: mnLastFrameSeen == frame id,
+ * src/Tracking.cc:3310-3316).  The views [n_frames][n] stay on the device, attached to the handle, for
+ * orbx_search_by_projection_batch(map_points = NULL, points_stride = n, n_map_points[f] = n); views_out (may be NULL) receives
+ * a host copy.  Float arithmetic in the reference's expression order; PredictScale's logarithm is the device's logf: a level may
+ * differ from a glibc build by one where log(ratio) / logScaleFactor is within rounding of an integer. */
+int orbx_project_map_points_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose* poses, float min_x, float min_y,
+                                  float max_x, float max_y, float viewing_cos_limit, const uint8_t* skip,
+                                  orbx_map_point_view* views_out);
 
 /* Replaces the matching part of the relocalisation matcher ORBmatcher::SearchByProjection(Frame& CurrentFrame,
  * KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1808-1918; callers

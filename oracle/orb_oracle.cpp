@@ -2226,4 +2226,58 @@ int search_by_bow(const std::vector<uint32_t>& kfNodes, const std::vector<int>& 
   return nmatches;
 }
 
+
+// ---- Frame::isInFrustum + MapPoint::PredictScale (test infrastructure for orbx_project_map_points_batch) ----------------------
+MapPointView is_in_frustum(const FramePose& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
+                           float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
+                           int nlevels, double margin[2]) {
+  MapPointView v{};
+  v.proj_x = -1.f;   // src/Frame.cc:635-636
+  v.proj_y = -1.f;
+  double gate = 1e30, frac = 1e30;
+  auto near = [&](float value, float threshold) {
+    const double d = std::fabs((double)value - (double)threshold) / std::max(1.0, std::fabs((double)threshold));
+    gate = std::min(gate, d);
+  };
+  auto done = [&]() {
+    if (margin) { margin[0] = gate; margin[1] = frac; }
+    return v;
+  };
+  // Pc = mRcw * P + mtcw   (:642)
+  const float X = ((T.Rcw[0] * P[0] + T.Rcw[1] * P[1]) + T.Rcw[2] * P[2]) + T.tcw[0];
+  const float Y = ((T.Rcw[3] * P[0] + T.Rcw[4] * P[1]) + T.Rcw[5] * P[2]) + T.tcw[1];
+  const float Z = ((T.Rcw[6] * P[0] + T.Rcw[7] * P[1]) + T.Rcw[8] * P[2]) + T.tcw[2];
+  const float pcDist = std::sqrt((X * X + Y * Y) + Z * Z);   // Pc.norm()
+  const float invz = 1.0f / Z;
+  near(Z, 0.f);
+  if (Z < 0.0f) return done();   // :648
+  const float u = T.fx * X / Z + T.cx, vv = T.fy * Y / Z + T.cy;   // Pinhole::project (src/CameraModels/Pinhole.cpp:46-52)
+  near(u, minX); near(u, maxX);
+  if (u < minX || u > maxX) return done();
+  near(vv, minY); near(vv, maxY);
+  if (vv < minY || vv > maxY) return done();
+  const float maxD = 1.2f * maxDistance, minD = 0.8f * minDistance;   // Get{Max,Min}DistanceInvariance (src/MapPoint.cc:531-541)
+  const float ox = P[0] - T.Ow[0], oy = P[1] - T.Ow[1], oz = P[2] - T.Ow[2];
+  const float dist = std::sqrt((ox * ox + oy * oy) + oz * oz);
+  near(dist, minD); near(dist, maxD);
+  if (dist < minD || dist > maxD) return done();
+  const float viewCos = ((ox * Pn[0] + oy * Pn[1]) + oz * Pn[2]) / dist;
+  near(viewCos, viewingCosLimit);
+  if (viewCos < viewingCosLimit) return done();
+  const float ratio = maxDistance / dist;   // PredictScale: mfMaxDistance / currentDist
+  const float q = std::log(ratio) / logScaleFactor;
+  frac = std::fabs((double)q - std::nearbyint((double)q));
+  int nScale = (int)std::ceil(q);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= nlevels) nScale = nlevels - 1;
+  v.in_view = 1;
+  v.proj_x = u;
+  v.proj_xr = u - T.bf * invz;
+  v.track_depth = pcDist;
+  v.proj_y = vv;
+  v.predicted_level = nScale;
+  v.view_cos = viewCos;
+  return done();
+}
+
 }  // namespace orbo

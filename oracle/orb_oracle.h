@@ -199,6 +199,18 @@ struct MapPointView {
 static_assert(sizeof(MapPointView) == 60, "POD layout shared with orbx_map_point_view");
 // occupied[i] != 0  <=>  F.mvpMapPoints[i] != NULL && ->Observations() > 0 (in/out: assignments update it).
 // match[i] = index of the map point assigned to keypoint i by this call, or -1.  Returns nmatches.
+// Frame::isInFrustum (src/Frame.cc:632-690, pinhole case Nleft == -1) with MapPoint::PredictScale (src/MapPoint.cc:559-573):
+// the members SearchByProjection reads back from the MapPoint, as a MapPointView.  pose = mRcw (row-major), mtcw, mOw, the Pinhole
+// parameters, mbf.  Float arithmetic in the reference's expression order (Eigen's 3x3 product and dot / norm reductions evaluate
+// left to right; no contraction).  margin (may be NULL) receives how far the decisive quantities are from their gates, for the
+// tolerance tests of the device kernel: [0] min over the gates passed / failed of |value - threshold| / max(1, |threshold|),
+// [1] distance of log(ratio) / logScaleFactor from the nearest integer (ceil's rounding point).
+struct FramePose {
+  float Rcw[9], tcw[3], Ow[3], fx, fy, cx, cy, bf;
+};
+MapPointView is_in_frustum(const FramePose& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
+                           float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
+                           int nlevels, double margin[2]);
 int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
                              const FrameGrid& grid, const std::vector<float>& scaleFactors,
                              const std::vector<MapPointView>& mps, float th, bool bFarPoints, float thFarPoints,

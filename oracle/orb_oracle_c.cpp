@@ -523,4 +523,25 @@ int oro_search_for_triangulation_rig(const uint32_t* nodes1, int nNodes1, const 
   return n;
 }
 
+
+// Frame::isInFrustum for n points x one pose; views [n] (flags / descriptors are the caller's), margins [n][2] (may be NULL)
+void oro_is_in_frustum(const float* pose20, int n, const float* pos, const float* normal, const float* minDist, const float* maxDist,
+                       float minX, float minY, float maxX, float maxY, float viewCosLimit, float logScaleFactor, int nlevels,
+                       MapPointView* views, double* margins) {
+  FramePose T;
+  std::memcpy(&T, pose20, sizeof(T));
+  static_assert(sizeof(FramePose) == 20 * sizeof(float), "pose = 20 packed floats");
+  for (int i = 0; i < n; i++) {
+    double m[2];
+    const MapPointView v = is_in_frustum(T, pos + 3 * i, normal + 3 * i, minDist[i], maxDist[i], minX, minY, maxX, maxY, viewCosLimit,
+                                         logScaleFactor, nlevels, m);
+    const MapPointView keep = views[i];
+    views[i] = v;
+    views[i].bad = keep.bad;
+    views[i].has_observations = keep.has_observations;
+    std::memcpy(views[i].desc, keep.desc, 32);
+    if (margins) { margins[2 * i] = m[0]; margins[2 * i + 1] = m[1]; }
+  }
+}
+
 }  // extern "C"

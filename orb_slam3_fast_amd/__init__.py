@@ -134,6 +134,8 @@ def lib():
         L.orbx_search_by_projection_frame_batch.argtypes = [vp, i, i, f, f, f, f, vp, vp, i, i, i, vp, vp, vp, vp]
         L.orbx_search_by_projection_batch.argtypes = [vp, i, i, f, f, f, f, vp, vp, i, f, i, f, f, i, vp, vp, vp, vp]
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
+        L.orbx_map_upload.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
+        L.orbx_project_map_points_batch.argtypes = [vp, i, vp, f, f, f, f, f, vp, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
         L.orbx_search_for_triangulation_rig.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, i, vp,
@@ -332,6 +334,28 @@ class ORBextractor:
         v = self._result_views(hb, 2, bf > 0)
         out = ((ml.value,) + self._take(v[0], nl.value), (mr.value,) + self._take(v[1], nr.value))
         return out + ((v["ur"][:nl.value].copy(), v["dp"][:nl.value].copy()),) if bf > 0 else out
+
+    def map_upload(self, world_pos, normal, min_distance, max_distance, desc, flags):
+        """The local map as structure-of-arrays, resident on the device (orbx_map_upload): GetWorldPos / GetNormal [n][3],
+        mfMinDistance / mfMaxDistance [n], GetDescriptor [n][32], flags bit 0 isBad, bit 1 Observations() > 0."""
+        a = [np.ascontiguousarray(world_pos, np.float32), np.ascontiguousarray(normal, np.float32),
+             np.ascontiguousarray(min_distance, np.float32), np.ascontiguousarray(max_distance, np.float32),
+             np.ascontiguousarray(desc, np.uint8), np.ascontiguousarray(flags, np.uint8)]
+        n = len(a[2])
+        _check(lib().orbx_map_upload(self._h, n, *[_p(x) for x in a]))
+        self._map_n = n
+
+    def project_map_points(self, poses, bounds, viewing_cos_limit=0.5, skip=None, want_views=False):
+        """Frame::isInFrustum of every uploaded map point for every pose ([n_frames][20] floats: Rcw row-major, tcw, Ow, fx fy cx cy,
+        bf) on the device (orbx_project_map_points_batch).  Returns the views (MP_DTYPE [n_frames][n]) when want_views."""
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 20)
+        F = len(poses)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8).reshape(F, self._map_n)
+        views = np.zeros((F, self._map_n), MP_DTYPE) if want_views else None
+        _check(lib().orbx_project_map_points_batch(self._h, F, _p(poses), bounds[0], bounds[1], bounds[2], bounds[3],
+                                                   float(viewing_cos_limit), None if sk is None else _p(sk),
+                                                   None if views is None else _p(views)))
+        return views
 
     def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
         """Enqueue extraction of device-resident images (raw device pointer).  Asynchronous."""
@@ -966,6 +990,23 @@ class ORBmatcher:
         nm = np.zeros(n_frames, np.int32)
         _check(lib().orbx_search_by_projection_batch(
             ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(mp), _p(npts), mp.shape[1],
+            float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, int(stereo_pair0),
+            None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
+
+    def SearchByProjectionBatchDevice(self, ex, first_image, n_frames, bounds, occupied=None, th=1.0, bFarPoints=False,
+                                      thFarPoints=50.0, stereo_pair0=-1):
+        """SearchByProjection (local map points) on the frames of ex's last extraction batch with the views made ON THE DEVICE by
+        project_map_points (orbx_search_by_projection_batch with map_points = NULL)."""
+        n = ex._map_n
+        npts = np.full(n_frames, n, np.int32)
+        cap = ex.capacity
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, cap)
+        occ = np.zeros((n_frames, cap), np.uint8)
+        match = np.full((n_frames, cap), -1, np.int32)
+        nm = np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_batch(
+            ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], None, _p(npts), n,
             float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, int(stereo_pair0),
             None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
         return nm, match, occ

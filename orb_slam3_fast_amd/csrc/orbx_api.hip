@@ -750,6 +750,8 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
   ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
   ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free(); ex->d_yrow.free(); ex->d_packCtr.free();
+  ex->d_mapPos.free(); ex->d_mapNormal.free(); ex->d_mapMinD.free(); ex->d_mapMaxD.free(); ex->d_mapDesc.free(); ex->d_mapFlags.free();
+  ex->d_mapSkip.free(); ex->d_poses.free(); ex->d_views.free();
   ex->d_latBands.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);

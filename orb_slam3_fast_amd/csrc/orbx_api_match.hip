@@ -711,9 +711,15 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     if (n_points[f] > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 points in a frame");
     maxPts = std::max(maxPts, n_points[f]);
   }
-  if (maxPts && (mode == 0 ? !mps : !pts)) return fail(ORBX_E_BADARG, "null points");
+  const bool devViews = mode == 0 && !mps && maxPts > 0;   // views made on the device by orbx_project_map_points_batch
+  if (devViews) {
+    if (ex->viewsFrames < n_frames || ex->viewsStride != stride) return fail(ORBX_E_BADARG, "map_points == NULL needs a preceding orbx_project_map_points_batch with the same frames and points_stride == its n");
+    for (int f = 0; f < n_frames; f++)
+      if (n_points[f] != ex->viewsStride) return fail(ORBX_E_BADARG, "map_points == NULL: n_map_points[f] must equal the uploaded map's n");
+  }
+  if (maxPts && !devViews && (mode == 0 ? !mps : !pts)) return fail(ORBX_E_BADARG, "null points");
   const int nlevels = ex->prm.nlevels;
-  if (mode == 0)
+  if (mode == 0 && !devViews)
     for (int f = 0; f < n_frames; f++)
       for (int i = 0; i < n_points[f]; i++) {
         const orbx_map_point_view& m = mps[(size_t)f * stride + i];
@@ -744,8 +750,9 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
   if (!occupied_in) occ0.assign((size_t)F * cap, 0);
   // (the header only promises points[f * stride .. f * stride + n_points[f]) of every frame: the last frame's padding is not read)
   const size_t ptsRead = ((size_t)(F - 1) * std::max(stride, 1) + (size_t)std::max(n_points[F - 1], 0)) * ptBytes;
-  const size_t oPts = pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr, (size_t)F * std::max(stride, 1) * ptBytes,
-                             ptsRead);
+  const size_t oPts = devViews ? pk.add(nullptr, 16)
+                               : pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr,
+                                        (size_t)F * std::max(stride, 1) * ptBytes, ptsRead);
   const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
   const size_t oFr = pk.add(frames.data(), (size_t)F * sizeof(ProjArgs));
   const size_t oOcc = pk.add(occupied_in ? occupied_in : occ0.data(), (size_t)F * cap);
@@ -778,7 +785,7 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     a.desc = ex->d_desc.p + (size_t)img * cap * 32;
     a.uRight = stereo_pair0 >= 0 ? ex->d_uR.p + (size_t)(stereo_pair0 + f) * cap : nullptr;
     a.scale = pk.ptr<float>(oSf);
-    a.mps = mode == 0 ? pk.ptr<orbx_map_point_view>(oPts) + (size_t)f * stride : nullptr;
+    a.mps = mode == 0 ? (devViews ? ex->d_views.p : pk.ptr<orbx_map_point_view>(oPts)) + (size_t)f * stride : nullptr;
     a.pts = mode == 1 ? pk.ptr<orbx_projected_point>(oPts) + (size_t)f * stride : nullptr;
     a.nmp = n_points[f];
     a.mode = mode; a.checkOri = check_ori; a.maxDist = 100 /* TH_HIGH */; a.claimAll = 0;
@@ -833,8 +840,13 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     int32_t* mt = match + (size_t)f * cap;
     if (occupied_in) std::memcpy(occ, occupied_in + (size_t)f * cap, cap); else std::memset(occ, 0, cap);
     for (int i = 0; i < cap; i++) mt[i] = -1;
+    std::vector<orbx_map_point_view> hv;
+    if (devViews) {   // (the one-shot path takes host arrays)
+      hv.resize((size_t)stride);
+      HIPC(hipMemcpy(hv.data(), ex->d_views.p + (size_t)f * stride, (size_t)stride * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
+    }
     rc = search_by_projection_impl(ex->device, k.data(), d.data(), stereo_pair0 >= 0 ? ur.data() : nullptr, n, min_x, min_y, max_x,
-                                   max_y, ex->scale.data(), nlevels, mode == 0 ? mps + (size_t)f * stride : nullptr,
+                                   max_y, ex->scale.data(), nlevels, mode == 0 ? (devViews ? hv.data() : mps + (size_t)f * stride) : nullptr,
                                    mode == 1 ? pts + (size_t)f * stride : nullptr, n_points[f], th, far_points, th_far, nnratio,
                                    check_ori, occ, mt);
     if (rc < 0) return rc;
@@ -845,6 +857,70 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
   return total;
 }
 }  // namespace
+
+int orbx_map_upload(orbx_extractor* ex, int n, const float* world_pos, const float* normal, const float* min_distance,
+                    const float* max_distance, const uint8_t* desc, const uint8_t* flags) {
+  if (!ex || n < 0 || n > 15000 || (n && (!world_pos || !normal || !min_distance || !max_distance || !desc || !flags)))
+    return fail(ORBX_E_BADARG, "bad argument (at most 15000 points)");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  const size_t m = (size_t)std::max(n, 1);
+  HIPC(hipStreamSynchronize(ex->stream));   // (a projection of the previous map may still read the arrays)
+  hipError_t e = ex->d_mapPos.grow(3 * m);
+  if (e == hipSuccess) e = ex->d_mapNormal.grow(3 * m);
+  if (e == hipSuccess) e = ex->d_mapMinD.grow(m);
+  if (e == hipSuccess) e = ex->d_mapMaxD.grow(m);
+  if (e == hipSuccess) e = ex->d_mapDesc.grow(32 * m);
+  if (e == hipSuccess) e = ex->d_mapFlags.grow(m);
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  ex->mapN = 0;
+  ex->viewsFrames = 0;
+  if (n) {
+    HIPC(hipMemcpy(ex->d_mapPos.p, world_pos, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_mapNormal.p, normal, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_mapMinD.p, min_distance, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_mapMaxD.p, max_distance, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_mapDesc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_mapFlags.p, flags, (size_t)n, hipMemcpyHostToDevice));
+  }
+  ex->mapN = n;
+  return ORBX_OK;
+}
+
+int orbx_project_map_points_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose* poses, float min_x, float min_y,
+                                  float max_x, float max_y, float viewing_cos_limit, const uint8_t* skip,
+                                  orbx_map_point_view* views_out) {
+  if (!ex || n_frames < 0 || n_frames > 4096 || (n_frames && !poses)) return fail(ORBX_E_BADARG, "bad argument");
+  if (ex->mapN <= 0) return fail(ORBX_E_BADARG, "no map uploaded (orbx_map_upload)");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  ex->viewsFrames = 0;
+  if (n_frames == 0) return ORBX_OK;
+  const int n = ex->mapN;
+  hipError_t e = ex->d_poses.grow((size_t)n_frames);
+  if (e == hipSuccess) e = ex->d_views.grow((size_t)n_frames * n);
+  if (e == hipSuccess && skip) e = ex->d_mapSkip.grow((size_t)n_frames * n);
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  HIPC(hipMemcpyAsync(ex->d_poses.p, poses, (size_t)n_frames * sizeof(orbx_frame_pose), hipMemcpyHostToDevice, ex->stream));
+  if (skip) HIPC(hipMemcpyAsync(ex->d_mapSkip.p, skip, (size_t)n_frames * n, hipMemcpyHostToDevice, ex->stream));
+  MapProjArgs a{};
+  a.pos = ex->d_mapPos.p; a.normal = ex->d_mapNormal.p; a.minDist = ex->d_mapMinD.p; a.maxDist = ex->d_mapMaxD.p;
+  a.desc = ex->d_mapDesc.p; a.flags = ex->d_mapFlags.p; a.skip = skip ? ex->d_mapSkip.p : nullptr;
+  a.poses = ex->d_poses.p; a.views = ex->d_views.p;
+  a.n = n; a.nlevels = ex->prm.nlevels;
+  a.minX = min_x; a.minY = min_y; a.maxX = max_x; a.maxY = max_y; a.viewCosLimit = viewing_cos_limit;
+  a.logScaleFactor = logf(ex->prm.scale_factor);   // Frame::mfLogScaleFactor = log(mfScaleFactor)
+  HIPC(launch_project_map(a, n_frames, ex->stream));
+  if (views_out) {
+    HIPC(hipMemcpyAsync(views_out, ex->d_views.p, (size_t)n_frames * n * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost, ex->stream));
+    HIPC(hipStreamSynchronize(ex->stream));   // (the poses / skip flags of a pageable caller array have been read as well)
+  } else {
+    HIPC(hipStreamSynchronize(ex->stream));   // pageable host sources: the call returns when they have been consumed
+  }
+  ex->viewsFrames = n_frames;
+  ex->viewsStride = n;
+  return ORBX_OK;
+}
 
 int orbx_search_by_projection_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
                                     float max_y, const orbx_map_point_view* map_points, const int32_t* n_map_points,

@@ -1609,6 +1609,64 @@ hipError_t launch_fe_concat(const FeConcatArgs& a, int nFrames, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Frame::isInFrustum (src/Frame.cc:632-690, pinhole case Nleft == -1) + MapPoint::PredictScale (src/MapPoint.cc:559-573) for every
+// (local map point, frame of the batch): what Tracking::SearchLocalPoints computes on the host before SearchByProjection reads it
+// back from the MapPoint members (src/ORBmatcher.cc:62-76).  One thread per point and frame; float arithmetic in the reference's
+// expression order, no contraction (TU flag); the logarithm of PredictScale is the device's logf (the level can differ from a
+// glibc build where log(ratio) / logScaleFactor lies within rounding of an integer: tolerance parity, tests/test_projection_device.py).
+// Writes the orbx_map_point_view records the matcher kernels consume -- the views stay in HBM.
+__global__ __launch_bounds__(256) void k_project_map(MapProjArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  if (i >= a.n) return;
+  const orbx_frame_pose& T = a.poses[f];
+  orbx_map_point_view v;
+  v.proj_x = -1.f; v.proj_y = -1.f; v.proj_xr = 0.f; v.view_cos = 0.f; v.track_depth = 0.f; v.predicted_level = 0;
+  v.in_view = 0;
+  const uint8_t fl = a.flags[i];
+  v.bad = fl & 1; v.has_observations = (fl >> 1) & 1; v.pad_ = 0;
+  const uint4* d4 = reinterpret_cast<const uint4*>(a.desc + (size_t)i * 32);
+  const uint4 da = d4[0], db = d4[1];
+  const float Px = a.pos[3 * i], Py = a.pos[3 * i + 1], Pz = a.pos[3 * i + 2];
+  bool ok = !(a.skip && a.skip[(size_t)f * a.n + i]);
+  // Pc = mRcw * P + mtcw
+  const float X = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.Rcw[0], Px), __fmul_rn(T.Rcw[1], Py)), __fmul_rn(T.Rcw[2], Pz)), T.tcw[0]);
+  const float Y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.Rcw[3], Px), __fmul_rn(T.Rcw[4], Py)), __fmul_rn(T.Rcw[5], Pz)), T.tcw[1]);
+  const float Z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.Rcw[6], Px), __fmul_rn(T.Rcw[7], Py)), __fmul_rn(T.Rcw[8], Pz)), T.tcw[2]);
+  const float pcDist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y)), __fmul_rn(Z, Z)));
+  const float invz = __fdiv_rn(1.0f, Z);
+  ok = ok && !(Z < 0.0f);
+  const float u = __fadd_rn(__fdiv_rn(__fmul_rn(T.fx, X), Z), T.cx), vv = __fadd_rn(__fdiv_rn(__fmul_rn(T.fy, Y), Z), T.cy);
+  ok = ok && !(u < a.minX || u > a.maxX) && !(vv < a.minY || vv > a.maxY);
+  const float ox = __fsub_rn(Px, T.Ow[0]), oy = __fsub_rn(Py, T.Ow[1]), oz = __fsub_rn(Pz, T.Ow[2]);
+  const float dist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ox, ox), __fmul_rn(oy, oy)), __fmul_rn(oz, oz)));
+  const float maxD = __fmul_rn(1.2f, a.maxDist[i]), minD = __fmul_rn(0.8f, a.minDist[i]);
+  ok = ok && !(dist < minD || dist > maxD);
+  const float viewCos = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(ox, a.normal[3 * i]), __fmul_rn(oy, a.normal[3 * i + 1])),
+                                           __fmul_rn(oz, a.normal[3 * i + 2])), dist);
+  ok = ok && !(viewCos < a.viewCosLimit);
+  if (ok) {
+    const float ratio = __fdiv_rn(a.maxDist[i], dist);
+    int lvl = (int)ceilf(__fdiv_rn(logf(ratio), a.logScaleFactor));
+    lvl = lvl < 0 ? 0 : (lvl >= a.nlevels ? a.nlevels - 1 : lvl);
+    v.in_view = 1;
+    v.proj_x = u;
+    v.proj_y = vv;
+    v.proj_xr = __fsub_rn(u, __fmul_rn(T.bf, invz));
+    v.track_depth = pcDist;
+    v.view_cos = viewCos;
+    v.predicted_level = lvl;
+  }
+  uint32_t* o = reinterpret_cast<uint32_t*>(a.views + (size_t)f * a.n + i);   // 60-byte records: 15 dwords
+  o[0] = __builtin_bit_cast(uint32_t, v.proj_x); o[1] = __builtin_bit_cast(uint32_t, v.proj_y); o[2] = __builtin_bit_cast(uint32_t, v.proj_xr);
+  o[3] = __builtin_bit_cast(uint32_t, v.view_cos); o[4] = __builtin_bit_cast(uint32_t, v.track_depth); o[5] = (uint32_t)v.predicted_level;
+  o[6] = (uint32_t)v.in_view | ((uint32_t)v.bad << 8) | ((uint32_t)v.has_observations << 16);
+  o[7] = da.x; o[8] = da.y; o[9] = da.z; o[10] = da.w; o[11] = db.x; o[12] = db.y; o[13] = db.z; o[14] = db.w;
+}
+hipError_t launch_project_map(const MapProjArgs& a, int nFrames, hipStream_t s) {
+  if (a.n > 0 && nFrames > 0) hipLaunchKernelGGL(k_project_map, dim3((a.n + 255) / 256, nFrames), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
   if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, 1);
   const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;  // one int per accepted match

@@ -70,6 +70,7 @@ struct DevBuf {
     if (!count) return hipSuccess;
     return hipMalloc((void**)&p, count * sizeof(T));
   }
+  hipError_t grow(size_t count) { return count <= n ? hipSuccess : alloc(count); }   // keeps a large enough buffer
   void free() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -271,6 +272,12 @@ struct orbx_extractor {
   int stagePitch = 0;
   int stereoPairs = 0;             // high-water allocation of d_uR / d_depth / d_sad (pairs)
   int lastStereoPairs = 0;         // pairs of the stereo association run since the last extraction (0: none)
+  // device-resident local map (orbx_map_upload) and the views orbx_project_map_points_batch made of it
+  DevBuf<float> d_mapPos, d_mapNormal, d_mapMinD, d_mapMaxD;
+  DevBuf<uint8_t> d_mapDesc, d_mapFlags, d_mapSkip;
+  DevBuf<orbx_frame_pose> d_poses;
+  DevBuf<orbx_map_point_view> d_views;
+  int mapN = 0, viewsFrames = 0, viewsStride = 0;
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   int hostResImages = 0;           // images of the last single-frame host entry in that block (orbx_host_results)
   bool hostResStereo = false;      // ... and whether uRight / depth of image 0 are there

@@ -358,6 +358,16 @@ hipError_t launch_proj_cands_fill(const ProjArgs& a, hipStream_t s);            
 hipError_t launch_proj_rounds(const ProjArgs& a, int first_round, int rounds, hipStream_t s);  // fixed-point rounds
 hipError_t launch_proj_finish(const ProjArgs& a, int last_round, hipStream_t s);     // match / occupied / cull / count
 hipError_t launch_proj_resolve_serial(const ProjArgs& a, hipStream_t s);             // the one-wave walk (fallback)
+// on-device Frame::isInFrustum for (map point, frame) pairs -> orbx_map_point_view records [nFrames][n] (orbx_guided.hip)
+struct MapProjArgs {
+  const float *pos, *normal, *minDist, *maxDist;
+  const uint8_t *desc, *flags, *skip;
+  const orbx_frame_pose* poses;
+  orbx_map_point_view* views;
+  int n, nlevels;
+  float minX, minY, maxX, maxY, viewCosLimit, logScaleFactor;
+};
+hipError_t launch_project_map(const MapProjArgs& a, int nFrames, hipStream_t s);
 hipError_t launch_proj_batch(const ProjArgs* d_frames, int nFrames, int maxPts, int maxN2, int mode, int checkOri, int rounds,
                              hipStream_t s);                                        // all frames of a batch, one launch per kernel
 

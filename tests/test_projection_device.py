@@ -1,0 +1,127 @@
+"""Device-side projection for the batched local-map matcher (round 6): Frame::isInFrustum +
+MapPoint::PredictScale (src/Frame.cc:632-690, src/MapPoint.cc:559-573) evaluated on the GPU for every (map point, frame), the views
+consumed in place by the batched SearchByProjection (src/ORBmatcher.cc:41-221).
+
+Parity: the projection is float arithmetic -- tolerance parity like the KB8 tail.  Gate decisions must equal the oracle's unless the
+oracle reports the decisive quantity within 1e-5 (relative) of its threshold; coordinates / depth / viewing cosine within 1e-5
+relative (the expression order is the reference's, so they are in fact bit-equal except for the division / square-root
+implementation); the predicted level equal unless log(ratio) / logScaleFactor lies within 1e-4 of an integer.  The MATCHER is
+exact: fed with the device-made views, the oracle's SearchByProjection must return the device's matches bit for bit."""
+import numpy as np
+import pytest
+
+import orb_slam3_fast_amd as orbx
+from orb_slam3_fast_amd import synth
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _scene(rng, w, h, F, kps_per_frame, descs_per_frame, fx=420.0):
+    """Map points back-projected from the frames' own keypoints (so that the matcher finds them) plus points behind / beside the
+    cameras; poses = small motions around the identity."""
+    cx, cy, bf = w / 2.0, h / 2.0, 0.12 * fx
+    poses, Rs, ts = [], [], []
+    for f in range(F):
+        R = _rot(*(rng.normal(0, 0.01, 3)))
+        t = rng.normal(0, 0.05, 3)
+        Ow = -R.T @ t
+        poses.append(np.concatenate([R.reshape(-1), t, Ow, [fx, fx, cx, cy, bf]]).astype(np.float32))
+        Rs.append(R), ts.append(t)
+    pos, nrm, mind, maxd, desc, flags = [], [], [], [], [], []
+    for f in range(F):
+        k, d = kps_per_frame[f], descs_per_frame[f]
+        take = rng.choice(len(k), size=min(260, len(k)), replace=False)
+        for i in take:
+            z = rng.uniform(2.0, 30.0)
+            pc = np.array([(k["x"][i] + rng.normal(0, 1.5) - cx) / fx * z, (k["y"][i] + rng.normal(0, 1.5) - cy) / fx * z, z])
+            P = Rs[f].T @ (pc - ts[f])
+            pos.append(P)
+            v = P - (-Rs[f].T @ ts[f])
+            dist = np.linalg.norm(v)
+            n_ = v / dist + rng.normal(0, 0.25, 3)
+            nrm.append(n_ / np.linalg.norm(n_))
+            sc = 1.2 ** int(k["octave"][i])
+            maxd.append(dist * sc * rng.uniform(0.95, 1.05))
+            mind.append(maxd[-1] / 1.2 ** 7)
+            desc.append(d[i] ^ np.packbits(rng.random((32, 8)) < 0.03, axis=1).reshape(32))
+            flags.append((0 if rng.random() > 0.04 else 1) | (2 if rng.random() < 0.9 else 0))
+    for _ in range(300):   # clutter: behind the cameras, outside the image, far outside the distance range
+        P = rng.normal(0, 8.0, 3)
+        pos.append(P)
+        n_ = rng.normal(0, 1, 3)
+        nrm.append(n_ / np.linalg.norm(n_))
+        m = rng.uniform(0.5, 40.0)
+        maxd.append(m)
+        mind.append(m / 3.5)
+        desc.append(rng.integers(0, 256, 32, dtype=np.uint8))
+        flags.append(2)
+    return (np.stack(poses), np.array(pos, np.float32), np.array(nrm, np.float32), np.array(mind, np.float32), np.array(maxd, np.float32),
+            np.array(desc, np.uint8), np.array(flags, np.uint8))
+
+
+@pytest.mark.gpu
+def test_device_projection_and_matcher_against_the_oracle(oracle):
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h, nf, F = 640, 480, 1000, 5
+    rng = np.random.default_rng(31)
+    cur = [synth.stereo_pair(w, h, 140 + f, 1) for f in range(F)]
+    dev = DeviceBuffer.from_numpy(np.stack([c[0] for c in cur] + [c[1] for c in cur]))
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * F)
+    ex.extract_batch_device(dev.ptr.value, 2 * F, w, h, w, w * h)
+    orbx.stereo_match_async(ex, ex, 0.12 * 532.03, 0.12, first_left=0, first_right=F, n_pairs=F)
+    ex.sync()
+    frames = [ex.download(f)[1:] for f in range(F)]
+    poses, pos, nrm, mind, maxd, desc, flags = _scene(rng, w, h, F, [k for k, _ in frames], [d for _, d in frames])
+    n = len(pos)
+    bounds = (0.0, 0.0, float(w), float(h))
+    skip = (rng.random((F, n)) < 0.05).astype(np.uint8)
+    ex.map_upload(pos, nrm, mind, maxd, desc, flags)
+    views = ex.project_map_points(poses, bounds, 0.5, skip, want_views=True)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    n_view = n_gate = n_lvl = 0
+    for f in range(F):
+        ov, mg = oracle.is_in_frustum(poses[f], pos, nrm, mind, maxd, bounds, 0.5, logsf, 8, flags, desc)
+        ov["in_view"] = np.where(skip[f] != 0, 0, ov["in_view"])
+        v = views[f]
+        assert np.array_equal(v["bad"], ov["bad"]) and np.array_equal(v["has_observations"], ov["has_observations"])
+        assert np.array_equal(v["desc"], ov["desc"])
+        diff = v["in_view"] != ov["in_view"]
+        assert (mg[diff, 0] < 1e-5).all(), (f, mg[diff])          # a gate decision may only differ AT its threshold
+        n_gate += int(diff.sum())
+        both = (v["in_view"] != 0) & (ov["in_view"] != 0)
+        n_view += int(both.sum())
+        for name in ("proj_x", "proj_y", "proj_xr", "track_depth", "view_cos"):
+            a, b = v[name][both].astype(np.float64), ov[name][both].astype(np.float64)
+            assert (np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(b))).all(), name
+        ld = both & (v["predicted_level"] != ov["predicted_level"])
+        assert (mg[ld, 1] < 1e-4).all() and (np.abs(v["predicted_level"][ld] - ov["predicted_level"][ld]) <= 1).all()
+        n_lvl += int(ld.sum())
+    assert n_view > 600 and n_gate <= 3 and n_lvl <= 3, (n_view, n_gate, n_lvl)
+    # the matcher on the device-resident views == the oracle's SearchByProjection on the SAME (downloaded) views, bit for bit
+    occ_in = (rng.random((F, ex.capacity)) < 0.04).astype(np.uint8)
+    u_all, _ = orbx.ComputeStereoMatches(ex, ex, 0.12 * 532.03, 0.12, first_left=0, first_right=F, n_pairs=F)
+    sf = ex.GetScaleFactors()
+    total = 0
+    for use_ur in (True, False):
+        nm, match, occ = orbx.ORBmatcher(0.8, True).SearchByProjectionBatchDevice(ex, 0, F, bounds, occ_in, th=3.0,
+                                                                                  stereo_pair0=0 if use_ur else -1)
+        for f in range(F):
+            k, d = frames[f]
+            on, om, oo = oracle.search_by_projection(k, d, u_all[f, :len(k)] if use_ur else None, bounds, sf, views[f], 3.0, False, 50.0,
+                                                     0.8, occ_in[f, :len(k)])
+            assert nm[f] == on and np.array_equal(match[f, :len(k)], om) and np.array_equal(occ[f, :len(k)], oo), (use_ur, f)
+            total += on
+        # and equals the host-view batched entry
+        nm2, match2, occ2 = orbx.ORBmatcher(0.8, True).SearchByProjectionBatch(ex, 0, F, bounds, views, np.full(F, n, np.int32), occ_in,
+                                                                               th=3.0, stereo_pair0=0 if use_ur else -1)
+        assert np.array_equal(nm, nm2) and np.array_equal(match, match2) and np.array_equal(occ, occ2)
+    assert total > 400, total
+    # argument errors
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBmatcher(0.8, True).SearchByProjectionBatchDevice(ex, 0, F + 1, bounds)       # more frames than were projected

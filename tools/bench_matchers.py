@@ -185,6 +185,37 @@ for name, fn in (("SearchByProjection(Cur, Last), batch of %d frames" % FB,
     tb = (time.perf_counter() - t0) / reps * 1e3
     print("%-62s %12.3f   (%.3f ms per frame, %d matches in frame 0; one-shot call above: per frame)" % (name, tb, tb / FB, int(r[0][0])))
 
+# the same local-map matcher with the projection ON THE DEVICE (round 6): the map (~1500 points) is uploaded once as SoA, a call sends
+# 32 poses (80 B each), isInFrustum + PredictScale run in k_project_map, the views never exist on the host
+rngp = np.random.default_rng(5)
+nmap = len(mps)
+fxp = 420.0
+posM = np.stack([(mps["proj_x"] - w / 2) / fxp * 8.0, (mps["proj_y"] - h / 2) / fxp * 8.0, np.full(nmap, 8.0)], 1).astype(np.float32)
+nrmM = np.tile(np.array([0, 0, 1], np.float32), (nmap, 1))
+maxM = (8.0 * 1.2 ** np.clip(mps["predicted_level"], 0, 7)).astype(np.float32)
+minM = (maxM / 1.2 ** 7).astype(np.float32)
+flagsM = (mps["bad"] | (mps["has_observations"] << 1)).astype(np.uint8)
+posesB = np.stack([np.concatenate([np.eye(3).reshape(-1), [0.002 * i, 0, 0], [-0.002 * i, 0, 0], [fxp, fxp, w / 2, h / 2, 0.12 * fxp]])
+                   for i in range(FB)]).astype(np.float32)
+exb.map_upload(posM, nrmM, minM, maxM, mps["desc"], flagsM)
+def dev_step():
+    exb.project_map_points(posesB, bounds, 0.5)
+    return m.SearchByProjectionBatchDevice(exb, 0, FB, bounds, occB, 3.0, True, 60.0)
+for _ in range(3):
+    r = dev_step()
+t0 = time.perf_counter()
+for _ in range(reps):
+    exb.project_map_points(posesB, bounds, 0.5)
+tp = (time.perf_counter() - t0) / reps * 1e3
+t0 = time.perf_counter()
+for _ in range(reps):
+    r = dev_step()
+tb = (time.perf_counter() - t0) / reps * 1e3
+print("%-62s %12.3f   (%.3f ms per frame, of which isInFrustum + PredictScale of %d points x %d poses on the device %.3f ms; %d matches "
+      "in frame 0; per call %d B of poses instead of %d B of host-projected views)"
+      % ("SearchByProjection(F, MapPoints), device-side projection, %d frames" % FB, tb, tb / FB, nmap, FB, tp, int(r[0][0]), posesB.nbytes,
+         mpsB.nbytes))
+
 # batched SearchForInitialization on the frames of an extraction batch (round 5): F1 = the previous frame's keypoints from the
 # host for every pair, F2 = the batch's images (exb holds L1, R1 alternating: even images are the frame `kc` came from)
 k1B, d1B, prevB = [kp] * FB, [dp] * FB, [prev] * FB
