@@ -92,6 +92,11 @@ __device__ __forceinline__ void compass_pair(const uint32_t (&r)[7][3], orbx_h2 
 #ifndef ORBX_EVEN_FILTER
 #define ORBX_EVEN_FILTER 0
 #endif
+// TIMING-ONLY ablations (wrong results; tools/build_variant.sh): 1 no tile load, 2 no stage 1 (no survivors), 4 no stage 2 (survivors
+// dropped), 8 no NMS / emit, 16 return behind the scalar front
+#ifndef DET_ABLATE
+#define DET_ABLATE 0
+#endif
 __device__ __forceinline__ orbx_h2 even_ring_contrast2_lds(const uint8_t* a8, const uint8_t* b8, int TP) {
   orbx_h2 e[8];
 #pragma unroll
@@ -318,7 +323,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
-  bool tileDone = false;
+  if ((DET_ABLATE & 16) && dw != 4095) { if (lane == 0) *myCount = 0; return; }
+  bool tileDone = (DET_ABLATE & 1) && dw != 4095;
   if (TPC != 0 && kDetectWideLoad) {
     // Fast loader for the compile-time tile pitches: a row is TPC / P pieces of P = 16, 8 or 4 bytes (the largest power of two that
     // divides the pitch: 48 -> 3 x 16, 56 -> 7 x 8, 44 / 52 -> 11 / 13 x 4); lane = (row, piece), one UNALIGNED global load
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
         __syncthreads();
       }
 #endif
+      if ((DET_ABLATE & 4) && dw != 4095) nSurv = 0;
       for (int base = 0; base < nSurv; base += 128) {  // two survivors per lane (packed f16 contrast)
         const int rem = nSurv - base;
         const uint64_t vA = low_lanes(rem), vB = low_lanes(rem - 64);
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     const uint64_t notLastR = ~__ballot(j0 == qpr - 1);
     // ceil(dh / dq) = floor((dh - 0.5) / dq) + 1; as a quad count, so that one loop serves both schemes
     const int nRounds = kRowRounds ? ((int)(((float)dh - 0.5f) * __builtin_amdgcn_rcpf((float)dq)) + 1) * 64 : nq;
-    for (int qb = 0; qb < nRounds; qb += 64) {
+    for (int qb = 0; qb < ((DET_ABLATE & 2) && dw != 4095 ? 0 : nRounds); qb += 64) {
       uint64_t actM;
       int q0;
       if (kRowRounds) {
@@ -553,7 +560,8 @@ __global__ __launch_bounds__(64) void k_detect(Geom g, Pyr p, uint32_t* __restri
     if (pass == 0) DET_MK();
     flush_survivors();
     if (pass == 0) DET_MK();
-    const int nCorners = nList;
+    const int nCorners = ((DET_ABLATE & 8) && dw != 4095) ? 0 : nList;
+    if ((DET_ABLATE & 8) && dw != 4095) kept = 1;
     // 3x3 non-max suppression (strict '>') inside the cell + emission
     if (TAP && pass == 0) {  // test tap (orbx_debug_score_map): the cell's FAST scores at iniThFAST, 0 = no corner
       uint8_t* dm = dbgScore + (long long)img * g.pyrImg + L.off;
