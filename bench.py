@@ -702,7 +702,7 @@ def other_configs_leg(a, local_rank, torch):
     by synchronisations) but small: 8 pairs (16 images) per step, --other-steps steps after a short preheat.  `value` of
     the JSON line stays config C3."""
     res = {}
-    PROFILE_TAG = {"C2_640x480_mono": "C2", "C4_512x512_fisheye_stereo": "C4"}   # committed rocprofv3 PMC passes at the full batch
+    PROFILE_TAG = {"C2_640x480_mono": "C2", "640x480_stereo": "S640", "C4_512x512_fisheye_stereo": "C4"}   # committed rocprofv3 PMC passes at the full batch
     specs = [("C2_640x480_mono", ["--mode", "mono", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
              ("640x480_stereo", ["--mode", "stereo", "--width", "640", "--height", "480", "--nfeatures", "1000"]),
              ("C4_512x512_fisheye_stereo", ["--mode", "fisheye", "--width", "512", "--height", "512", "--nfeatures", "1500"])]
@@ -768,7 +768,7 @@ def other_configs_leg(a, local_rank, torch):
             ach = st[domk]["algorithmic_GBps"]
             traffic, tsrc = None, None
             if pairs == 32 and name in PROFILE_TAG:   # the PMC passes were collected at this batch (64 images per launch)
-                for tag in ("r5", "r4a"):
+                for tag in ("r6", "r5", "r4a"):
                     f = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, PROFILE_TAG[name]))
                     if os.path.exists(f):
                         try:

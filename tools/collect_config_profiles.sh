@@ -23,5 +23,6 @@ run_cfg() {
   echo "== $cfg"; head -12 $O/${TAG}_${cfg}_kernel_stats_1handle.csv
 }
 run_cfg C2 --mode mono --width 640 --height 480 --nfeatures 1000
+run_cfg S640 --mode stereo --width 640 --height 480 --nfeatures 1000
 run_cfg C4 --mode fisheye --width 512 --height 512 --nfeatures 1500
 run_cfg C5 --config C5

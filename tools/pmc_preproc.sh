@@ -19,4 +19,17 @@ for what in rectify clahe; do
     if [ -n "$db" ]; then python $R/tools/pmc_insts.py $db k_ >> $O/${TAG}_preproc_pmc.txt; else echo "$what group $i ($grp): no output: $(tail -1 /tmp/pp_$i.err | cut -c1-200)" >> $O/${TAG}_preproc_pmc.txt; fi
   done
 done
+python - "$O/${TAG}_preproc_pmc.txt" "$O/${TAG}_preproc_traffic.json" <<'PY'
+import json, re, sys
+# HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 tallies 128-byte read requests at 64 bytes: tools/pmc_summary.py)
+f, w = {}, {}
+for line in open(sys.argv[1]):
+    m = re.match(r"(k_\w+) (FETCH_SIZE|WRITE_SIZE)=(\d+)", line)
+    if m:
+        (f if m.group(2) == "FETCH_SIZE" else w)[m.group(1)] = int(m.group(3))
+out = {k: int((2 * f.get(k, 0) + w.get(k, 0)) * 1024) for k in set(f) | set(w)}
+out["_note"] = "HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024, separate rocprofv3 --pmc passes over tools/bench_preproc.py (64 frames per launch)"
+out["_raw_KiB"] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
+json.dump(out, open(sys.argv[2], "w"), indent=1, sort_keys=True)
+PY
 cat $O/${TAG}_preproc_pmc.txt
