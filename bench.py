@@ -758,7 +758,8 @@ def other_configs_leg(a, local_rank, torch):
             st = {}
             for kname, (ms, cnt) in prof.items():
                 if kname == "k_stereo_match" and b.mode == "fisheye":   # SURVEY 8d bf_knn2: 32 (nQ + nT) + 16 nQ per pair
-                    nb, shown = b.pairs * (32 * (nq + nt) + 16 * nq), "k_fisheye_batch"
+                    # the stage = k_fisheye_init + k_fisheye_scan (2-NN on the matrix pipe) + k_fisheye_tri (triangulation)
+                    nb, shown = b.pairs * (32 * (nq + nt) + 16 * nq), "k_fisheye_scan+tri"
                 else:
                     nb, shown = algorithmic_bytes(kname, NI, P, plevels, ncand, nsel, nmatch, b.pairs), kname
                 per_launch_group = nb * NP / cnt        # bytes of one launch (k_resize: the chain's bytes / its launches)
@@ -772,7 +773,12 @@ def other_configs_leg(a, local_rank, torch):
                     f = os.path.join(ROOT, "profiles", "%s_%s_pmc_traffic.json" % (tag, PROFILE_TAG[name]))
                     if os.path.exists(f):
                         try:
-                            traffic = json.load(open(f)).get("k_fisheye_batch" if domk == "k_fisheye_batch" else domk, {}).get("hbm_bytes_per_launch")
+                            tj = json.load(open(f))
+                            if domk == "k_fisheye_scan+tri":
+                                parts = [tj.get(k_, {}).get("hbm_bytes_per_launch") for k_ in ("k_fisheye_scan", "k_fisheye_tri")]
+                                traffic = sum(parts) if all(x is not None for x in parts) else tj.get("k_fisheye_batch", {}).get("hbm_bytes_per_launch")
+                            else:
+                                traffic = tj.get(domk, {}).get("hbm_bytes_per_launch")
                             tsrc = "profiles/" + os.path.basename(f)
                         except Exception:
                             traffic = None

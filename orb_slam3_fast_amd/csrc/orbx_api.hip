@@ -748,7 +748,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->h_lap = nullptr;
   ex->d_dbgScore.free(); ex->d_pyr.free(); ex->d_blur.free(); ex->d_stage.free(); ex->d_desc.free(); ex->d_cand.free(); ex->d_cellCand.free(); ex->d_cellCount.free(); ex->d_cellPrefix.free();
   ex->d_sel.free(); ex->d_knode.free(); ex->d_candCount.free(); ex->d_selCount.free(); ex->d_slot.free();
-  ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
+  ex->d_nOut.free(); ex->d_mono.free(); ex->d_lap.free(); ex->d_fl2r.free(); ex->d_fr2l.free(); ex->d_fcnt.free(); ex->d_fcand.free(); ex->d_bowWord.free(); ex->d_bowNode.free(); ex->d_bowStart.free();
   ex->d_bowCounts.free(); ex->d_bowWeight.free(); ex->d_bowValues.free(); ex->d_bowWords.free(); ex->d_bowNodes.free(); ex->d_bowFeats.free(); ex->d_fdepth.free(); ex->d_fp3d.free(); ex->d_xtab.free(); ex->d_tailBands.free(); ex->d_yofs.free(); ex->d_yrow.free(); ex->d_packCtr.free();
   ex->d_mapPos.free(); ex->d_mapNormal.free(); ex->d_mapMinD.free(); ex->d_mapMaxD.free(); ex->d_mapDesc.free(); ex->d_mapFlags.free();
   ex->d_mapSkip.free(); ex->d_poses.free(); ex->d_views.free();
@@ -1467,7 +1467,8 @@ int orbx_fisheye_stereo_match_batch(orbx_extractor* left, int first_left, orbx_e
     HIPC(left->d_fr2l.alloc((size_t)n_pairs * capR));
     HIPC(left->d_fdepth.alloc((size_t)n_pairs * capL));
     HIPC(left->d_fp3d.alloc((size_t)n_pairs * capL * 3));
-    HIPC(left->d_fcnt.alloc((size_t)n_pairs * 2));
+    HIPC(left->d_fcnt.alloc((size_t)n_pairs * 2 + 1));   // + the length of the accepted-pair list
+    HIPC(left->d_fcand.alloc((size_t)n_pairs * capL * 2));
     left->fisheyePairs = n_pairs;
     left->fisheyeCapR = (int)capR;
   }
@@ -1485,6 +1486,7 @@ int orbx_fisheye_stereo_match_batch(orbx_extractor* left, int first_left, orbx_e
   for (int l = 0; l < ORBX_MAX_LEVELS; l++) a.sigma2[l] = l < a.nLevels ? left->sig2[l] : 0.f;  // Frame::mvLevelSigma2
   a.leftToRight = left->d_fl2r.p; a.rightToLeft = left->d_fr2l.p; a.depth = left->d_fdepth.p; a.p3D = left->d_fp3d.p;
   a.counters = left->d_fcnt.p;
+  a.cand = reinterpret_cast<uint2*>(left->d_fcand.p); a.candCount = left->d_fcnt.p + 2 * (size_t)n_pairs;
   {
     StageTimer t(left, s, ORBX_STAGE_STEREO_MATCH);
     HIPC(launch_fisheye_batch(a, n_pairs, s));

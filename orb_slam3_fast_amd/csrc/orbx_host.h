@@ -304,7 +304,7 @@ struct orbx_extractor {
   DevBuf<double> d_bowWeight, d_bowValues;
   DevBuf<uint32_t> d_bowWords, d_bowNodes, d_bowFeats;
   int bowImages = 0;
-  DevBuf<int> d_fl2r, d_fr2l, d_fcnt;  // batched fisheye association (orbx_fisheye_stereo_match_batch)
+  DevBuf<int> d_fl2r, d_fr2l, d_fcnt, d_fcand;  // batched fisheye association (orbx_fisheye_stereo_match_batch)
   DevBuf<float> d_fdepth, d_fp3d;
   int fisheyePairs = 0, fisheyeCapR = 0;
   // per-launch HIP event log (orbx_profile_*)

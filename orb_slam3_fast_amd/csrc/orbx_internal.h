@@ -172,6 +172,8 @@ struct FisheyeBatchArgs {
   float* depth;             // [pairs][capL]  (pre-set to -1)
   float* p3D;               // [pairs][capL][3] (pre-set to 0)
   int* counters;            // [pairs][2] = nMatches, descMatches (pre-set to 0)
+  uint2* cand;              // [pairs * capL] scratch: accepted (pair, iL | iR << 16) of the scan, read by the triangulation launch
+  int* candCount;           // its length (pre-set to 0)
 };
 hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream_t s);
 

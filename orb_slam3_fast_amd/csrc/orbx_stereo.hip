@@ -1090,104 +1090,263 @@ hipError_t launch_tri_match_rig(const TriArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Batched variant on the extractors' device-resident results: thread per lapping-area left keypoint of pair
-// blockIdx.y does the 2-NN over the pair's right lapping rows (256-row LDS tiles, as k_bf_knn2), the Lowe test and the
-// triangulation in one go.
-constexpr int kFeWaves = 8;  // waves per 64-query block of k_fisheye_batch
-__global__ __launch_bounds__(64 * kFeWaves) void k_fisheye_batch(FisheyeBatchArgs a) {
-  // 64 queries per block (lane = query); wave w scans the train rows t = w (mod 8) of every 256-row LDS tile (all lanes read the
-  // same row: broadcast, 2 x ds_read_b128), the eight partial (distance, index) top-2 lists are merged lexicographically --
-  // exactly the stable first-minimum order of the serial scan -- and wave 0 triangulates.  Round 4: eight waves instead of four
-  // (the 608 blocks of a 32-pair batch left most SIMDs with two waves) and the next tile is in flight, one uint4 per thread,
-  // while the current one is scanned: k_fisheye_batch 109 -> see DESIGN.md 4.
-  __shared__ uint4 tile[2][256 * 2];
-  __shared__ uint32_t part[kFeWaves - 1][64][2];  // waves 1..7: packed (distance << 16 | index) best / second
+// Batched variant on the extractors' device-resident results: the 2-NN of every lapping-area left keypoint of pair blockIdx.y over
+// the pair's right lapping rows and the Lowe test (k_fisheye_scan), then the triangulation of the accepted pairs (k_fisheye_tri).
+// Round 6: the N x N Hamming scan runs on the matrix pipe.  With the train's bits b in {0, 1} and the query's bits mapped to
+// a" = 1 - 2 a in {+1, -1}, a".b = |b| - 2 a.b, so popcount(a ^ b) = |a| + |b| - 2 a.b = |a| + a".b: one integer dot product over
+// the 256 bits with the per-query constant as the MFMA's C input.  A workgroup expands a sub-tile of 128 train descriptors ONCE
+// into LDS in the A-operand layout of v_mfma_i32_16x16x64_i8 (16 bits -> 16 bytes by one v_mul_u32_u24 per nibble:
+// (nib * 0x204081) & 0x01010101); a wave keeps the +-1 bytes of 32 queries as B operands for the whole scan and takes a share of
+// every sub-tile's trains: a 16-train x 16-query block of distances is four MFMAs, every A tile read from LDS serves two of them,
+// and the D layout (lane = query column, registers = trains 4 g + r) leaves a lane with ONE query per block, so the top-2 update
+// is v_lshl_or (key = distance << 16 | train index) + min / max / min per distance where the v_bcnt loop of rounds 1 - 5 spent
+// 21 instructions per train (measurements: DESIGN.md 4 / HISTORY.md round 6).
+// Keys keep the stable first-minimum order of BFMatcher::knnMatch; the lanes and waves that share a query merge their lists at the
+// end (lexicographic keys: any merge order gives the serial scan's result).  The accepted (query, train) pairs go to a compact
+// list, so the double-precision triangulation runs with full waves in its own launch instead of one sparse wave per workgroup.
+#ifndef FE_ABLATE
+#define FE_ABLATE 0
+#endif
+typedef int orbx_v4i_s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ orbx_v4i_s expand16(uint32_t h) {   // bit j of h -> byte j (0 / 1) of the 16-byte operand
+  orbx_v4i_s v;
+#pragma unroll
+  for (int j = 0; j < 4; j++) v[j] = (int)(__umul24((h >> (4 * j)) & 0xFu, 0x00204081u) & 0x01010101u);
+  return v;
+}
+__device__ __forceinline__ void top2_insert(uint32_t& k0, uint32_t& k1, uint32_t key) {
+  const uint32_t lo = min(k0, key);
+  k1 = min(k1, max(k0, key));
+  k0 = lo;
+}
+constexpr int kFeSub = 128;                  // trains per expanded sub-tile: eight 16-train groups
+constexpr int kFeQ = 128;                    // queries per workgroup: four wave columns of 32
+constexpr int kFeTW = 2;                     // train shares: wave (qw, tw) takes groups tw * 8 / kFeTW .. of every sub-tile
+constexpr int kFeThreads = 64 * 4 * kFeTW;
+constexpr int kFeGW = 8 / kFeTW;             // 16-train groups per wave and sub-tile
+constexpr int kFePF = 4;                     // sub-tiles of raw descriptor dwords in flight (even: the LDS buffer is sub-tile & 1)
+__global__ __launch_bounds__(kFeThreads, 4) void k_fisheye_scan(FisheyeBatchArgs a) {
+  __shared__ uint4 exA[2][8][4][64];          // [buffer][16-train group][k step][lane]: 2 x 32 KB
+  __shared__ uint32_t fin[kFeTW][2][kFeQ];    // per train share: the queries' two best keys
   const int pr = blockIdx.y;
   const int imL = a.firstL + pr, imR = a.firstR + pr;
   const int nL = min(a.nL[imL], a.capL), nR = min(a.nR[imR], a.capR);
   const int monoL = min(max(a.monoL[imL], 0), nL), monoR = min(max(a.monoR[imR], 0), nR);
   const int nQ = nL - monoL, nT = nR - monoR;
-  if ((int)blockIdx.x * 64 >= nQ) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int q = blockIdx.x * 64 + lane;
-  const uint4* dQ = reinterpret_cast<const uint4*>(a.dL + ((long long)imL * a.capL + monoL) * 32);
-  const uint4* dT = reinterpret_cast<const uint4*>(a.dR + ((long long)imR * a.capR + monoR) * 32);
-  uint4 qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
-  if (q < nQ) {
-    qa = dQ[(long long)q * 2];
-    qb = dQ[(long long)q * 2 + 1];
-  }
-  uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;  // (distance << 16 | train index): lexicographic order, nT < 65536
-  const int nTiles = (nT + 255) >> 8;
-  const int tid = threadIdx.x;  // 512 threads = the 512 uint4 of a tile
-  uint4 nx = tid < 2 * min(256, nT) ? dT[tid] : make_uint4(0, 0, 0, 0);
-  for (int ti = 0; ti < nTiles; ti++) {
-    const int t0 = ti << 8, nt = min(256, nT - t0), buf = ti & 1;
-    tile[buf][tid] = nx;  // (the other buffer is still being read by slower waves: two barriers per tile would serialise them)
-    __syncthreads();
-    if (ti + 1 < nTiles) {
-      const int i2 = 2 * (t0 + 256) + tid;
-      nx = i2 < 2 * nT ? dT[i2] : make_uint4(0, 0, 0, 0);
+  if ((int)blockIdx.x * kFeQ >= nQ) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4;
+  const int qw = w & 3, tw = w >> 2;
+  const uint32_t* dQ = reinterpret_cast<const uint32_t*>(a.dL + ((long long)imL * a.capL + monoL) * 32);
+  const uint32_t* dT = reinterpret_cast<const uint32_t*>(a.dR + ((long long)imR * a.capR + monoR) * 32);
+  orbx_v4i_s bq[2][4], pq[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {   // this lane's two queries (shared by the four lanes n, n + 16, ..)
+    const int q = blockIdx.x * kFeQ + 32 * qw + 16 * h + n;
+    uint32_t qd[8];
+    int pc = 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      qd[d] = q < nQ ? dQ[(long long)q * 8 + d] : 0u;
+      pc += __popc(qd[d]);
     }
-    for (int t = w; t < nt; t += kFeWaves) {
-      const uint4 ta = tile[buf][2 * t], tb = tile[buf][2 * t + 1];
-      const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
-                    __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
-      const uint32_t key = ((uint32_t)d << 16) | (uint32_t)(t0 + t);
-      const uint32_t lo = min(k0, key);
-      k1 = min(k1, max(k0, key));
-      k0 = lo;
+    pq[h] = orbx_v4i_s{pc, pc, pc, pc};
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {   // bits [64 ks + 16 g, + 16) of the query: 1 -> -1 (0xFF), 0 -> +1
+      const uint32_t x = q < nQ ? dQ[(long long)q * 8 + 2 * ks + (g >> 1)] : 0u;   // (a second load, not a select of qd[]: no scratch)
+      const orbx_v4i_s m = expand16((g & 1) ? (x >> 16) : (x & 0xFFFFu));
+#pragma unroll
+      for (int j = 0; j < 4; j++) bq[h][ks][j] = (int)(((uint32_t)m[j] * 0xFEu) ^ 0x01010101u);
     }
   }
-  if (w > 0) {
-    part[w - 1][lane][0] = k0;
-    part[w - 1][lane][1] = k1;
+  uint32_t k0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, k1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // (distance << 16 | train index), nT < 65536
+  const int nSub = (nT + kFeSub - 1) / kFeSub;
+  // the workgroup expands dword e >> 7 (wave-uniform) of train e & 127 of the sub-tile, e = tid (+ kFeThreads)
+  // The raw dwords travel kFePF sub-tiles ahead in registers: a sub-tile's compute (a few hundred cycles) is far shorter than the
+  // latency of its loads (descriptors written by another XCD's k_describe come from the memory side), and one workgroup or two
+  // per CU cannot hide it by occupancy.
+  constexpr int kItems = 1024 / kFeThreads;
+  uint32_t nx[kFePF][kItems];
+  auto load_sub = [&](int sIdx, uint32_t (&x)[kItems]) {   // (branch-free: rows behind nT re-read the last train and are penalised below)
+#pragma unroll
+    for (int u = 0; u < kItems; u++) {
+      const int e = tid + u * kFeThreads, t = min(sIdx * kFeSub + (e & 127), nT - 1);
+      x[u] = dT[(long long)t * 8 + (e >> 7)];
+    }
+  };
+  auto expand_sub = [&](const uint32_t (&x)[kItems], int buf) {
+#if FE_ABLATE != 2   // (2: timing only, no expansion)
+#pragma unroll
+    for (int u = 0; u < kItems; u++) {
+      const int e = tid + u * kFeThreads, ei = e & 127, ed = e >> 7;
+      const orbx_v4i_s lo = expand16(x[u] & 0xFFFFu), hi = expand16(x[u] >> 16);
+      uint4* dst = &exA[buf][ei >> 4][ed >> 1][32 * (ed & 1) + (ei & 15)];
+      dst[0] = make_uint4((uint32_t)lo[0], (uint32_t)lo[1], (uint32_t)lo[2], (uint32_t)lo[3]);
+      dst[16] = make_uint4((uint32_t)hi[0], (uint32_t)hi[1], (uint32_t)hi[2], (uint32_t)hi[3]);
+    }
+#endif
+  };
+  if (nSub > 0) {
+#pragma unroll
+    for (int j = 0; j < kFePF; j++) load_sub(j, nx[j]);
+    expand_sub(nx[0], 0);
+    load_sub(kFePF, nx[0]);
+  }
+  // Iteration si: barrier; the groups of sub-tile si from buffer si & 1 and, in the same basic block, the expansion of sub-tile
+  // si + 1 into the other buffer (its vector work fills the MFMA chains' shadows instead of a phase of its own between two
+  // barriers); ring slot (si + 1) % kFePF is then re-loaded with sub-tile si + 1 + kFePF.  One barrier per sub-tile is enough: a
+  // wave that writes buffer b in iteration si has passed iteration si's barrier, behind every read of b (iteration si - 1).
+  for (int sb = 0; sb < nSub; sb += kFePF) {
+#pragma unroll
+    for (int j = 0; j < kFePF; j++) {
+      const int si = sb + j;
+      if (si >= nSub) break;
+      const int buf = j & 1, t0 = si * kFeSub;   // (kFePF is even)
+      uint32_t (&slot)[kItems] = nx[(j + 1) % kFePF];
+      __syncthreads();
+      // The wave's kFeGW groups of this sub-tile, branch-free so that the scheduler can overlap a group's LDS reads and its two
+      // independent MFMA chains with the previous group's top-2 updates.  A sub-tile that crosses nT (the scan's last) adds
+      // 0x4000 to the distances of the rows behind nT through the C input: such keys never beat a train's.
+      auto groups = [&](auto partial) {
+        const uint4* src = &exA[buf][kFeGW * tw][0][lane];
+        orbx_v4i_s av4[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          const uint4 av = src[ks * 64];
+          av4[0][ks] = orbx_v4i_s{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+        }
+#pragma unroll
+        for (int u = 0; u < kFeGW; u++) {
+          if (u + 1 < kFeGW) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+              const uint4 av = src[((u + 1) * 4 + ks) * 64];
+              av4[(u + 1) & 1][ks] = orbx_v4i_s{(int)av.x, (int)av.y, (int)av.z, (int)av.w};
+            }
+          }
+          const int tg = t0 + 16 * (kFeGW * tw + u);   // the group's first train
+          uint32_t tr[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) tr[r] = (uint32_t)(tg + 4 * g + r);
+          orbx_v4i_s acc[2] = {pq[0], pq[1]};
+          if constexpr (decltype(partial)::value) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int pen = (int)tr[r] < nT ? 0 : 0x4000;
+              acc[0][r] += pen;
+              acc[1][r] += pen;
+            }
+          }
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#if FE_ABLATE == 4   // timing only: no MFMA
+              acc[h][ks] ^= av4[u & 1][ks][0] ^ av4[u & 1][ks][1] ^ av4[u & 1][ks][2] ^ av4[u & 1][ks][3] ^ bq[h][ks][0];
+#else
+              acc[h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av4[u & 1][ks], bq[h][ks], acc[h], 0, 0, 0);
+#endif
+            }
+          }
+          // acc[h][r] = |a| + a" . b = the distance of query (h, n) and train tg + 4 g + r
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+#if FE_ABLATE == 3   // timing only: no top-2 epilogue
+            k0[h] ^= (uint32_t)(acc[h][0] + acc[h][1] + acc[h][2] + acc[h][3]);
+            continue;
+#endif
+#pragma unroll
+            for (int r = 0; r < 4; r++) top2_insert(k0[h], k1[h], ((uint32_t)acc[h][r] << 16) | tr[r]);
+          }
+        }
+        expand_sub(slot, buf ^ 1);              // sub-tile si + 1 (behind the scan's end: a re-read of the last rows, never used)
+        load_sub(si + 1 + kFePF, slot);
+      };
+      if (t0 + kFeSub <= nT) groups(std::false_type{});
+      else groups(std::true_type{});
+    }
+  }
+  // the four lanes (n, g) of a query merge their lists, then the train shares through LDS
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const uint32_t o0 = (uint32_t)__shfl_xor((int)k0[h], o), o1 = (uint32_t)__shfl_xor((int)k1[h], o);
+      top2_insert(k0[h], k1[h], o0);
+      top2_insert(k0[h], k1[h], o1);
+    }
+    if (lane < 16) {
+      fin[tw][0][32 * qw + 16 * h + lane] = k0[h];
+      fin[tw][1][32 * qw + 16 * h + lane] = k1[h];
+    }
   }
   __syncthreads();
-  bool desc = false, matched = false;
-  if (w == 0) {
+  if (w >= kFeQ / 64) return;
+  const int ql = 64 * w + lane, qf = blockIdx.x * kFeQ + ql;
+  uint32_t f0 = fin[0][0][ql], f1 = fin[0][1][ql];
 #pragma unroll
-    for (int o = 0; o < kFeWaves - 1; o++) {
+  for (int t = 1; t < kFeTW; t++) {
+    top2_insert(f0, f1, fin[t][0][ql]);
+    top2_insert(f0, f1, fin[t][1][ql]);
+  }
+  const int b0 = (int)(f0 >> 16), b1 = (int)(f1 >> 16);
+  const bool desc = qf < nQ && b1 < 0x4000 && (double)(float)b0 < __dmul_rn((double)(float)b1, 0.7);  // src/Frame.cc:1302
+  const uint64_t md = __ballot(desc);
+  if (md == 0) return;
+  int base = 0;
+  if (lane == 0) {
+    atomicAdd(a.counters + 2 * pr + 1, __popcll(md));
+    base = atomicAdd(a.candCount, __popcll(md));
+  }
+  base = __shfl(base, 0);
+  if (desc)
+    a.cand[base + __popcll(md & ((1ull << lane) - 1))] =
+        make_uint2((uint32_t)pr, (uint32_t)(qf + monoL) | ((uint32_t)((int)(f0 & 0xFFFF) + monoR) << 16));
+}
+
+// Triangulation of the accepted pairs (src/Frame.cc:1302-1316): one lane per entry of the compact list.
+__global__ __launch_bounds__(64) void k_fisheye_tri(FisheyeBatchArgs a) {
+  const int nc = *a.candCount;
+  for (int i0 = blockIdx.x * 64; i0 < nc; i0 += gridDim.x * 64) {
+  const int idx = i0 + threadIdx.x;
+  bool matched = false;
+  int pr = -1;
+  if (idx < nc) {
+    const uint2 c = a.cand[idx];
+    pr = (int)c.x;
+    const int iL = (int)(c.y & 0xFFFF), iR = (int)(c.y >> 16);
+    const int imL = a.firstL + pr, imR = a.firstR + pr;
+    const orbx_keypoint kp1 = a.kL[(long long)imL * a.capL + iL], kp2 = a.kR[(long long)imR * a.capR + iR];
+    KB8Cam c1, c2;
 #pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const uint32_t key = part[o][lane][e];
-        const uint32_t lo = min(k0, key);
-        k1 = min(k1, max(k0, key));
-        k0 = lo;
-      }
+    for (int i = 0; i < 8; i++) {
+      c1.p[i] = a.rig.cam1[i];
+      c2.p[i] = a.rig.cam2[i];
     }
-    const int b0 = (int)(k0 >> 16), b1 = (int)(k1 >> 16), i0 = (int)(k0 & 0xFFFF);
-    if (q < nQ && k1 != 0xFFFFFFFFu && (double)(float)b0 < __dmul_rn((double)(float)b1, 0.7)) {  // src/Frame.cc:1302
-      desc = true;
-      const int iL = q + monoL, iR = i0 + monoR;
-      const orbx_keypoint kp1 = a.kL[(long long)imL * a.capL + iL], kp2 = a.kR[(long long)imR * a.capR + iR];
-      KB8Cam c1, c2;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        c1.p[i] = a.rig.cam1[i];
-        c2.p[i] = a.rig.cam2[i];
-      }
-      c1.precision = c2.precision = a.rig.precision;
-      const float sigma1 = a.sigma2[min(max(kp1.octave, 0), a.nLevels - 1)];
-      const float sigma2 = a.sigma2[min(max(kp2.octave, 0), a.nLevels - 1)];
-      float P[3] = {0.f, 0.f, 0.f};
-      const float d = kb8_triangulate_matches(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, a.rig.R12, a.rig.t12, sigma1, sigma2, P);
-      if (d > 0.0001f) {
-        matched = true;
-        const long long o = (long long)pr * a.capL + iL;
-        a.leftToRight[o] = iR;
-        atomicMax(a.rightToLeft + (long long)pr * a.capR + iR, iL);
-        a.p3D[3 * o] = P[0];
-        a.p3D[3 * o + 1] = P[1];
-        a.p3D[3 * o + 2] = P[2];
-        a.depth[o] = d;
-      }
+    c1.precision = c2.precision = a.rig.precision;
+    const float sigma1 = a.sigma2[min(max(kp1.octave, 0), a.nLevels - 1)];
+    const float sigma2 = a.sigma2[min(max(kp2.octave, 0), a.nLevels - 1)];
+    float P[3] = {0.f, 0.f, 0.f};
+    const float d = kb8_triangulate_matches(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, a.rig.R12, a.rig.t12, sigma1, sigma2, P);
+    if (d > 0.0001f) {
+      matched = true;
+      const long long o = (long long)pr * a.capL + iL;
+      a.leftToRight[o] = iR;
+      atomicMax(a.rightToLeft + (long long)pr * a.capR + iR, iL);
+      a.p3D[3 * o] = P[0];
+      a.p3D[3 * o + 1] = P[1];
+      a.p3D[3 * o + 2] = P[2];
+      a.depth[o] = d;
     }
-    const uint64_t mm = __ballot(matched), md = __ballot(desc);
-    if (lane == 0) {
-      if (mm) atomicAdd(a.counters + 2 * pr, __popcll(mm));
-      if (md) atomicAdd(a.counters + 2 * pr + 1, __popcll(md));
-    }
+  }
+  // nMatches per pair: the list is not grouped by pair, so a wave counts the pair of its first matched lane, then the next ..
+  uint64_t mm = __ballot(matched);
+  while (mm) {
+    const int lead = __ffsll((long long)mm) - 1;
+    const int p0 = __shfl(pr, lead);
+    const uint64_t same = __ballot(matched && pr == p0);
+    if ((int)threadIdx.x == lead) atomicAdd(a.counters + 2 * p0, __popcll(same));
+    mm &= ~same;
+  }
   }
 }
 
@@ -1203,13 +1362,15 @@ __global__ __launch_bounds__(256) void k_fisheye_init(FisheyeBatchArgs a, int np
     if (i < nr) a.rightToLeft[i] = -1;
     if (i < 2 * npairs) a.counters[i] = 0;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.candCount = 0;
 }
 
 hipError_t launch_fisheye_batch(const FisheyeBatchArgs& a, int npairs, hipStream_t s) {
   const long long work = (long long)npairs * (a.capL > a.capR ? a.capL : a.capR) * 3;
   hipLaunchKernelGGL(k_fisheye_init, dim3((unsigned)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048)), dim3(256), 0, s, a,
                      npairs);
-  hipLaunchKernelGGL(k_fisheye_batch, dim3((a.capL + 63) / 64, npairs), dim3(64 * kFeWaves), 0, s, a);
+  hipLaunchKernelGGL(k_fisheye_scan, dim3((a.capL + kFeQ - 1) / kFeQ, npairs), dim3(kFeThreads), 0, s, a);
+  hipLaunchKernelGGL(k_fisheye_tri, dim3((unsigned)std::min<long long>(((long long)npairs * a.capL + 63) / 64, 512)), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 
