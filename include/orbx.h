@@ -75,12 +75,19 @@ int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, fl
  * (src/ORBextractor.cc:1074-1076) runs on 8-bit fixed-point taps that changed between releases -- {18,34,49,55,49,34,18} / 256 in
  * OpenCV 4.0 .. 4.5.0 (the README's "tested with 4.4.0", README.md:101; the taps sum to 257, results saturate at 255) and
  * {18,34,48,56,48,34,18} / 256 from 4.5.1 on (CMakeLists.txt:38-41 asks for "> 4.4"; what distributions ship).
- * opencv_version = 440 or 451 (the default); anything else is ORBX_E_BADARG.  Applies to every later extraction of the handle
- * (k_describe's per-keypoint blur and the blurred levels of orbx_pyramid_level).  OpenCV 3.x's float filter is not modelled.
- * STATUS: both settings follow this repo's restatement of OpenCV's fixed-point path with exact accumulation and ONE rounding
- * (oracle/orb_oracle.cpp gaussian_blur7), which is not pinned against any real OpenCV build (none exists in this environment).
- * For 440 in particular the model is the SCALAR ufixedpoint path: OpenCV 4.0 .. 4.5.0's SIMD vertical pass may differ from it
- * in rounding on the 257-sum taps (unverified; tools/gen_golden_opencv.py with opencv-python 4.4.0 would settle it). */
+ * opencv_version = 451 (the default), 440, 44016 or 44032; anything else is ORBX_E_BADARG.  Applies to every later extraction of
+ * the handle (k_describe's per-keypoint blur and the blurred levels of orbx_pyramid_level).  OpenCV 3.x's float filter is not
+ * modelled.
+ *   440   : the 257-sum taps through the SCALAR ufixedpoint path, every column rounded once.
+ *   44016 / 44032 : the same taps as a build whose vertical pass runs the 16-lane (SSE2 / NEON baseline) or 32-lane (AVX2
+ *           dispatch) vector body of smooth.simd.hpp: that body re-biases its 8.8 rows by -32768 and gives the bias back as the
+ *           constant 128 << 16, which is 32768 short when the taps sum to 257 -- exactly the rounding half, so columns
+ *           [0, (w / lanes) * lanes) of every level FLOOR and only the scalar tail behind them rounds (flat 100 -> 100 in the
+ *           body, 101 in the tail; oracle/orb_oracle.cpp gaussian_blur7, tests/test_tables.py).  A reference built against
+ *           OpenCV 4.4.0 on x86-64 is expected to behave as 44032.
+ * STATUS: all settings follow this repo's restatement of OpenCV's fixed-point path (oracle/orb_oracle.cpp gaussian_blur7), which
+ * is not pinned against any real OpenCV build (none exists in this environment); tools/gen_golden_opencv.py with opencv-python
+ * 4.4.0 would settle which of 440 / 44016 / 44032 a given build is -- switching is this one call. */
 int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version);
 
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:1015-1106) for ONE host image (CV_8UC1, `stride`

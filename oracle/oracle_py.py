@@ -81,7 +81,8 @@ class OracleExtractor:
             self.h = None
 
     def set_blur_taps(self, variant):
-        """GaussianBlur taps of OpenCV 4.0 .. 4.5.0 (440) or >= 4.5.1 (451, the default): orb_oracle.cpp kBlurTaps440 / 451."""
+        """GaussianBlur taps of OpenCV 4.0 .. 4.5.0 (440: scalar model; 44016 / 44032: with the flooring 16- / 32-lane vector body
+        of those releases' vertical pass) or >= 4.5.1 (451, the default): orb_oracle.cpp kBlurTaps440 / 451, gaussian_blur7."""
         lib().oro_set_blur_taps(self.h, int(variant))
 
     def tables(self):

@@ -528,9 +528,22 @@ static inline int reflect101(int p, int n) {
   return p;
 }
 // GaussianBlur 7x7 sigma=2 CV_8U fixed point: u16 horizontal, u32 vertical, one final rounding.
-void gaussian_blur7(const Image& src, Image& dst, const int taps[7]) {
+// simd_vec (0, 16 or 32; meaningful for the 257-sum taps of OpenCV 4.0 .. 4.5.0 only): the model of those releases' VECTORISED
+// vertical pass (modules/imgproc/src/smooth.simd.hpp, vlineSmoothONa_yzy_a<uint8_t, ufixedpoint16>, restated from the published
+// source -- OpenCV is not in /root/reference and not in this image: parity unpinned).  Its body handles simd_vec columns per step
+// for x in [0, (w / simd_vec) * simd_vec): the 8.8 rows are re-biased by -32768 into signed 16-bit lanes, multiplied by the taps
+// with v_dotprod, the bias is given back as the CONSTANT 128 << 16 = 32768 * 256, and v_rshr_pack<16> adds the rounding half
+// (32768) before the shift.  With taps that sum to 256 this is the exact rounded sum.  With the 257-sum taps the bias taken out is
+// 32768 * 257, so the constant leaves the result 32768 short -- exactly the rounding half: the body FLOORS, the scalar loop behind
+// it (the last w % simd_vec columns, ufixedpoint32 arithmetic) rounds.  Known answer: a flat image of 100 blurs to
+// 257 * 257 * 100 / 65536 = 100.78 -> 100 in the body, 101 in the tail.  simd_vec = 16 for the SSE2 / NEON baseline build, 32 when
+// the AVX2 dispatch of smooth.simd.hpp runs (any x86-64 host since 2013 with the default CPU_DISPATCH).
+void gaussian_blur7(const Image& src, Image& dst, const int taps[7], int simd_vec) {
   const int w = src.w, h = src.h;
   dst = Image(w, h);
+  int sumw = 0;
+  for (int k = 0; k < 7; k++) sumw += taps[k];
+  const int body_end = (simd_vec > 0 && sumw == 257) ? (w / simd_vec) * simd_vec : 0;
   std::vector<uint32_t> hp((size_t)w * h);
   for (int y = 0; y < h; y++) {
     const uint8_t* S = src.row(y);
@@ -546,7 +559,7 @@ void gaussian_blur7(const Image& src, Image& dst, const int taps[7]) {
       uint64_t acc = 0;
       for (int k = 0; k < 7; k++) acc += (uint64_t)taps[k] * hp[(size_t)reflect101(y + k - 3, h) * w + x];
       if (acc > 0xFFFFFFFFull) acc = 0xFFFFFFFFull;  // ufixedpoint32 saturates
-      uint32_t v = (uint32_t)((acc + 32768u) >> 16);
+      uint32_t v = (uint32_t)((acc + (x < body_end ? 0u : 32768u)) >> 16);
       D[x] = (uint8_t)(v > 255 ? 255 : v);
     }
   }
@@ -850,7 +863,7 @@ int Extractor::extract(const uint8_t* img, int w, int h, ptrdiff_t stride, int l
   for (int l = 0; l < nlevels; l++) {
     std::vector<KeyPoint>& lk = all[l];
     if (lk.empty()) continue;
-    gaussian_blur7(pyramid[l], blurred[l], blur_taps);
+    gaussian_blur7(pyramid[l], blurred[l], blur_taps, blur_simd_vec);
     const float scale = t.scale[l];
     for (KeyPoint& kp : lk) {
       uint8_t d[32];
@@ -900,7 +913,7 @@ int Extractor::extract_mt(const uint8_t* img, int w, int h, ptrdiff_t stride, in
   });
   per_level([&](int l) {
     if (all[l].empty()) return;
-    gaussian_blur7(pyramid[l], blurred[l], blur_taps);
+    gaussian_blur7(pyramid[l], blurred[l], blur_taps, blur_simd_vec);
     dl[l].resize(all[l].size() * 32);
     for (size_t i = 0; i < all[l].size(); i++) orb_descriptor(blurred[l], all[l][i].x, all[l][i].y, all[l][i].angle, &dl[l][i * 32]);
   });

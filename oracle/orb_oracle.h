@@ -53,7 +53,7 @@ struct FastPt { int x, y, score; };
 void fast9_16(const uint8_t* img, int stride, int cols, int rows, int threshold, bool nms,
               std::vector<FastPt>& out);                              // B3
 int fast_corner_score16(const uint8_t* ptr, const int pixel[25], int threshold);
-void gaussian_blur7(const Image& src, Image& dst, const int taps[7]);  // B4
+void gaussian_blur7(const Image& src, Image& dst, const int taps[7], int simd_vec = 0);  // B4 (simd_vec: orb_oracle.cpp)
 extern const int kBlurTaps451[7];  // OpenCV >= 4.5.1 : 18,34,48,56,48,34,18
 extern const int kBlurTaps440[7];  // OpenCV 4.0-4.5.0: 18,34,49,55,49,34,18
 
@@ -88,6 +88,7 @@ class Extractor {
   int nfeatures, nlevels, iniTh, minTh;
   double scaleFactor;  // the reference keeps it as double (include/ORBextractor.h:106)
   const int* blur_taps = kBlurTaps451;
+  int blur_simd_vec = 0;  // 16 / 32: OpenCV 4.0 .. 4.5.0's vectorised vertical pass floors its body columns (gaussian_blur7)
 };
 
 float ic_angle(const Image& im, int cx, int cy, const std::vector<int>& umax);

@@ -18,8 +18,12 @@ void* oro_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int m
   return new Extractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
 }
 void oro_destroy(void* h) { delete (Extractor*)h; }
+// variant: 451 (OpenCV >= 4.5.1), 440 (4.0 .. 4.5.0, scalar model), 44016 / 44032 (4.0 .. 4.5.0 with the 16- / 32-lane vector body)
+static const int* blur_variant_taps(int variant) { return variant == 440 || variant == 44016 || variant == 44032 ? kBlurTaps440 : kBlurTaps451; }
+static int blur_variant_vec(int variant) { return variant == 44016 ? 16 : variant == 44032 ? 32 : 0; }
 void oro_set_blur_taps(void* h, int variant) {
-  ((Extractor*)h)->blur_taps = variant == 440 ? kBlurTaps440 : kBlurTaps451;
+  ((Extractor*)h)->blur_taps = blur_variant_taps(variant);
+  ((Extractor*)h)->blur_simd_vec = blur_variant_vec(variant);
 }
 void oro_tables(void* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* nfeat,
                 int* umax) {
@@ -143,7 +147,7 @@ void oro_fast_score_map(const uint8_t* img, int stride, int cols, int rows, int 
 void oro_blur(const uint8_t* src, int w, int h, uint8_t* dst, int variant) {
   Image s(w, h), d;
   std::memcpy(s.px.data(), src, (size_t)w * h);
-  gaussian_blur7(s, d, variant == 440 ? kBlurTaps440 : kBlurTaps451);
+  gaussian_blur7(s, d, blur_variant_taps(variant), blur_variant_vec(variant));
   std::memcpy(dst, d.px.data(), (size_t)w * h);
 }
 float oro_fast_atan2(float y, float x) { return fast_atan2(y, x); }

@@ -433,7 +433,8 @@ class ORBextractor:
     # ---- mvImagePyramid (include/ORBextractor.h:86)
     def set_opencv_compat(self, opencv_version):
         """Gaussian taps of the reference build's OpenCV (include/orbx.h: orbx_set_opencv_compat): 440 = OpenCV 4.0 .. 4.5.0
-        (README.md:101 "tested with 4.4.0"), 451 = OpenCV >= 4.5.1 (the default)."""
+        (README.md:101 "tested with 4.4.0") through the scalar fixed-point path, 44016 / 44032 = the same taps with the flooring 16- /
+        32-lane vector body of those releases' vertical pass, 451 = OpenCV >= 4.5.1 (the default)."""
         _check(lib().orbx_set_opencv_compat(self._h, int(opencv_version)))
 
     def image_pyramid(self, level, image=0, blurred=False):

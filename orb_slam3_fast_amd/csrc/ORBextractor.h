@@ -232,7 +232,8 @@ class ORBextractor {
   }
 
   // Not in the reference (its OpenCV is chosen at link time): which OpenCV's GaussianBlur taps the descriptors follow --
-  // 440 = OpenCV 4.0 .. 4.5.0 (README.md:101 "tested with 4.4.0"), 451 = OpenCV >= 4.5.1 (default).  include/orbx.h.
+  // 440 = OpenCV 4.0 .. 4.5.0 (README.md:101 "tested with 4.4.0"; 44016 / 44032 = with the flooring 16- / 32-lane vector body of
+  // its vertical pass), 451 = OpenCV >= 4.5.1 (default).  include/orbx.h.
   void SetOpenCVCompat(int opencv_version) {
     if (orbx_set_opencv_compat(h_, opencv_version) != ORBX_OK)
       throw std::invalid_argument(std::string("ORBextractor::SetOpenCVCompat: ") + orbx_last_error());

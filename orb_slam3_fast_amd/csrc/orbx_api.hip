@@ -775,9 +775,10 @@ int orbx_get_tables(const orbx_extractor* ex, float* scale, float* inv_scale, fl
 
 int orbx_set_opencv_compat(orbx_extractor* ex, int opencv_version) {
   if (!ex) return fail(ORBX_E_BADARG, "null handle");
-  if (opencv_version != 440 && opencv_version != 451)
-    return fail(ORBX_E_BADARG, "opencv_version: 440 (OpenCV 4.0 .. 4.5.0) or 451 (OpenCV >= 4.5.1)");
-  const int v = opencv_version == 440 ? 1 : 0;
+  if (opencv_version != 440 && opencv_version != 451 && opencv_version != 44016 && opencv_version != 44032)
+    return fail(ORBX_E_BADARG, "opencv_version: 440 / 44016 / 44032 (OpenCV 4.0 .. 4.5.0: scalar model / 16- / 32-lane vector body) or "
+                               "451 (OpenCV >= 4.5.1)");
+  const int v = opencv_version == 440 ? 1 : opencv_version == 44016 ? 16 : opencv_version == 44032 ? 32 : 0;
   if (v == ex->cv440) return ORBX_OK;
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;

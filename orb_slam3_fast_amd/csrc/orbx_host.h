@@ -316,7 +316,7 @@ struct orbx_extractor {
   std::vector<EvRec> evLog;
   size_t lastEv = 0;
   bool lastEvValid = false;
-  int cv440 = 0;                   // orbx_set_opencv_compat: 1 = Gaussian taps of OpenCV 4.0 .. 4.5.0
+  int cv440 = 0;                   // orbx_set_opencv_compat: 1 / 16 / 32 = Gaussian taps of OpenCV 4.0 .. 4.5.0 (Geom::cv440)
   bool blurValid = false;          // d_blur holds the blurred levels of the last extraction (filled on demand)
   hipEvent_t next_event() {
     if (evCursor == evPool.size()) {

@@ -36,7 +36,8 @@ struct Geom {
   int listCap;                   // max pixels in one cell's detectable window
   int selImg;                    // selected-keypoint slots per image (sum of selCap)
   int outCap;                    // output keypoint capacity per image
-  int cv440;                     // 1: Gaussian taps of OpenCV 4.0 .. 4.5.0 (orbx_set_opencv_compat), 0: OpenCV >= 4.5.1
+  int cv440;                     // 0: Gaussian taps of OpenCV >= 4.5.1; 1: of OpenCV 4.0 .. 4.5.0 (orbx_set_opencv_compat), every column rounded;
+                                 // 16 / 32: the same taps with the flooring 16- / 32-column vector body of those releases' vertical pass
   long long pyrImg;              // bytes per image of the internal pyramid block
   long long candImg;             // dense candidate entries per image
   long long cellImg;             // per-cell slot entries per image

@@ -1954,6 +1954,9 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
   const int tx = (L.w + BL_TW - 1) / BL_TW;
   if (tile >= tx * ((L.h + BL_TH - 1) / BL_TH)) return;
   const int x0 = (tile % tx) * BL_TW, y0 = (tile / tx) * BL_TH;
+  // Geom::cv440 = 16 / 32: columns [0, w & ~(vec - 1)) are the vector body of OpenCV 4.0 .. 4.5.0's vertical pass, which FLOORS
+  // on the 257-sum taps (oracle/orb_oracle.cpp gaussian_blur7); the scalar tail behind it rounds
+  const int bodyEnd = T440 && g.cv440 > 1 ? (L.w & ~(g.cv440 - 1)) : 0;
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   constexpr int IW = BL_TW / 4 + 2;  // in-tile dwords per row
@@ -2022,17 +2025,18 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, Pyr p, int level0, int lev
       // constant rides in as the first accumulator, so an output is 4 v_dot2_u32_u16
       const uint32_t w01 = 18u | (34u << 16), w23 = kT2 | (kT3 << 16), w45 = kT2 | (34u << 16), w6 = 18u;  // even r
       const uint32_t v0 = 18u << 16, v12 = 34u | (kT2 << 16), v34 = kT3 | (kT2 << 16), v56 = 34u | (18u << 16);  // odd r
+      const uint32_t rnd = T440 && x0 + 4 * bc + cI < bodyEnd ? 0u : 32768u;
 #pragma unroll
       for (int rr = 0; rr < 4; rr++) {
         const int k0 = rr >> 1;
         uint32_t acc;
         if ((rr & 1) == 0) {  // rows r = 4br + rr (even): pairs k0 .. k0+2, then the low half of pair k0+3
-          acc = udot2_u16(pr[k0], w01, 32768u);
+          acc = udot2_u16(pr[k0], w01, rnd);
           acc = udot2_u16(pr[k0 + 1], w23, acc);
           acc = udot2_u16(pr[k0 + 2], w45, acc);
           acc = udot2_u16(pr[k0 + 3], w6, acc);
         } else {              // odd r: high half of pair k0, then pairs k0+1 .. k0+3
-          acc = udot2_u16(pr[k0], v0, 32768u);
+          acc = udot2_u16(pr[k0], v0, rnd);
           acc = udot2_u16(pr[k0 + 1], v12, acc);
           acc = udot2_u16(pr[k0 + 2], v34, acc);
           acc = udot2_u16(pr[k0 + 3], v56, acc);
@@ -2318,6 +2322,7 @@ __global__ __launch_bounds__(64, 4) void k_describe(Geom g, Pyr p, DescPlan dp, 
   int pitch;
   const uint8_t* im = level_ptr(g, p, img, l, pitch);
   const int rowValid = l ? L.pitch : L.w;   // bytes of an image row that may be read (level 0 is the caller's buffer)
+  const int bodyEnd = T440 && g.cv440 > 1 ? (L.w & ~(g.cv440 - 1)) : 0;   // (k_blur: the columns OpenCV 4.0 .. 4.5.0's vector body floors)
   // constant operands, resident across the wave's keypoints
   const BlurMfmaTab& tab = T440 ? c_blur_tab_440 : c_blur_tab_451;
   orbx_v4i bh[3], av[3];
@@ -2457,9 +2462,13 @@ __global__ __launch_bounds__(64, 4) void k_describe(Geom g, Pyr p, DescPlan dp, 
     // ---- blur (orbx_blur_mfma.h; see k_describe)
     constexpr int kBias = BlurMfmaConst<T440>::bias, kKc = BlurMfmaConst<T440>::kc;
     const orbx_v4i cz = {0, 0, 0, 0}, cb = {kBias, kBias, kBias, kBias};
+    const int sBody = T440 ? bodyEnd - (Xk - 18 - misk) - 4 * lg : 0;   // patch columns 16 ct + r < sBody of this lane: floor
 #pragma unroll
     for (int ct = 0; ct < 3; ct++) {
       orbx_v4i lo = cz, hi = cz;
+      uint32_t kcv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) kcv[r] = T440 ? (uint32_t)kKc - (16 * ct + r < sBody ? 32768u : 0u) : (uint32_t)kKc;
 #pragma unroll
       for (int rt = 0; rt < 3; rt++) {
         const orbx_v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(ah[rt], bh[ct], T440 ? cb : cz, 0, 0, 0);
@@ -2473,7 +2482,7 @@ __global__ __launch_bounds__(64, 4) void k_describe(Geom g, Pyr p, DescPlan dp, 
         const orbx_v4i HI = __builtin_amdgcn_mfma_i32_16x16x64_i8(hi, av[mt], cz, 0, 0, 0);
         orbx_v4i cin;
 #pragma unroll
-        for (int r = 0; r < 4; r++) cin[r] = (int)(((uint32_t)HI[r] << 8) + (uint32_t)kKc);
+        for (int r = 0; r < 4; r++) cin[r] = (int)(((uint32_t)HI[r] << 8) + kcv[r]);
         const orbx_v4i V = __builtin_amdgcn_mfma_i32_16x16x64_i8(lo, av[mt], cin, 0, 0, 0);
         uint32_t v[4];
 #pragma unroll

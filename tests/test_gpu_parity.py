@@ -107,14 +107,16 @@ def test_opencv_compat_selects_the_gaussian_taps(gpu, oracle, w, h, nf, stream):
     """VERDICT (round 3): the reference README names OpenCV 4.4.0 (README.md:101), whose GaussianBlur taps {18,34,49,55,49,34,18}
     differ from the >= 4.5.1 set {18,34,48,56,48,34,18} the product used to hard-code.  orbx_set_opencv_compat(440 | 451) selects
     them in k_describe and k_blur; both are compared with the oracle's oro_set_blur_taps on the C2 / C3 sizes, and a saturated
-    patch exercises the 257-sum clamp (255, not 257 & 255)."""
+    patch exercises the 257-sum clamp (255, not 257 & 255).  Round 6: 44016 / 44032 = the 4.0 .. 4.5.0 taps with the flooring 16- /
+    32-lane vector body of those releases' vertical pass (columns below (w / lanes) * lanes of EVERY level floor, the scalar tail
+    rounds): a third arithmetic in both kernels, compared the same way."""
     img = synth.mono_frame(w, h, stream)
     img[h // 2 - 40:h // 2 + 40, w // 2 - 60:w // 2 + 60] = np.where(
         np.random.default_rng(stream).random((80, 120)) < 0.5, 255, 250).astype(np.uint8)   # blurred values reach 255 / 256+
     ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
     oe = oracle.OracleExtractor(nf, 1.2, 8, 20, 7)
     res = {}
-    for variant in (451, 440, 451):
+    for variant in (451, 440, 44016, 44032, 451):
         ex.set_opencv_compat(variant)
         oe.set_blur_taps(variant)
         mono, k, d = ex(img, (0, 0))
@@ -126,6 +128,7 @@ def test_opencv_compat_selects_the_gaussian_taps(gpu, oracle, w, h, nf, stream):
         res.setdefault(variant, d.copy())
         assert np.array_equal(res[variant], d)
     assert not np.array_equal(res[440], res[451])            # the two OpenCV generations do give different descriptors
+    assert not np.array_equal(res[440], res[44032]) and not np.array_equal(res[44016], res[44032])   # and so do the vector bodies
     assert (oracle.blur(oe.level(0), 440) == 255).any()
     with pytest.raises(orbx.OrbxError):
         ex.set_opencv_compat(320)

@@ -8,7 +8,10 @@ OpenCV fixture -- parity stays "partial" -- but each holds a piece of the restat
   maximum over a score map that tests/test_pin_skimage.py pins to scikit-image;
 * (second half of round 5) the OUTPUTS of cv::resize (src/ORBextractor.cc:1122), GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101
   (:1074-1076, both tap generations) and cv::remap INTER_LINEAR (src/System.cc:294) against real-valued models in double precision
-  (numpy, scipy.ndimage.correlate1d / map_coordinates): within the fixed-point quantisation and unbiased.
+  (numpy, scipy.ndimage.correlate1d / map_coordinates): within the fixed-point quantisation and unbiased;
+* (round 6) the vector body of OpenCV 4.0 .. 4.5.0's vertical Gaussian pass on the 257-sum taps (a third blur mode: floor in the
+  body, round in the scalar tail), cv::remap's 1/32 bilinear table and cv::cvtColor's fixed-point gray weights against
+  exact-rational models.
 """
 import ctypes as C
 from fractions import Fraction
@@ -197,3 +200,122 @@ def test_remap_within_quantisation_of_real_bilinear(oracle):
     assert smooth.sum() > 8000
     assert np.abs(d).max() < 1.0, np.abs(d).max()
     assert abs(d.mean()) < 0.2
+
+
+# ----------------------------------------------------------------------------------------------------------------- round 6
+def _vline_simd_body(hp, taps):
+    """The arithmetic of smooth.simd.hpp's vlineSmoothONa_yzy_a<uint8_t, ufixedpoint16> body as published (OpenCV 4.0 .. 4.5.0),
+    lane by lane in numpy: 8.8 rows re-biased into int16 (v_add_wrap with 0x8000), int32 dot products with the int16 taps
+    (v_dotprod), + the constant 128 << 16, v_rshr_pack<16> (add 1 << 15, arithmetic shift, saturate to int16), then the
+    unsigned 16 -> 8 pack (saturate to 0 .. 255).  hp: [7][n] uint16 rows, taps: 7 ints."""
+    s16 = (hp.astype(np.int64) - 32768)                         # the wrapped add as a signed value
+    assert (s16 >= -32768).all() and (s16 <= 32767).all()
+    acc = (s16 * np.asarray(taps, np.int64)[:, None]).sum(0) + (128 << 16)
+    assert (np.abs(acc) < 2 ** 31).all()                        # int32 lanes do not overflow
+    r = np.clip((acc + (1 << 15)) >> 16, -32768, 32767)         # v_rshr_pack<16>: int32 -> int16 with rounding and saturation
+    return np.clip(r, 0, 255).astype(np.uint8)                  # v_pack_u: int16 -> uint8 with saturation
+
+
+def test_gaussian_blur_440_vector_body_floors_and_scalar_tail_rounds(oracle):
+    """VERDICT (round 5, item 7): OpenCV 4.0 .. 4.5.0's vectorised vertical pass gives the -32768 bias of its int16 rows back as
+    the constant 128 << 16 = 32768 * 256; the 4.0 .. 4.5.0 taps sum to 257, so the result is 32768 short -- the rounding half.
+    The oracle models this as variants 44016 / 44032 (body = the first (w / lanes) * lanes columns, orb_oracle.cpp
+    gaussian_blur7).  Pinned here: the known answer flat 100 -> 100 in the body and 101 in the tail; the body columns equal the
+    lane-level emulation of the published vector arithmetic (_vline_simd_body), the tail columns the rounded scalar sum; an image
+    narrower than the vector is all tail; the >= 4.5.1 taps (sum 256) give the same bytes through the body arithmetic as through
+    the rounded sum, i.e. the mode exists only for the 257-sum taps."""
+    t440, t451 = np.array([18, 34, 49, 55, 49, 34, 18]), np.array([18, 34, 48, 56, 48, 34, 18])
+    flat = np.full((12, 75), 100, np.uint8)
+    for variant, lanes in ((44016, 16), (44032, 32)):
+        out = oracle.blur(flat, variant)
+        body = (75 // lanes) * lanes
+        assert (out[:, :body] == 100).all() and (out[:, body:] == 101).all(), variant
+    assert (oracle.blur(flat, 440) == 101).all() and (oracle.blur(flat, 451) == 100).all()
+    assert (oracle.blur(flat[:, :20], 44032) == 101).all()       # w < lanes: the vector loop never runs
+    assert (oracle.blur(flat[:, :20], 44016)[:, :16] == 100).all()
+    rng = np.random.default_rng(606)
+    img = rng.integers(0, 256, (40, 117), dtype=np.uint8)
+    img[5:20, 30:80] = np.where(rng.random((15, 50)) < 0.5, 255, 252)          # saturation: sums reach 256.9
+    h, w = img.shape
+
+    def rows_h(taps):   # the horizontal pass in exact integers with BORDER_REFLECT_101 and the ufixedpoint16 saturation
+        xi = np.abs(np.arange(-3, w + 3))
+        xi = np.where(xi >= w, 2 * w - 2 - xi, xi)
+        pad = img[:, xi].astype(np.int64)
+        hp = sum(int(taps[k]) * pad[:, k:k + w] for k in range(7))
+        return np.minimum(hp, 65535)
+
+    for taps, variants in ((t440, (44016, 44032)), (t451, ())):
+        hp = rows_h(taps)
+        yi = np.abs(np.arange(-3, h + 3))
+        yi = np.where(yi >= h, 2 * h - 2 - yi, yi)
+        hpp = hp[yi]
+        simd = np.stack([_vline_simd_body(hpp[y:y + 7], taps) for y in range(h)])
+        exact = sum(int(taps[k]) * hpp[k:k + h] for k in range(7))
+        rounded = np.minimum((exact + 32768) >> 16, 255).astype(np.uint8)
+        floored = np.minimum(exact >> 16, 255).astype(np.uint8)
+        if taps is t451:
+            assert np.array_equal(simd, rounded)                 # sum 256: the bias constant is exact, body == scalar
+            assert np.array_equal(oracle.blur(img, 451), rounded)
+            continue
+        assert np.array_equal(simd, floored)                     # sum 257: the body floors
+        assert (floored != rounded).mean() > 0.3                 # (and that is not a rare event: about half of the pixels)
+        assert np.array_equal(oracle.blur(img, 440), rounded)
+        for variant in variants:
+            lanes = variant - 44000
+            body = (w // lanes) * lanes
+            out = oracle.blur(img, variant)
+            assert np.array_equal(out[:, :body], simd[:, :body]) and np.array_equal(out[:, body:], rounded[:, body:]), variant
+
+
+def test_remap_table_against_exact_rational_bilinear(oracle):
+    """cv::remap INTER_LINEAR on CV_8U (src/System.cc:294): coordinates are quantised to 1/32 (cvRound(x * 32), INTER_BITS = 5),
+    the four weights of a cell come from a 32 x 32 table of int16 values scaled by 2^15 whose entries are exact --
+    (32 - fx)(32 - fy) * 32 etc. -- and the result is (sum + 2^14) >> 15.  With exact weights the output must equal the
+    exact-rational bilinear value at the QUANTISED position rounded half up, for every one of the 1024 fractional cells and for
+    every pixel configuration -- computed here with fractions.Fraction, no floating point and no oracle code."""
+    rng = np.random.default_rng(607)
+    src = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    fy, fx = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
+    for (iy, ix) in ((0, 0), (3, 5), (7, 9)):
+        mx = (ix + fx / 32.0).astype(np.float32)
+        my = (iy + fy / 32.0).astype(np.float32)
+        out = oracle.remap(src, mx, my)
+        for a in range(32):
+            for b in range(32):
+                p00, p01, p10, p11 = (int(src[iy, ix]), int(src[iy, ix + 1]), int(src[iy + 1, ix]), int(src[iy + 1, ix + 1]))
+                u, v = Fraction(b, 32), Fraction(a, 32)
+                exact = (1 - v) * ((1 - u) * p00 + u * p01) + v * ((1 - u) * p10 + u * p11)
+                want = (exact + Fraction(1, 2)).__floor__()
+                assert int(out[a, b]) == want, (iy, ix, a, b)
+    # the quantisation rule itself: cvRound is round-half-to-even on x * 32 evaluated in float
+    xs = np.array([2.0 + k / 64.0 for k in range(64)], np.float32)            # every half step between two table entries
+    out = oracle.remap(src, xs[None, :], np.full((1, 64), 4.0, np.float32))
+    for k in range(64):
+        q = int(np.rint(np.float32(xs[k]) * np.float32(32.0)))                # rint = half to even
+        ixq, fq = q >> 5, q & 31
+        exact = (1 - Fraction(fq, 32)) * int(src[4, ixq]) + Fraction(fq, 32) * int(src[4, ixq + 1])
+        assert int(out[0, k]) == (exact + Fraction(1, 2)).__floor__(), k
+
+
+def test_gray_weights_against_exact_rational_coefficients(oracle):
+    """cv::cvtColor(.., COLOR_RGB2GRAY / BGR2GRAY) on CV_8U (src/Tracking.cc:1394-1412): Y = 0.299 R + 0.587 G + 0.114 B in fixed
+    point.  OpenCV >= 3.4.2 / 4.x: 15 fractional bits, R and G weights rounded to nearest, B = 2^15 - R - G so that the weights
+    sum to exactly one (9798, 19235, 3735); older releases: 14 bits, all three rounded (4899, 9617, 1868 -- they happen to sum to
+    2^14).  Pinned: the constants against the exact rationals; white stays white; and on random pixels the output is within
+    1/2 + (the weights' quantisation error) of the exact-rational luma -- in integers, no floating point."""
+    cR, cG, cB = Fraction(299, 1000), Fraction(587, 1000), Fraction(114, 1000)
+    for bits, (wr, wg, wb) in ((15, (9798, 19235, 3735)), (14, (4899, 9617, 1868))):
+        one = 1 << bits
+        assert wr == round(cR * one) and wg == round(cG * one) and wr + wg + wb == one
+        assert abs(Fraction(wb, one) - cB) < Fraction(1, one)
+        rng = np.random.default_rng(608 + bits)
+        px = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+        px[0, :4] = [[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 0, 255]]
+        got = oracle.cvt_gray(px, True, bits).astype(np.int64)
+        r, g, b = (px[..., i].astype(np.int64) for i in range(3))
+        assert np.array_equal(got, (r * wr + g * wg + b * wb + one // 2) >> bits)      # the fixed-point formula itself
+        exact1000 = 299 * r + 587 * g + 114 * b                                         # 1000 x the exact-rational luma
+        slack = 500 + int(1000 * 255 * (abs(Fraction(wr, one) - cR) + abs(Fraction(wg, one) - cG) + abs(Fraction(wb, one) - cB))) + 1
+        assert (np.abs(1000 * got - exact1000) <= slack).all()
+        assert got[0, 0] == 255 and got[0, 1] == 0
