@@ -904,9 +904,9 @@ def preproc_leg(orbx, np):
     t = timed(lambda: pp.run_device(frames.ptr.value, B, w, w * h))
     nb = B * 2 * w * h + 2 * 8 * w * h
     out["rectify_1280x720"] = {"value": round(B / t, 1), "unit": "frames/s", "us_per_batch": round(t * 1e6, 2), "batch": B,
-                               "roofline": {"kernel": "k_remap1", "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "roofline": {"kernel": "k_remap_lds", "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
-                                            "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_remap1")}}
+                                            "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_remap_lds", traf.get("k_remap1"))}}
     w2 = h2 = 512
     f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
     pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)

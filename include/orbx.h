@@ -766,6 +766,10 @@ void orbx_debug_set_stereo_direct(int max_pairs);
  * workgroup per interpolation cell with the cell's table in LDS where the geometry allows it, 0 = the per-pixel table gathers
  * everywhere. */
 void orbx_debug_set_clahe_cell_kernel(int on);
+/* Test hook of the pre-processing plans' two cv::remap forms (src/System.cc:294-295): 1 (default) = the source footprint of
+ * every 128 x 8 output tile staged through LDS (k_remap_lds) where the plan's maps allow it, 0 = the per-thread window
+ * gathers (k_remap1) everywhere. */
+void orbx_debug_set_remap_lds(int on);
 /* Test hook of the pyramid's fused small-level launches (k_resize_tail: up to three consecutive levels of
  * ComputePyramid, src/ORBextractor.cc:1108-1145, per launch).  first_level: -1 = the library's policy, 0 = no fusion (every
  * level through k_resize), >= 2 = fuse from that level on; max_levels / band_rows: levels per launch and rows of the last

@@ -170,6 +170,8 @@ def lib():
         L.orbx_debug_set_stereo_direct.restype = None
         L.orbx_debug_set_clahe_cell_kernel.argtypes = [i]
         L.orbx_debug_set_clahe_cell_kernel.restype = None
+        L.orbx_debug_set_remap_lds.argtypes = [i]
+        L.orbx_debug_set_remap_lds.restype = None
         L.orbx_debug_set_resize_tail.argtypes = [i, i, i]
         L.orbx_debug_set_resize_tail.restype = None
         L.orbx_debug_resize_plan.argtypes = [vp, vp, vp, vp, i]

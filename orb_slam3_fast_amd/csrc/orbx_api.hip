@@ -1579,6 +1579,7 @@ int orbx_level_stats(orbx_extractor* ex, int image, int32_t* w, int32_t* h, int3
 void orbx_debug_introsort(uint64_t* v, int n) { debug_introsort_host(v, n); }
 void orbx_debug_set_detect_list_cap(int cap) { debug_set_detect_list_cap(cap); }
 void orbx_debug_set_clahe_cell_kernel(int on) { debug_set_clahe_cell_kernel(on); }
+void orbx_debug_set_remap_lds(int on) { debug_set_remap_lds(on); }
 void orbx_debug_set_octree_global(int on) { debug_set_octree_global(on); }
 void orbx_debug_set_stereo_direct(int max_pairs) { debug_set_stereo_direct(max_pairs); }
 void orbx_debug_set_resize_tail(int first_level, int max_levels, int band_rows) {

@@ -173,6 +173,9 @@ struct orbx_preproc {
   ClaheArgs clahe{};
   DevBuf<float> d_mapx, d_mapy;
   long long mapPitch = 0;
+  DevBuf<int> d_remapTab;          // k_remap_lds footprints (remap_tile_table), when every tile of the plan fits
+  int remapTilesX = 0, remapTilesY = 0;
+  bool remapLds = false;
   DevBuf<int> d_xofs, d_yofs;
   DevBuf<short> d_xab, d_yab;
   DevBuf<uint8_t> d_clahe, d_lut, d_geo, d_gray;
@@ -182,7 +185,7 @@ struct orbx_preproc {
   const uint8_t* out = nullptr;  // result of the last run (a stage buffer, or the caller's frames when nothing is enabled)
   long long outPitch = 0, outImgPitch = 0;
   ~orbx_preproc() {
-    d_mapx.free(); d_mapy.free(); d_xofs.free(); d_yofs.free(); d_xab.free(); d_yab.free();
+    d_mapx.free(); d_mapy.free(); d_remapTab.free(); d_xofs.free(); d_yofs.free(); d_xab.free(); d_yab.free();
     d_clahe.free(); d_lut.free(); d_geo.free(); d_gray.free(); d_cells.free();
   }
 };
@@ -234,6 +237,15 @@ int orbx_preproc_create(const orbx_preproc_params* p, int max_batch, int device,
                       (size_t)p->out_w * 4, p->out_h, hipMemcpyHostToDevice));
       chk(hipMemcpy2D(pp->d_mapy.p + m * per, (size_t)pp->mapPitch * 4, p->map_y + (size_t)m * ms * p->out_h, (size_t)ms * 4,
                       (size_t)p->out_w * 4, p->out_h, hipMemcpyHostToDevice));
+    }
+    if (cn == 1) {   // the LDS-staged kernel needs every output tile's source footprint (orbx_preproc.hip remap_tile_table)
+      std::vector<int> tab;
+      pp->remapLds = remap_tile_table(p->map_x, p->map_y, (long long)ms, p->out_w, p->out_h, p->src_w, p->src_h, p->n_maps, tab,
+                                      pp->remapTilesX, pp->remapTilesY);
+      if (pp->remapLds) {
+        chk(pp->d_remapTab.alloc(tab.size()));
+        if (e == hipSuccess) chk(hipMemcpy(pp->d_remapTab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+      }
     }
   }
   if (resize) {
@@ -296,6 +308,9 @@ static int preproc_enqueue(orbx_preproc* pp, const uint8_t* d_frames, int n, ptr
     a.nMaps = p.n_maps;
     a.dst = pp->d_geo.p; a.dw = pp->outW; a.dh = pp->outH; a.dstPitch = pp->geoPitch; a.dstImgPitch = pp->geoPitch * pp->outH;
     a.mapVec4 = 1; a.dstVec4 = 1;
+    if (pp->remapLds && !(((uintptr_t)cur | (uintptr_t)cp | (uintptr_t)cip) & 15)) {   // 16-byte staging pieces: aligned rows
+      a.tileTab = pp->d_remapTab.p; a.tilesX = pp->remapTilesX; a.tilesY = pp->remapTilesY;
+    }
     e = launch_remap(a, n, s);
     cur = a.dst; cp = a.dstPitch; cip = a.dstImgPitch;
   } else if (e == hipSuccess && pp->doResize) {

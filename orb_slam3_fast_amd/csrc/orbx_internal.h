@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 #include "../../include/orbx.h"
 
@@ -271,7 +272,12 @@ struct RemapArgs {
   const float* mapx; const float* mapy; long long mapPitch, mapImgPitch; int nMaps;  // pitches in floats
   uint8_t* dst; int dw, dh; long long dstPitch, dstImgPitch;
   int mapVec4, dstVec4;  // 16-byte aligned map rows / 4-byte aligned destination rows
+  const int* tileTab;    // k_remap_lds: per (map, tile) footprint entries of remap_tile_table (nullptr: k_remap1 / k_remap)
+  int tilesX, tilesY;
 };
+bool remap_tile_table(const float* mapx, const float* mapy, long long mapStride, int dw, int dh, int sw, int sh, int nMaps,
+                      std::vector<int>& tab, int& tilesX, int& tilesY);
+void debug_set_remap_lds(int on);
 hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s);
 // cv::CLAHE::apply (k_clahe_lut + k_clahe_apply)
 struct ClaheArgs {

@@ -1,6 +1,10 @@
 // orbx_preproc.hip — image pre-processing in front of the extractor (gray, resize, cv::remap, CLAHE) and
 // Frame::UndistortKeyPoints (src/Frame.cc:853-919).
 #include "orbx_device.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
 
 namespace orbx {
 
@@ -280,8 +284,263 @@ __global__ __launch_bounds__(256, 8) void k_remap1(RemapArgs a, int nimg, int xb
     }
   }
 }
+static int g_remap_lds = [] { const char* e = getenv("ORBX_REMAP_LDS"); return e ? atoi(e) : 1; }();   // test / A-B hook
+                                        // (orbx_debug_set_remap_lds, ORBX_REMAP_LDS): 0 = the plans keep k_remap1
+void debug_set_remap_lds(int on) { g_remap_lds = on; }
+// ---------------------------------------------------------------------------------------------------------------- round 6b
+// k_remap_lds: the same arithmetic with the source pixels staged through LDS.  k_remap1's gathers go through the texture
+// addresser three 12-byte loads per thread and image (28 cycles each: the unit is busy 70 % of the launch) although
+// the 1024 pixels of a workgroup read one compact footprint of the source.  Here the HOST works out that footprint once per
+// plan (remap_tile_table below: per 128 x 8 output tile the bounding box of its taps, dword-aligned, with the margin the
+// 12-byte windows and the third window row need), the workgroup copies it with coalesced dword loads -- for two images of the
+// group per trip, the next trip's loads in flight under the current blends -- and the windows come from LDS.
+// Used by the pre-processing plans whose every tile fits kRemapLdsDwords (rectification maps do; a plan with a wider tile, an
+// unaligned source or cn != 1 keeps k_remap1 / k_remap).  Results are bit-identical: the taps, weights and blends are k_remap1's.
+#ifndef REMAP_ABLATE
+#define REMAP_ABLATE 0
+#endif
+#ifndef REMAP_ROWMAJOR
+#define REMAP_ROWMAJOR 0
+#endif
+constexpr int kRemapTileW = 128, kRemapTileH = 8;
+#ifndef REMAP_AHEAD
+#define REMAP_AHEAD 1
+#endif
+constexpr int kRemapAhead = REMAP_AHEAD;            // trips of staging loads in flight (1: measured best -- 2 / 4 trips ahead ran 68 / 85 us against 44.7)
+constexpr int kRemapLdsDwords = 1024;                 // per staged image: 4 KB, four dwords per thread
+__global__ __launch_bounds__(256) void k_remap_lds(RemapArgs a, int nimg, int nblk, int gsz) {
+  __shared__ uint4 stage[2][2][kRemapLdsDwords / 4];   // [trip parity][image of the trip][footprint]: 16 KB
+  const int chunk = (nblk + 7) >> 3, T = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);   // XCD-contiguous tile order (k_remap1)
+  if (T >= nblk) return;
+  const int xb = a.tilesX, yb = a.tilesY;
+#if REMAP_ROWMAJOR
+  const int tz = T / (xb * yb), tq = T - tz * (xb * yb), ty = tq / xb, tx = tq - ty * xb, txy = tx * yb + ty;
+#else
+  const int tz = T / (xb * yb), txy = T - tz * (xb * yb), tx = txy / yb, ty = txy - tx * yb;
+#endif
+  const int m = tz % a.nMaps, grp = tz / a.nMaps;
+  const int4 fp = *reinterpret_cast<const int4*>(a.tileTab + 8ll * ((long long)m * xb * yb + txy));        // x0a, y0, dwords per row, rows
+  const int fmagic = a.tileTab[8ll * ((long long)m * xb * yb + txy) + 4];                                   // ceil(2^32 / dwords per row)
+  const int x0a = fp.x, fy0 = fp.y, wQ = fp.z, total = fp.z * fp.w, P = 16 * fp.z;   // (16-byte units: one slot per thread)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int y = ty * kRemapTileH + 2 * w + (lane >> 5), x0 = tx * kRemapTileW + 4 * (lane & 31);
+  const bool rowIn = y < a.dh;
+  // the thread's four map entries; positions behind the right / bottom edge repeat the edge's entry (their taps stay inside the
+  // footprint, their results are not stored)
+  const int yr = min(y, a.dh - 1);
+  const float* MX = a.mapx + (long long)m * a.mapImgPitch + (long long)yr * a.mapPitch;
+  const float* MY = a.mapy + (long long)m * a.mapImgPitch + (long long)yr * a.mapPitch;
+  float mx[4], my[4];
+  const bool full = x0 + 3 < a.dw;
+  if (full && a.mapVec4) {
+    const float4 vx = *reinterpret_cast<const float4*>(MX + x0), vy = *reinterpret_cast<const float4*>(MY + x0);
+    mx[0] = vx.x; mx[1] = vx.y; mx[2] = vx.z; mx[3] = vx.w;
+    my[0] = vy.x; my[1] = vy.y; my[2] = vy.z; my[3] = vy.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int xr = min(x0 + k, a.dw - 1);
+      mx[k] = MX[xr];
+      my[k] = MY[xr];
+    }
+  }
+  // staging slot: 16-byte piece tid of the footprint = (row tid / wQ, piece tid % wQ); threads behind the footprint's end idle
+  const int pitch = (int)a.srcPitch;
+  const bool sIn = tid < total;
+  int sOff;
+  {
+    const int i = min(tid, total - 1);
+    const int r = (int)__umulhi((unsigned)i, (unsigned)fmagic), c = i - r * wQ;
+    sOff = (fy0 + r) * pitch + x0a + 16 * c;
+  }
+  // taps (k_remap1)
+  auto taps = [&](float fmx, float fmy, int& sxk, int& sy0k, int& sy1k, uint32_t& wl, uint32_t& wh) {
+    const int fsx = cv_round_sse(fmx * 32.f), fsy = cv_round_sse(fmy * 32.f);
+    const int sx = min(max(fsx >> 5, -32768), 32767), sy = min(max(fsy >> 5, -32768), 32767);
+    const int fx = fsx & 31, fy = fsy & 31;
+    uint32_t w0 = (32 - fx) * (32 - fy) * 32, w1 = fx * (32 - fy) * 32, w2 = (32 - fx) * fy * 32, w3 = fx * fy * 32;
+    if ((fx | fy) == 0) { w0 = 32767; w3 = 1; }
+    const bool xin0 = (unsigned)sx < (unsigned)a.sw, xin1 = (unsigned)(sx + 1) < (unsigned)a.sw;
+    const bool yin0 = (unsigned)sy < (unsigned)a.sh, yin1 = (unsigned)(sy + 1) < (unsigned)a.sh;
+    if (!xin0) w0 = w2 = 0;
+    if (!xin1) w1 = w3 = 0;
+    if (!yin0) w0 = w1 = 0;
+    if (!yin1) w2 = w3 = 0;
+    sxk = min(max(sx, 0), a.sw - 2);
+    if (sxk > sx) { w0 = w1; w2 = w3; w1 = w3 = 0; }
+    else if (sxk < sx) { w1 = w0; w3 = w2; w0 = w2 = 0; }
+    wl = w0 | (w1 << 16);
+    wh = w2 | (w3 << 16);
+    sy0k = min(max(sy, 0), a.sh - 1);
+    sy1k = min(max(sy + 1, 0), a.sh - 1);
+  };
+  uint32_t wlo[4], whi[4];
+  int sxc[4], syc0[4], syc1[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) taps(mx[k], my[k], sxc[k], syc0[k], syc1[k], wlo[k], whi[k]);
+  const int bx = min(min(sxc[0], sxc[1]), min(sxc[2], sxc[3]));
+  const int by = min(min(syc0[0], syc0[1]), min(syc0[2], syc0[3]));
+  bool fast = true;
+  uint32_t selTop[4], wrow[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int d = sxc[k] - bx, e0 = syc0[k] - by, e1 = syc1[k] - by;
+    fast = fast && d <= 6 && e0 <= 1 && e1 <= 2;
+    selTop[k] = (uint32_t)d | 0x0c000c00u | ((uint32_t)(d + 1) << 16);
+#pragma unroll
+    for (int j = 0; j < 3; j++) wrow[k][j] = (e0 == j ? wlo[k] : 0u) + (e1 == j ? whi[k] : 0u);
+  }
+  const int bs = bx & 3;
+  fast = fast && bx - bs + 12 <= a.sw;   // (the footprint ends at the row end: remap_tile_table)
+  // LDS byte offsets of the window rows (the footprint holds 12 bytes from bx & ~3 on rows by .. min(by + 2, sh - 1): remap_tile_table)
+  const int lw0 = (by - fy0) * P + (bx - bs - x0a);
+  const int lw1 = (min(by + 1, a.sh - 1) - fy0) * P + (bx - bs - x0a), lw2 = (min(by + 2, a.sh - 1) - fy0) * P + (bx - bs - x0a);
+  const uint8_t* __restrict__ src = a.src;
+  uint8_t* __restrict__ dst = a.dst;
+  const int first = grp * gsz, perMap = (nimg - m + a.nMaps - 1) / a.nMaps;
+  const int count = min(gsz, perMap - first);
+  const bool allFast = __builtin_amdgcn_ballot_w64(!fast) == 0;
+  auto blend = [&](const uint32_t* st) -> uint32_t {
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(st);
+    uint32_t packed = 0;
+#if REMAP_ABLATE == 2   // timing only: no blend
+    return *reinterpret_cast<const uint32_t*>(sb + lw0);
+#endif
+    if (allFast) {
+      const uint32_t* q0 = reinterpret_cast<const uint32_t*>(sb + lw0);
+      const uint32_t* q1 = reinterpret_cast<const uint32_t*>(sb + lw1);
+      const uint32_t* q2 = reinterpret_cast<const uint32_t*>(sb + lw2);
+      const uint32_t a0 = q0[0], a1 = q0[1], a2 = q0[2], b0 = q1[0], b1 = q1[1], b2 = q1[2], c0 = q2[0], c1 = q2[1], c2 = q2[2];
+      const uint2 r0 = make_uint2(__builtin_amdgcn_alignbyte(a1, a0, bs), __builtin_amdgcn_alignbyte(a2, a1, bs));
+      const uint2 r1 = make_uint2(__builtin_amdgcn_alignbyte(b1, b0, bs), __builtin_amdgcn_alignbyte(b2, b1, bs));
+      const uint2 r2 = make_uint2(__builtin_amdgcn_alignbyte(c1, c0, bs), __builtin_amdgcn_alignbyte(c2, c1, bs));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t acc = udot2_u16(__builtin_amdgcn_perm(r0.y, r0.x, selTop[k]), wrow[k][0], 16384u);
+        acc = udot2_u16(__builtin_amdgcn_perm(r1.y, r1.x, selTop[k]), wrow[k][1], acc);
+        acc = udot2_u16(__builtin_amdgcn_perm(r2.y, r2.x, selTop[k]), wrow[k][2], acc);
+        packed |= (acc >> 15) << (8 * k);
+      }
+    } else {   // a wave with a thread whose taps spread further than the window (a seam, strong magnification): byte reads.
+               // The per-pixel taps are rebuilt from the map entries here (rare path) instead of living in 20 registers.
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int sxk, sy0k, sy1k;
+        uint32_t wl, wh;
+        taps(mx[k], my[k], sxk, sy0k, sy1k, wl, wh);
+        const uint8_t* t = sb + (sy0k - fy0) * P + (sxk - x0a);
+        const uint8_t* b = sb + (sy1k - fy0) * P + (sxk - x0a);
+        uint32_t acc = udot2_u16((uint32_t)t[0] | ((uint32_t)t[1] << 16), wl, 16384u);
+        acc = udot2_u16((uint32_t)b[0] | ((uint32_t)b[1] << 16), wh, acc);
+        packed |= (acc >> 15) << (8 * k);
+      }
+    }
+    return packed;
+  };
+  auto put = [&](int img, uint32_t packed) {
+#if REMAP_ABLATE == 1   // timing only: no stores
+    if (packed != 0x12345678u) return;
+#endif
+    if (!rowIn || x0 >= a.dw) return;
+    uint8_t* D = dst + (long long)img * a.dstImgPitch + (long long)y * a.dstPitch + x0;
+    if (full && a.dstVec4) {
+      *reinterpret_cast<uint32_t*>(D) = packed;
+    } else {
+      for (int k = 0; k < 4 && x0 + k < a.dw; k++) D[k] = (uint8_t)(packed >> (8 * k));
+    }
+  };
+  // Staging: one 16-byte load per thread and image (global_load_dwordx4 + ds_write_b128), two images per trip, the next trip's
+  // loads in flight under the current blends.  Measured at 64 x 1280x720, 32 images per group (HISTORY.md, round 6): dword pieces
+  // in registers one trip ahead 47.0 us, the same by LDS-DMA up to six trips ahead 47.0, these 16-byte pieces 44.7 -- and 68 / 85 us
+  // with two / four trips of them in flight.  The timing ablation puts loads + stores alone at 29 us (185 MB over the memory side
+  // at the measured copy rate), the blends alone at 19, the whole at their sum minus 4: more loads in flight do not buy overlap
+  // here, they cost it.
+  if (count <= 0) return;   // (uniform: map m has no image in this batch -- an odd batch's last map)
+  const int ntrips = (count + 1) >> 1;
+  uint4 ra[kRemapAhead], rb[kRemapAhead];   // trips t + 1 .. t + kRemapAhead in flight while trip t is blended
+  auto fetch = [&](int trip, uint4& xa, uint4& xb) {
+    const int tc = min(trip, ntrips - 1);   // (behind the last trip: a repeat of it, never staged)
+    const int imgA = m + a.nMaps * (first + 2 * tc), imgB = m + a.nMaps * (first + min(2 * tc + 1, count - 1));
+    if (sIn && REMAP_ABLATE != 3) {
+      xa = *reinterpret_cast<const uint4*>(src + (long long)imgA * a.srcImgPitch + sOff);
+      xb = *reinterpret_cast<const uint4*>(src + (long long)imgB * a.srcImgPitch + sOff);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < kRemapAhead; q++) fetch(q, ra[q], rb[q]);
+  for (int tb = 0; tb < ntrips; tb += kRemapAhead) {
+#pragma unroll
+    for (int q = 0; q < kRemapAhead; q++) {
+      const int t = tb + q;
+      if (t >= ntrips) break;
+      uint4* sA = stage[t & 1][0];
+      uint4* sB = stage[t & 1][1];
+      if (sIn) {
+        sA[tid] = ra[q];
+        sB[tid] = rb[q];
+      }
+      __syncthreads();   // (one barrier per trip: a buffer is written again two trips later, behind the barrier that follows its reads)
+      fetch(t + kRemapAhead, ra[q], rb[q]);
+      const int imgA = m + a.nMaps * (first + 2 * t);
+      put(imgA, blend(reinterpret_cast<const uint32_t*>(sA)));
+      if (2 * t + 1 < count) put(imgA + a.nMaps, blend(reinterpret_cast<const uint32_t*>(sB)));
+    }
+  }
+}
+
+// Footprints of k_remap_lds (host, once per plan).  For map m and output tile (tx, ty) -- kRemapTileW x kRemapTileH pixels --
+// the taps of the tile's pixels are evaluated exactly as the kernel does (cvRound(32 x) >> 5, clamped into the source) and their
+// bounding box is widened to what the kernel reads: columns from (min sx) & ~15 to past the 12-byte window of the right-most
+// thread in 16-byte pieces, rows down to the third window row.  Entry = {x0a, y0, pieces per row, rows, ceil(2^32 / pieces per row), 0, 0, 0}.
+// Returns false when a tile needs more than kRemapLdsDwords (the plan keeps k_remap1) or the footprint would leave the rows.
+bool remap_tile_table(const float* mapx, const float* mapy, long long mapStride, int dw, int dh, int sw, int sh, int nMaps,
+                      std::vector<int>& tab, int& tilesX, int& tilesY) {
+  tilesX = (dw + kRemapTileW - 1) / kRemapTileW;
+  tilesY = (dh + kRemapTileH - 1) / kRemapTileH;
+  tab.assign((size_t)8 * tilesX * tilesY * nMaps, 0);
+  if (sw < 32 || (sw & 15)) return false;   // (16-byte staging pieces inside the rows; narrower / unaligned sources keep k_remap1)
+  auto cvr = [](float t) { return std::fabs(t) < 2147483648.f ? (int)std::nearbyintf(t) : (int)0x80000000; };
+  for (int m = 0; m < nMaps; m++)
+    for (int tx = 0; tx < tilesX; tx++)
+      for (int ty = 0; ty < tilesY; ty++) {
+        int minX = sw, maxX = 0, minY = sh, maxY = 0;
+        for (int y = ty * kRemapTileH; y < std::min(dh, (ty + 1) * kRemapTileH); y++) {
+          const float* MX = mapx + ((long long)m * dh + y) * mapStride;
+          const float* MY = mapy + ((long long)m * dh + y) * mapStride;
+          for (int x = tx * kRemapTileW; x < std::min(dw, (tx + 1) * kRemapTileW); x++) {
+            const int fsx = cvr(MX[x] * 32.f), fsy = cvr(MY[x] * 32.f);
+            const int sx = std::min(std::max(fsx >> 5, -32768), 32767), sy = std::min(std::max(fsy >> 5, -32768), 32767);
+            const int sxc = std::min(std::max(sx, 0), sw - 2);
+            const int y0c = std::min(std::max(sy, 0), sh - 1), y1c = std::min(std::max(sy + 1, 0), sh - 1);
+            minX = std::min(minX, sxc); maxX = std::max(maxX, sxc);
+            minY = std::min(minY, y0c); maxY = std::max(maxY, y1c);
+          }
+        }
+        int x0a = minX & ~15;
+        int endX = std::max(maxX + 2, (maxX & ~3) + 12);
+        endX = std::min((endX + 15) & ~15, sw);           // (a window that would cross the row end is not taken by the kernel's fast path)
+        if (endX - x0a < 32) x0a = endX - 32;             // (two pieces at least: the row / column split of a slot multiplies by 2^32 / pieces)
+        const int wD = (endX - x0a) / 16, rows = std::min(maxY + 2, sh) - minY;
+        if (wD <= 0 || rows <= 0 || (long long)wD * rows > kRemapLdsDwords / 4) return false;
+        int* e = &tab[(size_t)8 * (((size_t)m * tilesX + tx) * tilesY + ty)];
+        e[0] = x0a; e[1] = minY; e[2] = wD; e[3] = rows;
+        e[4] = (int)(unsigned)((0x100000000ull + (unsigned)wD - 1) / (unsigned)wD);
+      }
+  return true;
+}
+
 hipError_t launch_remap(const RemapArgs& a, int nimg, hipStream_t s) {
-  if (a.cn == 1 && a.sw >= 8) {
+  if (a.cn == 1 && a.tileTab && g_remap_lds) {
+    // images per workgroup: the taps and weights of a tile are built once per group, so larger groups halve that share of the
+    // vector work -- as long as the launch keeps a few workgroups per CU slot
+    static const int gforce = [] { const char* e = getenv("ORBX_REMAP_GROUP"); return e ? atoi(e) : 0; }();
+    const int perMap = (nimg + a.nMaps - 1) / a.nMaps, tiles = a.tilesX * a.tilesY * a.nMaps;
+    int gsz = 8;
+    while (gsz < 32 && gsz < perMap && (long long)tiles * ((perMap + 2 * gsz - 1) / (2 * gsz)) >= 1500) gsz *= 2;
+    if (gforce > 0) gsz = gforce;
+    const int groups = (perMap + gsz - 1) / gsz, nblk = tiles * groups;
+    hipLaunchKernelGGL(k_remap_lds, dim3(8 * ((nblk + 7) / 8)), dim3(256), 0, s, a, nimg, nblk, gsz);
+  } else if (a.cn == 1 && a.sw >= 8) {
     const int perMap = (nimg + a.nMaps - 1) / a.nMaps, groups = (perMap + kRemapGroup - 1) / kRemapGroup;
     const int xb = (a.dw + 255) / 256, yb = (a.dh + 3) / 4, nblk = xb * yb * a.nMaps * groups;
     hipLaunchKernelGGL(k_remap1, dim3(8 * ((nblk + 7) / 8)), dim3(256), 0, s, a, nimg, xb, yb, nblk);

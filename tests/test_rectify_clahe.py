@@ -199,6 +199,68 @@ def test_hip_remap_matches_oracle(oracle, kind):
 
 
 @pytest.mark.gpu
+def test_hip_preproc_remap_forms_match_oracle(oracle):
+    """The plans' two cv::remap forms (round 6: source footprints staged through LDS, k_remap_lds / per-thread window gathers,
+    k_remap1) against the oracle: rectification maps of several sizes (tile edges: widths that are no multiple of 128, heights
+    that are no multiple of 8), two maps, batches whose per-map image count is odd, even, below and above one group of eight;
+    maps with seams and taps outside the source (the byte-read branch, zero weights); maps whose footprints do not fit (random,
+    a strong rotation: the plan keeps k_remap1 whatever the hook says) -- every result equal to the oracle's."""
+    import ctypes as C
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd import hipmem
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    rng = np.random.default_rng(66)
+
+    def seam_maps(dw, dh, sw, sh):   # a rectification map with a vertical seam, a shifted band and a region far outside the source
+        mx, my = synth.rectify_maps(dw, dh, sw, sh, seed=5)
+        mx, my = mx.copy(), my.copy()
+        mx[:, dw // 2:] += 9.25
+        my[dh // 3:dh // 3 + 5, :] += 3.5
+        mx[:7, :40] = -20.0
+        my[-6:, -50:] = sh + 30.0
+        mx[10:14, 60:64] = sw - 1.25       # the pair straddles the right edge
+        my[20:23, 10:20] = -0.75           # and the top edge
+        return mx, my
+
+    cases = [((752, 480), (720, 460), "rectify", 2, (1, 2, 3, 4, 9, 17, 18)), ((1280, 720), (1280, 720), "rectify", 2, (2, 5)),
+             ((640, 480), (601, 353), "rectify", 1, (1, 8, 9)), ((512, 512), (512, 512), "seam", 2, (4, 7)),
+             ((256, 64), (130, 9), "rectify", 1, (3,)), ((640, 480), (600, 350), "random", 1, (2,)),
+             ((752, 480), (720, 460), "rotate", 2, (3,))]
+    try:
+        for (sw, sh), (dw, dh), kind, nmaps, batches in cases:
+            maps = []
+            for m in range(nmaps):
+                if kind == "rectify":
+                    maps.append(synth.rectify_maps(dw, dh, sw, sh, seed=10 + m))
+                elif kind == "seam":
+                    mx, my = seam_maps(dw, dh, sw, sh)
+                    maps.append((mx + m, my))
+                elif kind == "rotate":
+                    maps.append(synth.rectify_maps(dw, dh, sw, sh, seed=3, rot_deg=(2.0, -1.0, 25.0 + m)))
+                else:
+                    maps.append(_maps(rng, dw, dh, sw, sh, "random"))
+            mapsx, mapsy = np.stack([a for a, _ in maps]), np.stack([b for _, b in maps])
+            pp = orbx.Preproc(sw, sh, channels=1, maps=(mapsx, mapsy), max_batch=max(batches))
+            for n in batches:
+                frames = np.stack([synth.mono_frame(sw, sh, 100 + i) if sw >= 512 else rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+                                   for i in range(min(n, 3))])
+                frames = np.ascontiguousarray(frames[np.arange(n) % len(frames)])
+                frames[:, ::7, ::5] = rng.integers(0, 256, frames[:, ::7, ::5].shape, dtype=np.uint8)
+                raw = DeviceBuffer.from_numpy(frames)
+                want = [oracle.remap(frames[i], mapsx[i % nmaps], mapsy[i % nmaps]) for i in range(n)]
+                for hook in (1, 0):
+                    orbx.lib().orbx_debug_set_remap_lds(hook)
+                    ptr, w, h, rp, ip = pp.run_device(raw.ptr.value, n, sw, sw * sh)
+                    got = np.zeros((n, ip), np.uint8)
+                    hipmem._ck(hipmem.hip().hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), got.nbytes, 2))
+                    got = got[:, :h * rp].reshape(n, h, rp)[:, :, :w]
+                    for i in range(n):
+                        assert np.array_equal(got[i], want[i]), (kind, (sw, sh), (dw, dh), n, hook, i)
+    finally:
+        orbx.lib().orbx_debug_set_remap_lds(1)
+
+
+@pytest.mark.gpu
 def test_hip_clahe_matches_oracle(oracle):
     import orb_slam3_fast_amd as orbx
     rng = np.random.default_rng(12)

@@ -22,7 +22,10 @@ run_cfg() {
   python $R/tools/pmc_insts.py $(find /tmp/cp_i -name "*.db" | head -1) k_ > $O/${TAG}_${cfg}_pmc_insts.txt
   echo "== $cfg"; head -12 $O/${TAG}_${cfg}_kernel_stats_1handle.csv
 }
-run_cfg C2 --mode mono --width 640 --height 480 --nfeatures 1000
-run_cfg S640 --mode stereo --width 640 --height 480 --nfeatures 1000
-run_cfg C4 --mode fisheye --width 512 --height 512 --nfeatures 1500
-run_cfg C5 --config C5
+ONLY=${2:-all}   # second argument: one configuration (C2 | S640 | C4 | C5) instead of all four
+want() { [ "$ONLY" = all ] || [ "$ONLY" = "$1" ]; }
+want C2 && run_cfg C2 --mode mono --width 640 --height 480 --nfeatures 1000
+want S640 && run_cfg S640 --mode stereo --width 640 --height 480 --nfeatures 1000
+want C4 && run_cfg C4 --mode fisheye --width 512 --height 512 --nfeatures 1500
+want C5 && run_cfg C5 --config C5
+true

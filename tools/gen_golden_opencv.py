@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """ONE COMMAND that pins every OpenCV rule the oracle restates from memory ("[OCV-mem]") against
 real OpenCV.  This image has no cv2 (no network), so the fixture cannot be produced here; on any box with
-`opencv-python` / `opencv-python-headless` >= 4.5.1 (numpy only besides):
+`opencv-python` / `opencv-python-headless` >= 4.5.1 (numpy only besides; a 4.0 .. 4.5.0 wheel works too -- the tests then report which
+of the blur models 440 / 44016 / 44032 of orbx_set_opencv_compat that build follows):
 
     python tools/gen_golden_opencv.py            # writes tests/golden/opencv_pins.npz
     python -m pytest tests/test_oracle_vs_opencv.py tests/test_gpu_parity.py -q
