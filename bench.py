@@ -895,6 +895,17 @@ def preproc_leg(orbx, np):
         traf = json.load(open(os.path.join(ROOT, "profiles", "r6_preproc_traffic.json")))
     except Exception:
         traf = {}
+    def rocprof_us(csv_name, *kernels):
+        """Sum of the kernels' average durations in a committed rocprofv3 --kernel-trace --stats summary (profiles/), or None."""
+        try:
+            tot = 0.0
+            for line in open(os.path.join(ROOT, "profiles", csv_name)):
+                for k_ in kernels:
+                    if k_ in line.split(",")[0]:
+                        tot += float(line.strip().split(",")[-2])
+            return round(tot, 2) or None
+        except Exception:
+            return None
     out = {}
     B, w, h = 64, 1280, 720
     L, R = synth.stereo_pair(w, h, 5)
@@ -906,7 +917,11 @@ def preproc_leg(orbx, np):
     out["rectify_1280x720"] = {"value": round(B / t, 1), "unit": "frames/s", "us_per_batch": round(t * 1e6, 2), "batch": B,
                                "roofline": {"kernel": "k_remap_lds", "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
-                                            "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_remap_lds", traf.get("k_remap1"))}}
+                                            "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_remap_lds", traf.get("k_remap1")),
+                                            "kernel_us_rocprof": rocprof_us("r6_preproc_rectify_stats.csv", "k_remap")}}
+    ku = out["rectify_1280x720"]["roofline"]["kernel_us_rocprof"]
+    if ku:
+        out["rectify_1280x720"]["roofline"]["kernel_frac"] = round(nb / (ku * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     w2 = h2 = 512
     f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
     pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)
@@ -916,9 +931,14 @@ def preproc_leg(orbx, np):
                             "roofline": {"kernel": "k_clahe_lut + k_clahe_apply_cell", "bound": "hbm", "achieved": round(nb / t / 1e9, 1),
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
                                          "algorithmic_bytes_per_launch": nb,
-                                         "traffic": (traf.get("k_clahe_lut", 0) + traf.get("k_clahe_apply_cell", 0)) or None}}
-    out["note"] = ("wall clock of synchronised runs (two launches for CLAHE: their boundary is inside); kernel durations and PMC passes: "
-                   "profiles/r6_preproc_*")
+                                         "traffic": (traf.get("k_clahe_lut", 0) + traf.get("k_clahe_apply_cell", 0)) or None,
+                                         "kernel_us_rocprof": rocprof_us("r6_preproc_clahe_stats.csv", "k_clahe_lut", "k_clahe_apply")}}
+    ku = out["clahe_512x512"]["roofline"]["kernel_us_rocprof"]
+    if ku:
+        out["clahe_512x512"]["roofline"]["kernel_frac"] = round(nb / (ku * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    out["note"] = ("value / achieved / frac: wall clock of synchronised runs (launch + synchronisation inside; two launches for CLAHE); "
+                   "kernel_us_rocprof / kernel_frac: the kernels' own durations from the committed rocprofv3 summary of the same "
+                   "workload (profiles/r6_preproc_*_stats.csv), traffic from its --pmc passes")
     return out
 
 
