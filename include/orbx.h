@@ -765,6 +765,11 @@ void orbx_debug_set_stereo_direct(int max_pairs);
 /* Test hook of orbx_clahe's two apply forms (cv::CLAHE::apply, Examples/Stereo/stereo_tum_vi.cc:100,142-143): 1 (default) = one
  * workgroup per interpolation cell with the cell's table in LDS where the geometry allows it, 0 = the per-pixel table gathers
  * everywhere. */
+/* Test hook of the batched, device-resident association paths (orbx_fisheye_stereo_match_batch, orbx_stereo_match_batch, the
+ * batched matchers): overwrites image `image` of the handle's LAST extraction batch with n keypoints / descriptors given by the
+ * caller (serial-order slots, mono_index = first lapping row), so that crafted sets -- ties, empty and one-row lapping areas,
+ * sizes around the kernels' tile edges -- reach the kernels that normally only see extractor output.  Synchronises the stream. */
+int orbx_debug_upload_results(orbx_extractor* ex, int image, const orbx_keypoint* kps, const uint8_t* desc, int n, int mono_index);
 void orbx_debug_set_clahe_cell_kernel(int on);
 /* Test hook of the pre-processing plans' two cv::remap forms (src/System.cc:294-295): 1 (default) = the source footprint of
  * every 128 x 8 output tile staged through LDS (k_remap_lds) where the plan's maps allow it, 0 = the per-thread window

@@ -170,6 +170,7 @@ def lib():
         L.orbx_debug_set_stereo_direct.restype = None
         L.orbx_debug_set_clahe_cell_kernel.argtypes = [i]
         L.orbx_debug_set_clahe_cell_kernel.restype = None
+        L.orbx_debug_upload_results.argtypes = [vp, i, vp, vp, i, i]
         L.orbx_debug_set_remap_lds.argtypes = [i]
         L.orbx_debug_set_remap_lds.restype = None
         L.orbx_debug_set_resize_tail.argtypes = [i, i, i]

@@ -1495,6 +1495,22 @@ int orbx_fisheye_stereo_match_batch(orbx_extractor* left, int first_left, orbx_e
   return ORBX_OK;
 }
 
+int orbx_debug_upload_results(orbx_extractor* ex, int image, const orbx_keypoint* kps, const uint8_t* desc, int n, int mono_index) {
+  if (!ex || (!kps && n > 0) || (!desc && n > 0)) return fail(ORBX_E_BADARG, "null argument");
+  if (image < 0 || image >= ex->lastN) return fail(ORBX_E_BADARG, "image outside the last extraction");
+  const int cap = ex->gmax.outCap;
+  if (n < 0 || n > cap || mono_index < 0 || mono_index > n) return fail(ORBX_E_BADARG, "counts outside the handle's capacity");
+  HIPC(hipSetDevice(ex->device));
+  HIPC(hipStreamSynchronize(ex->stream));
+  if (n > 0) {
+    HIPC(hipMemcpy(ex->d_kps.p + (size_t)image * cap, kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_desc.p + (size_t)image * cap * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+  }
+  HIPC(hipMemcpy(ex->d_nOut.p + image, &n, sizeof(int), hipMemcpyHostToDevice));
+  HIPC(hipMemcpy(ex->d_mono.p + image, &mono_index, sizeof(int), hipMemcpyHostToDevice));
+  return ORBX_OK;
+}
+
 int orbx_fisheye_results_device(const orbx_extractor* left, const int32_t** d_left_to_right, const int32_t** d_right_to_left,
                                 const float** d_depth, const float** d_points3d, const int32_t** d_counts) {
   if (!left || left->fisheyePairs == 0) return fail(ORBX_E_BADARG, "no fisheye association has been run on this handle");

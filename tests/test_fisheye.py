@@ -249,6 +249,67 @@ def test_hip_fisheye_batch_on_device_results(oracle):
         assert host[0] == n and np.array_equal(host[2], hip[2]) and host[4].tobytes() == hip[4].tobytes()
 
 
+@pytest.mark.gpu
+def test_hip_fisheye_batch_scan_edge_cases(oracle):
+    """The batched association's 2-NN scan (round 6: k_fisheye_scan, Hamming distances as an i8 matrix product) on crafted
+    lapping sets that extractor output never produces, injected with orbx_debug_upload_results: train counts around the 16-row
+    MFMA group and the 128-row sub-tile (0, 1, 2, 15 .. 17, 127 .. 129, 257), query counts around the 16- / 32- / 128-query
+    wave and workgroup edges, exact ties (duplicated train descriptors at several distances: BFMatcher keeps the FIRST minimum,
+    a duplicate of the best makes the Lowe ratio fail), all-zero and all-one descriptors (distance 0 and 256), and a pair whose
+    left lapping area is empty.  Integer results (pair indices, descriptor-match counts) must equal the oracle's exactly, the
+    float results within the tolerance of compare_float_results."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w = h = 512
+    npairs = 4
+    imgs = np.stack([synth.mono_frame(w, h, 300 + i) for i in range(2 * npairs)])
+    ex = orbx.ORBextractor(1500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * npairs)
+    d = DeviceBuffer.from_numpy(imgs)
+    ex.extract_batch_device(d.ptr.value, 2 * npairs, w, h, w, w * h)   # (allocates the result arrays; contents are replaced below)
+    ex.sync()
+    sigma2 = ex.GetScaleSigmaSquares()
+    rng = np.random.default_rng(4242)
+    sizes = [(0, 5), (3, 0), (3, 1), (1, 2), (5, 15), (17, 16), (33, 17), (127, 127), (128, 128), (129, 129), (130, 257), (300, 31)]
+    cases = []
+    for nq, nt in sizes:
+        sc = synth.fisheye_stereo_scene(500 + nq + 7 * nt, n_left=nq + 6, n_right=nt + 4, mono_left=6, mono_right=4)
+        kL, dL, kR, dR = sc["kL"].copy(), sc["dL"].copy(), sc["kR"].copy(), sc["dR"].copy()
+        if nt >= 8 and nq >= 3:
+            dR[4 + nt - 1] = dR[4 + 1]                       # the LAST train duplicates train 1: ties go to the lower index
+            dR[4 + 3] = dR[4 + 2]                            # adjacent duplicate
+            dL[6 + 0] = dR[4 + 1]                            # query 0 at distance 0 from both copies: ratio test fails (0 < 0.7 * 0)
+            dL[6 + 1] = dR[4 + 2]
+            dL[6 + 1, 0] ^= 1                                # query 1 at distance 1 from trains 2 and 3
+            dL[6 + 2] = 0
+            dR[4 + 5] = 255                                  # distance 256 from an all-zero query
+            dR[4 + 6] = 0                                    # and distance 0
+        cases.append((kL, dL, 6, kR, dR, 4, sc))
+    lib = orbx.lib()
+    for c0 in range(0, len(cases), npairs):
+        chunk = cases[c0:c0 + npairs]
+        for p, (kL, dL, mL, kR, dR, mR, sc) in enumerate(chunk):
+            for image, (k, dd, mono) in ((p, (kL, dL, mL)), (npairs + p, (kR, dR, mR))):
+                k = np.ascontiguousarray(k.astype(orbx.KP_DTYPE))
+                dd = np.ascontiguousarray(dd, np.uint8)
+                orbx._check(lib.orbx_debug_upload_results(ex._h, image, orbx._p(k), orbx._p(dd), len(k), mono))
+        rig = _rig(orbx, chunk[0][6])
+        orbx.fisheye_match_async(ex, ex, rig, first_left=0, first_right=npairs, n_pairs=len(chunk))
+        ex.sync()
+        for p, (kL, dL, mL, kR, dR, mR, sc) in enumerate(chunk):
+            n, nd, l2r, r2l, dep, pts = orbx.fisheye_download(ex, ex, p)
+            hip = (n, nd, l2r[: len(kL)], r2l[: len(kR)], dep[: len(kL)], pts[: len(kL)])
+            ora = oracle.fisheye_stereo_match(kL, dL, mL, kR, dR, mR, _rig(oracle, chunk[0][6]), sigma2)
+            assert nd == ora[1], (len(kL) - mL, len(kR) - mR, nd, ora[1])      # the Lowe-accepted pairs: pure integer work
+            assert compare_float_results(hip, ora[:6], ora[6], mL) <= 2, (len(kL) - mL, len(kR) - mR)
+            assert (l2r[len(kL):] == -1).all() and (r2l[len(kR):] == -1).all()
+            if len(kR) - mR >= 8 and len(kL) - mL >= 3:
+                # the 2-NN itself, without the geometry: the oracle's brute-force scan on the same rows
+                idx, dist, ok = oracle.bf_knn2(dL[mL:], dR[mR:])
+                assert idx[0, 0] == 1 and dist[0, 0] == 0 and dist[0, 1] == 0      # duplicate pair: first minimum = the lower index
+                assert idx[1, 0] == 2 and idx[1, 1] == 3 and dist[1, 0] == 1
+                assert dist[2, 0] == 0 and idx[2, 0] == 6
+
+
 # ---------------------------------------------------------------------------------------------- SearchByProjection, Nleft != -1
 def _fisheye_frame(mod, seed, w=512, h=512):
     """A stereo-fisheye frame as the tracker sees it: N = nL + nR keypoints (mvKeys then mvKeysRight) from the synthetic
