@@ -1159,7 +1159,11 @@ __global__ __launch_bounds__(kFeThreads, 4) void k_fisheye_scan(FisheyeBatchArgs
     }
   }
   uint32_t k0[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, k1[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};  // (distance << 16 | train index), nT < 65536
+#if FE_ABLATE == 5   // timing only: no sub-tiles (the workgroup's fixed part alone)
+  const int nSub = nT < 0 ? 1 : 0;
+#else
   const int nSub = (nT + kFeSub - 1) / kFeSub;
+#endif
   // the workgroup expands dword e >> 7 (wave-uniform) of train e & 127 of the sub-tile, e = tid (+ kFeThreads)
   // The raw dwords travel kFePF sub-tiles ahead in registers: a sub-tile's compute (a few hundred cycles) is far shorter than the
   // latency of its loads (descriptors written by another XCD's k_describe come from the memory side), and one workgroup or two
