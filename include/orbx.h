@@ -507,7 +507,8 @@ int orbx_search_by_projection_frame(int device, const orbx_keypoint* kps_un, con
  * n_matches [n_frames].  Every kernel of the chain runs ONCE for all frames (blockIdx.y = frame) with a fixed number of
  * fixed-point rounds enqueued blindly; a frame that needs more (or larger candidate lists) is redone through the one-shot path:
  * results are those of n_frames separate calls.  map_points == NULL (round 6): the views come from the handle's last
- * orbx_project_map_points_batch and never touch the host (points_stride and every n_map_points[f] must equal its n).
+ * orbx_project_map_points_batch and never touch the host (points_stride and every n_map_points[f] must equal its n); points ==
+ * NULL in the frame flavour: from the last orbx_project_last_frames_batch (points_stride / n_points[f] = the upload's).
  * Returns the total number of matches or a negative error. */
 int orbx_search_by_projection_batch(orbx_extractor* ex, int first_image, int n_frames, float min_x, float min_y, float max_x,
                                     float max_y, const orbx_map_point_view* map_points, const int32_t* n_map_points,
@@ -543,6 +544,30 @@ int orbx_map_upload(orbx_extractor* ex, int n, const float* world_pos, const flo
 int orbx_project_map_points_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose* poses, float min_x, float min_y,
                                   float max_x, float max_y, float viewing_cos_limit, const uint8_t* skip,
                                   orbx_map_point_view* views_out);
+
+/* ---- device-side projection for the batched frame-to-frame matcher (round 6) -------------------------------------------------
+ * ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) projects LastFrame's map points itself
+ * (src/ORBmatcher.cc:1606-1648): x3Dc = Tcw * x3Dw with Tcw a Sophus::SE3f -- the unit-quaternion sandwich of
+ * Thirdparty/Sophus/sophus/so3.hpp:358-366 plus the translation --, invzc = 1.0 / z, Pinhole::project, the bounds skips, radius =
+ * th * mvScaleFactors[nLastOctave], the level window by bForward / bBackward, ur = u - mbf * invzc.  Here the LastFrames of the
+ * batch's cameras are uploaded once per tracking step as structure-of-arrays, every camera contributes its pose, and the
+ * orbx_projected_point views are made on the device and stay there for orbx_search_by_projection_frame_batch(points = NULL).
+ * Pose = Tcw as Sophus stores it (quaternion x y z w, translation), the Pinhole parameters, mbf and the caller's forward /
+ * backward decision (:1611-1612, from tlc(2) and mb): direction 0 = neither, 1 = bForward, 2 = bBackward. */
+typedef struct orbx_frame_pose_q {
+  float q[4], t[3], fx, fy, cx, cy, bf;
+  int32_t direction;
+} orbx_frame_pose_q;
+/* LastFrame f of camera f (n_frames cameras, points_stride entries each, n_points[f] used): per keypoint i of that LastFrame the
+ * world position of mvpMapPoints[i] (n_frames x stride x 3), mvKeys[i].octave, mvKeysUn[i].angle, pMP->GetDescriptor()
+ * (x 32), flags bit 0 = the point exists and is no outlier (:1615-1617), bit 1 = Observations() > 0.  Copied into the handle. */
+int orbx_last_frames_upload(orbx_extractor* ex, int n_frames, int points_stride, const int32_t* n_points, const float* world_pos,
+                            const int32_t* octave, const float* angle, const uint8_t* desc, const uint8_t* flags);
+/* The projection block for every uploaded point of n_frames frames (scale factors = the handle's; bounds = mnMinX .. mnMaxY).
+ * views_out (may be NULL) receives a host copy [n_frames][points_stride].  Float arithmetic in the reference's expression order
+ * (tolerance parity at the gates, like orbx_project_map_points_batch; 0 / 0 projections are marked invalid). */
+int orbx_project_last_frames_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose_q* poses, float min_x, float min_y,
+                                   float max_x, float max_y, float th, orbx_projected_point* views_out);
 
 /* Replaces the matching part of the relocalisation matcher ORBmatcher::SearchByProjection(Frame& CurrentFrame,
  * KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1808-1918; callers

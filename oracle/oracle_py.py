@@ -318,6 +318,23 @@ PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"
 assert PP_DTYPE.itemsize == 64
 
 
+def project_last_frame(pose, direction, pos, octave, angle, flags, desc, th, scale_factors, bounds):
+    """The projection block of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1606-1669) for n LastFrame points
+    and ONE pose (12 floats: Sophus quaternion x y z w, translation, fx fy cx cy, bf).  Returns (views PP_DTYPE [n], margins [n])."""
+    pose = np.ascontiguousarray(pose, np.float32).reshape(12)
+    pos = np.ascontiguousarray(pos, np.float32)
+    octave, angle = np.ascontiguousarray(octave, np.int32), np.ascontiguousarray(angle, np.float32)
+    fl, sf = np.ascontiguousarray(flags, np.uint8), np.ascontiguousarray(scale_factors, np.float32)
+    n = len(octave)
+    views = np.zeros(n, PP_DTYPE)
+    views["desc"] = _u8(desc)
+    margins = np.zeros(n, np.float64)
+    lib().oro_project_last_frame(_p(pose), int(direction), n, _p(pos), _p(octave), _p(angle), _p(fl), C.c_float(th), _p(sf), len(sf),
+                                 C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(views),
+                                 _p(margins))
+    return views, margins
+
+
 def search_by_projection_frame(k, desc, uright, bounds, pts, check_ori, occupied):
     k = np.ascontiguousarray(k)
     desc = _u8(desc)

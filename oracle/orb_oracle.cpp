@@ -2241,6 +2241,50 @@ int search_by_bow(const std::vector<uint32_t>& kfNodes, const std::vector<int>& 
 
 
 // ---- Frame::isInFrustum + MapPoint::PredictScale (test infrastructure for orbx_project_map_points_batch) ----------------------
+ProjectedPoint project_last_frame_point(const FramePoseQ& T, const float Pw[3], int lastOctave, float lastAngle, float th,
+                                        const std::vector<float>& scaleFactors, float minX, float minY, float maxX, float maxY,
+                                        double* margin) {
+  ProjectedPoint o{};
+  double gate = 1e30;
+  auto near = [&](float value, float threshold) {
+    const double d = std::fabs((double)value - (double)threshold) / std::max(1.0, std::fabs((double)threshold));
+    gate = std::min(gate, d);
+  };
+  auto done = [&]() {
+    if (margin) *margin = gate;
+    return o;
+  };
+  o.angle = lastAngle;
+  const float qx = T.q[0], qy = T.q[1], qz = T.q[2], qw = T.q[3];
+  const float px = Pw[0], py = Pw[1], pz = Pw[2];
+  // Thirdparty/Sophus/sophus/so3.hpp:363-365
+  float ux = qy * pz - qz * py, uy = qz * px - qx * pz, uz = qx * py - qy * px;   // uv = q.vec().cross(p)
+  ux += ux; uy += uy; uz += uz;                                                    // uv += uv
+  const float cxv = qy * uz - qz * uy, cyv = qz * ux - qx * uz, czv = qx * uy - qy * ux;   // q.vec().cross(uv)
+  const float rx = (px + qw * ux) + cxv, ry = (py + qw * uy) + cyv, rz = (pz + qw * uz) + czv;
+  const float xc = rx + T.t[0], yc = ry + T.t[1], zc = rz + T.t[2];               // se3.hpp:323: so3() * p + translation()
+  const float invzc = (float)(1.0 / (double)zc);                                  // src/ORBmatcher.cc:1626
+  near(zc, 0.f);
+  if (invzc < 0) return done();                                                   // :1628
+  const float u = T.fx * xc / zc + T.cx, v = T.fy * yc / zc + T.cy;               // src/CameraModels/Pinhole.cpp:46-52
+  if (!(u == u) || !(v == v)) return done();   // (0 / 0: the reference's comparisons all fail and it goes on with NaN; not modelled)
+  near(u, minX); near(u, maxX);
+  if (u < minX || u > maxX) return done();                                        // :1632-1633
+  near(v, minY); near(v, maxY);
+  if (v < minY || v > maxY) return done();                                        // :1634-1635
+  const int nLevels = (int)scaleFactors.size();
+  const int oct = std::min(std::max(lastOctave, 0), nLevels - 1);
+  o.radius = th * scaleFactors[oct];                                              // :1643
+  if (T.direction == 1) { o.min_level = oct; o.max_level = -1; }                  // :1647-1649 GetFeaturesInArea(u, v, r, nLastOctave)
+  else if (T.direction == 2) { o.min_level = 0; o.max_level = oct; }              // :1650-1652
+  else { o.min_level = oct - 1; o.max_level = oct + 1; }                          // :1653-1655
+  o.u = u;
+  o.v = v;
+  o.ur = u - T.bf * invzc;                                                        // :1669
+  o.valid = 1;
+  return done();
+}
+
 MapPointView is_in_frustum(const FramePose& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
                            float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
                            int nlevels, double margin[2]) {

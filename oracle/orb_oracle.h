@@ -229,6 +229,20 @@ struct ProjectedPoint {
   uint8_t desc[32];
 };
 static_assert(sizeof(ProjectedPoint) == 64, "POD layout shared with orbx_projected_point");
+// The projection block of that matcher (src/ORBmatcher.cc:1606-1648) for ONE LastFrame point: x3Dc = Tcw * x3Dw with Tcw a
+// Sophus::SE3f, i.e. the unit-quaternion sandwich of Thirdparty/Sophus/sophus/so3.hpp:358-366 (uv = q.vec x p; uv += uv;
+// p + q.w * uv + q.vec x uv) plus the translation (se3.hpp:321-324) -- NOT a matrix product --; invzc = 1.0 / z in double,
+// narrowed; `invzc < 0` skip; Pinhole::project; the image-bounds skips; radius = th * mvScaleFactors[nLastOctave]; the level
+// window by bForward / bBackward (direction 1 / 2; decided by the caller from tlc(2) and mb, :1611-1612); ur = u - mbf * invzc
+// (:1669).  Float arithmetic in Eigen's coefficient order (cross product a1 b2 - a2 b1, ..), no contraction.
+// margin (may be NULL): min |value - threshold| / max(1, |threshold|) over the gates evaluated, for the device kernel's tolerance tests.
+struct FramePoseQ {
+  float q[4] /* x y z w */, t[3], fx, fy, cx, cy, bf;
+  int32_t direction;   // 0: neither, 1: bForward, 2: bBackward
+};
+ProjectedPoint project_last_frame_point(const FramePoseQ& T, const float Pw[3], int lastOctave, float lastAngle, float th,
+                                        const std::vector<float>& scaleFactors, float minX, float minY, float maxX, float maxY,
+                                        double* margin);
 // match[i2] = index of the LastFrame point assigned to CurrentFrame keypoint i2, or -1.  Returns nmatches.
 int search_by_projection_frame(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
                                const FrameGrid& grid, const std::vector<ProjectedPoint>& pts, bool checkOri,

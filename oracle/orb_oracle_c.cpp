@@ -528,6 +528,29 @@ int oro_search_for_triangulation_rig(const uint32_t* nodes1, int nNodes1, const 
 }
 
 
+// The projection block of SearchByProjection(CurrentFrame, LastFrame) for n LastFrame points x one pose (13 floats: quaternion
+// x y z w, translation, fx fy cx cy, bf; + direction); flags bit 0 = has a MapPoint and is no outlier, bit 1 = Observations() > 0;
+// views [n] (descriptors are the caller's), margins [n] (may be NULL)
+void oro_project_last_frame(const float* pose12, int direction, int n, const float* pos, const int* octave, const float* angle,
+                            const uint8_t* flags, float th, const float* sf, int nLevels, float minX, float minY, float maxX,
+                            float maxY, ProjectedPoint* views, double* margins) {
+  FramePoseQ T;
+  std::memcpy(&T, pose12, 12 * sizeof(float));
+  T.direction = direction;
+  const std::vector<float> scale(sf, sf + nLevels);
+  for (int i = 0; i < n; i++) {
+    ProjectedPoint keep = views[i];
+    double m = 1e30;
+    ProjectedPoint v{};
+    v.angle = angle[i];
+    if (flags[i] & 1) v = project_last_frame_point(T, pos + 3 * i, octave[i], angle[i], th, scale, minX, minY, maxX, maxY, &m);
+    v.has_observations = (flags[i] >> 1) & 1;
+    std::memcpy(v.desc, keep.desc, 32);
+    views[i] = v;
+    if (margins) margins[i] = m;
+  }
+}
+
 // Frame::isInFrustum for n points x one pose; views [n] (flags / descriptors are the caller's), margins [n][2] (may be NULL)
 void oro_is_in_frustum(const float* pose20, int n, const float* pos, const float* normal, const float* minDist, const float* maxDist,
                        float minX, float minY, float maxX, float maxY, float viewCosLimit, float logScaleFactor, int nlevels,

@@ -136,6 +136,8 @@ def lib():
         L.orbx_search_by_projection_keyframe.argtypes = [i, vp, vp, i, f, f, f, f, vp, i, i, i, vp, vp]
         L.orbx_map_upload.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
         L.orbx_project_map_points_batch.argtypes = [vp, i, vp, f, f, f, f, f, vp, vp]
+        L.orbx_last_frames_upload.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp]
+        L.orbx_project_last_frames_batch.argtypes = [vp, i, vp, f, f, f, f, f, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
         L.orbx_search_for_triangulation_rig.argtypes = [i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, vp, i, vp, vp, vp, i, i, vp, vp, i, vp,
@@ -358,6 +360,32 @@ class ORBextractor:
         _check(lib().orbx_project_map_points_batch(self._h, F, _p(poses), bounds[0], bounds[1], bounds[2], bounds[3],
                                                    float(viewing_cos_limit), None if sk is None else _p(sk),
                                                    None if views is None else _p(views)))
+        return views
+
+    def last_frames_upload(self, n_points, world_pos, octave, angle, desc, flags):
+        """The LastFrames of the batch's cameras as structure-of-arrays on the device (orbx_last_frames_upload): n_points [F];
+        world_pos [F][stride][3], octave / angle / flags [F][stride], desc [F][stride][32]; flags bit 0 = map point present and no
+        outlier, bit 1 = Observations() > 0."""
+        npts = np.ascontiguousarray(n_points, np.int32)
+        F = len(npts)
+        pos = np.ascontiguousarray(world_pos, np.float32).reshape(F, -1, 3)
+        stride = pos.shape[1]
+        a = [pos, np.ascontiguousarray(octave, np.int32).reshape(F, stride), np.ascontiguousarray(angle, np.float32).reshape(F, stride),
+             np.ascontiguousarray(desc, np.uint8).reshape(F, stride, 32), np.ascontiguousarray(flags, np.uint8).reshape(F, stride)]
+        _check(lib().orbx_last_frames_upload(self._h, F, stride, _p(npts), *[_p(x) for x in a]))
+        self._lf_n, self._lf_stride = npts.copy(), stride
+
+    def project_last_frames(self, poses, directions, bounds, th, want_views=False):
+        """The projection block of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1606-1669) for every uploaded
+        LastFrame point on the device (orbx_project_last_frames_batch): poses [F][12] floats (Sophus quaternion x y z w, translation,
+        fx fy cx cy, bf), directions [F] (0 neither, 1 bForward, 2 bBackward).  Returns the views (PP_DTYPE [F][stride]) if asked."""
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 12)
+        F = len(poses)
+        rec = np.zeros(F, np.dtype([("p", "<f4", (12,)), ("direction", "<i4")]))
+        rec["p"], rec["direction"] = poses, np.ascontiguousarray(directions, np.int32)
+        views = np.zeros((F, self._lf_stride), PP_DTYPE) if want_views else None
+        _check(lib().orbx_project_last_frames_batch(self._h, F, _p(rec), bounds[0], bounds[1], bounds[2], bounds[3], float(th),
+                                                    None if views is None else _p(views)))
         return views
 
     def extract_batch_device(self, d_images_ptr, n_images, w, h, row_pitch, image_pitch, lap=None):
@@ -978,6 +1006,20 @@ class ORBmatcher:
         nm = np.zeros(n_frames, np.int32)
         _check(lib().orbx_search_by_projection_frame_batch(
             ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(pp), _p(npts), pp.shape[1],
+            int(self.mbCheckOrientation), int(stereo_pair0), None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
+
+    def SearchByProjectionFrameBatchDevice(self, ex, first_image, n_frames, bounds, occupied=None, stereo_pair0=-1):
+        """SearchByProjectionFrame on the frames of ex's last extraction batch with the views made ON THE DEVICE by
+        project_last_frames (orbx_search_by_projection_frame_batch with points = NULL)."""
+        npts = np.ascontiguousarray(ex._lf_n[:n_frames], np.int32)
+        cap = ex.capacity
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, cap)
+        occ = np.zeros((n_frames, cap), np.uint8)
+        match = np.full((n_frames, cap), -1, np.int32)
+        nm = np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_frame_batch(
+            ex._h, int(first_image), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], None, _p(npts), ex._lf_stride,
             int(self.mbCheckOrientation), int(stereo_pair0), None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
         return nm, match, occ
 

@@ -711,13 +711,20 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     if (n_points[f] > 15000) return fail(ORBX_E_CAPACITY, "more than 15000 points in a frame");
     maxPts = std::max(maxPts, n_points[f]);
   }
+  const bool devViewsP = mode == 1 && !pts && maxPts > 0;  // views made on the device by orbx_project_last_frames_batch
+  if (devViewsP) {
+    if (ex->pviewsFrames < n_frames || ex->lfStride != stride)
+      return fail(ORBX_E_BADARG, "points == NULL needs a preceding orbx_project_last_frames_batch with the same frames and points_stride");
+    for (int f = 0; f < n_frames; f++)
+      if (n_points[f] != ex->lfN[f]) return fail(ORBX_E_BADARG, "points == NULL: n_points[f] must equal the uploaded LastFrame's");
+  }
   const bool devViews = mode == 0 && !mps && maxPts > 0;   // views made on the device by orbx_project_map_points_batch
   if (devViews) {
     if (ex->viewsFrames < n_frames || ex->viewsStride != stride) return fail(ORBX_E_BADARG, "map_points == NULL needs a preceding orbx_project_map_points_batch with the same frames and points_stride == its n");
     for (int f = 0; f < n_frames; f++)
       if (n_points[f] != ex->viewsStride) return fail(ORBX_E_BADARG, "map_points == NULL: n_map_points[f] must equal the uploaded map's n");
   }
-  if (maxPts && !devViews && (mode == 0 ? !mps : !pts)) return fail(ORBX_E_BADARG, "null points");
+  if (maxPts && !devViews && !devViewsP && (mode == 0 ? !mps : !pts)) return fail(ORBX_E_BADARG, "null points");
   const int nlevels = ex->prm.nlevels;
   if (mode == 0 && !devViews)
     for (int f = 0; f < n_frames; f++)
@@ -750,7 +757,7 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
   if (!occupied_in) occ0.assign((size_t)F * cap, 0);
   // (the header only promises points[f * stride .. f * stride + n_points[f]) of every frame: the last frame's padding is not read)
   const size_t ptsRead = ((size_t)(F - 1) * std::max(stride, 1) + (size_t)std::max(n_points[F - 1], 0)) * ptBytes;
-  const size_t oPts = devViews ? pk.add(nullptr, 16)
+  const size_t oPts = (devViews || devViewsP) ? pk.add(nullptr, 16)
                                : pk.add(maxPts ? (mode == 0 ? (const void*)mps : (const void*)pts) : nullptr,
                                         (size_t)F * std::max(stride, 1) * ptBytes, ptsRead);
   const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
@@ -786,7 +793,7 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     a.uRight = stereo_pair0 >= 0 ? ex->d_uR.p + (size_t)(stereo_pair0 + f) * cap : nullptr;
     a.scale = pk.ptr<float>(oSf);
     a.mps = mode == 0 ? (devViews ? ex->d_views.p : pk.ptr<orbx_map_point_view>(oPts)) + (size_t)f * stride : nullptr;
-    a.pts = mode == 1 ? pk.ptr<orbx_projected_point>(oPts) + (size_t)f * stride : nullptr;
+    a.pts = mode == 1 ? (devViewsP ? ex->d_pviews.p : pk.ptr<orbx_projected_point>(oPts)) + (size_t)f * stride : nullptr;
     a.nmp = n_points[f];
     a.mode = mode; a.checkOri = check_ori; a.maxDist = 100 /* TH_HIGH */; a.claimAll = 0;
     a.th = th; a.thFar = th_far; a.nnratio = nnratio; a.far = far_points;
@@ -841,13 +848,18 @@ int proj_batch_impl(orbx_extractor* ex, int first_image, int n_frames, float min
     if (occupied_in) std::memcpy(occ, occupied_in + (size_t)f * cap, cap); else std::memset(occ, 0, cap);
     for (int i = 0; i < cap; i++) mt[i] = -1;
     std::vector<orbx_map_point_view> hv;
+    std::vector<orbx_projected_point> hp;
     if (devViews) {   // (the one-shot path takes host arrays)
       hv.resize((size_t)stride);
       HIPC(hipMemcpy(hv.data(), ex->d_views.p + (size_t)f * stride, (size_t)stride * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
     }
+    if (devViewsP) {
+      hp.resize((size_t)stride);
+      HIPC(hipMemcpy(hp.data(), ex->d_pviews.p + (size_t)f * stride, (size_t)stride * sizeof(orbx_projected_point), hipMemcpyDeviceToHost));
+    }
     rc = search_by_projection_impl(ex->device, k.data(), d.data(), stereo_pair0 >= 0 ? ur.data() : nullptr, n, min_x, min_y, max_x,
                                    max_y, ex->scale.data(), nlevels, mode == 0 ? (devViews ? hv.data() : mps + (size_t)f * stride) : nullptr,
-                                   mode == 1 ? pts + (size_t)f * stride : nullptr, n_points[f], th, far_points, th_far, nnratio,
+                                   mode == 1 ? (devViewsP ? hp.data() : pts + (size_t)f * stride) : nullptr, n_points[f], th, far_points, th_far, nnratio,
                                    check_ori, occ, mt);
     if (rc < 0) return rc;
     n_matches[f] = rc;
@@ -919,6 +931,69 @@ int orbx_project_map_points_batch(orbx_extractor* ex, int n_frames, const orbx_f
   }
   ex->viewsFrames = n_frames;
   ex->viewsStride = n;
+  return ORBX_OK;
+}
+
+int orbx_last_frames_upload(orbx_extractor* ex, int n_frames, int points_stride, const int32_t* n_points, const float* world_pos,
+                            const int32_t* octave, const float* angle, const uint8_t* desc, const uint8_t* flags) {
+  if (!ex || n_frames < 0 || n_frames > 4096 || points_stride < 0 || points_stride > 15000 ||
+      (n_frames && (!n_points || (points_stride && (!world_pos || !octave || !angle || !desc || !flags)))))
+    return fail(ORBX_E_BADARG, "bad argument (at most 15000 points per frame)");
+  for (int f = 0; f < n_frames; f++)
+    if (n_points[f] < 0 || n_points[f] > points_stride) return fail(ORBX_E_BADARG, "n_points[f] outside [0, points_stride]");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  HIPC(hipStreamSynchronize(ex->stream));   // (a projection of the previous upload may still read the arrays)
+  ex->lfFrames = 0;
+  ex->pviewsFrames = 0;
+  const size_t m = std::max<size_t>((size_t)n_frames * points_stride, 1);
+  hipError_t e = ex->d_lfPos.grow(3 * m);
+  if (e == hipSuccess) e = ex->d_lfAngle.grow(m);
+  if (e == hipSuccess) e = ex->d_lfOct.grow(m);
+  if (e == hipSuccess) e = ex->d_lfDesc.grow(32 * m);
+  if (e == hipSuccess) e = ex->d_lfFlags.grow(m);
+  if (e == hipSuccess) e = ex->d_lfN.grow((size_t)std::max(n_frames, 1));
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  const size_t n = (size_t)n_frames * points_stride;
+  if (n) {
+    HIPC(hipMemcpy(ex->d_lfPos.p, world_pos, n * 12, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_lfOct.p, octave, n * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_lfAngle.p, angle, n * 4, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_lfDesc.p, desc, n * 32, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(ex->d_lfFlags.p, flags, n, hipMemcpyHostToDevice));
+  }
+  if (n_frames) HIPC(hipMemcpy(ex->d_lfN.p, n_points, (size_t)n_frames * sizeof(int), hipMemcpyHostToDevice));
+  ex->lfN.assign(n_points, n_points + n_frames);
+  ex->lfFrames = n_frames;
+  ex->lfStride = points_stride;
+  return ORBX_OK;
+}
+
+int orbx_project_last_frames_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose_q* poses, float min_x, float min_y,
+                                   float max_x, float max_y, float th, orbx_projected_point* views_out) {
+  if (!ex || n_frames < 0 || (n_frames && !poses)) return fail(ORBX_E_BADARG, "bad argument");
+  if (n_frames > ex->lfFrames) return fail(ORBX_E_BADARG, "more frames than LastFrames uploaded (orbx_last_frames_upload)");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  ex->pviewsFrames = 0;
+  if (n_frames == 0) return ORBX_OK;
+  const int stride = ex->lfStride;
+  hipError_t e = ex->d_posesQ.grow((size_t)n_frames);
+  if (e == hipSuccess) e = ex->d_pviews.grow((size_t)n_frames * std::max(stride, 1));
+  if (e == hipSuccess) e = ex->d_scaleF.grow((size_t)ex->prm.nlevels);
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  HIPC(hipMemcpyAsync(ex->d_posesQ.p, poses, (size_t)n_frames * sizeof(orbx_frame_pose_q), hipMemcpyHostToDevice, ex->stream));
+  HIPC(hipMemcpyAsync(ex->d_scaleF.p, ex->scale.data(), (size_t)ex->prm.nlevels * sizeof(float), hipMemcpyHostToDevice, ex->stream));
+  LastProjArgs a{};
+  a.pos = ex->d_lfPos.p; a.octave = ex->d_lfOct.p; a.angle = ex->d_lfAngle.p; a.desc = ex->d_lfDesc.p; a.flags = ex->d_lfFlags.p;
+  a.npts = ex->d_lfN.p; a.poses = ex->d_posesQ.p; a.scale = ex->d_scaleF.p; a.views = ex->d_pviews.p;
+  a.stride = stride; a.nlevels = ex->prm.nlevels;
+  a.minX = min_x; a.minY = min_y; a.maxX = max_x; a.maxY = max_y; a.th = th;
+  HIPC(launch_project_last(a, n_frames, ex->stream));
+  if (views_out && stride)
+    HIPC(hipMemcpyAsync(views_out, ex->d_pviews.p, (size_t)n_frames * stride * sizeof(orbx_projected_point), hipMemcpyDeviceToHost, ex->stream));
+  HIPC(hipStreamSynchronize(ex->stream));   // pageable host sources: the call returns when they have been consumed
+  ex->pviewsFrames = n_frames;
   return ORBX_OK;
 }
 

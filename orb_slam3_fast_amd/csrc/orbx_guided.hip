@@ -1667,6 +1667,60 @@ hipError_t launch_project_map(const MapProjArgs& a, int nFrames, hipStream_t s) 
   return hipGetLastError();
 }
 
+// The projection block of ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1606-1669, pinhole
+// case) for every (LastFrame point, camera) of a batch: Tcw * x3Dw is Sophus' unit-quaternion sandwich
+// (Thirdparty/Sophus/sophus/so3.hpp:358-366: uv = q.vec x p; uv += uv; p + q.w uv + q.vec x uv) plus the translation, in Eigen's
+// coefficient order without contraction; invzc = 1.0 / z in double, narrowed (:1626); Pinhole::project; the bounds skips; radius,
+// the level window by the caller's forward / backward decision, ur.  Writes the 64-byte orbx_projected_point records the matcher
+// kernels consume -- they stay in HBM.
+__global__ __launch_bounds__(256) void k_project_last(LastProjArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  if (i >= a.stride) return;
+  const size_t e = (size_t)f * a.stride + i;
+  const orbx_frame_pose_q& T = a.poses[f];
+  const uint8_t fl = i < a.npts[f] ? a.flags[e] : 0;
+  const uint4* d4 = reinterpret_cast<const uint4*>(a.desc + e * 32);
+  const uint4 da = d4[0], db = d4[1];
+  float u = 0.f, v = 0.f, ur = 0.f, radius = 0.f;
+  int minL = 0, maxL = 0;
+  bool ok = (fl & 1) != 0;
+  if (ok) {
+    const float px = a.pos[3 * e], py = a.pos[3 * e + 1], pz = a.pos[3 * e + 2];
+    const float qx = T.q[0], qy = T.q[1], qz = T.q[2], qw = T.q[3];
+    float ux = __fsub_rn(__fmul_rn(qy, pz), __fmul_rn(qz, py)), uy = __fsub_rn(__fmul_rn(qz, px), __fmul_rn(qx, pz)),
+          uz = __fsub_rn(__fmul_rn(qx, py), __fmul_rn(qy, px));
+    ux = __fadd_rn(ux, ux); uy = __fadd_rn(uy, uy); uz = __fadd_rn(uz, uz);
+    const float cxv = __fsub_rn(__fmul_rn(qy, uz), __fmul_rn(qz, uy)), cyv = __fsub_rn(__fmul_rn(qz, ux), __fmul_rn(qx, uz)),
+                czv = __fsub_rn(__fmul_rn(qx, uy), __fmul_rn(qy, ux));
+    const float xc = __fadd_rn(__fadd_rn(__fadd_rn(px, __fmul_rn(qw, ux)), cxv), T.t[0]);
+    const float yc = __fadd_rn(__fadd_rn(__fadd_rn(py, __fmul_rn(qw, uy)), cyv), T.t[1]);
+    const float zc = __fadd_rn(__fadd_rn(__fadd_rn(pz, __fmul_rn(qw, uz)), czv), T.t[2]);
+    const float invzc = (float)__ddiv_rn(1.0, (double)zc);
+    ok = !(invzc < 0.f);
+    u = __fadd_rn(__fdiv_rn(__fmul_rn(T.fx, xc), zc), T.cx);
+    v = __fadd_rn(__fdiv_rn(__fmul_rn(T.fy, yc), zc), T.cy);
+    ok = ok && u == u && v == v && !(u < a.minX || u > a.maxX) && !(v < a.minY || v > a.maxY);
+    const int oct = min(max(a.octave[e], 0), a.nlevels - 1);
+    radius = __fmul_rn(a.th, a.scale[oct]);
+    if (T.direction == 1) { minL = oct; maxL = -1; }
+    else if (T.direction == 2) { minL = 0; maxL = oct; }
+    else { minL = oct - 1; maxL = oct + 1; }
+    ur = __fsub_rn(u, __fmul_rn(T.bf, invzc));
+  }
+  uint32_t* o = reinterpret_cast<uint32_t*>(a.views + e);   // 64-byte records: 16 dwords
+  const uint32_t z = 0u;
+  o[0] = ok ? __builtin_bit_cast(uint32_t, u) : z; o[1] = ok ? __builtin_bit_cast(uint32_t, v) : z;
+  o[2] = ok ? __builtin_bit_cast(uint32_t, ur) : z; o[3] = ok ? __builtin_bit_cast(uint32_t, radius) : z;
+  o[4] = __builtin_bit_cast(uint32_t, i < a.npts[f] ? a.angle[e] : 0.f);
+  o[5] = ok ? (uint32_t)minL : z; o[6] = ok ? (uint32_t)maxL : z;
+  o[7] = (ok ? 1u : 0u) | ((uint32_t)((fl >> 1) & 1) << 8);
+  o[8] = da.x; o[9] = da.y; o[10] = da.z; o[11] = da.w; o[12] = db.x; o[13] = db.y; o[14] = db.z; o[15] = db.w;
+}
+hipError_t launch_project_last(const LastProjArgs& a, int nFrames, hipStream_t s) {
+  if (a.stride > 0 && nFrames > 0) hipLaunchKernelGGL(k_project_last, dim3((a.stride + 255) / 256, nFrames), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_proj_fill(const ProjArgs& a, hipStream_t s) {
   if (a.nmp > 0) hipLaunchKernelGGL(k_proj_cands<false>, dim3((a.nmp + 3) / 4), dim3(256), 0, s, ProjRef<false>{a}, 1);
   const size_t lds = (a.mode == 1 && a.checkOri) ? (size_t)(a.nmp + 4) * 4 : 16;  // one int per accepted match

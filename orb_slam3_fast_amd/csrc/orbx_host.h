@@ -277,6 +277,15 @@ struct orbx_extractor {
   DevBuf<uint8_t> d_mapDesc, d_mapFlags, d_mapSkip;
   DevBuf<orbx_frame_pose> d_poses;
   DevBuf<orbx_map_point_view> d_views;
+  // LastFrames of the batch's cameras (orbx_last_frames_upload) and their device-made projections (orbx_project_last_frames_batch)
+  DevBuf<float> d_lfPos, d_lfAngle;
+  DevBuf<int> d_lfOct, d_lfN;
+  DevBuf<uint8_t> d_lfDesc, d_lfFlags;
+  DevBuf<orbx_frame_pose_q> d_posesQ;
+  DevBuf<orbx_projected_point> d_pviews;
+  DevBuf<float> d_scaleF;          // mvScaleFactors for k_project_last
+  int lfFrames = 0, lfStride = 0, pviewsFrames = 0;
+  std::vector<int> lfN;
   int mapN = 0, viewsFrames = 0, viewsStride = 0;
   uint8_t* hostResults = nullptr;  // pinned: results of up to two images land here with async copies and ONE sync
   int hostResImages = 0;           // images of the last single-frame host entry in that block (orbx_host_results)

@@ -377,6 +377,20 @@ struct MapProjArgs {
   float minX, minY, maxX, maxY, viewCosLimit, logScaleFactor;
 };
 hipError_t launch_project_map(const MapProjArgs& a, int nFrames, hipStream_t s);
+// k_project_last: the projection block of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1606-1669) on the device
+struct LastProjArgs {
+  const float* pos;              // [frames][stride][3]
+  const int* octave;             // [frames][stride]
+  const float* angle;
+  const uint8_t *desc, *flags;   // [frames][stride][32] / [frames][stride]
+  const int* npts;               // [frames]
+  const orbx_frame_pose_q* poses;
+  const float* scale;            // mvScaleFactors
+  orbx_projected_point* views;   // [frames][stride]
+  int stride, nlevels;
+  float minX, minY, maxX, maxY, th;
+};
+hipError_t launch_project_last(const LastProjArgs& a, int nFrames, hipStream_t s);
 hipError_t launch_proj_batch(const ProjArgs* d_frames, int nFrames, int maxPts, int maxN2, int mode, int checkOri, int rounds,
                              hipStream_t s);                                        // all frames of a batch, one launch per kernel
 

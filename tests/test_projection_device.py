@@ -125,3 +125,99 @@ def test_device_projection_and_matcher_against_the_oracle(oracle):
     # argument errors
     with pytest.raises(orbx.OrbxError):
         orbx.ORBmatcher(0.8, True).SearchByProjectionBatchDevice(ex, 0, F + 1, bounds)       # more frames than were projected
+
+
+def _quat(R):
+    """Unit quaternion (x, y, z, w) of a rotation matrix (w > 0: small rotations), float64."""
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+
+
+@pytest.mark.gpu
+def test_device_projection_of_last_frames_and_matcher_against_the_oracle(oracle):
+    """Round 6, the frame-to-frame flavour: the projection block of SearchByProjection(CurrentFrame, LastFrame)
+    (src/ORBmatcher.cc:1606-1669; Tcw * x3Dw = Sophus' quaternion sandwich, Thirdparty/Sophus/sophus/so3.hpp:358-366) on the device
+    for the LastFrames of five cameras, consumed in place by the batched matcher.  Parity as above: a gate decision may differ from
+    the oracle's only where the oracle reports the decisive quantity within 1e-5 of its threshold, coordinates within 1e-5
+    relative (in fact bit-equal up to the division), level windows / radius / angle / descriptors equal; the MATCHER is exact: on
+    the device-made views the oracle's SearchByProjectionFrame returns the device's matches bit for bit, with and without the
+    stereo-consistency gate, and the device-view call equals the host-view batched entry."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h, nf, F = 640, 480, 1000, 5
+    rng = np.random.default_rng(77)
+    cur = [synth.stereo_pair(w, h, 160 + f, 1) for f in range(F)]
+    dev = DeviceBuffer.from_numpy(np.stack([c[0] for c in cur] + [c[1] for c in cur]))
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * F)
+    ex.extract_batch_device(dev.ptr.value, 2 * F, w, h, w, w * h)
+    orbx.stereo_match_async(ex, ex, 0.12 * 532.03, 0.12, first_left=0, first_right=F, n_pairs=F)
+    ex.sync()
+    frames = [ex.download(f)[1:] for f in range(F)]
+    fx, cx, cy = 420.0, w / 2.0, h / 2.0
+    bf = 0.12 * fx
+    stride = 700
+    npts = np.array([700, 650, 0, 512, 699], np.int32)
+    pos = np.zeros((F, stride, 3), np.float32)
+    octv = np.zeros((F, stride), np.int32)
+    ang = np.zeros((F, stride), np.float32)
+    desc = rng.integers(0, 256, (F, stride, 32), dtype=np.uint8)
+    flags = np.zeros((F, stride), np.uint8)
+    poses = np.zeros((F, 12), np.float32)
+    directions = np.array([0, 1, 2, 0, 1], np.int32)
+    for f in range(F):
+        R = _rot(*(rng.normal(0, 0.01, 3)))
+        t = rng.normal(0, 0.05, 3)
+        poses[f] = np.concatenate([_quat(R), t, [fx, fx, cx, cy, bf]])
+        k, d = frames[f]
+        n = int(npts[f])
+        src = rng.integers(0, len(k), n)                     # the current-frame keypoint each LastFrame point lands near
+        z = rng.uniform(2.0, 30.0, n)
+        pc = np.stack([(k["x"][src] + rng.normal(0, 1.5, n) - cx) / fx * z, (k["y"][src] + rng.normal(0, 1.5, n) - cy) / fx * z, z], 1)
+        clutter = rng.random(n) < 0.15                        # behind the camera / outside the image
+        pc[clutter] = rng.normal(0, 6.0, (int(clutter.sum()), 3))
+        pos[f, :n] = (pc - t) @ R                             # x3Dw = R^T (x3Dc - t)
+        octv[f, :n] = np.clip(k["octave"][src] + rng.integers(-1, 2, n), 0, 7)
+        ang[f, :n] = k["angle"][src] + rng.normal(0, 4, n)
+        desc[f, :n] = d[src] ^ np.packbits(rng.random((n, 32, 8)) < 0.03, axis=2).reshape(n, 32)
+        flags[f, :n] = (rng.random(n) < 0.9).astype(np.uint8) | ((rng.random(n) < 0.85).astype(np.uint8) << 1)
+    bounds = (0.0, 0.0, float(w), float(h))
+    th = 7.0
+    ex.last_frames_upload(npts, pos, octv, ang, desc, flags)
+    views = ex.project_last_frames(poses, directions, bounds, th, want_views=True)
+    sf = ex.GetScaleFactors()
+    n_valid = n_gate = 0
+    for f in range(F):
+        n = int(npts[f])
+        ov, mg = oracle.project_last_frame(poses[f], directions[f], pos[f, :n], octv[f, :n], ang[f, :n], flags[f, :n], desc[f, :n], th, sf,
+                                           bounds)
+        v = views[f, :n]
+        assert (views[f, n:]["valid"] == 0).all()
+        assert np.array_equal(v["desc"], ov["desc"]) and np.array_equal(v["has_observations"], ov["has_observations"])
+        assert np.array_equal(v["angle"].view(np.uint32), ov["angle"].view(np.uint32))
+        diff = v["valid"] != ov["valid"]
+        assert (mg[diff] < 1e-5).all(), (f, mg[diff])
+        n_gate += int(diff.sum())
+        both = (v["valid"] != 0) & (ov["valid"] != 0)
+        n_valid += int(both.sum())
+        for name in ("u", "v", "ur"):
+            a, b = v[name][both].astype(np.float64), ov[name][both].astype(np.float64)
+            assert (np.abs(a - b) <= 1e-5 * np.maximum(1.0, np.abs(b))).all(), name
+        for name in ("radius", "min_level", "max_level"):
+            assert np.array_equal(v[name][both], ov[name][both]), name
+    assert n_valid > 1500 and n_gate <= 3, (n_valid, n_gate)
+    occ_in = (rng.random((F, ex.capacity)) < 0.04).astype(np.uint8)
+    u_all, _ = orbx.ComputeStereoMatches(ex, ex, 0.12 * 532.03, 0.12, first_left=0, first_right=F, n_pairs=F)
+    total = 0
+    for use_ur in (True, False):
+        m = orbx.ORBmatcher(0.9, True)
+        nm, match, occ = m.SearchByProjectionFrameBatchDevice(ex, 0, F, bounds, occ_in, stereo_pair0=0 if use_ur else -1)
+        for f in range(F):
+            k, d = frames[f]
+            on, om, oo = oracle.search_by_projection_frame(k, d, u_all[f, :len(k)] if use_ur else None, bounds, views[f, :int(npts[f])], True,
+                                                           occ_in[f, :len(k)])
+            assert nm[f] == on and np.array_equal(match[f, :len(k)], om) and np.array_equal(occ[f, :len(k)], oo), (use_ur, f)
+            total += on
+        nm2, match2, occ2 = m.SearchByProjectionFrameBatch(ex, 0, F, bounds, views, npts, occ_in, stereo_pair0=0 if use_ur else -1)
+        assert np.array_equal(nm, nm2) and np.array_equal(match, match2) and np.array_equal(occ, occ2)
+    assert total > 600, total
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBmatcher(0.9, True).SearchByProjectionFrameBatchDevice(ex, 0, F + 1, bounds)

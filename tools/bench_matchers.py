@@ -216,6 +216,39 @@ print("%-62s %12.3f   (%.3f ms per frame, of which isInFrustum + PredictScale of
       % ("SearchByProjection(F, MapPoints), device-side projection, %d frames" % FB, tb, tb / FB, nmap, FB, tp, int(r[0][0]), posesB.nbytes,
          mpsB.nbytes))
 
+# the frame-to-frame matcher with the projection ON THE DEVICE (round 6b): the LastFrames' points (world position, octave, angle,
+# descriptor) are uploaded once per step as SoA, a call sends 32 poses (52 B each), the projection block of
+# SearchByProjection(CurrentFrame, LastFrame) runs in k_project_last, the views never exist on the host
+npl = len(pts)
+zl = 8.0
+posL = np.stack([np.stack([(pts["u"] + np.float32(0.25 * i) - w / 2) / fxp * zl, (pts["v"] - h / 2) / fxp * zl, np.full(npl, zl)], 1)
+                 for i in range(FB)]).astype(np.float32)
+octL = np.stack([np.clip(pts["min_level"] + 1, 0, 7)] * FB).astype(np.int32)
+angL = np.stack([pts["angle"]] * FB).astype(np.float32)
+descL = np.stack([pts["desc"]] * FB)
+flagsL = np.stack([(pts["valid"] | (pts["has_observations"] << 1)).astype(np.uint8)] * FB)
+posesQ = np.stack([np.concatenate([[0, 0, 0, 1], [0, 0, 0], [fxp, fxp, w / 2, h / 2, 0.12 * fxp]]) for i in range(FB)]).astype(np.float32)
+dirsQ = np.zeros(FB, np.int32)
+exb.last_frames_upload(np.full(FB, npl, np.int32), posL, octL, angL, descL, flagsL)
+thL = float(pts["radius"][pts["valid"] != 0][0] / exb.GetScaleFactors()[int(octL[0][pts["valid"] != 0][0])]) if (pts["valid"] != 0).any() else 7.0
+def dev_step_frame():
+    exb.project_last_frames(posesQ, dirsQ, bounds, thL)
+    return m.SearchByProjectionFrameBatchDevice(exb, 0, FB, bounds, occB)
+for _ in range(3):
+    r = dev_step_frame()
+t0 = time.perf_counter()
+for _ in range(reps):
+    exb.project_last_frames(posesQ, dirsQ, bounds, thL)
+tp = (time.perf_counter() - t0) / reps * 1e3
+t0 = time.perf_counter()
+for _ in range(reps):
+    r = dev_step_frame()
+tb = (time.perf_counter() - t0) / reps * 1e3
+print("%-62s %12.3f   (%.3f ms per frame, of which the projection of %d points x %d poses on the device %.3f ms; %d matches in frame 0; "
+      "per call %d B of poses instead of %d B of host-projected points)"
+      % ("SearchByProjection(Cur, Last), device-side projection, %d frames" % FB, tb, tb / FB, npl, FB, tp, int(r[0][0]),
+         posesQ.nbytes + dirsQ.nbytes, ptsB.nbytes))
+
 # batched SearchForInitialization on the frames of an extraction batch (round 5): F1 = the previous frame's keypoints from the
 # host for every pair, F2 = the batch's images (exb holds L1, R1 alternating: even images are the frame `kc` came from)
 k1B, d1B, prevB = [kp] * FB, [dp] * FB, [prev] * FB
