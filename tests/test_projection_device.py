@@ -221,3 +221,49 @@ def test_device_projection_of_last_frames_and_matcher_against_the_oracle(oracle)
     assert total > 600, total
     with pytest.raises(orbx.OrbxError):
         orbx.ORBmatcher(0.9, True).SearchByProjectionFrameBatchDevice(ex, 0, F + 1, bounds)
+
+
+def test_oracle_last_frame_projection_against_a_float64_model(oracle):
+    """The oracle's restatement of the projection block (Sophus' quaternion sandwich in float) against an independent model: the
+    rotation MATRIX of the same quaternion, everything in float64.  Coordinates agree to float rounding, the gates wherever the
+    float64 value is not within 1e-4 of a threshold, the level windows follow the direction flag, invalid records are zeroed."""
+    rng = np.random.default_rng(5)
+    w, h, fx = 640.0, 480.0, 420.0
+    n = 4000
+    R = _rot(0.02, -0.015, 0.03)
+    t = np.array([0.04, -0.02, 0.1])
+    q = _quat(R)
+    pose = np.concatenate([q, t, [fx, fx, w / 2, h / 2, 0.12 * fx]]).astype(np.float32)
+    pc = np.stack([rng.uniform(-12, 12, n), rng.uniform(-9, 9, n), rng.uniform(-2, 20, n)], 1)
+    pw = ((pc - t) @ R).astype(np.float32)
+    octv = rng.integers(0, 8, n).astype(np.int32)
+    ang = rng.uniform(0, 360, n).astype(np.float32)
+    flags = ((rng.random(n) < 0.9).astype(np.uint8)) | ((rng.random(n) < 0.5).astype(np.uint8) << 1)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sf = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    q64, t64 = pose[:4].astype(np.float64), pose[4:7].astype(np.float64)
+    x, y, z, ww = q64
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * ww), 2 * (x * z + y * ww)],
+                   [2 * (x * y + z * ww), 1 - 2 * (x * x + z * z), 2 * (y * z - x * ww)],
+                   [2 * (x * z - y * ww), 2 * (y * z + x * ww), 1 - 2 * (x * x + y * y)]])
+    X = pw.astype(np.float64) @ Rq.T + t64
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = fx * X[:, 0] / X[:, 2] + w / 2
+        v = fx * X[:, 1] / X[:, 2] + h / 2
+    for direction in (0, 1, 2):
+        views, _ = oracle.project_last_frame(pose, direction, pw, octv, ang, flags, desc, 7.0, sf, (0.0, 0.0, w, h))
+        want = ((flags & 1) != 0) & (X[:, 2] > 0) & (u >= 0) & (u <= w) & (v >= 0) & (v <= h)
+        near = (np.abs(X[:, 2]) < 1e-4) | (np.abs(u) < 1e-3) | (np.abs(u - w) < 1e-3) | (np.abs(v) < 1e-3) | (np.abs(v - h) < 1e-3)
+        ok = views["valid"] != 0
+        assert np.array_equal(ok[~near], want[~near])
+        assert ok.sum() > 500
+        assert (np.abs(views["u"][ok] - u[ok]) < 2e-3).all() and (np.abs(views["v"][ok] - v[ok]) < 2e-3).all()
+        assert (np.abs(views["ur"][ok] - (u[ok] - 0.12 * fx / X[ok, 2])) < 2e-3).all()
+        assert np.array_equal(views["radius"][ok], (np.float32(7.0) * sf[octv[ok]]).astype(np.float32))
+        lo = {0: octv - 1, 1: octv, 2: np.zeros_like(octv)}[direction]
+        hi = {0: octv + 1, 1: np.full_like(octv, -1), 2: octv}[direction]
+        assert np.array_equal(views["min_level"][ok], lo[ok]) and np.array_equal(views["max_level"][ok], hi[ok])
+        bad = ~ok
+        assert not views["u"][bad].any() and not views["radius"][bad].any() and not views["min_level"][bad].any()
+        assert np.array_equal(views["angle"], ang) and np.array_equal(views["has_observations"], (flags >> 1) & 1)
+        assert np.array_equal(views["desc"], desc)
