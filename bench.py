@@ -922,6 +922,19 @@ def preproc_leg(orbx, np):
     ku = out["rectify_1280x720"]["roofline"]["kernel_us_rocprof"]
     if ku:
         out["rectify_1280x720"]["roofline"]["kernel_frac"] = round(nb / (ku * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    rgbf = DeviceBuffer.from_numpy(np.stack([np.stack([L, R, L], 2), np.stack([R, L, R], 2)] * (B // 2)))
+    pg = orbx.Preproc(w, h, channels=3, rgb=True, max_batch=B)
+    t = timed(lambda: pg.run_device(rgbf.ptr.value, B, 3 * w, 3 * w * h))
+    nb = B * 4 * w * h
+    out["gray_1280x720x3"] = {"value": round(B / t, 1), "unit": "frames/s", "us_per_batch": round(t * 1e6, 2), "batch": B,
+                              "roofline": {"kernel": "k_cvt_gray16", "bound": "hbm", "achieved": round(nb / t / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(nb / t / 1e9 / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes_per_launch": nb, "traffic": traf.get("k_cvt_gray16"),
+                                           "kernel_us_rocprof": rocprof_us("r6_preproc_gray_stats.csv", "k_cvt_gray16")}}
+    ku = out["gray_1280x720x3"]["roofline"]["kernel_us_rocprof"]
+    if ku:
+        out["gray_1280x720x3"]["roofline"]["kernel_frac"] = round(nb / (ku * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    del rgbf, pg
     w2 = h2 = 512
     f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
     pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)

@@ -42,9 +42,50 @@ __global__ __launch_bounds__(256) void k_resize_generic(const uint8_t* __restric
   }
 }
 
+// The same conversion as a streaming kernel (round 6): a thread owns 16 consecutive pixels of a row -- three (four) 16-byte loads,
+// one 16-byte store, eight vector instructions per pixel (byte extract x 3, 24-bit multiply-add x 3, shift, pack) -- for rows
+// whose pixels start on 16-byte boundaries (base and pitches multiples of 16; x is a multiple of 16, so x * cn is too).  The
+// last w % 16 pixels of a row and unaligned frames go through k_cvt_gray.  1 B written + cn B read per pixel: HBM-bound.
+template <int CN>
+__global__ __launch_bounds__(256) void k_cvt_gray16(const uint8_t* __restrict__ src, int segs, int h, long long sp, long long sip, int rgb,
+                                                    uint8_t* __restrict__ dst, long long dp, long long dip) {
+  const int item = blockIdx.x * 256 + threadIdx.x;   // (row, 16-pixel segment), row-major
+  if (item >= segs * h) return;
+  const int y = item / segs, sg = item - y * segs;
+  const uint4* S = reinterpret_cast<const uint4*>(src + blockIdx.y * sip + y * sp + (long long)sg * 16 * CN);
+  uint32_t d[4 * CN];
+#pragma unroll
+  for (int k = 0; k < CN; k++) {
+    const uint4 q = S[k];
+    d[4 * k] = q.x; d[4 * k + 1] = q.y; d[4 * k + 2] = q.z; d[4 * k + 3] = q.w;
+  }
+  const uint32_t w0 = rgb ? 9798u : 3735u, w2 = rgb ? 3735u : 9798u;   // weight of channel 0 / channel 2 (R or B first)
+  uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int px = 0; px < 16; px++) {
+    const int b0 = px * CN, b1 = b0 + 1, b2 = b0 + 2;   // byte positions of the pixel's three colour channels (compile time)
+    const uint32_t c0 = (d[b0 >> 2] >> (8 * (b0 & 3))) & 255u, c1 = (d[b1 >> 2] >> (8 * (b1 & 3))) & 255u,
+                   c2 = (d[b2 >> 2] >> (8 * (b2 & 3))) & 255u;
+    const uint32_t g = (__umul24(c0, w0) + __umul24(c1, 19235u) + __umul24(c2, w2) + 16384u) >> 15;
+    out[px >> 2] |= g << (8 * (px & 3));
+  }
+  *reinterpret_cast<uint4*>(dst + blockIdx.y * dip + y * dp + (long long)sg * 16) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 hipError_t launch_cvt_gray(const uint8_t* src, int w, int h, long long sp, long long sip, int cn, int rgb, uint8_t* dst,
                            long long dp, long long dip, int nimg, hipStream_t s) {
-  hipLaunchKernelGGL(k_cvt_gray, dim3((w + 255) / 256, h, nimg), dim3(256), 0, s, src, w, h, sp, sip, cn, rgb, dst, dp, dip);
+  const bool aligned = !(((uintptr_t)src | (uintptr_t)dst | (uintptr_t)sp | (uintptr_t)sip | (uintptr_t)dp | (uintptr_t)dip) & 15);
+  static const bool naive = getenv("ORBX_GRAY_NAIVE") && atoi(getenv("ORBX_GRAY_NAIVE")) != 0;   // A / B switch: the per-pixel kernel everywhere
+  const int segs = aligned && !naive && (cn == 3 || cn == 4) ? w / 16 : 0;
+  if (segs > 0) {
+    const dim3 grid((unsigned)(((long long)segs * h + 255) / 256), nimg);
+    if (cn == 3) hipLaunchKernelGGL(k_cvt_gray16<3>, grid, dim3(256), 0, s, src, segs, h, sp, sip, rgb, dst, dp, dip);
+    else hipLaunchKernelGGL(k_cvt_gray16<4>, grid, dim3(256), 0, s, src, segs, h, sp, sip, rgb, dst, dp, dip);
+  }
+  const int x0 = 16 * segs;   // the rest of every row, pixel by pixel
+  if (x0 < w)
+    hipLaunchKernelGGL(k_cvt_gray, dim3((w - x0 + 255) / 256, h, nimg), dim3(256), 0, s, src + (long long)x0 * cn, w - x0, h, sp, sip, cn, rgb,
+                       dst + x0, dp, dip);
   return hipGetLastError();
 }
 hipError_t launch_resize_generic(const uint8_t* src, int sw, int sh, long long sp, long long sip, int cn, uint8_t* dst, int dw,

@@ -42,7 +42,7 @@ def test_oracle_multichannel_resize_is_per_channel(oracle):
 def test_hip_preprocess_matches_oracle(oracle):
     import orb_slam3_fast_amd as orbx
     rng = np.random.default_rng(3)
-    for (h, w, cn) in ((480, 640, 3), (350, 601, 4), (33, 47, 3)):
+    for (h, w, cn) in ((480, 640, 3), (350, 601, 4), (33, 47, 3), (720, 1280, 3), (720, 1280, 4), (64, 1296, 3), (5, 16, 4)):   # (round 6: 16-pixel streaming form + row tails)
         img = _img(rng, h, w, cn)
         for rgb in (True, False):
             assert np.array_equal(orbx.cvtColorGray(img, rgb), oracle.cvt_gray(img, rgb))

@@ -2,6 +2,7 @@
 """Throughput of the device-resident pre-processing chain on synthetic frames resident in HBM:
   rectify : 64 x 1280x720 raw frames -> cv::remap with two float maps (left / right)        [C3-sized]
   clahe   : 64 x 512x512 frames -> CLAHE(3.0, 8x8)                                          [C4 / TUM-VI-sized]
+  gray    : 64 x 1280x720 RGB frames -> cv::cvtColor(RGB2GRAY)                              [colour cameras, Tracking::GrabImage*]
   chain   : CLAHE + remap + extraction of 32 stereo pairs 752x480 through orbx_extract_batch_raw_device
 Wall clock around synchronised runs (kernel durations: run under rocprofv3 --kernel-trace --stats)."""
 import json
@@ -30,7 +31,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()  # a generation-2 collection inside a 2 ms timing window would dominate it
-    only = sys.argv[1] if len(sys.argv) > 1 else None  # 'rectify' | 'clahe': just that stage (for kernel traces)
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # 'rectify' | 'clahe' | 'gray': just that stage (for kernel traces)
     out = {}
     B = 64
     w, h = 1280, 720
@@ -45,8 +46,14 @@ def main():
     f2 = DeviceBuffer.from_numpy(np.stack([synth.mono_frame(w2, h2, i) for i in range(4)] * (B // 4)))
     pc = orbx.Preproc(w2, h2, clahe=(3.0, (8, 8)), max_batch=B)
     t = timed(lambda: pc.run_device(f2.ptr.value, B, w2, w2 * h2)) if only in (None, 'clahe') else 1.0
+    tg = 1.0
+    if only in (None, 'gray'):
+        rgbf = DeviceBuffer.from_numpy(np.stack([np.stack([L, R, L], 2), np.stack([R, L, R], 2)] * (B // 2)))
+        pg = orbx.Preproc(w, h, channels=3, rgb=True, max_batch=B)
+        tg = timed(lambda: pg.run_device(rgbf.ptr.value, B, 3 * w, 3 * w * h))
     if only:
         return
+    out["gray_1280x720x3"] = {"frames_per_s": B / tg, "us_per_batch": tg * 1e6, "batch": B, "algorithmic_GBps": B * (4 * w * h) / tg / 1e9}
     out["clahe_512x512"] = {"frames_per_s": B / t, "us_per_batch": t * 1e6, "batch": B, "algorithmic_GBps": B * (3 * w2 * h2) / t / 1e9}
     w3, h3 = 752, 480
     L3, R3 = synth.stereo_pair(w3, h3, 6)
