@@ -178,6 +178,10 @@ struct orbx_preproc {
   bool remapLds = false;
   DevBuf<int> d_xofs, d_yofs;
   DevBuf<short> d_xab, d_yab;
+  DevBuf<uint4> d_rxtab;           // single-channel resize through the pyramid's kernel (launch_resize_plain): its tables
+  DevBuf<uint32_t> d_ryrow;
+  DevBuf<short> d_ryab;
+  bool resizeFast = false;
   DevBuf<uint8_t> d_clahe, d_lut, d_geo, d_gray;
   DevBuf<uint32_t> d_cells;
   long long clahePitch = 0, geoPitch = 0, grayPitch = 0;
@@ -185,7 +189,7 @@ struct orbx_preproc {
   const uint8_t* out = nullptr;  // result of the last run (a stage buffer, or the caller's frames when nothing is enabled)
   long long outPitch = 0, outImgPitch = 0;
   ~orbx_preproc() {
-    d_mapx.free(); d_mapy.free(); d_remapTab.free(); d_xofs.free(); d_yofs.free(); d_xab.free(); d_yab.free();
+    d_mapx.free(); d_mapy.free(); d_remapTab.free(); d_xofs.free(); d_yofs.free(); d_xab.free(); d_yab.free(); d_rxtab.free(); d_ryrow.free(); d_ryab.free();
     d_clahe.free(); d_lut.free(); d_geo.free(); d_gray.free(); d_cells.free();
   }
 };
@@ -257,6 +261,29 @@ int orbx_preproc_create(const orbx_preproc_params* p, int max_batch, int device,
     if (e == hipSuccess) chk(hipMemcpy(pp->d_yofs.p, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
     if (e == hipSuccess) chk(hipMemcpy(pp->d_xab.p, xab.data(), xab.size() * sizeof(short), hipMemcpyHostToDevice));
     if (e == hipSuccess) chk(hipMemcpy(pp->d_yab.p, yab.data(), yab.size() * sizeof(short), hipMemcpyHostToDevice));
+    // single-channel frames: the same cv::resize through the pyramid's tiled kernel (tables of a two-level geometry)
+    static const bool plainOff = getenv("ORBX_RESIZE_PLAIN") && atoi(getenv("ORBX_RESIZE_PLAIN")) == 0;   // A / B switch
+    if (cn == 1 && !plainOff && p->out_w >= 4 && resize_plain_lds(p->src_w, p->src_h, p->out_w, p->out_h) <= 60 * 1024) {
+      Geom g2{};
+      g2.nlevels = 2;
+      g2.lv[0].w = p->src_w; g2.lv[0].h = p->src_h;
+      g2.lv[1].w = p->out_w; g2.lv[1].h = p->out_h;
+      std::vector<uint4> xt;
+      std::vector<int> yo;
+      std::vector<short> ya;
+      build_coefs(g2, xt, yo, ya);
+      std::vector<uint32_t> yrow(yo.size(), 0);
+      for (int dy = 0; dy < p->out_h; dy++) {
+        const int a = std::min(std::max(yo[dy], 0), p->src_h - 1), b = std::min(std::max(yo[dy] + 1, 0), p->src_h - 1);
+        yrow[dy] = (uint32_t)a | ((uint32_t)b << 16);
+      }
+      chk(pp->d_rxtab.alloc(xt.size() + 64)); chk(pp->d_ryrow.alloc(yrow.size() + 64)); chk(pp->d_ryab.alloc(ya.size() + 128));
+      if (e == hipSuccess) chk(hipMemcpy(pp->d_rxtab.p, xt.data(), xt.size() * sizeof(uint4), hipMemcpyHostToDevice));
+      if (e == hipSuccess) chk(hipMemcpy(pp->d_ryrow.p, yrow.data(), yrow.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      if (e == hipSuccess) chk(hipMemcpy(pp->d_ryab.p, ya.data(), ya.size() * sizeof(short), hipMemcpyHostToDevice));
+      if (e == hipSuccess) chk(prepare_resize_plain(p->src_w, p->src_h, p->out_w, p->out_h));
+      pp->resizeFast = e == hipSuccess;
+    }
   }
   if (remap || resize) {
     pp->geoPitch = ((long long)pp->outW * cn + 3) & ~3ll;
@@ -314,8 +341,12 @@ static int preproc_enqueue(orbx_preproc* pp, const uint8_t* d_frames, int n, ptr
     e = launch_remap(a, n, s);
     cur = a.dst; cp = a.dstPitch; cip = a.dstImgPitch;
   } else if (e == hipSuccess && pp->doResize) {
-    e = launch_resize_generic(cur, p.src_w, p.src_h, cp, cip, cn, pp->d_geo.p, pp->outW, pp->outH, pp->geoPitch,
-                              pp->geoPitch * pp->outH, pp->d_xofs.p, pp->d_xab.p, pp->d_yofs.p, pp->d_yab.p, n, s);
+    if (pp->resizeFast && cp < (1ll << 31))
+      e = launch_resize_plain(cur, p.src_w, p.src_h, cp, cip, pp->d_geo.p, pp->outW, pp->outH, pp->geoPitch, pp->geoPitch * pp->outH,
+                              pp->d_rxtab.p, pp->d_ryrow.p, pp->d_ryab.p, n, s);
+    else
+      e = launch_resize_generic(cur, p.src_w, p.src_h, cp, cip, cn, pp->d_geo.p, pp->outW, pp->outH, pp->geoPitch,
+                                pp->geoPitch * pp->outH, pp->d_xofs.p, pp->d_xab.p, pp->d_yofs.p, pp->d_yab.p, n, s);
     cur = pp->d_geo.p; cp = pp->geoPitch; cip = pp->geoPitch * pp->outH;
   }
   if (e == hipSuccess && pp->doGray) {

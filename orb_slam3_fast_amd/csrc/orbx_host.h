@@ -27,6 +27,7 @@ namespace orbx_host {
 
 
 extern thread_local std::string g_err;  // defined in orbx_api.hip
+void build_coefs(const Geom& g, std::vector<uint4>& xtab, std::vector<int>& yofs, std::vector<short>& yab);   // orbx_api.hip: k_resize's tables
 inline int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;

@@ -92,6 +92,12 @@ hipError_t prepare_resize_tail(unsigned ldsBytes);
 hipError_t raise_dynamic_lds(const void* fn, size_t bytes);   // per-device running maximum of a kernel's dynamic-LDS limit
 
 // Launch wrappers (orbx_kernels.hip).  All enqueue on `s` and return the HIP status.
+// whole single-channel frames through the pyramid's resize kernel (pre-processing plans; orbx_kernels.hip)
+size_t resize_plain_lds(int sw, int sh, int dw, int dh);
+hipError_t prepare_resize_plain(int sw, int sh, int dw, int dh);
+hipError_t launch_resize_plain(const uint8_t* src, int sw, int sh, long long sp, long long sip, uint8_t* dst, int dw, int dh,
+                               long long dp, long long dip, const uint4* xtab, const uint32_t* yrow, const short* yab, int nimg,
+                               hipStream_t s);
 hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const uint4* xtab, const uint32_t* yofs /* clamped row pairs */,
                          const short* yab, hipStream_t s);
 hipError_t launch_detect(const Geom& g, const Pyr& p, int nimg, uint32_t* cellCand, int* cellCount, int level0,

@@ -350,6 +350,36 @@ hipError_t launch_resize(const Geom& g, const Pyr& p, int nimg, int level, const
 }
 
 
+// cv::resize(INTER_LINEAR) of whole single-channel frames -- System::TrackStereo's input resize (src/System.cc:297-298,
+// settings_->needToResize()) -- with the pyramid's kernel: the arithmetic is the same cv::resize, so the pre-processing
+// plans build the level tables for the pair (source size, output size) and launch k_resize on it (round 6; the per-pixel
+// k_resize_generic ran 64 x 752x480 -> 600x350 in 73 us).  A two-level geometry by value: level 0 = the caller's frames, level 1 =
+// the plan's output buffer.
+static Geom resize_plain_geom(int sw, int sh, int dw, int dh, long long dp, long long dip) {
+  Geom g{};
+  g.nlevels = 2;
+  g.lv[0].w = sw; g.lv[0].h = sh;
+  g.lv[1].w = dw; g.lv[1].h = dh; g.lv[1].pitch = (int)dp;
+  g.lv[1].xcoef = 0; g.lv[1].ycoef = 0; g.lv[1].off = 0;
+  g.pyrImg = dip;
+  return g;
+}
+size_t resize_plain_lds(int sw, int sh, int dw, int dh) { return resize_lds_bytes(resize_plain_geom(sw, sh, dw, dh, 0, 0)); }
+hipError_t prepare_resize_plain(int sw, int sh, int dw, int dh) {
+  const size_t lds = std::max<size_t>(resize_plain_lds(sw, sh, dw, dh), 1024);
+  hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(k_resize<0>), lds);
+  if (e == hipSuccess) e = raise_dynamic_lds(reinterpret_cast<const void*>(k_resize<kResizeNdw>), lds);
+  return e;
+}
+hipError_t launch_resize_plain(const uint8_t* src, int sw, int sh, long long sp, long long sip, uint8_t* dst, int dw, int dh,
+                               long long dp, long long dip, const uint4* xtab, const uint32_t* yrow, const short* yab, int nimg,
+                               hipStream_t s) {
+  const Geom g = resize_plain_geom(sw, sh, dw, dh, dp, dip);
+  Pyr p{};
+  p.l0 = src; p.l0Row = sp; p.l0Img = sip; p.pyr = dst;
+  return launch_resize(g, p, nimg, 1, xtab, yrow, yab, s);
+}
+
 // ================================================================================================ octree
 // DistributeOctTree without moving keys: every candidate keeps a node id (knode), a pass counts the keys of
 // each child quadrant with LDS atomics, and the node list of the next pass is laid out by prefix sums in

@@ -58,6 +58,34 @@ def test_hip_preprocess_matches_oracle(oracle):
 
 
 @pytest.mark.gpu
+def test_hip_plan_resize_of_mono_frames_matches_oracle(oracle):
+    """System::TrackStereo's input resize (src/System.cc:297-298) in a pre-processing plan, single-channel frames: since round 6 the
+    pyramid's tiled cv::resize kernel on a two-level geometry (launch_resize_plain) instead of the per-pixel kernel.  Scale factors
+    from 0.8 (enlarging) to 3 (footprints of 50 rows), sizes that are no multiples of the 256 x 16 tile, the EuRoC pair
+    752x480 -> 600x350, batches of one and several frames, a source whose last dword is partial -- all equal to the oracle's
+    cv::resize restatement."""
+    import orb_slam3_fast_amd as orbx
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    rng = np.random.default_rng(8)
+    for (w, h, dw, dh, n) in ((752, 480, 600, 350, 3), (1280, 720, 640, 360, 2), (640, 480, 800, 600, 1), (1281, 721, 427, 241, 2),
+                              (600, 350, 257, 17, 1), (333, 222, 111, 74, 4), (512, 512, 500, 100, 1), (97, 61, 83, 50, 2)):
+        frames = np.stack([_img(rng, h, w, 1)[..., 0] for _ in range(n)])
+        dev = DeviceBuffer.from_numpy(frames)
+        pp = orbx.Preproc(w, h, channels=1, out_size=(dw, dh), max_batch=n)
+        assert (pp.out_w, pp.out_h) == (dw, dh)
+        for i in range(n):
+            assert np.array_equal(pp.run(frames[i]), oracle.resize(frames[i], dw, dh)), (w, h, dw, dh, i)
+        ptr, ow, oh, rp, ip = pp.run_device(dev.ptr.value, n, w, w * h)
+        got = np.zeros((n, ip), np.uint8)
+        import ctypes as C
+        from orb_slam3_fast_amd import hipmem
+        hipmem._ck(hipmem.hip().hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), got.nbytes, 2))
+        got = got[:, :oh * rp].reshape(n, oh, rp)[:, :, :ow]
+        for i in range(n):
+            assert np.array_equal(got[i], oracle.resize(frames[i], dw, dh)), (w, h, dw, dh, i)
+
+
+@pytest.mark.gpu
 def test_hip_color_frame_to_keypoints_flow(oracle):
     """TUM-like flow: colour frame -> gray (mbRGB) -> resize to the settings' size -> ORBextractor."""
     import orb_slam3_fast_amd as orbx
