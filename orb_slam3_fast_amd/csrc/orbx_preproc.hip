@@ -829,14 +829,23 @@ __global__ __launch_bounds__(256) void k_clahe_apply16(ClaheArgs a, const uint32
 // k_clahe_pack launch, no cell-table buffer) and the 16 look-ups of a thread are LDS reads.  A cell is tw x th pixels (half that at
 // the image border) = tw / 16 segments per row; thread = (segment, row phase).  Same float blend in OpenCV's expression order.
 __global__ __launch_bounds__(256) void k_clahe_apply_cell(ClaheArgs a) {
-  __shared__ uint32_t tab[256];
+  __shared__ __attribute__((aligned(16))) uint32_t tab[256];
   const int ncx = a.tilesX + 1, cx = blockIdx.x % ncx, cy = blockIdx.x / ncx, img = blockIdx.y, tid = threadIdx.x;
-  {
+  if (tid < 64) {   // the four luts as DWORDS by one wave (16 byte loads per workgroup before: the texture addresser takes a wave's
+                    // byte load lane by lane), transposed to one table entry per grey value by four v_perm
     const int tx1 = max(cx - 1, 0), tx2 = min(cx, a.tilesX - 1), ty1 = max(cy - 1, 0), ty2 = min(cy, a.tilesY - 1);
-    const uint8_t* L = a.lut + (long long)img * a.tilesX * a.tilesY * 256;
-    const uint32_t l11 = L[(ty1 * a.tilesX + tx1) * 256 + tid], l12 = L[(ty1 * a.tilesX + tx2) * 256 + tid];
-    const uint32_t l21 = L[(ty2 * a.tilesX + tx1) * 256 + tid], l22 = L[(ty2 * a.tilesX + tx2) * 256 + tid];
-    tab[tid] = l11 | (l12 << 8) | (l21 << 16) | (l22 << 24);
+    const uint32_t* L = reinterpret_cast<const uint32_t*>(a.lut + (long long)img * a.tilesX * a.tilesY * 256);   // (256-byte luts: aligned)
+    const uint32_t l11 = L[(ty1 * a.tilesX + tx1) * 64 + tid], l12 = L[(ty1 * a.tilesX + tx2) * 64 + tid];
+    const uint32_t l21 = L[(ty2 * a.tilesX + tx1) * 64 + tid], l22 = L[(ty2 * a.tilesX + tx2) * 64 + tid];
+    // entry of grey value 4 tid + j = byte j of (l11, l12, l21, l22)
+    const uint32_t lo01 = __builtin_amdgcn_perm(l12, l11, 0x05010400u), hi01 = __builtin_amdgcn_perm(l12, l11, 0x07030602u);   // [a0 b0 a1 b1], [a2 b2 a3 b3]
+    const uint32_t lo23 = __builtin_amdgcn_perm(l22, l21, 0x05010400u), hi23 = __builtin_amdgcn_perm(l22, l21, 0x07030602u);
+    uint4 e;
+    e.x = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);   // [a0 b0 c0 d0]
+    e.y = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);   // [a1 b1 c1 d1]
+    e.z = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    e.w = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+    reinterpret_cast<uint4*>(tab)[tid] = e;
   }
   // pixel (x, y) belongs to cell (floor(x / tw - 0.5) + 1, floor(y / th - 0.5) + 1): columns [cx tw - tw / 2, cx tw + tw / 2)
   const int xb = max(cx * a.tw - (a.tw >> 1), 0), xe = min(cx * a.tw + (a.tw >> 1), a.w);
