@@ -2105,55 +2105,88 @@ __global__ __launch_bounds__(256) void k_slots(Geom g, const uint32_t* __restric
                                                const int* __restrict__ selCount, const int* __restrict__ lap,
                                                int* __restrict__ slot, int* __restrict__ nOut,
                                                int* __restrict__ mono) {
+  // Round 6: a chain of latencies, not work (14 us for 16 images x 1500 keypoints: thread 0 walked the level counts one load
+  // after the other, every thread fetched its keys one dependent load at a time -- twice --, and the 256-wide scan took 16
+  // barriers).  Now: the level counts in parallel + a wave scan, a thread's keys requested together and kept in registers (up to
+  // kKeep; longer runs re-read), the lapping counts by a DPP wave scan and one combine across the four waves.
   __shared__ int cum[ORBX_MAX_LEVELS + 1];
-  __shared__ int tsum[256];
-  const int tid = threadIdx.x, img = blockIdx.x;
-  if (tid == 0) {
-    int c = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-      cum[l] = c;
-      c += selCount[img * g.nlevels + l];
-    }
-    cum[g.nlevels] = c;
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, img = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 64) {
+    const int c = lane < g.nlevels ? selCount[img * g.nlevels + lane] : 0;
+    const int inc = wave_scan_dpp(c);            // inclusive
+    if (lane < g.nlevels) cum[lane] = inc - c;
+    if (lane == g.nlevels - 1) cum[g.nlevels] = inc;
   }
   __syncthreads();
   const int n = cum[g.nlevels];
   const float lap0 = (float)lap[2 * img], lap1 = (float)lap[2 * img + 1];
   const int per = (n + 255) >> 8;
   const int b = min(tid * per, n), e = min(b + per, n);
-  auto in_lap = [&](int gidx, int& lvl, int& idx) {
+  constexpr int kKeep = 8;
+  auto locate = [&](int gidx, int& lvl, int& idx) {
     lvl = 0;
     while (gidx >= cum[lvl + 1]) lvl++;
     idx = gidx - cum[lvl];
-    const uint32_t key = sel[(long long)img * g.selImg + g.lv[lvl].selOff + idx];
+  };
+  auto lapping = [&](uint32_t key, int lvl) {
     float x = (float)key_x(key);
     if (lvl != 0) x = x * g.lv[lvl].scale;
     return x >= lap0 && x <= lap1;
   };
+  uint32_t keys[kKeep];
+  int lvs[kKeep], adr[kKeep];
   int cnt = 0;
-  for (int i = b; i < e; i++) {
-    int lv, ix;
-    cnt += in_lap(i, lv, ix) ? 1 : 0;
+  if (per <= kKeep) {
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) {
+      const int i = b + k;
+      lvs[k] = 0;
+      adr[k] = 0;
+      keys[k] = 0;
+      if (i < e) {
+        int ix;
+        locate(i, lvs[k], ix);
+        adr[k] = g.lv[lvs[k]].selOff + ix;
+        keys[k] = sel[(long long)img * g.selImg + adr[k]];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) cnt += (b + k < e && lapping(keys[k], lvs[k])) ? 1 : 0;
+  } else {
+    for (int i = b; i < e; i++) {
+      int lv, ix;
+      locate(i, lv, ix);
+      cnt += lapping(sel[(long long)img * g.selImg + g.lv[lv].selOff + ix], lv) ? 1 : 0;
+    }
   }
-  tsum[tid] = cnt;
+  const int incl = wave_scan_dpp(cnt);
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int t = tid >= d ? tsum[tid - d] : 0;
-    __syncthreads();
-    tsum[tid] += t;
-    __syncthreads();
-  }
-  int lapBefore = tid ? tsum[tid - 1] : 0;
-  for (int i = b; i < e; i++) {
-    int lv, ix;
-    const bool il = in_lap(i, lv, ix);
-    const int s = il ? (n - 1 - lapBefore) : (i - lapBefore);
-    slot[(long long)img * g.selImg + g.lv[lv].selOff + ix] = s;
-    lapBefore += il ? 1 : 0;
+  int lapBefore = incl - cnt;
+  for (int k = 0; k < wave; k++) lapBefore += wsum[k];
+  if (per <= kKeep) {
+#pragma unroll
+    for (int k = 0; k < kKeep; k++) {
+      const int i = b + k;
+      if (i < e) {
+        const bool il = lapping(keys[k], lvs[k]);
+        slot[(long long)img * g.selImg + adr[k]] = il ? (n - 1 - lapBefore) : (i - lapBefore);
+        lapBefore += il ? 1 : 0;
+      }
+    }
+  } else {
+    for (int i = b; i < e; i++) {
+      int lv, ix;
+      locate(i, lv, ix);
+      const bool il = lapping(sel[(long long)img * g.selImg + g.lv[lv].selOff + ix], lv);
+      slot[(long long)img * g.selImg + g.lv[lv].selOff + ix] = il ? (n - 1 - lapBefore) : (i - lapBefore);
+      lapBefore += il ? 1 : 0;
+    }
   }
   if (tid == 0) {
     nOut[img] = n;
-    mono[img] = n - tsum[255];
+    mono[img] = n - (wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   }
 }
 
