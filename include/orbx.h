@@ -689,6 +689,23 @@ typedef struct orbx_map_point_right {
   uint8_t in_view_r, pad_[3];
 } orbx_map_point_right;
 
+/* Device-side projection for stereo-fisheye frames (Nleft != -1; the pinhole form is orbx_project_map_points_batch, same uploaded map):
+ * Frame::isInFrustum runs isInFrustumChecks (src/Frame.cc:689-697, :1333-1410)
+ * once per camera with KannalaBrandt8::project (src/CameraModels/KannalaBrandt8.cpp:67-86).  A camera's pose = the (mR, mt, twc) the
+ * reference forms at :1342-1351 -- (mRcw, mtcw, mOw) for the left camera, (Rrl * mRcw, Rrl * mtcw + trl, mRwc * mTlr.translation()
+ * + mOw) for the right one, computed by the caller in float -- plus that camera's eight KB8 parameters.  The views of both
+ * cameras stay on the device for orbx_search_by_projection_fisheye_batch(map_points = NULL, map_points_right = NULL); views_out /
+ * views_right_out (may be NULL) receive host copies in the matcher's input form ([n_frames][n] each).  Tolerance parity (device
+ * atan2f / cosf / sinf / logf). */
+typedef struct orbx_frame_pose_kb8 {
+  float R[9], t[3], twc[3], kb8[8];
+} orbx_frame_pose_kb8;
+int orbx_project_map_points_fisheye_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose_kb8* left_poses,
+                                          const orbx_frame_pose_kb8* right_poses, float min_x, float min_y, float max_x, float max_y,
+                                          float viewing_cos_limit, const uint8_t* skip, orbx_map_point_view* views_out,
+                                          orbx_map_point_right* views_right_out);
+
+
 /* Replaces ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, bFarPoints, thFarPoints)
  * (src/ORBmatcher.cc:41-221) for F.Nleft != -1: left-camera search, right-camera search (radius not scaled by th, :144),
  * and the assignments to the stereo partner slots (:126-132, :199-204).  occupied / match have N entries, the right
@@ -716,6 +733,8 @@ int orbx_search_by_projection_frame_fisheye(int device, const orbx_keypoint* kps
  * keypoints | right keypoints] like the one-shot calls' N = Nleft + Nright arrays; n_matches [n_frames].  Every kernel of the
  * chain runs ONCE for all frames and both cameras with a fixed number of fixed-point rounds enqueued blindly; a frame that needs
  * more (or larger candidate / writer lists) is redone through the one-shot path: results are those of n_frames separate calls.
+ * map_points == NULL && map_points_right == NULL (round 6): the views of both cameras come from the handle's last
+ * orbx_project_map_points_fisheye_batch (points_stride and every n_map_points[f] must equal the uploaded map's n).
  * Returns the total number of matches or a negative error. */
 int orbx_search_by_projection_fisheye_batch(orbx_extractor* ex, int first_left, int first_right, int n_frames, float min_x, float min_y,
                                             float max_x, float max_y, const orbx_map_point_view* map_points,

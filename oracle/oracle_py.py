@@ -312,6 +312,23 @@ def is_in_frustum(pose, pos, normal, min_dist, max_dist, bounds, view_cos_limit,
     return views, margins
 
 
+def is_in_frustum_kb8(pose, pos, normal, min_dist, max_dist, bounds, view_cos_limit, log_scale_factor, nlevels, flags, desc):
+    """Frame::isInFrustumChecks for n points and ONE camera of a stereo-fisheye frame (23 floats: R row-major, t, twc, KB8
+    parameters).  Returns (views MP_DTYPE [n] of that camera, margins [n][2])."""
+    pose = np.ascontiguousarray(pose, np.float32).reshape(23)
+    pos, normal = np.ascontiguousarray(pos, np.float32), np.ascontiguousarray(normal, np.float32)
+    mn, mx = np.ascontiguousarray(min_dist, np.float32), np.ascontiguousarray(max_dist, np.float32)
+    n = len(mn)
+    views = np.zeros(n, MP_DTYPE)
+    fl = np.ascontiguousarray(flags, np.uint8)
+    views["bad"], views["has_observations"], views["desc"] = fl & 1, (fl >> 1) & 1, _u8(desc)
+    margins = np.zeros((n, 2), np.float64)
+    lib().oro_is_in_frustum_kb8(_p(pose), n, _p(pos), _p(normal), _p(mn), _p(mx), C.c_float(bounds[0]), C.c_float(bounds[1]),
+                                C.c_float(bounds[2]), C.c_float(bounds[3]), C.c_float(view_cos_limit), C.c_float(log_scale_factor),
+                                int(nlevels), _p(views), _p(margins))
+    return views, margins
+
+
 PP_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("angle", "<f4"), ("min_level", "<i4"),
                      ("max_level", "<i4"), ("valid", "u1"), ("has_observations", "u1"), ("pad_", "u1", (2,)),
                      ("desc", "u1", (32,))])

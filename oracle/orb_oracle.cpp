@@ -2241,6 +2241,58 @@ int search_by_bow(const std::vector<uint32_t>& kfNodes, const std::vector<int>& 
 
 
 // ---- Frame::isInFrustum + MapPoint::PredictScale (test infrastructure for orbx_project_map_points_batch) ----------------------
+MapPointView is_in_frustum_kb8(const FramePoseKB8& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
+                               float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
+                               int nlevels, double margin[2]) {
+  MapPointView v{};
+  double gate = 1e30, frac = 1e30;
+  auto near = [&](float value, float threshold) {
+    const double d = std::fabs((double)value - (double)threshold) / std::max(1.0, std::fabs((double)threshold));
+    gate = std::min(gate, d);
+  };
+  auto done = [&]() {
+    if (margin) { margin[0] = gate; margin[1] = frac; }
+    return v;
+  };
+  // Pc = mR * P + mt   (src/Frame.cc:1354)
+  const float X = ((T.R[0] * P[0] + T.R[1] * P[1]) + T.R[2] * P[2]) + T.t[0];
+  const float Y = ((T.R[3] * P[0] + T.R[4] * P[1]) + T.R[5] * P[2]) + T.t[1];
+  const float Z = ((T.R[6] * P[0] + T.R[7] * P[1]) + T.R[8] * P[2]) + T.t[2];
+  const float pcDist = std::sqrt((X * X + Y * Y) + Z * Z);
+  near(Z, 0.f);
+  if (Z < 0.0f) return done();   // :1359
+  KB8 cam{};
+  for (int i = 0; i < 8; i++) cam.p[i] = T.kb8[i];
+  const float Pc[3] = {X, Y, Z};
+  float uv[2];
+  kb8_project(cam, Pc, uv);      // :1363-1366
+  near(uv[0], minX); near(uv[0], maxX);
+  if (uv[0] < minX || uv[0] > maxX) return done();
+  near(uv[1], minY); near(uv[1], maxY);
+  if (uv[1] < minY || uv[1] > maxY) return done();
+  const float maxD = 1.2f * maxDistance, minD = 0.8f * minDistance;
+  const float ox = P[0] - T.Ow[0], oy = P[1] - T.Ow[1], oz = P[2] - T.Ow[2];   // PO = P - twc
+  const float dist = std::sqrt((ox * ox + oy * oy) + oz * oz);
+  near(dist, minD); near(dist, maxD);
+  if (dist < minD || dist > maxD) return done();
+  const float viewCos = ((ox * Pn[0] + oy * Pn[1]) + oz * Pn[2]) / dist;
+  near(viewCos, viewingCosLimit);
+  if (viewCos < viewingCosLimit) return done();
+  const float ratio = maxDistance / dist;
+  const float q = std::log(ratio) / logScaleFactor;
+  frac = std::fabs((double)q - std::nearbyint((double)q));
+  int nScale = (int)std::ceil(q);
+  if (nScale < 0) nScale = 0;
+  else if (nScale >= nlevels) nScale = nlevels - 1;
+  v.in_view = 1;
+  v.proj_x = uv[0];
+  v.proj_y = uv[1];
+  v.track_depth = pcDist;
+  v.view_cos = viewCos;
+  v.predicted_level = nScale;
+  return done();
+}
+
 ProjectedPoint project_last_frame_point(const FramePoseQ& T, const float Pw[3], int lastOctave, float lastAngle, float th,
                                         const std::vector<float>& scaleFactors, float minX, float minY, float maxX, float maxY,
                                         double* margin) {

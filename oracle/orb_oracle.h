@@ -212,6 +212,17 @@ struct FramePose {
 MapPointView is_in_frustum(const FramePose& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
                            float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
                            int nlevels, double margin[2]);
+// Frame::isInFrustumChecks (src/Frame.cc:1333-1410) for ONE camera of a stereo-fisheye frame: pose = (mR, mt, twc) of that camera --
+// (mRcw, mtcw, mOw) for the left one, (Rrl * mRcw, Rrl * mtcw + trl, mRwc * mTlr.translation() + mOw) for the right one, formed by
+// the caller in float as :1342-1351 does -- and its KannalaBrandt8 parameters; the projection is KannalaBrandt8::project
+// (src/CameraModels/KannalaBrandt8.cpp:67-86).  Result as a MapPointView (proj_x / proj_y / view_cos / track_depth /
+// predicted_level / in_view of THAT camera); margin as is_in_frustum.
+struct FramePoseKB8 {
+  float R[9], t[3], Ow[3], kb8[8];
+};
+MapPointView is_in_frustum_kb8(const FramePoseKB8& T, const float P[3], const float Pn[3], float minDistance, float maxDistance,
+                               float minX, float minY, float maxX, float maxY, float viewingCosLimit, float logScaleFactor,
+                               int nlevels, double margin[2]);
 int search_by_projection_map(const std::vector<KeyPoint>& kpsUn, const uint8_t* desc, const float* uRight,
                              const FrameGrid& grid, const std::vector<float>& scaleFactors,
                              const std::vector<MapPointView>& mps, float th, bool bFarPoints, float thFarPoints,

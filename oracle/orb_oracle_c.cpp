@@ -528,6 +528,27 @@ int oro_search_for_triangulation_rig(const uint32_t* nodes1, int nNodes1, const 
 }
 
 
+// Frame::isInFrustumChecks for n points x ONE camera pose of a stereo-fisheye frame (23 floats: R row-major, t, twc, 8 KB8
+// parameters); views [n] receive that camera's proj_x / proj_y / view_cos / track_depth / predicted_level / in_view
+void oro_is_in_frustum_kb8(const float* pose23, int n, const float* pos, const float* normal, const float* minDist, const float* maxDist,
+                           float minX, float minY, float maxX, float maxY, float viewCosLimit, float logScaleFactor, int nlevels,
+                           MapPointView* views, double* margins) {
+  FramePoseKB8 T;
+  static_assert(sizeof(FramePoseKB8) == 23 * sizeof(float), "pose = 23 packed floats");
+  std::memcpy(&T, pose23, sizeof(T));
+  for (int i = 0; i < n; i++) {
+    double m[2];
+    const MapPointView v = is_in_frustum_kb8(T, pos + 3 * i, normal + 3 * i, minDist[i], maxDist[i], minX, minY, maxX, maxY, viewCosLimit,
+                                             logScaleFactor, nlevels, m);
+    const MapPointView keep = views[i];
+    views[i] = v;
+    views[i].bad = keep.bad;
+    views[i].has_observations = keep.has_observations;
+    std::memcpy(views[i].desc, keep.desc, 32);
+    if (margins) { margins[2 * i] = m[0]; margins[2 * i + 1] = m[1]; }
+  }
+}
+
 // The projection block of SearchByProjection(CurrentFrame, LastFrame) for n LastFrame points x one pose (13 floats: quaternion
 // x y z w, translation, fx fy cx cy, bf; + direction); flags bit 0 = has a MapPoint and is no outlier, bit 1 = Observations() > 0;
 // views [n] (descriptors are the caller's), margins [n] (may be NULL)

@@ -137,6 +137,7 @@ def lib():
         L.orbx_map_upload.argtypes = [vp, i, vp, vp, vp, vp, vp, vp]
         L.orbx_project_map_points_batch.argtypes = [vp, i, vp, f, f, f, f, f, vp, vp]
         L.orbx_last_frames_upload.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp]
+        L.orbx_project_map_points_fisheye_batch.argtypes = [vp, i, vp, vp, f, f, f, f, f, vp, vp, vp]
         L.orbx_project_last_frames_batch.argtypes = [vp, i, vp, f, f, f, f, f, vp]
         L.orbx_search_for_triangulation.argtypes = [i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, i,
                                                     vp, vp, i, i, i, vp]
@@ -361,6 +362,21 @@ class ORBextractor:
                                                    float(viewing_cos_limit), None if sk is None else _p(sk),
                                                    None if views is None else _p(views)))
         return views
+
+    def project_map_points_fisheye(self, left_poses, right_poses, bounds, viewing_cos_limit=0.5, skip=None, want_views=False):
+        """Frame::isInFrustum for stereo-fisheye frames on the device (orbx_project_map_points_fisheye_batch): one pose per camera
+        and frame, 23 floats each (R row-major, t, twc, 8 KB8 parameters) -- the right camera's as the reference derives it
+        (src/Frame.cc:1342-1351).  Returns (MP_DTYPE [F][n], MPR_DTYPE [F][n]) when want_views."""
+        pl = np.ascontiguousarray(left_poses, np.float32).reshape(-1, 23)
+        pr = np.ascontiguousarray(right_poses, np.float32).reshape(-1, 23)
+        F = len(pl)
+        sk = None if skip is None else np.ascontiguousarray(skip, np.uint8).reshape(F, self._map_n)
+        vl = np.zeros((F, self._map_n), MP_DTYPE) if want_views else None
+        vr = np.zeros((F, self._map_n), MPR_DTYPE) if want_views else None
+        _check(lib().orbx_project_map_points_fisheye_batch(self._h, F, _p(pl), _p(pr), bounds[0], bounds[1], bounds[2], bounds[3],
+                                                           float(viewing_cos_limit), None if sk is None else _p(sk),
+                                                           None if vl is None else _p(vl), None if vr is None else _p(vr)))
+        return (vl, vr) if want_views else None
 
     def last_frames_upload(self, n_points, world_pos, octave, angle, desc, flags):
         """The LastFrames of the batch's cameras as structure-of-arrays on the device (orbx_last_frames_upload): n_points [F];
@@ -1189,6 +1205,22 @@ class ORBmatcher:
         _check(lib().orbx_search_by_projection_fisheye_batch(
             ex._h, int(first_left), int(first_right), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], _p(mp), _p(mr), _p(npts),
             mp.shape[1], float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, _p(l2r), _p(r2l),
+            None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
+        return nm, match, occ
+
+    def SearchByProjectionFisheyeBatchDevice(self, ex, first_left, first_right, n_frames, bounds, leftToRight, rightToLeft, occupied=None,
+                                             th=1.0, bFarPoints=False, thFarPoints=50.0):
+        """SearchByProjectionFisheye on the two-camera frames of ex's last extraction batch with both cameras' views made ON THE
+        DEVICE by project_map_points_fisheye (orbx_search_by_projection_fisheye_batch with map_points = map_points_right = NULL)."""
+        cap, n = ex.capacity, ex._map_n
+        npts = np.full(n_frames, n, np.int32)
+        l2r = np.ascontiguousarray(leftToRight, np.int32).reshape(n_frames, cap)
+        r2l = np.ascontiguousarray(rightToLeft, np.int32).reshape(n_frames, cap)
+        occ_in = None if occupied is None else np.ascontiguousarray(occupied, np.uint8).reshape(n_frames, 2 * cap)
+        occ, match, nm = np.zeros((n_frames, 2 * cap), np.uint8), np.full((n_frames, 2 * cap), -1, np.int32), np.zeros(n_frames, np.int32)
+        _check(lib().orbx_search_by_projection_fisheye_batch(
+            ex._h, int(first_left), int(first_right), int(n_frames), bounds[0], bounds[1], bounds[2], bounds[3], None, None, _p(npts), n,
+            float(th), int(bFarPoints), float(thFarPoints), self.mfNNratio, _p(l2r), _p(r2l),
             None if occ_in is None else _p(occ_in), _p(occ), _p(match), _p(nm)))
         return nm, match, occ
 

@@ -753,7 +753,7 @@ void orbx_extractor_destroy(orbx_extractor* ex) {
   ex->d_mapPos.free(); ex->d_mapNormal.free(); ex->d_mapMinD.free(); ex->d_mapMaxD.free(); ex->d_mapDesc.free(); ex->d_mapFlags.free();
   ex->d_mapSkip.free(); ex->d_poses.free(); ex->d_views.free();
   ex->d_lfPos.free(); ex->d_lfAngle.free(); ex->d_lfOct.free(); ex->d_lfN.free(); ex->d_lfDesc.free(); ex->d_lfFlags.free();
-  ex->d_posesQ.free(); ex->d_pviews.free(); ex->d_scaleF.free();
+  ex->d_posesQ.free(); ex->d_pviews.free(); ex->d_scaleF.free(); ex->d_posesK.free(); ex->d_fviewsL.free(); ex->d_fviewsR.free();
   ex->d_latBands.free();
   ex->d_yab.free(); ex->d_kps.free(); ex->d_uR.free(); ex->d_depth.free(); ex->d_sad.free(); ex->d_rowStart.free(); ex->d_srec.free(); ex->d_sdesc.free();
   for (hipEvent_t e : ex->evPool) (void)hipEventDestroy(e);

@@ -887,6 +887,7 @@ int orbx_map_upload(orbx_extractor* ex, int n, const float* world_pos, const flo
   if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
   ex->mapN = 0;
   ex->viewsFrames = 0;
+  ex->fviewsFrames = 0;
   if (n) {
     HIPC(hipMemcpy(ex->d_mapPos.p, world_pos, (size_t)n * 12, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(ex->d_mapNormal.p, normal, (size_t)n * 12, hipMemcpyHostToDevice));
@@ -931,6 +932,54 @@ int orbx_project_map_points_batch(orbx_extractor* ex, int n_frames, const orbx_f
   }
   ex->viewsFrames = n_frames;
   ex->viewsStride = n;
+  return ORBX_OK;
+}
+
+int orbx_project_map_points_fisheye_batch(orbx_extractor* ex, int n_frames, const orbx_frame_pose_kb8* left_poses,
+                                          const orbx_frame_pose_kb8* right_poses, float min_x, float min_y, float max_x, float max_y,
+                                          float viewing_cos_limit, const uint8_t* skip, orbx_map_point_view* views_out,
+                                          orbx_map_point_right* views_right_out) {
+  if (!ex || n_frames < 0 || n_frames > 4096 || (n_frames && (!left_poses || !right_poses))) return fail(ORBX_E_BADARG, "bad argument");
+  if (ex->mapN <= 0) return fail(ORBX_E_BADARG, "no map uploaded (orbx_map_upload)");
+  int rc = set_device(ex->device);
+  if (rc != ORBX_OK) return rc;
+  ex->fviewsFrames = 0;
+  if (n_frames == 0) return ORBX_OK;
+  const int n = ex->mapN;
+  hipError_t e = ex->d_posesK.grow(2 * (size_t)n_frames);
+  if (e == hipSuccess) e = ex->d_fviewsL.grow((size_t)n_frames * n);
+  if (e == hipSuccess) e = ex->d_fviewsR.grow((size_t)n_frames * n);
+  if (e == hipSuccess && skip) e = ex->d_mapSkip.grow((size_t)n_frames * n);
+  if (e != hipSuccess) return fail(ORBX_E_HIP, hipGetErrorString(e));
+  HIPC(hipMemcpyAsync(ex->d_posesK.p, left_poses, (size_t)n_frames * sizeof(orbx_frame_pose_kb8), hipMemcpyHostToDevice, ex->stream));
+  HIPC(hipMemcpyAsync(ex->d_posesK.p + n_frames, right_poses, (size_t)n_frames * sizeof(orbx_frame_pose_kb8), hipMemcpyHostToDevice, ex->stream));
+  if (skip) HIPC(hipMemcpyAsync(ex->d_mapSkip.p, skip, (size_t)n_frames * n, hipMemcpyHostToDevice, ex->stream));
+  MapProjKb8Args a{};
+  a.pos = ex->d_mapPos.p; a.normal = ex->d_mapNormal.p; a.minDist = ex->d_mapMinD.p; a.maxDist = ex->d_mapMaxD.p;
+  a.desc = ex->d_mapDesc.p; a.flags = ex->d_mapFlags.p; a.skip = skip ? ex->d_mapSkip.p : nullptr;
+  a.posesL = ex->d_posesK.p; a.posesR = ex->d_posesK.p + n_frames; a.viewsL = ex->d_fviewsL.p; a.viewsR = ex->d_fviewsR.p;
+  a.n = n; a.nlevels = ex->prm.nlevels;
+  a.minX = min_x; a.minY = min_y; a.maxX = max_x; a.maxY = max_y; a.viewCosLimit = viewing_cos_limit;
+  a.logScaleFactor = logf(ex->prm.scale_factor);
+  HIPC(launch_project_map_kb8(a, n_frames, ex->stream));
+  HIPC(hipStreamSynchronize(ex->stream));   // pageable host sources: the call returns when they have been consumed
+  if (views_out || views_right_out) {       // the matcher's input form: left views (proj_xr = mTrackProjXR) + the right camera's members
+    std::vector<orbx_map_point_view> hl((size_t)n_frames * n), hr((size_t)n_frames * n);
+    HIPC(hipMemcpy(hl.data(), ex->d_fviewsL.p, hl.size() * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(hr.data(), ex->d_fviewsR.p, hr.size() * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
+    for (size_t o = 0; o < hl.size(); o++) {
+      if (views_out) views_out[o] = hl[o];
+      if (views_right_out) {
+        orbx_map_point_right r{};
+        r.proj_yr = hr[o].proj_y; r.view_cos_r = hr[o].view_cos;
+        r.predicted_level_r = hr[o].in_view ? hr[o].predicted_level : -1;
+        r.in_view_r = hr[o].in_view;
+        views_right_out[o] = r;
+      }
+    }
+  }
+  ex->fviewsFrames = n_frames;
+  ex->fviewsStride = n;
   return ORBX_OK;
 }
 
@@ -1505,6 +1554,8 @@ int proj_fisheye_batch_impl(orbx_extractor* ex, int first_left, int first_right,
   const int F = n_frames, cap = ex->gmax.outCap, nlevels = ex->prm.nlevels, st = std::max(stride, 1);
   int maxPts = 0;
   for (int f = 0; f < F; f++) maxPts = std::max(maxPts, n_points[f]);
+  const bool devViews = mode == 0 && !viewsL && !viewsR && maxPts > 0;   // both lists made by orbx_project_map_points_fisheye_batch
+  std::vector<orbx_map_point_view> hvL, hvR;                             // (host copies for a frame that falls back to the one-shot path)
   int rc = set_device(ex->device);
   if (rc != ORBX_OK) return rc;
   std::vector<int> nL(F), nR(F);
@@ -1536,8 +1587,8 @@ int proj_fisheye_batch_impl(orbx_extractor* ex, int first_left, int first_right,
   const size_t ptsRead = ((size_t)(F - 1) * st + (size_t)n_points[F - 1]) * ptBytes;
   const void* srcL = mode == 0 ? (const void*)viewsL : (const void*)ptsL;
   const void* srcR = mode == 0 ? (const void*)viewsR : (const void*)ptsR;
-  const size_t oPL = pk.add(maxPts ? srcL : nullptr, (size_t)F * st * ptBytes, ptsRead);
-  const size_t oPR = pk.add(maxPts ? srcR : nullptr, (size_t)F * st * ptBytes, ptsRead);
+  const size_t oPL = devViews ? pk.add(nullptr, 16) : pk.add(maxPts ? srcL : nullptr, (size_t)F * st * ptBytes, ptsRead);
+  const size_t oPR = devViews ? pk.add(nullptr, 16) : pk.add(maxPts ? srcR : nullptr, (size_t)F * st * ptBytes, ptsRead);
   const size_t oSf = pk.add(ex->scale.data(), (size_t)nlevels * sizeof(float));
   const size_t oA12 = pk.add(mode == 0 ? l2r : nullptr, (size_t)F * cap * 4), oA21 = pk.add(mode == 0 ? r2l : nullptr, (size_t)F * cap * 4);
   const size_t oSd = pk.add(sides.data(), sides.size() * sizeof(ProjArgs)), oFr = pk.add(frames.data(), (size_t)F * sizeof(ProjFeArgs));
@@ -1578,7 +1629,7 @@ int proj_fisheye_batch_impl(orbx_extractor* ex, int first_left, int first_right,
       a.desc = dc + (size_t)first * 32; a.uRight = nullptr;   // no mvuRight gate when F.Nleft != -1 (:90, :1667)
       a.scale = pk.ptr<float>(oSf);
       const size_t oP = sd ? oPR : oPL;
-      a.mps = mode == 0 ? pk.ptr<orbx_map_point_view>(oP) + (size_t)f * st : nullptr;
+      a.mps = mode == 0 ? (devViews ? (sd ? ex->d_fviewsR.p : ex->d_fviewsL.p) : pk.ptr<orbx_map_point_view>(oP)) + (size_t)f * st : nullptr;
       a.pts = mode == 1 ? pk.ptr<orbx_projected_point>(oP) + (size_t)f * st : nullptr;
       a.nmp = n_points[f]; a.mode = mode; a.checkOri = check_ori;
       a.th = sd ? 1.0f : th;   // the right-camera radius is not scaled by th (:144)
@@ -1644,8 +1695,14 @@ int proj_fisheye_batch_impl(orbx_extractor* ex, int first_left, int first_right,
     int32_t* mt = match + (size_t)f * n2c;
     if (occupied_in) std::memcpy(occ, occupied_in + (size_t)f * n2c, n2c); else std::memset(occ, 0, n2c);
     for (int i = 0; i < n2c; i++) mt[i] = -1;
+    if (devViews) {
+      hvL.resize((size_t)st); hvR.resize((size_t)st);
+      HIPC(hipMemcpy(hvL.data(), ex->d_fviewsL.p + (size_t)f * st, (size_t)st * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
+      HIPC(hipMemcpy(hvR.data(), ex->d_fviewsR.p + (size_t)f * st, (size_t)st * sizeof(orbx_map_point_view), hipMemcpyDeviceToHost));
+    }
     rc = search_by_projection_fisheye_impl(ex->device, k.data(), d.data(), nL[f], nR[f], min_x, min_y, max_x, max_y, ex->scale.data(),
-                                           nlevels, mode == 0 ? viewsL + (size_t)f * st : nullptr, mode == 0 ? viewsR + (size_t)f * st : nullptr,
+                                           nlevels, mode == 0 ? (devViews ? hvL.data() : viewsL + (size_t)f * st) : nullptr,
+                                           mode == 0 ? (devViews ? hvR.data() : viewsR + (size_t)f * st) : nullptr,
                                            mode == 1 ? ptsL + (size_t)f * st : nullptr, mode == 1 ? ptsR + (size_t)f * st : nullptr,
                                            n_points[f], th, far_points, th_far, nnratio, check_ori,
                                            mode == 0 ? l2r + (size_t)f * cap : nullptr, mode == 0 ? r2l + (size_t)f * cap : nullptr, occ, mt);
@@ -1684,6 +1741,15 @@ int orbx_search_by_projection_fisheye_batch(orbx_extractor* ex, int first_left, 
   const int nlevels = ex->prm.nlevels, st = std::max(points_stride, 1);
   int maxPts = 0;
   for (int f = 0; f < n_frames; f++) maxPts = std::max(maxPts, n_map_points[f]);
+  if (maxPts && !map_points && !map_points_right) {   // views of both cameras made on the device
+    if (ex->fviewsFrames < n_frames || ex->fviewsStride != points_stride)
+      return fail(ORBX_E_BADARG, "map_points == NULL needs a preceding orbx_project_map_points_fisheye_batch with the same frames and points_stride == its n");
+    for (int f = 0; f < n_frames; f++)
+      if (n_map_points[f] != ex->fviewsStride) return fail(ORBX_E_BADARG, "map_points == NULL: n_map_points[f] must equal the uploaded map's n");
+    return proj_fisheye_batch_impl(ex, first_left, first_right, n_frames, min_x, min_y, max_x, max_y, 0, nullptr, nullptr, nullptr, nullptr,
+                                   n_map_points, points_stride, th, far_points, th_far_points, nnratio, 0, left_to_right, right_to_left,
+                                   occupied_in, occupied, match, n_matches);
+  }
   if (maxPts && (!map_points || !map_points_right)) return fail(ORBX_E_BADARG, "null map points");
   // the right camera as a second list of views, exactly as the one-shot call builds it (:141-144)
   std::vector<orbx_map_point_view> left((size_t)n_frames * st), right((size_t)n_frames * st);

@@ -285,6 +285,9 @@ struct orbx_extractor {
   DevBuf<orbx_frame_pose_q> d_posesQ;
   DevBuf<orbx_projected_point> d_pviews;
   DevBuf<float> d_scaleF;          // mvScaleFactors for k_project_last
+  DevBuf<orbx_frame_pose_kb8> d_posesK;                 // stereo-fisheye device projection (orbx_project_map_points_fisheye_batch)
+  DevBuf<orbx_map_point_view> d_fviewsL, d_fviewsR;     // its two view lists
+  int fviewsFrames = 0, fviewsStride = 0;
   int lfFrames = 0, lfStride = 0, pviewsFrames = 0;
   std::vector<int> lfN;
   int mapN = 0, viewsFrames = 0, viewsStride = 0;

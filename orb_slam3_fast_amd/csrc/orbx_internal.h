@@ -383,6 +383,16 @@ struct MapProjArgs {
   float minX, minY, maxX, maxY, viewCosLimit, logScaleFactor;
 };
 hipError_t launch_project_map(const MapProjArgs& a, int nFrames, hipStream_t s);
+// k_project_map_kb8: Frame::isInFrustumChecks for both cameras of stereo-fisheye frames (orbx_stereo.hip, beside the KB8 model)
+struct MapProjKb8Args {
+  const float *pos, *normal, *minDist, *maxDist;
+  const uint8_t *desc, *flags, *skip;
+  const orbx_frame_pose_kb8 *posesL, *posesR;
+  orbx_map_point_view *viewsL, *viewsR;   // the matcher's two lists (left camera; right camera with proj_x / proj_y = mTrackProjXR / YR)
+  int n, nlevels;
+  float minX, minY, maxX, maxY, viewCosLimit, logScaleFactor;
+};
+hipError_t launch_project_map_kb8(const MapProjKb8Args& a, int nFrames, hipStream_t s);
 // k_project_last: the projection block of SearchByProjection(CurrentFrame, LastFrame) (src/ORBmatcher.cc:1606-1669) on the device
 struct LastProjArgs {
   const float* pos;              // [frames][stride][3]

@@ -1354,6 +1354,66 @@ __global__ __launch_bounds__(64) void k_fisheye_tri(FisheyeBatchArgs a) {
   }
 }
 
+// Frame::isInFrustum for stereo-fisheye frames (src/Frame.cc:689-697): isInFrustumChecks (:1333-1410) for the left and the right
+// camera of every (map point, frame), with KannalaBrandt8::project; float in the reference's expression order (device atan2f / cosf /
+// sinf / logf: tolerance parity).  Writes the two view lists the fisheye matcher consumes: the left camera's (proj_xr =
+// mTrackProjXR) and the right camera's (proj_x / proj_y / view_cos / predicted_level / in_view of the right check, the rest copied).
+__global__ __launch_bounds__(256) void k_project_map_kb8(MapProjKb8Args a) {
+  const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+  if (i >= a.n) return;
+  const uint8_t fl = a.flags[i];
+  const uint4* d4 = reinterpret_cast<const uint4*>(a.desc + (size_t)i * 32);
+  const uint4 da = d4[0], db = d4[1];
+  const float Px = a.pos[3 * i], Py = a.pos[3 * i + 1], Pz = a.pos[3 * i + 2];
+  const float nx = a.normal[3 * i], ny = a.normal[3 * i + 1], nz = a.normal[3 * i + 2];
+  const float maxDist = a.maxDist[i], minDist = a.minDist[i];
+  const bool offered = !(a.skip && a.skip[(size_t)f * a.n + i]);
+  struct Cam { float u, v, viewCos, depth; int lvl; bool ok; };
+  auto check = [&](const orbx_frame_pose_kb8& T) {
+    Cam c{0.f, 0.f, 0.f, 0.f, 0, offered};
+    const float X = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.R[0], Px), __fmul_rn(T.R[1], Py)), __fmul_rn(T.R[2], Pz)), T.t[0]);
+    const float Y = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.R[3], Px), __fmul_rn(T.R[4], Py)), __fmul_rn(T.R[5], Pz)), T.t[1]);
+    const float Z = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(T.R[6], Px), __fmul_rn(T.R[7], Py)), __fmul_rn(T.R[8], Pz)), T.t[2]);
+    const float pcDist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y)), __fmul_rn(Z, Z)));
+    c.ok = c.ok && !(Z < 0.0f);
+    KB8Cam cam;
+#pragma unroll
+    for (int k = 0; k < 8; k++) cam.p[k] = T.kb8[k];
+    cam.precision = 0.f;
+    const float Pc[3] = {X, Y, Z};
+    float uv[2];
+    kb8_project(cam, Pc, uv);
+    c.ok = c.ok && !(uv[0] < a.minX || uv[0] > a.maxX) && !(uv[1] < a.minY || uv[1] > a.maxY);
+    const float ox = __fsub_rn(Px, T.twc[0]), oy = __fsub_rn(Py, T.twc[1]), oz = __fsub_rn(Pz, T.twc[2]);
+    const float dist = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(ox, ox), __fmul_rn(oy, oy)), __fmul_rn(oz, oz)));
+    const float maxD = __fmul_rn(1.2f, maxDist), minD = __fmul_rn(0.8f, minDist);
+    c.ok = c.ok && !(dist < minD || dist > maxD);
+    const float viewCos = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(ox, nx), __fmul_rn(oy, ny)), __fmul_rn(oz, nz)), dist);
+    c.ok = c.ok && !(viewCos < a.viewCosLimit);
+    int lvl = (int)ceilf(__fdiv_rn(logf(__fdiv_rn(maxDist, dist)), a.logScaleFactor));
+    lvl = lvl < 0 ? 0 : (lvl >= a.nlevels ? a.nlevels - 1 : lvl);
+    c.u = uv[0]; c.v = uv[1]; c.viewCos = viewCos; c.depth = pcDist; c.lvl = lvl;
+    return c;
+  };
+  const Cam L = check(a.posesL[f]), R = check(a.posesR[f]);
+  const uint32_t flagsW = ((uint32_t)(fl & 1) << 8) | ((uint32_t)((fl >> 1) & 1) << 16);
+  const uint32_t xr = R.ok ? __builtin_bit_cast(uint32_t, R.u) : 0u, depthL = L.ok ? __builtin_bit_cast(uint32_t, L.depth) : 0u;
+  uint32_t* o = reinterpret_cast<uint32_t*>(a.viewsL + (size_t)f * a.n + i);   // 60-byte records: 15 dwords
+  o[0] = L.ok ? __builtin_bit_cast(uint32_t, L.u) : 0xBF800000u; o[1] = L.ok ? __builtin_bit_cast(uint32_t, L.v) : 0xBF800000u;   // (-1.f: k_project_map)
+  o[2] = xr; o[3] = L.ok ? __builtin_bit_cast(uint32_t, L.viewCos) : 0u; o[4] = depthL; o[5] = L.ok ? (uint32_t)L.lvl : 0u;
+  o[6] = (L.ok ? 1u : 0u) | flagsW;
+  o[7] = da.x; o[8] = da.y; o[9] = da.z; o[10] = da.w; o[11] = db.x; o[12] = db.y; o[13] = db.z; o[14] = db.w;
+  uint32_t* r = reinterpret_cast<uint32_t*>(a.viewsR + (size_t)f * a.n + i);
+  r[0] = xr; r[1] = R.ok ? __builtin_bit_cast(uint32_t, R.v) : 0u; r[2] = xr; r[3] = R.ok ? __builtin_bit_cast(uint32_t, R.viewCos) : 0u;
+  r[4] = depthL; r[5] = R.ok ? (uint32_t)R.lvl : 0u;
+  r[6] = (R.ok ? 1u : 0u) | flagsW;
+  r[7] = da.x; r[8] = da.y; r[9] = da.z; r[10] = da.w; r[11] = db.x; r[12] = db.y; r[13] = db.z; r[14] = db.w;
+}
+hipError_t launch_project_map_kb8(const MapProjKb8Args& a, int nFrames, hipStream_t s) {
+  if (a.n > 0 && nFrames > 0) hipLaunchKernelGGL(k_project_map_kb8, dim3((a.n + 255) / 256, nFrames), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // One launch presets every output of the batch: -1 matches / depths, zero points and counters.
 __global__ __launch_bounds__(256) void k_fisheye_init(FisheyeBatchArgs a, int npairs) {
   const long long nl = (long long)npairs * a.capL, nr = (long long)npairs * a.capR;

@@ -267,3 +267,174 @@ def test_oracle_last_frame_projection_against_a_float64_model(oracle):
         assert not views["u"][bad].any() and not views["radius"][bad].any() and not views["min_level"][bad].any()
         assert np.array_equal(views["angle"], ang) and np.array_equal(views["has_observations"], (flags >> 1) & 1)
         assert np.array_equal(views["desc"], desc)
+
+
+@pytest.mark.gpu
+def test_device_projection_for_fisheye_frames_and_matcher_against_the_oracle(oracle):
+    """Round 6: Frame::isInFrustum of stereo-fisheye frames (isInFrustumChecks per camera with KannalaBrandt8::project,
+    src/Frame.cc:689-697, 1333-1410) on the device, both cameras' views consumed in place by the batched fisheye matcher
+    (src/ORBmatcher.cc:41-221 with Nleft != -1).  Parity: per camera, gate decisions equal the oracle's restatement unless the oracle
+    reports the decisive quantity within 1e-4 of its threshold (device atan2f / cosf / sinf), coordinates within 2e-4 relative,
+    levels equal unless log(ratio) / logScaleFactor is within 1e-4 of an integer; the MATCHER is exact: the device-view call equals
+    the host-view batched entry fed with the downloaded views, which equals the oracle's matcher on them."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    w, h, nf, F = 640, 480, 800, 3
+    rng = np.random.default_rng(99)
+    pairs = [synth.stereo_pair(w, h, 180 + f) for f in range(F)]
+    dev = DeviceBuffer.from_numpy(np.stack([p[0] for p in pairs] + [p[1] for p in pairs]))
+    ex = orbx.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2 * F)
+    ex.extract_batch_device(dev.ptr.value, 2 * F, w, h, w, w * h)
+    ex.sync()
+    cap = ex.capacity
+    kb1 = np.array([190.97, 190.97, w / 2 + 1.3, h / 2 - 0.8, 0.0034, 0.00071, -0.0020, 0.00020], np.float32)
+    kb2 = np.array([190.44, 190.44, w / 2 - 2.1, h / 2 + 1.1, 0.0034, 0.00071, -0.0020, 0.00020], np.float32)
+    Rrl, trl = _rot(0.004, -0.006, 0.002), np.array([-0.101, 0.002, 0.001])
+    framesL = [ex.download(f)[1:] for f in range(F)]
+    framesR = [ex.download(F + f)[1:] for f in range(F)]
+
+    def unproject(kb, u, v):   # rough inverse of the KB8 projection (theta from r by a few Newton steps), float64: scene construction only
+        x, y = (u - kb[2]) / kb[0], (v - kb[3]) / kb[1]
+        r = np.hypot(x, y)
+        th = r.copy()
+        for _ in range(8):
+            t2 = th * th
+            fth = th * (1 + kb[4] * t2 + kb[5] * t2 ** 2 + kb[6] * t2 ** 3 + kb[7] * t2 ** 4) - r
+            dth = 1 + 3 * kb[4] * t2 + 5 * kb[5] * t2 ** 2 + 7 * kb[6] * t2 ** 3 + 9 * kb[7] * t2 ** 4
+            th = th - fth / dth
+        s = np.where(r > 1e-9, np.tan(th) / np.maximum(r, 1e-9), 1.0)
+        return np.stack([x * s, y * s, np.ones_like(x)], 1)
+
+    posesL, posesR, Rs, ts = [], [], [], []
+    for f in range(F):
+        R = _rot(*(rng.normal(0, 0.01, 3)))
+        t = rng.normal(0, 0.05, 3)
+        Ow = -R.T @ t
+        Rr, tr = Rrl @ R, Rrl @ t + trl
+        twc_r = R.T @ (-Rrl.T @ trl) + Ow       # mRwc * mTlr.translation() + mOw
+        posesL.append(np.concatenate([R.reshape(-1), t, Ow, kb1]).astype(np.float32))
+        posesR.append(np.concatenate([Rr.reshape(-1), tr, twc_r, kb2]).astype(np.float32))
+        Rs.append(R), ts.append(t)
+    pos, nrm, mind, maxd, desc, flags = [], [], [], [], [], []
+    for f in range(F):
+        for (k, d), kb, Rc, tc in ((framesL[f], kb1, Rs[f], ts[f]), (framesR[f], kb2, Rrl @ Rs[f], Rrl @ ts[f] + trl)):
+            take = rng.choice(len(k), size=min(180, len(k)), replace=False)
+            rays = unproject(kb.astype(np.float64), k["x"][take] + rng.normal(0, 1.5, len(take)), k["y"][take] + rng.normal(0, 1.5, len(take)))
+            for j, i in enumerate(take):
+                z = rng.uniform(2.0, 30.0)
+                P = Rc.T @ (rays[j] * z - tc)
+                pos.append(P)
+                v = P - (-Rs[f].T @ ts[f])
+                dist = np.linalg.norm(v)
+                n_ = v / dist + rng.normal(0, 0.25, 3)
+                nrm.append(n_ / np.linalg.norm(n_))
+                sc = 1.2 ** int(k["octave"][i])
+                maxd.append(dist * sc * rng.uniform(0.95, 1.05))
+                mind.append(maxd[-1] / 1.2 ** 7)
+                desc.append(d[i] ^ np.packbits(rng.random((32, 8)) < 0.03, axis=1).reshape(32))
+                flags.append((0 if rng.random() > 0.04 else 1) | (2 if rng.random() < 0.9 else 0))
+    for _ in range(250):
+        P = rng.normal(0, 8.0, 3)
+        pos.append(P)
+        n_ = rng.normal(0, 1, 3)
+        nrm.append(n_ / np.linalg.norm(n_))
+        m = rng.uniform(0.5, 40.0)
+        maxd.append(m)
+        mind.append(m / 3.5)
+        desc.append(rng.integers(0, 256, 32, dtype=np.uint8))
+        flags.append(2)
+    pos, nrm = np.array(pos, np.float32), np.array(nrm, np.float32)
+    mind, maxd = np.array(mind, np.float32), np.array(maxd, np.float32)
+    desc, flags = np.array(desc, np.uint8), np.array(flags, np.uint8)
+    n = len(pos)
+    bounds = (0.0, 0.0, float(w), float(h))
+    ex.map_upload(pos, nrm, mind, maxd, desc, flags)
+    vl, vr = ex.project_map_points_fisheye(np.stack(posesL), np.stack(posesR), bounds, 0.5, None, want_views=True)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    seen = [0, 0]
+    for f in range(F):
+        ol, ml = oracle.is_in_frustum_kb8(posesL[f], pos, nrm, mind, maxd, bounds, 0.5, logsf, 8, flags, desc)
+        orr, mr = oracle.is_in_frustum_kb8(posesR[f], pos, nrm, mind, maxd, bounds, 0.5, logsf, 8, flags, desc)
+        assert np.array_equal(vl[f]["desc"], ol["desc"]) and np.array_equal(vl[f]["bad"], ol["bad"])
+        for cam, (inv, px, py, vc, lv, ov, mg) in enumerate((
+                (vl[f]["in_view"], vl[f]["proj_x"], vl[f]["proj_y"], vl[f]["view_cos"], vl[f]["predicted_level"], ol, ml),
+                (vr[f]["in_view_r"], vl[f]["proj_xr"], vr[f]["proj_yr"], vr[f]["view_cos_r"], vr[f]["predicted_level_r"], orr, mr))):
+            diff = (inv != 0) != (ov["in_view"] != 0)
+            assert (mg[diff, 0] < 1e-4).all(), (f, cam, mg[diff])
+            both = (inv != 0) & (ov["in_view"] != 0)
+            seen[cam] += int(both.sum())
+            for got, name in ((px, "proj_x"), (py, "proj_y"), (vc, "view_cos")):
+                a_, b_ = got[both].astype(np.float64), ov[name][both].astype(np.float64)
+                assert (np.abs(a_ - b_) <= 2e-4 * np.maximum(1.0, np.abs(b_))).all(), (cam, name)
+            ld = both & (lv != ov["predicted_level"])
+            assert (mg[ld, 1] < 1e-4).all()
+        assert (vr[f]["predicted_level_r"][vr[f]["in_view_r"] == 0] == -1).all()
+    assert seen[0] > 300 and seen[1] > 300, seen
+    # the matcher: device views == host-view batched entry on the downloaded views == the oracle on them
+    l2r, r2l = np.full((F, cap), -1, np.int32), np.full((F, cap), -1, np.int32)
+    for f in range(F):
+        idx, dist, ok = oracle.bf_knn2(framesL[f][1], framesR[f][1])
+        lr = np.where(ok.astype(bool) & (rng.random(len(idx)) < 0.8), idx[:, 0], -1).astype(np.int32)
+        l2r[f, :len(lr)] = lr
+        for i in np.nonzero(lr >= 0)[0]:
+            r2l[f, lr[i]] = i
+    occ = (rng.random((F, 2 * cap)) < 0.04).astype(np.uint8)
+    m = orbx.ORBmatcher(0.8, True)
+    total = 0
+    for th, far in ((3.0, True), (1.0, False)):
+        nm, match, oc = m.SearchByProjectionFisheyeBatchDevice(ex, 0, F, F, bounds, l2r, r2l, occ, th, far, 60.0)
+        nm2, match2, oc2 = m.SearchByProjectionFisheyeBatch(ex, 0, F, F, bounds, vl, vr, np.full(F, n, np.int32), l2r, r2l, occ, th, far, 60.0)
+        assert np.array_equal(nm, nm2) and np.array_equal(match, match2) and np.array_equal(oc, oc2)
+        sf = ex.GetScaleFactors()
+        for f in range(F):
+            kL, dL = framesL[f]
+            kR, dR = framesR[f]
+            nL, nn = len(kL), len(kL) + len(kR)
+            occf = occ[f, :nn]                      # rows are [left keypoints | right keypoints] at Nleft, like the one-shot arrays
+            exp = oracle.search_by_projection_fisheye(np.concatenate([kL, kR]), np.concatenate([dL, dR]), nL, bounds, sf,
+                                                      vl[f].view(oracle.MP_DTYPE), vr[f].view(oracle.MPR_DTYPE), th, far, 60.0, 0.8,
+                                                      l2r[f, :nL], r2l[f, :len(kR)], occf)
+            got_match, got_occ = match[f, :nn], oc[f, :nn]
+            assert nm[f] == exp[0] and np.array_equal(got_match, exp[1]) and np.array_equal(got_occ, exp[2]), (f, th)
+            total += int(nm[f])
+    assert total > 150, total
+
+
+def test_oracle_kb8_frustum_against_a_float64_model(oracle):
+    """The oracle's isInFrustumChecks restatement with KannalaBrandt8::project against the same formulas in float64 (numpy):
+    gates equal away from their thresholds, projections / viewing cosine / depth to float rounding, PredictScale's level equal
+    unless the float64 quotient is within 1e-4 of an integer."""
+    rng = np.random.default_rng(12)
+    w, h, n = 640.0, 480.0, 5000
+    kb = np.array([190.97, 190.97, w / 2 + 1.3, h / 2 - 0.8, 0.0034, 0.00071, -0.0020, 0.00020])
+    R, t = _rot(0.02, -0.01, 0.03), np.array([0.03, -0.02, 0.05])
+    Ow = -R.T @ t
+    pose = np.concatenate([R.reshape(-1), t, Ow, kb]).astype(np.float32)
+    P = rng.normal(0, 6.0, (n, 3)).astype(np.float32)
+    Pn = rng.normal(0, 1, (n, 3))
+    Pn = (Pn / np.linalg.norm(Pn, axis=1)[:, None]).astype(np.float32)
+    maxd = rng.uniform(2, 40, n).astype(np.float32)
+    mind = (maxd / 3.5).astype(np.float32)
+    flags = np.full(n, 2, np.uint8)
+    desc = np.zeros((n, 32), np.uint8)
+    logsf = np.float32(np.log(np.float32(1.2)))
+    views, mg = oracle.is_in_frustum_kb8(pose, P, Pn, mind, maxd, (0.0, 0.0, w, h), 0.5, logsf, 8, flags, desc)
+    R64, t64, O64 = pose[:9].astype(np.float64).reshape(3, 3), pose[9:12].astype(np.float64), pose[12:15].astype(np.float64)
+    Pc = P.astype(np.float64) @ R64.T + t64
+    th = np.arctan2(np.hypot(Pc[:, 0], Pc[:, 1]), Pc[:, 2])
+    psi = np.arctan2(Pc[:, 1], Pc[:, 0])
+    r = th + kb[4] * th ** 3 + kb[5] * th ** 5 + kb[6] * th ** 7 + kb[7] * th ** 9
+    u, v = kb[0] * r * np.cos(psi) + kb[2], kb[1] * r * np.sin(psi) + kb[3]
+    PO = P.astype(np.float64) - O64
+    dist = np.linalg.norm(PO, axis=1)
+    vc = (PO * Pn.astype(np.float64)).sum(1) / dist
+    ok = (Pc[:, 2] >= 0) & (u >= 0) & (u <= w) & (v >= 0) & (v <= h) & (dist >= 0.8 * mind) & (dist <= 1.2 * maxd) & (vc >= 0.5)
+    clear = mg[:, 0] > 1e-4
+    got = views["in_view"] != 0
+    assert np.array_equal(got[clear], ok[clear]) and got.sum() > 100
+    assert (np.abs(views["proj_x"][got] - u[got]) < 2e-3).all() and (np.abs(views["proj_y"][got] - v[got]) < 2e-3).all()
+    assert (np.abs(views["view_cos"][got] - vc[got]) < 1e-5).all()
+    assert (np.abs(views["track_depth"][got] - np.linalg.norm(Pc, axis=1)[got]) < 1e-4).all()
+    q = np.log(maxd.astype(np.float64) / dist) / np.float64(logsf)
+    lvl = np.clip(np.ceil(q), 0, 7).astype(np.int32)
+    sure = got & (np.abs(q - np.rint(q)) > 1e-4)
+    assert np.array_equal(views["predicted_level"][sure], lvl[sure])
