@@ -267,6 +267,78 @@ def test_fuzz_preprocess(oracle):
     assert not fails, fails[:10]
 
 
+def test_fuzz_preproc_plans(oracle):
+    """The pre-processing PLANS' round-6 kernels over random geometry: k_remap_lds (tile footprints through LDS; sources whose width is
+    a multiple of 16, both forms via the hook, maps from mild rectifications to shears whose tiles do not fit and fall back), the
+    single-channel input resize through the pyramid kernel, and the 16-pixel gray conversion with row tails -- against the oracle."""
+    from orb_slam3_fast_amd.hipmem import DeviceBuffer
+    import ctypes as C
+    from orb_slam3_fast_amd import hipmem
+    ncases = int(os.environ.get("ORBX_FUZZ_CASES", "60")) // 2 + 1
+    seed0 = int(os.environ.get("ORBX_FUZZ_SEED", "12345")) + 13000
+    fails = []
+
+    def run_plan(pp, frames, w, h):
+        n = len(frames)
+        dev = DeviceBuffer.from_numpy(frames)
+        rowb = frames.shape[2] * (frames.shape[3] if frames.ndim == 4 else 1)
+        ptr, ow, oh, rp, ip = pp.run_device(dev.ptr.value, n, rowb, rowb * h)
+        got = np.zeros((n, ip), np.uint8)
+        hipmem._ck(hipmem.hip().hipMemcpy(got.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), got.nbytes, 2))
+        return got[:, :oh * rp].reshape(n, oh, rp)[:, :, :ow]
+
+    try:
+        for case in range(ncases):
+            rng = np.random.default_rng(seed0 + case)
+            sw, sh = 16 * int(rng.integers(2, 50)), int(rng.integers(12, 400))
+            dw, dh = int(rng.integers(5, 700)), int(rng.integers(3, 400))
+            n = int(rng.integers(1, 20))
+            nmaps = int(rng.integers(1, 3))
+            frames = rng.integers(0, 256, (n, sh, sw), dtype=np.uint8)
+            u, v = np.meshgrid(np.arange(dw, dtype=np.float32), np.arange(dh, dtype=np.float32))
+            kind = int(rng.integers(0, 4))
+            maps = []
+            for m in range(nmaps):
+                if kind == 0:
+                    maps.append(synth.rectify_maps(dw, dh, sw, sh, seed=case + m, k1=float(rng.uniform(-0.3, 0.1)), rot_deg=tuple(rng.uniform(-1, 1, 3))))
+                elif kind == 1:
+                    sc = float(rng.choice([0.6, 0.9, 1.0, 1.3, 2.2]))
+                    maps.append(((u * sc + v * 0.05 - 2 + m).astype(np.float32), (v * sc - u * 0.03 + 1).astype(np.float32)))
+                elif kind == 2:   # a seam and a region outside the source
+                    mx, my = (u * (sw / max(dw, 1)) + 0.4).astype(np.float32), (v * (sh / max(dh, 1)) - 0.6).astype(np.float32)
+                    mx[:, dw // 2:] += 7.25
+                    my[: max(dh // 5, 1)] = -9.0
+                    maps.append((mx, my))
+                else:
+                    maps.append(((u + rng.integers(0, 33, (dh, dw)) / 32).astype(np.float32), (v + rng.integers(0, 33, (dh, dw)) / 32).astype(np.float32)))
+            mapsx, mapsy = np.stack([a for a, _ in maps]), np.stack([b for _, b in maps])
+            pp = orbx.Preproc(sw, sh, channels=1, maps=(mapsx, mapsy), max_batch=n)
+            want = [oracle.remap(frames[i], mapsx[i % nmaps], mapsy[i % nmaps]) for i in range(n)]
+            for hook in (1, 0):
+                orbx.lib().orbx_debug_set_remap_lds(hook)
+                got = run_plan(pp, frames, sw, sh)
+                if not all(np.array_equal(got[i], want[i]) for i in range(n)):
+                    fails.append(("remap plan", case, hook, sw, sh, dw, dh, n, nmaps, kind))
+            # input resize of mono frames (the pyramid kernel on a two-level geometry)
+            rw, rh = int(rng.integers(8, 2 * sw)), int(rng.integers(4, 2 * sh))
+            if rw * 4 > sw and rh * 4 > sh:     # (scale factors below 4: beyond that the plan keeps the per-pixel kernel anyway)
+                pr = orbx.Preproc(sw, sh, channels=1, out_size=(rw, rh), max_batch=n)
+                got = run_plan(pr, frames, sw, sh)
+                if not all(np.array_equal(got[i], oracle.resize(frames[i], rw, rh)) for i in range(n)):
+                    fails.append(("resize plan", case, sw, sh, rw, rh, n))
+            # gray: widths with and without a row tail, three / four channels
+            cn, gw = int(rng.choice([3, 4])), int(rng.integers(1, 300))
+            col = rng.integers(0, 256, (min(n, 3), sh, gw, cn), dtype=np.uint8)
+            rgb = bool(rng.integers(0, 2))
+            pg = orbx.Preproc(gw, sh, channels=cn, rgb=rgb, max_batch=len(col))
+            got = run_plan(pg, col, gw, sh)
+            if not all(np.array_equal(got[i], oracle.cvt_gray(col[i], rgb)) for i in range(len(col))):
+                fails.append(("gray plan", case, gw, sh, cn, rgb))
+    finally:
+        orbx.lib().orbx_debug_set_remap_lds(1)
+    assert not fails, fails[:10]
+
+
 def test_fuzz_bow(oracle):
     """ComputeBoW + SearchByBoW over random tree shapes, scoring / weighting types, feature counts and eye splits."""
     import sys
